@@ -1,0 +1,342 @@
+"""ORACLE tooling: generate tests/golden/* by running the IMPORTED REFERENCE (/root/reference, via oracle/ref_shim.py)
+on procedural weights/inputs, and cross-check the oracle restatement against it while doing so.
+
+Run in the build container only:   python -m oracle.gen_golden
+Outputs are data only (inputs are re-derivable from the hash; expected outputs are stored):
+  tests/golden/builder_<cfg>.json   layer table / save list / strides / state_dict keys+shapes   (§8c a)
+  tests/golden/ops_unit.npz         per-op outputs on small procedural tensors                   (§8c b)
+  tests/golden/nms_cases.npz        NMS inputs + reference outputs                               (§8c c)
+  tests/golden/e2e_<cfg>.npz        head-output slices/statistics + post-NMS rows, B=2            (§8c d)
+"""
+
+from __future__ import annotations
+
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+GOLD = ROOT / "tests" / "golden"
+
+from oracle import modules as om  # noqa: E402
+from oracle import nms as onms  # noqa: E402
+from oracle import tasks as ot  # noqa: E402
+from oracle.ref_shim import import_reference  # noqa: E402
+from ultralytics_pro_amd.utils import procedural as P  # noqa: E402
+
+REF_CFG = {
+    "yolov8n": "/root/reference/ultralytics/cfg/models/v8/Detect/yolov8n.yaml",
+    "yolov8s": "/root/reference/ultralytics/cfg/models/v8/Detect/yolov8s.yaml",
+    "yolov3-tiny": "/root/reference/ultralytics/cfg/models/v3/Detect/yolov3-tiny.yaml",
+    "yolov5-BoT3": "/root/reference/ultralytics/cfg/models/v5/Detect/yolov5-BoT3.yaml",
+    "yolov3-rtdetr": "/root/reference/ultralytics/cfg/models/v3/Detect/yolov3-rtdetr.yaml",
+}
+
+
+def unit_input(name, shape, lo=-1.0, hi=1.0):
+    return P.uniform(f"unit:{name}", shape, lo, hi)
+
+
+def maxdiff(a, b):
+    return float((a - b).abs().max()) if a.numel() else 0.0
+
+
+def builder_tables(rt):
+    for name, path in REF_CFG.items():
+        cls = rt.RTDETRDetectionModel if "rtdetr" in name else rt.DetectionModel
+        ref = cls(path, ch=3, nc=80, verbose=False)
+        mine = ot.DetectionModel(name + ".yaml")
+        rsd, msd = ref.state_dict(), mine.state_dict()
+        assert list(rsd.keys()) == list(msd.keys()), f"{name}: state_dict keys differ"
+        assert all(tuple(rsd[k].shape) == tuple(msd[k].shape) for k in rsd), f"{name}: shapes differ"
+        table = [dict(i=m.i, f=m.f, type=m.type.split(".")[-1], np=int(sum(p.numel() for p in m.parameters())))
+                 for m in ref.model]
+        mtable = [dict(i=m.i, f=m.f, type=m.type.split(".")[-1], np=int(sum(p.numel() for p in m.parameters())))
+                  for m in mine.model]
+        assert table == mtable, f"{name}: layer tables differ"
+        assert list(ref.save) == list(mine.save)
+        assert torch.equal(ref.stride.float(), mine.stride.float())
+        out = dict(config=name, layers=table, save=list(ref.save), stride=[float(s) for s in ref.stride],
+                   n_params=int(sum(p.numel() for p in ref.parameters())),
+                   state_dict=[[k, list(v.shape)] for k, v in rsd.items()])
+        (GOLD / f"builder_{name}.json").write_text(json.dumps(out, separators=(",", ":")))
+        print(f"builder {name}: {out['n_params']} params, {len(table)} layers, save={out['save']}")
+
+
+def ops_unit(rt):
+    """Per-op goldens: reference module with procedural weights on a small procedural tensor."""
+    import ultralytics.nn.modules as rm
+    from ultralytics.nn.modules.block import BoT3 as RBoT3
+    from ultralytics.nn.modules.block import MHSA as RMHSA
+    from ultralytics.nn.modules.transformer import MLP as RMLP
+    from ultralytics.nn.modules.transformer import MSDeformAttn as RMSDA
+    from ultralytics.nn.modules.utils import inverse_sigmoid as r_inv_sig
+    from ultralytics.utils.tal import dist2bbox as r_dist2bbox
+    from ultralytics.utils.tal import make_anchors as r_make_anchors
+    from ultralytics.utils.torch_utils import fuse_conv_and_bn as r_fuse
+
+    G = {}
+
+    def bn_fix(m):
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.eps, mod.momentum = 1e-3, 0.03
+        return m.eval()
+
+    def pair(name, rcls, ocls, args, xshape, family="default", post=None):
+        r = bn_fix(rcls(*args))
+        o = bn_fix(ocls(*args))
+        P.apply_procedural_weights(r, family=family)
+        P.apply_procedural_weights(o, family=family)
+        x = unit_input(name, xshape)
+        with torch.no_grad():
+            yr, yo = r(x), o(x)
+        d = maxdiff(yr, yo)
+        assert d <= 1e-5, f"{name}: oracle vs reference {d}"
+        G[name] = yr.numpy()
+        print(f"unit {name}: out {tuple(yr.shape)} oracle-vs-ref {d:.2e}")
+        return r, o, x
+
+    # Conv variants, unfused + fused
+    for tag, args, xs in [("conv_k1", (16, 32, 1, 1), (2, 16, 12, 12)), ("conv_k3s1", (16, 32, 3, 1), (2, 16, 12, 12)),
+                          ("conv_k3s2", (16, 32, 3, 2), (2, 16, 13, 13)), ("conv_k6s2p2", (3, 16, 6, 2, 2), (2, 3, 20, 20)),
+                          ("conv_stem", (3, 16, 3, 2), (2, 3, 16, 16))]:
+        r, o, x = pair(tag, rm.Conv, om.Conv, args, xs)
+        r.conv = r_fuse(r.conv, r.bn)
+        o.conv = om.fuse_conv_and_bn(o.conv, o.bn)
+        with torch.no_grad():
+            yr, yo = r.forward_fuse(x), o.forward_fuse(x)
+        assert maxdiff(yr, yo) <= 1e-6
+        assert torch.equal(r.conv.weight, o.conv.weight) and torch.equal(r.conv.bias, o.conv.bias)
+        G[tag + "_fused"] = yr.numpy()
+        G[tag + "_fused_w"] = r.conv.weight.detach().numpy()
+        G[tag + "_fused_b"] = r.conv.bias.detach().numpy()
+    pair("bottleneck", rm.Bottleneck, om.Bottleneck, (16, 16, True, 1, (3, 3), 1.0), (2, 16, 10, 10))
+    pair("bottleneck_noadd", rm.Bottleneck, om.Bottleneck, (16, 32, False), (2, 16, 10, 10))
+    pair("c2f_n2", rm.C2f, om.C2f, (32, 32, 2, True), (2, 32, 10, 10))
+    pair("c2f_n1_noshortcut", rm.C2f, om.C2f, (48, 32, 1, False), (2, 48, 10, 10))
+    pair("c3_n1", rm.C3, om.C3, (32, 32, 1, True), (2, 32, 10, 10))
+    pair("sppf", rm.SPPF, om.SPPF, (32, 32, 5), (2, 32, 9, 11))
+    pair("mhsa", RMHSA, om.MHSA, (32, 6, 6, 4), (2, 32, 6, 6))
+    pair("bot3", RBoT3, om.BoT3, (32, 32, 1, 0.5, 1, 6, 6), (2, 32, 6, 6))
+    pair("mlp", RMLP, om.MLP, (16, 32, 4, 3), (2, 10, 16))
+    # Upsample + Concat
+    a, b = unit_input("up_a", (2, 8, 5, 5)), unit_input("up_b", (2, 4, 10, 10))
+    y = rm.Concat(1)([torch.nn.Upsample(None, 2, "nearest")(a), b])
+    assert torch.equal(y, om.Concat(1)([torch.nn.Upsample(None, 2, "nearest")(a), b]))
+    G["upsample_concat"] = y.numpy()
+    # DFL / anchors / dist2bbox
+    x = unit_input("dfl", (2, 64, 21), -4, 4)
+    yr, yo = rm.DFL(16)(x), om.DFL(16)(x)
+    assert maxdiff(yr, yo) <= 1e-6
+    G["dfl"] = yr.detach().numpy()
+    feats = [torch.zeros(1, 1, 80, 80), torch.zeros(1, 1, 40, 40), torch.zeros(1, 1, 20, 20)]
+    ar, sr = r_make_anchors(feats, torch.tensor([8.0, 16.0, 32.0]), 0.5)
+    ao, so = om.make_anchors(feats, torch.tensor([8.0, 16.0, 32.0]), 0.5)
+    assert torch.equal(ar, ao) and torch.equal(sr, so)
+    G["anchors_head"] = ar[:100].numpy()
+    G["anchors_sum"] = np.array([float(ar.double().sum()), float(sr.double().sum())])
+    d = unit_input("dist", (2, 4, 50), 0, 15)
+    ap = unit_input("dist_anchor", (1, 2, 50), 0, 80)
+    yr, yo = r_dist2bbox(d, ap, xywh=True, dim=1), om.dist2bbox(d, ap, xywh=True, dim=1)
+    assert torch.equal(yr, yo)
+    G["dist2bbox"] = yr.numpy()
+    # Detect on three tiny maps (legacy head)
+    rm.Detect.legacy = True
+    rd = bn_fix(rm.Detect(80, (16, 32, 64)))
+    od = bn_fix(om.Detect(80, (16, 32, 64)))
+    for d_ in (rd, od):
+        d_.stride = torch.tensor([8.0, 16.0, 32.0])
+        P.apply_procedural_weights(d_, family="yolov8n")
+    xs = [unit_input(f"det{i}", s) for i, s in enumerate([(2, 16, 8, 8), (2, 32, 4, 4), (2, 64, 2, 2)])]
+    with torch.no_grad():
+        yr, rawr = rd([t.clone() for t in xs])
+        yo, rawo = od([t.clone() for t in xs])
+    d = maxdiff(yr, yo)
+    assert d <= 1e-4, d
+    G["detect_y"] = yr.numpy()
+    G["detect_raw0"] = rawr[0].numpy()
+    print(f"unit detect: {tuple(yr.shape)} oracle-vs-ref {d:.2e}")
+    # inverse_sigmoid known-answer (nn/modules/utils.py:93-95) + bias_init_with_prob (:49-51)
+    v = torch.tensor([0.2, 0.5, 0.8])
+    assert torch.equal(r_inv_sig(v), om.inverse_sigmoid(v))
+    G["inverse_sigmoid"] = r_inv_sig(v).numpy()
+    G["bias_init_with_prob"] = np.array([om.bias_init_with_prob(0.01)])
+    # MSDeformAttn: value (2,84,32) for shapes [(8,8),(4,4),(2,2)], 4-d reference boxes
+    r = RMSDA(32, 3, 4, 4).eval()
+    o = om.MSDeformAttn(32, 3, 4, 4).eval()
+    P.apply_procedural_weights(r)
+    P.apply_procedural_weights(o)
+    q = unit_input("msda_q", (2, 10, 32))
+    ref_b = unit_input("msda_ref", (2, 10, 1, 4), 0.1, 0.9)
+    val = unit_input("msda_v", (2, 84, 32))
+    shapes = [[8, 8], [4, 4], [2, 2]]
+    with torch.no_grad():
+        yr, yo = r(q, ref_b, val, shapes), o(q, ref_b, val, shapes)
+    d = maxdiff(yr, yo)
+    assert d <= 1e-5, d
+    G["msdeform_attn"] = yr.numpy()
+    print(f"unit msdeform_attn: {tuple(yr.shape)} oracle-vs-ref {d:.2e}")
+    # RTDETRDecoder small (hd=32, nq=10, nh=4, ndl=2, d_ffn=64)
+    args = (80, (16, 32, 64), 32, 10, 4, 4, 2, 64)
+    r = bn_fix(rm.RTDETRDecoder(*args))
+    o = bn_fix(om.RTDETRDecoder(*args))
+    P.apply_procedural_weights(r)
+    P.apply_procedural_weights(o)
+    xs = [unit_input(f"rtd{i}", s) for i, s in enumerate([(2, 16, 8, 8), (2, 32, 4, 4), (2, 64, 2, 2)])]
+    with torch.no_grad():
+        yr = r([t.clone() for t in xs])[0]
+        yo = o([t.clone() for t in xs])[0]
+    d = maxdiff(yr, yo)
+    assert d <= 1e-5, d
+    G["rtdetr_decoder_small"] = yr.numpy()
+    print(f"unit rtdetr_decoder: {tuple(yr.shape)} oracle-vs-ref {d:.2e}")
+    np.savez_compressed(GOLD / "ops_unit.npz", **G)
+
+
+def nms_cases(rt):
+    from ultralytics.utils.nms import TorchNMS
+    from ultralytics.utils.nms import non_max_suppression as r_nms
+
+    G = {}
+    # docstring known-answer (utils/nms.py:252-254): IoU = 25/175 -> keep both
+    b = torch.tensor([[0.0, 0, 10, 10], [5, 5, 15, 15]])
+    s = torch.tensor([0.9, 0.8])
+    k = TorchNMS.nms(b, s, 0.5)
+    assert k.tolist() == onms.greedy_nms(b, s, 0.5).tolist() == [0, 1]
+    G["doc_keep"] = k.numpy()
+
+    def case(name, pred, **kw):
+        kw.setdefault("max_time_img", 1e9)
+        out_r, keep_r = r_nms(pred.clone(), return_idxs=True, **kw)
+        kw.pop("max_time_img")
+        out_o, keep_o = onms.non_max_suppression(pred.clone(), return_idxs=True, **kw)
+        for a, b_, ka, kb in zip(out_r, out_o, keep_r, keep_o):
+            assert a.shape == b_.shape and torch.equal(a, b_), f"{name}: oracle NMS differs from reference"
+            assert ka.view(-1).long().tolist() == kb.view(-1).long().tolist(), name
+        G[name + "_pred"] = pred.numpy()
+        G[name + "_n"] = np.array([o.shape[0] for o in out_r])
+        G[name + "_out"] = torch.cat(out_r, 0).numpy() if sum(o.shape[0] for o in out_r) else np.zeros((0, 6), "f4")
+        G[name + "_keep"] = torch.cat([k_.view(-1).long() for k_ in keep_r]).numpy()
+        G[name + "_kw"] = np.array(json.dumps(kw))
+        print(f"nms {name}: n={[o.shape[0] for o in out_r]}")
+
+    def mk(boxes_xywh, cls_scores, nc=80):
+        """boxes (n,4) xywh, cls_scores list of (class, score) per box -> (1, 4+nc, n)."""
+        n = len(boxes_xywh)
+        p = torch.zeros(1, 4 + nc, n)
+        p[0, :4] = torch.tensor(boxes_xywh, dtype=torch.float32).T
+        for i, cs in enumerate(cls_scores):
+            for c, sc in (cs if isinstance(cs, list) else [cs]):
+                p[0, 4 + c, i] = sc
+        return p
+
+    case("identical", mk([[50, 50, 20, 20]] * 3, [(0, 0.9), (0, 0.8), (0, 0.7)]), conf_thres=0.25, iou_thres=0.5)
+    # IoU exactly == thr must be KEPT (iou <= thr): boxes [0,0,10,10] & [0,0,10,5] -> IoU 0.5
+    case("iou_eq_thr", mk([[5, 5, 10, 10], [5, 2.5, 10, 5]], [(0, 0.9), (0, 0.8)]), conf_thres=0.25, iou_thres=0.5)
+    case("cross_class", mk([[50, 50, 20, 20]] * 2, [(3, 0.9), (4, 0.8)]), conf_thres=0.25, iou_thres=0.5)
+    case("agnostic", mk([[50, 50, 20, 20]] * 2, [(3, 0.9), (4, 0.8)]), conf_thres=0.25, iou_thres=0.5, agnostic=True)
+    # class-79 offset rounding: 79*7680 = 606720, fp32 ulp 0.0625 px
+    case("cls79_offset", mk([[100.3, 100.3, 10.03, 10.03], [100.33, 100.31, 10.06, 10.02], [103.4, 100.3, 10.0, 10.0]],
+                            [(79, 0.9), (79, 0.8), (79, 0.7)]), conf_thres=0.25, iou_thres=0.45)
+    case("classes_filter", mk([[50, 50, 20, 20], [150, 50, 20, 20], [250, 50, 20, 20]], [(1, 0.9), (2, 0.8), (3, 0.7)]),
+         conf_thres=0.25, iou_thres=0.5, classes=[1, 3])
+    case("empty", torch.zeros(2, 84, 16), conf_thres=0.25, iou_thres=0.5)
+    case("multi_label", mk([[50, 50, 20, 20], [52, 50, 20, 20]], [[(1, 0.9), (2, 0.6)], [(1, 0.5), (7, 0.4)]]),
+         conf_thres=0.25, iou_thres=0.5, multi_label=True)
+    # > max_det: 40 disjoint boxes, max_det=10
+    grid = [[20 + 30 * (i % 8), 20 + 30 * (i // 8), 10, 10] for i in range(40)]
+    sc = P.hash_uniform("nms:maxdet", 40)
+    case("gt_max_det", mk(grid, [(i % 5, float(0.3 + 0.6 * sc[i])) for i in range(40)]), conf_thres=0.25, iou_thres=0.5,
+         max_det=10)
+    # > max_nms: 64 candidates, max_nms=32
+    case("gt_max_nms", mk(grid + grid[:24], [(i % 3, float(0.3 + 0.6 * v)) for i, v in enumerate(P.hash_uniform("nms:maxnms", 64))]),
+         conf_thres=0.25, iou_thres=0.5, max_nms=32)
+    # random dense cases with distinct scores, (2, 84, 512)
+    for t in range(3):
+        n = 512
+        p = torch.zeros(2, 84, n)
+        u = P.uniform(f"nms:rand{t}", (2, 8, n), 0, 1)
+        p[:, 0] = u[:, 0] * 600 + 20
+        p[:, 1] = u[:, 1] * 600 + 20
+        p[:, 2] = u[:, 2] * 150 + 10
+        p[:, 3] = u[:, 3] * 150 + 10
+        p[:, 4:] = P.uniform(f"nms:randcls{t}", (2, 80, n), 0, 1) ** 300  # few high scores, all distinct
+        case(f"rand{t}_predict", p, conf_thres=0.25, iou_thres=0.7)
+        case(f"rand{t}_val", p, conf_thres=0.001, iou_thres=0.7, multi_label=True, max_det=300)
+        case(f"rand{t}_agn", p, conf_thres=0.25, iou_thres=0.45, agnostic=True)
+    np.savez_compressed(GOLD / "nms_cases.npz", **G)
+
+
+def e2e(rt):
+    from ultralytics.utils.nms import non_max_suppression as r_nms
+
+    for name in ["yolov3-tiny", "yolov8n", "yolov8s", "yolov5-BoT3", "yolov3-rtdetr"]:
+        is_rt = "rtdetr" in name
+        cls = rt.RTDETRDetectionModel if is_rt else rt.DetectionModel
+        ref = cls(REF_CFG[name], ch=3, nc=80, verbose=False)
+        fam = P.model_family(ot.DetectionModel(name + ".yaml"))
+        P.apply_procedural_weights(ref, family=fam)
+        ref.eval().fuse(verbose=False)
+        mine = ot.DetectionModel(name + ".yaml")
+        P.apply_procedural_weights(mine)
+        mine.fuse()
+        x = P.synthetic_images(2)
+        with torch.no_grad():
+            yr = ref(x.clone())[0]
+            yo = mine(x.clone())[0]
+        d = maxdiff(yr, yo)
+        print(f"e2e {name}: y {tuple(yr.shape)} oracle-vs-ref max|d| = {d:.3e}")
+        assert d <= 2e-3, d
+        G = {"oracle_vs_ref_maxdiff": np.array([d])}
+        if is_rt:
+            G["y"] = yr.numpy()  # (2,300,84) = 200 KB
+            conf = 0.25
+            outs = []
+            for b in range(2):
+                bbox = torch.ops.aten.clone(yr[b, :, :4])
+                outs.append(onms.rtdetr_postprocess(yr[b:b + 1], conf)[0])
+            G["post_n"] = np.array([o.shape[0] for o in outs])
+            G["post_rows"] = torch.cat(outs, 0).numpy()
+        else:
+            A = yr.shape[-1]
+            sel = np.unique(np.concatenate([np.arange(0, A, max(1, A // 256)), np.arange(64), np.arange(A - 64, A)]))
+            G["anchor_sel"] = sel
+            G["y_sel"] = yr[:, :, sel].numpy()
+            G["y_sum"] = np.array([float(yr[:, :4].double().sum()), float(yr[:, 4:].double().sum())])
+            G["y_chan_mean"] = yr.double().mean(dim=(0, 2)).numpy()
+            for tag, kw in [("predict", dict(conf_thres=0.25, iou_thres=0.7, max_det=300)),
+                            ("val", dict(conf_thres=0.001, iou_thres=0.7, max_det=300, multi_label=True))]:
+                out_r = r_nms(yr.clone(), max_time_img=1e9, **kw)
+                out_o = onms.non_max_suppression(yo.clone(), **kw)
+                out_oo = onms.non_max_suppression(yr.clone(), **kw)
+                for a, b_ in zip(out_r, out_oo):
+                    assert torch.equal(a, b_), f"{name}/{tag}: oracle NMS != reference NMS on identical input"
+                G[f"{tag}_n"] = np.array([o.shape[0] for o in out_r])
+                G[f"{tag}_rows"] = torch.cat(out_r, 0).numpy()
+                print(f"   {tag}: n={[o.shape[0] for o in out_r]} (oracle-model n={[o.shape[0] for o in out_o]})")
+        np.savez_compressed(GOLD / f"e2e_{name}.npz", **G)
+
+
+def main():
+    torch.manual_seed(0)
+    GOLD.mkdir(parents=True, exist_ok=True)
+    rt = import_reference()
+    which = sys.argv[1:] or ["builder", "ops", "nms", "e2e"]
+    with torch.no_grad():
+        if "builder" in which:
+            builder_tables(rt)
+        if "ops" in which:
+            ops_unit(rt)
+        if "nms" in which:
+            nms_cases(rt)
+        if "e2e" in which:
+            e2e(rt)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,154 @@
+"""ORACLE (test infrastructure, never shipped in the product path).
+
+CPU restatement of the reference graph builder / layer executor for the 12 module names the five BASELINE configs
+use: `parse_model` (nn/tasks.py:2409-3146), `BaseModel._predict_once` (:1046-1085), `BaseModel.fuse` (:1120-1134),
+`DetectionModel.__init__` (:1284-1340), `yaml_model_load` / `guess_model_scale` (:3147-3185).
+Pinned by tests/golden/builder_*.json (layer table, save list, strides, state_dict keys of the imported reference).
+"""
+
+from __future__ import annotations
+
+import ast
+import contextlib
+import math
+import re
+from copy import deepcopy
+from pathlib import Path
+
+import torch
+import torch.nn as nn
+import yaml
+
+from .modules import (C2f, C3, SPPF, BoT3, Bottleneck, Concat, Conv, Detect, RTDETRDecoder, fuse_conv_and_bn)
+
+CFG_DIR = Path(__file__).resolve().parents[1] / "ultralytics_pro_amd" / "cfg" / "models"
+
+_MODULES = {m.__name__: m for m in (Conv, C2f, C3, SPPF, BoT3, Bottleneck, Concat, Detect, RTDETRDecoder)}
+_BASE = {Conv, C2f, C3, SPPF, BoT3, Bottleneck}  # subset of base_modules, nn/tasks.py:2446-2710
+_REPEAT = {C2f, C3}  # subset of repeat_modules (BoT3 is NOT in it)
+
+
+def make_divisible(x, divisor):
+    """utils/ops.py:137-150."""
+    return math.ceil(x / divisor) * divisor
+
+
+def yaml_model_load(path):
+    """Strip the scale letter (yolov8n.yaml -> yolov8.yaml) and attach `scale` (nn/tasks.py:3147-3185)."""
+    path = Path(path)
+    stem = path.stem
+    scale = ""
+    m = re.match(r"^(yolo(?:v)?\d+)([nslmx])$", stem)  # bare family name + scale letter only
+    if m:
+        stem, scale = m.group(1), m.group(2)
+    cands = [path] if path.is_file() else list(CFG_DIR.rglob(stem + ".yaml"))
+    if not cands:
+        raise FileNotFoundError(path)
+    d = yaml.safe_load(cands[0].read_text())
+    d["scale"] = scale
+    d["yaml_file"] = str(path)
+    return d
+
+
+def parse_model(d, ch):
+    """YAML rows [from, repeats, module, args] -> nn.Sequential + save list (nn/tasks.py:2409-3146)."""
+    d = deepcopy(d)
+    max_channels = float("inf")
+    nc, scales = d.get("nc"), d.get("scales")
+    depth, width = d.get("depth_multiple", 1.0), d.get("width_multiple", 1.0)
+    scale = d.get("scale")
+    if scales:
+        if not scale:
+            scale = next(iter(scales.keys()))  # falls to the first scale ('n'), tasks.py:2430-2433
+        depth, width, max_channels = scales[scale][:3]
+    ch = [ch]
+    layers, save, c2 = [], [], ch[-1]
+    for i, (f, n, m, args) in enumerate(d["backbone"] + d["head"]):
+        m = getattr(nn, m[3:]) if "nn." in m else _MODULES[m]
+        args = list(args)
+        for j, a in enumerate(args):
+            if isinstance(a, str):
+                with contextlib.suppress(ValueError):
+                    args[j] = nc if a == "nc" else ast.literal_eval(a)
+        n = max(round(n * depth), 1) if n > 1 else n
+        if m in _BASE:
+            c1, c2 = ch[f], args[0]
+            if c2 != nc:
+                c2 = make_divisible(min(c2, max_channels) * width, 8)
+            args = [c1, c2, *args[1:]]
+            if m in _REPEAT:
+                args.insert(2, n)
+                n = 1
+        elif m is Concat:
+            c2 = sum(ch[x] for x in f)
+        elif m is Detect:
+            args.append([ch[x] for x in f])
+        elif m is RTDETRDecoder:
+            args.insert(1, [ch[x] for x in f])
+        else:
+            c2 = ch[f]
+        m_ = nn.Sequential(*(m(*args) for _ in range(n))) if n > 1 else m(*args)
+        m_.np = sum(x.numel() for x in m_.parameters())
+        m_.i, m_.f, m_.type = i, f, f"{m.__module__}.{m.__name__}"
+        m_.build_args = args
+        save.extend(x % i for x in ([f] if isinstance(f, int) else f) if x != -1)
+        layers.append(m_)
+        if i == 0:
+            ch = []
+        ch.append(c2)
+    return nn.Sequential(*layers), sorted(save)
+
+
+class DetectionModel(nn.Module):
+    """nn/tasks.py:1256-1340 (+ RTDETRDetectionModel :1608 which only swaps the head / loss)."""
+
+    def __init__(self, cfg="yolov8n.yaml", ch=3, nc=None):
+        super().__init__()
+        self.yaml = cfg if isinstance(cfg, dict) else yaml_model_load(cfg)
+        if nc and nc != self.yaml["nc"]:
+            self.yaml["nc"] = nc
+        self.model, self.save = parse_model(self.yaml, ch=ch)
+        self.names = {i: f"{i}" for i in range(self.yaml["nc"])}
+        self.inplace = True
+        self.end2end = False
+        m = self.model[-1]
+        if isinstance(m, Detect):
+            s = 256  # stride discovery by a 256x256 zero-image forward in train mode (tasks.py:1315-1331)
+            self.train()
+            with torch.no_grad():
+                outs = self._predict_once(torch.zeros(1, ch, s, s))
+            m.stride = torch.tensor([s / x.shape[-2] for x in outs])
+            self.stride = m.stride
+            m.bias_init()
+        else:
+            self.stride = torch.Tensor([32])
+        for mod in self.modules():  # initialize_weights, utils/torch_utils.py:463-473
+            if isinstance(mod, nn.BatchNorm2d):
+                mod.eps = 1e-3
+                mod.momentum = 0.03
+        self.eval()
+
+    def forward(self, x):
+        return self._predict_once(x)
+
+    def _predict_once(self, x):
+        """tasks.py:1046-1085."""
+        y = []
+        for m in self.model:
+            if m.f != -1:
+                x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
+            x = m(x)
+            y.append(x if m.i in self.save else None)
+        return x
+
+    def fuse(self):
+        """Fold BN into every Conv and rebind forward (tasks.py:1120-1134)."""
+        for m in self.model.modules():
+            if isinstance(m, Conv) and hasattr(m, "bn"):
+                m.conv = fuse_conv_and_bn(m.conv, m.bn)
+                delattr(m, "bn")
+                m.forward = m.forward_fuse
+        return self
+
+
+RTDETRDetectionModel = DetectionModel  # eval path is identical; only the training loss differs (tasks.py:1608)
