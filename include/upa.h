@@ -1,0 +1,101 @@
+/* upa.h - C ABI of libupa_hip.so: the MI355X (gfx950) kernels behind the ultralytics.nn operator API.
+ *
+ * The reference (Chriz122/ultralytics_pro) has no FFI: its operator layer is Python classes that call torch ops
+ * (SURVEY.md 8b).  Each entry point below replaces the torch dispatch of one reference operator on the detect hot
+ * path; the citation after each prototype names the reference code whose arithmetic it takes over
+ * (paths relative to ultralytics/).
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative UPA_E* code otherwise; no exceptions, no hidden allocation,
+ *    no global state; all work is enqueued on `stream` (a hipStream_t passed as void*) and is graph-capturable.
+ *  - activations are NHWC "views": element (n,h,w,c) of a view lives at ptr + ((n*H + h)*W + w)*ld + c, where
+ *    `ld` (pixel stride, elements) may exceed C, so a view can be a channel slice of a wider concat buffer
+ *    (concat-by-construction, C2f/SPPF/Concat).  Channel offsets and C must be multiples of 16 bytes.
+ *  - dtype: UPA_F32 (parity mode, exact f32 MFMA) or UPA_BF16 (perf mode, bf16 storage, f32 accumulate).
+ *  - model boundary tensors keep the reference layout: input NCHW, Detect output (B, 4+nc, A) f32,
+ *    NMS output (B, max_det, 6) f32 + int32 counts.
+ */
+#ifndef UPA_H
+#define UPA_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { UPA_F32 = 0, UPA_BF16 = 1 };
+enum { UPA_ACT_NONE = 0, UPA_ACT_SILU = 1, UPA_ACT_RELU = 2 };
+enum { UPA_OK = 0, UPA_EINVAL = -1, UPA_EUNSUPPORTED = -2, UPA_EWORKSPACE = -3, UPA_ELAUNCH = -4 };
+
+/* Library / device info. Returns the ABI version (int); fills name with the kernel target ("gfx950"). */
+int upa_version(void);
+const char* upa_last_error(void);
+
+/* ---- convolution -------------------------------------------------------------------------------------------------
+ * y = act(conv2d(x, W) + bias) [+ residual]          nn/modules/conv.py:188-197 (Conv.forward_fuse), block.py:668
+ * Weights are pre-packed by upa_pack_conv_weight (BN already folded: utils/torch_utils.py:236-266).
+ * Implicit GEMM on MFMA, input halo tile staged in LDS; groups=1, dilation=1, square kernel k in [1,7]. */
+size_t upa_conv_packed_weight_bytes(int cout, int cin, int k, int dtype);
+/* Host-side packing: w is OIHW f32 (cout,cin,k,k) in HOST memory; out is HOST memory of the size above. */
+int upa_pack_conv_weight(const float* w_oihw, int cout, int cin, int k, int dtype, void* out);
+int upa_conv2d_bias_act(const void* x, int n, int h, int w, int cin, int ldx,
+                        const void* w_packed, const float* bias /* f32[cout padded to 16] or NULL */,
+                        void* y, int cout, int ldy,
+                        const void* residual /* NULL or view shaped like y */, int ldr,
+                        int k, int stride, int pad, int act, int dtype, void* stream);
+
+/* First layer: reads the model input NCHW (f32 or bf16, 1..4 channels) directly, writes NHWC.   conv.py:188-197
+ * w is OIHW f32 on the DEVICE (cout<=64), bias f32[cout] on the device. */
+int upa_conv2d_stem_nchw(const void* x_nchw, int x_dtype, int n, int cin, int h, int w,
+                         const float* w_oihw, const float* bias, void* y, int cout, int ldy,
+                         int k, int stride, int pad, int act, int dtype, void* stream);
+
+/* ---- pooling / resampling / concat (HBM-bound) --------------------------------------------------------------- */
+/* nn.MaxPool2d(k, s, p) with -inf padding; pad_br>0 emulates nn.ZeroPad2d([0,pad_br,0,pad_br]) in front of it
+ * (zeros, not -inf, take part in the max).                                   cfg yolov3-tiny.yaml rows 1-12 */
+int upa_maxpool2d(const void* x, int n, int h, int w, int c, int ldx, void* y, int oh, int ow, int ldy,
+                  int k, int stride, int pad, int pad_br, int dtype, void* stream);
+/* SPPF pooling chain: y1 = mp5(x), y2 = mp5(y1), y3 = mp5(y2) (== 5/9/13 windows)          block.py:402-406 */
+int upa_sppf_pool3(const void* x, int n, int h, int w, int c, int ldx, void* y1, void* y2, void* y3, int ldy,
+                   int dtype, void* stream);
+/* nn.Upsample(scale 2, nearest) written into a channel slice (fused Upsample+Concat)       conv.py:850-875 */
+int upa_upsample2x(const void* x, int n, int h, int w, int c, int ldx, void* y, int ldy, int dtype, void* stream);
+/* view -> view copy (Concat of tensors that could not be produced in place)                conv.py:874 */
+int upa_copy_view(const void* x, int n, int h, int w, int c, int ldx, void* y, int ldy, int dtype, void* stream);
+/* y = a + b (views)                                                                        block.py:6091 */
+int upa_add_view(const void* a, int lda, const void* b, int ldb, void* y, int ldy, int n, int h, int w, int c,
+                 int dtype, void* stream);
+/* layout conversion at the module boundary (NCHW f32 <-> NHWC dtype) */
+int upa_nchw_to_nhwc(const float* x, int n, int c, int h, int w, void* y, int ldy, int dtype, void* stream);
+int upa_nhwc_to_nchw(const void* x, int n, int h, int w, int c, int ldx, float* y, int dtype, void* stream);
+
+/* ---- Detect decode ------------------------------------------------------------------------------------------------
+ * One level: box logits (n,h,w,4*reg_max) + cls logits (n,h,w,nc) NHWC -> y[b, 0:4, a0:a0+h*w] = xywh*stride
+ * (DFL softmax-expectation, dist2bbox with cell-centre anchors), y[b, 4:4+nc, ...] = sigmoid(cls).
+ * y is (n, 4+nc, a_total) f32.        head.py:151-169, block.py:250-253, utils/tal.py:352-376 */
+int upa_detect_decode(const void* box, int ldb, const void* cls, int ldc, int n, int h, int w, int reg_max, int nc,
+                      float stride_px, float* y, int a_total, int a0, int dtype, void* stream);
+
+/* ---- NMS ----------------------------------------------------------------------------------------------------------
+ * Batched non_max_suppression over pred (b, 4+nc, a) f32 xywh+scores -> out (b, max_det, 6) f32
+ * [x1,y1,x2,y2,conf,cls], counts int32[b], keep_idx int32 (b, max_det) anchor indices (may be NULL).
+ * classes_mask: NULL or uint8[nc] (1 = keep class).  Greedy hard NMS, class offset cls*max_wh added in f32,
+ * IoU without eps, survivor iff IoU <= thr, score-descending (ties: lower candidate index first).
+ *                                                                  utils/nms.py:13-166, :239-296 */
+size_t upa_nms_workspace_bytes(int b, int nc, int a, int multi_label, int max_nms);
+int upa_nms_batched(const float* pred, int b, int nc, int a, float conf_thres, float iou_thres, int multi_label,
+                    int agnostic, const uint8_t* classes_mask, int max_det, int max_nms, float max_wh,
+                    float* out, int32_t* counts, int32_t* keep_idx, void* workspace, size_t workspace_bytes,
+                    void* stream);
+
+/* ---- HIP graph helpers (capture a launch sequence once, replay per batch) ------------------------------------- */
+int upa_graph_begin(void* stream);
+int upa_graph_end(void* stream, void** graph_exec_out);
+int upa_graph_launch(void* graph_exec, void* stream);
+int upa_graph_destroy(void* graph_exec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,228 @@
+"""-m gpu: every HIP operator, called through the C ABI via the reference-shaped Python modules, against the oracle
+on the same procedural weights / inputs.  f32 = parity mode (tight tolerances); bf16 = perf mode (bf16 rounding)."""
+
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import modules as om
+from oracle import nms as onms
+from ultralytics_pro_amd.utils import procedural as P
+
+pytestmark = pytest.mark.gpu
+
+CONV_CASES = [
+    # c1, c2, k, s, p, H, W, N
+    (16, 32, 1, 1, None, 12, 12, 2),
+    (16, 32, 3, 1, None, 12, 12, 2),
+    (16, 32, 3, 2, None, 13, 13, 2),
+    (32, 64, 3, 2, None, 40, 40, 2),
+    (64, 64, 3, 1, None, 40, 40, 3),
+    (64, 80, 3, 1, None, 20, 20, 2),
+    (80, 80, 3, 1, None, 23, 17, 2),
+    (48, 32, 1, 1, None, 24, 24, 2),
+    (192, 128, 1, 1, None, 20, 20, 2),
+    (384, 256, 1, 1, None, 10, 10, 2),
+    (128, 128, 3, 1, None, 20, 20, 2),
+    (256, 64, 3, 1, None, 20, 20, 1),
+    (128, 256, 3, 2, None, 40, 40, 1),
+    (16, 16, 3, 1, None, 64, 64, 1),
+    (32, 16, 1, 1, None, 33, 9, 1),
+    (512, 1024, 3, 1, None, 10, 10, 1),
+    (1024, 256, 1, 1, None, 10, 10, 1),
+]
+
+
+def _mods():
+    from ultralytics_pro_amd.nn import modules as pm
+    from ultralytics_pro_amd.nn.modules import resample
+    return pm, resample
+
+
+def _pair(ocls, pcls, args, name, family="default"):
+    from tests.hip_utils import DEV, bn_fix
+    o = bn_fix(ocls(*args))
+    p = bn_fix(pcls(*args))
+    P.apply_procedural_weights(o, family=family)
+    P.apply_procedural_weights(p, family=family)
+    return o, p.to(DEV)
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[f"c{c[0]}-{c[1]}k{c[2]}s{c[3]}_{c[5]}x{c[6]}" for c in CONV_CASES])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_conv(case, dtype):
+    from tests.hip_utils import bf16_round, to_cpu_nchw, to_dev_nhwc, unit_input
+    pm, _ = _mods()
+    c1, c2, k, s, p, H, W, N = case
+    o, m = _pair(om.Conv, pm.Conv, (c1, c2, k, s, p), "conv")
+    x = unit_input(f"conv{case}", (N, c1, H, W))
+    if dtype == torch.bfloat16:
+        x = bf16_round(x)
+    with torch.no_grad():
+        ref = o(x)
+        y = to_cpu_nchw(m(to_dev_nhwc(x, dtype)))
+    assert y.shape == ref.shape
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    assert (y - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", [(3, 16, 3, 2, None, 64, 64), (3, 16, 6, 2, 2, 64, 64), (3, 32, 3, 1, None, 40, 48)],
+                         ids=["v8stem", "v5stem", "v3stem"])
+def test_stem_reads_nchw(case, dtype):
+    from tests.hip_utils import DEV, bf16_round, to_cpu_nchw, unit_input
+    pm, _ = _mods()
+    c1, c2, k, s, p, H, W = case
+    o, m = _pair(om.Conv, pm.Conv, (c1, c2, k, s, p), "stem")
+    x = unit_input(f"stem{case}", (2, c1, H, W), 0, 1)
+    m.compute_dtype = dtype
+    xin = x.to(DEV)
+    if dtype == torch.bfloat16:
+        xin = xin.to(torch.bfloat16)  # the reference's `im.half()` (predictor.py:151-173) - plumbing cast
+        x = bf16_round(x)
+    with torch.no_grad():
+        ref = o(x)
+        y = to_cpu_nchw(m(xin))
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert (y - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+
+
+BLOCKS = [
+    ("bottleneck", "Bottleneck", (16, 16, True, 1, (3, 3), 1.0), (2, 16, 10, 10)),
+    ("bottleneck_noadd", "Bottleneck", (16, 32, False), (2, 16, 10, 10)),
+    ("c2f_n2", "C2f", (32, 32, 2, True), (2, 32, 10, 10)),
+    ("c2f_n1_noshortcut", "C2f", (48, 32, 1, False), (2, 48, 10, 10)),
+    ("c3_n1", "C3", (32, 32, 1, True), (2, 32, 10, 10)),
+    ("sppf", "SPPF", (32, 32, 5), (2, 32, 9, 11)),
+]
+
+
+@pytest.mark.parametrize("name,cls,args,xshape", BLOCKS, ids=[b[0] for b in BLOCKS])
+def test_blocks_match_golden_and_oracle(name, cls, args, xshape, golden_dir):
+    """Same inputs as tests/golden/ops_unit.npz: HIP f32 vs the reference's recorded output."""
+    from tests.hip_utils import to_cpu_nchw, to_dev_nhwc, unit_input
+    pm, _ = _mods()
+    G = np.load(golden_dir / "ops_unit.npz")
+    o, m = _pair(getattr(om, cls), getattr(pm, cls), args, name)
+    x = unit_input(name, xshape)
+    with torch.no_grad():
+        y = to_cpu_nchw(m(to_dev_nhwc(x)))
+    assert np.abs(y.numpy() - G[name]).max() <= 2e-5
+    with torch.no_grad():
+        yb = to_cpu_nchw(m(to_dev_nhwc(x, torch.bfloat16)))
+    assert np.abs(yb.numpy() - G[name]).max() <= 6e-2 * max(1.0, np.abs(G[name]).max())
+
+
+def test_upsample_concat_exact(golden_dir):
+    from tests.hip_utils import to_cpu_nchw, to_dev_nhwc, unit_input
+    pm, rs = _mods()
+    G = np.load(golden_dir / "ops_unit.npz")
+    a, b = unit_input("up_a", (2, 8, 5, 5)), unit_input("up_b", (2, 4, 10, 10))
+    y = pm.Concat(1)([rs.Upsample(None, 2, "nearest")(to_dev_nhwc(a)), to_dev_nhwc(b)])
+    assert np.array_equal(to_cpu_nchw(y).numpy(), G["upsample_concat"])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_maxpool_variants_exact(dtype):
+    from tests.hip_utils import bf16_round, to_cpu_nchw, to_dev_nhwc, unit_input
+    _, rs = _mods()
+    x = unit_input("pool", (2, 16, 13, 10))
+    if dtype == torch.bfloat16:
+        x = bf16_round(x)
+    xd = to_dev_nhwc(x, dtype)
+    y = to_cpu_nchw(rs.MaxPool2d(2, 2, 0)(xd))
+    assert torch.equal(y, torch.nn.MaxPool2d(2, 2, 0)(x))
+    y = to_cpu_nchw(rs.MaxPool2d(2, 1, 0)(rs.ZeroPad2d([0, 1, 0, 1])(xd)))
+    assert torch.equal(y, torch.nn.MaxPool2d(2, 1, 0)(torch.nn.ZeroPad2d([0, 1, 0, 1])(x)))
+    y = to_cpu_nchw(rs.MaxPool2d(5, 1, 2)(xd))
+    assert torch.equal(y, torch.nn.MaxPool2d(5, 1, 2)(x))
+
+
+def test_detect_head_matches_golden(golden_dir):
+    from tests.hip_utils import DEV, bn_fix, to_cpu_nchw, to_dev_nhwc, unit_input
+    pm, _ = _mods()
+    G = np.load(golden_dir / "ops_unit.npz")
+    pm.Detect.legacy = True
+    d = bn_fix(pm.Detect(80, (16, 32, 64)))
+    d.stride = torch.tensor([8.0, 16.0, 32.0])
+    P.apply_procedural_weights(d, family="yolov8n")
+    d = d.to(DEV)
+    xs = [to_dev_nhwc(unit_input(f"det{i}", s)) for i, s in enumerate([(2, 16, 8, 8), (2, 32, 4, 4), (2, 64, 2, 2)])]
+    with torch.no_grad():
+        y, raw = d(xs)
+    torch.cuda.synchronize()
+    assert y.shape == (2, 84, 84)
+    assert np.abs(to_cpu_nchw(raw[0]).numpy() - G["detect_raw0"]).max() <= 5e-5
+    d_ = np.abs(y.cpu().numpy() - G["detect_y"])
+    assert d_[:, :4].max() <= 1e-3 and d_[:, 4:].max() <= 1e-5
+
+
+def test_detect_decode_vs_oracle_random_logits():
+    """Decode kernel alone: DFL + dist2bbox + sigmoid on wide-range logits, f32 and bf16 inputs."""
+    from tests.hip_utils import DEV, bf16_round, to_dev_nhwc, unit_input
+    pm, _ = _mods()
+    pm.Detect.legacy = True
+    for dtype in (torch.float32, torch.bfloat16):
+        det = pm.Detect(80, (64, 128)).eval()
+        det.stride = torch.tensor([8.0, 16.0])
+        raws = [unit_input(f"rawlvl{i}", (2, 144, s, s + 3), -8, 8) for i, s in enumerate((12, 6))]
+        if dtype == torch.bfloat16:
+            raws = [bf16_round(r) for r in raws]
+        oref = om.Detect(80, (64, 128)).eval()
+        oref.stride = det.stride
+        ref = oref._inference([r.clone() for r in raws])
+        y = det._inference([to_dev_nhwc(r, dtype) for r in raws])
+        torch.cuda.synchronize()
+        diff = (y.cpu() - ref).abs()
+        assert diff[:, :4].max() <= 2e-4 and diff[:, 4:].max() <= 2e-6, (dtype, diff[:, :4].max(), diff[:, 4:].max())
+
+
+def _nms_names(g):
+    return sorted(k[:-5] for k in g.files if k.endswith("_pred"))
+
+
+def test_nms_golden_cases_bit_exact(golden_dir):
+    """Every reference NMS fixture (hand cases + random dense cases): rows, counts and kept indices bit-exact."""
+    from tests.hip_utils import DEV
+    from ultralytics_pro_amd.utils.nms import non_max_suppression
+    g = np.load(golden_dir / "nms_cases.npz")
+    for name in _nms_names(g):
+        kw = json.loads(str(g[name + "_kw"]))
+        pred = torch.from_numpy(g[name + "_pred"]).to(DEV)
+        out, keep = non_max_suppression(pred, return_idxs=True, **kw)
+        assert [o.shape[0] for o in out] == list(g[name + "_n"]), name
+        rows = torch.cat(out, 0).cpu().numpy()
+        assert np.array_equal(rows, g[name + "_out"]), name
+        assert np.array_equal(torch.cat(keep).cpu().numpy(), g[name + "_keep"]), name
+
+
+def test_nms_large_multilabel_vs_oracle():
+    """> max_nms candidates (radix select + global bitonic path) and ragged per-image counts, vs the oracle."""
+    from tests.hip_utils import DEV
+    from ultralytics_pro_amd.utils.nms import non_max_suppression
+    n = 3000
+    p = torch.zeros(3, 84, n)
+    u = P.uniform("nmsbig:box", (3, 4, n), 0, 1)
+    p[:, 0] = u[:, 0] * 600 + 20
+    p[:, 1] = u[:, 1] * 600 + 20
+    p[:, 2] = u[:, 2] * 60 + 10
+    p[:, 3] = u[:, 3] * 60 + 10
+    p[:, 4:] = P.uniform("nmsbig:cls", (3, 80, n), 0, 1) ** 4
+    p[2, 4:, 100:] = 0  # ragged: third image has few candidates
+    for kw in (dict(conf_thres=0.001, iou_thres=0.7, multi_label=True, max_det=300, max_nms=30000),
+               dict(conf_thres=0.05, iou_thres=0.5, multi_label=True, max_det=100, max_nms=5000),
+               dict(conf_thres=0.25, iou_thres=0.45)):
+        ref = onms.non_max_suppression(p.clone(), **kw)
+        out = non_max_suppression(p.to(DEV), **kw)
+        for a, b in zip(out, ref):
+            assert a.shape == b.shape
+            assert torch.equal(a.cpu(), b), kw
+
+
+def test_cpu_tensor_fails_loudly():
+    from ultralytics_pro_amd._lib import UpaError
+    pm, _ = _mods()
+    with pytest.raises(UpaError):
+        pm.Conv(16, 16, 3).eval()(torch.zeros(1, 16, 8, 8))

@@ -1,0 +1,92 @@
+"""ctypes binding of libupa_hip.so (the C ABI declared in include/upa.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, a RuntimeError is raised.
+`import torch` must precede the dlopen so that the library binds to the HIP runtime torch already loaded
+(one runtime per process: streams and device pointers are shared with torch's allocator).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import torch  # noqa: F401  (loads libamdhip64.so.7 first - see module docstring)
+
+UPA_F32, UPA_BF16 = 0, 1
+ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("UPA_HIP_LIB", _PKG / "libupa_hip.so"))
+
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); must list every prototype of include/upa.h (tests/test_abi.py checks this)
+PROTOTYPES = {
+    "upa_version": (_i, []),
+    "upa_last_error": (C.c_char_p, []),
+    "upa_conv_packed_weight_bytes": (_sz, [_i, _i, _i, _i]),
+    "upa_pack_conv_weight": (_i, [_vp, _i, _i, _i, _i, _vp]),
+    "upa_conv2d_bias_act": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "upa_conv2d_stem_nchw": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "upa_maxpool2d": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "upa_sppf_pool3": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
+    "upa_upsample2x": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
+    "upa_copy_view": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
+    "upa_add_view": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "upa_nchw_to_nhwc": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
+    "upa_nhwc_to_nchw": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "upa_detect_decode": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _i, _i, _vp]),
+    "upa_nms_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "upa_nms_batched": (_i, [_vp, _i, _i, _i, _f, _f, _i, _i, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "upa_graph_begin": (_i, [_vp]),
+    "upa_graph_end": (_i, [_vp, C.POINTER(_vp)]),
+    "upa_graph_launch": (_i, [_vp, _vp]),
+    "upa_graph_destroy": (_i, [_vp]),
+}
+
+_lib = None
+
+
+class UpaError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the HIP library; raises loudly when it is absent - there is no CPU fallback."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.is_file():
+            raise UpaError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(make -C ultralytics_pro_amd/csrc). The HIP path has no fallback.")
+        handle = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(handle, name)  # AttributeError if the .so is stale
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().upa_last_error().decode(errors="replace")
+        raise UpaError(f"{what or 'upa call'} failed (rc={rc}): {msg}")
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return UPA_F32
+    if dt == torch.bfloat16:
+        return UPA_BF16
+    raise UpaError(f"unsupported activation dtype {dt}; use torch.float32 (parity) or torch.bfloat16 (perf)")
+
+
+def current_stream(device=None) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_gpu(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise UpaError(f"{what}: tensor is on {t.device}; the HIP path only runs on an MI355X (cuda:N) - "
+                       "there is deliberately no CPU fallback")

@@ -1,0 +1,66 @@
+// Shared device/host helpers for libupa_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/upa.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+
+void upa_set_error(const char* fmt, ...);
+
+#define UPA_CHECK_ARG(cond, ...)      \
+  do {                                \
+    if (!(cond)) {                    \
+      upa_set_error(__VA_ARGS__);     \
+      return UPA_EINVAL;              \
+    }                                 \
+  } while (0)
+
+#define UPA_LAUNCH_CHECK()                                       \
+  do {                                                           \
+    hipError_t e__ = hipGetLastError();                          \
+    if (e__ != hipSuccess) {                                     \
+      upa_set_error("launch failed: %s", hipGetErrorString(e__)); \
+      return UPA_ELAUNCH;                                        \
+    }                                                            \
+  } while (0)
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+// round-to-nearest-even f32 -> bf16 (a plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 and keeps NaN a NaN)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  __bf16 b = (__bf16)f;
+  return *reinterpret_cast<bf16_t*>(&b);
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+}
+
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<float> {
+  static constexpr int E = 4;       // elements per 16 bytes
+  static constexpr int KT_CH = 16;  // channels per 64-byte k-tile
+  __device__ static float load(const float* p) { return *p; }
+};
+template <> struct ElemTraits<bf16_t> {
+  static constexpr int E = 8;
+  static constexpr int KT_CH = 32;
+  __device__ static float load(const bf16_t* p) { return bf16_to_f32(*p); }
+};
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == UPA_ACT_SILU) return silu_f(v);
+  if (act == UPA_ACT_RELU) return fmaxf(v, 0.0f);
+  return v;
+}
+
+static inline int upa_elem_size(int dtype) { return dtype == UPA_BF16 ? 2 : 4; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

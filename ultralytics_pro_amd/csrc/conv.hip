@@ -1,0 +1,338 @@
+// Implicit-GEMM convolution on MFMA for gfx950 (CDNA4).
+//
+//   y[n,oy,ox,co] = act( sum_{kh,kw,ci} x[n, oy*s+kh-p, ox*s+kw-p, ci] * W[co,ci,kh,kw] + bias[co] ) (+ residual)
+//
+// Replaces the torch dispatch of Conv.forward_fuse (ultralytics/nn/modules/conv.py:188-197) with BN folded
+// (utils/torch_utils.py:236-266) and the Bottleneck residual add (nn/modules/block.py:668) fused in the epilogue.
+//
+// Mapping (one workgroup = WM x WN wavefronts of 64 lanes):
+//   * the workgroup owns a TH x TW tile of output pixels of one image (BM = TH*TW = WM*MTW*16 pixels) and
+//     BN = WN*NTW*16 output channels;
+//   * the input halo tile ((TH-1)s+k) x ((TW-1)s+k) pixels x (<= CKT*64 bytes of channels) is staged ONCE per channel
+//     chunk in LDS (zero-filled outside the image and past Cin); every tap (kh,kw) then reads it at a shifted offset,
+//     so each input byte is fetched from HBM/L2 once per workgroup instead of k*k times;
+//   * GEMM orientation: A = weights (rows = output channels), B = pixels (columns); D[row=co][col=pixel] leaves each
+//     lane with 4 consecutive output channels of one pixel -> one 8/16-byte NHWC store per accumulator tile;
+//   * weights are pre-packed in exact A-fragment order ([tap][ktile][ntile][lane][16 B]) so a wave's fragment load is
+//     one fully coalesced 1 KiB global_load_dwordx4 (served by L2/L1; the whole yolov8n weight set is 6 MB);
+//   * bf16: v_mfma_f32_16x16x32_bf16 (one per 64-byte k-tile); f32: 4 x v_mfma_f32_16x16x4_f32 per k-tile - exact f32
+//     (k-ordered fmaf chain), used for the <=1e-3 parity mode.  k order inside a tile is permuted identically for A
+//     and B (lane group g supplies bytes [16g,16g+16) of the tile), which leaves the sum unchanged.
+//   * LDS pixel stride = chunk bytes + 16 so consecutive pixels land on different 16-byte bank slots.
+#include "common.h"
+
+struct ConvParams {
+  const char* x;
+  char* y;
+  const char* res;
+  const char* w;
+  const float* bias;
+  int N, H, W, Cin, ldx;
+  int OH, OW, Cout, ldy, ldr;
+  int KS, stride, pad;
+  int TH, TW, tilesX, tilesY;
+  int KTT;  // k-tiles per tap  (Cin padded to the k-tile / channels per k-tile)
+  int CKT;  // k-tiles per LDS chunk (1, 2 or 4)
+  int NTn;  // n-tiles in the packed weights (Cout padded to 16 / 16)
+  int act;
+  int IH, IW, PS;  // halo tile dims, LDS pixel stride in bytes
+  unsigned magicIW;  // ceil(2^32 / IW)
+};
+
+template <typename T, bool PRECISE>
+__device__ __forceinline__ float act_fn(float v, int act) {
+  if (act == UPA_ACT_SILU) {
+    if (PRECISE) return v / (1.0f + __expf(-v));
+    return v * __frcp_rn(1.0f + __expf(-v));
+  }
+  if (act == UPA_ACT_RELU) return fmaxf(v, 0.0f);
+  return v;
+}
+
+template <typename T, int WM, int WN, int MTW, int NTW>
+__global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ES = sizeof(T);
+  constexpr int E = 16 / ES;      // elements per 16 bytes
+  constexpr int KT_CH = 64 / ES;  // channels per k-tile
+  constexpr int NTHREADS = WM * WN * 64;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int wm = wave / WN, wn = wave % WN;
+
+  // ---- tile decode
+  int bid = blockIdx.x;
+  const int tilesPerImg = p.tilesX * p.tilesY;
+  const int n = bid / tilesPerImg;
+  bid -= n * tilesPerImg;
+  const int tyi = bid / p.tilesX;
+  const int txi = bid - tyi * p.tilesX;
+  const int oy0 = tyi * p.TH, ox0 = txi * p.TW;
+  const int iy0 = oy0 * p.stride - p.pad, ix0 = ox0 * p.stride - p.pad;
+  const int nt0 = (blockIdx.y * WN + wn) * NTW;  // first n-tile of this wave
+
+  f32x4 acc[MTW][NTW];
+#pragma unroll
+  for (int i = 0; i < MTW; ++i)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // per-lane LDS byte offset of the top-left tap of its pixel, for each m-tile
+  int pixbase[MTW];
+  int pty[MTW], ptx[MTW];
+#pragma unroll
+  for (int i = 0; i < MTW; ++i) {
+    const int pp = (wm * MTW + i) * 16 + r;
+    const int ty = pp / p.TW;
+    const int tx = pp - ty * p.TW;
+    pty[i] = ty;
+    ptx[i] = tx;
+    pixbase[i] = ((ty * p.stride) * p.IW + tx * p.stride) * p.PS + g * 16;
+  }
+
+  const int nChunks = (p.KTT + p.CKT - 1) / p.CKT;
+  const int G16 = p.CKT * 4;  // 16-byte groups per pixel per chunk (power of two)
+  const int g16shift = (p.CKT == 1) ? 2 : (p.CKT == 2 ? 3 : 4);
+  const int haloItems = p.IH * p.IW * G16;
+  const size_t wTileStride = (size_t)p.NTn * 1024;  // bytes per (tap, ktile)
+
+  for (int c = 0; c < nChunks; ++c) {
+    const int nkt = min(p.CKT, p.KTT - c * p.CKT);
+    const int c0 = c * p.CKT * KT_CH;
+    if (c > 0) __syncthreads();
+    // ---- stage the halo tile of this channel chunk
+    for (int idx = tid; idx < haloItems; idx += NTHREADS) {
+      const int pix = idx >> g16shift;
+      const int cg = idx & (G16 - 1);
+      const int py = __umulhi((unsigned)pix, p.magicIW);
+      const int px = pix - py * p.IW;
+      const int iy = iy0 + py, ix = ix0 + px;
+      const int ch = c0 + cg * E;
+      u32x4 v = u32x4{0u, 0u, 0u, 0u};
+      if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && ch < p.Cin) {
+        const size_t off = (((size_t)n * p.H + iy) * p.W + ix) * (size_t)p.ldx + ch;
+        v = *reinterpret_cast<const u32x4*>(p.x + off * ES);
+      }
+      *reinterpret_cast<u32x4*>(smem + pix * p.PS + cg * 16) = v;
+    }
+    __syncthreads();
+    // ---- taps x k-tiles
+    for (int kh = 0; kh < p.KS; ++kh) {
+      for (int kw = 0; kw < p.KS; ++kw) {
+        const int tapoff = (kh * p.IW + kw) * p.PS;
+        const int ktg0 = (kh * p.KS + kw) * p.KTT + c * p.CKT;
+        for (int kt = 0; kt < nkt; ++kt) {
+          const char* wbase = p.w + (size_t)(ktg0 + kt) * wTileStride + (size_t)nt0 * 1024 + lane * 16;
+          u32x4 a[NTW];
+#pragma unroll
+          for (int j = 0; j < NTW; ++j) a[j] = *reinterpret_cast<const u32x4*>(wbase + j * 1024);
+          u32x4 b[MTW];
+#pragma unroll
+          for (int i = 0; i < MTW; ++i)
+            b[i] = *reinterpret_cast<const u32x4*>(smem + pixbase[i] + tapoff + kt * 64);
+#pragma unroll
+          for (int i = 0; i < MTW; ++i) {
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+              if constexpr (ES == 2) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&a[j]),
+                                                                    *reinterpret_cast<bf16x8*>(&b[i]), acc[i][j], 0, 0, 0);
+              } else {
+                const float* af = reinterpret_cast<const float*>(&a[j]);
+                const float* bf = reinterpret_cast<const float*>(&b[i]);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], bf[0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1], bf[1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[2], bf[2], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[3], bf[3], acc[i][j], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: bias + act (+ residual) -> NHWC store; lane holds channels co0..co0+3 of pixel (col r)
+#pragma unroll
+  for (int i = 0; i < MTW; ++i) {
+    const int oy = oy0 + pty[i], ox = ox0 + ptx[i];
+    if (pty[i] >= p.TH || oy >= p.OH || ox >= p.OW) continue;
+    const size_t pixoff = ((size_t)n * p.OH + oy) * p.OW + ox;
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      const int co = (nt0 + j) * 16 + g * 4;
+      if (co >= p.Cout) continue;
+      float v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float t = acc[i][j][q] + (p.bias ? p.bias[co + q] : 0.f);
+        v[q] = act_fn<T, ES == 4>(t, p.act);
+      }
+      if constexpr (ES == 4) {
+        if (p.res) {
+          const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + (pixoff * p.ldr + co) * 4);
+          v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3];
+        }
+        *reinterpret_cast<f32x4*>(p.y + (pixoff * p.ldy + co) * 4) = f32x4{v[0], v[1], v[2], v[3]};
+      } else {
+        if (p.res) {
+          const u32x2 rv = *reinterpret_cast<const u32x2*>(p.res + (pixoff * p.ldr + co) * 2);
+          v[0] += __uint_as_float(rv[0] << 16);
+          v[1] += __uint_as_float(rv[0] & 0xFFFF0000u);
+          v[2] += __uint_as_float(rv[1] << 16);
+          v[3] += __uint_as_float(rv[1] & 0xFFFF0000u);
+        }
+        *reinterpret_cast<u32x2*>(p.y + (pixoff * p.ldy + co) * 2) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------
+static inline unsigned short host_f32_to_bf16(float f) {
+  unsigned u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (unsigned short)((u >> 16) | 0x40);  // NaN stays NaN
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+extern "C" size_t upa_conv_packed_weight_bytes(int cout, int cin, int k, int dtype) {
+  const int ktch = dtype == UPA_BF16 ? 32 : 16;
+  const int ktt = cdiv(cin, ktch);
+  const int ntn = cdiv(cout, 16);
+  return (size_t)k * k * ktt * ntn * 1024;
+}
+
+// Packed layout: [tap = kh*k+kw][ktile][ntile][lane = g*16 + r][E elements], element j of lane (g, r) =
+// W[co = ntile*16 + r][ci = ktile*KT_CH + g*E + j][kh][kw]  (zero beyond cout / cin).
+extern "C" int upa_pack_conv_weight(const float* w, int cout, int cin, int k, int dtype, void* out) {
+  UPA_CHECK_ARG(w && out && cout > 0 && cin > 0 && k >= 1 && k <= 7, "pack_conv_weight: bad args");
+  const int E = dtype == UPA_BF16 ? 8 : 4;
+  const int ktch = 4 * E;
+  const int ktt = cdiv(cin, ktch), ntn = cdiv(cout, 16);
+  size_t idx = 0;
+  for (int kh = 0; kh < k; ++kh)
+    for (int kw = 0; kw < k; ++kw)
+      for (int kt = 0; kt < ktt; ++kt)
+        for (int nt = 0; nt < ntn; ++nt)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int g = lane >> 4, r = lane & 15;
+            const int co = nt * 16 + r;
+            for (int j = 0; j < E; ++j, ++idx) {
+              const int ci = kt * ktch + g * E + j;
+              float v = 0.f;
+              if (co < cout && ci < cin) v = w[(((size_t)co * cin + ci) * k + kh) * k + kw];
+              if (dtype == UPA_BF16)
+                ((unsigned short*)out)[idx] = host_f32_to_bf16(v);
+              else
+                ((float*)out)[idx] = v;
+            }
+          }
+  return UPA_OK;
+}
+
+namespace {
+
+struct TileCfg {
+  int TH, TW;
+};
+
+template <typename T, int WM, int WN, int MTW, int NTW>
+int launch_conv(ConvParams& p, hipStream_t stream) {
+  constexpr int BM = WM * MTW * 16;
+  constexpr int BN = WN * NTW * 16;
+  // tile shape: BM pixels as TH x TW
+  int TW, TH;
+  if (p.KS == 1 && p.stride == 1 && p.pad == 0) {
+    // pointwise: flatten (n,h,w) into one pixel row - views have a uniform pixel stride
+    const long P = (long)p.N * p.H * p.W;
+    p.N = 1; p.H = 1; p.W = (int)P; p.OH = 1; p.OW = (int)P;
+    TH = 1; TW = BM;
+  } else {
+    TW = p.OW >= 16 ? 16 : 8;
+    if (p.OW % 16 != 0 && p.OW % 20 == 0 && BM % 20 == 0) TW = 20;
+    if (BM % TW != 0) TW = 16;
+    TH = BM / TW;
+  }
+  p.TH = TH; p.TW = TW;
+  p.tilesX = cdiv(p.OW, TW);
+  p.tilesY = cdiv(p.OH, TH);
+  p.IH = (TH - 1) * p.stride + p.KS;
+  p.IW = (TW - 1) * p.stride + p.KS;
+  // extra rows so that pixels past the tile (BM not a multiple of TW) still read inside the allocation
+  const int rowsNeeded = (cdiv(BM, TW) - 1) * p.stride + p.KS;
+  const int IHalloc = rowsNeeded > p.IH ? rowsNeeded : p.IH;
+  p.PS = p.CKT * 64 + 16;
+  p.magicIW = (unsigned)((0x100000000ULL + p.IW - 1) / p.IW);
+  const size_t lds = (size_t)IHalloc * p.IW * p.PS + 64;
+  if (lds > 160 * 1024) return UPA_EUNSUPPORTED;
+  dim3 grid((unsigned)((long)p.tilesX * p.tilesY * p.N), (unsigned)cdiv(p.NTn * 16, BN));
+  auto kern = conv_igemm_kernel<T, WM, WN, MTW, NTW>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { upa_set_error("conv: cannot raise LDS limit: %s", hipGetErrorString(e)); return UPA_ELAUNCH; }
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, stream, p);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+template <typename T>
+int dispatch_conv(ConvParams& p, hipStream_t stream) {
+  const int ntn = p.NTn;
+  const long M = (long)p.N * p.OH * p.OW;
+  // n-tiling: prefer covering all output channels in one workgroup (input tile read once)
+  // candidates (WM, WN, MTW, NTW): BM = WM*MTW*16, BN = WN*NTW*16
+  if (ntn == 1) return launch_conv<T, 4, 1, 2, 1>(p, stream);                     // BN=16,  BM=128
+  if (ntn == 2) return launch_conv<T, 4, 1, 2, 2>(p, stream);                     // BN=32,  BM=128
+  if (ntn == 3) return launch_conv<T, 4, 1, 2, 3>(p, stream);                     // BN=48
+  if (ntn == 5) return launch_conv<T, 4, 1, 2, 5>(p, stream);                     // BN=80,  BM=128
+  if (ntn % 4 == 0) {
+    if (M >= 128 * 1024 || ntn == 4) return launch_conv<T, 2, 2, 4, 2>(p, stream);  // BN=64, BM=128
+    return launch_conv<T, 2, 2, 2, 2>(p, stream);                                 // BN=64, BM=64 (small maps)
+  }
+  if (ntn % 2 == 0) return launch_conv<T, 4, 1, 2, 2>(p, stream);
+  return launch_conv<T, 4, 1, 2, 1>(p, stream);
+}
+
+}  // namespace
+
+extern "C" int upa_conv2d_bias_act(const void* x, int n, int h, int w, int cin, int ldx, const void* w_packed,
+                                   const float* bias, void* y, int cout, int ldy, const void* residual, int ldr, int k,
+                                   int stride, int pad, int act, int dtype, void* stream) {
+  UPA_CHECK_ARG(x && w_packed && y, "conv2d: null pointer");
+  UPA_CHECK_ARG(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, "conv2d: bad shape");
+  UPA_CHECK_ARG(k >= 1 && k <= 7 && stride >= 1 && stride <= 2 && pad >= 0 && pad < k, "conv2d: unsupported k/s/p");
+  UPA_CHECK_ARG(dtype == UPA_F32 || dtype == UPA_BF16, "conv2d: bad dtype");
+  const int es = upa_elem_size(dtype);
+  const int E = 16 / es;
+  UPA_CHECK_ARG(cin % E == 0 && ldx % E == 0, "conv2d: cin/ldx must be multiples of %d elements", E);
+  UPA_CHECK_ARG(cout % 4 == 0 && ldy % 4 == 0 && (!residual || ldr % 4 == 0), "conv2d: cout/ldy/ldr % 4 != 0");
+  UPA_CHECK_ARG(((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 8 == 0), "conv2d: misaligned view");
+  ConvParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = (const char*)x; p.y = (char*)y; p.res = (const char*)residual; p.w = (const char*)w_packed; p.bias = bias;
+  p.N = n; p.H = h; p.W = w; p.Cin = cin; p.ldx = ldx;
+  p.OH = (h + 2 * pad - k) / stride + 1;
+  p.OW = (w + 2 * pad - k) / stride + 1;
+  p.Cout = cout; p.ldy = ldy; p.ldr = ldr;
+  p.KS = k; p.stride = stride; p.pad = pad; p.act = act;
+  const int ktch = 64 / es;
+  p.KTT = cdiv(cin, ktch);
+  p.NTn = cdiv(cout, 16);
+  // chunk: up to 4 k-tiles (256 B of channels per pixel) for stride 1, 2 for stride 2 (bigger halo)
+  int ckt = p.KTT >= 4 ? 4 : (p.KTT >= 2 ? 2 : 1);
+  if (stride == 2 && ckt > 2) ckt = 2;
+  if (k > 3 && ckt > 1) ckt = 1;
+  p.CKT = ckt;
+  hipStream_t s = (hipStream_t)stream;
+  int rc = dtype == UPA_BF16 ? dispatch_conv<bf16_t>(p, s) : dispatch_conv<float>(p, s);
+  if (rc == UPA_EUNSUPPORTED) upa_set_error("conv2d: tile does not fit LDS (k=%d s=%d cin=%d)", k, stride, cin);
+  return rc;
+}

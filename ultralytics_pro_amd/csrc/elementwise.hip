@@ -1,0 +1,317 @@
+// HBM-bound NHWC kernels: max pooling, the SPPF pooling chain, nearest 2x upsample into a channel slice, view copy/add
+// and NCHW<->NHWC boundary conversion.  All move 16 bytes of channels per lane (8 bf16 / 4 f32), lanes run along the
+// channel axis first so a wave touches whole contiguous pixel rows.
+#include "common.h"
+
+namespace {
+
+template <typename T> struct Vec16;  // 16 bytes of T as float lanes
+template <> struct Vec16<float> {
+  static constexpr int E = 4;
+  float v[4];
+  __device__ static Vec16 load(const char* p) {
+    Vec16 r;
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+    r.v[0] = t[0]; r.v[1] = t[1]; r.v[2] = t[2]; r.v[3] = t[3];
+    return r;
+  }
+  __device__ void store(char* p) const { *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]}; }
+};
+template <> struct Vec16<bf16_t> {
+  static constexpr int E = 8;
+  float v[8];
+  __device__ static Vec16 load(const char* p) {
+    Vec16 r;
+    const u32x4 t = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      r.v[2 * i] = __uint_as_float(t[i] << 16);
+      r.v[2 * i + 1] = __uint_as_float(t[i] & 0xFFFF0000u);
+    }
+    return r;
+  }
+  __device__ void store(char* p) const {
+    *reinterpret_cast<u32x4*>(p) =
+        u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+  }
+};
+
+// ---- generic max pool -------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_kernel(const char* x, char* y, int N, int H, int W, int C, int ldx, int OH,
+                                                      int OW, int ldy, int K, int S, int P, int padBR) {
+  constexpr int E = Vec16<T>::E;
+  const int CG = C / E;
+  const long total = (long)N * OH * OW * CG;
+  for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
+    const int cg = (int)(gid % CG);
+    long pix = gid / CG;
+    const int ox = (int)(pix % OW);
+    const int oy = (int)((pix / OW) % OH);
+    const int n = (int)(pix / ((long)OW * OH));
+    Vec16<T> m;
+#pragma unroll
+    for (int i = 0; i < E; ++i) m.v[i] = -INFINITY;
+    for (int kh = 0; kh < K; ++kh) {
+      const int iy = oy * S - P + kh;
+      for (int kw = 0; kw < K; ++kw) {
+        const int ix = ox * S - P + kw;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+          const Vec16<T> t = Vec16<T>::load(x + ((((size_t)n * H + iy) * W + ix) * ldx + cg * E) * sizeof(T));
+#pragma unroll
+          for (int i = 0; i < E; ++i) m.v[i] = fmaxf(m.v[i], t.v[i]);
+        } else if (iy >= 0 && ix >= 0 && iy < H + padBR && ix < W + padBR) {  // nn.ZeroPad2d cells: value 0
+#pragma unroll
+          for (int i = 0; i < E; ++i) m.v[i] = fmaxf(m.v[i], 0.f);
+        }
+      }
+    }
+    m.store(y + ((((size_t)n * OH + oy) * OW + ox) * ldy + cg * E) * sizeof(T));
+  }
+}
+
+// ---- SPPF: three chained 5x5/s1/p2 max pools == 5x5, 9x9, 13x13 windows of x (-inf padding) -------------------
+template <typename T>
+__global__ __launch_bounds__(256) void sppf_pool3_kernel(const char* x, char* y1, char* y2, char* y3, int N, int H, int W,
+                                                         int C, int ldx, int ldy) {
+  constexpr int E = Vec16<T>::E;
+  const int CG = C / E;
+  const long total = (long)N * H * W * CG;
+  for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
+    const int cg = (int)(gid % CG);
+    long pix = gid / CG;
+    const int ox = (int)(pix % W);
+    const int oy = (int)((pix / W) % H);
+    const int n = (int)(pix / ((long)W * H));
+    Vec16<T> m5, m9, m13;
+#pragma unroll
+    for (int i = 0; i < E; ++i) m5.v[i] = m9.v[i] = m13.v[i] = -INFINITY;
+    for (int dy = -6; dy <= 6; ++dy) {
+      const int iy = oy + dy;
+      if (iy < 0 || iy >= H) continue;
+      const int ady = dy < 0 ? -dy : dy;
+      for (int dx = -6; dx <= 6; ++dx) {
+        const int ix = ox + dx;
+        if (ix < 0 || ix >= W) continue;
+        const int adx = dx < 0 ? -dx : dx;
+        const int rad = ady > adx ? ady : adx;
+        const Vec16<T> t = Vec16<T>::load(x + ((((size_t)n * H + iy) * W + ix) * ldx + cg * E) * sizeof(T));
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+          m13.v[i] = fmaxf(m13.v[i], t.v[i]);
+          if (rad <= 4) m9.v[i] = fmaxf(m9.v[i], t.v[i]);
+          if (rad <= 2) m5.v[i] = fmaxf(m5.v[i], t.v[i]);
+        }
+      }
+    }
+    const size_t o = (((size_t)n * H + oy) * W + ox) * ldy + cg * E;
+    m5.store(y1 + o * sizeof(T));
+    m9.store(y2 + o * sizeof(T));
+    m13.store(y3 + o * sizeof(T));
+  }
+}
+
+// ---- nearest 2x upsample / copy / add -------------------------------------------------------------------------------
+template <int MODE>  // 0 copy, 1 upsample2x
+__global__ __launch_bounds__(256) void move16_kernel(const char* x, char* y, int N, int OH, int OW, int CG, long ldxB,
+                                                     long ldyB) {
+  const long total = (long)N * OH * OW * CG;
+  for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
+    const int cg = (int)(gid % CG);
+    long pix = gid / CG;
+    size_t src;
+    if (MODE == 1) {
+      const int ox = (int)(pix % OW);
+      const int oy = (int)((pix / OW) % OH);
+      const int n = (int)(pix / ((long)OW * OH));
+      src = ((size_t)n * (OH / 2) + (oy >> 1)) * (OW / 2) + (ox >> 1);
+    } else {
+      src = (size_t)pix;
+    }
+    *reinterpret_cast<u32x4*>(y + (size_t)pix * ldyB + cg * 16) = *reinterpret_cast<const u32x4*>(x + src * ldxB + cg * 16);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_kernel(const char* a, const char* b, char* y, long P, int CG, int lda, int ldb,
+                                                  int ldy) {
+  constexpr int E = Vec16<T>::E;
+  const long total = P * CG;
+  for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
+    const int cg = (int)(gid % CG);
+    const size_t pix = gid / CG;
+    Vec16<T> va = Vec16<T>::load(a + (pix * lda + cg * E) * sizeof(T));
+    const Vec16<T> vb = Vec16<T>::load(b + (pix * ldb + cg * E) * sizeof(T));
+#pragma unroll
+    for (int i = 0; i < E; ++i) va.v[i] += vb.v[i];
+    va.store(y + (pix * ldy + cg * E) * sizeof(T));
+  }
+}
+
+// ---- NCHW f32 <-> NHWC T (module boundary; tiles transposed through LDS so both sides stay coalesced) ------------
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* x, char* y, int C, long HW, int ldy) {
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z;
+  const long p0 = (long)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + j;
+    const long pp = p0 + tx;
+    tile[j][tx] = (c < C && pp < HW) ? x[((size_t)n * C + c) * HW + pp] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const long pp = p0 + j;
+    const int c = c0 + tx;
+    if (pp < HW && c < C) {
+      const float v = tile[tx][j];
+      char* dst = y + (((size_t)n * HW + pp) * ldy + c) * sizeof(T);
+      if constexpr (sizeof(T) == 4) *reinterpret_cast<float*>(dst) = v;
+      else *reinterpret_cast<bf16_t*>(dst) = f32_to_bf16(v);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const char* x, float* y, int C, long HW, int ldx) {
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z;
+  const long p0 = (long)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) {
+    const long pp = p0 + j;
+    const int c = c0 + tx;
+    float v = 0.f;
+    if (pp < HW && c < C) {
+      const char* src = x + (((size_t)n * HW + pp) * ldx + c) * sizeof(T);
+      if constexpr (sizeof(T) == 4) v = *reinterpret_cast<const float*>(src);
+      else v = bf16_to_f32(*reinterpret_cast<const bf16_t*>(src));
+    }
+    tile[j][tx] = v;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + j;
+    const long pp = p0 + tx;
+    if (c < C && pp < HW) y[((size_t)n * C + c) * HW + pp] = tile[tx][j];
+  }
+}
+
+inline unsigned grid_for(long total) {
+  long b = (total + 255) / 256;
+  const long cap = 256L * 16;
+  return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace
+
+#define CHECK_VIEW(c, ld, dtype)                                                                      \
+  UPA_CHECK_ARG((c) % (16 / upa_elem_size(dtype)) == 0 && (ld) % (16 / upa_elem_size(dtype)) == 0, \
+                "channel count / stride must be multiples of 16 bytes")
+
+extern "C" int upa_maxpool2d(const void* x, int n, int h, int w, int c, int ldx, void* y, int oh, int ow, int ldy, int k,
+                             int stride, int pad, int pad_br, int dtype, void* stream) {
+  UPA_CHECK_ARG(x && y && k >= 1 && stride >= 1, "maxpool2d: bad args");
+  CHECK_VIEW(c, ldx, dtype);
+  CHECK_VIEW(c, ldy, dtype);
+  UPA_CHECK_ARG(oh == (h + pad_br + 2 * pad - k) / stride + 1 && ow == (w + pad_br + 2 * pad - k) / stride + 1,
+                "maxpool2d: output shape mismatch");
+  const long total = (long)n * oh * ow * (c / (16 / upa_elem_size(dtype)));
+  if (dtype == UPA_BF16)
+    hipLaunchKernelGGL(maxpool_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const char*)x,
+                       (char*)y, n, h, w, c, ldx, oh, ow, ldy, k, stride, pad, pad_br);
+  else
+    hipLaunchKernelGGL(maxpool_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const char*)x,
+                       (char*)y, n, h, w, c, ldx, oh, ow, ldy, k, stride, pad, pad_br);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+extern "C" int upa_sppf_pool3(const void* x, int n, int h, int w, int c, int ldx, void* y1, void* y2, void* y3, int ldy,
+                              int dtype, void* stream) {
+  UPA_CHECK_ARG(x && y1 && y2 && y3, "sppf_pool3: null pointer");
+  CHECK_VIEW(c, ldx, dtype);
+  CHECK_VIEW(c, ldy, dtype);
+  const long total = (long)n * h * w * (c / (16 / upa_elem_size(dtype)));
+  if (dtype == UPA_BF16)
+    hipLaunchKernelGGL(sppf_pool3_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const char*)x, (char*)y1, (char*)y2, (char*)y3, n, h, w, c, ldx, ldy);
+  else
+    hipLaunchKernelGGL(sppf_pool3_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const char*)x, (char*)y1, (char*)y2, (char*)y3, n, h, w, c, ldx, ldy);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+extern "C" int upa_upsample2x(const void* x, int n, int h, int w, int c, int ldx, void* y, int ldy, int dtype,
+                              void* stream) {
+  UPA_CHECK_ARG(x && y, "upsample2x: null pointer");
+  CHECK_VIEW(c, ldx, dtype);
+  CHECK_VIEW(c, ldy, dtype);
+  const int es = upa_elem_size(dtype);
+  const int cg = c * es / 16;
+  const long total = (long)n * (2 * h) * (2 * w) * cg;
+  hipLaunchKernelGGL(move16_kernel<1>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const char*)x, (char*)y,
+                     n, 2 * h, 2 * w, cg, (long)ldx * es, (long)ldy * es);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+extern "C" int upa_copy_view(const void* x, int n, int h, int w, int c, int ldx, void* y, int ldy, int dtype,
+                             void* stream) {
+  UPA_CHECK_ARG(x && y, "copy_view: null pointer");
+  CHECK_VIEW(c, ldx, dtype);
+  CHECK_VIEW(c, ldy, dtype);
+  const int es = upa_elem_size(dtype);
+  const int cg = c * es / 16;
+  const long total = (long)n * h * w * cg;
+  hipLaunchKernelGGL(move16_kernel<0>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const char*)x, (char*)y,
+                     n, h, w, cg, (long)ldx * es, (long)ldy * es);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+extern "C" int upa_add_view(const void* a, int lda, const void* b, int ldb, void* y, int ldy, int n, int h, int w, int c,
+                            int dtype, void* stream) {
+  UPA_CHECK_ARG(a && b && y, "add_view: null pointer");
+  CHECK_VIEW(c, lda, dtype);
+  CHECK_VIEW(c, ldb, dtype);
+  CHECK_VIEW(c, ldy, dtype);
+  const long P = (long)n * h * w;
+  const int cg = c / (16 / upa_elem_size(dtype));
+  if (dtype == UPA_BF16)
+    hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(grid_for(P * cg)), dim3(256), 0, (hipStream_t)stream, (const char*)a,
+                       (const char*)b, (char*)y, P, cg, lda, ldb, ldy);
+  else
+    hipLaunchKernelGGL(add_kernel<float>, dim3(grid_for(P * cg)), dim3(256), 0, (hipStream_t)stream, (const char*)a,
+                       (const char*)b, (char*)y, P, cg, lda, ldb, ldy);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+extern "C" int upa_nchw_to_nhwc(const float* x, int n, int c, int h, int w, void* y, int ldy, int dtype, void* stream) {
+  UPA_CHECK_ARG(x && y && n > 0 && c > 0, "nchw_to_nhwc: bad args");
+  const long hw = (long)h * w;
+  dim3 grid((unsigned)((hw + 31) / 32), (unsigned)cdiv(c, 32), (unsigned)n);
+  if (dtype == UPA_BF16)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, x, (char*)y, c, hw, ldy);
+  else
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, x, (char*)y, c, hw, ldy);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+extern "C" int upa_nhwc_to_nchw(const void* x, int n, int h, int w, int c, int ldx, float* y, int dtype, void* stream) {
+  UPA_CHECK_ARG(x && y && n > 0 && c > 0, "nhwc_to_nchw: bad args");
+  const long hw = (long)h * w;
+  dim3 grid((unsigned)((hw + 31) / 32), (unsigned)cdiv(c, 32), (unsigned)n);
+  if (dtype == UPA_BF16)
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const char*)x, y, c, hw, ldx);
+  else
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const char*)x, y, c, hw, ldx);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}

@@ -1,0 +1,326 @@
+// Batched non_max_suppression, zero host synchronisation, fixed-shape outputs.
+// Replaces ultralytics/utils/nms.py:13-166 (candidate filter, best-class / multi-label expansion, class filter,
+// top-max_nms by score, class offset, greedy NMS, max_det) and TorchNMS.nms (:239-296).
+//
+// Three kernels per call:
+//  1. nms_candidates   (B x anchor-chunks workgroups)  per anchor: max/argmax over classes (first max wins) or every
+//                      class above conf (multi_label); survivors are appended as unique 64-bit keys
+//                        key = (~score_bits << 32) | (anchor*nc + cls)
+//                      with one wave-aggregated atomic per wave.  Ascending key order == score descending, ties by
+//                      ascending candidate order == the stable sort of the reference's candidate list.
+//  2. nms_sort         (one 1024-thread workgroup per image)  if n > max_nms an MSB-first radix select finds the exact
+//                      max_nms-th key (keys are unique) and compacts; then a bitonic sort (LDS when it fits).
+//  3. nms_greedy       (one 512-thread workgroup per image)  walks the sorted candidates 64 at a time: every wave
+//                      tests the chunk against a slice of the kept list held in LDS, wave 0 resolves the in-chunk
+//                      dependencies with a 64x64 suppression bit matrix, appends survivors, stops at max_det.
+// IoU arithmetic follows the reference op for op in f32 (class offset added to the boxes first, areas from the offset
+// boxes, no eps, survivor iff iou <= thr); FP contraction is disabled so no FMA changes a keep/suppress decision.
+#include "common.h"
+#pragma clang fp contract(off)
+
+typedef unsigned long long u64;
+
+namespace {
+
+struct NmsWs {
+  int* count;   // [B] candidates appended
+  int* nsorted; // [B] candidates after select
+  u64* keys;    // [B][cap]
+  u64* sel;     // [B][selcap]
+};
+
+__global__ __launch_bounds__(256) void nms_candidates_kernel(const float* pred, int B, int nc, int A, float conf,
+                                                             int multi_label, const uint8_t* cmask, int* count, u64* keys,
+                                                             long cap) {
+  const int b = blockIdx.y;
+  const int a = blockIdx.x * 256 + threadIdx.x;
+  const bool valid = a < A;
+  const float* pb = pred + (size_t)b * (4 + nc) * A + (size_t)4 * A + (valid ? a : 0);
+  u64* kb = keys + (size_t)b * cap;
+  const int lane = threadIdx.x & 63;
+  if (!multi_label) {
+    float best = -INFINITY;
+    int bc = 0;
+    if (valid) {
+      for (int c = 0; c < nc; ++c) {
+        const float v = pb[(size_t)c * A];
+        if (v > best) { best = v; bc = c; }
+      }
+    }
+    const bool cand = valid && best > conf && (!cmask || cmask[bc]);
+    const u64 m = __ballot(cand);
+    if (m) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&count[b], __popcll(m));
+      base = __shfl(base, 0);
+      if (cand) {
+        const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (slot < cap) kb[slot] = ((u64)(~__float_as_uint(best)) << 32) | (unsigned)(a * nc + bc);
+      }
+    }
+  } else {
+    for (int c = 0; c < nc; ++c) {
+      const float v = valid ? pb[(size_t)c * A] : -INFINITY;
+      const bool cand = valid && v > conf && (!cmask || cmask[c]);
+      const u64 m = __ballot(cand);
+      if (m) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&count[b], __popcll(m));
+        base = __shfl(base, 0);
+        if (cand) {
+          const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+          if (slot < cap) kb[slot] = ((u64)(~__float_as_uint(v)) << 32) | (unsigned)(a * nc + c);
+        }
+      }
+    }
+  }
+}
+
+// bitonic sort of `buf[0..npad)` (npad power of two) ascending, all threads of the workgroup
+template <int NT>
+__device__ void bitonic_sort(u64* buf, int npad) {
+  for (int k = 2; k <= npad; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < (npad >> 1); t += NT) {
+        const int i = 2 * t - (t & (j - 1));  // index with bit j clear
+        const int l = i + j;
+        const bool up = (i & k) == 0;
+        const u64 x = buf[i], y = buf[l];
+        if ((x > y) == up) { buf[i] = y; buf[l] = x; }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+constexpr int SORT_NT = 1024;
+constexpr int LDS_SORT_CAP = 16384;  // u64 -> 128 KiB of dynamic LDS (covers every single-label case, A <= 16384)
+
+__global__ __launch_bounds__(SORT_NT) void nms_sort_kernel(const int* count, int* nsorted, u64* keys, u64* sel, long cap,
+                                                           int selcap, int max_nms) {
+  extern __shared__ __attribute__((aligned(16))) u64 lbuf[];  // LDS_SORT_CAP keys
+  __shared__ int hist[256];
+  __shared__ u64 s_prefix;
+  __shared__ int s_remaining, s_n;
+  const int b = blockIdx.x;
+  u64* kb = keys + (size_t)b * cap;
+  u64* sb = sel + (size_t)b * selcap;
+  int n = count[b];
+  if (n > cap) n = (int)cap;
+  if (n > max_nms) {
+    // exact threshold key K*: exactly max_nms keys are <= K* (keys are unique)
+    if (threadIdx.x == 0) { s_prefix = 0ull; s_remaining = max_nms; s_n = 0; }
+    for (int shift = 56; shift >= 0; shift -= 8) {
+      for (int i = threadIdx.x; i < 256; i += SORT_NT) hist[i] = 0;
+      __syncthreads();
+      const u64 prefix = s_prefix;
+      const u64 himask = shift == 56 ? 0ull : (~0ull << (shift + 8));
+      for (int i = threadIdx.x; i < n; i += SORT_NT) {
+        const u64 k = kb[i];
+        if ((k & himask) == (prefix & himask)) atomicAdd(&hist[(int)((k >> shift) & 255ull)], 1);
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        int rem = s_remaining, cum = 0, d = 0;
+        for (; d < 256; ++d) {
+          if (cum + hist[d] >= rem) break;
+          cum += hist[d];
+        }
+        s_remaining = rem - cum;
+        s_prefix = prefix | ((u64)d << shift);
+      }
+      __syncthreads();
+    }
+    const u64 kstar = s_prefix;
+    for (int i = threadIdx.x; i < n; i += SORT_NT) {
+      const u64 k = kb[i];
+      if (k <= kstar) {
+        const int slot = atomicAdd(&s_n, 1);
+        if (slot < selcap) sb[slot] = k;
+      }
+    }
+    __syncthreads();
+    n = s_n < max_nms ? s_n : max_nms;
+    kb = sb;  // source is now the compacted list
+    __syncthreads();
+  }
+  int npad = 1;
+  while (npad < n) npad <<= 1;
+  if (npad < 2) npad = 2;
+  if (npad <= LDS_SORT_CAP) {
+    for (int i = threadIdx.x; i < npad; i += SORT_NT) lbuf[i] = i < n ? kb[i] : ~0ull;
+    __syncthreads();
+    bitonic_sort<SORT_NT>(lbuf, npad);
+    for (int i = threadIdx.x; i < n; i += SORT_NT) sb[i] = lbuf[i];
+  } else {
+    if (kb != sb)
+      for (int i = threadIdx.x; i < n; i += SORT_NT) sb[i] = kb[i];
+    for (int i = n + threadIdx.x; i < npad; i += SORT_NT) sb[i] = ~0ull;
+    __syncthreads();
+    bitonic_sort<SORT_NT>(sb, npad);  // global memory; visibility inside one workgroup via __syncthreads
+  }
+  if (threadIdx.x == 0) nsorted[b] = n;
+}
+
+__device__ __forceinline__ bool iou_gt(float ax1, float ay1, float ax2, float ay2, float aarea, float bx1, float by1,
+                                       float bx2, float by2, float barea, float thr) {
+  const float w = fmaxf(fminf(ax2, bx2) - fmaxf(ax1, bx1), 0.f);
+  const float h = fmaxf(fminf(ay2, by2) - fmaxf(ay1, by1), 0.f);
+  const float inter = w * h;
+  const float iou = inter / (aarea + barea - inter);
+  return !(iou <= thr);  // reference keeps `iou <= thr`; NaN is not kept either
+}
+
+constexpr int GREEDY_NT = 512;
+constexpr int GREEDY_NW = GREEDY_NT / 64;
+constexpr int MAX_DET_CAP = 1024;
+
+__global__ __launch_bounds__(GREEDY_NT) void nms_greedy_kernel(const float* pred, int nc, int A, const int* nsorted,
+                                                               const u64* sel, int selcap, float iou_thr, int agnostic,
+                                                               float max_wh, int max_det, float* out, int* counts,
+                                                               int* keep_idx) {
+  __shared__ float kx1[MAX_DET_CAP], ky1[MAX_DET_CAP], kx2[MAX_DET_CAP], ky2[MAX_DET_CAP], kar[MAX_DET_CAP];
+  __shared__ u64 alive_w[GREEDY_NW];
+  __shared__ int s_kept;
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = nsorted[b];
+  const u64* sb = sel + (size_t)b * selcap;
+  const float* pb = pred + (size_t)b * (4 + nc) * A;
+  float* ob = out + (size_t)b * max_det * 6;
+  // zero the fixed-shape output
+  for (int i = threadIdx.x; i < max_det * 6; i += GREEDY_NT) ob[i] = 0.f;
+  if (keep_idx)
+    for (int i = threadIdx.x; i < max_det; i += GREEDY_NT) keep_idx[(size_t)b * max_det + i] = -1;
+  if (threadIdx.x == 0) s_kept = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 64) {
+    const int kept = s_kept;
+    if (kept >= max_det) break;
+    const int ci = base + lane;
+    const bool valid = ci < n;
+    float rx1 = 0, ry1 = 0, rx2 = 0, ry2 = 0, score = 0, clsf = 0;  // raw (un-offset) box
+    float x1 = 0, y1 = 0, x2 = 0, y2 = 0, area = 0;
+    int anchor = 0;
+    if (valid) {
+      const u64 key = sb[ci];
+      const unsigned ok = (unsigned)(key & 0xFFFFFFFFull);
+      anchor = (int)(ok / (unsigned)nc);
+      const int c = (int)(ok - (unsigned)anchor * (unsigned)nc);
+      score = __uint_as_float(~(unsigned)(key >> 32));
+      clsf = (float)c;
+      const float cx = pb[anchor], cy = pb[(size_t)A + anchor], w = pb[(size_t)2 * A + anchor],
+                  h = pb[(size_t)3 * A + anchor];
+      const float hw = w / 2.f, hh = h / 2.f;  // xywh2xyxy, utils/ops.py:268-284
+      rx1 = cx - hw; ry1 = cy - hh; rx2 = cx + hw; ry2 = cy + hh;
+      const float off = clsf * (agnostic ? 0.f : max_wh);  // nms.py:143
+      x1 = rx1 + off; y1 = ry1 + off; x2 = rx2 + off; y2 = ry2 + off;
+      area = (x2 - x1) * (y2 - y1);
+    }
+    // phase 1: this wave tests the chunk against its slice of the kept list
+    bool sup = false;
+    for (int k = wave; k < kept; k += GREEDY_NW)
+      sup |= iou_gt(kx1[k], ky1[k], kx2[k], ky2[k], kar[k], x1, y1, x2, y2, area, iou_thr);
+    const u64 am = __ballot(valid && !sup);
+    if (lane == 0) alive_w[wave] = am;
+    __syncthreads();
+    if (wave == 0) {
+      u64 alive = alive_w[0];
+#pragma unroll
+      for (int q = 1; q < GREEDY_NW; ++q) alive &= alive_w[q];
+      // phase 2: in-chunk suppression bits (earlier lane i suppresses me)
+      u64 m = 0ull;
+      for (int i = 0; i < 63; ++i) {
+        const float ix1 = __shfl(x1, i), iy1 = __shfl(y1, i), ix2 = __shfl(x2, i), iy2 = __shfl(y2, i),
+                    iar = __shfl(area, i);
+        if (i < lane && ((alive >> i) & 1ull) && iou_gt(ix1, iy1, ix2, iy2, iar, x1, y1, x2, y2, area, iou_thr))
+          m |= 1ull << i;
+      }
+      // sequential resolve
+      u64 keepmask = 0ull;
+      const unsigned mlo = (unsigned)m, mhi = (unsigned)(m >> 32);
+      for (int i = 0; i < 64; ++i) {
+        const u64 mi = ((u64)(unsigned)__shfl((int)mhi, i) << 32) | (unsigned)__shfl((int)mlo, i);
+        if (((alive >> i) & 1ull) && !(mi & keepmask)) keepmask |= 1ull << i;
+      }
+      if ((keepmask >> lane) & 1ull) {
+        const int idx = kept + __popcll(keepmask & ((1ull << lane) - 1ull));
+        if (idx < max_det) {
+          kx1[idx] = x1; ky1[idx] = y1; kx2[idx] = x2; ky2[idx] = y2; kar[idx] = area;
+          float* o = ob + (size_t)idx * 6;
+          o[0] = rx1; o[1] = ry1; o[2] = rx2; o[3] = ry2; o[4] = score; o[5] = clsf;
+          if (keep_idx) keep_idx[(size_t)b * max_det + idx] = anchor;
+        }
+      }
+      if (lane == 0) {
+        const int nk = kept + __popcll(keepmask);
+        s_kept = nk < max_det ? nk : max_det;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) counts[b] = s_kept;
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline int pow2_ge(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+}  // namespace
+
+extern "C" size_t upa_nms_workspace_bytes(int b, int nc, int a, int multi_label, int max_nms) {
+  const size_t cap = (size_t)a * (multi_label ? nc : 1);
+  const size_t selcap = (size_t)pow2_ge(max_nms < 2 ? 2 : max_nms);
+  return 256 + align_up((size_t)b * 2 * sizeof(int), 256) + (size_t)b * cap * 8 + (size_t)b * selcap * 8;
+}
+
+extern "C" int upa_nms_batched(const float* pred, int b, int nc, int a, float conf_thres, float iou_thres, int multi_label,
+                               int agnostic, const uint8_t* classes_mask, int max_det, int max_nms, float max_wh,
+                               float* out, int32_t* counts, int32_t* keep_idx, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+  UPA_CHECK_ARG(pred && out && counts && workspace, "nms: null pointer");
+  UPA_CHECK_ARG(b > 0 && nc > 0 && a > 0, "nms: bad shape");
+  UPA_CHECK_ARG(conf_thres >= 0.f && conf_thres <= 1.f, "Invalid Confidence threshold %f, valid values are between 0.0 and 1.0",
+                conf_thres);
+  UPA_CHECK_ARG(iou_thres >= 0.f && iou_thres <= 1.f, "Invalid IoU %f, valid values are between 0.0 and 1.0", iou_thres);
+  UPA_CHECK_ARG(max_det >= 1 && max_det <= MAX_DET_CAP, "nms: max_det must be in [1, %d]", MAX_DET_CAP);
+  UPA_CHECK_ARG(max_nms >= 1 && max_nms <= (1 << 20), "nms: max_nms out of range");
+  UPA_CHECK_ARG((long)a * nc < (1L << 31), "nms: a*nc overflows the 32-bit candidate index");
+  if (workspace_bytes < upa_nms_workspace_bytes(b, nc, a, multi_label, max_nms)) {
+    upa_set_error("nms: workspace too small");
+    return UPA_EWORKSPACE;
+  }
+  multi_label = multi_label && nc > 1;  // nms.py:82
+  const long cap = (long)a * (multi_label ? nc : 1);
+  const int selcap = pow2_ge(max_nms < 2 ? 2 : max_nms);
+  char* ws = (char*)workspace;
+  ws = (char*)align_up((size_t)ws, 256);
+  int* count = (int*)ws;
+  int* nsorted = count + b;
+  ws += align_up((size_t)b * 2 * sizeof(int), 256);
+  u64* keys = (u64*)ws;
+  u64* sel = keys + (size_t)b * cap;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(count, 0, (size_t)b * 2 * sizeof(int), s) != hipSuccess) {
+    upa_set_error("nms: memset failed");
+    return UPA_ELAUNCH;
+  }
+  hipLaunchKernelGGL(nms_candidates_kernel, dim3((unsigned)cdiv(a, 256), (unsigned)b), dim3(256), 0, s, pred, b, nc, a,
+                     conf_thres, multi_label, classes_mask, count, keys, cap);
+  UPA_LAUNCH_CHECK();
+  {
+    hipError_t e = hipFuncSetAttribute((const void*)nms_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       LDS_SORT_CAP * 8);
+    if (e != hipSuccess) { upa_set_error("nms: cannot raise LDS limit: %s", hipGetErrorString(e)); return UPA_ELAUNCH; }
+  }
+  hipLaunchKernelGGL(nms_sort_kernel, dim3((unsigned)b), dim3(SORT_NT), LDS_SORT_CAP * 8, s, count, nsorted, keys, sel,
+                     cap, selcap, max_nms);
+  UPA_LAUNCH_CHECK();
+  hipLaunchKernelGGL(nms_greedy_kernel, dim3((unsigned)b), dim3(GREEDY_NT), 0, s, pred, nc, a, nsorted, sel, selcap,
+                     iou_thres, agnostic, max_wh, max_det, out, counts, keep_idx);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}

@@ -1,0 +1,174 @@
+"""Tensor plumbing between the Python operator API and the C ABI.
+
+Activations are ordinary torch tensors whose LOGICAL shape is the reference's (N, C, H, W) but whose memory is an
+NHWC "view": strides (H*W*ld, 1, W*ld, ld) with ld >= C, i.e. possibly a channel slice of a wider concat buffer.
+torch is used for allocation, streams and views only - no torch kernel touches activation data on the product path.
+"""
+
+from __future__ import annotations
+
+import contextlib
+import ctypes as C
+from dataclasses import dataclass
+
+import torch
+
+from .. import _lib as L
+
+
+@dataclass
+class View:
+    ptr: int
+    n: int
+    h: int
+    w: int
+    c: int
+    ld: int
+    dtype: int  # UPA_F32 / UPA_BF16
+
+
+def _pixel_stride(t: torch.Tensor) -> int:
+    n, c, h, w = t.shape
+    s = t.stride()
+    if w > 1:
+        return s[3]
+    if h > 1:
+        return s[2]
+    if n > 1:
+        return s[0]
+    return c
+
+
+def is_nhwc_view(t: torch.Tensor) -> bool:
+    """True iff t is logically (N, C, H, W) with strides (H*W*ld, 1, W*ld, ld), ld >= C (size-1 dims are free)."""
+    if t.dim() != 4:
+        return False
+    n, c, h, w = t.shape
+    s = t.stride()
+    ld = _pixel_stride(t)
+    return (ld >= c and (c == 1 or s[1] == 1) and (w == 1 or s[3] == ld) and (h == 1 or s[2] == w * ld)
+            and (n == 1 or s[0] == h * w * ld))
+
+
+def view_of(t: torch.Tensor) -> View:
+    """Describe an NHWC-strided logical-NCHW tensor for the C ABI (raises if the layout is anything else)."""
+    L.require_gpu(t, "view_of")
+    if getattr(t, "_upa_pad_br", 0):
+        raise L.UpaError("a ZeroPad2d-tagged tensor can only feed MaxPool2d on the HIP path")
+    if not is_nhwc_view(t):
+        raise L.UpaError(f"tensor with shape {tuple(t.shape)} strides {t.stride()} is not an NHWC view")
+    n, c, h, w = t.shape
+    return View(t.data_ptr(), n, h, w, c, _pixel_stride(t), L.dtype_code(t.dtype))
+
+
+class BufferPool:
+    """Static activation buffers keyed by call site: the second and later forwards of a model allocate nothing, which
+    is what makes the layer loop capturable into a hipGraph (no allocator calls inside the captured region)."""
+
+    def __init__(self):
+        self.buffers: dict = {}
+
+    def get(self, key, shape, dtype, device) -> torch.Tensor:
+        k = (key, tuple(shape), dtype, str(device))
+        t = self.buffers.get(k)
+        if t is None:
+            t = torch.empty(shape, dtype=dtype, device=device)
+            self.buffers[k] = t
+        return t
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.buffers.values())
+
+
+_POOL: list = [None]
+
+
+@contextlib.contextmanager
+def static_buffers(pool: BufferPool):
+    prev = _POOL[0]
+    _POOL[0] = pool
+    try:
+        yield pool
+    finally:
+        _POOL[0] = prev
+
+
+def alloc_nhwc(n: int, c: int, h: int, w: int, dtype: torch.dtype, device, key=None) -> torch.Tensor:
+    """New NHWC buffer returned as a logical (N, C, H, W) tensor."""
+    pool = _POOL[0]
+    if pool is not None and key is not None:
+        buf = pool.get(key, (n, h, w, c), dtype, device)
+    else:
+        buf = torch.empty((n, h, w, c), dtype=dtype, device=device)
+    return buf.permute(0, 3, 1, 2)
+
+
+def alloc_plain(shape, dtype, device, key=None) -> torch.Tensor:
+    pool = _POOL[0]
+    if pool is not None and key is not None:
+        return pool.get(key, tuple(shape), dtype, device)
+    return torch.empty(tuple(shape), dtype=dtype, device=device)
+
+
+def channel_slice(t: torch.Tensor, c0: int, c1: int) -> torch.Tensor:
+    """Channel sub-view [c0, c1) of an NHWC-strided tensor (pure view arithmetic)."""
+    return t[:, c0:c1]
+
+
+def to_nhwc(x: torch.Tensor, dtype: torch.dtype, key=None) -> torch.Tensor:
+    """Bring an arbitrary 4-D tensor into an NHWC view of `dtype` (HIP transpose kernel when a copy is needed)."""
+    L.require_gpu(x, "to_nhwc")
+    if is_nhwc_view(x) and x.dtype == dtype and (x.shape[1] * x.element_size()) % 16 == 0 and x.data_ptr() % 16 == 0:
+        return x
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        if is_nhwc_view(x):  # NHWC of another dtype: go through NCHW f32
+            x = to_nchw_f32(x)
+        else:
+            raise L.UpaError("to_nhwc expects a contiguous float32 NCHW tensor or an NHWC view")
+    n, c, h, w = x.shape
+    y = alloc_nhwc(n, c, h, w, dtype, x.device, key)
+    v = view_of(y)
+    L.check(L.lib().upa_nchw_to_nhwc(x.data_ptr(), n, c, h, w, v.ptr, v.ld, v.dtype, L.current_stream(x.device)),
+            "nchw_to_nhwc")
+    return y
+
+
+def to_nchw_f32(x: torch.Tensor, key=None) -> torch.Tensor:
+    """NHWC view -> contiguous float32 NCHW (the reference's tensor layout), via the HIP transpose kernel."""
+    v = view_of(x)
+    y = alloc_plain((v.n, v.c, v.h, v.w), torch.float32, x.device, key)
+    L.check(L.lib().upa_nhwc_to_nchw(v.ptr, v.n, v.h, v.w, v.c, v.ld, y.data_ptr(), v.dtype, L.current_stream(x.device)),
+            "nhwc_to_nchw")
+    return y
+
+
+class HipGraph:
+    """Capture a sequence of upa_* launches issued on the current stream and replay it (upa_graph_* in upa.h)."""
+
+    def __init__(self):
+        self.exec = C.c_void_p()
+        self.stream = None
+
+    def capture(self, fn, device=None):
+        self.stream = torch.cuda.Stream(device=device)
+        self.stream.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(self.stream):
+            s = self.stream.cuda_stream
+            L.check(L.lib().upa_graph_begin(s), "graph_begin")
+            try:
+                out = fn()
+            finally:
+                rc = L.lib().upa_graph_end(s, C.byref(self.exec))
+            L.check(rc, "graph_end")
+        torch.cuda.current_stream(device).wait_stream(self.stream)
+        return out
+
+    def replay(self, device=None):
+        L.check(L.lib().upa_graph_launch(self.exec, L.current_stream(device)), "graph_launch")
+
+    def __del__(self):
+        try:
+            if self.exec:
+                L.lib().upa_graph_destroy(self.exec)
+        except Exception:
+            pass

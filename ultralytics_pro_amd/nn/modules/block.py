@@ -1,0 +1,193 @@
+"""Block modules with the reference's operator API (ultralytics/nn/modules/block.py), composed from HIP kernels.
+
+Concatenations never copy: a block allocates its concat buffer once and every producing conv writes its channel slice
+in place (`out=` views); Bottleneck residual adds are fused in the second conv's epilogue.
+"""
+
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from ... import _lib as L
+from ...engine import runtime as R
+from .conv import Conv, _HipConvMixin, hip_conv2d
+
+__all__ = ("DFL", "SPPF", "C2f", "C3", "Bottleneck", "MHSA", "BottleneckTransformer", "BoT3")
+
+
+class DFL(nn.Module):
+    """Integral module of Distribution Focal Loss (block.py:232-253).  On the HIP path the softmax-expectation is part of
+    `upa_detect_decode`; this module only carries the arange(c1) weights for the state_dict."""
+
+    def __init__(self, c1: int = 16):
+        super().__init__()
+        self.conv = nn.Conv2d(c1, 1, 1, bias=False).requires_grad_(False)
+        self.conv.weight.data[:] = torch.arange(c1, dtype=torch.float).view(1, c1, 1, 1)
+        self.c1 = c1
+
+    def forward(self, x):
+        raise L.UpaError("DFL is fused into upa_detect_decode on the HIP path; call Detect instead")
+
+
+class Bottleneck(nn.Module):
+    """Standard bottleneck: x + cv2(cv1(x)) when shortcut and c1 == c2 (block.py:644-668)."""
+
+    def __init__(self, c1, c2, shortcut=True, g=1, k=(3, 3), e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = Conv(c1, c_, k[0], 1)
+        self.cv2 = Conv(c_, c2, k[1], 1, g=g)
+        self.add = shortcut and c1 == c2
+
+    def forward(self, x, out=None):
+        x = R.to_nhwc(x, x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.float32)
+        return self.cv2(self.cv1(x), out=out, residual=x if self.add else None)
+
+
+class C2f(nn.Module):
+    """CSP bottleneck with 2 convolutions (block.py:457-488): cv1 -> chunk(2) -> n chained Bottlenecks -> cat -> cv2.
+    One (2+n)c-channel buffer: cv1 fills [0,2c), bottleneck i reads slice [(1+i)c,(2+i)c) and writes [(2+i)c,(3+i)c)."""
+
+    def __init__(self, c1, c2, n=1, shortcut=False, g=1, e=0.5):
+        super().__init__()
+        self.c = int(c2 * e)
+        self.cv1 = Conv(c1, 2 * self.c, 1, 1)
+        self.cv2 = Conv((2 + n) * self.c, c2, 1)
+        self.m = nn.ModuleList(Bottleneck(self.c, self.c, shortcut, g, k=((3, 3), (3, 3)), e=1.0) for _ in range(n))
+
+    def forward(self, x, out=None):
+        x = R.to_nhwc(x, x.dtype)
+        n, _, h, w = x.shape
+        c, nb = self.c, len(self.m)
+        cat = R.alloc_nhwc(n, (2 + nb) * c, h, w, x.dtype, x.device, key=(id(self), "cat"))
+        self.cv1(x, out=cat[:, : 2 * c])
+        for i, m in enumerate(self.m):
+            m(cat[:, (1 + i) * c: (2 + i) * c], out=cat[:, (2 + i) * c: (3 + i) * c])
+        return self.cv2(cat, out=out)
+
+
+class C3(nn.Module):
+    """CSP bottleneck with 3 convolutions (block.py:509-532): cv3(cat(m(cv1(x)), cv2(x)))."""
+
+    def __init__(self, c1, c2, n=1, shortcut=True, g=1, e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c1, c_, 1, 1)
+        self.cv3 = Conv(2 * c_, c2, 1)
+        self.m = nn.Sequential(*(Bottleneck(c_, c_, shortcut, g, k=((1, 1), (3, 3)), e=1.0) for _ in range(n)))
+
+    def forward(self, x, out=None):
+        x = R.to_nhwc(x, x.dtype)
+        n, _, h, w = x.shape
+        c_ = self.cv1.conv.out_channels
+        cat = R.alloc_nhwc(n, 2 * c_, h, w, x.dtype, x.device, key=(id(self), "cat"))
+        self.cv2(x, out=cat[:, c_:])
+        y = self.cv1(x) if len(self.m) else self.cv1(x, out=cat[:, :c_])
+        for i, m in enumerate(self.m):
+            y = m(y, out=cat[:, :c_] if i == len(self.m) - 1 else None)
+        return self.cv3(cat, out=out)
+
+
+class SPPF(nn.Module):
+    """Spatial Pyramid Pooling - Fast (block.py:382-406): cv1 -> 3 chained MaxPool2d(5,1,2) -> cat 4 -> cv2.
+    The three pools are one kernel (5/9/13 windows of the cv1 output) writing straight into the concat buffer."""
+
+    def __init__(self, c1, c2, k=5):
+        super().__init__()
+        c_ = c1 // 2
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c_ * 4, c2, 1, 1)
+        self.m = nn.MaxPool2d(kernel_size=k, stride=1, padding=k // 2)
+
+    def forward(self, x, out=None):
+        if self.m.kernel_size != 5:
+            raise L.UpaError("HIP SPPF implements k=5 (every reference YAML on the hot path)")
+        x = R.to_nhwc(x, x.dtype)
+        n, _, h, w = x.shape
+        c_ = self.cv1.conv.out_channels
+        cat = R.alloc_nhwc(n, 4 * c_, h, w, x.dtype, x.device, key=(id(self), "cat"))
+        self.cv1(x, out=cat[:, :c_])
+        v = R.view_of(cat[:, :c_])
+        ptr = lambda i: R.view_of(cat[:, i * c_: (i + 1) * c_]).ptr  # noqa: E731
+        L.check(L.lib().upa_sppf_pool3(v.ptr, v.n, v.h, v.w, v.c, v.ld, ptr(1), ptr(2), ptr(3), v.ld, v.dtype,
+                                       L.current_stream(x.device)), "sppf_pool3")
+        return self.cv2(cat, out=out)
+
+
+class MHSA(nn.Module, _HipConvMixin):
+    """Multi-head self attention over a feature map (block.py:6020-6062): q,k,v 1x1 convs with bias, energy = q^T k
+    (unscaled), softmax over keys, out = v.attn^T, `view` back with (W,H) reinterpretation."""
+
+    def __init__(self, n_dims, width=14, height=14, heads=4, pos_emb=False):
+        super().__init__()
+        if pos_emb:
+            raise L.UpaError("MHSA(pos_emb=True) is not used on the hot path (block.py:6078) and is not implemented")
+        self.heads = heads
+        self.query = nn.Conv2d(n_dims, n_dims, kernel_size=1)
+        self.key = nn.Conv2d(n_dims, n_dims, kernel_size=1)
+        self.value = nn.Conv2d(n_dims, n_dims, kernel_size=1)
+        self.pos = pos_emb
+        self.softmax = nn.Softmax(dim=-1)
+
+    def forward(self, x, out=None, residual=None):
+        x = R.to_nhwc(x, x.dtype)
+        n, c, h, w = x.shape
+        qkv = R.alloc_nhwc(n, 3 * c, h, w, x.dtype, x.device, key=(id(self), "qkv"))
+        for i, conv in enumerate((self.query, self.key, self.value)):
+            pk = self._packed(conv, None, x.device, x.dtype, False)
+            hip_conv2d(x, pk, 1, 0, L.ACT_NONE, out=qkv[:, i * c: (i + 1) * c])
+        y = out if out is not None else R.alloc_nhwc(n, c, h, w, x.dtype, x.device, key=(id(self), "y"))
+        vq, vy = R.view_of(qkv[:, :c]), R.view_of(y)
+        rp, rld = (None, 0)
+        if residual is not None:
+            vr = R.view_of(residual)
+            rp, rld = vr.ptr, vr.ld
+        esz = x.element_size()
+        L.check(L.lib().upa_mhsa(vq.ptr, vq.ptr + c * esz, vq.ptr + 2 * c * esz, vq.ld, n, h * w, self.heads,
+                                 c // self.heads, rp, rld, vy.ptr, vy.ld, vq.dtype, L.current_stream(x.device)), "mhsa")
+        return y
+
+
+class BottleneckTransformer(nn.Module):
+    """x + MHSA(cv1(x)) (block.py:6065-6092); `fc1` is a dead parameter kept for the state_dict (:6088)."""
+
+    def __init__(self, c1, c2, stride=1, heads=4, mhsa=True, resolution=None, expansion=1):
+        super().__init__()
+        if not mhsa or stride != 1 or c1 != expansion * c2:
+            raise L.UpaError("BottleneckTransformer: only the BoT3 configuration (mhsa, stride 1, c1 == c2) is built")
+        c_ = int(c2 * expansion)
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = nn.Sequential(MHSA(c2, width=int(resolution[0]), height=int(resolution[1]), heads=heads))
+        self.shortcut = c1 == c2
+        self.fc1 = nn.Linear(c2, c2)
+
+    def forward(self, x, out=None):
+        x = R.to_nhwc(x, x.dtype)
+        return self.cv2[0](self.cv1(x), out=out, residual=x if self.shortcut else None)
+
+
+class BoT3(nn.Module):
+    """CSP bottleneck whose inner blocks are BottleneckTransformers (block.py:6095-6109)."""
+
+    def __init__(self, c1, c2, n=1, e=0.5, e2=1, w=20, h=20):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c1, c_, 1, 1)
+        self.cv3 = Conv(2 * c_, c2, 1)
+        self.m = nn.Sequential(
+            *[BottleneckTransformer(c_, c_, stride=1, heads=4, mhsa=True, resolution=(w, h), expansion=e2)
+              for _ in range(n)])
+
+    def forward(self, x, out=None):
+        x = R.to_nhwc(x, x.dtype)
+        n, _, h, w = x.shape
+        c_ = self.cv1.conv.out_channels
+        cat = R.alloc_nhwc(n, 2 * c_, h, w, x.dtype, x.device, key=(id(self), "cat"))
+        self.cv2(x, out=cat[:, c_:])
+        y = self.cv1(x)
+        for i, m in enumerate(self.m):
+            y = m(y, out=cat[:, :c_] if i == len(self.m) - 1 else None)
+        return self.cv3(cat, out=out)

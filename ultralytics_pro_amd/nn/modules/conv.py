@@ -1,0 +1,191 @@
+"""Convolution modules with the reference's operator API (ultralytics/nn/modules/conv.py), dispatching into HIP.
+
+`Conv(c1, c2, k, s, p, g, d, act)` keeps the reference constructor, attribute names (`conv`, `bn`, `act`) and therefore
+state_dict keys (conv.py:147-197).  The nn.Conv2d / nn.BatchNorm2d children are parameter containers only: `forward`
+folds BN (utils/torch_utils.py:236-266), packs the weights once per dtype into MFMA fragment order and calls
+`upa_conv2d_bias_act` / `upa_conv2d_stem_nchw`.  There is no torch fallback: CPU tensors raise.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from ... import _lib as L
+from ...engine import runtime as R
+
+__all__ = ("autopad", "Conv", "Concat", "hip_conv2d", "PackedConv")
+
+
+def autopad(k, p=None, d=1):
+    """Pad to 'same' shape outputs (conv.py:64-70)."""
+    if d > 1:
+        k = d * (k - 1) + 1 if isinstance(k, int) else [d * (x - 1) + 1 for x in k]
+    if p is None:
+        p = k // 2 if isinstance(k, int) else [x // 2 for x in k]
+    return p
+
+
+def fold_bn(conv: nn.Conv2d, bn: nn.BatchNorm2d | None):
+    """(W', b') of utils/torch_utils.py:236-266 in the same operation order, as float32 CPU tensors."""
+    w = conv.weight.detach().float().cpu()
+    b = None if conv.bias is None else conv.bias.detach().float().cpu()
+    if bn is None:
+        return w, (torch.zeros(w.shape[0]) if b is None else b)
+    g, beta = bn.weight.detach().float().cpu(), bn.bias.detach().float().cpu()
+    mu, var = bn.running_mean.detach().float().cpu(), bn.running_var.detach().float().cpu()
+    w_bn = torch.diag(g.div(torch.sqrt(bn.eps + var)))
+    wf = torch.mm(w_bn, w.view(w.shape[0], -1)).view(w.shape)
+    b_conv = torch.zeros(w.shape[0]) if b is None else b
+    bf = torch.mm(w_bn, b_conv.reshape(-1, 1)).reshape(-1) + (beta - g.mul(mu).div(torch.sqrt(var + bn.eps)))
+    return wf, bf
+
+
+class PackedConv:
+    """Device-resident packed weights of one conv for one dtype."""
+
+    def __init__(self, w: torch.Tensor, b: torch.Tensor, k: int, device, dtype: torch.dtype, stem: bool):
+        self.cout, self.cin, self.k = int(w.shape[0]), int(w.shape[1]), k
+        self.bias = b.contiguous().to(device)
+        self.stem = stem
+        if stem:  # first layer reads NCHW directly and keeps f32 OIHW weights
+            self.w = w.contiguous().to(device)
+            return
+        code = L.dtype_code(dtype)
+        nbytes = L.lib().upa_conv_packed_weight_bytes(self.cout, self.cin, k, code)
+        host = torch.empty(nbytes, dtype=torch.uint8)
+        wc = w.contiguous()
+        L.check(L.lib().upa_pack_conv_weight(wc.data_ptr(), self.cout, self.cin, k, code, host.data_ptr()), "pack_conv")
+        self.w = host.to(device)
+
+
+def hip_conv2d(x: torch.Tensor, pk: PackedConv, stride: int, pad: int, act: int, out: torch.Tensor | None = None,
+               residual: torch.Tensor | None = None, out_dtype: torch.dtype | None = None, key=None) -> torch.Tensor:
+    """y = act(conv(x) + b) (+ residual) on the HIP path. x: NHWC view, or raw NCHW model input when pk.stem."""
+    L.require_gpu(x, "conv2d")
+    lib = L.lib()
+    stream = L.current_stream(x.device)
+    if pk.stem:
+        if not (x.is_contiguous() and x.dtype in (torch.float32, torch.bfloat16)):
+            raise L.UpaError("first-layer input must be a contiguous NCHW float32/bfloat16 tensor")
+        n, cin, h, w = x.shape
+        odt = out_dtype or x.dtype
+        oh, ow = (h + 2 * pad - pk.k) // stride + 1, (w + 2 * pad - pk.k) // stride + 1
+        y = out if out is not None else R.alloc_nhwc(n, pk.cout, oh, ow, odt, x.device, key)
+        vy = R.view_of(y)
+        L.check(lib.upa_conv2d_stem_nchw(x.data_ptr(), L.dtype_code(x.dtype), n, cin, h, w, pk.w.data_ptr(),
+                                         pk.bias.data_ptr(), vy.ptr, pk.cout, vy.ld, pk.k, stride, pad, act, vy.dtype,
+                                         stream), "conv2d_stem")
+        return y
+    vx = R.view_of(x)
+    oh, ow = (vx.h + 2 * pad - pk.k) // stride + 1, (vx.w + 2 * pad - pk.k) // stride + 1
+    y = out if out is not None else R.alloc_nhwc(vx.n, pk.cout, oh, ow, x.dtype, x.device, key)
+    vy = R.view_of(y)
+    if vy.dtype != vx.dtype or (vy.n, vy.h, vy.w, vy.c) != (vx.n, oh, ow, pk.cout):
+        raise L.UpaError(f"conv2d: bad output view {tuple(y.shape)} for input {tuple(x.shape)}")
+    rp, rld = None, 0
+    if residual is not None:
+        vr = R.view_of(residual)
+        if (vr.n, vr.h, vr.w, vr.c, vr.dtype) != (vy.n, vy.h, vy.w, vy.c, vy.dtype):
+            raise L.UpaError("conv2d: residual shape/dtype mismatch")
+        rp, rld = vr.ptr, vr.ld
+    L.check(lib.upa_conv2d_bias_act(vx.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, pk.w.data_ptr(), pk.bias.data_ptr(), vy.ptr,
+                                    pk.cout, vy.ld, rp, rld, pk.k, stride, pad, act, vx.dtype, stream), "conv2d")
+    return y
+
+
+class _HipConvMixin:
+    """Lazily folded / packed weights, cached per (device, dtype); invalidated by train() / load_state_dict()."""
+
+    def _packed(self, conv: nn.Conv2d, bn, device, dtype, stem: bool) -> PackedConv:
+        cache = self.__dict__.setdefault("_pk_cache", {})
+        key = (id(conv), str(device), dtype, stem)
+        pk = cache.get(key)
+        if pk is None:
+            k = conv.kernel_size[0]
+            if conv.kernel_size[0] != conv.kernel_size[1] or conv.groups != 1 or conv.dilation != (1, 1) or \
+                    conv.stride[0] != conv.stride[1] or conv.padding[0] != conv.padding[1]:
+                raise L.UpaError(f"HIP conv supports square kernels, groups=1, dilation=1 only, got {conv}")
+            w, b = fold_bn(conv, bn)
+            pk = PackedConv(w, b, k, device, dtype, stem)
+            cache[key] = pk
+        return pk
+
+    def invalidate_packed(self):
+        self.__dict__.pop("_pk_cache", None)
+
+
+def _is_model_input(x: torch.Tensor, cin: int) -> bool:
+    """A raw NCHW image batch (<= 4 channels, contiguous): handled by the stem kernel."""
+    return cin <= 4 and x.dim() == 4 and x.is_contiguous() and (x.shape[2] > 1 or x.shape[3] > 1)
+
+
+class Conv(nn.Module, _HipConvMixin):
+    """Standard convolution: conv2d(bias=False) -> BatchNorm2d -> SiLU (conv.py:147-197)."""
+
+    default_act = nn.SiLU()  # default activation
+
+    def __init__(self, c1, c2, k=1, s=1, p=None, g=1, d=1, act=True):
+        super().__init__()
+        self.conv = nn.Conv2d(c1, c2, k, s, autopad(k, p, d), groups=g, dilation=d, bias=False)
+        self.bn = nn.BatchNorm2d(c2)
+        self.act = self.default_act if act is True else act if isinstance(act, nn.Module) else nn.Identity()
+        self.compute_dtype = None  # set by the model for the first layer (stem output dtype)
+
+    def _act_code(self) -> int:
+        if isinstance(self.act, nn.SiLU):
+            return L.ACT_SILU
+        if isinstance(self.act, nn.ReLU):
+            return L.ACT_RELU
+        if isinstance(self.act, nn.Identity):
+            return L.ACT_NONE
+        raise L.UpaError(f"activation {self.act} has no HIP epilogue")
+
+    def forward(self, x, out=None, residual=None):
+        """act(bn(conv(x))) with BN folded into the HIP conv epilogue (conv.py:177-197 compute the same function)."""
+        if self.training:
+            raise L.UpaError("training-mode Conv (batch-statistics BN) is not on the HIP path yet (SURVEY §8f rank 2)")
+        stem = _is_model_input(x, self.conv.in_channels)
+        dt = (self.compute_dtype or x.dtype) if stem else x.dtype
+        pk = self._packed(self.conv, getattr(self, "bn", None), x.device, dt, stem)
+        return hip_conv2d(x, pk, self.conv.stride[0], self.conv.padding[0], self._act_code(), out=out, residual=residual,
+                          out_dtype=dt, key=(id(self), "y"))
+
+    forward_fuse = forward  # BN is always folded on the HIP path (tasks.py:1134 rebinding is a no-op here)
+
+    def train(self, mode: bool = True):
+        self.invalidate_packed()
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *a, **k):
+        self.invalidate_packed()
+        return super()._load_from_state_dict(*a, **k)
+
+
+class Concat(nn.Module):
+    """Concatenate a list of tensors along `dimension` (conv.py:850-875): channel-slice copies into one NHWC buffer.
+    (Inside a planned model the producers write into the slices directly and no copy is launched.)"""
+
+    def __init__(self, dimension=1):
+        super().__init__()
+        self.d = dimension
+
+    def forward(self, x):
+        if self.d != 1:
+            raise L.UpaError("HIP Concat supports the channel dimension only")
+        xs = list(x)
+        n, _, h, w = xs[0].shape
+        ctot = sum(int(t.shape[1]) for t in xs)
+        y = R.alloc_nhwc(n, ctot, h, w, xs[0].dtype, xs[0].device, key=(id(self), "y"))
+        c0 = 0
+        for t in xs:
+            c = int(t.shape[1])
+            dst = y[:, c0:c0 + c]
+            if not (t.data_ptr() == dst.data_ptr() and t.stride() == dst.stride()):
+                vs, vd = R.view_of(t), R.view_of(dst)
+                L.check(L.lib().upa_copy_view(vs.ptr, vs.n, vs.h, vs.w, vs.c, vs.ld, vd.ptr, vd.ld, vs.dtype,
+                                              L.current_stream(t.device)), "copy_view")
+            c0 += c
+        return y

@@ -1,0 +1,256 @@
+"""Graph builder and layer executor with the reference's API (ultralytics/nn/tasks.py): `parse_model` resolves YAML rows
+by class NAME (tasks.py:2836-2842) to the HIP operator library, `BaseModel._predict_once` is the layer loop
+(:1046-1085).  `DetectionModel.compile()` walks that loop once under hipGraph capture with static buffers and replays
+it per batch - HIP graphs instead of a tracing compiler.
+"""
+
+from __future__ import annotations
+
+import ast
+import contextlib
+import math
+import re
+from copy import deepcopy
+from pathlib import Path
+
+import torch
+import torch.nn as nn
+import yaml
+
+from .. import _lib as L
+from ..engine import runtime as R
+from .modules import (C2f, C3, SPPF, BoT3, Bottleneck, Concat, Conv, Detect)
+from .modules.resample import MaxPool2d, Upsample, ZeroPad2d
+
+CFG_DIR = Path(__file__).resolve().parents[1] / "cfg" / "models"
+
+_NN_STANDINS = {"Upsample": Upsample, "MaxPool2d": MaxPool2d, "ZeroPad2d": ZeroPad2d}
+
+
+def _registry():
+    reg = {m.__name__: m for m in (Conv, C2f, C3, SPPF, BoT3, Bottleneck, Concat, Detect)}
+    try:
+        from .modules.rtdetr import RTDETRDecoder
+        reg["RTDETRDecoder"] = RTDETRDecoder
+    except ImportError:
+        pass
+    return reg
+
+
+BASE_MODULES = {"Conv", "C2f", "C3", "SPPF", "BoT3", "Bottleneck"}  # subset of base_modules, tasks.py:2446-2710
+REPEAT_MODULES = {"C2f", "C3"}  # subset of repeat_modules (BoT3 is not one: SURVEY §8a row 15)
+
+
+def make_divisible(x, divisor):
+    """Nearest multiple of divisor not below x (utils/ops.py:137-150)."""
+    return math.ceil(x / divisor) * divisor
+
+
+def yaml_model_load(path):
+    """Load a model YAML; 'yolov8n.yaml' resolves to yolov8.yaml with scale 'n' (tasks.py:3147-3185)."""
+    path = Path(path)
+    stem, scale = path.stem, ""
+    m = re.match(r"^(yolo(?:v)?\d+)([nslmx])$", stem)
+    if m:
+        stem, scale = m.group(1), m.group(2)
+    cands = [path] if path.is_file() else sorted(CFG_DIR.rglob(stem + ".yaml"))
+    if not cands:
+        raise FileNotFoundError(f"model YAML '{path}' not found under {CFG_DIR}")
+    d = yaml.safe_load(cands[0].read_text())
+    d["scale"] = scale
+    d["yaml_file"] = str(path)
+    return d
+
+
+def parse_model(d, ch, verbose=False):
+    """Parse a YOLO model.yaml dictionary into an nn.Sequential of HIP modules + sorted save list (tasks.py:2409-3146)."""
+    d = deepcopy(d)
+    reg = _registry()
+    legacy = True  # v3/v5/v8 YAMLs never flip it (tasks.py:2424)
+    max_channels = float("inf")
+    nc, scales = d.get("nc"), d.get("scales")
+    depth, width = d.get("depth_multiple", 1.0), d.get("width_multiple", 1.0)
+    scale = d.get("scale")
+    if scales:
+        if not scale:
+            scale = next(iter(scales.keys()))  # "no model scale passed. Assuming scale='n'" (tasks.py:2430-2433)
+        depth, width, max_channels = scales[scale][:3]
+    ch = [ch]
+    layers, save, c2 = [], [], ch[-1]
+    for i, (f, n, mname, args) in enumerate(d["backbone"] + d["head"]):
+        if mname.startswith("nn."):
+            if mname[3:] not in _NN_STANDINS:
+                raise L.UpaError(f"'{mname}' has no HIP implementation (supported: {sorted(_NN_STANDINS)})")
+            m = _NN_STANDINS[mname[3:]]
+        elif mname in reg:
+            m = reg[mname]
+        else:
+            raise L.UpaError(f"module '{mname}' is outside the hot-path operator set {sorted(reg)} (SURVEY §2)")
+        args = list(args)
+        for j, a in enumerate(args):
+            if isinstance(a, str):
+                with contextlib.suppress(ValueError):
+                    args[j] = nc if a == "nc" else ast.literal_eval(a)
+        n = n_ = max(round(n * depth), 1) if n > 1 else n
+        if mname in BASE_MODULES:
+            c1, c2 = ch[f], args[0]
+            if c2 != nc:
+                c2 = make_divisible(min(c2, max_channels) * width, 8)
+            args = [c1, c2, *args[1:]]
+            if mname in REPEAT_MODULES:
+                args.insert(2, n)
+                n = 1
+        elif mname == "Concat":
+            c2 = sum(ch[x] for x in f)
+        elif mname == "Detect":
+            args.append([ch[x] for x in f])
+            m.legacy = legacy
+        elif mname == "RTDETRDecoder":
+            args.insert(1, [ch[x] for x in f])
+        else:
+            c2 = ch[f]
+        m_ = HipSequential(*(m(*args) for _ in range(n))) if n > 1 else m(*args)
+        t = f"{m.__module__}.{m.__name__}"
+        m.np = sum(x.numel() for x in m_.parameters())
+        m_.np = m.np
+        m_.i, m_.f, m_.type = i, f, t
+        if verbose:
+            print(f"{i:>3}{f!s:>20}{n_:>3}{m_.np:10.0f}  {t:<45}{args!s:<30}")
+        save.extend(x % i for x in ([f] if isinstance(f, int) else f) if x != -1)
+        layers.append(m_)
+        if i == 0:
+            ch = []
+        ch.append(c2)
+    return nn.Sequential(*layers), sorted(save)
+
+
+class HipSequential(nn.Sequential):
+    """n > 1 repeats of a module (tasks.py:3113); the last repeat may write into a caller-provided view."""
+
+    def forward(self, x, out=None):
+        mods = list(self)
+        for j, m in enumerate(mods):
+            x = m(x, out=out) if (j == len(mods) - 1 and out is not None) else m(x)
+        return x
+
+
+class BaseModel(nn.Module):
+    """Base class: forward -> predict -> _predict_once (tasks.py:987-1134)."""
+
+    def forward(self, x, *args, **kwargs):
+        if isinstance(x, dict):
+            raise L.UpaError("training / loss forward is not on the HIP path yet (SURVEY §8f rank 2)")
+        return self.predict(x, *args, **kwargs)
+
+    def predict(self, x, profile=False, visualize=False, augment=False, embed=None):
+        if augment or visualize or embed is not None or profile:
+            raise L.UpaError("augment / visualize / embed / profile are outside the hot-path scope")
+        return self._predict_once(x)
+
+    def _predict_once(self, x):
+        """The layer loop: route `m.f`, run, save if in `save` (tasks.py:1046-1085)."""
+        y = []
+        for m in self.model:
+            if m.f != -1:
+                x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
+            x = m(x)
+            y.append(x if m.i in self.save else None)
+        return x
+
+    def fuse(self, verbose=True):
+        """BN folding happens inside the HIP conv weights packing; kept for API parity (tasks.py:1120-1134)."""
+        self._fused = True
+        return self
+
+    def is_fused(self, thresh=10):
+        return bool(getattr(self, "_fused", False))
+
+    # ---- compute dtype (the reference's `.half()`, autobackend.py:216: here bf16 storage / f32 accumulate) -----------
+    def set_compute_dtype(self, dtype: torch.dtype):
+        L.dtype_code(dtype)
+        first = self.model[0]
+        for m in first.modules():
+            if isinstance(m, Conv):
+                m.compute_dtype = dtype
+                break
+        self.compute_dtype = dtype
+        self._graphs = {}
+        return self
+
+    # ---- hipGraph replay -----------------------------------------------------------------------------------------------
+    def compile(self, example: torch.Tensor, post=None):
+        """Capture `_predict_once(example)` (plus an optional post-processing callable) into a hipGraph.
+
+        Returns a callable `run(x)`: copies nothing - `x` must be the SAME tensor object / storage as `example`
+        (inputs already resident, as in a serving loop that writes frames into a fixed buffer)."""
+        L.require_gpu(example, "compile")
+        pool = R.BufferPool()
+
+        def body():
+            out = self._predict_once(example)
+            return post(out) if post is not None else out
+
+        with torch.no_grad(), R.static_buffers(pool):
+            body()  # warm-up: allocates every static buffer, packs weights, sets LDS attributes
+            torch.cuda.synchronize(example.device)
+            graph = R.HipGraph()
+            result = graph.capture(body, device=example.device)
+        torch.cuda.synchronize(example.device)
+
+        def run():
+            graph.replay(example.device)
+            return result
+
+        run.graph, run.pool, run.result = graph, pool, result
+        return run
+
+
+class DetectionModel(BaseModel):
+    """YOLO detection model (tasks.py:1256-1340)."""
+
+    def __init__(self, cfg="yolov8n.yaml", ch=3, nc=None, verbose=False):
+        super().__init__()
+        self.yaml = cfg if isinstance(cfg, dict) else yaml_model_load(cfg)
+        if nc and nc != self.yaml["nc"]:
+            self.yaml["nc"] = nc
+        self.model, self.save = parse_model(deepcopy(self.yaml), ch=ch, verbose=verbose)
+        self.names = {i: f"{i}" for i in range(self.yaml["nc"])}
+        self.inplace = self.yaml.get("inplace", True)
+        self.end2end = False
+        self.compute_dtype = torch.float32
+        m = self.model[-1]
+        if isinstance(m, Detect):
+            # The reference discovers strides with a 256x256 zero-image forward (tasks.py:1315-1331); the HIP build has
+            # no CPU forward, so the same numbers come from the static shape walk of the graph.
+            m.stride = torch.tensor([float(s) for s in self._infer_strides(ch)])
+            self.stride = m.stride
+            m.bias_init()
+        else:
+            self.stride = torch.Tensor([32])
+        for mod in self.modules():  # initialize_weights (utils/torch_utils.py:463-473)
+            if isinstance(mod, nn.BatchNorm2d):
+                mod.eps = 1e-3
+                mod.momentum = 0.03
+        self.eval()
+
+    def _infer_strides(self, ch=None):
+        """Down-sampling factor of every Detect input from the layer strides (no tensors involved)."""
+        scale = []
+        for m in self.model:
+            f = m.f
+            if isinstance(m, Detect):
+                return [scale[j] for j in f]
+            fin = f if isinstance(f, int) else f[0]
+            s = (scale[-1] if scale else 1.0) if fin == -1 else scale[fin]
+            for mm in (list(m) if isinstance(m, HipSequential) else [m]):
+                if isinstance(mm, Conv):
+                    s *= mm.conv.stride[0]
+                elif isinstance(mm, MaxPool2d):
+                    s *= mm.stride
+                elif isinstance(mm, Upsample):
+                    s /= 2
+            scale.append(s)
+        return [32.0]
+
+
+RTDETRDetectionModel = DetectionModel  # eval path differs only in the head module (tasks.py:1608)
