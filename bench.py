@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""bench.py - headline metric of BASELINE.json: images/sec/GPU, YOLOv8n 640x640 bs=32, forward + Detect decode + NMS.
+
+  python bench.py --gpus N --steps K --warmup W [--dtype bf16|f32] [--batch 32]
+  (N > 1: launched by torch.distributed.run, one rank per GPU; batch-sharded replicas, no data-path collective)
+
+A "step" = one pass of the hot path over one batch of 32 synthetic images already resident in HBM:
+model forward (stem + 63 implicit-GEMM convs + SPPF/upsample kernels) -> Detect decode -> batched NMS
+(conf 0.25, iou 0.7, max_det 300: the predict defaults), replayed as ONE hipGraph.
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, timed live with HIP events) and `cpu_baseline`
+(the oracle on this host's cores, bounded sample).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+import torch  # noqa: E402
+
+GFLOP_PER_IMG = 8.744  # yolov8n @640, 2*MAC over all 64 Conv2d
+PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16 (MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3  # MFMA f32
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--model", default="yolov8n")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-threads", type=int, default=32)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+
+    from ultralytics_pro_amd import _lib as L
+    from ultralytics_pro_amd.nn.modules import conv as pconv
+    from ultralytics_pro_amd.nn.tasks import DetectionModel
+    from ultralytics_pro_amd.utils import procedural as P
+    from ultralytics_pro_amd.utils.nms import nms_raw
+
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model = DetectionModel(args.model + ".yaml")
+    P.apply_procedural_weights(model)
+    model = model.to(dev).eval()
+    model.set_compute_dtype(dtype)
+    # per-rank shard of the global batch: images [rank*B, (rank+1)*B) of the procedural stream
+    x = P.synthetic_images(args.batch, first=rank * args.batch).to(dev)
+    if dtype == torch.bfloat16:
+        x = x.to(torch.bfloat16)  # the reference's `im.half()` for a half model (predictor.py:151-173)
+    x = x.contiguous()
+
+    def post(o):
+        return nms_raw(o[0], 0.25, 0.7, max_det=300, key="bench")
+
+    with torch.no_grad():
+        run = model.compile(x, post=post)
+        for _ in range(args.warmup):
+            run()
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = args.batch * world * args.steps / dt
+    out, counts, _ = run.result
+    ndet = counts.tolist()
+
+    roofline, kernels, cpu_baseline = None, None, None
+    if rank == 0:
+        roofline, kernels = kernel_profile(model, x, dtype, dev, args, pconv, L, post)
+        if not args.no_cpu_baseline:
+            cpu_baseline = run_cpu_baseline(args)
+    if rank == 0:
+        line = {
+            "metric": "images/sec/GPU YOLOv8n 640x640 bs=32 (forward + Detect decode + NMS)",
+            "value": round(value, 1),
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic (procedural images + procedural weights, resident in HBM)",
+            "config": {"workload": f"{args.model} detect 640x640 bs={args.batch} {args.dtype} inference, 1 hipGraph/step: "
+                                   "forward+decode+NMS(conf .25, iou .7, max_det 300)",
+                       "global_batch": args.batch * world, "per_gpu_batch": args.batch, "parallelism": f"dp{world} replicas"},
+            "images_per_sec_per_gpu": round(value / world, 1),
+            "detections_per_image_mean": round(sum(ndet) / max(1, len(ndet)), 1),
+            "model_tflops": round(value / world * GFLOP_PER_IMG / 1e3, 2),
+            "roofline": roofline,
+            "kernels": kernels,
+            "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def kernel_profile(model, x, dtype, dev, args, pconv, L, post, iters=5):
+    """Per-kernel-family device time of one step, measured live with HIP events on the launch stream (eager replay of the
+    same launch sequence), and the roofline of the dominant kernel instantiation."""
+    code = L.dtype_code(dtype)
+    es = 2 if code == L.UPA_BF16 else 4
+    records = []  # (family, flops, bytes, start_event, end_event)
+    orig = pconv.hip_conv2d
+
+    def timed_conv(xx, pk, stride, pad, act, out=None, residual=None, out_dtype=None, key=None):
+        if pk.stem:
+            n, cin, h, w = xx.shape
+            fam = "stem_conv_kernel"
+        else:
+            n, cin, h, w = xx.shape
+            var = L.lib().upa_conv_variant(n, h, w, cin, pk.cout, pk.k, stride, pad, code)
+            fam = "conv_igemm_kernel<%s,%d,%d,%d,%d>" % ("bf16" if es == 2 else "f32", (var >> 12) & 15, (var >> 8) & 15,
+                                                         (var >> 4) & 15, var & 15)
+        oh, ow = (h + 2 * pad - pk.k) // stride + 1, (w + 2 * pad - pk.k) // stride + 1
+        flops = 2.0 * n * oh * ow * pk.cout * cin * pk.k * pk.k
+        in_es = xx.element_size()
+        nbytes = n * h * w * cin * in_es + n * oh * ow * pk.cout * es + pk.cout * cin * pk.k * pk.k * es
+        if residual is not None:
+            nbytes += n * oh * ow * pk.cout * es
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = orig(xx, pk, stride, pad, act, out=out, residual=residual, out_dtype=out_dtype, key=key)
+        e1.record()
+        records.append((fam, flops, nbytes, e0, e1))
+        return y
+
+    from ultralytics_pro_amd.engine import runtime as R
+    from ultralytics_pro_amd.nn.modules import block as pblock
+    from ultralytics_pro_amd.nn.modules import head as phead
+
+    step_ms = []
+    pool = R.BufferPool()
+    mods = (pconv, pblock, phead)
+    try:
+        for m in mods:
+            m.hip_conv2d = timed_conv
+        with torch.no_grad(), R.static_buffers(pool):
+            for it in range(iters + 1):
+                records.clear()
+                s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s0.record()
+                o = model._predict_once(x)
+                post(o)
+                s1.record()
+                torch.cuda.synchronize(dev)
+                if it > 0:
+                    step_ms.append(s0.elapsed_time(s1))
+                    last = [(f, fl, nb, a.elapsed_time(b)) for f, fl, nb, a, b in records]
+    finally:
+        for m in mods:
+            m.hip_conv2d = orig
+    fam = {}
+    for f, fl, nb, ms in last:
+        d = fam.setdefault(f, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+        d["launches"] += 1
+        d["ms"] += ms
+        d["flops"] += fl
+        d["bytes"] += nb
+    conv_ms = sum(d["ms"] for d in fam.values())
+    dom_name, dom = max(fam.items(), key=lambda kv: kv[1]["ms"])
+    peak = PEAK_BF16_TFLOPS if es == 2 else PEAK_F32_TFLOPS
+    achieved_tf = dom["flops"] / dom["launches"] / (dom["ms"] / dom["launches"] * 1e-3) / 1e12
+    achieved_gbs = dom["bytes"] / dom["launches"] / (dom["ms"] / dom["launches"] * 1e-3) / 1e9
+    # which roof binds this kernel: algorithmic intensity vs machine balance
+    ai = dom["flops"] / dom["bytes"]
+    bound = "mfma" if ai > peak * 1e12 / (PEAK_HBM_GBS * 1e9) else "hbm"
+    roofline = {
+        "kernel": dom_name,
+        "bound": bound,
+        "achieved": round(achieved_tf if bound == "mfma" else achieved_gbs, 2),
+        "peak": peak if bound == "mfma" else PEAK_HBM_GBS,
+        "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+        "frac": round((achieved_tf / peak) if bound == "mfma" else (achieved_gbs / PEAK_HBM_GBS), 4),
+        "traffic": None,
+        "launches_per_step": dom["launches"],
+        "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 2),
+        "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
+        "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
+        "flop_per_byte": round(ai, 1),
+        "achieved_tflops": round(achieved_tf, 2),
+        "achieved_gbs": round(achieved_gbs, 1),
+        "timing": "HIP events around each launch on the launch stream, eager replay, mean of last pass",
+    }
+    kernels = {
+        "eager_step_ms": round(sum(step_ms) / len(step_ms), 4),
+        "conv_ms_total": round(conv_ms, 4),
+        "families": {k: dict(launches=v["launches"], ms=round(v["ms"], 4), tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                             gbs=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)) for k, v in sorted(fam.items())},
+    }
+    return roofline, kernels
+
+
+def run_cpu_baseline(args):
+    """The oracle (CPU restatement validated against the reference) on this host's cores: bounded sample."""
+    from oracle import nms as onms
+    from oracle import tasks as ot
+    from ultralytics_pro_amd.utils import procedural as P
+
+    host_cores = os.cpu_count() or 1
+    cores = min(host_cores, args.cpu_threads)  # torch CPU convs regress badly when oversubscribed (256 threads: 0.15 img/s)
+    torch.set_num_threads(cores)
+    m = ot.DetectionModel(args.model + ".yaml")
+    P.apply_procedural_weights(m)
+    m.fuse()
+    b = args.cpu_batch
+    x = P.synthetic_images(b)
+    best_f, best_t = 1e30, 1e30
+    with torch.no_grad():
+        m(x[:1])
+        for _ in range(3):
+            t0 = time.perf_counter()
+            y = m(x)[0]
+            t1 = time.perf_counter()
+            onms.non_max_suppression(y, 0.25, 0.7, max_det=300)
+            t2 = time.perf_counter()
+            best_f, best_t = min(best_f, t1 - t0), min(best_t, t2 - t0)
+    return {"value": round(b / best_t, 2), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (torch CPU fp32, fused eval) {args.model} bs={b} forward+NMS, best of 3; forward only "
+                      f"{b / best_f:.2f} images/s; host has {host_cores} logical cores"}
+
+
+if __name__ == "__main__":
+    main()

@@ -45,6 +45,9 @@ int upa_conv2d_bias_act(const void* x, int n, int h, int w, int cin, int ldx,
                         const void* residual /* NULL or view shaped like y */, int ldr,
                         int k, int stride, int pad, int act, int dtype, void* stream);
 
+/* Introspection for benchmarks: the kernel instantiation (WM<<12 | WN<<8 | MTW<<4 | NTW) the call above would use. */
+int upa_conv_variant(int n, int h, int w, int cin, int cout, int k, int stride, int pad, int dtype);
+
 /* First layer: reads the model input NCHW (f32 or bf16, 1..4 channels) directly, writes NHWC.   conv.py:188-197
  * w is OIHW f32 on the DEVICE (cout<=64), bias f32[cout] on the device. */
 int upa_conv2d_stem_nchw(const void* x_nchw, int x_dtype, int n, int cin, int h, int w,

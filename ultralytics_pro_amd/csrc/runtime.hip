@@ -30,7 +30,7 @@ extern "C" int upa_graph_end(void* stream, void** graph_exec_out) {
   if (e != hipSuccess || !graph) { upa_set_error("graph_end: %s", hipGetErrorString(e)); return UPA_ELAUNCH; }
   hipGraphExec_t exec = nullptr;
   e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-  hipGraphDestroy(graph);
+  (void)hipGraphDestroy(graph);
   if (e != hipSuccess) { upa_set_error("graph_instantiate: %s", hipGetErrorString(e)); return UPA_ELAUNCH; }
   *graph_exec_out = (void*)exec;
   return UPA_OK;
@@ -44,6 +44,6 @@ extern "C" int upa_graph_launch(void* graph_exec, void* stream) {
 }
 
 extern "C" int upa_graph_destroy(void* graph_exec) {
-  if (graph_exec) hipGraphExecDestroy((hipGraphExec_t)graph_exec);
+  if (graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)graph_exec);
   return UPA_OK;
 }

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       float t = acc[c + q] + bsh[c + q];
-      if (p.act == UPA_ACT_SILU) t = F32 ? t / (1.0f + __expf(-t)) : t * __frcp_rn(1.0f + __expf(-t));
+      if (p.act == UPA_ACT_SILU) t = F32 ? t / (1.0f + expf(-t)) : t * __frcp_rn(1.0f + __expf(-t));
       v[q] = t;
     }
     if constexpr (F32)

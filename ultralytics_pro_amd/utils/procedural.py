@@ -104,11 +104,11 @@ CLS_BIAS_SPREAD = 0.5
 # The head's input magnitude differs per architecture, so these are tuned (oracle, build container) until ~2 % of
 # anchors exceed conf=0.25 with distinct scores and the DFL bins are peaky-but-not-one-hot (logit std 3-4).
 HEAD_RECIPE = {
-    "default": (5.0, -4.4, 14.0),
-    "yolov8n": (5.0, -4.4, 14.0),
-    "yolov8s": (1.0, -6.0, 5.0),
-    "yolov3-tiny": (0.6, -5.6, 1.8),
-    "yolov5-BoT3": (0.8, -5.0, 1.8),
+    "default": (5.0, -4.4, 5.0),
+    "yolov8n": (5.0, -4.4, 5.0),
+    "yolov8s": (1.0, -6.0, 2.0),
+    "yolov3-tiny": (0.6, -5.6, 0.7),
+    "yolov5-BoT3": (0.8, -5.0, 0.7),
 }
 RTDETR_SCORE_BIAS = -6.5
 RTDETR_SCORE_GAIN = 1.5
