@@ -92,6 +92,12 @@ int upa_nms_batched(const float* pred, int b, int nc, int a, float conf_thres, f
                     float* out, int32_t* counts, int32_t* keep_idx, void* workspace, size_t workspace_bytes,
                     void* stream);
 
+/* ---- attention (BoT3) --------------------------------------------------------------------------------------------
+ * MHSA core: q,k,v are NHWC views (n*hw pixels, pixel stride ldqkv) holding heads*d channels each; energy = q^T k
+ * (unscaled), softmax over keys, out = v.attn^T; optional residual add (BottleneckTransformer).  block.py:6036-6091 */
+int upa_mhsa(const void* q, const void* k, const void* v, int ldqkv, int n, int hw, int heads, int d,
+             const void* residual, int ldr, void* y, int ldy, int dtype, void* stream);
+
 /* ---- HIP graph helpers (capture a launch sequence once, replay per batch) ------------------------------------- */
 int upa_graph_begin(void* stream);
 int upa_graph_end(void* stream, void** graph_exec_out);

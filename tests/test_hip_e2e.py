@@ -23,7 +23,7 @@ def _build(name, dtype):
     return m
 
 
-@pytest.mark.parametrize("name", ["yolov8n", "yolov3-tiny"])
+@pytest.mark.parametrize("name", ["yolov8n", "yolov3-tiny", "yolov5-BoT3"])
 def test_e2e_f32_matches_reference_golden(name, golden_dir):
     from tests.hip_utils import DEV
     from ultralytics_pro_amd.utils.nms import non_max_suppression

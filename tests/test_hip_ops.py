@@ -96,6 +96,8 @@ BLOCKS = [
     ("c2f_n1_noshortcut", "C2f", (48, 32, 1, False), (2, 48, 10, 10)),
     ("c3_n1", "C3", (32, 32, 1, True), (2, 32, 10, 10)),
     ("sppf", "SPPF", (32, 32, 5), (2, 32, 9, 11)),
+    ("mhsa", "MHSA", (32, 6, 6, 4), (2, 32, 6, 6)),
+    ("bot3", "BoT3", (32, 32, 1, 0.5, 1, 6, 6), (2, 32, 6, 6)),
 ]
 
 
@@ -113,6 +115,20 @@ def test_blocks_match_golden_and_oracle(name, cls, args, xshape, golden_dir):
     with torch.no_grad():
         yb = to_cpu_nchw(m(to_dev_nhwc(x, torch.bfloat16)))
     assert np.abs(yb.numpy() - G[name]).max() <= 6e-2 * max(1.0, np.abs(G[name]).max())
+
+
+def test_mhsa_hot_path_shape_vs_oracle():
+    """BoT3's real MHSA problem: 128 channels, 4 heads x 32 dims, 20x20 = 400 keys, plus the fused residual."""
+    from tests.hip_utils import to_cpu_nchw, to_dev_nhwc, unit_input
+    pm, _ = _mods()
+    o, m = _pair(om.BottleneckTransformer, pm.BottleneckTransformer, (128, 128, 1, 4, True, (20, 20), 1), "bt")
+    x = unit_input("bt_hot", (2, 128, 20, 20))
+    with torch.no_grad():
+        ref = o(x)
+        y = to_cpu_nchw(m(to_dev_nhwc(x)))
+        yb = to_cpu_nchw(m(to_dev_nhwc(x, torch.bfloat16)))
+    assert (y - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    assert (yb - ref).abs().max().item() <= 4e-2 * max(1.0, ref.abs().max().item())
 
 
 def test_upsample_concat_exact(golden_dir):

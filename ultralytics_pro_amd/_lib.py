@@ -40,6 +40,7 @@ PROTOTYPES = {
     "upa_detect_decode": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _i, _i, _vp]),
     "upa_nms_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "upa_nms_batched": (_i, [_vp, _i, _i, _i, _f, _f, _i, _i, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "upa_mhsa": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
     "upa_graph_begin": (_i, [_vp]),
     "upa_graph_end": (_i, [_vp, C.POINTER(_vp)]),
     "upa_graph_launch": (_i, [_vp, _vp]),

@@ -1,0 +1,112 @@
+// MHSA core of the BoT3 block: per (image, head) dense self-attention over the L = H*W pixels of a feature map,
+//   energy[p][q] = sum_i Q[i][p] K[i][q]   (NOT scaled by 1/sqrt(d)),  attn = softmax_q(energy),
+//   out[i][p]    = sum_q V[i][q] attn[p][q]                                  (+ residual, BottleneckTransformer)
+// Replaces torch.matmul / Softmax / matmul of MHSA.forward (ultralytics/nn/modules/block.py:6036-6062) and the
+// `x + ...` of BottleneckTransformer.forward (:6090-6091).  q/k/v come from three 1x1 convs written into one NHWC
+// buffer (channels [q | k | v]), so a (pixel, head) row is d contiguous elements.
+//
+// L = 400, d = 32 on the hot path (yolov5n-BoT3 @640): K and V of one (image, head) fit LDS (f32: 100 KiB, bf16: 50 KiB),
+// are staged once per workgroup and broadcast-read by all lanes; one lane owns one query row and keeps a running
+// (max, sum, out[d]) online softmax in registers, so the L x L energy matrix never exists in memory.
+#include "common.h"
+
+template <typename T, int D>
+__global__ __launch_bounds__(128) void mhsa_kernel(const char* q, const char* k, const char* v, int ld, int L, int heads,
+                                                   const char* res, int ldr, char* y, int ldy) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  T* ks = reinterpret_cast<T*>(sm);  // [L][D]
+  T* vs = ks + (size_t)L * D;        // [L][D]
+  const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+  const size_t pix0 = (size_t)b * L;
+  constexpr int E = 16 / sizeof(T);
+  if constexpr (D % E == 0) {
+    constexpr int G = D / E;  // 16-byte groups per row
+    for (int i = threadIdx.x; i < L * G; i += 128) {
+      const int p = i / G, gq = i % G;
+      const size_t off = ((pix0 + p) * ld + h * D + gq * E) * sizeof(T);
+      reinterpret_cast<u32x4*>(ks)[i] = *reinterpret_cast<const u32x4*>(k + off);
+      reinterpret_cast<u32x4*>(vs)[i] = *reinterpret_cast<const u32x4*>(v + off);
+    }
+  } else {  // tiny heads (unit-test sized): element-wise staging
+    for (int i = threadIdx.x; i < L * D; i += 128) {
+      const int p = i / D, e = i % D;
+      const size_t off = ((pix0 + p) * ld + h * D + e) * sizeof(T);
+      ks[i] = *reinterpret_cast<const T*>(k + off);
+      vs[i] = *reinterpret_cast<const T*>(v + off);
+    }
+  }
+  __syncthreads();
+  const int p = blockIdx.y * 128 + threadIdx.x;
+  if (p >= L) return;
+  float qr[D], o[D];
+  {
+    const T* qp = reinterpret_cast<const T*>(q + ((pix0 + p) * ld + h * D) * sizeof(T));
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      qr[i] = ElemTraits<T>::load(qp + i);
+      o[i] = 0.f;
+    }
+  }
+  float m = -INFINITY, l = 0.f;
+  for (int j = 0; j < L; ++j) {
+    const T* kr = ks + (size_t)j * D;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < D; ++i) s = fmaf(qr[i], ElemTraits<T>::load(kr + i), s);
+    const float mn = fmaxf(m, s);
+    const float alpha = expf(m - mn);  // exp(-inf) = 0 on the first key
+    const float pj = expf(s - mn);
+    l = l * alpha + pj;
+    const T* vr = vs + (size_t)j * D;
+#pragma unroll
+    for (int i = 0; i < D; ++i) o[i] = fmaf(pj, ElemTraits<T>::load(vr + i), o[i] * alpha);
+    m = mn;
+  }
+  const float inv = 1.0f / l;
+  T* yp = reinterpret_cast<T*>(y + ((pix0 + p) * ldy + h * D) * sizeof(T));
+  const T* rp = res ? reinterpret_cast<const T*>(res + ((pix0 + p) * ldr + h * D) * sizeof(T)) : nullptr;
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    float val = o[i] * inv;
+    if (rp) val += ElemTraits<T>::load(rp + i);
+    if constexpr (sizeof(T) == 4) yp[i] = val;
+    else yp[i] = f32_to_bf16(val);
+  }
+}
+
+template <typename T, int D>
+static int launch_mhsa(const void* q, const void* k, const void* v, int ld, int n, int hw, int heads, const void* residual,
+                       int ldr, void* y, int ldy, hipStream_t s) {
+  const size_t lds = (size_t)2 * hw * D * sizeof(T);
+  if (lds > 150 * 1024) {
+    upa_set_error("mhsa: %d keys x %d dims do not fit LDS", hw, D);
+    return UPA_EUNSUPPORTED;
+  }
+  dim3 grid((unsigned)(n * heads), (unsigned)cdiv(hw, 128));
+  auto kern = mhsa_kernel<T, D>;
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, grid, dim3(128), lds, s, (const char*)q, (const char*)k, (const char*)v, ld, hw, heads,
+                     (const char*)residual, ldr, (char*)y, ldy);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+extern "C" int upa_mhsa(const void* q, const void* k, const void* v, int ldqkv, int n, int hw, int heads, int d,
+                        const void* residual, int ldr, void* y, int ldy, int dtype, void* stream) {
+  UPA_CHECK_ARG(q && k && v && y, "mhsa: null pointer");
+  const int es = upa_elem_size(dtype);
+  UPA_CHECK_ARG(ldqkv % (16 / es) == 0 && ldy % (16 / es) == 0, "mhsa: strides must be multiples of 16 bytes");
+  hipStream_t s = (hipStream_t)stream;
+#define UPA_MHSA_CASE(DD)                                                                                         \
+  if (d == DD)                                                                                                    \
+    return dtype == UPA_BF16 ? launch_mhsa<bf16_t, DD>(q, k, v, ldqkv, n, hw, heads, residual, ldr, y, ldy, s)     \
+                             : launch_mhsa<float, DD>(q, k, v, ldqkv, n, hw, heads, residual, ldr, y, ldy, s);
+  UPA_MHSA_CASE(4)
+  UPA_MHSA_CASE(8)
+  UPA_MHSA_CASE(16)
+  UPA_MHSA_CASE(32)
+  UPA_MHSA_CASE(64)
+#undef UPA_MHSA_CASE
+  upa_set_error("mhsa: head dim %d not supported (4, 8, 16, 32, 64)", d);
+  return UPA_EUNSUPPORTED;
+}

@@ -19,6 +19,10 @@
 //     (k-ordered fmaf chain), used for the <=1e-3 parity mode.  k order inside a tile is permuted identically for A
 //     and B (lane group g supplies bytes [16g,16g+16) of the tile), which leaves the sum unchanged.
 //   * LDS pixel stride = chunk bytes + 16 so consecutive pixels land on different 16-byte bank slots.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "common.h"
 
 struct ConvParams {
@@ -39,23 +43,30 @@ struct ConvParams {
   unsigned magicIW;  // ceil(2^32 / IW)
 };
 
-template <typename T, bool PRECISE>
-__device__ __forceinline__ float act_fn(float v, int act) {
-  if (act == UPA_ACT_SILU) {
-    if (PRECISE) return v / (1.0f + expf(-v));  // ocml expf (<= 1 ulp) + IEEE divide: f32 parity mode
+template <bool PRECISE, int ACT>
+__device__ __forceinline__ float act_fn(float v) {
+  if constexpr (ACT == UPA_ACT_SILU) {
+    if constexpr (PRECISE) return v / (1.0f + expf(-v));  // ocml expf (<= 1 ulp) + IEEE divide: f32 parity mode
     return v * __frcp_rn(1.0f + __expf(-v));
+  } else if constexpr (ACT == UPA_ACT_RELU) {
+    return fmaxf(v, 0.0f);
+  } else {
+    return v;
   }
-  if (act == UPA_ACT_RELU) return fmaxf(v, 0.0f);
-  return v;
 }
 
-template <typename T, int WM, int WN, int MTW, int NTW>
+// CKT = k-tiles (64 B of channels each) staged per LDS chunk and held per tap in registers; the host picks a CKT that
+// divides KTT, so every chunk is full.
+template <typename T, int WM, int WN, int MTW, int NTW, int CKT>
 __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = sizeof(T);
   constexpr int E = 16 / ES;      // elements per 16 bytes
   constexpr int KT_CH = 64 / ES;  // channels per k-tile
   constexpr int NTHREADS = WM * WN * 64;
+  constexpr int G16 = CKT * 4;    // 16-byte groups per pixel per chunk
+  constexpr int G16SHIFT = CKT == 1 ? 2 : (CKT == 2 ? 3 : 4);
+  static_assert(CKT == 1 || CKT == 2 || CKT == 4, "CKT must be 1, 2 or 4");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -93,19 +104,72 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
     pixbase[i] = ((ty * p.stride) * p.IW + tx * p.stride) * p.PS + g * 16;
   }
 
-  const int nChunks = (p.KTT + p.CKT - 1) / p.CKT;
-  const int G16 = p.CKT * 4;  // 16-byte groups per pixel per chunk (power of two)
-  const int g16shift = (p.CKT == 1) ? 2 : (p.CKT == 2 ? 3 : 4);
+  const int nChunks = p.KTT / CKT;
   const int haloItems = p.IH * p.IW * G16;
   const size_t wTileStride = (size_t)p.NTn * 1024;  // bytes per (tap, ktile)
+  const char* wlane = p.w + (size_t)nt0 * 1024 + lane * 16;
+  const int taps = p.KS * p.KS;
+
+  // Weight fragments of one tap (CKT k-tiles x NTW n-tiles) live in registers, ping-pong buffered: while the MFMAs of
+  // tap t run from one buffer, the 1 KiB-per-wave coalesced loads of tap t+1 (or of the next chunk's first tap - they
+  // do not depend on the LDS tile) land in the other.
+  u32x4 A0[CKT][NTW], A1[CKT][NTW];
+  auto fetch_tap = [&](u32x4(&dst)[CKT][NTW], int c, int tap) {
+    const char* wb = wlane + (size_t)(tap * p.KTT + c * CKT) * wTileStride;
+#pragma unroll
+    for (int kt = 0; kt < CKT; ++kt)
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) dst[kt][j] = *reinterpret_cast<const u32x4*>(wb + kt * wTileStride + j * 1024);
+  };
+  auto compute_tap = [&](u32x4(&A)[CKT][NTW], int tapoff) {
+#pragma unroll
+    for (int kt = 0; kt < CKT; ++kt) {
+      u32x4 b[MTW];
+#pragma unroll
+      for (int i = 0; i < MTW; ++i) b[i] = *reinterpret_cast<const u32x4*>(smem + pixbase[i] + tapoff + kt * 64);
+#pragma unroll
+      for (int i = 0; i < MTW; ++i) {
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+          if constexpr (ES == 2) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&A[kt][j]),
+                                                                *reinterpret_cast<bf16x8*>(&b[i]), acc[i][j], 0, 0, 0);
+          } else {
+            const float* af = reinterpret_cast<const float*>(&A[kt][j]);
+            const float* bf = reinterpret_cast<const float*>(&b[i]);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], bf[0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1], bf[1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[2], bf[2], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[3], bf[3], acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+  };
+  fetch_tap(A0, 0, 0);
+
+  // bias of this wave's output channels (4 consecutive per accumulator tile), fetched once up front
+  f32x4 biasv[NTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    const int co = (nt0 + j) * 16 + g * 4;
+    biasv[j] = (p.bias && co < p.Cout) ? *reinterpret_cast<const f32x4*>(p.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  [[maybe_unused]] f32x4 accT[MTW][NTW];  // f32 parity mode: per-chunk partial sums folded into a running total
+  if constexpr (ES == 4) {
+#pragma unroll
+    for (int i = 0; i < MTW; ++i)
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) accT[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   for (int c = 0; c < nChunks; ++c) {
-    const int nkt = min(p.CKT, p.KTT - c * p.CKT);
-    const int c0 = c * p.CKT * KT_CH;
+    const int c0 = c * CKT * KT_CH;
     if (c > 0) __syncthreads();
     // ---- stage the halo tile of this channel chunk
     for (int idx = tid; idx < haloItems; idx += NTHREADS) {
-      const int pix = idx >> g16shift;
+      const int pix = idx >> G16SHIFT;
       const int cg = idx & (G16 - 1);
       const int py = __umulhi((unsigned)pix, p.magicIW);
       const int px = pix - py * p.IW;
@@ -119,76 +183,86 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
       *reinterpret_cast<u32x4*>(smem + pix * p.PS + cg * 16) = v;
     }
     __syncthreads();
-    // ---- taps x k-tiles
-    for (int kh = 0; kh < p.KS; ++kh) {
-      for (int kw = 0; kw < p.KS; ++kw) {
-        const int tapoff = (kh * p.IW + kw) * p.PS;
-        const int ktg0 = (kh * p.KS + kw) * p.KTT + c * p.CKT;
-        for (int kt = 0; kt < nkt; ++kt) {
-          const char* wbase = p.w + (size_t)(ktg0 + kt) * wTileStride + (size_t)nt0 * 1024 + lane * 16;
-          u32x4 a[NTW];
+    // ---- taps, two per trip (ping-pong)
+    int kh = 0, kw = 0;
+    for (int tap = 0; tap < taps; tap += 2) {
+      const bool has1 = tap + 1 < taps;
+      if (has1) fetch_tap(A1, c, tap + 1);
+      else if (c + 1 < nChunks) fetch_tap(A1, c + 1, 0);
+      compute_tap(A0, (kh * p.IW + kw) * p.PS);
+      if (++kw == p.KS) { kw = 0; ++kh; }
+      if (has1) {
+        if (tap + 2 < taps) fetch_tap(A0, c, tap + 2);
+        else if (c + 1 < nChunks) fetch_tap(A0, c + 1, 0);
+        compute_tap(A1, (kh * p.IW + kw) * p.PS);
+        if (++kw == p.KS) { kw = 0; ++kh; }
+      } else if (c + 1 < nChunks) {
+        // odd tap count: the next chunk's first tap was fetched into A1
 #pragma unroll
-          for (int j = 0; j < NTW; ++j) a[j] = *reinterpret_cast<const u32x4*>(wbase + j * 1024);
-          u32x4 b[MTW];
+        for (int kt = 0; kt < CKT; ++kt)
 #pragma unroll
-          for (int i = 0; i < MTW; ++i)
-            b[i] = *reinterpret_cast<const u32x4*>(smem + pixbase[i] + tapoff + kt * 64);
-#pragma unroll
-          for (int i = 0; i < MTW; ++i) {
-#pragma unroll
-            for (int j = 0; j < NTW; ++j) {
-              if constexpr (ES == 2) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&a[j]),
-                                                                    *reinterpret_cast<bf16x8*>(&b[i]), acc[i][j], 0, 0, 0);
-              } else {
-                const float* af = reinterpret_cast<const float*>(&a[j]);
-                const float* bf = reinterpret_cast<const float*>(&b[i]);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], bf[0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1], bf[1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[2], bf[2], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[3], bf[3], acc[i][j], 0, 0, 0);
-              }
-            }
-          }
-        }
+          for (int j = 0; j < NTW; ++j) A0[kt][j] = A1[kt][j];
       }
+    }
+    if constexpr (ES == 4) {
+      if (nChunks > 1) {
+#pragma unroll
+        for (int i = 0; i < MTW; ++i)
+#pragma unroll
+          for (int j = 0; j < NTW; ++j) {
+            accT[i][j] += acc[i][j];
+            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+      }
+    }
+  }
+  if constexpr (ES == 4) {
+    if (nChunks > 1) {
+#pragma unroll
+      for (int i = 0; i < MTW; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[i][j] = accT[i][j];
     }
   }
 
-  // ---- epilogue: bias + act (+ residual) -> NHWC store; lane holds channels co0..co0+3 of pixel (col r)
+  // ---- epilogue: bias + act (+ residual) -> NHWC store; lane holds channels co..co+3 of pixel (col r)
+  auto epilogue = [&](auto act_tag) {
+    constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-  for (int i = 0; i < MTW; ++i) {
-    const int oy = oy0 + pty[i], ox = ox0 + ptx[i];
-    if (pty[i] >= p.TH || oy >= p.OH || ox >= p.OW) continue;
-    const size_t pixoff = ((size_t)n * p.OH + oy) * p.OW + ox;
+    for (int i = 0; i < MTW; ++i) {
+      const int oy = oy0 + pty[i], ox = ox0 + ptx[i];
+      const bool pvalid = pty[i] < p.TH && oy < p.OH && ox < p.OW;
+      const size_t pixoff = ((size_t)n * p.OH + oy) * p.OW + ox;
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) {
-      const int co = (nt0 + j) * 16 + g * 4;
-      if (co >= p.Cout) continue;
-      float v[4];
+      for (int j = 0; j < NTW; ++j) {
+        const int co = (nt0 + j) * 16 + g * 4;
+        if (!pvalid || co >= p.Cout) continue;
+        float v[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float t = acc[i][j][q] + (p.bias ? p.bias[co + q] : 0.f);
-        v[q] = act_fn<T, ES == 4>(t, p.act);
-      }
-      if constexpr (ES == 4) {
-        if (p.res) {
-          const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + (pixoff * p.ldr + co) * 4);
-          v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3];
+        for (int q = 0; q < 4; ++q) v[q] = act_fn<ES == 4, ACT>(acc[i][j][q] + biasv[j][q]);
+        if constexpr (ES == 4) {
+          if (p.res) {
+            const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + (pixoff * p.ldr + co) * 4);
+            v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3];
+          }
+          *reinterpret_cast<f32x4*>(p.y + (pixoff * p.ldy + co) * 4) = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+          if (p.res) {
+            const u32x2 rv = *reinterpret_cast<const u32x2*>(p.res + (pixoff * p.ldr + co) * 2);
+            v[0] += __uint_as_float(rv[0] << 16);
+            v[1] += __uint_as_float(rv[0] & 0xFFFF0000u);
+            v[2] += __uint_as_float(rv[1] << 16);
+            v[3] += __uint_as_float(rv[1] & 0xFFFF0000u);
+          }
+          *reinterpret_cast<u32x2*>(p.y + (pixoff * p.ldy + co) * 2) =
+              u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
         }
-        *reinterpret_cast<f32x4*>(p.y + (pixoff * p.ldy + co) * 4) = f32x4{v[0], v[1], v[2], v[3]};
-      } else {
-        if (p.res) {
-          const u32x2 rv = *reinterpret_cast<const u32x2*>(p.res + (pixoff * p.ldr + co) * 2);
-          v[0] += __uint_as_float(rv[0] << 16);
-          v[1] += __uint_as_float(rv[0] & 0xFFFF0000u);
-          v[2] += __uint_as_float(rv[1] << 16);
-          v[3] += __uint_as_float(rv[1] & 0xFFFF0000u);
-        }
-        *reinterpret_cast<u32x2*>(p.y + (pixoff * p.ldy + co) * 2) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
       }
     }
-  }
+  };
+  if (p.act == UPA_ACT_SILU) epilogue(std::integral_constant<int, UPA_ACT_SILU>{});
+  else if (p.act == UPA_ACT_RELU) epilogue(std::integral_constant<int, UPA_ACT_RELU>{});
+  else epilogue(std::integral_constant<int, UPA_ACT_NONE>{});
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -246,11 +320,11 @@ struct TileCfg {
 thread_local int g_query_only = 0;   // upa_conv_variant: run the dispatch logic without launching
 thread_local int g_last_variant = 0;
 
-template <typename T, int WM, int WN, int MTW, int NTW>
-int launch_conv(ConvParams& p, hipStream_t stream) {
+template <typename T, int WM, int WN, int MTW, int NTW, int CKT>
+int launch_conv_ckt(ConvParams& p, hipStream_t stream) {
   constexpr int BM = WM * MTW * 16;
   constexpr int BN = WN * NTW * 16;
-  g_last_variant = (WM << 12) | (WN << 8) | (MTW << 4) | NTW;
+  g_last_variant = (CKT << 16) | (WM << 12) | (WN << 8) | (MTW << 4) | NTW;
   if (g_query_only) return UPA_OK;
   // tile shape: BM pixels as TH x TW
   int TW, TH;
@@ -278,7 +352,7 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
   const size_t lds = (size_t)IHalloc * p.IW * p.PS + 64;
   if (lds > 160 * 1024) return UPA_EUNSUPPORTED;
   dim3 grid((unsigned)((long)p.tilesX * p.tilesY * p.N), (unsigned)cdiv(p.NTn * 16, BN));
-  auto kern = conv_igemm_kernel<T, WM, WN, MTW, NTW>;
+  auto kern = conv_igemm_kernel<T, WM, WN, MTW, NTW, CKT>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { upa_set_error("conv: cannot raise LDS limit: %s", hipGetErrorString(e)); return UPA_ELAUNCH; }
@@ -286,6 +360,13 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
   hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, stream, p);
   UPA_LAUNCH_CHECK();
   return UPA_OK;
+}
+
+template <typename T, int WM, int WN, int MTW, int NTW>
+int launch_conv(ConvParams& p, hipStream_t stream) {
+  if (p.CKT == 4) return launch_conv_ckt<T, WM, WN, MTW, NTW, 4>(p, stream);
+  if (p.CKT == 2) return launch_conv_ckt<T, WM, WN, MTW, NTW, 2>(p, stream);
+  return launch_conv_ckt<T, WM, WN, MTW, NTW, 1>(p, stream);
 }
 
 template <typename T>
@@ -348,9 +429,15 @@ extern "C" int upa_conv2d_bias_act(const void* x, int n, int h, int w, int cin, 
   p.KTT = cdiv(cin, ktch);
   p.NTn = cdiv(cout, 16);
   // chunk: up to 4 k-tiles (256 B of channels per pixel) for stride 1, 2 for stride 2 (bigger halo)
-  int ckt = p.KTT >= 4 ? 4 : (p.KTT >= 2 ? 2 : 1);
-  if (stride == 2 && ckt > 2) ckt = 2;
+  // chunk = CKT k-tiles; CKT must divide KTT (every chunk full). Up to 4 (256 B of channels per pixel) for stride 1,
+  // 2 for stride 2 (bigger halo tile) and for wide-N variants (register budget of the per-tap weight buffers).
+  int ckt = (p.KTT % 4 == 0) ? 4 : ((p.KTT % 2 == 0) ? 2 : 1);
+  if ((stride == 2 || p.NTn == 5 || p.NTn == 3) && ckt > 2) ckt = 2;
   if (k > 3 && ckt > 1) ckt = 1;
+  if (const char* e = getenv("UPA_CONV_CKT")) {  // tuning override (must still divide KTT)
+    const int v = atoi(e);
+    if ((v == 1 || v == 2 || v == 4) && p.KTT % v == 0 && v <= ckt) ckt = v;
+  }
   p.CKT = ckt;
   hipStream_t s = (hipStream_t)stream;
   int rc = dtype == UPA_BF16 ? dispatch_conv<bf16_t>(p, s) : dispatch_conv<float>(p, s);

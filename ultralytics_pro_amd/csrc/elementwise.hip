@@ -70,44 +70,51 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const char* x, char* y, in
   }
 }
 
-// ---- SPPF: three chained 5x5/s1/p2 max pools == 5x5, 9x9, 13x13 windows of x (-inf padding) -------------------
+// ---- SPPF: three chained 5x5/s1/p2 max pools (-inf padding), one (image, 16-byte channel group) plane per workgroup.
+// The plane lives in LDS; each 5x5 pool is separable (row max then column max), so a pixel costs 30 LDS reads for the
+// three outputs instead of 169 global reads, and x is read from HBM exactly once.
 template <typename T>
 __global__ __launch_bounds__(256) void sppf_pool3_kernel(const char* x, char* y1, char* y2, char* y3, int N, int H, int W,
                                                          int C, int ldx, int ldy) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
   constexpr int E = Vec16<T>::E;
   const int CG = C / E;
-  const long total = (long)N * H * W * CG;
-  for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
-    const int cg = (int)(gid % CG);
-    long pix = gid / CG;
-    const int ox = (int)(pix % W);
-    const int oy = (int)((pix / W) % H);
-    const int n = (int)(pix / ((long)W * H));
-    Vec16<T> m5, m9, m13;
+  const int n = blockIdx.x / CG, cg = blockIdx.x % CG;
+  const int HW = H * W;
+  u32x4* a = reinterpret_cast<u32x4*>(sm);  // current stage input  [HW]
+  u32x4* t = a + HW;                        // row-max scratch       [HW]
+  for (int p = threadIdx.x; p < HW; p += 256)
+    a[p] = *reinterpret_cast<const u32x4*>(x + (((size_t)n * HW + p) * ldx + cg * E) * sizeof(T));
+  __syncthreads();
+  char* outs[3] = {y1, y2, y3};
+  for (int stage = 0; stage < 3; ++stage) {
+    for (int p = threadIdx.x; p < HW; p += 256) {  // horizontal 5-max
+      const int py = p / W, px = p - py * W;
+      Vec16<T> m = Vec16<T>::load(reinterpret_cast<const char*>(&a[p]));
+      for (int dx = -2; dx <= 2; ++dx) {
+        const int qx = px + dx;
+        if (dx == 0 || qx < 0 || qx >= W) continue;
+        const Vec16<T> v = Vec16<T>::load(reinterpret_cast<const char*>(&a[py * W + qx]));
 #pragma unroll
-    for (int i = 0; i < E; ++i) m5.v[i] = m9.v[i] = m13.v[i] = -INFINITY;
-    for (int dy = -6; dy <= 6; ++dy) {
-      const int iy = oy + dy;
-      if (iy < 0 || iy >= H) continue;
-      const int ady = dy < 0 ? -dy : dy;
-      for (int dx = -6; dx <= 6; ++dx) {
-        const int ix = ox + dx;
-        if (ix < 0 || ix >= W) continue;
-        const int adx = dx < 0 ? -dx : dx;
-        const int rad = ady > adx ? ady : adx;
-        const Vec16<T> t = Vec16<T>::load(x + ((((size_t)n * H + iy) * W + ix) * ldx + cg * E) * sizeof(T));
-#pragma unroll
-        for (int i = 0; i < E; ++i) {
-          m13.v[i] = fmaxf(m13.v[i], t.v[i]);
-          if (rad <= 4) m9.v[i] = fmaxf(m9.v[i], t.v[i]);
-          if (rad <= 2) m5.v[i] = fmaxf(m5.v[i], t.v[i]);
-        }
+        for (int i = 0; i < E; ++i) m.v[i] = fmaxf(m.v[i], v.v[i]);
       }
+      m.store(reinterpret_cast<char*>(&t[p]));
     }
-    const size_t o = (((size_t)n * H + oy) * W + ox) * ldy + cg * E;
-    m5.store(y1 + o * sizeof(T));
-    m9.store(y2 + o * sizeof(T));
-    m13.store(y3 + o * sizeof(T));
+    __syncthreads();
+    for (int p = threadIdx.x; p < HW; p += 256) {  // vertical 5-max -> stage output (also next stage's input)
+      const int py = p / W, px = p - py * W;
+      Vec16<T> m = Vec16<T>::load(reinterpret_cast<const char*>(&t[p]));
+      for (int dy = -2; dy <= 2; ++dy) {
+        const int qy = py + dy;
+        if (dy == 0 || qy < 0 || qy >= H) continue;
+        const Vec16<T> v = Vec16<T>::load(reinterpret_cast<const char*>(&t[qy * W + px]));
+#pragma unroll
+        for (int i = 0; i < E; ++i) m.v[i] = fmaxf(m.v[i], v.v[i]);
+      }
+      m.store(reinterpret_cast<char*>(&a[p]));
+      m.store(outs[stage] + (((size_t)n * HW + p) * ldy + cg * E) * sizeof(T));
+    }
+    __syncthreads();
   }
 }
 
@@ -235,13 +242,16 @@ extern "C" int upa_sppf_pool3(const void* x, int n, int h, int w, int c, int ldx
   UPA_CHECK_ARG(x && y1 && y2 && y3, "sppf_pool3: null pointer");
   CHECK_VIEW(c, ldx, dtype);
   CHECK_VIEW(c, ldy, dtype);
-  const long total = (long)n * h * w * (c / (16 / upa_elem_size(dtype)));
+  const size_t lds = (size_t)h * w * 32;
+  UPA_CHECK_ARG(lds <= 64 * 1024, "sppf_pool3: plane %dx%d does not fit LDS", h, w);
+  const int cg = c / (16 / upa_elem_size(dtype));
+  dim3 grid((unsigned)(n * cg));
   if (dtype == UPA_BF16)
-    hipLaunchKernelGGL(sppf_pool3_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                       (const char*)x, (char*)y1, (char*)y2, (char*)y3, n, h, w, c, ldx, ldy);
+    hipLaunchKernelGGL(sppf_pool3_kernel<bf16_t>, grid, dim3(256), lds, (hipStream_t)stream, (const char*)x, (char*)y1,
+                       (char*)y2, (char*)y3, n, h, w, c, ldx, ldy);
   else
-    hipLaunchKernelGGL(sppf_pool3_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                       (const char*)x, (char*)y1, (char*)y2, (char*)y3, n, h, w, c, ldx, ldy);
+    hipLaunchKernelGGL(sppf_pool3_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, (const char*)x, (char*)y1,
+                       (char*)y2, (char*)y3, n, h, w, c, ldx, ldy);
   UPA_LAUNCH_CHECK();
   return UPA_OK;
 }

@@ -124,6 +124,37 @@ def parse_model(d, ch, verbose=False):
     return nn.Sequential(*layers), sorted(save)
 
 
+def _out_hw(m, h, w):
+    """Spatial size of a layer's output for an (h, w) input (only stride-changing layers matter)."""
+    for mm in (list(m) if isinstance(m, HipSequential) else [m]):
+        if isinstance(mm, Conv):
+            k, s, p = mm.conv.kernel_size[0], mm.conv.stride[0], mm.conv.padding[0]
+            h, w = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+        elif isinstance(mm, MaxPool2d):
+            k, s, p = mm.kernel_size, mm.stride, mm.padding
+            h, w = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+        elif isinstance(mm, Upsample):
+            h, w = 2 * h, 2 * w
+    return h, w
+
+
+def _out_channels(m, ch):
+    """Output channels of layer m given the per-layer list so far."""
+    last = m[-1] if isinstance(m, HipSequential) else m
+    if isinstance(last, Conv):
+        return last.conv.out_channels
+    if isinstance(last, (C2f, SPPF)):
+        return last.cv2.conv.out_channels
+    if isinstance(last, (C3, BoT3)):
+        return last.cv3.conv.out_channels
+    if isinstance(last, Bottleneck):
+        return last.cv2.conv.out_channels
+    if isinstance(last, Concat):
+        return sum(ch[m.i - 1 if j == -1 else j] for j in m.f)
+    src = m.f if isinstance(m.f, int) else m.f[0]
+    return ch[m.i - 1 if src == -1 else src] if ch else 0
+
+
 class HipSequential(nn.Sequential):
     """n > 1 repeats of a module (tasks.py:3113); the last repeat may write into a caller-provided view."""
 
@@ -132,6 +163,9 @@ class HipSequential(nn.Sequential):
         for j, m in enumerate(mods):
             x = m(x, out=out) if (j == len(mods) - 1 and out is not None) else m(x)
         return x
+
+
+_OUT_CAPABLE = (Conv, C2f, C3, SPPF, BoT3, Bottleneck, Upsample, MaxPool2d, HipSequential)
 
 
 class BaseModel(nn.Module):
@@ -148,14 +182,58 @@ class BaseModel(nn.Module):
         return self._predict_once(x)
 
     def _predict_once(self, x):
-        """The layer loop: route `m.f`, run, save if in `save` (tasks.py:1046-1085)."""
-        y = []
+        """The layer loop: route `m.f`, run, save if in `save` (tasks.py:1046-1085).
+
+        Concat-by-construction: a layer whose output feeds a `Concat` row writes straight into its channel slice of
+        that Concat's buffer (`out=` view), so Upsample+Concat / Conv+Concat never copy (yolov8.yaml rows 10-21)."""
+        place = self._concat_placement()
+        y, cat_buf = [], {}
         for m in self.model:
             if m.f != -1:
                 x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
-            x = m(x)
+            if m.i in place and torch.is_tensor(x):
+                li, c0, c1, ctot = place[m.i]
+                n, _, h, w = x.shape
+                oh, ow = _out_hw(m, h, w)
+                buf = cat_buf.get(li)
+                if buf is None:
+                    dt = getattr(self, "compute_dtype", None) if (x.shape[1] <= 4 and not R.is_nhwc_view(x)) else None
+                    buf = R.alloc_nhwc(n, ctot, oh, ow, dt or x.dtype, x.device, key=(id(self.model[li]), "y"))
+                    cat_buf[li] = buf
+                x = m(x, out=buf[:, c0:c1])
+            elif isinstance(m, Concat) and m.i in cat_buf:
+                buf, c0 = cat_buf[m.i], 0
+                for t in x:  # anything not produced in place (none for the reference YAMLs) is copied by Concat rules
+                    c = int(t.shape[1])
+                    dst = buf[:, c0:c0 + c]
+                    if not (t.data_ptr() == dst.data_ptr() and t.stride() == dst.stride()):
+                        vs, vd = R.view_of(R.to_nhwc(t, buf.dtype)), R.view_of(dst)
+                        L.check(L.lib().upa_copy_view(vs.ptr, vs.n, vs.h, vs.w, vs.c, vs.ld, vd.ptr, vd.ld, vs.dtype,
+                                                      L.current_stream(t.device)), "copy_view")
+                    c0 += c
+                x = buf
+            else:
+                x = m(x)
             y.append(x if m.i in self.save else None)
         return x
+
+    def _concat_placement(self):
+        """{producer layer index: (concat layer index, c0, c1, c_total)} for producers that accept `out=`."""
+        plan = self.__dict__.get("_cat_plan")
+        if plan is None:
+            plan, ch = {}, []
+            for m in self.model:  # output channels per layer
+                ch.append(_out_channels(m, ch))
+            for m in self.model:
+                if isinstance(m, Concat) and m.d == 1:
+                    srcs = [(m.i - 1 if j == -1 else j) for j in m.f]
+                    ctot, c0 = sum(ch[j] for j in srcs), 0
+                    for j in srcs:
+                        if j not in plan and isinstance(self.model[j], _OUT_CAPABLE) and srcs.count(j) == 1:
+                            plan[j] = (m.i, c0, c0 + ch[j], ctot)
+                        c0 += ch[j]
+            self.__dict__["_cat_plan"] = plan
+        return plan
 
     def fuse(self, verbose=True):
         """BN folding happens inside the HIP conv weights packing; kept for API parity (tasks.py:1120-1134)."""

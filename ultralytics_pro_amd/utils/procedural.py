@@ -98,6 +98,7 @@ def synthetic_images(batch: int, ch: int = 3, h: int = 640, w: int = 640, seed: 
 # regenerating tests/golden.
 # --------------------------------------------------------------------------------------------------------------------
 CONV_GAIN2 = 6.5  # conv weights ~ U(-a, a), a = sqrt(CONV_GAIN2 / fan_in): keeps SiLU activations O(0.3) at any depth
+ATTN_GAIN2 = 1.0  # MHSA q/k/v 1x1 convs (block.py:6020-6062): energy = q^T k is NOT scaled by 1/sqrt(d)
 RES_GAIN2 = 0.3  # last conv of a residual branch (Bottleneck.cv2 with add=True): damped, else x + f(x) chains explode
 CLS_BIAS_SPREAD = 0.5
 # Detect-head recipe per model family: (final cls 1x1 weight gain, mean final cls bias, final box 1x1 weight gain).
@@ -108,7 +109,7 @@ HEAD_RECIPE = {
     "yolov8n": (5.0, -4.4, 5.0),
     "yolov8s": (1.0, -6.0, 2.0),
     "yolov3-tiny": (0.6, -5.6, 0.7),
-    "yolov5-BoT3": (0.8, -5.0, 0.7),
+    "yolov5-BoT3": (0.8, -5.0, 0.25),
 }
 RTDETR_SCORE_BIAS = -6.5
 RTDETR_SCORE_GAIN = 1.5
@@ -146,6 +147,8 @@ def procedural_tensor(key: str, ref: torch.Tensor, kind: str, seed: int = 0, res
         g2 = 3.0
         if kind == "conv" and not det_final:
             g2 = RES_GAIN2 if residual_tail else CONV_GAIN2
+            if parts[-2] in ("query", "key", "value"):  # MHSA 1x1 convs: keep the unscaled q^T k energies O(1)
+                g2 = ATTN_GAIN2
         a = math.sqrt(g2 / _fan_in(shape))
         gain = 1.0
         if det_final:
