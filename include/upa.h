@@ -92,11 +92,41 @@ int upa_nms_batched(const float* pred, int b, int nc, int a, float conf_thres, f
                     float* out, int32_t* counts, int32_t* keep_idx, void* workspace, size_t workspace_bytes,
                     void* stream);
 
-/* ---- attention (BoT3) --------------------------------------------------------------------------------------------
- * MHSA core: q,k,v are NHWC views (n*hw pixels, pixel stride ldqkv) holding heads*d channels each; energy = q^T k
- * (unscaled), softmax over keys, out = v.attn^T; optional residual add (BottleneckTransformer).  block.py:6036-6091 */
-int upa_mhsa(const void* q, const void* k, const void* v, int ldqkv, int n, int hw, int heads, int d,
+/* ---- attention (BoT3, RT-DETR self-attention) ---------------------------------------------------------------------
+ * Dense multi-head attention core: q,k,v are row views (n*hw rows, row stride ldqkv elements) holding heads*d channels;
+ * energy = (scale*q)^T k, softmax over keys, out = v.attn^T; optional residual add.
+ * scale = 1 for MHSA (block.py:6036-6091, unscaled), 1/sqrt(d) for nn.MultiheadAttention (transformer.py:670-673). */
+int upa_mhsa(const void* q, const void* k, const void* v, int ldqkv, int n, int hw, int heads, int d, float scale,
              const void* residual, int ldr, void* y, int ldy, int dtype, void* stream);
+
+/* ---- RT-DETR decoder head pieces (f32 token rows) -------------------------------------------------------------------
+ * nn.Linear: y[m,n] = act(x[m,k] . W[n,k]^T + bias[n]) (+ residual); W packed by upa_pack_conv_weight(k=1, UPA_F32).
+ *                                                                     transformer.py:348-399, head.py:1993-2003 */
+int upa_linear(const float* x, long m, int k, int ldx, const void* w_packed, const float* bias, float* y, int n, int ldy,
+               const float* residual, int ldr, int act, void* stream);
+/* y = LayerNorm(x (+ residual))                                                  transformer.py:660-685 */
+int upa_layer_norm(const float* x, const float* residual, int m, int c, const float* gamma, const float* beta, float eps,
+                   float* y, void* stream);
+int upa_rows_add(const float* a, const float* b, float* y, long m, int c, void* stream);
+int upa_rows_scale(const float* x, const float* row_scale, float* y, long m, int c, void* stream);   /* head.py:2169 */
+int upa_rows_gather(const float* x, const int32_t* row_idx, float* y, long m_out, int c, void* stream); /* head.py:2180 */
+/* Query selection: per image top-k tokens by max class logit, sorted descending (ties: lower token index first).
+ * Token rows are level-major: row = sum_{l'<l} b*hw[l'] + img*hw[l] + p.  out_tok = reference token index.  head.py:2175 */
+int upa_topk_tokens(const float* scores, int nc, int n_levels, const int32_t* level_hw, int b, int k, int32_t* out_rows,
+                    int32_t* out_tok, void* stream);
+/* y = sigmoid(delta + inverse_sigmoid(ref, eps=1e-5))            transformer.py:756-757, nn/modules/utils.py:79-100 */
+int upa_box_refine(const float* delta, const float* ref, float* y, long n_boxes, void* stream);
+/* y = delta + anchors[tok] (logit-space reference boxes)                                       head.py:2183 */
+int upa_box_add_anchors(const float* delta, const int32_t* tok, const float* anchors, float* y, long n_boxes, void* stream);
+int upa_sigmoid(const float* x, float* y, long n, void* stream);
+/* y[m] = [boxes[m] (4) | sigmoid(scores[m]) (nc)]                                              head.py:2074 */
+int upa_rtdetr_output(const float* boxes, const float* scores, float* y, long m, int nc, void* stream);
+/* Multi-scale deformable attention sampling: value rows level-major (heads*d wide), offsets (b*len_q, heads*L*P*2),
+ * attention logits (b*len_q, heads*L*P) (softmax applied here), 4-d reference boxes (b*len_q, 4) in [0,1];
+ * bilinear, zero padding, align_corners=False.                   nn/modules/utils.py:103-159, transformer.py:540-556 */
+int upa_msdeform_attn(const float* value, const int32_t* shapes_hw, int n_levels, int b, int heads, int d,
+                      const float* offsets, const float* attn_logits, const float* ref_boxes, int len_q, int n_points,
+                      float* y, void* stream);
 
 /* ---- HIP graph helpers (capture a launch sequence once, replay per batch) ------------------------------------- */
 int upa_graph_begin(void* stream);

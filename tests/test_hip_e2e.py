@@ -86,3 +86,20 @@ def test_e2e_bf16_agrees_with_f32_detections():
     assert dbox.flatten().quantile(0.99).item() <= 4.0
     for a, b in zip(outs[torch.float32][1], outs[torch.bfloat16][1]):
         assert abs(a.shape[0] - b.shape[0]) <= max(3, int(0.15 * a.shape[0]))
+
+
+def test_e2e_rtdetr_f32_matches_reference_golden(golden_dir):
+    """Config 5: yolov3-rtdetr (darknet53 backbone + RTDETRDecoder), B=2: queries are compared row by row - the top-300
+    selection order must reproduce the reference's (head.py:2175)."""
+    from tests.hip_utils import DEV
+    g = np.load(golden_dir / "e2e_yolov3-rtdetr.npz")
+    m = _build("yolov3-rtdetr", torch.float32)
+    x = P.synthetic_images(2).to(DEV)
+    with torch.no_grad():
+        y = m(x)[0]
+    torch.cuda.synchronize()
+    d = np.abs(y.cpu().numpy() - g["y"])
+    print(f"rtdetr f32: max|box d|={d[..., :4].max():.3e} (normalised) max|score d|={d[..., 4:].max():.3e}")
+    assert d.max() <= TOL
+    outs = onms.rtdetr_postprocess(y.cpu(), 0.25)
+    assert [o.shape[0] for o in outs] == list(g["post_n"])

@@ -195,6 +195,46 @@ def test_detect_decode_vs_oracle_random_logits():
         assert diff[:, :4].max() <= 2e-4 and diff[:, 4:].max() <= 2e-6, (dtype, diff[:, :4].max(), diff[:, 4:].max())
 
 
+def test_rtdetr_decoder_small_matches_golden(golden_dir):
+    """RTDETRDecoder(hd=32, nq=10, nh=4, ndl=2, d_ffn=64) on three tiny maps vs the reference's recorded output."""
+    from tests.hip_utils import DEV, bn_fix, to_dev_nhwc, unit_input
+    from ultralytics_pro_amd.nn.modules.rtdetr import RTDETRDecoder
+    G = np.load(golden_dir / "ops_unit.npz")
+    r = bn_fix(RTDETRDecoder(80, (16, 32, 64), 32, 10, 4, 4, 2, 64))
+    P.apply_procedural_weights(r)
+    r = r.to(DEV)
+    xs = [to_dev_nhwc(unit_input(f"rtd{i}", s)) for i, s in enumerate([(2, 16, 8, 8), (2, 32, 4, 4), (2, 64, 2, 2)])]
+    with torch.no_grad():
+        y = r(xs)[0]
+    torch.cuda.synchronize()
+    assert y.shape == (2, 10, 84)
+    assert np.abs(y.cpu().numpy() - G["rtdetr_decoder_small"]).max() <= 1e-4
+
+
+def test_msdeform_attn_matches_golden(golden_dir):
+    from tests.hip_utils import DEV, unit_input
+    from ultralytics_pro_amd.nn.modules.rtdetr import MSDeformAttn
+    G = np.load(golden_dir / "ops_unit.npz")
+    m = MSDeformAttn(32, 3, 4, 4).eval()
+    P.apply_procedural_weights(m)
+    m = m.to(DEV)
+    q = unit_input("msda_q", (2, 10, 32)).to(DEV)
+    ref_b = unit_input("msda_ref", (2, 10, 1, 4), 0.1, 0.9).to(DEV)
+    val = unit_input("msda_v", (2, 84, 32))
+    # level-major token rows: [all images of level 0 | level 1 | level 2]
+    shapes = [[8, 8], [4, 4], [2, 2]]
+    parts, t0 = [], 0
+    for h, w in shapes:
+        parts.append(val[:, t0: t0 + h * w].reshape(-1, 32))
+        t0 += h * w
+    value_rows = torch.cat(parts, 0).contiguous().to(DEV)
+    shp = torch.tensor([d for s_ in shapes for d in s_], dtype=torch.int32)
+    with torch.no_grad():
+        y = m(q.reshape(20, 32).contiguous(), ref_b.reshape(20, 4).contiguous(), value_rows, {"host_ptr": shp.data_ptr()}, 2)
+    torch.cuda.synchronize()
+    assert np.abs(y.cpu().numpy().reshape(2, 10, 32) - G["msdeform_attn"]).max() <= 1e-5
+
+
 def _nms_names(g):
     return sorted(k[:-5] for k in g.files if k.endswith("_pred"))
 

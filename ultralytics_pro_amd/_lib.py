@@ -40,7 +40,18 @@ PROTOTYPES = {
     "upa_detect_decode": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _i, _i, _vp]),
     "upa_nms_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "upa_nms_batched": (_i, [_vp, _i, _i, _i, _f, _f, _i, _i, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "upa_mhsa": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
+    "upa_mhsa": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _i, _vp]),
+    "upa_linear": (_i, [_vp, C.c_long, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp]),
+    "upa_layer_norm": (_i, [_vp, _vp, _i, _i, _vp, _vp, _f, _vp, _vp]),
+    "upa_rows_add": (_i, [_vp, _vp, _vp, C.c_long, _i, _vp]),
+    "upa_rows_scale": (_i, [_vp, _vp, _vp, C.c_long, _i, _vp]),
+    "upa_rows_gather": (_i, [_vp, _vp, _vp, C.c_long, _i, _vp]),
+    "upa_topk_tokens": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp]),
+    "upa_box_refine": (_i, [_vp, _vp, _vp, C.c_long, _vp]),
+    "upa_box_add_anchors": (_i, [_vp, _vp, _vp, _vp, C.c_long, _vp]),
+    "upa_sigmoid": (_i, [_vp, _vp, C.c_long, _vp]),
+    "upa_rtdetr_output": (_i, [_vp, _vp, _vp, C.c_long, _i, _vp]),
+    "upa_msdeform_attn": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "upa_graph_begin": (_i, [_vp]),
     "upa_graph_end": (_i, [_vp, C.POINTER(_vp)]),
     "upa_graph_launch": (_i, [_vp, _vp]),

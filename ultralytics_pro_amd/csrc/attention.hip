@@ -1,6 +1,8 @@
 // MHSA core of the BoT3 block: per (image, head) dense self-attention over the L = H*W pixels of a feature map,
 //   energy[p][q] = sum_i Q[i][p] K[i][q]   (NOT scaled by 1/sqrt(d)),  attn = softmax_q(energy),
 //   out[i][p]    = sum_q V[i][q] attn[p][q]                                  (+ residual, BottleneckTransformer)
+// The same kernel is the core of nn.MultiheadAttention in the RT-DETR decoder (scale = 1/sqrt(d), 300 queries,
+// transformer.py:670-673): there "pixels" are query tokens.
 // Replaces torch.matmul / Softmax / matmul of MHSA.forward (ultralytics/nn/modules/block.py:6036-6062) and the
 // `x + ...` of BottleneckTransformer.forward (:6090-6091).  q/k/v come from three 1x1 convs written into one NHWC
 // buffer (channels [q | k | v]), so a (pixel, head) row is d contiguous elements.
@@ -12,7 +14,7 @@
 
 template <typename T, int D>
 __global__ __launch_bounds__(128) void mhsa_kernel(const char* q, const char* k, const char* v, int ld, int L, int heads,
-                                                   const char* res, int ldr, char* y, int ldy) {
+                                                   const char* res, int ldr, char* y, int ldy, float scale) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
   T* ks = reinterpret_cast<T*>(sm);  // [L][D]
   T* vs = ks + (size_t)L * D;        // [L][D]
@@ -43,7 +45,7 @@ __global__ __launch_bounds__(128) void mhsa_kernel(const char* q, const char* k,
     const T* qp = reinterpret_cast<const T*>(q + ((pix0 + p) * ld + h * D) * sizeof(T));
 #pragma unroll
     for (int i = 0; i < D; ++i) {
-      qr[i] = ElemTraits<T>::load(qp + i);
+      qr[i] = ElemTraits<T>::load(qp + i) * scale;  // nn.MultiheadAttention scales q; BoT3's MHSA passes 1.0
       o[i] = 0.f;
     }
   }
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(128) void mhsa_kernel(const char* q, const char* k,
 
 template <typename T, int D>
 static int launch_mhsa(const void* q, const void* k, const void* v, int ld, int n, int hw, int heads, const void* residual,
-                       int ldr, void* y, int ldy, hipStream_t s) {
+                       int ldr, void* y, int ldy, float scale, hipStream_t s) {
   const size_t lds = (size_t)2 * hw * D * sizeof(T);
   if (lds > 150 * 1024) {
     upa_set_error("mhsa: %d keys x %d dims do not fit LDS", hw, D);
@@ -86,21 +88,21 @@ static int launch_mhsa(const void* q, const void* k, const void* v, int ld, int 
   auto kern = mhsa_kernel<T, D>;
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kern, grid, dim3(128), lds, s, (const char*)q, (const char*)k, (const char*)v, ld, hw, heads,
-                     (const char*)residual, ldr, (char*)y, ldy);
+                     (const char*)residual, ldr, (char*)y, ldy, scale);
   UPA_LAUNCH_CHECK();
   return UPA_OK;
 }
 
 extern "C" int upa_mhsa(const void* q, const void* k, const void* v, int ldqkv, int n, int hw, int heads, int d,
-                        const void* residual, int ldr, void* y, int ldy, int dtype, void* stream) {
+                        float scale, const void* residual, int ldr, void* y, int ldy, int dtype, void* stream) {
   UPA_CHECK_ARG(q && k && v && y, "mhsa: null pointer");
   const int es = upa_elem_size(dtype);
   UPA_CHECK_ARG(ldqkv % (16 / es) == 0 && ldy % (16 / es) == 0, "mhsa: strides must be multiples of 16 bytes");
   hipStream_t s = (hipStream_t)stream;
 #define UPA_MHSA_CASE(DD)                                                                                         \
   if (d == DD)                                                                                                    \
-    return dtype == UPA_BF16 ? launch_mhsa<bf16_t, DD>(q, k, v, ldqkv, n, hw, heads, residual, ldr, y, ldy, s)     \
-                             : launch_mhsa<float, DD>(q, k, v, ldqkv, n, hw, heads, residual, ldr, y, ldy, s);
+    return dtype == UPA_BF16 ? launch_mhsa<bf16_t, DD>(q, k, v, ldqkv, n, hw, heads, residual, ldr, y, ldy, scale, s)     \
+                             : launch_mhsa<float, DD>(q, k, v, ldqkv, n, hw, heads, residual, ldr, y, ldy, scale, s);
   UPA_MHSA_CASE(4)
   UPA_MHSA_CASE(8)
   UPA_MHSA_CASE(16)

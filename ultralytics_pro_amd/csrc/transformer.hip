@@ -1,0 +1,329 @@
+// Row-wise f32 kernels of the RT-DETR decoder head (ultralytics/nn/modules/head.py:1905-2224, transformer.py:438-773).
+// The GEMMs (nn.Linear) run on the MFMA conv kernel as 1x1 convolutions over token rows (upa_linear below); this file
+// holds what is left: LayerNorm (+ residual), query selection top-k, row gather / mask, the multi-scale deformable
+// bilinear sampling, and the small box arithmetic.  All HBM/latency-bound; one wave or one lane per row.
+#include "common.h"
+
+typedef unsigned long long u64;
+
+// ---------------------------------------------------------------------------------------------------------------------
+// y = LayerNorm(x (+ r)) * gamma + beta, one wave per row (nn.LayerNorm, transformer.py:660-685; head.py:1998)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layer_norm_kernel(const float* x, const float* r, const float* gamma,
+                                                         const float* beta, float eps, float* y, int M, int C) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float* xr = x + (size_t)row * C;
+  const float* rr = r ? r + (size_t)row * C : nullptr;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += xr[c] + (rr ? rr[c] : 0.f);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s / (float)C;
+  float v = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float d = xr[c] + (rr ? rr[c] : 0.f) - mean;
+    v += d * d;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  const float rstd = 1.0f / sqrtf(v / (float)C + eps);
+  float* yr = y + (size_t)row * C;
+  for (int c = lane; c < C; c += 64) yr[c] = (xr[c] + (rr ? rr[c] : 0.f) - mean) * rstd * gamma[c] + beta[c];
+}
+
+extern "C" int upa_layer_norm(const float* x, const float* residual, int m, int c, const float* gamma, const float* beta,
+                              float eps, float* y, void* stream) {
+  UPA_CHECK_ARG(x && gamma && beta && y && m > 0 && c > 0, "layer_norm: bad args");
+  hipLaunchKernelGGL(layer_norm_kernel, dim3((unsigned)cdiv(m, 4)), dim3(256), 0, (hipStream_t)stream, x, residual, gamma,
+                     beta, eps, y, m, c);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Row utilities: y = a + b ; y = x * mask[row] ; y[i] = x[idx[i]]
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rows_kernel(int mode, const float* a, const float* b, const int* idx, float* y,
+                                                   long M, int C) {
+  const long total = M * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long row = i / C;
+    const int c = (int)(i - row * C);
+    if (mode == 0) y[i] = a[i] + b[i];
+    else if (mode == 1) y[i] = a[i] * b[row];
+    else y[i] = a[(size_t)idx[row] * C + c];
+  }
+}
+
+static unsigned rows_grid(long total) {
+  long g = (total + 255) / 256;
+  return (unsigned)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+
+extern "C" int upa_rows_add(const float* a, const float* b, float* y, long m, int c, void* stream) {
+  UPA_CHECK_ARG(a && b && y, "rows_add: null pointer");
+  hipLaunchKernelGGL(rows_kernel, dim3(rows_grid(m * c)), dim3(256), 0, (hipStream_t)stream, 0, a, b, nullptr, y, m, c);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+extern "C" int upa_rows_scale(const float* x, const float* row_scale, float* y, long m, int c, void* stream) {
+  UPA_CHECK_ARG(x && row_scale && y, "rows_scale: null pointer");
+  hipLaunchKernelGGL(rows_kernel, dim3(rows_grid(m * c)), dim3(256), 0, (hipStream_t)stream, 1, x, row_scale, nullptr, y, m,
+                     c);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+extern "C" int upa_rows_gather(const float* x, const int32_t* row_idx, float* y, long m_out, int c, void* stream) {
+  UPA_CHECK_ARG(x && row_idx && y, "rows_gather: null pointer");
+  hipLaunchKernelGGL(rows_kernel, dim3(rows_grid(m_out * c)), dim3(256), 0, (hipStream_t)stream, 2, x, nullptr, row_idx, y,
+                     m_out, c);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Query selection: per image, top-k tokens by max class logit (head.py:2175).  Tokens are stored level-major
+// (row = lvl_row0[l] + b*lvl_hw[l] + p); the reference's token index t = lvl_tok0[l] + p orders ties (lower t first).
+// One 1024-thread workgroup per image: row max -> 64-bit keys -> LDS bitonic sort -> first k.
+// ---------------------------------------------------------------------------------------------------------------------
+struct LevelTable {
+  int n_levels;
+  int hw[4];
+  int row0[4];  // first row of the level in the level-major token matrix
+  int tok0[4];  // first reference token index of the level
+};
+
+__global__ __launch_bounds__(1024) void topk_tokens_kernel(const float* scores, int nc, LevelTable lt, int B, int T, int K,
+                                                           int npad, int32_t* out_rows, int32_t* out_tok) {
+  extern __shared__ __attribute__((aligned(16))) u64 keys[];
+  const int b = blockIdx.x;
+  for (int t = threadIdx.x; t < npad; t += 1024) {
+    u64 key = ~0ull;
+    if (t < T) {
+      int l = 0;
+      while (l + 1 < lt.n_levels && t >= lt.tok0[l + 1]) ++l;
+      const int p = t - lt.tok0[l];
+      const size_t row = (size_t)lt.row0[l] + (size_t)b * lt.hw[l] + p;
+      const float* s = scores + row * nc;
+      float m = s[0];
+      for (int c = 1; c < nc; ++c) m = fmaxf(m, s[c]);
+      // order-preserving float -> uint (handles negatives), descending
+      unsigned u = __float_as_uint(m);
+      u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+      key = ((u64)(~u) << 32) | (unsigned)t;
+    }
+    keys[t] = key;
+  }
+  __syncthreads();
+  for (int k = 2; k <= npad; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < (npad >> 1); t += 1024) {
+        const int i = 2 * t - (t & (j - 1));
+        const int l = i + j;
+        const bool up = (i & k) == 0;
+        const u64 x = keys[i], y = keys[l];
+        if ((x > y) == up) { keys[i] = y; keys[l] = x; }
+      }
+      __syncthreads();
+    }
+  }
+  for (int q = threadIdx.x; q < K; q += 1024) {
+    const int t = (int)(keys[q] & 0xFFFFFFFFull);
+    int l = 0;
+    while (l + 1 < lt.n_levels && t >= lt.tok0[l + 1]) ++l;
+    out_rows[(size_t)b * K + q] = lt.row0[l] + b * lt.hw[l] + (t - lt.tok0[l]);
+    out_tok[(size_t)b * K + q] = t;
+  }
+}
+
+extern "C" int upa_topk_tokens(const float* scores, int nc, int n_levels, const int32_t* level_hw, int b, int k,
+                               int32_t* out_rows, int32_t* out_tok, void* stream) {
+  UPA_CHECK_ARG(scores && level_hw && out_rows && out_tok && n_levels >= 1 && n_levels <= 4, "topk_tokens: bad args");
+  LevelTable lt;
+  lt.n_levels = n_levels;
+  int tok = 0, row = 0;
+  for (int l = 0; l < n_levels; ++l) {
+    lt.hw[l] = level_hw[l];
+    lt.tok0[l] = tok;
+    lt.row0[l] = row;
+    tok += level_hw[l];
+    row += level_hw[l] * b;
+  }
+  for (int l = n_levels; l < 4; ++l) lt.hw[l] = lt.tok0[l] = lt.row0[l] = 0;
+  const int T = tok;
+  UPA_CHECK_ARG(k <= T, "topk_tokens: k > tokens");
+  int npad = 2;
+  while (npad < T) npad <<= 1;
+  const size_t lds = (size_t)npad * 8;
+  UPA_CHECK_ARG(lds <= 150 * 1024, "topk_tokens: %d tokens do not fit LDS", T);
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)topk_tokens_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(topk_tokens_kernel, dim3((unsigned)b), dim3(1024), lds, (hipStream_t)stream, scores, nc, lt, b, T, k,
+                     npad, out_rows, out_tok);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Box arithmetic.  mode 0: y = sigmoid(d + inverse_sigmoid(ref))   (transformer.py:756-757, nn/modules/utils.py:79-100)
+//                  mode 1: y = d + anchors[tok]  (logit-space reference boxes, head.py:2183)   mode 2: y = sigmoid(x)
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + expf(-v)); }
+__device__ __forceinline__ float inv_sigmoid_f(float x, float eps) {
+  x = fminf(fmaxf(x, 0.f), 1.f);
+  const float x1 = fmaxf(x, eps), x2 = fmaxf(1.f - x, eps);
+  return logf(x1 / x2);
+}
+
+__global__ __launch_bounds__(256) void box_kernel(int mode, const float* d, const float* ref, const int32_t* tok,
+                                                  const float* anchors, float* y, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  if (mode == 0) y[i] = sigmoid_f(d[i] + inv_sigmoid_f(ref[i], 1e-5f));
+  else if (mode == 1) y[i] = d[i] + anchors[(size_t)tok[i >> 2] * 4 + (i & 3)];
+  else y[i] = sigmoid_f(d[i]);
+}
+
+extern "C" int upa_box_refine(const float* delta, const float* ref, float* y, long n_boxes, void* stream) {
+  UPA_CHECK_ARG(delta && ref && y, "box_refine: null pointer");
+  hipLaunchKernelGGL(box_kernel, dim3((unsigned)cdiv((int)(n_boxes * 4), 256)), dim3(256), 0, (hipStream_t)stream, 0, delta,
+                     ref, nullptr, nullptr, y, n_boxes * 4);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+extern "C" int upa_box_add_anchors(const float* delta, const int32_t* tok, const float* anchors, float* y, long n_boxes,
+                                   void* stream) {
+  UPA_CHECK_ARG(delta && tok && anchors && y, "box_add_anchors: null pointer");
+  hipLaunchKernelGGL(box_kernel, dim3((unsigned)cdiv((int)(n_boxes * 4), 256)), dim3(256), 0, (hipStream_t)stream, 1, delta,
+                     nullptr, tok, anchors, y, n_boxes * 4);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+extern "C" int upa_sigmoid(const float* x, float* y, long n, void* stream) {
+  UPA_CHECK_ARG(x && y, "sigmoid: null pointer");
+  hipLaunchKernelGGL(box_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, 2, x, nullptr, nullptr,
+                     nullptr, y, n);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+// y[m, 0:4] = boxes[m], y[m, 4:4+nc] = sigmoid(scores[m])        (head.py:2074)
+__global__ __launch_bounds__(256) void rtdetr_output_kernel(const float* boxes, const float* scores, float* y, long M,
+                                                            int nc) {
+  const int no = 4 + nc;
+  const long total = M * no;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long m = i / no;
+    const int c = (int)(i - m * no);
+    y[i] = c < 4 ? boxes[m * 4 + c] : sigmoid_f(scores[m * nc + (c - 4)]);
+  }
+}
+extern "C" int upa_rtdetr_output(const float* boxes, const float* scores, float* y, long m, int nc, void* stream) {
+  UPA_CHECK_ARG(boxes && scores && y, "rtdetr_output: null pointer");
+  hipLaunchKernelGGL(rtdetr_output_kernel, dim3(rows_grid(m * (4 + nc))), dim3(256), 0, (hipStream_t)stream, boxes, scores,
+                     y, m, nc);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Multi-scale deformable attention sampling (nn/modules/utils.py:103-159 + transformer.py:540-556, 4-d reference boxes):
+//   for (b, q, head): w = softmax over (levels x points) of the attention logits;
+//   loc = ref_xy + off / n_points * ref_wh * 0.5 ; bilinear sample (align_corners=False, zero padding) of the value map
+//   of each level; out[b,q,head,:] = sum_{l,p} w * sample.
+// Half a wave (32 lanes = the 32 channels of one head) per (b, q, head): every corner fetch is one 128-byte line.
+// value rows are level-major: row(l, b, y, x) = row0[l] + (b*H_l + y)*W_l + x, width = heads*D.
+// ---------------------------------------------------------------------------------------------------------------------
+struct DeformLevels {
+  int n_levels;
+  int h[4], w[4], row0[4];
+};
+
+template <int D, int NP>
+__global__ __launch_bounds__(256) void msdeform_kernel(const float* value, DeformLevels lv, int B, int LQ, int heads,
+                                                       const float* offsets, const float* logits, const float* ref,
+                                                       float* y) {
+  static_assert(256 % D == 0, "D lanes per (b, q, head) item");
+  const long item = (long)blockIdx.x * (256 / D) + (threadIdx.x / D);  // (b, q, head)
+  const int ch = threadIdx.x % D;
+  const long total = (long)B * LQ * heads;
+  if (item >= total) return;
+  const int head = (int)(item % heads);
+  const long bq = item / heads;
+  const int b = (int)(bq / LQ);
+  const int NLP = lv.n_levels * NP;
+  const float* lg = logits + bq * (heads * NLP) + head * NLP;
+  const float* of = offsets + bq * (heads * NLP * 2) + head * NLP * 2;
+  const float rx = ref[bq * 4 + 0], ry = ref[bq * 4 + 1], rw = ref[bq * 4 + 2], rh = ref[bq * 4 + 3];
+  float mx = lg[0];
+  for (int i = 1; i < NLP; ++i) mx = fmaxf(mx, lg[i]);
+  float den = 0.f;
+  for (int i = 0; i < NLP; ++i) den += expf(lg[i] - mx);
+  const int C = heads * D;
+  float acc = 0.f;
+  for (int l = 0; l < lv.n_levels; ++l) {
+    const int H = lv.h[l], W = lv.w[l];
+    const float* vbase = value + ((size_t)lv.row0[l] + (size_t)b * H * W) * C + head * D + ch;
+    for (int p = 0; p < NP; ++p) {
+      const int i = l * NP + p;
+      const float wgt = expf(lg[i] - mx) / den;
+      const float lx = rx + of[2 * i] / (float)NP * rw * 0.5f;
+      const float ly = ry + of[2 * i + 1] / (float)NP * rh * 0.5f;
+      // grid_sample(align_corners=False): grid = 2*loc-1 -> pixel = ((grid+1)*size-1)/2
+      const float gx = 2.f * lx - 1.f, gy = 2.f * ly - 1.f;
+      const float ix = ((gx + 1.f) * (float)W - 1.f) / 2.f, iy = ((gy + 1.f) * (float)H - 1.f) / 2.f;
+      const float x0f = floorf(ix), y0f = floorf(iy);
+      const int x0 = (int)x0f, y0 = (int)y0f;
+      const float tx = ix - x0f, ty = iy - y0f;
+      float s = 0.f;
+      const bool xin0 = x0 >= 0 && x0 < W, xin1 = x0 + 1 >= 0 && x0 + 1 < W;
+      const bool yin0 = y0 >= 0 && y0 < H, yin1 = y0 + 1 >= 0 && y0 + 1 < H;
+      if (yin0 && xin0) s += vbase[((size_t)y0 * W + x0) * C] * (1.f - tx) * (1.f - ty);
+      if (yin0 && xin1) s += vbase[((size_t)y0 * W + x0 + 1) * C] * tx * (1.f - ty);
+      if (yin1 && xin0) s += vbase[((size_t)(y0 + 1) * W + x0) * C] * (1.f - tx) * ty;
+      if (yin1 && xin1) s += vbase[((size_t)(y0 + 1) * W + x0 + 1) * C] * tx * ty;
+      acc += wgt * s;
+    }
+  }
+  y[bq * C + head * D + ch] = acc;
+}
+
+extern "C" int upa_msdeform_attn(const float* value, const int32_t* shapes_hw, int n_levels, int b, int heads, int d,
+                                 const float* offsets, const float* attn_logits, const float* ref_boxes, int len_q,
+                                 int n_points, float* y, void* stream) {
+  UPA_CHECK_ARG(value && shapes_hw && offsets && attn_logits && ref_boxes && y, "msdeform_attn: null pointer");
+  UPA_CHECK_ARG(n_levels >= 1 && n_levels <= 4 && (d == 32 || d == 8) && n_points == 4,
+                "msdeform_attn: supports <=4 levels, head dim 32 (or 8), 4 points (head.py:1951-1961)");
+  DeformLevels lv;
+  lv.n_levels = n_levels;
+  int row = 0;
+  for (int l = 0; l < 4; ++l) {
+    lv.h[l] = l < n_levels ? shapes_hw[2 * l] : 0;
+    lv.w[l] = l < n_levels ? shapes_hw[2 * l + 1] : 0;
+    lv.row0[l] = row;
+    row += lv.h[l] * lv.w[l] * b;
+  }
+  const long items = (long)b * len_q * heads;
+  if (d == 32)
+    hipLaunchKernelGGL((msdeform_kernel<32, 4>), dim3((unsigned)((items + 7) / 8)), dim3(256), 0, (hipStream_t)stream, value,
+                       lv, b, len_q, heads, offsets, attn_logits, ref_boxes, y);
+  else
+    hipLaunchKernelGGL((msdeform_kernel<8, 4>), dim3((unsigned)((items + 31) / 32)), dim3(256), 0, (hipStream_t)stream, value,
+                       lv, b, len_q, heads, offsets, attn_logits, ref_boxes, y);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// nn.Linear on token rows = 1x1 convolution over a (1, 1, M, K) NHWC view on the f32 MFMA kernel (exact f32 chain).
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" int upa_conv2d_bias_act(const void*, int, int, int, int, int, const void*, const float*, void*, int, int,
+                                   const void*, int, int, int, int, int, int, void*);
+
+extern "C" int upa_linear(const float* x, long m, int k, int ldx, const void* w_packed, const float* bias, float* y, int n,
+                          int ldy, const float* residual, int ldr, int act, void* stream) {
+  UPA_CHECK_ARG(m > 0 && m < (1L << 31), "linear: bad row count");
+  return upa_conv2d_bias_act(x, 1, 1, (int)m, k, ldx, w_packed, bias, y, n, ldy, residual, ldr, 1, 1, 0, act, UPA_F32, stream);
+}

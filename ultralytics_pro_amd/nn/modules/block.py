@@ -146,7 +146,8 @@ class MHSA(nn.Module, _HipConvMixin):
             rp, rld = vr.ptr, vr.ld
         esz = x.element_size()
         L.check(L.lib().upa_mhsa(vq.ptr, vq.ptr + c * esz, vq.ptr + 2 * c * esz, vq.ld, n, h * w, self.heads,
-                                 c // self.heads, rp, rld, vy.ptr, vy.ld, vq.dtype, L.current_stream(x.device)), "mhsa")
+                                 c // self.heads, 1.0, rp, rld, vy.ptr, vy.ld, vq.dtype, L.current_stream(x.device)),
+                "mhsa")
         return y
 
 
