@@ -258,7 +258,8 @@ def test_nms_large_multilabel_vs_oracle():
     """> max_nms candidates (radix select + global bitonic path) and ragged per-image counts, vs the oracle."""
     from tests.hip_utils import DEV
     from ultralytics_pro_amd.utils.nms import non_max_suppression
-    n = 3000
+    torch.set_num_threads(4)  # the oracle's Python NMS loop crawls when oversubscribed on the 256-core GPU host
+    n = 1200
     p = torch.zeros(3, 84, n)
     u = P.uniform("nmsbig:box", (3, 4, n), 0, 1)
     p[:, 0] = u[:, 0] * 600 + 20
@@ -267,8 +268,8 @@ def test_nms_large_multilabel_vs_oracle():
     p[:, 3] = u[:, 3] * 60 + 10
     p[:, 4:] = P.uniform("nmsbig:cls", (3, 80, n), 0, 1) ** 4
     p[2, 4:, 100:] = 0  # ragged: third image has few candidates
-    for kw in (dict(conf_thres=0.001, iou_thres=0.7, multi_label=True, max_det=300, max_nms=30000),
-               dict(conf_thres=0.05, iou_thres=0.5, multi_label=True, max_det=100, max_nms=5000),
+    for kw in (dict(conf_thres=0.001, iou_thres=0.7, multi_label=True, max_det=300, max_nms=30000),  # > LDS sort cap
+               dict(conf_thres=0.05, iou_thres=0.5, multi_label=True, max_det=100, max_nms=2000),    # radix select
                dict(conf_thres=0.25, iou_thres=0.45)):
         ref = onms.non_max_suppression(p.clone(), **kw)
         out = non_max_suppression(p.to(DEV), **kw)

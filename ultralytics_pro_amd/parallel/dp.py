@@ -1,0 +1,61 @@
+"""Batch-sharded data parallelism for the inference / validate path: one process per GPU, weights replicated, images
+sharded, NO collective inside the forward path.  The only exchanges are end-of-run ones:
+
+* `max_over_ranks`  - the bench's step time (max over ranks), one scalar all-reduce;
+* `gather_detections` - the validator's end-of-run gather of per-image detections to every rank. The reference pickles
+  Python lists through `dist.gather_object` (models/yolo/detect/val.py:225-240); here the NMS kernel already produces
+  fixed-shape `(B, max_det, 6)` + counts tensors, so it is two `all_gather_into_tensor` calls on RCCL (backend "nccl"
+  on ROCm; "gloo" in the CPU tests), no pickling, no host round trip.
+"""
+
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend: str | None = None) -> tuple[int, int, int]:
+    """(rank, world, local_rank) from the torchrun environment; initialises the default group when world > 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group(backend=backend)
+    return rank, world, local
+
+
+def shard_first_image(rank: int, per_rank_batch: int) -> int:
+    """Index of the first image of `rank`'s shard in the global (procedural) image stream: weak scaling keeps the
+    per-GPU batch fixed (trainer.py:317 divides the global batch instead; `bench.py` reports `scaling: weak`)."""
+    return rank * per_rank_batch
+
+
+def max_over_ranks(seconds: float, device=None) -> float:
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_detections(out: torch.Tensor, counts: torch.Tensor):
+    """All-gather fixed-shape NMS outputs: (B, max_det, 6), (B,) per rank -> (world*B, max_det, 6), (world*B,)
+    ordered by rank, i.e. by global image index for shards made with `shard_first_image`."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return out, counts
+    world = dist.get_world_size()
+    g_out = torch.empty((world * out.shape[0], *out.shape[1:]), dtype=out.dtype, device=out.device)
+    g_cnt = torch.empty((world * counts.shape[0],), dtype=counts.dtype, device=counts.device)
+    dist.all_gather_into_tensor(g_out, out.contiguous())
+    dist.all_gather_into_tensor(g_cnt, counts.contiguous())
+    return g_out, g_cnt
