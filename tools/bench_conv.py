@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--only", default="", help="cin,cout,k,H filter, e.g. 64,64,3,80")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -52,8 +53,11 @@ def main():
     torch.cuda.synchronize()
     agg = {}
     tot_ms = tot_fl = tot_by = 0.0
+    only = tuple(int(v) for v in args.only.split(",")) if args.only else None
     for (xx, pk, stride, pad, act, y, residual, odt) in calls:
         n, cin, h, w = xx.shape
+        if only and (cin, pk.cout, pk.k, h) != only:
+            continue
         oh, ow = y.shape[2], y.shape[3]
         fl = 2.0 * n * oh * ow * pk.cout * cin * pk.k * pk.k
         by = n * h * w * cin * xx.element_size() + n * oh * ow * pk.cout * es * (2 if residual is not None else 1) + \

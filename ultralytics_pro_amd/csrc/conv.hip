@@ -41,6 +41,9 @@ struct ConvParams {
   int act;
   int IH, IW, PS;  // halo tile dims, LDS pixel stride in bytes
   unsigned magicIW;  // ceil(2^32 / IW)
+  int tw_shift;      // log2(TW): tile widths are powers of two
+  int stageRows;     // halo rows covered per staging pass = NTHREADS / (IW * G16) (>= 1)
+  int ablate;        // debug: 1 = no input loads, 2 = no weight loads, 4 = no stores, 8 = no MFMA
 };
 
 template <bool PRECISE, int ACT>
@@ -97,18 +100,24 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
 #pragma unroll
   for (int i = 0; i < MTW; ++i) {
     const int pp = (wm * MTW + i) * 16 + r;
-    const int ty = pp / p.TW;
-    const int tx = pp - ty * p.TW;
+    const int ty = pp >> p.tw_shift;
+    const int tx = pp & (p.TW - 1);
     pty[i] = ty;
     ptx[i] = tx;
     pixbase[i] = ((ty * p.stride) * p.IW + tx * p.stride) * p.PS + g * 16;
   }
 
   const int nChunks = p.KTT / CKT;
-  const int haloItems = p.IH * p.IW * G16;
   const size_t wTileStride = (size_t)p.NTn * 1024;  // bytes per (tap, ktile)
   const char* wlane = p.w + (size_t)nt0 * 1024 + lane * 16;
   const int taps = p.KS * p.KS;
+  // staging coordinates of this thread (fixed for the whole kernel): the halo tile is a grid of rows x
+  // (IW * G16) 16-byte columns; threads tile it as stageRows x colSpan and stride over it without any division
+  const int scolsPerRow = p.IW * G16;
+  const int colSpan = scolsPerRow < NTHREADS ? scolsPerRow : NTHREADS;
+  const int srow0 = tid / colSpan;  // one division per thread, outside every loop
+  const int scol0 = tid - srow0 * colSpan;
+  const bool sthread_valid = srow0 < p.stageRows;
 
   // Weight fragments of one tap (CKT k-tiles x NTW n-tiles) live in registers, ping-pong buffered: while the MFMAs of
   // tap t run from one buffer, the 1 KiB-per-wave coalesced loads of tap t+1 (or of the next chunk's first tap - they
@@ -116,12 +125,16 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
   u32x4 A0[CKT][NTW], A1[CKT][NTW];
   auto fetch_tap = [&](u32x4(&dst)[CKT][NTW], int c, int tap) {
     const char* wb = wlane + (size_t)(tap * p.KTT + c * CKT) * wTileStride;
+    if (p.ablate & 2) return;
 #pragma unroll
     for (int kt = 0; kt < CKT; ++kt)
 #pragma unroll
-      for (int j = 0; j < NTW; ++j) dst[kt][j] = *reinterpret_cast<const u32x4*>(wb + kt * wTileStride + j * 1024);
+      for (int j = 0; j < NTW; ++j)  // n-tiles past the packed weights (Cout 80 run as 96) contribute zeros
+        dst[kt][j] = (nt0 + j < p.NTn) ? *reinterpret_cast<const u32x4*>(wb + kt * wTileStride + j * 1024)
+                                       : u32x4{0u, 0u, 0u, 0u};
   };
   auto compute_tap = [&](u32x4(&A)[CKT][NTW], int tapoff) {
+    if (p.ablate & 8) return;
 #pragma unroll
     for (int kt = 0; kt < CKT; ++kt) {
       u32x4 b[MTW];
@@ -167,20 +180,28 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
   for (int c = 0; c < nChunks; ++c) {
     const int c0 = c * CKT * KT_CH;
     if (c > 0) __syncthreads();
-    // ---- stage the halo tile of this channel chunk
-    for (int idx = tid; idx < haloItems; idx += NTHREADS) {
-      const int pix = idx >> G16SHIFT;
-      const int cg = idx & (G16 - 1);
-      const int py = __umulhi((unsigned)pix, p.magicIW);
-      const int px = pix - py * p.IW;
-      const int iy = iy0 + py, ix = ix0 + px;
-      const int ch = c0 + cg * E;
-      u32x4 v = u32x4{0u, 0u, 0u, 0u};
-      if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && ch < p.Cin) {
-        const size_t off = (((size_t)n * p.H + iy) * p.W + ix) * (size_t)p.ldx + ch;
-        v = *reinterpret_cast<const u32x4*>(p.x + off * ES);
+    // ---- stage the halo tile of this channel chunk.  A thread owns one (halo column, 16-byte channel group) and walks
+    // down the rows: no per-item division, addresses advance by a row pitch, two rows of loads are in flight before
+    // the first LDS write.
+    if (sthread_valid) {
+      for (int col = scol0; col < scolsPerRow; col += colSpan) {
+        const int spx = col >> G16SHIFT, scg = col & (G16 - 1);
+        const int six = ix0 + spx;
+        const int ch = c0 + scg * E;
+        const bool ok = six >= 0 && six < p.W && ch < p.Cin && !(p.ablate & 1);
+        const char* gsrc = p.x + ((((size_t)n * p.H) * p.W + six) * (size_t)p.ldx + ch) * ES;
+        const size_t rowPitch = (size_t)p.W * p.ldx * ES;
+        char* ldst = smem + spx * p.PS + scg * 16;
+        for (int py = srow0; py < p.IH; py += 2 * p.stageRows) {
+          const int iyA = iy0 + py, iyB = iyA + p.stageRows;
+          const bool inB = py + p.stageRows < p.IH;
+          u32x4 va = u32x4{0u, 0u, 0u, 0u}, vb = va;
+          if (ok && iyA >= 0 && iyA < p.H) va = *reinterpret_cast<const u32x4*>(gsrc + (size_t)iyA * rowPitch);
+          if (ok && inB && iyB >= 0 && iyB < p.H) vb = *reinterpret_cast<const u32x4*>(gsrc + (size_t)iyB * rowPitch);
+          *reinterpret_cast<u32x4*>(ldst + py * p.IW * p.PS) = va;
+          if (inB) *reinterpret_cast<u32x4*>(ldst + (py + p.stageRows) * p.IW * p.PS) = vb;
+        }
       }
-      *reinterpret_cast<u32x4*>(smem + pix * p.PS + cg * 16) = v;
     }
     __syncthreads();
     // ---- taps, two per trip (ping-pong)
@@ -225,44 +246,69 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
     }
   }
 
-  // ---- epilogue: bias + act (+ residual) -> NHWC store; lane holds channels co..co+3 of pixel (col r)
-  auto epilogue = [&](auto act_tag) {
+  // ---- epilogue.  Phase 1: every lane writes act(acc + bias) as f32 into an LDS [pixel][channel] tile (the halo
+  // buffer is dead by now).  Phase 2: the workgroup streams the tile out as whole NHWC rows - 16 bytes per lane,
+  // BN*ES contiguous bytes per pixel (128 B for 64 bf16 channels) - adding the residual from equally coalesced loads.
+  // (The direct form stored 8 B per lane in 32-B runs and cost 25 % of the conv time.)
+  constexpr int BNB = WN * NTW * 16;        // channels per workgroup
+  constexpr int OROW = BNB + 4;             // f32 row stride in LDS (pad 16 B)
+  float* otile = reinterpret_cast<float*>(smem);
+  __syncthreads();
+  auto phase1 = [&](auto act_tag) {
     constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
     for (int i = 0; i < MTW; ++i) {
-      const int oy = oy0 + pty[i], ox = ox0 + ptx[i];
-      const bool pvalid = pty[i] < p.TH && oy < p.OH && ox < p.OW;
-      const size_t pixoff = ((size_t)n * p.OH + oy) * p.OW + ox;
+      const int pp = (wm * MTW + i) * 16 + r;
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
-        const int co = (nt0 + j) * 16 + g * 4;
-        if (!pvalid || co >= p.Cout) continue;
-        float v[4];
+        const int cb = (wn * NTW + j) * 16 + g * 4;
+        f32x4 v;
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = act_fn<ES == 4, ACT>(acc[i][j][q] + biasv[j][q]);
-        if constexpr (ES == 4) {
-          if (p.res) {
-            const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + (pixoff * p.ldr + co) * 4);
-            v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3];
-          }
-          *reinterpret_cast<f32x4*>(p.y + (pixoff * p.ldy + co) * 4) = f32x4{v[0], v[1], v[2], v[3]};
-        } else {
-          if (p.res) {
-            const u32x2 rv = *reinterpret_cast<const u32x2*>(p.res + (pixoff * p.ldr + co) * 2);
-            v[0] += __uint_as_float(rv[0] << 16);
-            v[1] += __uint_as_float(rv[0] & 0xFFFF0000u);
-            v[2] += __uint_as_float(rv[1] << 16);
-            v[3] += __uint_as_float(rv[1] & 0xFFFF0000u);
-          }
-          *reinterpret_cast<u32x2*>(p.y + (pixoff * p.ldy + co) * 2) =
-              u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-        }
+        *reinterpret_cast<f32x4*>(otile + pp * OROW + cb) = v;
       }
     }
   };
-  if (p.act == UPA_ACT_SILU) epilogue(std::integral_constant<int, UPA_ACT_SILU>{});
-  else if (p.act == UPA_ACT_RELU) epilogue(std::integral_constant<int, UPA_ACT_RELU>{});
-  else epilogue(std::integral_constant<int, UPA_ACT_NONE>{});
+  if (p.act == UPA_ACT_SILU) phase1(std::integral_constant<int, UPA_ACT_SILU>{});
+  else if (p.act == UPA_ACT_RELU) phase1(std::integral_constant<int, UPA_ACT_RELU>{});
+  else phase1(std::integral_constant<int, UPA_ACT_NONE>{});
+  __syncthreads();
+  {
+    constexpr int GPP = BNB / E;            // 16-byte output groups per pixel
+    constexpr int BMP = WM * MTW * 16;      // pixels per workgroup
+    const int cbase = blockIdx.y * BNB;
+#pragma unroll 2
+    for (int idx = tid; idx < BMP * GPP; idx += NTHREADS) {
+      const int pp = idx / GPP, gq = idx - pp * GPP;   // GPP is a compile-time constant
+      const int ty = pp >> p.tw_shift, tx = pp & (p.TW - 1);
+      const int oy = oy0 + ty, ox = ox0 + tx;
+      const int co = cbase + gq * E;
+      if (ty >= p.TH || oy >= p.OH || ox >= p.OW || co >= p.Cout || (p.ablate & 4)) continue;
+      const size_t pixoff = ((size_t)n * p.OH + oy) * p.OW + ox;
+      const float* src = otile + pp * OROW + gq * E;
+      if constexpr (ES == 4) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(src);
+        if (p.res) {
+          const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + (pixoff * p.ldr + co) * 4);
+          v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3];
+        }
+        *reinterpret_cast<f32x4*>(p.y + (pixoff * p.ldy + co) * 4) = v;
+      } else {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+        float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        if (p.res) {
+          const u32x4 rv = *reinterpret_cast<const u32x4*>(p.res + (pixoff * p.ldr + co) * 2);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            v[2 * q] += __uint_as_float(rv[q] << 16);
+            v[2 * q + 1] += __uint_as_float(rv[q] & 0xFFFF0000u);
+          }
+        }
+        *reinterpret_cast<u32x4*>(p.y + (pixoff * p.ldy + co) * 2) =
+            u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -335,11 +381,11 @@ int launch_conv_ckt(ConvParams& p, hipStream_t stream) {
     TH = 1; TW = BM;
   } else {
     TW = p.OW >= 16 ? 16 : 8;
-    if (p.OW % 16 != 0 && p.OW % 20 == 0 && BM % 20 == 0) TW = 20;
-    if (BM % TW != 0) TW = 16;
     TH = BM / TW;
   }
   p.TH = TH; p.TW = TW;
+  p.tw_shift = 0;
+  while ((1 << p.tw_shift) < TW) ++p.tw_shift;
   p.tilesX = cdiv(p.OW, TW);
   p.tilesY = cdiv(p.OH, TH);
   p.IH = (TH - 1) * p.stride + p.KS;
@@ -349,7 +395,11 @@ int launch_conv_ckt(ConvParams& p, hipStream_t stream) {
   const int IHalloc = rowsNeeded > p.IH ? rowsNeeded : p.IH;
   p.PS = p.CKT * 64 + 16;
   p.magicIW = (unsigned)((0x100000000ULL + p.IW - 1) / p.IW);
-  const size_t lds = (size_t)IHalloc * p.IW * p.PS + 64;
+  p.stageRows = (WM * WN * 64) / (p.IW * CKT * 4);
+  if (p.stageRows < 1) p.stageRows = 1;  // halo row wider than the workgroup: threads stride over its columns
+  size_t lds = (size_t)IHalloc * p.IW * p.PS + 64;
+  const size_t ldsOut = (size_t)BM * (BN + 4) * sizeof(float);
+  if (ldsOut > lds) lds = ldsOut;
   if (lds > 160 * 1024) return UPA_EUNSUPPORTED;
   dim3 grid((unsigned)((long)p.tilesX * p.tilesY * p.N), (unsigned)cdiv(p.NTn * 16, BN));
   auto kern = conv_igemm_kernel<T, WM, WN, MTW, NTW, CKT>;
@@ -378,7 +428,12 @@ int dispatch_conv(ConvParams& p, hipStream_t stream) {
   if (ntn == 1) return launch_conv<T, 4, 1, 2, 1>(p, stream);                     // BN=16,  BM=128
   if (ntn == 2) return launch_conv<T, 4, 1, 2, 2>(p, stream);                     // BN=32,  BM=128
   if (ntn == 3) return launch_conv<T, 4, 1, 2, 3>(p, stream);                     // BN=48
-  if (ntn == 5) return launch_conv<T, 4, 1, 2, 5>(p, stream);                     // BN=80,  BM=128
+  if (ntn == 5) {  // Cout = 80 (Detect class branch): run as 96 = 2 x 3 n-tiles, the 6th tile is zero-filled
+    static const int old5 = getenv("UPA_CONV_OLD5") ? atoi(getenv("UPA_CONV_OLD5")) : 0;
+    if (old5) return launch_conv<T, 4, 1, 2, 5>(p, stream);
+    if (M >= 128 * 1024) return launch_conv<T, 2, 2, 4, 3>(p, stream);            // BN=96, BM=128
+    return launch_conv<T, 2, 2, 2, 3>(p, stream);                                 // BN=96, BM=64
+  }
   if (ntn % 4 == 0) {
     if (M >= 128 * 1024 || ntn == 4) return launch_conv<T, 2, 2, 4, 2>(p, stream);  // BN=64, BM=128
     return launch_conv<T, 2, 2, 2, 2>(p, stream);                                 // BN=64, BM=64 (small maps)
@@ -415,8 +470,10 @@ extern "C" int upa_conv2d_bias_act(const void* x, int n, int h, int w, int cin, 
   const int es = upa_elem_size(dtype);
   const int E = 16 / es;
   UPA_CHECK_ARG(cin % E == 0 && ldx % E == 0, "conv2d: cin/ldx must be multiples of %d elements", E);
-  UPA_CHECK_ARG(cout % 4 == 0 && ldy % 4 == 0 && (!residual || ldr % 4 == 0), "conv2d: cout/ldy/ldr % 4 != 0");
-  UPA_CHECK_ARG(g_query_only || (((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 8 == 0)), "conv2d: misaligned view");
+  UPA_CHECK_ARG(cout % E == 0 && ldy % E == 0 && (!residual || ldr % E == 0),
+                "conv2d: cout/ldy/ldr must be multiples of %d elements (16-byte row stores)", E);
+  UPA_CHECK_ARG(g_query_only || (((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) &&
+                                 (!residual || (uintptr_t)residual % 16 == 0)), "conv2d: misaligned view");
   ConvParams p;
   memset(&p, 0, sizeof(p));
   p.x = (const char*)x; p.y = (char*)y; p.res = (const char*)residual; p.w = (const char*)w_packed; p.bias = bias;
@@ -425,6 +482,8 @@ extern "C" int upa_conv2d_bias_act(const void* x, int n, int h, int w, int cin, 
   p.OW = (w + 2 * pad - k) / stride + 1;
   p.Cout = cout; p.ldy = ldy; p.ldr = ldr;
   p.KS = k; p.stride = stride; p.pad = pad; p.act = act;
+  static const int ablate = getenv("UPA_CONV_ABLATE") ? atoi(getenv("UPA_CONV_ABLATE")) : 0;
+  p.ablate = ablate;
   const int ktch = 64 / es;
   p.KTT = cdiv(cin, ktch);
   p.NTn = cdiv(cout, 16);
