@@ -49,7 +49,9 @@ int upa_conv2d_bias_act(const void* x, int n, int h, int w, int cin, int ldx,
 int upa_conv_variant(int n, int h, int w, int cin, int cout, int k, int stride, int pad, int dtype);
 
 /* First layer: reads the model input NCHW (f32 or bf16, 1..4 channels) directly, writes NHWC.   conv.py:188-197
- * w is OIHW f32 on the DEVICE (cout<=64), bias f32[cout] on the device. */
+ * w = device copy of the upa_pack_stem_weight output ([tap][ci][cout padded to 16] f32), bias f32[cout] on the device. */
+size_t upa_stem_packed_weight_bytes(int cout, int cin, int k);
+int upa_pack_stem_weight(const float* w_oihw, int cout, int cin, int k, float* out /* host */);
 int upa_conv2d_stem_nchw(const void* x_nchw, int x_dtype, int n, int cin, int h, int w,
                          const float* w_oihw, const float* bias, void* y, int cout, int ldy,
                          int k, int stride, int pad, int act, int dtype, void* stream);

@@ -29,6 +29,8 @@ PROTOTYPES = {
     "upa_pack_conv_weight": (_i, [_vp, _i, _i, _i, _i, _vp]),
     "upa_conv2d_bias_act": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "upa_conv_variant": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "upa_stem_packed_weight_bytes": (_sz, [_i, _i, _i]),
+    "upa_pack_stem_weight": (_i, [_vp, _i, _i, _i, _vp]),
     "upa_conv2d_stem_nchw": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "upa_maxpool2d": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "upa_sppf_pool3": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),

@@ -46,11 +46,17 @@ struct ConvParams {
   int ablate;        // debug: 1 = no input loads, 2 = no weight loads, 4 = no stores, 8 = no MFMA
 };
 
+// 16 zero bytes in device memory: source of every out-of-image / padded-channel 16-byte group of the halo DMA
+__device__ __attribute__((aligned(16))) unsigned g_zero16[4] = {0u, 0u, 0u, 0u};
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
 template <bool PRECISE, int ACT>
 __device__ __forceinline__ float act_fn(float v) {
   if constexpr (ACT == UPA_ACT_SILU) {
     if constexpr (PRECISE) return v / (1.0f + expf(-v));  // ocml expf (<= 1 ulp) + IEEE divide: f32 parity mode
-    return v * __frcp_rn(1.0f + __expf(-v));
+    return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));  // bf16 perf mode: v_exp_f32 + v_rcp_f32 (1 ulp), no IEEE divide
   } else if constexpr (ACT == UPA_ACT_RELU) {
     return fmaxf(v, 0.0f);
   } else {
@@ -94,7 +100,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
 #pragma unroll
     for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // per-lane LDS byte offset of the top-left tap of its pixel, for each m-tile
+  // per-lane halo-tile pixel index of the top-left tap of its pixel, for each m-tile
   int pixbase[MTW];
   int pty[MTW], ptx[MTW];
 #pragma unroll
@@ -104,21 +110,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
     const int tx = pp & (p.TW - 1);
     pty[i] = ty;
     ptx[i] = tx;
-    pixbase[i] = ((ty * p.stride) * p.IW + tx * p.stride) * p.PS + g * 16;
+    pixbase[i] = (ty * p.stride) * p.IW + tx * p.stride;
   }
 
   const int nChunks = p.KTT / CKT;
   const size_t wTileStride = (size_t)p.NTn * 1024;  // bytes per (tap, ktile)
   const char* wlane = p.w + (size_t)nt0 * 1024 + lane * 16;
   const int taps = p.KS * p.KS;
-  // staging coordinates of this thread (fixed for the whole kernel): the halo tile is a grid of rows x
-  // (IW * G16) 16-byte columns; threads tile it as stageRows x colSpan and stride over it without any division
-  const int scolsPerRow = p.IW * G16;
-  const int colSpan = scolsPerRow < NTHREADS ? scolsPerRow : NTHREADS;
-  const int srow0 = tid / colSpan;  // one division per thread, outside every loop
-  const int scol0 = tid - srow0 * colSpan;
-  const bool sthread_valid = srow0 < p.stageRows;
-
   // Weight fragments of one tap (CKT k-tiles x NTW n-tiles) live in registers, ping-pong buffered: while the MFMAs of
   // tap t run from one buffer, the 1 KiB-per-wave coalesced loads of tap t+1 (or of the next chunk's first tap - they
   // do not depend on the LDS tile) land in the other.
@@ -133,13 +131,23 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
         dst[kt][j] = (nt0 + j < p.NTn) ? *reinterpret_cast<const u32x4*>(wb + kt * wTileStride + j * 1024)
                                        : u32x4{0u, 0u, 0u, 0u};
   };
-  auto compute_tap = [&](u32x4(&A)[CKT][NTW], int tapoff) {
+  // LDS halo image: pixel-major, G16 16-byte slots per pixel, NO padding (the DMA writes 1 KiB contiguous per wave);
+  // the 16-byte group cg of pixel pl sits in slot cg ^ swz(pl): conflict-free ds_read_b128 for CKT 1 / 2 (2-way CKT 4)
+  auto compute_tap = [&](u32x4(&A)[CKT][NTW], int tapshift) {
     if (p.ablate & 8) return;
+    int paddr[MTW], pswz[MTW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+      const int pl = pixbase[i] + tapshift;
+      paddr[i] = pl * (G16 * 16);
+      pswz[i] = (CKT == 1 ? (pl >> 1) : pl) & (G16 - 1);
+    }
 #pragma unroll
     for (int kt = 0; kt < CKT; ++kt) {
       u32x4 b[MTW];
 #pragma unroll
-      for (int i = 0; i < MTW; ++i) b[i] = *reinterpret_cast<const u32x4*>(smem + pixbase[i] + tapoff + kt * 64);
+      for (int i = 0; i < MTW; ++i)
+        b[i] = *reinterpret_cast<const u32x4*>(smem + paddr[i] + (((kt * 4 + g) ^ pswz[i]) << 4));
 #pragma unroll
       for (int i = 0; i < MTW; ++i) {
 #pragma unroll
@@ -180,28 +188,31 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
   for (int c = 0; c < nChunks; ++c) {
     const int c0 = c * CKT * KT_CH;
     if (c > 0) __syncthreads();
-    // ---- stage the halo tile of this channel chunk.  A thread owns one (halo column, 16-byte channel group) and walks
-    // down the rows: no per-item division, addresses advance by a row pitch, two rows of loads are in flight before
-    // the first LDS write.
-    if (sthread_valid) {
-      for (int col = scol0; col < scolsPerRow; col += colSpan) {
-        const int spx = col >> G16SHIFT, scg = col & (G16 - 1);
-        const int six = ix0 + spx;
-        const int ch = c0 + scg * E;
-        const bool ok = six >= 0 && six < p.W && ch < p.Cin && !(p.ablate & 1);
-        const char* gsrc = p.x + ((((size_t)n * p.H) * p.W + six) * (size_t)p.ldx + ch) * ES;
-        const size_t rowPitch = (size_t)p.W * p.ldx * ES;
-        char* ldst = smem + spx * p.PS + scg * 16;
-        for (int py = srow0; py < p.IH; py += 2 * p.stageRows) {
-          const int iyA = iy0 + py, iyB = iyA + p.stageRows;
-          const bool inB = py + p.stageRows < p.IH;
-          u32x4 va = u32x4{0u, 0u, 0u, 0u}, vb = va;
-          if (ok && iyA >= 0 && iyA < p.H) va = *reinterpret_cast<const u32x4*>(gsrc + (size_t)iyA * rowPitch);
-          if (ok && inB && iyB >= 0 && iyB < p.H) vb = *reinterpret_cast<const u32x4*>(gsrc + (size_t)iyB * rowPitch);
-          *reinterpret_cast<u32x4*>(ldst + py * p.IW * p.PS) = va;
-          if (inB) *reinterpret_cast<u32x4*>(ldst + (py + p.stageRows) * p.IW * p.PS) = vb;
-        }
+    // ---- stage the halo tile of this channel chunk by LDS-DMA (global_load_lds_dwordx4): no VGPR data, no ds_write,
+    // every 16-byte item of the tile is in flight at once and the workgroup pays ONE memory round trip (the register
+    // staged form paid five in sequence: 12k of the 29k cycles a wave lived).  Each wave-instruction fills 1 KiB of
+    // contiguous LDS; out-of-image pixels and channels past Cin are sourced from a 16-byte zero page.
+    {
+      const int haloItems = p.IH * p.IW * G16;
+      const int haloPadded = (haloItems + 63) & ~63;
+      const int waveBase = __builtin_amdgcn_readfirstlane(wave * 64);
+      for (int base = 0; base < haloPadded; base += NTHREADS) {
+        const int wbase = base + waveBase;  // first item of this wave-instruction (uniform)
+        if (wbase >= haloPadded) break;
+        const int idx = wbase + lane;
+        const int pix = idx >> G16SHIFT;
+        const int slot = idx & (G16 - 1);
+        const int cg = slot ^ ((CKT == 1 ? (pix >> 1) : pix) & (G16 - 1));
+        const int py = __umulhi((unsigned)pix, p.magicIW);
+        const int px = pix - py * p.IW;
+        const int iy = iy0 + py, ix = ix0 + px;
+        const int ch = c0 + cg * E;
+        const char* src = reinterpret_cast<const char*>(g_zero16);
+        if (idx < haloItems && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && ch < p.Cin && !(p.ablate & 1))
+          src = p.x + ((((size_t)n * p.H + iy) * p.W + ix) * (size_t)p.ldx + ch) * ES;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + wbase * 16), 16, 0, 0);
       }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
     // ---- taps, two per trip (ping-pong)
@@ -210,12 +221,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
       const bool has1 = tap + 1 < taps;
       if (has1) fetch_tap(A1, c, tap + 1);
       else if (c + 1 < nChunks) fetch_tap(A1, c + 1, 0);
-      compute_tap(A0, (kh * p.IW + kw) * p.PS);
+      compute_tap(A0, kh * p.IW + kw);
       if (++kw == p.KS) { kw = 0; ++kh; }
       if (has1) {
         if (tap + 2 < taps) fetch_tap(A0, c, tap + 2);
         else if (c + 1 < nChunks) fetch_tap(A0, c + 1, 0);
-        compute_tap(A1, (kh * p.IW + kw) * p.PS);
+        compute_tap(A1, kh * p.IW + kw);
         if (++kw == p.KS) { kw = 0; ++kh; }
       } else if (c + 1 < nChunks) {
         // odd tap count: the next chunk's first tap was fetched into A1
@@ -393,11 +404,11 @@ int launch_conv_ckt(ConvParams& p, hipStream_t stream) {
   // extra rows so that pixels past the tile (BM not a multiple of TW) still read inside the allocation
   const int rowsNeeded = (cdiv(BM, TW) - 1) * p.stride + p.KS;
   const int IHalloc = rowsNeeded > p.IH ? rowsNeeded : p.IH;
-  p.PS = p.CKT * 64 + 16;
+  p.PS = p.CKT * 64;  // unpadded: LDS-DMA writes contiguous kilobytes; bank conflicts are handled by the XOR swizzle
   p.magicIW = (unsigned)((0x100000000ULL + p.IW - 1) / p.IW);
   p.stageRows = (WM * WN * 64) / (p.IW * CKT * 4);
   if (p.stageRows < 1) p.stageRows = 1;  // halo row wider than the workgroup: threads stride over its columns
-  size_t lds = (size_t)IHalloc * p.IW * p.PS + 64;
+  size_t lds = (((size_t)IHalloc * p.IW * (p.CKT * 4) + 63) & ~(size_t)63) * 16 + 1024;
   const size_t ldsOut = (size_t)BM * (BN + 4) * sizeof(float);
   if (ldsOut > lds) lds = ldsOut;
   if (lds > 160 * 1024) return UPA_EUNSUPPORTED;

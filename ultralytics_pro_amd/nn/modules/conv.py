@@ -50,8 +50,12 @@ class PackedConv:
         self.cout, self.cin, self.k = int(w.shape[0]), int(w.shape[1]), k
         self.bias = b.contiguous().to(device)
         self.stem = stem
-        if stem:  # first layer reads NCHW directly and keeps f32 OIHW weights
-            self.w = w.contiguous().to(device)
+        if stem:  # first layer reads NCHW directly; f32 weights repacked [tap][ci][cout padded to 16]
+            nbytes = L.lib().upa_stem_packed_weight_bytes(self.cout, self.cin, k)
+            host = torch.empty(nbytes // 4, dtype=torch.float32)
+            wc = w.contiguous()
+            L.check(L.lib().upa_pack_stem_weight(wc.data_ptr(), self.cout, self.cin, k, host.data_ptr()), "pack_stem")
+            self.w = host.to(device)
             return
         code = L.dtype_code(dtype)
         nbytes = L.lib().upa_conv_packed_weight_bytes(self.cout, self.cin, k, code)
