@@ -42,7 +42,16 @@ __global__ __launch_bounds__(256) void nms_candidates_kernel(const float* pred, 
     float best = -INFINITY;
     int bc = 0;
     if (valid) {
-      for (int c = 0; c < nc; ++c) {
+      int c = 0;
+      for (; c + 8 <= nc; c += 8) {  // 8 independent loads in flight, then the ordered first-max scan
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = pb[(size_t)(c + q) * A];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (v[q] > best) { best = v[q]; bc = c + q; }
+      }
+      for (; c < nc; ++c) {
         const float v = pb[(size_t)c * A];
         if (v > best) { best = v; bc = c; }
       }
@@ -228,20 +237,19 @@ __global__ __launch_bounds__(GREEDY_NT) void nms_greedy_kernel(const float* pred
       u64 alive = alive_w[0];
 #pragma unroll
       for (int q = 1; q < GREEDY_NW; ++q) alive &= alive_w[q];
-      // phase 2: in-chunk suppression bits (earlier lane i suppresses me)
-      u64 m = 0ull;
-      for (int i = 0; i < 63; ++i) {
+      // phase 2: resolve the chunk greedily over the SET bits only: take the lowest alive lane, keep it, broadcast its
+      // box, drop every later alive lane it suppresses.  Iterations = boxes kept from this chunk (usually a handful),
+      // not 64 + 64 as a full suppression matrix + scan would cost.
+      u64 rem = alive, keepmask = 0ull;
+      while (rem) {
+        const int i = __ffsll((unsigned long long)rem) - 1;
+        keepmask |= 1ull << i;
+        rem &= rem - 1ull;
+        if (kept + __popcll(keepmask) >= max_det) break;
         const float ix1 = __shfl(x1, i), iy1 = __shfl(y1, i), ix2 = __shfl(x2, i), iy2 = __shfl(y2, i),
                     iar = __shfl(area, i);
-        if (i < lane && ((alive >> i) & 1ull) && iou_gt(ix1, iy1, ix2, iy2, iar, x1, y1, x2, y2, area, iou_thr))
-          m |= 1ull << i;
-      }
-      // sequential resolve
-      u64 keepmask = 0ull;
-      const unsigned mlo = (unsigned)m, mhi = (unsigned)(m >> 32);
-      for (int i = 0; i < 64; ++i) {
-        const u64 mi = ((u64)(unsigned)__shfl((int)mhi, i) << 32) | (unsigned)__shfl((int)mlo, i);
-        if (((alive >> i) & 1ull) && !(mi & keepmask)) keepmask |= 1ull << i;
+        const bool sup = ((rem >> lane) & 1ull) && iou_gt(ix1, iy1, ix2, iy2, iar, x1, y1, x2, y2, area, iou_thr);
+        rem &= ~__ballot(sup);
       }
       if ((keepmask >> lane) & 1ull) {
         const int idx = kept + __popcll(keepmask & ((1ull << lane) - 1ull));
