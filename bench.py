@@ -184,8 +184,9 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
                 name = f"void stem_conv_kernel<{tname}, 16>(StemParams)"
             else:
                 var = L.lib().upa_conv_variant(n, h, w, cin, pk.cout, pk.k, stride, pad, code)
-                name = "void conv_igemm_kernel<%s, %d, %d, %d, %d, %d>(ConvParams)" % (
-                    tname, (var >> 12) & 15, (var >> 8) & 15, (var >> 4) & 15, var & 15, (var >> 16) & 15)
+                name = "void %s<%s, %d, %d, %d, %d, %d>(ConvParams)" % (
+                    "conv_ws_kernel" if (var >> 20) & 1 else "conv_igemm_kernel", tname, (var >> 12) & 15, (var >> 8) & 15,
+                    (var >> 4) & 15, var & 15, (var >> 16) & 15)
             flops = 2.0 * n * oh * ow * pk.cout * cin * pk.k * pk.k
             nbytes = n * h * w * cin * xx.element_size() + n * oh * ow * pk.cout * es * (2 if residual is not None else 1) \
                 + pk.cout * cin * pk.k * pk.k * es

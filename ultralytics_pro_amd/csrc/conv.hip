@@ -43,6 +43,8 @@ struct ConvParams {
   unsigned magicIW;  // ceil(2^32 / IW)
   int tw_shift;      // log2(TW): tile widths are powers of two
   int stageRows;     // halo rows covered per staging pass = NTHREADS / (IW * G16) (>= 1)
+  int numTiles;      // ws kernel: spatial tiles in total (over all images)
+  int wsNTB;         // ws kernel: n-tiles per workgroup
   int ablate;        // debug: 1 = no input loads, 2 = no weight loads, 4 = no stores, 8 = no MFMA
 };
 
@@ -322,6 +324,202 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weights-stationary persistent variant ("ws"): used when the folded weights of the workgroup's output-channel slice fit
+// LDS next to two halo buffers (K*BN*ES <= ~90 KB: every 3x3 conv of yolov8n up to 64->64, every small 1x1).
+//   * grid = (min(#tiles, #CUs), Cout slices); a workgroup DMAs its weight slab into LDS ONCE, then walks its spatial
+//     tiles; the halo of tile t+1 is DMA'd into the other buffer while tile t is computed, and the compute loop touches
+//     LDS only (A and B fragments by ds_read_b128), so there is no vmcnt wait inside it;
+//   * one wave per SIMD (WM x WN = 4 waves), big per-wave tiles (MTW x NTW 16x16 tiles, up to 64 px x 64 ch) keep the
+//     LDS read traffic at <= 50 % of the LDS rate at full MFMA issue;
+//   * KTT (k-tiles per tap = whole Cin) is a template parameter: the halo row holds every input channel.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, int WM, int WN, int MTW, int NTW, int KTT>
+__global__ __launch_bounds__(WM* WN * 64) void conv_ws_kernel(const ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ES = sizeof(T);
+  constexpr int E = 16 / ES;
+  constexpr int NTHREADS = WM * WN * 64;
+  constexpr int G16 = KTT * 4;
+  constexpr int G16SHIFT = KTT == 1 ? 2 : (KTT == 2 ? 3 : 4);
+  constexpr int NTB = WN * NTW;  // n-tiles per workgroup
+  static_assert(KTT == 1 || KTT == 2 || KTT == 4, "KTT must be 1, 2 or 4");
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int wm = wave / WN, wn = wave % WN;
+  const int taps = p.KS * p.KS;
+  const int ntb0 = blockIdx.y * NTB;          // first n-tile of this workgroup
+  const int nt0 = ntb0 + wn * NTW;            // first n-tile of this wave
+
+  const int wBytes = taps * KTT * NTB * 1024;
+  const int haloItems = p.IH * p.IW * G16;
+  const int haloPadded = (haloItems + 63) & ~63;
+  char* wsm = smem;
+  char* hbuf0 = smem + wBytes;
+  char* hbuf1 = hbuf0 + haloPadded * 16;
+
+  // ---- weights: one DMA pass, [tap][kt][NTB][lane][16 B] (a contiguous copy when the slice covers every n-tile)
+  {
+    const int items = wBytes >> 4;
+    for (int base = wave * 64; base < items; base += NTHREADS) {
+      const int idx = base + lane;
+      const int seg = idx / (NTB * 64);          // (tap, kt)
+      const int within = idx - seg * (NTB * 64);
+      const int nt = ntb0 + (within >> 6);
+      const char* src = (nt < p.NTn) ? p.w + (((size_t)seg * p.NTn + ntb0) * 64 + within) * 16
+                                     : reinterpret_cast<const char*>(g_zero16);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(wsm + base * 16), 16, 0, 0);
+    }
+  }
+  auto stage = [&](int tile, char* dst) {
+    const int tilesPerImg = p.tilesX * p.tilesY;
+    const int n = tile / tilesPerImg;
+    const int rem = tile - n * tilesPerImg;
+    const int tyi = rem / p.tilesX, txi = rem - tyi * p.tilesX;
+    const int iy0 = tyi * p.TH * p.stride - p.pad, ix0 = txi * p.TW * p.stride - p.pad;
+    for (int base = wave * 64; base < haloPadded; base += NTHREADS) {
+      const int idx = base + lane;
+      const int pix = idx >> G16SHIFT;
+      const int slot = idx & (G16 - 1);
+      const int cg = slot ^ ((KTT == 1 ? (pix >> 1) : pix) & (G16 - 1));
+      const int py = __umulhi((unsigned)pix, p.magicIW);
+      const int px = pix - py * p.IW;
+      const int iy = iy0 + py, ix = ix0 + px;
+      const int ch = cg * E;
+      const char* src = reinterpret_cast<const char*>(g_zero16);
+      if (idx < haloItems && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && ch < p.Cin)
+        src = p.x + ((((size_t)n * p.H + iy) * p.W + ix) * (size_t)p.ldx + ch) * ES;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + base * 16), 16, 0, 0);
+    }
+  };
+
+  int pixbase[MTW], pty[MTW], ptx[MTW];
+#pragma unroll
+  for (int i = 0; i < MTW; ++i) {
+    const int pp = (wm * MTW + i) * 16 + r;
+    pty[i] = pp >> p.tw_shift;
+    ptx[i] = pp & (p.TW - 1);
+    pixbase[i] = (pty[i] * p.stride) * p.IW + ptx[i] * p.stride;
+  }
+  f32x4 biasv[NTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    const int co = (nt0 + j) * 16 + g * 4;
+    biasv[j] = (p.bias && co < p.Cout) ? *reinterpret_cast<const f32x4*>(p.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  int tile = blockIdx.x;
+  if (tile < p.numTiles) stage(tile, hbuf0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const char* wlds = wsm + (wn * NTW) * 1024 + lane * 16;
+  int buf = 0;
+  for (; tile < p.numTiles; tile += gridDim.x, buf ^= 1) {
+    const char* hb = buf ? hbuf1 : hbuf0;
+    const int next = tile + gridDim.x;
+    if (next < p.numTiles) stage(next, buf ? hbuf0 : hbuf1);  // lands while this tile is computed
+
+    f32x4 acc[MTW][NTW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i)
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int kh = 0, kw = 0;
+    for (int tap = 0; tap < taps; ++tap) {
+      const int tapshift = kh * p.IW + kw;
+      int paddr[MTW], pswz[MTW];
+#pragma unroll
+      for (int i = 0; i < MTW; ++i) {
+        const int pl = pixbase[i] + tapshift;
+        paddr[i] = pl * (G16 * 16);
+        pswz[i] = (KTT == 1 ? (pl >> 1) : pl) & (G16 - 1);
+      }
+      const char* wt = wlds + (size_t)tap * KTT * NTB * 1024;
+#pragma unroll
+      for (int kt = 0; kt < KTT; ++kt) {
+        u32x4 a[NTW], b[MTW];
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) a[j] = *reinterpret_cast<const u32x4*>(wt + (kt * NTB + j) * 1024);
+#pragma unroll
+        for (int i = 0; i < MTW; ++i)
+          b[i] = *reinterpret_cast<const u32x4*>(hb + paddr[i] + (((kt * 4 + g) ^ pswz[i]) << 4));
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) {
+#pragma unroll
+          for (int j = 0; j < NTW; ++j) {
+            if constexpr (ES == 2) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&a[j]),
+                                                                  *reinterpret_cast<bf16x8*>(&b[i]), acc[i][j], 0, 0, 0);
+            } else {
+              const float* af = reinterpret_cast<const float*>(&a[j]);
+              const float* bf = reinterpret_cast<const float*>(&b[i]);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], bf[0], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1], bf[1], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[2], bf[2], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[3], bf[3], acc[i][j], 0, 0, 0);
+            }
+          }
+        }
+      }
+      if (++kw == p.KS) { kw = 0; ++kh; }
+    }
+    // next tile's halo must have landed before anyone reads it; wait BEFORE this tile's stores are issued (vmcnt also
+    // counts stores), so the wait covers only the DMA, which had the whole compute phase to complete
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- epilogue (direct): lane holds 4 consecutive couts of one pixel per accumulator tile
+    const int tilesPerImg = p.tilesX * p.tilesY;
+    const int n = tile / tilesPerImg;
+    const int rem = tile - n * tilesPerImg;
+    const int tyi = rem / p.tilesX, txi = rem - tyi * p.tilesX;
+    const int oy0 = tyi * p.TH, ox0 = txi * p.TW;
+    auto epilogue = [&](auto act_tag) {
+      constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+      for (int i = 0; i < MTW; ++i) {
+        const int oy = oy0 + pty[i], ox = ox0 + ptx[i];
+        const bool pvalid = pty[i] < p.TH && oy < p.OH && ox < p.OW;
+        const size_t pixoff = ((size_t)n * p.OH + oy) * p.OW + ox;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+          const int co = (nt0 + j) * 16 + g * 4;
+          if (!pvalid || co >= p.Cout) continue;
+          float v[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = act_fn<ES == 4, ACT>(acc[i][j][q] + biasv[j][q]);
+          if constexpr (ES == 4) {
+            if (p.res) {
+              const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + (pixoff * p.ldr + co) * 4);
+              v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3];
+            }
+            *reinterpret_cast<f32x4*>(p.y + (pixoff * p.ldy + co) * 4) = f32x4{v[0], v[1], v[2], v[3]};
+          } else {
+            if (p.res) {
+              const u32x2 rv = *reinterpret_cast<const u32x2*>(p.res + (pixoff * p.ldr + co) * 2);
+              v[0] += __uint_as_float(rv[0] << 16);
+              v[1] += __uint_as_float(rv[0] & 0xFFFF0000u);
+              v[2] += __uint_as_float(rv[1] << 16);
+              v[3] += __uint_as_float(rv[1] & 0xFFFF0000u);
+            }
+            *reinterpret_cast<u32x2*>(p.y + (pixoff * p.ldy + co) * 2) =
+                u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          }
+        }
+      }
+    };
+    if (p.act == UPA_ACT_SILU) epilogue(std::integral_constant<int, UPA_ACT_SILU>{});
+    else if (p.act == UPA_ACT_RELU) epilogue(std::integral_constant<int, UPA_ACT_RELU>{});
+    else epilogue(std::integral_constant<int, UPA_ACT_NONE>{});
+    __syncthreads();  // every wave is done with hb (and sees the landed next halo) before it is overwritten / read
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
@@ -430,8 +628,99 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
   return launch_conv_ckt<T, WM, WN, MTW, NTW, 1>(p, stream);
 }
 
+
+// ---- weights-stationary launcher: returns UPA_EUNSUPPORTED when the problem does not qualify (caller falls back)
+template <typename T, int WM, int WN, int MTW, int NTW, int KTT>
+int launch_ws(ConvParams& p, hipStream_t stream) {
+  constexpr int BM = WM * MTW * 16;
+  constexpr int NTB = WN * NTW;
+  const int taps = p.KS * p.KS;
+  const size_t wBytes = (size_t)taps * KTT * NTB * 1024;
+  int TW, TH;
+  if (p.KS == 1 && p.stride == 1 && p.pad == 0) {
+    const long P = (long)p.N * p.H * p.W;
+    p.N = 1; p.H = 1; p.W = (int)P; p.OH = 1; p.OW = (int)P;
+    TH = 1; TW = BM;
+  } else {
+    TW = 16;
+    TH = BM / TW;
+  }
+  p.TH = TH; p.TW = TW;
+  p.tw_shift = 0;
+  while ((1 << p.tw_shift) < TW) ++p.tw_shift;
+  p.tilesX = cdiv(p.OW, TW);
+  p.tilesY = cdiv(p.OH, TH);
+  p.IH = (TH - 1) * p.stride + p.KS;
+  p.IW = (TW - 1) * p.stride + p.KS;
+  p.magicIW = (unsigned)((0x100000000ULL + p.IW - 1) / p.IW);
+  p.CKT = KTT;
+  p.PS = KTT * 64;
+  const size_t halo = (((size_t)p.IH * p.IW * (KTT * 4) + 63) & ~(size_t)63) * 16;
+  const size_t lds = wBytes + 2 * halo + 1024;
+  if (lds > 160 * 1024) return UPA_EUNSUPPORTED;
+  p.numTiles = p.tilesX * p.tilesY * p.N;
+  p.wsNTB = NTB;
+  const int gridY = cdiv(p.NTn, NTB);
+  static int numCU = 0;
+  if (!numCU) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&numCU, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || numCU <= 0) numCU = 256;
+  }
+  int perCU = (int)((160 * 1024) / lds);  // co-resident workgroups per CU (LDS-limited), capped by the wave slots
+  if (perCU > 4) perCU = 4;
+  // measured on MI355X: with one workgroup per CU (4 waves, nothing to overlap the epilogue / LDS latency with) the
+  // persistent form loses to the one-tile-per-workgroup kernel at 4 workgroups/CU (64->64 3x3 @80x80: 39.8 vs 28.3 us);
+  // with >= 2 co-resident workgroups it wins (32->32 3x3: 15.5 vs 17.3 us, 16->16 3x3 @160x160: 28.7 vs 35.0 us)
+  if (perCU < 2) return UPA_EUNSUPPORTED;
+  int gx = numCU * perCU / gridY;
+  if (gx < 1) gx = 1;
+  if (gx > p.numTiles) gx = p.numTiles;
+  g_last_variant = (1 << 20) | (KTT << 16) | (WM << 12) | (WN << 8) | (MTW << 4) | NTW;
+  if (g_query_only) return UPA_OK;
+  auto kern = conv_ws_kernel<T, WM, WN, MTW, NTW, KTT>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { upa_set_error("conv ws: cannot raise LDS limit: %s", hipGetErrorString(e)); return UPA_ELAUNCH; }
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)gridY), dim3(WM * WN * 64), lds, stream, p);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+template <typename T, int KTT>
+int dispatch_ws_ktt(ConvParams p, hipStream_t stream) {  // p by value: launch_ws mutates it
+  const int ntn = p.NTn;
+  const long M = (long)p.N * p.OH * p.OW;
+  if (M < 64 * 1024) return UPA_EUNSUPPORTED;              // few tiles: the one-tile-per-workgroup kernel parallelises better
+  if (ntn == 1) return launch_ws<T, 4, 1, 4, 1, KTT>(p, stream);   // 256 px x 16 ch
+  if (ntn == 2) return launch_ws<T, 4, 1, 4, 2, KTT>(p, stream);   // 256 px x 32 ch
+  if (ntn == 4) {
+    ConvParams q = p;
+    int rc = launch_ws<T, 4, 1, 4, 4, KTT>(q, stream);             // 256 px x 64 ch
+    if (rc != UPA_EUNSUPPORTED) return rc;
+    return launch_ws<T, 2, 2, 4, 2, KTT>(p, stream);               // 128 px x 64 ch
+  }
+  return UPA_EUNSUPPORTED;
+}
+
+template <typename T>
+int dispatch_ws(const ConvParams& p, hipStream_t stream) {
+  static const int off = getenv("UPA_CONV_NO_WS") ? atoi(getenv("UPA_CONV_NO_WS")) : 0;
+  if (off) return UPA_EUNSUPPORTED;
+  if (p.KS != 3 || p.stride != 1) return UPA_EUNSUPPORTED;  // 1x1 and stride-2 layers measured faster on the igemm kernel
+  if (p.KTT == 1) return dispatch_ws_ktt<T, 1>(p, stream);
+  if (p.KTT == 2) return dispatch_ws_ktt<T, 2>(p, stream);
+  if (p.KTT == 4) return dispatch_ws_ktt<T, 4>(p, stream);
+  return UPA_EUNSUPPORTED;
+}
+
 template <typename T>
 int dispatch_conv(ConvParams& p, hipStream_t stream) {
+  {
+    const int rc = dispatch_ws<T>(p, stream);
+    if (rc != UPA_EUNSUPPORTED) return rc;
+  }
   const int ntn = p.NTn;
   const long M = (long)p.N * p.OH * p.OW;
   // n-tiling: prefer covering all output channels in one workgroup (input tile read once)
