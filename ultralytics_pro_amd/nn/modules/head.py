@@ -56,18 +56,63 @@ class Detect(nn.Module, _HipConvMixin):
         pk = self._packed(seq[2], None, x.device, x.dtype, False)
         hip_conv2d(t, pk, 1, 0, L.ACT_NONE, out=out)
 
+    # ---- branch-level concurrency -------------------------------------------------------------------------------------
+    # The box and class branches of a level are independent 3-conv chains and a level only depends on its own input
+    # (head.py:116-126), so the executor may start a level the moment its feature map exists (`start_level`, called by
+    # BaseModel._predict_once) on two side HIP streams forked from the producing stream; `forward` joins them before
+    # the decode.  Under hipGraph capture the event fork/join becomes parallel graph branches.  The small 20x20/40x40
+    # launches of the neck and the head are latency-bound (a few hundred workgroups on 256 CUs), so they overlap well.
+    concurrent = True
+
+    def _side_streams(self, device):
+        st = self.__dict__.get("_streams")
+        if st is None or st[0].device != device:
+            st = [torch.cuda.Stream(device=device) for _ in range(2 * self.nl)]
+            self.__dict__["_streams"] = st
+        return st
+
+    def start_level(self, i: int, x: torch.Tensor) -> None:
+        """Launch level i's two branches (asynchronously when `concurrent`); results land in the level's raw buffer."""
+        pend = self.__dict__.setdefault("_pending", {})
+        x = R.to_nhwc(x, x.dtype)
+        nb = 4 * self.reg_max
+        n, _, h, w = x.shape
+        buf = R.alloc_nhwc(n, self.no, h, w, x.dtype, x.device, key=(id(self), "raw", i))
+        if not self.concurrent:
+            self._branch(self.cv2[i], x, buf[:, :nb])
+            self._branch(self.cv3[i], x, buf[:, nb:])
+            pend[i] = (buf, [])
+            return
+        main = torch.cuda.current_stream(x.device)
+        fork = torch.cuda.Event()
+        fork.record(main)
+        joins = []
+        streams = self._side_streams(x.device)
+        for k, (seq, out) in enumerate(((self.cv2[i], buf[:, :nb]), (self.cv3[i], buf[:, nb:]))):
+            side = streams[2 * i + k]
+            side.wait_event(fork)
+            with torch.cuda.stream(side):
+                self._branch(seq, x, out)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            joins.append(ev)
+        pend[i] = (buf, joins)
+
     def forward(self, x):
         if self.training:
             raise L.UpaError("training-mode Detect is not on the HIP path yet (SURVEY §8f rank 2)")
-        x = [R.to_nhwc(t, t.dtype) for t in x]
-        nb = 4 * self.reg_max
+        pend = self.__dict__.setdefault("_pending", {})
+        for i in range(self.nl):
+            if i not in pend:
+                self.start_level(i, x[i])
+        main = torch.cuda.current_stream(x[0].device)
         raw = []
         for i in range(self.nl):
-            n, _, h, w = x[i].shape
-            buf = R.alloc_nhwc(n, self.no, h, w, x[i].dtype, x[i].device, key=(id(self), "raw", i))
-            self._branch(self.cv2[i], x[i], buf[:, :nb])
-            self._branch(self.cv3[i], x[i], buf[:, nb:])
+            buf, joins = pend[i]
+            for ev in joins:
+                main.wait_event(ev)
             raw.append(buf)
+        pend.clear()
         y = self._inference(raw)
         return y if self.export else (y, raw)
 

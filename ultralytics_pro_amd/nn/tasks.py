@@ -188,6 +188,11 @@ class BaseModel(nn.Module):
         that Concat's buffer (`out=` view), so Upsample+Concat / Conv+Concat never copy (yolov8.yaml rows 10-21)."""
         place = self._concat_placement()
         y, cat_buf = [], {}
+        det = self.model[-1] if isinstance(self.model[-1], Detect) else None
+        det_level = {}
+        if det is not None:
+            det.__dict__.setdefault("_pending", {}).clear()
+            det_level = {(det.i - 1 if j == -1 else j): k for k, j in enumerate(det.f)} if isinstance(det.f, list) else {}
         for m in self.model:
             if m.f != -1:
                 x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
@@ -215,6 +220,8 @@ class BaseModel(nn.Module):
             else:
                 x = m(x)
             y.append(x if m.i in self.save else None)
+            if m.i in det_level and torch.is_tensor(x):  # a Detect input is ready: start that level's branches now
+                det.start_level(det_level[m.i], x)
         return x
 
     def _concat_placement(self):
