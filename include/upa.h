@@ -130,6 +130,10 @@ int upa_msdeform_attn(const float* value, const int32_t* shapes_hw, int n_levels
                       const float* offsets, const float* attn_logits, const float* ref_boxes, int len_q, int n_points,
                       float* y, void* stream);
 
+/* ---- validation ---------------------------------------------------------------------------------------------------
+ * out[i,j] = IoU(box1[i], box2[j]) with eps in the denominator (xyxy f32).            utils/metrics.py:54-74 */
+int upa_box_iou(const float* box1, int n, const float* box2, int m, float eps, float* out, void* stream);
+
 /* ---- HIP graph helpers (capture a launch sequence once, replay per batch) ------------------------------------- */
 int upa_graph_begin(void* stream);
 int upa_graph_end(void* stream, void** graph_exec_out);

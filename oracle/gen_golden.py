@@ -7,6 +7,7 @@ Outputs are data only (inputs are re-derivable from the hash; expected outputs a
   tests/golden/ops_unit.npz         per-op outputs on small procedural tensors                   (§8c b)
   tests/golden/nms_cases.npz        NMS inputs + reference outputs                               (§8c c)
   tests/golden/e2e_<cfg>.npz        head-output slices/statistics + post-NMS rows, B=2            (§8c d)
+  tests/golden/map_yolov8n.npz      synthetic-GT validation set: detections, labels, TP matrices, AP (§8f rank 1)
 """
 
 from __future__ import annotations
@@ -322,11 +323,71 @@ def e2e(rt):
         np.savez_compressed(GOLD / f"e2e_{name}.npz", **G)
 
 
+def synthetic_ground_truth(dets, image_index):
+    """GT for the synthetic mAP set: a jittered subset of one image's own detections (so mAP is non-trivial and identical
+    pipelines give identical mAP). dets: (n,6) val-mode NMS rows. Returns (boxes (m,4), cls (m,))."""
+    n = dets.shape[0]
+    u = P.hash_uniform(f"map:gt:{image_index}", 8 * max(n, 1)).reshape(-1, 8)
+    rows = [i for i in range(0, min(n, 90), 3)]
+    boxes, cls = [], []
+    for i in rows:
+        b = dets[i, :4].clone()
+        w, h = (b[2] - b[0]).clamp(min=1.0), (b[3] - b[1]).clamp(min=1.0)
+        jit = torch.from_numpy(u[i, :4].copy()) - 0.5  # +-0.5
+        scale = 0.02 + 0.5 * float(u[i, 4]) ** 2        # most boxes tight (IoU > 0.9), some loose (IoU ~ 0.5)
+        b = b + jit * scale * torch.stack([w, h, w, h])
+        c = dets[i, 5] if u[i, 5] > 0.15 else (dets[i, 5] + 1) % 80  # 15 % wrong-class labels
+        boxes.append(b)
+        cls.append(c)
+    if not boxes:
+        return torch.zeros((0, 4)), torch.zeros((0,))
+    return torch.stack(boxes), torch.stack(cls)
+
+
+def map_golden(rt):
+    """Reference validation arithmetic on the synthetic set: NMS(val settings) -> _process_batch -> ap_per_class."""
+    from ultralytics.engine.validator import BaseValidator
+    from ultralytics.utils import metrics as rmet
+    from ultralytics.utils.nms import non_max_suppression as r_nms
+    from oracle import metrics as omet
+
+    name = "yolov8n"
+    ref = rt.DetectionModel(REF_CFG[name], ch=3, nc=80, verbose=False)
+    P.apply_procedural_weights(ref, family=name)
+    ref.eval().fuse(verbose=False)
+    x = P.synthetic_images(4)
+    yr = ref(x)[0]
+    dets = r_nms(yr.clone(), conf_thres=0.001, iou_thres=0.7, max_det=300, multi_label=True, max_time_img=1e9)
+
+    class _V:  # match_predictions only needs self.iouv (detect/val.py:59)
+        iouv = torch.linspace(0.5, 0.95, 10)
+
+    G, tps, confs, pcls, tcls = {}, [], [], [], []
+    for i, d in enumerate(dets):
+        gb, gc = synthetic_ground_truth(d, i)
+        iou = rmet.box_iou(gb, d[:, :4])
+        tp = BaseValidator.match_predictions(_V, d[:, 5], gc, iou).numpy()
+        tp_o = omet.process_batch(d[:, :4], d[:, 5], gb, gc)
+        assert np.array_equal(tp, tp_o), "oracle match_predictions != reference"
+        G[f"det{i}"], G[f"gt_boxes{i}"], G[f"gt_cls{i}"], G[f"tp{i}"] = d.numpy(), gb.numpy(), gc.numpy(), tp
+        tps.append(tp); confs.append(d[:, 4].numpy()); pcls.append(d[:, 5].numpy()); tcls.append(gc.numpy())
+    tp, conf, pc, tc = (np.concatenate(v, 0) for v in (tps, confs, pcls, tcls))
+    res = rmet.ap_per_class(tp, conf, pc, tc)
+    p_, r_, f1_, ap_, uc_ = res[2], res[3], res[4], res[5], res[6]
+    po, ro, fo, apo, uco = omet.ap_per_class(tp, conf, pc, tc)
+    assert np.array_equal(ap_, apo) and np.array_equal(p_, po) and np.array_equal(r_, ro) and np.array_equal(uc_, uco)
+    G.update(p=p_, r=r_, f1=f1_, ap=ap_, classes=uc_,
+             mean=np.array([p_.mean(), r_.mean(), ap_[:, 0].mean(), ap_.mean()]))
+    print(f"map {name}: {len(tp)} dets, {len(tc)} labels, P={p_.mean():.4f} R={r_.mean():.4f} mAP50={ap_[:, 0].mean():.4f} "
+          f"mAP50-95={ap_.mean():.4f}")
+    np.savez_compressed(GOLD / f"map_{name}.npz", **G)
+
+
 def main():
     torch.manual_seed(0)
     GOLD.mkdir(parents=True, exist_ok=True)
     rt = import_reference()
-    which = sys.argv[1:] or ["builder", "ops", "nms", "e2e"]
+    which = sys.argv[1:] or ["builder", "ops", "nms", "e2e", "map"]
     with torch.no_grad():
         if "builder" in which:
             builder_tables(rt)
@@ -336,6 +397,8 @@ def main():
             nms_cases(rt)
         if "e2e" in which:
             e2e(rt)
+        if "map" in which:
+            map_golden(rt)
 
 
 if __name__ == "__main__":

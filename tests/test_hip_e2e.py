@@ -103,3 +103,32 @@ def test_e2e_rtdetr_f32_matches_reference_golden(golden_dir):
     assert d.max() <= TOL
     outs = onms.rtdetr_postprocess(y.cpu(), 0.25)
     assert [o.shape[0] for o in outs] == list(g["post_n"])
+
+
+@pytest.mark.parametrize("shape", [(1, 384, 640), (3, 320, 256), (2, 352, 608)], ids=["b1_384x640", "b3_320x256", "b2_352x608"])
+def test_e2e_rect_and_odd_batches_vs_oracle(shape):
+    """Non-square inputs (the reference predicts with rect=True, engine/model.py:527), batch 1 and odd batches, feature
+    maps that are not multiples of the conv tiles (44x76, 40x32, ...): HIP f32 vs the oracle, boxes/scores/classes."""
+    from tests.hip_utils import DEV
+    from ultralytics_pro_amd.utils.nms import non_max_suppression
+    b, h, w = shape
+    x = P.synthetic_images(b, h=h, w=w)
+    o = ot.DetectionModel("yolov8n.yaml")
+    P.apply_procedural_weights(o)
+    o.fuse()
+    with torch.no_grad():
+        y_ref = o(x)[0]
+    m = _build("yolov8n", torch.float32)
+    with torch.no_grad():
+        y = m(x.to(DEV))[0]
+    torch.cuda.synchronize()
+    assert y.shape == y_ref.shape
+    d = (y.cpu() - y_ref).abs()
+    assert d[:, :4].max().item() <= TOL and d[:, 4:].max().item() <= TOL
+    out = non_max_suppression(y, 0.25, 0.7)
+    ref = onms.non_max_suppression(y_ref, 0.25, 0.7)
+    assert [a.shape[0] for a in out] == [r.shape[0] for r in ref]
+    for a, r in zip(out, ref):
+        if r.shape[0]:
+            assert (a.cpu()[:, :5] - r[:, :5]).abs().max().item() <= TOL
+            assert torch.equal(a.cpu()[:, 5], r[:, 5])

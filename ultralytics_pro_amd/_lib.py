@@ -54,6 +54,7 @@ PROTOTYPES = {
     "upa_sigmoid": (_i, [_vp, _vp, C.c_long, _vp]),
     "upa_rtdetr_output": (_i, [_vp, _vp, _vp, C.c_long, _i, _vp]),
     "upa_msdeform_attn": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "upa_box_iou": (_i, [_vp, _i, _vp, _i, _f, _vp, _vp]),
     "upa_graph_begin": (_i, [_vp]),
     "upa_graph_end": (_i, [_vp, C.POINTER(_vp)]),
     "upa_graph_launch": (_i, [_vp, _vp]),
