@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-enum { UPA_F32 = 0, UPA_BF16 = 1 };
+enum { UPA_F32 = 0, UPA_BF16 = 1, UPA_U8_BGR_HWC = 2 /* stem input only: uint8 (N,H,W,3) BGR frames */ };
 enum { UPA_ACT_NONE = 0, UPA_ACT_SILU = 1, UPA_ACT_RELU = 2 };
 enum { UPA_OK = 0, UPA_EINVAL = -1, UPA_EUNSUPPORTED = -2, UPA_EWORKSPACE = -3, UPA_ELAUNCH = -4 };
 
@@ -133,6 +133,11 @@ int upa_msdeform_attn(const float* value, const int32_t* shapes_hw, int n_levels
 /* ---- validation ---------------------------------------------------------------------------------------------------
  * out[i,j] = IoU(box1[i], box2[j]) with eps in the denominator (xyxy f32).            utils/metrics.py:54-74 */
 int upa_box_iou(const float* box1, int n, const float* box2, int m, float eps, float* out, void* stream);
+
+/* In-place scale_boxes + clip_boxes on xyxy rows: box -= (pad_x, pad_y, pad_x, pad_y); box /= gain; clip to (w0, h0).
+ * rows: n rows of `row_stride` floats, the box in the first 4.                              utils/ops.py:102-178 */
+int upa_scale_boxes(float* rows, long n, int row_stride, float gain, float pad_x, float pad_y, int padding, float w0,
+                    float h0, void* stream);
 
 /* ---- HIP graph helpers (capture a launch sequence once, replay per batch) ------------------------------------- */
 int upa_graph_begin(void* stream);

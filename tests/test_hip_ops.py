@@ -283,3 +283,39 @@ def test_cpu_tensor_fails_loudly():
     pm, _ = _mods()
     with pytest.raises(UpaError):
         pm.Conv(16, 16, 3).eval()(torch.zeros(1, 16, 8, 8))
+
+
+def test_stem_reads_uint8_bgr_frames():
+    """uint8 HWC BGR frames go straight into the first conv (BGR->RGB, HWC->CHW, /255 fused),
+    against the reference's preprocess semantics (engine/predictor.py:151-173) followed by the oracle Conv."""
+    from tests.hip_utils import DEV, to_cpu_nchw
+    pm, _ = _mods()
+    o, m = _pair(om.Conv, pm.Conv, (3, 16, 3, 2), "stem_u8")
+    frames = (P.hash_uniform("u8frames", 2 * 48 * 64 * 3) * 256).astype("uint8").reshape(2, 48, 64, 3)  # BGR
+    ref_in = torch.from_numpy(frames[..., ::-1].transpose(0, 3, 1, 2).copy()).float() / 255  # predictor.preprocess
+    m.compute_dtype = torch.float32
+    with torch.no_grad():
+        ref = o(ref_in)
+        y = to_cpu_nchw(m(torch.from_numpy(frames).to(DEV)))
+    assert (y - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_scale_boxes_matches_reference_formula():
+    """scale_boxes + clip_boxes (utils/ops.py:102-178): letterboxed 640x640 -> 1080x810 original, and ratio_pad form."""
+    from tests.hip_utils import DEV
+    from ultralytics_pro_amd.utils.ops import scale_boxes
+    b = P.uniform("scale_boxes", (50, 6), -20, 660)
+    for img1, img0, rp in (((640, 640), (1080, 810), None), ((384, 640), (720, 1280), None),
+                           ((640, 640), (500, 375), ((1.28,), (80.0, 0.0)))):
+        ref = b.clone()
+        if rp is None:
+            gain = min(img1[0] / img0[0], img1[1] / img0[1])
+            px, py = round((img1[1] - img0[1] * gain) / 2 - 0.1), round((img1[0] - img0[0] * gain) / 2 - 0.1)
+        else:
+            gain, (px, py) = rp[0][0], rp[1]
+        ref[:, [0, 2]] -= px
+        ref[:, [1, 3]] -= py
+        ref[:, :4] /= gain
+        ref[:, 0].clamp_(0, img0[1]); ref[:, 1].clamp_(0, img0[0]); ref[:, 2].clamp_(0, img0[1]); ref[:, 3].clamp_(0, img0[0])
+        got = scale_boxes(img1, b.clone().to(DEV), img0, ratio_pad=rp)
+        assert torch.equal(got.cpu(), ref)

@@ -13,7 +13,7 @@ from pathlib import Path
 
 import torch  # noqa: F401  (loads libamdhip64.so.7 first - see module docstring)
 
-UPA_F32, UPA_BF16 = 0, 1
+UPA_F32, UPA_BF16, UPA_U8_BGR_HWC = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
 
 _PKG = Path(__file__).resolve().parent
@@ -55,6 +55,7 @@ PROTOTYPES = {
     "upa_rtdetr_output": (_i, [_vp, _vp, _vp, C.c_long, _i, _vp]),
     "upa_msdeform_attn": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "upa_box_iou": (_i, [_vp, _i, _vp, _i, _f, _vp, _vp]),
+    "upa_scale_boxes": (_i, [_vp, C.c_long, _i, _f, _f, _f, _i, _f, _f, _vp]),
     "upa_graph_begin": (_i, [_vp]),
     "upa_graph_end": (_i, [_vp, C.POINTER(_vp)]),
     "upa_graph_launch": (_i, [_vp, _vp]),

@@ -25,3 +25,29 @@ extern "C" int upa_box_iou(const float* box1, int n, const float* box2, int m, f
   UPA_LAUNCH_CHECK();
   return UPA_OK;
 }
+
+// scale_boxes + clip_boxes (utils/ops.py:102-178), in place on the first 4 floats of each row, same op order.
+__global__ __launch_bounds__(256) void scale_boxes_kernel(float* rows, long n, int rs, float gain, float px, float py,
+                                                          int padding, float w0, float h0) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float* b = rows + i * rs;
+  float x1 = b[0], y1 = b[1], x2 = b[2], y2 = b[3];
+  if (padding) { x1 -= px; y1 -= py; x2 -= px; y2 -= py; }
+  x1 /= gain; y1 /= gain; x2 /= gain; y2 /= gain;
+  b[0] = fminf(fmaxf(x1, 0.f), w0);
+  b[1] = fminf(fmaxf(y1, 0.f), h0);
+  b[2] = fminf(fmaxf(x2, 0.f), w0);
+  b[3] = fminf(fmaxf(y2, 0.f), h0);
+}
+
+extern "C" int upa_scale_boxes(float* rows, long n, int row_stride, float gain, float pad_x, float pad_y, int padding,
+                               float w0, float h0, void* stream) {
+  UPA_CHECK_ARG(n == 0 || rows, "scale_boxes: null pointer");
+  UPA_CHECK_ARG(row_stride >= 4 && gain > 0.f, "scale_boxes: bad row stride / gain");
+  if (n == 0) return UPA_OK;
+  hipLaunchKernelGGL(scale_boxes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rows, n,
+                     row_stride, gain, pad_x, pad_y, padding, w0, h0);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}

@@ -38,7 +38,38 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p) {
   const size_t plane = (size_t)p.H * p.W;
   // ---- stage.  A thread owns one patch column (bf16: one aligned pair of columns) and walks the cin*PR patch lines in
   // steps of LSTEP, four lines in flight: no per-element division (only incremental line -> (ci,row) counters).
-  {
+  if (p.x_bf16 == 2) {
+    // uint8 HWC BGR frames (what the reference's predictor receives, engine/predictor.py:151-173): BGR->RGB,
+    // HWC->CHW, uint8->float and /255 all happen in this load - the separate preprocessing passes disappear.
+    const unsigned char* xu = (const unsigned char*)p.x;
+    const int npix = p.PR * p.PC;
+    for (int base = 0; base < npix; base += 256 * 4) {
+      unsigned v[4][3];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = base + q * 256 + tid;
+        v[q][0] = v[q][1] = v[q][2] = 0u;
+        if (i < npix) {
+          const int row = i / p.PC, col = i - row * p.PC;
+          const int iy = iy0 + row, ix = ix0 + col;
+          if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && !(p.ablate & 1)) {
+            const unsigned char* px = xu + (((size_t)n * p.H + iy) * p.W + ix) * 3;
+            v[q][0] = px[2]; v[q][1] = px[1]; v[q][2] = px[0];  // channel reversal
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = base + q * 256 + tid;
+        if (i < npix) {
+          const int row = i / p.PC, col = i - row * p.PC;
+#pragma unroll
+          for (int ci = 0; ci < 3; ++ci)
+            patch[(ci * p.PR + row) * p.PCS + col] = (float)v[q][ci] / 255.0f;  // `im.float(); im /= 255`
+        }
+      }
+    }
+  } else {
     const bool bf = p.x_bf16 != 0;
     const int ixa = bf ? (ix0 & ~1) : ix0;   // bf16: even start -> 4-byte aligned pairs (two's complement floors)
     const int shift = ix0 - ixa;             // 0 or 1
@@ -164,6 +195,8 @@ extern "C" int upa_conv2d_stem_nchw(const void* x, int x_dtype, int n, int cin, 
                                     const float* bias, void* y, int cout, int ldy, int k, int stride, int pad, int act,
                                     int dtype, void* stream) {
   UPA_CHECK_ARG(x && wt && y, "stem: null pointer");
+  UPA_CHECK_ARG(x_dtype == UPA_F32 || x_dtype == UPA_BF16 || (x_dtype == UPA_U8_BGR_HWC && cin == 3),
+                "stem: input must be NCHW f32/bf16 or NHWC uint8 BGR with 3 channels");
   UPA_CHECK_ARG(cin >= 1 && cin <= 4 && cout % 4 == 0 && ldy % 8 == 0 && (uintptr_t)y % 16 == 0,
                 "stem: cin must be <=4, cout %% 4 == 0, output view 16-byte aligned");
   UPA_CHECK_ARG(k >= 1 && k <= 7 && stride >= 1 && stride <= 2 && pad >= 0, "stem: bad k/s/p");
@@ -172,7 +205,7 @@ extern "C" int upa_conv2d_stem_nchw(const void* x, int x_dtype, int n, int cin, 
   p.N = n; p.Cin = cin; p.H = h; p.W = w;
   p.OH = (h + 2 * pad - k) / stride + 1;
   p.OW = (w + 2 * pad - k) / stride + 1;
-  p.Cout = cout; p.ldy = ldy; p.KS = k; p.stride = stride; p.pad = pad; p.act = act; p.x_bf16 = (x_dtype == UPA_BF16);
+  p.Cout = cout; p.ldy = ldy; p.KS = k; p.stride = stride; p.pad = pad; p.act = act; p.x_bf16 = x_dtype == UPA_BF16 ? 1 : (x_dtype == UPA_U8_BGR_HWC ? 2 : 0);
   p.TW = p.OW >= 64 ? 64 : (p.OW >= 32 ? 32 : 16);
   p.TH = 256 / p.TW;
   p.tilesX = cdiv(p.OW, p.TW);

@@ -72,14 +72,22 @@ def hip_conv2d(x: torch.Tensor, pk: PackedConv, stride: int, pad: int, act: int,
     lib = L.lib()
     stream = L.current_stream(x.device)
     if pk.stem:
-        if not (x.is_contiguous() and x.dtype in (torch.float32, torch.bfloat16)):
-            raise L.UpaError("first-layer input must be a contiguous NCHW float32/bfloat16 tensor")
-        n, cin, h, w = x.shape
-        odt = out_dtype or x.dtype
+        if x.dtype == torch.uint8:  # raw (N, H, W, 3) BGR frames: BGR->RGB, HWC->CHW, /255 fused into the stem load
+            if not (x.is_contiguous() and x.dim() == 4 and x.shape[-1] == 3):
+                raise L.UpaError("uint8 input must be a contiguous (N, H, W, 3) BGR batch")
+            n, h, w, cin = x.shape
+            odt = out_dtype or torch.float32
+            xcode = L.UPA_U8_BGR_HWC
+        else:
+            if not (x.is_contiguous() and x.dtype in (torch.float32, torch.bfloat16)):
+                raise L.UpaError("first-layer input must be a contiguous NCHW float32/bfloat16 tensor")
+            n, cin, h, w = x.shape
+            odt = out_dtype or x.dtype
+            xcode = L.dtype_code(x.dtype)
         oh, ow = (h + 2 * pad - pk.k) // stride + 1, (w + 2 * pad - pk.k) // stride + 1
         y = out if out is not None else R.alloc_nhwc(n, pk.cout, oh, ow, odt, x.device, key)
         vy = R.view_of(y)
-        L.check(lib.upa_conv2d_stem_nchw(x.data_ptr(), L.dtype_code(x.dtype), n, cin, h, w, pk.w.data_ptr(),
+        L.check(lib.upa_conv2d_stem_nchw(x.data_ptr(), xcode, n, cin, h, w, pk.w.data_ptr(),
                                          pk.bias.data_ptr(), vy.ptr, pk.cout, vy.ld, pk.k, stride, pad, act, vy.dtype,
                                          stream), "conv2d_stem")
         return y
@@ -122,7 +130,9 @@ class _HipConvMixin:
 
 
 def _is_model_input(x: torch.Tensor, cin: int) -> bool:
-    """A raw NCHW image batch (<= 4 channels, contiguous): handled by the stem kernel."""
+    """A raw image batch - NCHW float (<= 4 channels) or uint8 (N, H, W, 3) BGR frames: handled by the stem kernel."""
+    if x.dtype == torch.uint8:
+        return x.dim() == 4 and x.shape[-1] == 3 and cin == 3
     return cin <= 4 and x.dim() == 4 and x.is_contiguous() and (x.shape[2] > 1 or x.shape[3] > 1)
 
 
