@@ -132,3 +132,23 @@ def test_e2e_rect_and_odd_batches_vs_oracle(shape):
         if r.shape[0]:
             assert (a.cpu()[:, :5] - r[:, :5]).abs().max().item() <= TOL
             assert torch.equal(a.cpu()[:, 5], r[:, 5])
+
+
+def test_e2e_micro_batched_graph_equals_single_graph():
+    """compile(micro_batches=2): two sub-batches on parallel hipGraph branches give bit-identical detections."""
+    from tests.hip_utils import DEV
+    from ultralytics_pro_amd.utils.nms import nms_raw
+    m = _build("yolov8n", torch.float32)
+    x = P.synthetic_images(4).to(DEV)
+    with torch.no_grad():
+        run1 = m.compile(x, post=lambda o: nms_raw(o[0], 0.25, 0.7, key="one"))
+        out1, cnt1, _ = run1()
+        torch.cuda.synchronize()
+        out1, cnt1 = out1.clone(), cnt1.clone()
+        run2 = m.compile(x, post=lambda o: nms_raw(o[0], 0.25, 0.7, key="two"), micro_batches=2)
+        parts = run2()
+        parts = run2()
+        torch.cuda.synchronize()
+    out2 = torch.cat([p_[0] for p_ in parts], 0)
+    cnt2 = torch.cat([p_[1] for p_ in parts], 0)
+    assert torch.equal(cnt1, cnt2) and torch.equal(out1, out2)

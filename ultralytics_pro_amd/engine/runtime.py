@@ -81,6 +81,21 @@ class BufferPool:
 
 
 _POOL: list = [None]
+_TAG: list = [0]  # micro-batch tag: keeps the static buffers / side streams of concurrently scheduled sub-batches apart
+
+
+@contextlib.contextmanager
+def pool_tag(tag):
+    prev = _TAG[0]
+    _TAG[0] = tag
+    try:
+        yield
+    finally:
+        _TAG[0] = prev
+
+
+def current_tag():
+    return _TAG[0]
 
 
 @contextlib.contextmanager
@@ -97,7 +112,7 @@ def alloc_nhwc(n: int, c: int, h: int, w: int, dtype: torch.dtype, device, key=N
     """New NHWC buffer returned as a logical (N, C, H, W) tensor."""
     pool = _POOL[0]
     if pool is not None and key is not None:
-        buf = pool.get(key, (n, h, w, c), dtype, device)
+        buf = pool.get((_TAG[0], key), (n, h, w, c), dtype, device)
     else:
         buf = torch.empty((n, h, w, c), dtype=dtype, device=device)
     return buf.permute(0, 3, 1, 2)
@@ -106,7 +121,7 @@ def alloc_nhwc(n: int, c: int, h: int, w: int, dtype: torch.dtype, device, key=N
 def alloc_plain(shape, dtype, device, key=None) -> torch.Tensor:
     pool = _POOL[0]
     if pool is not None and key is not None:
-        return pool.get(key, tuple(shape), dtype, device)
+        return pool.get((_TAG[0], key), tuple(shape), dtype, device)
     return torch.empty(tuple(shape), dtype=dtype, device=device)
 
 

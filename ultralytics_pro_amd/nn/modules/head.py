@@ -65,20 +65,28 @@ class Detect(nn.Module, _HipConvMixin):
     concurrent = True
 
     def _side_streams(self, device):
-        st = self.__dict__.get("_streams")
-        if st is None or st[0].device != device:
+        pools = self.__dict__.setdefault("_streams", {})
+        key = (R.current_tag(), str(device))
+        st = pools.get(key)
+        if st is None:
             st = [torch.cuda.Stream(device=device) for _ in range(2 * self.nl)]
-            self.__dict__["_streams"] = st
+            pools[key] = st
         return st
+
+    def _pend(self):
+        return self.__dict__.setdefault("_pending", {}).setdefault(R.current_tag(), {})
 
     def start_level(self, i: int, x: torch.Tensor) -> None:
         """Launch level i's two branches (asynchronously when `concurrent`); results land in the level's raw buffer."""
-        pend = self.__dict__.setdefault("_pending", {})
+        pend = self._pend()
         x = R.to_nhwc(x, x.dtype)
         nb = 4 * self.reg_max
         n, _, h, w = x.shape
         buf = R.alloc_nhwc(n, self.no, h, w, x.dtype, x.device, key=(id(self), "raw", i))
-        if not self.concurrent:
+        if not self.concurrent or R.current_tag() != 0:
+            # inside a concurrently scheduled sub-batch (BaseModel.compile(micro_batches>1)) the branches stay on the
+            # sub-batch's stream: the sub-batches already overlap each other, and nesting a second level of event
+            # forks inside a forked capture stream crashed hipStreamEndCapture on ROCm 7.2 (segfault, not an error code)
             self._branch(self.cv2[i], x, buf[:, :nb])
             self._branch(self.cv3[i], x, buf[:, nb:])
             pend[i] = (buf, [])
@@ -101,7 +109,7 @@ class Detect(nn.Module, _HipConvMixin):
     def forward(self, x):
         if self.training:
             raise L.UpaError("training-mode Detect is not on the HIP path yet (SURVEY §8f rank 2)")
-        pend = self.__dict__.setdefault("_pending", {})
+        pend = self._pend()
         for i in range(self.nl):
             if i not in pend:
                 self.start_level(i, x[i])

@@ -191,7 +191,7 @@ class BaseModel(nn.Module):
         det = self.model[-1] if isinstance(self.model[-1], Detect) else None
         det_level = {}
         if det is not None:
-            det.__dict__.setdefault("_pending", {}).clear()
+            det._pend().clear()
             det_level = {(det.i - 1 if j == -1 else j): k for k, j in enumerate(det.f)} if isinstance(det.f, list) else {}
         for m in self.model:
             if m.f != -1:
@@ -263,17 +263,42 @@ class BaseModel(nn.Module):
         return self
 
     # ---- hipGraph replay -----------------------------------------------------------------------------------------------
-    def compile(self, example: torch.Tensor, post=None):
+    def compile(self, example: torch.Tensor, post=None, micro_batches: int = 1):
         """Capture `_predict_once(example)` (plus an optional post-processing callable) into a hipGraph.
 
-        Returns a callable `run(x)`: copies nothing - `x` must be the SAME tensor object / storage as `example`
-        (inputs already resident, as in a serving loop that writes frames into a fixed buffer)."""
+        Returns a callable `run()`: copies nothing - the input is read from `example`'s storage at every replay
+        (inputs already resident, as in a serving loop that writes frames into a fixed buffer).
+
+        micro_batches > 1 splits the batch into that many sub-batches that are walked on separate HIP streams (parallel
+        hipGraph branches): while one sub-batch's kernel drains (the 20x20 / 40x40 layers launch only a few hundred
+        workgroups on 256 CUs) the other sub-batch's kernels fill the idle CUs.  `post` is applied per sub-batch and
+        the results are returned as a list."""
         L.require_gpu(example, "compile")
         pool = R.BufferPool()
+        if micro_batches > 1:
+            if example.shape[0] % micro_batches:
+                raise L.UpaError("batch must be divisible by micro_batches")
+            step = example.shape[0] // micro_batches
+            side = [torch.cuda.Stream(device=example.device) for _ in range(micro_batches)]
 
-        def body():
-            out = self._predict_once(example)
-            return post(out) if post is not None else out
+            def body():
+                main = torch.cuda.current_stream(example.device)
+                fork = torch.cuda.Event()
+                fork.record(main)
+                outs = []
+                for k in range(micro_batches):
+                    side[k].wait_event(fork)
+                    with torch.cuda.stream(side[k]), R.pool_tag(k + 1):
+                        o = self._predict_once(example[k * step:(k + 1) * step])
+                        outs.append(post(o) if post is not None else o)
+                        ev = torch.cuda.Event()
+                        ev.record(side[k])
+                    main.wait_event(ev)
+                return outs
+        else:
+            def body():
+                out = self._predict_once(example)
+                return post(out) if post is not None else out
 
         with torch.no_grad(), R.static_buffers(pool):
             body()  # warm-up: allocates every static buffer, packs weights, sets LDS attributes
