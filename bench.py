@@ -43,7 +43,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-threads", type=int, default=32)
-    ap.add_argument("--micro-batches", type=int, default=2,
+    ap.add_argument("--serial", action="store_true",
+                    help="no intra-step concurrency (Detect branches on the main stream): per-kernel durations in a "
+                         "rocprofv3 trace of this mode are directly comparable with roofline.avg_launch_us")
+    ap.add_argument("--micro-batches", type=int, default=1,
                     help="walk the per-GPU batch as this many concurrent sub-batches (parallel hipGraph branches)")
     return ap.parse_args()
 
@@ -75,6 +78,8 @@ def main():
     P.apply_procedural_weights(model)
     model = model.to(dev).eval()
     model.set_compute_dtype(dtype)
+    if args.serial:
+        model.model[-1].concurrent = False
     # per-rank shard of the global batch: images [rank*B, (rank+1)*B) of the procedural stream
     x = P.synthetic_images(args.batch, first=rank * args.batch).to(dev)
     if dtype == torch.bfloat16:
@@ -130,7 +135,7 @@ def main():
             "data": "synthetic (procedural images + procedural weights, resident in HBM)",
             "config": {"workload": f"{args.model} detect 640x640 bs={args.batch} {args.dtype} inference, 1 hipGraph/step: "
                                    "forward+decode+NMS(conf .25, iou .7, max_det 300)",
-                       "micro_batches": args.micro_batches,
+                       "micro_batches": args.micro_batches, "intra_step_concurrency": not args.serial,
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch, "parallelism": f"dp{world} replicas"},
             "images_per_sec_per_gpu": round(value / world, 1),
             "detections_per_image_mean": round(sum(ndet) / max(1, len(ndet)), 1),
@@ -184,7 +189,7 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
             n, cin, h, w = xx.shape
             oh, ow = y.shape[2], y.shape[3]
             if pk.stem:
-                name = f"void stem_conv_kernel<{tname}, 16>(StemParams)"
+                name = f"void stem_conv_kernel<{tname}, 16, {'true' if act == 1 else 'false'}>(StemParams)"
             else:
                 var = L.lib().upa_conv_variant(n, h, w, cin, pk.cout, pk.k, stride, pad, code)
                 name = "void %s<%s, %d, %d, %d, %d, %d>(ConvParams)" % (
@@ -238,7 +243,9 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
         "flop_per_byte": round(ai, 1),
         "achieved_tflops": round(achieved_tf, 2),
         "achieved_gbs": round(achieved_gbs, 1),
-        "timing": f"HIP events around a hipGraph replay of {reps} back-to-back launches per layer, on the launch stream",
+        "timing": f"HIP events around a hipGraph replay of {reps} back-to-back launches per layer, on the launch stream "
+                  "(isolated kernel time; agrees with rocprofv3 AverageNs of `bench.py --serial`, while in the default "
+                  "run the Detect branches overlap on side streams and rocprofv3 reports stretched durations)",
     }
     kernels = {
         "conv_ms_per_step": round(conv_ms, 4),

@@ -715,9 +715,30 @@ int dispatch_ws(const ConvParams& p, hipStream_t stream) {
   return UPA_EUNSUPPORTED;
 }
 
+// Tuning hook (development): UPA_CONV_FORCE="WM,WN,MTW,NTW" forces one of the extra bf16 instantiations below for every
+// conv whose Cout fits it; used by tools/bench_conv.py sweeps, never set in production.
+template <typename T>
+int dispatch_forced(ConvParams& p, hipStream_t stream) {
+  if constexpr (sizeof(T) == 2) {
+    static const char* f = getenv("UPA_CONV_FORCE");
+    if (!f) return UPA_EUNSUPPORTED;
+    int wm = 0, wn = 0, mt = 0, nt = 0;
+    if (sscanf(f, "%d,%d,%d,%d", &wm, &wn, &mt, &nt) != 4) return UPA_EUNSUPPORTED;
+    if (p.NTn % (wn * nt) != 0 && p.NTn > wn * nt) return UPA_EUNSUPPORTED;
+    if (p.NTn < wn * nt) return UPA_EUNSUPPORTED;
+#define UPA_TRY(A, B, C, D) if (wm == A && wn == B && mt == C && nt == D) return launch_conv<T, A, B, C, D>(p, stream);
+    UPA_TRY(4, 1, 4, 2) UPA_TRY(4, 1, 2, 4) UPA_TRY(2, 2, 8, 2) UPA_TRY(4, 2, 2, 2) UPA_TRY(4, 1, 4, 4) UPA_TRY(2, 4, 4, 1)
+    UPA_TRY(4, 2, 4, 1) UPA_TRY(8, 1, 2, 2) UPA_TRY(4, 1, 4, 1) UPA_TRY(8, 1, 2, 1) UPA_TRY(4, 2, 4, 2)
+#undef UPA_TRY
+  }
+  return UPA_EUNSUPPORTED;
+}
+
 template <typename T>
 int dispatch_conv(ConvParams& p, hipStream_t stream) {
   {
+    const int rcf = dispatch_forced<T>(p, stream);
+    if (rcf != UPA_EUNSUPPORTED) return rcf;
     const int rc = dispatch_ws<T>(p, stream);
     if (rc != UPA_EUNSUPPORTED) return rc;
   }
