@@ -247,6 +247,15 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
                   "(isolated kernel time; agrees with rocprofv3 AverageNs of `bench.py --serial`, while in the default "
                   "run the Detect branches overlap on side streams and rocprofv3 reports stretched durations)",
     }
+    # HBM traffic per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see profiles/): only valid for
+    # the configuration they were collected on
+    try:
+        pmc = json.loads((ROOT / "profiles" / "r01_pmc_hbm_summary.json").read_text())
+        if pmc.get("config") == f"{args.model} bs={args.batch} {args.dtype}" and dom_name in pmc["kernels"]:
+            roofline["traffic"] = round(pmc["kernels"][dom_name]["hbm_bytes_per_launch"])
+            roofline["traffic_source"] = "profiles/r01_pmc_hbm_summary.json (rocprofv3 --pmc, separate passes)"
+    except (OSError, KeyError, ValueError):
+        pass
     kernels = {
         "conv_ms_per_step": round(conv_ms, 4),
         "conv_tflops": round(conv_flops / (conv_ms * 1e-3) / 1e12, 1),
