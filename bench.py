@@ -189,12 +189,17 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
             n, cin, h, w = xx.shape
             oh, ow = y.shape[2], y.shape[3]
             if pk.stem:
-                name = f"void stem_conv_kernel<{tname}, 16, {'true' if act == 1 else 'false'}>(StemParams)"
+                name = (f"void stem_mfma_kernel<{pk.cout // 16}, {pk.k}, {stride}, {'true' if act == 1 else 'false'}>(StemParams)" if es == 2 else
+                        f"void stem_conv_kernel<{tname}, 16, {'true' if act == 1 else 'false'}>(StemParams)")
             else:
                 var = L.lib().upa_conv_variant(n, h, w, cin, pk.cout, pk.k, stride, pad, code)
-                name = "void %s<%s, %d, %d, %d, %d, %d>(ConvParams)" % (
-                    "conv_ws_kernel" if (var >> 20) & 1 else "conv_igemm_kernel", tname, (var >> 12) & 15, (var >> 8) & 15,
-                    (var >> 4) & 15, var & 15, (var >> 16) & 15)
+                if (var >> 21) & 1:  # software-pipelined 3x3 (conv_pipe.hip): <NTW, act, residual>
+                    name = "void conv3x3_pipe_kernel<%d, %d, %s>(PipeParams)" % (
+                        var & 15, act, "true" if residual is not None else "false")
+                else:
+                    name = "void %s<%s, %d, %d, %d, %d, %d>(ConvParams)" % (
+                        "conv_ws_kernel" if (var >> 20) & 1 else "conv_igemm_kernel", tname, (var >> 12) & 15,
+                        (var >> 8) & 15, (var >> 4) & 15, var & 15, (var >> 16) & 15)
             flops = 2.0 * n * oh * ow * pk.cout * cin * pk.k * pk.k
             nbytes = n * h * w * cin * xx.element_size() + n * oh * ow * pk.cout * es * (2 if residual is not None else 1) \
                 + pk.cout * cin * pk.k * pk.k * es

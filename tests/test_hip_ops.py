@@ -68,6 +68,54 @@ def test_conv(case, dtype):
     assert (y - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
 
 
+PIPE_CASES = [
+    # c1, c2, H, W, N  (3x3 s1 p1, H % 8 == 0, W % 16 == 0: the software-pipelined kernel, csrc/conv_pipe.hip)
+    (64, 64, 16, 32, 2),     # KTT 2, NTW 4; interior + every edge
+    (32, 32, 8, 16, 3),      # single tile per image (all four edges at once)
+    (16, 16, 24, 16, 1),     # Cin 16: half a k-tile zero filled
+    (80, 80, 16, 16, 2),     # KTT 3 (80 of 96 channels), 80 couts = launches of 64 + 16
+    (128, 64, 8, 32, 1),     # KTT 4
+    (16, 32, 40, 48, 5),     # many tiles per persistent wave (5*5*3 = 75 tiles ... several rounds with UPA_PIPE_WGS small)
+    (64, 80, 8, 16, 2),
+    (48, 48, 16, 16, 1),     # 48 couts = 32 + 16
+    (24, 16, 8, 16, 1),      # Cin 24: partial k-tile
+]
+
+
+@pytest.mark.parametrize("case", PIPE_CASES, ids=[f"c{c[0]}-{c[1]}_{c[2]}x{c[3]}n{c[4]}" for c in PIPE_CASES])
+def test_conv_pipe_kernel(case):
+    """bf16 3x3 s1 convs through the persistent pipelined kernel vs the oracle Conv (conv.py:188-197) on bf16-rounded
+    inputs; includes image borders (zero padding by the DMA zero page), partial k-tiles and split output-channel launches."""
+    from tests.hip_utils import bf16_round, to_cpu_nchw, to_dev_nhwc
+    from ultralytics_pro_amd import _lib as L
+    pm, _ = _mods()
+    c1, c2, H, W, N = case
+    var = L.lib().upa_conv_variant(N, H, W, c1, c2, 3, 1, 1, 1)
+    assert (var >> 21) & 1, "case is not dispatched to the pipelined kernel"
+    o, m = _pair(om.Conv, pm.Conv, (c1, c2, 3, 1), "conv_pipe")
+    x = bf16_round(P.uniform(f"pipe{case}", (N, c1, H, W), -1, 1))
+    with torch.no_grad():
+        ref = o(x)
+        y = to_cpu_nchw(m(to_dev_nhwc(x, torch.bfloat16)))
+    assert y.shape == ref.shape
+    err = (y - ref).abs().max().item()
+    assert err <= 3e-2 * max(1.0, ref.abs().max().item()), err
+
+
+def test_conv_pipe_residual_and_concat_views():
+    """Bottleneck (block.py:644-668) with shortcut inside a C2f: residual add fused in the pipelined kernel's epilogue,
+    input / output / residual are channel slices of wider concat buffers (ld > C)."""
+    from tests.hip_utils import bf16_round, to_cpu_nchw, to_dev_nhwc
+    pm, _ = _mods()
+    o, m = _pair(om.C2f, pm.C2f, (64, 64, 2, True), "c2f_pipe")
+    x = bf16_round(P.uniform("c2f_pipe_x", (2, 64, 16, 32), -1, 1))
+    with torch.no_grad():
+        ref = o(x)
+        y = to_cpu_nchw(m(to_dev_nhwc(x, torch.bfloat16)))
+    err = (y - ref).abs().max().item()
+    assert err <= 4e-2 * max(1.0, ref.abs().max().item()), err
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 @pytest.mark.parametrize("case", [(3, 16, 3, 2, None, 64, 64), (3, 16, 6, 2, 2, 64, 64), (3, 32, 3, 1, None, 40, 48)],
                          ids=["v8stem", "v5stem", "v3stem"])
@@ -298,6 +346,31 @@ def test_stem_reads_uint8_bgr_frames():
         ref = o(ref_in)
         y = to_cpu_nchw(m(torch.from_numpy(frames).to(DEV)))
     assert (y - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("fmt", ["f32", "bf16", "u8"])
+@pytest.mark.parametrize("case", [(16, 3, 2, None, 50, 67), (32, 3, 1, None, 21, 130), (16, 6, 2, 2, 70, 66), (64, 3, 2, None, 24, 40)],
+                         ids=["v8n_odd", "v3_s1", "v5_k6", "cout64"])
+def test_stem_mfma_formats_and_ragged_sizes(case, fmt):
+    """bf16 compute mode of the first conv (MFMA form): f32 / bf16 NCHW and uint8 BGR HWC inputs, odd widths (unaligned
+    column pairs), partial tiles. Reference = oracle Conv on the bf16-rounded input (conv.py:188-197)."""
+    from tests.hip_utils import DEV, bf16_round, to_cpu_nchw
+    pm, _ = _mods()
+    c2, k, s, p, H, W = case
+    o, m = _pair(om.Conv, pm.Conv, (3, c2, k, s, p), "stem_mfma")
+    m.compute_dtype = torch.bfloat16
+    if fmt == "u8":
+        frames = (P.hash_uniform(f"u8m{case}", 2 * H * W * 3) * 256).astype("uint8").reshape(2, H, W, 3)
+        x = torch.from_numpy(frames[..., ::-1].transpose(0, 3, 1, 2).copy()).float() / 255
+        xin = torch.from_numpy(frames).to(DEV)
+    else:
+        x = P.uniform(f"stemm{case}", (2, 3, H, W), 0, 1)
+        xin = x.to(DEV).to(torch.bfloat16) if fmt == "bf16" else x.to(DEV)
+    with torch.no_grad():
+        ref = o(bf16_round(x))
+        y = to_cpu_nchw(m(xin))
+    assert y.shape == ref.shape
+    assert (y - ref).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
 
 
 def test_scale_boxes_matches_reference_formula():

@@ -39,8 +39,12 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   __bf16 b = (__bf16)f;
   return *reinterpret_cast<bf16_t*>(&b);
 }
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+// two round-to-nearest-even conversions in one v_cvt_pk_bf16_f32
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-  return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+  bf16x2 r = __builtin_convertvector(f32x2{lo, hi}, bf16x2);
+  return *reinterpret_cast<unsigned*>(&r);
 }
 
 template <typename T> struct ElemTraits;

@@ -24,6 +24,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "conv_pipe.h"
 
 struct ConvParams {
   const char* x;
@@ -795,6 +796,13 @@ extern "C" int upa_conv2d_bias_act(const void* x, int n, int h, int w, int cin, 
                 "conv2d: cout/ldy/ldr must be multiples of %d elements (16-byte row stores)", E);
   UPA_CHECK_ARG(g_query_only || (((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) &&
                                  (!residual || (uintptr_t)residual % 16 == 0)), "conv2d: misaligned view");
+  if (upa_conv_pipe_eligible(n, h, w, cin, ldx, cout, ldy, residual ? ldr : 0, k, stride, pad, act, dtype)) {
+    PipeParams q;
+    memset(&q, 0, sizeof(q));
+    q.x = (const char*)x; q.y = (char*)y; q.res = (const char*)residual; q.w = (const char*)w_packed; q.bias = bias;
+    q.N = n; q.H = h; q.W = w; q.Cin = cin; q.ldx = ldx; q.Cout = cout; q.ldy = ldy; q.ldr = ldr; q.act = act;
+    return upa_conv_pipe_launch(q, g_query_only, &g_last_variant, stream);
+  }
   ConvParams p;
   memset(&p, 0, sizeof(p));
   p.x = (const char*)x; p.y = (char*)y; p.res = (const char*)residual; p.w = (const char*)w_packed; p.bias = bias;

@@ -1,0 +1,18 @@
+// Internal interface between conv.hip (dispatch) and conv_pipe.hip (software-pipelined 3x3 stride-1 kernel).
+#pragma once
+struct PipeParams {
+  const char* x;
+  char* y;
+  const char* res;
+  const char* w;       // packed [tap][ktile][ntile][lane][16 B] (upa_pack_conv_weight)
+  const float* bias;
+  int N, H, W, Cin, ldx, Cout, ldy, ldr;
+  int KTT, NTn, nt0;   // k-tiles (32 bf16 channels), packed n-tiles, first n-tile of this launch
+  int tilesX, tilesY, numTiles;
+  int act;
+  int ablate;  // debug (UPA_PIPE_ABLATE): 1 no halo DMA, 2 no weight loads, 4 no stores, 8 no MFMA, 16 no epilogue
+};
+bool upa_conv_pipe_eligible(int n, int h, int w, int cin, int ldx, int cout, int ldy, int ldr, int k, int stride, int pad,
+                            int act, int dtype);
+// variant (if non-null) receives (1 << 21) | NTW of the first launch; query_only = 1 skips the launches
+int upa_conv_pipe_launch(PipeParams p, int query_only, int* variant, void* stream);

@@ -175,6 +175,249 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p) {
   }
 }
 
+// ---- MFMA form (bf16 compute mode, cin = 3).  The scalar-FMA kernel above spends cin*k*k*cout = 432 VALU FMAs per
+// output pixel (36 us of pure FMA issue for the yolov8n stem) - more than the HBM time of the layer.  Here the im2col row
+// of a pixel (K = 3*k*k, zero padded to 32*KSTEPS) is gathered from a bf16 LDS patch straight into the B operand of
+// v_mfma_f32_16x16x32_bf16 (8 two-byte LDS reads per lane per k-step), the weights sit in registers as A fragments for the
+// whole kernel, and a lane ends up with 4 consecutive output channels of one pixel: bias, SiLU, one 8-byte NHWC store.
+// One workgroup = 8 x 64 output pixels x all couts (NT tiles of 16); a wave owns two output rows.
+// All geometry is compile time (no integer divisions in the kernel); the patch origin is rounded down to 8 pixels so a
+// bf16 NCHW input whose width is a multiple of 8 is staged by LDS-DMA in 16-byte chunks (no VGPR round trip).
+typedef __attribute__((address_space(1))) const void* sgptr_t;
+typedef __attribute__((address_space(3))) void* slptr_t;
+__device__ __attribute__((aligned(16))) unsigned g_stem_zero16[4] = {0u, 0u, 0u, 0u};
+
+template <int KS, int S>
+struct StemGeo {
+  static constexpr int TH = 8, TW = 64;
+  static constexpr int PR = (TH - 1) * S + KS;          // patch rows
+  static constexpr int PC = (TW - 1) * S + KS;          // patch columns actually used
+  static constexpr int NCH = (PC + 7 + 7) / 8;          // 8-pixel chunks per line (origin shift <= 7)
+  static constexpr int LS = NCH * 8;                    // line stride (elements)
+  static constexpr int ITEMS = 3 * PR * NCH;            // 16-byte chunks in the patch
+  static constexpr int ITEMS_PAD = (ITEMS + 255) / 256 * 256;
+  static constexpr int KTOT = 3 * KS * KS;
+  static constexpr int KSTEPS = (KTOT + 31) / 32;
+};
+
+// Stage the patch of output tile `tile` into `buf` (bf16 [3][PR][LS], column 0 = the tile's first input column rounded
+// down to 8).  bf16 NCHW inputs with W % 8 == 0 go by LDS-DMA (asynchronous: caller waits vmcnt); the rest through VGPRs.
+template <int KS, int S>
+__device__ __forceinline__ void stem_stage(const StemParams& p, int tile, unsigned short* buf, int tid, int wave) {
+  using G = StemGeo<KS, S>;
+  const int tilesPerImg = p.tilesX * p.tilesY;
+  const int n = tile / tilesPerImg;
+  const int t2 = tile - n * tilesPerImg;
+  const int tyi = t2 / p.tilesX, txi = t2 - tyi * p.tilesX;
+  const int iy0 = tyi * G::TH * S - p.pad, ix0 = txi * G::TW * S - p.pad;
+  const int ixa = ix0 & ~7;                     // two's complement: floors negatives too
+  const int plane = p.H * p.W;                  // 3 * plane < 2^31 (checked by the launcher)
+  if (p.x_bf16 == 1 && (p.W & 7) == 0 && !(p.ablate & 16)) {
+    // lane = one 16-byte chunk (8 pixels of one line); chunks are entirely inside or outside the image
+    const bf16_t* xb = (const bf16_t*)p.x + (size_t)n * 3 * plane;
+#pragma unroll
+    for (int it = 0; it < G::ITEMS_PAD / 256; ++it) {
+      const int item = it * 256 + tid;
+      const int line = item / G::NCH, ch = item - line * G::NCH;
+      const int ci = line / G::PR, row = line - ci * G::PR;
+      const int iy = iy0 + row, ix = ixa + ch * 8;
+      const bool in = item < G::ITEMS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && !(p.ablate & 1);
+      const char* src = in ? reinterpret_cast<const char*>(xb + ci * plane + iy * p.W + ix)
+                           : reinterpret_cast<const char*>(g_stem_zero16);
+      __builtin_amdgcn_global_load_lds((sgptr_t)src, (slptr_t)((char*)buf + (it * 256 + wave * 64) * 16), 16, 0, 0);
+    }
+  } else if (p.x_bf16 == 2) {
+    // uint8 HWC BGR frames (engine/predictor.py:151-173): BGR->RGB, HWC->CHW, /255 fused into the load
+    const unsigned char* xu = (const unsigned char*)p.x;
+    for (int i = tid; i < G::PR * G::LS; i += 256) {
+      const int row = i / G::LS, col = i - row * G::LS;
+      const int iy = iy0 + row, ix = ixa + col;
+      float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+      if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+        const unsigned char* px = xu + (((size_t)n * p.H + iy) * p.W + ix) * 3;
+        v0 = (float)px[2] / 255.0f; v1 = (float)px[1] / 255.0f; v2 = (float)px[0] / 255.0f;
+      }
+      buf[(0 * G::PR + row) * G::LS + col] = f32_to_bf16(v0);
+      buf[(1 * G::PR + row) * G::LS + col] = f32_to_bf16(v1);
+      buf[(2 * G::PR + row) * G::LS + col] = f32_to_bf16(v2);
+    }
+  } else {
+    // f32 input or odd widths: one thread = one column pair of one line
+    const bool bf = p.x_bf16 != 0;
+    const bf16_t* xb = (const bf16_t*)p.x;
+    const float* xf = (const float*)p.x;
+    unsigned* bufw = reinterpret_cast<unsigned*>(buf);
+    constexpr int NP = G::LS / 2;
+    for (int i = tid; i < 3 * G::PR * NP; i += 256) {
+      const int line = i / NP, cp = i - line * NP;
+      const int ci = line / G::PR, row = line - ci * G::PR;
+      const int iy = iy0 + row, ix = ixa + 2 * cp;
+      float lo = 0.f, hi = 0.f;
+      if (iy >= 0 && iy < p.H) {
+        const size_t rb = ((size_t)n * 3 + ci) * plane + (size_t)iy * p.W;
+        if (ix >= 0 && ix < p.W) lo = bf ? bf16_to_f32(xb[rb + ix]) : xf[rb + ix];
+        if (ix + 1 >= 0 && ix + 1 < p.W) hi = bf ? bf16_to_f32(xb[rb + ix + 1]) : xf[rb + ix + 1];
+      }
+      bufw[i] = pack_bf16x2(lo, hi);
+    }
+  }
+}
+
+// Persistent: a workgroup walks tiles blockIdx.x, +gridDim.x, ...; while tile i is computed from one LDS buffer the
+// DMA of tile i+1 is already in flight into the other, so neither the weight fetch (once per workgroup) nor the memory
+// round trip of a patch is exposed per tile.
+template <int NT, int KS, int S, bool SILU>
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const StemParams p) {
+  using G = StemGeo<KS, S>;
+  constexpr int KSTEPS = G::KSTEPS;
+  constexpr int PATCH_BYTES = G::ITEMS_PAD * 16;
+  constexpr int OUT_ROW_BYTES = G::TW * NT * 32;      // one output row of the tile: 64 pixels x NT*16 bf16
+  extern __shared__ __attribute__((aligned(16))) char stem_sm[];  // [2][PATCH_BYTES] + [4 waves][OUT_ROW_BYTES]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ntiles = p.tilesX * p.tilesY * p.N;
+  int tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  stem_stage<KS, S>(p, tile, reinterpret_cast<unsigned short*>(stem_sm), tid, wave);
+  // ---- weights -> A fragments (lane: cout row lane%16, k = ks*32 + (lane/16)*8 + j), kept for the whole kernel;
+  // k = (kh*KS + kw)*3 + ci matches the packed [tap][ci][co] order
+  const int kg = lane >> 4, l16 = lane & 15;
+  const int wstride = (p.Cout + 15) / 16 * 16;
+  u32x4 afrag[NT][KSTEPS];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      float wv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = ks * 32 + kg * 8 + j;
+        wv[j] = k < G::KTOT ? p.w[k * wstride + nt * 16 + l16] : 0.f;
+      }
+      afrag[nt][ks] = u32x4{pack_bf16x2(wv[0], wv[1]), pack_bf16x2(wv[2], wv[3]), pack_bf16x2(wv[4], wv[5]),
+                            pack_bf16x2(wv[6], wv[7])};
+    }
+  f32x4 bias4[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias4[nt][r] = p.bias ? p.bias[nt * 16 + kg * 4 + r] : 0.f;
+  // per-lane gather offsets (bytes, inside a patch buffer) of the im2col row for output row `wave`, segment 0
+  const int shift = (-p.pad) & 7;  // tile origins are multiples of 64*S columns: the same for every tile
+  int gat[KSTEPS][8];
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = ks * 32 + kg * 8 + j;
+      int o = 0;
+      if (k < G::KTOT) {
+        const int tap = k / 3, ci = k - tap * 3;
+        const int kh = tap / KS, kw = tap - kh * KS;
+        o = (ci * G::PR + kh) * G::LS + kw;
+      }
+      gat[ks][j] = (o + shift + (wave * S) * G::LS + l16 * S) * 2;
+    }
+  char* ostage = stem_sm + 2 * PATCH_BYTES + wave * OUT_ROW_BYTES;
+  const int tilesPerImg = p.tilesX * p.tilesY;
+  constexpr int SEGS = G::TW / 16;
+  for (int cur = 0;; cur ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // patch `cur` landed for every wave; every wave is done reading the other buffer
+    const int next = tile + gridDim.x;
+    if (next < ntiles) stem_stage<KS, S>(p, next, reinterpret_cast<unsigned short*>(stem_sm + (cur ^ 1) * PATCH_BYTES), tid, wave);
+    const int n = tile / tilesPerImg;
+    const int t2 = tile - n * tilesPerImg;
+    const int tyi = t2 / p.tilesX, txi = t2 - tyi * p.tilesX;
+    const int oy0 = tyi * G::TH, ox0 = txi * G::TW;
+    const char* pb = stem_sm + cur * PATCH_BYTES;
+#pragma unroll
+    for (int rr = 0; rr < G::TH / 4; ++rr) {
+      if (p.ablate & 2) break;
+      f32x4 acc[SEGS][NT];
+      u32x4 b[SEGS][KSTEPS];
+#pragma unroll
+      for (int sx = 0; sx < SEGS; ++sx)
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+          unsigned e[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            e[j] = *reinterpret_cast<const unsigned short*>(pb + gat[ks][j] + (rr * 4 * S * G::LS + sx * 16 * S) * 2);
+          b[sx][ks] = u32x4{e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
+        }
+#pragma unroll
+      for (int sx = 0; sx < SEGS; ++sx)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          acc[sx][nt] = bias4[nt];
+#pragma unroll
+          for (int ks = 0; ks < KSTEPS; ++ks)
+            acc[sx][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&afrag[nt][ks]),
+                                                                  *reinterpret_cast<bf16x8*>(&b[sx][ks]), acc[sx][nt], 0, 0, 0);
+        }
+      // epilogue: bias is in, SiLU, bf16; the row goes through a wave-private LDS strip so that the global stores are
+      // whole contiguous 16-byte chunks (1 KiB per wave instruction) instead of 8-byte pieces of four lanes per pixel
+#pragma unroll
+      for (int sx = 0; sx < SEGS; ++sx)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float t = acc[sx][nt][r];
+            if constexpr (SILU) if (!(p.ablate & 4)) t = t * __builtin_amdgcn_rcpf(1.0f + __expf(-t));
+            v[r] = t;
+          }
+          *reinterpret_cast<u32x2*>(ostage + (sx * 16 + l16) * (NT * 32) + nt * 32 + kg * 8) =
+              u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int oy = oy0 + wave + rr * 4;
+      if (oy < p.OH && !(p.ablate & 8)) {
+        const unsigned rowpix = ((unsigned)n * p.OH + oy) * p.OW + ox0;  // < 2^31 pixels per tensor
+#pragma unroll
+        for (int c = 0; c < NT * 2; ++c) {
+          const int chunk = c * 64 + lane;
+          const int px = chunk / (NT * 2), part = chunk - px * (NT * 2);
+          const u32x4 val = *reinterpret_cast<const u32x4*>(ostage + chunk * 16);
+          if (ox0 + px < p.OW)
+            *reinterpret_cast<u32x4*>(p.y + ((size_t)(rowpix + px) * p.ldy + part * 8) * sizeof(bf16_t)) = val;
+        }
+      }
+    }
+    tile = next;
+    if (tile >= ntiles) break;
+  }
+}
+
+template <int NT, int KS, int S>
+static void launch_stem_mfma(const StemParams& p, int n, hipStream_t st) {
+  using G = StemGeo<KS, S>;
+  StemParams q = p;
+  q.TW = G::TW; q.TH = G::TH;
+  q.tilesX = cdiv(p.OW, G::TW);
+  q.tilesY = cdiv(p.OH, G::TH);
+  const long ntiles = (long)q.tilesX * q.tilesY * n;
+  static const int wgs = getenv("UPA_STEM_WGS") ? atoi(getenv("UPA_STEM_WGS")) : 1024;
+  dim3 grid((unsigned)(ntiles < wgs ? ntiles : wgs));
+  const size_t lds = (size_t)2 * G::ITEMS_PAD * 16 + 4 * G::TW * NT * 32;
+  if (p.act == UPA_ACT_SILU) {
+    auto kern = stem_mfma_kernel<NT, KS, S, true>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, q);
+  } else {
+    auto kern = stem_mfma_kernel<NT, KS, S, false>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, q);
+  }
+}
+template <int KS, int S>
+static void launch_stem_mfma_nt(const StemParams& p, int n, int nt, hipStream_t st) {
+  if (nt == 1) launch_stem_mfma<1, KS, S>(p, n, st);
+  else if (nt == 2) launch_stem_mfma<2, KS, S>(p, n, st);
+  else launch_stem_mfma<4, KS, S>(p, n, st);
+}
+
 // Host-side repack of OIHW f32 weights into [tap][ci][co padded to 16] (HOST memory in, HOST memory out).
 extern "C" size_t upa_stem_packed_weight_bytes(int cout, int cin, int k) {
   return (size_t)k * k * cin * ((cout + 15) / 16 * 16) * sizeof(float);
@@ -215,6 +458,19 @@ extern "C" int upa_conv2d_stem_nchw(const void* x, int x_dtype, int n, int cin, 
   p.PCS = p.PC + 1;
   static const int ablate = getenv("UPA_STEM_ABLATE") ? atoi(getenv("UPA_STEM_ABLATE")) : 0;
   p.ablate = ablate;
+  static const bool no_mfma = getenv("UPA_STEM_NO_MFMA") != nullptr;
+  const int nt16 = cout / 16;
+  if (dtype == UPA_BF16 && !no_mfma && cin == 3 && cout % 16 == 0 && (nt16 == 1 || nt16 == 2 || nt16 == 4) &&
+      ((k == 3 && (stride == 1 || stride == 2)) || (k == 6 && stride == 2)) && (long)cin * h * w < (1L << 31) &&
+      (long)n * p.OH * p.OW < (1L << 31)) {
+    UPA_CHECK_ARG(act == UPA_ACT_SILU || act == UPA_ACT_NONE, "stem: activation must be SiLU or none");
+    hipStream_t stm = (hipStream_t)stream;
+    if (k == 3 && stride == 2) launch_stem_mfma_nt<3, 2>(p, n, nt16, stm);
+    else if (k == 3) launch_stem_mfma_nt<3, 1>(p, n, nt16, stm);
+    else launch_stem_mfma_nt<6, 2>(p, n, nt16, stm);
+    UPA_LAUNCH_CHECK();
+    return UPA_OK;
+  }
   constexpr int CO_T = 16;
   dim3 grid((unsigned)((long)p.tilesX * p.tilesY * n), (unsigned)cdiv(cout, CO_T));
   const size_t lds = (size_t)cin * p.PR * p.PCS * sizeof(float);
