@@ -8,6 +8,7 @@ Outputs are data only (inputs are re-derivable from the hash; expected outputs a
   tests/golden/nms_cases.npz        NMS inputs + reference outputs                               (§8c c)
   tests/golden/e2e_<cfg>.npz        head-output slices/statistics + post-NMS rows, B=2            (§8c d)
   tests/golden/map_yolov8n.npz      synthetic-GT validation set: detections, labels, TP matrices, AP (§8f rank 1)
+  tests/golden/train_<cfg>.npz      training step(s): loss items, gradient norms / slices, updated state, EMA (§8f rank 2)
 """
 
 from __future__ import annotations
@@ -383,11 +384,83 @@ def map_golden(rt):
     np.savez_compressed(GOLD / f"map_{name}.npz", **G)
 
 
+def train_golden(rt):
+    """one training step (train-mode forward, v8DetectionLoss, backward, clip, SGD nesterov,
+    EMA) of the imported reference vs oracle/train.py on procedural weights, images and labels."""
+    from types import SimpleNamespace
+
+    from ultralytics.utils.torch_utils import ModelEMA
+
+    from oracle import train as otr
+
+    for name, bs, imgsz, steps in (("yolov8n", 4, 320, 2), ("yolov8s", 2, 256, 1)):
+        ref = rt.DetectionModel(REF_CFG[name], ch=3, nc=80, verbose=False)
+        P.apply_procedural_weights(ref, family=P.model_family(ot.DetectionModel(name + ".yaml")))
+        ref.args = SimpleNamespace(box=7.5, cls=0.5, dfl=1.5)
+        mine = ot.DetectionModel(name + ".yaml")
+        P.apply_procedural_weights(mine)
+        hyp = otr.HYP
+        g0, g1, g2 = otr.param_groups(ref)
+        opt = torch.optim.SGD([p for _, p in g2], lr=hyp["lr"], momentum=hyp["momentum"], nesterov=True)
+        opt.add_param_group({"params": [p for _, p in g0], "weight_decay": hyp["weight_decay"]})
+        opt.add_param_group({"params": [p for _, p in g1], "weight_decay": 0.0})
+        ema = ModelEMA(ref, decay=hyp["ema_decay"], tau=hyp["ema_tau"])
+        state = otr.TrainState(mine)
+        G = {"bs": np.array([bs]), "imgsz": np.array([imgsz]), "steps": np.array([steps])}
+        for step in range(steps):
+            x = P.synthetic_images(bs, h=imgsz, w=imgsz, seed=step)
+            lab = P.synthetic_labels(bs, seed=step)
+            batch = {"img": x, **lab}
+            ref.train()
+            loss, items_r = ref(dict(batch))                     # tasks.py: forward(dict) -> self.loss(batch)
+            loss.sum().backward()                                 # trainer.py:424-432 (world_size 1, no scaler)
+            norm_r = torch.nn.utils.clip_grad_norm_(ref.parameters(), max_norm=hyp["max_norm"])  # trainer.py:677
+            gr = {k: p.grad.detach().clone() for k, p in ref.named_parameters() if p.grad is not None}
+            opt.step()
+            opt.zero_grad()
+            ema.update(ref)
+            items_o, norm_o = otr.train_step(mine, state, {"img": x.clone(), **lab}, hyp)
+            go = {k: p.grad.detach().clone() for k, p in mine.named_parameters() if p.grad is not None}
+            assert set(gr) == set(go)
+            dl = maxdiff(items_r, items_o)
+            dg = max(maxdiff(gr[k], go[k]) for k in gr)
+            dp = max(maxdiff(a, b) for a, b in zip(ref.state_dict().values(), mine.state_dict().values()))
+            for (ka, a), (kb, b) in zip(ref.state_dict().items(), mine.state_dict().items()):
+                if maxdiff(a, b) != 0:
+                    print("   differs:", ka, kb, maxdiff(a, b), a.flatten()[:3].tolist(), b.flatten()[:3].tolist())
+                    break
+            de = max(maxdiff(ema.ema.state_dict()[k], state.ema[k]) for k in state.ema)
+            print(f"train {name} step {step}: loss items {items_r.tolist()} |grad| {float(norm_r):.4f}  oracle-vs-ref: "
+                  f"loss {dl:.2e} grad {dg:.2e} params {dp:.2e} ema {de:.2e}")
+            assert dl == 0 and dg == 0 and dp == 0 and de == 0 and float(norm_r) == norm_o
+            G[f"loss_items_{step}"] = items_r.numpy().copy()
+            G[f"grad_norm_{step}"] = np.array([float(norm_r)])
+            keys = list(gr.keys())
+            G[f"grad_l2_{step}"] = np.array([float(gr[k].double().norm()) for k in keys])   # after clipping
+            G[f"grad_sum_{step}"] = np.array([float(gr[k].double().sum()) for k in keys])
+            sd = ref.state_dict()
+            fk = [k for k, v in sd.items() if v.dtype.is_floating_point]
+            G[f"state_sum_{step}"] = np.array([float(sd[k].double().sum()) for k in fk])
+            G[f"state_l2_{step}"] = np.array([float(sd[k].double().norm()) for k in fk])
+            G[f"ema_sum_{step}"] = np.array([float(ema.ema.state_dict()[k].double().sum()) for k in fk])
+            # a few raw slices: the last head conv gradients (small tensors) and the first conv's weight after the step
+            G[f"grad_cls_bias_{step}"] = gr["model.22.cv3.0.2.bias"].numpy()
+            G[f"grad_box_bias_{step}"] = gr["model.22.cv2.2.2.bias"].numpy()
+            G[f"grad_stem_w_{step}"] = gr["model.0.conv.weight"].numpy()
+            G[f"grad_bn_w_{step}"] = gr["model.4.cv1.bn.weight"].numpy()
+            G[f"w_stem_{step}"] = sd["model.0.conv.weight"].numpy().copy()
+            G[f"bn_rm_{step}"] = sd["model.2.cv1.bn.running_mean"].numpy().copy()
+            G[f"bn_rv_{step}"] = sd["model.2.cv1.bn.running_var"].numpy().copy()
+        G["param_keys"] = np.array(keys)
+        G["state_keys"] = np.array(fk)
+        np.savez_compressed(GOLD / f"train_{name}.npz", **G)
+
+
 def main():
     torch.manual_seed(0)
     GOLD.mkdir(parents=True, exist_ok=True)
     rt = import_reference()
-    which = sys.argv[1:] or ["builder", "ops", "nms", "e2e", "map"]
+    which = sys.argv[1:] or ["builder", "ops", "nms", "e2e", "map", "train"]
     with torch.no_grad():
         if "builder" in which:
             builder_tables(rt)
@@ -399,6 +472,8 @@ def main():
             e2e(rt)
         if "map" in which:
             map_golden(rt)
+    if "train" in which:
+        train_golden(rt)
 
 
 if __name__ == "__main__":

@@ -113,8 +113,9 @@ class DetectionModel(nn.Module):
         self.end2end = False
         m = self.model[-1]
         if isinstance(m, Detect):
-            s = 256  # stride discovery by a 256x256 zero-image forward in train mode (tasks.py:1315-1331)
-            self.train()
+            s = 256  # stride discovery by a 256x256 zero-image forward (tasks.py:1315-1331): the body in eval mode so
+            self.eval()  # the BN statistics stay untouched, only the head in train mode (it returns the raw maps)
+            m.training = True
             with torch.no_grad():
                 outs = self._predict_once(torch.zeros(1, ch, s, s))
             m.stride = torch.tensor([s / x.shape[-2] for x in outs])

@@ -178,3 +178,31 @@ def test_e2e_rtdetr(golden_dir):
     assert np.abs(y.numpy() - g["y"]).max() <= 1e-4
     outs = onms.rtdetr_postprocess(y, 0.25)
     assert [o.shape[0] for o in outs] == list(g["post_n"])
+
+
+def test_oracle_train_step_matches_reference_golden(golden_dir):
+    """oracle/train.py (train-mode forward, v8DetectionLoss + TaskAlignedAssigner, backward, clip,
+    SGD nesterov, EMA) reproduces what the imported reference recorded in tests/golden/train_yolov8n.npz."""
+    from oracle import tasks as ot
+    from oracle import train as otr
+    G = np.load(golden_dir / "train_yolov8n.npz")
+    bs, imgsz = int(G["bs"][0]), int(G["imgsz"][0])
+    torch.set_num_threads(4)
+    m = ot.DetectionModel("yolov8n.yaml")
+    P.apply_procedural_weights(m)
+    state = otr.TrainState(m)
+    x = P.synthetic_images(bs, h=imgsz, w=imgsz, seed=0)
+    items, norm = otr.train_step(m, state, {"img": x, **P.synthetic_labels(bs, seed=0)})
+    np.testing.assert_allclose(items.numpy(), G["loss_items_0"], rtol=2e-5)
+    assert abs(norm - float(G["grad_norm_0"][0])) <= 2e-4 * norm
+    grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    keys = [str(k) for k in G["param_keys"]]
+    assert list(grads) == keys
+    l2 = np.array([float(grads[k].double().norm()) for k in keys])
+    np.testing.assert_allclose(l2, G["grad_l2_0"], rtol=2e-3, atol=1e-7)
+    np.testing.assert_allclose(grads["model.22.cv3.0.2.bias"].numpy(), G["grad_cls_bias_0"], rtol=1e-3, atol=1e-6)
+    sd = m.state_dict()
+    np.testing.assert_allclose(sd["model.0.conv.weight"].numpy(), G["w_stem_0"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(sd["model.2.cv1.bn.running_var"].numpy(), G["bn_rv_0"], rtol=1e-5)
+    fk = [str(k) for k in G["state_keys"]]
+    np.testing.assert_allclose(np.array([float(state.ema[k].double().sum()) for k in fk]), G["ema_sum_0"], rtol=1e-4, atol=1e-4)

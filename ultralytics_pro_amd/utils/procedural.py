@@ -201,3 +201,22 @@ def apply_procedural_weights(model: torch.nn.Module, seed: int = 0, family: str 
             if t is not None:
                 v.copy_(t.to(v.dtype))
     return model
+
+
+def synthetic_labels(batch: int, seed: int = 0, first: int = 0):
+    """Synthetic training labels: per image k ~ U{1..8} boxes, cls ~ U{0..79},
+    cx, cy ~ U(0.1, 0.9), w, h ~ U(0.05, 0.4), normalised xywh - the reference's batch dict layout
+    {"batch_idx" (n,), "cls" (n,), "bboxes" (n,4)} (utils/loss.py:486). Image `first + i` always gets the same labels,
+    so a rank's shard of a global batch is reproducible anywhere."""
+    import torch
+    bi, cl, bb = [], [], []
+    for i in range(batch):
+        u = hash_uniform(f"labels:{seed}:{first + i}", 1 + 8 * 5)
+        k = 1 + int(u[0] * 8)
+        r = u[1:].reshape(8, 5)[:k]
+        bi.append(np.full(k, i, dtype=np.float32))
+        cl.append(np.floor(r[:, 0] * 80).astype(np.float32))
+        box = np.stack([0.1 + 0.8 * r[:, 1], 0.1 + 0.8 * r[:, 2], 0.05 + 0.35 * r[:, 3], 0.05 + 0.35 * r[:, 4]], 1)
+        bb.append(box.astype(np.float32))
+    return {"batch_idx": torch.from_numpy(np.concatenate(bi)), "cls": torch.from_numpy(np.concatenate(cl)),
+            "bboxes": torch.from_numpy(np.concatenate(bb))}
