@@ -139,6 +139,65 @@ int upa_box_iou(const float* box1, int n, const float* box2, int m, float eps, f
 int upa_scale_boxes(float* rows, long n, int row_stride, float gain, float pad_x, float pad_y, int padding, float w0,
                     float h0, void* stream);
 
+/* ---- training step (BASELINE config 3) ------------------------------------------------------------
+ * What the reference gets from torch autograd around Conv = conv2d -> BatchNorm2d(batch statistics) -> SiLU
+ * (nn/modules/conv.py:177-186), the SPPF pools (nn/modules/block.py:402-406), nn.Upsample, v8DetectionLoss
+ * (utils/loss.py:415-528) and the optimizer step (engine/trainer.py:674-682).  Activations and their gradients are NHWC
+ * views (f32 or bf16), parameters / parameter gradients / statistics are f32.
+ *
+ * Device-side repack of OIHW f32 master weights into the MFMA fragment layout of upa_conv2d_bias_act.
+ * transpose_flip = 1 packs V[ci][co][kh][kw] = W[co][ci][k-1-kh][k-1-kw]: the data gradient of a stride-1 conv is then
+ * upa_conv2d_bias_act(dz, V, pad = k-1-p) (a stride-2 conv first goes through upa_dilate2x). */
+int upa_pack_conv_weight_dev(const float* w_oihw, int cout, int cin, int k, int dtype, int transpose_flip, void* out,
+                             void* stream);
+/* Batch statistics: sum / sumsq (f64, c each) over npix rows, then mean / biased var + nn.BatchNorm2d running update
+ * (running_var takes the unbiased estimate; running_* may be NULL). */
+int upa_bn_stats(const void* z, long npix, int c, int ldz, double* sum, double* sumsq, int dtype, void* stream);
+int upa_bn_finalize(const double* sum, const double* sumsq, long npix, int c, float momentum, float* mean, float* var,
+                    float* running_mean, float* running_var, void* stream);
+/* y = act(gamma * (z - mean) / sqrt(var + eps) + beta) (+ residual) */
+int upa_bn_act_fwd(const void* z, long npix, int c, int ldz, const float* mean, const float* var, const float* gamma,
+                   const float* beta, float eps, int act, void* y, int ldy, const void* residual, int ldr, int dtype,
+                   void* stream);
+/* Backward of the above (z saved from the forward): dgamma, dbeta (f32, optionally accumulated) and dz.
+ * ws: 2*c doubles of scratch. */
+int upa_bn_act_bwd(const void* z, const void* dy, long npix, int c, int ldz, int lddy, const float* mean, const float* var,
+                   const float* gamma, const float* beta, float eps, int act, void* dz, int lddz, float* dgamma, float* dbeta,
+                   int accumulate, double* ws, int dtype, void* stream);
+/* out[c] (+)= sum over rows of z[:, c]  (bias gradient of the plain nn.Conv2d head outputs). ws: 2*c doubles. */
+int upa_channel_sum(const void* z, long npix, int c, int ldz, float* out, int accumulate, double* ws, int dtype, void* stream);
+/* dW[co][ci][kh][kw] (OIHW f32, optionally accumulated) = sum_{n,oy,ox} dz[n,oy,ox,co] * x[n,oy*s+kh-p,ox*s+kw-p,ci]
+ * on exact-f32 MFMA; k in {1, 3}. */
+int upa_conv2d_wgrad(const void* x, int n, int h, int w, int cin, int ldx, const void* dz, int cout, int lddz, float* dw_oihw,
+                     int k, int stride, int pad, int accumulate, int dtype, void* stream);
+/* dst (n,h,w,c) = zero-inserted src (n,oh,ow,c): dst[y,x] = src[y/2,x/2] for even y, x (data gradient of stride 2). */
+int upa_dilate2x(const void* src, int n, int oh, int ow, int c, int lds, void* dst, int h, int w, int ldd, int dtype,
+                 void* stream);
+/* dx (n,h,w,c) (+)= 2x2 block sums of dy (n,2h,2w,c): backward of nn.Upsample(scale 2, nearest). */
+int upa_upsample2x_bwd(const void* dy, int n, int h, int w, int c, int lddy, void* dx, int lddx, int accumulate, int dtype,
+                       void* stream);
+/* Backward of nn.MaxPool2d(k, stride, pad): dy goes to the first maximum of each window (torch's index rule). */
+int upa_maxpool2d_bwd(const void* x, const void* dy, int n, int h, int w, int c, int ldx, int lddy, int k, int stride, int pad,
+                      void* dx, int lddx, int accumulate, int dtype, void* stream);
+/* *out (+)= sum g[i]^2 (f64): squared gradient norm for clip_grad_norm_. */
+int upa_sumsq(const float* g, long n, double* out, int accumulate, void* stream);
+/* clip_grad_norm_(max_norm) + SGD(nesterov, weight decay) + ModelEMA update over a flat parameter segment
+ * (engine/trainer.py:674-682, :891-950; utils/torch_utils.py:632-646).  ema may be NULL. */
+int upa_sgd_nesterov_ema(float* p, float* g, float* momentum_buf, float* ema, long n, const double* grad_sumsq, float max_norm,
+                         float lr, float momentum, float weight_decay, int first_step, float ema_d, int zero_grad, void* stream);
+int upa_ema_update(float* ema, const float* v, long n, float d, void* stream);
+/* dst view = src view converted between f32 and bf16 (head maps enter the loss as f32; c, strides multiples of 8). */
+int upa_cast_view(const void* src, int src_dtype, int lds, void* dst, int dst_dtype, int ldd, long npix, int c, void* stream);
+/* v8DetectionLoss forward + gradient wrt the raw head maps.  feats[l] / grads[l]: NHWC f32 rows [(b,y,x)][4*reg_max+nc]
+ * with row stride lds[l]; gt: (b, max_gt = 64, 5) rows (cls, x1, y1, x2, y2) in pixels, n_gt[b] valid rows.
+ * loss_items = (box, cls, dfl) as the reference reports them; gradients are those of loss.sum() * grad_scale
+ * (grad_scale = world_size, engine/trainer.py:424-425). */
+size_t upa_detection_loss_workspace_bytes(int b, int n_anchors);
+int upa_detection_loss(const float* const* feats, float* const* grads, const int* hs, const int* ws, const int* lds,
+                       const float* strides, int n_levels, int b, int nc, int reg_max, const float* gt, const int* n_gt,
+                       int max_gt, float gain_box, float gain_cls, float gain_dfl, float grad_scale, float* loss_items,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- HIP graph helpers (capture a launch sequence once, replay per batch) ------------------------------------- */
 int upa_graph_begin(void* stream);
 int upa_graph_end(void* stream, void** graph_exec_out);

@@ -56,6 +56,22 @@ PROTOTYPES = {
     "upa_msdeform_attn": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "upa_box_iou": (_i, [_vp, _i, _vp, _i, _f, _vp, _vp]),
     "upa_scale_boxes": (_i, [_vp, C.c_long, _i, _f, _f, _f, _i, _f, _f, _vp]),
+    "upa_pack_conv_weight_dev": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "upa_bn_stats": (_i, [_vp, C.c_long, _i, _i, _vp, _vp, _i, _vp]),
+    "upa_bn_finalize": (_i, [_vp, _vp, C.c_long, _i, _f, _vp, _vp, _vp, _vp, _vp]),
+    "upa_bn_act_fwd": (_i, [_vp, C.c_long, _i, _i, _vp, _vp, _vp, _vp, _f, _i, _vp, _i, _vp, _i, _i, _vp]),
+    "upa_bn_act_bwd": (_i, [_vp, _vp, C.c_long, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp]),
+    "upa_channel_sum": (_i, [_vp, C.c_long, _i, _i, _vp, _i, _vp, _i, _vp]),
+    "upa_conv2d_wgrad": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    "upa_dilate2x": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp]),
+    "upa_upsample2x_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
+    "upa_maxpool2d_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
+    "upa_sumsq": (_i, [_vp, C.c_long, _vp, _i, _vp]),
+    "upa_sgd_nesterov_ema": (_i, [_vp, _vp, _vp, _vp, C.c_long, _vp, _f, _f, _f, _f, _i, _f, _i, _vp]),
+    "upa_ema_update": (_i, [_vp, _vp, C.c_long, _f, _vp]),
+    "upa_cast_view": (_i, [_vp, _i, _i, _vp, _i, _i, C.c_long, _i, _vp]),
+    "upa_detection_loss_workspace_bytes": (_sz, [_i, _i]),
+    "upa_detection_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp, _sz, _vp]),
     "upa_graph_begin": (_i, [_vp]),
     "upa_graph_end": (_i, [_vp, C.POINTER(_vp)]),
     "upa_graph_launch": (_i, [_vp, _vp]),

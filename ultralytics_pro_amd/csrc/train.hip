@@ -1,0 +1,762 @@
+// Training-step kernels (SURVEY 8f rank 2 / BASELINE config 3): what the reference obtains from torch autograd for
+// Conv = conv2d -> BatchNorm2d(batch statistics) -> SiLU (ultralytics/nn/modules/conv.py:177-186), SPPF max pools
+// (nn/modules/block.py:402-406), nn.Upsample, and the optimizer step of engine/trainer.py:674-682.
+//   * upa_pack_conv_weight_dev    device-side repack of the f32 master weights (forward layout, or transposed + flipped
+//                                 for the data gradient, which then runs on the forward conv kernels)
+//   * upa_bn_stats / upa_bn_finalize   per-channel batch mean / biased variance (f64 combination), running-stat update
+//   * upa_bn_act_fwd              y = act(gamma * (z - mean) * rstd + beta) (+ residual)
+//   * upa_bn_act_bwd_reduce/_apply   d(gamma), d(beta) and dz through activation + batch-stat BN
+//   * upa_conv2d_wgrad            dW = sum over pixels of dz (x) x on exact-f32 MFMA (v_mfma_f32_16x16x4_f32): both
+//                                 operands are pixel-major (NHWC), which is exactly the k-per-lane layout of the f32
+//                                 MFMA - no transposition anywhere; persistent workgroups accumulate in registers
+//   * upa_channel_sum             bias gradient of the plain nn.Conv2d head outputs
+//   * upa_dilate2x, upa_upsample2x_bwd, upa_maxpool_bwd
+//   * upa_sumsq, upa_sgd_nesterov_ema   gradient norm, clipped SGD(nesterov) + weight decay + EMA in one pass
+// All HBM-bound except wgrad (f32 MFMA bound).
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+template <typename T> __device__ __forceinline__ void load16(const char* p, float* v);
+template <> __device__ __forceinline__ void load16<float>(const char* p, float* v) {
+  const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+  v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+}
+template <> __device__ __forceinline__ void load16<bf16_t>(const char* p, float* v) {
+  const u32x4 t = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[2 * i] = __uint_as_float(t[i] << 16);
+    v[2 * i + 1] = __uint_as_float(t[i] & 0xFFFF0000u);
+  }
+}
+template <typename T> __device__ __forceinline__ void store16(char* p, const float* v);
+template <> __device__ __forceinline__ void store16<float>(char* p, const float* v) {
+  *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+}
+template <> __device__ __forceinline__ void store16<bf16_t>(char* p, const float* v) {
+  *reinterpret_cast<u32x4*>(p) = u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                       pack_bf16x2(v[6], v[7])};
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void pack_weight_dev_kernel(const float* w, int cout, int cin, int k, int E, int transpose_flip, void* out,
+                                       long total) {
+  // logical weight V[co'][ci'][kh][kw]; transpose_flip: V[a][b][kh][kw] = W[b][a][k-1-kh][k-1-kw] (data gradient)
+  const int lc_out = transpose_flip ? cin : cout, lc_in = transpose_flip ? cout : cin;
+  const int ktch = 4 * E;
+  const int ktt = (lc_in + ktch - 1) / ktch, ntn = (lc_out + 15) / 16;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long t = idx;
+    const int j = (int)(t % E); t /= E;
+    const int lane = (int)(t % 64); t /= 64;
+    const int nt = (int)(t % ntn); t /= ntn;
+    const int kt = (int)(t % ktt); t /= ktt;
+    const int tap = (int)t;
+    const int kh = tap / k, kw = tap - kh * k;
+    const int g = lane >> 4, r = lane & 15;
+    const int co = nt * 16 + r, ci = kt * ktch + g * E + j;
+    float v = 0.f;
+    if (co < lc_out && ci < lc_in) {
+      if (transpose_flip) v = w[(((size_t)ci * cin + co) * k + (k - 1 - kh)) * k + (k - 1 - kw)];
+      else v = w[(((size_t)co * cin + ci) * k + kh) * k + kw];
+    }
+    if (E == 8) ((bf16_t*)out)[idx] = f32_to_bf16(v);
+    else ((float*)out)[idx] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Per-channel reductions over an NHWC view.  MODE 0: sum(z), sum(z^2).  MODE 1 (BN+act backward): sum(du),
+// sum(du * xhat) with du = dy * act'(gamma*xhat+beta).  MODE 2: sum(z) only (bias gradient).
+// Thread = one 16-byte channel group of a strided set of pixels; block partials meet in LDS (f64), one f64 atomic per
+// channel per block reaches HBM.
+struct ReduceParams {
+  const char* z; const char* dy;
+  long npix; int c, ldz, lddy;
+  const float* mean; const float* var; const float* gamma; const float* beta;
+  float eps; int act;
+  double* out0; double* out1;
+};
+
+__device__ __forceinline__ float silu_grad(float u) {
+  const float s = 1.0f / (1.0f + expf(-u));
+  return s * (1.0f + u * (1.0f - s));
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void channel_reduce_kernel(const ReduceParams p) {
+  extern __shared__ double red[];  // [2][c]
+  constexpr int E = 16 / sizeof(T);
+  const int cg = p.c / E;
+  const int ppb = 256 / cg;  // pixels per pass (>= 1: c <= 256*E checked by the launcher)
+  const int tid = threadIdx.x;
+  const int grp = tid % cg, sub = tid / cg;
+  for (int i = tid; i < 2 * p.c; i += 256) red[i] = 0.0;
+  __syncthreads();
+  float s0[E], s1[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) s0[e] = s1[e] = 0.f;
+  float mean[E], rstd[E], gam[E], bet[E];
+  if (MODE == 1) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int ch = grp * E + e;
+      mean[e] = p.mean[ch]; rstd[e] = 1.0f / sqrtf(p.var[ch] + p.eps); gam[e] = p.gamma[ch]; bet[e] = p.beta[ch];
+    }
+  }
+  if (sub < ppb) {
+    const long chunk = (p.npix + gridDim.x - 1) / gridDim.x;
+    const long p0 = (long)blockIdx.x * chunk;
+    long p1 = p0 + chunk;
+    if (p1 > p.npix) p1 = p.npix;
+    int cnt = 0;
+    for (long px = p0 + sub; px < p1; px += ppb) {
+      float v[E];
+      load16<T>(p.z + ((size_t)px * p.ldz + grp * E) * sizeof(T), v);
+      if (MODE == 0) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) { s0[e] += v[e]; s1[e] += v[e] * v[e]; }
+      } else if (MODE == 2) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) s0[e] += v[e];
+      } else {
+        float d[E];
+        load16<T>(p.dy + ((size_t)px * p.lddy + grp * E) * sizeof(T), d);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const float xh = (v[e] - mean[e]) * rstd[e];
+          float du = d[e];
+          if (p.act == UPA_ACT_SILU) du *= silu_grad(gam[e] * xh + bet[e]);
+          s0[e] += du;
+          s1[e] += du * xh;
+        }
+      }
+      if (++cnt == 64) {  // bound the f32 partial sums: fold into the f64 block accumulators
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          atomicAdd(&red[grp * E + e], (double)s0[e]);
+          if (MODE != 2) atomicAdd(&red[p.c + grp * E + e], (double)s1[e]);
+          s0[e] = s1[e] = 0.f;
+        }
+        cnt = 0;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      atomicAdd(&red[grp * E + e], (double)s0[e]);
+      if (MODE != 2) atomicAdd(&red[p.c + grp * E + e], (double)s1[e]);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < p.c; i += 256) {
+    atomicAdd(&p.out0[i], red[i]);
+    if (MODE != 2) atomicAdd(&p.out1[i], red[p.c + i]);
+  }
+}
+
+__global__ void bn_finalize_kernel(const double* sum, const double* sumsq, long npix, int c, float momentum, float* mean,
+                                   float* var, float* running_mean, float* running_var) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c) return;
+  const double m = sum[i] / (double)npix;
+  double v = sumsq[i] / (double)npix - m * m;
+  if (v < 0) v = 0;
+  mean[i] = (float)m;
+  var[i] = (float)v;
+  if (running_mean) {  // nn.BatchNorm2d: running_var takes the unbiased estimate
+    const double unb = npix > 1 ? v * (double)npix / (double)(npix - 1) : v;
+    running_mean[i] = (1.0f - momentum) * running_mean[i] + momentum * (float)m;
+    running_var[i] = (1.0f - momentum) * running_var[i] + momentum * (float)unb;
+  }
+}
+
+__global__ void sum_finalize_kernel(const double* s0, int c, float* out, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c) return;
+  out[i] = accumulate ? out[i] + (float)s0[i] : (float)s0[i];
+}
+
+__global__ void bn_bwd_finalize_kernel(const double* s0, const double* s1, int c, float* dgamma, float* dbeta,
+                                       int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c) return;
+  if (accumulate) { dbeta[i] += (float)s0[i]; dgamma[i] += (float)s1[i]; }
+  else { dbeta[i] = (float)s0[i]; dgamma[i] = (float)s1[i]; }
+}
+
+struct BnApplyParams {
+  const char* z; char* y; const char* aux;  // fwd: aux = residual; bwd: aux = dy
+  long npix; int c, ldz, ldy, ldaux;
+  const float* mean; const float* var; const float* gamma; const float* beta;
+  const double* s0; const double* s1;  // bwd: sum(du), sum(du*xhat)
+  float eps; int act;
+};
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyParams p) {
+  constexpr int E = 16 / sizeof(T);
+  const int cg = p.c / E;
+  const long total = p.npix * cg;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long px = idx / cg;
+    const int grp = (int)(idx - px * cg);
+    float v[E], o[E], a[E];
+    load16<T>(p.z + ((size_t)px * p.ldz + grp * E) * sizeof(T), v);
+    if (BWD || p.aux) load16<T>(p.aux + ((size_t)px * p.ldaux + grp * E) * sizeof(T), a);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int ch = grp * E + e;
+      const float rstd = 1.0f / sqrtf(p.var[ch] + p.eps);
+      const float xh = (v[e] - p.mean[ch]) * rstd;
+      const float u = p.gamma[ch] * xh + p.beta[ch];
+      if (!BWD) {
+        float r = u;
+        if (p.act == UPA_ACT_SILU) r = u / (1.0f + expf(-u));
+        if (p.aux) r += a[e];
+        o[e] = r;
+      } else {
+        float du = a[e];
+        if (p.act == UPA_ACT_SILU) du *= silu_grad(u);
+        const float inv = 1.0f / (float)p.npix;
+        o[e] = p.gamma[ch] * rstd * (du - ((float)p.s0[ch] + xh * (float)p.s1[ch]) * inv);
+      }
+    }
+    store16<T>(p.y + ((size_t)px * p.ldy + grp * E) * sizeof(T), o);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient.  dW[co][ci][kh][kw] = sum_{n,oy,ox} dz[n,oy,ox,co] * x[n, oy*s+kh-p, ox*s+kw-p, ci].
+// v_mfma_f32_16x16x4_f32: A[m][k] = dz[pixel k][co m], B[k][n] = x[pixel k shifted by the tap][ci n], lane = (m or n,
+// k) - one f32 per lane straight out of an LDS image of the NHWC tile, rows padded to C+16 floats so the four pixel
+// groups of a wave fall on disjoint banks.  A workgroup (2 x 2 waves, each MT x NT 16x16 tiles for every tap) owns a
+// (co, ci) block and walks spatial tiles persistently; the taps x tiles accumulators live in registers and reach HBM as
+// one f32 atomic per element per workgroup.
+struct WgradParams {
+  const char* x; const char* dz; float* dw;
+  int N, H, W, Cin, ldx, OH, OW, Cout, lddz;
+  int KS, stride, pad;
+  int TH, TW, tilesX, tilesY, numTiles, IH, IW;
+  int wgsPerBlock;
+};
+
+template <typename T, int MT, int NT, int KK>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) float wsm[];
+  constexpr int BCO = 2 * MT * 16, BCI = 2 * NT * 16;
+  constexpr int RZ = BCO + 16, RX = BCI + 16;  // LDS row strides (floats)
+  constexpr int E = 16 / sizeof(T);
+  float* zt = wsm;                               // [TH*TW][RZ]
+  float* xt = wsm + (size_t)p.TH * p.TW * RZ;    // [IH*IW][RX]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l16 = lane & 15, kq = lane >> 4;
+  const int co0 = blockIdx.y * BCO, ci0 = blockIdx.z * BCI;
+  f32x4 acc[KK * KK][MT][NT];
+#pragma unroll
+  for (int t = 0; t < KK * KK; ++t)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int tilesPerImg = p.tilesX * p.tilesY;
+  const int npx = p.TH * p.TW;
+  for (int tile = blockIdx.x; tile < p.numTiles; tile += gridDim.x) {
+    const int n = tile / tilesPerImg;
+    const int t2 = tile - n * tilesPerImg;
+    const int tyi = t2 / p.tilesX, txi = t2 - tyi * p.tilesX;
+    const int oy0 = tyi * p.TH, ox0 = txi * p.TW;
+    const int iy0 = oy0 * p.stride - p.pad, ix0 = ox0 * p.stride - p.pad;
+    __syncthreads();  // previous tile fully consumed
+    // ---- stage dz tile (zero outside the output map / past Cout)
+    for (int i = tid; i < npx * (BCO / E); i += 256) {
+      const int px = i / (BCO / E), g = i - px * (BCO / E);
+      const int ty = px / p.TW, tx = px - ty * p.TW;
+      const int oy = oy0 + ty, ox = ox0 + tx, co = co0 + g * E;
+      float v[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) v[e] = 0.f;
+      if (oy < p.OH && ox < p.OW && co < p.Cout)
+        load16<T>(p.dz + ((((size_t)n * p.OH + oy) * p.OW + ox) * p.lddz + co) * sizeof(T), v);
+#pragma unroll
+      for (int e = 0; e < E; e += 4) *reinterpret_cast<f32x4*>(zt + px * RZ + g * E + e) = f32x4{v[e], v[e + 1], v[e + 2], v[e + 3]};
+    }
+    // ---- stage x halo tile (zero padding / past Cin)
+    const int nhx = p.IH * p.IW;
+    for (int i = tid; i < nhx * (BCI / E); i += 256) {
+      const int px = i / (BCI / E), g = i - px * (BCI / E);
+      const int py = px / p.IW, pxx = px - py * p.IW;
+      const int iy = iy0 + py, ix = ix0 + pxx, ci = ci0 + g * E;
+      float v[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) v[e] = 0.f;
+      if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && ci < p.Cin)
+        load16<T>(p.x + ((((size_t)n * p.H + iy) * p.W + ix) * p.ldx + ci) * sizeof(T), v);
+#pragma unroll
+      for (int e = 0; e < E; e += 4) *reinterpret_cast<f32x4*>(xt + px * RX + g * E + e) = f32x4{v[e], v[e + 1], v[e + 2], v[e + 3]};
+    }
+    __syncthreads();
+    // ---- 4 pixels per MFMA step; lane group kq takes pixel q*4 + kq
+    for (int q = 0; q < npx; q += 4) {
+      const int px = q + kq;
+      const int ty = px / p.TW, tx = px - ty * p.TW;
+      float a[MT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a[i] = zt[px * RZ + (wm * MT + i) * 16 + l16];
+      const float* xb = xt + ((ty * p.stride) * p.IW + tx * p.stride) * RX + wn * NT * 16 + l16;
+#pragma unroll
+      for (int kh = 0; kh < KK; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < KK; ++kw) {
+          float b[NT];
+#pragma unroll
+          for (int j = 0; j < NT; ++j) b[j] = xb[(kh * p.IW + kw) * RX + j * 16];
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[kh * KK + kw][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[kh * KK + kw][i][j], 0, 0, 0);
+        }
+    }
+  }
+  // ---- flush: D[row = co][col = ci]: lane holds rows 4*kq..+3 of column l16
+#pragma unroll
+  for (int t = 0; t < KK * KK; ++t)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = co0 + (wm * MT + i) * 16 + kq * 4 + r;
+          const int ci = ci0 + (wn * NT + j) * 16 + l16;
+          if (co < p.Cout && ci < p.Cin)
+            atomicAdd(p.dw + ((size_t)co * p.Cin + ci) * (KK * KK) + t, acc[t][i][j][r]);
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void dilate2x_kernel(const char* src, int n, int oh, int ow, int c, int lds_, char* dst, int h, int w, int ldd) {
+  // dst[n, y, x, :] = src[n, y/2, x/2, :] if y, x even and inside (oh, ow) else 0   (data gradient of stride-2 convs)
+  constexpr int E = 16 / sizeof(T);
+  const int cg = c / E;
+  const long total = (long)n * h * w * cg;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long t = idx;
+    const int g = (int)(t % cg); t /= cg;
+    const int x = (int)(t % w); t /= w;
+    const int y = (int)(t % h); t /= h;
+    const int b = (int)t;
+    u32x4 v = u32x4{0u, 0u, 0u, 0u};
+    if (!(y & 1) && !(x & 1) && (y >> 1) < oh && (x >> 1) < ow)
+      v = *reinterpret_cast<const u32x4*>(src + ((((size_t)b * oh + (y >> 1)) * ow + (x >> 1)) * lds_ + g * E) * sizeof(T));
+    *reinterpret_cast<u32x4*>(dst + ((((size_t)b * h + y) * w + x) * ldd + g * E) * sizeof(T)) = v;
+  }
+}
+
+template <typename T>
+__global__ void upsample2x_bwd_kernel(const char* dy, int n, int h, int w, int c, int lddy, char* dx, int lddx, int accumulate) {
+  // dx[n, y, x, :] (+)= sum of the 2x2 block of dy (dy is (2h, 2w))
+  constexpr int E = 16 / sizeof(T);
+  const int cg = c / E;
+  const long total = (long)n * h * w * cg;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long t = idx;
+    const int g = (int)(t % cg); t /= cg;
+    const int x = (int)(t % w); t /= w;
+    const int y = (int)(t % h); t /= h;
+    const int b = (int)t;
+    float s[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) s[e] = 0.f;
+    char* dst = dx + ((((size_t)b * h + y) * w + x) * lddx + g * E) * sizeof(T);
+    if (accumulate) load16<T>(dst, s);
+#pragma unroll
+    for (int dy_ = 0; dy_ < 2; ++dy_)
+#pragma unroll
+      for (int dx_ = 0; dx_ < 2; ++dx_) {
+        float v[E];
+        load16<T>(dy + ((((size_t)b * 2 * h + 2 * y + dy_) * 2 * w + 2 * x + dx_) * lddy + g * E) * sizeof(T), v);
+#pragma unroll
+        for (int e = 0; e < E; ++e) s[e] += v[e];
+      }
+    store16<T>(dst, s);
+  }
+}
+
+template <typename T>
+__global__ void maxpool_bwd_kernel(const char* x, const char* dy, int n, int h, int w, int c, int ldx, int lddy, int k,
+                                   int stride, int pad, int oh, int ow, char* dx, int lddx, int accumulate) {
+  // gather form (deterministic): input pixel i collects dy of every window whose FIRST maximum (row-major scan, the
+  // index torch's max_pool2d_with_indices keeps) is i.
+  constexpr int E = 16 / sizeof(T);
+  const int cg = c / E;
+  const long total = (long)n * h * w * cg;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long t = idx;
+    const int g = (int)(t % cg); t /= cg;
+    const int ix = (int)(t % w); t /= w;
+    const int iy = (int)(t % h); t /= h;
+    const int b = (int)t;
+    float acc[E], me[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = 0.f;
+    char* dst = dx + ((((size_t)b * h + iy) * w + ix) * lddx + g * E) * sizeof(T);
+    if (accumulate) load16<T>(dst, acc);
+    load16<T>(x + ((((size_t)b * h + iy) * w + ix) * ldx + g * E) * sizeof(T), me);
+    // windows (oy, ox) containing (iy, ix): oy*stride - pad <= iy < oy*stride - pad + k
+    for (int oy = 0; oy < oh; ++oy) {
+      const int wy0 = oy * stride - pad;
+      if (iy < wy0 || iy >= wy0 + k) continue;
+      for (int ox = 0; ox < ow; ++ox) {
+        const int wx0 = ox * stride - pad;
+        if (ix < wx0 || ix >= wx0 + k) continue;
+        // is (iy, ix) the first maximum of this window?
+        bool first[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) first[e] = true;
+        for (int yy = wy0; yy < wy0 + k; ++yy) {
+          if (yy < 0 || yy >= h) continue;
+          for (int xx = wx0; xx < wx0 + k; ++xx) {
+            if (xx < 0 || xx >= w || (yy == iy && xx == ix)) continue;
+            float o[E];
+            load16<T>(x + ((((size_t)b * h + yy) * w + xx) * ldx + g * E) * sizeof(T), o);
+            const bool before = yy < iy || (yy == iy && xx < ix);
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+              if (o[e] > me[e] || (before && o[e] == me[e])) first[e] = false;
+          }
+        }
+        float d[E];
+        load16<T>(dy + ((((size_t)b * oh + oy) * ow + ox) * lddy + g * E) * sizeof(T), d);
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+          if (first[e]) acc[e] += d[e];
+      }
+    }
+    store16<T>(dst, acc);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void sumsq_kernel(const float* g, long n, double* out) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += (double)g[i] * (double)g[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicAdd(out, red[0]);
+}
+
+// torch.nn.utils.clip_grad_norm_ + torch.optim.SGD(nesterov) + ModelEMA.update over one flat parameter segment
+// (engine/trainer.py:674-682, utils/torch_utils.py:632-646).  sumsq = squared gradient norm of ALL parameters.
+__global__ void sgd_nesterov_ema_kernel(float* p, float* g, float* buf, float* ema, long n, const double* sumsq, float max_norm,
+                                        float lr, float momentum, float wd, int first_step, float ema_d, int zero_grad) {
+  const float total = (float)sqrt(*sumsq);
+  float coef = max_norm / (total + 1e-6f);
+  if (coef > 1.0f) coef = 1.0f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float gi = g[i] * coef;
+    const float pi = p[i];
+    if (wd != 0.f) gi = gi + wd * pi;
+    float b = first_step ? gi : momentum * buf[i] + gi;
+    buf[i] = b;
+    gi = gi + momentum * b;
+    const float pn = pi + (-lr) * gi;
+    p[i] = pn;
+    if (ema) {
+      float e = ema[i] * ema_d;
+      e = e + (1.0f - ema_d) * pn;
+      ema[i] = e;
+    }
+    if (zero_grad) g[i] = 0.f;
+  }
+}
+
+__global__ void ema_only_kernel(float* ema, const float* v, long n, float d) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float e = ema[i] * d;
+    ema[i] = e + (1.0f - d) * v[i];
+  }
+}
+
+template <typename TS, typename TD>
+__global__ void cast_view_kernel(const char* src, int lds_, char* dst, int ldd, long npix, int c) {
+  // 8 channels per thread (32 B of f32 / 16 B of bf16)
+  const int cg = c / 8;
+  const long total = npix * cg;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long px = idx / cg;
+    const int g = (int)(idx - px * cg);
+    float v[8];
+    const char* sp = src + ((size_t)px * lds_ + g * 8) * sizeof(TS);
+    if constexpr (sizeof(TS) == 4) { load16<float>(sp, v); load16<float>(sp + 16, v + 4); }
+    else load16<bf16_t>(sp, v);
+    char* dp = dst + ((size_t)px * ldd + g * 8) * sizeof(TD);
+    if constexpr (sizeof(TD) == 4) { store16<float>(dp, v); store16<float>(dp + 16, v + 4); }
+    else store16<bf16_t>(dp, v);
+  }
+}
+
+int grid_for(long total, int per_block = 256, int cap = 256 * 16) {
+  long g = (total + per_block - 1) / per_block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" int upa_pack_conv_weight_dev(const float* w_oihw, int cout, int cin, int k, int dtype, int transpose_flip,
+                                        void* out, void* stream) {
+  UPA_CHECK_ARG(w_oihw && out && cout > 0 && cin > 0 && k >= 1 && k <= 7, "pack_conv_weight_dev: bad args");
+  const int E = dtype == UPA_BF16 ? 8 : 4;
+  const int lc_out = transpose_flip ? cin : cout, lc_in = transpose_flip ? cout : cin;
+  const long total = (long)k * k * ((lc_in + 4 * E - 1) / (4 * E)) * ((lc_out + 15) / 16) * 64 * E;
+  hipLaunchKernelGGL(pack_weight_dev_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, w_oihw, cout, cin, k, E,
+                     transpose_flip, out, total);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+static int check_view(long npix, int c, int ld, int dtype, const char* what) {
+  const int E = 16 / upa_elem_size(dtype);
+  UPA_CHECK_ARG(npix > 0 && c > 0 && c % E == 0 && ld % E == 0 && c <= 256 * E, "%s: channels / stride must be multiples of %d (<= %d)",
+                what, E, 256 * E);
+  return UPA_OK;
+}
+
+extern "C" int upa_bn_stats(const void* z, long npix, int c, int ldz, double* sum, double* sumsq, int dtype, void* stream) {
+  UPA_CHECK_ARG(z && sum && sumsq, "bn_stats: null pointer");
+  if (int rc = check_view(npix, c, ldz, dtype, "bn_stats")) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  (void)hipMemsetAsync(sum, 0, sizeof(double) * c, s);
+  (void)hipMemsetAsync(sumsq, 0, sizeof(double) * c, s);
+  ReduceParams p{};
+  p.z = (const char*)z; p.npix = npix; p.c = c; p.ldz = ldz; p.out0 = sum; p.out1 = sumsq;
+  const int grid = grid_for(npix, 64, 2048);
+  const size_t lds = 2 * c * sizeof(double);
+  if (dtype == UPA_BF16) hipLaunchKernelGGL((channel_reduce_kernel<bf16_t, 0>), dim3(grid), dim3(256), lds, s, p);
+  else hipLaunchKernelGGL((channel_reduce_kernel<float, 0>), dim3(grid), dim3(256), lds, s, p);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+extern "C" int upa_bn_finalize(const double* sum, const double* sumsq, long npix, int c, float momentum, float* mean, float* var,
+                               float* running_mean, float* running_var, void* stream) {
+  UPA_CHECK_ARG(sum && sumsq && mean && var && npix > 0, "bn_finalize: bad args");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, sum, sumsq, npix, c, momentum,
+                     mean, var, running_mean, running_var);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+extern "C" int upa_bn_act_fwd(const void* z, long npix, int c, int ldz, const float* mean, const float* var, const float* gamma,
+                              const float* beta, float eps, int act, void* y, int ldy, const void* residual, int ldr, int dtype,
+                              void* stream) {
+  UPA_CHECK_ARG(z && y && mean && var && gamma && beta, "bn_act_fwd: null pointer");
+  UPA_CHECK_ARG(act == UPA_ACT_SILU || act == UPA_ACT_NONE, "bn_act_fwd: activation must be SiLU or none");
+  if (int rc = check_view(npix, c, ldz, dtype, "bn_act_fwd")) return rc;
+  BnApplyParams p{};
+  p.z = (const char*)z; p.y = (char*)y; p.aux = (const char*)residual; p.npix = npix; p.c = c; p.ldz = ldz; p.ldy = ldy; p.ldaux = ldr;
+  p.mean = mean; p.var = var; p.gamma = gamma; p.beta = beta; p.eps = eps; p.act = act;
+  const int E = 16 / upa_elem_size(dtype);
+  const int grid = grid_for(npix * (c / E), 256, 256 * 32);
+  if (dtype == UPA_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((bn_apply_kernel<float, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+extern "C" int upa_bn_act_bwd(const void* z, const void* dy, long npix, int c, int ldz, int lddy, const float* mean,
+                              const float* var, const float* gamma, const float* beta, float eps, int act, void* dz, int lddz,
+                              float* dgamma, float* dbeta, int accumulate, double* ws /* 2*c doubles */, int dtype, void* stream) {
+  UPA_CHECK_ARG(z && dy && dz && mean && var && gamma && beta && dgamma && dbeta && ws, "bn_act_bwd: null pointer");
+  UPA_CHECK_ARG(act == UPA_ACT_SILU || act == UPA_ACT_NONE, "bn_act_bwd: activation must be SiLU or none");
+  if (int rc = check_view(npix, c, ldz, dtype, "bn_act_bwd")) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  (void)hipMemsetAsync(ws, 0, sizeof(double) * 2 * c, s);
+  ReduceParams r{};
+  r.z = (const char*)z; r.dy = (const char*)dy; r.npix = npix; r.c = c; r.ldz = ldz; r.lddy = lddy;
+  r.mean = mean; r.var = var; r.gamma = gamma; r.beta = beta; r.eps = eps; r.act = act; r.out0 = ws; r.out1 = ws + c;
+  const int grid = grid_for(npix, 64, 2048);
+  const size_t lds = 2 * c * sizeof(double);
+  if (dtype == UPA_BF16) hipLaunchKernelGGL((channel_reduce_kernel<bf16_t, 1>), dim3(grid), dim3(256), lds, s, r);
+  else hipLaunchKernelGGL((channel_reduce_kernel<float, 1>), dim3(grid), dim3(256), lds, s, r);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, s, ws, ws + c, c, dgamma, dbeta, accumulate);
+  BnApplyParams p{};
+  p.z = (const char*)z; p.y = (char*)dz; p.aux = (const char*)dy; p.npix = npix; p.c = c; p.ldz = ldz; p.ldy = lddz; p.ldaux = lddy;
+  p.mean = mean; p.var = var; p.gamma = gamma; p.beta = beta; p.s0 = ws; p.s1 = ws + c; p.eps = eps; p.act = act;
+  const int E = 16 / upa_elem_size(dtype);
+  const int grid2 = grid_for(npix * (c / E), 256, 256 * 32);
+  if (dtype == UPA_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, true>), dim3(grid2), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((bn_apply_kernel<float, true>), dim3(grid2), dim3(256), 0, s, p);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+extern "C" int upa_channel_sum(const void* z, long npix, int c, int ldz, float* out, int accumulate, double* ws, int dtype,
+                               void* stream) {
+  UPA_CHECK_ARG(z && out && ws, "channel_sum: null pointer");
+  if (int rc = check_view(npix, c, ldz, dtype, "channel_sum")) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  (void)hipMemsetAsync(ws, 0, sizeof(double) * 2 * c, s);
+  ReduceParams r{};
+  r.z = (const char*)z; r.npix = npix; r.c = c; r.ldz = ldz; r.out0 = ws; r.out1 = ws + c;
+  const int grid = grid_for(npix, 64, 2048);
+  if (dtype == UPA_BF16) hipLaunchKernelGGL((channel_reduce_kernel<bf16_t, 2>), dim3(grid), dim3(256), 2 * c * sizeof(double), s, r);
+  else hipLaunchKernelGGL((channel_reduce_kernel<float, 2>), dim3(grid), dim3(256), 2 * c * sizeof(double), s, r);
+  hipLaunchKernelGGL(sum_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, s, ws, c, out, accumulate);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+template <typename T, int MT, int NT>
+static int launch_wgrad(WgradParams& p, hipStream_t s) {
+  constexpr int BCO = 2 * MT * 16, BCI = 2 * NT * 16;
+  // tile: LDS = (TH*TW*(BCO+16) + IH*IW*(BCI+16)) * 4 bytes <= ~150 KB
+  int TH = 8, TW = 16;
+  auto lds_bytes = [&](int th, int tw) {
+    const long ih = (th - 1) * p.stride + p.KS, iw = (tw - 1) * p.stride + p.KS;
+    return (size_t)((long)th * tw * (BCO + 16) + ih * iw * (BCI + 16)) * 4;
+  };
+  while (lds_bytes(TH, TW) > 150 * 1024 && TH > 1) TH >>= 1;
+  while (lds_bytes(TH, TW) > 150 * 1024 && TW > 4) TW >>= 1;
+  UPA_CHECK_ARG(lds_bytes(TH, TW) <= 150 * 1024, "wgrad: tile does not fit LDS (k=%d s=%d)", p.KS, p.stride);
+  p.TH = TH; p.TW = TW;
+  p.tilesX = cdiv(p.OW, TW); p.tilesY = cdiv(p.OH, TH);
+  p.numTiles = p.tilesX * p.tilesY * p.N;
+  p.IH = (TH - 1) * p.stride + p.KS; p.IW = (TW - 1) * p.stride + p.KS;
+  const int bco = cdiv(p.Cout, BCO), bci = cdiv(p.Cin, BCI);
+  int wgs = 256 / (bco * bci);
+  if (wgs < 1) wgs = 1;
+  if (wgs > p.numTiles) wgs = p.numTiles;
+  const size_t lds = lds_bytes(TH, TW);
+  dim3 grid(wgs, bco, bci);
+#define UPA_WG_LAUNCH(KK_)                                                                                        \
+  do {                                                                                                            \
+    auto kern = wgrad_kernel<T, MT, NT, KK_>;                                                                     \
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);                                                         \
+  } while (0)
+  if (p.KS == 1) UPA_WG_LAUNCH(1);
+  else if (p.KS == 3) UPA_WG_LAUNCH(3);
+  else { upa_set_error("wgrad: kernel size %d not built (1 and 3 are)", p.KS); return UPA_EUNSUPPORTED; }
+#undef UPA_WG_LAUNCH
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+extern "C" int upa_conv2d_wgrad(const void* x, int n, int h, int w, int cin, int ldx, const void* dz, int cout, int lddz,
+                                float* dw_oihw, int k, int stride, int pad, int accumulate, int dtype, void* stream) {
+  UPA_CHECK_ARG(x && dz && dw_oihw, "wgrad: null pointer");
+  UPA_CHECK_ARG(dtype == UPA_F32 || dtype == UPA_BF16, "wgrad: bad dtype");
+  const int E = 16 / upa_elem_size(dtype);
+  UPA_CHECK_ARG(ldx % E == 0 && lddz % E == 0 && cout % E == 0, "wgrad: strides / cout must be multiples of %d", E);
+  UPA_CHECK_ARG(cin % E == 0 || cin < E, "wgrad: cin must be a multiple of %d (or a padded narrow input)", E);
+  hipStream_t s = (hipStream_t)stream;
+  if (!accumulate) (void)hipMemsetAsync(dw_oihw, 0, sizeof(float) * (size_t)cout * cin * k * k, s);
+  WgradParams p{};
+  p.x = (const char*)x; p.dz = (const char*)dz; p.dw = dw_oihw;
+  p.N = n; p.H = h; p.W = w; p.Cin = cin; p.ldx = ldx; p.Cout = cout; p.lddz = lddz;
+  p.OH = (h + 2 * pad - k) / stride + 1; p.OW = (w + 2 * pad - k) / stride + 1;
+  p.KS = k; p.stride = stride; p.pad = pad;
+  const bool small = cin <= 32 || cout <= 32;
+  if (dtype == UPA_BF16) return small ? launch_wgrad<bf16_t, 1, 1>(p, s) : launch_wgrad<bf16_t, 2, 2>(p, s);
+  return small ? launch_wgrad<float, 1, 1>(p, s) : launch_wgrad<float, 2, 2>(p, s);
+}
+
+extern "C" int upa_dilate2x(const void* src, int n, int oh, int ow, int c, int lds_, void* dst, int h, int w, int ldd, int dtype,
+                            void* stream) {
+  UPA_CHECK_ARG(src && dst, "dilate2x: null pointer");
+  if (int rc = check_view((long)n * h * w, c, lds_, dtype, "dilate2x")) return rc;
+  const int E = 16 / upa_elem_size(dtype);
+  const long total = (long)n * h * w * (c / E);
+  if (dtype == UPA_BF16) hipLaunchKernelGGL((dilate2x_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                                           (const char*)src, n, oh, ow, c, lds_, (char*)dst, h, w, ldd);
+  else hipLaunchKernelGGL((dilate2x_kernel<float>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const char*)src, n, oh,
+                          ow, c, lds_, (char*)dst, h, w, ldd);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+extern "C" int upa_upsample2x_bwd(const void* dy, int n, int h, int w, int c, int lddy, void* dx, int lddx, int accumulate, int dtype,
+                                  void* stream) {
+  UPA_CHECK_ARG(dy && dx, "upsample2x_bwd: null pointer");
+  if (int rc = check_view((long)n * h * w, c, lddy, dtype, "upsample2x_bwd")) return rc;
+  const int E = 16 / upa_elem_size(dtype);
+  const long total = (long)n * h * w * (c / E);
+  if (dtype == UPA_BF16) hipLaunchKernelGGL((upsample2x_bwd_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                                           (const char*)dy, n, h, w, c, lddy, (char*)dx, lddx, accumulate);
+  else hipLaunchKernelGGL((upsample2x_bwd_kernel<float>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const char*)dy, n,
+                          h, w, c, lddy, (char*)dx, lddx, accumulate);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+extern "C" int upa_maxpool2d_bwd(const void* x, const void* dy, int n, int h, int w, int c, int ldx, int lddy, int k, int stride,
+                                 int pad, void* dx, int lddx, int accumulate, int dtype, void* stream) {
+  UPA_CHECK_ARG(x && dy && dx && k >= 1 && stride >= 1, "maxpool2d_bwd: bad args");
+  if (int rc = check_view((long)n * h * w, c, ldx, dtype, "maxpool2d_bwd")) return rc;
+  const int oh = (h + 2 * pad - k) / stride + 1, ow = (w + 2 * pad - k) / stride + 1;
+  const int E = 16 / upa_elem_size(dtype);
+  const long total = (long)n * h * w * (c / E);
+  if (dtype == UPA_BF16) hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                                           (const char*)x, (const char*)dy, n, h, w, c, ldx, lddy, k, stride, pad, oh, ow, (char*)dx,
+                                           lddx, accumulate);
+  else hipLaunchKernelGGL((maxpool_bwd_kernel<float>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const char*)x,
+                          (const char*)dy, n, h, w, c, ldx, lddy, k, stride, pad, oh, ow, (char*)dx, lddx, accumulate);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+extern "C" int upa_sumsq(const float* g, long n, double* out, int accumulate, void* stream) {
+  UPA_CHECK_ARG(g && out && n > 0, "sumsq: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  if (!accumulate) (void)hipMemsetAsync(out, 0, sizeof(double), s);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 1024, 1024)), dim3(256), 0, s, g, n, out);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+extern "C" int upa_sgd_nesterov_ema(float* p, float* g, float* momentum_buf, float* ema, long n, const double* grad_sumsq,
+                                    float max_norm, float lr, float momentum, float weight_decay, int first_step, float ema_d,
+                                    int zero_grad, void* stream) {
+  UPA_CHECK_ARG(p && g && momentum_buf && grad_sumsq && n > 0, "sgd: bad args");
+  hipLaunchKernelGGL(sgd_nesterov_ema_kernel, dim3(grid_for(n, 1024, 2048)), dim3(256), 0, (hipStream_t)stream, p, g, momentum_buf,
+                     ema, n, grad_sumsq, max_norm, lr, momentum, weight_decay, first_step, ema_d, zero_grad);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+extern "C" int upa_ema_update(float* ema, const float* v, long n, float d, void* stream) {
+  UPA_CHECK_ARG(ema && v && n > 0, "ema_update: bad args");
+  hipLaunchKernelGGL(ema_only_kernel, dim3(grid_for(n, 1024, 2048)), dim3(256), 0, (hipStream_t)stream, ema, v, n, d);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+extern "C" int upa_cast_view(const void* src, int src_dtype, int lds_, void* dst, int dst_dtype, int ldd, long npix, int c,
+                             void* stream) {
+  UPA_CHECK_ARG(src && dst && npix > 0 && c % 8 == 0 && lds_ % 8 == 0 && ldd % 8 == 0, "cast_view: bad args (c, strides multiples of 8)");
+  const int grid = grid_for(npix * (c / 8));
+  hipStream_t s = (hipStream_t)stream;
+  if (src_dtype == UPA_BF16 && dst_dtype == UPA_F32)
+    hipLaunchKernelGGL((cast_view_kernel<bf16_t, float>), dim3(grid), dim3(256), 0, s, (const char*)src, lds_, (char*)dst, ldd, npix, c);
+  else if (src_dtype == UPA_F32 && dst_dtype == UPA_BF16)
+    hipLaunchKernelGGL((cast_view_kernel<float, bf16_t>), dim3(grid), dim3(256), 0, s, (const char*)src, lds_, (char*)dst, ldd, npix, c);
+  else if (src_dtype == UPA_F32 && dst_dtype == UPA_F32)
+    hipLaunchKernelGGL((cast_view_kernel<float, float>), dim3(grid), dim3(256), 0, s, (const char*)src, lds_, (char*)dst, ldd, npix, c);
+  else
+    hipLaunchKernelGGL((cast_view_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, s, (const char*)src, lds_, (char*)dst, ldd, npix, c);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}

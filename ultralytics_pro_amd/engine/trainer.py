@@ -1,0 +1,644 @@
+"""Training step of the detection model on the HIP path (BASELINE config 3).
+
+Mirrors the reference's step - forward in train mode, `v8DetectionLoss`, `loss.sum() * world_size`, backward, gradient
+all-reduce, `optimizer_step` = clip_grad_norm_(10) + SGD(nesterov) + EMA (ultralytics/engine/trainer.py:416-432,
+:674-682, :891-950; utils/torch_utils.py:606-650; utils/loss.py:415-528) - without torch autograd: every layer has an
+explicit forward that keeps what its explicit backward needs, all of it upa_* kernels (include/upa.h, "training step").
+
+  Conv (conv -> BN(batch statistics) -> SiLU):  z = conv(x, W);  (mean, var) = stats(z);  y = act(bn(z)) (+ residual)
+      backward: dz, dgamma, dbeta = bn_act_bwd(z, dy);  dW += wgrad(x, dz);  dx (+)= conv(dz, W^T flipped)
+  C2f / Bottleneck / SPPF / Upsample / Concat / Detect: compositions of the above + pool / upsample backward kernels.
+
+torch is used for memory, streams, views and torch.distributed (the gradient all-reduce over RCCL).  Parameters live
+in one flat f32 buffer (grouped: biases | decayed weights | norm weights, trainer.py:917-926) so the optimizer is three
+fused launches; `model.parameters()` are views into it, the state_dict stays the reference's.
+Only the yolov8 module set is differentiable here (Conv, C2f, Bottleneck, SPPF, nn.Upsample, Concat, Detect); other
+modules raise.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from ..nn.modules import block as B
+from ..nn.modules import conv as CV
+from ..nn.modules import head as H
+from ..nn.modules import resample as RS
+from . import runtime as R
+
+HYP = dict(lr=0.01, momentum=0.9, weight_decay=5e-4, max_norm=10.0, ema_decay=0.9999, ema_tau=2000.0,
+           box=7.5, cls=0.5, dfl=1.5)
+MAX_GT = 64
+
+
+def _s(dev):
+    return L.current_stream(dev)
+
+
+class _Ctx:
+    """Per-trainer scratch shared by all layers."""
+
+    def __init__(self, device, dtype):
+        self.device, self.dtype = device, dtype
+        self.code = L.dtype_code(dtype)
+        self.es = 2 if dtype == torch.bfloat16 else 4
+        self.E = 16 // self.es
+        self.ws = torch.zeros(4 * 2048, dtype=torch.float64, device=device)  # channel-reduction scratch (c <= 2048)
+        self.tape = []  # backward closures, run in reverse
+
+
+def _new(n, c, h, w, dtype, dev, key):
+    return R.alloc_nhwc(n, c, h, w, dtype, dev, key)
+
+
+class ConvT:
+    """Train-mode forward/backward of one conv (+ BatchNorm2d + activation, or + bias for the plain head outputs)."""
+
+    def __init__(self, ctx: _Ctx, conv: nn.Conv2d, bn, act_code: int, name: str):
+        if conv.groups != 1 or conv.dilation != (1, 1) or conv.kernel_size[0] != conv.kernel_size[1]:
+            raise L.UpaError(f"training supports square kernels, groups=1, dilation=1 only ({name})")
+        self.ctx, self.conv, self.bn, self.act, self.name = ctx, conv, bn, act_code, name
+        self.k, self.s, self.p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        if self.k not in (1, 3) or self.s not in (1, 2):
+            raise L.UpaError(f"training supports k in (1,3), stride in (1,2) ({name}: k={self.k} s={self.s})")
+        self.cout, self.cin = conv.out_channels, conv.in_channels
+        dev, code = ctx.device, ctx.code
+        nb = L.lib().upa_conv_packed_weight_bytes(self.cout, self.cin, self.k, code)
+        self.wp = torch.empty(nb, dtype=torch.uint8, device=dev)          # forward layout
+        nbt = L.lib().upa_conv_packed_weight_bytes(self.cin, self.cout, self.k, code)
+        self.wpt = torch.empty(nbt, dtype=torch.uint8, device=dev)        # transposed + flipped (data gradient)
+        if bn is not None:
+            self.mean = torch.empty(self.cout, dtype=torch.float32, device=dev)
+            self.var = torch.empty(self.cout, dtype=torch.float32, device=dev)
+        self.x = self.z = None
+
+    def pack(self):
+        lib, c = L.lib(), self.ctx
+        w = self.conv.weight
+        L.check(lib.upa_pack_conv_weight_dev(w.data_ptr(), self.cout, self.cin, self.k, c.code, 0, self.wp.data_ptr(),
+                                             _s(c.device)), "pack_dev")
+        L.check(lib.upa_pack_conv_weight_dev(w.data_ptr(), self.cout, self.cin, self.k, c.code, 1, self.wpt.data_ptr(),
+                                             _s(c.device)), "pack_dev_t")
+
+    def _conv(self, x, wp, cout, k, s, p, out, bias=None, residual=None):
+        vx, vy = R.view_of(x), R.view_of(out)
+        rp, rld = (None, 0)
+        if residual is not None:
+            vr = R.view_of(residual)
+            rp, rld = vr.ptr, vr.ld
+        L.check(L.lib().upa_conv2d_bias_act(vx.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, wp.data_ptr(),
+                                            None if bias is None else bias.data_ptr(), vy.ptr, cout, vy.ld, rp, rld, k, s, p,
+                                            L.ACT_NONE, vx.dtype, _s(x.device)), f"conv2d[{self.name}]")
+
+    def forward(self, x, out=None, residual=None):
+        c, lib = self.ctx, L.lib()
+        n, _, h, w = x.shape
+        oh, ow = (h + 2 * self.p - self.k) // self.s + 1, (w + 2 * self.p - self.k) // self.s + 1
+        self.x = x
+        if self.bn is None:  # plain nn.Conv2d with bias: y = conv(x) + b
+            y = out if out is not None else _new(n, self.cout, oh, ow, c.dtype, c.device, (id(self), "y"))
+            self._conv(x, self.wp, self.cout, self.k, self.s, self.p, y, bias=self.conv.bias)
+            return y
+        z = _new(n, self.cout, oh, ow, c.dtype, c.device, (id(self), "z"))
+        self._conv(x, self.wp, self.cout, self.k, self.s, self.p, z)
+        vz = R.view_of(z)
+        npix = vz.n * vz.h * vz.w
+        ws = c.ws
+        L.check(lib.upa_bn_stats(vz.ptr, npix, vz.c, vz.ld, ws.data_ptr(), ws.data_ptr() + 8 * self.cout, vz.dtype,
+                                 _s(c.device)), "bn_stats")
+        bn = self.bn
+        L.check(lib.upa_bn_finalize(ws.data_ptr(), ws.data_ptr() + 8 * self.cout, npix, self.cout, float(bn.momentum),
+                                    self.mean.data_ptr(), self.var.data_ptr(), bn.running_mean.data_ptr(),
+                                    bn.running_var.data_ptr(), _s(c.device)), "bn_finalize")
+        y = out if out is not None else _new(n, self.cout, oh, ow, c.dtype, c.device, (id(self), "y"))
+        vy = R.view_of(y)
+        rp, rld = (None, 0)
+        if residual is not None:
+            vr = R.view_of(residual)
+            rp, rld = vr.ptr, vr.ld
+        L.check(lib.upa_bn_act_fwd(vz.ptr, npix, vz.c, vz.ld, self.mean.data_ptr(), self.var.data_ptr(), bn.weight.data_ptr(),
+                                   bn.bias.data_ptr(), float(bn.eps), self.act, vy.ptr, vy.ld, rp, rld, vz.dtype,
+                                   _s(c.device)), "bn_act_fwd")
+        self.z = z
+        return y
+
+    def backward(self, dy, dx=None, accumulate=False):
+        """dy: gradient of this layer's output (NHWC view). dx: view receiving / accumulating the input gradient."""
+        c, lib = self.ctx, L.lib()
+        vdy = R.view_of(dy)
+        npix = vdy.n * vdy.h * vdy.w
+        st = _s(c.device)
+        if self.bn is None:
+            dz = dy
+            L.check(lib.upa_channel_sum(vdy.ptr, npix, vdy.c, vdy.ld, self.conv.bias.grad.data_ptr(), 1, c.ws.data_ptr(),
+                                        vdy.dtype, st), "bias_grad")
+        else:
+            vz = R.view_of(self.z)
+            dz = _new(vz.n, vz.c, vz.h, vz.w, c.dtype, c.device, (id(self), "dz"))
+            vdz = R.view_of(dz)
+            bn = self.bn
+            L.check(lib.upa_bn_act_bwd(vz.ptr, vdy.ptr, npix, vz.c, vz.ld, vdy.ld, self.mean.data_ptr(), self.var.data_ptr(),
+                                       bn.weight.data_ptr(), bn.bias.data_ptr(), float(bn.eps), self.act, vdz.ptr, vdz.ld,
+                                       bn.weight.grad.data_ptr(), bn.bias.grad.data_ptr(), 1, c.ws.data_ptr(), vz.dtype, st),
+                    "bn_act_bwd")
+        vx, vdz = R.view_of(self.x), R.view_of(dz)
+        L.check(lib.upa_conv2d_wgrad(vx.ptr, vx.n, vx.h, vx.w, self.cin, vx.ld, vdz.ptr, self.cout, vdz.ld,
+                                     self.conv.weight.grad.data_ptr(), self.k, self.s, self.p, 1, vx.dtype, st),
+                f"wgrad[{self.name}]")
+        if dx is None:
+            return
+        src = dz
+        if self.s == 2:  # zero-insert dz to the input resolution, then a stride-1 correlation with the flipped weights
+            up = _new(vx.n, self.cout, vx.h, vx.w, c.dtype, c.device, (id(self), "dz_up"))
+            vu = R.view_of(up)
+            L.check(lib.upa_dilate2x(vdz.ptr, vdz.n, vdz.h, vdz.w, vdz.c, vdz.ld, vu.ptr, vu.h, vu.w, vu.ld, vdz.dtype, st),
+                    "dilate2x")
+            src = up
+        self._conv(src, self.wpt, self.cin, self.k, 1, self.k - 1 - self.p, dx, residual=dx if accumulate else None)
+
+
+class _Seq:
+    """Helpers shared by the composite layers."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+
+class BottleneckT(_Seq):
+    def __init__(self, ctx, m: B.Bottleneck, name):
+        super().__init__(ctx)
+        self.cv1 = ConvT(ctx, m.cv1.conv, m.cv1.bn, m.cv1._act_code(), name + ".cv1")
+        self.cv2 = ConvT(ctx, m.cv2.conv, m.cv2.bn, m.cv2._act_code(), name + ".cv2")
+        self.add = m.add
+
+    def convs(self):
+        return [self.cv1, self.cv2]
+
+    def forward(self, x, out=None):
+        t = self.cv1.forward(x)
+        return self.cv2.forward(t, out=out, residual=x if self.add else None)
+
+    def backward(self, dy, dx, accumulate):
+        c = self.ctx
+        vt = R.view_of(self.cv2.x)
+        dt = _new(vt.n, vt.c, vt.h, vt.w, c.dtype, c.device, (id(self), "dt"))
+        self.cv2.backward(dy, dt, False)
+        self.cv1.backward(dt, dx, accumulate)
+        if self.add:  # y = x + f(x): the shortcut passes dy straight through
+            add_into(c, dy, dx)
+
+
+def add_into(ctx, src, dst):
+    """dst += src (NHWC views)."""
+    vs, vd = R.view_of(src), R.view_of(dst)
+    L.check(L.lib().upa_add_view(vd.ptr, vd.ld, vs.ptr, vs.ld, vd.ptr, vd.ld, vd.n, vd.h, vd.w, vd.c, vd.dtype, _s(ctx.device)),
+            "add_view")
+
+
+def copy_into(ctx, src, dst):
+    vs, vd = R.view_of(src), R.view_of(dst)
+    L.check(L.lib().upa_copy_view(vs.ptr, vs.n, vs.h, vs.w, vs.c, vs.ld, vd.ptr, vd.ld, vs.dtype, _s(ctx.device)), "copy_view")
+
+
+class C2fT(_Seq):
+    def __init__(self, ctx, m: B.C2f, name):
+        super().__init__(ctx)
+        self.c = m.c
+        self.cv1 = ConvT(ctx, m.cv1.conv, m.cv1.bn, m.cv1._act_code(), name + ".cv1")
+        self.cv2 = ConvT(ctx, m.cv2.conv, m.cv2.bn, m.cv2._act_code(), name + ".cv2")
+        self.m = [BottleneckT(ctx, b, f"{name}.m.{i}") for i, b in enumerate(m.m)]
+
+    def convs(self):
+        return [self.cv1, self.cv2] + [cv for b in self.m for cv in b.convs()]
+
+    def forward(self, x, out=None):
+        c, k = self.ctx, self.c
+        n, _, h, w = x.shape
+        cat = _new(n, (2 + len(self.m)) * k, h, w, c.dtype, c.device, (id(self), "cat"))
+        self.cv1.forward(x, out=cat[:, :2 * k])
+        for i, b in enumerate(self.m):
+            b.forward(cat[:, (1 + i) * k:(2 + i) * k], out=cat[:, (2 + i) * k:(3 + i) * k])
+        self.cat = cat
+        return self.cv2.forward(cat, out=out)
+
+    def backward(self, dy, dx, accumulate):
+        c, k = self.ctx, self.c
+        n, ct, h, w = self.cat.shape
+        g = _new(n, ct, h, w, c.dtype, c.device, (id(self), "gcat"))
+        self.cv2.backward(dy, g, False)
+        for i in reversed(range(len(self.m))):
+            self.m[i].backward(g[:, (2 + i) * k:(3 + i) * k], g[:, (1 + i) * k:(2 + i) * k], True)
+        self.cv1.backward(g[:, :2 * k], dx, accumulate)
+
+
+class SPPFT(_Seq):
+    def __init__(self, ctx, m: B.SPPF, name):
+        super().__init__(ctx)
+        self.cv1 = ConvT(ctx, m.cv1.conv, m.cv1.bn, m.cv1._act_code(), name + ".cv1")
+        self.cv2 = ConvT(ctx, m.cv2.conv, m.cv2.bn, m.cv2._act_code(), name + ".cv2")
+        self.k = m.m.kernel_size if isinstance(m.m.kernel_size, int) else m.m.kernel_size[0]
+
+    def convs(self):
+        return [self.cv1, self.cv2]
+
+    def forward(self, x, out=None):
+        c = self.ctx
+        n, _, h, w = x.shape
+        cm = self.cv1.cout
+        cat = _new(n, 4 * cm, h, w, c.dtype, c.device, (id(self), "cat"))
+        self.cv1.forward(x, out=cat[:, :cm])
+        for i in range(3):  # three chained MaxPool2d(k, 1, k//2) (block.py:402-406)
+            vs, vd = R.view_of(cat[:, i * cm:(i + 1) * cm]), R.view_of(cat[:, (i + 1) * cm:(i + 2) * cm])
+            L.check(L.lib().upa_maxpool2d(vs.ptr, vs.n, vs.h, vs.w, vs.c, vs.ld, vd.ptr, vd.h, vd.w, vd.ld, self.k, 1,
+                                          self.k // 2, 0, vs.dtype, _s(c.device)), "maxpool2d")
+        self.cat = cat
+        return self.cv2.forward(cat, out=out)
+
+    def backward(self, dy, dx, accumulate):
+        c = self.ctx
+        n, ct, h, w = self.cat.shape
+        cm = ct // 4
+        g = _new(n, ct, h, w, c.dtype, c.device, (id(self), "gcat"))
+        self.cv2.backward(dy, g, False)
+        for i in (2, 1, 0):
+            vx, vdy, vdx = R.view_of(self.cat[:, i * cm:(i + 1) * cm]), R.view_of(g[:, (i + 1) * cm:(i + 2) * cm]), \
+                R.view_of(g[:, i * cm:(i + 1) * cm])
+            L.check(L.lib().upa_maxpool2d_bwd(vx.ptr, vdy.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, vdy.ld, self.k, 1, self.k // 2,
+                                              vdx.ptr, vdx.ld, 1, vx.dtype, _s(c.device)), "maxpool2d_bwd")
+        self.cv1.backward(g[:, :cm], dx, accumulate)
+
+
+class _Node:
+    """One row of the model YAML inside the training graph."""
+
+    def __init__(self, i, f, kind, op):
+        self.i, self.f, self.kind, self.op = i, f, kind, op
+        self.y = None       # forward output
+        self.g = None       # gradient buffer of the output
+        self.g_ready = False
+
+
+class DetectionTrainer:
+    """One-process-per-GPU trainer for a DetectionModel (reference: engine/trainer.py BaseTrainer._do_train inner loop)."""
+
+    def __init__(self, model, dtype=torch.bfloat16, hyp=None, device=None, world_size=1, ema=True):
+        self.model = model
+        self.hyp = dict(HYP, **(hyp or {}))
+        self.device = torch.device(device or "cuda:0")
+        self.dtype = dtype
+        self.world_size = world_size
+        self.ctx = _Ctx(self.device, dtype)
+        self.pool = R.BufferPool()
+        self.updates = 0
+        self.first_step = True
+        model.to(self.device)
+        self._flatten_parameters(ema)
+        self._build_graph()
+
+    # ---- parameters ---------------------------------------------------------------------------------------------------
+    def _flatten_parameters(self, ema):
+        """Flat f32 buffers [biases | decayed weights | norm weights] with model.parameters() viewing into them."""
+        g0, g1, g2 = [], [], []
+        norm = tuple(v for k, v in nn.__dict__.items() if "Norm" in k)
+        for mname, mod in self.model.named_modules():
+            for pname, p in mod.named_parameters(recurse=False):
+                if not p.requires_grad:
+                    continue
+                full = f"{mname}.{pname}" if mname else pname
+                (g2 if "bias" in full else g1 if isinstance(mod, norm) else g0).append(p)
+        self.groups = []
+        total = sum(p.numel() for g in (g2, g0, g1) for p in g)
+        dev = self.device
+        self.P = torch.empty(total, dtype=torch.float32, device=dev)
+        self.G = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.M = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        for params, wd in ((g2, 0.0), (g0, self.hyp["weight_decay"]), (g1, 0.0)):
+            start = off
+            for p in params:
+                n = p.numel()
+                self.P[off:off + n].copy_(p.detach().reshape(-1))  # plumbing: one-time gather of the initial weights
+                p.data = self.P[off:off + n].view(p.shape)
+                p.grad = self.G[off:off + n].view(p.shape)
+                off += n
+            self.groups.append((start, off - start, wd))
+        self.E = self.P.clone() if ema else None  # ModelEMA copy of the parameters
+        bufs = [b for b in self.model.buffers() if b.dtype.is_floating_point]
+        nb = sum(b.numel() for b in bufs)
+        self.RB = torch.empty(max(nb, 1), dtype=torch.float32, device=dev)
+        off = 0
+        for b in bufs:
+            n = b.numel()
+            self.RB[off:off + n].copy_(b.detach().reshape(-1))
+            b.data = self.RB[off:off + n].view(b.shape)
+            off += n
+        self.nbuf = nb
+        self.ERB = self.RB.clone() if ema else None
+        self.sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
+
+    # ---- graph --------------------------------------------------------------------------------------------------------
+    def _build_graph(self):
+        ctx = self.ctx
+        self.nodes = []
+        self.convs = []
+        for m in self.model.model:
+            name = f"model.{m.i}"
+            if isinstance(m, H.Detect):
+                op = DetectT(ctx, m, name, self)
+                kind = "detect"
+            elif isinstance(m, B.C2f):
+                op, kind = C2fT(ctx, m, name), "c2f"
+            elif isinstance(m, B.SPPF):
+                op, kind = SPPFT(ctx, m, name), "sppf"
+            elif isinstance(m, CV.Conv):
+                op, kind = ConvT(ctx, m.conv, m.bn, m._act_code(), name), "conv"
+            elif isinstance(m, CV.Concat):
+                op, kind = None, "concat"
+            elif isinstance(m, RS.Upsample):
+                op, kind = None, "upsample"
+            else:
+                raise L.UpaError(f"{type(m).__name__} (layer {m.i}) has no training path on HIP yet")
+            if op is not None:
+                self.convs += op.convs() if hasattr(op, "convs") else [op]
+            self.nodes.append(_Node(m.i, m.f, kind, op))
+        self.detect = self.nodes[-1].op
+
+    # ---- one step -----------------------------------------------------------------------------------------------------
+    def _input_nhwc(self, img):
+        """(N,3,H,W) f32 NCHW image batch -> NHWC view padded to one 16-byte channel group (pad channels stay zero)."""
+        n, c, h, w = img.shape
+        E = self.ctx.E
+        zeroed = self.__dict__.setdefault("_img_zeroed", set())
+        buf = self.pool.get(("img", n, h, w), (n, h, w, E), self.dtype, self.device)
+        if (n, h, w) not in zeroed:
+            buf.zero_()  # one-time: the pad channels are never written again
+            zeroed.add((n, h, w))
+        L.check(L.lib().upa_nchw_to_nhwc(img.data_ptr(), n, c, h, w, buf.data_ptr(), E, self.ctx.code, _s(self.device)),
+                "nchw_to_nhwc")
+        return buf.permute(0, 3, 1, 2)
+
+    def forward_backward(self, img, labels):
+        """img: (N,3,H,W) float32 NCHW on the device; labels: the reference's batch dict (batch_idx, cls, bboxes).
+        Fills the flat gradient buffer; returns loss_items (3,) on the device."""
+        ctx, dev = self.ctx, self.device
+        L.require_gpu(img, "train")
+        self.model.train()
+        with R.static_buffers(self.pool):
+            for cv in self.convs:
+                cv.pack()
+            x = self._input_nhwc(img.float().contiguous() if img.dtype != torch.float32 else img.contiguous())
+            # the stem sees E input channels: 3 real + zero padding (the packed weights are zero there as well)
+            ys = []
+            for nd in self.nodes:
+                xin = x if nd.f == -1 else (ys[nd.f] if isinstance(nd.f, int) else [x if j == -1 else ys[j] for j in nd.f])
+                nd.xin = xin
+                if nd.kind in ("conv", "c2f", "sppf"):
+                    y = nd.op.forward(xin)
+                elif nd.kind == "upsample":
+                    n, c, h, w = xin.shape
+                    y = _new(n, c, 2 * h, 2 * w, ctx.dtype, dev, (id(nd), "y"))
+                    vs, vd = R.view_of(xin), R.view_of(y)
+                    L.check(L.lib().upa_upsample2x(vs.ptr, vs.n, vs.h, vs.w, vs.c, vs.ld, vd.ptr, vd.ld, vs.dtype, _s(dev)),
+                            "upsample2x")
+                elif nd.kind == "concat":
+                    n, _, h, w = xin[0].shape
+                    y = _new(n, sum(int(t.shape[1]) for t in xin), h, w, ctx.dtype, dev, (id(nd), "y"))
+                    c0 = 0
+                    for t in xin:
+                        copy_into(ctx, t, y[:, c0:c0 + t.shape[1]])
+                        c0 += t.shape[1]
+                else:  # detect
+                    y = nd.op.forward(xin)
+                nd.y = y
+                nd.g = None
+                nd.g_ready = False
+                x = y
+                ys.append(y)
+            items = self.detect.loss_backward(labels, img.shape[0])
+            # ---- backward over the layer list in reverse
+            for nd in reversed(self.nodes[:-1]):
+                if nd.g is None:
+                    continue  # output unused by the loss
+                dy = nd.g
+                if nd.kind in ("conv", "c2f", "sppf"):
+                    if nd.i == 0:
+                        nd.op.backward(dy, None, False)
+                    else:
+                        src = self.nodes[nd.f] if nd.f != -1 else self.nodes[nd.i - 1]
+                        dx, acc = self._grad_of(src)
+                        nd.op.backward(dy, dx, acc)
+                elif nd.kind == "upsample":
+                    src = self.nodes[nd.f] if nd.f != -1 else self.nodes[nd.i - 1]
+                    dx, acc = self._grad_of(src)
+                    vdy, vdx = R.view_of(dy), R.view_of(dx)
+                    L.check(L.lib().upa_upsample2x_bwd(vdy.ptr, vdx.n, vdx.h, vdx.w, vdx.c, vdy.ld, vdx.ptr, vdx.ld, int(acc),
+                                                       vdx.dtype, _s(dev)), "upsample2x_bwd")
+                elif nd.kind == "concat":
+                    c0 = 0
+                    for j in nd.f:
+                        src = self.nodes[j] if j != -1 else self.nodes[nd.i - 1]
+                        cj = int(src.y.shape[1])
+                        dx, acc = self._grad_of(src)
+                        if acc:
+                            add_into(ctx, dy[:, c0:c0 + cj], dx)
+                        else:
+                            copy_into(ctx, dy[:, c0:c0 + cj], dx)
+                        c0 += cj
+        return items
+
+    def _grad_of(self, node):
+        """(gradient buffer of node's output, accumulate?) - the first producer writes, later ones accumulate."""
+        if node.g is None:
+            n, c, h, w = node.y.shape
+            node.g = _new(n, c, h, w, self.ctx.dtype, self.device, (id(node), "g"))
+            return node.g, False
+        return node.g, True
+
+    def grad_sumsq(self):
+        off_end = self.groups[-1][0] + self.groups[-1][1]
+        L.check(L.lib().upa_sumsq(self.G.data_ptr(), off_end, self.sumsq.data_ptr(), 0, _s(self.device)), "sumsq")
+        return self.sumsq
+
+    def all_reduce_gradients(self):
+        """Batch-DP exchange step: one SUM all-reduce of the flat f32 gradient buffer over RCCL.
+        The reference multiplies the loss by world_size and lets DDP average the gradients (trainer.py:424-425), i.e.
+        every rank ends up with sum_over_ranks d(loss_rank) - exactly the SUM of the unscaled per-rank gradients."""
+        if self.world_size > 1:
+            import torch.distributed as dist
+            n = self.groups[-1][0] + self.groups[-1][1]
+            dist.all_reduce(self.G[:n], op=dist.ReduceOp.SUM)
+
+    def optimizer_step(self):
+        h = self.hyp
+        lib, st = L.lib(), _s(self.device)
+        self.grad_sumsq()
+        self.updates += 1
+        d = h["ema_decay"] * (1 - math.exp(-self.updates / h["ema_tau"]))
+        for start, n, wd in self.groups:
+            if n == 0:
+                continue
+            o = 4 * start
+            L.check(lib.upa_sgd_nesterov_ema(self.P.data_ptr() + o, self.G.data_ptr() + o, self.M.data_ptr() + o,
+                                             (self.E.data_ptr() + o) if self.E is not None else None, n,
+                                             self.sumsq.data_ptr(), h["max_norm"], h["lr"], h["momentum"], wd,
+                                             int(self.first_step), d, 1, st), "sgd")
+        if self.ERB is not None and self.nbuf:
+            L.check(lib.upa_ema_update(self.ERB.data_ptr(), self.RB.data_ptr(), self.nbuf, d, st), "ema_buffers")
+        self.first_step = False
+
+    def step(self, img, labels):
+        items = self.forward_backward(img, labels)
+        self.all_reduce_gradients()
+        self.optimizer_step()
+        return items
+
+    def grad_norm(self) -> float:
+        return float(torch.sqrt(self.grad_sumsq())[0])
+
+    def ema_state_dict(self):
+        """The EMA weights under the reference's state_dict keys (for validation / checkpoints)."""
+        out = {}
+        for k, p in self.model.named_parameters():
+            if p.requires_grad and self.E is not None:
+                off = (p.data_ptr() - self.P.data_ptr()) // 4
+                out[k] = self.E[off:off + p.numel()].view(p.shape)
+            else:
+                out[k] = p.detach()
+        for k, b in self.model.named_buffers():
+            if b.dtype.is_floating_point and self.ERB is not None:
+                off = (b.data_ptr() - self.RB.data_ptr()) // 4
+                out[k] = self.ERB[off:off + b.numel()].view(b.shape)
+            else:
+                out[k] = b
+        return out
+
+
+class DetectT(_Seq):
+    """Train-mode Detect (head.py:116-126 returns the raw per-level maps) + v8DetectionLoss + its gradient."""
+
+    def __init__(self, ctx, m: H.Detect, name, trainer):
+        super().__init__(ctx)
+        self.m, self.tr = m, trainer
+        self.nl, self.nc, self.reg_max, self.no = m.nl, m.nc, m.reg_max, m.no
+        self.br = []
+        for i in range(m.nl):
+            row = []
+            for tag, seq in (("cv2", m.cv2[i]), ("cv3", m.cv3[i])):
+                row.append([ConvT(ctx, seq[0].conv, seq[0].bn, seq[0]._act_code(), f"{name}.{tag}.{i}.0"),
+                            ConvT(ctx, seq[1].conv, seq[1].bn, seq[1]._act_code(), f"{name}.{tag}.{i}.1"),
+                            ConvT(ctx, seq[2], None, L.ACT_NONE, f"{name}.{tag}.{i}.2")])
+            self.br.append(row)
+
+    def convs(self):
+        return [cv for row in self.br for seq in row for cv in seq]
+
+    def forward(self, xs):
+        c = self.ctx
+        dev = c.device
+        nb = 4 * self.reg_max
+        self.xs = list(xs)
+        self.raw, self.raw32 = [], []
+        for i, x in enumerate(xs):
+            n, _, h, w = x.shape
+            raw = _new(n, self.no, h, w, c.dtype, dev, (id(self), "raw", i))
+            for k, (seq, out) in enumerate(zip(self.br[i], (raw[:, :nb], raw[:, nb:]))):
+                t = seq[1].forward(seq[0].forward(x))
+                seq[2].forward(t, out=out)
+            self.raw.append(raw)
+            if c.dtype == torch.float32:
+                self.raw32.append(raw)
+            else:  # the loss reads f32 maps
+                r32 = _new(n, self.no, h, w, torch.float32, dev, (id(self), "raw32", i))
+                vs, vd = R.view_of(raw), R.view_of(r32)
+                L.check(L.lib().upa_cast_view(vs.ptr, vs.dtype, vs.ld, vd.ptr, vd.dtype, vd.ld, vs.n * vs.h * vs.w, vs.c,
+                                              _s(dev)), "cast_view")
+                self.raw32.append(r32)
+        return self.raw
+
+    def loss_backward(self, labels, batch_size):
+        """v8DetectionLoss (utils/loss.py:471-528) + gradient; then backward through the head into the neck outputs."""
+        c, tr = self.ctx, self.tr
+        dev = c.device
+        lib = L.lib()
+        h = tr.hyp
+        imgsz_h = int(self.raw[0].shape[2] * float(self.m.stride[0]))
+        imgsz_w = int(self.raw[0].shape[3] * float(self.m.stride[0]))
+        gt, ngt = pack_targets(labels, batch_size, imgsz_h, imgsz_w)
+        gt_d = tr.pool.get(("gt", batch_size), (batch_size, MAX_GT, 5), torch.float32, dev)
+        ngt_d = tr.pool.get(("ngt", batch_size), (batch_size,), torch.int32, dev)
+        gt_d.copy_(gt, non_blocking=True)
+        ngt_d.copy_(ngt, non_blocking=True)
+        grads32 = []
+        for i, r in enumerate(self.raw32):
+            n, ch, hh, ww = r.shape
+            grads32.append(_new(n, ch, hh, ww, torch.float32, dev, (id(self), "graw32", i)))
+        nl = self.nl
+        FP = C.c_void_p * nl
+        feats = FP(*[R.view_of(r).ptr for r in self.raw32])
+        grads = FP(*[R.view_of(g).ptr for g in grads32])
+        IA = C.c_int * nl
+        hs = IA(*[int(r.shape[2]) for r in self.raw32])
+        ws = IA(*[int(r.shape[3]) for r in self.raw32])
+        lds = IA(*[R.view_of(r).ld for r in self.raw32])
+        strides = (C.c_float * nl)(*[float(s) for s in self.m.stride])
+        A = sum(int(r.shape[2]) * int(r.shape[3]) for r in self.raw32)
+        nbytes = lib.upa_detection_loss_workspace_bytes(batch_size, A)
+        wsb = tr.pool.get(("loss_ws", batch_size, A), (nbytes,), torch.uint8, dev)
+        items = tr.pool.get(("loss_items",), (3,), torch.float32, dev)
+        L.check(lib.upa_detection_loss(C.cast(feats, C.c_void_p), C.cast(grads, C.c_void_p), C.cast(hs, C.c_void_p),
+                                       C.cast(ws, C.c_void_p), C.cast(lds, C.c_void_p), C.cast(strides, C.c_void_p), nl,
+                                       batch_size, self.nc, self.reg_max, gt_d.data_ptr(), ngt_d.data_ptr(), MAX_GT, h["box"],
+                                       h["cls"], h["dfl"], 1.0, items.data_ptr(), wsb.data_ptr(), nbytes,
+                                       _s(dev)), "detection_loss")
+        nb = 4 * self.reg_max
+        for i in range(nl):
+            g32 = grads32[i]
+            if c.dtype == torch.float32:
+                graw = g32
+            else:
+                n, ch, hh, ww = g32.shape
+                graw = _new(n, ch, hh, ww, c.dtype, dev, (id(self), "graw", i))
+                vs, vd = R.view_of(g32), R.view_of(graw)
+                L.check(lib.upa_cast_view(vs.ptr, vs.dtype, vs.ld, vd.ptr, vd.dtype, vd.ld, vs.n * vs.h * vs.w, vs.c, _s(dev)),
+                        "cast_view")
+            # feature map feeding level i: route the gradient into the producing node
+            src = tr.nodes[self.m.f[i]]
+            dx, acc = tr._grad_of(src)
+            for k, (seq, dy) in enumerate(zip(self.br[i], (graw[:, :nb], graw[:, nb:]))):
+                vt1, vt0 = R.view_of(seq[2].x), R.view_of(seq[1].x)
+                d1 = _new(vt1.n, vt1.c, vt1.h, vt1.w, c.dtype, dev, (id(self), "d1", i, k))
+                d0 = _new(vt0.n, vt0.c, vt0.h, vt0.w, c.dtype, dev, (id(self), "d0", i, k))
+                seq[2].backward(dy, d1, False)
+                seq[1].backward(d1, d0, False)
+                seq[0].backward(d0, dx, acc or k > 0)
+        return items
+
+
+def pack_targets(labels, batch_size, imgsz_h, imgsz_w):
+    """loss.py:445-461 on the host: (n,) image index, (n,) class, (n,4) normalised xywh -> padded (B, MAX_GT, 5)
+    [cls, x1, y1, x2, y2] in pixels + per-image counts (host tensors; a few hundred bytes per step)."""
+    bi = labels["batch_idx"].view(-1).cpu().long()
+    cls = labels["cls"].view(-1).cpu().float()
+    bb = labels["bboxes"].view(-1, 4).cpu().float()
+    gt = torch.zeros(batch_size, MAX_GT, 5)
+    ngt = torch.zeros(batch_size, dtype=torch.int32)
+    scale = torch.tensor([imgsz_w, imgsz_h, imgsz_w, imgsz_h], dtype=torch.float32)
+    for j in range(batch_size):
+        sel = bi == j
+        k = int(sel.sum())
+        if k > MAX_GT:
+            raise L.UpaError(f"image {j} has {k} boxes; the loss kernel pads to {MAX_GT}")
+        if k:
+            xywh = bb[sel] * scale
+            xy, wh = xywh[:, :2], xywh[:, 2:] / 2
+            gt[j, :k, 0] = cls[sel]
+            gt[j, :k, 1:3] = xy - wh
+            gt[j, :k, 3:5] = xy + wh
+            # rows whose box sums to zero are masked out by the reference (mask_gt, loss.py:489): keep only real boxes
+        ngt[j] = k
+    return gt, ngt
