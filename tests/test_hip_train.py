@@ -292,7 +292,7 @@ def test_training_step_yolov8n_matches_reference_golden(dtype, golden_dir):
         tr.optimizer_step()
         torch.cuda.synchronize()
         sd = m.state_dict()
-        np.testing.assert_allclose(sd["model.0.conv.weight"].cpu().numpy(), G[f"w_stem_{step}"], rtol=0, atol=2e-5 if f32 else 5e-3)
+        np.testing.assert_allclose(sd["model.0.conv.weight"].cpu().numpy(), G[f"w_stem_{step}"], rtol=0, atol=2e-5 if f32 else 1.5e-2)
         np.testing.assert_allclose(sd["model.2.cv1.bn.running_var"].cpu().numpy(), G[f"bn_rv_{step}"], rtol=2e-3 if f32 else 0.1)
         fk = [str(k) for k in G["state_keys"]]
         ema = tr.ema_state_dict()
