@@ -167,9 +167,11 @@ int upa_bn_act_bwd(const void* z, const void* dy, long npix, int c, int ldz, int
 /* out[c] (+)= sum over rows of z[:, c]  (bias gradient of the plain nn.Conv2d head outputs). ws: 2*c doubles. */
 int upa_channel_sum(const void* z, long npix, int c, int ldz, float* out, int accumulate, double* ws, int dtype, void* stream);
 /* dW[co][ci][kh][kw] (OIHW f32, optionally accumulated) = sum_{n,oy,ox} dz[n,oy,ox,co] * x[n,oy*s+kh-p,ox*s+kw-p,ci]
- * on exact-f32 MFMA; k in {1, 3}. */
+ * on exact-f32 MFMA; k in {1, 3}.  Workgroups store partial blocks into the caller's workspace and a second kernel sums
+ * them in a fixed order (deterministic, and no contended atomics). */
+size_t upa_conv2d_wgrad_workspace_bytes(int cin, int cout, int k);
 int upa_conv2d_wgrad(const void* x, int n, int h, int w, int cin, int ldx, const void* dz, int cout, int lddz, float* dw_oihw,
-                     int k, int stride, int pad, int accumulate, int dtype, void* stream);
+                     int k, int stride, int pad, int accumulate, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 /* dst (n,h,w,c) = zero-inserted src (n,oh,ow,c): dst[y,x] = src[y/2,x/2] for even y, x (data gradient of stride 2). */
 int upa_dilate2x(const void* src, int n, int oh, int ow, int c, int lds, void* dst, int h, int w, int ldd, int dtype,
                  void* stream);
@@ -177,8 +179,9 @@ int upa_dilate2x(const void* src, int n, int oh, int ow, int c, int lds, void* d
 int upa_upsample2x_bwd(const void* dy, int n, int h, int w, int c, int lddy, void* dx, int lddx, int accumulate, int dtype,
                        void* stream);
 /* Backward of nn.MaxPool2d(k, stride, pad): dy goes to the first maximum of each window (torch's index rule). */
+size_t upa_maxpool2d_bwd_workspace_bytes(int n, int h, int w, int c, int k, int stride, int pad);
 int upa_maxpool2d_bwd(const void* x, const void* dy, int n, int h, int w, int c, int ldx, int lddy, int k, int stride, int pad,
-                      void* dx, int lddx, int accumulate, int dtype, void* stream);
+                      void* dx, int lddx, int accumulate, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 /* *out (+)= sum g[i]^2 (f64): squared gradient norm for clip_grad_norm_. */
 int upa_sumsq(const float* g, long n, double* out, int accumulate, void* stream);
 /* clip_grad_norm_(max_norm) + SGD(nesterov, weight decay) + ModelEMA update over a flat parameter segment

@@ -157,7 +157,10 @@ def test_pool_upsample_backward(dtype):
     dx = R.alloc_nhwc(2, 16, 9, 11, dtype, DEV)
     vdx = R.view_of(dx)
     st = L.current_stream(DEV)
-    L.check(L.lib().upa_maxpool2d_bwd(vx.ptr, vdy.ptr, 2, 9, 11, 16, vx.ld, vdy.ld, 5, 1, 2, vdx.ptr, vdx.ld, 0, vx.dtype, st))
+    nws = L.lib().upa_maxpool2d_bwd_workspace_bytes(2, 9, 11, 16, 5, 1, 2)
+    wsb = torch.empty(nws, dtype=torch.uint8, device=DEV)
+    L.check(L.lib().upa_maxpool2d_bwd(vx.ptr, vdy.ptr, 2, 9, 11, 16, vx.ld, vdy.ld, 5, 1, 2, vdx.ptr, vdx.ld, 0, vx.dtype,
+                                      wsb.data_ptr(), nws, st))
     assert _rel(to_cpu_nchw(dx), xr.grad) <= (1e-6 if dtype == torch.float32 else 2e-2)
     # nearest 2x upsample backward
     u = P.uniform("ux", (2, 16, 5, 7), -1, 1).requires_grad_(True)

@@ -62,10 +62,12 @@ PROTOTYPES = {
     "upa_bn_act_fwd": (_i, [_vp, C.c_long, _i, _i, _vp, _vp, _vp, _vp, _f, _i, _vp, _i, _vp, _i, _i, _vp]),
     "upa_bn_act_bwd": (_i, [_vp, _vp, C.c_long, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp]),
     "upa_channel_sum": (_i, [_vp, C.c_long, _i, _i, _vp, _i, _vp, _i, _vp]),
-    "upa_conv2d_wgrad": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    "upa_conv2d_wgrad_workspace_bytes": (_sz, [_i, _i, _i]),
+    "upa_conv2d_wgrad": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "upa_dilate2x": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp]),
     "upa_upsample2x_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
-    "upa_maxpool2d_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
+    "upa_maxpool2d_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
+    "upa_maxpool2d_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "upa_sumsq": (_i, [_vp, C.c_long, _vp, _i, _vp]),
     "upa_sgd_nesterov_ema": (_i, [_vp, _vp, _vp, _vp, C.c_long, _vp, _f, _f, _f, _f, _i, _f, _i, _vp]),
     "upa_ema_update": (_i, [_vp, _vp, C.c_long, _f, _vp]),

@@ -113,28 +113,40 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(const ReduceParams 
     long p1 = p0 + chunk;
     if (p1 > p.npix) p1 = p.npix;
     int cnt = 0;
-    for (long px = p0 + sub; px < p1; px += ppb) {
-      float v[E];
-      load16<T>(p.z + ((size_t)px * p.ldz + grp * E) * sizeof(T), v);
-      if (MODE == 0) {
+    constexpr int U = 4;  // pixels in flight per thread
+    for (long px = p0 + sub; px < p1; px += (long)U * ppb) {
+      float v[U][E], d[U][E];
 #pragma unroll
-        for (int e = 0; e < E; ++e) { s0[e] += v[e]; s1[e] += v[e] * v[e]; }
-      } else if (MODE == 2) {
+      for (int u = 0; u < U; ++u) {
+        const long q = px + (long)u * ppb;
+        if (q < p1) {
+          load16<T>(p.z + ((size_t)q * p.ldz + grp * E) * sizeof(T), v[u]);
+          if (MODE == 1) load16<T>(p.dy + ((size_t)q * p.lddy + grp * E) * sizeof(T), d[u]);
+        } else {
 #pragma unroll
-        for (int e = 0; e < E; ++e) s0[e] += v[e];
-      } else {
-        float d[E];
-        load16<T>(p.dy + ((size_t)px * p.lddy + grp * E) * sizeof(T), d);
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-          const float xh = (v[e] - mean[e]) * rstd[e];
-          float du = d[e];
-          if (p.act == UPA_ACT_SILU) du *= silu_grad(gam[e] * xh + bet[e]);
-          s0[e] += du;
-          s1[e] += du * xh;
+          for (int e = 0; e < E; ++e) { v[u][e] = MODE == 1 ? mean[e] : 0.f; d[u][e] = 0.f; }
         }
       }
-      if (++cnt == 64) {  // bound the f32 partial sums: fold into the f64 block accumulators
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (MODE == 0) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) { s0[e] += v[u][e]; s1[e] += v[u][e] * v[u][e]; }
+        } else if (MODE == 2) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) s0[e] += v[u][e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            const float xh = (v[u][e] - mean[e]) * rstd[e];
+            float du = d[u][e];
+            if (p.act == UPA_ACT_SILU) du *= silu_grad(gam[e] * xh + bet[e]);
+            s0[e] += du;
+            s1[e] += du * xh;
+          }
+        }
+      }
+      if (++cnt == 16) {  // bound the f32 partial sums (64 pixels): fold into the f64 block accumulators
 #pragma unroll
         for (int e = 0; e < E; ++e) {
           atomicAdd(&red[grp * E + e], (double)s0[e]);
@@ -195,33 +207,42 @@ struct BnApplyParams {
   float eps; int act;
 };
 
+// Thread = one 16-byte channel group walking a strided set of pixels: the per-channel constants (mean, rstd, gamma,
+// beta, the two backward sums) are fetched once into registers, the loop is load - math - store.
 template <typename T, bool BWD>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyParams p) {
   constexpr int E = 16 / sizeof(T);
   const int cg = p.c / E;
-  const long total = p.npix * cg;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const long px = idx / cg;
-    const int grp = (int)(idx - px * cg);
+  const int ppb = 256 / cg;
+  const int tid = threadIdx.x;
+  const int grp = tid % cg, sub = tid / cg;
+  if (sub >= ppb) return;
+  float mean[E], rstd[E], gam[E], bet[E], k0[E], k1[E];
+  const float inv = 1.0f / (float)p.npix;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int ch = grp * E + e;
+    mean[e] = p.mean[ch]; rstd[e] = 1.0f / sqrtf(p.var[ch] + p.eps); gam[e] = p.gamma[ch]; bet[e] = p.beta[ch];
+    if (BWD) { k0[e] = (float)p.s0[ch]; k1[e] = (float)p.s1[ch]; }
+  }
+  const bool silu = p.act == UPA_ACT_SILU;
+  for (long px = (long)blockIdx.x * ppb + sub; px < p.npix; px += (long)gridDim.x * ppb) {
     float v[E], o[E], a[E];
     load16<T>(p.z + ((size_t)px * p.ldz + grp * E) * sizeof(T), v);
     if (BWD || p.aux) load16<T>(p.aux + ((size_t)px * p.ldaux + grp * E) * sizeof(T), a);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      const int ch = grp * E + e;
-      const float rstd = 1.0f / sqrtf(p.var[ch] + p.eps);
-      const float xh = (v[e] - p.mean[ch]) * rstd;
-      const float u = p.gamma[ch] * xh + p.beta[ch];
+      const float xh = (v[e] - mean[e]) * rstd[e];
+      const float u = gam[e] * xh + bet[e];
       if (!BWD) {
         float r = u;
-        if (p.act == UPA_ACT_SILU) r = u / (1.0f + expf(-u));
+        if (silu) r = u / (1.0f + expf(-u));
         if (p.aux) r += a[e];
         o[e] = r;
       } else {
         float du = a[e];
-        if (p.act == UPA_ACT_SILU) du *= silu_grad(u);
-        const float inv = 1.0f / (float)p.npix;
-        o[e] = p.gamma[ch] * rstd * (du - ((float)p.s0[ch] + xh * (float)p.s1[ch]) * inv);
+        if (silu) du *= silu_grad(u);
+        o[e] = gam[e] * rstd[e] * (du - (k0[e] + xh * k1[e]) * inv);
       }
     }
     store16<T>(p.y + ((size_t)px * p.ldy + grp * E) * sizeof(T), o);
@@ -240,7 +261,7 @@ struct WgradParams {
   int N, H, W, Cin, ldx, OH, OW, Cout, lddz;
   int KS, stride, pad;
   int TH, TW, tilesX, tilesY, numTiles, IH, IW;
-  int wgsPerBlock;
+  float* partial;  // [co block][ci block][workgroup][tap][BCO][BCI] partial sums (plain stores; reduced by a second kernel)
 };
 
 template <typename T, int MT, int NT, int KK>
@@ -322,7 +343,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
         }
     }
   }
-  // ---- flush: D[row = co][col = ci]: lane holds rows 4*kq..+3 of column l16
+  // ---- flush: D[row = co][col = ci]: lane holds rows 4*kq..+3 of column l16.  Every workgroup of a (co, ci) block
+  // would hit the same dW addresses at the same moment with atomics (measured: ~270 us of serialised L2 atomics per
+  // call); instead each workgroup stores its partial block and a small second kernel sums them in a fixed order.
+  float* part = p.partial + ((((size_t)blockIdx.y * gridDim.z + blockIdx.z) * gridDim.x + blockIdx.x) * (KK * KK)) * (BCO * BCI);
 #pragma unroll
   for (int t = 0; t < KK * KK; ++t)
 #pragma unroll
@@ -331,11 +355,32 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int co = co0 + (wm * MT + i) * 16 + kq * 4 + r;
-          const int ci = ci0 + (wn * NT + j) * 16 + l16;
-          if (co < p.Cout && ci < p.Cin)
-            atomicAdd(p.dw + ((size_t)co * p.Cin + ci) * (KK * KK) + t, acc[t][i][j][r]);
+          const int col = (wm * MT + i) * 16 + kq * 4 + r;
+          const int cil = (wn * NT + j) * 16 + l16;
+          part[((size_t)t * BCO + col) * BCI + cil] = acc[t][i][j][r];
         }
+}
+
+// dW[co][ci][t] (+)= sum over the workgroups of a block of their partial sums (fixed order: deterministic)
+__global__ void wgrad_reduce_kernel(const float* partial, int wgs, int bco, int bci, int BCO, int BCI, int kk2, float* dw, int Cout,
+                                    int Cin, int accumulate) {
+  const long per_wg = (long)kk2 * BCO * BCI;
+  const long total = (long)bco * bci * per_wg;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long t_ = idx;
+    const int cil = (int)(t_ % BCI); t_ /= BCI;
+    const int col = (int)(t_ % BCO); t_ /= BCO;
+    const int t = (int)(t_ % kk2); t_ /= kk2;
+    const int bz = (int)(t_ % bci);
+    const int by = (int)(t_ / bci);
+    const int co = by * BCO + col, ci = bz * BCI + cil;
+    if (co >= Cout || ci >= Cin) continue;
+    const float* src = partial + (((size_t)by * bci + bz) * wgs) * per_wg + ((size_t)t * BCO + col) * BCI + cil;
+    float s = 0.f;
+    for (int w = 0; w < wgs; ++w) s += src[(size_t)w * per_wg];
+    float* d = dw + ((size_t)co * Cin + ci) * kk2 + t;
+    *d = accumulate ? *d + s : s;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -388,11 +433,47 @@ __global__ void upsample2x_bwd_kernel(const char* dy, int n, int h, int w, int c
   }
 }
 
+// MaxPool2d backward in two passes: (1) per output window the position (kh*k + kw) of its FIRST maximum in row-major
+// scan order - the index torch's max_pool2d_with_indices keeps (k*k loads per output element); (2) every input pixel
+// gathers dy from the windows that elected it (k*k one-byte index loads per element).  Deterministic, no atomics.
 template <typename T>
-__global__ void maxpool_bwd_kernel(const char* x, const char* dy, int n, int h, int w, int c, int ldx, int lddy, int k,
-                                   int stride, int pad, int oh, int ow, char* dx, int lddx, int accumulate) {
-  // gather form (deterministic): input pixel i collects dy of every window whose FIRST maximum (row-major scan, the
-  // index torch's max_pool2d_with_indices keeps) is i.
+__global__ void maxpool_argmax_kernel(const char* x, int n, int h, int w, int c, int ldx, int k, int stride, int pad, int oh, int ow,
+                                      unsigned char* arg /* [n][oh][ow][c] */) {
+  constexpr int E = 16 / sizeof(T);
+  const int cg = c / E;
+  const long total = (long)n * oh * ow * cg;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long t = idx;
+    const int g = (int)(t % cg); t /= cg;
+    const int ox = (int)(t % ow); t /= ow;
+    const int oy = (int)(t % oh); t /= oh;
+    const int b = (int)t;
+    float best[E];
+    unsigned char bi[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { best[e] = -INFINITY; bi[e] = 255; }
+    for (int kh = 0; kh < k; ++kh) {
+      const int yy = oy * stride - pad + kh;
+      if (yy < 0 || yy >= h) continue;
+      for (int kw = 0; kw < k; ++kw) {
+        const int xx = ox * stride - pad + kw;
+        if (xx < 0 || xx >= w) continue;
+        float v[E];
+        load16<T>(x + ((((size_t)b * h + yy) * w + xx) * ldx + g * E) * sizeof(T), v);
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+          if (v[e] > best[e] || bi[e] == 255) { best[e] = v[e]; bi[e] = (unsigned char)(kh * k + kw); }
+      }
+    }
+    unsigned char* dst = arg + ((((size_t)b * oh + oy) * ow + ox) * c + g * E);
+#pragma unroll
+    for (int e = 0; e < E; ++e) dst[e] = bi[e];
+  }
+}
+
+template <typename T>
+__global__ void maxpool_bwd_kernel(const unsigned char* arg, const char* dy, int n, int h, int w, int c, int lddy, int k, int stride,
+                                   int pad, int oh, int ow, char* dx, int lddx, int accumulate) {
   constexpr int E = 16 / sizeof(T);
   const int cg = c / E;
   const long total = (long)n * h * w * cg;
@@ -402,40 +483,33 @@ __global__ void maxpool_bwd_kernel(const char* x, const char* dy, int n, int h, 
     const int ix = (int)(t % w); t /= w;
     const int iy = (int)(t % h); t /= h;
     const int b = (int)t;
-    float acc[E], me[E];
+    float acc[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) acc[e] = 0.f;
     char* dst = dx + ((((size_t)b * h + iy) * w + ix) * lddx + g * E) * sizeof(T);
     if (accumulate) load16<T>(dst, acc);
-    load16<T>(x + ((((size_t)b * h + iy) * w + ix) * ldx + g * E) * sizeof(T), me);
-    // windows (oy, ox) containing (iy, ix): oy*stride - pad <= iy < oy*stride - pad + k
-    for (int oy = 0; oy < oh; ++oy) {
-      const int wy0 = oy * stride - pad;
-      if (iy < wy0 || iy >= wy0 + k) continue;
-      for (int ox = 0; ox < ow; ++ox) {
-        const int wx0 = ox * stride - pad;
-        if (ix < wx0 || ix >= wx0 + k) continue;
-        // is (iy, ix) the first maximum of this window?
-        bool first[E];
+    for (int kh = 0; kh < k; ++kh) {
+      const int ny = iy + pad - kh;  // oy * stride
+      if (ny < 0 || ny % stride) continue;
+      const int oy = ny / stride;
+      if (oy >= oh) continue;
+      for (int kw = 0; kw < k; ++kw) {
+        const int nx = ix + pad - kw;
+        if (nx < 0 || nx % stride) continue;
+        const int ox = nx / stride;
+        if (ox >= ow) continue;
+        const size_t o = ((size_t)b * oh + oy) * ow + ox;
+        const unsigned char* ai = arg + o * c + g * E;
+        bool any = false;
+        unsigned char a8[E];
 #pragma unroll
-        for (int e = 0; e < E; ++e) first[e] = true;
-        for (int yy = wy0; yy < wy0 + k; ++yy) {
-          if (yy < 0 || yy >= h) continue;
-          for (int xx = wx0; xx < wx0 + k; ++xx) {
-            if (xx < 0 || xx >= w || (yy == iy && xx == ix)) continue;
-            float o[E];
-            load16<T>(x + ((((size_t)b * h + yy) * w + xx) * ldx + g * E) * sizeof(T), o);
-            const bool before = yy < iy || (yy == iy && xx < ix);
-#pragma unroll
-            for (int e = 0; e < E; ++e)
-              if (o[e] > me[e] || (before && o[e] == me[e])) first[e] = false;
-          }
-        }
+        for (int e = 0; e < E; ++e) { a8[e] = ai[e]; any |= a8[e] == kh * k + kw; }
+        if (!any) continue;
         float d[E];
-        load16<T>(dy + ((((size_t)b * oh + oy) * ow + ox) * lddy + g * E) * sizeof(T), d);
+        load16<T>(dy + (o * lddy + g * E) * sizeof(T), d);
 #pragma unroll
         for (int e = 0; e < E; ++e)
-          if (first[e]) acc[e] += d[e];
+          if (a8[e] == kh * k + kw) acc[e] += d[e];
       }
     }
     store16<T>(dst, acc);
@@ -569,7 +643,7 @@ extern "C" int upa_bn_act_fwd(const void* z, long npix, int c, int ldz, const fl
   p.z = (const char*)z; p.y = (char*)y; p.aux = (const char*)residual; p.npix = npix; p.c = c; p.ldz = ldz; p.ldy = ldy; p.ldaux = ldr;
   p.mean = mean; p.var = var; p.gamma = gamma; p.beta = beta; p.eps = eps; p.act = act;
   const int E = 16 / upa_elem_size(dtype);
-  const int grid = grid_for(npix * (c / E), 256, 256 * 32);
+  const int grid = grid_for(npix, 256 / (c / E) * 4, 256 * 16);
   if (dtype == UPA_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL((bn_apply_kernel<float, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   UPA_LAUNCH_CHECK();
@@ -596,7 +670,7 @@ extern "C" int upa_bn_act_bwd(const void* z, const void* dy, long npix, int c, i
   p.z = (const char*)z; p.y = (char*)dz; p.aux = (const char*)dy; p.npix = npix; p.c = c; p.ldz = ldz; p.ldy = lddz; p.ldaux = lddy;
   p.mean = mean; p.var = var; p.gamma = gamma; p.beta = beta; p.s0 = ws; p.s1 = ws + c; p.eps = eps; p.act = act;
   const int E = 16 / upa_elem_size(dtype);
-  const int grid2 = grid_for(npix * (c / E), 256, 256 * 32);
+  const int grid2 = grid_for(npix, 256 / (c / E) * 4, 256 * 16);
   if (dtype == UPA_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, true>), dim3(grid2), dim3(256), 0, s, p);
   else hipLaunchKernelGGL((bn_apply_kernel<float, true>), dim3(grid2), dim3(256), 0, s, p);
   UPA_LAUNCH_CHECK();
@@ -619,8 +693,12 @@ extern "C" int upa_channel_sum(const void* z, long npix, int c, int ldz, float* 
   return UPA_OK;
 }
 
+static size_t wgrad_partial_bytes(int bco_n, int bci_n, int wgs, int BCO, int BCI, int k) {
+  return (size_t)bco_n * bci_n * wgs * k * k * BCO * BCI * sizeof(float);
+}
+
 template <typename T, int MT, int NT>
-static int launch_wgrad(WgradParams& p, hipStream_t s) {
+static int launch_wgrad(WgradParams& p, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
   constexpr int BCO = 2 * MT * 16, BCI = 2 * NT * 16;
   // tile: LDS = (TH*TW*(BCO+16) + IH*IW*(BCI+16)) * 4 bytes <= ~150 KB
   int TH = 8, TW = 16;
@@ -639,6 +717,9 @@ static int launch_wgrad(WgradParams& p, hipStream_t s) {
   int wgs = 256 / (bco * bci);
   if (wgs < 1) wgs = 1;
   if (wgs > p.numTiles) wgs = p.numTiles;
+  const size_t need = wgrad_partial_bytes(bco, bci, wgs, BCO, BCI, p.KS);
+  UPA_CHECK_ARG(ws && ws_bytes >= need, "wgrad: workspace too small (%zu < %zu bytes)", ws_bytes, need);
+  p.partial = (float*)ws;
   const size_t lds = lds_bytes(TH, TW);
   dim3 grid(wgs, bco, bci);
 #define UPA_WG_LAUNCH(KK_)                                                                                        \
@@ -648,30 +729,52 @@ static int launch_wgrad(WgradParams& p, hipStream_t s) {
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);                                                         \
   } while (0)
   if (p.KS == 1) UPA_WG_LAUNCH(1);
-  else if (p.KS == 3) UPA_WG_LAUNCH(3);
-  else { upa_set_error("wgrad: kernel size %d not built (1 and 3 are)", p.KS); return UPA_EUNSUPPORTED; }
+  else if (p.KS == 3) {
+    if constexpr (MT * NT <= 4) UPA_WG_LAUNCH(3);
+    else { upa_set_error("wgrad: 128x128 blocks are built for k = 1 only"); return UPA_EUNSUPPORTED; }
+  } else { upa_set_error("wgrad: kernel size %d not built (1 and 3 are)", p.KS); return UPA_EUNSUPPORTED; }
 #undef UPA_WG_LAUNCH
+  const long total = (long)bco * bci * p.KS * p.KS * BCO * BCI;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(total)), dim3(256), 0, s, p.partial, wgs, bco, bci, BCO, BCI, p.KS * p.KS,
+                     p.dw, p.Cout, p.Cin, accumulate);
   UPA_LAUNCH_CHECK();
   return UPA_OK;
 }
 
+static bool wgrad_small(int cin, int cout) { return cin <= 32 || cout <= 32; }
+
+extern "C" size_t upa_conv2d_wgrad_workspace_bytes(int cin, int cout, int k) {
+  const int B = (k == 1 && cin >= 128 && cout >= 128) ? 128 : (wgrad_small(cin, cout) ? 32 : 64);
+  const int bco = cdiv(cout, B), bci = cdiv(cin, B);
+  int wgs = 256 / (bco * bci);
+  if (wgs < 1) wgs = 1;
+  return wgrad_partial_bytes(bco, bci, wgs, B, B, k);
+}
+
 extern "C" int upa_conv2d_wgrad(const void* x, int n, int h, int w, int cin, int ldx, const void* dz, int cout, int lddz,
-                                float* dw_oihw, int k, int stride, int pad, int accumulate, int dtype, void* stream) {
+                                float* dw_oihw, int k, int stride, int pad, int accumulate, int dtype, void* workspace,
+                                size_t workspace_bytes, void* stream) {
   UPA_CHECK_ARG(x && dz && dw_oihw, "wgrad: null pointer");
   UPA_CHECK_ARG(dtype == UPA_F32 || dtype == UPA_BF16, "wgrad: bad dtype");
   const int E = 16 / upa_elem_size(dtype);
   UPA_CHECK_ARG(ldx % E == 0 && lddz % E == 0 && cout % E == 0, "wgrad: strides / cout must be multiples of %d", E);
   UPA_CHECK_ARG(cin % E == 0 || cin < E, "wgrad: cin must be a multiple of %d (or a padded narrow input)", E);
   hipStream_t s = (hipStream_t)stream;
-  if (!accumulate) (void)hipMemsetAsync(dw_oihw, 0, sizeof(float) * (size_t)cout * cin * k * k, s);
   WgradParams p{};
   p.x = (const char*)x; p.dz = (const char*)dz; p.dw = dw_oihw;
   p.N = n; p.H = h; p.W = w; p.Cin = cin; p.ldx = ldx; p.Cout = cout; p.lddz = lddz;
   p.OH = (h + 2 * pad - k) / stride + 1; p.OW = (w + 2 * pad - k) / stride + 1;
   p.KS = k; p.stride = stride; p.pad = pad;
-  const bool small = cin <= 32 || cout <= 32;
-  if (dtype == UPA_BF16) return small ? launch_wgrad<bf16_t, 1, 1>(p, s) : launch_wgrad<bf16_t, 2, 2>(p, s);
-  return small ? launch_wgrad<float, 1, 1>(p, s) : launch_wgrad<float, 2, 2>(p, s);
+  const bool small = wgrad_small(cin, cout);
+  if (k == 1 && cin >= 128 && cout >= 128) {  // pointwise = plain GEMM over the pixels: 128 x 128 blocks
+    return dtype == UPA_BF16 ? launch_wgrad<bf16_t, 4, 4>(p, accumulate, workspace, workspace_bytes, s)
+                             : launch_wgrad<float, 4, 4>(p, accumulate, workspace, workspace_bytes, s);
+  }
+  if (dtype == UPA_BF16)
+    return small ? launch_wgrad<bf16_t, 1, 1>(p, accumulate, workspace, workspace_bytes, s)
+                 : launch_wgrad<bf16_t, 2, 2>(p, accumulate, workspace, workspace_bytes, s);
+  return small ? launch_wgrad<float, 1, 1>(p, accumulate, workspace, workspace_bytes, s)
+               : launch_wgrad<float, 2, 2>(p, accumulate, workspace, workspace_bytes, s);
 }
 
 extern "C" int upa_dilate2x(const void* src, int n, int oh, int ow, int c, int lds_, void* dst, int h, int w, int ldd, int dtype,
@@ -702,18 +805,33 @@ extern "C" int upa_upsample2x_bwd(const void* dy, int n, int h, int w, int c, in
   return UPA_OK;
 }
 
+extern "C" size_t upa_maxpool2d_bwd_workspace_bytes(int n, int h, int w, int c, int k, int stride, int pad) {
+  const int oh = (h + 2 * pad - k) / stride + 1, ow = (w + 2 * pad - k) / stride + 1;
+  return (size_t)n * oh * ow * c;
+}
+
 extern "C" int upa_maxpool2d_bwd(const void* x, const void* dy, int n, int h, int w, int c, int ldx, int lddy, int k, int stride,
-                                 int pad, void* dx, int lddx, int accumulate, int dtype, void* stream) {
-  UPA_CHECK_ARG(x && dy && dx && k >= 1 && stride >= 1, "maxpool2d_bwd: bad args");
+                                 int pad, void* dx, int lddx, int accumulate, int dtype, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+  UPA_CHECK_ARG(x && dy && dx && k >= 1 && k <= 15 && stride >= 1, "maxpool2d_bwd: bad args");
   if (int rc = check_view((long)n * h * w, c, ldx, dtype, "maxpool2d_bwd")) return rc;
   const int oh = (h + 2 * pad - k) / stride + 1, ow = (w + 2 * pad - k) / stride + 1;
+  UPA_CHECK_ARG(workspace && workspace_bytes >= (size_t)n * oh * ow * c, "maxpool2d_bwd: workspace too small");
   const int E = 16 / upa_elem_size(dtype);
-  const long total = (long)n * h * w * (c / E);
-  if (dtype == UPA_BF16) hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                                           (const char*)x, (const char*)dy, n, h, w, c, ldx, lddy, k, stride, pad, oh, ow, (char*)dx,
-                                           lddx, accumulate);
-  else hipLaunchKernelGGL((maxpool_bwd_kernel<float>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const char*)x,
-                          (const char*)dy, n, h, w, c, ldx, lddy, k, stride, pad, oh, ow, (char*)dx, lddx, accumulate);
+  const long tot_o = (long)n * oh * ow * (c / E), tot_i = (long)n * h * w * (c / E);
+  unsigned char* arg = (unsigned char*)workspace;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == UPA_BF16) {
+    hipLaunchKernelGGL((maxpool_argmax_kernel<bf16_t>), dim3(grid_for(tot_o)), dim3(256), 0, s, (const char*)x, n, h, w, c, ldx, k, stride,
+                       pad, oh, ow, arg);
+    hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t>), dim3(grid_for(tot_i)), dim3(256), 0, s, arg, (const char*)dy, n, h, w, c, lddy, k,
+                       stride, pad, oh, ow, (char*)dx, lddx, accumulate);
+  } else {
+    hipLaunchKernelGGL((maxpool_argmax_kernel<float>), dim3(grid_for(tot_o)), dim3(256), 0, s, (const char*)x, n, h, w, c, ldx, k, stride,
+                       pad, oh, ow, arg);
+    hipLaunchKernelGGL((maxpool_bwd_kernel<float>), dim3(grid_for(tot_i)), dim3(256), 0, s, arg, (const char*)dy, n, h, w, c, lddy, k,
+                       stride, pad, oh, ow, (char*)dx, lddx, accumulate);
+  }
   UPA_LAUNCH_CHECK();
   return UPA_OK;
 }

@@ -49,7 +49,7 @@ class _Ctx:
         self.es = 2 if dtype == torch.bfloat16 else 4
         self.E = 16 // self.es
         self.ws = torch.zeros(4 * 2048, dtype=torch.float64, device=device)  # channel-reduction scratch (c <= 2048)
-        self.tape = []  # backward closures, run in reverse
+        self.wgrad_ws = torch.empty(0, dtype=torch.uint8, device=device)  # weight-gradient partial sums (largest layer)
 
 
 def _new(n, c, h, w, dtype, dev, key):
@@ -76,6 +76,9 @@ class ConvT:
             self.mean = torch.empty(self.cout, dtype=torch.float32, device=dev)
             self.var = torch.empty(self.cout, dtype=torch.float32, device=dev)
         self.x = self.z = None
+        nws = L.lib().upa_conv2d_wgrad_workspace_bytes(self.cin, self.cout, self.k)
+        if nws > ctx.wgrad_ws.numel():
+            ctx.wgrad_ws = torch.empty(nws, dtype=torch.uint8, device=dev)  # shared by all layers (stream ordered)
 
     def pack(self):
         lib, c = L.lib(), self.ctx
@@ -148,7 +151,8 @@ class ConvT:
                     "bn_act_bwd")
         vx, vdz = R.view_of(self.x), R.view_of(dz)
         L.check(lib.upa_conv2d_wgrad(vx.ptr, vx.n, vx.h, vx.w, self.cin, vx.ld, vdz.ptr, self.cout, vdz.ld,
-                                     self.conv.weight.grad.data_ptr(), self.k, self.s, self.p, 1, vx.dtype, st),
+                                     self.conv.weight.grad.data_ptr(), self.k, self.s, self.p, 1, vx.dtype,
+                                     c.wgrad_ws.data_ptr(), c.wgrad_ws.numel(), st),
                 f"wgrad[{self.name}]")
         if dx is None:
             return
@@ -268,8 +272,10 @@ class SPPFT(_Seq):
         for i in (2, 1, 0):
             vx, vdy, vdx = R.view_of(self.cat[:, i * cm:(i + 1) * cm]), R.view_of(g[:, (i + 1) * cm:(i + 2) * cm]), \
                 R.view_of(g[:, i * cm:(i + 1) * cm])
+            nws = L.lib().upa_maxpool2d_bwd_workspace_bytes(vx.n, vx.h, vx.w, vx.c, self.k, 1, self.k // 2)
+            ws = R.alloc_plain((nws,), torch.uint8, c.device, (id(self), "argmax"))
             L.check(L.lib().upa_maxpool2d_bwd(vx.ptr, vdy.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, vdy.ld, self.k, 1, self.k // 2,
-                                              vdx.ptr, vdx.ld, 1, vx.dtype, _s(c.device)), "maxpool2d_bwd")
+                                              vdx.ptr, vdx.ld, 1, vx.dtype, ws.data_ptr(), nws, _s(c.device)), "maxpool2d_bwd")
         self.cv1.backward(g[:, :cm], dx, accumulate)
 
 
