@@ -39,7 +39,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--model", default="yolov8n")
+    ap.add_argument("--model", default=None, help="default: yolov8n (infer), yolov8s (train)")
+    ap.add_argument("--workload", default="infer", choices=["infer", "train"],
+                    help="infer = BASELINE config 2 (the headline metric); train = config 3: one batch-DP training step "
+                         "(forward, v8DetectionLoss, backward, gradient all-reduce over RCCL, clip + SGD nesterov + EMA)")
+    ap.add_argument("--imgsz", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-threads", type=int, default=32)
@@ -53,6 +57,10 @@ def parse():
 
 def main():
     args = parse()
+    if args.model is None:
+        args.model = "yolov8s" if args.workload == "train" else "yolov8n"
+    if args.workload == "train":
+        return main_train(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -148,6 +156,152 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main_train(args):
+    """BASELINE config 3: yolov8s 640x640, per-GPU batch 32 (global 256 on 8 GPUs), one training step per `step`:
+    train-mode forward, v8DetectionLoss + TaskAlignedAssigner, backward, ONE all-reduce (SUM) of the flat f32 gradient
+    buffer over RCCL/xGMI, clip_grad_norm_(10) + SGD(nesterov) + EMA.  Weak scaling: per-GPU work is fixed."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+    from ultralytics_pro_amd import _lib as L
+    from ultralytics_pro_amd.engine import runtime as R
+    from ultralytics_pro_amd.engine.trainer import DetectionTrainer
+    from ultralytics_pro_amd.nn.tasks import DetectionModel
+    from ultralytics_pro_amd.utils import procedural as P
+
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model = DetectionModel(args.model + ".yaml")
+    P.apply_procedural_weights(model)
+    tr = DetectionTrainer(model, dtype=dtype, device=dev, world_size=world)
+    x = P.synthetic_images(args.batch, h=args.imgsz, w=args.imgsz, first=rank * args.batch).to(dev)
+    lab = P.synthetic_labels(args.batch, first=rank * args.batch)
+    for _ in range(max(args.warmup, 1)):
+        items = tr.step(x, lab)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        items = tr.step(x, lab)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    value = args.batch * world * args.steps / dt
+    roofline = cpu_baseline = None
+    if rank == 0:
+        roofline = wgrad_profile(tr, L, R, dev, dtype)
+        if not args.no_cpu_baseline:
+            cpu_baseline = run_cpu_train_baseline(args)
+        nparam = sum(n for _, n, _ in tr.groups)
+        print(json.dumps({
+            "metric": f"images/sec {args.model} {args.imgsz}x{args.imgsz} training step, per-GPU batch {args.batch} "
+                      "(forward + v8DetectionLoss + backward + gradient all-reduce + clip/SGD-nesterov/EMA)",
+            "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic (procedural images, labels and initial weights, resident in HBM)",
+            "config": {"workload": f"{args.model} detect {args.imgsz}x{args.imgsz} batch-DP training step, per-GPU batch "
+                                   f"{args.batch}, {args.dtype} activations / f32 master weights and gradients",
+                       "global_batch": args.batch * world, "per_gpu_batch": args.batch, "parallelism": f"dp{world}",
+                       "exchange": f"1 all-reduce(SUM) of {nparam * 4 / 1e6:.1f} MB f32 gradients per step (RCCL)",
+                       "optimizer": "SGD(lr 0.01, momentum 0.9, nesterov, wd 5e-4) + clip 10.0 + EMA"},
+            "images_per_sec_per_gpu": round(value / world, 1),
+            "loss_items": [round(float(v), 4) for v in items.tolist()],
+            "roofline": roofline, "cpu_baseline": cpu_baseline}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def wgrad_profile(tr, L, R, dev, dtype, reps=5):
+    """Dominant kernel of the training step = the weight-gradient MFMA kernel: every layer's launch re-issued `reps` times
+    back to back on the current stream between HIP events (its operands are still resident from the last step)."""
+    fam = {}
+    lib = L.lib()
+    st = L.current_stream(dev)
+    scratch = {}
+    for cv in tr.convs:
+        if cv.x is None:
+            continue
+        vx = R.view_of(cv.x)
+        oh, ow = (vx.h + 2 * cv.p - cv.k) // cv.s + 1, (vx.w + 2 * cv.p - cv.k) // cv.s + 1
+        dz = scratch.setdefault((vx.n, cv.cout, oh, ow), torch.zeros(vx.n, oh, ow, cv.cout, dtype=dtype, device=dev))
+        dw = torch.zeros(cv.cout, cv.cin, cv.k, cv.k, device=dev)
+        ws = tr.ctx.wgrad_ws
+
+        def call():
+            L.check(lib.upa_conv2d_wgrad(vx.ptr, vx.n, vx.h, vx.w, cv.cin, vx.ld, dz.data_ptr(), cv.cout, cv.cout, dw.data_ptr(),
+                                         cv.k, cv.s, cv.p, 1, vx.dtype, ws.data_ptr(), ws.numel(), st), "wgrad")
+        call()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            call()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        ms = e0.elapsed_time(e1) / reps
+        small = cv.cin <= 32 or cv.cout <= 32
+        mt = 4 if (cv.k == 1 and cv.cin >= 128 and cv.cout >= 128) else (1 if small else 2)
+        name = "void (anonymous namespace)::wgrad_kernel<%s, %d, %d, %d>((anonymous namespace)::WgradParams)" % (
+            "unsigned short" if dtype == torch.bfloat16 else "float", mt, mt, cv.k)
+        d = fam.setdefault(name, dict(launches=0, ms=0.0, flops=0.0))
+        d["launches"] += 1
+        d["ms"] += ms
+        d["flops"] += 2.0 * vx.n * oh * ow * cv.cout * cv.cin * cv.k * cv.k
+    name, d = max(fam.items(), key=lambda kv: kv[1]["ms"])
+    avg_s = d["ms"] / d["launches"] * 1e-3
+    tf = d["flops"] / d["launches"] / avg_s / 1e12
+    return {"kernel": name, "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tf / PEAK_F32_TFLOPS, 4), "traffic": None, "launches_per_step": d["launches"],
+            "avg_launch_us": round(avg_s * 1e6, 1),
+            "algorithmic_flops_per_launch": d["flops"] / d["launches"],
+            "note": "weight gradient on exact-f32 MFMA (v_mfma_f32_16x16x4_f32); time includes the partial-sum reduction kernel",
+            "wgrad_ms_per_step": round(sum(v["ms"] for v in fam.values()), 3)}
+
+
+def run_cpu_train_baseline(args):
+    """The oracle training step (torch autograd on this host's cores), bounded sample: bs 4, 320x320."""
+    from oracle import tasks as ot
+    from oracle import train as otr
+    from ultralytics_pro_amd.utils import procedural as P
+
+    host_cores = os.cpu_count() or 1
+    cores = min(host_cores, args.cpu_threads)
+    torch.set_num_threads(cores)
+    m = ot.DetectionModel(args.model + ".yaml")
+    P.apply_procedural_weights(m)
+    st = otr.TrainState(m)
+    bs, sz = 4, 320
+    batch = {"img": P.synthetic_images(bs, h=sz, w=sz), **P.synthetic_labels(bs)}
+    otr.train_step(m, st, batch)
+    best = 1e30
+    for _ in range(2):
+        t0 = time.perf_counter()
+        otr.train_step(m, st, batch)
+        best = min(best, time.perf_counter() - t0)
+    px_ratio = (sz * sz) / float(args.imgsz * args.imgsz)
+    return {"value": round(bs / best * px_ratio, 2), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"oracle train step (torch CPU fp32 autograd) {args.model} bs={bs} {sz}x{sz}, best of 2 = "
+                      f"{bs / best:.2f} images/s at {sz}px, scaled by the pixel ratio to {args.imgsz}px; host has "
+                      f"{host_cores} logical cores"}
 
 
 def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):

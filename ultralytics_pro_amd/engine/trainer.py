@@ -475,9 +475,9 @@ class DetectionTrainer:
         The reference multiplies the loss by world_size and lets DDP average the gradients (trainer.py:424-425), i.e.
         every rank ends up with sum_over_ranks d(loss_rank) - exactly the SUM of the unscaled per-rank gradients."""
         if self.world_size > 1:
-            import torch.distributed as dist
+            from ..parallel import allreduce_gradients_
             n = self.groups[-1][0] + self.groups[-1][1]
-            dist.all_reduce(self.G[:n], op=dist.ReduceOp.SUM)
+            allreduce_gradients_(self.G[:n])
 
     def optimizer_step(self):
         h = self.hyp

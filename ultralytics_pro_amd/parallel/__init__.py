@@ -1,1 +1,2 @@
-from .dp import gather_detections, init_distributed, max_over_ranks, shard_first_image  # noqa: F401
+from .dp import (allreduce_gradients_, gather_detections, init_distributed, max_over_ranks,  # noqa: F401
+                 shard_first_image)

@@ -59,3 +59,13 @@ def gather_detections(out: torch.Tensor, counts: torch.Tensor):
     dist.all_gather_into_tensor(g_out, out.contiguous())
     dist.all_gather_into_tensor(g_cnt, counts.contiguous())
     return g_out, g_cnt
+
+
+def allreduce_gradients_(flat_grads: torch.Tensor) -> torch.Tensor:
+    """The one exchange step of the batch-DP training step: in-place SUM all-reduce of the flat f32 gradient
+    buffer (RCCL on the GPU, gloo in the CPU tests).  The reference multiplies each rank's loss by world_size and lets
+    DDP AVERAGE the gradients (engine/trainer.py:424-425): every rank ends up with sum_r d(loss_r)/dw - exactly the SUM
+    of the unscaled per-rank gradients, which is what this computes (one collective, no scaling pass)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM)
+    return flat_grads
