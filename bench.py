@@ -50,8 +50,10 @@ def parse():
     ap.add_argument("--serial", action="store_true",
                     help="no intra-step concurrency (Detect branches on the main stream): per-kernel durations in a "
                          "rocprofv3 trace of this mode are directly comparable with roofline.avg_launch_us")
-    ap.add_argument("--micro-batches", type=int, default=1,
-                    help="walk the per-GPU batch as this many concurrent sub-batches (parallel hipGraph branches)")
+    ap.add_argument("--micro-batches", type=int, default=2,
+                    help="walk the per-GPU batch as this many concurrent sub-batches (parallel hipGraph branches of ONE "
+                         "graph; the whole batch is still processed every step). 2 measured best on MI355X: the "
+                         "latency-bound 20x20/40x40 layers of one half overlap the other half's")
     return ap.parse_args()
 
 
