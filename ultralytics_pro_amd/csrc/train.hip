@@ -361,25 +361,187 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
         }
 }
 
-// dW[co][ci][t] (+)= sum over the workgroups of a block of their partial sums (fixed order: deterministic)
-__global__ void wgrad_reduce_kernel(const float* partial, int wgs, int bco, int bci, int BCO, int BCI, int kk2, float* dw, int Cout,
-                                    int Cin, int accumulate) {
+// ---- bf16 MFMA form of the weight gradient (3x3).  v_mfma_f32_16x16x32_bf16 wants 8 consecutive k (= pixels) per lane,
+// but both operands are pixel-major in memory.  gfx950's transposing LDS read closes the gap: ds_read_b64_tr_b16 hands
+// lane i of a 16-lane block element [row i/4 + 4j][column i%4] (j = 0..3) of the 16 x 4 block whose row r is the 8 bytes
+// lane r pointed at (probed on hardware: tools/experiments/ds_read_tr.hip).  Pointing lane r at
+// [pixel base + r/4][channels 4*(r%4)..+3] therefore leaves lane i with channel i of 4 consecutive pixels - half an MFMA
+// operand - straight out of a plain [pixel][channel] LDS image, so the tile is staged with ordinary 16-byte copies, the
+// tap shift is a pixel offset and stride 2 is a different per-lane address; nothing is transposed in software.
+// Workgroup = 3 waves; wave w takes kernel row kh = w (3 taps) of the whole 64 x 64 (co, ci) block: 48 MFMAs per
+// 32 ds_read_tr per 32-pixel step.  The next tile's global loads are in flight (in registers) while the current tile is
+// multiplied.  Partial blocks go through the same two-stage reduction as the f32 kernel.
+typedef short v4s16 __attribute__((ext_vector_type(4)));
+
+template <int S>
+__global__ __launch_bounds__(192) void wgrad_bf16_k3_kernel(const WgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) char wsm_b[];
+  constexpr int BCO = 64, BCI = 64;
+  constexpr int PZ = BCO * 2 + 32, PX = BCI * 2 + 32;       // LDS pixel pitch (bytes): +32 spreads 4 rows over the banks
+  constexpr int TW = 16;
+  constexpr int NTHR = 192;
+  const int TH = p.TH, IH = p.IH, IW = p.IW;
+  const int npx = TH * TW, nhx = IH * IW;
+  char* zt = wsm_b;
+  char* xt = wsm_b + (size_t)npx * PZ;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int kh = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kg = lane >> 4, r16 = lane & 15;
+  const int co0 = blockIdx.y * BCO, ci0 = blockIdx.z * BCI;
+  const int tilesPerImg = p.tilesX * p.tilesY;
+  f32x4 acc[3][4][4];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // staging: chunk c (16 bytes = 8 channels of one pixel) of the dz tile then of the x halo; thread takes c = tid + q*192
+  constexpr int MAXQ = 16;  // (128 + 180) or (64 + 297) pixels * 8 chunks / 192 threads
+  const int nchunk = (npx + nhx) * 8;
+  u32x4 stg[MAXQ];
+  auto fetch = [&](int tile) __attribute__((always_inline)) {
+    const int n = tile / tilesPerImg;
+    const int t2 = tile - n * tilesPerImg;
+    const int tyi = t2 / p.tilesX, txi = t2 - tyi * p.tilesX;
+    const int oy0 = tyi * TH, ox0 = txi * TW;
+    const int iy0 = oy0 * S - p.pad, ix0 = ox0 * S - p.pad;
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+      const int c = tid + q * NTHR;
+      u32x4 v = u32x4{0u, 0u, 0u, 0u};
+      if (c < nchunk) {
+        const int px = c >> 3, g = c & 7;
+        if (px < npx) {
+          const int ty = px >> 4, tx = px & 15;
+          const int oy = oy0 + ty, ox = ox0 + tx, co = co0 + g * 8;
+          if (oy < p.OH && ox < p.OW && co < p.Cout)
+            v = *reinterpret_cast<const u32x4*>(p.dz + ((((size_t)n * p.OH + oy) * p.OW + ox) * p.lddz + co) * 2);
+        } else {
+          const int hp = px - npx;
+          const int py = hp / IW, pxx = hp - py * IW;
+          const int iy = iy0 + py, ix = ix0 + pxx, ci = ci0 + g * 8;
+          if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && ci < p.Cin)
+            v = *reinterpret_cast<const u32x4*>(p.x + ((((size_t)n * p.H + iy) * p.W + ix) * p.ldx + ci) * 2);
+        }
+      }
+      stg[q] = v;
+    }
+  };
+  auto commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+      const int c = tid + q * NTHR;
+      if (c < nchunk) {
+        const int px = c >> 3, g = c & 7;
+        char* dst = px < npx ? zt + px * PZ + g * 16 : xt + (px - npx) * PX + g * 16;
+        *reinterpret_cast<u32x4*>(dst) = stg[q];
+      }
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < p.numTiles) fetch(tile);
+  for (; tile < p.numTiles; tile += gridDim.x) {
+    __syncthreads();  // everyone is done reading the previous tile
+    commit();
+    __syncthreads();
+    const int next = tile + gridDim.x;
+    if (next < p.numTiles) fetch(next);  // in flight during the MFMAs below
+    const int ksteps = npx >> 5;
+    for (int ks = 0; ks < ksteps; ++ks) {
+      // the two 4-pixel halves of this lane block's 8 pixels
+      int zoff[2], xoff[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int px = ks * 32 + kg * 8 + h * 4 + (r16 >> 2);
+        const int ty = px >> 4, tx = px & 15;
+        zoff[h] = px * PZ + (r16 & 3) * 8;
+        xoff[h] = ((ty * S + kh) * IW + tx * S) * PX + (r16 & 3) * 8;
+      }
+      u32x4 a[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(zt + zoff[0] + i * 32));
+        const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(zt + zoff[1] + i * 32));
+        a[i] = u32x4{((const unsigned*)&lo)[0], ((const unsigned*)&lo)[1], ((const unsigned*)&hi)[0], ((const unsigned*)&hi)[1]};
+      }
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        u32x4 b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) v4s16*)(xt + xoff[0] + kw * PX + j * 32));
+          const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) v4s16*)(xt + xoff[1] + kw * PX + j * 32));
+          b[j] = u32x4{((const unsigned*)&lo)[0], ((const unsigned*)&lo)[1], ((const unsigned*)&hi)[0], ((const unsigned*)&hi)[1]};
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[kw][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&a[i]), *reinterpret_cast<bf16x8*>(&b[j]),
+                                                                    acc[kw][i][j], 0, 0, 0);
+      }
+    }
+  }
+  // flush this wave's three taps of the 64 x 64 block: D[row = co][col = ci], lane holds rows 4*kg..+3 of column r16
+  float* part = p.partial + ((((size_t)blockIdx.y * gridDim.z + blockIdx.z) * gridDim.x + blockIdx.x) * 9) * (BCO * BCI);
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          part[((size_t)(kh * 3 + kw) * BCO + i * 16 + kg * 4 + r) * BCI + j * 16 + r16] = acc[kw][i][j][r];
+}
+
+// dW[co][ci][t] (+)= sum over the workgroups of a block of their partial sums (fixed order: deterministic).
+// Block = 16 consecutive elements x 16 slices of the workgroup axis: a thread adds its slice with 8 independent loads in
+// flight (the one-thread-per-element form ran 512 dependent-latency loads per thread: 120 us for 75 MB), the slices
+// meet in LDS.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial, int wgs, int bco, int bci, int BCO, int BCI, int kk2,
+                                                           float* dw, int Cout, int Cin, int accumulate) {
+  __shared__ float red[16][17];
   const long per_wg = (long)kk2 * BCO * BCI;
   const long total = (long)bco * bci * per_wg;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+  const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  for (long base = (long)blockIdx.x * 16; base < total; base += (long)gridDim.x * 16) {
+    const long idx = base + e;  // BCI is a multiple of 16: the 16 elements share (block, tap, co row)
     long t_ = idx;
     const int cil = (int)(t_ % BCI); t_ /= BCI;
     const int col = (int)(t_ % BCO); t_ /= BCO;
     const int t = (int)(t_ % kk2); t_ /= kk2;
     const int bz = (int)(t_ % bci);
     const int by = (int)(t_ / bci);
-    const int co = by * BCO + col, ci = bz * BCI + cil;
-    if (co >= Cout || ci >= Cin) continue;
     const float* src = partial + (((size_t)by * bci + bz) * wgs) * per_wg + ((size_t)t * BCO + col) * BCI + cil;
+    const int per = (wgs + 15) / 16;
+    const int w0 = sl * per, w1 = (w0 + per < wgs) ? w0 + per : wgs;
     float s = 0.f;
-    for (int w = 0; w < wgs; ++w) s += src[(size_t)w * per_wg];
-    float* d = dw + ((size_t)co * Cin + ci) * kk2 + t;
-    *d = accumulate ? *d + s : s;
+    int w = w0;
+    for (; w + 8 <= w1; w += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(w + u) * per_wg];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; w < w1; ++w) s += src[(size_t)w * per_wg];
+    red[sl][e] = s;
+    __syncthreads();
+    if (sl == 0) {
+      float tot = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) tot += red[q][e];
+      const int co = by * BCO + col, ci = bz * BCI + cil;
+      if (co < Cout && ci < Cin) {
+        float* d = dw + ((size_t)co * Cin + ci) * kk2 + t;
+        *d = accumulate ? *d + tot : tot;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -735,7 +897,7 @@ static int launch_wgrad(WgradParams& p, int accumulate, void* ws, size_t ws_byte
   } else { upa_set_error("wgrad: kernel size %d not built (1 and 3 are)", p.KS); return UPA_EUNSUPPORTED; }
 #undef UPA_WG_LAUNCH
   const long total = (long)bco * bci * p.KS * p.KS * BCO * BCI;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(total)), dim3(256), 0, s, p.partial, wgs, bco, bci, BCO, BCI, p.KS * p.KS,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(total, 16, 8192)), dim3(256), 0, s, p.partial, wgs, bco, bci, BCO, BCI, p.KS * p.KS,
                      p.dw, p.Cout, p.Cin, accumulate);
   UPA_LAUNCH_CHECK();
   return UPA_OK;
@@ -743,10 +905,43 @@ static int launch_wgrad(WgradParams& p, int accumulate, void* ws, size_t ws_byte
 
 static bool wgrad_small(int cin, int cout) { return cin <= 32 || cout <= 32; }
 
+static int launch_wgrad_bf16_k3(WgradParams& p, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
+  constexpr int BCO = 64, BCI = 64, PZ = 160, PX = 160;
+  p.TW = 16;
+  p.TH = p.stride == 1 ? 8 : 4;
+  p.tilesX = cdiv(p.OW, p.TW); p.tilesY = cdiv(p.OH, p.TH);
+  p.numTiles = p.tilesX * p.tilesY * p.N;
+  p.IH = (p.TH - 1) * p.stride + 3; p.IW = (p.TW - 1) * p.stride + 3;
+  const int bco = cdiv(p.Cout, BCO), bci = cdiv(p.Cin, BCI);
+  int wgs = 512 / (bco * bci);  // two 3-wave workgroups per CU
+  if (wgs < 1) wgs = 1;
+  if (wgs > p.numTiles) wgs = p.numTiles;
+  const size_t need = wgrad_partial_bytes(bco, bci, wgs, BCO, BCI, 3);
+  UPA_CHECK_ARG(ws && ws_bytes >= need, "wgrad: workspace too small (%zu < %zu bytes)", ws_bytes, need);
+  p.partial = (float*)ws;
+  const size_t lds = (size_t)p.TH * p.TW * PZ + (size_t)p.IH * p.IW * PX;
+  UPA_CHECK_ARG((p.TH * p.TW + p.IH * p.IW) * 8 <= 16 * 192, "wgrad: staging registers too few for this tile");
+  dim3 grid(wgs, bco, bci);
+  if (p.stride == 1) {
+    auto kern = wgrad_bf16_k3_kernel<1>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, grid, dim3(192), lds, s, p);
+  } else {
+    auto kern = wgrad_bf16_k3_kernel<2>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, grid, dim3(192), lds, s, p);
+  }
+  const long total = (long)bco * bci * 9 * BCO * BCI;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(total, 16, 8192)), dim3(256), 0, s, p.partial, wgs, bco, bci, BCO, BCI, 9, p.dw,
+                     p.Cout, p.Cin, accumulate);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
 extern "C" size_t upa_conv2d_wgrad_workspace_bytes(int cin, int cout, int k) {
   const int B = (k == 1 && cin >= 128 && cout >= 128) ? 128 : (wgrad_small(cin, cout) ? 32 : 64);
   const int bco = cdiv(cout, B), bci = cdiv(cin, B);
-  int wgs = 256 / (bco * bci);
+  int wgs = (k == 3 && B == 64 ? 512 : 256) / (bco * bci);  // the bf16 3x3 kernel runs two workgroups per CU
   if (wgs < 1) wgs = 1;
   return wgrad_partial_bytes(bco, bci, wgs, B, B, k);
 }
@@ -766,6 +961,9 @@ extern "C" int upa_conv2d_wgrad(const void* x, int n, int h, int w, int cin, int
   p.OH = (h + 2 * pad - k) / stride + 1; p.OW = (w + 2 * pad - k) / stride + 1;
   p.KS = k; p.stride = stride; p.pad = pad;
   const bool small = wgrad_small(cin, cout);
+  static const bool no_bf16_mfma = getenv("UPA_WGRAD_F32_MFMA") != nullptr;
+  if (dtype == UPA_BF16 && k == 3 && !small && !no_bf16_mfma && cin % 8 == 0)
+    return launch_wgrad_bf16_k3(p, accumulate, workspace, workspace_bytes, s);
   if (k == 1 && cin >= 128 && cout >= 128) {  // pointwise = plain GEMM over the pixels: 128 x 128 blocks
     return dtype == UPA_BF16 ? launch_wgrad<bf16_t, 4, 4>(p, accumulate, workspace, workspace_bytes, s)
                              : launch_wgrad<float, 4, 4>(p, accumulate, workspace, workspace_bytes, s);
