@@ -150,21 +150,25 @@ int upa_scale_boxes(float* rows, long n, int row_stride, float gain, float pad_x
  * upa_conv2d_bias_act(dz, V, pad = k-1-p) (a stride-2 conv first goes through upa_dilate2x). */
 int upa_pack_conv_weight_dev(const float* w_oihw, int cout, int cin, int k, int dtype, int transpose_flip, void* out,
                              void* stream);
-/* Batch statistics: sum / sumsq (f64, c each) over npix rows, then mean / biased var + nn.BatchNorm2d running update
- * (running_var takes the unbiased estimate; running_* may be NULL). */
-int upa_bn_stats(const void* z, long npix, int c, int ldz, double* sum, double* sumsq, int dtype, void* stream);
-int upa_bn_finalize(const double* sum, const double* sumsq, long npix, int c, float momentum, float* mean, float* var,
-                    float* running_mean, float* running_var, void* stream);
+/* Per-channel reductions run in two stages without atomics: per-block f64 partial sums, then a fixed-order combine.
+ * `ws` = upa_channel_reduce_workspace_bytes(c) bytes of scratch shared by upa_bn_stats / upa_bn_finalize (which must
+ * follow each other on one stream), upa_bn_act_bwd and upa_channel_sum.
+ * Batch statistics -> mean / biased var + nn.BatchNorm2d running update (running_var takes the unbiased estimate;
+ * running_* may be NULL). */
+size_t upa_channel_reduce_workspace_bytes(int c);
+int upa_bn_stats(const void* z, long npix, int c, int ldz, double* ws, int dtype, void* stream);
+int upa_bn_finalize(const double* ws, long npix, int c, float momentum, float* mean, float* var, float* running_mean,
+                    float* running_var, void* stream);
 /* y = act(gamma * (z - mean) / sqrt(var + eps) + beta) (+ residual) */
 int upa_bn_act_fwd(const void* z, long npix, int c, int ldz, const float* mean, const float* var, const float* gamma,
                    const float* beta, float eps, int act, void* y, int ldy, const void* residual, int ldr, int dtype,
                    void* stream);
 /* Backward of the above (z saved from the forward): dgamma, dbeta (f32, optionally accumulated) and dz.
- * ws: 2*c doubles of scratch. */
+ * ws: upa_channel_reduce_workspace_bytes(c). */
 int upa_bn_act_bwd(const void* z, const void* dy, long npix, int c, int ldz, int lddy, const float* mean, const float* var,
                    const float* gamma, const float* beta, float eps, int act, void* dz, int lddz, float* dgamma, float* dbeta,
                    int accumulate, double* ws, int dtype, void* stream);
-/* out[c] (+)= sum over rows of z[:, c]  (bias gradient of the plain nn.Conv2d head outputs). ws: 2*c doubles. */
+/* out[c] (+)= sum over rows of z[:, c]  (bias gradient of the plain nn.Conv2d head outputs). ws as above. */
 int upa_channel_sum(const void* z, long npix, int c, int ldz, float* out, int accumulate, double* ws, int dtype, void* stream);
 /* dW[co][ci][kh][kw] (OIHW f32, optionally accumulated) = sum_{n,oy,ox} dz[n,oy,ox,co] * x[n,oy*s+kh-p,ox*s+kw-p,ci]
  * on exact-f32 MFMA; k in {1, 3}.  Workgroups store partial blocks into the caller's workspace and a second kernel sums

@@ -30,6 +30,8 @@ CONV_TRAIN_CASES = [
     (48, 80, 3, 1, 1, 9, 13),
     (128, 64, 3, 2, 2, 13, 11),
     (80, 144, 1, 1, 2, 8, 8),
+    (256, 128, 1, 1, 3, 9, 11),   # pointwise bf16 MFMA weight gradient: 2 x 1 blocks of 128, ragged pixel count
+    (192, 136, 1, 1, 1, 16, 16),  # channel counts that are not multiples of the 128 block
 ]
 
 

@@ -57,8 +57,9 @@ PROTOTYPES = {
     "upa_box_iou": (_i, [_vp, _i, _vp, _i, _f, _vp, _vp]),
     "upa_scale_boxes": (_i, [_vp, C.c_long, _i, _f, _f, _f, _i, _f, _f, _vp]),
     "upa_pack_conv_weight_dev": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
-    "upa_bn_stats": (_i, [_vp, C.c_long, _i, _i, _vp, _vp, _i, _vp]),
-    "upa_bn_finalize": (_i, [_vp, _vp, C.c_long, _i, _f, _vp, _vp, _vp, _vp, _vp]),
+    "upa_channel_reduce_workspace_bytes": (_sz, [_i]),
+    "upa_bn_stats": (_i, [_vp, C.c_long, _i, _i, _vp, _i, _vp]),
+    "upa_bn_finalize": (_i, [_vp, C.c_long, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "upa_bn_act_fwd": (_i, [_vp, C.c_long, _i, _i, _vp, _vp, _vp, _vp, _f, _i, _vp, _i, _vp, _i, _i, _vp]),
     "upa_bn_act_bwd": (_i, [_vp, _vp, C.c_long, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp]),
     "upa_channel_sum": (_i, [_vp, C.c_long, _i, _i, _vp, _i, _vp, _i, _vp]),

@@ -163,10 +163,28 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(const ReduceParams 
     }
   }
   __syncthreads();
+  // per-block partial sums, plain stores: [block][2][c] (a second kernel adds the blocks in a fixed order - with f64
+  // atomics every extra block made the contention on the c addresses worse: 2048 blocks were the optimum at 1.2 TB/s)
+  double* part = p.out0 + (size_t)blockIdx.x * 2 * p.c;
   for (int i = tid; i < p.c; i += 256) {
-    atomicAdd(&p.out0[i], red[i]);
-    if (MODE != 2) atomicAdd(&p.out1[i], red[p.c + i]);
+    part[i] = red[i];
+    part[p.c + i] = MODE != 2 ? red[p.c + i] : 0.0;
   }
+}
+
+// out[which][ch] = sum over blocks of part[block][which][ch]; one workgroup per (which, ch)
+__global__ __launch_bounds__(256) void combine_partials_kernel(const double* part, int nblocks, int c, double* out) {
+  __shared__ double red[256];
+  const int idx = blockIdx.x;  // which * c + ch
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += 256) s += part[(size_t)b * 2 * c + idx];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[idx] = red[0];
 }
 
 __global__ void bn_finalize_kernel(const double* sum, const double* sumsq, long npix, int c, float momentum, float* mean,
@@ -498,6 +516,100 @@ __global__ __launch_bounds__(192) void wgrad_bf16_k3_kernel(const WgradParams p)
           part[((size_t)(kh * 3 + kw) * BCO + i * 16 + kg * 4 + r) * BCI + j * 16 + r16] = acc[kw][i][j][r];
 }
 
+// Pointwise (1x1, stride 1) form: dW[co][ci] = sum over pixels dz[p][co] * x[p][ci], a plain GEMM with the pixel axis as K.
+// 128 x 128 (co, ci) block per workgroup, 4 waves = 4 quadrants of 4 x 4 MFMA tiles, 128-pixel tiles, same transposing
+// LDS reads and register prefetch as above.
+__global__ __launch_bounds__(256) void wgrad_bf16_k1_kernel(const WgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) char wsm_c[];
+  constexpr int BCO = 128, BCI = 128;
+  constexpr int PZ = BCO * 2 + 32, PX = BCI * 2 + 32;
+  constexpr int NPX = 128;
+  constexpr int NTHR = 256;
+  char* zt = wsm_c;
+  char* xt = wsm_c + (size_t)NPX * PZ;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int kg = lane >> 4, r16 = lane & 15;
+  const int co0 = blockIdx.y * BCO, ci0 = blockIdx.z * BCI;
+  const long P = (long)p.N * p.H * p.W;  // pixels (views have a uniform pixel stride)
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int MAXQ = 16;  // 128 pixels * 16 chunks * 2 operands / 256 threads
+  u32x4 stg[MAXQ];
+  auto fetch = [&](long tile) __attribute__((always_inline)) {
+    const long p0 = tile * NPX;
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+      const int c = tid + q * NTHR;       // [operand][pixel][16 chunks]
+      const int op = c >> 11, px = (c >> 4) & 127, g = c & 15;
+      u32x4 v = u32x4{0u, 0u, 0u, 0u};
+      const long pp = p0 + px;
+      if (pp < P) {
+        if (op == 0) {
+          if (co0 + g * 8 < p.Cout) v = *reinterpret_cast<const u32x4*>(p.dz + ((size_t)pp * p.lddz + co0 + g * 8) * 2);
+        } else {
+          if (ci0 + g * 8 < p.Cin) v = *reinterpret_cast<const u32x4*>(p.x + ((size_t)pp * p.ldx + ci0 + g * 8) * 2);
+        }
+      }
+      stg[q] = v;
+    }
+  };
+  auto commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+      const int c = tid + q * NTHR;
+      const int op = c >> 11, px = (c >> 4) & 127, g = c & 15;
+      *reinterpret_cast<u32x4*>((op == 0 ? zt + px * PZ : xt + px * PX) + g * 16) = stg[q];
+    }
+  };
+  const long ntiles = (P + NPX - 1) / NPX;
+  long tile = blockIdx.x;
+  if (tile < ntiles) fetch(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
+#pragma unroll
+    for (int ks = 0; ks < NPX / 32; ++ks) {
+      int off[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) off[h] = (ks * 32 + kg * 8 + h * 4 + (r16 >> 2)) * PZ + (r16 & 3) * 8;
+      u32x4 a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(zt + off[0] + (wm * 4 + i) * 32));
+        const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(zt + off[1] + (wm * 4 + i) * 32));
+        a[i] = u32x4{((const unsigned*)&lo)[0], ((const unsigned*)&lo)[1], ((const unsigned*)&hi)[0], ((const unsigned*)&hi)[1]};
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(xt + off[0] + (wn * 4 + j) * 32));
+        const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(xt + off[1] + (wn * 4 + j) * 32));
+        b[j] = u32x4{((const unsigned*)&lo)[0], ((const unsigned*)&lo)[1], ((const unsigned*)&hi)[0], ((const unsigned*)&hi)[1]};
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&a[i]), *reinterpret_cast<bf16x8*>(&b[j]),
+                                                              acc[i][j], 0, 0, 0);
+    }
+  }
+  float* part = p.partial + (((size_t)blockIdx.y * gridDim.z + blockIdx.z) * gridDim.x + blockIdx.x) * (BCO * BCI);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        part[(size_t)((wm * 4 + i) * 16 + kg * 4 + r) * BCI + (wn * 4 + j) * 16 + r16] = acc[i][j][r];
+}
+
 // dW[co][ci][t] (+)= sum over the workgroups of a block of their partial sums (fixed order: deterministic).
 // Block = 16 consecutive elements x 16 slices of the workgroup axis: a thread adds its slice with 8 independent loads in
 // flight (the one-thread-per-element form ran 512 dependent-latency loads per thread: 120 us for 75 MB), the slices
@@ -742,6 +854,13 @@ __global__ void cast_view_kernel(const char* src, int lds_, char* dst, int ldd, 
   }
 }
 
+int grid_for(long total, int per_block, int cap);
+int reduce_grid(long npix) {
+  static const int ppb = getenv("UPA_RED_PPB") ? atoi(getenv("UPA_RED_PPB")) : 64;
+  static const int cap = getenv("UPA_RED_CAP") ? atoi(getenv("UPA_RED_CAP")) : 2048;
+  return grid_for(npix, ppb, cap < 2048 ? cap : 2048);  // the workspace holds 2048 block partials
+}
+
 int grid_for(long total, int per_block = 256, int cap = 256 * 16) {
   long g = (total + per_block - 1) / per_block;
   if (g > cap) g = cap;
@@ -770,26 +889,43 @@ static int check_view(long npix, int c, int ld, int dtype, const char* what) {
   return UPA_OK;
 }
 
-extern "C" int upa_bn_stats(const void* z, long npix, int c, int ldz, double* sum, double* sumsq, int dtype, void* stream) {
-  UPA_CHECK_ARG(z && sum && sumsq, "bn_stats: null pointer");
+extern "C" size_t upa_channel_reduce_workspace_bytes(int c) {
+  return (size_t)(2048 + 1) * 2 * c * sizeof(double);  // per-block partials + the combined sums
+}
+
+static int run_channel_reduce(ReduceParams& r, int mode, int dtype, double* ws, hipStream_t s) {
+  const int grid = reduce_grid(r.npix);
+  r.out0 = ws; r.out1 = nullptr;
+  const size_t lds = 2 * r.c * sizeof(double);
+#define UPA_RED(MODE_)                                                                                               \
+  do {                                                                                                               \
+    if (dtype == UPA_BF16) hipLaunchKernelGGL((channel_reduce_kernel<bf16_t, MODE_>), dim3(grid), dim3(256), lds, s, r); \
+    else hipLaunchKernelGGL((channel_reduce_kernel<float, MODE_>), dim3(grid), dim3(256), lds, s, r);               \
+  } while (0)
+  if (mode == 0) UPA_RED(0);
+  else if (mode == 1) UPA_RED(1);
+  else UPA_RED(2);
+#undef UPA_RED
+  double* fin = ws + (size_t)2048 * 2 * r.c;
+  hipLaunchKernelGGL(combine_partials_kernel, dim3(2 * r.c), dim3(256), 0, s, ws, grid, r.c, fin);
+  return UPA_OK;
+}
+
+extern "C" int upa_bn_stats(const void* z, long npix, int c, int ldz, double* ws, int dtype, void* stream) {
+  UPA_CHECK_ARG(z && ws, "bn_stats: null pointer");
   if (int rc = check_view(npix, c, ldz, dtype, "bn_stats")) return rc;
-  hipStream_t s = (hipStream_t)stream;
-  (void)hipMemsetAsync(sum, 0, sizeof(double) * c, s);
-  (void)hipMemsetAsync(sumsq, 0, sizeof(double) * c, s);
   ReduceParams p{};
-  p.z = (const char*)z; p.npix = npix; p.c = c; p.ldz = ldz; p.out0 = sum; p.out1 = sumsq;
-  const int grid = grid_for(npix, 64, 2048);
-  const size_t lds = 2 * c * sizeof(double);
-  if (dtype == UPA_BF16) hipLaunchKernelGGL((channel_reduce_kernel<bf16_t, 0>), dim3(grid), dim3(256), lds, s, p);
-  else hipLaunchKernelGGL((channel_reduce_kernel<float, 0>), dim3(grid), dim3(256), lds, s, p);
+  p.z = (const char*)z; p.npix = npix; p.c = c; p.ldz = ldz;
+  run_channel_reduce(p, 0, dtype, ws, (hipStream_t)stream);
   UPA_LAUNCH_CHECK();
   return UPA_OK;
 }
 
-extern "C" int upa_bn_finalize(const double* sum, const double* sumsq, long npix, int c, float momentum, float* mean, float* var,
+extern "C" int upa_bn_finalize(const double* ws, long npix, int c, float momentum, float* mean, float* var,
                                float* running_mean, float* running_var, void* stream) {
-  UPA_CHECK_ARG(sum && sumsq && mean && var && npix > 0, "bn_finalize: bad args");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, sum, sumsq, npix, c, momentum,
+  UPA_CHECK_ARG(ws && mean && var && npix > 0, "bn_finalize: bad args");
+  const double* fin = ws + (size_t)2048 * 2 * c;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, fin, fin + c, npix, c, momentum,
                      mean, var, running_mean, running_var);
   UPA_LAUNCH_CHECK();
   return UPA_OK;
@@ -819,18 +955,15 @@ extern "C" int upa_bn_act_bwd(const void* z, const void* dy, long npix, int c, i
   UPA_CHECK_ARG(act == UPA_ACT_SILU || act == UPA_ACT_NONE, "bn_act_bwd: activation must be SiLU or none");
   if (int rc = check_view(npix, c, ldz, dtype, "bn_act_bwd")) return rc;
   hipStream_t s = (hipStream_t)stream;
-  (void)hipMemsetAsync(ws, 0, sizeof(double) * 2 * c, s);
   ReduceParams r{};
   r.z = (const char*)z; r.dy = (const char*)dy; r.npix = npix; r.c = c; r.ldz = ldz; r.lddy = lddy;
-  r.mean = mean; r.var = var; r.gamma = gamma; r.beta = beta; r.eps = eps; r.act = act; r.out0 = ws; r.out1 = ws + c;
-  const int grid = grid_for(npix, 64, 2048);
-  const size_t lds = 2 * c * sizeof(double);
-  if (dtype == UPA_BF16) hipLaunchKernelGGL((channel_reduce_kernel<bf16_t, 1>), dim3(grid), dim3(256), lds, s, r);
-  else hipLaunchKernelGGL((channel_reduce_kernel<float, 1>), dim3(grid), dim3(256), lds, s, r);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, s, ws, ws + c, c, dgamma, dbeta, accumulate);
+  r.mean = mean; r.var = var; r.gamma = gamma; r.beta = beta; r.eps = eps; r.act = act;
+  run_channel_reduce(r, 1, dtype, ws, s);
+  double* fin = ws + (size_t)2048 * 2 * c;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, s, fin, fin + c, c, dgamma, dbeta, accumulate);
   BnApplyParams p{};
   p.z = (const char*)z; p.y = (char*)dz; p.aux = (const char*)dy; p.npix = npix; p.c = c; p.ldz = ldz; p.ldy = lddz; p.ldaux = lddy;
-  p.mean = mean; p.var = var; p.gamma = gamma; p.beta = beta; p.s0 = ws; p.s1 = ws + c; p.eps = eps; p.act = act;
+  p.mean = mean; p.var = var; p.gamma = gamma; p.beta = beta; p.s0 = fin; p.s1 = fin + c; p.eps = eps; p.act = act;
   const int E = 16 / upa_elem_size(dtype);
   const int grid2 = grid_for(npix, 256 / (c / E) * 4, 256 * 16);
   if (dtype == UPA_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, true>), dim3(grid2), dim3(256), 0, s, p);
@@ -844,13 +977,10 @@ extern "C" int upa_channel_sum(const void* z, long npix, int c, int ldz, float* 
   UPA_CHECK_ARG(z && out && ws, "channel_sum: null pointer");
   if (int rc = check_view(npix, c, ldz, dtype, "channel_sum")) return rc;
   hipStream_t s = (hipStream_t)stream;
-  (void)hipMemsetAsync(ws, 0, sizeof(double) * 2 * c, s);
   ReduceParams r{};
-  r.z = (const char*)z; r.npix = npix; r.c = c; r.ldz = ldz; r.out0 = ws; r.out1 = ws + c;
-  const int grid = grid_for(npix, 64, 2048);
-  if (dtype == UPA_BF16) hipLaunchKernelGGL((channel_reduce_kernel<bf16_t, 2>), dim3(grid), dim3(256), 2 * c * sizeof(double), s, r);
-  else hipLaunchKernelGGL((channel_reduce_kernel<float, 2>), dim3(grid), dim3(256), 2 * c * sizeof(double), s, r);
-  hipLaunchKernelGGL(sum_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, s, ws, c, out, accumulate);
+  r.z = (const char*)z; r.npix = npix; r.c = c; r.ldz = ldz;
+  run_channel_reduce(r, 2, dtype, ws, s);
+  hipLaunchKernelGGL(sum_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, s, ws + (size_t)2048 * 2 * c, c, out, accumulate);
   UPA_LAUNCH_CHECK();
   return UPA_OK;
 }
@@ -905,6 +1035,28 @@ static int launch_wgrad(WgradParams& p, int accumulate, void* ws, size_t ws_byte
 
 static bool wgrad_small(int cin, int cout) { return cin <= 32 || cout <= 32; }
 
+static int launch_wgrad_bf16_k1(WgradParams& p, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
+  constexpr int BCO = 128, BCI = 128;
+  const long P = (long)p.N * p.H * p.W;
+  const long ntiles = (P + 127) / 128;
+  const int bco = cdiv(p.Cout, BCO), bci = cdiv(p.Cin, BCI);
+  long wgs = 256 / (bco * bci);
+  if (wgs < 1) wgs = 1;
+  if (wgs > ntiles) wgs = ntiles;
+  const size_t need = wgrad_partial_bytes(bco, bci, (int)wgs, BCO, BCI, 1);
+  UPA_CHECK_ARG(ws && ws_bytes >= need, "wgrad: workspace too small (%zu < %zu bytes)", ws_bytes, need);
+  p.partial = (float*)ws;
+  const size_t lds = (size_t)128 * (BCO * 2 + 32) + (size_t)128 * (BCI * 2 + 32);
+  auto kern = wgrad_bf16_k1_kernel;
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, dim3((unsigned)wgs, bco, bci), dim3(256), lds, s, p);
+  const long total = (long)bco * bci * BCO * BCI;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(total, 16, 8192)), dim3(256), 0, s, p.partial, (int)wgs, bco, bci, BCO, BCI, 1, p.dw,
+                     p.Cout, p.Cin, accumulate);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
 static int launch_wgrad_bf16_k3(WgradParams& p, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
   constexpr int BCO = 64, BCI = 64, PZ = 160, PX = 160;
   p.TW = 16;
@@ -939,11 +1091,19 @@ static int launch_wgrad_bf16_k3(WgradParams& p, int accumulate, void* ws, size_t
 }
 
 extern "C" size_t upa_conv2d_wgrad_workspace_bytes(int cin, int cout, int k) {
-  const int B = (k == 1 && cin >= 128 && cout >= 128) ? 128 : (wgrad_small(cin, cout) ? 32 : 64);
-  const int bco = cdiv(cout, B), bci = cdiv(cin, B);
-  int wgs = (k == 3 && B == 64 ? 512 : 256) / (bco * bci);  // the bf16 3x3 kernel runs two workgroups per CU
-  if (wgs < 1) wgs = 1;
-  return wgrad_partial_bytes(bco, bci, wgs, B, B, k);
+  // upper bound over the kernels the dispatcher may pick (f32 32/64/128 blocks with <= 256 workgroups, bf16 3x3 64-blocks
+  // with <= 512, bf16 pointwise 128-blocks with <= 256)
+  size_t best = 0;
+  const int Bs[3] = {32, 64, 128};
+  for (int b = 0; b < 3; ++b) {
+    const int B = Bs[b];
+    const int bco = cdiv(cout, B), bci = cdiv(cin, B);
+    int wgs = (k == 3 && B == 64 ? 512 : 256) / (bco * bci);
+    if (wgs < 1) wgs = 1;
+    const size_t n = wgrad_partial_bytes(bco, bci, wgs, B, B, k);
+    if (n > best) best = n;
+  }
+  return best;
 }
 
 extern "C" int upa_conv2d_wgrad(const void* x, int n, int h, int w, int cin, int ldx, const void* dz, int cout, int lddz,
@@ -962,8 +1122,10 @@ extern "C" int upa_conv2d_wgrad(const void* x, int n, int h, int w, int cin, int
   p.KS = k; p.stride = stride; p.pad = pad;
   const bool small = wgrad_small(cin, cout);
   static const bool no_bf16_mfma = getenv("UPA_WGRAD_F32_MFMA") != nullptr;
-  if (dtype == UPA_BF16 && k == 3 && !small && !no_bf16_mfma && cin % 8 == 0)
+  if (dtype == UPA_BF16 && k == 3 && cin >= 16 && cout >= 16 && !no_bf16_mfma && cin % 8 == 0)
     return launch_wgrad_bf16_k3(p, accumulate, workspace, workspace_bytes, s);
+  if (dtype == UPA_BF16 && k == 1 && stride == 1 && pad == 0 && cin >= 32 && cout >= 32 && !no_bf16_mfma && cin % 8 == 0)
+    return launch_wgrad_bf16_k1(p, accumulate, workspace, workspace_bytes, s);
   if (k == 1 && cin >= 128 && cout >= 128) {  // pointwise = plain GEMM over the pixels: 128 x 128 blocks
     return dtype == UPA_BF16 ? launch_wgrad<bf16_t, 4, 4>(p, accumulate, workspace, workspace_bytes, s)
                              : launch_wgrad<float, 4, 4>(p, accumulate, workspace, workspace_bytes, s);

@@ -48,7 +48,8 @@ class _Ctx:
         self.code = L.dtype_code(dtype)
         self.es = 2 if dtype == torch.bfloat16 else 4
         self.E = 16 // self.es
-        self.ws = torch.zeros(4 * 2048, dtype=torch.float64, device=device)  # channel-reduction scratch (c <= 2048)
+        # channel-reduction scratch (per-block partial sums + combined sums), sized for c <= 1024
+        self.ws = torch.zeros(L.lib().upa_channel_reduce_workspace_bytes(1024) // 8, dtype=torch.float64, device=device)
         self.wgrad_ws = torch.empty(0, dtype=torch.uint8, device=device)  # weight-gradient partial sums (largest layer)
 
 
@@ -112,10 +113,9 @@ class ConvT:
         vz = R.view_of(z)
         npix = vz.n * vz.h * vz.w
         ws = c.ws
-        L.check(lib.upa_bn_stats(vz.ptr, npix, vz.c, vz.ld, ws.data_ptr(), ws.data_ptr() + 8 * self.cout, vz.dtype,
-                                 _s(c.device)), "bn_stats")
+        L.check(lib.upa_bn_stats(vz.ptr, npix, vz.c, vz.ld, ws.data_ptr(), vz.dtype, _s(c.device)), "bn_stats")
         bn = self.bn
-        L.check(lib.upa_bn_finalize(ws.data_ptr(), ws.data_ptr() + 8 * self.cout, npix, self.cout, float(bn.momentum),
+        L.check(lib.upa_bn_finalize(ws.data_ptr(), npix, self.cout, float(bn.momentum),
                                     self.mean.data_ptr(), self.var.data_ptr(), bn.running_mean.data_ptr(),
                                     bn.running_var.data_ptr(), _s(c.device)), "bn_finalize")
         y = out if out is not None else _new(n, self.cout, oh, ow, c.dtype, c.device, (id(self), "y"))
