@@ -189,10 +189,12 @@ int upa_maxpool2d_bwd(const void* x, const void* dy, int n, int h, int w, int c,
 /* *out (+)= sum g[i]^2 (f64): squared gradient norm for clip_grad_norm_. */
 int upa_sumsq(const float* g, long n, double* out, int accumulate, void* stream);
 /* clip_grad_norm_(max_norm) + SGD(nesterov, weight decay) + ModelEMA update over a flat parameter segment
- * (engine/trainer.py:674-682, :891-950; utils/torch_utils.py:632-646).  ema may be NULL. */
+ * (engine/trainer.py:674-682, :891-950; utils/torch_utils.py:632-646).  ema may be NULL.  ema_d_dev (nullable): device
+ * float that overrides ema_d - lets a captured hipGraph of the step read the per-step EMA decay. */
 int upa_sgd_nesterov_ema(float* p, float* g, float* momentum_buf, float* ema, long n, const double* grad_sumsq, float max_norm,
-                         float lr, float momentum, float weight_decay, int first_step, float ema_d, int zero_grad, void* stream);
-int upa_ema_update(float* ema, const float* v, long n, float d, void* stream);
+                         float lr, float momentum, float weight_decay, int first_step, float ema_d, const float* ema_d_dev,
+                         int zero_grad, void* stream);
+int upa_ema_update(float* ema, const float* v, long n, float d, const float* d_dev, void* stream);
 /* dst view = src view converted between f32 and bf16 (head maps enter the loss as f32; c, strides multiples of 8). */
 int upa_cast_view(const void* src, int src_dtype, int lds, void* dst, int dst_dtype, int ldd, long npix, int c, void* stream);
 /* v8DetectionLoss forward + gradient wrt the raw head maps.  feats[l] / grads[l]: NHWC f32 rows [(b,y,x)][4*reg_max+nc]

@@ -201,7 +201,7 @@ def test_sgd_nesterov_clip_ema_matches_torch():
         G_ = g.to(DEV)
         L.check(L.lib().upa_sumsq(G_.data_ptr(), n, sumsq.data_ptr(), 0, st))
         L.check(L.lib().upa_sgd_nesterov_ema(P_.data_ptr(), G_.data_ptr(), M_.data_ptr(), E_.data_ptr(), n, sumsq.data_ptr(), 10.0,
-                                             0.01, 0.9, 5e-4, int(step == 0), float(d), 1, st))
+                                             0.01, 0.9, 5e-4, int(step == 0), float(d), None, 1, st))
         assert float(G_.abs().max()) == 0.0
         assert float((P_.cpu() - pr.detach()).abs().max()) <= 2e-6
         assert float((E_.cpu() - ema_r).abs().max()) <= 2e-6
@@ -306,3 +306,37 @@ def test_training_step_yolov8n_matches_reference_golden(dtype, golden_dir):
             np.testing.assert_allclose(got, G[f"ema_sum_{step}"], rtol=1e-3, atol=1e-2)
     # bf16 bounds are statistical: 8 mantissa bits through ~60 layers with random weights move individual
     # TaskAlignedAssigner decisions, so single gradients differ by tens of percent while losses / norms stay within ~10 %
+
+
+def test_compiled_training_step_equals_eager():
+    """DetectionTrainer.compile(): the hipGraph replay of the step (static buffers, device-side EMA decay, labels uploaded
+    outside the graph) follows the eager step: same loss items per step and the same weights / EMA after four steps."""
+    from tests.hip_utils import DEV
+    from ultralytics_pro_amd.engine.trainer import DetectionTrainer
+    from ultralytics_pro_amd.nn.tasks import DetectionModel
+    bs, sz = 4, 192
+    runs = []
+    for compiled in (False, True):
+        m = DetectionModel("yolov8n.yaml")
+        P.apply_procedural_weights(m)
+        tr = DetectionTrainer(m, dtype=torch.bfloat16, device=DEV)
+        batches = [(P.synthetic_images(bs, h=sz, w=sz, seed=s).to(DEV), P.synthetic_labels(bs, seed=s)) for s in range(4)]
+        items = []
+        if compiled:
+            # two eager steps, then capture without further warm-up steps
+            items.append(tr.step(*batches[0]).cpu().clone())
+            items.append(tr.step(*batches[1]).cpu().clone())
+            tr.compile(*batches[1], warm_steps=0)
+            for b in batches[2:]:
+                items.append(tr.step(*b).cpu().clone())
+        else:
+            for b in batches:
+                items.append(tr.step(*b).cpu().clone())
+        torch.cuda.synchronize()
+        runs.append((items, m.state_dict()["model.0.conv.weight"].cpu().clone(), tr.E.cpu().clone(), tr.updates))
+    (ia, wa, ea, ua), (ib, wb, eb, ub) = runs
+    assert ua == ub == 4
+    for a, b in zip(ia, ib):
+        np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-5)
+    np.testing.assert_allclose(wa.numpy(), wb.numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(ea.numpy(), eb.numpy(), rtol=1e-5, atol=1e-7)

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--imgsz", type=int, default=640)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--eager", action="store_true", help="no hipGraph capture of the step")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     m = DetectionModel(a.model + ".yaml")
@@ -28,7 +29,11 @@ def main():
     tr = DetectionTrainer(m, dtype=torch.bfloat16 if a.dtype == "bf16" else torch.float32, device=dev)
     x = P.synthetic_images(a.batch, h=a.imgsz, w=a.imgsz).to(dev)
     lab = P.synthetic_labels(a.batch)
-    for _ in range(2):
+    if a.eager:
+        for _ in range(2):
+            items = tr.step(x, lab)
+    else:
+        tr.compile(x, lab)
         items = tr.step(x, lab)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -172,49 +172,51 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(const ReduceParams 
   }
 }
 
-// out[which][ch] = sum over blocks of part[block][which][ch]; one workgroup per (which, ch)
-__global__ __launch_bounds__(256) void combine_partials_kernel(const double* part, int nblocks, int c, double* out) {
-  __shared__ double red[256];
-  const int idx = blockIdx.x;  // which * c + ch
-  double s = 0.0;
-  for (int b = threadIdx.x; b < nblocks; b += 256) s += part[(size_t)b * 2 * c + idx];
-  red[threadIdx.x] = s;
+// Second stage: one workgroup per channel adds the block partials of both sums in a fixed order, then applies the
+// epilogue of the operation (MODE 0: batch statistics + running update; 1: dgamma / dbeta + the sums kept as f64 for the
+// dz pass; 2: bias gradient).
+struct CombineParams {
+  const double* part; int nblocks, c; double* fin;
+  long npix; float momentum; float* mean; float* var; float* running_mean; float* running_var;  // MODE 0
+  float* dgamma; float* dbeta; int accumulate;                                                   // MODE 1 / 2 (dbeta = out)
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void combine_finalize_kernel(const CombineParams p) {
+  __shared__ double red[2][256];
+  const int ch = blockIdx.x;
+  double s0 = 0.0, s1 = 0.0;
+  for (int b = threadIdx.x; b < p.nblocks; b += 256) {
+    const double* q = p.part + (size_t)b * 2 * p.c;
+    s0 += q[ch];
+    if (MODE != 2) s1 += q[p.c + ch];
+  }
+  red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[idx] = red[0];
-}
-
-__global__ void bn_finalize_kernel(const double* sum, const double* sumsq, long npix, int c, float momentum, float* mean,
-                                   float* var, float* running_mean, float* running_var) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= c) return;
-  const double m = sum[i] / (double)npix;
-  double v = sumsq[i] / (double)npix - m * m;
-  if (v < 0) v = 0;
-  mean[i] = (float)m;
-  var[i] = (float)v;
-  if (running_mean) {  // nn.BatchNorm2d: running_var takes the unbiased estimate
-    const double unb = npix > 1 ? v * (double)npix / (double)(npix - 1) : v;
-    running_mean[i] = (1.0f - momentum) * running_mean[i] + momentum * (float)m;
-    running_var[i] = (1.0f - momentum) * running_var[i] + momentum * (float)unb;
+  if (threadIdx.x != 0) return;
+  s0 = red[0][0]; s1 = red[1][0];
+  if (MODE == 0) {
+    const double m = s0 / (double)p.npix;
+    double v = s1 / (double)p.npix - m * m;
+    if (v < 0) v = 0;
+    p.mean[ch] = (float)m;
+    p.var[ch] = (float)v;
+    if (p.running_mean) {  // nn.BatchNorm2d: running_var takes the unbiased estimate
+      const double unb = p.npix > 1 ? v * (double)p.npix / (double)(p.npix - 1) : v;
+      p.running_mean[ch] = (1.0f - p.momentum) * p.running_mean[ch] + p.momentum * (float)m;
+      p.running_var[ch] = (1.0f - p.momentum) * p.running_var[ch] + p.momentum * (float)unb;
+    }
+  } else if (MODE == 1) {
+    p.fin[ch] = s0; p.fin[p.c + ch] = s1;
+    if (p.accumulate) { p.dbeta[ch] += (float)s0; p.dgamma[ch] += (float)s1; }
+    else { p.dbeta[ch] = (float)s0; p.dgamma[ch] = (float)s1; }
+  } else {
+    p.dbeta[ch] = p.accumulate ? p.dbeta[ch] + (float)s0 : (float)s0;
   }
-}
-
-__global__ void sum_finalize_kernel(const double* s0, int c, float* out, int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= c) return;
-  out[i] = accumulate ? out[i] + (float)s0[i] : (float)s0[i];
-}
-
-__global__ void bn_bwd_finalize_kernel(const double* s0, const double* s1, int c, float* dgamma, float* dbeta,
-                                       int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= c) return;
-  if (accumulate) { dbeta[i] += (float)s0[i]; dgamma[i] += (float)s1[i]; }
-  else { dbeta[i] = (float)s0[i]; dgamma[i] = (float)s1[i]; }
 }
 
 struct BnApplyParams {
@@ -807,7 +809,9 @@ __global__ void sumsq_kernel(const float* g, long n, double* out) {
 // torch.nn.utils.clip_grad_norm_ + torch.optim.SGD(nesterov) + ModelEMA.update over one flat parameter segment
 // (engine/trainer.py:674-682, utils/torch_utils.py:632-646).  sumsq = squared gradient norm of ALL parameters.
 __global__ void sgd_nesterov_ema_kernel(float* p, float* g, float* buf, float* ema, long n, const double* sumsq, float max_norm,
-                                        float lr, float momentum, float wd, int first_step, float ema_d, int zero_grad) {
+                                        float lr, float momentum, float wd, int first_step, float ema_d, const float* ema_d_dev,
+                                        int zero_grad) {
+  if (ema_d_dev) ema_d = *ema_d_dev;  // replayed graphs read the per-step decay from device memory
   const float total = (float)sqrt(*sumsq);
   float coef = max_norm / (total + 1e-6f);
   if (coef > 1.0f) coef = 1.0f;
@@ -829,7 +833,8 @@ __global__ void sgd_nesterov_ema_kernel(float* p, float* g, float* buf, float* e
   }
 }
 
-__global__ void ema_only_kernel(float* ema, const float* v, long n, float d) {
+__global__ void ema_only_kernel(float* ema, const float* v, long n, float d, const float* d_dev) {
+  if (d_dev) d = *d_dev;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     float e = ema[i] * d;
     ema[i] = e + (1.0f - d) * v[i];
@@ -906,9 +911,7 @@ static int run_channel_reduce(ReduceParams& r, int mode, int dtype, double* ws, 
   else if (mode == 1) UPA_RED(1);
   else UPA_RED(2);
 #undef UPA_RED
-  double* fin = ws + (size_t)2048 * 2 * r.c;
-  hipLaunchKernelGGL(combine_partials_kernel, dim3(2 * r.c), dim3(256), 0, s, ws, grid, r.c, fin);
-  return UPA_OK;
+  return grid;  // block partials are in ws[0 .. grid*2c)
 }
 
 extern "C" int upa_bn_stats(const void* z, long npix, int c, int ldz, double* ws, int dtype, void* stream) {
@@ -924,9 +927,10 @@ extern "C" int upa_bn_stats(const void* z, long npix, int c, int ldz, double* ws
 extern "C" int upa_bn_finalize(const double* ws, long npix, int c, float momentum, float* mean, float* var,
                                float* running_mean, float* running_var, void* stream) {
   UPA_CHECK_ARG(ws && mean && var && npix > 0, "bn_finalize: bad args");
-  const double* fin = ws + (size_t)2048 * 2 * c;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, fin, fin + c, npix, c, momentum,
-                     mean, var, running_mean, running_var);
+  CombineParams q{};
+  q.part = ws; q.nblocks = reduce_grid(npix); q.c = c; q.npix = npix; q.momentum = momentum; q.mean = mean; q.var = var;
+  q.running_mean = running_mean; q.running_var = running_var;
+  hipLaunchKernelGGL((combine_finalize_kernel<0>), dim3(c), dim3(256), 0, (hipStream_t)stream, q);
   UPA_LAUNCH_CHECK();
   return UPA_OK;
 }
@@ -958,9 +962,11 @@ extern "C" int upa_bn_act_bwd(const void* z, const void* dy, long npix, int c, i
   ReduceParams r{};
   r.z = (const char*)z; r.dy = (const char*)dy; r.npix = npix; r.c = c; r.ldz = ldz; r.lddy = lddy;
   r.mean = mean; r.var = var; r.gamma = gamma; r.beta = beta; r.eps = eps; r.act = act;
-  run_channel_reduce(r, 1, dtype, ws, s);
+  const int nb = run_channel_reduce(r, 1, dtype, ws, s);
   double* fin = ws + (size_t)2048 * 2 * c;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, s, fin, fin + c, c, dgamma, dbeta, accumulate);
+  CombineParams q{};
+  q.part = ws; q.nblocks = nb; q.c = c; q.fin = fin; q.dgamma = dgamma; q.dbeta = dbeta; q.accumulate = accumulate;
+  hipLaunchKernelGGL((combine_finalize_kernel<1>), dim3(c), dim3(256), 0, s, q);
   BnApplyParams p{};
   p.z = (const char*)z; p.y = (char*)dz; p.aux = (const char*)dy; p.npix = npix; p.c = c; p.ldz = ldz; p.ldy = lddz; p.ldaux = lddy;
   p.mean = mean; p.var = var; p.gamma = gamma; p.beta = beta; p.s0 = fin; p.s1 = fin + c; p.eps = eps; p.act = act;
@@ -979,8 +985,10 @@ extern "C" int upa_channel_sum(const void* z, long npix, int c, int ldz, float* 
   hipStream_t s = (hipStream_t)stream;
   ReduceParams r{};
   r.z = (const char*)z; r.npix = npix; r.c = c; r.ldz = ldz;
-  run_channel_reduce(r, 2, dtype, ws, s);
-  hipLaunchKernelGGL(sum_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, s, ws + (size_t)2048 * 2 * c, c, out, accumulate);
+  const int nb = run_channel_reduce(r, 2, dtype, ws, s);
+  CombineParams q{};
+  q.part = ws; q.nblocks = nb; q.c = c; q.dbeta = out; q.accumulate = accumulate;
+  hipLaunchKernelGGL((combine_finalize_kernel<2>), dim3(c), dim3(256), 0, s, q);
   UPA_LAUNCH_CHECK();
   return UPA_OK;
 }
@@ -1207,17 +1215,17 @@ extern "C" int upa_sumsq(const float* g, long n, double* out, int accumulate, vo
 
 extern "C" int upa_sgd_nesterov_ema(float* p, float* g, float* momentum_buf, float* ema, long n, const double* grad_sumsq,
                                     float max_norm, float lr, float momentum, float weight_decay, int first_step, float ema_d,
-                                    int zero_grad, void* stream) {
+                                    const float* ema_d_dev, int zero_grad, void* stream) {
   UPA_CHECK_ARG(p && g && momentum_buf && grad_sumsq && n > 0, "sgd: bad args");
   hipLaunchKernelGGL(sgd_nesterov_ema_kernel, dim3(grid_for(n, 1024, 2048)), dim3(256), 0, (hipStream_t)stream, p, g, momentum_buf,
-                     ema, n, grad_sumsq, max_norm, lr, momentum, weight_decay, first_step, ema_d, zero_grad);
+                     ema, n, grad_sumsq, max_norm, lr, momentum, weight_decay, first_step, ema_d, ema_d_dev, zero_grad);
   UPA_LAUNCH_CHECK();
   return UPA_OK;
 }
 
-extern "C" int upa_ema_update(float* ema, const float* v, long n, float d, void* stream) {
+extern "C" int upa_ema_update(float* ema, const float* v, long n, float d, const float* d_dev, void* stream) {
   UPA_CHECK_ARG(ema && v && n > 0, "ema_update: bad args");
-  hipLaunchKernelGGL(ema_only_kernel, dim3(grid_for(n, 1024, 2048)), dim3(256), 0, (hipStream_t)stream, ema, v, n, d);
+  hipLaunchKernelGGL(ema_only_kernel, dim3(grid_for(n, 1024, 2048)), dim3(256), 0, (hipStream_t)stream, ema, v, n, d, d_dev);
   UPA_LAUNCH_CHECK();
   return UPA_OK;
 }

@@ -302,6 +302,10 @@ class DetectionTrainer:
         self.pool = R.BufferPool()
         self.updates = 0
         self.first_step = True
+        self._graphs = None
+        self._capturing = False
+        self._imgsz = None
+        self.gt_d = self.ngt_d = None
         model.to(self.device)
         self._flatten_parameters(ema)
         self._build_graph()
@@ -346,6 +350,8 @@ class DetectionTrainer:
         self.nbuf = nb
         self.ERB = self.RB.clone() if ema else None
         self.sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.ema_d_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.ema_d_host = torch.zeros(1, dtype=torch.float32).pin_memory() if torch.cuda.is_available() else torch.zeros(1)
 
     # ---- graph --------------------------------------------------------------------------------------------------------
     def _build_graph(self):
@@ -485,6 +491,9 @@ class DetectionTrainer:
         self.grad_sumsq()
         self.updates += 1
         d = h["ema_decay"] * (1 - math.exp(-self.updates / h["ema_tau"]))
+        dp = None
+        if self._capturing:  # a replayed graph reads the decay of the current step from device memory
+            dp = self.ema_d_dev.data_ptr()
         for start, n, wd in self.groups:
             if n == 0:
                 continue
@@ -492,16 +501,72 @@ class DetectionTrainer:
             L.check(lib.upa_sgd_nesterov_ema(self.P.data_ptr() + o, self.G.data_ptr() + o, self.M.data_ptr() + o,
                                              (self.E.data_ptr() + o) if self.E is not None else None, n,
                                              self.sumsq.data_ptr(), h["max_norm"], h["lr"], h["momentum"], wd,
-                                             int(self.first_step), d, 1, st), "sgd")
+                                             int(self.first_step), d, dp, 1, st), "sgd")
         if self.ERB is not None and self.nbuf:
-            L.check(lib.upa_ema_update(self.ERB.data_ptr(), self.RB.data_ptr(), self.nbuf, d, st), "ema_buffers")
+            L.check(lib.upa_ema_update(self.ERB.data_ptr(), self.RB.data_ptr(), self.nbuf, d, dp, st), "ema_buffers")
         self.first_step = False
 
     def step(self, img, labels):
+        """One training step. After `compile()` the step is replayed as hipGraphs (one graph on a single GPU; forward +
+        backward | all-reduce | optimizer on several)."""
+        if self._graphs is not None:
+            return self._replay(img, labels)
         items = self.forward_backward(img, labels)
         self.all_reduce_gradients()
         self.optimizer_step()
         return items
+
+    def compile(self, img, labels, warm_steps=2):
+        """Capture the step (fixed shapes) once eager steps have allocated every static buffer and passed the first-step
+        branch of the optimizer (`warm_steps` of them are run here on the given batch; pass 0 if >= 1 step already ran).
+        Host-side inputs (image batch, labels, EMA decay) are copied into static device buffers before each replay;
+        everything else is upa_* launches recorded once."""
+        for _ in range(warm_steps):
+            self.step(img, labels)
+        if self.first_step:
+            raise L.UpaError("compile(): run at least one eager step first (the optimizer's first step differs)")
+        torch.cuda.synchronize(self.device)
+        self._static_img = self.pool.get(("img_in",) + tuple(img.shape), tuple(img.shape), torch.float32, self.device)
+        self._static_img.copy_(img)
+        self._upload_labels(labels, img.shape[0])
+        self._capturing = True
+        try:
+            g1 = R.HipGraph()
+            if self.world_size == 1:
+                def whole():
+                    it = self.forward_backward(self._static_img, None)
+                    self.optimizer_step()
+                    return it
+                self._items = g1.capture(whole, device=self.device)
+                self._graphs = (g1,)
+            else:
+                g2 = R.HipGraph()
+                self._items = g1.capture(lambda: self.forward_backward(self._static_img, None), device=self.device)
+                g2.capture(self.optimizer_step, device=self.device)
+                self._graphs = (g1, g2)
+        finally:
+            self._capturing = False
+        self.updates -= 1  # the capture itself executed nothing
+        return self
+
+    def _replay(self, img, labels):
+        h = self.hyp
+        self._static_img.copy_(img, non_blocking=True)
+        self._upload_labels(labels, img.shape[0])
+        self.updates += 1
+        self.ema_d_host[0] = h["ema_decay"] * (1 - math.exp(-self.updates / h["ema_tau"]))
+        self.ema_d_dev.copy_(self.ema_d_host, non_blocking=True)
+        self._graphs[0].replay(self.device)
+        if len(self._graphs) == 2:
+            self.all_reduce_gradients()
+            self._graphs[1].replay(self.device)
+        return self._items
+
+    def _upload_labels(self, labels, batch_size):
+        imgsz_h, imgsz_w = self._imgsz
+        gt, ngt = pack_targets(labels, batch_size, imgsz_h, imgsz_w)
+        self.gt_d.copy_(gt, non_blocking=True)
+        self.ngt_d.copy_(ngt, non_blocking=True)
 
     def grad_norm(self) -> float:
         return float(torch.sqrt(self.grad_sumsq())[0])
@@ -574,11 +639,13 @@ class DetectT(_Seq):
         h = tr.hyp
         imgsz_h = int(self.raw[0].shape[2] * float(self.m.stride[0]))
         imgsz_w = int(self.raw[0].shape[3] * float(self.m.stride[0]))
-        gt, ngt = pack_targets(labels, batch_size, imgsz_h, imgsz_w)
-        gt_d = tr.pool.get(("gt", batch_size), (batch_size, MAX_GT, 5), torch.float32, dev)
-        ngt_d = tr.pool.get(("ngt", batch_size), (batch_size,), torch.int32, dev)
-        gt_d.copy_(gt, non_blocking=True)
-        ngt_d.copy_(ngt, non_blocking=True)
+        tr._imgsz = (imgsz_h, imgsz_w)
+        if tr.gt_d is None or tr.gt_d.shape[0] != batch_size:
+            tr.gt_d = torch.zeros(batch_size, MAX_GT, 5, dtype=torch.float32, device=dev)
+            tr.ngt_d = torch.zeros(batch_size, dtype=torch.int32, device=dev)
+        if labels is not None:  # None: already uploaded into the static buffers (graph replay)
+            tr._upload_labels(labels, batch_size)
+        gt_d, ngt_d = tr.gt_d, tr.ngt_d
         grads32 = []
         for i, r in enumerate(self.raw32):
             n, ch, hh, ww = r.shape
