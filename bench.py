@@ -263,8 +263,9 @@ def wgrad_profile(tr, L, R, dev, dtype, reps=5):
         ms = e0.elapsed_time(e1) / reps
         bf = dtype == torch.bfloat16
         # the dispatch of upa_conv2d_wgrad (csrc/train.hip): bf16 MFMA kernels where the channel counts allow
-        if bf and cv.k == 3 and cv.cin >= 16 and cv.cout >= 16 and cv.cin % 8 == 0:
-            name, peak = "void (anonymous namespace)::wgrad_bf16_k3_kernel<%d>((anonymous namespace)::WgradParams)" % cv.s, PEAK_BF16_TFLOPS
+        if bf and cv.k == 3 and cv.cout >= 16 and (cv.cin % 8 == 0 or cv.cin < 8):
+            name, peak = "void (anonymous namespace)::wgrad_bf16_k3_kernel<%d, %d>((anonymous namespace)::WgradParams)" % (
+                cv.s, 16 if cv.cin <= 16 else 64), PEAK_BF16_TFLOPS
         elif bf and cv.k == 1 and cv.s == 1 and cv.p == 0 and cv.cin >= 32 and cv.cout >= 32 and cv.cin % 8 == 0:
             name, peak = "(anonymous namespace)::wgrad_bf16_k1_kernel((anonymous namespace)::WgradParams)", PEAK_BF16_TFLOPS
         else:

@@ -139,6 +139,30 @@ def test_head_conv_with_bias_and_stem_input():
     op.backward(to_dev_nhwc(dy), None, False)
     assert _rel(to_cpu_nchw(y), ref.detach()) <= 2e-4
     assert _rel(dc.weight.grad.cpu(), conv.weight.grad) <= 2e-4
+    # the same stem in bf16 mode: input padded to 8 channels, narrow-input bf16 MFMA weight gradient (16-channel block)
+    from tests.hip_utils import bf16_round
+    ctxb = _ctx(torch.bfloat16)
+    convb = nn.Conv2d(3, 32, 3, 2, 1, bias=False)
+    with torch.no_grad():
+        convb.weight.copy_(bf16_round(convb.weight))
+    bnb = nn.BatchNorm2d(32, eps=1e-3, momentum=0.03)
+    xb = bf16_round(P.uniform("sxb", (2, 3, 40, 64), 0, 1))
+    refb = F.silu(bnb(convb(xb)))
+    dyb = bf16_round(P.uniform("sdyb", tuple(refb.shape), -1, 1))
+    refb.backward(dyb)
+    dcb, dbb = nn.Conv2d(3, 32, 3, 2, 1, bias=False).to(DEV), nn.BatchNorm2d(32, eps=1e-3, momentum=0.03).to(DEV)
+    with torch.no_grad():
+        dcb.weight.copy_(convb.weight)
+    for p in list(dcb.parameters()) + list(dbb.parameters()):
+        p.grad = torch.zeros_like(p)
+    opb = T.ConvT(ctxb, dcb, dbb, 1, "sb")
+    opb.pack()
+    bufb = torch.zeros(2, 40, 64, 8, device=DEV, dtype=torch.bfloat16)
+    bufb[..., :3] = xb.permute(0, 2, 3, 1).to(DEV).to(torch.bfloat16)
+    yb = opb.forward(bufb.permute(0, 3, 1, 2))
+    opb.backward(to_dev_nhwc(dyb, torch.bfloat16), None, False)
+    assert _rel(to_cpu_nchw(yb), refb.detach()) <= 3e-2
+    assert _rel(dcb.weight.grad.cpu(), convb.weight.grad) <= 3e-2
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])

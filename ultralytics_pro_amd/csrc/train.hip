@@ -393,10 +393,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 // multiplied.  Partial blocks go through the same two-stage reduction as the f32 kernel.
 typedef short v4s16 __attribute__((ext_vector_type(4)));
 
-template <int S>
+// BCI = input channels per block: 64, or 16 for narrow inputs (the 3-channel stem, padded to one 16-byte group).
+template <int S, int BCI>
 __global__ __launch_bounds__(192) void wgrad_bf16_k3_kernel(const WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) char wsm_b[];
-  constexpr int BCO = 64, BCI = 64;
+  constexpr int BCO = 64;
+  constexpr int NT = BCI / 16;   // ci tiles
+  constexpr int XG = BCI / 8;    // 16-byte chunks per input pixel
   constexpr int PZ = BCO * 2 + 32, PX = BCI * 2 + 32;       // LDS pixel pitch (bytes): +32 spreads 4 rows over the banks
   constexpr int TW = 16;
   constexpr int NTHR = 192;
@@ -409,16 +412,17 @@ __global__ __launch_bounds__(192) void wgrad_bf16_k3_kernel(const WgradParams p)
   const int kg = lane >> 4, r16 = lane & 15;
   const int co0 = blockIdx.y * BCO, ci0 = blockIdx.z * BCI;
   const int tilesPerImg = p.tilesX * p.tilesY;
-  f32x4 acc[3][4][4];
+  f32x4 acc[3][4][NT];
 #pragma unroll
   for (int t = 0; t < 3; ++t)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NT; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   // staging: chunk c (16 bytes = 8 channels of one pixel) of the dz tile then of the x halo; thread takes c = tid + q*192
   constexpr int MAXQ = 16;  // (128 + 180) or (64 + 297) pixels * 8 chunks / 192 threads
-  const int nchunk = (npx + nhx) * 8;
+  const int nzc = npx * 8;                 // dz chunks, then XG chunks per halo pixel
+  const int nchunk = nzc + nhx * XG;
   u32x4 stg[MAXQ];
   auto fetch = [&](int tile) __attribute__((always_inline)) {
     const int n = tile / tilesPerImg;
@@ -431,14 +435,14 @@ __global__ __launch_bounds__(192) void wgrad_bf16_k3_kernel(const WgradParams p)
       const int c = tid + q * NTHR;
       u32x4 v = u32x4{0u, 0u, 0u, 0u};
       if (c < nchunk) {
-        const int px = c >> 3, g = c & 7;
-        if (px < npx) {
+        if (c < nzc) {
+          const int px = c >> 3, g = c & 7;
           const int ty = px >> 4, tx = px & 15;
           const int oy = oy0 + ty, ox = ox0 + tx, co = co0 + g * 8;
           if (oy < p.OH && ox < p.OW && co < p.Cout)
             v = *reinterpret_cast<const u32x4*>(p.dz + ((((size_t)n * p.OH + oy) * p.OW + ox) * p.lddz + co) * 2);
         } else {
-          const int hp = px - npx;
+          const int hp = (c - nzc) / XG, g = (c - nzc) - hp * XG;
           const int py = hp / IW, pxx = hp - py * IW;
           const int iy = iy0 + py, ix = ix0 + pxx, ci = ci0 + g * 8;
           if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && ci < p.Cin)
@@ -453,8 +457,9 @@ __global__ __launch_bounds__(192) void wgrad_bf16_k3_kernel(const WgradParams p)
     for (int q = 0; q < MAXQ; ++q) {
       const int c = tid + q * NTHR;
       if (c < nchunk) {
-        const int px = c >> 3, g = c & 7;
-        char* dst = px < npx ? zt + px * PZ + g * 16 : xt + (px - npx) * PX + g * 16;
+        char* dst;
+        if (c < nzc) dst = zt + (c >> 3) * PZ + (c & 7) * 16;
+        else { const int hp = (c - nzc) / XG, g = (c - nzc) - hp * XG; dst = xt + hp * PX + g * 16; }
         *reinterpret_cast<u32x4*>(dst) = stg[q];
       }
     }
@@ -487,9 +492,9 @@ __global__ __launch_bounds__(192) void wgrad_bf16_k3_kernel(const WgradParams p)
       }
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
-        u32x4 b[4];
+        u32x4 b[NT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NT; ++j) {
           const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
               (__attribute__((address_space(3))) v4s16*)(xt + xoff[0] + kw * PX + j * 32));
           const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -499,7 +504,7 @@ __global__ __launch_bounds__(192) void wgrad_bf16_k3_kernel(const WgradParams p)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
+          for (int j = 0; j < NT; ++j)
             acc[kw][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&a[i]), *reinterpret_cast<bf16x8*>(&b[j]),
                                                                     acc[kw][i][j], 0, 0, 0);
       }
@@ -512,7 +517,7 @@ __global__ __launch_bounds__(192) void wgrad_bf16_k3_kernel(const WgradParams p)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           part[((size_t)(kh * 3 + kw) * BCO + i * 16 + kg * 4 + r) * BCI + j * 16 + r16] = acc[kw][i][j][r];
@@ -1065,8 +1070,9 @@ static int launch_wgrad_bf16_k1(WgradParams& p, int accumulate, void* ws, size_t
   return UPA_OK;
 }
 
-static int launch_wgrad_bf16_k3(WgradParams& p, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
-  constexpr int BCO = 64, BCI = 64, PZ = 160, PX = 160;
+template <int BCI>
+static int launch_wgrad_bf16_k3_t(WgradParams& p, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
+  constexpr int BCO = 64, PZ = BCO * 2 + 32, PX = BCI * 2 + 32;
   p.TW = 16;
   p.TH = p.stride == 1 ? 8 : 4;
   p.tilesX = cdiv(p.OW, p.TW); p.tilesY = cdiv(p.OH, p.TH);
@@ -1080,14 +1086,14 @@ static int launch_wgrad_bf16_k3(WgradParams& p, int accumulate, void* ws, size_t
   UPA_CHECK_ARG(ws && ws_bytes >= need, "wgrad: workspace too small (%zu < %zu bytes)", ws_bytes, need);
   p.partial = (float*)ws;
   const size_t lds = (size_t)p.TH * p.TW * PZ + (size_t)p.IH * p.IW * PX;
-  UPA_CHECK_ARG((p.TH * p.TW + p.IH * p.IW) * 8 <= 16 * 192, "wgrad: staging registers too few for this tile");
+  UPA_CHECK_ARG(p.TH * p.TW * 8 + p.IH * p.IW * (BCI / 8) <= 16 * 192, "wgrad: staging registers too few for this tile");
   dim3 grid(wgs, bco, bci);
   if (p.stride == 1) {
-    auto kern = wgrad_bf16_k3_kernel<1>;
+    auto kern = wgrad_bf16_k3_kernel<1, BCI>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, grid, dim3(192), lds, s, p);
   } else {
-    auto kern = wgrad_bf16_k3_kernel<2>;
+    auto kern = wgrad_bf16_k3_kernel<2, BCI>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, grid, dim3(192), lds, s, p);
   }
@@ -1096,6 +1102,11 @@ static int launch_wgrad_bf16_k3(WgradParams& p, int accumulate, void* ws, size_t
                      p.Cout, p.Cin, accumulate);
   UPA_LAUNCH_CHECK();
   return UPA_OK;
+}
+
+static int launch_wgrad_bf16_k3(WgradParams& p, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
+  return p.Cin <= 16 ? launch_wgrad_bf16_k3_t<16>(p, accumulate, ws, ws_bytes, s)
+                     : launch_wgrad_bf16_k3_t<64>(p, accumulate, ws, ws_bytes, s);
 }
 
 extern "C" size_t upa_conv2d_wgrad_workspace_bytes(int cin, int cout, int k) {
@@ -1130,7 +1141,7 @@ extern "C" int upa_conv2d_wgrad(const void* x, int n, int h, int w, int cin, int
   p.KS = k; p.stride = stride; p.pad = pad;
   const bool small = wgrad_small(cin, cout);
   static const bool no_bf16_mfma = getenv("UPA_WGRAD_F32_MFMA") != nullptr;
-  if (dtype == UPA_BF16 && k == 3 && cin >= 16 && cout >= 16 && !no_bf16_mfma && cin % 8 == 0)
+  if (dtype == UPA_BF16 && k == 3 && cout >= 16 && !no_bf16_mfma && (cin % 8 == 0 || (cin < 8 && ldx >= 8)))
     return launch_wgrad_bf16_k3(p, accumulate, workspace, workspace_bytes, s);
   if (dtype == UPA_BF16 && k == 1 && stride == 1 && pad == 0 && cin >= 32 && cout >= 32 && !no_bf16_mfma && cin % 8 == 0)
     return launch_wgrad_bf16_k1(p, accumulate, workspace, workspace_bytes, s);
