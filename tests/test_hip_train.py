@@ -332,9 +332,12 @@ def test_training_step_yolov8n_matches_reference_golden(dtype, golden_dir):
     # TaskAlignedAssigner decisions, so single gradients differ by tens of percent while losses / norms stay within ~10 %
 
 
-def test_compiled_training_step_equals_eager():
+@pytest.mark.parametrize("world", [1, 2], ids=["one_graph", "two_graphs_around_the_allreduce"])
+def test_compiled_training_step_equals_eager(world):
     """DetectionTrainer.compile(): the hipGraph replay of the step (static buffers, device-side EMA decay, labels uploaded
-    outside the graph) follows the eager step: same loss items per step and the same weights / EMA after four steps."""
+    outside the graph) follows the eager step: same loss items per step and the same weights / EMA after four steps.
+    world = 2 exercises the multi-GPU structure (forward+backward graph | gradient all-reduce | optimizer graph) in one
+    process: without an initialised process group the all-reduce helper is the identity."""
     from tests.hip_utils import DEV
     from ultralytics_pro_amd.engine.trainer import DetectionTrainer
     from ultralytics_pro_amd.nn.tasks import DetectionModel
@@ -343,7 +346,7 @@ def test_compiled_training_step_equals_eager():
     for compiled in (False, True):
         m = DetectionModel("yolov8n.yaml")
         P.apply_procedural_weights(m)
-        tr = DetectionTrainer(m, dtype=torch.bfloat16, device=DEV)
+        tr = DetectionTrainer(m, dtype=torch.bfloat16, device=DEV, world_size=world)
         batches = [(P.synthetic_images(bs, h=sz, w=sz, seed=s).to(DEV), P.synthetic_labels(bs, seed=s)) for s in range(4)]
         items = []
         if compiled:
@@ -351,6 +354,7 @@ def test_compiled_training_step_equals_eager():
             items.append(tr.step(*batches[0]).cpu().clone())
             items.append(tr.step(*batches[1]).cpu().clone())
             tr.compile(*batches[1], warm_steps=0)
+            assert len(tr._graphs) == world
             for b in batches[2:]:
                 items.append(tr.step(*b).cpu().clone())
         else:
