@@ -419,10 +419,36 @@ __global__ __launch_bounds__(192) void wgrad_bf16_k3_kernel(const WgradParams p)
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // staging: chunk c (16 bytes = 8 channels of one pixel) of the dz tile then of the x halo; thread takes c = tid + q*192
+  // staging: chunk c (16 bytes = 8 channels of one pixel) of the dz tile then of the x halo; thread takes c = tid + q*192.
+  // The decode of a chunk (operand, tile row / column, channel group, LDS address) does not depend on the tile: it is
+  // done once (the per-tile form spent ~60 VALU instructions per chunk on divisions - more issue time than the MFMAs).
   constexpr int MAXQ = 16;  // (128 + 180) or (64 + 297) pixels * 8 chunks / 192 threads
   const int nzc = npx * 8;                 // dz chunks, then XG chunks per halo pixel
   const int nchunk = nzc + nhx * XG;
+  int rel[MAXQ];      // element offset from the tile's dz / x origin pixel (channel block included)
+  int ldsoff[MAXQ];   // byte offset in LDS, -1: no chunk
+  int rc[MAXQ];       // (row << 16) | col inside the tile / halo, bit 31: x operand
+  bool chok[MAXQ];    // channel group inside Cout / Cin
+#pragma unroll
+  for (int q = 0; q < MAXQ; ++q) {
+    const int c = tid + q * NTHR;
+    rel[q] = 0; ldsoff[q] = -1; rc[q] = 0; chok[q] = false;
+    if (c < nzc) {
+      const int px = c >> 3, g = c & 7;
+      const int ty = px >> 4, tx = px & 15;
+      rel[q] = (ty * p.OW + tx) * p.lddz + co0 + g * 8;
+      ldsoff[q] = px * PZ + g * 16;
+      rc[q] = (ty << 16) | tx;
+      chok[q] = co0 + g * 8 < p.Cout;
+    } else if (c < nchunk) {
+      const int hp = (c - nzc) / XG, g = (c - nzc) - hp * XG;
+      const int py = hp / IW, pxx = hp - py * IW;
+      rel[q] = (py * p.W + pxx) * p.ldx + ci0 + g * 8;
+      ldsoff[q] = npx * PZ + hp * PX + g * 16;
+      rc[q] = (int)(0x80000000u | (py << 16) | pxx);
+      chok[q] = ci0 + g * 8 < p.Cin;
+    }
+  }
   u32x4 stg[MAXQ];
   auto fetch = [&](int tile) __attribute__((always_inline)) {
     const int n = tile / tilesPerImg;
@@ -430,39 +456,25 @@ __global__ __launch_bounds__(192) void wgrad_bf16_k3_kernel(const WgradParams p)
     const int tyi = t2 / p.tilesX, txi = t2 - tyi * p.tilesX;
     const int oy0 = tyi * TH, ox0 = txi * TW;
     const int iy0 = oy0 * S - p.pad, ix0 = ox0 * S - p.pad;
+    const bf16_t* zb = (const bf16_t*)p.dz + ((size_t)(n * p.OH + oy0) * p.OW + ox0) * p.lddz;
+    const bf16_t* xb = (const bf16_t*)p.x + ((long)(n * p.H + iy0) * p.W + ix0) * p.ldx;  // may point before the tensor: masked
 #pragma unroll
     for (int q = 0; q < MAXQ; ++q) {
-      const int c = tid + q * NTHR;
       u32x4 v = u32x4{0u, 0u, 0u, 0u};
-      if (c < nchunk) {
-        if (c < nzc) {
-          const int px = c >> 3, g = c & 7;
-          const int ty = px >> 4, tx = px & 15;
-          const int oy = oy0 + ty, ox = ox0 + tx, co = co0 + g * 8;
-          if (oy < p.OH && ox < p.OW && co < p.Cout)
-            v = *reinterpret_cast<const u32x4*>(p.dz + ((((size_t)n * p.OH + oy) * p.OW + ox) * p.lddz + co) * 2);
-        } else {
-          const int hp = (c - nzc) / XG, g = (c - nzc) - hp * XG;
-          const int py = hp / IW, pxx = hp - py * IW;
-          const int iy = iy0 + py, ix = ix0 + pxx, ci = ci0 + g * 8;
-          if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && ci < p.Cin)
-            v = *reinterpret_cast<const u32x4*>(p.x + ((((size_t)n * p.H + iy) * p.W + ix) * p.ldx + ci) * 2);
-        }
+      const int r = (rc[q] >> 16) & 0x7fff, cc = rc[q] & 0xffff;
+      if (rc[q] >= 0) {
+        if (chok[q] && ldsoff[q] >= 0 && oy0 + r < p.OH && ox0 + cc < p.OW) v = *reinterpret_cast<const u32x4*>(zb + rel[q]);
+      } else {
+        const int iy = iy0 + r, ix = ix0 + cc;
+        if (chok[q] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) v = *reinterpret_cast<const u32x4*>(xb + rel[q]);
       }
       stg[q] = v;
     }
   };
   auto commit = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int q = 0; q < MAXQ; ++q) {
-      const int c = tid + q * NTHR;
-      if (c < nchunk) {
-        char* dst;
-        if (c < nzc) dst = zt + (c >> 3) * PZ + (c & 7) * 16;
-        else { const int hp = (c - nzc) / XG, g = (c - nzc) - hp * XG; dst = xt + hp * PX + g * 16; }
-        *reinterpret_cast<u32x4*>(dst) = stg[q];
-      }
-    }
+    for (int q = 0; q < MAXQ; ++q)
+      if (ldsoff[q] >= 0) *reinterpret_cast<u32x4*>(wsm_b + ldsoff[q]) = stg[q];
   };
   int tile = blockIdx.x;
   if (tile < p.numTiles) fetch(tile);
