@@ -82,7 +82,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: weight pointers and n-tile tests stay on the SALU
   const int r = lane & 15, g = lane >> 4;
   const int wm = wave / WN, wn = wave % WN;
 
@@ -118,20 +118,21 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
 
   const int nChunks = p.KTT / CKT;
   const size_t wTileStride = (size_t)p.NTn * 1024;  // bytes per (tap, ktile)
-  const char* wlane = p.w + (size_t)nt0 * 1024 + lane * 16;
+  const char* wuni = p.w + (size_t)nt0 * 1024;  // wave-uniform part of the weight address (SGPRs)
+  const unsigned lane16 = lane * 16;              // per-lane part: global_load ... v_off, s[base] addressing
   const int taps = p.KS * p.KS;
   // Weight fragments of one tap (CKT k-tiles x NTW n-tiles) live in registers, ping-pong buffered: while the MFMAs of
   // tap t run from one buffer, the 1 KiB-per-wave coalesced loads of tap t+1 (or of the next chunk's first tap - they
   // do not depend on the LDS tile) land in the other.
   u32x4 A0[CKT][NTW], A1[CKT][NTW];
   auto fetch_tap = [&](u32x4(&dst)[CKT][NTW], int c, int tap) {
-    const char* wb = wlane + (size_t)(tap * p.KTT + c * CKT) * wTileStride;
+    const char* wb = wuni + (size_t)(tap * p.KTT + c * CKT) * wTileStride;
     if (p.ablate & 2) return;
 #pragma unroll
     for (int kt = 0; kt < CKT; ++kt)
 #pragma unroll
       for (int j = 0; j < NTW; ++j)  // n-tiles past the packed weights (Cout 80 run as 96) contribute zeros
-        dst[kt][j] = (nt0 + j < p.NTn) ? *reinterpret_cast<const u32x4*>(wb + kt * wTileStride + j * 1024)
+        dst[kt][j] = (nt0 + j < p.NTn) ? *reinterpret_cast<const u32x4*>(wb + kt * wTileStride + j * 1024 + lane16)
                                        : u32x4{0u, 0u, 0u, 0u};
   };
   // LDS halo image: pixel-major, G16 16-byte slots per pixel, NO padding (the DMA writes 1 KiB contiguous per wave);
