@@ -368,3 +368,35 @@ def test_compiled_training_step_equals_eager(world):
         np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-5)
     np.testing.assert_allclose(wa.numpy(), wb.numpy(), rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(ea.numpy(), eb.numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_training_step_yolov8s_f32_matches_reference_golden(golden_dir):
+    """BASELINE config 3's model (yolov8s), one f32 training step vs the imported reference's record
+    (tests/golden/train_yolov8s.npz: bs 2, 256 x 256): loss items, gradient norm, per-parameter gradient norms, updated
+    stem weights and BN running variance."""
+    from tests.hip_utils import DEV
+    from ultralytics_pro_amd.engine.trainer import DetectionTrainer
+    from ultralytics_pro_amd.nn.tasks import DetectionModel
+    G = np.load(golden_dir / "train_yolov8s.npz")
+    bs, imgsz = int(G["bs"][0]), int(G["imgsz"][0])
+    m = DetectionModel("yolov8s.yaml")
+    P.apply_procedural_weights(m)
+    tr = DetectionTrainer(m, dtype=torch.float32, device=DEV)
+    x = P.synthetic_images(bs, h=imgsz, w=imgsz, seed=0).to(DEV)
+    items = tr.forward_backward(x, P.synthetic_labels(bs, seed=0))
+    norm = tr.grad_norm()
+    ref_norm = float(G["grad_norm_0"][0])
+    np.testing.assert_allclose(items.cpu().numpy(), G["loss_items_0"], rtol=2e-3)
+    assert abs(norm - ref_norm) <= 3e-3 * ref_norm
+    keys = [str(k) for k in G["param_keys"]]
+    named = dict(m.named_parameters())
+    coef = min(1.0, 10.0 / (ref_norm + 1e-6))
+    l2 = np.array([float(named[k].grad.double().norm()) * coef for k in keys])
+    ref_l2 = G["grad_l2_0"]
+    big = ref_l2 > 1e-3 * ref_l2.max()
+    np.testing.assert_allclose(l2[big], ref_l2[big], rtol=2e-2)
+    tr.optimizer_step()
+    torch.cuda.synchronize()
+    sd = m.state_dict()
+    np.testing.assert_allclose(sd["model.0.conv.weight"].cpu().numpy(), G["w_stem_0"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(sd["model.2.cv1.bn.running_var"].cpu().numpy(), G["bn_rv_0"], rtol=2e-3)
