@@ -127,7 +127,7 @@ def main():
     roofline, kernels, cpu_baseline = None, None, None
     if rank == 0:
         roofline, kernels = kernel_profile(model, x, dtype, dev, args, pconv, L, post)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
             cpu_baseline = run_cpu_baseline(args)
     if rank == 0:
         line = {
@@ -212,7 +212,7 @@ def main_train(args):
     roofline = cpu_baseline = None
     if rank == 0:
         roofline = wgrad_profile(tr, L, R, dev, dtype)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             cpu_baseline = run_cpu_train_baseline(args)
         nparam = sum(n for _, n, _ in tr.groups)
         print(json.dumps({
