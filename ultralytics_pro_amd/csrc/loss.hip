@@ -88,6 +88,7 @@ __global__ void loss_decode_kernel(const LossLevels L, float* pbox /* [B][A][4] 
 // strictly inside the gt box (tal.py:146-178, 271-291); 0 elsewhere.
 __global__ __launch_bounds__(256) void tal_topk_kernel(const LossLevels L, const float* pbox, const float* gt /* [B][MAXG][5] */,
                                                         const int* n_gt, int* cand /* [B][MAXG][TOPK] anchor or -1 */) {
+  extern __shared__ float s_metric[];  // [A]: the alignment metric of every anchor for this gt (computed once)
   const int b = blockIdx.x / MAXG, g = blockIdx.x % MAXG;
   int* out = cand + ((size_t)b * MAXG + g) * TOPK;
   if (g >= n_gt[b]) {
@@ -99,32 +100,33 @@ __global__ __launch_bounds__(256) void tal_topk_kernel(const LossLevels L, const
   const float gx1 = gb[1], gy1 = gb[2], gx2 = gb[3], gy2 = gb[4];
   __shared__ float s_val[256];
   __shared__ int s_idx[256];
-  __shared__ int chosen[TOPK];
   const int tid = threadIdx.x;
+  for (int a = tid; a < L.A; a += 256) {
+    int lvl, ay, ax;
+    anchor_decode(L, a, lvl, ay, ax);
+    const float st = L.stride[lvl];
+    const float px = ((float)ax + 0.5f) * st, py = ((float)ay + 0.5f) * st;
+    const float dmin = fminf(fminf(px - gx1, py - gy1), fminf(gx2 - px, gy2 - py));
+    float metric = 0.f;
+    if (dmin > 1e-9f) {
+      const float* pb = pbox + ((size_t)b * L.A + a) * 4;
+      float ov = ciou(gx1, gy1, gx2, gy2, pb[0] * st, pb[1] * st, pb[2] * st, pb[3] * st);
+      ov = fmaxf(ov, 0.f);
+      const float logit = L.feat[lvl][((size_t)(b * L.h[lvl] + ay) * L.w[lvl] + ax) * L.ld[lvl] + 4 * REG + cls];
+      const float sc = 1.0f / (1.0f + expf(-logit));
+      const float o2 = ov * ov;
+      metric = sqrtf(sc) * (o2 * o2 * o2);
+    }
+    s_metric[a] = metric;
+  }
+  __syncthreads();
   for (int k = 0; k < TOPK; ++k) {
-    // best (metric desc, anchor asc) not chosen yet
+    // best (metric desc, anchor asc) among the remaining anchors; taken ones are marked -1
     float best = -1.f;
     int besti = 0x7fffffff;
     for (int a = tid; a < L.A; a += 256) {
-      bool taken = false;
-      for (int q = 0; q < k; ++q) taken |= chosen[q] == a;
-      if (taken) continue;
-      int lvl, ay, ax;
-      anchor_decode(L, a, lvl, ay, ax);
-      const float st = L.stride[lvl];
-      const float px = ((float)ax + 0.5f) * st, py = ((float)ay + 0.5f) * st;
-      const float dmin = fminf(fminf(px - gx1, py - gy1), fminf(gx2 - px, gy2 - py));
-      float metric = 0.f;
-      if (dmin > 1e-9f) {
-        const float* pb = pbox + ((size_t)b * L.A + a) * 4;
-        float ov = ciou(gx1, gy1, gx2, gy2, pb[0] * st, pb[1] * st, pb[2] * st, pb[3] * st);
-        ov = fmaxf(ov, 0.f);
-        const float logit = L.feat[lvl][((size_t)(b * L.h[lvl] + ay) * L.w[lvl] + ax) * L.ld[lvl] + 4 * REG + cls];
-        const float sc = 1.0f / (1.0f + expf(-logit));
-        const float o2 = ov * ov;
-        metric = sqrtf(sc) * (o2 * o2 * o2);
-      }
-      if (metric > best || (metric == best && a < besti)) { best = metric; besti = a; }
+      const float m = s_metric[a];
+      if (m > best) { best = m; besti = a; }  // ascending a: the first maximum wins
     }
     s_val[tid] = best; s_idx[tid] = besti;
     __syncthreads();
@@ -136,10 +138,12 @@ __global__ __launch_bounds__(256) void tal_topk_kernel(const LossLevels L, const
       }
       __syncthreads();
     }
-    if (tid == 0) chosen[k] = s_idx[0];
+    if (tid == 0) {
+      out[k] = s_idx[0];
+      s_metric[s_idx[0]] = -1.f;
+    }
     __syncthreads();
   }
-  if (tid < TOPK) out[tid] = chosen[tid];
 }
 
 // ---- 3. per image: resolve assignments ---------------------------------------------------------------------------
@@ -249,6 +253,43 @@ __global__ __launch_bounds__(256) void tal_resolve_kernel(const LossLevels L, co
   if (tid == 0) { atomicAdd(tss, red[0]); atomicAdd(n_fg, redn[0]); }
 }
 
+// ---- 4a. classification term, one thread per (anchor, class): SlideLoss(BCEWithLogits) (loss.py:21-46, auto_iou = 0.5)
+__global__ __launch_bounds__(256) void loss_cls_kernel(const LossLevels L, const float* gt, const Assign* asg, const double* tss_p,
+                                                        double* out, float gain_cls, float grad_scale) {
+  const float tss = fmaxf((float)*tss_p, 1.f);
+  const float gs = grad_scale * (float)L.B / tss;
+  double l_cls = 0.0;
+  const long total = (long)L.B * L.A * L.nc;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long i = idx / L.nc;
+    const int c = (int)(idx - i * L.nc);
+    const int b = (int)(i / L.A), a = (int)(i - (long)b * L.A);
+    int lvl, ay, ax;
+    anchor_decode(L, a, lvl, ay, ax);
+    const size_t roff = ((size_t)(b * L.h[lvl] + ay) * L.w[lvl] + ax) * L.ld[lvl] + 4 * REG + c;
+    const Assign as = asg[i];
+    const int tcls = as.gt >= 0 ? (int)gt[((size_t)b * MAXG + as.gt) * 5] : -1;
+    const float x = L.feat[lvl][roff];
+    const float t = c == tcls ? as.score : 0.f;
+    float wgt;
+    if (t <= 0.4f) wgt = 1.0f;
+    else if (t < 0.5f) wgt = 1.6487212707001282f;  // exp(1 - 0.5)
+    else wgt = expf(-(t - 1.0f));
+    const float bce = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));  // max(x,0) - x*t + log(1 + exp(-|x|))
+    l_cls += (double)(bce * wgt);
+    const float sg = 1.0f / (1.0f + expf(-x));
+    L.grad[lvl][roff] = gain_cls * gs * wgt * (sg - t);
+  }
+  __shared__ double red[256];
+  red[threadIdx.x] = l_cls;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicAdd(&out[1], red[0]);
+}
+
 // ---- 4. losses and gradients ---------------------------------------------------------------------------------------
 // out[0..2] += box, cls, dfl sums (before the gains and the / target_scores_sum); gradients carry
 // gain * batch_size * grad_scale / max(tss, 1).
@@ -267,21 +308,6 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const LossLevels L, cons
     const float* row = L.feat[lvl] + roff;
     float* grow = L.grad[lvl] + roff;
     const Assign as = asg[i];
-    const int tcls = as.gt >= 0 ? (int)gt[((size_t)b * MAXG + as.gt) * 5] : -1;
-    // ---- classification: SlideLoss(BCEWithLogits) (loss.py:21-46 with auto_iou = 0.5)
-    for (int c = 0; c < L.nc; ++c) {
-      const float x = row[4 * REG + c];
-      const float t = c == tcls ? as.score : 0.f;
-      float wgt;
-      if (t <= 0.4f) wgt = 1.0f;
-      else if (t < 0.5f) wgt = 1.6487212707001282f;  // exp(1 - 0.5)
-      else wgt = expf(-(t - 1.0f));
-      // max(x,0) - x*t + log1p(exp(-|x|))
-      const float bce = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
-      l_cls += (double)(bce * wgt);
-      const float sg = 1.0f / (1.0f + expf(-x));
-      grow[4 * REG + c] = gain_cls * gs * wgt * (sg - t);
-    }
     // ---- box + DFL for positive anchors
     if (as.gt < 0) {
       for (int k = 0; k < 4 * REG; ++k) grow[k] = 0.f;
@@ -425,8 +451,11 @@ extern "C" int upa_detection_loss(const float* const* feats, float* const* grads
   const long total = (long)b * a;
   const int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
   hipLaunchKernelGGL(loss_decode_kernel, dim3(grid), dim3(256), 0, s, L, pbox);
-  hipLaunchKernelGGL(tal_topk_kernel, dim3(b * MAXG), dim3(256), 0, s, L, pbox, gt, n_gt, cand);
+  hipLaunchKernelGGL(tal_topk_kernel, dim3(b * MAXG), dim3(256), (size_t)a * sizeof(float), s, L, pbox, gt, n_gt, cand);
   hipLaunchKernelGGL(tal_resolve_kernel, dim3(b), dim3(256), 0, s, L, pbox, gt, n_gt, cand, asg, count, scal, n_fg);
+  const long tot_c = total * nc;
+  hipLaunchKernelGGL(loss_cls_kernel, dim3((int)((tot_c + 255) / 256 > 8192 ? 8192 : (tot_c + 255) / 256)), dim3(256), 0, s, L, gt, asg,
+                     scal, scal + 1, gain_cls, grad_scale);
   hipLaunchKernelGGL(loss_grad_kernel, dim3(grid), dim3(256), 0, s, L, pbox, gt, asg, scal, scal + 1, gain_box, gain_cls, gain_dfl,
                      grad_scale);
   hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1), 0, s, scal + 1, scal, gain_box, gain_cls, gain_dfl, loss_items);
