@@ -56,6 +56,12 @@ int upa_conv2d_stem_nchw(const void* x_nchw, int x_dtype, int n, int cin, int h,
                          const float* w_oihw, const float* bias, void* y, int cout, int ldy,
                          int k, int stride, int pad, int act, int dtype, void* stream);
 
+/* Conv(3,16,3,2,1)+SiLU -> Conv(16,32,3,2,1)+SiLU fused (yolov8n rows 0-1, cfg/models/v8/yolov8.yaml): bf16 NCHW input
+ * (w % 8 == 0, h % 4 == 0), the 16-channel stem output only ever exists as an LDS tile.  w0 / b0: upa_pack_stem_weight
+ * layout + folded bias; w1 / b1: upa_pack_conv_weight(UPA_BF16) layout + folded bias; y: NHWC bf16 (n, h/4, w/4, 32). */
+int upa_stem_conv_fused(const void* x, int n, int h, int w, const float* w0, const float* b0, const void* w1,
+                        const float* b1, void* y, int ldy, void* stream);
+
 /* ---- pooling / resampling / concat (HBM-bound) --------------------------------------------------------------- */
 /* nn.MaxPool2d(k, s, p) with -inf padding; pad_br>0 emulates nn.ZeroPad2d([0,pad_br,0,pad_br]) in front of it
  * (zeros, not -inf, take part in the max).                                   cfg yolov3-tiny.yaml rows 1-12 */

@@ -392,3 +392,30 @@ def test_scale_boxes_matches_reference_formula():
         ref[:, 0].clamp_(0, img0[1]); ref[:, 1].clamp_(0, img0[0]); ref[:, 2].clamp_(0, img0[1]); ref[:, 3].clamp_(0, img0[0])
         got = scale_boxes(img1, b.clone().to(DEV), img0, ratio_pad=rp)
         assert torch.equal(got.cpu(), ref)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 128, 128), (3, 3, 100, 136), (1, 3, 64, 256)], ids=["sq", "ragged", "wide"])
+def test_fused_stem_and_second_conv_equals_the_two_layers(shape):
+    """yolov8n rows 0-1 as one kernel (upa_stem_conv_fused: the stem output stays in LDS) vs the two separate HIP layers
+    and vs the oracle (Conv, conv.py:188-197) on a bf16 NCHW input; image borders, partial tiles, odd tile counts."""
+    from tests.hip_utils import DEV, bf16_round, to_cpu_nchw
+    from ultralytics_pro_amd.nn.tasks import DetectionModel
+    from oracle import tasks as ot
+    m = DetectionModel("yolov8n.yaml")
+    P.apply_procedural_weights(m)
+    m = m.to(DEV).eval()
+    m.set_compute_dtype(torch.bfloat16)
+    x = bf16_round(P.uniform(f"fstem{shape}", shape, 0, 1))
+    xd = x.to(DEV).to(torch.bfloat16).contiguous()
+    with torch.no_grad():
+        assert m._stem_fusable(xd, m._concat_placement())
+        fused = to_cpu_nchw(m._fused_stem(xd))
+        two = to_cpu_nchw(m.model[1](m.model[0](xd)))
+        o = ot.DetectionModel("yolov8n.yaml")
+        P.apply_procedural_weights(o)
+        o.fuse()
+        ref = o.model[1](o.model[0](x))
+    assert fused.shape == two.shape == ref.shape
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((fused - two).abs().max()) <= 2e-2 * scale
+    assert float((fused - ref).abs().max()) <= 3e-2 * scale

@@ -418,6 +418,188 @@ static void launch_stem_mfma_nt(const StemParams& p, int n, int nt, hipStream_t 
   else launch_stem_mfma<4, KS, S>(p, n, st);
 }
 
+// ---- Stem + second conv fused (yolov8n: Conv(3,16,3,2) -> Conv(16,32,3,2), both SiLU; yolov8.yaml rows 0-1).
+// The stem output is the largest activation of the network (bs 32: 105 MB written and read back = more HBM time than
+// either conv); here it only ever exists as a 17 x 33 pixel LDS tile.  Per 8 x 16 output tile of the second conv:
+//   1. input patch (35 x 67 pixels x 3) by LDS-DMA, double buffered across tiles (persistent workgroup);
+//   2. stem: im2col gather + one MFMA per 16 stem pixels (as stem_mfma_kernel), SiLU, bf16, written to an LDS tile laid
+//      out [row][column parity][column/2][16 ch] with 48-byte pixel pitch (stride-2 reads of the next stage then step
+//      through consecutive 48-byte slots: conflict-free ds_read_b128); stem pixels outside the stem map are ZERO (the
+//      second conv's padding);
+//   3. second conv as implicit GEMM from that tile: 16 input channels = half a 32-wide MFMA k-step, so k-steps pair two
+//      taps (lane groups 0-1 take tap 2s, groups 2-3 tap 2s+1): 5 k-steps instead of 9; the A fragments are read
+//      straight from the standard packed weights (only the address of a lane's 16 bytes changes);
+//   4. bias, SiLU, bf16, v_permlane16_swap pairs the two 16-channel tiles into 16-byte stores.
+struct StemFusedParams {
+  const void* x; const float* w0; const float* b0; const char* w1; const float* b1; char* y;
+  int N, H, W, H0, W0, OH, OW, ldy, x_bf16;
+  int tilesX, tilesY;
+};
+
+namespace sf {
+constexpr int T1H = 8, T1W = 16;               // output tile of the second conv
+constexpr int S0H = 2 * T1H + 1, S0W = 2 * T1W + 1;  // stem tile 17 x 33
+constexpr int S0WH = (S0W + 1) / 2;            // 17 columns per parity
+constexpr int SPITCH = 48;                     // bytes per stem pixel in LDS (32 used)
+constexpr int STILE = S0H * 2 * S0WH * SPITCH; // 27744
+constexpr int PR = 2 * S0H + 1, PC = 2 * S0W + 1;  // input patch 35 x 67
+constexpr int NCH = (PC + 7 + 7) / 8;          // 16-byte chunks per patch line (origin rounded down to 8 pixels)
+constexpr int LS = NCH * 8;
+constexpr int ITEMS = 3 * PR * NCH;
+constexpr int ITEMS_PAD = (ITEMS + 255) / 256 * 256;
+constexpr int PATCH = ITEMS_PAD * 16;
+}  // namespace sf
+
+__global__ __launch_bounds__(256) void stem_conv_fused_kernel(const StemFusedParams p) {
+  using namespace sf;
+  extern __shared__ __attribute__((aligned(16))) char fsm[];  // [2][PATCH] input patches, [STILE] stem tile
+  char* stile = fsm + 2 * PATCH;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kg = lane >> 4, l16 = lane & 15;
+  const int ntiles = p.tilesX * p.tilesY * p.N;
+  const int tilesPerImg = p.tilesX * p.tilesY;
+  const int plane = p.H * p.W;
+  auto stage = [&](int tile, char* buf) __attribute__((always_inline)) {
+    const int n = tile / tilesPerImg;
+    const int t2 = tile - n * tilesPerImg;
+    const int tyi = t2 / p.tilesX, txi = t2 - tyi * p.tilesX;
+    // output tile origin (oy0, ox0) -> stem origin (2*oy0 - 1, 2*ox0 - 1) -> input origin (2*sy0 - 1, 2*sx0 - 1)
+    const int iy0 = 2 * (2 * tyi * T1H - 1) - 1, ix0 = 2 * (2 * txi * T1W - 1) - 1;
+    const int ixa = ix0 & ~7;
+    const bf16_t* xb = (const bf16_t*)p.x + (size_t)n * 3 * plane;
+#pragma unroll
+    for (int it = 0; it < ITEMS_PAD / 256; ++it) {
+      const int item = it * 256 + tid;
+      const int line = item / NCH, ch = item - line * NCH;
+      const int ci = line / PR, row = line - ci * PR;
+      const int iy = iy0 + row, ix = ixa + ch * 8;
+      const bool in = item < ITEMS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      const char* src = in ? reinterpret_cast<const char*>(xb + ci * plane + iy * p.W + ix)
+                           : reinterpret_cast<const char*>(g_stem_zero16);
+      __builtin_amdgcn_global_load_lds((sgptr_t)src, (slptr_t)(buf + (it * 256 + wave * 64) * 16), 16, 0, 0);
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  stage(tile, fsm);
+  // ---- stem weights -> one A fragment; k = (kh*3 + kw)*3 + ci (packed [tap][ci][co16] f32)
+  u32x4 a0;
+  {
+    float wv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = kg * 8 + j;
+      wv[j] = k < 27 ? p.w0[k * 16 + l16] : 0.f;
+    }
+    a0 = u32x4{pack_bf16x2(wv[0], wv[1]), pack_bf16x2(wv[2], wv[3]), pack_bf16x2(wv[4], wv[5]), pack_bf16x2(wv[6], wv[7])};
+  }
+  f32x4 bias0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bias0[r] = p.b0 ? p.b0[kg * 4 + r] : 0.f;
+  // second conv: A fragments [k-step][n-tile] from the standard packed layout [tap][1 k-tile][2 n-tiles][lane][16 B]:
+  // lane (kg, r) of k-step s needs W[co = nt*16 + r][ci = (kg&1)*8 ..+7][tap = 2s + (kg>>1)] = the 16 bytes of packed lane
+  // ((kg&1)*16 + r) of that tap
+  u32x4 a1[5][2];
+#pragma unroll
+  for (int s = 0; s < 5; ++s)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int tap = 2 * s + (kg >> 1);
+      a1[s][nt] = tap < 9 ? *reinterpret_cast<const u32x4*>(p.w1 + ((size_t)(tap * 2 + nt) * 64 + (kg & 1) * 16 + l16) * 16)
+                          : u32x4{0u, 0u, 0u, 0u};
+    }
+  f32x4 bias1[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias1[nt][r] = p.b1 ? p.b1[nt * 16 + kg * 4 + r] : 0.f;
+  // stem gather offsets (elements inside a patch buffer): k -> (tap, ci) -> patch[ci][kh][kw + shift]
+  const int shift = 5;  // input origin 4*(16*txi) - 3: (-3) & 7
+  int goff[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = kg * 8 + j;
+    int o = 0;
+    if (k < 27) {
+      const int tap = k / 3, ci = k - tap * 3;
+      const int kh = tap / 3, kw = tap - kh * 3;
+      o = (ci * PR + kh) * LS + kw;
+    }
+    goff[j] = (o + shift) * 2;
+  }
+  for (int cur = 0;; cur ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // patch `cur` landed; everyone is done with the stem tile and the other patch buffer
+    const int next = tile + gridDim.x;
+    if (next < ntiles) stage(next, fsm + (cur ^ 1) * PATCH);
+    const int n = tile / tilesPerImg;
+    const int t2 = tile - n * tilesPerImg;
+    const int tyi = t2 / p.tilesX, txi = t2 - tyi * p.tilesX;
+    const int oy0 = tyi * T1H, ox0 = txi * T1W;
+    const int sy0 = 2 * oy0 - 1, sx0 = 2 * ox0 - 1;  // stem coordinates of the stem tile origin
+    const char* pb = fsm + cur * PATCH;
+    // ---- stage 2: the 17 x 33 stem tile, 16 stem pixels per MFMA; segment = 16 consecutive pixels of the linearised tile
+    constexpr int NSEG = (S0H * S0W + 15) / 16;  // 36
+    for (int sg = wave; sg < NSEG; sg += 4) {
+      const int q = sg * 16 + l16;
+      const int r = q / S0W, c = q - r * S0W;     // stem tile row / column of this lane's pixel (q may run past the tile)
+      unsigned e[8];
+      const char* base = pb + ((2 * r) * LS + 2 * c) * 2;
+      const bool qin = q < S0H * S0W;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] = qin ? *reinterpret_cast<const unsigned short*>(base + goff[j]) : 0u;
+      u32x4 b = u32x4{e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
+      f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&a0), *reinterpret_cast<bf16x8*>(&b), bias0, 0, 0, 0);
+      // lane (kg, l16): channels 4kg..4kg+3 of stem pixel q; zero outside the stem map (padding of the second conv)
+      const int sy = sy0 + r, sx = sx0 + c;
+      const bool inmap = sy >= 0 && sy < p.H0 && sx >= 0 && sx < p.W0;
+      float v[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float u = acc[t];
+        v[t] = inmap ? u * __builtin_amdgcn_rcpf(1.0f + __expf(-u)) : 0.f;
+      }
+      if (qin)
+        *reinterpret_cast<u32x2*>(stile + ((r * 2 + (c & 1)) * S0WH + (c >> 1)) * SPITCH + kg * 8) =
+            u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    }
+    __syncthreads();
+    // ---- stage 3: second conv, wave w owns output rows 2w, 2w+1 (16 pixels each) x 32 channels
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int i = wave * 2 + rr;
+      f32x4 acc[2] = {bias1[0], bias1[1]};
+#pragma unroll
+      for (int s = 0; s < 5; ++s) {
+        int tap = 2 * s + (kg >> 1);
+        if (tap > 8) tap = 8;  // zero weights there
+        const int kh = tap / 3, kw = tap - kh * 3;
+        const int sr = 2 * i + kh, sc = 2 * l16 + kw;
+        const u32x4 b = *reinterpret_cast<const u32x4*>(stile + ((sr * 2 + (sc & 1)) * S0WH + (sc >> 1)) * SPITCH + (kg & 1) * 16);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&a1[s][nt]), *reinterpret_cast<const bf16x8*>(&b),
+                                                            acc[nt], 0, 0, 0);
+      }
+      const int oy = oy0 + i, ox = ox0 + l16;
+      float v0[4], v1[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        v0[t] = acc[0][t] * __builtin_amdgcn_rcpf(1.0f + __expf(-acc[0][t]));
+        v1[t] = acc[1][t] * __builtin_amdgcn_rcpf(1.0f + __expf(-acc[1][t]));
+      }
+      auto lo = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v1[0], v1[1]), false, false);
+      auto hi = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[2], v1[3]), false, false);
+      const int cb = 16 * (kg & 1) + 8 * (kg >> 1);
+      if (oy < p.OH && ox < p.OW)
+        *reinterpret_cast<u32x4*>(p.y + ((size_t)((n * p.OH + oy) * p.OW + ox) * p.ldy + cb) * 2) = u32x4{lo[0], hi[0], lo[1], hi[1]};
+    }
+    tile = next;
+    if (tile >= ntiles) break;
+  }
+}
+
 // Host-side repack of OIHW f32 weights into [tap][ci][co padded to 16] (HOST memory in, HOST memory out).
 extern "C" size_t upa_stem_packed_weight_bytes(int cout, int cin, int k) {
   return (size_t)k * k * cin * ((cout + 15) / 16 * 16) * sizeof(float);
@@ -484,6 +666,28 @@ extern "C" int upa_conv2d_stem_nchw(const void* x, int x_dtype, int n, int cin, 
     if (act == UPA_ACT_SILU) hipLaunchKernelGGL((stem_conv_kernel<float, CO_T, true>), grid, dim3(256), lds, st, p);
     else hipLaunchKernelGGL((stem_conv_kernel<float, CO_T, false>), grid, dim3(256), lds, st, p);
   }
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+/* Fused Conv(3,16,3,2,1)+SiLU -> Conv(16,32,3,2,1)+SiLU on a bf16 NCHW input (W % 8 == 0): the 16-channel intermediate never
+ * reaches HBM.  w0 / b0: stem weights packed by upa_pack_stem_weight (+ folded bias); w1 / b1: second conv packed by
+ * upa_pack_conv_weight(bf16) (+ folded bias).  y: NHWC bf16 view (n, h/4, w/4, 32). */
+extern "C" int upa_stem_conv_fused(const void* x, int n, int h, int w, const float* w0, const float* b0, const void* w1,
+                                   const float* b1, void* y, int ldy, void* stream) {
+  UPA_CHECK_ARG(x && w0 && w1 && y, "stem_conv_fused: null pointer");
+  UPA_CHECK_ARG(w % 8 == 0 && h % 4 == 0 && w % 4 == 0 && (long)3 * h * w < (1L << 31), "stem_conv_fused: w %% 8, h %% 4 == 0 required");
+  UPA_CHECK_ARG(ldy % 8 == 0 && (uintptr_t)y % 16 == 0, "stem_conv_fused: output view must be 16-byte aligned");
+  StemFusedParams p{};
+  p.x = x; p.w0 = w0; p.b0 = b0; p.w1 = (const char*)w1; p.b1 = b1; p.y = (char*)y;
+  p.N = n; p.H = h; p.W = w; p.H0 = h / 2; p.W0 = w / 2; p.OH = h / 4; p.OW = w / 4; p.ldy = ldy;
+  p.tilesX = cdiv(p.OW, sf::T1W); p.tilesY = cdiv(p.OH, sf::T1H);
+  const long ntiles = (long)p.tilesX * p.tilesY * n;
+  static const int wgs = getenv("UPA_STEMF_WGS") ? atoi(getenv("UPA_STEMF_WGS")) : 512;
+  const size_t lds = (size_t)2 * sf::PATCH + sf::STILE;
+  auto kern = stem_conv_fused_kernel;
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < wgs ? ntiles : wgs)), dim3(256), lds, (hipStream_t)stream, p);
   UPA_LAUNCH_CHECK();
   return UPA_OK;
 }

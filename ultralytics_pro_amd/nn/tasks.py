@@ -193,7 +193,15 @@ class BaseModel(nn.Module):
         if det is not None:
             det._pend().clear()
             det_level = {(det.i - 1 if j == -1 else j): k for k, j in enumerate(det.f)} if isinstance(det.f, list) else {}
+        fused_stem = self._stem_fusable(x, place)
         for m in self.model:
+            if fused_stem and m.i == 0:  # layers 0 and 1 run as ONE kernel: the stem output never reaches HBM
+                x = self._fused_stem(x)
+                y.append(None)
+                continue
+            if fused_stem and m.i == 1:
+                y.append(x if 1 in self.save else None)
+                continue
             if m.f != -1:
                 x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
             if m.i in place and torch.is_tensor(x):
@@ -223,6 +231,34 @@ class BaseModel(nn.Module):
             if m.i in det_level and torch.is_tensor(x):  # a Detect input is ready: start that level's branches now
                 det.start_level(det_level[m.i], x)
         return x
+
+    def _stem_fusable(self, x, place) -> bool:
+        """yolov8n's first two rows (Conv(3,16,3,2), Conv(16,32,3,2), SiLU, bf16 NCHW input, neither output used by a later
+        row other than the next one): `upa_stem_conv_fused` runs them as one kernel (csrc/stem.hip)."""
+        if self.__dict__.get("_no_stem_fusion") or len(self.model) < 3 or not torch.is_tensor(x):
+            return False
+        a, b = self.model[0], self.model[1]
+        if not (type(a) is Conv and type(b) is Conv) or b.f != -1 or 0 in self.save or 0 in place or 1 in place:
+            return False
+        if getattr(self, "compute_dtype", None) != torch.bfloat16 or x.dtype != torch.bfloat16 or x.dim() != 4:
+            return False
+        ca, cb = a.conv, b.conv
+        ok = (ca.in_channels, ca.out_channels, ca.kernel_size, ca.stride, ca.padding) == (3, 16, (3, 3), (2, 2), (1, 1)) and \
+            (cb.in_channels, cb.out_channels, cb.kernel_size, cb.stride, cb.padding) == (16, 32, (3, 3), (2, 2), (1, 1)) and \
+            isinstance(a.act, nn.SiLU) and isinstance(b.act, nn.SiLU) and not a.training
+        n, c, h, w = x.shape
+        return bool(ok and c == 3 and x.is_contiguous() and w % 8 == 0 and h % 4 == 0 and w % 4 == 0)
+
+    def _fused_stem(self, x):
+        a, b = self.model[0], self.model[1]
+        pa = a._packed(a.conv, getattr(a, "bn", None), x.device, torch.bfloat16, True)
+        pb = b._packed(b.conv, getattr(b, "bn", None), x.device, torch.bfloat16, False)
+        n, _, h, w = x.shape
+        y = R.alloc_nhwc(n, 32, h // 4, w // 4, torch.bfloat16, x.device, key=(id(b), "y"))
+        vy = R.view_of(y)
+        L.check(L.lib().upa_stem_conv_fused(x.data_ptr(), n, h, w, pa.w.data_ptr(), pa.bias.data_ptr(), pb.w.data_ptr(),
+                                            pb.bias.data_ptr(), vy.ptr, vy.ld, L.current_stream(x.device)), "stem_conv_fused")
+        return y
 
     def _concat_placement(self):
         """{producer layer index: (concat layer index, c0, c1, c_total)} for producers that accept `out=`."""
