@@ -185,6 +185,14 @@ int upa_conv2d_wgrad(const void* x, int n, int h, int w, int cin, int ldx, const
 /* dst (n,h,w,c) = zero-inserted src (n,oh,ow,c): dst[y,x] = src[y/2,x/2] for even y, x (data gradient of stride 2). */
 int upa_dilate2x(const void* src, int n, int oh, int ow, int c, int lds, void* dst, int h, int w, int ldd, int dtype,
                  void* stream);
+/* Data gradient of a 3x3 stride-2 pad-1 conv by output parity: four 2x2 stride-1 correlations over dz (1/2/2/4 live taps)
+ * instead of a 9-tap one over the zero-inserted dz.  upa_dgrad_s2_phase_weights writes V[phase = 2*py+px][ci][co][2][2] (f32,
+ * "OIHW" with O = cin); each V[phase] is packed with upa_pack_conv_weight_dev(cout' = cin, cin' = cout, k = 2) and run as
+ * upa_conv2d_bias_act(dz, k 2, stride 1, pad 1) into a phase map of (oh+1, ow+1) pixels; upa_interleave2x scatters
+ * dx[2i+py][2j+px] (+)= phase[py][px][i+1][j+1]. */
+int upa_dgrad_s2_phase_weights(const float* w_oihw, int cout, int cin, float* v, void* stream);
+int upa_interleave2x(const void* t00, const void* t01, const void* t10, const void* t11, int n, int oh1, int ow1, int c, int ldt,
+                     void* dx, int h, int w, int lddx, int accumulate, int dtype, void* stream);
 /* dx (n,h,w,c) (+)= 2x2 block sums of dy (n,2h,2w,c): backward of nn.Upsample(scale 2, nearest). */
 int upa_upsample2x_bwd(const void* dy, int n, int h, int w, int c, int lddy, void* dx, int lddx, int accumulate, int dtype,
                        void* stream);

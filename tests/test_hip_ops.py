@@ -32,6 +32,8 @@ CONV_CASES = [
     (32, 16, 1, 1, None, 33, 9, 1),
     (512, 1024, 3, 1, None, 10, 10, 1),
     (1024, 256, 1, 1, None, 10, 10, 1),
+    (64, 32, 2, 1, 1, 9, 9, 2),     # even kernel, pad 1: the phase correlations of the stride-2 data gradient
+    (128, 64, 2, 1, 1, 21, 21, 1),
 ]
 
 

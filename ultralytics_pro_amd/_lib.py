@@ -67,6 +67,8 @@ PROTOTYPES = {
     "upa_conv2d_wgrad_workspace_bytes": (_sz, [_i, _i, _i]),
     "upa_conv2d_wgrad": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "upa_dilate2x": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp]),
+    "upa_dgrad_s2_phase_weights": (_i, [_vp, _i, _i, _vp, _vp]),
+    "upa_interleave2x": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "upa_upsample2x_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "upa_maxpool2d_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "upa_maxpool2d_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _sz, _vp]),

@@ -809,6 +809,58 @@ __global__ void maxpool_bwd_kernel(const unsigned char* arg, const char* dy, int
   }
 }
 
+// ---- data gradient of a 3x3 stride-2 pad-1 convolution by output parity ------------------------------------------------
+// dx[2i+py][2j+px] only receives the taps with kh = py+1 (mod 2), kw = px+1 (mod 2): four small stride-1 correlations
+// over dz with 1, 2, 2 and 4 taps instead of a 9-tap correlation over a 4x zero-inserted dz.  Each phase is expressed as a
+// 2x2 kernel V_p (zero taps where the parity has none) applied with pad 1 - out'[i'] = sum_a dz[i'+a-1] V[a], and the
+// phase value of (i, j) is out'[i+1][j+1] - so the forward conv kernels run it unchanged; upa_interleave2x scatters the
+// four phase maps into dx.   V_p[ci][co][a][b] = W[co][ci][kh][kw] with (py=0: a=0 -> kh=1; py=1: a=0 -> kh=2, a=1 -> kh=0).
+__global__ void dgrad_s2_phase_weights_kernel(const float* w, int cout, int cin, float* v) {
+  const long total = 4L * cin * cout * 4;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long t = idx;
+    const int b = (int)(t & 1); t >>= 1;
+    const int a = (int)(t & 1); t >>= 1;
+    const int co = (int)(t % cout); t /= cout;
+    const int ci = (int)(t % cin);
+    const int ph = (int)(t / cin);
+    const int py = ph >> 1, px = ph & 1;
+    const int kh = py == 0 ? (a == 0 ? 1 : -1) : (a == 0 ? 2 : 0);
+    const int kw = px == 0 ? (b == 0 ? 1 : -1) : (b == 0 ? 2 : 0);
+    v[idx] = (kh < 0 || kw < 0) ? 0.f : w[(((size_t)co * cin + ci) * 3 + kh) * 3 + kw];
+  }
+}
+
+template <typename T>
+__global__ void interleave2x_kernel(const char* t0, const char* t1, const char* t2, const char* t3, int n, int oh1, int ow1, int c,
+                                    int ldt, char* dx, int h, int w, int lddx, int accumulate) {
+  constexpr int E = 16 / sizeof(T);
+  const int cg = c / E;
+  const long total = (long)n * h * w * cg;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long t = idx;
+    const int g = (int)(t % cg); t /= cg;
+    const int x = (int)(t % w); t /= w;
+    const int y = (int)(t % h); t /= h;
+    const int b = (int)t;
+    const int ph = ((y & 1) << 1) | (x & 1);
+    const char* src = ph == 0 ? t0 : (ph == 1 ? t1 : (ph == 2 ? t2 : t3));
+    const int i = (y >> 1) + 1, j = (x >> 1) + 1;
+    float v[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = 0.f;
+    if (i < oh1 && j < ow1) load16<T>(src + ((((size_t)b * oh1 + i) * ow1 + j) * ldt + g * E) * sizeof(T), v);
+    char* dst = dx + ((((size_t)b * h + y) * w + x) * lddx + g * E) * sizeof(T);
+    if (accumulate) {
+      float o[E];
+      load16<T>(dst, o);
+#pragma unroll
+      for (int e = 0; e < E; ++e) v[e] += o[e];
+    }
+    store16<T>(dst, v);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void sumsq_kernel(const float* g, long n, double* out) {
   __shared__ double red[256];
@@ -1266,6 +1318,29 @@ extern "C" int upa_cast_view(const void* src, int src_dtype, int lds_, void* dst
     hipLaunchKernelGGL((cast_view_kernel<float, float>), dim3(grid), dim3(256), 0, s, (const char*)src, lds_, (char*)dst, ldd, npix, c);
   else
     hipLaunchKernelGGL((cast_view_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, s, (const char*)src, lds_, (char*)dst, ldd, npix, c);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+extern "C" int upa_dgrad_s2_phase_weights(const float* w_oihw, int cout, int cin, float* v, void* stream) {
+  UPA_CHECK_ARG(w_oihw && v && cout > 0 && cin > 0, "dgrad_s2_phase_weights: bad args");
+  hipLaunchKernelGGL(dgrad_s2_phase_weights_kernel, dim3(grid_for(16L * cin * cout)), dim3(256), 0, (hipStream_t)stream, w_oihw, cout, cin, v);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+extern "C" int upa_interleave2x(const void* t00, const void* t01, const void* t10, const void* t11, int n, int oh1, int ow1, int c,
+                                int ldt, void* dx, int h, int w, int lddx, int accumulate, int dtype, void* stream) {
+  UPA_CHECK_ARG(t00 && t01 && t10 && t11 && dx, "interleave2x: null pointer");
+  if (int rc = check_view((long)n * h * w, c, lddx, dtype, "interleave2x")) return rc;
+  const int E = 16 / upa_elem_size(dtype);
+  const long total = (long)n * h * w * (c / E);
+  if (dtype == UPA_BF16)
+    hipLaunchKernelGGL((interleave2x_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const char*)t00,
+                       (const char*)t01, (const char*)t10, (const char*)t11, n, oh1, ow1, c, ldt, (char*)dx, h, w, lddx, accumulate);
+  else
+    hipLaunchKernelGGL((interleave2x_kernel<float>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const char*)t00,
+                       (const char*)t01, (const char*)t10, (const char*)t11, n, oh1, ow1, c, ldt, (char*)dx, h, w, lddx, accumulate);
   UPA_LAUNCH_CHECK();
   return UPA_OK;
 }

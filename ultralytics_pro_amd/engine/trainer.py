@@ -76,6 +76,11 @@ class ConvT:
         if bn is not None:
             self.mean = torch.empty(self.cout, dtype=torch.float32, device=dev)
             self.var = torch.empty(self.cout, dtype=torch.float32, device=dev)
+        self.phase = None
+        if self.s == 2 and self.k == 3 and self.p == 1:  # data gradient by output parity: four packed 2x2 kernels
+            nph = L.lib().upa_conv_packed_weight_bytes(self.cin, self.cout, 2, code)
+            self.phase_v = torch.empty(4 * self.cin * self.cout * 4, dtype=torch.float32, device=dev)
+            self.phase = [torch.empty(nph, dtype=torch.uint8, device=dev) for _ in range(4)]
         self.x = self.z = None
         nws = L.lib().upa_conv2d_wgrad_workspace_bytes(self.cin, self.cout, self.k)
         if nws > ctx.wgrad_ws.numel():
@@ -86,8 +91,16 @@ class ConvT:
         w = self.conv.weight
         L.check(lib.upa_pack_conv_weight_dev(w.data_ptr(), self.cout, self.cin, self.k, c.code, 0, self.wp.data_ptr(),
                                              _s(c.device)), "pack_dev")
-        L.check(lib.upa_pack_conv_weight_dev(w.data_ptr(), self.cout, self.cin, self.k, c.code, 1, self.wpt.data_ptr(),
-                                             _s(c.device)), "pack_dev_t")
+        if self.phase is None:
+            L.check(lib.upa_pack_conv_weight_dev(w.data_ptr(), self.cout, self.cin, self.k, c.code, 1, self.wpt.data_ptr(),
+                                                 _s(c.device)), "pack_dev_t")
+        else:
+            L.check(lib.upa_dgrad_s2_phase_weights(w.data_ptr(), self.cout, self.cin, self.phase_v.data_ptr(), _s(c.device)),
+                    "phase_weights")
+            per = self.cin * self.cout * 4 * 4  # bytes of one V[phase]
+            for ph in range(4):
+                L.check(lib.upa_pack_conv_weight_dev(self.phase_v.data_ptr() + ph * per, self.cin, self.cout, 2, c.code, 0,
+                                                     self.phase[ph].data_ptr(), _s(c.device)), "pack_phase")
 
     def _conv(self, x, wp, cout, k, s, p, out, bias=None, residual=None):
         vx, vy = R.view_of(x), R.view_of(out)
@@ -156,8 +169,20 @@ class ConvT:
                 f"wgrad[{self.name}]")
         if dx is None:
             return
+        if self.phase is not None:
+            # stride 2: four 2x2 stride-1 correlations over dz (one per output parity) + one interleave pass
+            ts, keep = [], []
+            for ph in range(4):
+                t = _new(vdz.n, self.cin, vdz.h + 1, vdz.w + 1, c.dtype, c.device, (id(self), "phase", ph))
+                self._conv(dz, self.phase[ph], self.cin, 2, 1, 1, t)
+                keep.append(t)  # views are raw pointers: the tensors must outlive the interleave launch
+                ts.append(R.view_of(t))
+            vdx = R.view_of(dx)
+            L.check(lib.upa_interleave2x(ts[0].ptr, ts[1].ptr, ts[2].ptr, ts[3].ptr, vdz.n, vdz.h + 1, vdz.w + 1, self.cin, ts[0].ld,
+                                         vdx.ptr, vdx.h, vdx.w, vdx.ld, int(accumulate), vdx.dtype, st), "interleave2x")
+            return
         src = dz
-        if self.s == 2:  # zero-insert dz to the input resolution, then a stride-1 correlation with the flipped weights
+        if self.s == 2:  # other stride-2 shapes: zero-insert dz, then a stride-1 correlation with the flipped weights
             up = _new(vx.n, self.cout, vx.h, vx.w, c.dtype, c.device, (id(self), "dz_up"))
             vu = R.view_of(up)
             L.check(lib.upa_dilate2x(vdz.ptr, vdz.n, vdz.h, vdz.w, vdz.c, vdz.ld, vu.ptr, vu.h, vu.w, vu.ld, vdz.dtype, st),
