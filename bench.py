@@ -392,6 +392,25 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
             d["ms"] += ms
             d["flops"] += flops
             d["bytes"] += nbytes
+    if torch.is_tensor(x) and model._stem_fusable(x, model._concat_placement()):
+        # rows 0-1 run as one kernel that bypasses hip_conv2d (csrc/stem.hip: stem_conv_fused_kernel)
+        n_, _, h_, w_ = x.shape
+        with torch.no_grad(), R.static_buffers(pool):
+            def body_f():
+                for _ in range(reps):
+                    model._fused_stem(x)
+            body_f()
+            g = R.HipGraph()
+            g.capture(body_f, device=dev)
+            g.replay(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            g.replay(dev)
+            e1.record()
+            torch.cuda.synchronize(dev)
+        fl = 2.0 * n_ * ((h_ // 2) * (w_ // 2) * 16 * 27 + (h_ // 4) * (w_ // 4) * 32 * 144)
+        by = n_ * 3 * h_ * w_ * es + n_ * (h_ // 4) * (w_ // 4) * 32 * es
+        fam["stem_conv_fused_kernel(StemFusedParams)"] = dict(launches=1, ms=e0.elapsed_time(e1) / reps, flops=fl, bytes=float(by))
     conv_ms = sum(d["ms"] for d in fam.values())
     conv_flops = sum(d["flops"] for d in fam.values())
     conv_bytes = sum(d["bytes"] for d in fam.values())
