@@ -502,24 +502,27 @@ __global__ __launch_bounds__(192) void wgrad_bf16_k3_kernel(const WgradParams p)
         const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(zt + zoff[1] + i * 32));
         a[i] = u32x4{((const unsigned*)&lo)[0], ((const unsigned*)&lo)[1], ((const unsigned*)&hi)[0], ((const unsigned*)&hi)[1]};
       }
+      // all three tap columns are fetched before the first MFMA: the reads of column kw+1 are in flight under the MFMAs
+      // of column kw (with one shared fragment buffer the LDS latency sat in front of every 16 MFMAs)
+      u32x4 b[3][NT];
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        u32x4 b[NT];
+      for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
               (__attribute__((address_space(3))) v4s16*)(xt + xoff[0] + kw * PX + j * 32));
           const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
               (__attribute__((address_space(3))) v4s16*)(xt + xoff[1] + kw * PX + j * 32));
-          b[j] = u32x4{((const unsigned*)&lo)[0], ((const unsigned*)&lo)[1], ((const unsigned*)&hi)[0], ((const unsigned*)&hi)[1]};
+          b[kw][j] = u32x4{((const unsigned*)&lo)[0], ((const unsigned*)&lo)[1], ((const unsigned*)&hi)[0], ((const unsigned*)&hi)[1]};
         }
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j)
-            acc[kw][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&a[i]), *reinterpret_cast<bf16x8*>(&b[j]),
+            acc[kw][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&a[i]), *reinterpret_cast<bf16x8*>(&b[kw][j]),
                                                                     acc[kw][i][j], 0, 0, 0);
-      }
     }
   }
   // flush this wave's three taps of the 64 x 64 block: D[row = co][col = ci], lane holds rows 4*kg..+3 of column r16
