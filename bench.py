@@ -44,16 +44,20 @@ def parse():
                     help="infer = BASELINE config 2 (the headline metric); train = config 3: one batch-DP training step "
                          "(forward, v8DetectionLoss, backward, gradient all-reduce over RCCL, clip + SGD nesterov + EMA)")
     ap.add_argument("--imgsz", type=int, default=640)
+    ap.add_argument("--in-flight", type=int, default=0,
+                    help="steps in flight: consecutive steps are replayed round-robin on this many HIP streams (each with its "
+                         "own graph and static buffers), so the NMS tail of step k overlaps the convolutions of step k+1. "
+                         "0 = autotune: a few (in-flight, micro-batches) pairs are timed for 20 steps, the fastest is used")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--serial", action="store_true",
                     help="no intra-step concurrency (Detect branches on the main stream): per-kernel durations in a "
                          "rocprofv3 trace of this mode are directly comparable with roofline.avg_launch_us")
-    ap.add_argument("--micro-batches", type=int, default=2,
+    ap.add_argument("--micro-batches", type=int, default=0,
                     help="walk the per-GPU batch as this many concurrent sub-batches (parallel hipGraph branches of ONE "
-                         "graph; the whole batch is still processed every step). 2 measured best on MI355X: the "
-                         "latency-bound 20x20/40x40 layers of one half overlap the other half's")
+                         "graph; the whole batch is still processed every step): the latency-bound 20x20/40x40 layers of "
+                         "one half overlap the other half's. 0 = autotune together with --in-flight")
     return ap.parse_args()
 
 
@@ -99,17 +103,32 @@ def main():
     def post(o):
         return nms_raw(o[0], 0.25, 0.7, max_det=300, key="bench")
 
+    from ultralytics_pro_amd.engine.pipeline import PipelinedRunner, autotune
+    tuned = None
     with torch.no_grad():
-        run = model.compile(x, post=post, micro_batches=args.micro_batches)
+        if args.serial:
+            args.micro_batches, args.in_flight = args.micro_batches or 1, args.in_flight or 1
+        if args.micro_batches == 0 or args.in_flight == 0:
+            # most promising first: how streams land on the runtime's hardware queues depends on creation order
+            cands = [(f, m) for f in ((args.in_flight,) if args.in_flight else (3, 1, 2))
+                     for m in ((args.micro_batches,) if args.micro_batches else (2, 1))]
+            if not args.in_flight and not args.micro_batches:
+                cands = [(3, 2), (1, 2), (2, 1), (3, 1)]
+            runner, table = autotune(model, x, post, candidates=cands)
+            tuned = {f"in_flight={f},micro_batches={m}": round(t * 1e3, 4) for (f, m), t in table.items()}
+            args.in_flight, args.micro_batches = runner.in_flight, runner.micro_batches
+        else:
+            runner = PipelinedRunner(model, x, post, micro_batches=args.micro_batches, in_flight=args.in_flight)
+        run = runner.runs[0]
         for _ in range(args.warmup):
-            run()
+            runner.step()
         torch.cuda.synchronize(dev)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            run()
+            runner.step()
         torch.cuda.synchronize(dev)
         if dist is not None:
             dist.barrier()
@@ -146,6 +165,8 @@ def main():
             "config": {"workload": f"{args.model} detect 640x640 bs={args.batch} {args.dtype} inference, 1 hipGraph/step: "
                                    "forward+decode+NMS(conf .25, iou .7, max_det 300)",
                        "micro_batches": args.micro_batches, "intra_step_concurrency": not args.serial,
+                       "steps_in_flight": max(1, args.in_flight), "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
+                       "autotune_ms_per_step": tuned,
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch, "parallelism": f"dp{world} replicas"},
             "images_per_sec_per_gpu": round(value / world, 1),
             "detections_per_image_mean": round(sum(ndet) / max(1, len(ndet)), 1),

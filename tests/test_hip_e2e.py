@@ -152,3 +152,27 @@ def test_e2e_micro_batched_graph_equals_single_graph():
     out2 = torch.cat([p_[0] for p_ in parts], 0)
     cnt2 = torch.cat([p_[1] for p_ in parts], 0)
     assert torch.equal(cnt1, cnt2) and torch.equal(out1, out2)
+
+
+def test_e2e_pipelined_runner_copies_equal_single_graph():
+    """engine.pipeline.PipelinedRunner: three compiled copies of the step in flight on separate streams (each split into
+    two concurrent sub-batches) - every copy reproduces the single-graph detections bit for bit, repeatedly."""
+    from tests.hip_utils import DEV
+    from ultralytics_pro_amd.engine.pipeline import PipelinedRunner
+    from ultralytics_pro_amd.utils.nms import nms_raw
+    m = _build("yolov8n", torch.bfloat16)
+    x = P.synthetic_images(4).to(DEV).to(torch.bfloat16).contiguous()
+    with torch.no_grad():
+        run1 = m.compile(x, post=lambda o: nms_raw(o[0], 0.25, 0.7, key="ref"))
+        out1, cnt1, _ = run1()
+        torch.cuda.synchronize()
+        out1, cnt1 = out1.clone(), cnt1.clone()
+        runner = PipelinedRunner(m, x, post=lambda o: nms_raw(o[0], 0.25, 0.7, key="pipe"), micro_batches=2, in_flight=3)
+        for _ in range(7):  # not a multiple of in_flight: the copies end at different points of the rotation
+            runner.step()
+        torch.cuda.synchronize()
+    assert runner.i == 7 and len(runner.results()) == 3
+    for parts in runner.results():
+        out = torch.cat([p_[0] for p_ in parts], 0)
+        cnt = torch.cat([p_[1] for p_ in parts], 0)
+        assert torch.equal(cnt, cnt1) and torch.equal(out, out1)

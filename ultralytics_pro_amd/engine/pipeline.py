@@ -1,0 +1,61 @@
+"""Throughput executor: several compiled copies of the inference step kept in flight on separate HIP streams.
+
+One hipGraph replay of the step ends in a latency-bound tail (Detect decode + NMS: a few dozen workgroups on 256 CUs).
+Replaying consecutive batches round-robin on `in_flight` streams - each with its own graph and static buffers - lets the
+tail of batch k overlap the convolutions of batch k+1, the way a serving loop keeps several requests in flight.  How well
+streams overlap depends on how the HIP runtime maps them onto hardware queues (GPU_MAX_HW_QUEUES, creation order), so
+`autotune` measures a few (in_flight, micro_batches) combinations for a handful of steps and keeps the fastest.
+"""
+
+from __future__ import annotations
+
+import time
+
+import torch
+
+
+class PipelinedRunner:
+    def __init__(self, model, example: torch.Tensor, post=None, micro_batches: int = 2, in_flight: int = 2):
+        self.model, self.example, self.post = model, example, post
+        self.micro_batches, self.in_flight = micro_batches, max(1, in_flight)
+        self.device = example.device
+        with torch.no_grad():
+            self.runs = [model.compile(example, post=post, micro_batches=micro_batches) for _ in range(self.in_flight)]
+        self.lanes = [torch.cuda.Stream(device=self.device) for _ in self.runs] if self.in_flight > 1 else [None]
+        self.i = 0
+
+    def step(self):
+        """Enqueue one batch; returns the (static) result object of the copy that ran it - valid after a synchronize."""
+        k = self.i % self.in_flight
+        self.i += 1
+        if self.lanes[k] is None:
+            return self.runs[k]()
+        with torch.cuda.stream(self.lanes[k]):
+            return self.runs[k]()
+
+    def results(self):
+        return [r.result for r in self.runs]
+
+    def measure(self, steps: int = 20, warmup: int = 4) -> float:
+        for _ in range(warmup):
+            self.step()
+        torch.cuda.synchronize(self.device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        torch.cuda.synchronize(self.device)
+        return (time.perf_counter() - t0) / steps
+
+
+def autotune(model, example, post=None, candidates=((1, 2), (2, 1), (2, 2), (3, 2)), steps: int = 20):
+    """Try (in_flight, micro_batches) candidates, return (best PipelinedRunner, {candidate: seconds per step})."""
+    best, best_t, table = None, float("inf"), {}
+    for in_flight, mb in candidates:
+        if example.shape[0] % mb:
+            continue
+        r = PipelinedRunner(model, example, post, micro_batches=mb, in_flight=in_flight)
+        t = r.measure(steps)
+        table[(in_flight, mb)] = t
+        if t < best_t:
+            best, best_t = r, t
+    return best, table
