@@ -15,13 +15,14 @@ import torch
 
 
 class PipelinedRunner:
-    def __init__(self, model, example: torch.Tensor, post=None, micro_batches: int = 2, in_flight: int = 2):
+    def __init__(self, model, example: torch.Tensor, post=None, micro_batches: int = 2, in_flight: int = 2, priority: int = 0):
         self.model, self.example, self.post = model, example, post
-        self.micro_batches, self.in_flight = micro_batches, max(1, in_flight)
+        self.micro_batches, self.in_flight, self.priority = micro_batches, max(1, in_flight), priority
         self.device = example.device
         with torch.no_grad():
             self.runs = [model.compile(example, post=post, micro_batches=micro_batches) for _ in range(self.in_flight)]
-        self.lanes = [torch.cuda.Stream(device=self.device) for _ in self.runs] if self.in_flight > 1 else [None]
+        # lane streams; `priority` (0 normal, -1 high) selects the runtime's queue set for them
+        self.lanes = [torch.cuda.Stream(device=self.device, priority=priority) for _ in self.runs] if self.in_flight > 1 else [None]
         self.i = 0
 
     def step(self):
@@ -47,15 +48,17 @@ class PipelinedRunner:
         return (time.perf_counter() - t0) / steps
 
 
-def autotune(model, example, post=None, candidates=((1, 2), (2, 1), (2, 2), (3, 2)), steps: int = 20):
-    """Try (in_flight, micro_batches) candidates, return (best PipelinedRunner, {candidate: seconds per step})."""
+def autotune(model, example, post=None, candidates=((3, 2, 0), (2, 2, -1), (1, 2, 0), (2, 1, 0)), steps: int = 20):
+    """Try (in_flight, micro_batches[, lane priority]) candidates; returns (best PipelinedRunner, {candidate: s/step})."""
     best, best_t, table = None, float("inf"), {}
-    for in_flight, mb in candidates:
+    for cand in candidates:
+        in_flight, mb = cand[0], cand[1]
+        prio = cand[2] if len(cand) > 2 else 0
         if example.shape[0] % mb:
             continue
-        r = PipelinedRunner(model, example, post, micro_batches=mb, in_flight=in_flight)
+        r = PipelinedRunner(model, example, post, micro_batches=mb, in_flight=in_flight, priority=prio)
         t = r.measure(steps)
-        table[(in_flight, mb)] = t
+        table[(in_flight, mb, prio)] = t
         if t < best_t:
             best, best_t = r, t
     return best, table
