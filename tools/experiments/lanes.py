@@ -9,8 +9,12 @@ dev = torch.device('cuda:0')
 m = DetectionModel('yolov8n.yaml'); P.apply_procedural_weights(m); m = m.to(dev).eval(); m.set_compute_dtype(torch.bfloat16)
 xs = P.synthetic_images(32).to(dev).to(torch.bfloat16).contiguous()
 cfgs = [tuple(int(v) for v in a.split(',')) for a in sys.argv[1:]] or [(32, 3, 2)]
-for (lb, lanes, mb) in cfgs:
+for cfg in cfgs:
+    lb, lanes, mb = cfg[:3]
+    pr = cfg[3] if len(cfg) > 3 else 0
+    sp = cfg[4] if len(cfg) > 4 else 0
     x = xs[:lb].contiguous()
-    r = PipelinedRunner(m, x, post=lambda o: nms_raw(o[0], 0.25, 0.7, max_det=300, key=f"l{lb}{lanes}{mb}"), micro_batches=mb, in_flight=lanes)
+    r = PipelinedRunner(m, x, post=lambda o: nms_raw(o[0], 0.25, 0.7, max_det=300, key=f"l{lb}{lanes}{mb}"), micro_batches=mb, in_flight=lanes,
+                        priority=pr, sub_priority=sp)
     t = r.measure(steps=100 * (32 // lb), warmup=10)
-    print(f"lane batch {lb} lanes {lanes} mb {mb}: {lb / t:9.1f} img/s")
+    print(f"lane batch {lb} lanes {lanes} mb {mb} prio {pr} sub {sp}: {lb / t:9.1f} img/s")

@@ -15,12 +15,14 @@ import torch
 
 
 class PipelinedRunner:
-    def __init__(self, model, example: torch.Tensor, post=None, micro_batches: int = 2, in_flight: int = 2, priority: int = 0):
+    def __init__(self, model, example: torch.Tensor, post=None, micro_batches: int = 2, in_flight: int = 2, priority: int = 0,
+                 sub_priority: int = 0):
         self.model, self.example, self.post = model, example, post
         self.micro_batches, self.in_flight, self.priority = micro_batches, max(1, in_flight), priority
         self.device = example.device
         with torch.no_grad():
-            self.runs = [model.compile(example, post=post, micro_batches=micro_batches) for _ in range(self.in_flight)]
+            self.runs = [model.compile(example, post=post, micro_batches=micro_batches, stream_priority=sub_priority)
+                         for _ in range(self.in_flight)]
         # lane streams; `priority` (0 normal, -1 high) selects the runtime's queue set for them
         self.lanes = [torch.cuda.Stream(device=self.device, priority=priority) for _ in self.runs] if self.in_flight > 1 else [None]
         self.i = 0

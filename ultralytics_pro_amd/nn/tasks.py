@@ -299,7 +299,7 @@ class BaseModel(nn.Module):
         return self
 
     # ---- hipGraph replay -----------------------------------------------------------------------------------------------
-    def compile(self, example: torch.Tensor, post=None, micro_batches: int = 1):
+    def compile(self, example: torch.Tensor, post=None, micro_batches: int = 1, stream_priority: int = 0):
         """Capture `_predict_once(example)` (plus an optional post-processing callable) into a hipGraph.
 
         Returns a callable `run()`: copies nothing - the input is read from `example`'s storage at every replay
@@ -315,7 +315,7 @@ class BaseModel(nn.Module):
             if example.shape[0] % micro_batches:
                 raise L.UpaError("batch must be divisible by micro_batches")
             step = example.shape[0] // micro_batches
-            side = [torch.cuda.Stream(device=example.device) for _ in range(micro_batches)]
+            side = [torch.cuda.Stream(device=example.device, priority=stream_priority) for _ in range(micro_batches)]
 
             def body():
                 main = torch.cuda.current_stream(example.device)
