@@ -51,6 +51,12 @@ class _Ctx:
         # channel-reduction scratch (per-block partial sums + combined sums), sized for c <= 1024
         self.ws = torch.zeros(L.lib().upa_channel_reduce_workspace_bytes(1024) // 8, dtype=torch.float64, device=device)
         self.wgrad_ws = torch.empty(0, dtype=torch.uint8, device=device)  # weight-gradient partial sums (largest layer)
+        # weight gradients run on a side stream (a parallel branch of the captured graph): a layer's dW only needs its
+        # input and dz, so it overlaps the data-gradient / BN-backward chain of the layers in front of it
+        import os
+        self.wgrad_stream = None if os.environ.get("UPA_TRAIN_NO_OVERLAP") else \
+            torch.cuda.Stream(device=device, priority=int(os.environ.get("UPA_WGRAD_PRIO", "0")))
+        self.wgrad_pending = False
 
 
 def _new(n, c, h, w, dtype, dev, key):
@@ -163,10 +169,19 @@ class ConvT:
                                        bn.weight.grad.data_ptr(), bn.bias.grad.data_ptr(), 1, c.ws.data_ptr(), vz.dtype, st),
                     "bn_act_bwd")
         vx, vdz = R.view_of(self.x), R.view_of(dz)
-        L.check(lib.upa_conv2d_wgrad(vx.ptr, vx.n, vx.h, vx.w, self.cin, vx.ld, vdz.ptr, self.cout, vdz.ld,
-                                     self.conv.weight.grad.data_ptr(), self.k, self.s, self.p, 1, vx.dtype,
-                                     c.wgrad_ws.data_ptr(), c.wgrad_ws.numel(), st),
-                f"wgrad[{self.name}]")
+        if c.wgrad_stream is None:
+            L.check(lib.upa_conv2d_wgrad(vx.ptr, vx.n, vx.h, vx.w, self.cin, vx.ld, vdz.ptr, self.cout, vdz.ld,
+                                         self.conv.weight.grad.data_ptr(), self.k, self.s, self.p, 1, vx.dtype,
+                                         c.wgrad_ws.data_ptr(), c.wgrad_ws.numel(), st), f"wgrad[{self.name}]")
+        else:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(c.device))  # dz is ready
+            c.wgrad_stream.wait_event(ev)
+            L.check(lib.upa_conv2d_wgrad(vx.ptr, vx.n, vx.h, vx.w, self.cin, vx.ld, vdz.ptr, self.cout, vdz.ld,
+                                         self.conv.weight.grad.data_ptr(), self.k, self.s, self.p, 1, vx.dtype,
+                                         c.wgrad_ws.data_ptr(), c.wgrad_ws.numel(), c.wgrad_stream.cuda_stream),
+                    f"wgrad[{self.name}]")
+            c.wgrad_pending = True
         if dx is None:
             return
         if self.phase is not None:
@@ -486,7 +501,16 @@ class DetectionTrainer:
                         else:
                             copy_into(ctx, dy[:, c0:c0 + cj], dx)
                         c0 += cj
+            self._join_wgrad()
         return items
+
+    def _join_wgrad(self):
+        ctx = self.ctx
+        if ctx.wgrad_stream is not None and ctx.wgrad_pending:
+            ev = torch.cuda.Event()
+            ev.record(ctx.wgrad_stream)
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            ctx.wgrad_pending = False
 
     def _grad_of(self, node):
         """(gradient buffer of node's output, accumulate?) - the first producer writes, later ones accumulate."""
