@@ -54,8 +54,11 @@ class _Ctx:
         # weight gradients run on a side stream (a parallel branch of the captured graph): a layer's dW only needs its
         # input and dz, so it overlaps the data-gradient / BN-backward chain of the layers in front of it
         import os
-        self.wgrad_stream = None if os.environ.get("UPA_TRAIN_NO_OVERLAP") else \
-            torch.cuda.Stream(device=device, priority=int(os.environ.get("UPA_WGRAD_PRIO", "0")))
+        nws = int(os.environ.get("UPA_WGRAD_STREAMS", "1"))
+        self.wgrad_streams = [] if os.environ.get("UPA_TRAIN_NO_OVERLAP") else \
+            [torch.cuda.Stream(device=device) for _ in range(nws)]
+        self.wgrad_wss = [self.wgrad_ws for _ in self.wgrad_streams]  # one partial-sum workspace per stream
+        self.wgrad_rr = 0
         self.wgrad_pending = False
 
 
@@ -91,6 +94,8 @@ class ConvT:
         nws = L.lib().upa_conv2d_wgrad_workspace_bytes(self.cin, self.cout, self.k)
         if nws > ctx.wgrad_ws.numel():
             ctx.wgrad_ws = torch.empty(nws, dtype=torch.uint8, device=dev)  # shared by all layers (stream ordered)
+            ctx.wgrad_wss = [ctx.wgrad_ws if j == 0 else torch.empty(nws, dtype=torch.uint8, device=dev)
+                             for j in range(len(ctx.wgrad_streams))]
 
     def pack(self):
         lib, c = L.lib(), self.ctx
@@ -169,18 +174,20 @@ class ConvT:
                                        bn.weight.grad.data_ptr(), bn.bias.grad.data_ptr(), 1, c.ws.data_ptr(), vz.dtype, st),
                     "bn_act_bwd")
         vx, vdz = R.view_of(self.x), R.view_of(dz)
-        if c.wgrad_stream is None:
+        if not c.wgrad_streams:
             L.check(lib.upa_conv2d_wgrad(vx.ptr, vx.n, vx.h, vx.w, self.cin, vx.ld, vdz.ptr, self.cout, vdz.ld,
                                          self.conv.weight.grad.data_ptr(), self.k, self.s, self.p, 1, vx.dtype,
                                          c.wgrad_ws.data_ptr(), c.wgrad_ws.numel(), st), f"wgrad[{self.name}]")
         else:
+            j = c.wgrad_rr % len(c.wgrad_streams)
+            c.wgrad_rr += 1
+            side, ws = c.wgrad_streams[j], c.wgrad_wss[j]
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(c.device))  # dz is ready
-            c.wgrad_stream.wait_event(ev)
+            side.wait_event(ev)
             L.check(lib.upa_conv2d_wgrad(vx.ptr, vx.n, vx.h, vx.w, self.cin, vx.ld, vdz.ptr, self.cout, vdz.ld,
                                          self.conv.weight.grad.data_ptr(), self.k, self.s, self.p, 1, vx.dtype,
-                                         c.wgrad_ws.data_ptr(), c.wgrad_ws.numel(), c.wgrad_stream.cuda_stream),
-                    f"wgrad[{self.name}]")
+                                         ws.data_ptr(), ws.numel(), side.cuda_stream), f"wgrad[{self.name}]")
             c.wgrad_pending = True
         if dx is None:
             return
@@ -506,10 +513,11 @@ class DetectionTrainer:
 
     def _join_wgrad(self):
         ctx = self.ctx
-        if ctx.wgrad_stream is not None and ctx.wgrad_pending:
-            ev = torch.cuda.Event()
-            ev.record(ctx.wgrad_stream)
-            torch.cuda.current_stream(self.device).wait_event(ev)
+        if ctx.wgrad_streams and ctx.wgrad_pending:
+            for side in ctx.wgrad_streams:
+                ev = torch.cuda.Event()
+                ev.record(side)
+                torch.cuda.current_stream(self.device).wait_event(ev)
             ctx.wgrad_pending = False
 
     def _grad_of(self, node):
