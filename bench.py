@@ -113,9 +113,10 @@ def main():
             cands = [(f, m) for f in ((args.in_flight,) if args.in_flight else (3, 1, 2))
                      for m in ((args.micro_batches,) if args.micro_batches else (2, 1))]
             if not args.in_flight and not args.micro_batches:
-                cands = [(2, 2, -1), (3, 2, 0), (1, 2, 0), (2, 1, 0), (3, 1, 0)]
+                cands = [(4, 1, 0, 1), (3, 1, 0, 1), (2, 2, -1, 0), (1, 2, 0, 0)]
             runner, table = autotune(model, x, post, candidates=cands)
-            tuned = {f"in_flight={k[0]},micro_batches={k[1]},lane_priority={k[2]}": round(t * 1e3, 4) for k, t in table.items()}
+            tuned = {f"in_flight={k[0]},micro_batches={k[1]},lane_priority={k[2]},linear_graphs={k[3]}": round(t * 1e3, 4)
+                     for k, t in table.items()}
             args.in_flight, args.micro_batches = runner.in_flight, runner.micro_batches
         else:
             runner = PipelinedRunner(model, x, post, micro_batches=args.micro_batches, in_flight=args.in_flight)
@@ -164,8 +165,8 @@ def main():
             "data": "synthetic (procedural images + procedural weights, resident in HBM)",
             "config": {"workload": f"{args.model} detect 640x640 bs={args.batch} {args.dtype} inference, 1 hipGraph/step: "
                                    "forward+decode+NMS(conf .25, iou .7, max_det 300)",
-                       "micro_batches": args.micro_batches, "intra_step_concurrency": not args.serial,
-                       "steps_in_flight": max(1, args.in_flight), "lane_priority": runner.priority, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
+                       "micro_batches": args.micro_batches, "intra_step_concurrency": not (args.serial or runner.linear),
+                       "steps_in_flight": max(1, args.in_flight), "lane_priority": runner.priority, "linear_graphs": runner.linear, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        "autotune_ms_per_step": tuned,
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch, "parallelism": f"dp{world} replicas"},
             "images_per_sec_per_gpu": round(value / world, 1),

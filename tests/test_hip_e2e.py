@@ -168,11 +168,16 @@ def test_e2e_pipelined_runner_copies_equal_single_graph():
         torch.cuda.synchronize()
         out1, cnt1 = out1.clone(), cnt1.clone()
         runner = PipelinedRunner(m, x, post=lambda o: nms_raw(o[0], 0.25, 0.7, key="pipe"), micro_batches=2, in_flight=3)
+        lin = PipelinedRunner(m, x, post=lambda o: nms_raw(o[0], 0.25, 0.7, key="lin"), micro_batches=1, in_flight=4, linear=True)
         for _ in range(7):  # not a multiple of in_flight: the copies end at different points of the rotation
             runner.step()
+            lin.step()
         torch.cuda.synchronize()
-    assert runner.i == 7 and len(runner.results()) == 3
+    assert runner.i == 7 and len(runner.results()) == 3 and len(lin.results()) == 4
+    assert m.model[-1].concurrent  # the linear runner restored the head's concurrency flag
     for parts in runner.results():
         out = torch.cat([p_[0] for p_ in parts], 0)
         cnt = torch.cat([p_[1] for p_ in parts], 0)
+        assert torch.equal(cnt, cnt1) and torch.equal(out, out1)
+    for (out, cnt, _) in lin.results():  # linear copies: one graph, whole batch
         assert torch.equal(cnt, cnt1) and torch.equal(out, out1)

@@ -7,6 +7,8 @@ from ultralytics_pro_amd.utils.nms import nms_raw
 from ultralytics_pro_amd.engine.pipeline import PipelinedRunner
 dev = torch.device('cuda:0')
 m = DetectionModel('yolov8n.yaml'); P.apply_procedural_weights(m); m = m.to(dev).eval(); m.set_compute_dtype(torch.bfloat16)
+import os
+if os.environ.get('SERIAL_HEAD'): m.model[-1].concurrent = False
 xs = P.synthetic_images(32).to(dev).to(torch.bfloat16).contiguous()
 cfgs = [tuple(int(v) for v in a.split(',')) for a in sys.argv[1:]] or [(32, 3, 2)]
 for cfg in cfgs:

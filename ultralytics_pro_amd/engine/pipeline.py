@@ -16,13 +16,24 @@ import torch
 
 class PipelinedRunner:
     def __init__(self, model, example: torch.Tensor, post=None, micro_batches: int = 2, in_flight: int = 2, priority: int = 0,
-                 sub_priority: int = 0):
+                 sub_priority: int = 0, linear: bool = False):
         self.model, self.example, self.post = model, example, post
         self.micro_batches, self.in_flight, self.priority = micro_batches, max(1, in_flight), priority
         self.device = example.device
-        with torch.no_grad():
-            self.runs = [model.compile(example, post=post, micro_batches=micro_batches, stream_priority=sub_priority)
-                         for _ in range(self.in_flight)]
+        # linear: every copy is ONE chain of launches (no forks inside the graph: Detect branches stay on the capture
+        # stream) - the copies, one stream each, are the only concurrency, which maps cleanly onto the hardware queues
+        self.linear = bool(linear)
+        det = model.model[-1]
+        saved = getattr(det, "concurrent", None)
+        if self.linear and saved is not None:
+            det.concurrent = False
+        try:
+            with torch.no_grad():
+                self.runs = [model.compile(example, post=post, micro_batches=micro_batches, stream_priority=sub_priority)
+                             for _ in range(self.in_flight)]
+        finally:
+            if self.linear and saved is not None:
+                det.concurrent = saved
         # lane streams; `priority` (0 normal, -1 high) selects the runtime's queue set for them
         self.lanes = [torch.cuda.Stream(device=self.device, priority=priority) for _ in self.runs] if self.in_flight > 1 else [None]
         self.i = 0
@@ -50,17 +61,18 @@ class PipelinedRunner:
         return (time.perf_counter() - t0) / steps
 
 
-def autotune(model, example, post=None, candidates=((3, 2, 0), (2, 2, -1), (1, 2, 0), (2, 1, 0)), steps: int = 20):
-    """Try (in_flight, micro_batches[, lane priority]) candidates; returns (best PipelinedRunner, {candidate: s/step})."""
+def autotune(model, example, post=None, candidates=((4, 1, 0, 1), (2, 2, -1, 0), (3, 2, 0, 0), (1, 2, 0, 0)), steps: int = 20):
+    """Try (in_flight, micro_batches, lane priority, linear) candidates; returns (best runner, {candidate: s/step})."""
     best, best_t, table = None, float("inf"), {}
     for cand in candidates:
         in_flight, mb = cand[0], cand[1]
         prio = cand[2] if len(cand) > 2 else 0
+        linear = bool(cand[3]) if len(cand) > 3 else False
         if example.shape[0] % mb:
             continue
-        r = PipelinedRunner(model, example, post, micro_batches=mb, in_flight=in_flight, priority=prio)
+        r = PipelinedRunner(model, example, post, micro_batches=mb, in_flight=in_flight, priority=prio, linear=linear)
         t = r.measure(steps)
-        table[(in_flight, mb, prio)] = t
+        table[(in_flight, mb, prio, int(linear))] = t
         if t < best_t:
             best, best_t = r, t
     return best, table
