@@ -146,7 +146,11 @@ def main():
 
     roofline, kernels, cpu_baseline = None, None, None
     if rank == 0:
+        if os.environ.get("UPA_BENCH_TRACE"):
+            print("[bench] timed region done", file=sys.stderr, flush=True)
         roofline, kernels = kernel_profile(model, x, dtype, dev, args, pconv, L, post)
+        if os.environ.get("UPA_BENCH_TRACE"):
+            print("[bench] kernel profile done", file=sys.stderr, flush=True)
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
             cpu_baseline = run_cpu_baseline(args)
     if rank == 0:

@@ -9,6 +9,8 @@ streams overlap depends on how the HIP runtime maps them onto hardware queues (G
 
 from __future__ import annotations
 
+import os
+import sys
 import time
 
 import torch
@@ -35,15 +37,13 @@ class PipelinedRunner:
             if self.linear and saved is not None:
                 det.concurrent = saved
         # lane streams; `priority` (0 normal, -1 high) selects the runtime's queue set for them
-        self.lanes = [torch.cuda.Stream(device=self.device, priority=priority) for _ in self.runs] if self.in_flight > 1 else [None]
+        self.lanes = [torch.cuda.Stream(device=self.device, priority=priority) for _ in self.runs]
         self.i = 0
 
     def step(self):
         """Enqueue one batch; returns the (static) result object of the copy that ran it - valid after a synchronize."""
         k = self.i % self.in_flight
         self.i += 1
-        if self.lanes[k] is None:
-            return self.runs[k]()
         with torch.cuda.stream(self.lanes[k]):
             return self.runs[k]()
 
@@ -61,6 +61,11 @@ class PipelinedRunner:
         return (time.perf_counter() - t0) / steps
 
 
+def _trace(msg):
+    if os.environ.get("UPA_BENCH_TRACE"):
+        print(f"[pipeline] {msg}", file=sys.stderr, flush=True)
+
+
 def autotune(model, example, post=None, candidates=((4, 1, 0, 1), (2, 2, -1, 0), (3, 2, 0, 0), (1, 2, 0, 0)), steps: int = 20):
     """Try (in_flight, micro_batches, lane priority, linear) candidates; returns (best runner, {candidate: s/step})."""
     best, best_t, table = None, float("inf"), {}
@@ -70,8 +75,11 @@ def autotune(model, example, post=None, candidates=((4, 1, 0, 1), (2, 2, -1, 0),
         linear = bool(cand[3]) if len(cand) > 3 else False
         if example.shape[0] % mb:
             continue
+        _trace(f"candidate {cand}: compile")
         r = PipelinedRunner(model, example, post, micro_batches=mb, in_flight=in_flight, priority=prio, linear=linear)
+        _trace(f"candidate {cand}: measure")
         t = r.measure(steps)
+        _trace(f"candidate {cand}: {t * 1e3:.3f} ms")
         table[(in_flight, mb, prio, int(linear))] = t
         if t < best_t:
             best, best_t = r, t

@@ -108,12 +108,20 @@ def static_buffers(pool: BufferPool):
         _POOL[0] = prev
 
 
+def _unkeyed(what):
+    """An allocation without a key while static buffers are active would be freed after graph capture and leave the
+    captured launches with a dangling pointer: refuse it."""
+    raise L.UpaError(f"unkeyed allocation {what} inside static_buffers(): every buffer of a captured step needs a key")
+
+
 def alloc_nhwc(n: int, c: int, h: int, w: int, dtype: torch.dtype, device, key=None) -> torch.Tensor:
     """New NHWC buffer returned as a logical (N, C, H, W) tensor."""
     pool = _POOL[0]
     if pool is not None and key is not None:
         buf = pool.get((_TAG[0], key), (n, h, w, c), dtype, device)
     else:
+        if pool is not None:
+            _unkeyed(("nhwc", n, c, h, w))
         buf = torch.empty((n, h, w, c), dtype=dtype, device=device)
     return buf.permute(0, 3, 1, 2)
 
@@ -122,6 +130,8 @@ def alloc_plain(shape, dtype, device, key=None) -> torch.Tensor:
     pool = _POOL[0]
     if pool is not None and key is not None:
         return pool.get((_TAG[0], key), tuple(shape), dtype, device)
+    if pool is not None:
+        _unkeyed(("plain",) + tuple(shape))
     return torch.empty(tuple(shape), dtype=dtype, device=device)
 
 
@@ -179,7 +189,19 @@ class HipGraph:
         return out
 
     def replay(self, device=None):
-        L.check(L.lib().upa_graph_launch(self.exec, L.current_stream(device)), "graph_launch")
+        """Launch the instantiated graph in stream order with the caller's current stream.
+
+        Never on the null stream: replaying a graph with parallel branches there and graphs on other streams afterwards
+        ended in GPU memory-access faults on ROCm 7.2 (tools/experiments/fault_bisect.sh: 1-2 of 6 processes survive;
+        6 of 6 with every launch on a created stream) - from the null stream the launch goes to the capture stream,
+        ordered before and after by stream waits."""
+        cur = torch.cuda.current_stream(device)
+        if cur.cuda_stream == 0:
+            self.stream.wait_stream(cur)
+            L.check(L.lib().upa_graph_launch(self.exec, self.stream.cuda_stream), "graph_launch")
+            cur.wait_stream(self.stream)
+        else:
+            L.check(L.lib().upa_graph_launch(self.exec, cur.cuda_stream), "graph_launch")
 
     def __del__(self):
         try:
