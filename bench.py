@@ -49,6 +49,8 @@ def parse():
                          "own graph and static buffers), so the NMS tail of step k overlaps the convolutions of step k+1. "
                          "0 = autotune: a few (in-flight, micro-batches) pairs are timed for 20 steps, the fastest is used")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-profile", action="store_true",
+                    help="skip the per-layer roofline timing (counter-collection runs: tools/pmc_step.sh)")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--serial", action="store_true",
@@ -148,7 +150,8 @@ def main():
     if rank == 0:
         if os.environ.get("UPA_BENCH_TRACE"):
             print("[bench] timed region done", file=sys.stderr, flush=True)
-        roofline, kernels = kernel_profile(model, x, dtype, dev, args, pconv, L, post)
+        if not args.no_kernel_profile:
+            roofline, kernels = kernel_profile(model, x, dtype, dev, args, pconv, L, post)
         if os.environ.get("UPA_BENCH_TRACE"):
             print("[bench] kernel profile done", file=sys.stderr, flush=True)
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
@@ -407,7 +410,9 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
                         f"void stem_conv_kernel<{tname}, 16, {'true' if act == 1 else 'false'}>(StemParams)")
             else:
                 var = L.lib().upa_conv_variant(n, h, w, cin, pk.cout, pk.k, stride, pad, code)
-                if (var >> 21) & 1:  # software-pipelined 3x3 (conv_pipe.hip): <NTW, act, residual>
+                if (var >> 22) & 1:  # streaming pointwise kernel (conv1x1.hip): <NTW, MT, WAVES>
+                    name = "void conv1x1_stream_kernel<%d, %d, %d>(C1Params)" % (var & 15, (var >> 4) & 15, (var >> 8) & 31)
+                elif (var >> 21) & 1:  # software-pipelined 3x3 (conv_pipe.hip): <NTW, act, residual>
                     name = "void conv3x3_pipe_kernel<%d, %d, %s>(PipeParams)" % (
                         var & 15, act, "true" if residual is not None else "false")
                 else:

@@ -104,6 +104,44 @@ def test_conv_pipe_kernel(case):
     assert err <= 3e-2 * max(1.0, ref.abs().max().item()), err
 
 
+C1_CASES = [
+    # c1, c2, H, W, N, act, env  (1x1 s1: the streaming pointwise kernel, csrc/conv1x1.hip)
+    (64, 64, 16, 16, 2, True, {}),                                   # KTT 2, NTW 4
+    (48, 32, 9, 7, 3, True, {}),                                     # 189 pixels: ragged last tile; Cin 48: half a k-tile
+    (80, 80, 20, 20, 2, False, {}),                                  # NTW 5 (odd tail store), KTT 3 partial, no activation
+    (384, 256, 10, 10, 2, True, {}),                                 # 16 n-tiles: two workgroup rows of 8; KTT 12
+    (192, 128, 12, 20, 1, True, {"UPA_C1_MT": "2", "UPA_C1_WAVES": "8"}),
+    (32, 32, 40, 48, 2, True, {"UPA_C1_MT": "4", "UPA_C1_WGS": "3"}),   # many rounds per persistent wave, ring wraps
+    (32, 16, 33, 9, 1, True, {"UPA_C1_MT": "4", "UPA_C1_WGS": "2"}),    # KTT 1: an epilogue every step (store counting)
+    (128, 192, 8, 8, 1, False, {"UPA_C1_MT": "2", "UPA_C1_WGS": "1"}),  # 12 n-tiles: second row half masked
+    (256, 128, 5, 5, 1, True, {"UPA_C1_WAVES": "4"}),                # KTT 8 = the whole ring of an MT 1 wave
+    (96, 64, 30, 30, 1, True, {"UPA_C1_MT": "1", "UPA_C1_WAVES": "4", "UPA_C1_WGS": "2"}),
+]
+
+
+@pytest.mark.parametrize("case", C1_CASES, ids=[f"c{c[0]}-{c[1]}_{c[2]}x{c[3]}n{c[4]}{'' if c[5] else '_lin'}{'_' + '_'.join(v for v in c[6].values()) if c[6] else ''}" for c in C1_CASES])
+def test_conv1x1_stream_kernel(case, monkeypatch):
+    """bf16 pointwise convs through the streaming kernel vs the oracle Conv (conv.py:188-197) on bf16-rounded inputs:
+    ragged pixel counts, partial k-tiles, odd / split / masked output-channel tiles, every (MT, waves) shape of the
+    kernel and few workgroups (many ring rounds per wave: the counted vmcnt waits)."""
+    from tests.hip_utils import bf16_round, to_cpu_nchw, to_dev_nhwc
+    from ultralytics_pro_amd import _lib as L
+    pm, _ = _mods()
+    c1, c2, H, W, N, act, env = case
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    var = L.lib().upa_conv_variant(N, H, W, c1, c2, 1, 1, 0, 1)
+    assert (var >> 22) & 1, "case is not dispatched to the streaming 1x1 kernel"
+    o, m = _pair(om.Conv, pm.Conv, (c1, c2, 1, 1, None, 1, 1, act), "conv1x1")
+    x = bf16_round(P.uniform(f"c1{case[:5]}", (N, c1, H, W), -1, 1))
+    with torch.no_grad():
+        ref = o(x)
+        y = to_cpu_nchw(m(to_dev_nhwc(x, torch.bfloat16)))
+    assert y.shape == ref.shape
+    err = (y - ref).abs().max().item()
+    assert err <= 3e-2 * max(1.0, ref.abs().max().item()), err
+
+
 def test_conv_pipe_residual_and_concat_views():
     """Bottleneck (block.py:644-668) with shortcut inside a C2f: residual add fused in the pipelined kernel's epilogue,
     input / output / residual are channel slices of wider concat buffers (ld > C)."""

@@ -804,6 +804,13 @@ extern "C" int upa_conv2d_bias_act(const void* x, int n, int h, int w, int cin, 
     q.N = n; q.H = h; q.W = w; q.Cin = cin; q.ldx = ldx; q.Cout = cout; q.ldy = ldy; q.ldr = ldr; q.act = act;
     return upa_conv_pipe_launch(q, g_query_only, &g_last_variant, stream);
   }
+  if (upa_conv1x1_eligible(n, h, w, cin, ldx, cout, ldy, residual != nullptr, k, stride, pad, act, dtype)) {
+    C1Params q;
+    memset(&q, 0, sizeof(q));
+    q.x = (const char*)x; q.y = (char*)y; q.w = (const char*)w_packed; q.bias = bias;
+    q.Cin = cin; q.ldx = ldx; q.Cout = cout; q.ldy = ldy; q.act = act;
+    return upa_conv1x1_launch(q, n * h * w, g_query_only, &g_last_variant, stream);
+  }
   ConvParams p;
   memset(&p, 0, sizeof(p));
   p.x = (const char*)x; p.y = (char*)y; p.res = (const char*)residual; p.w = (const char*)w_packed; p.bias = bias;

@@ -1,0 +1,329 @@
+// Streaming pointwise (1x1, stride 1) convolution for gfx950, bf16 perf mode: C2f cv1 / cv2, SPPF cv1 / cv2 and the
+// final 1x1 of every Detect branch (Conv.forward_fuse, ultralytics/nn/modules/conv.py:188-197 with BN folded per
+// utils/torch_utils.py:236-266; nn.Conv2d(c, 4*reg_max | nc, 1) of head.py:94-100).  Same math and packed-weight layout as
+// conv.hip; a 1x1 conv is a GEMM [pixels x Cin] x [Cin x Cout] at 30-130 FLOP/B, i.e. HBM-bound on MI355X, so the kernel
+// is built like a copy engine with MFMAs attached:
+//   * the (n, h, w) pixels of an NHWC view have one uniform stride, so the image is a flat list of 16-pixel tiles; a wave
+//     is a persistent worker that owns groups of MT tiles x all NTW*16 output channels of its workgroup - every input
+//     byte is fetched once per workgroup row, nothing is staged twice;
+//   * input tiles go global -> LDS by LDS-DMA straight into MFMA B-fragment order (lane (p, g) fetches the 16 bytes of
+//     pixel p, channel group g: the LDS image of a (tile, k-tile) is 1 KiB lane-linear, read back by one conflict-free
+//     ds_read_b128), into a wave-private ring of three (group, k-tile) stages: two stages are always in flight while the
+//     third is multiplied, with COUNTED s_waitcnt vmcnt(N) - loads, LDS-DMAs and stores retire in issue order, so N is
+//     the number of vector-memory instructions this wave issued after the stage it needs (tracked in a scalar);
+//   * the workgroup's weight slice (KTT x NTW KiB, A-fragment order) is DMA'd into LDS once; A fragments are re-read from
+//     LDS per k-tile and reused over the MT pixel tiles;
+//   * no workgroup barrier after the weight fill, no per-tile index arithmetic beyond one multiply per (tile, group);
+//   * epilogue from the accumulators: bias, SiLU, bf16 pack, v_permlane16_swap pairs channel quads into 16-byte stores.
+#include <stdlib.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "common.h"
+#include "conv_pipe.h"
+
+typedef __attribute__((address_space(1))) const void* c1gptr_t;
+typedef __attribute__((address_space(3))) void* c1lptr_t;
+
+__device__ __attribute__((aligned(16))) unsigned g_c1_zero16[4] = {0u, 0u, 0u, 0u};
+
+namespace {
+// stages of the wave-private input ring: two stages (of MT KiB) are in flight per wave while the third is multiplied.
+// Measured on MI355X (bs 32 yolov8n layers): 4 stages at MT 2 and 8 at MT 1 were slower wherever the bigger ring cost a
+// co-resident workgroup (192->128 @40x40: 15.5 vs 13.4 us) and equal elsewhere - occupancy, not ring depth, hides latency.
+constexpr int ring_of(int) { return 3; }
+
+template <class F, int... Is>
+__device__ __forceinline__ void for_stages(F& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+
+// s_waitcnt takes an immediate: uniform compare tree over the possible counts (a smaller count than necessary is safe)
+__device__ __forceinline__ void vm_wait(int n) {
+#define UPA_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+  switch (n) {
+    UPA_W(0) UPA_W(1) UPA_W(2) UPA_W(3) UPA_W(4) UPA_W(5) UPA_W(6) UPA_W(7) UPA_W(8) UPA_W(9) UPA_W(10) UPA_W(11)
+    UPA_W(12) UPA_W(13) UPA_W(14) UPA_W(15) UPA_W(16) UPA_W(17) UPA_W(18) UPA_W(19) UPA_W(20) UPA_W(21) UPA_W(22)
+    UPA_W(23) UPA_W(24) UPA_W(25) UPA_W(26) UPA_W(27) UPA_W(28) UPA_W(29) UPA_W(30) UPA_W(31) UPA_W(32) UPA_W(33)
+    UPA_W(34) UPA_W(35) UPA_W(36) UPA_W(37) UPA_W(38) UPA_W(39) UPA_W(40) UPA_W(41) UPA_W(42) UPA_W(43) UPA_W(44)
+    UPA_W(45) UPA_W(46) UPA_W(47) UPA_W(48)
+    default: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
+  }
+#undef UPA_W
+}
+}  // namespace
+
+template <int NTW, int MT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void conv1x1_stream_kernel(const C1Params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int RING = ring_of(MT);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int p16 = lane & 15, kg = lane >> 4;
+  const int nt0 = blockIdx.y * NTW;
+  char* wl = smem;                                                   // weights [kt][j][lane][16 B]
+  char* ring = smem + p.KTT * NTW * 1024 + wave * (RING * MT * 1024);  // wave-private input stages
+  float* bl = reinterpret_cast<float*>(smem + p.KTT * NTW * 1024 + WAVES * (RING * MT * 1024));  // bias slice
+
+  const int gw = blockIdx.x * WAVES + wave, GW = gridDim.x * WAVES;
+  const int ldx2 = p.ldx * 2, ldy2 = p.ldy * 2;
+  const int ngrpAll = p.Cin >> 3;  // valid 16-byte channel groups of a pixel
+
+  // ---- issue side: DMA of unit (group ig, k-tile ikt) into a ring stage; `seq` counts this wave's vector-memory
+  // instructions, mark[s] = seq right after stage s was requested
+  int seq = 0;
+  int mark[RING];
+  int ig = gw, ikt = 0;
+  unsigned ioff[MT];  // byte offset of this lane's pixel in each tile of the issue group (0xffffffff: past the end)
+  auto issue_group = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int pix = (ig * MT + i) * 16 + p16;
+      ioff[i] = pix < p.P ? (unsigned)pix * (unsigned)ldx2 + (unsigned)(kg * 16) : 0xffffffffu;
+    }
+  };
+  issue_group();
+  auto issue = [&](int stage) __attribute__((always_inline)) {
+    if (ig < p.groups) {
+      const bool chok = kg < ngrpAll - ikt * 4;
+      const char* xk = p.x + ikt * 64;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const char* src = (chok && ioff[i] != 0xffffffffu && !(p.ablate & 1)) ? xk + ioff[i]
+                                                                            : reinterpret_cast<const char*>(g_c1_zero16);
+        __builtin_amdgcn_global_load_lds((c1gptr_t)src, (c1lptr_t)(ring + (stage * MT + i) * 1024), 16, 0, 0);
+      }
+      seq += MT;
+      if (++ikt == p.KTT) {
+        ikt = 0;
+        ig += GW;
+        issue_group();
+      }
+    }
+    mark[stage] = seq;
+  };
+
+  f32x4 acc[MT][NTW];
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  zero_acc();
+
+  auto epilogue = [&](int g, auto act_tag) __attribute__((always_inline)) {
+    constexpr int ACT = decltype(act_tag)::value;
+    auto act = [](float v) __attribute__((always_inline)) {
+      if constexpr (ACT == UPA_ACT_SILU) return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+      else return v;
+    };
+    const int co0 = nt0 * 16;
+    f32x4 biasv[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) biasv[j] = *reinterpret_cast<const f32x4*>(bl + j * 16 + kg * 4);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int tb = (g * MT + i) * 16;  // uniform
+      if (tb >= p.P) continue;
+      const int pix = tb + p16;
+      const bool pok = pix < p.P && !(p.ablate & 4);
+      char* yrow = p.y + ((size_t)pix * ldy2 + co0 * 2);
+#pragma unroll
+      for (int j = 0; j + 1 < NTW; j += 2) {
+        if (nt0 + j >= p.NTn) continue;  // uniform
+        // 16-lane row kg holds channels 16j+4kg..+3 (tile j) and 16(j+1)+4kg..+3 (tile j+1); after the swap even rows
+        // own 8 consecutive channels of tile j, odd rows 8 of tile j+1
+        const int cb = 16 * (j + (kg & 1)) + 8 * (kg >> 1);
+        float v0[4], v1[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          v0[q] = act(acc[i][j][q] + biasv[j][q]);
+          v1[q] = act(acc[i][j + 1][q] + biasv[j + 1][q]);
+        }
+        auto lo = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v1[0], v1[1]), false, false);
+        auto hi = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[2], v1[3]), false, false);
+        if (pok && co0 + cb < p.Cout) *reinterpret_cast<u32x4*>(yrow + cb * 2) = u32x4{lo[0], hi[0], lo[1], hi[1]};
+        ++seq;  // lane (pixel tb, kg 0) is always active here: the store is certainly issued
+      }
+      if constexpr (NTW & 1) {
+        constexpr int j = NTW - 1;
+        if (nt0 + j < p.NTn) {
+          const int cb = 16 * j + 4 * kg;
+          float v[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = act(acc[i][j][q] + biasv[j][q]);
+          if (pok && co0 + cb < p.Cout)
+            *reinterpret_cast<u32x2*>(yrow + cb * 2) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          ++seq;
+        }
+      }
+    }
+  };
+
+  // ---- compute side
+  int cg = gw, ckt = 0;
+  bool running = true;
+  auto step = [&](auto stage_tag) __attribute__((always_inline)) {
+    constexpr int S = decltype(stage_tag)::value;
+    issue((S + RING - 1) % RING);  // the stage multiplied one step ago is free again
+    vm_wait(seq - mark[S]);
+    if (!(p.ablate & 8)) {
+      const char* st = ring + S * MT * 1024 + lane * 16;
+      const char* wk = wl + ckt * (NTW * 1024) + lane * 16;
+      u32x4 b[MT], a[NTW];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) b[i] = *reinterpret_cast<const u32x4*>(st + i * 1024);
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) a[j] = *reinterpret_cast<const u32x4*>(wk + j * 1024);
+#pragma unroll
+      for (int j = 0; j < NTW; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a[j]),
+                                                              *reinterpret_cast<const bf16x8*>(&b[i]), acc[i][j], 0, 0, 0);
+    }
+    if (++ckt == p.KTT) {
+      if (p.act == UPA_ACT_SILU) epilogue(cg, std::integral_constant<int, UPA_ACT_SILU>{});
+      else epilogue(cg, std::integral_constant<int, UPA_ACT_NONE>{});
+      zero_acc();
+      ckt = 0;
+      cg += GW;
+      running = cg < p.groups;
+    }
+  };
+  // the first input stages leave before the weights: one memory round trip for both
+  auto first = [&](auto stage_tag) __attribute__((always_inline)) { issue(decltype(stage_tag)::value); };
+  for_stages(first, std::make_integer_sequence<int, RING - 1>{});
+  // ---- weight slice -> LDS (once per workgroup); n-tiles past the packed weights read zeros
+  for (int q = wave; q < p.KTT * NTW; q += WAVES) {
+    const int kt = q / NTW, j = q - kt * NTW;
+    const char* src = reinterpret_cast<const char*>(g_c1_zero16);
+    if (nt0 + j < p.NTn && !(p.ablate & 2)) src = p.w + ((size_t)(kt * p.NTn + nt0 + j) * 1024 + lane * 16);
+    __builtin_amdgcn_global_load_lds((c1gptr_t)src, (c1lptr_t)(wl + q * 1024), 16, 0, 0);
+  }
+  // bias slice -> LDS (read back per epilogue: keeps NTW*4 registers free for the accumulators)
+  if (threadIdx.x < NTW * 16) {
+    const int co = nt0 * 16 + threadIdx.x;
+    bl[threadIdx.x] = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  if (gw >= p.groups) return;
+  auto guarded = [&](auto stage_tag) __attribute__((always_inline)) {
+    if (running) step(stage_tag);
+  };
+  while (running) for_stages(guarded, std::make_integer_sequence<int, RING>{});
+}
+
+namespace {
+
+template <int NTW, int MT, int WAVES>
+int launch_c1_inst(const C1Params& p, dim3 grid, size_t lds, hipStream_t s) {
+  auto kern = conv1x1_stream_kernel<NTW, MT, WAVES>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, s, p);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+template <int NTW>
+int launch_c1_ntw(const C1Params& p, int mt, int waves, dim3 grid, size_t lds, hipStream_t s) {
+  if (waves == 8) {
+    if (mt == 4) return launch_c1_inst<NTW, 4, 8>(p, grid, lds, s);
+    if (mt == 2) return launch_c1_inst<NTW, 2, 8>(p, grid, lds, s);
+    return launch_c1_inst<NTW, 1, 8>(p, grid, lds, s);
+  }
+  if (mt == 4) return launch_c1_inst<NTW, 4, 4>(p, grid, lds, s);
+  if (mt == 2) return launch_c1_inst<NTW, 2, 4>(p, grid, lds, s);
+  return launch_c1_inst<NTW, 1, 4>(p, grid, lds, s);
+}
+
+int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+}  // namespace
+
+bool upa_conv1x1_eligible(int n, int h, int w, int cin, int ldx, int cout, int ldy, bool residual, int k, int stride,
+                          int pad, int act, int dtype) {
+  static const bool off = getenv("UPA_CONV_NO_1X1") != nullptr;
+  if (off) return false;
+  if (dtype != UPA_BF16 || k != 1 || stride != 1 || pad != 0 || residual) return false;
+  if (act != UPA_ACT_SILU && act != UPA_ACT_NONE) return false;
+  if (cin % 8 != 0 || cout % 8 != 0 || ldx % 8 != 0 || ldy % 8 != 0) return false;
+  const long px = (long)n * h * w;
+  if (px * ldx * 2 >= (1L << 31) - 4096 || px * ldy * 2 >= (1L << 31) - 4096) return false;  // 32-bit byte offsets
+  const int ktt = (cin + 31) / 32;
+  const int ntw = cout > 128 ? 8 : (cout + 15) / 16;
+  if ((size_t)ktt * ntw * 1024 + 4 * ring_of(1) * 1024 + 512 > 160 * 1024) return false;  // weight slice + the smallest ring
+  return true;
+}
+
+int upa_conv1x1_launch(C1Params p, int n_pixels, int query_only, int* variant, void* stream) {
+  p.P = n_pixels;
+  p.KTT = (p.Cin + 31) / 32;
+  p.NTn = (p.Cout + 15) / 16;
+  static const int ablate = env_int("UPA_C1_ABLATE", 0);
+  p.ablate = ablate;
+  const int ntw = p.NTn > 8 ? 8 : p.NTn;
+  const int gridY = (p.NTn + ntw - 1) / ntw;
+  const size_t wbytes = (size_t)p.KTT * ntw * 1024;
+  const int tiles = (p.P + 15) / 16;
+  static int numCU = 0;
+  if (!numCU) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&numCU, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || numCU <= 0) numCU = 256;
+  }
+  // pixel tiles per wave and step: enough groups that every SIMD of the chip has a few to pipeline
+  const int f_mt = env_int("UPA_C1_MT", 0), f_waves = env_int("UPA_C1_WAVES", 0), f_wgs = env_int("UPA_C1_WGS", 0);  // tuning / tests
+  int mt = tiles >= 8192 ? 4 : (tiles >= 2048 ? 2 : 1);
+  if (mt * ntw > 32) mt = 32 / ntw;  // accumulator budget: MT * NTW tiles of 4 registers
+  if (mt == 3) mt = 2;
+  int waves = 8;
+  if (f_mt) mt = f_mt;
+  if (f_waves) waves = f_waves;
+  if (waves != 4) waves = 8;
+  auto lds_of = [&]() { return wbytes + (size_t)waves * ring_of(mt) * mt * 1024 + 512; };
+  size_t lds = lds_of();
+  while (lds > 160 * 1024 && mt > 1) { mt >>= 1; lds = lds_of(); }
+  while (lds > 160 * 1024 && waves > 4) { waves >>= 1; lds = lds_of(); }
+  if (lds > 160 * 1024) { upa_set_error("conv1x1: weight slice does not fit LDS"); return UPA_EUNSUPPORTED; }
+  p.groups = (tiles + mt - 1) / mt;
+  int perCU = (int)((160 * 1024) / lds);
+  const int waveCap = 32 / waves;  // 8 waves per SIMD
+  if (perCU > waveCap) perCU = waveCap;
+  if (perCU > 4) perCU = 4;
+  if (perCU < 1) perCU = 1;
+  int gx = (p.groups + waves - 1) / waves;
+  int cap = numCU * perCU / gridY;
+  if (f_wgs) cap = f_wgs;
+  if (cap < 1) cap = 1;
+  if (gx > cap) {
+    // equal rounds for every wave: ceil(groups / (rounds * waves)) workgroups
+    const int rounds = (p.groups + cap * waves - 1) / (cap * waves);
+    gx = (p.groups + rounds * waves - 1) / (rounds * waves);
+  }
+  if (variant) *variant = (1 << 22) | (waves << 8) | (mt << 4) | ntw;
+  if (query_only) return UPA_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)gx, (unsigned)gridY);
+  switch (ntw) {
+    case 1: return launch_c1_ntw<1>(p, mt, waves, grid, lds, s);
+    case 2: return launch_c1_ntw<2>(p, mt, waves, grid, lds, s);
+    case 3: return launch_c1_ntw<3>(p, mt, waves, grid, lds, s);
+    case 4: return launch_c1_ntw<4>(p, mt, waves, grid, lds, s);
+    case 5: return launch_c1_ntw<5>(p, mt, waves, grid, lds, s);
+    case 6: return launch_c1_ntw<6>(p, mt, waves, grid, lds, s);
+    case 7: return launch_c1_ntw<7>(p, mt, waves, grid, lds, s);
+    default: return launch_c1_ntw<8>(p, mt, waves, grid, lds, s);
+  }
+}

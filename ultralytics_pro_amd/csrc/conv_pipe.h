@@ -16,3 +16,20 @@ bool upa_conv_pipe_eligible(int n, int h, int w, int cin, int ldx, int cout, int
                             int act, int dtype);
 // variant (if non-null) receives (1 << 21) | NTW of the first launch; query_only = 1 skips the launches
 int upa_conv_pipe_launch(PipeParams p, int query_only, int* variant, void* stream);
+
+// ---- conv1x1.hip: streaming pointwise convolution (bf16, k1 s1 p0, no residual)
+struct C1Params {
+  const char* x;
+  char* y;
+  const char* w;       // packed [ktile][ntile][lane][16 B]
+  const float* bias;
+  int P;               // pixels (n*h*w): an NHWC view has one uniform pixel stride
+  int Cin, ldx, Cout, ldy;
+  int KTT, NTn, groups;
+  int act;
+  int ablate;  // debug (UPA_C1_ABLATE): 1 no input DMA, 2 no weight loads, 4 no stores, 8 no MFMA
+};
+bool upa_conv1x1_eligible(int n, int h, int w, int cin, int ldx, int cout, int ldy, bool residual, int k, int stride,
+                          int pad, int act, int dtype);
+// variant (if non-null) receives (1 << 22) | waves << 8 | MT << 4 | NTW; query_only = 1 skips the launch
+int upa_conv1x1_launch(C1Params p, int n_pixels, int query_only, int* variant, void* stream);
