@@ -31,5 +31,6 @@ summary = {"command": "tools/pmc_hbm.sh = rocprofv3 --pmc FETCH_SIZE | --pmc WRI
            "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request -> doubled (MI355X_MICROARCH.md HBM); WRITE_SIZE exact; both in KB",
            "config": "yolov8n bs=32 bf16", "kernels": kern}
 json.dump(summary, open("profiles/r01_pmc_hbm_summary.json", "w"), indent=1)
+json.dump(summary, open(f"{out}/summary.json", "w"), indent=1)  # gpurun merges gpurun_out/ back, not profiles/
 print("kernels:", len(kern))
 PY

@@ -72,6 +72,7 @@ __device__ __forceinline__ float act_fn(float v) {
 template <typename T, int WM, int WN, int MTW, int NTW, int CKT>
 __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (p.ablate & 32) return;  // debug: launch + workgroup dispatch only
   constexpr int ES = sizeof(T);
   constexpr int E = 16 / ES;      // elements per 16 bytes
   constexpr int KT_CH = 64 / ES;  // channels per k-tile
@@ -340,6 +341,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
 template <typename T, int WM, int WN, int MTW, int NTW, int KTT>
 __global__ __launch_bounds__(WM* WN * 64) void conv_ws_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (p.ablate & 32) return;  // debug: launch + workgroup dispatch only
   constexpr int ES = sizeof(T);
   constexpr int E = 16 / ES;
   constexpr int NTHREADS = WM * WN * 64;

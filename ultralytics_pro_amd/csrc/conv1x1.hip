@@ -57,6 +57,7 @@ __device__ __forceinline__ void vm_wait(int n) {
 template <int NTW, int MT, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void conv1x1_stream_kernel(const C1Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (p.ablate & 32) return;  // debug: launch + workgroup dispatch only
   constexpr int RING = ring_of(MT);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

@@ -41,6 +41,7 @@ constexpr int WAVES = 4;
 template <int NTW, int ACT, bool RES>
 __global__ __launch_bounds__(WAVES * 64, 1) void conv3x3_pipe_kernel(const PipeParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (p.ablate & 32) return;  // debug: launch + workgroup dispatch only
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   char* hb = smem + wave * (2 * HB);  // wave-private double buffer

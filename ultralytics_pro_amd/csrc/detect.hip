@@ -89,11 +89,12 @@ __global__ __launch_bounds__(WAVES * 64) void detect_decode_kernel(const char* b
     float sum = 0.f, e = 0.f;
 #pragma unroll
     for (int i = 0; i < REG; ++i) {
-      const float ex = expf(v[i] - m);
+      // bf16 perf mode: v_exp_f32 / v_rcp_f32 (1 ulp) - the logits carry 8 bits; f32 parity mode: ocml expf + IEEE divide
+      const float ex = sizeof(T) == 2 ? __builtin_amdgcn_exp2f((v[i] - m) * 1.44269504088896340736f) : expf(v[i] - m);
       sum += ex;
       e += ex * (float)i;
     }
-    dist[s] = e / sum;
+    dist[s] = sizeof(T) == 2 ? e * __builtin_amdgcn_rcpf(sum) : e / sum;
   }
   const float cx = (float)ax + 0.5f, cy = (float)ay + 0.5f;
   const float x1 = cx - dist[0], y1 = cy - dist[1], x2 = cx + dist[2], y2 = cy + dist[3];
@@ -107,7 +108,10 @@ __global__ __launch_bounds__(WAVES * 64) void detect_decode_kernel(const char* b
     unpack(*reinterpret_cast<const u32x4*>(csm + (lane * gcp + (grp ^ (lane & (gcp - 1)))) * 16), v);
 #pragma unroll
     for (int i = 0; i < E; ++i)
-      if (grp * E + i < nc) yb[(size_t)(4 + grp * E + i) * a_total] = 1.0f / (1.0f + expf(-v[i]));
+      if (grp * E + i < nc)
+        yb[(size_t)(4 + grp * E + i) * a_total] =
+            sizeof(T) == 2 ? __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[i] * -1.44269504088896340736f))
+                           : 1.0f / (1.0f + expf(-v[i]));
   }
 }
 
