@@ -86,7 +86,7 @@ static int launch_mhsa(const void* q, const void* k, const void* v, int ld, int 
   }
   dim3 grid((unsigned)(n * heads), (unsigned)cdiv(hw, 128));
   auto kern = mhsa_kernel<T, D>;
-  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)upa_full_lds<mhsa_kernel<T, D>>();
   hipLaunchKernelGGL(kern, grid, dim3(128), lds, s, (const char*)q, (const char*)k, (const char*)v, ld, hw, heads,
                      (const char*)residual, ldr, (char*)y, ldy, scale);
   UPA_LAUNCH_CHECK();

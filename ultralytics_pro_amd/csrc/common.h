@@ -66,5 +66,19 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   return v;
 }
 
+// Raise a kernel's dynamic-LDS limit to the whole 160 KB of a gfx950 CU (less its static __shared__), once per kernel instantiation (C++11 static
+// initialisation: thread safe, no API call on later launches, and no launch ever lowers a limit another launch - or a
+// captured graph node - relies on).
+template <auto Kern>
+inline hipError_t upa_full_lds() {
+  static const hipError_t e = [] {
+    hipFuncAttributes fa;
+    int room = 160 * 1024;
+    if (hipFuncGetAttributes(&fa, (const void*)Kern) == hipSuccess) room -= (int)fa.sharedSizeBytes;  // static __shared__
+    return hipFuncSetAttribute((const void*)Kern, hipFuncAttributeMaxDynamicSharedMemorySize, room);
+  }();
+  return e;
+}
+
 static inline int upa_elem_size(int dtype) { return dtype == UPA_BF16 ? 2 : 4; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -616,9 +616,9 @@ int launch_conv_ckt(ConvParams& p, hipStream_t stream) {
   if (lds > 160 * 1024) return UPA_EUNSUPPORTED;
   dim3 grid((unsigned)((long)p.tilesX * p.tilesY * p.N), (unsigned)cdiv(p.NTn * 16, BN));
   auto kern = conv_igemm_kernel<T, WM, WN, MTW, NTW, CKT>;
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { upa_set_error("conv: cannot raise LDS limit: %s", hipGetErrorString(e)); return UPA_ELAUNCH; }
+  if (hipError_t e = upa_full_lds<conv_igemm_kernel<T, WM, WN, MTW, NTW, CKT>>(); e != hipSuccess) {
+    upa_set_error("conv: cannot raise LDS limit: %s", hipGetErrorString(e));
+    return UPA_ELAUNCH;
   }
   hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, stream, p);
   UPA_LAUNCH_CHECK();
@@ -683,9 +683,9 @@ int launch_ws(ConvParams& p, hipStream_t stream) {
   g_last_variant = (1 << 20) | (KTT << 16) | (WM << 12) | (WN << 8) | (MTW << 4) | NTW;
   if (g_query_only) return UPA_OK;
   auto kern = conv_ws_kernel<T, WM, WN, MTW, NTW, KTT>;
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { upa_set_error("conv ws: cannot raise LDS limit: %s", hipGetErrorString(e)); return UPA_ELAUNCH; }
+  if (hipError_t e = upa_full_lds<conv_ws_kernel<T, WM, WN, MTW, NTW, KTT>>(); e != hipSuccess) {
+    upa_set_error("conv ws: cannot raise LDS limit: %s", hipGetErrorString(e));
+    return UPA_ELAUNCH;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)gridY), dim3(WM * WN * 64), lds, stream, p);
   UPA_LAUNCH_CHECK();

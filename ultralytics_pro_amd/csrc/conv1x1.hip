@@ -224,11 +224,7 @@ namespace {
 template <int NTW, int MT, int WAVES>
 int launch_c1_inst(const C1Params& p, dim3 grid, size_t lds, hipStream_t s) {
   auto kern = conv1x1_stream_kernel<NTW, MT, WAVES>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  (void)upa_full_lds<conv1x1_stream_kernel<NTW, MT, WAVES>>();
   hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, s, p);
   UPA_LAUNCH_CHECK();
   return UPA_OK;

@@ -253,11 +253,7 @@ static int launch_pipe(const PipeParams& p, int grid, hipStream_t s) {
 #define UPA_PIPE_LAUNCH(ACT_, RES_)                                                                              \
   do {                                                                                                           \
     auto kern = conv3x3_pipe_kernel<NTW, ACT_, RES_>;                                                            \
-    static bool attr_set = false;                                                                                \
-    if (!attr_set) {                                                                                             \
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
-      attr_set = true;                                                                                           \
-    }                                                                                                            \
+    (void)upa_full_lds<conv3x3_pipe_kernel<NTW, ACT_, RES_>>();                                                  \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, s, p);                                           \
   } while (0)
   if (p.act == UPA_ACT_SILU) {

@@ -133,12 +133,12 @@ extern "C" int upa_detect_decode(const void* box, int ldb, const void* cls, int 
   hipStream_t s = (hipStream_t)stream;
   if (dtype == UPA_BF16) {
     auto kern = detect_decode_kernel<bf16_t, 16, WAVES>;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)upa_full_lds<detect_decode_kernel<bf16_t, 16, WAVES>>();
     hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, s, (const char*)box, ldb, (const char*)cls, ldc, n, h, w, nc,
                        stride_px, y, a_total, a0);
   } else {
     auto kern = detect_decode_kernel<float, 16, WAVES>;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)upa_full_lds<detect_decode_kernel<float, 16, WAVES>>();
     hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, s, (const char*)box, ldb, (const char*)cls, ldc, n, h, w, nc,
                        stride_px, y, a_total, a0);
   }

@@ -320,8 +320,7 @@ extern "C" int upa_nms_batched(const float* pred, int b, int nc, int a, float co
                      conf_thres, multi_label, classes_mask, count, keys, cap);
   UPA_LAUNCH_CHECK();
   {
-    hipError_t e = hipFuncSetAttribute((const void*)nms_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       LDS_SORT_CAP * 8);
+    hipError_t e = upa_full_lds<nms_sort_kernel>();
     if (e != hipSuccess) { upa_set_error("nms: cannot raise LDS limit: %s", hipGetErrorString(e)); return UPA_ELAUNCH; }
   }
   hipLaunchKernelGGL(nms_sort_kernel, dim3((unsigned)b), dim3(SORT_NT), LDS_SORT_CAP * 8, s, count, nsorted, keys, sel,

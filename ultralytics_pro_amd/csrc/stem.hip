@@ -403,11 +403,11 @@ static void launch_stem_mfma(const StemParams& p, int n, hipStream_t st) {
   const size_t lds = (size_t)2 * G::ITEMS_PAD * 16 + 4 * G::TW * NT * 32;
   if (p.act == UPA_ACT_SILU) {
     auto kern = stem_mfma_kernel<NT, KS, S, true>;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)upa_full_lds<stem_mfma_kernel<NT, KS, S, true>>();
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, q);
   } else {
     auto kern = stem_mfma_kernel<NT, KS, S, false>;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)upa_full_lds<stem_mfma_kernel<NT, KS, S, false>>();
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, q);
   }
 }
@@ -686,7 +686,7 @@ extern "C" int upa_stem_conv_fused(const void* x, int n, int h, int w, const flo
   static const int wgs = getenv("UPA_STEMF_WGS") ? atoi(getenv("UPA_STEMF_WGS")) : 512;
   const size_t lds = (size_t)2 * sf::PATCH + sf::STILE;
   auto kern = stem_conv_fused_kernel;
-  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)upa_full_lds<stem_conv_fused_kernel>();
   hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < wgs ? ntiles : wgs)), dim3(256), lds, (hipStream_t)stream, p);
   UPA_LAUNCH_CHECK();
   return UPA_OK;

@@ -1097,7 +1097,7 @@ static int launch_wgrad(WgradParams& p, int accumulate, void* ws, size_t ws_byte
 #define UPA_WG_LAUNCH(KK_)                                                                                        \
   do {                                                                                                            \
     auto kern = wgrad_kernel<T, MT, NT, KK_>;                                                                     \
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+    (void)upa_full_lds<wgrad_kernel<T, MT, NT, KK_>>();                                                           \
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);                                                         \
   } while (0)
   if (p.KS == 1) UPA_WG_LAUNCH(1);
@@ -1128,7 +1128,7 @@ static int launch_wgrad_bf16_k1(WgradParams& p, int accumulate, void* ws, size_t
   p.partial = (float*)ws;
   const size_t lds = (size_t)128 * (BCO * 2 + 32) + (size_t)128 * (BCI * 2 + 32);
   auto kern = wgrad_bf16_k1_kernel;
-  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)upa_full_lds<wgrad_bf16_k1_kernel>();
   hipLaunchKernelGGL(kern, dim3((unsigned)wgs, bco, bci), dim3(256), lds, s, p);
   const long total = (long)bco * bci * BCO * BCI;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(total, 16, 8192)), dim3(256), 0, s, p.partial, (int)wgs, bco, bci, BCO, BCI, 1, p.dw,
@@ -1157,11 +1157,11 @@ static int launch_wgrad_bf16_k3_t(WgradParams& p, int accumulate, void* ws, size
   dim3 grid(wgs, bco, bci);
   if (p.stride == 1) {
     auto kern = wgrad_bf16_k3_kernel<1, BCI>;
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)upa_full_lds<wgrad_bf16_k3_kernel<1, BCI>>();
     hipLaunchKernelGGL(kern, grid, dim3(192), lds, s, p);
   } else {
     auto kern = wgrad_bf16_k3_kernel<2, BCI>;
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)upa_full_lds<wgrad_bf16_k3_kernel<2, BCI>>();
     hipLaunchKernelGGL(kern, grid, dim3(192), lds, s, p);
   }
   const long total = (long)bco * bci * 9 * BCO * BCI;

@@ -158,8 +158,7 @@ extern "C" int upa_topk_tokens(const float* scores, int nc, int n_levels, const 
   while (npad < T) npad <<= 1;
   const size_t lds = (size_t)npad * 8;
   UPA_CHECK_ARG(lds <= 150 * 1024, "topk_tokens: %d tokens do not fit LDS", T);
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)topk_tokens_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)upa_full_lds<topk_tokens_kernel>();
   hipLaunchKernelGGL(topk_tokens_kernel, dim3((unsigned)b), dim3(1024), lds, (hipStream_t)stream, scores, nc, lt, b, T, k,
                      npad, out_rows, out_tok);
   UPA_LAUNCH_CHECK();
