@@ -200,8 +200,10 @@ int upa_upsample2x_bwd(const void* dy, int n, int h, int w, int c, int lddy, voi
 size_t upa_maxpool2d_bwd_workspace_bytes(int n, int h, int w, int c, int k, int stride, int pad);
 int upa_maxpool2d_bwd(const void* x, const void* dy, int n, int h, int w, int c, int ldx, int lddy, int k, int stride, int pad,
                       void* dx, int lddx, int accumulate, int dtype, void* workspace, size_t workspace_bytes, void* stream);
-/* *out (+)= sum g[i]^2 (f64): squared gradient norm for clip_grad_norm_. */
-int upa_sumsq(const float* g, long n, double* out, int accumulate, void* stream);
+/* *out (+)= sum g[i]^2 (f64): squared gradient norm for clip_grad_norm_ (trainer.py:676).  Fixed summation order (block
+ * partials in `workspace`, upa_sumsq_workspace_bytes() bytes, then one folding workgroup): bit-reproducible. */
+size_t upa_sumsq_workspace_bytes(void);
+int upa_sumsq(const float* g, long n, double* out, int accumulate, void* workspace, void* stream);
 /* clip_grad_norm_(max_norm) + SGD(nesterov, weight decay) + ModelEMA update over a flat parameter segment
  * (engine/trainer.py:674-682, :891-950; utils/torch_utils.py:632-646).  ema may be NULL.  ema_d_dev (nullable): device
  * float that overrides ema_d - lets a captured hipGraph of the step read the per-step EMA decay. */

@@ -181,3 +181,66 @@ def test_e2e_pipelined_runner_copies_equal_single_graph():
         assert torch.equal(cnt, cnt1) and torch.equal(out, out1)
     for (out, cnt, _) in lin.results():  # linear copies: one graph, whole batch
         assert torch.equal(cnt, cnt1) and torch.equal(out, out1)
+
+
+def _iou_matrix(b):
+    area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    lt = torch.max(b[:, None, :2], b[None, :, :2])
+    rb = torch.min(b[:, None, 2:], b[None, :, 2:])
+    inter = (rb - lt).clamp(min=0).prod(2)
+    return inter / (area[:, None] + area[None, :] - inter)
+
+
+def test_e2e_full_size_properties():
+    """BASELINE.json's headline configuration itself (yolov8n, 32 x 3 x 640 x 640, bf16, conf 0.25, iou 0.7) through
+    size-independent properties: every copy of the pipelined runner (the bench default: 4 linear graphs in flight)
+    reproduces the single-graph detections bit for bit; per image the detections are sorted by score (nms.py:137-141),
+    above the confidence threshold, at most max_det, finite, inside the letterboxed image up to the box size; NMS is
+    idempotent - no two kept boxes of one class overlap by more than iou_thres (nms.py:143-156), so running the
+    reference's NMS on its own output would keep all of them; and an image's detections do not depend on the batch it
+    is in (f32 parity mode: the same four images as a batch of 4, boxes / scores to 1e-3, equal classes)."""
+    from tests.hip_utils import DEV
+    from ultralytics_pro_amd.engine.pipeline import PipelinedRunner
+    from ultralytics_pro_amd.utils.nms import nms_raw
+    m = _build("yolov8n", torch.bfloat16)
+    x32 = P.synthetic_images(32).to(DEV)
+    x = x32.to(torch.bfloat16).contiguous()
+    with torch.no_grad():
+        run1 = m.compile(x, post=lambda o: nms_raw(o[0], 0.25, 0.7, key="ref"))
+        out1, cnt1, _ = run1()
+        torch.cuda.synchronize()
+        out1, cnt1 = out1.clone(), cnt1.clone()
+        lin = PipelinedRunner(m, x, post=lambda o: nms_raw(o[0], 0.25, 0.7, key="lin"), micro_batches=1, in_flight=4, linear=True)
+        for _ in range(9):
+            lin.step()
+        torch.cuda.synchronize()
+    for (out, cnt, _) in lin.results():
+        assert torch.equal(cnt, cnt1) and torch.equal(out, out1)
+    out, cnt = out1.cpu(), cnt1.cpu().tolist()
+    assert sum(cnt) > 32, "the synthetic batch is expected to produce detections"
+    for i, n in enumerate(cnt):
+        assert 0 <= n <= 300
+        d = out[i, :n]
+        if n == 0:
+            continue
+        assert torch.isfinite(d).all()
+        assert (d[:, 4] > 0.25).all() and (d[:, 4] <= 1.0).all()
+        assert (d[1:, 4] <= d[:-1, 4]).all(), "scores must be descending"
+        assert ((d[:, 5] >= 0) & (d[:, 5] < 80) & (d[:, 5] == d[:, 5].round())).all()
+        assert (d[:, 2] >= d[:, 0]).all() and (d[:, 3] >= d[:, 1]).all()
+        iou = _iou_matrix(d[:, :4])
+        same = d[:, 5][:, None] == d[:, 5][None, :]
+        iou = torch.where(same, iou, torch.zeros_like(iou)).triu(1)
+        assert iou.max().item() <= 0.7 + 1e-6, "two kept boxes of one class overlap by more than iou_thres"
+    # batch-composition independence, f32 parity mode
+    mf = _build("yolov8n", torch.float32)
+    with torch.no_grad():
+        o32, c32, _ = nms_raw(mf(x32)[0], 0.25, 0.7, key="f32_32")
+        o4, c4, _ = nms_raw(mf(x32[8:12].contiguous())[0], 0.25, 0.7, key="f32_4")
+        torch.cuda.synchronize()
+    assert torch.equal(c32[8:12].cpu(), c4.cpu())
+    for j in range(4):
+        n = int(c4[j])
+        a, b = o32[8 + j, :n].cpu(), o4[j, :n].cpu()
+        assert (a[:, :5] - b[:, :5]).abs().max().item() <= TOL if n else True
+        assert torch.equal(a[:, 5], b[:, 5])

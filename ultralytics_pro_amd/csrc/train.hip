@@ -865,7 +865,9 @@ __global__ void interleave2x_kernel(const char* t0, const char* t1, const char* 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void sumsq_kernel(const float* g, long n, double* out) {
+// Two stages, both in a fixed order (no atomics: the norm - and with it the clip coefficient of every weight - is the same
+// bit pattern run after run): per-block partial sums, then one workgroup folds the partials.
+__global__ void sumsq_kernel(const float* g, long n, double* partial) {
   __shared__ double red[256];
   double s = 0.0;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += (double)g[i] * (double)g[i];
@@ -875,7 +877,20 @@ __global__ void sumsq_kernel(const float* g, long n, double* out) {
     if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) atomicAdd(out, red[0]);
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ void sumsq_fold_kernel(const double* partial, int nblocks, double* out, int accumulate) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 256) s += partial[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = accumulate ? *out + red[0] : red[0];
 }
 
 // torch.nn.utils.clip_grad_norm_ + torch.optim.SGD(nesterov) + ModelEMA.update over one flat parameter segment
@@ -1282,11 +1297,14 @@ extern "C" int upa_maxpool2d_bwd(const void* x, const void* dy, int n, int h, in
   return UPA_OK;
 }
 
-extern "C" int upa_sumsq(const float* g, long n, double* out, int accumulate, void* stream) {
-  UPA_CHECK_ARG(g && out && n > 0, "sumsq: bad args");
+extern "C" size_t upa_sumsq_workspace_bytes(void) { return 1024 * sizeof(double); }
+
+extern "C" int upa_sumsq(const float* g, long n, double* out, int accumulate, void* workspace, void* stream) {
+  UPA_CHECK_ARG(g && out && workspace && n > 0, "sumsq: bad args");
   hipStream_t s = (hipStream_t)stream;
-  if (!accumulate) (void)hipMemsetAsync(out, 0, sizeof(double), s);
-  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 1024, 1024)), dim3(256), 0, s, g, n, out);
+  const int grid = grid_for(n, 1024, 1024);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, s, g, n, (double*)workspace);
+  hipLaunchKernelGGL(sumsq_fold_kernel, dim3(1), dim3(256), 0, s, (const double*)workspace, grid, out, accumulate);
   UPA_LAUNCH_CHECK();
   return UPA_OK;
 }

@@ -397,6 +397,7 @@ class DetectionTrainer:
         self.nbuf = nb
         self.ERB = self.RB.clone() if ema else None
         self.sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.sumsq_ws = torch.zeros(L.lib().upa_sumsq_workspace_bytes() // 8, dtype=torch.float64, device=dev)
         self.ema_d_dev = torch.zeros(1, dtype=torch.float32, device=dev)
         self.ema_d_host = torch.zeros(1, dtype=torch.float32).pin_memory() if torch.cuda.is_available() else torch.zeros(1)
 
@@ -530,7 +531,8 @@ class DetectionTrainer:
 
     def grad_sumsq(self):
         off_end = self.groups[-1][0] + self.groups[-1][1]
-        L.check(L.lib().upa_sumsq(self.G.data_ptr(), off_end, self.sumsq.data_ptr(), 0, _s(self.device)), "sumsq")
+        L.check(L.lib().upa_sumsq(self.G.data_ptr(), off_end, self.sumsq.data_ptr(), 0, self.sumsq_ws.data_ptr(),
+                                  _s(self.device)), "sumsq")
         return self.sumsq
 
     def all_reduce_gradients(self):
