@@ -156,6 +156,14 @@ int upa_scale_boxes(float* rows, long n, int row_stride, float gain, float pad_x
  * upa_conv2d_bias_act(dz, V, pad = k-1-p) (a stride-2 conv first goes through upa_dilate2x). */
 int upa_pack_conv_weight_dev(const float* w_oihw, int cout, int cin, int k, int dtype, int transpose_flip, void* out,
                              void* stream);
+/* The same for every conv of a model in ONE launch (the weights change once per optimizer step, trainer.py:674-682):
+ * descs_dev = n descriptors in device memory, one per (conv, layout). */
+typedef struct UpaPackDesc {
+  const float* w_oihw;
+  void* out;
+  int cout, cin, k, dtype, transpose_flip, reserved;
+} UpaPackDesc;
+int upa_pack_conv_weights_batched(const UpaPackDesc* descs_dev, int n, void* stream);
 /* Per-channel reductions run in two stages without atomics: per-block f64 partial sums, then a fixed-order combine.
  * `ws` = upa_channel_reduce_workspace_bytes(c) bytes of scratch shared by upa_bn_stats / upa_bn_finalize (which must
  * follow each other on one stream), upa_bn_act_bwd and upa_channel_sum.

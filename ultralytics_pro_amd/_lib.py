@@ -72,6 +72,7 @@ PROTOTYPES = {
     "upa_upsample2x_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "upa_maxpool2d_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "upa_maxpool2d_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "upa_pack_conv_weights_batched": (_i, [_vp, _i, _vp]),
     "upa_sumsq_workspace_bytes": (C.c_size_t, []),
     "upa_sumsq": (_i, [_vp, C.c_long, _vp, _i, _vp, _vp]),
     "upa_sgd_nesterov_ema": (_i, [_vp, _vp, _vp, _vp, C.c_long, _vp, _f, _f, _f, _f, _i, _f, _vp, _i, _vp]),

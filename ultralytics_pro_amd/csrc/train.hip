@@ -42,8 +42,8 @@ template <> __device__ __forceinline__ void store16<bf16_t>(char* p, const float
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void pack_weight_dev_kernel(const float* w, int cout, int cin, int k, int E, int transpose_flip, void* out,
-                                       long total) {
+__device__ __forceinline__ void pack_weight_body(const float* w, int cout, int cin, int k, int E, int transpose_flip, void* out,
+                                                 long total) {
   // logical weight V[co'][ci'][kh][kw]; transpose_flip: V[a][b][kh][kw] = W[b][a][k-1-kh][k-1-kw] (data gradient)
   const int lc_out = transpose_flip ? cin : cout, lc_in = transpose_flip ? cout : cin;
   const int ktch = 4 * E;
@@ -66,6 +66,21 @@ __global__ void pack_weight_dev_kernel(const float* w, int cout, int cin, int k,
     if (E == 8) ((bf16_t*)out)[idx] = f32_to_bf16(v);
     else ((float*)out)[idx] = v;
   }
+}
+
+__global__ void pack_weight_dev_kernel(const float* w, int cout, int cin, int k, int E, int transpose_flip, void* out,
+                                       long total) {
+  pack_weight_body(w, cout, cin, k, E, transpose_flip, out, total);
+}
+
+// every conv of a model in one launch: blockIdx.y = descriptor (the per-layer form cost 147 launches of 4.5 us per
+// training step of yolov8s)
+__global__ void pack_weight_batched_kernel(const UpaPackDesc* descs) {
+  const UpaPackDesc d = descs[blockIdx.y];
+  const int E = d.dtype == UPA_BF16 ? 8 : 4;
+  const int lc_out = d.transpose_flip ? d.cin : d.cout, lc_in = d.transpose_flip ? d.cout : d.cin;
+  const long total = (long)d.k * d.k * ((lc_in + 4 * E - 1) / (4 * E)) * ((lc_out + 15) / 16) * 64 * E;
+  pack_weight_body(d.w_oihw, d.cout, d.cin, d.k, E, d.transpose_flip, d.out, total);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -970,6 +985,13 @@ extern "C" int upa_pack_conv_weight_dev(const float* w_oihw, int cout, int cin, 
   const long total = (long)k * k * ((lc_in + 4 * E - 1) / (4 * E)) * ((lc_out + 15) / 16) * 64 * E;
   hipLaunchKernelGGL(pack_weight_dev_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, w_oihw, cout, cin, k, E,
                      transpose_flip, out, total);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+extern "C" int upa_pack_conv_weights_batched(const UpaPackDesc* descs_dev, int n, void* stream) {
+  UPA_CHECK_ARG(descs_dev && n > 0 && n <= 65535, "pack_conv_weights_batched: bad args");
+  hipLaunchKernelGGL(pack_weight_batched_kernel, dim3(64, (unsigned)n), dim3(256), 0, (hipStream_t)stream, descs_dev);
   UPA_LAUNCH_CHECK();
   return UPA_OK;
 }

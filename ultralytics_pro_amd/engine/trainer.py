@@ -21,6 +21,8 @@ from __future__ import annotations
 import ctypes as C
 import math
 
+import numpy as np
+
 import torch
 import torch.nn as nn
 
@@ -112,6 +114,25 @@ class ConvT:
             for ph in range(4):
                 L.check(lib.upa_pack_conv_weight_dev(self.phase_v.data_ptr() + ph * per, self.cin, self.cout, 2, c.code, 0,
                                                      self.phase[ph].data_ptr(), _s(c.device)), "pack_phase")
+
+    def pack_descs(self):
+        """(w_ptr, out_ptr, cout, cin, k, dtype, transpose_flip) of every repack `pack()` launches, for the batched form
+        (upa_pack_conv_weights_batched); a stride-2 conv's phase kernels are read from `phase_v`, which
+        `pack_phase_weights()` must have refreshed first."""
+        c, w = self.ctx, self.conv.weight
+        d = [(w.data_ptr(), self.wp.data_ptr(), self.cout, self.cin, self.k, c.code, 0)]
+        if self.phase is None:
+            d.append((w.data_ptr(), self.wpt.data_ptr(), self.cout, self.cin, self.k, c.code, 1))
+        else:
+            per = self.cin * self.cout * 4 * 4
+            d += [(self.phase_v.data_ptr() + ph * per, self.phase[ph].data_ptr(), self.cin, self.cout, 2, c.code, 0)
+                  for ph in range(4)]
+        return d
+
+    def pack_phase_weights(self):
+        if self.phase is not None:
+            L.check(L.lib().upa_dgrad_s2_phase_weights(self.conv.weight.data_ptr(), self.cout, self.cin,
+                                                       self.phase_v.data_ptr(), _s(self.ctx.device)), "phase_weights")
 
     def _conv(self, x, wp, cout, k, s, p, out, bias=None, residual=None):
         vx, vy = R.view_of(x), R.view_of(out)
@@ -406,6 +427,7 @@ class DetectionTrainer:
         ctx = self.ctx
         self.nodes = []
         self.convs = []
+        self._pack_table, self._pack_n = None, 0
         for m in self.model.model:
             name = f"model.{m.i}"
             if isinstance(m, H.Detect):
@@ -442,6 +464,22 @@ class DetectionTrainer:
                 "nchw_to_nhwc")
         return buf.permute(0, 3, 1, 2)
 
+    def _pack_weights(self):
+        """Repack every conv's master weights into the MFMA fragment layouts (forward, data gradient) - one launch for the
+        whole model plus one per stride-2 conv (its four phase kernels).  The descriptor table is built once: the master
+        weights are views of the flat parameter buffer and the packed buffers are owned by the layers."""
+        for cv in self.convs:
+            cv.pack_phase_weights()
+        if self._pack_table is None:
+            rows = [d for cv in self.convs for d in cv.pack_descs()]
+            t = np.zeros(len(rows), dtype=np.dtype([("w", "<u8"), ("out", "<u8"), ("cout", "<i4"), ("cin", "<i4"), ("k", "<i4"),
+                                                    ("dtype", "<i4"), ("tf", "<i4"), ("reserved", "<i4")]))
+            for i, r in enumerate(rows):
+                t[i] = r + (0,)
+            self._pack_table = torch.from_numpy(t.view(np.uint8).copy()).to(self.device)
+            self._pack_n = len(rows)
+        L.check(L.lib().upa_pack_conv_weights_batched(self._pack_table.data_ptr(), self._pack_n, _s(self.device)), "pack_batched")
+
     def forward_backward(self, img, labels):
         """img: (N,3,H,W) float32 NCHW on the device; labels: the reference's batch dict (batch_idx, cls, bboxes).
         Fills the flat gradient buffer; returns loss_items (3,) on the device."""
@@ -449,8 +487,7 @@ class DetectionTrainer:
         L.require_gpu(img, "train")
         self.model.train()
         with R.static_buffers(self.pool):
-            for cv in self.convs:
-                cv.pack()
+            self._pack_weights()
             x = self._input_nhwc(img.float().contiguous() if img.dtype != torch.float32 else img.contiguous())
             # the stem sees E input channels: 3 real + zero padding (the packed weights are zero there as well)
             ys = []
