@@ -96,8 +96,16 @@ struct ReduceParams {
   double* out0; double* out1;
 };
 
+// FAST (bf16 perf mode): v_exp_f32 / v_rcp_f32, 1 ulp - the operands carry 8 bits; the f32 parity mode keeps ocml expf
+// and the IEEE divide.  (These element-wise passes are VALU-bound, not HBM-bound, with the accurate forms.)
+template <bool FAST>
+__device__ __forceinline__ float sigmoid_t(float u) {
+  if constexpr (FAST) return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u * -1.44269504088896340736f));
+  else return 1.0f / (1.0f + expf(-u));
+}
+template <bool FAST>
 __device__ __forceinline__ float silu_grad(float u) {
-  const float s = 1.0f / (1.0f + expf(-u));
+  const float s = sigmoid_t<FAST>(u);
   return s * (1.0f + u * (1.0f - s));
 }
 
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(const ReduceParams 
           for (int e = 0; e < E; ++e) {
             const float xh = (v[u][e] - mean[e]) * rstd[e];
             float du = d[u][e];
-            if (p.act == UPA_ACT_SILU) du *= silu_grad(gam[e] * xh + bet[e]);
+            if (p.act == UPA_ACT_SILU) du *= silu_grad<sizeof(T) == 2>(gam[e] * xh + bet[e]);
             s0[e] += du;
             s1[e] += du * xh;
           }
@@ -271,12 +279,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyParams p) {
       const float u = gam[e] * xh + bet[e];
       if (!BWD) {
         float r = u;
-        if (silu) r = u / (1.0f + expf(-u));
+        if (silu) r = sizeof(T) == 2 ? u * sigmoid_t<true>(u) : u / (1.0f + expf(-u));
         if (p.aux) r += a[e];
         o[e] = r;
       } else {
         float du = a[e];
-        if (silu) du *= silu_grad(u);
+        if (silu) du *= silu_grad<sizeof(T) == 2>(u);
         o[e] = gam[e] * rstd[e] * (du - (k0[e] + xh * k1[e]) * inv);
       }
     }
