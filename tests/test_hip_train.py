@@ -430,3 +430,39 @@ def test_training_step_full_size_is_deterministic_and_descends():
     assert all(torch.isfinite(t).all() and (t > 0).all() for t in ia)
     assert np.isfinite(ga) and ga > 0 and da > 0
     assert ia[-1].sum().item() < ia[0].sum().item(), "three SGD steps on one batch must lower the loss"
+
+
+def test_batched_weight_repack_equals_per_layer_and_host_pack():
+    """upa_pack_conv_weights_batched (one launch for every conv of the model, csrc/train.hip) writes the same bytes as
+    upa_pack_conv_weight_dev per layer and - forward layout - as the host packer used for inference
+    (upa_pack_conv_weight); covers 3x3 / 1x1, Cin not a multiple of the k-tile, transposed + flipped data-gradient
+    layouts and both dtypes."""
+    from tests.hip_utils import DEV
+    from ultralytics_pro_amd import _lib as L
+    lib = L.lib()
+    st = L.current_stream(DEV)
+    cases = [(64, 48, 3, 0), (64, 48, 3, 1), (80, 64, 1, 0), (16, 8, 3, 1), (128, 96, 1, 1), (32, 32, 2, 0)]
+    desc = np.dtype([("w", "<u8"), ("out", "<u8"), ("cout", "<i4"), ("cin", "<i4"), ("k", "<i4"), ("dtype", "<i4"),
+                     ("tf", "<i4"), ("reserved", "<i4")])
+    for code, tdt in ((1, torch.bfloat16), (0, torch.float32)):
+        ws, outs_b, outs_s, table = [], [], [], np.zeros(len(cases), dtype=desc)
+        for i, (co, ci, k, tf) in enumerate(cases):
+            w = P.uniform(f"pk{i}", (co, ci, k, k), -1, 1).to(DEV).contiguous()
+            lco, lci = (ci, co) if tf else (co, ci)
+            nb = lib.upa_conv_packed_weight_bytes(lco, lci, k, code)
+            ob = torch.zeros(nb, dtype=torch.uint8, device=DEV)
+            os_ = torch.zeros(nb, dtype=torch.uint8, device=DEV)
+            L.check(lib.upa_pack_conv_weight_dev(w.data_ptr(), co, ci, k, code, tf, os_.data_ptr(), st))
+            table[i] = (w.data_ptr(), ob.data_ptr(), co, ci, k, code, tf, 0)
+            ws.append(w); outs_b.append(ob); outs_s.append(os_)
+            if not tf:
+                host = torch.zeros(nb, dtype=torch.uint8)
+                wc = w.cpu().contiguous()
+                L.check(lib.upa_pack_conv_weight(wc.data_ptr(), co, ci, k, code, host.data_ptr()))
+                torch.cuda.synchronize()
+                assert torch.equal(os_.cpu(), host)
+        tdev = torch.from_numpy(table.view(np.uint8).copy()).to(DEV)
+        L.check(lib.upa_pack_conv_weights_batched(tdev.data_ptr(), len(cases), st))
+        torch.cuda.synchronize()
+        for ob, os_ in zip(outs_b, outs_s):
+            assert torch.equal(ob, os_)

@@ -972,7 +972,11 @@ __global__ void cast_view_kernel(const char* src, int lds_, char* dst, int ldd, 
 int grid_for(long total, int per_block, int cap);
 int reduce_grid(long npix) {
   static const int ppb = getenv("UPA_RED_PPB") ? atoi(getenv("UPA_RED_PPB")) : 64;
-  static const int cap = getenv("UPA_RED_CAP") ? atoi(getenv("UPA_RED_CAP")) : 2048;
+  // measured on MI355X (tools/bench_bn.py, stats / whole backward in us): 512 blocks beat 2048 on every mid-size layer
+  // (204800 px x 128 ch: 14.0 / 61 vs 22.8 / 79; 819200 x 32: 14.6 / 62 vs 22.7 / 74 - fewer per-block prologues, LDS
+  // folds and partial rows); only the 3.3 M-pixel stem output prefers 1024 (35.5 vs 39.7)
+  static const int cap_env = getenv("UPA_RED_CAP") ? atoi(getenv("UPA_RED_CAP")) : 0;
+  const int cap = cap_env > 0 ? cap_env : (npix > 1500000 ? 1024 : 512);
   return grid_for(npix, ppb, cap < 2048 ? cap : 2048);  // the workspace holds 2048 block partials
 }
 
