@@ -77,7 +77,9 @@ int upa_copy_view(const void* x, int n, int h, int w, int c, int ldx, void* y, i
 /* y = a + b (views)                                                                        block.py:6091 */
 int upa_add_view(const void* a, int lda, const void* b, int ldb, void* y, int ldy, int n, int h, int w, int c,
                  int dtype, void* stream);
-/* layout conversion at the module boundary (NCHW f32 <-> NHWC dtype) */
+/* layout conversion at the module boundary (NCHW f32 <-> NHWC dtype).  Narrow inputs (c <= 16 / elem size, e.g. an image
+ * batch) whose rows are 16-byte aligned (ldy a multiple of 16 / elem size) are written as one 16-byte group per pixel:
+ * channels c .. 16/elem-1 of that group are set to zero (the channel padding the first conv expects). */
 int upa_nchw_to_nhwc(const float* x, int n, int c, int h, int w, void* y, int ldy, int dtype, void* stream);
 int upa_nhwc_to_nchw(const void* x, int n, int h, int w, int c, int ldx, float* y, int dtype, void* stream);
 

@@ -181,6 +181,27 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* x, char*
   }
 }
 
+// Narrow inputs (an image batch: C = 3): one thread per pixel reads its C planes (each plane coalesced across the wave) and
+// writes one 16-byte NHWC group, channels C.. of the group zero.  The 32 x 32 tile form above spent 32 channel slots on 3
+// channels: 337 us for a 32 x 3 x 640 x 640 batch against a 60 us HBM floor.
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_narrow_kernel(const float* x, char* y, int C, long HW, int ldy, long total) {
+  constexpr int E = 16 / sizeof(T);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long n = i / HW, pp = i - n * HW;
+    float v[E];
+#pragma unroll
+    for (int c = 0; c < E; ++c) v[c] = c < C ? x[((size_t)n * C + c) * HW + pp] : 0.f;
+    char* dst = y + (size_t)i * ldy * sizeof(T);
+    if constexpr (sizeof(T) == 4) {
+      *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+    } else {
+      *reinterpret_cast<u32x4*>(dst) = u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                             pack_bf16x2(v[6], v[7])};
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const char* x, float* y, int C, long HW, int ldx) {
   __shared__ float tile[32][33];
@@ -305,6 +326,18 @@ extern "C" int upa_add_view(const void* a, int lda, const void* b, int ldb, void
 extern "C" int upa_nchw_to_nhwc(const float* x, int n, int c, int h, int w, void* y, int ldy, int dtype, void* stream) {
   UPA_CHECK_ARG(x && y && n > 0 && c > 0, "nchw_to_nhwc: bad args");
   const long hw = (long)h * w;
+  const int E = 16 / upa_elem_size(dtype);
+  if (c <= E && ldy % E == 0 && ((uintptr_t)y % 16) == 0) {  // image batches: one 16-byte group per pixel
+    const long total = (long)n * hw;
+    long g = (total + 255) / 256;
+    if (g > 16384) g = 16384;
+    if (dtype == UPA_BF16)
+      hipLaunchKernelGGL(nchw_to_nhwc_narrow_kernel<bf16_t>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, (char*)y, c, hw, ldy, total);
+    else
+      hipLaunchKernelGGL(nchw_to_nhwc_narrow_kernel<float>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, (char*)y, c, hw, ldy, total);
+    UPA_LAUNCH_CHECK();
+    return UPA_OK;
+  }
   dim3 grid((unsigned)((hw + 31) / 32), (unsigned)cdiv(c, 32), (unsigned)n);
   if (dtype == UPA_BF16)
     hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, x, (char*)y, c, hw, ldy);
