@@ -1169,7 +1169,9 @@ static int launch_wgrad_bf16_k1(WgradParams& p, int accumulate, void* ws, size_t
   const long P = (long)p.N * p.H * p.W;
   const long ntiles = (P + 127) / 128;
   const int bco = cdiv(p.Cout, BCO), bci = cdiv(p.Cin, BCI);
-  long wgs = 256 / (bco * bci);
+  // 128 workgroups: 15.68 ms per yolov8s step against 15.88 at 256 (overlapped on the side stream; alone 256 is faster)
+  static const int k1_budget = getenv("UPA_WGRAD_K1_WGS") ? atoi(getenv("UPA_WGRAD_K1_WGS")) : 128;
+  long wgs = (k1_budget > 0 && k1_budget <= 256 ? k1_budget : 128) / (bco * bci);
   if (wgs < 1) wgs = 1;
   if (wgs > ntiles) wgs = ntiles;
   const size_t need = wgrad_partial_bytes(bco, bci, (int)wgs, BCO, BCI, 1);
@@ -1195,7 +1197,12 @@ static int launch_wgrad_bf16_k3_t(WgradParams& p, int accumulate, void* ws, size
   p.numTiles = p.tilesX * p.tilesY * p.N;
   p.IH = (p.TH - 1) * p.stride + 3; p.IW = (p.TW - 1) * p.stride + 3;
   const int bco = cdiv(p.Cout, BCO), bci = cdiv(p.Cin, BCI);
-  int wgs = 512 / (bco * bci);  // two 3-wave workgroups per CU
+  // workgroups per launch (= slices of the pixel axis x channel blocks).  Measured on MI355X, yolov8s batch 32 step:
+  // 512 (two 3-wave workgroups per CU) 16.16 ms, 256: 15.89, 128: 15.81 with the weight gradients overlapped on the side
+  // stream; 17.14 / 16.78 / 18.79 without overlap - fewer slices halve the partial-sum traffic (75 MB per layer at 512)
+  // and leave CUs to the main stream; 256 is the best of both
+  static const int wg_budget = getenv("UPA_WGRAD_WGS") ? atoi(getenv("UPA_WGRAD_WGS")) : 256;
+  int wgs = (wg_budget > 0 && wg_budget <= 512 ? wg_budget : 256) / (bco * bci);
   if (wgs < 1) wgs = 1;
   if (wgs > p.numTiles) wgs = p.numTiles;
   const size_t need = wgrad_partial_bytes(bco, bci, wgs, BCO, BCI, 3);
