@@ -1202,7 +1202,12 @@ static int launch_wgrad_bf16_k3_t(WgradParams& p, int accumulate, void* ws, size
   // stream; 17.14 / 16.78 / 18.79 without overlap - fewer slices halve the partial-sum traffic (75 MB per layer at 512)
   // and leave CUs to the main stream; 256 is the best of both
   static const int wg_budget = getenv("UPA_WGRAD_WGS") ? atoi(getenv("UPA_WGRAD_WGS")) : 256;
-  int wgs = (wg_budget > 0 && wg_budget <= 512 ? wg_budget : 256) / (bco * bci);
+  // ... except the stem (3.3 M output pixels): its weight gradient is the last kernel of the backward pass, nothing is
+  // left to overlap it with, and alone it takes 280 us at 512 workgroups against 480 at 256 (15.42 vs 15.63 ms per step)
+  static const long big_px = getenv("UPA_WGRAD_BIG_PX") ? atol(getenv("UPA_WGRAD_BIG_PX")) : 3000000;
+  int budget = wg_budget > 0 && wg_budget <= 512 ? wg_budget : 256;
+  if (big_px > 0 && (long)p.N * p.OH * p.OW >= big_px) budget = 512;  // the first layers run last in the backward pass
+  int wgs = budget / (bco * bci);
   if (wgs < 1) wgs = 1;
   if (wgs > p.numTiles) wgs = p.numTiles;
   const size_t need = wgrad_partial_bytes(bco, bci, wgs, BCO, BCI, 3);
