@@ -27,6 +27,8 @@ if str(ROOT) not in sys.path:
 import torch  # noqa: E402
 
 GFLOP_PER_IMG = 8.744  # yolov8n @640, 2*MAC over all 64 Conv2d
+# the other configs of BASELINE.json (same convention); the headline metric is always yolov8n
+GFLOP_OTHER = {"yolov3-tiny": 19.002, "yolov8s": 28.603, "yolov5-BoT3": 7.882 + 0.041, "yolov3-rtdetr": 256.56 + 11.49}
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16 (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3  # MFMA f32
 PEAK_HBM_GBS = 8000.0
@@ -101,9 +103,20 @@ def main():
     if dtype == torch.bfloat16:
         x = x.to(torch.bfloat16)  # the reference's `im.half()` for a half model (predictor.py:151-173)
     x = x.contiguous()
+    if os.environ.get("UPA_POOL_TRACE"):
+        print(f"[pool] {x.data_ptr():#x} +{x.numel() * x.element_size():#x} end {x.data_ptr() + x.numel() * x.element_size():#x} input x",
+              file=sys.stderr, flush=True)
 
-    def post(o):
-        return nms_raw(o[0], 0.25, 0.7, max_det=300, key="bench")
+    rtdetr = "rtdetr" in args.model
+    if rtdetr:  # config 5: no NMS, RTDETRPredictor.postprocess (models/rtdetr/predict.py:35-74)
+        from ultralytics_pro_amd.utils.nms import rtdetr_postprocess_raw
+
+        def post(o):
+            out, counts = rtdetr_postprocess_raw(o[0], 0.25, 300, (args.imgsz, args.imgsz), key="bench")
+            return out, counts, None
+    else:
+        def post(o):
+            return nms_raw(o[0], 0.25, 0.7, max_det=300, key="bench")
 
     from ultralytics_pro_amd.engine.pipeline import PipelinedRunner, autotune
     tuned = None
@@ -158,7 +171,9 @@ def main():
             cpu_baseline = run_cpu_baseline(args)
     if rank == 0:
         line = {
-            "metric": "images/sec/GPU YOLOv8n 640x640 bs=32 (forward + Detect decode + NMS)",
+            "metric": ("images/sec/GPU YOLOv8n 640x640 bs=32 (forward + Detect decode + NMS)" if args.model == "yolov8n" and args.batch == 32
+                       else f"images/sec/GPU {args.model} {args.imgsz}x{args.imgsz} bs={args.batch} "
+                            f"(forward + {'RT-DETR decoder + postprocess' if rtdetr else 'Detect decode + NMS'})"),
             "value": round(value, 1),
             "unit": "images/s",
             "n_gpus": world,
@@ -171,14 +186,15 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic (procedural images + procedural weights, resident in HBM)",
             "config": {"workload": f"{args.model} detect 640x640 bs={args.batch} {args.dtype} inference, 1 hipGraph/step: "
-                                   "forward+decode+NMS(conf .25, iou .7, max_det 300)",
+                                   + ("forward+RT-DETR decoder (f32)+postprocess(conf .25, max_det 300)" if rtdetr else
+                                      "forward+decode+NMS(conf .25, iou .7, max_det 300)"),
                        "micro_batches": args.micro_batches, "intra_step_concurrency": not (args.serial or runner.linear),
                        "steps_in_flight": max(1, args.in_flight), "lane_priority": runner.priority, "linear_graphs": runner.linear, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        "autotune_ms_per_step": tuned,
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch, "parallelism": f"dp{world} replicas"},
             "images_per_sec_per_gpu": round(value / world, 1),
             "detections_per_image_mean": round(sum(ndet) / max(1, len(ndet)), 1),
-            "model_tflops": round(value / world * GFLOP_PER_IMG / 1e3, 2),
+            "model_tflops": round(value / world * GFLOP_OTHER.get(args.model, GFLOP_PER_IMG) / 1e3, 2),
             "roofline": roofline,
             "kernels": kernels,
             "cpu_baseline": cpu_baseline,

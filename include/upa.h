@@ -131,6 +131,13 @@ int upa_box_add_anchors(const float* delta, const int32_t* tok, const float* anc
 int upa_sigmoid(const float* x, float* y, long n, void* stream);
 /* y[m] = [boxes[m] (4) | sigmoid(scores[m]) (nc)]                                              head.py:2074 */
 int upa_rtdetr_output(const float* boxes, const float* scores, float* y, long m, int nc, void* stream);
+/* RTDETRPredictor.postprocess (models/rtdetr/predict.py:35-74) for the whole batch: preds (b, q, 4+nc) normalised
+ * cxcywh | class scores -> out (b, max_det, 6) = [x1, y1, x2, y2, score, cls] sorted by score (ties: lower query first),
+ * rows >= counts[b] are left untouched.  Boxes are scaled by the image size: orig_wh (b, 2) = (width, height) per image in
+ * device memory, or NULL to use (ow, oh) for every image.  classes_mask (nc bytes, nullable) = `classes` filter.
+ * q <= 1024.  Bit-exact with the reference arithmetic. */
+int upa_rtdetr_postprocess(const float* preds, int b, int q, int nc, float conf, const unsigned char* classes_mask, int max_det,
+                           const float* orig_wh, float ow, float oh, float* out, int32_t* counts, void* stream);
 /* Multi-scale deformable attention sampling: value rows level-major (heads*d wide), offsets (b*len_q, heads*L*P*2),
  * attention logits (b*len_q, heads*L*P) (softmax applied here), 4-d reference boxes (b*len_q, 4) in [0,1];
  * bilinear, zero padding, align_corners=False.                   nn/modules/utils.py:103-159, transformer.py:540-556 */

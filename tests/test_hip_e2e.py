@@ -103,6 +103,37 @@ def test_e2e_rtdetr_f32_matches_reference_golden(golden_dir):
     assert d.max() <= TOL
     outs = onms.rtdetr_postprocess(y.cpu(), 0.25)
     assert [o.shape[0] for o in outs] == list(g["post_n"])
+    # the product's RTDETRPredictor.postprocess (upa_rtdetr_postprocess) on the same decoder output: bit-exact
+    from ultralytics_pro_amd.utils.nms import rtdetr_postprocess
+    mine = rtdetr_postprocess(y, 0.25)
+    for a, b in zip(mine, outs):
+        assert torch.equal(a.cpu(), b)
+
+
+def test_rtdetr_postprocess_vs_oracle_random():
+    """upa_rtdetr_postprocess vs the oracle's restatement of models/rtdetr/predict.py:35-74 on random decoder outputs:
+    confidence filter, class filter, ties in the score (stable order), max_det truncation, per-image original shapes,
+    an image with no detection; boxes / scores / classes bit-exact."""
+    from tests.hip_utils import DEV
+    from ultralytics_pro_amd.utils.nms import rtdetr_postprocess
+    B, Q, nc = 5, 300, 80
+    box = P.uniform("rtp_box", (B, Q, 4), 0.05, 0.9)
+    sc = P.uniform("rtp_sc", (B, Q, nc), 0.0, 0.6)
+    sc[1, 10] = sc[1, 3]             # a tie in every class of two queries
+    sc[2] *= 0.3                     # nothing above conf in image 2
+    sc[3, :, 7] = 0.9 + 0.0001 * torch.arange(Q)  # every query valid: max_det truncation
+    preds = torch.cat([box, sc], -1).contiguous()
+    for conf, max_det, classes, shapes in ((0.25, 300, None, None), (0.4, 100, None, None), (0.25, 300, [7, 11, 42], None),
+                                           (0.3, 50, None, [(480, 640), (640, 640), (100, 200), (720, 1280), (333, 500)])):
+        ref = []
+        for i in range(B):
+            hw = (640, 640) if shapes is None else shapes[i]
+            ref += onms.rtdetr_postprocess(preds[i:i + 1], conf, max_det, imgsz=hw, classes=classes)
+        mine = rtdetr_postprocess(preds.to(DEV), conf, max_det, classes=classes, orig_shapes=shapes)
+        assert [m.shape[0] for m in mine] == [r.shape[0] for r in ref]
+        for a, b in zip(mine, ref):
+            assert torch.equal(a.cpu(), b)
+    assert ref[2].shape[0] == 0
 
 
 @pytest.mark.parametrize("shape", [(1, 384, 640), (3, 320, 256), (2, 352, 608)], ids=["b1_384x640", "b3_320x256", "b2_352x608"])

@@ -80,5 +80,15 @@ inline hipError_t upa_full_lds() {
   return e;
 }
 
+// Zero n 32-bit words with a kernel.  Used instead of hipMemsetAsync wherever the launch sequence may be captured into a
+// hipGraph: with several graphs of the same step in flight on separate streams, the runtime's memset nodes now and then
+// left the NMS candidate counters un-zeroed (ROCm 7.2) - a stale counter became a negative slot index and the candidate
+// store faulted gigabytes below the workspace ("Memory access fault by GPU", nms_candidates_kernel under
+// librocm-debug-agent).  A kernel node has none of that.
+__global__ void upa_zero_words_kernel(unsigned* p, int n);
+inline void upa_zero_words(void* p, int n_words, hipStream_t s) {
+  hipLaunchKernelGGL(upa_zero_words_kernel, dim3((n_words + 255) / 256), dim3(256), 0, s, (unsigned*)p, n_words);
+}
+
 static inline int upa_elem_size(int dtype) { return dtype == UPA_BF16 ? 2 : 4; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

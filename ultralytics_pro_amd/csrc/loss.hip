@@ -447,7 +447,7 @@ extern "C" int upa_detection_loss(const float* const* feats, float* const* grads
   Assign* asg = (Assign*)(cand + (size_t)b * MAXG * TOPK);
   int* count = (int*)(asg + (size_t)b * a);
   hipStream_t s = (hipStream_t)stream;
-  (void)hipMemsetAsync(wsb, 0, 64, s);
+  upa_zero_words(wsb, 16, s);  // not hipMemsetAsync: see upa_zero_words (common.h)
   const long total = (long)b * a;
   const int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
   hipLaunchKernelGGL(loss_decode_kernel, dim3(grid), dim3(256), 0, s, L, pbox);

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void nms_candidates_kernel(const float* pred, 
       base = __shfl(base, 0);
       if (cand) {
         const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
-        if (slot < cap) kb[slot] = ((u64)(~__float_as_uint(best)) << 32) | (unsigned)(a * nc + bc);
+        if (slot >= 0 && slot < cap) kb[slot] = ((u64)(~__float_as_uint(best)) << 32) | (unsigned)(a * nc + bc);
       }
     }
   } else {
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void nms_candidates_kernel(const float* pred, 
         base = __shfl(base, 0);
         if (cand) {
           const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
-          if (slot < cap) kb[slot] = ((u64)(~__float_as_uint(v)) << 32) | (unsigned)(a * nc + c);
+          if (slot >= 0 && slot < cap) kb[slot] = ((u64)(~__float_as_uint(v)) << 32) | (unsigned)(a * nc + c);
         }
       }
     }
@@ -312,10 +312,7 @@ extern "C" int upa_nms_batched(const float* pred, int b, int nc, int a, float co
   u64* keys = (u64*)ws;
   u64* sel = keys + (size_t)b * cap;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(count, 0, (size_t)b * 2 * sizeof(int), s) != hipSuccess) {
-    upa_set_error("nms: memset failed");
-    return UPA_ELAUNCH;
-  }
+  upa_zero_words(count, 2 * b, s);  // not hipMemsetAsync: see upa_zero_words (common.h)
   hipLaunchKernelGGL(nms_candidates_kernel, dim3((unsigned)cdiv(a, 256), (unsigned)b), dim3(256), 0, s, pred, b, nc, a,
                      conf_thres, multi_label, classes_mask, count, keys, cap);
   UPA_LAUNCH_CHECK();

@@ -15,6 +15,11 @@ void upa_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* upa_last_error(void) { return g_err; }
+
+__global__ void upa_zero_words_kernel(unsigned* p, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
 extern "C" int upa_version(void) { return 1; }
 
 extern "C" int upa_graph_begin(void* stream) {

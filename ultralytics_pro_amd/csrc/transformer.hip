@@ -227,6 +227,57 @@ extern "C" int upa_rtdetr_output(const float* boxes, const float* scores, float*
   return UPA_OK;
 }
 
+// RTDETRPredictor.postprocess (ultralytics/models/rtdetr/predict.py:35-74), one workgroup per image, one thread per
+// query: xywh2xyxy (ops.py:268-284: xy -/+ wh / 2), best class (first maximum, as torch.max), score > conf (and the
+// optional class filter), descending score order (ties: lower query first - the oracle's stable argsort), [:max_det],
+// x * ow, y * oh.  Fixed-shape outputs (out (B, max_det, 6), counts (B,)) so the step stays capturable; every float
+// operation is the reference's, in its order, with FP contraction off: bit-exact.
+__global__ __launch_bounds__(1024) void rtdetr_postprocess_kernel(const float* preds, int Q, int nc, float conf,
+                                                                  const unsigned char* classes_mask, int max_det,
+                                                                  const float* orig_wh, float ow, float oh, float* out,
+                                                                  int* counts) {
+  extern __shared__ float sc[];  // [Q] score of a valid query, -1 for a filtered one (scores are sigmoids: > 0)
+  const int b = blockIdx.x, q = threadIdx.x;
+  float box[4] = {0.f, 0.f, 0.f, 0.f}, best = -1.f;
+  int cls = 0;
+  bool valid = false;
+  if (q < Q) {
+    const float* p = preds + ((size_t)b * Q + q) * (4 + nc);
+    const float hw = p[2] / 2, hh = p[3] / 2;
+    box[0] = p[0] - hw; box[1] = p[1] - hh; box[2] = p[0] + hw; box[3] = p[1] + hh;
+    best = p[4];
+    for (int c = 1; c < nc; ++c)
+      if (p[4 + c] > best) { best = p[4 + c]; cls = c; }
+    valid = best > conf && (!classes_mask || classes_mask[cls]);
+    sc[q] = valid ? best : -1.f;
+  }
+  __syncthreads();
+  if (orig_wh) { ow = orig_wh[2 * b]; oh = orig_wh[2 * b + 1]; }
+  int rank = 0, nvalid = 0;
+  for (int j = 0; j < Q; ++j) {
+    const float s = sc[j];
+    nvalid += s >= 0.f;
+    rank += (s > best) || (s == best && j < q);
+  }
+  if (q == 0) counts[b] = nvalid < max_det ? nvalid : max_det;
+  if (valid && rank < max_det) {
+    float* o = out + ((size_t)b * max_det + rank) * 6;
+    o[0] = box[0] * ow; o[1] = box[1] * oh; o[2] = box[2] * ow; o[3] = box[3] * oh;
+    o[4] = best; o[5] = (float)cls;
+  }
+}
+extern "C" int upa_rtdetr_postprocess(const float* preds, int b, int q, int nc, float conf, const unsigned char* classes_mask,
+                                      int max_det, const float* orig_wh, float ow, float oh, float* out, int32_t* counts,
+                                      void* stream) {
+  UPA_CHECK_ARG(preds && out && counts && b > 0 && nc > 0 && max_det > 0, "rtdetr_postprocess: bad args");
+  UPA_CHECK_ARG(q > 0 && q <= 1024, "rtdetr_postprocess: 1..1024 queries per image (head.py:1905 uses 300), got %d", q);
+  const int threads = (q + 63) / 64 * 64;
+  hipLaunchKernelGGL(rtdetr_postprocess_kernel, dim3((unsigned)b), dim3(threads), (size_t)q * sizeof(float), (hipStream_t)stream,
+                     preds, q, nc, conf, classes_mask, max_det, orig_wh, ow, oh, out, (int*)counts);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Multi-scale deformable attention sampling (nn/modules/utils.py:103-159 + transformer.py:540-556, 4-d reference boxes):
 //   for (b, q, head): w = softmax over (levels x points) of the attention logits;

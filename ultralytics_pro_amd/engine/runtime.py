@@ -61,6 +61,9 @@ def view_of(t: torch.Tensor) -> View:
     return View(t.data_ptr(), n, h, w, c, _pixel_stride(t), L.dtype_code(t.dtype))
 
 
+_TRACE_POOL = bool(__import__("os").environ.get("UPA_POOL_TRACE"))
+
+
 class BufferPool:
     """Static activation buffers keyed by call site: the second and later forwards of a model allocate nothing, which
     is what makes the layer loop capturable into a hipGraph (no allocator calls inside the captured region)."""
@@ -74,6 +77,10 @@ class BufferPool:
         if t is None:
             t = torch.empty(shape, dtype=dtype, device=device)
             self.buffers[k] = t
+            if _TRACE_POOL:
+                import sys
+                print(f"[pool] {t.data_ptr():#x} +{t.numel() * t.element_size():#x} end {t.data_ptr() + t.numel() * t.element_size():#x} {key}",
+                      file=sys.stderr, flush=True)
         return t
 
     def nbytes(self) -> int:

@@ -63,6 +63,11 @@ class PackedConv:
         wc = w.contiguous()
         L.check(L.lib().upa_pack_conv_weight(wc.data_ptr(), self.cout, self.cin, k, code, host.data_ptr()), "pack_conv")
         self.w = host.to(device)
+        if R._TRACE_POOL:
+            import sys
+            for nm, t in (("w", self.w), ("bias", self.bias)):
+                print(f"[pool] {t.data_ptr():#x} +{t.numel() * t.element_size():#x} end {t.data_ptr() + t.numel() * t.element_size():#x} "
+                      f"packed {nm} cout={self.cout} cin={self.cin} k={k}", file=sys.stderr, flush=True)
 
 
 def hip_conv2d(x: torch.Tensor, pk: PackedConv, stride: int, pad: int, act: int, out: torch.Tensor | None = None,

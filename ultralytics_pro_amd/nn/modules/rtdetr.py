@@ -325,8 +325,17 @@ class RTDETRDecoder(nn.Module):
         feats = _Rows.new(bs * T, hd, dev, key=(id(self), "feats"))
         row0 = 0
         for i, t in enumerate(x):
-            if t.dtype != torch.float32:
-                raise L.UpaError("RTDETRDecoder runs in float32 (parity mode); run the backbone in float32 too")
+            if t.dtype == torch.bfloat16:
+                # bf16 backbone (perf mode): the decoder itself stays in float32 - its 300-query attention stack is < 5 %
+                # of the model's FLOPs and carries the score ranking - so the three feature maps are widened once here
+                vt = R.view_of(t)
+                tf = R.alloc_nhwc(vt.n, vt.c, vt.h, vt.w, torch.float32, dev, key=(id(self), "widen", i))
+                vf = R.view_of(tf)
+                L.check(lib.upa_cast_view(vt.ptr, L.UPA_BF16, vt.ld, vf.ptr, L.UPA_F32, vf.ld, vt.n * vt.h * vt.w, vt.c, st_),
+                        "cast_view")
+                t = tf
+            elif t.dtype != torch.float32:
+                raise L.UpaError(f"RTDETRDecoder takes float32 or bfloat16 feature maps, got {t.dtype}")
             conv, bn = self.input_proj[i][0], self.input_proj[i][1]
             cache = self.__dict__.setdefault("_pk_cache", {})
             pk = cache.get(("proj", i, str(dev)))

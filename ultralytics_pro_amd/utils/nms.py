@@ -64,3 +64,36 @@ def non_max_suppression(prediction, conf_thres: float = 0.25, iou_thres: float =
     if return_idxs:
         return res, [keep[i, : n[i]].long() for i in range(len(n))]
     return res
+
+
+def rtdetr_postprocess_raw(preds: torch.Tensor, conf: float = 0.25, max_det: int = 300, imgsz=(640, 640), classes=None,
+                           orig_shapes=None, key=None):
+    """Device-side RTDETRPredictor.postprocess (models/rtdetr/predict.py:35-74): (out (B, max_det, 6) f32, counts (B,)
+    int32) without syncing.  `imgsz` = (h, w) every box is scaled to, or `orig_shapes` = per-image (h, w) list."""
+    if isinstance(preds, (list, tuple)):
+        preds = preds[0]
+    L.require_gpu(preds, "rtdetr_postprocess")
+    if preds.dtype != torch.float32 or not preds.is_contiguous() or preds.dim() != 3:
+        raise L.UpaError("rtdetr_postprocess expects the contiguous float32 (B, queries, 4+nc) RTDETRDecoder output")
+    b, q, nd = preds.shape
+    nc, dev = nd - 4, preds.device
+    out = R.alloc_plain((b, max_det, 6), torch.float32, dev, key=(key, "rtdetr_out"))
+    counts = R.alloc_plain((b,), torch.int32, dev, key=(key, "rtdetr_counts"))
+    cmask = wh = None
+    if classes is not None:
+        m = torch.zeros(nc, dtype=torch.uint8)
+        m[torch.as_tensor(list(classes), dtype=torch.long)] = 1
+        cmask = m.to(dev)
+    if orig_shapes is not None:
+        wh = torch.tensor([[float(s[1]), float(s[0])] for s in orig_shapes], dtype=torch.float32).to(dev)
+    L.check(L.lib().upa_rtdetr_postprocess(preds.data_ptr(), b, q, nc, float(conf), None if cmask is None else cmask.data_ptr(),
+                                           int(max_det), None if wh is None else wh.data_ptr(), float(imgsz[1]), float(imgsz[0]),
+                                           out.data_ptr(), counts.data_ptr(), L.current_stream(dev)), "rtdetr_postprocess")
+    return out, counts
+
+
+def rtdetr_postprocess(preds, conf: float = 0.25, max_det: int = 300, imgsz=(640, 640), classes=None, orig_shapes=None):
+    """List of (n, 6) tensors [x1, y1, x2, y2, score, cls] per image, sorted by score (models/rtdetr/predict.py:35-74)."""
+    out, counts = rtdetr_postprocess_raw(preds, conf, max_det, imgsz, classes, orig_shapes)
+    n = counts.tolist()
+    return [out[i, : n[i]] for i in range(len(n))]
