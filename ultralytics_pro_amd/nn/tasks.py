@@ -168,6 +168,9 @@ class HipSequential(nn.Sequential):
 _OUT_CAPABLE = (Conv, C2f, C3, SPPF, BoT3, Bottleneck, Upsample, MaxPool2d, HipSequential)
 
 
+_EXTRA_LAUNCHES = int(__import__("os").environ.get("UPA_EXTRA_LAUNCHES", "0"))
+
+
 class BaseModel(nn.Module):
     """Base class: forward -> predict -> _predict_once (tasks.py:987-1134)."""
 
@@ -228,6 +231,10 @@ class BaseModel(nn.Module):
             else:
                 x = m(x)
             y.append(x if m.i in self.save else None)
+            if _EXTRA_LAUNCHES and torch.is_tensor(x):  # experiment: what does one more tiny dependent launch cost a step?
+                d = R.alloc_plain((64,), torch.float32, x.device, key=("extra_launch", m.i))
+                for _ in range(_EXTRA_LAUNCHES):
+                    L.check(L.lib().upa_sigmoid(d.data_ptr(), d.data_ptr(), 64, L.current_stream(x.device)), "extra")
             if m.i in det_level and torch.is_tensor(x):  # a Detect input is ready: start that level's branches now
                 det.start_level(det_level[m.i], x)
         return x
