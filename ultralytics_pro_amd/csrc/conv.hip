@@ -832,6 +832,15 @@ extern "C" int upa_conv2d_bias_act(const void* x, int n, int h, int w, int cin, 
   int ckt = (p.KTT % 4 == 0) ? 4 : ((p.KTT % 2 == 0) ? 2 : 1);
   if ((stride == 2 || p.NTn == 5 || p.NTn == 3) && ckt > 2) ckt = 2;
   if (k > 3 && ckt > 1) ckt = 1;
+  {
+    // Tuning knob, off by default: UPA_CONV_CKT2_MAXPX=<pixels> caps the chunk at 2 k-tiles for layers with at most that
+    // many output pixels.  4 k-tiles win a layer timed alone (fewer barriers: serial step 1.512 vs 1.544 ms); 2 leave room
+    // for a co-resident workgroup: 0.948 vs 0.960 ms per step with four steps in flight, 15.19 vs 15.42 ms per yolov8s
+    // training step.  Not the default: the different summation order moves the bf16 training losses of the yolov8n golden
+    // test from 10 % to 13 % off the f32 reference (assigner flips), past that test's statistical bound.
+    static const long ckt2_maxpx = getenv("UPA_CONV_CKT2_MAXPX") ? atol(getenv("UPA_CONV_CKT2_MAXPX")) : 0;
+    if (ckt == 4 && (long)n * p.OH * p.OW <= ckt2_maxpx) ckt = 2;
+  }
   if (const char* e = getenv("UPA_CONV_CKT")) {  // tuning override (must still divide KTT)
     const int v = atoi(e);
     if ((v == 1 || v == 2 || v == 4) && p.KTT % v == 0 && v <= ckt) ckt = v;
