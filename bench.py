@@ -428,6 +428,8 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
                 var = L.lib().upa_conv_variant(n, h, w, cin, pk.cout, pk.k, stride, pad, code)
                 if (var >> 22) & 1:  # streaming pointwise kernel (conv1x1.hip): <NTW, MT, WAVES>
                     name = "void conv1x1_stream_kernel<%d, %d, %d>(C1Params)" % (var & 15, (var >> 4) & 15, (var >> 8) & 31)
+                elif (var >> 21) & 1 and (var >> 8) & 1:  # 16 -> 16 channel variant of the pipelined kernel: <act, residual>
+                    name = "void conv3x3_c16_kernel<%d, %s>(PipeParams)" % (act, "true" if residual is not None else "false")
                 elif (var >> 21) & 1:  # software-pipelined 3x3 (conv_pipe.hip): <NTW, act, residual>
                     name = "void conv3x3_pipe_kernel<%d, %d, %s>(PipeParams)" % (
                         var & 15, act, "true" if residual is not None else "false")

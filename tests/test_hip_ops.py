@@ -81,6 +81,8 @@ PIPE_CASES = [
     (64, 80, 8, 16, 2),
     (48, 48, 16, 16, 1),     # 48 couts = 32 + 16
     (24, 16, 8, 16, 1),      # Cin 24: partial k-tile
+    (16, 16, 8, 16, 3),      # 16 -> 16: the two-taps-per-MFMA variant (conv3x3_c16_kernel), one tile per image
+    (16, 16, 40, 48, 2),     # ... many tiles per persistent wave, interior tiles
 ]
 
 
@@ -149,6 +151,14 @@ def test_conv_pipe_residual_and_concat_views():
     pm, _ = _mods()
     o, m = _pair(om.C2f, pm.C2f, (64, 64, 2, True), "c2f_pipe")
     x = bf16_round(P.uniform("c2f_pipe_x", (2, 64, 16, 32), -1, 1))
+    with torch.no_grad():
+        ref = o(x)
+        y = to_cpu_nchw(m(to_dev_nhwc(x, torch.bfloat16)))
+    err = (y - ref).abs().max().item()
+    assert err <= 4e-2 * max(1.0, ref.abs().max().item()), err
+    # 32-channel C2f: its Bottlenecks are 16 -> 16 convs with shortcut (conv3x3_c16_kernel, residual epilogue)
+    o, m = _pair(om.C2f, pm.C2f, (32, 32, 2, True), "c2f_c16")
+    x = bf16_round(P.uniform("c2f_c16_x", (2, 32, 24, 32), -1, 1))
     with torch.no_grad():
         ref = o(x)
         y = to_cpu_nchw(m(to_dev_nhwc(x, torch.bfloat16)))

@@ -247,6 +247,185 @@ __global__ __launch_bounds__(WAVES * 64, 1) void conv3x3_pipe_kernel(const PipeP
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 16 -> 16 channel variant (the Bottleneck convs of the first C2f, 160 x 160 at 640 px input: 819 k pixels per launch).
+// With 16 input channels a 64-byte k-tile is half padding and the generic kernels spend ~150 VALU instructions per
+// 16-pixel MFMA column on addresses and padding (PMC: the layer took the same 33 us with loads, stores and MFMAs removed).
+// Here the halo pixel is 32 data bytes (+16 pad) and ONE MFMA k-step covers TWO taps: lane groups kg 0/1 carry the 16
+// channels of tap 2s, groups 2/3 those of tap 2s+1 (the A fragment is assembled from the standard packed weights by a lane
+// remap; the tenth tap is zero), so a tile row costs 5 MFMAs and 5 immediate-offset ds_read_b128 instead of 9 + 9.
+// The epilogue pairs two pixel ROWS through v_permlane16_swap: every lane stores 16 bytes (8 channels of one pixel).
+namespace c16 {
+constexpr int PS = 48;                       // LDS bytes per halo pixel
+constexpr int NSLOT = IH * IW * 3;           // 16-byte DMA slots (2 data + 1 pad per pixel)
+constexpr int NDMA = (NSLOT + 63) / 64;      // 9
+constexpr int HB = NDMA * 1024;
+}  // namespace c16
+
+template <int ACT, bool RES>
+__global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_c16_kernel(const PipeParams p) {
+  using namespace c16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  char* hb = smem + wave * (2 * c16::HB);
+  const int kg = lane >> 4, p16 = lane & 15;
+
+  int rel[c16::NDMA], meta[c16::NDMA];
+#pragma unroll
+  for (int k = 0; k < c16::NDMA; ++k) {
+    const int slot = k * 64 + lane;
+    const int pixel = slot / 3, grp = slot - pixel * 3;
+    const int py = pixel / IW, px = pixel - py * IW;
+    rel[k] = ((py * p.W + px) * p.ldx + grp * 8) * 2;
+    meta[k] = (py == 0 ? 1 : 0) | (py == IH - 1 ? 2 : 0) | (px == 0 ? 4 : 0) | (px == IW - 1 ? 8 : 0) |
+              ((grp == 2 || slot >= c16::NSLOT) ? 16 : 0);
+  }
+  const int gw = blockIdx.x * WAVES + wave, GW = gridDim.x * WAVES;
+  if (gw >= p.numTiles) return;
+  const int tilesPerImg = p.tilesX * p.tilesY;
+  struct TileCtx {
+    int n, oy0, ox0, em;
+    const char* xb;
+  };
+  auto decode = [&](int t) __attribute__((always_inline)) {
+    TileCtx c;
+    c.n = t / tilesPerImg;
+    const int t2 = t - c.n * tilesPerImg;
+    const int tyi = t2 / p.tilesX, txi = t2 - tyi * p.tilesX;
+    c.oy0 = tyi * TH;
+    c.ox0 = txi * TW;
+    c.em = (c.oy0 == 0 ? 1 : 0) | (c.oy0 + TH >= p.H ? 2 : 0) | (c.ox0 == 0 ? 4 : 0) | (c.ox0 + TW >= p.W ? 8 : 0);
+    c.xb = p.x + ((long)((c.n * p.H + c.oy0 - 1) * p.W + c.ox0 - 1) * p.ldx) * 2;
+    return c;
+  };
+  auto issue_dma = [&](const TileCtx& c, int buf) __attribute__((always_inline)) {
+    if (p.ablate & 1) return;
+#pragma unroll
+    for (int k = 0; k < c16::NDMA; ++k) {
+      const bool valid = (meta[k] & (c.em | 16)) == 0;
+      const char* src = valid ? c.xb + rel[k] : reinterpret_cast<const char*>(g_pipe_zero16);
+      __builtin_amdgcn_global_load_lds((pgptr_t)src, (plptr_t)(hb + buf * c16::HB + k * 1024), 16, 0, 0);
+    }
+  };
+  // A fragments of the five tap pairs (standard packing: [tap][ktile 0][ntile 0][lane][16 B], lanes kg 0/1 = channels 0-15)
+  u32x4 A[5];
+  int boffs[5];  // this lane's byte offset of its tap inside the halo, relative to (row 0, pixel p16)
+#pragma unroll
+  for (int s2 = 0; s2 < 5; ++s2) {
+    const int tap = 2 * s2 + (kg >> 1);
+    const int tapc = tap < 9 ? tap : 8;
+    A[s2] = (tap < 9 && !(p.ablate & 2))
+                ? *reinterpret_cast<const u32x4*>(p.w + ((size_t)tap * p.NTn * 1024 + ((kg & 1) * 16 + p16) * 16))
+                : u32x4{0u, 0u, 0u, 0u};
+    const int dy = tapc / 3, dx = tapc - dy * 3;
+    boffs[s2] = ((dy * IW + dx + p16) * c16::PS) + (kg & 1) * 16;
+  }
+  const f32x4 biasv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + kg * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  auto act = [](float v) __attribute__((always_inline)) {
+    if constexpr (ACT == UPA_ACT_SILU) return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+    else return v;
+  };
+
+  int tile = gw, buf = 0;
+  bool first = true;
+  TileCtx cur = decode(tile);
+  issue_dma(cur, 0);
+  while (true) {
+    const int ntile = tile + GW;
+    const bool hasNext = ntile < p.numTiles;
+    TileCtx nxt = cur;
+    // this tile's halo must have landed; the TH / 2 stores of the previous tile are the youngest vector-memory operations of
+    // the wave (operations retire in issue order) and may stay in flight
+    if (first || (p.ablate & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    first = false;
+    static_assert(TH == 8, "vmcnt(4) above = TH / 2 epilogue stores");
+    if (hasNext) {
+      nxt = decode(ntile);
+      issue_dma(nxt, buf ^ 1);
+    }
+    const char* hbuf = hb + buf * c16::HB;
+    f32x4 acc[TH];
+#pragma unroll
+    for (int i = 0; i < TH; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!(p.ablate & 8)) {
+#pragma unroll
+      for (int i = 0; i < TH; ++i) {
+#pragma unroll
+        for (int s2 = 0; s2 < 5; ++s2) {
+          const u32x4 b = *reinterpret_cast<const u32x4*>(hbuf + boffs[s2] + i * (IW * c16::PS));
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&A[s2]),
+                                                           *reinterpret_cast<const bf16x8*>(&b), acc[i], 0, 0, 0);
+        }
+      }
+    }
+    // epilogue: rows i (even) and i+1 swap halves - even 16-lane groups end up with 8 consecutive channels of row i, odd
+    // groups with 8 of row i+1
+    const unsigned pixbase = (unsigned)((cur.n * p.H + cur.oy0) * p.W + cur.ox0 + p16);
+#pragma unroll
+    for (int i = 0; i < TH; i += 2) {
+      float v0[4], v1[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v0[q] = act(acc[i][q] + biasv[q]);
+        v1[q] = act(acc[i + 1][q] + biasv[q]);
+      }
+      const unsigned pix = pixbase + (unsigned)((i + (kg & 1)) * p.W);
+      const int cb = 8 * (kg >> 1);
+      char* ydst = p.y + ((size_t)pix * p.ldy + cb) * 2;
+      if constexpr (RES) {
+        float x8[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v0[q]), __float_as_uint(v1[q]), false, false);
+          x8[q] = __uint_as_float(sw[0]);
+          x8[4 + q] = __uint_as_float(sw[1]);
+        }
+        const u32x4 rv = *reinterpret_cast<const u32x4*>(p.res + ((size_t)pix * p.ldr + cb) * 2);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          x8[2 * q] += __uint_as_float(rv[q] << 16);
+          x8[2 * q + 1] += __uint_as_float(rv[q] & 0xFFFF0000u);
+        }
+        if (!(p.ablate & 4))
+          *reinterpret_cast<u32x4*>(ydst) = u32x4{pack_bf16x2(x8[0], x8[1]), pack_bf16x2(x8[2], x8[3]),
+                                                  pack_bf16x2(x8[4], x8[5]), pack_bf16x2(x8[6], x8[7])};
+      } else {
+        auto lo = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v1[0], v1[1]), false, false);
+        auto hi = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[2], v1[3]), false, false);
+        if (!(p.ablate & 4)) *reinterpret_cast<u32x4*>(ydst) = u32x4{lo[0], hi[0], lo[1], hi[1]};
+      }
+    }
+    if (!hasNext) break;
+    cur = nxt;
+    tile = ntile;
+    buf ^= 1;
+  }
+}
+
+static int launch_c16(const PipeParams& p, hipStream_t s) {
+  const size_t lds = (size_t)WAVES * 2 * c16::HB;
+  static const int max_wgs = getenv("UPA_C16_WGS") ? atoi(getenv("UPA_C16_WGS")) : 512;
+  int grid = (p.numTiles + WAVES - 1) / WAVES;
+  if (grid > max_wgs) grid = max_wgs;
+#define UPA_C16_LAUNCH(ACT_, RES_)                                                                        \
+  do {                                                                                                    \
+    (void)upa_full_lds<conv3x3_c16_kernel<ACT_, RES_>>();                                                 \
+    hipLaunchKernelGGL((conv3x3_c16_kernel<ACT_, RES_>), dim3(grid), dim3(WAVES * 64), lds, s, p);        \
+  } while (0)
+  if (p.act == UPA_ACT_SILU) {
+    if (p.res) UPA_C16_LAUNCH(UPA_ACT_SILU, true);
+    else UPA_C16_LAUNCH(UPA_ACT_SILU, false);
+  } else {
+    if (p.res) UPA_C16_LAUNCH(UPA_ACT_NONE, true);
+    else UPA_C16_LAUNCH(UPA_ACT_NONE, false);
+  }
+#undef UPA_C16_LAUNCH
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
 template <int NTW>
 static int launch_pipe(const PipeParams& p, int grid, hipStream_t s) {
   const size_t lds = (size_t)WAVES * 2 * HB;
@@ -281,7 +460,9 @@ bool upa_conv_pipe_eligible(int n, int h, int w, int cin, int ldx, int cout, int
   // input for too little work (31.3 vs 28.6, 46.9 vs 41.0)
   const int ntn = (cout + 15) / 16;
   static const bool all_shapes = getenv("UPA_PIPE_ALL") != nullptr;
-  if (!all_shapes && (ntn & 1) && !(ntn >= 5 && cin >= 80)) return false;
+  static const bool no_c16 = getenv("UPA_CONV_NO_C16") != nullptr;
+  const bool c16_shape = cin == 16 && cout == 16 && !no_c16;  // conv3x3_c16_kernel
+  if (!all_shapes && !c16_shape && (ntn & 1) && !(ntn >= 5 && cin >= 80)) return false;
   const long px = (long)n * h * w;
   if (px * ldx * 2 >= (1L << 31) || px * ldy * 2 >= (1L << 31) || px * ldr * 2 >= (1L << 31)) return false;
   // enough wave tiles to fill the chip; low-resolution layers stay on the tile-per-workgroup kernel
@@ -299,6 +480,11 @@ int upa_conv_pipe_launch(PipeParams p, int query_only, int* variant, void* strea
   p.NTn = (p.Cout + 15) / 16;
   static const int ablate = getenv("UPA_PIPE_ABLATE") ? atoi(getenv("UPA_PIPE_ABLATE")) : 0;
   p.ablate = ablate;
+  static const bool no_c16 = getenv("UPA_CONV_NO_C16") != nullptr;
+  if (p.Cin == 16 && p.Cout == 16 && !no_c16) {
+    if (variant) *variant = (1 << 21) | (1 << 8) | 1;
+    return query_only ? UPA_OK : launch_c16(p, s);
+  }
   static const int max_wgs = getenv("UPA_PIPE_WGS") ? atoi(getenv("UPA_PIPE_WGS")) : 256;
   int grid = (p.numTiles + WAVES - 1) / WAVES;
   if (grid > max_wgs) grid = max_wgs;
