@@ -262,6 +262,81 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
     }
   }
 
+  // ---- bf16 epilogue straight from the accumulators (as conv_pipe.hip): bias, activation, bf16 pack, a
+  // v_permlane16_swap pairs neighbouring channel quads so every lane stores 16 contiguous bytes (64 B per pixel per
+  // instruction); the residual is read with the same shape.  No LDS round trip, no barrier, and the workgroup needs LDS
+  // for its halo only (one more co-resident workgroup per CU on most layers).  UPA_CONV_LDS_EPILOGUE=1 (p.ablate bit 6)
+  // keeps the two-phase LDS form below, which the f32 parity mode always uses.
+  if constexpr (ES == 2) {
+    if (!(p.ablate & 64)) {
+      auto direct = [&](auto act_tag) __attribute__((always_inline)) {
+        constexpr int ACT = decltype(act_tag)::value;
+        const int cw = (blockIdx.y * WN + wn) * NTW * 16;  // first channel of this wave
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) {
+          const int oy = oy0 + pty[i], ox = ox0 + ptx[i];
+          const bool pok = pty[i] < p.TH && oy < p.OH && ox < p.OW && !(p.ablate & 4);
+          const size_t pixoff = ((size_t)n * p.OH + oy) * p.OW + ox;
+          char* yrow = p.y + (pixoff * p.ldy + cw) * 2;
+          const char* rrow = p.res ? p.res + (pixoff * p.ldr + cw) * 2 : nullptr;
+#pragma unroll
+          for (int j = 0; j + 1 < NTW; j += 2) {
+            const int cb = 16 * (j + (g & 1)) + 8 * (g >> 1);
+            float v0[4], v1[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              v0[q] = act_fn<false, ACT>(acc[i][j][q] + biasv[j][q]);
+              v1[q] = act_fn<false, ACT>(acc[i][j + 1][q] + biasv[j + 1][q]);
+            }
+            const bool ok = pok && cw + cb < p.Cout;
+            if (p.res) {
+              float x8[8];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v0[q]), __float_as_uint(v1[q]), false, false);
+                x8[q] = __uint_as_float(sw[0]);
+                x8[4 + q] = __uint_as_float(sw[1]);
+              }
+              if (ok) {
+                const u32x4 rv = *reinterpret_cast<const u32x4*>(rrow + cb * 2);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  x8[2 * q] += __uint_as_float(rv[q] << 16);
+                  x8[2 * q + 1] += __uint_as_float(rv[q] & 0xFFFF0000u);
+                }
+                *reinterpret_cast<u32x4*>(yrow + cb * 2) = u32x4{pack_bf16x2(x8[0], x8[1]), pack_bf16x2(x8[2], x8[3]),
+                                                                pack_bf16x2(x8[4], x8[5]), pack_bf16x2(x8[6], x8[7])};
+              }
+            } else {
+              auto lo = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v1[0], v1[1]), false, false);
+              auto hi = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[2], v1[3]), false, false);
+              if (ok) *reinterpret_cast<u32x4*>(yrow + cb * 2) = u32x4{lo[0], hi[0], lo[1], hi[1]};
+            }
+          }
+          if constexpr (NTW & 1) {
+            constexpr int j = NTW - 1;
+            const int cb = 16 * j + 4 * g;
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = act_fn<false, ACT>(acc[i][j][q] + biasv[j][q]);
+            if (pok && cw + cb < p.Cout) {
+              if (p.res) {
+                const u32x2 rv = *reinterpret_cast<const u32x2*>(rrow + cb * 2);
+                v[0] += __uint_as_float(rv[0] << 16); v[1] += __uint_as_float(rv[0] & 0xFFFF0000u);
+                v[2] += __uint_as_float(rv[1] << 16); v[3] += __uint_as_float(rv[1] & 0xFFFF0000u);
+              }
+              *reinterpret_cast<u32x2*>(yrow + cb * 2) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            }
+          }
+        }
+      };
+      if (p.act == UPA_ACT_SILU) direct(std::integral_constant<int, UPA_ACT_SILU>{});
+      else if (p.act == UPA_ACT_RELU) direct(std::integral_constant<int, UPA_ACT_RELU>{});
+      else direct(std::integral_constant<int, UPA_ACT_NONE>{});
+      return;
+    }
+  }
+
   // ---- epilogue.  Phase 1: every lane writes act(acc + bias) as f32 into an LDS [pixel][channel] tile (the halo
   // buffer is dead by now).  Phase 2: the workgroup streams the tile out as whole NHWC rows - 16 bytes per lane,
   // BN*ES contiguous bytes per pixel (128 B for 64 bf16 channels) - adding the residual from equally coalesced loads.
@@ -611,8 +686,10 @@ int launch_conv_ckt(ConvParams& p, hipStream_t stream) {
   p.stageRows = (WM * WN * 64) / (p.IW * CKT * 4);
   if (p.stageRows < 1) p.stageRows = 1;  // halo row wider than the workgroup: threads stride over its columns
   size_t lds = (((size_t)IHalloc * p.IW * (p.CKT * 4) + 63) & ~(size_t)63) * 16 + 1024;
+  static const bool lds_epilogue = getenv("UPA_CONV_LDS_EPILOGUE") != nullptr;
+  if (lds_epilogue) p.ablate |= 64;
   const size_t ldsOut = (size_t)BM * (BN + 4) * sizeof(float);
-  if (ldsOut > lds) lds = ldsOut;
+  if ((sizeof(T) == 4 || lds_epilogue) && ldsOut > lds) lds = ldsOut;  // the bf16 epilogue does not go through LDS
   if (lds > 160 * 1024) return UPA_EUNSUPPORTED;
   dim3 grid((unsigned)((long)p.tilesX * p.tilesY * p.N), (unsigned)cdiv(p.NTn * 16, BN));
   auto kern = conv_igemm_kernel<T, WM, WN, MTW, NTW, CKT>;
