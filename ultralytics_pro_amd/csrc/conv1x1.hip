@@ -39,18 +39,21 @@ __device__ __forceinline__ void for_stages(F& f, std::integer_sequence<int, Is..
   (f(std::integral_constant<int, Is>{}), ...);
 }
 
-// s_waitcnt takes an immediate: uniform compare tree over the possible counts (a smaller count than necessary is safe)
+// s_waitcnt takes an immediate.  In steady state the count a wave needs is one of three values - the DMAs of the RING-1
+// younger stages plus the stores of zero, one or two epilogues - so three uniform compares pick it; anything else (the
+// first / last groups of a wave, masked tail stores) waits for everything, which is always safe.  (A generic 49-way
+// switch here compiled to a compare tree that made the kernel SALU-bound: 150 s_waitcnt sites, 430 branches.)
+template <int N>
+__device__ __forceinline__ void vm_wait_imm() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+template <int C0, int SE>
 __device__ __forceinline__ void vm_wait(int n) {
-#define UPA_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-  switch (n) {
-    UPA_W(0) UPA_W(1) UPA_W(2) UPA_W(3) UPA_W(4) UPA_W(5) UPA_W(6) UPA_W(7) UPA_W(8) UPA_W(9) UPA_W(10) UPA_W(11)
-    UPA_W(12) UPA_W(13) UPA_W(14) UPA_W(15) UPA_W(16) UPA_W(17) UPA_W(18) UPA_W(19) UPA_W(20) UPA_W(21) UPA_W(22)
-    UPA_W(23) UPA_W(24) UPA_W(25) UPA_W(26) UPA_W(27) UPA_W(28) UPA_W(29) UPA_W(30) UPA_W(31) UPA_W(32) UPA_W(33)
-    UPA_W(34) UPA_W(35) UPA_W(36) UPA_W(37) UPA_W(38) UPA_W(39) UPA_W(40) UPA_W(41) UPA_W(42) UPA_W(43) UPA_W(44)
-    UPA_W(45) UPA_W(46) UPA_W(47) UPA_W(48)
-    default: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
-  }
-#undef UPA_W
+  if (n == C0) vm_wait_imm<C0>();
+  else if (n == C0 + SE) vm_wait_imm<(C0 + SE < 64 ? C0 + SE : 0)>();
+  else if (n == C0 + 2 * SE) vm_wait_imm<(C0 + 2 * SE < 64 ? C0 + 2 * SE : 0)>();
+  else vm_wait_imm<0>();
 }
 }  // namespace
 
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_stream_kernel(const C1Para
   auto step = [&](auto stage_tag) __attribute__((always_inline)) {
     constexpr int S = decltype(stage_tag)::value;
     issue((S + RING - 1) % RING);  // the stage multiplied one step ago is free again
-    vm_wait(seq - mark[S]);
+    vm_wait<(RING - 1) * MT, MT * ((NTW + 1) / 2)>(seq - mark[S]);
     if (!(p.ablate & 8)) {
       const char* st = ring + S * MT * 1024 + lane * 16;
       const char* wk = wl + ckt * (NTW * 1024) + lane * 16;
