@@ -126,15 +126,26 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
   // tap t run from one buffer, the 1 KiB-per-wave coalesced loads of tap t+1 (or of the next chunk's first tap - they
   // do not depend on the LDS tile) land in the other.
   u32x4 A0[CKT][NTW], A1[CKT][NTW];
+  // n-tiles past the packed weights (Cout 80 run as 96) contribute zeros; the common case - every n-tile of the wave
+  // exists - is decided once, so a tap's fragment loads are straight-line code (the per-fragment test compiled into a
+  // uniform branch and a block of register moves per load)
+  const bool wfull = nt0 + NTW <= p.NTn && !(p.ablate & 2);
   auto fetch_tap = [&](u32x4(&dst)[CKT][NTW], int c, int tap) {
     const char* wb = wuni + (size_t)(tap * p.KTT + c * CKT) * wTileStride;
-    if (p.ablate & 2) return;
+    if (wfull) {
 #pragma unroll
-    for (int kt = 0; kt < CKT; ++kt)
+      for (int kt = 0; kt < CKT; ++kt)
 #pragma unroll
-      for (int j = 0; j < NTW; ++j)  // n-tiles past the packed weights (Cout 80 run as 96) contribute zeros
-        dst[kt][j] = (nt0 + j < p.NTn) ? *reinterpret_cast<const u32x4*>(wb + kt * wTileStride + j * 1024 + lane16)
-                                       : u32x4{0u, 0u, 0u, 0u};
+        for (int j = 0; j < NTW; ++j) dst[kt][j] = *reinterpret_cast<const u32x4*>(wb + kt * wTileStride + j * 1024 + lane16);
+    } else {
+      if (p.ablate & 2) return;
+#pragma unroll
+      for (int kt = 0; kt < CKT; ++kt)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+          dst[kt][j] = (nt0 + j < p.NTn) ? *reinterpret_cast<const u32x4*>(wb + kt * wTileStride + j * 1024 + lane16)
+                                         : u32x4{0u, 0u, 0u, 0u};
+    }
   };
   // LDS halo image: pixel-major, G16 16-byte slots per pixel, NO padding (the DMA writes 1 KiB contiguous per wave);
   // the 16-byte group cg of pixel pl sits in slot cg ^ swz(pl): conflict-free ds_read_b128 for CKT 1 / 2 (2-way CKT 4)
