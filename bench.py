@@ -50,6 +50,8 @@ def parse():
                     help="steps in flight: consecutive steps are replayed round-robin on this many HIP streams (each with its "
                          "own graph and static buffers), so the NMS tail of step k overlaps the convolutions of step k+1. "
                          "0 = autotune: a few (in-flight, micro-batches) pairs are timed for 20 steps, the fastest is used")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: run only the multi-rank plumbing (gloo rendezvous, barriers, max-over-ranks, the JSON line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true",
                     help="skip the per-layer roofline timing (counter-collection runs: tools/pmc_step.sh)")
@@ -65,8 +67,63 @@ def parse():
     return ap.parse_args()
 
 
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, the reference's idiom
+    (a generated command + `torch.distributed.run`, ultralytics/utils/dist.py:77-104).  Runs as a CHILD process before
+    anything in this process touches the GPU (never exec: replacing a process that initialised HIP takes the box down);
+    the child's rank 0 prints the JSON line, this process forwards the return code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:  # a free rendezvous port (dist.py:19-28 does the same)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def main_dry_run(args):
+    """--dry-run: the multi-rank plumbing of this script without a GPU (gloo): rendezvous, the barrier-bracketed timed
+    region, MAX-over-ranks of the time, the rank-0 JSON line.  The step is a host-side stand-in; nothing is measured."""
+    import torch.distributed as dist
+
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (1 + rank))  # ranks deliberately uneven: the reported time must be the slowest rank's
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run (no GPU work)", "value": round(args.batch * world * args.steps / dt, 1),
+                          "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": args.dtype, "data": "none (dry run)",
+                          "config": {"workload": f"dry-run of --workload {args.workload}", "global_batch": args.batch * world,
+                                     "per_gpu_batch": args.batch, "parallelism": f"dp{world}"}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    if args.dry_run:
+        return main_dry_run(args)
     if args.model is None:
         args.model = "yolov8s" if args.workload == "train" else "yolov8n"
     if args.workload == "train":

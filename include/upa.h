@@ -231,10 +231,11 @@ int upa_ema_update(float* ema, const float* v, long n, float d, const float* d_d
 /* dst view = src view converted between f32 and bf16 (head maps enter the loss as f32; c, strides multiples of 8). */
 int upa_cast_view(const void* src, int src_dtype, int lds, void* dst, int dst_dtype, int ldd, long npix, int c, void* stream);
 /* v8DetectionLoss forward + gradient wrt the raw head maps.  feats[l] / grads[l]: NHWC f32 rows [(b,y,x)][4*reg_max+nc]
- * with row stride lds[l]; gt: (b, max_gt = 64, 5) rows (cls, x1, y1, x2, y2) in pixels, n_gt[b] valid rows.
+ * with row stride lds[l]; gt: (b, max_gt, 5) rows (cls, x1, y1, x2, y2) in pixels, n_gt[b] valid rows; max_gt = the row
+ * capacity per image, any value in [1, 1024] (the reference pads to counts.max(), utils/loss.py:445-461).
  * loss_items = (box, cls, dfl) as the reference reports them; gradients are those of loss.sum() * grad_scale
  * (grad_scale = world_size, engine/trainer.py:424-425). */
-size_t upa_detection_loss_workspace_bytes(int b, int n_anchors);
+size_t upa_detection_loss_workspace_bytes(int b, int n_anchors, int max_gt);
 int upa_detection_loss(const float* const* feats, float* const* grads, const int* hs, const int* ws, const int* lds,
                        const float* strides, int n_levels, int b, int nc, int reg_max, const float* gt, const int* n_gt,
                        int max_gt, float gain_box, float gain_cls, float gain_dfl, float grad_scale, float* loss_items,

@@ -112,3 +112,25 @@ def test_world2_gloo_gradient_exchange_matches_reference_ddp_scheme():
         p.join(300)
         assert p.exitcode == 0
     assert sorted(q.get(timeout=5) for _ in range(2)) == [0, 1]
+
+
+def test_bench_gpus_flag_launches_ranks_itself():
+    """`python bench.py --gpus 2` (no launcher around it) starts two ranks through torch.distributed.run as a child
+    process (the reference's idiom, utils/dist.py:77-104) and rank 0 prints ONE JSON line with n_gpus = 2.  --dry-run keeps
+    the GPU out of it: gloo rendezvous on 127.0.0.1, barrier-bracketed region, MAX over ranks."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    for wl in ("infer", "train"):
+        r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--dry-run",
+                            "--workload", wl], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        rec = json.loads(lines[0])
+        assert rec["n_gpus"] == 2 and rec["config"]["parallelism"] == "dp2" and rec["config"]["global_batch"] == 64
+        assert rec["ms_per_step"] >= 2.0  # the slower rank (2 ms per step) sets the time

@@ -23,7 +23,7 @@ def _build(name, dtype):
     return m
 
 
-@pytest.mark.parametrize("name", ["yolov8n", "yolov3-tiny", "yolov5-BoT3"])
+@pytest.mark.parametrize("name", ["yolov8n", "yolov8s", "yolov3-tiny", "yolov5-BoT3"])
 def test_e2e_f32_matches_reference_golden(name, golden_dir):
     from tests.hip_utils import DEV
     from ultralytics_pro_amd.utils.nms import non_max_suppression
@@ -65,27 +65,99 @@ def test_e2e_graph_replay_equals_eager():
         assert torch.equal(out[i, : r.shape[0]].cpu(), r)
 
 
-def test_e2e_bf16_agrees_with_f32_detections():
-    """Perf mode: bf16 storage cannot hold 1e-3 on 640-px boxes; gate on the reference's own AMP tolerance
-    (utils/checks.py:780, atol 0.5) for matched detections and on detection-set agreement."""
-    from tests.hip_utils import DEV
+# bf16 perf mode vs the REFERENCE goldens (not vs the HIP f32 path).  8 mantissa bits cannot hold 1e-3 px on 640-px boxes,
+# so the gate is detection-set agreement with the reference's f32 detections: IoU >= 0.9 same-class one-to-one matches
+# both ways, and box / score deviation of the matched rows.  Bounds = measured on MI355X (round 2, printed by the test)
+# with ~1.5x headroom; the reference's own AMP check allows atol 0.5 on boxes (utils/checks.py:780).
+BF16_BOUNDS = {  # name: (min recall, min precision, box p99 px, box max px, score p99)
+    "yolov8n": (0.97, 0.97, 1.0, 4.0, 0.02),
+    "yolov8s": (0.97, 0.97, 1.0, 4.0, 0.02),
+    "yolov3-tiny": (0.97, 0.97, 1.0, 4.0, 0.02),
+    "yolov5-BoT3": (0.97, 0.97, 1.0, 4.0, 0.02),
+}
+
+
+@pytest.mark.parametrize("name", list(BF16_BOUNDS))
+def test_e2e_bf16_matches_reference_golden(name, golden_dir):
+    """HIP bf16 pipeline (the mode the headline number is quoted in) vs tests/golden/e2e_<name>.npz = the imported
+    reference's f32 CPU output on the same procedural weights and images."""
+    from tests.hip_utils import DEV, detection_agreement, split_rows
     from ultralytics_pro_amd.utils.nms import non_max_suppression
+    g = np.load(golden_dir / f"e2e_{name}.npz")
+    m = _build(name, torch.bfloat16)
+    x = P.synthetic_images(2).to(DEV).to(torch.bfloat16).contiguous()
+    with torch.no_grad():
+        y = m(x)[0]
+    torch.cuda.synchronize()
+    d = np.abs(y.cpu()[:, :, g["anchor_sel"]].numpy() - g["y_sel"])
+    dbox, dsc = d[:, :4].ravel(), d[:, 4:].ravel()
+    out = [o.cpu().numpy() for o in non_max_suppression(y, conf_thres=0.25, iou_thres=0.7, max_det=300)]
+    ref = split_rows(g["predict_rows"], g["predict_n"])
+    a = detection_agreement(out, ref, 0.9)
+    print(f"{name} bf16 vs reference golden: head box |d| p50={np.median(dbox):.3f} p99={np.quantile(dbox, 0.99):.3f} "
+          f"max={dbox.max():.3f} px, score max|d|={dsc.max():.4f}; detections {a['n_mine']} vs {a['n_ref']}: recall "
+          f"{a['recall']:.3f} precision {a['precision']:.3f}, matched box p50={a['box_p50']:.3f} p99={a['box_p99']:.3f} "
+          f"max={a['box_max']:.3f} px, score p99={a['score_p99']:.4f} max={a['score_max']:.4f}")
+    rmin, pmin, bp99, bmax, sp99 = BF16_BOUNDS[name]
+    assert a["recall"] >= rmin and a["precision"] >= pmin
+    assert a["box_p99"] <= bp99 and a["box_max"] <= bmax and a["score_p99"] <= sp99
+    assert np.quantile(dbox, 0.99) <= bmax and dsc.max() <= 0.05
+
+
+@pytest.mark.parametrize("name", ["yolov8n", "yolov8s", "yolov3-tiny", "yolov5-BoT3"])
+def test_e2e_f32_val_mode_matches_reference_golden(name, golden_dir):
+    """The validate path of the same pipeline (conf 0.001, multi_label=True, max_det 300: validator defaults,
+    engine/validator.py + utils/nms.py:115-116): f32 HIP vs the reference rows stored in the e2e fixtures.  With 300 rows
+    per image cut by max_det, rows whose scores differ by less than the 1e-3 tolerance may swap places or fall on the
+    other side of the cut, so rows are matched one-to-one (same class, IoU >= 0.99) instead of position by position."""
+    from tests.hip_utils import DEV, detection_agreement, split_rows
+    from ultralytics_pro_amd.utils.nms import non_max_suppression
+    g = np.load(golden_dir / f"e2e_{name}.npz")
+    m = _build(name, torch.float32)
     x = P.synthetic_images(2).to(DEV)
-    outs = {}
-    for dt in (torch.float32, torch.bfloat16):
-        m = _build("yolov8n", dt)
-        with torch.no_grad():
-            y = m(x if dt == torch.float32 else x.to(torch.bfloat16))[0]
-        outs[dt] = (y.cpu(), [o.cpu() for o in non_max_suppression(y, 0.25, 0.7)])
-    y32, y16 = outs[torch.float32][0], outs[torch.bfloat16][0]
-    dbox = (y32[:, :4] - y16[:, :4]).abs()
-    dscore = (y32[:, 4:] - y16[:, 4:]).abs().max().item()
-    print(f"bf16 vs f32: box median|d|={dbox.median().item():.3f} p99={dbox.flatten().quantile(0.99).item():.3f} "
-          f"max={dbox.max().item():.3f} px; score max|d|={dscore:.4f}")
-    assert dscore <= 0.05
-    assert dbox.flatten().quantile(0.99).item() <= 4.0
-    for a, b in zip(outs[torch.float32][1], outs[torch.bfloat16][1]):
-        assert abs(a.shape[0] - b.shape[0]) <= max(3, int(0.15 * a.shape[0]))
+    with torch.no_grad():
+        y = m(x)[0]
+    out = [o.cpu().numpy() for o in non_max_suppression(y, conf_thres=0.001, iou_thres=0.7, max_det=300, multi_label=True)]
+    ref = split_rows(g["val_rows"], g["val_n"])
+    assert [o.shape[0] for o in out] == [r.shape[0] for r in ref]
+    exact = sum(int(np.array_equal(o[:, 5], r[:, 5]) and np.abs(o[:, :5] - r[:, :5]).max() <= TOL) for o, r in zip(out, ref))
+    a = detection_agreement(out, ref, 0.99)
+    print(f"{name} val mode f32: {exact}/{len(ref)} images identical row by row; recall {a['recall']:.4f} precision "
+          f"{a['precision']:.4f} box max {a['box_max']:.2e} score max {a['score_max']:.2e}")
+    assert a["recall"] >= 0.99 and a["precision"] >= 0.99
+    assert a["box_max"] <= 2 * TOL and a["score_max"] <= TOL
+
+
+def test_e2e_rtdetr_bf16_backbone_matches_reference_golden(golden_dir):
+    """Config 5 in its perf mode (bf16 darknet53 backbone, f32 RTDETRDecoder) vs the reference golden: the top-300 query
+    selection (head.py:2175) is order-sensitive, so queries are compared as sets - one-to-one by box IoU >= 0.9 and equal
+    arg-max class - and the post-processed detections (conf 0.25) by the same agreement measure as the Detect configs."""
+    from tests.hip_utils import DEV, detection_agreement, split_rows
+    from ultralytics_pro_amd.utils.nms import rtdetr_postprocess
+    g = np.load(golden_dir / "e2e_yolov3-rtdetr.npz")
+    m = _build("yolov3-rtdetr", torch.bfloat16)
+    x = P.synthetic_images(2).to(DEV).to(torch.bfloat16).contiguous()
+    with torch.no_grad():
+        y = m(x)[0]
+    torch.cuda.synchronize()
+    assert y.dtype == torch.float32 and tuple(y.shape) == tuple(g["y"].shape)
+
+    def rows(t):  # (300, 84) cxcywh-normalised + scores -> xyxy pixels, max score, class
+        t = np.asarray(t, dtype=np.float64)
+        cx, cy, w, h = t[:, 0], t[:, 1], t[:, 2], t[:, 3]
+        return np.stack([(cx - w / 2) * 640, (cy - h / 2) * 640, (cx + w / 2) * 640, (cy + h / 2) * 640,
+                         t[:, 4:].max(1), t[:, 4:].argmax(1)], 1)
+
+    yc = y.cpu().numpy()
+    q = detection_agreement([rows(yc[b]) for b in range(2)], [rows(g["y"][b]) for b in range(2)], 0.9)
+    post = [o.cpu().numpy() for o in rtdetr_postprocess(y, 0.25)]
+    a = detection_agreement(post, split_rows(g["post_rows"], g["post_n"]), 0.9)
+    print(f"rtdetr bf16 backbone vs reference golden: query-set overlap {q['recall']:.3f} (box p99 {q['box_p99']:.3f} px, score "
+          f"p99 {q['score_p99']:.4f}); detections {a['n_mine']} vs {a['n_ref']}: recall {a['recall']:.3f} precision "
+          f"{a['precision']:.3f} box p99 {a['box_p99']:.3f} max {a['box_max']:.3f} px score p99 {a['score_p99']:.4f}")
+    assert q["recall"] >= 0.90
+    assert a["recall"] >= 0.95 and a["precision"] >= 0.95
+    assert a["box_p99"] <= 2.0 and a["score_p99"] <= 0.03
 
 
 def test_e2e_rtdetr_f32_matches_reference_golden(golden_dir):
@@ -163,6 +235,43 @@ def test_e2e_rect_and_odd_batches_vs_oracle(shape):
         if r.shape[0]:
             assert (a.cpu()[:, :5] - r[:, :5]).abs().max().item() <= TOL
             assert torch.equal(a.cpu()[:, 5], r[:, 5])
+
+
+@pytest.mark.parametrize("nc", [1, 3, 20])
+def test_e2e_arbitrary_class_count_vs_oracle(nc):
+    """the reference accepts any nc; the class branch of Detect is padded to the 16-byte store width inside the
+    product (zero filters, never read back) - nc = 1, 3, 20 in f32 vs the oracle (1e-3) and in bf16 (runs, same shapes,
+    detection-set agreement with the f32 oracle)."""
+    from tests.hip_utils import DEV, detection_agreement
+    from ultralytics_pro_amd.nn.tasks import DetectionModel
+    from ultralytics_pro_amd.utils.nms import non_max_suppression
+    x = P.synthetic_images(2, h=320, w=320)
+    o = ot.DetectionModel("yolov8n.yaml", nc=nc)
+    P.apply_procedural_weights(o)
+    o.fuse()
+    with torch.no_grad():
+        y_ref = o(x)[0]
+    assert y_ref.shape[1] == 4 + nc
+    ref = onms.non_max_suppression(y_ref, 0.25, 0.7)
+    for dt in (torch.float32, torch.bfloat16):
+        m = DetectionModel("yolov8n.yaml", nc=nc)
+        P.apply_procedural_weights(m)
+        m = m.to(DEV).eval()
+        m.set_compute_dtype(dt)
+        xd = x.to(DEV) if dt == torch.float32 else x.to(DEV).to(torch.bfloat16).contiguous()
+        with torch.no_grad():
+            y, raw = m(xd)
+        torch.cuda.synchronize()
+        assert y.shape == y_ref.shape and all(r.shape[1] == 64 + nc for r in raw)
+        out = non_max_suppression(y, 0.25, 0.7)
+        if dt == torch.float32:
+            d = (y.cpu() - y_ref).abs()
+            assert d[:, :4].max().item() <= TOL and d[:, 4:].max().item() <= TOL
+            assert [a.shape[0] for a in out] == [r.shape[0] for r in ref]
+        else:
+            a = detection_agreement([t.cpu().numpy() for t in out], [r.numpy() for r in ref], 0.9)
+            print(f"nc={nc} bf16: recall {a['recall']:.3f} precision {a['precision']:.3f} ({a['n_mine']} vs {a['n_ref']} rows)")
+            assert a["n_ref"] == 0 or (a["recall"] >= 0.9 and a["precision"] >= 0.9)
 
 
 def test_e2e_micro_batched_graph_equals_single_graph():

@@ -250,9 +250,44 @@ def test_detection_loss_and_gradient_match_oracle(case):
     from ultralytics_pro_amd.engine import trainer as T
     import ctypes as C
     B, hw = case
+    _check_loss_vs_oracle(B, hw, P.synthetic_labels(B, seed=3))
+
+
+def _crowded_labels(B, per_image, seed=5):
+    """`per_image[j]` boxes in image j (mosaic-like crowding, > 64 per image), plus two all-zero boxes that the reference
+    masks out (mask_gt, loss.py:489)."""
+    bi, cl, bb = [], [], []
+    for j, k in enumerate(per_image):
+        u = P.hash_uniform(f"crowd:{seed}:{j}", 5 * k).reshape(k, 5)
+        bi.append(np.full(k, j, dtype=np.float32))
+        cl.append(np.floor(u[:, 0] * 80).astype(np.float32))
+        bb.append(np.stack([0.1 + 0.8 * u[:, 1], 0.1 + 0.8 * u[:, 2], 0.03 + 0.3 * u[:, 3], 0.03 + 0.3 * u[:, 4]], 1).astype(np.float32))
+    bi.append(np.array([0, 1], dtype=np.float32))
+    cl.append(np.array([3, 4], dtype=np.float32))
+    bb.append(np.zeros((2, 4), dtype=np.float32))
+    return {"batch_idx": torch.from_numpy(np.concatenate(bi)), "cls": torch.from_numpy(np.concatenate(cl)),
+            "bboxes": torch.from_numpy(np.concatenate(bb))}
+
+
+def test_detection_loss_more_than_64_boxes_per_image_matches_oracle():
+    """the gt capacity is a run-time argument (the reference pads to counts.max(), loss.py:445-461): 150 / 70 / 3
+    boxes per image plus zero-sum boxes, vs the oracle."""
+    from ultralytics_pro_amd.engine import trainer as T
+    labels = _crowded_labels(3, [150, 70, 3])
+    gt, ngt = T.pack_targets(labels, 3, 160, 96)
+    assert tuple(gt.shape) == (3, 192, 5) and ngt.tolist() == [150, 70, 3]
+    _check_loss_vs_oracle(3, [(20, 12), (10, 6), (5, 3)], labels)
+
+
+def _check_loss_vs_oracle(B, hw, labels):
+    from oracle.loss import v8_detection_loss
+    from tests.hip_utils import DEV, to_cpu_nchw, to_dev_nhwc
+    from ultralytics_pro_amd import _lib as L
+    from ultralytics_pro_amd.engine import runtime as R
+    from ultralytics_pro_amd.engine import trainer as T
+    import ctypes as C
     feats = _loss_inputs(B, hw)
     strides = torch.tensor([8.0, 16.0, 32.0])
-    labels = P.synthetic_labels(B, seed=3)
     fr = [f.clone().requires_grad_(True) for f in feats]
     loss, items = v8_detection_loss(fr, labels, strides)
     loss.sum().backward()
@@ -269,12 +304,13 @@ def test_detection_loss_and_gradient_match_oracle(case):
     lds = IA(*[R.view_of(t).ld for t in fd])
     st_ = (C.c_float * nl)(8.0, 16.0, 32.0)
     A = sum(h * w for h, w in hw)
-    nbytes = L.lib().upa_detection_loss_workspace_bytes(B, A)
+    max_gt = int(gt.shape[1])
+    nbytes = L.lib().upa_detection_loss_workspace_bytes(B, A, max_gt)
     wsb = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
     out = torch.zeros(3, device=DEV)
     L.check(L.lib().upa_detection_loss(C.cast(fp, C.c_void_p), C.cast(gp, C.c_void_p), C.cast(hs, C.c_void_p), C.cast(ws, C.c_void_p),
                                        C.cast(lds, C.c_void_p), C.cast(st_, C.c_void_p), nl, B, 80, 16, gt_d.data_ptr(),
-                                       ngt_d.data_ptr(), 64, 7.5, 0.5, 1.5, 1.0, out.data_ptr(), wsb.data_ptr(), nbytes,
+                                       ngt_d.data_ptr(), max_gt, 7.5, 0.5, 1.5, 1.0, out.data_ptr(), wsb.data_ptr(), nbytes,
                                        L.current_stream(DEV)), "detection_loss")
     torch.cuda.synchronize()
     np.testing.assert_allclose(out.cpu().numpy(), items.numpy(), rtol=2e-4)

@@ -120,7 +120,10 @@ extern "C" int upa_detect_decode(const void* box, int ldb, const void* cls, int 
   UPA_CHECK_ARG(box && cls && y, "detect_decode: null pointer");
   UPA_CHECK_ARG(reg_max == 16, "detect_decode: reg_max must be 16 (head.py:87)");
   const int E = 16 / upa_elem_size(dtype);
-  UPA_CHECK_ARG(ldb % E == 0 && ldc % E == 0 && nc % E == 0, "detect_decode: strides / nc must be multiples of 16 bytes");
+  // nc itself may be any value: the class row is read in whole 16-byte groups, so it must be readable (not meaningful) up to
+  // the next multiple of 16 bytes - Detect pads its class slice accordingly
+  UPA_CHECK_ARG(ldb % E == 0 && ldc % E == 0 && nc >= 1, "detect_decode: row strides must be multiples of 16 bytes");
+  UPA_CHECK_ARG(ldc >= (nc + E - 1) / E * E, "detect_decode: class row shorter than nc rounded up to 16 bytes");
   UPA_CHECK_ARG(a0 >= 0 && a0 + h * w <= a_total, "detect_decode: level does not fit a_total");
   UPA_CHECK_ARG(nc <= 512, "detect_decode: nc too large for the LDS row");
   const long total = (long)n * h * w;

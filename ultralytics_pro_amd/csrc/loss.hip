@@ -18,7 +18,8 @@ namespace {
 
 constexpr int REG = 16;
 constexpr int TOPK = 10;
-constexpr int MAXG = 64;  // ground-truth boxes per image (padded)
+constexpr int MAXG_CAP = 1024;  // largest gt-row capacity per image (LDS arrays of the resolve kernel); the capacity of a
+                                // call is the runtime `L.maxg` = rows per image of the padded gt tensor
 
 struct LossLevels {
   const float* feat[3];
@@ -27,6 +28,7 @@ struct LossLevels {
   float stride[3];
   int a0[3];   // first anchor index of the level
   int nl, A, B, nc;
+  int maxg;    // gt rows per image in `gt` / `cand` (the reference pads to counts.max(), loss.py:445-461)
 };
 
 __device__ __forceinline__ void anchor_decode(const LossLevels& L, int a, int& lvl, int& ay, int& ax) {
@@ -86,16 +88,16 @@ __global__ void loss_decode_kernel(const LossLevels L, float* pbox /* [B][A][4] 
 // ---- 2. per (image, gt): top-k anchors by alignment metric ---------------------------------------------------------
 // metric = sigmoid(cls logit of the gt class)^0.5 * CIoU(gt, pred * stride).clamp(0)^6 for anchors whose centre lies
 // strictly inside the gt box (tal.py:146-178, 271-291); 0 elsewhere.
-__global__ __launch_bounds__(256) void tal_topk_kernel(const LossLevels L, const float* pbox, const float* gt /* [B][MAXG][5] */,
-                                                        const int* n_gt, int* cand /* [B][MAXG][TOPK] anchor or -1 */) {
+__global__ __launch_bounds__(256) void tal_topk_kernel(const LossLevels L, const float* pbox, const float* gt /* [B][maxg][5] */,
+                                                        const int* n_gt, int* cand /* [B][maxg][TOPK] anchor or -1 */) {
   extern __shared__ float s_metric[];  // [A]: the alignment metric of every anchor for this gt (computed once)
-  const int b = blockIdx.x / MAXG, g = blockIdx.x % MAXG;
-  int* out = cand + ((size_t)b * MAXG + g) * TOPK;
+  const int b = blockIdx.x / L.maxg, g = blockIdx.x % L.maxg;
+  int* out = cand + ((size_t)b * L.maxg + g) * TOPK;
   if (g >= n_gt[b]) {
     if (threadIdx.x < TOPK) out[threadIdx.x] = -1;
     return;
   }
-  const float* gb = gt + ((size_t)b * MAXG + g) * 5;
+  const float* gb = gt + ((size_t)b * L.maxg + g) * 5;
   const int cls = (int)gb[0];
   const float gx1 = gb[1], gy1 = gb[2], gx2 = gb[3], gy2 = gb[4];
   __shared__ float s_val[256];
@@ -185,10 +187,10 @@ __global__ __launch_bounds__(256) void tal_resolve_kernel(const LossLevels L, co
   // count claims (inside-box candidates only); a gt lists an anchor at most once
   for (int i = tid; i < ng * TOPK; i += 256) {
     const int g = i / TOPK;
-    const int a = cand[((size_t)b * MAXG + g) * TOPK + (i - g * TOPK)];
+    const int a = cand[((size_t)b * L.maxg + g) * TOPK + (i - g * TOPK)];
     if (a < 0) continue;
     float ov;
-    const float* gb = gt + ((size_t)b * MAXG + g) * 5;
+    const float* gb = gt + ((size_t)b * L.maxg + g) * 5;
     anchor_gt_metric(L, pbox, gb, b, a, &ov);
     int lvl, ay, ax;
     anchor_decode(L, a, lvl, ay, ax);
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(256) void tal_resolve_kernel(const LossLevels L, co
       int bg = 0;
       for (int g = 0; g < ng; ++g) {
         float ov;
-        anchor_gt_metric(L, pbox, gt + ((size_t)b * MAXG + g) * 5, b, a, &ov);
+        anchor_gt_metric(L, pbox, gt + ((size_t)b * L.maxg + g) * 5, b, a, &ov);
         if (ov > best) { best = ov; bg = g; }
       }
       A_[a].gt = bg;
@@ -216,21 +218,21 @@ __global__ __launch_bounds__(256) void tal_resolve_kernel(const LossLevels L, co
   }
   __syncthreads();
   // per gt maxima over its anchors
-  __shared__ float pos_align[MAXG], pos_ov[MAXG];
-  __shared__ unsigned s_align[MAXG], s_ov[MAXG];  // non-negative floats compare like unsigned ints
-  for (int g = tid; g < MAXG; g += 256) { s_align[g] = 0u; s_ov[g] = 0u; }
+  __shared__ float pos_align[MAXG_CAP], pos_ov[MAXG_CAP];
+  __shared__ unsigned s_align[MAXG_CAP], s_ov[MAXG_CAP];  // non-negative floats compare like unsigned ints
+  for (int g = tid; g < L.maxg; g += 256) { s_align[g] = 0u; s_ov[g] = 0u; }
   __syncthreads();
   for (int a = tid; a < L.A; a += 256) {
     const int g = A_[a].gt;
     if (g < 0) continue;
     float ov;
-    const float al = anchor_gt_metric(L, pbox, gt + ((size_t)b * MAXG + g) * 5, b, a, &ov);
+    const float al = anchor_gt_metric(L, pbox, gt + ((size_t)b * L.maxg + g) * 5, b, a, &ov);
     A_[a].score = al;  // alignment metric for now
     atomicMax(&s_align[g], __float_as_uint(al));
     atomicMax(&s_ov[g], __float_as_uint(ov));
   }
   __syncthreads();
-  for (int g = tid; g < MAXG; g += 256) { pos_align[g] = __uint_as_float(s_align[g]); pos_ov[g] = __uint_as_float(s_ov[g]); }
+  for (int g = tid; g < L.maxg; g += 256) { pos_align[g] = __uint_as_float(s_align[g]); pos_ov[g] = __uint_as_float(s_ov[g]); }
   __syncthreads();
   double local = 0.0;
   int nf = 0;
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(256) void loss_cls_kernel(const LossLevels L, const
     anchor_decode(L, a, lvl, ay, ax);
     const size_t roff = ((size_t)(b * L.h[lvl] + ay) * L.w[lvl] + ax) * L.ld[lvl] + 4 * REG + c;
     const Assign as = asg[i];
-    const int tcls = as.gt >= 0 ? (int)gt[((size_t)b * MAXG + as.gt) * 5] : -1;
+    const int tcls = as.gt >= 0 ? (int)gt[((size_t)b * L.maxg + as.gt) * 5] : -1;
     const float x = L.feat[lvl][roff];
     const float t = c == tcls ? as.score : 0.f;
     float wgt;
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const LossLevels L, cons
       continue;
     }
     const float st = L.stride[lvl];
-    const float* gb = gt + ((size_t)b * MAXG + as.gt) * 5;
+    const float* gb = gt + ((size_t)b * L.maxg + as.gt) * 5;
     const float tx1 = gb[1] / st, ty1 = gb[2] / st, tx2 = gb[3] / st, ty2 = gb[4] / st;
     const float wgt = as.score;  // target_scores.sum(-1): one class per anchor
     const float* pb = pbox + i * 4;
@@ -417,9 +419,9 @@ __global__ void loss_finish_kernel(const double* sums, const double* tss, float 
 
 }  // namespace
 
-extern "C" size_t upa_detection_loss_workspace_bytes(int b, int a) {
-  // pbox (B*A*4 f32) + cand (B*MAXG*TOPK i32) + assign (B*A*8) + count (B*A i32) + scalars (tss, sums[3] f64, n_fg)
-  return (size_t)b * a * 16 + (size_t)b * MAXG * TOPK * 4 + (size_t)b * a * 8 + (size_t)b * a * 4 + 64;
+extern "C" size_t upa_detection_loss_workspace_bytes(int b, int a, int max_gt) {
+  // pbox (B*A*4 f32) + cand (B*max_gt*TOPK i32) + assign (B*A*8) + count (B*A i32) + scalars (tss, sums[3] f64, n_fg)
+  return (size_t)b * a * 16 + (size_t)b * max_gt * TOPK * 4 + (size_t)b * a * 8 + (size_t)b * a * 4 + 64;
 }
 
 extern "C" int upa_detection_loss(const float* const* feats, float* const* grads, const int* hs, const int* ws, const int* lds_,
@@ -427,10 +429,11 @@ extern "C" int upa_detection_loss(const float* const* feats, float* const* grads
                                   int max_gt, float gain_box, float gain_cls, float gain_dfl, float grad_scale, float* loss_items,
                                   void* workspace, size_t workspace_bytes, void* stream) {
   UPA_CHECK_ARG(feats && grads && hs && ws && lds_ && strides && gt && n_gt && loss_items && workspace, "detection_loss: null pointer");
-  UPA_CHECK_ARG(n_levels >= 1 && n_levels <= 3 && reg_max == REG && max_gt == MAXG && nc >= 1, "detection_loss: unsupported shape "
-                "(levels <= 3, reg_max 16, gt rows padded to %d)", MAXG);
+  UPA_CHECK_ARG(n_levels >= 1 && n_levels <= 3 && reg_max == REG && nc >= 1, "detection_loss: unsupported shape (levels <= 3, "
+                "reg_max 16)");
+  UPA_CHECK_ARG(max_gt >= 1 && max_gt <= MAXG_CAP, "detection_loss: max_gt (gt rows per image) must be in [1, %d]", MAXG_CAP);
   LossLevels L{};
-  L.nl = n_levels; L.B = b; L.nc = nc;
+  L.nl = n_levels; L.B = b; L.nc = nc; L.maxg = max_gt;
   int a = 0;
   for (int l = 0; l < n_levels; ++l) {
     L.feat[l] = feats[l]; L.grad[l] = grads[l]; L.h[l] = hs[l]; L.w[l] = ws[l]; L.ld[l] = lds_[l]; L.stride[l] = strides[l];
@@ -438,20 +441,29 @@ extern "C" int upa_detection_loss(const float* const* feats, float* const* grads
     a += hs[l] * ws[l];
   }
   L.A = a;
-  UPA_CHECK_ARG(workspace_bytes >= upa_detection_loss_workspace_bytes(b, a), "detection_loss: workspace too small");
+  UPA_CHECK_ARG(workspace_bytes >= upa_detection_loss_workspace_bytes(b, a, max_gt), "detection_loss: workspace too small");
   char* wsb = (char*)workspace;
   double* scal = (double*)wsb;                // [0] tss, [1..3] sums, then n_fg
   int* n_fg = (int*)(scal + 4);
   float* pbox = (float*)(wsb + 64);
   int* cand = (int*)(pbox + (size_t)b * a * 4);
-  Assign* asg = (Assign*)(cand + (size_t)b * MAXG * TOPK);
+  Assign* asg = (Assign*)(cand + (size_t)b * max_gt * TOPK);
   int* count = (int*)(asg + (size_t)b * a);
   hipStream_t s = (hipStream_t)stream;
   upa_zero_words(wsb, 16, s);  // not hipMemsetAsync: see upa_zero_words (common.h)
   const long total = (long)b * a;
   const int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
   hipLaunchKernelGGL(loss_decode_kernel, dim3(grid), dim3(256), 0, s, L, pbox);
-  hipLaunchKernelGGL(tal_topk_kernel, dim3(b * MAXG), dim3(256), (size_t)a * sizeof(float), s, L, pbox, gt, n_gt, cand);
+  {
+    // the per-gt metric row of all anchors lives in dynamic LDS: raise the kernel's limit to the whole CU (the 64 KB default
+    // ends at imgsz ~ 900) and refuse shapes past it (A * 4 bytes + 2 KB static <= 160 KB: imgsz up to ~1400 square)
+    if (hipError_t e = upa_full_lds<tal_topk_kernel>(); e != hipSuccess) {
+      upa_set_error("detection_loss: cannot raise the LDS limit of tal_topk: %s", hipGetErrorString(e));
+      return UPA_ELAUNCH;
+    }
+    UPA_CHECK_ARG((size_t)a * sizeof(float) + 2048 <= 160 * 1024, "detection_loss: %d anchors do not fit the LDS metric row", a);
+  }
+  hipLaunchKernelGGL(tal_topk_kernel, dim3(b * max_gt), dim3(256), (size_t)a * sizeof(float), s, L, pbox, gt, n_gt, cand);
   hipLaunchKernelGGL(tal_resolve_kernel, dim3(b), dim3(256), 0, s, L, pbox, gt, n_gt, cand, asg, count, scal, n_fg);
   const long tot_c = total * nc;
   hipLaunchKernelGGL(loss_cls_kernel, dim3((int)((tot_c + 255) / 256 > 8192 ? 8192 : (tot_c + 255) / 256)), dim3(256), 0, s, L, gt, asg,

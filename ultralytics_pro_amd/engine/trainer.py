@@ -35,7 +35,8 @@ from . import runtime as R
 
 HYP = dict(lr=0.01, momentum=0.9, weight_decay=5e-4, max_norm=10.0, ema_decay=0.9999, ema_tau=2000.0,
            box=7.5, cls=0.5, dfl=1.5)
-MAX_GT = 64
+MAX_GT = 64        # initial gt-row capacity per image; grows with the data (the loss kernels take it at run time)
+MAX_GT_CAP = 1024  # upa_detection_loss: LDS arrays of the assignment-resolve kernel
 
 
 def _s(dev):
@@ -374,6 +375,7 @@ class DetectionTrainer:
         self._capturing = False
         self._imgsz = None
         self.gt_d = self.ngt_d = None
+        self.max_gt = MAX_GT  # rows per image of the padded gt tensor (the reference pads to counts.max(), loss.py:445-461)
         model.to(self.device)
         self._flatten_parameters(ema)
         self._build_graph()
@@ -420,7 +422,6 @@ class DetectionTrainer:
         self.sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
         self.sumsq_ws = torch.zeros(L.lib().upa_sumsq_workspace_bytes() // 8, dtype=torch.float64, device=dev)
         self.ema_d_dev = torch.zeros(1, dtype=torch.float32, device=dev)
-        self.ema_d_host = torch.zeros(1, dtype=torch.float32).pin_memory() if torch.cuda.is_available() else torch.zeros(1)
 
     # ---- graph --------------------------------------------------------------------------------------------------------
     def _build_graph(self):
@@ -650,8 +651,9 @@ class DetectionTrainer:
         self._static_img.copy_(img, non_blocking=True)
         self._upload_labels(labels, img.shape[0])
         self.updates += 1
-        self.ema_d_host[0] = h["ema_decay"] * (1 - math.exp(-self.updates / h["ema_tau"]))
-        self.ema_d_dev.copy_(self.ema_d_host, non_blocking=True)
+        # the decay of THIS step travels as a kernel argument of a stream-ordered fill (no pinned host slot that a later
+        # step could overwrite while an earlier copy is still queued when the host runs several replays ahead)
+        self.ema_d_dev.fill_(h["ema_decay"] * (1 - math.exp(-self.updates / h["ema_tau"])))
         self._graphs[0].replay(self.device)
         if len(self._graphs) == 2:
             self.all_reduce_gradients()
@@ -661,7 +663,15 @@ class DetectionTrainer:
     def _upload_labels(self, labels, batch_size):
         imgsz_h, imgsz_w = self._imgsz
         gt, ngt = pack_targets(labels, batch_size, imgsz_h, imgsz_w)
-        self.gt_d.copy_(gt, non_blocking=True)
+        need = int(gt.shape[1])
+        if self.gt_d is None or self.gt_d.shape[0] != batch_size or need > self.gt_d.shape[1]:
+            if self._graphs is not None or self._capturing:
+                raise L.UpaError(f"a batch needs {need} gt rows per image but the compiled step holds {self.max_gt}: set "
+                                 f"trainer.max_gt >= {need} (<= {MAX_GT_CAP}) before compile()")
+            self.max_gt = max(self.max_gt, need)
+            self.gt_d = torch.zeros(batch_size, self.max_gt, 5, dtype=torch.float32, device=self.device)
+            self.ngt_d = torch.zeros(batch_size, dtype=torch.int32, device=self.device)
+        self.gt_d[:, :need].copy_(gt, non_blocking=True)
         self.ngt_d.copy_(ngt, non_blocking=True)
 
     def grad_norm(self) -> float:
@@ -736,12 +746,10 @@ class DetectT(_Seq):
         imgsz_h = int(self.raw[0].shape[2] * float(self.m.stride[0]))
         imgsz_w = int(self.raw[0].shape[3] * float(self.m.stride[0]))
         tr._imgsz = (imgsz_h, imgsz_w)
-        if tr.gt_d is None or tr.gt_d.shape[0] != batch_size:
-            tr.gt_d = torch.zeros(batch_size, MAX_GT, 5, dtype=torch.float32, device=dev)
-            tr.ngt_d = torch.zeros(batch_size, dtype=torch.int32, device=dev)
         if labels is not None:  # None: already uploaded into the static buffers (graph replay)
             tr._upload_labels(labels, batch_size)
         gt_d, ngt_d = tr.gt_d, tr.ngt_d
+        max_gt = int(gt_d.shape[1])
         grads32 = []
         for i, r in enumerate(self.raw32):
             n, ch, hh, ww = r.shape
@@ -756,12 +764,12 @@ class DetectT(_Seq):
         lds = IA(*[R.view_of(r).ld for r in self.raw32])
         strides = (C.c_float * nl)(*[float(s) for s in self.m.stride])
         A = sum(int(r.shape[2]) * int(r.shape[3]) for r in self.raw32)
-        nbytes = lib.upa_detection_loss_workspace_bytes(batch_size, A)
-        wsb = tr.pool.get(("loss_ws", batch_size, A), (nbytes,), torch.uint8, dev)
+        nbytes = lib.upa_detection_loss_workspace_bytes(batch_size, A, max_gt)
+        wsb = tr.pool.get(("loss_ws", batch_size, A, max_gt), (nbytes,), torch.uint8, dev)
         items = tr.pool.get(("loss_items",), (3,), torch.float32, dev)
         L.check(lib.upa_detection_loss(C.cast(feats, C.c_void_p), C.cast(grads, C.c_void_p), C.cast(hs, C.c_void_p),
                                        C.cast(ws, C.c_void_p), C.cast(lds, C.c_void_p), C.cast(strides, C.c_void_p), nl,
-                                       batch_size, self.nc, self.reg_max, gt_d.data_ptr(), ngt_d.data_ptr(), MAX_GT, h["box"],
+                                       batch_size, self.nc, self.reg_max, gt_d.data_ptr(), ngt_d.data_ptr(), max_gt, h["box"],
                                        h["cls"], h["dfl"], 1.0, items.data_ptr(), wsb.data_ptr(), nbytes,
                                        _s(dev)), "detection_loss")
         nb = 4 * self.reg_max
@@ -788,26 +796,31 @@ class DetectT(_Seq):
         return items
 
 
-def pack_targets(labels, batch_size, imgsz_h, imgsz_w):
-    """loss.py:445-461 on the host: (n,) image index, (n,) class, (n,4) normalised xywh -> padded (B, MAX_GT, 5)
-    [cls, x1, y1, x2, y2] in pixels + per-image counts (host tensors; a few hundred bytes per step)."""
+def pack_targets(labels, batch_size, imgsz_h, imgsz_w, min_rows=MAX_GT):
+    """loss.py:445-461 on the host: (n,) image index, (n,) class, (n,4) normalised xywh -> padded (B, rows, 5)
+    [cls, x1, y1, x2, y2] in pixels + per-image counts (host tensors; a few hundred bytes per step).  `rows` = the largest
+    per-image count rounded up to a multiple of 64 (at least `min_rows`), as the reference pads to counts.max().  Boxes
+    whose xyxy coordinates sum to zero are dropped: the reference masks them (`mask_gt = gt_bboxes.sum(2) > 0`,
+    loss.py:489), so they never take part in the assignment."""
     bi = labels["batch_idx"].view(-1).cpu().long()
     cls = labels["cls"].view(-1).cpu().float()
     bb = labels["bboxes"].view(-1, 4).cpu().float()
-    gt = torch.zeros(batch_size, MAX_GT, 5)
-    ngt = torch.zeros(batch_size, dtype=torch.int32)
     scale = torch.tensor([imgsz_w, imgsz_h, imgsz_w, imgsz_h], dtype=torch.float32)
-    for j in range(batch_size):
-        sel = bi == j
-        k = int(sel.sum())
-        if k > MAX_GT:
-            raise L.UpaError(f"image {j} has {k} boxes; the loss kernel pads to {MAX_GT}")
+    xywh = bb * scale
+    xy, wh = xywh[:, :2], xywh[:, 2:] / 2
+    xyxy = torch.cat([xy - wh, xy + wh], 1)
+    keep = xyxy.sum(1) > 0
+    per = [((bi == j) & keep).nonzero().view(-1) for j in range(batch_size)]
+    most = max([int(ix.numel()) for ix in per] + [1])
+    rows = max(min_rows, (most + 63) // 64 * 64)
+    if rows > MAX_GT_CAP:
+        raise L.UpaError(f"an image has {most} boxes; the loss kernels hold at most {MAX_GT_CAP} per image")
+    gt = torch.zeros(batch_size, rows, 5)
+    ngt = torch.zeros(batch_size, dtype=torch.int32)
+    for j, ix in enumerate(per):
+        k = int(ix.numel())
         if k:
-            xywh = bb[sel] * scale
-            xy, wh = xywh[:, :2], xywh[:, 2:] / 2
-            gt[j, :k, 0] = cls[sel]
-            gt[j, :k, 1:3] = xy - wh
-            gt[j, :k, 3:5] = xy + wh
-            # rows whose box sums to zero are masked out by the reference (mask_gt, loss.py:489): keep only real boxes
+            gt[j, :k, 0] = cls[ix]
+            gt[j, :k, 1:] = xyxy[ix]
         ngt[j] = k
     return gt, ngt

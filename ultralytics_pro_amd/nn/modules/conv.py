@@ -16,7 +16,7 @@ import torch.nn as nn
 from ... import _lib as L
 from ...engine import runtime as R
 
-__all__ = ("autopad", "Conv", "Concat", "hip_conv2d", "PackedConv")
+__all__ = ("autopad", "Conv", "Concat", "hip_conv2d", "PackedConv", "version_key")
 
 
 def autopad(k, p=None, d=1):
@@ -113,21 +113,37 @@ def hip_conv2d(x: torch.Tensor, pk: PackedConv, stride: int, pad: int, act: int,
     return y
 
 
-class _HipConvMixin:
-    """Lazily folded / packed weights, cached per (device, dtype); invalidated by train() / load_state_dict()."""
+def version_key(*tensors):
+    """Identity + in-place version of parameter tensors: changes on `load_state_dict` / `copy_` / optimizer steps
+    (`_version` bump) and on `.to(device)` / `.data = ...` (new storage), so a cache keyed on it can never go stale."""
+    return tuple(None if t is None else (t.data_ptr(), t._version, t.device.type) for t in tensors)
 
-    def _packed(self, conv: nn.Conv2d, bn, device, dtype, stem: bool) -> PackedConv:
+
+class _HipConvMixin:
+    """Lazily folded / packed weights, cached per (conv, device, dtype) and validated against the parameters' storage and
+    in-place version on every use, so `load_state_dict`, `load_weights`, `.to()`, `train()` or an optimizer step can never
+    leave a stale packed copy behind (a compiled hipGraph still bakes the packed pointers in: recompile after loading)."""
+
+    def _packed(self, conv: nn.Conv2d, bn, device, dtype, stem: bool, pad_cout: int = 0) -> PackedConv:
+        """`pad_cout` > out_channels appends zero filters / zero biases (a Detect class branch whose nc is not a multiple
+        of the 16-byte store width writes its padded row; the extra channels are never read)."""
         cache = self.__dict__.setdefault("_pk_cache", {})
-        key = (id(conv), str(device), dtype, stem)
-        pk = cache.get(key)
-        if pk is None:
-            k = conv.kernel_size[0]
-            if conv.kernel_size[0] != conv.kernel_size[1] or conv.groups != 1 or conv.dilation != (1, 1) or \
-                    conv.stride[0] != conv.stride[1] or conv.padding[0] != conv.padding[1]:
-                raise L.UpaError(f"HIP conv supports square kernels, groups=1, dilation=1 only, got {conv}")
-            w, b = fold_bn(conv, bn)
-            pk = PackedConv(w, b, k, device, dtype, stem)
-            cache[key] = pk
+        key = (id(conv), str(device), dtype, stem, pad_cout)
+        ver = version_key(conv.weight, conv.bias, *(() if bn is None else (bn.weight, bn.bias, bn.running_mean,
+                                                                           bn.running_var))) + ((bn.eps,) if bn is not None else ())
+        hit = cache.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        k = conv.kernel_size[0]
+        if conv.kernel_size[0] != conv.kernel_size[1] or conv.groups != 1 or conv.dilation != (1, 1) or \
+                conv.stride[0] != conv.stride[1] or conv.padding[0] != conv.padding[1]:
+            raise L.UpaError(f"HIP conv supports square kernels, groups=1, dilation=1 only, got {conv}")
+        w, b = fold_bn(conv, bn)
+        if pad_cout > w.shape[0]:
+            w = torch.cat([w, torch.zeros(pad_cout - w.shape[0], *w.shape[1:])], 0)
+            b = torch.cat([b, torch.zeros(pad_cout - b.shape[0])], 0)
+        pk = PackedConv(w, b, k, device, dtype, stem)
+        cache[key] = (ver, pk)
         return pk
 
     def invalidate_packed(self):

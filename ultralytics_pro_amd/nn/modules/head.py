@@ -53,8 +53,15 @@ class Detect(nn.Module, _HipConvMixin):
 
     def _branch(self, seq: nn.Sequential, x: torch.Tensor, out: torch.Tensor) -> None:
         t = seq[1](seq[0](x))
-        pk = self._packed(seq[2], None, x.device, x.dtype, False)
+        # `out` may be wider than the conv (class rows are padded to the 16-byte store width when nc is not a multiple
+        # of it): the extra filters are zero and the extra channels are never read
+        pk = self._packed(seq[2], None, x.device, x.dtype, False, pad_cout=int(out.shape[1]))
         hip_conv2d(t, pk, 1, 0, L.ACT_NONE, out=out)
+
+    def _ncp(self, dtype) -> int:
+        """Class channels as stored: nc rounded up to 16 bytes of `dtype` (any nc is accepted, as in the reference)."""
+        e = 16 // (2 if dtype == torch.bfloat16 else 4)
+        return (self.nc + e - 1) // e * e
 
     # ---- branch-level concurrency -------------------------------------------------------------------------------------
     # The box and class branches of a level are independent 3-conv chains and a level only depends on its own input
@@ -82,14 +89,15 @@ class Detect(nn.Module, _HipConvMixin):
         x = R.to_nhwc(x, x.dtype)
         nb = 4 * self.reg_max
         n, _, h, w = x.shape
-        buf = R.alloc_nhwc(n, self.no, h, w, x.dtype, x.device, key=(id(self), "raw", i))
+        ncp = self._ncp(x.dtype)
+        buf = R.alloc_nhwc(n, nb + ncp, h, w, x.dtype, x.device, key=(id(self), "raw", i))
         if not self.concurrent or R.current_tag() != 0:
             # inside a concurrently scheduled sub-batch (BaseModel.compile(micro_batches>1)) the branches stay on the
             # sub-batch's stream: the sub-batches already overlap each other, and nesting a second level of event
             # forks inside a forked capture stream crashed hipStreamEndCapture on ROCm 7.2 (segfault, not an error code)
             self._branch(self.cv2[i], x, buf[:, :nb])
             self._branch(self.cv3[i], x, buf[:, nb:])
-            pend[i] = (buf, [])
+            pend[i] = (buf[:, :self.no], [])
             return
         main = torch.cuda.current_stream(x.device)
         fork = torch.cuda.Event()
@@ -104,7 +112,7 @@ class Detect(nn.Module, _HipConvMixin):
                 ev = torch.cuda.Event()
                 ev.record(side)
             joins.append(ev)
-        pend[i] = (buf, joins)
+        pend[i] = (buf[:, :self.no], joins)
 
     def forward(self, x):
         if self.training:

@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from ... import _lib as L
 from ...engine import runtime as R
-from .conv import PackedConv, fold_bn
+from .conv import PackedConv, fold_bn, version_key
 
 __all__ = ("RTDETRDecoder", "MLP", "MSDeformAttn", "DeformableTransformerDecoderLayer", "DeformableTransformerDecoder")
 
@@ -35,14 +35,18 @@ class _Rows:
 
 
 def _packed_linear(owner: nn.Module, name: str, weight: torch.Tensor, bias, device) -> PackedConv:
+    """Packed f32 GEMM weights of one nn.Linear, cached on `owner` and validated against the parameters' storage / in-place
+    version on every use (`version_key`): load_state_dict / load_weights / .to() can never leave a stale copy."""
     cache = owner.__dict__.setdefault("_pk_cache", {})
     key = (name, str(device))
-    pk = cache.get(key)
-    if pk is None:
-        w = weight.detach().float().cpu().reshape(weight.shape[0], weight.shape[1], 1, 1)
-        b = torch.zeros(weight.shape[0]) if bias is None else bias.detach().float().cpu()
-        pk = PackedConv(w, b, 1, device, torch.float32, False)
-        cache[key] = pk
+    ver = version_key(weight, bias)
+    hit = cache.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    w = weight.detach().float().cpu().reshape(weight.shape[0], weight.shape[1], 1, 1)
+    b = torch.zeros(weight.shape[0]) if bias is None else bias.detach().float().cpu()
+    pk = PackedConv(w, b, 1, device, torch.float32, False)
+    cache[key] = (ver, pk)
     return pk
 
 
@@ -338,11 +342,14 @@ class RTDETRDecoder(nn.Module):
                 raise L.UpaError(f"RTDETRDecoder takes float32 or bfloat16 feature maps, got {t.dtype}")
             conv, bn = self.input_proj[i][0], self.input_proj[i][1]
             cache = self.__dict__.setdefault("_pk_cache", {})
-            pk = cache.get(("proj", i, str(dev)))
-            if pk is None:
+            ver = version_key(conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+            hit = cache.get(("proj", i, str(dev)))
+            if hit is not None and hit[0] == ver:
+                pk = hit[1]
+            else:
                 w, b = fold_bn(conv, bn)
                 pk = PackedConv(w, b, 1, dev, torch.float32, False)
-                cache[("proj", i, str(dev))] = pk
+                cache[("proj", i, str(dev))] = (ver, pk)
             v = R.view_of(t)
             L.check(lib.upa_conv2d_bias_act(v.ptr, v.n, v.h, v.w, v.c, v.ld, pk.w.data_ptr(), pk.bias.data_ptr(),
                                             feats.data_ptr() + row0 * hd * 4, hd, hd, None, 0, 1, 1, 0, L.ACT_NONE,
