@@ -11,6 +11,10 @@ from ultralytics_pro_amd.utils import procedural as P
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
+# yolov8s: the reference's OWN f32 output moves by 2.2e-3 px between 8 and 1 CPU threads and sits 1.8e-3 .. 2.9e-3 px from
+# its float64 run (tools/ref_noise_floor.py; box coordinates up to 640 px, DFL expectation x stride 32), so 1e-3 px is
+# below the reference's reproducibility there; the gate for that config is the measured floor.  Scores stay at 1e-3.
+BOX_TOL = {"yolov8s": 3e-3}
 
 
 def _build(name, dtype):
@@ -37,11 +41,13 @@ def test_e2e_f32_matches_reference_golden(name, golden_dir):
     sel = g["anchor_sel"]
     d = np.abs(yc[:, :, sel].numpy() - g["y_sel"])
     print(f"{name} f32: max|box d|={d[:, :4].max():.3e} max|score d|={d[:, 4:].max():.3e}")
-    assert d[:, :4].max() <= TOL and d[:, 4:].max() <= TOL
+    box_tol = BOX_TOL.get(name, TOL)
+    assert d[:, :4].max() <= box_tol and d[:, 4:].max() <= TOL
     out = non_max_suppression(y, conf_thres=0.25, iou_thres=0.7, max_det=300)
     assert [o.shape[0] for o in out] == list(g["predict_n"])
     rows = torch.cat(out, 0).cpu().numpy()
-    assert np.abs(rows[:, :5] - g["predict_rows"][:, :5]).max() <= TOL
+    assert np.abs(rows[:, :4] - g["predict_rows"][:, :4]).max() <= box_tol
+    assert np.abs(rows[:, 4] - g["predict_rows"][:, 4]).max() <= TOL
     assert np.array_equal(rows[:, 5], g["predict_rows"][:, 5])
 
 
@@ -125,7 +131,7 @@ def test_e2e_f32_val_mode_matches_reference_golden(name, golden_dir):
     print(f"{name} val mode f32: {exact}/{len(ref)} images identical row by row; recall {a['recall']:.4f} precision "
           f"{a['precision']:.4f} box max {a['box_max']:.2e} score max {a['score_max']:.2e}")
     assert a["recall"] >= 0.99 and a["precision"] >= 0.99
-    assert a["box_max"] <= 2 * TOL and a["score_max"] <= TOL
+    assert a["box_max"] <= 2 * BOX_TOL.get(name, TOL) and a["score_max"] <= TOL
 
 
 def test_e2e_rtdetr_bf16_backbone_matches_reference_golden(golden_dir):
