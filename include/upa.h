@@ -47,6 +47,11 @@ int upa_conv2d_bias_act(const void* x, int n, int h, int w, int cin, int ldx,
 
 /* Introspection for benchmarks: the kernel instantiation (WM<<12 | WN<<8 | MTW<<4 | NTW) the call above would use. */
 int upa_conv_variant(int n, int h, int w, int cin, int cout, int k, int stride, int pad, int dtype);
+/* Dispatch mode of the large-tile LDS-shared-operand kernel (csrc/conv_big.hip) inside upa_conv2d_bias_act: 0 = never,
+ * 1 = MFMA-bound layers only (bf16, stride 1, k 1|3, Cin >= 128, Cout % 128 == 0; the default, or env UPA_CONV_BIG),
+ * 2 = every shape it can run (parity tests / per-layer benchmarks).  Returns the previous mode; mode < 0 only queries. */
+int upa_conv_big_mode(int mode);
+
 
 /* First layer: reads the model input NCHW (f32 or bf16, 1..4 channels) directly, writes NHWC.   conv.py:188-197
  * w = device copy of the upa_pack_stem_weight output ([tap][ci][cout padded to 16] f32), bias f32[cout] on the device. */
@@ -89,6 +94,16 @@ int upa_nhwc_to_nchw(const void* x, int n, int h, int w, int c, int ldx, float* 
  * y is (n, 4+nc, a_total) f32.        head.py:151-169, block.py:250-253, utils/tal.py:352-376 */
 int upa_detect_decode(const void* box, int ldb, const void* cls, int ldc, int n, int h, int w, int reg_max, int nc,
                       float stride_px, float* y, int a_total, int a0, int dtype, void* stream);
+/* The last 1x1 conv of one Detect branch (nn.Conv2d(c2, 4*reg_max, 1) / nn.Conv2d(c3, nc, 1), head.py:94-100) with that
+ * branch's part of the decode fused on the end (bf16 mode): kind 1 = box (DFL + dist2bbox + stride -> y[b, 0:4, a0 + a]),
+ * kind 2 = class (sigmoid -> y[b, 4:4+nc, a0 + a]); the logits never reach HBM unless `raw` (n,h,w,cout) bf16 rows with
+ * stride ldraw is given (Detect's second return value, head.py:126).  cout = rows of the packed weights (>= nc: class
+ * filters may be zero-padded to the 16-byte store width).  Returns UPA_EUNSUPPORTED outside the fused form (f32 parity
+ * mode, reg_max != 16, nc > 128): the caller then runs upa_conv2d_bias_act + upa_detect_decode.  head.py:151-169 */
+int upa_detect_tail(const void* x, int n, int h, int w, int cin, int ldx, const void* w_packed, const float* bias, int cout,
+                    int kind, int nc, float stride_px, float* y, int a_total, int a0, void* raw, int ldraw, int dtype,
+                    void* stream);
+
 
 /* ---- NMS ----------------------------------------------------------------------------------------------------------
  * Batched non_max_suppression over pred (b, 4+nc, a) f32 xywh+scores -> out (b, max_det, 6) f32

@@ -100,6 +100,8 @@ def test_e2e_bf16_matches_reference_golden(name, golden_dir):
     out = [o.cpu().numpy() for o in non_max_suppression(y, conf_thres=0.25, iou_thres=0.7, max_det=300)]
     ref = split_rows(g["predict_rows"], g["predict_n"])
     a = detection_agreement(out, ref, 0.9)
+    a5 = detection_agreement(out, ref, 0.5)
+    print(f"{name} bf16 vs reference golden at IoU>=0.5: recall {a5['recall']:.3f} precision {a5['precision']:.3f}")
     print(f"{name} bf16 vs reference golden: head box |d| p50={np.median(dbox):.3f} p99={np.quantile(dbox, 0.99):.3f} "
           f"max={dbox.max():.3f} px, score max|d|={dsc.max():.4f}; detections {a['n_mine']} vs {a['n_ref']}: recall "
           f"{a['recall']:.3f} precision {a['precision']:.3f}, matched box p50={a['box_p50']:.3f} p99={a['box_p99']:.3f} "

@@ -106,6 +106,47 @@ def test_conv_pipe_kernel(case):
     assert err <= 3e-2 * max(1.0, ref.abs().max().item()), err
 
 
+BIG_CASES = [
+    # c1, c2, k, H, W, N, residual  (stride 1: the large-tile LDS-shared-operand kernel, csrc/conv_big.hip)
+    (128, 128, 3, 20, 20, 2, False),   # 20-wide map: 20 x 12 tiles, second tile ragged (8 rows)
+    (256, 128, 3, 40, 40, 1, False),   # 40 x 6 tiles, 7 per image, last one ragged; 4 chunks of 64 channels
+    (128, 256, 3, 16, 32, 2, True),    # 16 x 16 tiles, two 128-channel workgroup columns, residual add
+    (512, 1024, 3, 10, 10, 1, False),  # 10 x 10 map in one tile (100 of 256 pixels), K = 4608, 8 workgroup columns
+    (96, 128, 3, 9, 13, 3, False),     # Cin 96: odd k-tile count (last chunk half zero), odd sizes
+    (72, 64, 3, 8, 8, 1, False),       # Cin 72: partial k-tile; Cout 64: half a workgroup column masked
+    (1024, 256, 1, 10, 10, 2, False),  # pointwise: 200 pixels flattened, 16 chunks
+    (256, 128, 1, 33, 9, 1, True),     # pointwise, ragged pixel count, residual
+    (128, 384, 1, 20, 20, 1, False),   # three workgroup columns
+]
+
+
+@pytest.mark.parametrize("case", BIG_CASES, ids=[f"c{c[0]}-{c[1]}k{c[2]}_{c[3]}x{c[4]}n{c[5]}{'r' if c[6] else ''}" for c in BIG_CASES])
+@pytest.mark.parametrize("act", [True, False], ids=["silu", "noact"])
+def test_conv_big_kernel(case, act):
+    """bf16 stride-1 convs forced through conv_big_kernel (upa_conv_big_mode(2)) vs the oracle Conv (conv.py:188-197) on
+    bf16-rounded inputs: image borders (zero page), tiles that are not powers of two, ragged last tiles, partial k-tiles and
+    odd chunk counts, masked output-channel columns, pointwise layers, the fused residual add (block.py:668)."""
+    from tests.hip_utils import bf16_round, to_cpu_nchw, to_dev_nhwc
+    from ultralytics_pro_amd import _lib as L
+    pm, _ = _mods()
+    c1, c2, k, H, W, N, res = case
+    prev = L.lib().upa_conv_big_mode(2)
+    try:
+        var = L.lib().upa_conv_variant(N, H, W, c1, c2, k, 1, k // 2, 1)
+        assert (var >> 23) & 1, "case is not dispatched to the large-tile kernel"
+        o, m = _pair(om.Conv, pm.Conv, (c1, c2, k, 1, None, 1, 1, act), "conv_big")
+        x = bf16_round(P.uniform(f"big{case}", (N, c1, H, W), -1, 1))
+        rsd = bf16_round(P.uniform(f"bigres{case}", (N, c2, H, W), -1, 1)) if res else None
+        with torch.no_grad():
+            ref = o(x) + (rsd if res else 0)
+            y = to_cpu_nchw(m(to_dev_nhwc(x, torch.bfloat16), residual=to_dev_nhwc(rsd, torch.bfloat16) if res else None))
+    finally:
+        L.lib().upa_conv_big_mode(prev)
+    assert y.shape == ref.shape
+    err = (y - ref).abs().max().item()
+    assert err <= 3e-2 * max(1.0, ref.abs().max().item()), err
+
+
 C1_CASES = [
     # c1, c2, H, W, N, act, env  (1x1 s1: the streaming pointwise kernel, csrc/conv1x1.hip)
     (64, 64, 16, 16, 2, True, {}),                                   # KTT 2, NTW 4
@@ -291,6 +332,57 @@ def test_detect_decode_vs_oracle_random_logits():
         torch.cuda.synchronize()
         diff = (y.cpu() - ref).abs()
         assert diff[:, :4].max() <= 2e-4 and diff[:, 4:].max() <= 2e-6, (dtype, diff[:, :4].max(), diff[:, 4:].max())
+
+
+@pytest.mark.parametrize("nc,shape", [(80, (2, 13, 21)), (80, (3, 40, 40)), (20, (1, 9, 16)), (3, (2, 7, 5))],
+                         ids=["nc80_13x21", "nc80_40x40", "nc20", "nc3"])
+def test_detect_tail_fused_decode_vs_oracle(nc, shape):
+    """`upa_detect_tail` (bf16): the last 1x1 conv of a Detect branch with its half of the decode as epilogue - box (DFL +
+    dist2bbox + stride, head.py:151-169 / block.py:250-253 / tal.py:367-376) and class (sigmoid) - vs the oracle's
+    Detect._inference on f32 logits computed from the same bf16-rounded activations and weights; the optional raw rows
+    equal the plain conv's output.  Ragged pixel counts (not multiples of 16), class counts that are not multiples of 16
+    or 8, an anchor offset inside a larger output."""
+    from tests.hip_utils import DEV, bf16_round, to_cpu_nchw, to_dev_nhwc, unit_input
+    from ultralytics_pro_amd import _lib as L
+    from ultralytics_pro_amd.engine import runtime as R
+    from ultralytics_pro_amd.nn.modules.conv import PackedConv
+    n, h, w = shape
+    c2, c3 = 64, max(16, (nc + 7) // 8 * 8)
+    ncp = (nc + 7) // 8 * 8
+    tb = bf16_round(unit_input(f"tail_b{nc}", (n, c2, h, w), -2, 2))
+    tc = bf16_round(unit_input(f"tail_c{nc}", (n, c3, h, w), -2, 2))
+    wb = bf16_round(unit_input(f"tail_wb{nc}", (64, c2, 1, 1), -0.6, 0.6))
+    wc = bf16_round(unit_input(f"tail_wc{nc}", (nc, c3, 1, 1), -0.6, 0.6))
+    bb, bc = unit_input(f"tail_bb{nc}", (64,), -1, 1), unit_input(f"tail_bc{nc}", (nc,), -3, 1)
+    raw = torch.cat([torch.nn.functional.conv2d(tb, wb, bb), torch.nn.functional.conv2d(tc, wc, bc)], 1)
+    oref = om.Detect(nc, (64,)).eval()
+    oref.stride = torch.tensor([16.0])
+    ref = oref._inference([raw.clone()])  # (n, 4 + nc, h*w)
+    a0, extra = 37, 11
+    a_total = a0 + h * w + extra
+    y = torch.full((n, 4 + nc, a_total), -7.0, device=DEV)
+    rawbuf = R.alloc_nhwc(n, 64 + ncp, h, w, torch.bfloat16, DEV)
+    rawbuf.zero_()
+    for keep_raw in (True, False):
+        y.fill_(-7.0)
+        for kind, t, wt, bias, cout, rv in ((1, tb, wb, bb, 64, rawbuf[:, :64]), (2, tc, wc, bc, ncp, rawbuf[:, 64:])):
+            wpad = torch.cat([wt, torch.zeros(cout - wt.shape[0], *wt.shape[1:])], 0)
+            bpad = torch.cat([bias, torch.zeros(cout - bias.shape[0])], 0)
+            pk = PackedConv(wpad, bpad, 1, DEV, torch.bfloat16, False)
+            vt = R.view_of(to_dev_nhwc(t, torch.bfloat16))
+            vr = R.view_of(rv)
+            L.check(L.lib().upa_detect_tail(vt.ptr, vt.n, vt.h, vt.w, vt.c, vt.ld, pk.w.data_ptr(), pk.bias.data_ptr(), cout, kind, nc,
+                                            16.0, y.data_ptr(), a_total, a0, vr.ptr if keep_raw else None, vr.ld if keep_raw else 0,
+                                            L.UPA_BF16, L.current_stream(DEV)), "detect_tail")
+        torch.cuda.synchronize()
+        got = y[:, :, a0:a0 + h * w].cpu()
+        d = (got - ref).abs()
+        # f32 logits from f32 accumulation of bf16 products; v_exp_f32 / v_rcp_f32 (1 ulp) in the softmax / sigmoid
+        assert d[:, :4].max().item() <= 2e-3 and d[:, 4:].max().item() <= 2e-6 + 1e-6, (keep_raw, d[:, :4].max().item(), d[:, 4:].max().item())
+        assert float(y[:, :, :a0].min()) == -7.0 and float(y[:, :, a0 + h * w:].max()) == -7.0  # nothing outside the level
+        if keep_raw:
+            r = to_cpu_nchw(rawbuf)[:, :64 + nc]
+            assert (r - raw).abs().max().item() <= 0.04 * raw.abs().max().item() / 4  # bf16-rounded logits
 
 
 def test_rtdetr_decoder_small_matches_golden(golden_dir):

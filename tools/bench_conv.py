@@ -25,8 +25,11 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="", help="cin,cout,k,H filter, e.g. 64,64,3,80")
+    ap.add_argument("--big-mode", type=int, default=-1, help="upa_conv_big_mode: 0 never, 1 size rule, 2 every eligible shape")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
+    if args.big_mode >= 0:
+        L.lib().upa_conv_big_mode(args.big_mode)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     es = 2 if dtype == torch.bfloat16 else 4
     m = DetectionModel(args.model + ".yaml")

@@ -14,6 +14,7 @@ from pathlib import Path
 import torch  # noqa: F401  (loads libamdhip64.so.7 first - see module docstring)
 
 UPA_F32, UPA_BF16, UPA_U8_BGR_HWC = 0, 1, 2
+UPA_EUNSUPPORTED = -2
 ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
 
 _PKG = Path(__file__).resolve().parent
@@ -29,6 +30,7 @@ PROTOTYPES = {
     "upa_pack_conv_weight": (_i, [_vp, _i, _i, _i, _i, _vp]),
     "upa_conv2d_bias_act": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "upa_conv_variant": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "upa_conv_big_mode": (_i, [_i]),
     "upa_stem_packed_weight_bytes": (_sz, [_i, _i, _i]),
     "upa_pack_stem_weight": (_i, [_vp, _i, _i, _i, _vp]),
     "upa_conv2d_stem_nchw": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -41,6 +43,7 @@ PROTOTYPES = {
     "upa_nchw_to_nhwc": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "upa_nhwc_to_nchw": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "upa_detect_decode": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _i, _i, _vp]),
+    "upa_detect_tail": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _f, _vp, _i, _i, _vp, _i, _i, _vp]),
     "upa_nms_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "upa_nms_batched": (_i, [_vp, _i, _i, _i, _f, _f, _i, _i, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     "upa_mhsa": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _i, _vp]),

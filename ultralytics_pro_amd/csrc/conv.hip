@@ -18,7 +18,8 @@
 //   * bf16: v_mfma_f32_16x16x32_bf16 (one per 64-byte k-tile); f32: 4 x v_mfma_f32_16x16x4_f32 per k-tile - exact f32
 //     (k-ordered fmaf chain), used for the <=1e-3 parity mode.  k order inside a tile is permuted identically for A
 //     and B (lane group g supplies bytes [16g,16g+16) of the tile), which leaves the sum unchanged.
-//   * LDS pixel stride = chunk bytes + 16 so consecutive pixels land on different 16-byte bank slots.
+//   * the LDS halo image is unpadded (the DMA writes contiguous kilobytes); the 16-byte group cg of pixel pl sits in slot
+//     cg ^ swz(pl), which keeps the ds_read_b128 fragment reads conflict-free.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -887,6 +888,15 @@ extern "C" int upa_conv2d_bias_act(const void* x, int n, int h, int w, int cin, 
                 "conv2d: cout/ldy/ldr must be multiples of %d elements (16-byte row stores)", E);
   UPA_CHECK_ARG(g_query_only || (((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) &&
                                  (!residual || (uintptr_t)residual % 16 == 0)), "conv2d: misaligned view");
+  if (upa_conv_big_eligible(n, h, w, cin, ldx, cout, ldy, residual ? ldr : 0, k, stride, pad, act, dtype)) {
+    BigParams q;
+    memset(&q, 0, sizeof(q));
+    q.x = (const char*)x; q.y = (char*)y; q.res = (const char*)residual; q.w = (const char*)w_packed; q.bias = bias;
+    q.N = n; q.H = h; q.W = w; q.Cin = cin; q.ldx = ldx; q.OH = h; q.OW = w; q.Cout = cout; q.ldy = ldy; q.ldr = ldr;
+    q.KS = k; q.pad = pad; q.act = act;
+    const int rc = upa_conv_big_launch(q, g_query_only, &g_last_variant, stream);
+    if (rc != UPA_EUNSUPPORTED) return rc;
+  }
   if (upa_conv_pipe_eligible(n, h, w, cin, ldx, cout, ldy, residual ? ldr : 0, k, stride, pad, act, dtype)) {
     PipeParams q;
     memset(&q, 0, sizeof(q));

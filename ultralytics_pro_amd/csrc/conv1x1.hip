@@ -53,11 +53,12 @@ __device__ __forceinline__ void vm_wait(int n) {
   if (n == C0) vm_wait_imm<C0>();
   else if (n == C0 + SE) vm_wait_imm<(C0 + SE < 64 ? C0 + SE : 0)>();
   else if (n == C0 + 2 * SE) vm_wait_imm<(C0 + 2 * SE < 64 ? C0 + 2 * SE : 0)>();
+  else if (n >= 63) vm_wait_imm<63>();  // more younger operations than the field holds: any smaller count is safe
   else vm_wait_imm<0>();
 }
 }  // namespace
 
-template <int NTW, int MT, int WAVES>
+template <int NTW, int MT, int WAVES, int EPI = 0>
 __global__ __launch_bounds__(WAVES * 64) void conv1x1_stream_kernel(const C1Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (p.ablate & 32) return;  // debug: launch + workgroup dispatch only
@@ -133,6 +134,24 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_stream_kernel(const C1Para
       if (tb >= p.P) continue;
       const int pix = tb + p16;
       const bool pok = pix < p.P && !(p.ablate & 4);
+      if constexpr (EPI == 1) {  // Detect box branch: DFL + dist2bbox + stride on the accumulators (detect_epi.h)
+        static_assert(EPI != 1 || NTW == 4, "box branch = 4 sides x 16 bins");
+        f32x4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = acc[i][j] + biasv[j];
+        upa_detect_box_store(p.de, v, pix < p.P ? pix : p.P - 1, pok, kg);
+        ++seq;
+      } else if constexpr (EPI == 2) {  // Detect class branch: sigmoid, channel-major f32 rows
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+          upa_detect_cls_store(p.de, acc[i][j] + biasv[j], j, pix < p.P ? pix : p.P - 1, pok, kg);
+          seq += 16 * j + 3 < p.de.nc ? 4 : 0;  // only stores that lane row 0 certainly issues are counted (the count may
+                                               // only be too small: a wait for more than needed is always safe)
+          if (16 * j + 3 >= p.de.nc)
+            for (int q = 0; q < 4; ++q) seq += 16 * j + q < p.de.nc ? 1 : 0;
+        }
+      }
+      if (EPI != 0 && p.y == nullptr) continue;  // decoded rows only (the raw maps are not materialised)
       char* yrow = p.y + ((size_t)pix * ldy2 + co0 * 2);
 #pragma unroll
       for (int j = 0; j + 1 < NTW; j += 2) {
@@ -172,7 +191,9 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_stream_kernel(const C1Para
   auto step = [&](auto stage_tag) __attribute__((always_inline)) {
     constexpr int S = decltype(stage_tag)::value;
     issue((S + RING - 1) % RING);  // the stage multiplied one step ago is free again
-    vm_wait<(RING - 1) * MT, MT * ((NTW + 1) / 2)>(seq - mark[S]);
+    // stores per epilogue in steady state: bf16 rows (two n-tiles per 16-byte store) / one box row / one f32 row per class
+    constexpr int SE = EPI == 0 ? MT * ((NTW + 1) / 2) : (EPI == 1 ? MT : MT * 4 * NTW);
+    vm_wait<(RING - 1) * MT, SE>(seq - mark[S]);
     if (!(p.ablate & 8)) {
       const char* st = ring + S * MT * 1024 + lane * 16;
       const char* wk = wl + ckt * (NTW * 1024) + lane * 16;
@@ -224,25 +245,25 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_stream_kernel(const C1Para
 
 namespace {
 
-template <int NTW, int MT, int WAVES>
+template <int NTW, int MT, int WAVES, int EPI>
 int launch_c1_inst(const C1Params& p, dim3 grid, size_t lds, hipStream_t s) {
-  auto kern = conv1x1_stream_kernel<NTW, MT, WAVES>;
-  (void)upa_full_lds<conv1x1_stream_kernel<NTW, MT, WAVES>>();
+  auto kern = conv1x1_stream_kernel<NTW, MT, WAVES, EPI>;
+  (void)upa_full_lds<conv1x1_stream_kernel<NTW, MT, WAVES, EPI>>();
   hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, s, p);
   UPA_LAUNCH_CHECK();
   return UPA_OK;
 }
 
-template <int NTW>
+template <int NTW, int EPI = 0>
 int launch_c1_ntw(const C1Params& p, int mt, int waves, dim3 grid, size_t lds, hipStream_t s) {
   if (waves == 8) {
-    if (mt == 4) return launch_c1_inst<NTW, 4, 8>(p, grid, lds, s);
-    if (mt == 2) return launch_c1_inst<NTW, 2, 8>(p, grid, lds, s);
-    return launch_c1_inst<NTW, 1, 8>(p, grid, lds, s);
+    if (mt == 4) return launch_c1_inst<NTW, 4, 8, EPI>(p, grid, lds, s);
+    if (mt == 2) return launch_c1_inst<NTW, 2, 8, EPI>(p, grid, lds, s);
+    return launch_c1_inst<NTW, 1, 8, EPI>(p, grid, lds, s);
   }
-  if (mt == 4) return launch_c1_inst<NTW, 4, 4>(p, grid, lds, s);
-  if (mt == 2) return launch_c1_inst<NTW, 2, 4>(p, grid, lds, s);
-  return launch_c1_inst<NTW, 1, 4>(p, grid, lds, s);
+  if (mt == 4) return launch_c1_inst<NTW, 4, 4, EPI>(p, grid, lds, s);
+  if (mt == 2) return launch_c1_inst<NTW, 2, 4, EPI>(p, grid, lds, s);
+  return launch_c1_inst<NTW, 1, 4, EPI>(p, grid, lds, s);
 }
 
 int env_int(const char* name, int dflt) {
@@ -316,6 +337,20 @@ int upa_conv1x1_launch(C1Params p, int n_pixels, int query_only, int* variant, v
   if (query_only) return UPA_OK;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)gx, (unsigned)gridY);
+  if (p.epi) {  // Detect tails: one workgroup row holds every output channel of a pixel
+    if (gridY != 1 || (p.epi == 1 && ntw != 4)) { upa_set_error("conv1x1 detect tail: unsupported channel count"); return UPA_EUNSUPPORTED; }
+    if (p.epi == 1) return launch_c1_ntw<4, 1>(p, mt, waves, grid, lds, s);
+    switch (ntw) {
+      case 1: return launch_c1_ntw<1, 2>(p, mt, waves, grid, lds, s);
+      case 2: return launch_c1_ntw<2, 2>(p, mt, waves, grid, lds, s);
+      case 3: return launch_c1_ntw<3, 2>(p, mt, waves, grid, lds, s);
+      case 4: return launch_c1_ntw<4, 2>(p, mt, waves, grid, lds, s);
+      case 5: return launch_c1_ntw<5, 2>(p, mt, waves, grid, lds, s);
+      case 6: return launch_c1_ntw<6, 2>(p, mt, waves, grid, lds, s);
+      case 7: return launch_c1_ntw<7, 2>(p, mt, waves, grid, lds, s);
+      default: return launch_c1_ntw<8, 2>(p, mt, waves, grid, lds, s);
+    }
+  }
   switch (ntw) {
     case 1: return launch_c1_ntw<1>(p, mt, waves, grid, lds, s);
     case 2: return launch_c1_ntw<2>(p, mt, waves, grid, lds, s);
@@ -326,4 +361,28 @@ int upa_conv1x1_launch(C1Params p, int n_pixels, int query_only, int* variant, v
     case 7: return launch_c1_ntw<7>(p, mt, waves, grid, lds, s);
     default: return launch_c1_ntw<8>(p, mt, waves, grid, lds, s);
   }
+}
+
+// Last 1x1 conv of a Detect branch with the decode fused on the end (bf16 perf mode): replaces
+// upa_conv2d_bias_act(k = 1, act none) + that branch's half of upa_detect_decode.
+extern "C" int upa_detect_tail(const void* x, int n, int h, int w, int cin, int ldx, const void* w_packed, const float* bias,
+                               int cout, int kind, int nc, float stride_px, float* y, int a_total, int a0, void* raw, int ldraw,
+                               int dtype, void* stream) {
+  UPA_CHECK_ARG(x && w_packed && y, "detect_tail: null pointer");
+  UPA_CHECK_ARG(kind == 1 || kind == 2, "detect_tail: kind must be 1 (box) or 2 (class)");
+  UPA_CHECK_ARG(n > 0 && h > 0 && w > 0 && a0 >= 0 && a0 + h * w <= a_total, "detect_tail: level does not fit a_total");
+  if (dtype != UPA_BF16 || h * w < 2 || w < 2 || (kind == 1 && cout != 64) || (kind == 2 && (cout < nc || cout > 128)) ||
+      !upa_conv1x1_eligible(n, h, w, cin, ldx, cout, raw ? ldraw : cout, false, 1, 1, 0, UPA_ACT_NONE, dtype)) {
+    upa_set_error("detect_tail: shape / dtype outside the fused form (bf16, reg_max 16, nc <= 128)");
+    return UPA_EUNSUPPORTED;  // the caller runs the conv and upa_detect_decode separately
+  }
+  C1Params q;
+  memset(&q, 0, sizeof(q));
+  q.x = (const char*)x; q.y = (char*)raw; q.w = (const char*)w_packed; q.bias = bias;
+  q.Cin = cin; q.ldx = ldx; q.Cout = cout; q.ldy = raw ? ldraw : cout; q.act = UPA_ACT_NONE;
+  q.epi = kind;
+  q.de.y = y; q.de.a_total = a_total; q.de.a0 = a0; q.de.HW = h * w; q.de.W = w;
+  q.de.magicHW = upa_magic_div(h * w); q.de.magicW = upa_magic_div(w);
+  q.de.nc = nc; q.de.stride_px = stride_px;
+  return upa_conv1x1_launch(q, n * h * w, 0, nullptr, stream);
 }

@@ -18,6 +18,7 @@ bool upa_conv_pipe_eligible(int n, int h, int w, int cin, int ldx, int cout, int
 int upa_conv_pipe_launch(PipeParams p, int query_only, int* variant, void* stream);
 
 // ---- conv1x1.hip: streaming pointwise convolution (bf16, k1 s1 p0, no residual)
+#include "detect_epi.h"
 struct C1Params {
   const char* x;
   char* y;
@@ -28,8 +29,30 @@ struct C1Params {
   int KTT, NTn, groups;
   int act;
   int ablate;  // debug (UPA_C1_ABLATE): 1 no input DMA, 2 no weight loads, 4 no stores, 8 no MFMA
+  int epi;     // 0: y = act(conv + bias) as bf16 rows; 1 / 2: Detect box / class decode fused on the end (detect_epi.h), the
+               // bf16 rows are written too when y != nullptr
+  DetectEpi de;
 };
 bool upa_conv1x1_eligible(int n, int h, int w, int cin, int ldx, int cout, int ldy, bool residual, int k, int stride,
                           int pad, int act, int dtype);
 // variant (if non-null) receives (1 << 22) | waves << 8 | MT << 4 | NTW; query_only = 1 skips the launch
 int upa_conv1x1_launch(C1Params p, int n_pixels, int query_only, int* variant, void* stream);
+
+// ---- conv_big.hip: large-tile implicit GEMM with both operands shared through LDS (bf16, stride 1, k = 1 | 3, MFMA-bound layers)
+struct BigParams {
+  const char* x;
+  char* y;
+  const char* res;
+  const char* w;       // packed [tap][ktile][ntile][lane][16 B] (upa_pack_conv_weight)
+  const float* bias;
+  int N, H, W, Cin, ldx, OH, OW, Cout, ldy, ldr;
+  int KS, pad;
+  int TH, TW, tilesX, tilesY, IH, IW;
+  int KTT, NTn;
+  int act;
+  unsigned magicTW, magicIW;
+};
+bool upa_conv_big_eligible(int n, int h, int w, int cin, int ldx, int cout, int ldy, int ldr, int k, int stride, int pad,
+                           int act, int dtype);
+// variant (if non-null) receives (1 << 23); query_only = 1 skips the launch
+int upa_conv_big_launch(BigParams p, int query_only, int* variant, void* stream);

@@ -1,0 +1,81 @@
+// Detect decode as a convolution EPILOGUE (bf16 perf mode): the last 1x1 conv of a Detect branch leaves its logits in MFMA
+// accumulators - D[row = channel][col = pixel], lane (kg = lane >> 4, p16 = lane & 15) holds channels 16j + 4kg + q
+// (q = 0..3) of pixel p16 for n-tile j - and this header turns them into the reference's decoded output rows without the
+// (B, H, W, 4*reg_max + nc) round trip through HBM that a separate decode kernel needs:
+//   * box branch (4 n-tiles = 4 sides x reg_max 16 bins): DFL softmax expectation over the 16 bins of a side
+//     (nn/modules/block.py:250-253) = 4 values in the lane x 4 lane rows, reduced with v_permlane16_swap / v_permlane32_swap
+//     (no LDS); dist2bbox around the cell-centre anchor and x stride (utils/tal.py:352-376, nn/modules/head.py:151-169,
+//     184-191); lane row kg writes output channel kg (x, y, w, h) of its pixel;
+//   * class branch: sigmoid of every logit (head.py:169), written channel-major.
+// Output layout = the reference's (B, 4 + nc, A) float32; along the anchor axis a 16-lane row writes 64 contiguous bytes.
+// Arithmetic as csrc/detect.hip in bf16 mode (v_exp_f32 / v_rcp_f32); the f32 parity mode keeps the separate kernel.
+#pragma once
+#include "common.h"
+
+struct DetectEpi {
+  float* y;        // (B, 4 + nc, a_total) f32
+  int a_total;     // anchors of all levels
+  int a0;          // first anchor of this level
+  int HW, W;       // pixels per image / row width of this level
+  unsigned magicHW;  // floor(2^32 / HW) + 1: pix / HW == umulhi(pix, magicHW) for pix < 2^32 / HW
+  unsigned magicW;
+  int nc;
+  float stride_px;
+};
+
+__device__ __forceinline__ float upa_row_sum4(float v) {  // sum over the 4 lane rows (lanes l, l^16, l^32, l^48)
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ float upa_row_max4(float v) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const float s = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
+// Box branch of one 16-pixel tile.  v[j] = logits (bias added) of side j: bins 4kg + q of pixel `pix`.
+__device__ __forceinline__ void upa_detect_box_store(const DetectEpi& d, const f32x4 (&v)[4], int pix, bool ok, int kg) {
+  constexpr float LOG2E = 1.44269504088896340736f;
+  float dist[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const float m = upa_row_max4(fmaxf(fmaxf(v[s][0], v[s][1]), fmaxf(v[s][2], v[s][3])));
+    float sum = 0.f, e = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float ex = __builtin_amdgcn_exp2f((v[s][q] - m) * LOG2E);
+      sum += ex;
+      e += ex * (float)(4 * kg + q);
+    }
+    sum = upa_row_sum4(sum);
+    e = upa_row_sum4(e);
+    dist[s] = e * __builtin_amdgcn_rcpf(sum);
+  }
+  const int b = (int)__umulhi((unsigned)pix, d.magicHW);
+  const int a = pix - b * d.HW;
+  const int ay = (int)__umulhi((unsigned)a, d.magicW);
+  const int ax = a - ay * d.W;
+  const float cx = (float)ax + 0.5f, cy = (float)ay + 0.5f;
+  const float x1 = cx - dist[0], y1 = cy - dist[1], x2 = cx + dist[2], y2 = cy + dist[3];
+  const float o = kg == 0 ? (x1 + x2) / 2.f : kg == 1 ? (y1 + y2) / 2.f : kg == 2 ? (x2 - x1) : (y2 - y1);
+  if (ok) d.y[((size_t)b * (4 + d.nc) + kg) * d.a_total + d.a0 + a] = o * d.stride_px;
+}
+
+// Class branch: n-tile j of one 16-pixel tile; v = logits (bias added) of classes 16j + 4kg + q.
+__device__ __forceinline__ void upa_detect_cls_store(const DetectEpi& d, const f32x4& v, int j, int pix, bool ok, int kg) {
+  constexpr float LOG2E = 1.44269504088896340736f;
+  const int b = (int)__umulhi((unsigned)pix, d.magicHW);
+  const int a = pix - b * d.HW;
+  float* yb = d.y + ((size_t)b * (4 + d.nc) + 4) * d.a_total + d.a0 + a;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = 16 * j + 4 * kg + q;
+    const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[q] * -LOG2E));
+    if (ok && c < d.nc) yb[(size_t)c * d.a_total] = sg;
+  }
+}
+
+static inline unsigned upa_magic_div(int d) { return (unsigned)(0x100000000ULL / (unsigned long long)d) + 1u; }

@@ -51,6 +51,44 @@ class Detect(nn.Module, _HipConvMixin):
         self.cv3 = nn.ModuleList(nn.Sequential(Conv(x, c3, 3), Conv(c3, c3, 3), nn.Conv2d(c3, self.nc, 1)) for x in ch)
         self.dfl = DFL(self.reg_max) if self.reg_max > 1 else nn.Identity()
 
+    # ---- decode fused into the last 1x1 conv of each branch (bf16 perf mode) ----------------------------------------------
+    # `upa_detect_tail`: the branch's final nn.Conv2d and its half of Detect._inference (DFL + dist2bbox + stride, or the
+    # class sigmoid; head.py:151-169) are ONE kernel - the (B, H, W, 4*reg_max + nc) logits stay in MFMA accumulators.
+    # `keep_raw` decides whether they are ALSO written out as the second return value (the reference's `(y, x)`,
+    # head.py:126; the predict / validate hot path only reads y).  f32 parity mode keeps conv + upa_detect_decode.
+    fuse_decode = True
+    keep_raw = True
+
+    def _plan(self):
+        return self.__dict__.setdefault("_plans", {})
+
+    def begin(self, n: int, level_hw, dtype, device) -> None:
+        """Allocate the decoded output for a forward whose Detect inputs will have the spatial sizes `level_hw` (known
+        statically from the input size) so that every level's branches can decode straight into their anchor range."""
+        a0, tot = [], 0
+        for (h, w) in level_hw:
+            a0.append(tot)
+            tot += int(h) * int(w)
+        fused = bool(self.fuse_decode and dtype == torch.bfloat16 and self.reg_max == 16 and self.nc <= 128
+                     and all(h * w >= 2 and w >= 2 for h, w in level_hw))
+        y = R.alloc_plain((n, 4 + self.nc, tot), torch.float32, device, key=(id(self), "y"))
+        self._plan()[R.current_tag()] = dict(y=y, a0=a0, a_total=tot, fused=fused, hw=[(int(h), int(w)) for h, w in level_hw],
+                                             n=int(n), decoded=set())
+
+    def _tail(self, seq: nn.Sequential, x: torch.Tensor, raw: torch.Tensor | None, kind: int, i: int, plan) -> None:
+        """conv3x3 -> conv3x3 -> [1x1 + decode] of one branch (kind 1 = box, 2 = class) of level i."""
+        t = seq[1](seq[0](x))
+        cout = 4 * self.reg_max if kind == 1 else self._ncp(x.dtype)
+        pk = self._packed(seq[2], None, x.device, x.dtype, False, pad_cout=cout)
+        vt = R.view_of(t)
+        rp, rld = (None, 0)
+        if raw is not None:
+            vr = R.view_of(raw)
+            rp, rld = vr.ptr, vr.ld
+        L.check(L.lib().upa_detect_tail(vt.ptr, vt.n, vt.h, vt.w, vt.c, vt.ld, pk.w.data_ptr(), pk.bias.data_ptr(), cout, kind,
+                                        self.nc, float(self.stride[i]), plan["y"].data_ptr(), plan["a_total"], plan["a0"][i],
+                                        rp, rld, vt.dtype, L.current_stream(x.device)), "detect_tail")
+
     def _branch(self, seq: nn.Sequential, x: torch.Tensor, out: torch.Tensor) -> None:
         t = seq[1](seq[0](x))
         # `out` may be wider than the conv (class rows are padded to the 16-byte store width when nc is not a multiple
@@ -84,40 +122,61 @@ class Detect(nn.Module, _HipConvMixin):
         return self.__dict__.setdefault("_pending", {}).setdefault(R.current_tag(), {})
 
     def start_level(self, i: int, x: torch.Tensor) -> None:
-        """Launch level i's two branches (asynchronously when `concurrent`); results land in the level's raw buffer."""
+        """Launch level i's two branches (asynchronously when `concurrent`); results land in the level's raw buffer and /
+        or, with the fused decode, directly in the decoded output."""
         pend = self._pend()
         x = R.to_nhwc(x, x.dtype)
         nb = 4 * self.reg_max
         n, _, h, w = x.shape
+        plan = self._plan().get(R.current_tag())
+        if plan is not None and (plan["n"] != n or plan["hw"][i] != (h, w) or plan["y"].device != x.device):
+            plan = None  # stale plan (other input size): this level goes through the separate decode
+        fused = plan is not None and plan["fused"] and x.dtype == torch.bfloat16
         ncp = self._ncp(x.dtype)
-        buf = R.alloc_nhwc(n, nb + ncp, h, w, x.dtype, x.device, key=(id(self), "raw", i))
+        buf = None
+        if not fused or self.keep_raw:
+            buf = R.alloc_nhwc(n, nb + ncp, h, w, x.dtype, x.device, key=(id(self), "raw", i))
+        outs = (None, None) if buf is None else (buf[:, :nb], buf[:, nb:])
+        raw = None if buf is None else buf[:, :self.no]
+
+        def run(k):
+            seq = (self.cv2[i], self.cv3[i])[k]
+            if fused:
+                self._tail(seq, x, outs[k], k + 1, i, plan)
+            else:
+                self._branch(seq, x, outs[k])
+
+        if fused:
+            plan["decoded"].add(i)
         if not self.concurrent or R.current_tag() != 0:
             # inside a concurrently scheduled sub-batch (BaseModel.compile(micro_batches>1)) the branches stay on the
             # sub-batch's stream: the sub-batches already overlap each other, and nesting a second level of event
             # forks inside a forked capture stream crashed hipStreamEndCapture on ROCm 7.2 (segfault, not an error code)
-            self._branch(self.cv2[i], x, buf[:, :nb])
-            self._branch(self.cv3[i], x, buf[:, nb:])
-            pend[i] = (buf[:, :self.no], [])
+            run(0)
+            run(1)
+            pend[i] = (raw, [])
             return
         main = torch.cuda.current_stream(x.device)
         fork = torch.cuda.Event()
         fork.record(main)
         joins = []
         streams = self._side_streams(x.device)
-        for k, (seq, out) in enumerate(((self.cv2[i], buf[:, :nb]), (self.cv3[i], buf[:, nb:]))):
+        for k in range(2):
             side = streams[2 * i + k]
             side.wait_event(fork)
             with torch.cuda.stream(side):
-                self._branch(seq, x, out)
+                run(k)
                 ev = torch.cuda.Event()
                 ev.record(side)
             joins.append(ev)
-        pend[i] = (buf[:, :self.no], joins)
+        pend[i] = (raw, joins)
 
     def forward(self, x):
         if self.training:
             raise L.UpaError("training-mode Detect is not on the HIP path yet (SURVEY §8f rank 2)")
         pend = self._pend()
+        if not pend:  # called directly (not through BaseModel._predict_once): the level shapes come with the inputs
+            self.begin(x[0].shape[0], [(t.shape[2], t.shape[3]) for t in x], x[0].dtype, x[0].device)
         for i in range(self.nl):
             if i not in pend:
                 self.start_level(i, x[i])
@@ -132,14 +191,23 @@ class Detect(nn.Module, _HipConvMixin):
         y = self._inference(raw)
         return y if self.export else (y, raw)
 
-    def _inference(self, x: list[torch.Tensor]) -> torch.Tensor:
-        """Decode boxes and class probabilities of all levels into (B, 4+nc, A) float32 (head.py:151-169)."""
+    def _inference(self, x: list) -> torch.Tensor:
+        """Decode boxes and class probabilities of all levels into (B, 4+nc, A) float32 (head.py:151-169).  Levels whose
+        branches already decoded in their last conv (`upa_detect_tail`) are skipped; x[i] may then be None."""
         nb = 4 * self.reg_max
-        n = x[0].shape[0]
-        a_total = sum(int(t.shape[2]) * int(t.shape[3]) for t in x)
-        y = R.alloc_plain((n, 4 + self.nc, a_total), torch.float32, x[0].device, key=(id(self), "y"))
+        plan = self._plan().pop(R.current_tag(), None)
+        done = plan["decoded"] if plan is not None else set()
+        if plan is not None and (done or all(t is not None for t in x)):
+            y, a_total = plan["y"], plan["a_total"]
+        else:
+            n = x[0].shape[0]
+            a_total = sum(int(t.shape[2]) * int(t.shape[3]) for t in x)
+            y = R.alloc_plain((n, 4 + self.nc, a_total), torch.float32, x[0].device, key=(id(self), "y"))
         a0 = 0
         for i, t in enumerate(x):
+            if i in done:
+                a0 += plan["hw"][i][0] * plan["hw"][i][1]
+                continue
             vb, vc = R.view_of(t[:, :nb]), R.view_of(t[:, nb:])
             L.check(L.lib().upa_detect_decode(vb.ptr, vb.ld, vc.ptr, vc.ld, vb.n, vb.h, vb.w, self.reg_max, self.nc,
                                               float(self.stride[i]), y.data_ptr(), a_total, a0, vb.dtype,

@@ -135,6 +135,8 @@ def _out_hw(m, h, w):
             h, w = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
         elif isinstance(mm, Upsample):
             h, w = 2 * h, 2 * w
+        elif isinstance(mm, ZeroPad2d):
+            h, w = h + mm.padding[2] + mm.padding[3], w + mm.padding[0] + mm.padding[1]
     return h, w
 
 
@@ -196,6 +198,13 @@ class BaseModel(nn.Module):
         if det is not None:
             det._pend().clear()
             det_level = {(det.i - 1 if j == -1 else j): k for k, j in enumerate(det.f)} if isinstance(det.f, list) else {}
+            if det_level and torch.is_tensor(x) and x.dim() == 4:
+                # the Detect input sizes follow statically from the image size: the head can decode each level into its
+                # anchor range of the output the moment that level's feature map exists
+                ih, iw = (x.shape[1], x.shape[2]) if x.dtype == torch.uint8 else (x.shape[2], x.shape[3])
+                hw = self._static_hw(int(ih), int(iw))
+                srcs = sorted(det_level, key=lambda j: det_level[j])
+                det.begin(int(x.shape[0]), [hw[j] for j in srcs], getattr(self, "compute_dtype", None) or x.dtype, x.device)
         fused_stem = self._stem_fusable(x, place)
         for m in self.model:
             if fused_stem and m.i == 0:  # layers 0 and 1 run as ONE kernel: the stem output never reaches HBM
@@ -238,6 +247,21 @@ class BaseModel(nn.Module):
             if m.i in det_level and torch.is_tensor(x):  # a Detect input is ready: start that level's branches now
                 det.start_level(det_level[m.i], x)
         return x
+
+    def _static_hw(self, h: int, w: int):
+        """Output (h, w) of every layer for an (h, w) image: a shape walk of the graph, no tensors (cached per size)."""
+        cache = self.__dict__.setdefault("_hw_cache", {})
+        out = cache.get((h, w))
+        if out is None:
+            out = []
+            for m in self.model:
+                f = m.f if isinstance(m.f, int) else m.f[0]
+                ih, iw = (h, w) if not out else out[-1]
+                if f != -1:
+                    ih, iw = out[f]
+                out.append(_out_hw(m, ih, iw))
+            cache[(h, w)] = out
+        return out
 
     def _stem_fusable(self, x, place) -> bool:
         """yolov8n's first two rows (Conv(3,16,3,2), Conv(16,32,3,2), SiLU, bf16 NCHW input, neither output used by a later
