@@ -87,6 +87,15 @@ int upa_add_view(const void* a, int lda, const void* b, int ldb, void* y, int ld
  * channels c .. 16/elem-1 of that group are set to zero (the channel padding the first conv expects). */
 int upa_nchw_to_nhwc(const float* x, int n, int c, int h, int w, void* y, int ldy, int dtype, void* stream);
 int upa_nhwc_to_nchw(const void* x, int n, int h, int w, int c, int ldx, float* y, int dtype, void* stream);
+/* LetterBox of uint8 (h0, w0, 3) frames (data/augment.py:1544-1700, the predictor's pre_transform, predictor.py:151-173):
+ * cv2.resize(INTER_LINEAR) to (new_h, new_w) - OpenCV's 8-bit fixed-point arithmetic, bit-exact against oracle/letterbox.py -
+ * placed at (top, left) of an (H, W, 3) output filled with pad_value.  The geometry (ratio, rounding, padding split) is the
+ * caller's: ultralytics_pro_amd/data/augment.py computes it exactly as LetterBox.__call__ does.  n frames of one size per
+ * call (src_image_stride bytes apart, rows src_row_stride bytes apart); dst is contiguous (n, H, W, 3) and feeds the stem
+ * conv as UPA_U8_BGR_HWC. */
+int upa_letterbox_u8(const void* src, int n, int h0, int w0, long src_image_stride, int src_row_stride, void* dst, int H, int W,
+                     int new_h, int new_w, int top, int left, int pad_value, void* stream);
+
 
 /* ---- Detect decode ------------------------------------------------------------------------------------------------
  * One level: box logits (n,h,w,4*reg_max) + cls logits (n,h,w,nc) NHWC -> y[b, 0:4, a0:a0+h*w] = xywh*stride

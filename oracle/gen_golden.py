@@ -8,6 +8,7 @@ Outputs are data only (inputs are re-derivable from the hash; expected outputs a
   tests/golden/nms_cases.npz        NMS inputs + reference outputs                               (§8c c)
   tests/golden/e2e_<cfg>.npz        head-output slices/statistics + post-NMS rows, B=2            (§8c d)
   tests/golden/map_yolov8n.npz      synthetic-GT validation set: detections, labels, TP matrices, AP (§8f rank 1)
+  tests/golden/letterbox.npz        LetterBox frames in / out (cv2.resize restated, see oracle/letterbox.py)          (§8f rank 3)
   tests/golden/train_<cfg>.npz      training step(s): loss items, gradient norms / slices, updated state, EMA (§8f rank 2)
 """
 
@@ -456,11 +457,71 @@ def train_golden(rt):
         np.savez_compressed(GOLD / f"train_{name}.npz", **G)
 
 
+def procedural_frame(h, w, key):
+    """uint8 BGR (h, w, 3) frame from the counter hash: smooth gradients + blocks + noise (so interpolation matters)."""
+    u = P.hash_uniform(f"frame:{key}", h * w * 3).reshape(h, w, 3)
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = (np.stack([xx / max(w - 1, 1), yy / max(h - 1, 1), ((xx // 7 + yy // 5) % 2).astype(np.float64)], -1) * 200 + 20)
+    return np.clip(base + (u - 0.5) * 70, 0, 255).astype(np.uint8)
+
+
+LETTERBOX_CASES = [
+    # (h, w), kwargs of LetterBox
+    ((37, 53), dict(new_shape=(64, 64))),
+    ((53, 37), dict(new_shape=(64, 64))),
+    ((48, 64), dict(new_shape=(64, 64))),                       # width already fits: resize skipped? (ratio 1) -> pad only
+    ((64, 64), dict(new_shape=(64, 64))),                       # nothing to do
+    ((100, 30), dict(new_shape=(64, 96))),                      # rectangular target
+    ((20, 31), dict(new_shape=(64, 64), scaleup=False)),        # small frame, no upscaling: pad only
+    ((20, 31), dict(new_shape=(64, 64), scaleup=True)),         # upscaling
+    ((75, 120), dict(new_shape=(64, 64), auto=True, stride=32)),  # minimum rectangle (the predictor's `auto` for .pt models)
+    ((75, 120), dict(new_shape=(64, 64), scale_fill=True)),     # stretch
+    ((75, 120), dict(new_shape=(64, 64), center=False)),        # top-left placement
+    ((33, 77), dict(new_shape=(64, 64), padding_value=0)),
+    ((120, 160), dict(new_shape=(160, 160))),                   # a 4:3 frame into a square
+]
+
+
+def letterbox_golden(rt):
+    """the reference's LetterBox class on procedural frames.  cv2 is absent from this image: its `resize`
+    is replaced by the oracle's restatement of OpenCV's 8-bit INTER_LINEAR (oracle/letterbox.py - that part is unpinned
+    against the real library), `copyMakeBorder` by its numpy definition; everything else is the reference's code."""
+    import cv2  # the stub module installed by ref_shim
+
+    from oracle import letterbox as ol
+
+    cv2.INTER_LINEAR, cv2.BORDER_CONSTANT = 1, 0
+    cv2.resize = lambda img, dsize, interpolation=None: ol.cv2_resize_linear_u8(img, dsize)
+
+    def copy_make_border(img, top, bottom, left, right, border_type, value=(0, 0, 0)):
+        h, w, c = img.shape
+        out = np.empty((h + top + bottom, w + left + right, c), dtype=img.dtype)
+        out[...] = np.asarray(value, dtype=img.dtype)[:c]
+        out[top:top + h, left:left + w] = img
+        return out
+
+    cv2.copyMakeBorder = copy_make_border
+    import ultralytics.data.augment as aug
+    aug.cv2 = cv2
+    G = {}
+    for i, ((h, w), kw) in enumerate(LETTERBOX_CASES):
+        img = procedural_frame(h, w, i)
+        ref = aug.LetterBox(**kw)(image=img.copy())
+        mine = ol.letterbox(img.copy(), **kw)
+        assert ref.shape == mine.shape and np.array_equal(ref, mine), f"letterbox case {i}: oracle != reference class"
+        G[f"in{i}"] = img
+        G[f"out{i}"] = ref
+        G[f"kw{i}"] = np.array(json.dumps(kw))
+        print(f"letterbox {i}: {(h, w)} {kw} -> {ref.shape}")
+    G["n"] = np.array([len(LETTERBOX_CASES)])
+    np.savez_compressed(GOLD / "letterbox.npz", **G)
+
+
 def main():
     torch.manual_seed(0)
     GOLD.mkdir(parents=True, exist_ok=True)
     rt = import_reference()
-    which = sys.argv[1:] or ["builder", "ops", "nms", "e2e", "map", "train"]
+    which = sys.argv[1:] or ["builder", "ops", "nms", "e2e", "map", "letterbox", "train"]
     with torch.no_grad():
         if "builder" in which:
             builder_tables(rt)
@@ -472,6 +533,8 @@ def main():
             e2e(rt)
         if "map" in which:
             map_golden(rt)
+        if "letterbox" in which:
+            letterbox_golden(rt)
     if "train" in which:
         train_golden(rt)
 

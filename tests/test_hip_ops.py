@@ -107,7 +107,13 @@ def test_conv_pipe_kernel(case):
 
 
 BIG_CASES = [
-    # c1, c2, k, H, W, N, residual  (stride 1: the large-tile LDS-shared-operand kernel, csrc/conv_big.hip)
+    # c1, c2, k, H, W, N, residual[, stride]  (the large-tile LDS-shared-operand kernel, csrc/conv_big.hip)
+    (64, 80, 3, 24, 40, 2, False),     # 96-channel variant (Cout 80: 5 of 6 n-tiles, odd tail store), 128-pixel workgroups
+    (80, 80, 3, 80, 80, 2, True),      # 96-channel variant with 256-pixel workgroups; Cin 80: 3 k-tiles, 2 chunks
+    (32, 64, 3, 33, 47, 1, False),     # 64-channel variant (8 x 1 waves)
+    (64, 128, 3, 40, 40, 2, False, 2),   # stride 2: 40 -> 20, halo (TH-1)*2+3
+    (128, 256, 3, 31, 45, 1, False, 2),  # stride 2, odd input sizes, two output columns
+    (32, 64, 3, 64, 64, 1, False, 2),    # stride 2, 64-channel variant
     (128, 128, 3, 20, 20, 2, False),   # 20-wide map: 20 x 12 tiles, second tile ragged (8 rows)
     (256, 128, 3, 40, 40, 1, False),   # 40 x 6 tiles, 7 per image, last one ragged; 4 chunks of 64 channels
     (128, 256, 3, 16, 32, 2, True),    # 16 x 16 tiles, two 128-channel workgroup columns, residual add
@@ -120,23 +126,24 @@ BIG_CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", BIG_CASES, ids=[f"c{c[0]}-{c[1]}k{c[2]}_{c[3]}x{c[4]}n{c[5]}{'r' if c[6] else ''}" for c in BIG_CASES])
+@pytest.mark.parametrize("case", BIG_CASES, ids=[f"c{c[0]}-{c[1]}k{c[2]}s{c[7] if len(c) > 7 else 1}_{c[3]}x{c[4]}n{c[5]}{'r' if c[6] else ''}" for c in BIG_CASES])
 @pytest.mark.parametrize("act", [True, False], ids=["silu", "noact"])
 def test_conv_big_kernel(case, act):
-    """bf16 stride-1 convs forced through conv_big_kernel (upa_conv_big_mode(2)) vs the oracle Conv (conv.py:188-197) on
+    """bf16 convs forced through conv_big_kernel (upa_conv_big_mode(2)) vs the oracle Conv (conv.py:188-197) on
     bf16-rounded inputs: image borders (zero page), tiles that are not powers of two, ragged last tiles, partial k-tiles and
     odd chunk counts, masked output-channel columns, pointwise layers, the fused residual add (block.py:668)."""
     from tests.hip_utils import bf16_round, to_cpu_nchw, to_dev_nhwc
     from ultralytics_pro_amd import _lib as L
     pm, _ = _mods()
-    c1, c2, k, H, W, N, res = case
+    c1, c2, k, H, W, N, res = case[:7]
+    st = case[7] if len(case) > 7 else 1
     prev = L.lib().upa_conv_big_mode(2)
     try:
-        var = L.lib().upa_conv_variant(N, H, W, c1, c2, k, 1, k // 2, 1)
+        var = L.lib().upa_conv_variant(N, H, W, c1, c2, k, st, k // 2, 1)
         assert (var >> 23) & 1, "case is not dispatched to the large-tile kernel"
-        o, m = _pair(om.Conv, pm.Conv, (c1, c2, k, 1, None, 1, 1, act), "conv_big")
+        o, m = _pair(om.Conv, pm.Conv, (c1, c2, k, st, None, 1, 1, act), "conv_big")
         x = bf16_round(P.uniform(f"big{case}", (N, c1, H, W), -1, 1))
-        rsd = bf16_round(P.uniform(f"bigres{case}", (N, c2, H, W), -1, 1)) if res else None
+        rsd = bf16_round(P.uniform(f"bigres{case}", (N, c2, (H - 1) // st + 1, (W - 1) // st + 1), -1, 1)) if res else None
         with torch.no_grad():
             ref = o(x) + (rsd if res else 0)
             y = to_cpu_nchw(m(to_dev_nhwc(x, torch.bfloat16), residual=to_dev_nhwc(rsd, torch.bfloat16) if res else None))

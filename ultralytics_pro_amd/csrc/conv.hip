@@ -892,8 +892,10 @@ extern "C" int upa_conv2d_bias_act(const void* x, int n, int h, int w, int cin, 
     BigParams q;
     memset(&q, 0, sizeof(q));
     q.x = (const char*)x; q.y = (char*)y; q.res = (const char*)residual; q.w = (const char*)w_packed; q.bias = bias;
-    q.N = n; q.H = h; q.W = w; q.Cin = cin; q.ldx = ldx; q.OH = h; q.OW = w; q.Cout = cout; q.ldy = ldy; q.ldr = ldr;
-    q.KS = k; q.pad = pad; q.act = act;
+    q.N = n; q.H = h; q.W = w; q.Cin = cin; q.ldx = ldx; q.Cout = cout; q.ldy = ldy; q.ldr = ldr;
+    q.OH = (h + 2 * pad - k) / stride + 1;
+    q.OW = (w + 2 * pad - k) / stride + 1;
+    q.KS = k; q.stride = stride; q.pad = pad; q.act = act;
     const int rc = upa_conv_big_launch(q, g_query_only, &g_last_variant, stream);
     if (rc != UPA_EUNSUPPORTED) return rc;
   }

@@ -1,23 +1,26 @@
-// Large-tile implicit-GEMM convolution for the MFMA-bound layers (bf16, stride 1, k = 1 | 3, Cout a multiple of 128):
-// darknet53 in yolov3-rtdetr, yolov8s, the 256..1024-channel layers of yolov3-tiny.  Same function as conv.hip
-// (Conv.forward_fuse, ultralytics/nn/modules/conv.py:188-197, BN folded per utils/torch_utils.py:236-266, optional
-// Bottleneck residual block.py:668) and the same packed-weight layout; what differs is where the operands come from.
+// Large-tile implicit-GEMM convolution with BOTH operands shared through LDS (bf16, k = 1 | 3, stride 1 | 2): the MFMA-bound
+// layers - darknet53 in yolov3-rtdetr, yolov8s, the 256..1024-channel layers of yolov3-tiny - and the 80-channel class branch
+// of Detect.  Same function as conv.hip (Conv.forward_fuse, ultralytics/nn/modules/conv.py:188-197, BN folded per
+// utils/torch_utils.py:236-266, optional Bottleneck residual block.py:668) and the same packed-weight layout; what differs
+// is where the operands come from.
 //
 // conv_igemm_kernel lets every wave fetch its own weight fragments from L2 (1 KiB per 4..8 MFMAs per wave): at Cin >= 128
 // that saturates the CU's 64 B/clk vector-memory path and the kernel sits at 14-17 % of the MFMA peak.  Here a workgroup of
-// 8 waves (2 per SIMD) owns 256 output pixels x 128 output channels and BOTH operands are shared through LDS:
-//   * B (pixels): the halo tile of a 64-channel chunk, (TH+k-1) x (TW+k-1) pixels x 128 B, staged once per chunk by LDS-DMA
-//     (global_load_lds_dwordx4, zero page outside the image / past Cin), XOR-swizzled so ds_read_b128 is conflict-free;
-//     every tap reads it at a shifted pixel offset;
-//   * A (weights): the 16 KiB slab of one (tap, chunk) - 2 k-tiles x 8 n-tiles in exact fragment order - DMA'd into one of
-//     two LDS buffers while the previous tap is multiplied; 16 coalesced 1 KiB wave-instructions per slab per WORKGROUP,
+// 8 waves (2 per SIMD) owns BM = 256 (or 128) output pixels x NTB * 16 output channels:
+//   * B (pixels): the halo tile of a 64-channel chunk, ((TH-1)s+k) x ((TW-1)s+k) pixels x 128 B, staged once per chunk by
+//     LDS-DMA (global_load_lds_dwordx4, zero page outside the image / past Cin), XOR-swizzled so ds_read_b128 is
+//     conflict-free; every tap reads it at a shifted pixel offset;
+//   * A (weights): the slab of one (tap, chunk) - 2 k-tiles x NTB n-tiles of 1 KiB in exact fragment order - DMA'd into one
+//     of two LDS buffers while the previous tap is multiplied: coalesced 1 KiB wave-instructions, once per WORKGROUP,
 //     i.e. 64 B of weight traffic per MFMA instead of 128-256 B;
-//   * wave tile 64 pixels x 64 channels (4 x 4 MFMA tiles, 64 accumulator registers): 8 ds_read_b128 per 16
-//     v_mfma_f32_16x16x32_bf16, half the LDS rate at full MFMA issue; <= 128 VGPRs so two workgroups share a CU
-//     (4 waves per SIMD) and one workgroup's barrier / DMA wait is covered by the other's MFMAs;
-//   * one barrier per tap (32 MFMAs per wave between barriers), the weight DMA of tap t+1 in flight across it;
+//   * wave tile MT x NT MFMA tiles (4 x 4 = 64 pixels x 64 channels in the main variant: 8 ds_read_b128 per 16
+//     v_mfma_f32_16x16x32_bf16, half the LDS rate at full MFMA issue); <= 128 VGPRs, so two workgroups share a CU (4 waves
+//     per SIMD) whenever their LDS fits and one workgroup's barrier / DMA wait is covered by the other's MFMAs;
+//   * one barrier per tap (2 * MT * NT MFMAs per wave between barriers), the weight DMA of tap t+1 in flight across it;
 //   * tile shape chosen per layer on the host (TW need not be a power of two: 20 x 12 for 20x20 maps, 40 x 6 for 40x40), the
 //     pixel -> (row, column) split is done once per lane with a multiply-high.
+// Variants <WM, WN, MT, NT> (WM * WN = 8 waves): 4,2,4,4 = 256 px x 128 ch; 4,2,2,4 = 128 px x 128 ch (few-pixel layers: twice
+// the workgroups); 4,2,4,3 / 4,2,2,3 = x 96 ch (Cout 80 / 96); 8,1,2,4 = 256 px x 64 ch.
 // Epilogue straight from the accumulators (bias, SiLU by v_exp_f32 / v_rcp_f32, bf16 pack, v_permlane16_swap -> 16-byte
 // NHWC stores, residual read with the same shape), as conv.hip.
 #include <stdlib.h>
@@ -33,10 +36,6 @@ typedef __attribute__((address_space(3))) void* blptr_t;
 __device__ __attribute__((aligned(16))) unsigned g_big_zero16[4] = {0u, 0u, 0u, 0u};
 
 namespace {
-constexpr int BIG_BM = 256;   // pixels per workgroup
-constexpr int BIG_NTB = 8;    // n-tiles (16 output channels) per workgroup
-constexpr int BIG_WBUF = 2 * BIG_NTB * 1024;  // one (tap, chunk) weight slab: 2 k-tiles x 8 n-tiles x 1 KiB
-
 template <int ACT>
 __device__ __forceinline__ float big_act(float v) {
   if constexpr (ACT == UPA_ACT_SILU) return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
@@ -45,14 +44,17 @@ __device__ __forceinline__ float big_act(float v) {
 }
 }  // namespace
 
-template <int KS>
+template <int KS, int STRIDE, int WM, int WN, int MT, int NT>
 __global__ __launch_bounds__(512, 4) void conv_big_kernel(const BigParams p) {
+  static_assert(WM * WN == 8, "8 waves per workgroup");
+  constexpr int NTB = WN * NT;            // n-tiles per workgroup
+  constexpr int WBUF = 2 * NTB * 1024;    // one (tap, chunk) weight slab: 2 k-tiles x NTB n-tiles x 1 KiB
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, g = lane >> 4;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
 
   int bid = blockIdx.x;
   const int tilesPerImg = p.tilesX * p.tilesY;
@@ -61,32 +63,32 @@ __global__ __launch_bounds__(512, 4) void conv_big_kernel(const BigParams p) {
   const int tyi = bid / p.tilesX;
   const int txi = bid - tyi * p.tilesX;
   const int oy0 = tyi * p.TH, ox0 = txi * p.TW;
-  const int iy0 = oy0 - p.pad, ix0 = ox0 - p.pad;
-  const int ntb0 = blockIdx.y * BIG_NTB;  // first n-tile of the workgroup
+  const int iy0 = oy0 * STRIDE - p.pad, ix0 = ox0 * STRIDE - p.pad;
+  const int ntb0 = blockIdx.y * NTB;  // first n-tile of the workgroup
 
   const int haloItems = p.IH * p.IW * 8;  // 16-byte items: 8 per pixel (64 channels)
   const int haloPadded = (haloItems + 63) & ~63;
   char* hal = smem;
   char* wbuf = smem + (size_t)haloPadded * 16;
 
-  // this lane's pixel of each of the wave's 4 m-tiles: tile row / column, halo pixel of tap (0, 0)
-  int pl0[4], pty[4], ptx[4];
+  // this lane's pixel of each of the wave's MT m-tiles: tile row / column, halo pixel of tap (0, 0)
+  int pl0[MT], pty[MT], ptx[MT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int pp = (wm * 4 + i) * 16 + r;
+  for (int i = 0; i < MT; ++i) {
+    const int pp = (wm * MT + i) * 16 + r;
     int ty = (int)__umulhi((unsigned)pp, p.magicTW);
     int tx = pp - ty * p.TW;
-    if (ty >= p.TH) { ty = p.TH; tx = 0; }  // past the tile (TH * TW < 256): computed on halo row TH, never stored
+    if (ty >= p.TH) { ty = p.TH; tx = 0; }  // past the tile (TH * TW < BM): multiplied on halo pixel 0, never stored
     pty[i] = ty;
     ptx[i] = tx;
-    pl0[i] = (ty < p.TH ? ty : 0) * p.IW + tx;
+    pl0[i] = ty < p.TH ? (ty * STRIDE) * p.IW + tx * STRIDE : 0;
   }
 
-  f32x4 acc[4][4];
+  f32x4 acc[MT][NT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   constexpr int TAPS = KS * KS;
   const int nChunks = (p.KTT + 1) >> 1;
@@ -108,15 +110,19 @@ __global__ __launch_bounds__(512, 4) void conv_big_kernel(const BigParams p) {
       __builtin_amdgcn_global_load_lds((bgptr_t)src, (blptr_t)(hal + base * 16), 16, 0, 0);
     }
   };
-  // weight slab of (tap, chunk c) -> buffer b: fragment f = kt * 8 + j; wave w brings fragments w (kt 0) and w + 8 (kt 1)
+  // weight slab of (tap, chunk c) -> buffer b: fragment f = kt * NTB + j (f < 2 * NTB); wave w brings fragments w, w + 8, ...
   auto stage_w = [&](int c, int tap, int b) __attribute__((always_inline)) {
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      const int ktg = c * 2 + kt;
-      const int nt = ntb0 + wave;
-      const char* src = reinterpret_cast<const char*>(g_big_zero16);
-      if (ktg < p.KTT && nt < p.NTn) src = p.w + (((size_t)(tap * p.KTT + ktg) * p.NTn + nt) * 64 + lane) * 16;
-      __builtin_amdgcn_global_load_lds((bgptr_t)src, (blptr_t)(wbuf + b * BIG_WBUF + (kt * 8 + wave) * 1024), 16, 0, 0);
+    for (int f0 = 0; f0 < 2 * NTB; f0 += 8) {
+      const int f = f0 + wave;
+      if (f < 2 * NTB) {
+        const int kt = f / NTB, j = f - kt * NTB;  // NTB is a compile-time constant
+        const int ktg = c * 2 + kt;
+        const int nt = ntb0 + j;
+        const char* src = reinterpret_cast<const char*>(g_big_zero16);
+        if (ktg < p.KTT && nt < p.NTn) src = p.w + (((size_t)(tap * p.KTT + ktg) * p.NTn + nt) * 64 + lane) * 16;
+        __builtin_amdgcn_global_load_lds((bgptr_t)src, (blptr_t)(wbuf + b * WBUF + f * 1024), 16, 0, 0);
+      }
     }
   };
 
@@ -125,30 +131,31 @@ __global__ __launch_bounds__(512, 4) void conv_big_kernel(const BigParams p) {
   int buf = 0;
   for (int c = 0; c < nChunks; ++c) {
     int kh = 0, kw = 0;
+#pragma unroll 1  // nine unrolled taps let the scheduler hoist every tap's addresses: 128+ VGPRs and spills in the 96-channel variant
     for (int tap = 0; tap < TAPS; ++tap) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of slab (c, tap) (and of the halo) has landed
       __syncthreads();                                  // ... everyone's; everyone is done with the other weight buffer
       if (tap + 1 < TAPS) stage_w(c, tap + 1, buf ^ 1);
       const int tapshift = kh * p.IW + kw;
-      const char* wb = wbuf + buf * BIG_WBUF + (wn * 4) * 1024 + lane * 16;
-      int paddr[4], pswz[4];
+      const char* wb = wbuf + buf * WBUF + (wn * NT) * 1024 + lane * 16;
+      int paddr[MT], pswz[MT];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < MT; ++i) {
         const int pl = pl0[i] + tapshift;
         paddr[i] = pl * 128;
         pswz[i] = pl & 7;
       }
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) {
-        u32x4 a[4], b[4];
+        u32x4 a[NT], b[MT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const u32x4*>(wb + (kt * 8 + j) * 1024);
+        for (int j = 0; j < NT; ++j) a[j] = *reinterpret_cast<const u32x4*>(wb + (kt * NTB + j) * 1024);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) b[i] = *reinterpret_cast<const u32x4*>(hal + paddr[i] + (((kt * 4 + g) ^ pswz[i]) << 4));
+        for (int i = 0; i < MT; ++i) b[i] = *reinterpret_cast<const u32x4*>(hal + paddr[i] + (((kt * 4 + g) ^ pswz[i]) << 4));
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
+          for (int j = 0; j < NT; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a[j]),
                                                                 *reinterpret_cast<const bf16x8*>(&b[i]), acc[i][j], 0, 0, 0);
       }
@@ -164,24 +171,24 @@ __global__ __launch_bounds__(512, 4) void conv_big_kernel(const BigParams p) {
 
   // ---- epilogue from the accumulators (as conv.hip): lane (g, r) holds channels 16j + 4g .. + 3 of pixel r of m-tile i;
   // v_permlane16_swap pairs the quads of two neighbouring n-tiles so every lane stores 16 contiguous bytes
-  const int cw = (blockIdx.y * BIG_NTB + wn * 4) * 16;  // first channel of this wave
-  f32x4 biasv[4];
+  const int cw = (blockIdx.y * NTB + wn * NT) * 16;  // first channel of this wave
+  f32x4 biasv[NT];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < NT; ++j) {
     const int co = cw + j * 16 + g * 4;
     biasv[j] = (p.bias && co < p.Cout) ? *reinterpret_cast<const f32x4*>(p.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   auto epilogue = [&](auto act_tag) __attribute__((always_inline)) {
     constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MT; ++i) {
       const int oy = oy0 + pty[i], ox = ox0 + ptx[i];
       const bool pok = pty[i] < p.TH && oy < p.OH && ox < p.OW;
       const size_t pixoff = ((size_t)n * p.OH + oy) * p.OW + ox;
       char* yrow = p.y + (pixoff * p.ldy + cw) * 2;
       const char* rrow = p.res ? p.res + (pixoff * p.ldr + cw) * 2 : nullptr;
 #pragma unroll
-      for (int j = 0; j < 4; j += 2) {
+      for (int j = 0; j + 1 < NT; j += 2) {
         const int cb = 16 * (j + (g & 1)) + 8 * (g >> 1);
         float v0[4], v1[4];
 #pragma unroll
@@ -214,6 +221,21 @@ __global__ __launch_bounds__(512, 4) void conv_big_kernel(const BigParams p) {
           if (ok) *reinterpret_cast<u32x4*>(yrow + cb * 2) = u32x4{lo[0], hi[0], lo[1], hi[1]};
         }
       }
+      if constexpr (NT & 1) {  // odd tile count: the last n-tile goes out as 8-byte channel quads
+        constexpr int j = NT - 1;
+        const int cb = 16 * j + 4 * g;
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = big_act<ACT>(acc[i][j][q] + biasv[j][q]);
+        if (pok && cw + cb < p.Cout) {
+          if (p.res) {
+            const u32x2 rv = *reinterpret_cast<const u32x2*>(rrow + cb * 2);
+            v[0] += __uint_as_float(rv[0] << 16); v[1] += __uint_as_float(rv[0] & 0xFFFF0000u);
+            v[2] += __uint_as_float(rv[1] << 16); v[3] += __uint_as_float(rv[1] & 0xFFFF0000u);
+          }
+          *reinterpret_cast<u32x2*>(yrow + cb * 2) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        }
+      }
     }
   };
   if (p.act == UPA_ACT_SILU) epilogue(std::integral_constant<int, UPA_ACT_SILU>{});
@@ -228,6 +250,55 @@ namespace {
 int big_env(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
+}
+
+int big_num_cu() {
+  static int numCU = 0;
+  if (!numCU) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&numCU, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || numCU <= 0) numCU = 256;
+  }
+  return numCU;
+}
+
+// Tile shape for a BM-pixel workgroup: fewest tiles per image first (least padding waste), then the smallest halo; the
+// halo of a 64-channel chunk plus the two weight buffers must fit `lds_cap` bytes.  Returns false if nothing fits.
+bool big_pick_tile(BigParams& p, int bm, int ntb, size_t lds_cap) {
+  long best = -1;
+  for (int tw = 2; tw <= 256 && tw <= ((p.OW + 1) & ~1); ++tw) {
+    int th = bm / tw;
+    if (th > p.OH) th = p.OH;
+    if (th < 1) continue;
+    const int ih = (th - 1) * p.stride + p.KS, iw = (tw - 1) * p.stride + p.KS;
+    const size_t lds = (((size_t)ih * iw * 8 + 63) & ~(size_t)63) * 16 + 2 * (size_t)(2 * ntb * 1024) + 256;
+    if (lds > lds_cap) continue;
+    const long tiles = (long)cdiv(p.OW, tw) * cdiv(p.OH, th);
+    const long cost = tiles * 65536 + (long)ih * iw;
+    if (best < 0 || cost < best) { best = cost; p.TH = th; p.TW = tw; }
+  }
+  return best >= 0;
+}
+
+template <int KS, int STRIDE, int WM, int WN, int MT, int NT>
+int big_launch_inst(const BigParams& p, size_t lds, hipStream_t s) {
+  constexpr int NTB = WN * NT;
+  const dim3 grid((unsigned)((long)p.tilesX * p.tilesY * p.N), (unsigned)cdiv(p.NTn, NTB));
+  auto kern = conv_big_kernel<KS, STRIDE, WM, WN, MT, NT>;
+  if (hipError_t e = upa_full_lds<conv_big_kernel<KS, STRIDE, WM, WN, MT, NT>>(); e != hipSuccess) {
+    upa_set_error("conv_big: cannot raise LDS limit: %s", hipGetErrorString(e));
+    return UPA_ELAUNCH;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, p);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+template <int WM, int WN, int MT, int NT>
+int big_launch_ks(const BigParams& p, size_t lds, hipStream_t s) {
+  if (p.KS == 1) return big_launch_inst<1, 1, WM, WN, MT, NT>(p, lds, s);
+  if (p.stride == 2) return big_launch_inst<3, 2, WM, WN, MT, NT>(p, lds, s);
+  return big_launch_inst<3, 1, WM, WN, MT, NT>(p, lds, s);
 }
 }  // namespace
 
@@ -244,64 +315,58 @@ bool upa_conv_big_eligible(int n, int h, int w, int cin, int ldx, int cout, int 
                            int act, int dtype) {
   const int mode = upa_conv_big_mode(-1);
   if (mode == 0) return false;
-  if (dtype != UPA_BF16 || stride != 1 || !(k == 1 || k == 3) || pad != k / 2) return false;
+  if (dtype != UPA_BF16 || !((k == 1 && stride == 1) || (k == 3 && (stride == 1 || stride == 2))) || pad != k / 2) return false;
   if (cin % 8 != 0 || ldx % 8 != 0 || cout % 8 != 0 || ldy % 8 != 0 || ldr % 8 != 0) return false;
   if (act != UPA_ACT_SILU && act != UPA_ACT_NONE && act != UPA_ACT_RELU) return false;
   if (mode == 2) return cout >= 64;
-  // MFMA-bound layers only: both operands wide enough that sharing the weights through LDS pays, output channels a whole
-  // number of 128-channel workgroup columns
+  const int oh = (h + 2 * pad - k) / stride + 1, ow = (w + 2 * pad - k) / stride + 1;
+  const long px = (long)n * oh * ow;
+  if (k == 1) {
+    // pointwise layers stream faster through conv1x1.hip while their weight slice fits LDS; past that (512+ channels in)
+    // the weights have to be shared per tap-chunk anyway
+    return cin >= 512 && cout % 128 == 0 && px >= 2048 &&
+           !upa_conv1x1_eligible(n, h, w, cin, ldx, cout, ldy, ldr != 0, k, stride, pad, act, dtype);
+  }
+  // measured on MI355X (tools/bench_conv.py, yolov3-rtdetr bs 16 / yolov8n bs 32): 3x3 layers with >= 128 input channels and
+  // whole 128-channel output columns run at 800-1000 TFLOP/s here against 430-615 on the per-wave-weights kernel; the
+  // 80-channel class branch of Detect (96-channel variant) wins from 64 input channels at 40x40 and above
   static const int min_cin = big_env("UPA_CONV_BIG_MIN_CIN", 128);
-  if (cin < min_cin || cout % 128 != 0) return false;
-  const long px = (long)n * h * w;
-  return px >= 2048;
+  if (cout % 128 == 0) return cin >= min_cin && px >= 2048;
+  if (cout == 80 || cout == 96) return cin >= 64 && px >= 32 * 1024;
+  return false;
 }
 
 int upa_conv_big_launch(BigParams p, int query_only, int* variant, void* stream) {
-  if (variant) *variant = (1 << 23);
-  if (query_only) return UPA_OK;
   p.KTT = (p.Cin + 31) / 32;
   p.NTn = (p.Cout + 15) / 16;
+  // workgroup columns: 128 channels, 96 for Cout in (64, 96], 64 for Cout <= 64
+  const int ntb = p.NTn <= 4 ? 4 : (p.NTn <= 6 ? 6 : 8);
+  const long px = (long)p.N * p.OH * p.OW;
+  const int cols = cdiv(p.NTn, ntb);
+  // 256-pixel workgroups unless that leaves most of the chip idle (fewer workgroups than CUs): then 128-pixel ones
+  int bm = 256;
+  if (ntb != 4 && (px + 255) / 256 * cols < big_num_cu()) bm = 128;
+  if (const int f = big_env("UPA_CONV_BIG_BM", 0); f == 128 || f == 256) bm = ntb == 4 ? 256 : f;
+  if (variant) *variant = (1 << 23) | (ntb << 4) | (bm >> 7);
+  if (query_only) return UPA_OK;
   if (p.KS == 1) {  // pointwise: an NHWC view has one uniform pixel stride - flatten (n, h, w) into one row
-    const long P = (long)p.N * p.H * p.W;
-    p.N = 1; p.H = 1; p.W = (int)P; p.OH = 1; p.OW = (int)P;
-    p.TH = 1; p.TW = BIG_BM;
-  } else {
-    // tile shape: TH x TW <= 256 pixels; fewest tiles per image first (least padding waste), then the smallest halo
-    long best = -1;
-    int bTH = 16, bTW = 16;
-    for (int tw = 4; tw <= 128 && tw <= ((p.OW + 3) & ~3); ++tw) {
-      int th = BIG_BM / tw;
-      if (th > p.OH) th = p.OH;
-      if (th < 1) continue;
-      const long tiles = (long)cdiv(p.OW, tw) * cdiv(p.OH, th);
-      const long halo = (long)(th + 2) * (tw + 2);
-      const long cost = tiles * 4096 + halo;
-      if (best < 0 || cost < best) { best = cost; bTH = th; bTW = tw; }
-    }
-    p.TH = bTH; p.TW = bTW;
+    p.N = 1; p.H = 1; p.W = (int)px; p.OH = 1; p.OW = (int)px;
+    p.TH = 1; p.TW = bm;
+  } else if (!big_pick_tile(p, bm, ntb, 80 * 1024 - 512) && !big_pick_tile(p, bm, ntb, 160 * 1024)) {
+    // (first try: two workgroups per CU; stride-2 halos may need the whole LDS)
+    return UPA_EUNSUPPORTED;
   }
   p.tilesX = cdiv(p.OW, p.TW);
   p.tilesY = cdiv(p.OH, p.TH);
-  p.IH = p.TH + p.KS - 1;
-  p.IW = p.TW + p.KS - 1;
+  p.IH = (p.TH - 1) * p.stride + p.KS;
+  p.IW = (p.TW - 1) * p.stride + p.KS;
   p.magicTW = (unsigned)((0x100000000ULL + p.TW - 1) / p.TW);
   p.magicIW = (unsigned)((0x100000000ULL + p.IW - 1) / p.IW);
-  // pixels past the tile read halo row TH (allocated: IH >= TH + 1 for k = 3; one extra row for k = 1)
-  const int rows = p.KS == 1 ? 2 : p.IH;
-  const size_t halo = (((size_t)rows * p.IW * 8 + 63) & ~(size_t)63) * 16;
-  const size_t lds = halo + 2 * (size_t)BIG_WBUF + 256;
+  const size_t halo = (((size_t)p.IH * p.IW * 8 + 63) & ~(size_t)63) * 16;
+  const size_t lds = halo + 2 * (size_t)(2 * ntb * 1024) + 256;
   if (lds > 160 * 1024) return UPA_EUNSUPPORTED;
-  const dim3 grid((unsigned)((long)p.tilesX * p.tilesY * p.N), (unsigned)cdiv(p.NTn, BIG_NTB));
   hipStream_t s = (hipStream_t)stream;
-  if (p.KS == 1) {
-    auto kern = conv_big_kernel<1>;
-    if (hipError_t e = upa_full_lds<conv_big_kernel<1>>(); e != hipSuccess) return UPA_ELAUNCH;
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, p);
-  } else {
-    auto kern = conv_big_kernel<3>;
-    if (hipError_t e = upa_full_lds<conv_big_kernel<3>>(); e != hipSuccess) return UPA_ELAUNCH;
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, p);
-  }
-  UPA_LAUNCH_CHECK();
-  return UPA_OK;
+  if (ntb == 8) return bm == 256 ? big_launch_ks<4, 2, 4, 4>(p, lds, s) : big_launch_ks<4, 2, 2, 4>(p, lds, s);
+  if (ntb == 6) return bm == 256 ? big_launch_ks<4, 2, 4, 3>(p, lds, s) : big_launch_ks<4, 2, 2, 3>(p, lds, s);
+  return big_launch_ks<8, 1, 2, 4>(p, lds, s);
 }

@@ -38,7 +38,7 @@ bool upa_conv1x1_eligible(int n, int h, int w, int cin, int ldx, int cout, int l
 // variant (if non-null) receives (1 << 22) | waves << 8 | MT << 4 | NTW; query_only = 1 skips the launch
 int upa_conv1x1_launch(C1Params p, int n_pixels, int query_only, int* variant, void* stream);
 
-// ---- conv_big.hip: large-tile implicit GEMM with both operands shared through LDS (bf16, stride 1, k = 1 | 3, MFMA-bound layers)
+// ---- conv_big.hip: large-tile implicit GEMM with both operands shared through LDS (bf16, k 1 | 3, stride 1 | 2)
 struct BigParams {
   const char* x;
   char* y;
@@ -46,7 +46,7 @@ struct BigParams {
   const char* w;       // packed [tap][ktile][ntile][lane][16 B] (upa_pack_conv_weight)
   const float* bias;
   int N, H, W, Cin, ldx, OH, OW, Cout, ldy, ldr;
-  int KS, pad;
+  int KS, stride, pad;
   int TH, TW, tilesX, tilesY, IH, IW;
   int KTT, NTn;
   int act;
@@ -54,5 +54,5 @@ struct BigParams {
 };
 bool upa_conv_big_eligible(int n, int h, int w, int cin, int ldx, int cout, int ldy, int ldr, int k, int stride, int pad,
                            int act, int dtype);
-// variant (if non-null) receives (1 << 23); query_only = 1 skips the launch
+// variant (if non-null) receives (1 << 23) | n-tiles per workgroup << 4 | pixels per workgroup / 128; query_only = 1 skips the launch
 int upa_conv_big_launch(BigParams p, int query_only, int* variant, void* stream);

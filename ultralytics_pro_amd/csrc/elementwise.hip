@@ -358,3 +358,90 @@ extern "C" int upa_nhwc_to_nchw(const void* x, int n, int h, int w, int c, int l
   UPA_LAUNCH_CHECK();
   return UPA_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LetterBox on uint8 HWC frames (ultralytics/data/augment.py:1544-1700, the predictor's pre_transform,
+// engine/predictor.py:151-173): bilinear resize to (new_h, new_w) + constant border, one pass, one thread per output pixel.
+// The resize is OpenCV's 8-bit INTER_LINEAR fixed-point arithmetic (imgproc/src/resize.cpp: coefficients
+// saturate_cast<short>(w * 2048), horizontal pass in int, vertical pass ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16)
+// + 2) >> 2), restated in oracle/letterbox.py; integer results are bit-exact against that oracle.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+struct LetterboxParams {
+  const unsigned char* src;
+  unsigned char* dst;
+  long src_image_stride;  // bytes
+  int src_row_stride;     // bytes
+  int h0, w0, H, W, new_h, new_w, top, left, pad;
+  int resize;             // 0: the unpadded size equals the source size (copy)
+  double scale_x, scale_y;
+};
+
+__device__ __forceinline__ void lb_coeff(int d, double scale, int ssize, bool pin, int& s0, int& s1, int& c0, int& c1) {
+  float f = (float)(((double)d + 0.5) * scale - 0.5);
+  int s = (int)floorf(f);
+  f -= (float)s;
+  if (pin) {  // horizontal set-up: index pinned AND fraction dropped at the borders
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
+    s0 = s;
+    s1 = s + 1 < ssize ? s + 1 : ssize - 1;
+  } else {    // vertical: fraction kept, rows clipped into the image
+    s0 = s < 0 ? 0 : (s > ssize - 1 ? ssize - 1 : s);
+    s1 = s + 1 < 0 ? 0 : (s + 1 > ssize - 1 ? ssize - 1 : s + 1);
+  }
+  const float w0 = rintf((1.f - f) * 2048.f), w1 = rintf(f * 2048.f);
+  c0 = (int)fminf(fmaxf(w0, -32768.f), 32767.f);
+  c1 = (int)fminf(fmaxf(w1, -32768.f), 32767.f);
+}
+
+__global__ __launch_bounds__(256) void letterbox_u8_kernel(const LetterboxParams p) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= p.W || y >= p.H) return;
+  unsigned char* o = p.dst + ((size_t)blockIdx.z * p.H + y) * (size_t)p.W * 3 + (size_t)x * 3;
+  const int dx = x - p.left, dy = y - p.top;
+  if (dx < 0 || dx >= p.new_w || dy < 0 || dy >= p.new_h) {
+    o[0] = o[1] = o[2] = (unsigned char)p.pad;
+    return;
+  }
+  const unsigned char* img = p.src + (size_t)blockIdx.z * p.src_image_stride;
+  if (!p.resize) {
+    const unsigned char* s = img + (size_t)dy * p.src_row_stride + dx * 3;
+    o[0] = s[0]; o[1] = s[1]; o[2] = s[2];
+    return;
+  }
+  int x0, x1, a0, a1, y0, y1, b0, b1;
+  lb_coeff(dx, p.scale_x, p.w0, true, x0, x1, a0, a1);
+  lb_coeff(dy, p.scale_y, p.h0, false, y0, y1, b0, b1);
+  const unsigned char* r0 = img + (size_t)y0 * p.src_row_stride;
+  const unsigned char* r1 = img + (size_t)y1 * p.src_row_stride;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int s0 = r0[x0 * 3 + c] * a0 + r0[x1 * 3 + c] * a1;
+    const int s1 = r1[x0 * 3 + c] * a0 + r1[x1 * 3 + c] * a1;
+    int v = (((b0 * (s0 >> 4)) >> 16) + ((b1 * (s1 >> 4)) >> 16) + 2) >> 2;
+    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    o[c] = (unsigned char)v;
+  }
+}
+}  // namespace
+
+extern "C" int upa_letterbox_u8(const void* src, int n, int h0, int w0, long src_image_stride, int src_row_stride, void* dst,
+                                int H, int W, int new_h, int new_w, int top, int left, int pad_value, void* stream) {
+  UPA_CHECK_ARG(src && dst && n > 0 && h0 > 0 && w0 > 0 && H > 0 && W > 0, "letterbox_u8: bad args");
+  UPA_CHECK_ARG(new_h > 0 && new_w > 0 && top >= 0 && left >= 0 && top + new_h <= H && left + new_w <= W,
+                "letterbox_u8: the resized frame does not fit the output");
+  UPA_CHECK_ARG(pad_value >= 0 && pad_value <= 255 && src_row_stride >= w0 * 3, "letterbox_u8: bad pad value / row stride");
+  LetterboxParams p;
+  p.src = (const unsigned char*)src; p.dst = (unsigned char*)dst;
+  p.src_image_stride = src_image_stride; p.src_row_stride = src_row_stride;
+  p.h0 = h0; p.w0 = w0; p.H = H; p.W = W; p.new_h = new_h; p.new_w = new_w; p.top = top; p.left = left; p.pad = pad_value;
+  p.resize = !(new_h == h0 && new_w == w0);
+  p.scale_x = 1.0 / ((double)new_w / (double)w0);  // resize.cpp: scale = 1. / inv_scale, inv_scale = dsize / ssize
+  p.scale_y = 1.0 / ((double)new_h / (double)h0);
+  hipLaunchKernelGGL(letterbox_u8_kernel, dim3((unsigned)cdiv(W, 64), (unsigned)cdiv(H, 4), (unsigned)n), dim3(256), 0,
+                     (hipStream_t)stream, p);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
