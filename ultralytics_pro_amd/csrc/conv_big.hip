@@ -327,12 +327,16 @@ bool upa_conv_big_eligible(int n, int h, int w, int cin, int ldx, int cout, int 
     return cin >= 512 && cout % 128 == 0 && px >= 2048 &&
            !upa_conv1x1_eligible(n, h, w, cin, ldx, cout, ldy, ldr != 0, k, stride, pad, act, dtype);
   }
-  // measured on MI355X (tools/bench_conv.py, yolov3-rtdetr bs 16 / yolov8n bs 32): 3x3 layers with >= 128 input channels and
-  // whole 128-channel output columns run at 800-1000 TFLOP/s here against 430-615 on the per-wave-weights kernel; the
-  // 80-channel class branch of Detect (96-channel variant) wins from 64 input channels at 40x40 and above
-  static const int min_cin = big_env("UPA_CONV_BIG_MIN_CIN", 128);
-  if (cout % 128 == 0) return cin >= min_cin && px >= 2048;
-  if (cout == 80 || cout == 96) return cin >= 64 && px >= 32 * 1024;
+  // measured on MI355X (tools/bench_conv.py, yolov3-rtdetr bs 16 / yolov8n bs 32, round 2): 3x3 layers with whole 128-channel
+  // output columns run at 800-1000 TFLOP/s here against 430-615 on the per-wave-weights kernel; the 80-channel class
+  // branch of Detect (96-channel variant: 64->80 @80x80 45.6 -> 33.7 us, 128->80 @40x40 31.7 -> 19.9, 256->80 @20x20
+  // 31.7 -> 25.8) and the 64-channel layers (64->64 @40x40 13.3 -> 11.5 us, @80x80 31.5 -> 27.9, 64->128 stride 2 @80x80
+  // 27.5 -> 21.4) win from 64 input channels; narrower inputs (32->64) and 1x1 layers stay where they are
+  static const int min_cin = big_env("UPA_CONV_BIG_MIN_CIN", 64);
+  if (cin < min_cin || px < 8192) return false;
+  if (cout % 128 == 0) return stride == 2 || cin >= 128 || px >= 200 * 1024;
+  if (cout == 80 || cout == 96) return stride == 1;
+  if (cout == 64) return stride == 1;
   return false;
 }
 

@@ -17,8 +17,15 @@ import torch
 
 
 class PipelinedRunner:
-    def __init__(self, model, example: torch.Tensor, post=None, micro_batches: int = 2, in_flight: int = 2, priority: int = 0,
+    """`example` may be ONE resident input batch or a LIST of distinct resident batches: every batch gets its own compiled
+    copy of the step (graph + static buffers) and the copies are replayed round-robin on `in_flight` lane streams.  With
+    >= 8 distinct 78.6 MB batches the inputs (629 MB) exceed the 256 MB Infinity Cache, so the input read of a step is a
+    real HBM read and not a replay of one cache-resident batch."""
+
+    def __init__(self, model, example, post=None, micro_batches: int = 2, in_flight: int = 2, priority: int = 0,
                  sub_priority: int = 0, linear: bool = False):
+        examples = list(example) if isinstance(example, (list, tuple)) else [example]
+        example = examples[0]
         self.model, self.example, self.post = model, example, post
         self.micro_batches, self.in_flight, self.priority = micro_batches, max(1, in_flight), priority
         self.device = example.device
@@ -31,21 +38,22 @@ class PipelinedRunner:
             det.concurrent = False
         try:
             with torch.no_grad():
-                self.runs = [model.compile(example, post=post, micro_batches=micro_batches, stream_priority=sub_priority)
-                             for _ in range(self.in_flight)]
+                ncopies = max(self.in_flight, len(examples))
+                self.runs = [model.compile(examples[j % len(examples)], post=post, micro_batches=micro_batches,
+                                           stream_priority=sub_priority) for j in range(ncopies)]
         finally:
             if self.linear and saved is not None:
                 det.concurrent = saved
         # lane streams; `priority` (0 normal, -1 high) selects the runtime's queue set for them
-        self.lanes = [torch.cuda.Stream(device=self.device, priority=priority) for _ in self.runs]
+        self.lanes = [torch.cuda.Stream(device=self.device, priority=priority) for _ in range(self.in_flight)]
         self.i = 0
 
     def step(self):
         """Enqueue one batch; returns the (static) result object of the copy that ran it - valid after a synchronize."""
-        k = self.i % self.in_flight
+        j = self.i % len(self.runs)
         self.i += 1
-        with torch.cuda.stream(self.lanes[k]):
-            return self.runs[k]()
+        with torch.cuda.stream(self.lanes[j % self.in_flight]):
+            return self.runs[j]()
 
     def results(self):
         return [r.result for r in self.runs]

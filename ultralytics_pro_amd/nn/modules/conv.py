@@ -183,7 +183,8 @@ class Conv(nn.Module, _HipConvMixin):
         if self.training:
             raise L.UpaError("training-mode Conv (batch-statistics BN) is not on the HIP path yet (SURVEY §8f rank 2)")
         stem = _is_model_input(x, self.conv.in_channels)
-        dt = (self.compute_dtype or x.dtype) if stem else x.dtype
+        # raw uint8 frames with no compute dtype chosen: float32 activations (the reference's `im.float()`, predictor.py:169)
+        dt = (self.compute_dtype or (torch.float32 if x.dtype == torch.uint8 else x.dtype)) if stem else x.dtype
         pk = self._packed(self.conv, getattr(self, "bn", None), x.device, dt, stem)
         return hip_conv2d(x, pk, self.conv.stride[0], self.conv.padding[0], self._act_code(), out=out, residual=residual,
                           out_dtype=dt, key=(id(self), "y"))

@@ -77,9 +77,12 @@ class Detect(nn.Module, _HipConvMixin):
 
     def _tail(self, seq: nn.Sequential, x: torch.Tensor, raw: torch.Tensor | None, kind: int, i: int, plan) -> None:
         """conv3x3 -> conv3x3 -> [1x1 + decode] of one branch (kind 1 = box, 2 = class) of level i."""
-        t = seq[1](seq[0](x))
-        cout = 4 * self.reg_max if kind == 1 else self._ncp(x.dtype)
-        pk = self._packed(seq[2], None, x.device, x.dtype, False, pad_cout=cout)
+        self._tail_call(seq[1](seq[0](x)), seq[2], raw, kind, i, plan)
+
+    def _tail_call(self, t: torch.Tensor, conv: nn.Conv2d, raw, kind: int, i: int, plan) -> None:
+        """The fused launch itself: t = the branch's second 3x3 output, conv = its final nn.Conv2d."""
+        cout = 4 * self.reg_max if kind == 1 else self._ncp(t.dtype)
+        pk = self._packed(conv, None, t.device, t.dtype, False, pad_cout=cout)
         vt = R.view_of(t)
         rp, rld = (None, 0)
         if raw is not None:
@@ -87,7 +90,7 @@ class Detect(nn.Module, _HipConvMixin):
             rp, rld = vr.ptr, vr.ld
         L.check(L.lib().upa_detect_tail(vt.ptr, vt.n, vt.h, vt.w, vt.c, vt.ld, pk.w.data_ptr(), pk.bias.data_ptr(), cout, kind,
                                         self.nc, float(self.stride[i]), plan["y"].data_ptr(), plan["a_total"], plan["a0"][i],
-                                        rp, rld, vt.dtype, L.current_stream(x.device)), "detect_tail")
+                                        rp, rld, vt.dtype, L.current_stream(t.device)), "detect_tail")
 
     def _branch(self, seq: nn.Sequential, x: torch.Tensor, out: torch.Tensor) -> None:
         t = seq[1](seq[0](x))
