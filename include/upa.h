@@ -177,6 +177,14 @@ int upa_box_iou(const float* box1, int n, const float* box2, int m, float eps, f
  * rows: n rows of `row_stride` floats, the box in the first 4.                              utils/ops.py:102-178 */
 int upa_scale_boxes(float* rows, long n, int row_stride, float gain, float pad_x, float pad_y, int padding, float w0,
                     float h0, void* stream);
+/* True-positive matrices of a whole batch: match_predictions (engine/validator.py:267-308, non-scipy branch) through
+ * DetectionValidator._process_batch (models/yolo/detect/val.py:274-288) on the fixed-shape NMS outputs - det (b, max_det, 6)
+ * rows [x1,y1,x2,y2,conf,cls] with counts (b,), gt (b, max_gt, 5) rows [cls,x1,y1,x2,y2] with ngt (b,) - at the n_thr = 10
+ * IoU thresholds (a HOST array; torch.linspace(0.5, 0.95, 10), val.py:59).  tp: (b, max_det, 10) bytes, rows past counts
+ * are zero.  IoU as utils/metrics.py:54-74. */
+int upa_match_predictions(const float* det, const int* counts, int b, int max_det, const float* gt, const int* ngt, int max_gt,
+                          const float* iou_thresholds, int n_thr, unsigned char* tp, void* stream);
+
 
 /* ---- training step (BASELINE config 3) ------------------------------------------------------------
  * What the reference gets from torch autograd around Conv = conv2d -> BatchNorm2d(batch statistics) -> SiLU

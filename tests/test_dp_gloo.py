@@ -134,3 +134,62 @@ def test_bench_gpus_flag_launches_ranks_itself():
         rec = json.loads(lines[0])
         assert rec["n_gpus"] == 2 and rec["config"]["parallelism"] == "dp2" and rec["config"]["global_batch"] == 64
         assert rec["ms_per_step"] >= 2.0  # the slower rank (2 ms per step) sets the time
+
+
+def _validator_rank(rank, world, port, golden, q):
+    import os
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    from ultralytics_pro_amd.engine.validator import DetectionValidator
+    G = np.load(golden)
+    v = DetectionValidator()
+    per = 4 // world
+    for i in range(rank * per, (rank + 1) * per):  # this rank's shard of the 4 golden images, one image per "batch"
+        det = torch.from_numpy(G[f"det{i}"])[None]
+        n = det.shape[1]
+        out = torch.zeros(1, 300, 6)
+        out[:, :n] = det
+        gcls = torch.from_numpy(G[f"gt_cls{i}"])
+        # GPU-free stand-in for the matching kernel: the reference's own TP matrix of this image
+        v._det.append(out)
+        v._cnt.append(torch.tensor([n], dtype=torch.int32))
+        tp = torch.zeros(1, 300, 10, dtype=torch.uint8)
+        tp[0, :n] = torch.from_numpy(G[f"tp{i}"].astype(np.uint8))
+        v._tp.append(tp)
+        g = torch.zeros(1, 64)
+        g[0, : gcls.shape[0]] = gcls
+        v._gt.append(g)
+        v._ngt.append(torch.tensor([gcls.shape[0]], dtype=torch.int32))
+    st = v.get_stats()
+    q.put((rank, st["mean"], st["ap"].tolist(), int(st["tp"].shape[0])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_validator_stats_gather_two_ranks_matches_reference_map(golden_dir):
+    """End-of-validation path across ranks (models/yolo/detect/val.py:222-240): every rank holds the statistics of its
+    image shard, `gather_stats` all-gathers the fixed-shape tensors (gloo here, RCCL on the GPUs) and EVERY rank computes
+    the reference's class metrics from the union: mAP / AP table equal tests/golden/map_yolov8n.npz bit for bit."""
+    import socket
+    import numpy as np
+    import torch.multiprocessing as mp
+    G = np.load(golden_dir / "map_yolov8n.npz")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_validator_rank, args=(r, 2, port, str(golden_dir / "map_yolov8n.npz"), q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p_ in procs:
+        p_.join(timeout=60)
+        assert p_.exitcode == 0
+    for rank, mean, ap, nrows in res:
+        assert nrows == sum(G[f"det{i}"].shape[0] for i in range(4))
+        assert np.array_equal(np.asarray(ap), G["ap"]), rank
+        assert np.allclose(mean, G["mean"], rtol=0, atol=1e-12), rank

@@ -76,3 +76,44 @@ def test_hip_pipeline_map_matches_reference(G):
     got = np.array(pmet.mean_results(p, r, ap))
     print("HIP mAP:", got, "reference:", G["mean"])
     assert np.abs(got - G["mean"]).max() <= 5e-3
+
+
+@pytest.mark.gpu
+def test_validator_single_rank_equals_reference_map(G):
+    """engine.validator.DetectionValidator on one GPU: model -> val-mode NMS -> batched matching kernel -> statistics ->
+    class metrics, one batch of 4 images and the same images as two batches of 2: the TP matrices equal the reference's
+    for its own detections, and the pipeline's mAP equals tests/golden/map_yolov8n.npz."""
+    from tests.hip_utils import DEV
+    from ultralytics_pro_amd.engine.validator import DetectionValidator
+    from ultralytics_pro_amd.nn.tasks import DetectionModel
+    from ultralytics_pro_amd.utils import metrics as pmet
+    # (1) the kernel on the reference's own detections: TP matrices bit for bit, batched with ragged label counts
+    det = torch.zeros(4, 300, 6)
+    gt = torch.zeros(4, 64, 5)
+    cnt, ngt = [], []
+    for i in range(4):
+        d, gb, gc = torch.from_numpy(G[f"det{i}"]), torch.from_numpy(G[f"gt_boxes{i}"]), torch.from_numpy(G[f"gt_cls{i}"])
+        det[i, : d.shape[0]] = d
+        gt[i, : gc.shape[0], 0] = gc
+        gt[i, : gc.shape[0], 1:] = gb
+        cnt.append(d.shape[0]); ngt.append(gc.shape[0])
+    tp = pmet.match_predictions_batched(det.to(DEV), torch.tensor(cnt, dtype=torch.int32, device=DEV), gt.to(DEV),
+                                        torch.tensor(ngt, dtype=torch.int32, device=DEV)).cpu().numpy().astype(bool)
+    for i in range(4):
+        assert np.array_equal(tp[i, : cnt[i]], G[f"tp{i}"]) and not tp[i, cnt[i]:].any()
+    # (2) the whole validate path
+    m = DetectionModel("yolov8n.yaml")
+    P.apply_procedural_weights(m)
+    m = m.to(DEV).eval()
+    x = P.synthetic_images(4).to(DEV)
+    gtd, ngd = gt.to(DEV), torch.tensor(ngt, dtype=torch.int32, device=DEV)
+    for split in ((0, 4),), ((0, 2), (2, 4)):
+        v = DetectionValidator(m)
+        with torch.no_grad():
+            for a, b in split:
+                v.update(m(x[a:b].contiguous()), gtd[a:b].contiguous(), ngd[a:b].contiguous())
+        st = v.get_stats()
+        got = np.array(st["mean"])
+        print("validator mAP:", got, "reference:", G["mean"])
+        assert np.abs(got - G["mean"]).max() <= 5e-3
+        assert st["tp"].shape[0] == sum(cnt)

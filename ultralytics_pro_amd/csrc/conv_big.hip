@@ -333,8 +333,9 @@ bool upa_conv_big_eligible(int n, int h, int w, int cin, int ldx, int cout, int 
   // 31.7 -> 25.8) and the 64-channel layers (64->64 @40x40 13.3 -> 11.5 us, @80x80 31.5 -> 27.9, 64->128 stride 2 @80x80
   // 27.5 -> 21.4) win from 64 input channels; narrower inputs (32->64) and 1x1 layers stay where they are
   static const int min_cin = big_env("UPA_CONV_BIG_MIN_CIN", 64);
-  if (cin < min_cin || px < 8192) return false;
-  if (cout % 128 == 0) return stride == 2 || cin >= 128 || px >= 200 * 1024;
+  if (cin < min_cin || px < 2048) return false;
+  if (cout % 128 == 0) return cin >= 128 || (px >= 8192 && (stride == 2 || px >= 200 * 1024));
+  if (px < 8192) return false;
   if (cout == 80 || cout == 96) return stride == 1;
   if (cout == 64) return stride == 1;
   return false;

@@ -81,7 +81,7 @@ def autotune(model, example, post=None, candidates=((4, 1, 0, 1), (2, 2, -1, 0),
         in_flight, mb = cand[0], cand[1]
         prio = cand[2] if len(cand) > 2 else 0
         linear = bool(cand[3]) if len(cand) > 3 else False
-        if example.shape[0] % mb:
+        if (example[0] if isinstance(example, (list, tuple)) else example).shape[0] % mb:
             continue
         _trace(f"candidate {cand}: compile")
         r = PipelinedRunner(model, example, post, micro_batches=mb, in_flight=in_flight, priority=prio, linear=linear)

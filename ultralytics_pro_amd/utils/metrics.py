@@ -1,10 +1,10 @@
 """Detection validation metrics with the reference's function names (ultralytics/utils/metrics.py,
 engine/validator.py:267-308, models/yolo/detect/val.py:274-288).
 
-The pairwise IoU matrix is the only device work (`upa_box_iou`); the greedy IoU matching and the AP integration are
-small host-side numpy code in the reference as well (it calls `.cpu().numpy()` first), and are written here against
-numpy the same way.  `DetMetrics.process()`'s numbers (P, R, mAP50, mAP50-95) are reproduced by `ap_per_class` +
-`mean_results`.
+IoU and the greedy prediction-to-label matching run on the GPU for a whole batch at once (`upa_match_predictions` on the
+fixed-shape NMS outputs: no per-image host round trip); what remains on the host is what the reference's `DetMetrics.process`
+does on the host too - the per-class cumulative sums and the 101-point AP integration over a few thousand rows, once per
+validation run (`ap_per_class` + `mean_results` reproduce P, R, mAP50, mAP50-95 bit for bit).
 """
 
 from __future__ import annotations
@@ -30,30 +30,34 @@ def box_iou(box1: torch.Tensor, box2: torch.Tensor, eps: float = 1e-7) -> torch.
 IOUV = np.linspace(0.5, 0.95, 10).astype(np.float32)  # torch.linspace(0.5, 0.95, 10), detect/val.py:59
 
 
-def match_predictions(pred_classes: torch.Tensor, true_classes: torch.Tensor, iou: torch.Tensor, iouv=IOUV) -> np.ndarray:
-    """Greedy one-to-one matching of predictions to labels at 10 IoU thresholds -> (N, 10) bool
-    (engine/validator.py:267-308, default non-scipy branch)."""
-    pc = pred_classes.detach().cpu().numpy()
-    tc = true_classes.detach().cpu().numpy()
-    m = iou.detach().cpu().numpy() * (tc[:, None] == pc[None, :])
-    correct = np.zeros((pc.shape[0], len(iouv)), dtype=bool)
-    for k, thr in enumerate([float(t) for t in iouv]):
-        lab, det = np.nonzero(m >= thr)
-        if lab.size:
-            pairs = np.stack([lab, det], 1)
-            if pairs.shape[0] > 1:
-                pairs = pairs[m[pairs[:, 0], pairs[:, 1]].argsort()[::-1]]
-                pairs = pairs[np.unique(pairs[:, 1], return_index=True)[1]]
-                pairs = pairs[np.unique(pairs[:, 0], return_index=True)[1]]
-            correct[pairs[:, 1].astype(int), k] = True
-    return correct
+def match_predictions_batched(det: torch.Tensor, counts: torch.Tensor, gt: torch.Tensor, ngt: torch.Tensor, iouv=IOUV,
+                              out: torch.Tensor | None = None) -> torch.Tensor:
+    """True-positive matrices of a whole batch on the GPU (`upa_match_predictions`): det (B, max_det, 6) + counts (B,) as
+    `nms_raw` returns them, gt (B, max_gt, 5) rows [cls, x1, y1, x2, y2] + ngt (B,) -> (B, max_det, 10) uint8, no host sync
+    (engine/validator.py:267-308 through models/yolo/detect/val.py:274-288)."""
+    L.require_gpu(det, "match_predictions")
+    b, max_det, _ = det.shape
+    thr = np.ascontiguousarray(np.asarray(iouv, dtype=np.float32))
+    tp = out if out is not None else torch.empty((b, max_det, thr.shape[0]), dtype=torch.uint8, device=det.device)
+    L.check(L.lib().upa_match_predictions(det.data_ptr(), counts.data_ptr(), b, max_det, gt.data_ptr(), ngt.data_ptr(),
+                                          int(gt.shape[1]), thr.ctypes.data, int(thr.shape[0]), tp.data_ptr(),
+                                          L.current_stream(det.device)), "match_predictions")
+    return tp
 
 
 def process_batch(pred_boxes: torch.Tensor, pred_cls: torch.Tensor, gt_boxes: torch.Tensor, gt_cls: torch.Tensor) -> np.ndarray:
-    """True-positive matrix of one image (detect/val.py:274-288)."""
-    if gt_cls.shape[0] == 0 or pred_cls.shape[0] == 0:
-        return np.zeros((pred_cls.shape[0], len(IOUV)), dtype=bool)
-    return match_predictions(pred_cls, gt_cls, box_iou(gt_boxes, pred_boxes))
+    """True-positive matrix of one image (detect/val.py:274-288) - the single-image form of `match_predictions_batched`."""
+    n, m = int(pred_cls.shape[0]), int(gt_cls.shape[0])
+    if m == 0 or n == 0:
+        return np.zeros((n, len(IOUV)), dtype=bool)
+    dev = pred_boxes.device
+    det = torch.zeros((1, n, 6), dtype=torch.float32, device=dev)
+    det[0, :, :4] = pred_boxes.float()
+    det[0, :, 5] = pred_cls.float()
+    gt = torch.cat([gt_cls.float().view(1, m, 1), gt_boxes.float().view(1, m, 4)], 2).contiguous()
+    cnt = torch.tensor([n], dtype=torch.int32, device=dev)
+    ng = torch.tensor([m], dtype=torch.int32, device=dev)
+    return match_predictions_batched(det, cnt, gt, ng)[0].cpu().numpy().astype(bool)
 
 
 def smooth(y: np.ndarray, f: float = 0.05) -> np.ndarray:
