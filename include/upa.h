@@ -52,6 +52,14 @@ int upa_conv_variant(int n, int h, int w, int cin, int cout, int k, int stride, 
  * 2 = every shape it can run (parity tests / per-layer benchmarks).  Returns the previous mode; mode < 0 only queries. */
 int upa_conv_big_mode(int mode);
 
+/* Bottleneck as one kernel (nn/modules/block.py:644-668 with k = (3, 3), e = 1.0 as C2f builds it, block.py:475):
+ * y = [x +] SiLU(conv3x3(SiLU(conv3x3(x, w1) + b1), w2) + b2), C -> C -> C channels, BN folded, the intermediate tile kept
+ * in LDS (csrc/conv_pair.hip).  x / y: NHWC views (n, h, w, c) with row strides ldx / ldy (channel slices of a C2f concat
+ * buffer).  Returns UPA_EUNSUPPORTED outside the fused form (bf16, SiLU, c = 32 | 64): the caller then runs two
+ * upa_conv2d_bias_act launches. */
+int upa_bottleneck_pair(const void* x, int n, int h, int w, int c, int ldx, const void* w1_packed, const float* b1,
+                        const void* w2_packed, const float* b2, void* y, int ldy, int residual, int act, int dtype, void* stream);
+
 
 /* First layer: reads the model input NCHW (f32 or bf16, 1..4 channels) directly, writes NHWC.   conv.py:188-197
  * w = device copy of the upa_pack_stem_weight output ([tap][ci][cout padded to 16] f32), bias f32[cout] on the device. */

@@ -42,19 +42,54 @@ class TrainState:
         self.updates = 0
 
 
-def train_step(model, state, batch, hyp=HYP, world_size=1):
-    """Returns (loss_items (3,), grad total norm before clipping). model is updated in place; grads left on .grad."""
+SCHED = dict(nbs=64, warmup_epochs=3.0, warmup_momentum=0.8, warmup_bias_lr=0.1, lrf=0.01, epochs=100)
+
+
+def schedule(ni, nb, global_batch, hyp=HYP, sched=SCHED, epoch=None):
+    """Warm-up and accumulation state of iteration `ni` (trainer.py:337-338, 392-413): returns (accumulate, lr per group in
+    the optimizer's order [biases, decayed weights, norm weights], momentum, weight_decay).
+    nw = max(round(warmup_epochs * nb), 100); ni <= nw: accumulate = max(1, round(interp(ni, [0, nw], [1, nbs / batch])));
+    group 0 (biases) lr falls from warmup_bias_lr to lr0 * lf(epoch), the others rise from 0; momentum rises from
+    warmup_momentum; lf = linear 1 -> lrf over the epochs (trainer.py:245); weight_decay * batch * accumulate0 / nbs."""
+    import numpy as np
+    acc0 = max(round(sched["nbs"] / global_batch), 1)
+    wd = hyp["weight_decay"] * global_batch * acc0 / sched["nbs"]
+    epoch = ni // nb if epoch is None else epoch
+    lf = max(1 - epoch / sched["epochs"], 0) * (1.0 - sched["lrf"]) + sched["lrf"]
+    nw = max(round(sched["warmup_epochs"] * nb), 100) if sched["warmup_epochs"] > 0 else -1
+    lr = hyp["lr"] * lf
+    if ni <= nw:
+        xi = [0, nw]
+        acc = max(1, int(np.interp(ni, xi, [1, sched["nbs"] / global_batch]).round()))
+        lrs = [float(np.interp(ni, xi, [sched["warmup_bias_lr"] if j == 0 else 0.0, lr])) for j in range(3)]
+        mom = float(np.interp(ni, xi, [sched["warmup_momentum"], hyp["momentum"]]))
+        return acc, lrs, mom, wd
+    return acc0, [lr, lr, lr], hyp["momentum"], wd
+
+
+def train_step(model, state, batch, hyp=HYP, world_size=1, lrs=None, momentum=None, weight_decay=None, optimize=True,
+               zero_grad=True):
+    """Returns (loss_items (3,), grad total norm before clipping). model is updated in place; grads left on .grad.
+    lrs / momentum / weight_decay override the constants of `hyp` (warm-up); optimize=False only accumulates gradients
+    (trainer.py:430: the optimizer steps every `accumulate` iterations), zero_grad=False keeps the gradients of the
+    previous iteration(s) so that this backward adds to them."""
     model.train()
-    for p in model.parameters():
-        p.grad = None
+    if zero_grad:
+        for p in model.parameters():
+            p.grad = None
     feats = model(batch["img"])
     loss, items = v8_detection_loss(feats, batch, model.stride, nc=model.model[-1].nc)
     (loss.sum() * world_size).backward()
+    if not optimize:
+        return items, float("nan")
+    lrs = [hyp["lr"]] * 3 if lrs is None else lrs
+    mom = hyp["momentum"] if momentum is None else momentum
+    wd0 = hyp["weight_decay"] if weight_decay is None else weight_decay
     params = [p for p in model.parameters() if p.grad is not None]
     total_norm = torch.nn.utils.clip_grad_norm_(params, max_norm=hyp["max_norm"])
     g0, g1, g2 = param_groups(model)
     with torch.no_grad():
-        for group, wd in ((g2, 0.0), (g0, hyp["weight_decay"]), (g1, 0.0)):
+        for (group, wd), lr_g in zip(((g2, 0.0), (g0, wd0), (g1, 0.0)), lrs):
             for name, p in group:
                 if p.grad is None:
                     continue
@@ -65,9 +100,9 @@ def train_step(model, state, batch, hyp=HYP, world_size=1):
                 if buf is None:
                     buf = state.momentum[name] = g.clone()  # torch.optim.SGD: first step copies the gradient
                 else:
-                    buf.mul_(hyp["momentum"]).add_(g)
-                g = g.add(buf, alpha=hyp["momentum"])  # nesterov
-                p.add_(g, alpha=-hyp["lr"])
+                    buf.mul_(mom).add_(g)
+                g = g.add(buf, alpha=mom)  # nesterov
+                p.add_(g, alpha=-lr_g)
         state.updates += 1
         d = hyp["ema_decay"] * (1 - math.exp(-state.updates / hyp["ema_tau"]))
         msd = model.state_dict()

@@ -154,6 +154,51 @@ def test_conv_big_kernel(case, act):
     assert err <= 3e-2 * max(1.0, ref.abs().max().item()), err
 
 
+PAIR_CASES = [
+    # c, H, W, N, shortcut  (Bottleneck(c, c, shortcut, k=(3,3), e=1.0) as one kernel, csrc/conv_pair.hip)
+    (64, 40, 40, 2, True),     # 14 x 14 tiles, 3 x 3 per image, ragged right / bottom tiles, residual
+    (64, 40, 40, 1, False),
+    (32, 80, 80, 2, True),     # C = 32: 64-byte pixels (one k-tile)
+    (32, 33, 47, 3, False),    # odd sizes, several images
+    (64, 20, 20, 2, True),     # a map barely larger than one tile
+    (32, 9, 5, 1, True),       # a map smaller than one tile: every mid pixel ring is image border (zero padding of conv 2)
+    (64, 14, 14, 1, True),     # exactly one tile
+]
+
+
+@pytest.mark.parametrize("case", PAIR_CASES, ids=[f"c{c[0]}_{c[1]}x{c[2]}n{c[3]}{'r' if c[4] else ''}" for c in PAIR_CASES])
+def test_bottleneck_pair_kernel(case):
+    """`upa_bottleneck_pair` (bf16): x + cv2(cv1(x)) of a C2f inner Bottleneck (block.py:644-668, k = (3,3), e = 1.0) as one
+    kernel with the intermediate tile in LDS, vs the oracle Bottleneck on bf16-rounded inputs with the intermediate rounded
+    to bf16 as the kernel stores it; then vs the product's own two-launch path (same weights), which it must match to bf16
+    resolution.  Zero padding of the SECOND conv at the image border (mid pixels outside the image must be zero, not
+    act(bias)), ragged tiles, strided input / output views (channel slices of a wider buffer as inside C2f)."""
+    from tests.hip_utils import DEV, bf16_round, to_cpu_nchw, to_dev_nhwc
+    from ultralytics_pro_amd.engine import runtime as R
+    pm, _ = _mods()
+    c, H, W, N, sc = case
+    o, m = _pair(om.Bottleneck, pm.Bottleneck, (c, c, sc, 1, (3, 3), 1.0), "pair")
+    x = bf16_round(P.uniform(f"pair{case}", (N, c, H, W), -1, 1))
+    with torch.no_grad():
+        t = bf16_round(o.cv1(x))
+        ref = o.cv2(t) + (x if sc else 0)
+    # x and y are channel slices [c, 2c) and [2c, 3c) of one 3c-channel buffer, as C2f lays them out
+    buf = R.alloc_nhwc(N, 3 * c, H, W, torch.bfloat16, DEV)
+    buf.zero_()
+    xin = buf[:, c:2 * c]
+    xin.copy_(to_dev_nhwc(x, torch.bfloat16))
+    with torch.no_grad():
+        m.fuse_pair = True
+        y = to_cpu_nchw(m(xin, out=buf[:, 2 * c:]))
+        m.fuse_pair = False
+        y2 = to_cpu_nchw(m(xin))
+    assert y.shape == ref.shape
+    scale = max(1.0, ref.abs().max().item())
+    assert (y - ref).abs().max().item() <= 3e-2 * scale, (y - ref).abs().max().item()
+    assert (y - y2).abs().max().item() <= 2e-2 * scale  # one bf16 ulp of the output
+    assert float(to_cpu_nchw(buf[:, :c]).abs().max()) == 0.0  # nothing written outside the output slice
+
+
 C1_CASES = [
     # c1, c2, H, W, N, act, env  (1x1 s1: the streaming pointwise kernel, csrc/conv1x1.hip)
     (64, 64, 16, 16, 2, True, {}),                                   # KTT 2, NTW 4

@@ -504,3 +504,53 @@ def test_batched_weight_repack_equals_per_layer_and_host_pack():
         torch.cuda.synchronize()
         for ob, os_ in zip(outs_b, outs_s):
             assert torch.equal(ob, os_)
+
+
+def test_warmup_and_accumulation_schedule_matches_oracle():
+    """engine/trainer.py:337-338, 392-413, 428-431 of the reference: per-iteration learning rates (bias group falling from
+    warmup_bias_lr, the others rising from 0), momentum rising from warmup_momentum, `accumulate` growing from 1 to
+    nbs / batch, the optimizer stepping only every `accumulate` iterations with the gradients of the iterations in between
+    summed, weight decay scaled by batch * accumulate / nbs.  Six iterations of yolov8n (bs 8 at 160 px -> accumulate
+    reaches 2 inside a 100-iteration warm-up when nbs = 64... shortened here with nbs = 16, nb = 2, warmup_epochs = 2)
+    on the HIP trainer (f32) vs the oracle loop built from oracle.train.schedule / train_step."""
+    from oracle import tasks as ot
+    from oracle import train as otr
+    from tests.hip_utils import DEV
+    from ultralytics_pro_amd.engine.trainer import DetectionTrainer
+    from ultralytics_pro_amd.nn.tasks import DetectionModel
+    bs, sz, iters = 8, 160, 6
+    sched = dict(otr.SCHED, nbs=16, warmup_epochs=2.0)  # nw = max(round(2 * 2), 100) = 100; accumulate -> 2 from ni = 25 on
+    # known answers of the schedule itself
+    assert otr.schedule(0, 2, bs, sched=sched)[:3] == (1, [0.1, 0.0, 0.0], 0.8)
+    a, lrs, mom, wd = otr.schedule(100, 2, bs, sched=sched)
+    assert a == 2 and abs(mom - 0.9) < 1e-12 and abs(wd - 5e-4 * bs * 2 / 16) < 1e-12
+    x = P.synthetic_images(bs, h=sz, w=sz)
+    lab = P.synthetic_labels(bs)
+    ref = ot.DetectionModel("yolov8n.yaml")
+    P.apply_procedural_weights(ref)
+    st = otr.TrainState(ref)
+    m = DetectionModel("yolov8n.yaml")
+    P.apply_procedural_weights(m)
+    tr = DetectionTrainer(m, dtype=torch.float32, device=DEV)
+    tr.set_schedule(2, **{k: sched[k] for k in ("nbs", "warmup_epochs")})
+    start = 48  # accumulate is 1 up to ni = 49 and 2 from ni = 50 on: optimizer steps at ni = 48, 49, 51, 53
+    tr.ni, tr.last_opt_step = start, start - 1
+    last = start - 1
+    batch = {"img": x, **lab}
+    for it in range(iters):
+        ni = start + it
+        acc, lrs, mom, wd = otr.schedule(ni, 2, bs, sched=sched)
+        do = ni - last >= acc
+        items_ref, _ = otr.train_step(ref, st, batch, lrs=lrs, momentum=mom, weight_decay=wd, optimize=do,
+                                      zero_grad=(ni - 1 == last))
+        if do:
+            last = ni
+        items = tr.step(x.to(DEV), lab)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(items.cpu().numpy(), items_ref.detach().numpy(), rtol=5e-3)
+    assert tr.last_opt_step == last and tr.updates == st.updates and st.updates >= 3
+    named = dict(m.named_parameters())
+    for k, p in ref.named_parameters():
+        if p.requires_grad:
+            d = float((named[k].detach().cpu() - p.detach()).abs().max())
+            assert d <= 5e-5 * max(1.0, float(p.detach().abs().max())), (k, d)

@@ -1,0 +1,291 @@
+// Bottleneck as ONE kernel: y = [x +] act(conv3x3_2(act(conv3x3_1(x) + b1)) + b2) with C -> C -> C channels (the C2f inner
+// blocks: ultralytics/nn/modules/block.py:644-668 with k = (3, 3), e = 1.0 as built by C2f, block.py:475; BN folded per
+// utils/torch_utils.py:236-266), bf16, C = 32 or 64.  The intermediate tensor never reaches HBM: it lives as a
+// (TH+2) x (TW+2) pixel tile in LDS, recomputed on a one-pixel ring around the output tile.
+//
+// Structure = conv_big.hip twice inside one workgroup (8 waves, 256 pixel slots, every output channel in the wave: WM 8 x WN 1):
+//   stage 1: input halo (TH+4) x (TW+4) x C staged by LDS-DMA (zero page outside the image); the nine weight slabs of conv 1
+//            stream through two LDS buffers, one tap ahead; result on the (TH+2) x (TW+2) <= 256 pixels of the mid tile:
+//            bias + SiLU -> bf16 -> LDS, ZERO where the mid pixel lies outside the image (the zero padding conv 2 sees);
+//   stage 2: the same loop reading the mid tile, weights of conv 2 (their first slab prefetched under stage 1's last tap);
+//            epilogue bias + SiLU + residual read from the input halo STILL IN LDS (no second global read of x) ->
+//            16-byte NHWC stores.
+// Cost: conv 1 is evaluated on (TH+2)(TW+2) / (TH*TW) pixels (1.31x at 14 x 14); saved: one launch, the intermediate's write
+// and read, the residual read, and - the point for the latency-bound 40x40 / 80x80 layers - one whole launch -> DMA ->
+// MFMA -> store dependency chain per Bottleneck.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+#include "conv_pipe.h"
+
+typedef __attribute__((address_space(1))) const void* pgptr_t;
+typedef __attribute__((address_space(3))) void* plptr_t;
+
+__device__ __attribute__((aligned(16))) unsigned g_pair_zero16[4] = {0u, 0u, 0u, 0u};
+
+namespace {
+template <int ACT>
+__device__ __forceinline__ float pair_act(float v) {
+  if constexpr (ACT == UPA_ACT_SILU) return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+  else if constexpr (ACT == UPA_ACT_RELU) return fmaxf(v, 0.0f);
+  else return v;
+}
+}  // namespace
+
+// CK = k-tiles (32 channels) of C: 1 (C = 32) or 2 (C = 64); NT = C / 16 n-tiles, all in every wave
+template <int CK, bool RES>
+__global__ __launch_bounds__(512, 4) void conv_pair_kernel(const PairParams p) {
+  constexpr int NT = CK * 2;
+  constexpr int G16 = CK * 4;              // 16-byte groups per pixel
+  constexpr int PB = G16 * 16;             // bytes per pixel in the LDS images
+  constexpr int WBUF = CK * NT * 1024;     // one tap's weight slab
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+
+  int bid = blockIdx.x;
+  const int tilesPerImg = p.tilesX * p.tilesY;
+  const int n = bid / tilesPerImg;
+  bid -= n * tilesPerImg;
+  const int tyi = bid / p.tilesX;
+  const int txi = bid - tyi * p.tilesX;
+  const int oy0 = tyi * p.TH, ox0 = txi * p.TW;
+  const int IH = p.TH + 4, IW = p.TW + 4, MH = p.TH + 2, MW = p.TW + 2;
+
+  auto swz = [](int pix) __attribute__((always_inline)) { return (CK == 1 ? (pix >> 1) : pix) & (G16 - 1); };
+
+  const int haloItems = IH * IW * G16;
+  const int haloPadded = (haloItems + 63) & ~63;
+  const int midBytes = ((MH * MW * PB) + 1023) & ~1023;
+  char* hal = smem;
+  char* mid = smem + (size_t)haloPadded * 16;
+  char* wbuf = mid + midBytes;
+
+  // ---- input halo: rows oy0-2 .. oy0+TH+1, columns ox0-2 .. ox0+TW+1, every channel
+  for (int base = wave * 64; base < haloPadded; base += 512) {
+    const int idx = base + lane;
+    const int pix = idx / G16;          // G16 is a power of two
+    const int slot = idx & (G16 - 1);
+    const int cg = slot ^ swz(pix);
+    const int py = (int)__umulhi((unsigned)pix, p.magicIW);
+    const int px = pix - py * IW;
+    const int iy = oy0 - 2 + py, ix = ox0 - 2 + px;
+    const char* src = reinterpret_cast<const char*>(g_pair_zero16);
+    if (idx < haloItems && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+      src = p.x + ((((size_t)n * p.H + iy) * p.W + ix) * (size_t)p.ldx + cg * 8) * 2;
+    __builtin_amdgcn_global_load_lds((pgptr_t)src, (plptr_t)(hal + base * 16), 16, 0, 0);
+  }
+  // weight slab of one tap: CK * NT fragments of 1 KiB, wave w brings fragments w, w + 8, ...
+  auto stage_w = [&](const char* w, int tap, int b) __attribute__((always_inline)) {
+#pragma unroll
+    for (int f0 = 0; f0 < CK * NT; f0 += 8) {
+      const int f = f0 + wave;
+      if (f < CK * NT)
+        __builtin_amdgcn_global_load_lds((pgptr_t)(w + (((size_t)tap * CK * NT + f) * 64 + lane) * 16),
+                                         (plptr_t)(wbuf + b * WBUF + f * 1024), 16, 0, 0);
+    }
+  };
+  stage_w(p.w1, 0, 0);
+
+  // one conv over an LDS image: this wave's two m-tiles (pixel slots wave*32 .. +31) x all NT n-tiles
+  f32x4 acc[2][NT];
+  auto conv_stage = [&](const char* img, int imgW, const int (&pl0)[2], const char* wcur, const char* wnext, int& buf)
+      __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int kh = 0, kw = 0;
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tap + 1 < 9) stage_w(wcur, tap + 1, buf ^ 1);
+      else if (wnext) stage_w(wnext, 0, buf ^ 1);  // first slab of the next conv rides under this conv's last tap
+      const int tapshift = kh * imgW + kw;
+      const char* wb = wbuf + buf * WBUF + lane * 16;
+      int paddr[2], pswz[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int pl = pl0[i] + tapshift;
+        paddr[i] = pl * PB;
+        pswz[i] = swz(pl);
+      }
+#pragma unroll
+      for (int kt = 0; kt < CK; ++kt) {
+        u32x4 a[NT], b[2];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) a[j] = *reinterpret_cast<const u32x4*>(wb + (kt * NT + j) * 1024);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) b[i] = *reinterpret_cast<const u32x4*>(img + paddr[i] + (((kt * 4 + g) ^ pswz[i]) << 4));
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a[j]),
+                                                                *reinterpret_cast<const bf16x8*>(&b[i]), acc[i][j], 0, 0, 0);
+      }
+      buf ^= 1;
+      if (++kw == 3) { kw = 0; ++kh; }
+    }
+  };
+
+  // ---- stage 1: conv 1 on the mid region (MH x MW pixels, pixel slot pp -> (my, mx))
+  int my[2], mx[2], pl1[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int pp = (wave * 2 + i) * 16 + r;
+    int y_ = (int)__umulhi((unsigned)pp, p.magicMW);
+    int x_ = pp - y_ * MW;
+    if (y_ >= MH) { y_ = MH; x_ = 0; }
+    my[i] = y_;
+    mx[i] = x_;
+    pl1[i] = y_ < MH ? y_ * IW + x_ : 0;
+  }
+  int buf = 0;
+  conv_stage(hal, IW, pl1, p.w1, p.w2, buf);
+  {
+    f32x4 bv[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bv[j] = *reinterpret_cast<const f32x4*>(p.b1 + j * 16 + g * 4);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (my[i] >= MH) continue;
+      const int gy = oy0 - 1 + my[i], gx = ox0 - 1 + mx[i];
+      const bool inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+      const int mp = my[i] * MW + mx[i];
+      char* row = mid + mp * PB;
+      const int sw = swz(mp);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = inside ? pair_act<UPA_ACT_SILU>(acc[i][j][q] + bv[j][q]) : 0.f;
+        // channels 16j + 4g .. + 3: 16-byte group 2j + (g >> 1), half (g & 1)
+        const int cg = 2 * j + (g >> 1);
+        *reinterpret_cast<u32x2*>(row + ((cg ^ sw) << 4) + (g & 1) * 8) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+      }
+    }
+  }
+  // (the barrier at the head of stage 2's first tap orders these LDS writes before any read of the mid tile)
+
+  // ---- stage 2: conv 2 on the output tile (TH x TW pixels) from the mid tile
+  int ty[2], tx[2], pl2[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int pp = (wave * 2 + i) * 16 + r;
+    int y_ = (int)__umulhi((unsigned)pp, p.magicTW);
+    int x_ = pp - y_ * p.TW;
+    if (y_ >= p.TH) { y_ = p.TH; x_ = 0; }
+    ty[i] = y_;
+    tx[i] = x_;
+    pl2[i] = y_ < p.TH ? y_ * MW + x_ : 0;
+  }
+  conv_stage(mid, MW, pl2, p.w2, nullptr, buf);
+
+  f32x4 bv[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) bv[j] = *reinterpret_cast<const f32x4*>(p.b2 + j * 16 + g * 4);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int oy = oy0 + ty[i], ox = ox0 + tx[i];
+    const bool pok = ty[i] < p.TH && oy < p.OH && ox < p.OW;
+    char* yrow = p.y + (((size_t)n * p.OH + oy) * p.OW + ox) * (size_t)p.ldy * 2;
+    const int hp = (ty[i] + 2) * IW + tx[i] + 2;  // this output pixel in the input halo (residual)
+    const char* xrow = hal + (ty[i] < p.TH ? hp : 0) * PB;
+    const int xsw = swz(ty[i] < p.TH ? hp : 0);
+#pragma unroll
+    for (int j = 0; j < NT; j += 2) {
+      const int cb = 16 * (j + (g & 1)) + 8 * (g >> 1);
+      float v0[4], v1[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v0[q] = pair_act<UPA_ACT_SILU>(acc[i][j][q] + bv[j][q]);
+        v1[q] = pair_act<UPA_ACT_SILU>(acc[i][j + 1][q] + bv[j + 1][q]);
+      }
+      if constexpr (RES) {  // x + ...: the lane's own 4 channels of tiles j and j + 1, from the halo tile in LDS
+        const u32x2 r0 = *reinterpret_cast<const u32x2*>(xrow + (((2 * j + (g >> 1)) ^ xsw) << 4) + (g & 1) * 8);
+        const u32x2 r1 = *reinterpret_cast<const u32x2*>(xrow + (((2 * (j + 1) + (g >> 1)) ^ xsw) << 4) + (g & 1) * 8);
+        v0[0] += __uint_as_float(r0[0] << 16); v0[1] += __uint_as_float(r0[0] & 0xFFFF0000u);
+        v0[2] += __uint_as_float(r0[1] << 16); v0[3] += __uint_as_float(r0[1] & 0xFFFF0000u);
+        v1[0] += __uint_as_float(r1[0] << 16); v1[1] += __uint_as_float(r1[0] & 0xFFFF0000u);
+        v1[2] += __uint_as_float(r1[1] << 16); v1[3] += __uint_as_float(r1[1] & 0xFFFF0000u);
+      }
+      auto lo = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v1[0], v1[1]), false, false);
+      auto hi = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[2], v1[3]), false, false);
+      if (pok) *reinterpret_cast<u32x4*>(yrow + cb * 2) = u32x4{lo[0], hi[0], lo[1], hi[1]};
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+int pair_env(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+template <int CK>
+int pair_launch(const PairParams& p, size_t lds, bool res, hipStream_t s) {
+  const dim3 grid((unsigned)((long)p.tilesX * p.tilesY * p.N));
+  if (res) {
+    auto kern = conv_pair_kernel<CK, true>;
+    if (upa_full_lds<conv_pair_kernel<CK, true>>() != hipSuccess) return UPA_ELAUNCH;
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, p);
+  } else {
+    auto kern = conv_pair_kernel<CK, false>;
+    if (upa_full_lds<conv_pair_kernel<CK, false>>() != hipSuccess) return UPA_ELAUNCH;
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, p);
+  }
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+}  // namespace
+
+extern "C" int upa_bottleneck_pair(const void* x, int n, int h, int w, int c, int ldx, const void* w1_packed, const float* b1,
+                                   const void* w2_packed, const float* b2, void* y, int ldy, int residual, int act, int dtype,
+                                   void* stream) {
+  UPA_CHECK_ARG(x && w1_packed && b1 && w2_packed && b2 && y && n > 0 && h > 0 && w > 0, "bottleneck_pair: bad args");
+  static const int off = pair_env("UPA_NO_PAIR", 0);
+  if (off || dtype != UPA_BF16 || act != UPA_ACT_SILU || !(c == 32 || c == 64) || ldx % 8 != 0 || ldy % 8 != 0 ||
+      ((uintptr_t)x % 16) != 0 || ((uintptr_t)y % 16) != 0) {
+    upa_set_error("bottleneck_pair: outside the fused form (bf16, SiLU, C = 32 | 64)");
+    return UPA_EUNSUPPORTED;  // the caller runs the two convolutions separately
+  }
+  PairParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = (const char*)x; p.y = (char*)y; p.w1 = (const char*)w1_packed; p.w2 = (const char*)w2_packed; p.b1 = b1; p.b2 = b2;
+  p.N = n; p.H = h; p.W = w; p.OH = h; p.OW = w; p.ldx = ldx; p.ldy = ldy;
+  const int ck = c / 32;
+  const int pb = ck * 64;
+  // output tile TH x TW with (TH+2)(TW+2) <= 256 mid pixels: fewest tiles per image, then the squarest
+  static const int fth = pair_env("UPA_PAIR_TH", 0), ftw = pair_env("UPA_PAIR_TW", 0);
+  long best = -1;
+  for (int tw = 2; tw <= 62 && tw <= ((w + 1) & ~1); ++tw) {
+    int th = 256 / (tw + 2) - 2;
+    if (th > h) th = h;
+    if (th < 1) continue;
+    const long tiles = (long)cdiv(w, tw) * cdiv(h, th);
+    const long cost = tiles * 65536 + (long)(th + 4) * (tw + 4);
+    if (best < 0 || cost < best) { best = cost; p.TH = th; p.TW = tw; }
+  }
+  if (fth > 0 && ftw > 0 && (fth + 2) * (ftw + 2) <= 256) { p.TH = fth; p.TW = ftw; }
+  p.tilesX = cdiv(w, p.TW);
+  p.tilesY = cdiv(h, p.TH);
+  const int IH = p.TH + 4, IW = p.TW + 4, MH = p.TH + 2, MW = p.TW + 2;
+  p.magicIW = (unsigned)((0x100000000ULL + IW - 1) / IW);
+  p.magicMW = (unsigned)((0x100000000ULL + MW - 1) / MW);
+  p.magicTW = (unsigned)((0x100000000ULL + p.TW - 1) / p.TW);
+  const size_t halo = (((size_t)IH * IW * (ck * 4) + 63) & ~(size_t)63) * 16;
+  const size_t mid = (((size_t)MH * MW * pb) + 1023) & ~(size_t)1023;
+  const size_t lds = halo + mid + 2 * (size_t)(ck * ck * 2 * 1024) + 256;
+  if (lds > 160 * 1024) return UPA_EUNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  return ck == 1 ? pair_launch<1>(p, lds, residual != 0, s) : pair_launch<2>(p, lds, residual != 0, s);
+}

@@ -56,3 +56,16 @@ bool upa_conv_big_eligible(int n, int h, int w, int cin, int ldx, int cout, int 
                            int act, int dtype);
 // variant (if non-null) receives (1 << 23) | n-tiles per workgroup << 4 | pixels per workgroup / 128; query_only = 1 skips the launch
 int upa_conv_big_launch(BigParams p, int query_only, int* variant, void* stream);
+
+// ---- conv_pair.hip: Bottleneck (3x3 -> 3x3 [+ x]) as one kernel, the intermediate tile in LDS (bf16, C = 32 | 64)
+struct PairParams {
+  const char* x;
+  char* y;
+  const char* w1;      // packed [tap][ktile][ntile][lane][16 B] of conv 1 (C -> C)
+  const char* w2;
+  const float* b1;
+  const float* b2;
+  int N, H, W, OH, OW, ldx, ldy;
+  int TH, TW, tilesX, tilesY;
+  unsigned magicIW, magicMW, magicTW;
+};

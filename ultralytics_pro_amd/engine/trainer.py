@@ -35,6 +35,8 @@ from . import runtime as R
 
 HYP = dict(lr=0.01, momentum=0.9, weight_decay=5e-4, max_norm=10.0, ema_decay=0.9999, ema_tau=2000.0,
            box=7.5, cls=0.5, dfl=1.5)
+# warm-up / accumulation schedule of the reference's training loop (engine/trainer.py:337-338, 392-413, 245; cfg/default.yaml)
+SCHED = dict(nbs=64, warmup_epochs=3.0, warmup_momentum=0.8, warmup_bias_lr=0.1, lrf=0.01, epochs=100)
 MAX_GT = 64        # initial gt-row capacity per image; grows with the data (the loss kernels take it at run time)
 MAX_GT_CAP = 1024  # upa_detection_loss: LDS arrays of the assignment-resolve kernel
 
@@ -375,6 +377,9 @@ class DetectionTrainer:
         self._capturing = False
         self._imgsz = None
         self.gt_d = self.ngt_d = None
+        self.schedule = None      # set_schedule(): warm-up interpolation + gradient accumulation of the reference's loop
+        self.ni = 0               # iteration counter (the reference's `ni = i + nb * epoch`)
+        self.last_opt_step = -1   # trainer.py:386
         self.max_gt = MAX_GT  # rows per image of the padded gt tensor (the reference pads to counts.max(), loss.py:445-461)
         model.to(self.device)
         self._flatten_parameters(ema)
@@ -582,7 +587,39 @@ class DetectionTrainer:
             n = self.groups[-1][0] + self.groups[-1][1]
             allreduce_gradients_(self.G[:n])
 
-    def optimizer_step(self):
+    def set_schedule(self, batches_per_epoch: int, global_batch: int | None = None, **overrides):
+        """Enable the reference's warm-up and gradient accumulation (engine/trainer.py:337-338, 392-413):
+        nw = max(round(warmup_epochs * nb), 100) iterations over which the bias learning rate falls from warmup_bias_lr to
+        lr0 * lf(epoch), every other learning rate rises from 0, the momentum rises from warmup_momentum and `accumulate`
+        grows from 1 to nbs / batch; afterwards the optimizer steps every max(round(nbs / batch), 1) iterations with
+        weight_decay * batch * accumulate / nbs.  `global_batch` = the reference's `batch_size` (all ranks together)."""
+        sc = dict(SCHED, **overrides)
+        sc["nb"] = int(batches_per_epoch)
+        sc["global_batch"] = global_batch
+        self.schedule = sc
+        if self._graphs is not None and len(self._graphs) == 1:
+            raise L.UpaError("set_schedule() before compile(): the optimizer has to stay outside the captured graph")
+        return self
+
+    def schedule_at(self, ni: int, batch_size: int):
+        """(accumulate, [lr biases, lr decayed weights, lr norm weights], momentum, weight_decay) of iteration ni."""
+        h, sc = self.hyp, self.schedule
+        if sc is None:
+            return 1, [h["lr"]] * 3, h["momentum"], h["weight_decay"]
+        gb = sc["global_batch"] or batch_size * self.world_size
+        acc0 = max(round(sc["nbs"] / gb), 1)
+        wd = h["weight_decay"] * gb * acc0 / sc["nbs"]
+        lf = max(1 - (ni // sc["nb"]) / sc["epochs"], 0) * (1.0 - sc["lrf"]) + sc["lrf"]
+        nw = max(round(sc["warmup_epochs"] * sc["nb"]), 100) if sc["warmup_epochs"] > 0 else -1
+        lr = h["lr"] * lf
+        if ni <= nw:
+            xi = [0, nw]
+            acc = max(1, int(np.interp(ni, xi, [1, sc["nbs"] / gb]).round()))
+            lrs = [float(np.interp(ni, xi, [sc["warmup_bias_lr"] if j == 0 else 0.0, lr])) for j in range(3)]
+            return acc, lrs, float(np.interp(ni, xi, [sc["warmup_momentum"], h["momentum"]])), wd
+        return acc0, [lr, lr, lr], h["momentum"], wd
+
+    def optimizer_step(self, lrs=None, momentum=None, weight_decay=None):
         h = self.hyp
         lib, st = L.lib(), _s(self.device)
         self.grad_sumsq()
@@ -591,13 +628,17 @@ class DetectionTrainer:
         dp = None
         if self._capturing:  # a replayed graph reads the decay of the current step from device memory
             dp = self.ema_d_dev.data_ptr()
-        for start, n, wd in self.groups:
+        lrs = [h["lr"]] * 3 if lrs is None else lrs
+        mom = h["momentum"] if momentum is None else momentum
+        for gi, (start, n, wd) in enumerate(self.groups):
             if n == 0:
                 continue
+            if wd and weight_decay is not None:
+                wd = weight_decay
             o = 4 * start
             L.check(lib.upa_sgd_nesterov_ema(self.P.data_ptr() + o, self.G.data_ptr() + o, self.M.data_ptr() + o,
                                              (self.E.data_ptr() + o) if self.E is not None else None, n,
-                                             self.sumsq.data_ptr(), h["max_norm"], h["lr"], h["momentum"], wd,
+                                             self.sumsq.data_ptr(), h["max_norm"], lrs[gi], mom, wd,
                                              int(self.first_step), d, dp, 1, st), "sgd")
         if self.ERB is not None and self.nbuf:
             L.check(lib.upa_ema_update(self.ERB.data_ptr(), self.RB.data_ptr(), self.nbuf, d, dp, st), "ema_buffers")
@@ -609,9 +650,22 @@ class DetectionTrainer:
         if self._graphs is not None:
             return self._replay(img, labels)
         items = self.forward_backward(img, labels)
-        self.all_reduce_gradients()
-        self.optimizer_step()
+        self._maybe_optimize(img.shape[0])
         return items
+
+    def _maybe_optimize(self, batch_size: int, graph=None):
+        """trainer.py:399-413 + 428-431: warm-up state of this iteration; the optimizer steps once `accumulate` iterations
+        have added their gradients to the flat buffer (each backward accumulates; the step zeroes it).  The gradient
+        all-reduce happens once per optimizer step: the sum of the per-iteration all-reduces DDP would do."""
+        acc, lrs, mom, wd = self.schedule_at(self.ni, batch_size)
+        if self.ni - self.last_opt_step >= acc:
+            self.all_reduce_gradients()
+            if graph is not None:
+                graph.replay(self.device)
+            else:
+                self.optimizer_step(lrs, mom, wd if self.schedule is not None else None)
+            self.last_opt_step = self.ni
+        self.ni += 1
 
     def compile(self, img, labels, warm_steps=2):
         """Capture the step (fixed shapes) once eager steps have allocated every static buffer and passed the first-step
@@ -629,7 +683,12 @@ class DetectionTrainer:
         self._capturing = True
         try:
             g1 = R.HipGraph()
-            if self.world_size == 1:
+            if self.schedule is not None:
+                # warm-up changes lr / momentum every iteration and accumulation skips optimizer steps: the forward +
+                # backward is the graph, the three fused optimizer launches stay eager
+                self._items = g1.capture(lambda: self.forward_backward(self._static_img, None), device=self.device)
+                self._graphs = (g1, None)
+            elif self.world_size == 1:
                 def whole():
                     it = self.forward_backward(self._static_img, None)
                     self.optimizer_step()
@@ -650,14 +709,27 @@ class DetectionTrainer:
         h = self.hyp
         self._static_img.copy_(img, non_blocking=True)
         self._upload_labels(labels, img.shape[0])
-        self.updates += 1
-        # the decay of THIS step travels as a kernel argument of a stream-ordered fill (no pinned host slot that a later
-        # step could overwrite while an earlier copy is still queued when the host runs several replays ahead)
-        self.ema_d_dev.fill_(h["ema_decay"] * (1 - math.exp(-self.updates / h["ema_tau"])))
+
+        def stage_decay():
+            # the decay of THIS optimizer step travels as a kernel argument of a stream-ordered fill (no pinned host slot
+            # that a later step could overwrite while an earlier copy is still queued when the host runs replays ahead)
+            self.updates += 1
+            self.ema_d_dev.fill_(h["ema_decay"] * (1 - math.exp(-self.updates / h["ema_tau"])))
+
+        if len(self._graphs) == 1:  # forward + backward + optimizer in one graph (single GPU, no schedule)
+            stage_decay()
+            self._graphs[0].replay(self.device)
+            self.last_opt_step = self.ni
+            self.ni += 1
+            return self._items
         self._graphs[0].replay(self.device)
-        if len(self._graphs) == 2:
-            self.all_reduce_gradients()
-            self._graphs[1].replay(self.device)
+        if self._graphs[1] is None:  # schedule active: eager optimizer (it counts the update itself)
+            self._maybe_optimize(img.shape[0])
+        else:
+            acc, _, _, _ = self.schedule_at(self.ni, img.shape[0])
+            if self.ni - self.last_opt_step >= acc:
+                stage_decay()
+            self._maybe_optimize(img.shape[0], graph=self._graphs[1])
         return self._items
 
     def _upload_labels(self, labels, batch_size):

@@ -40,8 +40,32 @@ class Bottleneck(nn.Module):
         self.cv2 = Conv(c_, c2, k[1], 1, g=g)
         self.add = shortcut and c1 == c2
 
+    fuse_pair = True  # bf16: both convs as one kernel, the intermediate tile in LDS (upa_bottleneck_pair)
+
+    def _pair_ok(self, x) -> bool:
+        a, b = self.cv1.conv, self.cv2.conv
+        return bool(self.fuse_pair and x.dtype == torch.bfloat16 and not self.training
+                    and a.kernel_size == (3, 3) and b.kernel_size == (3, 3) and a.stride == (1, 1) and b.stride == (1, 1)
+                    and a.padding == (1, 1) and b.padding == (1, 1) and a.groups == 1 and b.groups == 1
+                    and a.in_channels == a.out_channels == b.out_channels and a.in_channels in (32, 64)
+                    and isinstance(self.cv1.act, nn.SiLU) and isinstance(self.cv2.act, nn.SiLU)
+                    and hasattr(self.cv1, "bn") and hasattr(self.cv2, "bn"))
+
     def forward(self, x, out=None):
         x = R.to_nhwc(x, x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.float32)
+        if self._pair_ok(x):
+            n, c, h, w = x.shape
+            y = out if out is not None else R.alloc_nhwc(n, c, h, w, x.dtype, x.device, key=(id(self), "y"))
+            p1 = self.cv1._packed(self.cv1.conv, self.cv1.bn, x.device, x.dtype, False)
+            p2 = self.cv2._packed(self.cv2.conv, self.cv2.bn, x.device, x.dtype, False)
+            vx, vy = R.view_of(x), R.view_of(y)
+            rc = L.lib().upa_bottleneck_pair(vx.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, p1.w.data_ptr(), p1.bias.data_ptr(),
+                                             p2.w.data_ptr(), p2.bias.data_ptr(), vy.ptr, vy.ld, int(self.add), L.ACT_SILU,
+                                             vx.dtype, L.current_stream(x.device))
+            if rc == 0:
+                return y
+            if rc != L.UPA_EUNSUPPORTED:
+                L.check(rc, "bottleneck_pair")
         return self.cv2(self.cv1(x), out=out, residual=x if self.add else None)
 
 
