@@ -553,18 +553,45 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
             (n * h * w * cout * 2 if raw is not None else 0)
         calls.append((name, flops, nbytes, lambda: orig_tail(self, t, conv, raw, kind, i, plan_keep)))
 
+    orig_pair = L.lib().upa_bottleneck_pair
+    pair_calls = []
+
+    class _LibProxy:
+        """Forwards every C entry to the real library, recording upa_bottleneck_pair launches (Bottleneck.forward calls it
+        directly, not through hip_conv2d)."""
+
+        def __getattr__(self, name):
+            return getattr(real_lib, name)
+
+        def upa_bottleneck_pair(self, *a):
+            rc = orig_pair(*a)
+            if rc == 0:
+                pair_calls.append(a)
+            return rc
+
+    real_lib = L.lib()
+    proxy = _LibProxy()
     mods = (pconv, pblock, phead)
     pool = R.BufferPool()
+    orig_libfn = L.lib
     try:
         for m in mods:
             m.hip_conv2d = rec
         phead.Detect._tail_call = rec_tail
+        L.lib = lambda: proxy
         with torch.no_grad(), R.static_buffers(pool):
             post(model._predict_once(x))
     finally:
         for m in mods:
             m.hip_conv2d = orig
         phead.Detect._tail_call = orig_tail
+        L.lib = orig_libfn
+    for a in pair_calls:  # (x, n, h, w, c, ldx, w1, b1, w2, b2, y, ldy, residual, act, dtype, stream)
+        n_, h_, w_, c_ = a[1], a[2], a[3], a[4]
+        flops = 2 * 2.0 * n_ * h_ * w_ * c_ * c_ * 9
+        nbytes = 2 * (n_ * h_ * w_ * c_ * 2 * (2 + (0.5 if a[12] else 0)) + c_ * c_ * 9 * 2)  # two convs, each in + out (+ residual)
+        calls.append(("void conv_pair_kernel<%d, %s>(PairParams)" % (c_ // 32, "true" if a[12] else "false"), flops, nbytes,
+                      (lambda a=a: orig_pair(*a[:15], L.current_stream(dev)))))
     torch.cuda.synchronize(dev)
     fam = {}
     with torch.no_grad():

@@ -176,6 +176,12 @@ int upa_rtdetr_postprocess(const float* preds, int b, int q, int nc, float conf,
 int upa_msdeform_attn(const float* value, const int32_t* shapes_hw, int n_levels, int b, int heads, int d,
                       const float* offsets, const float* attn_logits, const float* ref_boxes, int len_q, int n_points,
                       float* y, void* stream);
+/* The same with the projected values given as rows of `value_dtype` (UPA_F32 | UPA_BF16) with row stride ldv elements: the
+ * value projections of ALL decoder layers computed as one GEMM (rows, n_layers * C) - layer i passes value + i * C. */
+int upa_msdeform_attn_strided(const void* value, int value_dtype, int ldv, const int32_t* shapes_hw, int n_levels, int b, int heads,
+                              int d, const float* offsets, const float* attn_logits, const float* ref_boxes, int len_q,
+                              int n_points, float* y, void* stream);
+
 
 /* ---- validation ---------------------------------------------------------------------------------------------------
  * out[i,j] = IoU(box1[i], box2[j]) with eps in the denominator (xyxy f32).            utils/metrics.py:54-74 */

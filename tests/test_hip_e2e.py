@@ -384,10 +384,16 @@ def test_e2e_full_size_properties():
         assert (d[1:, 4] <= d[:-1, 4]).all(), "scores must be descending"
         assert ((d[:, 5] >= 0) & (d[:, 5] < 80) & (d[:, 5] == d[:, 5].round())).all()
         assert (d[:, 2] >= d[:, 0]).all() and (d[:, 3] >= d[:, 1]).all()
+        # idempotence: the reference's greedy NMS (on class-offset boxes, offsets of cls * 7680 as nms.py:143-156 - at
+        # those magnitudes f32 coordinates carry 1/16 px, so the IoU the NMS sees differs from the plain-box IoU by up to
+        # ~1e-3) keeps every one of the kept boxes
+        off = d[:, 5:6] * 7680.0
+        kept = onms.greedy_nms(d[:, :4] + off, d[:, 4], 0.7)
+        assert kept.numel() == n, "the reference NMS applied to the kept detections drops some of them"
         iou = _iou_matrix(d[:, :4])
         same = d[:, 5][:, None] == d[:, 5][None, :]
         iou = torch.where(same, iou, torch.zeros_like(iou)).triu(1)
-        assert iou.max().item() <= 0.7 + 1e-6, "two kept boxes of one class overlap by more than iou_thres"
+        assert iou.max().item() <= 0.7 + 5e-3, "two kept boxes of one class overlap by more than iou_thres"
     # batch-composition independence, f32 parity mode
     mf = _build("yolov8n", torch.float32)
     with torch.no_grad():

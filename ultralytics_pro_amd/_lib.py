@@ -61,6 +61,7 @@ PROTOTYPES = {
     "upa_rtdetr_output": (_i, [_vp, _vp, _vp, C.c_long, _i, _vp]),
     "upa_rtdetr_postprocess": (_i, [_vp, _i, _i, _i, _f, _vp, _i, _vp, _f, _f, _vp, _vp, _vp]),
     "upa_msdeform_attn": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "upa_msdeform_attn_strided": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "upa_box_iou": (_i, [_vp, _i, _vp, _i, _f, _vp, _vp]),
     "upa_match_predictions": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp]),
     "upa_scale_boxes": (_i, [_vp, C.c_long, _i, _f, _f, _f, _i, _f, _f, _vp]),

@@ -324,8 +324,11 @@ bool upa_conv_big_eligible(int n, int h, int w, int cin, int ldx, int cout, int 
   if (k == 1) {
     // pointwise layers stream faster through conv1x1.hip while their weight slice fits LDS; past that (512+ channels in)
     // the weights have to be shared per tap-chunk anyway
-    return cin >= 512 && cout % 128 == 0 && px >= 2048 &&
-           !upa_conv1x1_eligible(n, h, w, cin, ldx, cout, ldy, ldr != 0, k, stride, pad, act, dtype);
+    // ... and GEMM-shaped ones with >= 1024 output columns (the RT-DETR value projections of all decoder layers batched:
+    // 134400 x 1536 x 256), where the streaming kernel would re-read its input once per 128-column row of workgroups
+    if (cout % 128 != 0 || px < 2048) return false;
+    if (cout >= 1024 && cin >= 128 && px >= 32 * 1024) return true;
+    return cin >= 512 && !upa_conv1x1_eligible(n, h, w, cin, ldx, cout, ldy, ldr != 0, k, stride, pad, act, dtype);
   }
   // measured on MI355X (tools/bench_conv.py, yolov3-rtdetr bs 16 / yolov8n bs 32, round 2): 3x3 layers with whole 128-channel
   // output columns run at 800-1000 TFLOP/s here against 430-615 on the per-wave-weights kernel; the 80-channel class

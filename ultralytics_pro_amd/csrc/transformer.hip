@@ -291,10 +291,16 @@ struct DeformLevels {
   int h[4], w[4], row0[4];
 };
 
-template <int D, int NP>
-__global__ __launch_bounds__(256) void msdeform_kernel(const float* value, DeformLevels lv, int B, int LQ, int heads,
+// VT = element type of the projected values: float rows, or bf16 rows (unsigned short) when the value projections of all
+// decoder layers were computed as one bf16 GEMM (perf mode); ldv = row stride of `value` in elements (>= heads * D).
+template <int D, int NP, typename VT>
+__global__ __launch_bounds__(256) void msdeform_kernel(const VT* value, int ldv, DeformLevels lv, int B, int LQ, int heads,
                                                        const float* offsets, const float* logits, const float* ref,
                                                        float* y) {
+  auto ldval = [](const VT* q) __attribute__((always_inline)) -> float {
+    if constexpr (sizeof(VT) == 2) return __uint_as_float(((unsigned)*q) << 16);
+    else return *q;
+  };
   static_assert(256 % D == 0, "D lanes per (b, q, head) item");
   const long item = (long)blockIdx.x * (256 / D) + (threadIdx.x / D);  // (b, q, head)
   const int ch = threadIdx.x % D;
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(256) void msdeform_kernel(const float* value, Defor
   float acc = 0.f;
   for (int l = 0; l < lv.n_levels; ++l) {
     const int H = lv.h[l], W = lv.w[l];
-    const float* vbase = value + ((size_t)lv.row0[l] + (size_t)b * H * W) * C + head * D + ch;
+    const VT* vbase = value + ((size_t)lv.row0[l] + (size_t)b * H * W) * (size_t)ldv + head * D + ch;
     for (int p = 0; p < NP; ++p) {
       const int i = l * NP + p;
       const float wgt = expf(lg[i] - mx) / den;
@@ -330,22 +336,23 @@ __global__ __launch_bounds__(256) void msdeform_kernel(const float* value, Defor
       float s = 0.f;
       const bool xin0 = x0 >= 0 && x0 < W, xin1 = x0 + 1 >= 0 && x0 + 1 < W;
       const bool yin0 = y0 >= 0 && y0 < H, yin1 = y0 + 1 >= 0 && y0 + 1 < H;
-      if (yin0 && xin0) s += vbase[((size_t)y0 * W + x0) * C] * (1.f - tx) * (1.f - ty);
-      if (yin0 && xin1) s += vbase[((size_t)y0 * W + x0 + 1) * C] * tx * (1.f - ty);
-      if (yin1 && xin0) s += vbase[((size_t)(y0 + 1) * W + x0) * C] * (1.f - tx) * ty;
-      if (yin1 && xin1) s += vbase[((size_t)(y0 + 1) * W + x0 + 1) * C] * tx * ty;
+      if (yin0 && xin0) s += ldval(vbase + ((size_t)y0 * W + x0) * ldv) * (1.f - tx) * (1.f - ty);
+      if (yin0 && xin1) s += ldval(vbase + ((size_t)y0 * W + x0 + 1) * ldv) * tx * (1.f - ty);
+      if (yin1 && xin0) s += ldval(vbase + ((size_t)(y0 + 1) * W + x0) * ldv) * (1.f - tx) * ty;
+      if (yin1 && xin1) s += ldval(vbase + ((size_t)(y0 + 1) * W + x0 + 1) * ldv) * tx * ty;
       acc += wgt * s;
     }
   }
   y[bq * C + head * D + ch] = acc;
 }
 
-extern "C" int upa_msdeform_attn(const float* value, const int32_t* shapes_hw, int n_levels, int b, int heads, int d,
-                                 const float* offsets, const float* attn_logits, const float* ref_boxes, int len_q,
-                                 int n_points, float* y, void* stream) {
+extern "C" int upa_msdeform_attn_strided(const void* value, int value_dtype, int ldv, const int32_t* shapes_hw, int n_levels,
+                                         int b, int heads, int d, const float* offsets, const float* attn_logits,
+                                         const float* ref_boxes, int len_q, int n_points, float* y, void* stream) {
   UPA_CHECK_ARG(value && shapes_hw && offsets && attn_logits && ref_boxes && y, "msdeform_attn: null pointer");
   UPA_CHECK_ARG(n_levels >= 1 && n_levels <= 4 && (d == 32 || d == 8) && n_points == 4,
                 "msdeform_attn: supports <=4 levels, head dim 32 (or 8), 4 points (head.py:1951-1961)");
+  UPA_CHECK_ARG((value_dtype == UPA_F32 || value_dtype == UPA_BF16) && ldv >= heads * d, "msdeform_attn: bad value dtype / stride");
   DeformLevels lv;
   lv.n_levels = n_levels;
   int row = 0;
@@ -356,14 +363,26 @@ extern "C" int upa_msdeform_attn(const float* value, const int32_t* shapes_hw, i
     row += lv.h[l] * lv.w[l] * b;
   }
   const long items = (long)b * len_q * heads;
-  if (d == 32)
-    hipLaunchKernelGGL((msdeform_kernel<32, 4>), dim3((unsigned)((items + 7) / 8)), dim3(256), 0, (hipStream_t)stream, value,
-                       lv, b, len_q, heads, offsets, attn_logits, ref_boxes, y);
-  else
-    hipLaunchKernelGGL((msdeform_kernel<8, 4>), dim3((unsigned)((items + 31) / 32)), dim3(256), 0, (hipStream_t)stream, value,
-                       lv, b, len_q, heads, offsets, attn_logits, ref_boxes, y);
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 g32((unsigned)((items + 7) / 8)), g8((unsigned)((items + 31) / 32));
+  if (value_dtype == UPA_F32) {
+    const float* v = (const float*)value;
+    if (d == 32) hipLaunchKernelGGL((msdeform_kernel<32, 4, float>), g32, dim3(256), 0, s, v, ldv, lv, b, len_q, heads, offsets, attn_logits, ref_boxes, y);
+    else hipLaunchKernelGGL((msdeform_kernel<8, 4, float>), g8, dim3(256), 0, s, v, ldv, lv, b, len_q, heads, offsets, attn_logits, ref_boxes, y);
+  } else {
+    const unsigned short* v = (const unsigned short*)value;
+    if (d == 32) hipLaunchKernelGGL((msdeform_kernel<32, 4, unsigned short>), g32, dim3(256), 0, s, v, ldv, lv, b, len_q, heads, offsets, attn_logits, ref_boxes, y);
+    else hipLaunchKernelGGL((msdeform_kernel<8, 4, unsigned short>), g8, dim3(256), 0, s, v, ldv, lv, b, len_q, heads, offsets, attn_logits, ref_boxes, y);
+  }
   UPA_LAUNCH_CHECK();
   return UPA_OK;
+}
+
+extern "C" int upa_msdeform_attn(const float* value, const int32_t* shapes_hw, int n_levels, int b, int heads, int d,
+                                 const float* offsets, const float* attn_logits, const float* ref_boxes, int len_q,
+                                 int n_points, float* y, void* stream) {
+  return upa_msdeform_attn_strided(value, UPA_F32, heads * d, shapes_hw, n_levels, b, heads, d, offsets, attn_logits, ref_boxes,
+                                   len_q, n_points, y, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

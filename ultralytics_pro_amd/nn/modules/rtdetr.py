@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from ... import _lib as L
 from ...engine import runtime as R
-from .conv import PackedConv, fold_bn, version_key
+from .conv import PackedConv, fold_bn, hip_conv2d, version_key
 
 __all__ = ("RTDETRDecoder", "MLP", "MSDeformAttn", "DeformableTransformerDecoderLayer", "DeformableTransformerDecoder")
 
@@ -132,19 +132,23 @@ class MSDeformAttn(nn.Module):
         nn.init.xavier_uniform_(self.output_proj.weight.data)
         nn.init.constant_(self.output_proj.bias.data, 0.0)
 
-    def forward(self, query, refer_bbox, value, shapes_dev, bs, residual=None, key=None):
-        """query (bs*nq, C) rows, refer_bbox (bs*nq, 4), value = level-major token rows (sum_l bs*H_l*W_l, C)."""
+    def forward(self, query, refer_bbox, value, shapes_dev, bs, residual=None, key=None, projected=None):
+        """query (bs*nq, C) rows, refer_bbox (bs*nq, 4), value = level-major token rows (sum_l bs*H_l*W_l, C).
+        projected = (pointer, dtype code, row stride): this layer's value projection already computed (all layers' value
+        projections as one bf16 GEMM, RTDETRDecoder.forward in perf mode)."""
         nq = query.shape[0] // bs
-        val = linear(self, "value_proj", self.value_proj.weight, self.value_proj.bias, value, key=(key, "val"))
+        if projected is None:
+            val = linear(self, "value_proj", self.value_proj.weight, self.value_proj.bias, value, key=(key, "val"))
+            projected = (val.data_ptr(), L.UPA_F32, self.d_model)
         off = linear(self, "sampling_offsets", self.sampling_offsets.weight, self.sampling_offsets.bias, query,
                      key=(key, "off"))
         aw = linear(self, "attention_weights", self.attention_weights.weight, self.attention_weights.bias, query,
                     key=(key, "aw"))
         samp = _Rows.new(query.shape[0], self.d_model, query.device, key=(key, "samp"))
-        L.check(L.lib().upa_msdeform_attn(val.data_ptr(), shapes_dev["host_ptr"], self.n_levels, bs, self.n_heads,
-                                          self.d_model // self.n_heads, off.data_ptr(), aw.data_ptr(),
-                                          refer_bbox.data_ptr(), nq, self.n_points, samp.data_ptr(),
-                                          L.current_stream(query.device)), "msdeform_attn")
+        L.check(L.lib().upa_msdeform_attn_strided(projected[0], projected[1], projected[2], shapes_dev["host_ptr"], self.n_levels,
+                                                  bs, self.n_heads, self.d_model // self.n_heads, off.data_ptr(), aw.data_ptr(),
+                                                  refer_bbox.data_ptr(), nq, self.n_points, samp.data_ptr(),
+                                                  L.current_stream(query.device)), "msdeform_attn")
         return linear(self, "output_proj", self.output_proj.weight, self.output_proj.bias, samp, residual=residual,
                       key=(key, "out"))
 
@@ -167,7 +171,7 @@ class DeformableTransformerDecoderLayer(nn.Module):
         self.dropout4 = nn.Dropout(dropout)
         self.norm3 = nn.LayerNorm(d_model)
 
-    def forward(self, embed, refer_bbox, feats, shapes_dev, bs, query_pos, key=None):
+    def forward(self, embed, refer_bbox, feats, shapes_dev, bs, query_pos, key=None, projected=None):
         """embed, query_pos: (bs*nq, C) rows.  Returns the updated embed."""
         mha = self.self_attn
         e, nh = mha.embed_dim, mha.num_heads
@@ -191,7 +195,7 @@ class DeformableTransformerDecoderLayer(nn.Module):
         embed = layer_norm(self.norm1, tgt, key=(key, "n1"))
         # cross attention
         q2 = rows_add(embed, query_pos, key=(key, "q2"))
-        tgt = self.cross_attn(q2, refer_bbox, feats, shapes_dev, bs, residual=embed, key=(key, "ca"))
+        tgt = self.cross_attn(q2, refer_bbox, feats, shapes_dev, bs, residual=embed, key=(key, "ca"), projected=projected)
         embed = layer_norm(self.norm2, tgt, key=(key, "n2"))
         # FFN
         hdn = linear(self, "linear1", self.linear1.weight, self.linear1.bias, embed, L.ACT_RELU, key=(key, "f1"))
@@ -209,7 +213,9 @@ class DeformableTransformerDecoder(nn.Module):
         self.hidden_dim = hidden_dim
         self.eval_idx = eval_idx if eval_idx >= 0 else num_layers + eval_idx
 
-    def forward(self, embed, refer_logit, feats, shapes_dev, bs, bbox_head, score_head, pos_mlp):
+    def forward(self, embed, refer_logit, feats, shapes_dev, bs, bbox_head, score_head, pos_mlp, projected=None):
+        """projected: None, or (pointer, dtype code, row stride) of the value projections of ALL layers side by side
+        (layer i = columns [i*C, (i+1)*C))."""
         lib, dev = L.lib(), embed.device
         st = L.current_stream(dev)
         m = embed.shape[0]
@@ -218,7 +224,11 @@ class DeformableTransformerDecoder(nn.Module):
         output = embed
         for i, layer in enumerate(self.layers):
             pos = pos_mlp(refer, key=(id(self), "pos", i))
-            output = layer(output, refer, feats, shapes_dev, bs, pos, key=(id(self), i))
+            pj = None
+            if projected is not None:
+                es = 2 if projected[1] == L.UPA_BF16 else 4
+                pj = (projected[0] + i * self.hidden_dim * es, projected[1], projected[2])
+            output = layer(output, refer, feats, shapes_dev, bs, pos, key=(id(self), i), projected=pj)
             bbox = bbox_head[i](output, key=(id(self), "bb", i))
             refined = _Rows.new(m, 4, dev, key=(id(self), "ref", i + 1))
             L.check(lib.upa_box_refine(bbox.data_ptr(), refer.data_ptr(), refined.data_ptr(), m, st), "box_refine")
@@ -241,6 +251,7 @@ class RTDETRDecoder(nn.Module):
     anchors = torch.empty(0)
     valid_mask = torch.empty(0)
     dynamic = False
+    fuse_value_proj = True  # perf mode: one bf16 GEMM for the value projections of all decoder layers
 
     def __init__(self, nc=80, ch=(512, 1024, 2048), hd=256, nq=300, ndp=4, nh=8, ndl=6, d_ffn=1024, dropout=0.0,
                  act=nn.ReLU(), eval_idx=-1, nd=100, label_noise_ratio=0.5, box_noise_scale=1.0, learnt_init_query=False):
@@ -328,6 +339,7 @@ class RTDETRDecoder(nn.Module):
         # ---- _get_encoder_input (head.py:2117-2141): 1x1 conv (BN folded) per level into the level-major token matrix
         feats = _Rows.new(bs * T, hd, dev, key=(id(self), "feats"))
         row0 = 0
+        perf = any(t.dtype == torch.bfloat16 for t in x)
         for i, t in enumerate(x):
             if t.dtype == torch.bfloat16:
                 # bf16 backbone (perf mode): the decoder itself stays in float32 - its 300-query attention stack is < 5 %
@@ -375,8 +387,33 @@ class RTDETRDecoder(nn.Module):
         L.check(lib.upa_box_add_anchors(delta.data_ptr(), toks.data_ptr(), st["anchors"].data_ptr(), refer_logit.data_ptr(),
                                         bs * nq, st_), "add_anchors")
         # ---- decoder (transformer.py:719-773)
+        projected = None
+        if perf and self.fuse_value_proj:
+            # perf mode (bf16 backbone): the value projection of every decoder layer reads the SAME encoder tokens
+            # (transformer.py:536, value = feats), so the ndl projections are one (rows, ndl * C) x C GEMM on bf16 MFMA
+            # instead of ndl exact-f32 GEMMs of 134400 x 256 x 256 (6 x 254 us at bs 16); the deformable sampling reads the
+            # bf16 rows with the layer's column offset.  Everything that ranks or refines queries stays float32.
+            nl_ = self.num_decoder_layers if self.decoder.eval_idx < 0 else self.decoder.eval_idx + 1
+            fb = R.alloc_nhwc(1, hd, 1, bs * T, torch.bfloat16, dev, key=(id(self), "feats_bf16"))
+            vf = R.view_of(fb)
+            L.check(lib.upa_cast_view(feats.data_ptr(), L.UPA_F32, hd, vf.ptr, L.UPA_BF16, vf.ld, bs * T, hd, st_), "cast_feats")
+            cache = self.__dict__.setdefault("_pk_cache", {})
+            ws = [self.decoder.layers[i].cross_attn.value_proj for i in range(nl_)]
+            ver = version_key(*[t for m_ in ws for t in (m_.weight, m_.bias)])
+            hit = cache.get(("value_all", str(dev)))
+            if hit is not None and hit[0] == ver:
+                pk = hit[1]
+            else:
+                w = torch.cat([m_.weight.detach().float().cpu() for m_ in ws], 0).view(nl_ * hd, hd, 1, 1)
+                b = torch.cat([m_.bias.detach().float().cpu() for m_ in ws], 0)
+                pk = PackedConv(w, b, 1, dev, torch.bfloat16, False)
+                cache[("value_all", str(dev))] = (ver, pk)
+            va = R.alloc_nhwc(1, nl_ * hd, 1, bs * T, torch.bfloat16, dev, key=(id(self), "value_all"))
+            hip_conv2d(fb, pk, 1, 0, L.ACT_NONE, out=va)
+            vv = R.view_of(va)
+            projected = (vv.ptr, L.UPA_BF16, vv.ld)
         boxes, dec_scores = self.decoder(top_feat, refer_logit, feats, st, bs, self.dec_bbox_head, self.dec_score_head,
-                                         self.query_pos_head)
+                                         self.query_pos_head, projected=projected)
         y = R.alloc_plain((bs, nq, 4 + self.nc), torch.float32, dev, key=(id(self), "y"))
         L.check(lib.upa_rtdetr_output(boxes.data_ptr(), dec_scores.data_ptr(), y.data_ptr(), bs * nq, self.nc, st_),
                 "rtdetr_output")
