@@ -259,8 +259,11 @@ def main():
             cpu_baseline = run_cpu_baseline(args)
     if rank == 0:
         line = {
-            "metric": ("images/sec/GPU YOLOv8n 640x640 bs=32 (forward + Detect decode + NMS)" if args.model == "yolov8n" and args.batch == 32
-                       else f"images/sec/GPU {args.model} {args.imgsz}x{args.imgsz} bs={args.batch} "
+            # `value` is the whole-job total over n_gpus ranks of per-GPU batch 32 (the contract); the per-GPU figure of
+            # BASELINE.json's "images/sec/GPU" is `images_per_sec_per_gpu` = value / n_gpus
+            "metric": ("images/sec (whole job = n_gpus x per-GPU bs=32) YOLOv8n 640x640 (forward + Detect decode + NMS)"
+                       if args.model == "yolov8n" and args.batch == 32
+                       else f"images/sec (whole job) {args.model} {args.imgsz}x{args.imgsz} per-GPU bs={args.batch} "
                             f"(forward + {'RT-DETR decoder + postprocess' if rtdetr else 'Detect decode + NMS'})"),
             "value": round(value, 1),
             "unit": "images/s",

@@ -287,7 +287,17 @@ int upa_detection_loss(const float* const* feats, float* const* grads, const int
                        int max_gt, float gain_box, float gain_cls, float gain_dfl, float grad_scale, float* loss_items,
                        void* workspace, size_t workspace_bytes, void* stream);
 
-/* ---- HIP graph helpers (capture a launch sequence once, replay per batch) ------------------------------------- */
+/* ---- HIP graph helpers (capture a launch sequence once, replay per batch) -------------------------------------
+ * upa_graph_begin / _end bracket a stream capture of upa_* launches; upa_graph_launch replays the instantiated graph.
+ * Two rules for graphs that run concurrently with other graphs (several steps in flight on separate streams), both found
+ * as intermittent "Memory access fault by GPU" aborts on ROCm 7.2 ("Two rules for graphs in flight"):
+ *  1. NO MEMSET NODES: nothing inside a captured region may call hipMemsetAsync - with several graphs in flight a memset
+ *     node now and then left its target stale.  Every upa_* entry that needs zeroed counters zeroes them with a kernel
+ *     (upa_zero_words, csrc/common.h); callers must do the same in their own captured code.
+ *  2. NEVER REPLAY ON THE NULL STREAM: upa_graph_launch(exec, 0) is legal but replaying graphs with parallel branches on the
+ *     null stream and other graphs on created streams raised the fault rate from rare to most processes.  The Python
+ *     wrapper (engine/runtime.HipGraph.replay) therefore REDIRECTS a launch requested on the null stream to the graph's own
+ *     capture stream, ordered before and after by stream waits - callers of this C API should pass a created stream. */
 int upa_graph_begin(void* stream);
 int upa_graph_end(void* stream, void** graph_exec_out);
 int upa_graph_launch(void* graph_exec, void* stream);

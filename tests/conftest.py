@@ -15,6 +15,9 @@ import os  # noqa: E402
 
 os.environ.setdefault("UPA_PIPE_MIN_TILES", "1")
 os.environ.setdefault("UPA_PIPE_ALL", "1")
+# the fused Bottleneck kernel (csrc/conv_pair.hip) is dispatched for C = 32 only in production (the 64-channel form is slower
+# than two launches at 40x40); the parity tests run both widths
+os.environ.setdefault("UPA_NO_PAIR", "0")
 
 
 def pytest_configure(config):

@@ -187,9 +187,23 @@ def test_bottleneck_pair_kernel(case):
     buf.zero_()
     xin = buf[:, c:2 * c]
     xin.copy_(to_dev_nhwc(x, torch.bfloat16))
+    from ultralytics_pro_amd import _lib as L
+    from ultralytics_pro_amd.engine import runtime as R2
     with torch.no_grad():
         m.fuse_pair = True
-        y = to_cpu_nchw(m(xin, out=buf[:, 2 * c:]))
+        if c == 64:  # not dispatched by default (UPA_NO_PAIR=2): call the kernel directly so the 64-channel form stays covered
+            p1 = m.cv1._packed(m.cv1.conv, m.cv1.bn, DEV, torch.bfloat16, False)
+            p2 = m.cv2._packed(m.cv2.conv, m.cv2.bn, DEV, torch.bfloat16, False)
+            vx, vy = R2.view_of(xin), R2.view_of(buf[:, 2 * c:])
+            rc = L.lib().upa_bottleneck_pair(vx.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, p1.w.data_ptr(), p1.bias.data_ptr(),
+                                             p2.w.data_ptr(), p2.bias.data_ptr(), vy.ptr, vy.ld, int(sc), L.ACT_SILU, vx.dtype,
+                                             L.current_stream(DEV))
+            if rc == L.UPA_EUNSUPPORTED:
+                pytest.skip("64-channel pair disabled in this build (UPA_NO_PAIR)")
+            L.check(rc, "bottleneck_pair")
+            y = to_cpu_nchw(buf[:, 2 * c:])
+        else:
+            y = to_cpu_nchw(m(xin, out=buf[:, 2 * c:]))
         m.fuse_pair = False
         y2 = to_cpu_nchw(m(xin))
     assert y.shape == ref.shape

@@ -1,6 +1,6 @@
 // Bottleneck as ONE kernel: y = [x +] act(conv3x3_2(act(conv3x3_1(x) + b1)) + b2) with C -> C -> C channels (the C2f inner
 // blocks: ultralytics/nn/modules/block.py:644-668 with k = (3, 3), e = 1.0 as built by C2f, block.py:475; BN folded per
-// utils/torch_utils.py:236-266), bf16, C = 32 or 64.  The intermediate tensor never reaches HBM: it lives as a
+// utils/torch_utils.py:236-266), bf16, C = 32 (dispatched) or 64 (built and tested; slower than two launches at 40x40, see the host side).  The intermediate tensor never reaches HBM: it lives as a
 // (TH+2) x (TW+2) pixel tile in LDS, recomputed on a one-pixel ring around the output tile.
 //
 // Structure = conv_big.hip twice inside one workgroup (8 waves, 256 pixel slots, every output channel in the wave: WM 8 x WN 1):
@@ -252,8 +252,12 @@ extern "C" int upa_bottleneck_pair(const void* x, int n, int h, int w, int c, in
                                    const void* w2_packed, const float* b2, void* y, int ldy, int residual, int act, int dtype,
                                    void* stream) {
   UPA_CHECK_ARG(x && w1_packed && b1 && w2_packed && b2 && y && n > 0 && h > 0 && w > 0, "bottleneck_pair: bad args");
-  static const int off = pair_env("UPA_NO_PAIR", 0);
-  if (off || dtype != UPA_BF16 || act != UPA_ACT_SILU || !(c == 32 || c == 64) || ldx % 8 != 0 || ldy % 8 != 0 ||
+  // 1: never; 2: not for C = 64 (the default); 3: not for C = 32; 0: both.  Measured on MI355X (yolov8n bs 32, four steps in
+  // flight): C = 32 pairs at 80x80 28.7 us against 16.4 + 19.1 us as two launches, step 0.800 -> 0.773 ms; C = 64 pairs at
+  // 40x40 30.9-32.2 us against 11.5 + 12.2 us (288 one-per-CU workgroups = two rounds; 12 x 12 / 10 x 10 tiles no better),
+  // step 0.773 -> 0.790 ms - the 64-channel form stays available but is not dispatched
+  static const int off = pair_env("UPA_NO_PAIR", 2);
+  if (off == 1 || (off == 2 && c == 64) || (off == 3 && c == 32) || dtype != UPA_BF16 || act != UPA_ACT_SILU || !(c == 32 || c == 64) || ldx % 8 != 0 || ldy % 8 != 0 ||
       ((uintptr_t)x % 16) != 0 || ((uintptr_t)y % 16) != 0) {
     upa_set_error("bottleneck_pair: outside the fused form (bf16, SiLU, C = 32 | 64)");
     return UPA_EUNSUPPORTED;  // the caller runs the two convolutions separately
@@ -265,7 +269,8 @@ extern "C" int upa_bottleneck_pair(const void* x, int n, int h, int w, int c, in
   const int ck = c / 32;
   const int pb = ck * 64;
   // output tile TH x TW with (TH+2)(TW+2) <= 256 mid pixels: fewest tiles per image, then the squarest
-  static const int fth = pair_env("UPA_PAIR_TH", 0), ftw = pair_env("UPA_PAIR_TW", 0);
+  static const int fth64 = pair_env("UPA_PAIR_T64", 0), fth32 = pair_env("UPA_PAIR_T32", 0);  // square tile edge per width
+  const int fth = c == 64 ? fth64 : fth32, ftw = fth;
   long best = -1;
   for (int tw = 2; tw <= 62 && tw <= ((w + 1) & ~1); ++tw) {
     int th = 256 / (tw + 2) - 2;

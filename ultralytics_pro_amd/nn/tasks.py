@@ -178,7 +178,10 @@ class BaseModel(nn.Module):
 
     def forward(self, x, *args, **kwargs):
         if isinstance(x, dict):
-            raise L.UpaError("training / loss forward is not on the HIP path yet (SURVEY §8f rank 2)")
+            # the reference computes the loss here (tasks.py:1003-1004); on the HIP path the train-mode forward, the loss and
+            # the explicit backward live together in engine/trainer.py (no torch autograd), so a batch dict is its input
+            raise L.UpaError("a batch dict is a training step: use ultralytics_pro_amd.engine.trainer.DetectionTrainer(model)"
+                             ".step(batch['img'], batch) - forward, v8DetectionLoss and backward run there as HIP kernels")
         return self.predict(x, *args, **kwargs)
 
     def predict(self, x, profile=False, visualize=False, augment=False, embed=None):
