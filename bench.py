@@ -459,7 +459,7 @@ def run_cpu_train_baseline(args):
     from ultralytics_pro_amd.utils import procedural as P
 
     host_cores = os.cpu_count() or 1
-    cores = min(host_cores, args.cpu_threads)
+    cores = min(host_cores, args.cpu_threads or 32)  # torch CPU convs regress when oversubscribed (see run_cpu_baseline)
     torch.set_num_threads(cores)
     m = ot.DetectionModel(args.model + ".yaml")
     P.apply_procedural_weights(m)

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Regenerates the numbers profiles/ holds (run on the GPU box; outputs under gpurun_out/final/, copied into profiles/ by hand).
+# Regenerates the numbers profiles/ holds (run on the GPU box; outputs under gpurun_out/final_r02/, copied into profiles/ by hand).
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/final
+O=$R/gpurun_out/final_r02
 mkdir -p $O
 cd $R
 python bench.py > $O/bench_default.json 2> $O/bench_default.err

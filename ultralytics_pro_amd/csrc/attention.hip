@@ -12,25 +12,31 @@
 // (max, sum, out[d]) online softmax in registers, so the L x L energy matrix never exists in memory.
 #include "common.h"
 
-template <typename T, int D>
-__global__ __launch_bounds__(128) void mhsa_kernel(const char* q, const char* k, const char* v, int ld, int L, int heads,
-                                                   const char* res, int ldr, char* y, int ldy, float scale) {
+// Work split: a workgroup = 64 queries x KP key partitions (KP waves): wave `part` walks keys [part*L/KP, (part+1)*L/KP) for
+// the 64 queries (one per lane) with the online softmax above; the KP partial states (max, sum, out[D]) are merged through
+// LDS by wave 0 (exact: out = sum_p out_p * exp(m_p - m) / sum_p l_p * exp(m_p - m)).  With one lane walking all L keys
+// (the first form) the RT-DETR self-attention (300 queries, 128 (image, head) pairs) ran 202 us on 384 two-wave workgroups.
+template <typename T, int D, int KP>
+__global__ __launch_bounds__(64 * KP) void mhsa_kernel(const char* q, const char* k, const char* v, int ld, int L, int heads,
+                                                      const char* res, int ldr, char* y, int ldy, float scale) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
   T* ks = reinterpret_cast<T*>(sm);  // [L][D]
   T* vs = ks + (size_t)L * D;        // [L][D]
+  float* part_sm = reinterpret_cast<float*>(vs + (size_t)L * D);  // [KP][D + 2][64] partial states (lane-major: conflict free)
+  constexpr int NT = 64 * KP;
   const int b = blockIdx.x / heads, h = blockIdx.x % heads;
   const size_t pix0 = (size_t)b * L;
   constexpr int E = 16 / sizeof(T);
   if constexpr (D % E == 0) {
     constexpr int G = D / E;  // 16-byte groups per row
-    for (int i = threadIdx.x; i < L * G; i += 128) {
+    for (int i = threadIdx.x; i < L * G; i += NT) {
       const int p = i / G, gq = i % G;
       const size_t off = ((pix0 + p) * ld + h * D + gq * E) * sizeof(T);
       reinterpret_cast<u32x4*>(ks)[i] = *reinterpret_cast<const u32x4*>(k + off);
       reinterpret_cast<u32x4*>(vs)[i] = *reinterpret_cast<const u32x4*>(v + off);
     }
   } else {  // tiny heads (unit-test sized): element-wise staging
-    for (int i = threadIdx.x; i < L * D; i += 128) {
+    for (int i = threadIdx.x; i < L * D; i += NT) {
       const int p = i / D, e = i % D;
       const size_t off = ((pix0 + p) * ld + h * D + e) * sizeof(T);
       ks[i] = *reinterpret_cast<const T*>(k + off);
@@ -38,11 +44,12 @@ __global__ __launch_bounds__(128) void mhsa_kernel(const char* q, const char* k,
     }
   }
   __syncthreads();
-  const int p = blockIdx.y * 128 + threadIdx.x;
-  if (p >= L) return;
+  const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int p = blockIdx.y * 64 + lane;
+  const bool valid = p < L;
   float qr[D], o[D];
   {
-    const T* qp = reinterpret_cast<const T*>(q + ((pix0 + p) * ld + h * D) * sizeof(T));
+    const T* qp = reinterpret_cast<const T*>(q + ((pix0 + (valid ? p : 0)) * ld + h * D) * sizeof(T));
 #pragma unroll
     for (int i = 0; i < D; ++i) {
       qr[i] = ElemTraits<T>::load(qp + i) * scale;  // nn.MultiheadAttention scales q; BoT3's MHSA passes 1.0
@@ -50,7 +57,9 @@ __global__ __launch_bounds__(128) void mhsa_kernel(const char* q, const char* k,
     }
   }
   float m = -INFINITY, l = 0.f;
-  for (int j = 0; j < L; ++j) {
+  const int per = (L + KP - 1) / KP;
+  const int j0 = part * per, j1 = min(L, j0 + per);
+  for (int j = j0; j < j1; ++j) {
     const T* kr = ks + (size_t)j * D;
     float s = 0.f;
 #pragma unroll
@@ -64,6 +73,32 @@ __global__ __launch_bounds__(128) void mhsa_kernel(const char* q, const char* k,
     for (int i = 0; i < D; ++i) o[i] = fmaf(pj, ElemTraits<T>::load(vr + i), o[i] * alpha);
     m = mn;
   }
+  if constexpr (KP > 1) {
+    float* mine = part_sm + (size_t)part * (D + 2) * 64;
+    mine[lane] = m;
+    mine[64 + lane] = l;
+#pragma unroll
+    for (int i = 0; i < D; ++i) mine[(2 + i) * 64 + lane] = o[i];
+    __syncthreads();
+    if (part != 0) return;
+    // merge in partition order (deterministic); a partition without keys carries m = -inf, l = 0
+    float mm = m;
+#pragma unroll
+    for (int q_ = 1; q_ < KP; ++q_) mm = fmaxf(mm, part_sm[(size_t)q_ * (D + 2) * 64 + lane]);
+    const float a0 = expf(m - mm);
+    l *= a0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) o[i] *= a0;
+#pragma unroll
+    for (int q_ = 1; q_ < KP; ++q_) {
+      const float* ot = part_sm + (size_t)q_ * (D + 2) * 64;
+      const float aq = expf(ot[lane] - mm);
+      l += ot[64 + lane] * aq;
+#pragma unroll
+      for (int i = 0; i < D; ++i) o[i] = fmaf(ot[(2 + i) * 64 + lane], aq, o[i]);
+    }
+  }
+  if (!valid) return;
   const float inv = 1.0f / l;
   T* yp = reinterpret_cast<T*>(y + ((pix0 + p) * ldy + h * D) * sizeof(T));
   const T* rp = res ? reinterpret_cast<const T*>(res + ((pix0 + p) * ldr + h * D) * sizeof(T)) : nullptr;
@@ -79,15 +114,16 @@ __global__ __launch_bounds__(128) void mhsa_kernel(const char* q, const char* k,
 template <typename T, int D>
 static int launch_mhsa(const void* q, const void* k, const void* v, int ld, int n, int hw, int heads, const void* residual,
                        int ldr, void* y, int ldy, float scale, hipStream_t s) {
-  const size_t lds = (size_t)2 * hw * D * sizeof(T);
-  if (lds > 150 * 1024) {
+  constexpr int KP = 4;
+  const size_t lds = (size_t)2 * hw * D * sizeof(T) + (size_t)KP * (D + 2) * 64 * sizeof(float);
+  if (lds > 158 * 1024) {
     upa_set_error("mhsa: %d keys x %d dims do not fit LDS", hw, D);
     return UPA_EUNSUPPORTED;
   }
-  dim3 grid((unsigned)(n * heads), (unsigned)cdiv(hw, 128));
-  auto kern = mhsa_kernel<T, D>;
-  (void)upa_full_lds<mhsa_kernel<T, D>>();
-  hipLaunchKernelGGL(kern, grid, dim3(128), lds, s, (const char*)q, (const char*)k, (const char*)v, ld, hw, heads,
+  dim3 grid((unsigned)(n * heads), (unsigned)cdiv(hw, 64));
+  auto kern = mhsa_kernel<T, D, KP>;
+  (void)upa_full_lds<mhsa_kernel<T, D, KP>>();
+  hipLaunchKernelGGL(kern, grid, dim3(64 * KP), lds, s, (const char*)q, (const char*)k, (const char*)v, ld, hw, heads,
                      (const char*)residual, ldr, (char*)y, ldy, scale);
   UPA_LAUNCH_CHECK();
   return UPA_OK;
