@@ -518,7 +518,7 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
         var = L.lib().upa_conv_variant(n, h, w, cin, pk.cout, pk.k, stride, pad, code)
         if (var >> 23) & 1:  # large-tile LDS-shared-operand kernel (conv_big.hip): <KS, STRIDE, WM, WN, MT, NT>
             ntb, mt = (var >> 4) & 15, 4 if (var & 15) == 2 else 2
-            wm, wn, nt = (8, 1, 4) if ntb == 4 else (4, 2, ntb // 2)
+            wm, wn, nt = (8, 1, 4) if (ntb == 4 and mt == 4) else (4, 2, ntb // 2)
             if ntb == 4:
                 mt = 2
             return "void conv_big_kernel<%d, %d, %d, %d, %d, %d>(BigParams)" % (pk.k, stride, wm, wn, mt, nt)

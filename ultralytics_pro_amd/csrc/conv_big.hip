@@ -20,7 +20,7 @@
 //   * tile shape chosen per layer on the host (TW need not be a power of two: 20 x 12 for 20x20 maps, 40 x 6 for 40x40), the
 //     pixel -> (row, column) split is done once per lane with a multiply-high.
 // Variants <WM, WN, MT, NT> (WM * WN = 8 waves): 4,2,4,4 = 256 px x 128 ch; 4,2,2,4 = 128 px x 128 ch (few-pixel layers: twice
-// the workgroups); 4,2,4,3 / 4,2,2,3 = x 96 ch (Cout 80 / 96); 8,1,2,4 = 256 px x 64 ch.
+// the workgroups); 4,2,4,3 / 4,2,2,3 = x 96 ch (Cout 80 / 96); 8,1,2,4 = 256 px x 64 ch; 4,2,2,2 = 128 px x 64 ch.
 // Epilogue straight from the accumulators (bias, SiLU by v_exp_f32 / v_rcp_f32, bf16 pack, v_permlane16_swap -> 16-byte
 // NHWC stores, residual read with the same shape), as conv.hip.
 #include <stdlib.h>
@@ -347,14 +347,17 @@ bool upa_conv_big_eligible(int n, int h, int w, int cin, int ldx, int cout, int 
 int upa_conv_big_launch(BigParams p, int query_only, int* variant, void* stream) {
   p.KTT = (p.Cin + 31) / 32;
   p.NTn = (p.Cout + 15) / 16;
-  // workgroup columns: 128 channels, 96 for Cout in (64, 96], 64 for Cout <= 64
-  const int ntb = p.NTn <= 4 ? 4 : (p.NTn <= 6 ? 6 : 8);
+  // workgroup columns: 128 channels, 96 for Cout in (64, 96], 64 for Cout <= 64 - and 64 for wider layers whose 128-pixel x
+  // 128-channel workgroups would still be fewer than the CUs (20x20 maps: twice the workgroups, each with half the weights)
+  int ntb = p.NTn <= 4 ? 4 : (p.NTn <= 6 ? 6 : 8);
   const long px = (long)p.N * p.OH * p.OW;
+  static const int split = big_env("UPA_CONV_BIG_SPLIT", 1);
+  if (split && ntb == 8 && p.NTn % 4 == 0 && (px + 127) / 128 * cdiv(p.NTn, 8) < big_num_cu()) ntb = 4;
   const int cols = cdiv(p.NTn, ntb);
   // 256-pixel workgroups unless that leaves most of the chip idle (fewer workgroups than CUs): then 128-pixel ones
   int bm = 256;
-  if (ntb != 4 && (px + 255) / 256 * cols < big_num_cu()) bm = 128;
-  if (const int f = big_env("UPA_CONV_BIG_BM", 0); f == 128 || f == 256) bm = ntb == 4 ? 256 : f;
+  if ((px + 255) / 256 * cols < big_num_cu()) bm = 128;
+  if (const int f = big_env("UPA_CONV_BIG_BM", 0); f == 128 || f == 256) bm = f;
   if (variant) *variant = (1 << 23) | (ntb << 4) | (bm >> 7);
   if (query_only) return UPA_OK;
   if (p.KS == 1) {  // pointwise: an NHWC view has one uniform pixel stride - flatten (n, h, w) into one row
@@ -376,5 +379,5 @@ int upa_conv_big_launch(BigParams p, int query_only, int* variant, void* stream)
   hipStream_t s = (hipStream_t)stream;
   if (ntb == 8) return bm == 256 ? big_launch_ks<4, 2, 4, 4>(p, lds, s) : big_launch_ks<4, 2, 2, 4>(p, lds, s);
   if (ntb == 6) return bm == 256 ? big_launch_ks<4, 2, 4, 3>(p, lds, s) : big_launch_ks<4, 2, 2, 3>(p, lds, s);
-  return big_launch_ks<8, 1, 2, 4>(p, lds, s);
+  return bm == 256 ? big_launch_ks<8, 1, 2, 4>(p, lds, s) : big_launch_ks<4, 2, 2, 2>(p, lds, s);
 }
