@@ -121,6 +121,18 @@ int upa_detect_tail(const void* x, int n, int h, int w, int cin, int ldx, const 
                     int kind, int nc, float stride_px, float* y, int a_total, int a0, void* raw, int ldraw, int dtype,
                     void* stream);
 
+/* The whole back half of a Detect branch in one launch (bf16): second 3x3 conv (BN + SiLU folded) -> final 1x1 conv -> that
+ * branch's half of the decode, the intermediate maps never leaving the registers.      head.py:94-100 (cv2/cv3), :116-126,
+ * :151-169.  kind 1 = box branch (c = 64 = 4 * reg_max 16), 2 = class branch (c <= 96, nc <= 96).  With CP = 64 / 96:
+ * w3_packed / b3 = upa_pack_conv_weight of the 3x3 conv as c -> CP (zero filters and biases appended);
+ * wt_packed = upa_pack_tail_weight(cout = CP, cin = CP) of the zero-padded 1x1 matrix, bt = CP biases.
+ * Returns UPA_EUNSUPPORTED outside that form (callers then run conv2d + upa_detect_tail). */
+size_t upa_tail_packed_weight_bytes(int cout, int cin);
+int upa_pack_tail_weight(const float* w, int cout, int cin, void* out);
+int upa_detect_branch_tail(const void* x, int n, int h, int w, int c, int ldx, const void* w3_packed, const float* b3,
+                           const void* wt_packed, const float* bt, int kind, int nc, float stride_px, float* y, int a_total,
+                           int a0, int dtype, void* stream);
+
 
 /* ---- NMS ----------------------------------------------------------------------------------------------------------
  * Batched non_max_suppression over pred (b, 4+nc, a) f32 xywh+scores -> out (b, max_det, 6) f32

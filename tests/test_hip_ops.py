@@ -451,6 +451,74 @@ def test_detect_tail_fused_decode_vs_oracle(nc, shape):
             assert (r - raw).abs().max().item() <= 0.04 * raw.abs().max().item() / 4  # bf16-rounded logits
 
 
+@pytest.mark.parametrize("nc,c3,shape", [(80, 80, (2, 13, 21)), (80, 80, (3, 40, 40)), (20, 64, (1, 9, 16)), (91, 96, (2, 7, 5)),
+                                         (80, 80, (20, 80, 80))],
+                         ids=["nc80_13x21", "nc80_40x40", "nc20_c64", "nc91_c96", "nc80_80x80_256px_tiles"])
+def test_detect_branch_tail_vs_unfused_and_oracle(nc, c3, shape):
+    """`upa_detect_branch_tail` (bf16): [conv3x3 + BN + SiLU -> 1x1 conv -> decode half] of a Detect branch in one launch
+    (head.py:94-100, 116-126, 151-169).  Checked (a) against the two-launch HIP path (conv2d, then upa_detect_tail) that
+    rounds the same intermediate to bf16 - only the k order of the 1x1 MFMA differs - and (b) against the oracle's
+    conv -> SiLU -> conv -> Detect._inference in f32 on the same bf16-rounded inputs and weights."""
+    from tests.hip_utils import DEV, bf16_round, to_dev_nhwc, unit_input
+    from ultralytics_pro_amd import _lib as L
+    from ultralytics_pro_amd.engine import runtime as R
+    from ultralytics_pro_amd.nn.modules.conv import PackedConv, hip_conv2d
+    n, h, w = shape
+    ncp = (nc + 7) // 8 * 8
+    a0, extra = 19, 5
+    a_total = a0 + h * w + extra
+    y = torch.full((n, 4 + nc, a_total), -7.0, device=DEV)
+    y2 = torch.full((n, 4 + nc, a_total), -7.0, device=DEV)
+    raws = []
+    for kind, c, cout1 in ((1, 64, 64), (2, c3, nc)):
+        cp = 64 if kind == 1 else 96
+        x = bf16_round(unit_input(f"bt_x{kind}{nc}", (n, c, h, w), -1.5, 1.5))
+        w3 = bf16_round(unit_input(f"bt_w3{kind}{nc}", (c, c, 3, 3), -0.12, 0.12))
+        b3 = unit_input(f"bt_b3{kind}{nc}", (c,), -0.5, 0.5)
+        w1 = bf16_round(unit_input(f"bt_w1{kind}{nc}", (cout1, c, 1, 1), -0.5, 0.5))
+        b1 = unit_input(f"bt_b1{kind}{nc}", (cout1,), -2, 1)
+        hmid = bf16_round(torch.nn.functional.silu(torch.nn.functional.conv2d(x, w3, b3, padding=1)))
+        raws.append(torch.nn.functional.conv2d(hmid, w1, b1))
+        xd = to_dev_nhwc(x, torch.bfloat16)
+        vx = R.view_of(xd)
+        # fused launch
+        w3p = torch.cat([w3, torch.zeros(cp - c, c, 3, 3)], 0)
+        b3p = torch.cat([b3, torch.zeros(cp - c)], 0)
+        pk3 = PackedConv(w3p, b3p, 3, DEV, torch.bfloat16, False)
+        wt = torch.zeros(cp, cp)
+        wt[:cout1, :c] = w1.reshape(cout1, c)
+        bt = torch.zeros(cp)
+        bt[:cout1] = b1
+        host = torch.empty(L.lib().upa_tail_packed_weight_bytes(cp, cp), dtype=torch.uint8)
+        L.check(L.lib().upa_pack_tail_weight(wt.data_ptr(), cp, cp, host.data_ptr()), "pack_tail_weight")
+        wtd, btd = host.to(DEV), bt.to(DEV)
+        L.check(L.lib().upa_detect_branch_tail(vx.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, pk3.w.data_ptr(), pk3.bias.data_ptr(),
+                                               wtd.data_ptr(), btd.data_ptr(), kind, nc, 16.0, y.data_ptr(), a_total, a0,
+                                               L.UPA_BF16, L.current_stream(DEV)), "detect_branch_tail")
+        # two launches
+        pk3u = PackedConv(w3, b3, 3, DEV, torch.bfloat16, False)
+        t = hip_conv2d(xd, pk3u, 1, 1, L.ACT_SILU)
+        cout = 64 if kind == 1 else ncp
+        w1p = torch.cat([w1, torch.zeros(cout - cout1, c, 1, 1)], 0)
+        b1p = torch.cat([b1, torch.zeros(cout - cout1)], 0)
+        pk1 = PackedConv(w1p, b1p, 1, DEV, torch.bfloat16, False)
+        vt = R.view_of(t)
+        L.check(L.lib().upa_detect_tail(vt.ptr, vt.n, vt.h, vt.w, vt.c, vt.ld, pk1.w.data_ptr(), pk1.bias.data_ptr(), cout, kind, nc,
+                                        16.0, y2.data_ptr(), a_total, a0, None, 0, L.UPA_BF16, L.current_stream(DEV)), "detect_tail")
+    torch.cuda.synchronize()
+    got, two = y[:, :, a0:a0 + h * w].cpu(), y2[:, :, a0:a0 + h * w].cpu()
+    d = (got - two).abs()
+    assert d[:, :4].max().item() <= 2e-3 and d[:, 4:].max().item() <= 1e-5, (d[:, :4].max().item(), d[:, 4:].max().item())
+    assert float(y[:, :, :a0].min()) == -7.0 and float(y[:, :, a0 + h * w:].max()) == -7.0
+    oref = om.Detect(nc, (64,)).eval()
+    oref.stride = torch.tensor([16.0])
+    ref = oref._inference([torch.cat(raws, 1)])
+    d = (got - ref).abs()
+    # a bf16 rounding of the intermediate that falls the other way (f32 summation order) moves a logit by <= 2^-8 * |h| * |w|
+    assert d[:, :4].max().item() <= 0.5 and d[:, :4].mean().item() <= 5e-3 and d[:, 4:].max().item() <= 1e-2, \
+        (d[:, :4].max().item(), d[:, :4].mean().item(), d[:, 4:].max().item())
+
+
 def test_rtdetr_decoder_small_matches_golden(golden_dir):
     """RTDETRDecoder(hd=32, nq=10, nh=4, ndl=2, d_ffn=64) on three tiny maps vs the reference's recorded output."""
     from tests.hip_utils import DEV, bn_fix, to_dev_nhwc, unit_input

@@ -44,9 +44,13 @@ __device__ __forceinline__ float big_act(float v) {
 }
 }  // namespace
 
-template <int KS, int STRIDE, int WM, int WN, int MT, int NT>
+// TAIL != 0 (Detect branches, WN = 1 so that a wave holds every channel of its pixels): the SiLU'd result of this 3x3 conv is
+// not stored but fed, from the accumulators, into the branch's final 1x1 conv and that conv's half of the decode - see the
+// tail section below.  TAIL 1 = box branch (DFL + dist2bbox), 2 = class branch (sigmoid).
+template <int KS, int STRIDE, int WM, int WN, int MT, int NT, int TAIL = 0>
 __global__ __launch_bounds__(512, 4) void conv_big_kernel(const BigParams p) {
   static_assert(WM * WN == 8, "8 waves per workgroup");
+  static_assert(TAIL == 0 || (WN == 1 && (NT % 2) == 0), "a tail needs every channel of a pixel in one wave");
   constexpr int NTB = WN * NT;            // n-tiles per workgroup
   constexpr int WBUF = 2 * NTB * 1024;    // one (tap, chunk) weight slab: 2 k-tiles x NTB n-tiles x 1 KiB
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -169,6 +173,65 @@ __global__ __launch_bounds__(512, 4) void conv_big_kernel(const BigParams p) {
     }
   }
 
+  if constexpr (TAIL != 0) {
+    // ---- Detect branch tail (head.py:94-100, 116-126, 151-169): h = SiLU(conv3x3 + b) never leaves the registers.
+    // D layout: lane (g, r) holds channels 16j + 4g .. + 3 of pixel r; two neighbouring n-tiles (2s, 2s + 1) packed to bf16
+    // ARE the B operand of a v_mfma_f32_16x16x32_bf16 k-step, in the k order (element e < 4: channel 32s + 4g + e, e >= 4:
+    // 32s + 16 + 4g + e - 4) - the 1x1 weights are packed on the host in the same order (upa_pack_tail_weight), so the final
+    // 1x1 conv is NT/2 k-steps x NT n-tiles of MFMA per m-tile straight from the accumulators: no LDS round trip, no store
+    // of the (B,H,W,64|80) intermediate, no third launch.  Its output feeds the decode epilogue of detect_epi.h.
+    f32x4 bv[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bv[j] = *reinterpret_cast<const f32x4*>(p.bias + j * 16 + g * 4);  // padded to NT * 16 by the host
+    f32x4 acc2[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s2 = 0; s2 < NT / 2; ++s2) {
+      u32x4 hb[MT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        float v0[4], v1[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          v0[q] = big_act<UPA_ACT_SILU>(acc[i][2 * s2][q] + bv[2 * s2][q]);
+          v1[q] = big_act<UPA_ACT_SILU>(acc[i][2 * s2 + 1][q] + bv[2 * s2 + 1][q]);
+        }
+        hb[i] = u32x4{pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])};
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const u32x4 a2 = *reinterpret_cast<const u32x4*>(p.tw + ((size_t)(s2 * NT + j) * 64 + lane) * 16);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+          acc2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a2),
+                                                               *reinterpret_cast<const bf16x8*>(&hb[i]), acc2[i][j], 0, 0, 0);
+      }
+    }
+    f32x4 tbv[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) tbv[j] = *reinterpret_cast<const f32x4*>(p.tb + j * 16 + g * 4);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int oy = oy0 + pty[i], ox = ox0 + ptx[i];
+      const bool pok = pty[i] < p.TH && oy < p.OH && ox < p.OW;
+      const int pix = pok ? (n * p.OH + oy) * p.OW + ox : 0;
+      if constexpr (TAIL == 1) {
+        static_assert(TAIL != 1 || NT == 4, "box branch = 4 sides x 16 bins");
+        f32x4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = acc2[i][j] + tbv[j];
+        upa_detect_box_store(p.de, v, pix, pok, g);
+      } else {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) upa_detect_cls_store(p.de, acc2[i][j] + tbv[j], j, pix, pok, g);
+      }
+    }
+    return;
+  }
+
   // ---- epilogue from the accumulators (as conv.hip): lane (g, r) holds channels 16j + 4g .. + 3 of pixel r of m-tile i;
   // v_permlane16_swap pairs the quads of two neighbouring n-tiles so every lane stores 16 contiguous bytes
   const int cw = (blockIdx.y * NTB + wn * NT) * 16;  // first channel of this wave
@@ -280,12 +343,12 @@ bool big_pick_tile(BigParams& p, int bm, int ntb, size_t lds_cap) {
   return best >= 0;
 }
 
-template <int KS, int STRIDE, int WM, int WN, int MT, int NT>
+template <int KS, int STRIDE, int WM, int WN, int MT, int NT, int TAIL = 0>
 int big_launch_inst(const BigParams& p, size_t lds, hipStream_t s) {
   constexpr int NTB = WN * NT;
   const dim3 grid((unsigned)((long)p.tilesX * p.tilesY * p.N), (unsigned)cdiv(p.NTn, NTB));
-  auto kern = conv_big_kernel<KS, STRIDE, WM, WN, MT, NT>;
-  if (hipError_t e = upa_full_lds<conv_big_kernel<KS, STRIDE, WM, WN, MT, NT>>(); e != hipSuccess) {
+  auto kern = conv_big_kernel<KS, STRIDE, WM, WN, MT, NT, TAIL>;
+  if (hipError_t e = upa_full_lds<conv_big_kernel<KS, STRIDE, WM, WN, MT, NT, TAIL>>(); e != hipSuccess) {
     upa_set_error("conv_big: cannot raise LDS limit: %s", hipGetErrorString(e));
     return UPA_ELAUNCH;
   }
@@ -301,6 +364,81 @@ int big_launch_ks(const BigParams& p, size_t lds, hipStream_t s) {
   return big_launch_inst<3, 1, WM, WN, MT, NT>(p, lds, s);
 }
 }  // namespace
+
+// Packed weights of a Detect branch's final 1x1 conv for the tail of conv_big_kernel: [k-step s][n-tile j][lane (g, r)][8 bf16],
+// element e of lane (g, r) = W[co = 16j + r][ci = 32s + (e < 4 ? 4g + e : 16 + 4g + e - 4)] - the k order in which two packed
+// accumulator tiles present their channels as an MFMA B operand.  cin / cout are zero-padded to 32 / 16.
+extern "C" size_t upa_tail_packed_weight_bytes(int cout, int cin) {
+  return (size_t)cdiv(cin, 32) * cdiv(cout, 16) * 1024;
+}
+
+static inline unsigned short big_host_bf16(float f) {
+  unsigned u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (unsigned short)((u >> 16) | 0x40);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+extern "C" int upa_pack_tail_weight(const float* w, int cout, int cin, void* out) {
+  UPA_CHECK_ARG(w && out && cout > 0 && cin > 0, "pack_tail_weight: bad args");
+  const int ks = cdiv(cin, 32), nt = cdiv(cout, 16);
+  unsigned short* o = (unsigned short*)out;
+  size_t idx = 0;
+  for (int s = 0; s < ks; ++s)
+    for (int j = 0; j < nt; ++j)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int g = lane >> 4, r = lane & 15;
+        const int co = 16 * j + r;
+        for (int e = 0; e < 8; ++e, ++idx) {
+          const int ci = 32 * s + (e < 4 ? 4 * g + e : 16 + 4 * g + e - 4);
+          o[idx] = big_host_bf16((co < cout && ci < cin) ? w[(size_t)co * cin + ci] : 0.f);
+        }
+      }
+  return UPA_OK;
+}
+
+// Second 3x3 conv of a Detect branch + the final 1x1 conv + that branch's half of the decode in ONE launch (bf16).
+// x: (n, h, w, c) NHWC view, c = 64 (box branch, kind 1) or <= 96 (class branch, kind 2).  With CP = 64 (box) / 96 (class):
+// w3 / b3 = the 3x3 conv packed by upa_pack_conv_weight as c -> CP (BN folded, zero filters / biases appended up to CP);
+// wt = the 1x1 conv as upa_pack_tail_weight(cout = CP, cin = CP) of the zero-padded matrix, bt = its CP biases.
+extern "C" int upa_detect_branch_tail(const void* x, int n, int h, int w, int c, int ldx, const void* w3_packed, const float* b3,
+                                      const void* wt_packed, const float* bt, int kind, int nc, float stride_px, float* y,
+                                      int a_total, int a0, int dtype, void* stream) {
+  UPA_CHECK_ARG(x && w3_packed && b3 && wt_packed && bt && y, "detect_branch_tail: null pointer");
+  UPA_CHECK_ARG(kind == 1 || kind == 2, "detect_branch_tail: kind must be 1 (box) or 2 (class)");
+  UPA_CHECK_ARG(n > 0 && h > 0 && w > 0 && a0 >= 0 && a0 + h * w <= a_total, "detect_branch_tail: level does not fit a_total");
+  static const int off = big_env("UPA_NO_BRANCH_TAIL", 0);
+  const int ntb = kind == 1 ? 4 : 6;
+  if (off || dtype != UPA_BF16 || c % 8 != 0 || ldx % 8 != 0 || h * w < 2 || w < 2 || (kind == 1 && c != 64) ||
+      (kind == 2 && (c > 96 || nc > 96)) || ((uintptr_t)x % 16) != 0) {
+    upa_set_error("detect_branch_tail: outside the fused form (bf16; box c = 64; class c <= 96, nc <= 96)");
+    return UPA_EUNSUPPORTED;
+  }
+  BigParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = (const char*)x; p.w = (const char*)w3_packed; p.bias = b3; p.tw = (const char*)wt_packed; p.tb = bt;
+  p.N = n; p.H = h; p.W = w; p.Cin = c; p.ldx = ldx; p.OH = h; p.OW = w; p.Cout = ntb * 16; p.KS = 3; p.stride = 1; p.pad = 1;
+  p.act = UPA_ACT_SILU;
+  p.KTT = cdiv(c, 32);
+  p.NTn = ntb;
+  p.de.y = y; p.de.a_total = a_total; p.de.a0 = a0; p.de.HW = h * w; p.de.W = w;
+  p.de.magicHW = upa_magic_div(h * w); p.de.magicW = upa_magic_div(w);
+  p.de.nc = nc; p.de.stride_px = stride_px;
+  const long px = (long)n * h * w;
+  const int bm = (px + 255) / 256 < big_num_cu() ? 128 : 256;  // 128-pixel workgroups (one m-tile per wave) on the small levels
+  if (!big_pick_tile(p, bm, ntb, 80 * 1024 - 512) && !big_pick_tile(p, bm, ntb, 160 * 1024)) return UPA_EUNSUPPORTED;
+  p.tilesX = cdiv(p.OW, p.TW);
+  p.tilesY = cdiv(p.OH, p.TH);
+  p.IH = p.TH + 2; p.IW = p.TW + 2;
+  p.magicTW = (unsigned)((0x100000000ULL + p.TW - 1) / p.TW);
+  p.magicIW = (unsigned)((0x100000000ULL + p.IW - 1) / p.IW);
+  const size_t halo = (((size_t)p.IH * p.IW * 8 + 63) & ~(size_t)63) * 16;
+  const size_t lds = halo + 2 * (size_t)(2 * ntb * 1024) + 256;
+  hipStream_t s = (hipStream_t)stream;
+  if (kind == 1) return bm == 256 ? big_launch_inst<3, 1, 8, 1, 2, 4, 1>(p, lds, s) : big_launch_inst<3, 1, 8, 1, 1, 4, 1>(p, lds, s);
+  return bm == 256 ? big_launch_inst<3, 1, 8, 1, 2, 6, 2>(p, lds, s) : big_launch_inst<3, 1, 8, 1, 1, 6, 2>(p, lds, s);
+}
 
 // Dispatch mode of the large-tile kernel: 0 = never, 1 = by the size rule of upa_conv_big_eligible (default), 2 = every
 // shape the kernel can run (parity tests, tools/bench_conv.py).  Initialised from UPA_CONV_BIG; mode < 0 only queries.

@@ -51,6 +51,9 @@ struct BigParams {
   int KTT, NTn;
   int act;
   unsigned magicTW, magicIW;
+  const char* tw;      // Detect branch tail: final 1x1 conv packed by upa_pack_tail_weight
+  const float* tb;     // ... its bias (zero-padded to 16 * n-tiles)
+  DetectEpi de;        // ... and the decode it feeds (detect_epi.h)
 };
 bool upa_conv_big_eligible(int n, int h, int w, int cin, int ldx, int cout, int ldy, int ldr, int k, int stride, int pad,
                            int act, int dtype);

@@ -10,7 +10,7 @@ import torch.nn as nn
 from ... import _lib as L
 from ...engine import runtime as R
 from .block import DFL
-from .conv import Conv, _HipConvMixin, hip_conv2d
+from .conv import Conv, _HipConvMixin, hip_conv2d, version_key
 
 __all__ = ("Detect",)
 
@@ -75,9 +75,51 @@ class Detect(nn.Module, _HipConvMixin):
         self._plan()[R.current_tag()] = dict(y=y, a0=a0, a_total=tot, fused=fused, hw=[(int(h), int(w)) for h, w in level_hw],
                                              n=int(n), decoded=set())
 
+    # `upa_detect_branch_tail`: with no raw output wanted, the branch's SECOND 3x3 conv joins that launch too (its SiLU'd
+    # accumulators are the MFMA operand of the 1x1 conv), so a branch is two launches: conv3x3, [conv3x3 + 1x1 + decode].
+    fuse_branch = True
+
     def _tail(self, seq: nn.Sequential, x: torch.Tensor, raw: torch.Tensor | None, kind: int, i: int, plan) -> None:
         """conv3x3 -> conv3x3 -> [1x1 + decode] of one branch (kind 1 = box, 2 = class) of level i."""
-        self._tail_call(seq[1](seq[0](x)), seq[2], raw, kind, i, plan)
+        t = seq[0](x)
+        if raw is None and self.fuse_branch and self._branch_tail(t, seq[1], seq[2], kind, i, plan):
+            return
+        self._tail_call(seq[1](t), seq[2], raw, kind, i, plan)
+
+    def _branch_tail(self, t: torch.Tensor, mid, conv: nn.Conv2d, kind: int, i: int, plan) -> bool:
+        """[conv3x3 + SiLU + 1x1 + decode] in one launch; False when the branch is outside the fused form."""
+        c = mid.conv.in_channels
+        cp = 64 if kind == 1 else 96
+        if not (isinstance(mid, Conv) and isinstance(mid.act, nn.SiLU) and mid.conv.kernel_size == (3, 3) and mid.conv.stride == (1, 1)
+                and mid.conv.padding == (1, 1) and mid.conv.groups == 1 and mid.conv.out_channels == c == conv.in_channels
+                and t.dtype == torch.bfloat16 and conv.kernel_size == (1, 1)
+                and (c == 64 if kind == 1 else (c <= 96 and c % 8 == 0 and self.nc <= 96))):
+            return False
+        pk3 = self._packed(mid.conv, mid.bn, t.device, t.dtype, False, pad_cout=cp)
+        cache = self.__dict__.setdefault("_pk_cache", {})
+        key = (id(conv), str(t.device), "tail", cp)
+        ver = version_key(conv.weight, conv.bias)
+        hit = cache.get(key)
+        if hit is None or hit[0] != ver:
+            w = torch.zeros(cp, cp)
+            b = torch.zeros(cp)
+            w[:conv.out_channels, :c] = conv.weight.detach().float().reshape(conv.out_channels, c).cpu()
+            if conv.bias is not None:
+                b[:conv.out_channels] = conv.bias.detach().float().cpu()
+            host = torch.empty(L.lib().upa_tail_packed_weight_bytes(cp, cp), dtype=torch.uint8)
+            L.check(L.lib().upa_pack_tail_weight(w.data_ptr(), cp, cp, host.data_ptr()), "pack_tail_weight")
+            hit = (ver, (host.to(t.device), b.to(t.device)))
+            cache[key] = hit
+        wt, bt = hit[1]
+        vt = R.view_of(t)
+        rc = L.lib().upa_detect_branch_tail(vt.ptr, vt.n, vt.h, vt.w, vt.c, vt.ld, pk3.w.data_ptr(), pk3.bias.data_ptr(),
+                                            wt.data_ptr(), bt.data_ptr(), kind, self.nc, float(self.stride[i]),
+                                            plan["y"].data_ptr(), plan["a_total"], plan["a0"][i], vt.dtype,
+                                            L.current_stream(t.device))
+        if rc == L.UPA_EUNSUPPORTED:
+            return False
+        L.check(rc, "detect_branch_tail")
+        return True
 
     def _tail_call(self, t: torch.Tensor, conv: nn.Conv2d, raw, kind: int, i: int, plan) -> None:
         """The fused launch itself: t = the branch's second 3x3 output, conv = its final nn.Conv2d."""
