@@ -79,7 +79,10 @@ def test_e2e_graph_replay_equals_eager():
 # across the threshold and flips NMS decisions - at IoU >= 0.5 every config agrees to >= 95 %, at IoU >= 0.9 to 80-92 %.
 # (The reference's own AMP check compares boxes with atol 0.5 on a trained model, utils/checks.py:780.)
 BF16_BOUNDS = {  # name: (recall@.9, precision@.9, recall@.5, precision@.5, matched box p99 px, box max px, score p99)
-    "yolov8n": (0.85, 0.85, 0.97, 0.95, 0.7, 1.5, 0.005),      # measured .906 .892 | .992 .977 | 0.34 0.53 0.0019
+    # yolov8n, three builds with the SAME rounding points (only f32 summation order differs: 0.02 % of model.2's outputs):
+    # .906 .892 | .992 .977, then .945 .945 | .984 .984 (Detect branch tail), then .883 .890 | .961 .969 (fused model.2) -
+    # 128 detections, so one threshold flip = 0.8 %; the bound sits below that spread
+    "yolov8n": (0.82, 0.82, 0.93, 0.93, 0.7, 1.5, 0.005),      # matched box p99 0.33-0.38, max 0.52-0.56 px, score p99 .0019-.0025
     "yolov8s": (0.72, 0.76, 0.92, 0.95, 9.0, 15.0, 0.04),      # measured .800 .839 | .954 .984 | 6.97 9.83 0.0286
     "yolov3-tiny": (0.85, 0.85, 0.95, 0.95, 3.5, 6.0, 0.015),  # measured .922 .940 | .980 .980 | 2.12 3.22 0.0098
     "yolov5-BoT3": (0.80, 0.80, 0.95, 0.95, 2.5, 20.0, 0.035),  # measured .857 .866 | .979 .989 | 1.56 14.4 0.0243
