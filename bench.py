@@ -521,7 +521,7 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
             wm, wn, nt = (8, 1, 4) if (ntb == 4 and mt == 4) else (4, 2, ntb // 2)
             if ntb == 4:
                 mt = 2
-            return "void conv_big_kernel<%d, %d, %d, %d, %d, %d>(BigParams)" % (pk.k, stride, wm, wn, mt, nt)
+            return "void conv_big_kernel<%d, %d, %d, %d, %d, %d, 0>(BigParams)" % (pk.k, stride, wm, wn, mt, nt)
         if (var >> 22) & 1:  # streaming pointwise kernel (conv1x1.hip): <NTW, MT, WAVES, EPI>
             return "void conv1x1_stream_kernel<%d, %d, %d, 0>(C1Params)" % (var & 15, (var >> 4) & 15, (var >> 8) & 31)
         if (var >> 21) & 1 and (var >> 8) & 1:  # 16 -> 16 channel variant of the pipelined kernel: <act, residual>
@@ -557,11 +557,13 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
         calls.append((name, flops, nbytes, lambda: orig_tail(self, t, conv, raw, kind, i, plan_keep)))
 
     orig_pair = L.lib().upa_bottleneck_pair
-    pair_calls = []
+    orig_c2f = L.lib().upa_c2f_fused
+    orig_btail = L.lib().upa_detect_branch_tail
+    pair_calls, c2f_calls, btail_calls = [], [], []
 
     class _LibProxy:
-        """Forwards every C entry to the real library, recording upa_bottleneck_pair launches (Bottleneck.forward calls it
-        directly, not through hip_conv2d)."""
+        """Forwards every C entry to the real library, recording the fused-block launches (Bottleneck / C2f / Detect call
+        them directly, not through hip_conv2d)."""
 
         def __getattr__(self, name):
             return getattr(real_lib, name)
@@ -570,6 +572,18 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
             rc = orig_pair(*a)
             if rc == 0:
                 pair_calls.append(a)
+            return rc
+
+        def upa_c2f_fused(self, *a):
+            rc = orig_c2f(*a)
+            if rc == 0:
+                c2f_calls.append(a)
+            return rc
+
+        def upa_detect_branch_tail(self, *a):
+            rc = orig_btail(*a)
+            if rc == 0:
+                btail_calls.append(a)
             return rc
 
     real_lib = L.lib()
@@ -595,6 +609,21 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
         nbytes = 2 * (n_ * h_ * w_ * c_ * 2 * (2 + (0.5 if a[12] else 0)) + c_ * c_ * 9 * 2)  # two convs, each in + out (+ residual)
         calls.append(("void conv_pair_kernel<%d, %s>(PairParams)" % (c_ // 32, "true" if a[12] else "false"), flops, nbytes,
                       (lambda a=a: orig_pair(*a[:15], L.current_stream(dev)))))
+    for a in c2f_calls:  # (x, n, h, w, c1, ldx, c, nb, shortcut, w1, b1, wm, bm, w2, b2, y, c2, ldy, act, dtype, stream)
+        npx, c1_, c_, nb_, c2_ = a[1] * a[2] * a[3], a[4], a[6], a[7], a[16]
+        wts = c1_ * 2 * c_ + nb_ * 18 * c_ * c_ + (2 + nb_) * c_ * c2_
+        flops = 2.0 * npx * wts
+        nbytes = npx * (c1_ + c2_) * 2 + wts * 2  # block input + block output + weights
+        name = "c2f16_fused_kernel(C2fParams)" if c_ == 16 else "void c2f32_fused_kernel<%d>(C2f32Params)" % nb_
+        calls.append((name, flops, nbytes, (lambda a=a: orig_c2f(*a[:20], L.current_stream(dev)))))
+    for a in btail_calls:  # (x, n, h, w, c, ldx, w3, b3, wt, bt, kind, nc, stride, y, a_total, a0, dtype, stream)
+        npx, c_, kind, nc_ = a[1] * a[2] * a[3], a[4], a[10], a[11]
+        cout = 64 if kind == 1 else nc_
+        flops = 2.0 * npx * (9 * c_ * c_ + c_ * cout)
+        nbytes = npx * c_ * 2 + npx * (4 if kind == 1 else nc_) * 4 + (9 * c_ * c_ + c_ * cout) * 2
+        mt = 1 if (npx + 255) // 256 < torch.cuda.get_device_properties(dev).multi_processor_count else 2
+        calls.append(("void conv_big_kernel<3, 1, 8, 1, %d, %d, %d>(BigParams)" % (mt, 4 if kind == 1 else 6, kind), flops, nbytes,
+                      (lambda a=a: orig_btail(*a[:17], L.current_stream(dev)))))
     torch.cuda.synchronize(dev)
     fam = {}
     with torch.no_grad():

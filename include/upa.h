@@ -121,14 +121,15 @@ int upa_detect_tail(const void* x, int n, int h, int w, int cin, int ldx, const 
                     int kind, int nc, float stride_px, float* y, int a_total, int a0, void* raw, int ldraw, int dtype,
                     void* stream);
 
-/* C2f(32 -> 32, n = 1, shortcut = True) in one launch (bf16, SiLU): cv1 -> Bottleneck(3x3, 3x3, + input) -> cv2 with the
- * intermediates in LDS / registers only.            nn/modules/block.py:457-488 (C2f.forward), :644-668 (Bottleneck.forward).
- * c1 / c2: channels in / out, c: hidden width (c2 * e), nb: bottlenecks; w1,b1 = cv1, wa,ba / wb,bb = m[0].cv1 / m[0].cv2,
- * w2,b2 = cv2, all upa_pack_conv_weight(bf16) with BN folded.  Returns UPA_EUNSUPPORTED outside (c1, c, c2, nb) = (32, 16,
- * 32, 1) with shortcut (callers then run the four convolutions). */
+/* A whole C2f block in one launch (bf16, SiLU): cv1 -> nb x Bottleneck(3x3, 3x3, [+ input]) -> cv2 with the intermediates in
+ * LDS / registers only.                            nn/modules/block.py:457-488 (C2f.forward), :644-668 (Bottleneck.forward).
+ * c1 / c2: channels in / out, c: hidden width (c2 * e), nb: Bottlenecks; w1,b1 = cv1; wm[2i], wm[2i+1] (bm likewise) =
+ * m[i].cv1, m[i].cv2; w2,b2 = cv2 - all upa_pack_conv_weight(bf16) with BN folded; wm / bm are HOST arrays of 2 nb device
+ * pointers.  Fused forms: (c1, c, c2, nb) = (32, 16, 32, 1) with shortcut (yolov8n model.2) and (64, 32, 64, 1 | 2) with or
+ * without shortcut (yolov8n model.4, yolov8s model.2); UPA_EUNSUPPORTED otherwise (callers run the separate convolutions). */
 int upa_c2f_fused(const void* x, int n, int h, int w, int c1, int ldx, int c, int nb, int shortcut, const void* w1,
-                  const float* b1, const void* wa, const float* ba, const void* wb, const float* bb, const void* w2,
-                  const float* b2, void* y, int c2, int ldy, int act, int dtype, void* stream);
+                  const float* b1, const void* const* wm, const float* const* bm, const void* w2, const float* b2, void* y,
+                  int c2, int ldy, int act, int dtype, void* stream);
 
 /* The whole back half of a Detect branch in one launch (bf16): second 3x3 conv (BN + SiLU folded) -> final 1x1 conv -> that
  * branch's half of the decode, the intermediate maps never leaving the registers.      head.py:94-100 (cv2/cv3), :116-126,

@@ -213,43 +213,52 @@ def test_bottleneck_pair_kernel(case):
     assert float(to_cpu_nchw(buf[:, :c]).abs().max()) == 0.0  # nothing written outside the output slice
 
 
-C2F_CASES = [(2, 37, 50), (1, 16, 16), (3, 5, 9), (2, 160, 160), (1, 33, 16)]
+C2F_CASES = [
+    # c1, n, shortcut, (N, H, W)
+    (32, 1, True, (2, 37, 50)), (32, 1, True, (1, 16, 16)), (32, 1, True, (3, 5, 9)), (32, 1, True, (2, 160, 160)),
+    (32, 1, True, (1, 33, 16)),
+    (64, 2, True, (2, 37, 50)), (64, 2, True, (1, 16, 16)), (64, 2, True, (3, 5, 9)), (64, 2, True, (2, 80, 80)),
+    (64, 1, True, (2, 33, 47)), (64, 1, False, (1, 20, 35)), (64, 2, False, (2, 18, 16)),
+]
 
 
-@pytest.mark.parametrize("shape", C2F_CASES, ids=[f"{s[0]}x{s[1]}x{s[2]}" for s in C2F_CASES])
-def test_c2f_fused_kernel(shape):
-    """`upa_c2f_fused` (bf16): C2f(32, 32, n=1, shortcut=True) - model.2 of yolov8n - as one kernel (block.py:457-488 with the
-    Bottleneck of :644-668 inside), vs the oracle C2f with every intermediate (cv1 output, the Bottleneck's mid tensor and its
-    output) rounded to bf16 where the kernel rounds them, and vs the product's own four-launch path on the same weights.
-    Ragged tiles, maps smaller than one 16 x 16 tile (every ring of the halo is image border: the 3x3 convs' zero padding must
-    be zero, not SiLU(bias)), several images, a strided output view."""
+@pytest.mark.parametrize("case", C2F_CASES, ids=[f"c{c[0]}n{c[1]}{'s' if c[2] else ''}_{c[3][0]}x{c[3][1]}x{c[3][2]}" for c in C2F_CASES])
+def test_c2f_fused_kernel(case):
+    """`upa_c2f_fused` (bf16): a whole C2f block (block.py:457-488 with the Bottlenecks of :644-668 inside) as one kernel -
+    C2f(32, 32, n=1) = model.2 of yolov8n, C2f(64, 64, n=2) = its model.4, C2f(64, 64, n=1) = model.2 of yolov8s - vs the
+    oracle C2f with every intermediate (cv1 output, each Bottleneck's mid tensor and output) rounded to bf16 where the
+    kernel rounds them, and vs the product's own multi-launch path on the same weights.  Ragged tiles, maps smaller than
+    one 16 x 16 tile (every ring of the halo is image border: the 3x3 convs' zero padding must be zero, not SiLU(bias)),
+    several images, with and without the shortcut, a strided output view."""
     from tests.hip_utils import DEV, bf16_round, to_cpu_nchw, to_dev_nhwc
     from ultralytics_pro_amd.engine import runtime as R
     pm, _ = _mods()
-    N, H, W = shape
-    o, m = _pair(om.C2f, pm.C2f, (32, 32, 1, True), "c2f_fused")
-    x = bf16_round(P.uniform(f"c2f{shape}", (N, 32, H, W), -1.5, 1.5))
+    c1, nb, sc, (N, H, W) = case
+    o, m = _pair(om.C2f, pm.C2f, (c1, c1, nb, sc), f"c2f_fused{c1}{nb}")
+    x = bf16_round(P.uniform(f"c2f{case}", (N, c1, H, W), -1.5, 1.5))
     with torch.no_grad():
         y01 = bf16_round(o.cv1(x))
-        y0, y1 = y01.chunk(2, 1)
-        t = bf16_round(o.m[0].cv1(y1))
-        b = bf16_round(y1 + o.m[0].cv2(t))
-        ref = o.cv2(torch.cat([y0, y1, b], 1))
-        buf = R.alloc_nhwc(N, 64, H, W, torch.bfloat16, DEV)
+        ys = list(y01.chunk(2, 1))
+        for bt in o.m:
+            t = bf16_round(bt.cv1(ys[-1]))
+            ys.append(bf16_round((ys[-1] if sc else 0) + bt.cv2(t)))
+        ref = o.cv2(torch.cat(ys, 1))
+        buf = R.alloc_nhwc(N, 2 * c1, H, W, torch.bfloat16, DEV)
         buf.zero_()
         xd = to_dev_nhwc(x, torch.bfloat16)
         m.fuse_block = True
         assert m._fused(xd, None) is not None, "the fused form was not dispatched"
-        y = to_cpu_nchw(m(xd, out=buf[:, 32:]))
+        y = to_cpu_nchw(m(xd, out=buf[:, c1:]))
         m.fuse_block = False
         y2 = to_cpu_nchw(m(xd))
     scale = max(1.0, ref.abs().max().item())
     assert (y - ref).abs().max().item() <= 3e-2 * scale, (y - ref).abs().max().item()
-    # same rounding points as the four launches; a bf16 tie that falls the other way in an intermediate moves few outputs
+    # same rounding points as the separate launches; a bf16 tie that falls the other way in an intermediate moves few outputs
+    # (measured: 0.02-0.03 % of the outputs differ with the shortcut, up to 1.4 % without it - nothing damps a flipped tie -; mean
+    # |error| against the plain-f32 oracle equal to 5 digits, experiments/c2f_err.py)
     d = (y - y2).abs()
-    # (measured: 0.02-0.03 % of the outputs differ; mean |error| against the plain-f32 oracle equal to 5 digits, experiments/c2f_err.py)
-    assert d.max().item() <= 3e-2 * scale and (d > 1e-6).float().mean().item() <= 0.005, (d.max().item(), (d > 1e-6).float().mean().item())
-    assert float(to_cpu_nchw(buf[:, :32]).abs().max()) == 0.0  # nothing written outside the output slice
+    assert d.max().item() <= 3e-2 * scale and (d > 1e-6).float().mean().item() <= 0.03, (d.max().item(), (d > 1e-6).float().mean().item())
+    assert float(to_cpu_nchw(buf[:, :c1]).abs().max()) == 0.0  # nothing written outside the output slice
 
 
 C1_CASES = [

@@ -193,27 +193,284 @@ __global__ __launch_bounds__(256) void c2f16_fused_kernel(const C2fParams p) {
   }
 }
 
-// x: (n, h, w, 32) NHWC bf16 view; w1 / b1: cv1 (1x1, 32 -> 32); wa / ba, wb / bb: the Bottleneck's two 3x3 convs (16 -> 16);
-// w2 / b2: cv2 (1x1, 48 -> 32) - all packed by upa_pack_conv_weight(bf16) with BN folded; y: (n, h, w, 32) view.
-extern "C" int upa_c2f_fused(const void* x, int n, int h, int w, int c1, int ldx, int c, int nb, int shortcut, const void* w1,
-                             const float* b1, const void* wa, const float* ba, const void* wb, const float* bb, const void* w2,
-                             const float* b2, void* y, int c2, int ldy, int act, int dtype, void* stream) {
-  UPA_CHECK_ARG(x && y && w1 && b1 && wa && ba && wb && bb && w2 && b2 && n > 0 && h > 0 && w > 0, "c2f_fused: bad args");
-  static const int off = getenv("UPA_NO_C2F") ? atoi(getenv("UPA_NO_C2F")) : 0;
-  if (off || dtype != UPA_BF16 || act != UPA_ACT_SILU || c1 != 32 || c != 16 || c2 != 32 || nb != 1 || !shortcut || ldx % 8 != 0 ||
-      ldy % 8 != 0 || ((uintptr_t)x % 16) != 0 || ((uintptr_t)y % 16) != 0) {
-    upa_set_error("c2f_fused: outside the fused form (bf16, SiLU, C2f(32, 32, n = 1, shortcut))");
-    return UPA_EUNSUPPORTED;  // the caller runs the four convolutions
+// =====================================================================================================================
+// C2f(64 -> 64, n = NB Bottlenecks of 32 channels) as one kernel: model.4 of yolov8n at 80 x 80 (NB = 2), model.2 of yolov8s
+// at 160 x 160 (NB = 1).  Same plan as above at twice the width: a channel group of 32 is exactly one MFMA k-step, so a 3x3
+// conv is 9 k-steps x 2 n-tiles per 16 pixels and cv2 is (2 + NB) k-steps x 4 n-tiles, one k-step per concatenated tensor.
+// A workgroup (16 waves, one per CU: the tiles below fill the LDS) owns a 16 x 16 output tile; with R = 2 NB:
+//   A. x halo tile (16 + 2R)^2 px x 128 B by LDS-DMA; y1 = SiLU(cv1 upper half) on every halo pixel, y0 = SiLU(cv1 lower
+//      half) on the tile's own pixels; both ZERO outside the image where they feed a 3x3 conv;
+//   B.. per Bottleneck: t = SiLU(conv3x3(prev)) on the ring R - 1, b = prev + SiLU(conv3x3(t)) on the ring R - 2, each as an
+//      LDS tile of 64 B / pixel (XOR-swizzled 16-byte groups, conflict-free ds_read_b128); the x tile's space is reused for
+//      the t tiles and the last b once cv1 is done;
+//   F. out = SiLU(cv2 . [y0 | y1 | b1 (| b2)]) from the four tiles, 16-byte NHWC stores.
+// Weights: a wave produces ONE 16-channel n-tile (wave & 1) of every 8th m-tile, so it needs 9 A fragments per 3x3 stage
+// (36 VGPRs); they are loaded from L2 into registers one stage ahead, no stage waits on them and there is no barrier inside
+// a stage - only one between stages.  (First form: 8 waves holding both n-tiles, 208 VGPRs, two waves per SIMD: 84 us for
+// model.4 - every wave's MFMA -> SiLU -> store chain ran exposed; 16 waves at <= 128 VGPRs interleave four per SIMD.)
+// Recompute on the rings (NB = 2): cv1 2.25x, the four 3x3 convs 1.89 / 1.56 / 1.27 / 1x of a 16 x 16 tile; in exchange the
+// 26 + 13 + 13 + 13 + 13 MB of intermediates (written once, read up to three times) never leave the CU.
+// =====================================================================================================================
+struct C2f32Params {
+  const char* x; char* y;
+  const char *w1, *w2;
+  const char* wm[4];     // m[0].cv1, m[0].cv2, m[1].cv1, m[1].cv2
+  const float *b1, *b2;
+  const float* bm[4];
+  int N, H, W, ldx, ldy, tilesX, tilesY, shortcut;
+};
+
+namespace c2f32 {
+using c2f::mfma32;
+using c2f::silu;
+constexpr int T = 16;
+constexpr int NW = 16;  // waves per workgroup
+__device__ __forceinline__ int swz64(int px) { return (px >> 1) & 3; }  // 64-byte pixel records: 4 groups of 16 B
+
+// address of the 8 bytes holding channels 16j + 4g .. + 3 of pixel px in a 64 B / px tile
+__device__ __forceinline__ int quad_addr(int px, int j, int g) { return px * 64 + (((2 * j + (g >> 1)) ^ swz64(px)) << 4) + (g & 1) * 8; }
+
+// the nine A fragments (one per tap) of n-tile j of a 3x3 conv 32 -> 32: packed [tap][1 k-tile][2 n-tiles][lane][16 B]
+__device__ __forceinline__ void load_w9(u32x4 (&w)[9], const char* src, int j, int lane) {
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) w[tap] = *reinterpret_cast<const u32x4*>(src + ((size_t)(tap * 2 + j) * 64 + lane) * 16);
+}
+
+// One 3x3 conv stage between two 64 B / px LDS tiles: dst (side SD, ring RD around the output tile) from src (side SD + 2).
+// A wave owns n-tile j (= wave & 1) of every 8th m-tile.  res: tile of side SR whose pixel (yy + OFF, xx + OFF) is added
+// after the activation (the Bottleneck shortcut), or nullptr.
+template <int SD, int RD, int SR, int OFF>
+__device__ __forceinline__ void conv3x3_stage(const char* src, char* dst, const u32x4 (&w)[9], const f32x4 bias, const char* res,
+                                              int oy0, int ox0, int H, int W, int wave, int g, int r) {
+  constexpr int SS = SD + 2, NPX = SD * SD, NMT = (NPX + 15) / 16;
+  const int j = wave & 1;
+  for (int mt = wave >> 1; mt < NMT; mt += NW / 2) {
+    const int q = mt * 16 + r;
+    const int qc = q < NPX ? q : NPX - 1;
+    const int yy = qc / SD, xx = qc - yy * SD;
+    const int sp = yy * SS + xx;
+    f32x4 acc = bias;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int px = sp + (tap / 3) * SS + (tap % 3);
+      acc = mfma32(w[tap], *reinterpret_cast<const u32x4*>(src + px * 64 + ((g ^ swz64(px)) << 4)), acc);
+    }
+    const int gy = oy0 - RD + yy, gx = ox0 - RD + xx;
+    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = in ? silu(acc[e]) : 0.f;
+    if (res) {  // the shortcut tensor is zero outside the image already
+      const u32x2 rr = *reinterpret_cast<const u32x2*>(res + quad_addr((yy + OFF) * SR + xx + OFF, j, g));
+      v[0] += __uint_as_float(rr[0] << 16); v[1] += __uint_as_float(rr[0] & 0xFFFF0000u);
+      v[2] += __uint_as_float(rr[1] << 16); v[3] += __uint_as_float(rr[1] & 0xFFFF0000u);
+    }
+    if (q < NPX) *reinterpret_cast<u32x2*>(dst + quad_addr(q, j, g)) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
   }
-  C2fParams p;
-  p.x = (const char*)x; p.y = (char*)y;
-  p.w1 = (const char*)w1; p.wa = (const char*)wa; p.wb = (const char*)wb; p.w2 = (const char*)w2;
-  p.b1 = b1; p.ba = ba; p.bb = bb; p.b2 = b2;
-  p.N = n; p.H = h; p.W = w; p.ldx = ldx; p.ldy = ldy;
-  p.tilesX = cdiv(w, c2f::TW); p.tilesY = cdiv(h, c2f::TH);
-  const long tiles = (long)p.tilesX * p.tilesY * n;
+}
+}  // namespace c2f32
+
+template <int NB>
+__global__ __launch_bounds__(1024) void c2f32_fused_kernel(const C2f32Params p) {
+  using namespace c2f32;
+  constexpr int R = 2 * NB;
+  constexpr int SX = T + 2 * R;                          // x / y1 tile side: 24 | 20
+  constexpr int XPX = SX * SX;                           // 576 | 400
+  constexpr int XITEMS = XPX * 8;                        // 16-byte items of the x tile (a multiple of 64: whole waves)
+  constexpr int XIT = (XITEMS + 1023) / 1024;
+  constexpr int XREG = XPX * 128;                        // x region (reused): 73728 | 51200
+  constexpr int Y1B = XPX * 64;                          // 36864 | 25600
+  constexpr int S_T1 = SX - 2, S_B1 = SX - 4;            // 22, 20 | 18, 16
+  constexpr int T1B = ((S_T1 * S_T1 + 15) / 16) * 16 * 64;
+  constexpr int S_T2 = S_B1 - 2;                         // 18 (NB = 2)
+  constexpr int T2B = ((S_T2 * S_T2 + 15) / 16) * 16 * 64;
+  static_assert(XITEMS % 64 == 0, "the DMA guard must be wave-uniform");
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  char* xs = sm;                                  // x; then t1 at 0, (NB = 2) t2 after it, the last b after that
+  char* y1s = sm + XREG;
+  char* y0s = y1s + Y1B;                          // 16 x 16 px
+  char* b1s = y0s + T * T * 64;                   // NB = 2 only: b1 on ring 2 (side 20); NB = 1 keeps b1 in the x region
+  char* t1s = xs;
+  char* t2s = xs + T1B;
+  char* bls = NB == 2 ? xs + T1B + T2B : xs + T1B;  // last Bottleneck's output (side 16)
+  static_assert(T1B + (NB == 2 ? T2B : 0) + T * T * 64 <= XREG, "t / b tiles must fit the dead x region");
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, r = lane & 15;
+  const int j = wave & 1;  // the n-tile (of a 32-channel tensor) this wave produces
+  int bid = blockIdx.x;
+  const int tilesPerImg = p.tilesX * p.tilesY;
+  const int n = bid / tilesPerImg;
+  bid -= n * tilesPerImg;
+  const int tyi = bid / p.tilesX, txi = bid - tyi * p.tilesX;
+  const int oy0 = tyi * T, ox0 = txi * T;
+
+  // ---- x halo tile: 128 B / px, 16-byte group cg of pixel px at slot cg ^ (px & 7)
+#pragma unroll
+  for (int it = 0; it < XIT; ++it) {
+    const int idx = it * 1024 + tid;
+    if (it * 1024 + wave * 64 < XITEMS) {
+      const int px = idx >> 3, slot = idx & 7;
+      const int cg = slot ^ (px & 7);
+      const int hy = px / SX, hx = px - hy * SX;
+      const int iy = oy0 - R + hy, ix = ox0 - R + hx;
+      const char* src = reinterpret_cast<const char*>(g_c2f_zero16);
+      if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) src = p.x + ((((size_t)n * p.H + iy) * p.W + ix) * (size_t)p.ldx + cg * 8) * 2;
+      __builtin_amdgcn_global_load_lds((cgptr_t)src, (clptr_t)(xs + (it * 1024 + wave * 64) * 16), 16, 0, 0);
+    }
+  }
+  // cv1 (64 -> 64: [2 k-tiles][4 n-tiles]): this wave's n-tiles j (y0) and 2 + j (y1); the first 3x3 conv's fragments
+  u32x4 w1f[2][2];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) w1f[kt][h2] = *reinterpret_cast<const u32x4*>(p.w1 + ((size_t)(kt * 4 + 2 * h2 + j) * 64 + lane) * 16);
+  const f32x4 b1y0 = *reinterpret_cast<const f32x4*>(p.b1 + j * 16 + 4 * g);
+  const f32x4 b1y1 = *reinterpret_cast<const f32x4*>(p.b1 + (2 + j) * 16 + 4 * g);
+  u32x4 wA[9], wB[9];
+  load_w9(wA, p.wm[0], j, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  f32x4 bA = *reinterpret_cast<const f32x4*>(p.bm[0] + j * 16 + 4 * g);
+  f32x4 bB = *reinterpret_cast<const f32x4*>(p.bm[1] + j * 16 + 4 * g);
+
+  // ---- A. cv1: y1 on every halo pixel, y0 on the tile's own pixels
+  for (int mt = wave >> 1; mt < XPX / 16; mt += NW / 2) {
+    const int q = mt * 16 + r;
+    f32x4 a = b1y1;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+      a = mfma32(w1f[kt][1], *reinterpret_cast<const u32x4*>(xs + q * 128 + (((kt * 4 + g) ^ (q & 7)) << 4)), a);
+    const int hy = q / SX, hx = q - hy * SX;
+    const int gy = oy0 - R + hy, gx = ox0 - R + hx;
+    const bool in = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = in ? silu(a[e]) : 0.f;
+    *reinterpret_cast<u32x2*>(y1s + quad_addr(q, j, g)) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+  }
+  for (int i = wave >> 1; i < T; i += NW / 2) {
+    const int q = (i + R) * SX + R + r;
+    f32x4 a = b1y0;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+      a = mfma32(w1f[kt][0], *reinterpret_cast<const u32x4*>(xs + q * 128 + (((kt * 4 + g) ^ (q & 7)) << 4)), a);
+    *reinterpret_cast<u32x2*>(y0s + quad_addr(i * T + r, j, g)) = u32x2{pack_bf16x2(silu(a[0]), silu(a[1])), pack_bf16x2(silu(a[2]), silu(a[3]))};
+  }
+  load_w9(wB, p.wm[1], j, lane);  // every later stage's weights are fetched one stage ahead
+  __syncthreads();  // y1 complete; x is dead
+
+  // ---- B. t1 = SiLU(conv3x3(y1)) on ring R - 1 (into the x region)
+  conv3x3_stage<S_T1, R - 1, 1, 0>(y1s, t1s, wA, bA, nullptr, oy0, ox0, p.H, p.W, wave, g, r);
+  __syncthreads();
+  const char* sc1 = p.shortcut ? y1s : nullptr;
+  constexpr int K2 = 2 + NB;
+  u32x4 w2f[K2][2];  // cv2 [k-tile][4 n-tiles]: this wave's n-tiles 2j, 2j + 1
+  if constexpr (NB == 2) {
+    load_w9(wA, p.wm[2], j, lane);
+    bA = *reinterpret_cast<const f32x4*>(p.bm[2] + j * 16 + 4 * g);
+    // ---- C. b1 = y1 + SiLU(conv3x3(t1)) on ring 2
+    conv3x3_stage<S_B1, R - 2, SX, 2>(t1s, b1s, wB, bB, sc1, oy0, ox0, p.H, p.W, wave, g, r);
+    __syncthreads();
+    load_w9(wB, p.wm[3], j, lane);
+    bB = *reinterpret_cast<const f32x4*>(p.bm[3] + j * 16 + 4 * g);
+    // ---- D. t2 = SiLU(conv3x3(b1)) on ring 1
+    conv3x3_stage<S_T2, 1, 1, 0>(b1s, t2s, wA, bA, nullptr, oy0, ox0, p.H, p.W, wave, g, r);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int kt = 0; kt < K2; ++kt)
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) w2f[kt][h2] = *reinterpret_cast<const u32x4*>(p.w2 + ((size_t)(kt * 4 + 2 * j + h2) * 64 + lane) * 16);
+  const f32x4 b2v[2] = {*reinterpret_cast<const f32x4*>(p.b2 + (2 * j) * 16 + 4 * g), *reinterpret_cast<const f32x4*>(p.b2 + (2 * j + 1) * 16 + 4 * g)};
+  if constexpr (NB == 2) {
+    // ---- E. b2 = b1 + SiLU(conv3x3(t2)) on the tile
+    conv3x3_stage<T, 0, S_B1, 2>(t2s, bls, wB, bB, p.shortcut ? b1s : nullptr, oy0, ox0, p.H, p.W, wave, g, r);
+  } else {
+    // ---- C. b1 = y1 + SiLU(conv3x3(t1)) on the tile
+    conv3x3_stage<T, 0, SX, 2>(t1s, bls, wB, bB, sc1, oy0, ox0, p.H, p.W, wave, g, r);
+  }
+  __syncthreads();
+
+  // ---- F. cv2 over [y0 | y1 | b1 (| b2)] of the tile's own pixels: a wave owns output channels 32j .. 32j + 31 of two rows
+  for (int i = wave >> 1; i < T; i += NW / 2) {
+    const int d = i * T + r;
+    const int qy1 = (i + R) * SX + R + r;
+    u32x4 op[K2];
+    op[0] = *reinterpret_cast<const u32x4*>(y0s + d * 64 + ((g ^ swz64(d)) << 4));
+    op[1] = *reinterpret_cast<const u32x4*>(y1s + qy1 * 64 + ((g ^ swz64(qy1)) << 4));
+    if constexpr (NB == 2) {
+      const int qb1 = (i + 2) * S_B1 + 2 + r;
+      op[2] = *reinterpret_cast<const u32x4*>(b1s + qb1 * 64 + ((g ^ swz64(qb1)) << 4));
+      op[3] = *reinterpret_cast<const u32x4*>(bls + d * 64 + ((g ^ swz64(d)) << 4));
+    } else {
+      op[2] = *reinterpret_cast<const u32x4*>(bls + d * 64 + ((g ^ swz64(d)) << 4));
+    }
+    f32x4 o0 = b2v[0], o1 = b2v[1];
+#pragma unroll
+    for (int kt = 0; kt < K2; ++kt) {
+      o0 = mfma32(w2f[kt][0], op[kt], o0);
+      o1 = mfma32(w2f[kt][1], op[kt], o1);
+    }
+    const int oy = oy0 + i, ox = ox0 + r;
+    float v0[4], v1[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v0[e] = silu(o0[e]);
+      v1[e] = silu(o1[e]);
+    }
+    auto lo = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v1[0], v1[1]), false, false);
+    auto hi = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[2], v1[3]), false, false);
+    const int cb = 16 * (2 * j + (g & 1)) + 8 * (g >> 1);
+    if (oy < p.H && ox < p.W)
+      *reinterpret_cast<u32x4*>(p.y + ((((size_t)n * p.H + oy) * p.W + ox) * (size_t)p.ldy + cb) * 2) = u32x4{lo[0], hi[0], lo[1], hi[1]};
+  }
+}
+
+// x: (n, h, w, c1) NHWC bf16 view; w1 / b1: cv1 (1x1, c1 -> 2c); wm[2i], wm[2i + 1] / bm[..]: Bottleneck i's two 3x3 convs
+// (c -> c); w2 / b2: cv2 (1x1, (2 + nb) c -> c2) - all packed by upa_pack_conv_weight(bf16) with BN folded; y: (n, h, w, c2).
+extern "C" int upa_c2f_fused(const void* x, int n, int h, int w, int c1, int ldx, int c, int nb, int shortcut, const void* w1,
+                             const float* b1, const void* const* wm, const float* const* bm, const void* w2, const float* b2,
+                             void* y, int c2, int ldy, int act, int dtype, void* stream) {
+  UPA_CHECK_ARG(x && y && w1 && b1 && wm && bm && w2 && b2 && n > 0 && h > 0 && w > 0 && nb >= 1, "c2f_fused: bad args");
+  static const int off = getenv("UPA_NO_C2F") ? atoi(getenv("UPA_NO_C2F")) : 0;  // 1: never, 2: not the 16-wide, 3: not the 32-wide
+  const bool f16 = c1 == 32 && c == 16 && c2 == 32 && nb == 1 && shortcut && off != 2;
+  const bool f32 = c1 == 64 && c == 32 && c2 == 64 && (nb == 1 || nb == 2) && off != 3;
+  if (off == 1 || dtype != UPA_BF16 || act != UPA_ACT_SILU || !(f16 || f32) || ldx % 8 != 0 || ldy % 8 != 0 ||
+      ((uintptr_t)x % 16) != 0 || ((uintptr_t)y % 16) != 0) {
+    upa_set_error("c2f_fused: outside the fused forms (bf16, SiLU; C2f(32, 32, n=1, shortcut) or C2f(64, 64, n=1|2))");
+    return UPA_EUNSUPPORTED;  // the caller runs the separate convolutions
+  }
+  for (int i = 0; i < 2 * nb; ++i) UPA_CHECK_ARG(wm[i] && bm[i], "c2f_fused: null Bottleneck weights");
+  const int tx = cdiv(w, 16), ty = cdiv(h, 16);
+  const long tiles = (long)tx * ty * n;
   UPA_CHECK_ARG(tiles < (1L << 31), "c2f_fused: too many tiles");
-  hipLaunchKernelGGL(c2f16_fused_kernel, dim3((unsigned)tiles), dim3(256), c2f::LDS, (hipStream_t)stream, p);
+  hipStream_t s = (hipStream_t)stream;
+  if (f16) {
+    C2fParams p;
+    p.x = (const char*)x; p.y = (char*)y;
+    p.w1 = (const char*)w1; p.wa = (const char*)wm[0]; p.wb = (const char*)wm[1]; p.w2 = (const char*)w2;
+    p.b1 = b1; p.ba = bm[0]; p.bb = bm[1]; p.b2 = b2;
+    p.N = n; p.H = h; p.W = w; p.ldx = ldx; p.ldy = ldy; p.tilesX = tx; p.tilesY = ty;
+    hipLaunchKernelGGL(c2f16_fused_kernel, dim3((unsigned)tiles), dim3(256), c2f::LDS, s, p);
+    UPA_LAUNCH_CHECK();
+    return UPA_OK;
+  }
+  C2f32Params p;
+  memset(&p, 0, sizeof(p));
+  p.x = (const char*)x; p.y = (char*)y; p.w1 = (const char*)w1; p.w2 = (const char*)w2; p.b1 = b1; p.b2 = b2;
+  for (int i = 0; i < 2 * nb; ++i) { p.wm[i] = (const char*)wm[i]; p.bm[i] = bm[i]; }
+  p.N = n; p.H = h; p.W = w; p.ldx = ldx; p.ldy = ldy; p.tilesX = tx; p.tilesY = ty; p.shortcut = shortcut ? 1 : 0;
+  if (nb == 2) {
+    constexpr size_t lds = 73728 + 36864 + 16384 + 25600;
+    if (upa_full_lds<c2f32_fused_kernel<2>>() != hipSuccess) return UPA_ELAUNCH;
+    hipLaunchKernelGGL(c2f32_fused_kernel<2>, dim3((unsigned)tiles), dim3(1024), lds, s, p);
+  } else {
+    constexpr size_t lds = 51200 + 25600 + 16384;
+    if (upa_full_lds<c2f32_fused_kernel<1>>() != hipSuccess) return UPA_ELAUNCH;
+    hipLaunchKernelGGL(c2f32_fused_kernel<1>, dim3((unsigned)tiles), dim3(1024), lds, s, p);
+  }
   UPA_LAUNCH_CHECK();
   return UPA_OK;
 }

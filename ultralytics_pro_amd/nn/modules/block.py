@@ -80,26 +80,32 @@ class C2f(nn.Module):
         self.cv2 = Conv((2 + n) * self.c, c2, 1)
         self.m = nn.ModuleList(Bottleneck(self.c, self.c, shortcut, g, k=((3, 3), (3, 3)), e=1.0) for _ in range(n))
 
-    fuse_block = True  # bf16 C2f(32, 32, n=1, shortcut): the whole block as one kernel (upa_c2f_fused)
+    fuse_block = True  # bf16 C2f(32, 32, n=1, shortcut) / C2f(64, 64, n=1|2): the whole block as one kernel (upa_c2f_fused)
 
     def _fused(self, x, out):
-        """One launch for the whole block when it has the fused form; None otherwise."""
-        m = self.m[0] if len(self.m) == 1 else None
-        convs = (self.cv1, self.cv2) + ((m.cv1, m.cv2) if m is not None else ())
-        if not (self.fuse_block and m is not None and x.dtype == torch.bfloat16 and not self.training and m.add
-                and self.c == 16 and self.cv1.conv.in_channels == 32 and self.cv2.conv.out_channels == 32
-                and m.cv1.conv.kernel_size == (3, 3) and m.cv2.conv.kernel_size == (3, 3)
-                and all(isinstance(cv.act, nn.SiLU) and cv.conv.groups == 1 and cv.conv.stride == (1, 1) for cv in convs)
-                and m.cv1.conv.padding == (1, 1) and m.cv2.conv.padding == (1, 1)):
+        """One launch for the whole block when it has a fused form; None otherwise."""
+        import ctypes as C
+        nb = len(self.m)
+        c1, c2 = self.cv1.conv.in_channels, self.cv2.conv.out_channels
+        form = (c1, self.c, c2)
+        if not (self.fuse_block and x.dtype == torch.bfloat16 and not self.training
+                and ((form == (32, 16, 32) and nb == 1 and self.m[0].add) or (form == (64, 32, 64) and nb in (1, 2)))):
+            return None
+        convs = [self.cv1, self.cv2] + [cv for m in self.m for cv in (m.cv1, m.cv2)]
+        if not (all(isinstance(cv.act, nn.SiLU) and cv.conv.groups == 1 and cv.conv.stride == (1, 1) and hasattr(cv, "bn")
+                    for cv in convs)
+                and all(cv.conv.kernel_size == (3, 3) and cv.conv.padding == (1, 1) for cv in convs[2:])
+                and all(m.add == self.m[0].add for m in self.m)):
             return None
         n, _, h, w = x.shape
-        y = out if out is not None else R.alloc_nhwc(n, 32, h, w, x.dtype, x.device, key=(id(self), "y"))
-        pk = [cv._packed(cv.conv, cv.bn, x.device, x.dtype, False) for cv in (self.cv1, m.cv1, m.cv2, self.cv2)]
+        y = out if out is not None else R.alloc_nhwc(n, c2, h, w, x.dtype, x.device, key=(id(self), "y"))
+        pk = [cv._packed(cv.conv, cv.bn, x.device, x.dtype, False) for cv in convs]
+        wm = (C.c_void_p * (2 * nb))(*[q.w.data_ptr() for q in pk[2:]])
+        bm = (C.c_void_p * (2 * nb))(*[q.bias.data_ptr() for q in pk[2:]])
         vx, vy = R.view_of(x), R.view_of(y)
-        rc = L.lib().upa_c2f_fused(vx.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, self.c, 1, 1, pk[0].w.data_ptr(), pk[0].bias.data_ptr(),
-                                   pk[1].w.data_ptr(), pk[1].bias.data_ptr(), pk[2].w.data_ptr(), pk[2].bias.data_ptr(),
-                                   pk[3].w.data_ptr(), pk[3].bias.data_ptr(), vy.ptr, vy.c, vy.ld, L.ACT_SILU, vx.dtype,
-                                   L.current_stream(x.device))
+        rc = L.lib().upa_c2f_fused(vx.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, self.c, nb, int(self.m[0].add), pk[0].w.data_ptr(),
+                                   pk[0].bias.data_ptr(), C.cast(wm, C.c_void_p), C.cast(bm, C.c_void_p), pk[1].w.data_ptr(),
+                                   pk[1].bias.data_ptr(), vy.ptr, vy.c, vy.ld, L.ACT_SILU, vx.dtype, L.current_stream(x.device))
         if rc == 0:
             return y
         if rc != L.UPA_EUNSUPPORTED:
