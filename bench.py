@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--serial", action="store_true",
                     help="no intra-step concurrency (Detect branches on the main stream): per-kernel durations in a "
                          "rocprofv3 trace of this mode are directly comparable with roofline.avg_launch_us")
+    ap.add_argument("--linear-graphs", type=int, default=1,
+                    help="with an explicit --in-flight / --micro-batches: 1 = every compiled step is one chain of launches (the "
+                         "steps in flight are the only concurrency), 0 = Detect branches fork inside the graph")
     ap.add_argument("--micro-batches", type=int, default=0,
                     help="walk the per-GPU batch as this many concurrent sub-batches (parallel hipGraph branches of ONE "
                          "graph; the whole batch is still processed every step): the latency-bound 20x20/40x40 layers of "
@@ -204,7 +207,7 @@ def main():
             args.in_flight, args.micro_batches = runner.in_flight, runner.micro_batches
         else:
             runner = PipelinedRunner(model, xs, post, micro_batches=args.micro_batches, in_flight=args.in_flight,
-                                     linear=bool(args.serial))
+                                     linear=bool(args.serial or (args.linear_graphs and args.micro_batches == 1)))
         run = runner.runs[0]
         for _ in range(args.warmup):
             runner.step()
