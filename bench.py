@@ -535,15 +535,17 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
             "conv_ws_kernel" if (var >> 20) & 1 else "conv_igemm_kernel", tname, (var >> 12) & 15,
             (var >> 8) & 15, (var >> 4) & 15, var & 15, (var >> 16) & 15)
 
-    def rec(xx, pk, stride, pad, act, out=None, residual=None, out_dtype=None, key=None):
-        y = orig(xx, pk, stride, pad, act, out=out, residual=residual, out_dtype=out_dtype, key=key)
+    def rec(xx, pk, stride, pad, act, out=None, residual=None, out_dtype=None, key=None, up=None):
+        y = orig(xx, pk, stride, pad, act, out=out, residual=residual, out_dtype=out_dtype, key=key, up=up)
         n, cin, h, w = xx.shape
         oh, ow = y.shape[2], y.shape[3]
         flops = 2.0 * n * oh * ow * pk.cout * cin * pk.k * pk.k
         nbytes = n * h * w * cin * xx.element_size() + n * oh * ow * pk.cout * es * (2 if residual is not None else 1) \
             + pk.cout * cin * pk.k * pk.k * es
+        if up is not None:  # virtual Upsample + Concat: the leading channels are read at quarter size
+            nbytes -= n * h * w * up.channels * xx.element_size() * 3 // 4
         calls.append((conv_name(n, h, w, cin, pk, stride, pad, act, residual), flops, nbytes,
-                      lambda: orig(xx, pk, stride, pad, act, out=y, residual=residual, out_dtype=out_dtype)))
+                      lambda: orig(xx, pk, stride, pad, act, out=y, residual=residual, out_dtype=out_dtype, up=up)))
         return y
 
     def rec_tail(self, t, conv, raw, kind, i, plan):

@@ -121,6 +121,14 @@ int upa_detect_tail(const void* x, int n, int h, int w, int cin, int ldx, const 
                     int kind, int nc, float stride_px, float* y, int a_total, int a0, void* raw, int ldraw, int dtype,
                     void* stream);
 
+/* 1x1 conv over Concat([Upsample(2x nearest)(up), skip]) with the upsample read on the fly (bf16): the first up_c channels of a
+ * pixel come from pixel (y/2, x/2) of `up` (n, h/2, w/2, up_c; pixel stride up_ld), the other cin - up_c from the concat buffer x
+ * (n, h, w, cin) where the skip producer wrote them in place; the upsampled copy is never materialised.
+ * nn.Upsample + Concat + C2f.cv1: yolov8.yaml rows 10-12 / 13-15, nn/modules/conv.py (Concat), block.py:479.
+ * UPA_EUNSUPPORTED outside the streaming 1x1 form (callers then write the upsample and call upa_conv2d_bias_act). */
+int upa_conv1x1_upcat(const void* x, int n, int h, int w, int cin, int ldx, const void* up, int up_c, int up_ld,
+                      const void* w_packed, const float* bias, void* y, int cout, int ldy, int act, int dtype, void* stream);
+
 /* A whole C2f block in one launch (bf16, SiLU): cv1 -> nb x Bottleneck(3x3, 3x3, [+ input]) -> cv2 with the intermediates in
  * LDS / registers only.                            nn/modules/block.py:457-488 (C2f.forward), :644-668 (Bottleneck.forward).
  * c1 / c2: channels in / out, c: hidden width (c2 * e), nb: Bottlenecks; w1,b1 = cv1; wm[2i], wm[2i+1] (bm likewise) =

@@ -213,6 +213,38 @@ def test_bottleneck_pair_kernel(case):
     assert float(to_cpu_nchw(buf[:, :c]).abs().max()) == 0.0  # nothing written outside the output slice
 
 
+@pytest.mark.parametrize("case", [(2, 128, 64, 128, 20, 20), (1, 256, 128, 128, 10, 12), (3, 32, 16, 48, 7, 9), (2, 48, 16, 32, 6, 6)],
+                         ids=["up128_skip64", "up256_skip128_cout128", "up32_ragged", "up48_fallback"])
+def test_conv1x1_virtual_upsample_concat(case):
+    """`upa_conv1x1_upcat`: the 1x1 conv after Concat([Upsample(2x nearest)(u), skip]) reading u at (y/2, x/2) instead of a
+    materialised upsample (yolov8.yaml rows 10-12 / 13-15; nn.Upsample + conv.py Concat + C2f.cv1 block.py:479).  Same kernel,
+    same values: bit-identical to the conv over the materialised concat buffer, and equal to the oracle's
+    Conv(cat(upsample(u), skip)) to bf16 resolution.  The 48-channel case is outside the fused form (k-tiles of 32 channels):
+    the call must fall back to writing the upsample."""
+    from tests.hip_utils import DEV, bf16_round, to_cpu_nchw, to_dev_nhwc
+    from ultralytics_pro_amd.engine import runtime as R
+    from ultralytics_pro_amd.nn.modules.conv import VirtualUpsample
+    pm, rs = _mods()
+    n, cu, cs, cout, h, w = case
+    o, m = _pair(om.Conv, pm.Conv, (cu + cs, cout, 1, 1), "upcat")
+    u = bf16_round(P.uniform(f"upcat_u{case}", (n, cu, h, w), -1, 1))
+    sk = bf16_round(P.uniform(f"upcat_s{case}", (n, cs, 2 * h, 2 * w), -1, 1))
+    with torch.no_grad():
+        ref = o(torch.cat([torch.nn.functional.interpolate(u, scale_factor=2, mode="nearest"), sk], 1))
+        ud = to_dev_nhwc(u, torch.bfloat16)
+        buf = R.alloc_nhwc(n, cu + cs, 2 * h, 2 * w, torch.bfloat16, DEV)
+        buf.fill_(7.0)  # the leading channels must not be read on the fused path
+        buf[:, cu:].copy_(to_dev_nhwc(sk, torch.bfloat16))
+        up = rs.Upsample(None, 2, "nearest")
+        done = []
+        y = to_cpu_nchw(m(buf, up=VirtualUpsample(ud, cu, lambda: done.append(up(ud, out=buf[:, :cu])))))
+        assert bool(done) == (cu % 32 != 0)  # fused unless the upsampled part is not whole k-tiles
+        up(ud, out=buf[:, :cu])
+        y2 = to_cpu_nchw(m(buf))
+    assert torch.equal(y, y2)
+    assert (y - ref).abs().max().item() <= 3e-2 * max(1.0, ref.abs().max().item())
+
+
 C2F_CASES = [
     # c1, n, shortcut, (N, H, W)
     (32, 1, True, (2, 37, 50)), (32, 1, True, (1, 16, 16)), (32, 1, True, (3, 5, 9)), (32, 1, True, (2, 160, 160)),

@@ -81,21 +81,31 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_stream_kernel(const C1Para
   int mark[RING];
   int ig = gw, ikt = 0;
   unsigned ioff[MT];  // byte offset of this lane's pixel in each tile of the issue group (0xffffffff: past the end)
+  unsigned uoff[MT];  // ... of its source pixel (y / 2, x / 2) in the half-resolution tensor of a virtual Upsample + Concat
   auto issue_group = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int pix = (ig * MT + i) * 16 + p16;
       ioff[i] = pix < p.P ? (unsigned)pix * (unsigned)ldx2 + (unsigned)(kg * 16) : 0xffffffffu;
+      if (EPI == 0 && p.upKT) {  // uniform (the Detect tails never take a virtual input)
+        const unsigned row = __umulhi((unsigned)pix, p.upMagicW);  // n * H + y
+        const unsigned xx = (unsigned)pix - row * (unsigned)p.upW;
+        const unsigned nn = __umulhi(row, p.upMagicH);
+        const unsigned yy = row - nn * (unsigned)p.upH;
+        const unsigned sp = (nn * (unsigned)(p.upH >> 1) + (yy >> 1)) * (unsigned)(p.upW >> 1) + (xx >> 1);
+        uoff[i] = sp * (unsigned)(p.up_ld * 2) + (unsigned)(kg * 16);
+      }
     }
   };
   issue_group();
   auto issue = [&](int stage) __attribute__((always_inline)) {
     if (ig < p.groups) {
       const bool chok = kg < ngrpAll - ikt * 4;
-      const char* xk = p.x + ikt * 64;
+      const bool fromUp = EPI == 0 && ikt < p.upKT;  // uniform
+      const char* xk = (fromUp ? p.up : p.x) + ikt * 64;
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        const char* src = (chok && ioff[i] != 0xffffffffu && !(p.ablate & 1)) ? xk + ioff[i]
+        const char* src = (chok && ioff[i] != 0xffffffffu && !(p.ablate & 1)) ? xk + (fromUp ? uoff[i] : ioff[i])
                                                                             : reinterpret_cast<const char*>(g_c1_zero16);
         __builtin_amdgcn_global_load_lds((c1gptr_t)src, (c1lptr_t)(ring + (stage * MT + i) * 1024), 16, 0, 0);
       }
@@ -384,5 +394,30 @@ extern "C" int upa_detect_tail(const void* x, int n, int h, int w, int cin, int 
   q.de.y = y; q.de.a_total = a_total; q.de.a0 = a0; q.de.HW = h * w; q.de.W = w;
   q.de.magicHW = upa_magic_div(h * w); q.de.magicW = upa_magic_div(w);
   q.de.nc = nc; q.de.stride_px = stride_px;
+  return upa_conv1x1_launch(q, n * h * w, 0, nullptr, stream);
+}
+
+// 1x1 conv whose input is Concat([Upsample(2x nearest)(up), skip]) WITHOUT the upsampled tensor ever being written: the first
+// up_c channels of a pixel are read from pixel (y / 2, x / 2) of `up` (n, h / 2, w / 2, up_c), the remaining cin - up_c from the
+// concat buffer x (n, h, w, cin) itself, where the skip producer wrote them in place.  Replaces nn.Upsample(None, 2, 'nearest')
+// + Concat (yolov8.yaml rows 10-11, 13-14; nn/modules/conv.py Concat.forward) + the following C2f's cv1 (block.py:479).
+// Returns UPA_EUNSUPPORTED when the shape is not the streaming kernel's (callers then write the upsample and run the conv).
+extern "C" int upa_conv1x1_upcat(const void* x, int n, int h, int w, int cin, int ldx, const void* up, int up_c, int up_ld,
+                                 const void* w_packed, const float* bias, void* y, int cout, int ldy, int act, int dtype,
+                                 void* stream) {
+  UPA_CHECK_ARG(x && up && w_packed && y && n > 0 && h > 0 && w > 0, "conv1x1_upcat: bad args");
+  static const bool off = getenv("UPA_NO_UPCAT") != nullptr;
+  if (off || (h & 1) || (w & 1) || up_c <= 0 || up_c % 32 != 0 || up_c >= cin || up_ld % 8 != 0 || ((uintptr_t)up % 16) != 0 ||
+      (long)n * (h / 2) * (w / 2) * up_ld * 2 >= (1L << 31) - 4096 ||
+      !upa_conv1x1_eligible(n, h, w, cin, ldx, cout, ldy, false, 1, 1, 0, act, dtype)) {
+    upa_set_error("conv1x1_upcat: outside the fused form (bf16 streaming 1x1, even h / w, up_c %% 32 == 0)");
+    return UPA_EUNSUPPORTED;
+  }
+  C1Params q;
+  memset(&q, 0, sizeof(q));
+  q.x = (const char*)x; q.y = (char*)y; q.w = (const char*)w_packed; q.bias = bias;
+  q.Cin = cin; q.ldx = ldx; q.Cout = cout; q.ldy = ldy; q.act = act;
+  q.up = (const char*)up; q.upKT = up_c / 32; q.up_ld = up_ld; q.upH = h; q.upW = w;
+  q.upMagicW = upa_magic_div(w); q.upMagicH = upa_magic_div(h);
   return upa_conv1x1_launch(q, n * h * w, 0, nullptr, stream);
 }

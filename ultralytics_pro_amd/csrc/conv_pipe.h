@@ -32,6 +32,11 @@ struct C1Params {
   int epi;     // 0: y = act(conv + bias) as bf16 rows; 1 / 2: Detect box / class decode fused on the end (detect_epi.h), the
                // bf16 rows are written too when y != nullptr
   DetectEpi de;
+  // virtual Upsample(2x nearest) + Concat in front of the conv (upa_conv1x1_upcat): the first upKT k-tiles of a pixel come from
+  // pixel (y / 2, x / 2) of the half-resolution tensor `up`, the rest from x (the concat buffer, whose first channels stay unwritten)
+  const char* up;
+  int upKT, up_ld, upH, upW;       // k-tiles taken from `up`, its pixel stride (elements), FULL-resolution H and W
+  unsigned upMagicW, upMagicH;
 };
 bool upa_conv1x1_eligible(int n, int h, int w, int cin, int ldx, int cout, int ldy, bool residual, int k, int stride,
                           int pad, int act, int dtype);

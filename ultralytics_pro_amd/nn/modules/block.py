@@ -112,15 +112,19 @@ class C2f(nn.Module):
             L.check(rc, "c2f_fused")
         return None
 
-    def forward(self, x, out=None):
+    def forward(self, x, out=None, up=None):
+        """`up`: a conv.VirtualUpsample for the leading channels of x (see BaseModel._predict_once) - consumed by cv1."""
         x = R.to_nhwc(x, x.dtype)
+        if up is not None and self.fuse_block and self.cv1.conv.in_channels in (32, 64):
+            up.materialize()  # the whole-block kernels read x themselves
+            up = None
         y = self._fused(x, out)
         if y is not None:
             return y
         n, _, h, w = x.shape
         c, nb = self.c, len(self.m)
         cat = R.alloc_nhwc(n, (2 + nb) * c, h, w, x.dtype, x.device, key=(id(self), "cat"))
-        self.cv1(x, out=cat[:, : 2 * c])
+        self.cv1(x, out=cat[:, : 2 * c], up=up)
         for i, m in enumerate(self.m):
             m(cat[:, (1 + i) * c: (2 + i) * c], out=cat[:, (2 + i) * c: (3 + i) * c])
         return self.cv2(cat, out=out)

@@ -70,8 +70,18 @@ class PackedConv:
                       f"packed {nm} cout={self.cout} cin={self.cin} k={k}", file=sys.stderr, flush=True)
 
 
+class VirtualUpsample:
+    """An Upsample(2x nearest) that was NOT launched: `src` is the half-resolution tensor, `channels` the leading channels
+    of the concat buffer it would have filled, `materialize()` launches it after all.  The 1x1 conv that consumes the
+    Concat reads `src` at (y/2, x/2) instead (`upa_conv1x1_upcat`)."""
+
+    def __init__(self, src: torch.Tensor, channels: int, materialize):
+        self.src, self.channels, self.materialize = src, int(channels), materialize
+
+
 def hip_conv2d(x: torch.Tensor, pk: PackedConv, stride: int, pad: int, act: int, out: torch.Tensor | None = None,
-               residual: torch.Tensor | None = None, out_dtype: torch.dtype | None = None, key=None) -> torch.Tensor:
+               residual: torch.Tensor | None = None, out_dtype: torch.dtype | None = None, key=None,
+               up: VirtualUpsample | None = None) -> torch.Tensor:
     """y = act(conv(x) + b) (+ residual) on the HIP path. x: NHWC view, or raw NCHW model input when pk.stem."""
     L.require_gpu(x, "conv2d")
     lib = L.lib()
@@ -108,6 +118,19 @@ def hip_conv2d(x: torch.Tensor, pk: PackedConv, stride: int, pad: int, act: int,
         if (vr.n, vr.h, vr.w, vr.c, vr.dtype) != (vy.n, vy.h, vy.w, vy.c, vy.dtype):
             raise L.UpaError("conv2d: residual shape/dtype mismatch")
         rp, rld = vr.ptr, vr.ld
+    if up is not None:
+        # the leading channels of x were never written: read them from the half-resolution tensor, or write them now
+        vu = R.view_of(up.src)
+        rc = L.UPA_EUNSUPPORTED
+        if pk.k == 1 and stride == 1 and pad == 0 and residual is None and vu.dtype == vx.dtype and vu.c == up.channels \
+                and (vu.n, 2 * vu.h, 2 * vu.w) == (vx.n, vx.h, vx.w):
+            rc = lib.upa_conv1x1_upcat(vx.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, vu.ptr, vu.c, vu.ld, pk.w.data_ptr(),
+                                       pk.bias.data_ptr(), vy.ptr, pk.cout, vy.ld, act, vx.dtype, stream)
+        if rc == 0:
+            return y
+        if rc != L.UPA_EUNSUPPORTED:
+            L.check(rc, "conv1x1_upcat")
+        up.materialize()
     L.check(lib.upa_conv2d_bias_act(vx.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, pk.w.data_ptr(), pk.bias.data_ptr(), vy.ptr,
                                     pk.cout, vy.ld, rp, rld, pk.k, stride, pad, act, vx.dtype, stream), "conv2d")
     return y
@@ -178,7 +201,7 @@ class Conv(nn.Module, _HipConvMixin):
             return L.ACT_NONE
         raise L.UpaError(f"activation {self.act} has no HIP epilogue")
 
-    def forward(self, x, out=None, residual=None):
+    def forward(self, x, out=None, residual=None, up=None):
         """act(bn(conv(x))) with BN folded into the HIP conv epilogue (conv.py:177-197 compute the same function)."""
         if self.training:
             raise L.UpaError("training-mode Conv (batch-statistics BN) is not on the HIP path yet (SURVEY §8f rank 2)")
@@ -186,8 +209,11 @@ class Conv(nn.Module, _HipConvMixin):
         # raw uint8 frames with no compute dtype chosen: float32 activations (the reference's `im.float()`, predictor.py:169)
         dt = (self.compute_dtype or (torch.float32 if x.dtype == torch.uint8 else x.dtype)) if stem else x.dtype
         pk = self._packed(self.conv, getattr(self, "bn", None), x.device, dt, stem)
+        if up is not None and stem:
+            up.materialize()
+            up = None
         return hip_conv2d(x, pk, self.conv.stride[0], self.conv.padding[0], self._act_code(), out=out, residual=residual,
-                          out_dtype=dt, key=(id(self), "y"))
+                          out_dtype=dt, key=(id(self), "y"), up=up)
 
     forward_fuse = forward  # BN is always folded on the HIP path (tasks.py:1134 rebinding is a no-op here)
 

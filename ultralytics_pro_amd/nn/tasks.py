@@ -20,6 +20,7 @@ import yaml
 from .. import _lib as L
 from ..engine import runtime as R
 from .modules import (C2f, C3, SPPF, BoT3, Bottleneck, Concat, Conv, Detect)
+from .modules.conv import VirtualUpsample
 from .modules.resample import MaxPool2d, Upsample, ZeroPad2d
 
 CFG_DIR = Path(__file__).resolve().parents[1] / "cfg" / "models"
@@ -209,6 +210,7 @@ class BaseModel(nn.Module):
                 srcs = sorted(det_level, key=lambda j: det_level[j])
                 det.begin(int(x.shape[0]), [hw[j] for j in srcs], getattr(self, "compute_dtype", None) or x.dtype, x.device)
         fused_stem = self._stem_fusable(x, place)
+        virt = {}  # concat layer index -> VirtualUpsample: an Upsample feeding that Concat which was not launched (see below)
         for m in self.model:
             if fused_stem and m.i == 0:  # layers 0 and 1 run as ONE kernel: the stem output never reaches HBM
                 x = self._fused_stem(x)
@@ -228,7 +230,15 @@ class BaseModel(nn.Module):
                     dt = getattr(self, "compute_dtype", None) if (x.shape[1] <= 4 and not R.is_nhwc_view(x)) else None
                     buf = R.alloc_nhwc(n, ctot, oh, ow, dt or x.dtype, x.device, key=(id(self.model[li]), "y"))
                     cat_buf[li] = buf
-                x = m(x, out=buf[:, c0:c1])
+                if self._virtual_upsample_ok(m, li, c0, c1, x):
+                    # Upsample -> Concat -> C2f: the C2f's cv1 reads the half-resolution tensor at (y/2, x/2) itself
+                    # (upa_conv1x1_upcat); the upsampled copy (52 + 26 MB per step for yolov8n) is never written
+                    virt[li] = VirtualUpsample(x, c1 - c0, (lambda m=m, x=x, dst=buf[:, c0:c1]: m(x, out=dst)))
+                    x = buf[:, c0:c1]
+                elif m.f == -1 and (m.i - 1) in virt:
+                    x = m(x, out=buf[:, c0:c1], up=virt.pop(m.i - 1))
+                else:
+                    x = m(x, out=buf[:, c0:c1])
             elif isinstance(m, Concat) and m.i in cat_buf:
                 buf, c0 = cat_buf[m.i], 0
                 for t in x:  # anything not produced in place (none for the reference YAMLs) is copied by Concat rules
@@ -240,8 +250,12 @@ class BaseModel(nn.Module):
                                                       L.current_stream(t.device)), "copy_view")
                     c0 += c
                 x = buf
+            elif m.f == -1 and (m.i - 1) in virt:
+                x = m(x, up=virt.pop(m.i - 1))
             else:
                 x = m(x)
+            if virt and not isinstance(m, (Upsample, Concat)):
+                raise L.UpaError(f"virtual Upsample of Concat row(s) {sorted(virt)} was not consumed by row {m.i}")
             y.append(x if m.i in self.save else None)
             if _EXTRA_LAUNCHES and torch.is_tensor(x):  # experiment: what does one more tiny dependent launch cost a step?
                 d = R.alloc_plain((64,), torch.float32, x.device, key=("extra_launch", m.i))
@@ -250,6 +264,17 @@ class BaseModel(nn.Module):
             if m.i in det_level and torch.is_tensor(x):  # a Detect input is ready: start that level's branches now
                 det.start_level(det_level[m.i], x)
         return x
+
+    virtual_upsample = True
+
+    def _virtual_upsample_ok(self, m, li: int, c0: int, c1: int, x) -> bool:
+        """An Upsample row may stay unlaunched when it fills the LEADING channels of a Concat that only the next row reads,
+        that row is a C2f (its cv1 is the 1x1 conv that can read the half-resolution tensor) and the data is bf16."""
+        if not (self.virtual_upsample and isinstance(m, Upsample) and c0 == 0 and (c1 - c0) % 32 == 0
+                and x.dtype == torch.bfloat16 and li not in self.save and li + 1 < len(self.model)):
+            return False
+        nxt = self.model[li + 1]
+        return isinstance(nxt, C2f) and nxt.f == -1 and nxt.cv1.conv.kernel_size == (1, 1) and not self.training
 
     def _static_hw(self, h: int, w: int):
         """Output (h, w) of every layer for an (h, w) image: a shape walk of the graph, no tensors (cached per size)."""
