@@ -670,7 +670,7 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
             torch.cuda.synchronize(dev)
         fl = 2.0 * n_ * ((h_ // 2) * (w_ // 2) * 16 * 27 + (h_ // 4) * (w_ // 4) * 32 * 144)
         by = n_ * 3 * h_ * w_ * es + n_ * (h_ // 4) * (w_ // 4) * 32 * es
-        fam["stem_conv_fused_kernel(StemFusedParams)"] = dict(launches=1, ms=e0.elapsed_time(e1) / reps, flops=fl, bytes=float(by))
+        fam["void stem_conv_fused_kernel<%d>(StemFusedParams)" % int(os.environ.get("UPA_STEMF_WAVES", "8"))] = dict(launches=1, ms=e0.elapsed_time(e1) / reps, flops=fl, bytes=float(by))
     conv_ms = sum(d["ms"] for d in fam.values())
     conv_flops = sum(d["flops"] for d in fam.values())
     conv_bytes = sum(d["bytes"] for d in fam.values())

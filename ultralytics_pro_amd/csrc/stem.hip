@@ -446,12 +446,18 @@ constexpr int PR = 2 * S0H + 1, PC = 2 * S0W + 1;  // input patch 35 x 67
 constexpr int NCH = (PC + 7 + 7) / 8;          // 16-byte chunks per patch line (origin rounded down to 8 pixels)
 constexpr int LS = NCH * 8;
 constexpr int ITEMS = 3 * PR * NCH;
-constexpr int ITEMS_PAD = (ITEMS + 255) / 256 * 256;
-constexpr int PATCH = ITEMS_PAD * 16;
+constexpr int items_pad(int nw) { return (ITEMS + nw * 64 - 1) / (nw * 64) * (nw * 64); }
+constexpr int patch_bytes(int nw) { return items_pad(nw) * 16; }
 }  // namespace sf
 
-__global__ __launch_bounds__(256) void stem_conv_fused_kernel(const StemFusedParams p) {
+// NW waves per workgroup: 4 (two workgroups = two waves per SIMD) or 8 (four per SIMD: the segments of stage 2 and the rows of
+// stage 3 are spread over twice the waves, the same LDS).
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void stem_conv_fused_kernel(const StemFusedParams p) {
   using namespace sf;
+  constexpr int ITEMS_PAD = items_pad(NW);
+  constexpr int PATCH = patch_bytes(NW);
+  constexpr int NTH = NW * 64;
   extern __shared__ __attribute__((aligned(16))) char fsm[];  // [2][PATCH] input patches, [STILE] stem tile
   char* stile = fsm + 2 * PATCH;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -469,15 +475,15 @@ __global__ __launch_bounds__(256) void stem_conv_fused_kernel(const StemFusedPar
     const int ixa = ix0 & ~7;
     const bf16_t* xb = (const bf16_t*)p.x + (size_t)n * 3 * plane;
 #pragma unroll
-    for (int it = 0; it < ITEMS_PAD / 256; ++it) {
-      const int item = it * 256 + tid;
+    for (int it = 0; it < ITEMS_PAD / NTH; ++it) {
+      const int item = it * NTH + tid;
       const int line = item / NCH, ch = item - line * NCH;
       const int ci = line / PR, row = line - ci * PR;
       const int iy = iy0 + row, ix = ixa + ch * 8;
       const bool in = item < ITEMS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
       const char* src = in ? reinterpret_cast<const char*>(xb + ci * plane + iy * p.W + ix)
                            : reinterpret_cast<const char*>(g_stem_zero16);
-      __builtin_amdgcn_global_load_lds((sgptr_t)src, (slptr_t)(buf + (it * 256 + wave * 64) * 16), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((sgptr_t)src, (slptr_t)(buf + (it * NTH + wave * 64) * 16), 16, 0, 0);
     }
   };
   int tile = blockIdx.x;
@@ -541,7 +547,7 @@ __global__ __launch_bounds__(256) void stem_conv_fused_kernel(const StemFusedPar
     const char* pb = fsm + cur * PATCH;
     // ---- stage 2: the 17 x 33 stem tile, 16 stem pixels per MFMA; segment = 16 consecutive pixels of the linearised tile
     constexpr int NSEG = (S0H * S0W + 15) / 16;  // 36
-    for (int sg = wave; sg < NSEG; sg += 4) {
+    for (int sg = wave; sg < NSEG; sg += NW) {
       const int q = sg * 16 + l16;
       const int r = q / S0W, c = q - r * S0W;     // stem tile row / column of this lane's pixel (q may run past the tile)
       unsigned e[8];
@@ -565,10 +571,10 @@ __global__ __launch_bounds__(256) void stem_conv_fused_kernel(const StemFusedPar
             u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
     }
     __syncthreads();
-    // ---- stage 3: second conv, wave w owns output rows 2w, 2w+1 (16 pixels each) x 32 channels
+    // ---- stage 3: second conv, a wave owns T1H / NW output rows (16 pixels each) x 32 channels
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-      const int i = wave * 2 + rr;
+    for (int rr = 0; rr < T1H / NW; ++rr) {
+      const int i = wave * (T1H / NW) + rr;
       f32x4 acc[2] = {bias1[0], bias1[1]};
 #pragma unroll
       for (int s = 0; s < 5; ++s) {
@@ -684,10 +690,15 @@ extern "C" int upa_stem_conv_fused(const void* x, int n, int h, int w, const flo
   p.tilesX = cdiv(p.OW, sf::T1W); p.tilesY = cdiv(p.OH, sf::T1H);
   const long ntiles = (long)p.tilesX * p.tilesY * n;
   static const int wgs = getenv("UPA_STEMF_WGS") ? atoi(getenv("UPA_STEMF_WGS")) : 512;
-  const size_t lds = (size_t)2 * sf::PATCH + sf::STILE;
-  auto kern = stem_conv_fused_kernel;
-  (void)upa_full_lds<stem_conv_fused_kernel>();
-  hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < wgs ? ntiles : wgs)), dim3(256), lds, (hipStream_t)stream, p);
+  static const int nw = getenv("UPA_STEMF_WAVES") ? atoi(getenv("UPA_STEMF_WAVES")) : 8;
+  const dim3 grid((unsigned)(ntiles < wgs ? ntiles : wgs));
+  if (nw == 4) {
+    (void)upa_full_lds<stem_conv_fused_kernel<4>>();
+    hipLaunchKernelGGL(stem_conv_fused_kernel<4>, grid, dim3(256), (size_t)2 * sf::patch_bytes(4) + sf::STILE, (hipStream_t)stream, p);
+  } else {
+    (void)upa_full_lds<stem_conv_fused_kernel<8>>();
+    hipLaunchKernelGGL(stem_conv_fused_kernel<8>, grid, dim3(512), (size_t)2 * sf::patch_bytes(8) + sf::STILE, (hipStream_t)stream, p);
+  }
   UPA_LAUNCH_CHECK();
   return UPA_OK;
 }
