@@ -39,9 +39,8 @@ constexpr int TH = 16, TW = 16;
 constexpr int XH = TH + 4, XW = TW + 4;      // x / y1 halo tile 20 x 20
 constexpr int MH = TH + 2, MW = TW + 2;      // t tile 18 x 18
 constexpr int XPX = XH * XW, MPX = MH * MW;  // 400, 324
-constexpr int XITEMS = XPX * 4;              // 16-byte items of the x tile
-constexpr int XIT = (XITEMS + 255) / 256;    // DMA rounds of 256 lanes
-constexpr int XS_BYTES = XIT * 256 * 16;     // 28672
+constexpr int XITEMS = XPX * 4;              // 16-byte items of the x tile (a multiple of 64: whole waves)
+constexpr int XS_BYTES = XITEMS * 16;        // 25600
 constexpr int Y1_BYTES = XPX * 32;           // 12800
 constexpr int MT_B = (MPX + 15) / 16;        // 21 m-tiles of t
 constexpr int TS_BYTES = MT_B * 16 * 32;     // 10752
@@ -56,8 +55,14 @@ __device__ __forceinline__ f32x4 mfma16(const u32x2& a, const u32x2& b, f32x4 c)
 }
 }  // namespace c2f
 
-__global__ __launch_bounds__(256) void c2f16_fused_kernel(const C2fParams p) {
+// NW waves per workgroup: 4 (84 VGPRs, three workgroups per CU = three waves per SIMD; the default) or 8 (107 VGPRs, two
+// workgroups = four per SIMD: measured 52.6 us against 51 and 0.651 against 0.647 ms per step - kept for experiments)
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void c2f16_fused_kernel(const C2fParams p) {
   using namespace c2f;
+  constexpr int NTH = NW * 64;
+  constexpr int XIT = (XITEMS + NTH - 1) / NTH;
+  static_assert(XITEMS % 64 == 0, "the DMA guard must be wave-uniform");
   extern __shared__ __attribute__((aligned(16))) char sm[];
   char* xs = sm;
   char* y1s = sm + XS_BYTES;
@@ -75,14 +80,15 @@ __global__ __launch_bounds__(256) void c2f16_fused_kernel(const C2fParams p) {
   // ---- 0. x halo tile
 #pragma unroll
   for (int it = 0; it < XIT; ++it) {
-    const int item = it * 256 + tid;
+    if (it * NTH + wave * 64 >= XITEMS) break;  // wave-uniform
+    const int item = it * NTH + tid;
     const int px = item >> 2, slot = item & 3;
     const int hy = px / XW, hx = px - hy * XW;
     const int iy = oy0 - 2 + hy, ix = ox0 - 2 + hx;
     const char* src = reinterpret_cast<const char*>(g_c2f_zero16);
-    if (item < XITEMS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+    if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
       src = p.x + (((size_t)n * p.H + iy) * p.W + ix) * (size_t)p.ldx * 2 + slot * 16;
-    __builtin_amdgcn_global_load_lds((cgptr_t)src, (clptr_t)(xs + (it * 256 + wave * 64) * 16), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((cgptr_t)src, (clptr_t)(xs + (it * NTH + wave * 64) * 16), 16, 0, 0);
   }
 
   // ---- weights -> registers while the tile is in flight.  Packed layout: [tap][k-tile][n-tile][lane (g, r)][16 B], lane (g, r) =
@@ -122,7 +128,7 @@ __global__ __launch_bounds__(256) void c2f16_fused_kernel(const C2fParams p) {
   __syncthreads();
 
   // ---- A. y1 on the 400 halo pixels
-  for (int mt = wave; mt < XPX / 16; mt += 4) {
+  for (int mt = wave; mt < XPX / 16; mt += NW) {
     const int q = mt * 16 + r;
     const u32x4 b = *reinterpret_cast<const u32x4*>(xs + q * 64 + g * 16);
     const f32x4 acc = mfma32(w_y1, b, bias_y1);
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(256) void c2f16_fused_kernel(const C2fParams p) {
   __syncthreads();
 
   // ---- B. t on the 18 x 18 inner pixels
-  for (int mt = wave; mt < MT_B; mt += 4) {
+  for (int mt = wave; mt < MT_B; mt += NW) {
     const int q = mt * 16 + r;
     const int qc = q < MPX ? q : MPX - 1;
     const int ty = qc / MW, tx = qc - ty * MW;
@@ -154,10 +160,10 @@ __global__ __launch_bounds__(256) void c2f16_fused_kernel(const C2fParams p) {
   }
   __syncthreads();
 
-  // ---- C + D. wave w owns tile rows 4w .. 4w + 3 (one m-tile each)
+  // ---- C + D. a wave owns TH / NW tile rows (one m-tile each)
 #pragma unroll 1
-  for (int rr = 0; rr < 4; ++rr) {
-    const int i = wave * 4 + rr;
+  for (int rr = 0; rr < TH / NW; ++rr) {
+    const int i = wave * (TH / NW) + rr;
     const char* base = ts + (i * MW + r) * 32;
     f32x4 acc = bias_b;
 #pragma unroll
@@ -453,7 +459,9 @@ extern "C" int upa_c2f_fused(const void* x, int n, int h, int w, int c1, int ldx
     p.w1 = (const char*)w1; p.wa = (const char*)wm[0]; p.wb = (const char*)wm[1]; p.w2 = (const char*)w2;
     p.b1 = b1; p.ba = bm[0]; p.bb = bm[1]; p.b2 = b2;
     p.N = n; p.H = h; p.W = w; p.ldx = ldx; p.ldy = ldy; p.tilesX = tx; p.tilesY = ty;
-    hipLaunchKernelGGL(c2f16_fused_kernel, dim3((unsigned)tiles), dim3(256), c2f::LDS, s, p);
+    static const int nw = getenv("UPA_C2F16_WAVES") ? atoi(getenv("UPA_C2F16_WAVES")) : 4;
+    if (nw == 4) hipLaunchKernelGGL(c2f16_fused_kernel<4>, dim3((unsigned)tiles), dim3(256), c2f::LDS, s, p);
+    else hipLaunchKernelGGL(c2f16_fused_kernel<8>, dim3((unsigned)tiles), dim3(512), c2f::LDS, s, p);
     UPA_LAUNCH_CHECK();
     return UPA_OK;
   }
