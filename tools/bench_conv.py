@@ -42,7 +42,9 @@ def main():
     calls = []
     orig = pconv.hip_conv2d
 
-    def rec(xx, pk, stride, pad, act, out=None, residual=None, out_dtype=None, key=None):
+    def rec(xx, pk, stride, pad, act, out=None, residual=None, out_dtype=None, key=None, up=None):
+        if up is not None:  # per-layer table: time the conv over the materialised concat buffer
+            up.materialize()
         y = orig(xx, pk, stride, pad, act, out=out, residual=residual, out_dtype=out_dtype, key=key)
         calls.append((xx, pk, stride, pad, act, y, residual, out_dtype))
         return y
