@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--no-kernel-profile", action="store_true",
                     help="skip the per-layer roofline timing (counter-collection runs: tools/pmc_step.sh)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = the plan of BASELINE.md section 3 (8, 32, physical cores)")
+    ap.add_argument("--cpu-baseline-child", default=None, metavar="OUT.json",
+                    help="internal: run only the CPU baseline leg (no GPU is touched) and keep OUT.json up to date after every "
+                         "measured line - bench.py starts itself this way as a child process with a wall-clock limit")
     ap.add_argument("--serial", action="store_true",
                     help="no intra-step concurrency (Detect branches on the main stream): per-kernel durations in a "
                          "rocprofv3 trace of this mode are directly comparable with roofline.avg_launch_us")
@@ -125,6 +128,14 @@ def main_dry_run(args):
         dist.destroy_process_group()
 
 
+_T0 = time.perf_counter()
+
+
+def _crumb(msg: str) -> None:
+    """Progress marker on stderr (stdout carries the one JSON line): tells where a run that never finished was stuck."""
+    print(f"[bench +{time.perf_counter() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -135,6 +146,8 @@ def main():
         args.model = "yolov8s" if args.workload == "train" else "yolov8n"
     if args.steps <= 0:
         args.steps = 80 if args.workload == "train" else (1500 if args.model == "yolov8n" else 200)
+    if args.cpu_baseline_child:
+        return cpu_baseline_child(args)
     if args.workload == "train":
         return main_train(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -209,6 +222,7 @@ def main():
             runner = PipelinedRunner(model, xs, post, micro_batches=args.micro_batches, in_flight=args.in_flight,
                                      linear=bool(args.serial or (args.linear_graphs and args.micro_batches == 1)))
         run = runner.runs[0]
+        _crumb("graphs compiled" + (" (autotuned)" if tuned else ""))
         for _ in range(args.warmup):
             runner.step()
         torch.cuda.synchronize(dev)
@@ -252,14 +266,13 @@ def main():
     elif rank == 0:
         serial_ms = ms_per_step
     if rank == 0:
-        if os.environ.get("UPA_BENCH_TRACE"):
-            print("[bench] timed region done", file=sys.stderr, flush=True)
+        _crumb("timed region + serial / latency legs done")
         if not args.no_kernel_profile:
             roofline, kernels = kernel_profile(model, x, dtype, dev, args, pconv, L, post)
-        if os.environ.get("UPA_BENCH_TRACE"):
-            print("[bench] kernel profile done", file=sys.stderr, flush=True)
+            _crumb("kernel profile done")
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
-            cpu_baseline = run_cpu_baseline(args)
+            cpu_baseline = run_cpu_baseline_bounded(args)
+            _crumb("cpu baseline done")
     if rank == 0:
         line = {
             # `value` is the whole-job total over n_gpus ranks of per-GPU batch 32 (the contract); the per-GPU figure of
@@ -375,7 +388,7 @@ def main_train(args):
     if rank == 0:
         roofline = wgrad_profile(tr, L, R, dev, dtype)
         if not args.no_cpu_baseline and world == 1:
-            cpu_baseline = run_cpu_train_baseline(args)
+            cpu_baseline = run_cpu_baseline_bounded(args)
         nparam = sum(n for _, n, _ in tr.groups)
         print(json.dumps({
             "metric": f"images/sec {args.model} {args.imgsz}x{args.imgsz} training step, per-GPU batch {args.batch} "
@@ -739,7 +752,65 @@ def physical_cores() -> int:
     return os.cpu_count() or 1
 
 
-def run_cpu_baseline(args, budget_s: float = 45.0):
+def cpu_baseline_child(args):
+    """Child-process entry of the CPU baseline leg: never touches the GPU; the result file is rewritten after every line."""
+    out = args.cpu_baseline_child
+    res = run_cpu_train_baseline(args) if args.workload == "train" else run_cpu_baseline(args, progress=out)
+    with open(out, "w") as f:
+        json.dump(res, f)
+    return 0
+
+
+def run_cpu_baseline_bounded(args, limit_s: float = 150.0):
+    """Run the CPU baseline leg as a child process (`bench.py --cpu-baseline-child`) with a hard wall-clock limit.
+
+    The leg times torch CPU convolutions at up to all physical cores of a host that bench.py does not own: on a busy or
+    oversubscribed host a single forward can take minutes (it once stalled a whole default run), and an in-process forward
+    cannot be interrupted.  The child keeps its result file current, so whatever was measured before the limit is reported
+    (`"truncated": true`); the GPU numbers never wait for more than `limit_s`."""
+    import subprocess
+    import tempfile
+    fd, out = tempfile.mkstemp(prefix="upa_cpu_baseline_", suffix=".json")
+    os.close(fd)
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", out, "--workload", args.workload, "--model", args.model,
+           "--batch", str(args.batch), "--imgsz", str(args.imgsz), "--cpu-threads", str(args.cpu_threads)]
+    env = dict(os.environ, OMP_WAIT_POLICY="passive", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    truncated = False
+    try:
+        subprocess.run(cmd, env=env, timeout=limit_s, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
+    except subprocess.TimeoutExpired:  # subprocess.run has killed the child
+        truncated = True
+    try:
+        with open(out) as f:
+            res = json.load(f)
+    except (OSError, ValueError):
+        res = None
+    finally:
+        try:
+            os.unlink(out)
+        except OSError:
+            pass
+    if res is None:
+        return {"value": None, "unit": "images/s", "cores": 0, "kind": "port",
+                "sample": f"CPU baseline leg produced nothing within {limit_s:.0f} s on this host (child process killed)"}
+    if truncated:
+        res["truncated"] = True
+        res["sample"] += f"; the leg was cut at {limit_s:.0f} s wall clock, later (config, threads) lines are missing"
+    return res
+
+
+def _cpu_baseline_result(args, lines, logical, phys):
+    head = [ln for ln in lines if ln["config"] == args.model and "forward_nms_img_s" in ln]
+    if not head:
+        return None
+    top = max(head, key=lambda ln: ln["forward_nms_img_s"])
+    return {"value": top["forward_nms_img_s"], "unit": "images/s", "cores": top["threads"], "kind": "port",
+            "sample": f"oracle (torch CPU fp32, fused eval) {args.model} bs={args.batch} forward+NMS at {top['threads']} threads, best "
+                      f"of {top['best_of']}; host: {logical} logical / {phys} physical cores; every (config, threads) line is in `lines`",
+            "host_logical_cores": logical, "host_physical_cores": phys, "lines": lines}
+
+
+def run_cpu_baseline(args, budget_s: float = 45.0, progress: str | None = None):
     """the oracle (CPU restatement, validated bit for bit against the imported reference) on THIS
     host's cores - fused eval, fp32 - for C2 (yolov8n, 32 x 3 x 640 x 640) and C1 (yolov3-tiny, 8 x 3 x 640 x 640), with
     N = 8 threads (the reference's own cap NUM_THREADS = min(8, cpus - 1), utils/__init__.py:43), N = 32 and N = all physical
@@ -785,12 +856,16 @@ def run_cpu_baseline(args, budget_s: float = 45.0):
                           "forward_img_s": round(b / best_f, 2), "forward_nms_img_s": round(b / (best_f + best_n), 2),
                           "speed": "Speed: %.1fms preprocess, %.1fms inference, %.1fms loss, %.1fms postprocess per image" % (
                               0.0, best_f / b * 1e3, 0.0, best_n / b * 1e3)})
-    head = [ln for ln in lines if ln["config"] == args.model and "forward_nms_img_s" in ln]
-    top = max(head, key=lambda ln: ln["forward_nms_img_s"])
-    return {"value": top["forward_nms_img_s"], "unit": "images/s", "cores": top["threads"], "kind": "port",
-            "sample": f"oracle (torch CPU fp32, fused eval) {args.model} bs={args.batch} forward+NMS at {top['threads']} threads, best "
-                      f"of {top['best_of']}; host: {logical} logical / {phys} physical cores; every (config, threads) line is in `lines`",
-            "host_logical_cores": logical, "host_physical_cores": phys, "lines": lines}
+            if progress:  # keep the parent's view current: it may have to kill this process at its wall-clock limit
+                part = _cpu_baseline_result(args, lines, logical, phys)
+                if part is not None:
+                    with open(progress + ".tmp", "w") as f:
+                        json.dump(part, f)
+                    os.replace(progress + ".tmp", progress)
+    res = _cpu_baseline_result(args, lines, logical, phys)
+    if res is None:
+        raise RuntimeError("CPU baseline: no line of the headline config was measured")
+    return res
 
 
 if __name__ == "__main__":

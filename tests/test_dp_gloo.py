@@ -169,6 +169,26 @@ def _validator_rank(rank, world, port, golden, q):
     dist.destroy_process_group()
 
 
+def test_bench_cpu_baseline_leg_is_wall_clock_bounded():
+    """bench.py's `cpu_baseline` leg runs as a child process with a hard limit: on a host it does not own (busy, or torch CPU
+    convs oversubscribed at all physical cores) one forward can take minutes, and the default `python bench.py` must still
+    finish within minutes.  With a limit shorter than one measurement the parent kills the child and reports that nothing
+    was measured instead of waiting."""
+    import argparse
+    import importlib.util
+    import time
+    from pathlib import Path
+    spec = importlib.util.spec_from_file_location("upa_bench", Path(__file__).resolve().parents[1] / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    args = argparse.Namespace(workload="infer", model="yolov8n", batch=32, imgsz=640, cpu_threads=2)
+    t0 = time.perf_counter()
+    res = bench.run_cpu_baseline_bounded(args, limit_s=3.0)
+    assert time.perf_counter() - t0 < 30.0
+    assert res["kind"] == "port" and res["unit"] == "images/s"
+    assert res["value"] is None or res.get("truncated")  # nothing (or only a prefix) fits into three seconds
+
+
 def test_validator_stats_gather_two_ranks_matches_reference_map(golden_dir):
     """End-of-validation path across ranks (models/yolo/detect/val.py:222-240): every rank holds the statistics of its
     image shard, `gather_stats` all-gathers the fixed-shape tensors (gloo here, RCCL on the GPUs) and EVERY rank computes
