@@ -4,20 +4,21 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/final_r02
 mkdir -p $O
 cd $R
-python bench.py > $O/bench_default.json 2> $O/bench_default.err
-python bench.py --serial --no-cpu-baseline > $O/bench_serial.json 2>/dev/null
-python bench.py --dtype f32 --no-cpu-baseline --steps 200 > $O/bench_f32.json 2>/dev/null
-for m in yolov8s yolov3-tiny yolov5-BoT3; do python bench.py --model $m --no-cpu-baseline --no-kernel-profile --steps 300 > $O/bench_$m.json 2>/dev/null; done
-python bench.py --model yolov3-rtdetr --batch 16 --no-cpu-baseline --no-kernel-profile > $O/bench_yolov3-rtdetr.json 2>/dev/null
-python bench.py --workload train > $O/bench_train.json 2> $O/bench_train.err
-bash tools/pmc_hbm.sh --no-kernel-profile > /dev/null 2>&1
+timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err
+timeout 600 python bench.py --serial --no-cpu-baseline > $O/bench_serial.json 2>/dev/null
+timeout 600 python bench.py --dtype f32 --no-cpu-baseline --steps 200 > $O/bench_f32.json 2>/dev/null
+for m in yolov8s yolov3-tiny yolov5-BoT3; do timeout 600 python bench.py --model $m --no-cpu-baseline --no-kernel-profile --steps 300 > $O/bench_$m.json 2>/dev/null; done
+timeout 600 python bench.py --model yolov3-rtdetr --batch 16 --no-cpu-baseline --no-kernel-profile > $O/bench_yolov3-rtdetr.json 2>/dev/null
+timeout 600 python bench.py --workload train > $O/bench_train.json 2> $O/bench_train.err
+timeout 900 bash tools/pmc_hbm.sh --no-kernel-profile > /dev/null 2>&1
 cp $R/gpurun_out/pmc_hbm/summary.json $O/pmc_hbm_summary.json
-bash tools/pmc_step.sh gpurun_out/pmc_step > /dev/null 2>&1
+timeout 600 python bench.py --no-cpu-baseline > $O/bench_default_with_traffic.json 2>/dev/null   # roofline.traffic from the PMC summary written just above
+timeout 1200 bash tools/pmc_step.sh gpurun_out/pmc_step > /dev/null 2>&1
 cp $R/gpurun_out/pmc_step/summary.txt $O/pmc_step_summary.txt
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -- python3 $R/bench.py --no-cpu-baseline --no-kernel-profile --steps 200 --warmup 10 > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_serial -- python3 $R/bench.py --serial --no-cpu-baseline --steps 60 --warmup 5 > $O/bench_serial_profiled.json 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_train -- python3 $R/bench.py --workload train --no-cpu-baseline --steps 10 --warmup 3 > /dev/null 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -- python3 $R/bench.py --no-cpu-baseline --no-kernel-profile --steps 200 --warmup 10 > /dev/null 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_serial -- python3 $R/bench.py --serial --no-cpu-baseline --steps 60 --warmup 5 > $O/bench_serial_profiled.json 2>/dev/null
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_train -- python3 $R/bench.py --workload train --no-cpu-baseline --steps 10 --warmup 3 > /dev/null 2>&1
 cd $R
 find $O -name "*kernel_trace.csv" -delete   # large; the stats CSVs are what profiles/ keeps
 echo done
