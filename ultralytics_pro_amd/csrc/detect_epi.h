@@ -21,6 +21,13 @@ struct DetectEpi {
   unsigned magicW;
   int nc;
   float stride_px;
+  // NMS prefilter ("hot anchors", class branch only; hot_count == nullptr: off): every anchor with ANY class score > hot_thr is
+  // appended to its image's list, so that non_max_suppression(conf_thres >= hot_thr) scans those anchors instead of re-reading
+  // the whole (B, nc, A) score block (upa_nms_batched_hot)
+  float hot_thr;
+  int* hot_count;               // [B]
+  unsigned long long* hot_keys; // [B][hot_cap], unordered: (~bits(best score) << 32) | (anchor * nc + best class) - the sort key of
+  int hot_cap;                  // utils/nms (score descending, then candidate index), best class = FIRST maximum (nms.py:109)
 };
 
 __device__ __forceinline__ float upa_row_sum4(float v) {  // sum over the 4 lane rows (lanes l, l^16, l^32, l^48)
@@ -64,8 +71,17 @@ __device__ __forceinline__ void upa_detect_box_store(const DetectEpi& d, const f
   if (ok) d.y[((size_t)b * (4 + d.nc) + kg) * d.a_total + d.a0 + a] = o * d.stride_px;
 }
 
-// Class branch: n-tile j of one 16-pixel tile; v = logits (bias added) of classes 16j + 4kg + q.
-__device__ __forceinline__ void upa_detect_cls_store(const DetectEpi& d, const f32x4& v, int j, int pix, bool ok, int kg) {
+__device__ __forceinline__ int upa_row_min4i(int v) {  // min over the 4 lane rows
+  auto a = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+  const int s = min((int)a[0], (int)a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap((unsigned)s, (unsigned)s, false, false);
+  return min((int)b[0], (int)b[1]);
+}
+
+// Class branch: n-tile j of one 16-pixel tile; v = logits (bias added) of classes 16j + 4kg + q.  (best, bc) = running first
+// maximum over this lane's classes (call with ascending j: within a lane the classes ascend with (j, q)).
+__device__ __forceinline__ void upa_detect_cls_store(const DetectEpi& d, const f32x4& v, int j, int pix, bool ok, int kg, float& best,
+                                                     int& bc) {
   constexpr float LOG2E = 1.44269504088896340736f;
   const int b = (int)__umulhi((unsigned)pix, d.magicHW);
   const int a = pix - b * d.HW;
@@ -74,7 +90,25 @@ __device__ __forceinline__ void upa_detect_cls_store(const DetectEpi& d, const f
   for (int q = 0; q < 4; ++q) {
     const int c = 16 * j + 4 * kg + q;
     const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[q] * -LOG2E));
-    if (ok && c < d.nc) yb[(size_t)c * d.a_total] = sg;
+    if (ok && c < d.nc) {
+      yb[(size_t)c * d.a_total] = sg;
+      if (sg > best) { best = sg; bc = c; }
+    }
+  }
+}
+
+// After the class rows of one 16-pixel tile: (best, bc) = this lane's first maximum (lane (kg, p16): classes 4kg + q of every
+// n-tile of pixel p16; best = -1 when the pixel is masked).  The pixel's first maximum over all classes = the row maximum of the
+// scores and, among the lane rows that hold it, the smallest class index; lane row 0 appends the NMS key of a hot anchor.
+__device__ __forceinline__ void upa_detect_hot_append(const DetectEpi& d, float best, int bc, int pix, int lane) {
+  const float m = upa_row_max4(best);
+  const int c = upa_row_min4i(best == m ? bc : 0x7FFFFFFF);
+  if (lane < 16 && m > d.hot_thr) {
+    const int b = (int)__umulhi((unsigned)pix, d.magicHW);
+    const int a = d.a0 + pix - b * d.HW;
+    const int slot = atomicAdd(&d.hot_count[b], 1);
+    if (slot >= 0 && slot < d.hot_cap)
+      d.hot_keys[(size_t)b * d.hot_cap + slot] = ((unsigned long long)(~__float_as_uint(m)) << 32) | (unsigned)(a * d.nc + c);
   }
 }
 

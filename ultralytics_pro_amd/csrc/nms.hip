@@ -85,6 +85,26 @@ __global__ __launch_bounds__(256) void nms_candidates_kernel(const float* pred, 
   }
 }
 
+// Candidates from the keys the Detect class tails listed (single-label rule: best class of an anchor, nms.py:109): filter by the
+// actual conf_thres / class mask and copy.  No read of pred at all.
+__global__ __launch_bounds__(256) void nms_candidates_hot_kernel(int nc, float conf, const uint8_t* cmask, const int* hot_count,
+                                                                 const u64* hot_keys, int hot_cap, int* count, u64* keys,
+                                                                 long cap) {
+  const int b = blockIdx.y;
+  int n = hot_count[b];
+  if (n > hot_cap) n = hot_cap;
+  u64* kb = keys + (size_t)b * cap;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const u64 k = hot_keys[(size_t)b * hot_cap + i];
+    const float best = __uint_as_float(~(unsigned)(k >> 32));
+    const int bc = (int)((unsigned)k % (unsigned)nc);
+    if (best > conf && (!cmask || cmask[bc])) {
+      const int slot = atomicAdd(&count[b], 1);
+      if (slot >= 0 && slot < cap) kb[slot] = k;
+    }
+  }
+}
+
 // bitonic sort of `buf[0..npad)` (npad power of two) ascending, all threads of the workgroup
 template <int NT>
 __device__ void bitonic_sort(u64* buf, int npad) {
@@ -285,10 +305,10 @@ extern "C" size_t upa_nms_workspace_bytes(int b, int nc, int a, int multi_label,
   return 256 + align_up((size_t)b * 2 * sizeof(int), 256) + (size_t)b * cap * 8 + (size_t)b * selcap * 8;
 }
 
-extern "C" int upa_nms_batched(const float* pred, int b, int nc, int a, float conf_thres, float iou_thres, int multi_label,
-                               int agnostic, const uint8_t* classes_mask, int max_det, int max_nms, float max_wh,
-                               float* out, int32_t* counts, int32_t* keep_idx, void* workspace, size_t workspace_bytes,
-                               void* stream) {
+static int nms_batched_impl(const float* pred, int b, int nc, int a, float conf_thres, float iou_thres, int multi_label,
+                            int agnostic, const uint8_t* classes_mask, int max_det, int max_nms, float max_wh,
+                            float* out, int32_t* counts, int32_t* keep_idx, void* workspace, size_t workspace_bytes,
+                            const int* hot_count, const u64* hot_keys, int hot_cap, void* stream) {
   UPA_CHECK_ARG(pred && out && counts && workspace, "nms: null pointer");
   UPA_CHECK_ARG(b > 0 && nc > 0 && a > 0, "nms: bad shape");
   UPA_CHECK_ARG(conf_thres >= 0.f && conf_thres <= 1.f, "Invalid Confidence threshold %f, valid values are between 0.0 and 1.0",
@@ -313,8 +333,12 @@ extern "C" int upa_nms_batched(const float* pred, int b, int nc, int a, float co
   u64* sel = keys + (size_t)b * cap;
   hipStream_t s = (hipStream_t)stream;
   upa_zero_words(count, 2 * b, s);  // not hipMemsetAsync: see upa_zero_words (common.h)
-  hipLaunchKernelGGL(nms_candidates_kernel, dim3((unsigned)cdiv(a, 256), (unsigned)b), dim3(256), 0, s, pred, b, nc, a,
-                     conf_thres, multi_label, classes_mask, count, keys, cap);
+  if (hot_count)  // the keys are unique and sorted afterwards: the order in which candidates are appended does not matter
+    hipLaunchKernelGGL(nms_candidates_hot_kernel, dim3(4, (unsigned)b), dim3(256), 0, s, nc, conf_thres, classes_mask, hot_count,
+                       hot_keys, hot_cap, count, keys, cap);
+  else
+    hipLaunchKernelGGL(nms_candidates_kernel, dim3((unsigned)cdiv(a, 256), (unsigned)b), dim3(256), 0, s, pred, b, nc, a,
+                       conf_thres, multi_label, classes_mask, count, keys, cap);
   UPA_LAUNCH_CHECK();
   {
     hipError_t e = upa_full_lds<nms_sort_kernel>();
@@ -327,4 +351,22 @@ extern "C" int upa_nms_batched(const float* pred, int b, int nc, int a, float co
                      iou_thres, agnostic, max_wh, max_det, out, counts, keep_idx);
   UPA_LAUNCH_CHECK();
   return UPA_OK;
+}
+
+extern "C" int upa_nms_batched(const float* pred, int b, int nc, int a, float conf_thres, float iou_thres, int multi_label,
+                               int agnostic, const uint8_t* classes_mask, int max_det, int max_nms, float max_wh,
+                               float* out, int32_t* counts, int32_t* keep_idx, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+  return nms_batched_impl(pred, b, nc, a, conf_thres, iou_thres, multi_label, agnostic, classes_mask, max_det, max_nms, max_wh,
+                          out, counts, keep_idx, workspace, workspace_bytes, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int upa_nms_batched_hot(const float* pred, int b, int nc, int a, float conf_thres, float iou_thres, int multi_label,
+                                   int agnostic, const uint8_t* classes_mask, int max_det, int max_nms, float max_wh,
+                                   float* out, int32_t* counts, int32_t* keep_idx, void* workspace, size_t workspace_bytes,
+                                   const int* hot_count, const u64* hot_keys, int hot_cap, void* stream) {
+  UPA_CHECK_ARG(hot_count && hot_keys && hot_cap >= a, "nms_hot: hot list missing or shorter than the anchor count");
+  UPA_CHECK_ARG(!(multi_label && nc > 1), "nms_hot: the listed keys follow the single-label rule (best class per anchor)");
+  return nms_batched_impl(pred, b, nc, a, conf_thres, iou_thres, multi_label, agnostic, classes_mask, max_det, max_nms, max_wh,
+                          out, counts, keep_idx, workspace, workspace_bytes, hot_count, (const u64*)hot_keys, hot_cap, stream);
 }
