@@ -43,7 +43,7 @@ def parse():
                     help="distinct resident input batches rotated through the steps (8 x 78.6 MB > the 256 MB Infinity Cache: "
                          "the input read of a step is a real HBM read)")
     ap.add_argument("--no-nms-prefilter", action="store_true",
-                    help="NMS scans every anchor's scores again instead of the anchors the Detect class tails listed (A/B switch)")
+                    help="NMS scans every anchor's scores again instead of the best-class keys the Detect class tails wrote (A/B switch)")
     ap.add_argument("--keep-raw", action="store_true",
                     help="also write Detect's raw per-level maps (the reference's second return value, unused by predict / NMS)")
     ap.add_argument("--batch", type=int, default=32)
@@ -181,8 +181,8 @@ def main():
         model.model[-1].concurrent = False
     if not args.keep_raw and hasattr(model.model[-1], "keep_raw"):
         model.model[-1].keep_raw = False  # predict / NMS read only the decoded output; the raw maps stay in registers
-        if hasattr(model.model[-1], "hot_thr") and not args.no_nms_prefilter:
-            model.model[-1].hot_thr = 0.25    # = the conf_thres of the NMS below: the class tails list the anchors above it
+        if hasattr(model.model[-1], "nms_keys") and not args.no_nms_prefilter:
+            model.model[-1].nms_keys = True   # the class tails also write every anchor's best-class NMS key for the NMS below
     # per-rank shard of the global stream: rank r owns batches r*K .. r*K+K-1 (K = --input-batches) of the procedural images
     nin = max(1, args.input_batches)
     xs = []
@@ -642,15 +642,14 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
         nbytes = npx * (c1_ + c2_) * 2 + wts * 2  # block input + block output + weights
         name = "void c2f16_fused_kernel<%d>(C2fParams)" % int(os.environ.get("UPA_C2F16_WAVES", "4")) if c_ == 16 else "void c2f32_fused_kernel<%d>(C2f32Params)" % nb_
         calls.append((name, flops, nbytes, (lambda a=a: orig_c2f(*a[:20], L.current_stream(dev)))))
-    for a in btail_calls:  # (x, n, h, w, c, ldx, w3, b3, wt, bt, kind, nc, stride, y, a_total, a0, hot_thr, hot_count, hot_list, hot_cap, dtype, stream)
-        a = a[:16] + (2.0, None, None, 0) + a[20:]  # the timing replays must not append to the NMS prefilter lists
+    for a in btail_calls:  # (x, n, h, w, c, ldx, w3, b3, wt, bt, kind, nc, stride, y, a_total, a0, best_keys, dtype, stream)
         npx, c_, kind, nc_ = a[1] * a[2] * a[3], a[4], a[10], a[11]
         cout = 64 if kind == 1 else nc_
         flops = 2.0 * npx * (9 * c_ * c_ + c_ * cout)
         nbytes = npx * c_ * 2 + npx * (4 if kind == 1 else nc_) * 4 + (9 * c_ * c_ + c_ * cout) * 2
         mt = 1 if (npx + 255) // 256 < torch.cuda.get_device_properties(dev).multi_processor_count else 2
         calls.append(("void conv_big_kernel<3, 1, 8, 1, %d, %d, %d>(BigParams)" % (mt, 4 if kind == 1 else 6, kind), flops, nbytes,
-                      (lambda a=a: orig_btail(*a[:21], L.current_stream(dev)))))
+                      (lambda a=a: orig_btail(*a[:18], L.current_stream(dev)))))
     torch.cuda.synchronize(dev)
     fam = {}
     with torch.no_grad():

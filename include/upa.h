@@ -147,14 +147,12 @@ int upa_c2f_fused(const void* x, int n, int h, int w, int c1, int ldx, int c, in
  * Returns UPA_EUNSUPPORTED outside that form (callers then run conv2d + upa_detect_tail). */
 size_t upa_tail_packed_weight_bytes(int cout, int cin);
 int upa_pack_tail_weight(const float* w, int cout, int cin, void* out);
-/* hot_count / hot_keys (class branch, may be NULL): NMS prefilter - for every anchor of this level whose best class score exceeds
- * hot_thr the NMS sort key (~bits(score) << 32 | anchor * nc + class; class = first maximum, nms.py:109) is appended (unordered)
- * to hot_keys[b * hot_cap + ...], hot_count[b] counts them; the caller zeroes hot_count before the first level;
- * hot_cap >= a_total.  Consumed by upa_nms_batched_hot. */
+/* best_keys (class branch, may be NULL): NMS prefilter - the NMS sort key of every anchor's best class,
+ * ~bits(score) << 32 | anchor * nc + class (class = first maximum, nms.py:109), as a dense (B, a_total) array.
+ * Consumed by upa_nms_batched_hot. */
 int upa_detect_branch_tail(const void* x, int n, int h, int w, int c, int ldx, const void* w3_packed, const float* b3,
                            const void* wt_packed, const float* bt, int kind, int nc, float stride_px, float* y, int a_total,
-                           int a0, float hot_thr, int* hot_count, unsigned long long* hot_keys, int hot_cap, int dtype,
-                           void* stream);
+                           int a0, unsigned long long* best_keys, int dtype, void* stream);
 
 
 /* ---- NMS ----------------------------------------------------------------------------------------------------------
@@ -164,14 +162,12 @@ int upa_detect_branch_tail(const void* x, int n, int h, int w, int c, int ldx, c
  * IoU without eps, survivor iff IoU <= thr, score-descending (ties: lower candidate index first).
  *                                                                  utils/nms.py:13-166, :239-296 */
 size_t upa_nms_workspace_bytes(int b, int nc, int a, int multi_label, int max_nms);
-/* upa_nms_batched (single-label form: multi_label = 0) with the candidate scan replaced by the keys a Detect class branch
- * listed while it wrote pred (upa_detect_branch_tail): identical results whenever every anchor whose best score exceeds
- * conf_thres is listed, i.e. for conf_thres >= the hot_thr the lists were built with (checked by the caller).  Saves the
- * re-read of the (B, nc, A) scores. */
+/* upa_nms_batched (single-label form: multi_label = 0) with the candidate scan over the (B, A) best-class keys a Detect class
+ * branch wrote next to pred (upa_detect_branch_tail) instead of the (B, nc, A) scores: identical results, 40x fewer bytes. */
 int upa_nms_batched_hot(const float* pred, int b, int nc, int a, float conf_thres, float iou_thres, int multi_label,
                         int agnostic, const uint8_t* classes_mask, int max_det, int max_nms, float max_wh, float* out,
-                        int32_t* counts, int32_t* keep_idx, void* workspace, size_t workspace_bytes, const int* hot_count,
-                        const unsigned long long* hot_keys, int hot_cap, void* stream);
+                        int32_t* counts, int32_t* keep_idx, void* workspace, size_t workspace_bytes,
+                        const unsigned long long* best_keys, void* stream);
 int upa_nms_batched(const float* pred, int b, int nc, int a, float conf_thres, float iou_thres, int multi_label,
                     int agnostic, const uint8_t* classes_mask, int max_det, int max_nms, float max_wh,
                     float* out, int32_t* counts, int32_t* keep_idx, void* workspace, size_t workspace_bytes,
@@ -341,7 +337,6 @@ int upa_detection_loss(const float* const* feats, float* const* grads, const int
  *     null stream and other graphs on created streams raised the fault rate from rare to most processes.  The Python
  *     wrapper (engine/runtime.HipGraph.replay) therefore REDIRECTS a launch requested on the null stream to the graph's own
  *     capture stream, ordered before and after by stream waits - callers of this C API should pass a created stream. */
-int upa_zero_words32(void* p, int n_words, void* stream); /* counters of captured code: a kernel, never a memset node */
 int upa_graph_begin(void* stream);
 int upa_graph_end(void* stream, void** graph_exec_out);
 int upa_graph_launch(void* graph_exec, void* stream);

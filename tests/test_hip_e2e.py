@@ -122,10 +122,10 @@ def test_e2e_bf16_matches_reference_golden(name, golden_dir):
 @pytest.mark.parametrize("name,conf,multi_label", [("yolov8n", 0.25, False), ("yolov8n", 0.4, False), ("yolov8n", 0.4, True),
                                                    ("yolov8s", 0.25, False)])
 def test_e2e_bf16_nms_prefilter_is_exact(name, conf, multi_label):
-    """NMS prefilter (`Detect.hot_thr`, `upa_nms_batched_hot`): the fused class tails list the NMS keys of the anchors whose best
-    score exceeds the threshold while they write the scores, and non_max_suppression (nms.py:13-166) with conf_thres >= that
-    threshold takes its candidates from the lists - the detections must be BIT-identical to the full scan of the same output,
-    eagerly and in a replayed hipGraph; a conf_thres below the threshold or multi_label must fall back to the full scan."""
+    """NMS prefilter (`Detect.nms_keys`, `upa_nms_batched_hot`): the fused class tails write the NMS key of every anchor's best
+    class next to the scores, and single-label non_max_suppression (nms.py:13-166) compacts those keys instead of re-reading
+    the scores - the detections must be BIT-identical to the full scan of the same output, eagerly and in a replayed
+    hipGraph, at any conf_thres; multi_label and outputs without keys (a clone) take the full scan."""
     from tests.hip_utils import DEV
     from ultralytics_pro_amd.utils.nms import nms_raw
     m = _build(name, torch.bfloat16)
@@ -133,25 +133,24 @@ def test_e2e_bf16_nms_prefilter_is_exact(name, conf, multi_label):
     det.keep_raw = False
     x = P.synthetic_images(3).to(DEV).to(torch.bfloat16).contiguous()
     with torch.no_grad():
-        det.hot_thr = None
+        det.nms_keys = False
         y0 = m(x)[0]
         assert not hasattr(y0, "_upa_hot")
         full = [t.clone() for t in nms_raw(y0, conf, 0.7, multi_label=multi_label, key="full")]
-        det.hot_thr = 0.25
+        det.nms_keys = True
         y1 = m(x)[0]
         assert torch.equal(y0, y1)
-        listed = getattr(y1, "_upa_hot", None)
-        if listed is None:
-            pytest.skip("this model's class branch is outside the fused tail form (no lists)")
+        if getattr(y1, "_upa_hot", None) is None:
+            pytest.skip("this model's class branch is outside the fused tail form (no keys)")
         hot = [t.clone() for t in nms_raw(y1, conf, 0.7, multi_label=multi_label, key="hot")]
         for a, b in zip(full, hot):
             assert torch.equal(a, b)
-        low = [t.clone() for t in nms_raw(y1, 0.1, 0.7, key="low")]           # below the list threshold: full scan
-        ref_low = [t.clone() for t in nms_raw(y1.clone(), 0.1, 0.7, key="low2")]  # a clone carries no lists
+        low = [t.clone() for t in nms_raw(y1, 0.05, 0.7, key="low")]
+        ref_low = [t.clone() for t in nms_raw(y1.clone(), 0.05, 0.7, key="low2")]  # a clone carries no keys: full scan
         for a, b in zip(low, ref_low):
             assert torch.equal(a, b)
         run = m.compile(x, post=lambda o: nms_raw(o[0], conf, 0.7, multi_label=multi_label, key="graph"))
-        for _ in range(3):  # the list counters are re-zeroed inside every replay
+        for _ in range(3):
             out = run()
             torch.cuda.synchronize()
             for a, b in zip(full, out):

@@ -50,9 +50,8 @@ PROTOTYPES = {
     "upa_c2f_fused": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "upa_tail_packed_weight_bytes": (_sz, [_i, _i]),
     "upa_pack_tail_weight": (_i, [_vp, _i, _i, _vp]),
-    "upa_detect_branch_tail": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _i, _i, _f, _vp, _vp, _i, _i, _vp]),
-    "upa_zero_words32": (_i, [_vp, _i, _vp]),
-    "upa_nms_batched_hot": (_i, [_vp, _i, _i, _i, _f, _f, _i, _i, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _i, _vp]),
+    "upa_detect_branch_tail": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _i, _i, _vp, _i, _vp]),
+    "upa_nms_batched_hot": (_i, [_vp, _i, _i, _i, _f, _f, _i, _i, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "upa_nms_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "upa_nms_batched": (_i, [_vp, _i, _i, _i, _f, _f, _i, _i, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     "upa_mhsa": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _i, _vp]),

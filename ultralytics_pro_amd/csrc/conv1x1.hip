@@ -155,7 +155,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_stream_kernel(const C1Para
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
           float best_ = -1.f;
-          int bc_ = 0;  // (the NMS prefilter lists are produced by the conv_big tail only)
+          int bc_ = 0;  // (the NMS key array is produced by the conv_big tail only)
           upa_detect_cls_store(p.de, acc[i][j] + biasv[j], j, pix < p.P ? pix : p.P - 1, pok, kg, best_, bc_);
           seq += 16 * j + 3 < p.de.nc ? 4 : 0;  // only stores that lane row 0 certainly issues are counted (the count may
                                                // only be too small: a wait for more than needed is always safe)

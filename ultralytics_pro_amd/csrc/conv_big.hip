@@ -234,7 +234,7 @@ __global__ __launch_bounds__(512, 4) void conv_big_kernel(const BigParams p) {
         int bc = 0;
 #pragma unroll
         for (int j = 0; j < NT; ++j) upa_detect_cls_store(p.de, acc2[i][j] + tbv[j], j, pix, pok, g, best, bc);
-        if (p.de.hot_count) upa_detect_hot_append(p.de, best, bc, pix, lane);  // uniform
+        if (p.de.best_keys) upa_detect_best_key_store(p.de, best, bc, pix, pok, lane);  // uniform
       }
     }
     return;
@@ -412,8 +412,7 @@ extern "C" int upa_pack_tail_weight(const float* w, int cout, int cin, void* out
 // wt = the 1x1 conv as upa_pack_tail_weight(cout = CP, cin = CP) of the zero-padded matrix, bt = its CP biases.
 extern "C" int upa_detect_branch_tail(const void* x, int n, int h, int w, int c, int ldx, const void* w3_packed, const float* b3,
                                       const void* wt_packed, const float* bt, int kind, int nc, float stride_px, float* y,
-                                      int a_total, int a0, float hot_thr, int* hot_count, unsigned long long* hot_keys, int hot_cap,
-                                      int dtype, void* stream) {
+                                      int a_total, int a0, unsigned long long* best_keys, int dtype, void* stream) {
   UPA_CHECK_ARG(x && w3_packed && b3 && wt_packed && bt && y, "detect_branch_tail: null pointer");
   UPA_CHECK_ARG(kind == 1 || kind == 2, "detect_branch_tail: kind must be 1 (box) or 2 (class)");
   UPA_CHECK_ARG(n > 0 && h > 0 && w > 0 && a0 >= 0 && a0 + h * w <= a_total, "detect_branch_tail: level does not fit a_total");
@@ -434,10 +433,7 @@ extern "C" int upa_detect_branch_tail(const void* x, int n, int h, int w, int c,
   p.de.y = y; p.de.a_total = a_total; p.de.a0 = a0; p.de.HW = h * w; p.de.W = w;
   p.de.magicHW = upa_magic_div(h * w); p.de.magicW = upa_magic_div(w);
   p.de.nc = nc; p.de.stride_px = stride_px;
-  p.de.hot_thr = 2.0f;  // no score exceeds it
-  if (kind == 2 && hot_count && hot_keys && hot_cap >= a_total && (long)a_total * nc < (1L << 31)) {
-    p.de.hot_thr = hot_thr; p.de.hot_count = hot_count; p.de.hot_keys = hot_keys; p.de.hot_cap = hot_cap;
-  }
+  if (kind == 2 && best_keys && (long)a_total * nc < (1L << 31)) p.de.best_keys = best_keys;
   const long px = (long)n * h * w;
   const int bm = (px + 255) / 256 < big_num_cu() ? 128 : 256;  // 128-pixel workgroups (one m-tile per wave) on the small levels
   if (!big_pick_tile(p, bm, ntb, 80 * 1024 - 512) && !big_pick_tile(p, bm, ntb, 160 * 1024)) return UPA_EUNSUPPORTED;

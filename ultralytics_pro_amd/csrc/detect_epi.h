@@ -21,13 +21,10 @@ struct DetectEpi {
   unsigned magicW;
   int nc;
   float stride_px;
-  // NMS prefilter ("hot anchors", class branch only; hot_count == nullptr: off): every anchor with ANY class score > hot_thr is
-  // appended to its image's list, so that non_max_suppression(conf_thres >= hot_thr) scans those anchors instead of re-reading
-  // the whole (B, nc, A) score block (upa_nms_batched_hot)
-  float hot_thr;
-  int* hot_count;               // [B]
-  unsigned long long* hot_keys; // [B][hot_cap], unordered: (~bits(best score) << 32) | (anchor * nc + best class) - the sort key of
-  int hot_cap;                  // utils/nms (score descending, then candidate index), best class = FIRST maximum (nms.py:109)
+  // NMS prefilter (class branch only; nullptr: off): the NMS sort key of every anchor's best class,
+  // (~bits(best score) << 32) | (anchor * nc + best class), best class = FIRST maximum (torch.max order, nms.py:109), as a dense
+  // (B, a_total) array - upa_nms_batched_hot takes its candidates from it instead of re-reading the (B, nc, A) score block
+  unsigned long long* best_keys;
 };
 
 __device__ __forceinline__ float upa_row_sum4(float v) {  // sum over the 4 lane rows (lanes l, l^16, l^32, l^48)
@@ -98,17 +95,15 @@ __device__ __forceinline__ void upa_detect_cls_store(const DetectEpi& d, const f
 }
 
 // After the class rows of one 16-pixel tile: (best, bc) = this lane's first maximum (lane (kg, p16): classes 4kg + q of every
-// n-tile of pixel p16; best = -1 when the pixel is masked).  The pixel's first maximum over all classes = the row maximum of the
-// scores and, among the lane rows that hold it, the smallest class index; lane row 0 appends the NMS key of a hot anchor.
-__device__ __forceinline__ void upa_detect_hot_append(const DetectEpi& d, float best, int bc, int pix, int lane) {
+// n-tile of pixel p16).  The pixel's first maximum over all classes = the row maximum of the scores and, among the lane rows
+// that hold it, the smallest class index; lane row 0 stores the anchor's NMS key (no atomics, no counters: a dense array).
+__device__ __forceinline__ void upa_detect_best_key_store(const DetectEpi& d, float best, int bc, int pix, bool ok, int lane) {
   const float m = upa_row_max4(best);
   const int c = upa_row_min4i(best == m ? bc : 0x7FFFFFFF);
-  if (lane < 16 && m > d.hot_thr) {
+  if (lane < 16 && ok) {
     const int b = (int)__umulhi((unsigned)pix, d.magicHW);
     const int a = d.a0 + pix - b * d.HW;
-    const int slot = atomicAdd(&d.hot_count[b], 1);
-    if (slot >= 0 && slot < d.hot_cap)
-      d.hot_keys[(size_t)b * d.hot_cap + slot] = ((unsigned long long)(~__float_as_uint(m)) << 32) | (unsigned)(a * d.nc + c);
+    d.best_keys[(size_t)b * d.a_total + a] = ((unsigned long long)(~__float_as_uint(m)) << 32) | (unsigned)(a * d.nc + c);
   }
 }
 

@@ -85,26 +85,6 @@ __global__ __launch_bounds__(256) void nms_candidates_kernel(const float* pred, 
   }
 }
 
-// Candidates from the keys the Detect class tails listed (single-label rule: best class of an anchor, nms.py:109): filter by the
-// actual conf_thres / class mask and copy.  No read of pred at all.
-__global__ __launch_bounds__(256) void nms_candidates_hot_kernel(int nc, float conf, const uint8_t* cmask, const int* hot_count,
-                                                                 const u64* hot_keys, int hot_cap, int* count, u64* keys,
-                                                                 long cap) {
-  const int b = blockIdx.y;
-  int n = hot_count[b];
-  if (n > hot_cap) n = hot_cap;
-  u64* kb = keys + (size_t)b * cap;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    const u64 k = hot_keys[(size_t)b * hot_cap + i];
-    const float best = __uint_as_float(~(unsigned)(k >> 32));
-    const int bc = (int)((unsigned)k % (unsigned)nc);
-    if (best > conf && (!cmask || cmask[bc])) {
-      const int slot = atomicAdd(&count[b], 1);
-      if (slot >= 0 && slot < cap) kb[slot] = k;
-    }
-  }
-}
-
 // bitonic sort of `buf[0..npad)` (npad power of two) ascending, all threads of the workgroup
 template <int NT>
 __device__ void bitonic_sort(u64* buf, int npad) {
@@ -125,8 +105,13 @@ __device__ void bitonic_sort(u64* buf, int npad) {
 constexpr int SORT_NT = 1024;
 constexpr int LDS_SORT_CAP = 16384;  // u64 -> 128 KiB of dynamic LDS (covers every single-label case, A <= 16384)
 
+// best_keys != nullptr (NMS prefilter): the candidates come from the dense (B, A) best-class keys the Detect class tails wrote
+// (single-label rule: best class of an anchor, nms.py:109) - this workgroup, which owns the image, first filters them by
+// conf_thres / class mask and compacts them into `keys` (slot counter in LDS, wave-aggregated: no global atomics - with a few
+// hundred candidates per image the atomics on count[b] were what the scan kernels spent their time on), then sorts as usual.
 __global__ __launch_bounds__(SORT_NT) void nms_sort_kernel(const int* count, int* nsorted, u64* keys, u64* sel, long cap,
-                                                           int selcap, int max_nms) {
+                                                           int selcap, int max_nms, const u64* best_keys, int nc, int A,
+                                                           float conf, const uint8_t* cmask) {
   extern __shared__ __attribute__((aligned(16))) u64 lbuf[];  // LDS_SORT_CAP keys
   __shared__ int hist[256];
   __shared__ u64 s_prefix;
@@ -134,7 +119,38 @@ __global__ __launch_bounds__(SORT_NT) void nms_sort_kernel(const int* count, int
   const int b = blockIdx.x;
   u64* kb = keys + (size_t)b * cap;
   u64* sb = sel + (size_t)b * selcap;
-  int n = count[b];
+  int n;
+  if (best_keys) {
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    for (int a0 = 0; a0 < A; a0 += SORT_NT) {
+      const int a = a0 + threadIdx.x;
+      u64 k = 0;
+      bool cand = false;
+      if (a < A) {
+        k = best_keys[(size_t)b * A + a];
+        const float best = __uint_as_float(~(unsigned)(k >> 32));
+        const int bc = (int)((unsigned)k - (unsigned)a * (unsigned)nc);
+        cand = best > conf && (!cmask || cmask[bc]);
+      }
+      const u64 m = __ballot(cand);
+      if (m) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&s_n, __popcll(m));
+        base = __shfl(base, 0);
+        if (cand) {
+          const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+          if (slot >= 0 && slot < cap) kb[slot] = k;
+        }
+      }
+    }
+    __syncthreads();  // the compacted keys (global) and the counter are visible to the whole workgroup
+    n = s_n;
+    __syncthreads();  // before s_n is reused below
+  } else {
+    n = count[b];
+  }
   if (n > cap) n = (int)cap;
   if (n > max_nms) {
     // exact threshold key K*: exactly max_nms keys are <= K* (keys are unique)
@@ -308,7 +324,7 @@ extern "C" size_t upa_nms_workspace_bytes(int b, int nc, int a, int multi_label,
 static int nms_batched_impl(const float* pred, int b, int nc, int a, float conf_thres, float iou_thres, int multi_label,
                             int agnostic, const uint8_t* classes_mask, int max_det, int max_nms, float max_wh,
                             float* out, int32_t* counts, int32_t* keep_idx, void* workspace, size_t workspace_bytes,
-                            const int* hot_count, const u64* hot_keys, int hot_cap, void* stream) {
+                            const u64* best_keys, void* stream) {
   UPA_CHECK_ARG(pred && out && counts && workspace, "nms: null pointer");
   UPA_CHECK_ARG(b > 0 && nc > 0 && a > 0, "nms: bad shape");
   UPA_CHECK_ARG(conf_thres >= 0.f && conf_thres <= 1.f, "Invalid Confidence threshold %f, valid values are between 0.0 and 1.0",
@@ -332,11 +348,10 @@ static int nms_batched_impl(const float* pred, int b, int nc, int a, float conf_
   u64* keys = (u64*)ws;
   u64* sel = keys + (size_t)b * cap;
   hipStream_t s = (hipStream_t)stream;
-  upa_zero_words(count, 2 * b, s);  // not hipMemsetAsync: see upa_zero_words (common.h)
-  if (hot_count)  // the keys are unique and sorted afterwards: the order in which candidates are appended does not matter
-    hipLaunchKernelGGL(nms_candidates_hot_kernel, dim3(4, (unsigned)b), dim3(256), 0, s, nc, conf_thres, classes_mask, hot_count,
-                       hot_keys, hot_cap, count, keys, cap);
-  else
+  // counters zeroed by a kernel, not hipMemsetAsync (see upa_zero_words, common.h); with best-class keys nothing counts in
+  // global memory: the sort kernel compacts its own candidates and always writes nsorted[b]
+  if (!best_keys) upa_zero_words(count, 2 * b, s);
+  if (!best_keys)  // (with best-class keys the sort kernel compacts its own candidates)
     hipLaunchKernelGGL(nms_candidates_kernel, dim3((unsigned)cdiv(a, 256), (unsigned)b), dim3(256), 0, s, pred, b, nc, a,
                        conf_thres, multi_label, classes_mask, count, keys, cap);
   UPA_LAUNCH_CHECK();
@@ -345,7 +360,7 @@ static int nms_batched_impl(const float* pred, int b, int nc, int a, float conf_
     if (e != hipSuccess) { upa_set_error("nms: cannot raise LDS limit: %s", hipGetErrorString(e)); return UPA_ELAUNCH; }
   }
   hipLaunchKernelGGL(nms_sort_kernel, dim3((unsigned)b), dim3(SORT_NT), LDS_SORT_CAP * 8, s, count, nsorted, keys, sel,
-                     cap, selcap, max_nms);
+                     cap, selcap, max_nms, best_keys, nc, a, conf_thres, classes_mask);
   UPA_LAUNCH_CHECK();
   hipLaunchKernelGGL(nms_greedy_kernel, dim3((unsigned)b), dim3(GREEDY_NT), 0, s, pred, nc, a, nsorted, sel, selcap,
                      iou_thres, agnostic, max_wh, max_det, out, counts, keep_idx);
@@ -358,15 +373,15 @@ extern "C" int upa_nms_batched(const float* pred, int b, int nc, int a, float co
                                float* out, int32_t* counts, int32_t* keep_idx, void* workspace, size_t workspace_bytes,
                                void* stream) {
   return nms_batched_impl(pred, b, nc, a, conf_thres, iou_thres, multi_label, agnostic, classes_mask, max_det, max_nms, max_wh,
-                          out, counts, keep_idx, workspace, workspace_bytes, nullptr, nullptr, 0, stream);
+                          out, counts, keep_idx, workspace, workspace_bytes, nullptr, stream);
 }
 
 extern "C" int upa_nms_batched_hot(const float* pred, int b, int nc, int a, float conf_thres, float iou_thres, int multi_label,
                                    int agnostic, const uint8_t* classes_mask, int max_det, int max_nms, float max_wh,
                                    float* out, int32_t* counts, int32_t* keep_idx, void* workspace, size_t workspace_bytes,
-                                   const int* hot_count, const u64* hot_keys, int hot_cap, void* stream) {
-  UPA_CHECK_ARG(hot_count && hot_keys && hot_cap >= a, "nms_hot: hot list missing or shorter than the anchor count");
-  UPA_CHECK_ARG(!(multi_label && nc > 1), "nms_hot: the listed keys follow the single-label rule (best class per anchor)");
+                                   const unsigned long long* best_keys, void* stream) {
+  UPA_CHECK_ARG(best_keys, "nms_hot: best-class keys missing");
+  UPA_CHECK_ARG(!(multi_label && nc > 1), "nms_hot: the keys follow the single-label rule (best class per anchor)");
   return nms_batched_impl(pred, b, nc, a, conf_thres, iou_thres, multi_label, agnostic, classes_mask, max_det, max_nms, max_wh,
-                          out, counts, keep_idx, workspace, workspace_bytes, hot_count, (const u64*)hot_keys, hot_cap, stream);
+                          out, counts, keep_idx, workspace, workspace_bytes, (const u64*)best_keys, stream);
 }

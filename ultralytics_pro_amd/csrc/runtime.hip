@@ -22,14 +22,6 @@ __global__ void upa_zero_words_kernel(unsigned* p, int n) {
 }
 extern "C" int upa_version(void) { return 1; }
 
-// Zero n 32-bit words by a KERNEL (not hipMemsetAsync: memset nodes misbehaved with several graphs in flight, see upa.h).
-extern "C" int upa_zero_words32(void* p, int n, void* stream) {
-  UPA_CHECK_ARG(p && n > 0, "zero_words32: bad args");
-  upa_zero_words(p, n, (hipStream_t)stream);
-  UPA_LAUNCH_CHECK();
-  return UPA_OK;
-}
-
 extern "C" int upa_graph_begin(void* stream) {
   hipError_t e = hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal);
   if (e != hipSuccess) { upa_set_error("graph_begin: %s", hipGetErrorString(e)); return UPA_ELAUNCH; }

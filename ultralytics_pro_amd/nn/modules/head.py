@@ -74,20 +74,17 @@ class Detect(nn.Module, _HipConvMixin):
         y = R.alloc_plain((n, 4 + self.nc, tot), torch.float32, device, key=(id(self), "y"))
         plan = dict(y=y, a0=a0, a_total=tot, fused=fused, hw=[(int(h), int(w)) for h, w in level_hw], n=int(n), decoded=set(),
                     hot=None, hot_levels=set())
-        if fused and self.hot_thr is not None and not self.keep_raw and self.fuse_branch:
-            # NMS prefilter: the class tails list every anchor with a score above hot_thr (upa_detect_branch_tail)
-            cnt = R.alloc_plain((n,), torch.int32, device, key=(id(self), "hot_count"))
-            lst = R.alloc_plain((n, tot), torch.int64, device, key=(id(self), "hot_keys"))  # NMS sort keys (u64 bit patterns)
-            L.check(L.lib().upa_zero_words32(cnt.data_ptr(), n, L.current_stream(device)), "zero_words32")
-            plan["hot"] = (cnt, lst, float(self.hot_thr))
+        if fused and self.nms_keys and not self.keep_raw and self.fuse_branch:
+            # NMS prefilter: the class tails also write every anchor's best-class NMS key (upa_detect_branch_tail)
+            plan["hot"] = R.alloc_plain((n, tot), torch.int64, device, key=(id(self), "best_keys"))  # u64 bit patterns
         self._plan()[R.current_tag()] = plan
 
     # `upa_detect_branch_tail`: with no raw output wanted, the branch's SECOND 3x3 conv joins that launch too (its SiLU'd
     # accumulators are the MFMA operand of the 1x1 conv), so a branch is two launches: conv3x3, [conv3x3 + 1x1 + decode].
     fuse_branch = True
-    # NMS prefilter threshold (None = off): when set (to the conf_thres the caller will pass to non_max_suppression, or lower),
-    # the fused class tails list the anchors with any score above it and `utils.nms` scans only those (upa_nms_batched_hot)
-    hot_thr = None
+    # NMS prefilter (off by default): the fused class tails also write the NMS sort key of every anchor's best class, a dense
+    # (B, A) array that `utils.nms` compacts instead of re-reading the (B, nc, A) scores (upa_nms_batched_hot; single-label NMS)
+    nms_keys = False
 
     def _tail(self, seq: nn.Sequential, x: torch.Tensor, raw: torch.Tensor | None, kind: int, i: int, plan) -> None:
         """conv3x3 -> conv3x3 -> [1x1 + decode] of one branch (kind 1 = box, 2 = class) of level i."""
@@ -126,13 +123,11 @@ class Detect(nn.Module, _HipConvMixin):
         rc = L.lib().upa_detect_branch_tail(vt.ptr, vt.n, vt.h, vt.w, vt.c, vt.ld, pk3.w.data_ptr(), pk3.bias.data_ptr(),
                                             wt.data_ptr(), bt.data_ptr(), kind, self.nc, float(self.stride[i]),
                                             plan["y"].data_ptr(), plan["a_total"], plan["a0"][i],
-                                            hot[2] if hot else 2.0, hot[0].data_ptr() if hot else None,
-                                            hot[1].data_ptr() if hot else None, plan["a_total"] if hot else 0, vt.dtype,
-                                            L.current_stream(t.device))
+                                            hot.data_ptr() if hot is not None else None, vt.dtype, L.current_stream(t.device))
         if rc == L.UPA_EUNSUPPORTED:
             return False
         L.check(rc, "detect_branch_tail")
-        if hot:
+        if hot is not None:
             plan["hot_levels"].add(i)
         return True
 
@@ -273,7 +268,7 @@ class Detect(nn.Module, _HipConvMixin):
                                               float(self.stride[i]), y.data_ptr(), a_total, a0, vb.dtype,
                                               L.current_stream(t.device)), "detect_decode")
             a0 += vb.h * vb.w
-        # NMS prefilter: valid only when every level's class branch went through the listing kernel in THIS forward
+        # NMS prefilter: valid only when every level's class branch wrote its keys in THIS forward
         hot = plan.get("hot") if plan is not None else None
         if hot is not None and plan["hot_levels"] == set(range(self.nl)) and y is plan["y"]:
             y._upa_hot = hot

@@ -38,16 +38,15 @@ def nms_raw(prediction: torch.Tensor, conf_thres=0.25, iou_thres=0.45, classes=N
         m = torch.zeros(nc, dtype=torch.uint8)
         m[torch.as_tensor(list(classes), dtype=torch.long)] = 1
         cmask = m.to(dev)
-    # Detect's fused class tails may have listed the NMS keys of the anchors whose best score exceeds a threshold
-    # (head.Detect.hot_thr): with conf_thres at or above it those ARE the candidates - no second read of the scores
+    # Detect's fused class tails may have written the NMS key of every anchor's best class next to the scores
+    # (head.Detect.nms_keys): single-label NMS compacts those (B, A) keys instead of re-reading the (B, nc, A) scores
     hot = getattr(prediction, "_upa_hot", None)
-    if hot is not None and float(conf_thres) >= hot[2] and hot[1].shape == (b, a) and hot[0].device == dev \
-            and not (multi_label and nc > 1):  # the listed keys are the single-label candidates (best class per anchor)
+    if hot is not None and tuple(hot.shape) == (b, a) and hot.device == dev and not (multi_label and nc > 1):
         L.check(lib.upa_nms_batched_hot(prediction.data_ptr(), b, nc, a, float(conf_thres), float(iou_thres),
                                         int(bool(multi_label)), int(bool(agnostic)), None if cmask is None else cmask.data_ptr(),
                                         int(max_det), int(max_nms), float(max_wh), out.data_ptr(), counts.data_ptr(),
-                                        keep.data_ptr(), ws.data_ptr(), ws_bytes, hot[0].data_ptr(), hot[1].data_ptr(), a,
-                                        L.current_stream(dev)), "nms_batched_hot")
+                                        keep.data_ptr(), ws.data_ptr(), ws_bytes, hot.data_ptr(), L.current_stream(dev)),
+                "nms_batched_hot")
         return out, counts, keep
     L.check(lib.upa_nms_batched(prediction.data_ptr(), b, nc, a, float(conf_thres), float(iou_thres), int(bool(multi_label)),
                                 int(bool(agnostic)), None if cmask is None else cmask.data_ptr(), int(max_det),
