@@ -56,16 +56,25 @@ __global__ __launch_bounds__(256) void nms_candidates_kernel(const float* pred, 
         if (v > best) { best = v; bc = c; }
       }
     }
+    // slots: waves reserve inside the workgroup (LDS), the workgroup reserves once in count[b] - one global atomic per 256
+    // anchors instead of one per wave with a candidate (same-address atomics serialise in L2: they, not the 86 MB of scores,
+    // were a third of this kernel's time)
+    __shared__ int blk_n, blk_base;
+    if (threadIdx.x == 0) blk_n = 0;
+    __syncthreads();
     const bool cand = valid && best > conf && (!cmask || cmask[bc]);
     const u64 m = __ballot(cand);
+    int local = 0;
     if (m) {
-      int base = 0;
-      if (lane == 0) base = atomicAdd(&count[b], __popcll(m));
-      base = __shfl(base, 0);
-      if (cand) {
-        const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
-        if (slot >= 0 && slot < cap) kb[slot] = ((u64)(~__float_as_uint(best)) << 32) | (unsigned)(a * nc + bc);
-      }
+      if (lane == 0) local = atomicAdd(&blk_n, __popcll(m));
+      local = __shfl(local, 0) + __popcll(m & ((1ull << lane) - 1ull));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && blk_n) blk_base = atomicAdd(&count[b], blk_n);
+    __syncthreads();
+    if (cand) {
+      const int slot = blk_base + local;
+      if (slot >= 0 && slot < cap) kb[slot] = ((u64)(~__float_as_uint(best)) << 32) | (unsigned)(a * nc + bc);
     }
   } else {
     for (int c = 0; c < nc; ++c) {
