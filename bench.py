@@ -640,7 +640,8 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
         wts = c1_ * 2 * c_ + nb_ * 18 * c_ * c_ + (2 + nb_) * c_ * c2_
         flops = 2.0 * npx * wts
         nbytes = npx * (c1_ + c2_) * 2 + wts * 2  # block input + block output + weights
-        name = "void c2f16_fused_kernel<%d>(C2fParams)" % int(os.environ.get("UPA_C2F16_WAVES", "4")) if c_ == 16 else "void c2f32_fused_kernel<%d>(C2f32Params)" % nb_
+        th = 10 if (c_ != 16 and nb_ == 2 and os.environ.get("UPA_C2F32_TH") == "10") else 16
+        name = "void c2f16_fused_kernel<%d>(C2fParams)" % int(os.environ.get("UPA_C2F16_WAVES", "4")) if c_ == 16 else "void c2f32_fused_kernel<%d, %d>(C2f32Params)" % (nb_, th)
         calls.append((name, flops, nbytes, (lambda a=a: orig_c2f(*a[:20], L.current_stream(dev)))))
     for a in btail_calls:  # (x, n, h, w, c, ldx, w3, b3, wt, bt, kind, nc, stride, y, a_total, a0, best_keys, dtype, stream)
         npx, c_, kind, nc_ = a[1] * a[2] * a[3], a[4], a[10], a[11]

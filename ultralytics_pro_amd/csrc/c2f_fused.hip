@@ -242,13 +242,14 @@ __device__ __forceinline__ void load_w9(u32x4 (&w)[9], const char* src, int j, i
   for (int tap = 0; tap < 9; ++tap) w[tap] = *reinterpret_cast<const u32x4*>(src + ((size_t)(tap * 2 + j) * 64 + lane) * 16);
 }
 
-// One 3x3 conv stage between two 64 B / px LDS tiles: dst (side SD, ring RD around the output tile) from src (side SD + 2).
+// One 3x3 conv stage between two 64 B / px LDS tiles: dst (SDH x SD pixels, ring RD around the output tile) from src (two more
+// rows and columns).
 // A wave owns n-tile j (= wave & 1) of every 8th m-tile.  res: tile of side SR whose pixel (yy + OFF, xx + OFF) is added
 // after the activation (the Bottleneck shortcut), or nullptr.
-template <int SD, int RD, int SR, int OFF>
+template <int SDH, int SD, int RD, int SR, int OFF>
 __device__ __forceinline__ void conv3x3_stage(const char* src, char* dst, const u32x4 (&w)[9], const f32x4 bias, const char* res,
                                               int oy0, int ox0, int H, int W, int wave, int g, int r) {
-  constexpr int SS = SD + 2, NPX = SD * SD, NMT = (NPX + 15) / 16;
+  constexpr int SS = SD + 2, NPX = SDH * SD, NMT = (NPX + 15) / 16;  // dst: SDH rows x SD columns
   const int j = wave & 1;
   for (int mt = wave >> 1; mt < NMT; mt += NW / 2) {
     const int q = mt * 16 + r;
@@ -276,30 +277,33 @@ __device__ __forceinline__ void conv3x3_stage(const char* src, char* dst, const 
 }
 }  // namespace c2f32
 
-template <int NB>
+// TH = output tile rows (16 columns always).  16 x 16 is the default; 10 rows balance the one-per-CU workgroups of yolov8n
+// model.4 (1280 tiles = 5.0 rounds instead of 800 = 3.125) but measured no faster - kept as an experiment switch (host side).
+template <int NB, int TH>
 __global__ __launch_bounds__(1024) void c2f32_fused_kernel(const C2f32Params p) {
   using namespace c2f32;
   constexpr int R = 2 * NB;
-  constexpr int SX = T + 2 * R;                          // x / y1 tile side: 24 | 20
-  constexpr int XPX = SX * SX;                           // 576 | 400
+  constexpr int SX = T + 2 * R, SXH = TH + 2 * R;        // x / y1 tile: SXH rows x SX columns (24 | 20 wide)
+  constexpr int XPX = SXH * SX;
   constexpr int XITEMS = XPX * 8;                        // 16-byte items of the x tile (a multiple of 64: whole waves)
   constexpr int XIT = (XITEMS + 1023) / 1024;
-  constexpr int XREG = XPX * 128;                        // x region (reused): 73728 | 51200
-  constexpr int Y1B = XPX * 64;                          // 36864 | 25600
-  constexpr int S_T1 = SX - 2, S_B1 = SX - 4;            // 22, 20 | 18, 16
-  constexpr int T1B = ((S_T1 * S_T1 + 15) / 16) * 16 * 64;
-  constexpr int S_T2 = S_B1 - 2;                         // 18 (NB = 2)
-  constexpr int T2B = ((S_T2 * S_T2 + 15) / 16) * 16 * 64;
-  static_assert(XITEMS % 64 == 0, "the DMA guard must be wave-uniform");
+  constexpr int XREG = XPX * 128;                        // x region (reused)
+  constexpr int Y1B = XPX * 64;
+  constexpr int S_T1 = SX - 2, S_B1 = SX - 4;            // widths 22, 20 | 18, 16
+  constexpr int H_T1 = SXH - 2, H_B1 = SXH - 4;
+  constexpr int T1B = ((H_T1 * S_T1 + 15) / 16) * 16 * 64;
+  constexpr int S_T2 = S_B1 - 2, H_T2 = H_B1 - 2;        // 18 wide (NB = 2)
+  constexpr int T2B = ((H_T2 * S_T2 + 15) / 16) * 16 * 64;
+  static_assert(XITEMS % 64 == 0 && XPX % 16 == 0, "the DMA guard must be wave-uniform, y1 in whole m-tiles");
   extern __shared__ __attribute__((aligned(16))) char sm[];
   char* xs = sm;                                  // x; then t1 at 0, (NB = 2) t2 after it, the last b after that
   char* y1s = sm + XREG;
-  char* y0s = y1s + Y1B;                          // 16 x 16 px
-  char* b1s = y0s + T * T * 64;                   // NB = 2 only: b1 on ring 2 (side 20); NB = 1 keeps b1 in the x region
+  char* y0s = y1s + Y1B;                          // TH x 16 px
+  char* b1s = y0s + TH * T * 64;                  // NB = 2 only: b1 on ring 2; NB = 1 keeps b1 in the x region
   char* t1s = xs;
   char* t2s = xs + T1B;
-  char* bls = NB == 2 ? xs + T1B + T2B : xs + T1B;  // last Bottleneck's output (side 16)
-  static_assert(T1B + (NB == 2 ? T2B : 0) + T * T * 64 <= XREG, "t / b tiles must fit the dead x region");
+  char* bls = NB == 2 ? xs + T1B + T2B : xs + T1B;  // last Bottleneck's output (TH x 16)
+  static_assert(T1B + (NB == 2 ? T2B : 0) + TH * T * 64 <= XREG, "t / b tiles must fit the dead x region");
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -310,7 +314,7 @@ __global__ __launch_bounds__(1024) void c2f32_fused_kernel(const C2f32Params p) 
   const int n = bid / tilesPerImg;
   bid -= n * tilesPerImg;
   const int tyi = bid / p.tilesX, txi = bid - tyi * p.tilesX;
-  const int oy0 = tyi * T, ox0 = txi * T;
+  const int oy0 = tyi * TH, ox0 = txi * T;
 
   // ---- x halo tile: 128 B / px, 16-byte group cg of pixel px at slot cg ^ (px & 7)
 #pragma unroll
@@ -356,7 +360,7 @@ __global__ __launch_bounds__(1024) void c2f32_fused_kernel(const C2f32Params p) 
     for (int e = 0; e < 4; ++e) v[e] = in ? silu(a[e]) : 0.f;
     *reinterpret_cast<u32x2*>(y1s + quad_addr(q, j, g)) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
   }
-  for (int i = wave >> 1; i < T; i += NW / 2) {
+  for (int i = wave >> 1; i < TH; i += NW / 2) {
     const int q = (i + R) * SX + R + r;
     f32x4 a = b1y0;
 #pragma unroll
@@ -368,7 +372,7 @@ __global__ __launch_bounds__(1024) void c2f32_fused_kernel(const C2f32Params p) 
   __syncthreads();  // y1 complete; x is dead
 
   // ---- B. t1 = SiLU(conv3x3(y1)) on ring R - 1 (into the x region)
-  conv3x3_stage<S_T1, R - 1, 1, 0>(y1s, t1s, wA, bA, nullptr, oy0, ox0, p.H, p.W, wave, g, r);
+  conv3x3_stage<H_T1, S_T1, R - 1, 1, 0>(y1s, t1s, wA, bA, nullptr, oy0, ox0, p.H, p.W, wave, g, r);
   __syncthreads();
   const char* sc1 = p.shortcut ? y1s : nullptr;
   constexpr int K2 = 2 + NB;
@@ -377,12 +381,12 @@ __global__ __launch_bounds__(1024) void c2f32_fused_kernel(const C2f32Params p) 
     load_w9(wA, p.wm[2], j, lane);
     bA = *reinterpret_cast<const f32x4*>(p.bm[2] + j * 16 + 4 * g);
     // ---- C. b1 = y1 + SiLU(conv3x3(t1)) on ring 2
-    conv3x3_stage<S_B1, R - 2, SX, 2>(t1s, b1s, wB, bB, sc1, oy0, ox0, p.H, p.W, wave, g, r);
+    conv3x3_stage<H_B1, S_B1, R - 2, SX, 2>(t1s, b1s, wB, bB, sc1, oy0, ox0, p.H, p.W, wave, g, r);
     __syncthreads();
     load_w9(wB, p.wm[3], j, lane);
     bB = *reinterpret_cast<const f32x4*>(p.bm[3] + j * 16 + 4 * g);
     // ---- D. t2 = SiLU(conv3x3(b1)) on ring 1
-    conv3x3_stage<S_T2, 1, 1, 0>(b1s, t2s, wA, bA, nullptr, oy0, ox0, p.H, p.W, wave, g, r);
+    conv3x3_stage<H_T2, S_T2, 1, 1, 0>(b1s, t2s, wA, bA, nullptr, oy0, ox0, p.H, p.W, wave, g, r);
     __syncthreads();
   }
 #pragma unroll
@@ -392,15 +396,15 @@ __global__ __launch_bounds__(1024) void c2f32_fused_kernel(const C2f32Params p) 
   const f32x4 b2v[2] = {*reinterpret_cast<const f32x4*>(p.b2 + (2 * j) * 16 + 4 * g), *reinterpret_cast<const f32x4*>(p.b2 + (2 * j + 1) * 16 + 4 * g)};
   if constexpr (NB == 2) {
     // ---- E. b2 = b1 + SiLU(conv3x3(t2)) on the tile
-    conv3x3_stage<T, 0, S_B1, 2>(t2s, bls, wB, bB, p.shortcut ? b1s : nullptr, oy0, ox0, p.H, p.W, wave, g, r);
+    conv3x3_stage<TH, T, 0, S_B1, 2>(t2s, bls, wB, bB, p.shortcut ? b1s : nullptr, oy0, ox0, p.H, p.W, wave, g, r);
   } else {
     // ---- C. b1 = y1 + SiLU(conv3x3(t1)) on the tile
-    conv3x3_stage<T, 0, SX, 2>(t1s, bls, wB, bB, sc1, oy0, ox0, p.H, p.W, wave, g, r);
+    conv3x3_stage<TH, T, 0, SX, 2>(t1s, bls, wB, bB, sc1, oy0, ox0, p.H, p.W, wave, g, r);
   }
   __syncthreads();
 
   // ---- F. cv2 over [y0 | y1 | b1 (| b2)] of the tile's own pixels: a wave owns output channels 32j .. 32j + 31 of two rows
-  for (int i = wave >> 1; i < T; i += NW / 2) {
+  for (int i = wave >> 1; i < TH; i += NW / 2) {
     const int d = i * T + r;
     const int qy1 = (i + R) * SX + R + r;
     u32x4 op[K2];
@@ -449,9 +453,10 @@ extern "C" int upa_c2f_fused(const void* x, int n, int h, int w, int c1, int ldx
     return UPA_EUNSUPPORTED;  // the caller runs the separate convolutions
   }
   for (int i = 0; i < 2 * nb; ++i) UPA_CHECK_ARG(wm[i] && bm[i], "c2f_fused: null Bottleneck weights");
-  const int tx = cdiv(w, 16), ty = cdiv(h, 16);
-  const long tiles = (long)tx * ty * n;
-  UPA_CHECK_ARG(tiles < (1L << 31), "c2f_fused: too many tiles");
+  const int tx = cdiv(w, 16);
+  int ty = cdiv(h, 16);
+  long tiles = (long)tx * ty * n;
+  UPA_CHECK_ARG(tiles < (1L << 31) / 2, "c2f_fused: too many tiles");
   hipStream_t s = (hipStream_t)stream;
   if (f16) {
     C2fParams p;
@@ -470,14 +475,31 @@ extern "C" int upa_c2f_fused(const void* x, int n, int h, int w, int c1, int ldx
   p.x = (const char*)x; p.y = (char*)y; p.w1 = (const char*)w1; p.w2 = (const char*)w2; p.b1 = b1; p.b2 = b2;
   for (int i = 0; i < 2 * nb; ++i) { p.wm[i] = (const char*)wm[i]; p.bm[i] = bm[i]; }
   p.N = n; p.H = h; p.W = w; p.ldx = ldx; p.ldy = ldy; p.tilesX = tx; p.tilesY = ty; p.shortcut = shortcut ? 1 : 0;
+  // LDS of <NB, TH>: x region + y1 + y0 (+ b1 on ring 2 for NB = 2)
+  auto lds_of = [](int nbk, int th) {
+    const int r = 2 * nbk, sxw = 16 + 2 * r, sxh = th + 2 * r;
+    size_t b = (size_t)sxh * sxw * (128 + 64) + (size_t)th * 16 * 64;
+    if (nbk == 2) b += (size_t)(((sxh - 4) * (sxw - 4) + 15) / 16) * 16 * 64;
+    return b;
+  };
   if (nb == 2) {
-    constexpr size_t lds = 73728 + 36864 + 16384 + 25600;
-    if (upa_full_lds<c2f32_fused_kernel<2>>() != hipSuccess) return UPA_ELAUNCH;
-    hipLaunchKernelGGL(c2f32_fused_kernel<2>, dim3((unsigned)tiles), dim3(1024), lds, s, p);
+    // 10-row tiles only on request (UPA_C2F32_TH=10): measured 80.1 against 83 us for model.4 alone and 0.636 against 0.626 ms
+    // per step with four steps in flight - a tile's time is set by its six barrier-separated stages and the DMA wait more than
+    // by its (m-tile, n-tile) unit count (222 against 354), so five balanced rounds do not beat 3.125 ragged ones
+    const char* fe = getenv("UPA_C2F32_TH");  // read per call: the parity tests run both tilings in one process
+    const bool th10 = fe && atoi(fe) == 10;
+    p.tilesY = th10 ? cdiv(h, 10) : cdiv(h, 16);
+    tiles = (long)tx * p.tilesY * n;
+    if (th10) {
+      if (upa_full_lds<c2f32_fused_kernel<2, 10>>() != hipSuccess) return UPA_ELAUNCH;
+      hipLaunchKernelGGL((c2f32_fused_kernel<2, 10>), dim3((unsigned)tiles), dim3(1024), lds_of(2, 10), s, p);
+    } else {
+      if (upa_full_lds<c2f32_fused_kernel<2, 16>>() != hipSuccess) return UPA_ELAUNCH;
+      hipLaunchKernelGGL((c2f32_fused_kernel<2, 16>), dim3((unsigned)tiles), dim3(1024), lds_of(2, 16), s, p);
+    }
   } else {
-    constexpr size_t lds = 51200 + 25600 + 16384;
-    if (upa_full_lds<c2f32_fused_kernel<1>>() != hipSuccess) return UPA_ELAUNCH;
-    hipLaunchKernelGGL(c2f32_fused_kernel<1>, dim3((unsigned)tiles), dim3(1024), lds, s, p);
+    if (upa_full_lds<c2f32_fused_kernel<1, 16>>() != hipSuccess) return UPA_ELAUNCH;
+    hipLaunchKernelGGL((c2f32_fused_kernel<1, 16>), dim3((unsigned)tiles), dim3(1024), lds_of(1, 16), s, p);
   }
   UPA_LAUNCH_CHECK();
   return UPA_OK;
