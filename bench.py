@@ -585,7 +585,8 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
     orig_pair = L.lib().upa_bottleneck_pair
     orig_c2f = L.lib().upa_c2f_fused
     orig_btail = L.lib().upa_detect_branch_tail
-    pair_calls, c2f_calls, btail_calls = [], [], []
+    orig_paircv2 = L.lib().upa_bottleneck_pair_cv2
+    pair_calls, c2f_calls, btail_calls, paircv2_calls = [], [], [], []
 
     class _LibProxy:
         """Forwards every C entry to the real library, recording the fused-block launches (Bottleneck / C2f / Detect call
@@ -598,6 +599,12 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
             rc = orig_pair(*a)
             if rc == 0:
                 pair_calls.append(a)
+            return rc
+
+        def upa_bottleneck_pair_cv2(self, *a):
+            rc = orig_paircv2(*a)
+            if rc == 0:
+                paircv2_calls.append(a)
             return rc
 
         def upa_c2f_fused(self, *a):
@@ -633,8 +640,14 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
         n_, h_, w_, c_ = a[1], a[2], a[3], a[4]
         flops = 2 * 2.0 * n_ * h_ * w_ * c_ * c_ * 9
         nbytes = 2 * (n_ * h_ * w_ * c_ * 2 * (2 + (0.5 if a[12] else 0)) + c_ * c_ * 9 * 2)  # two convs, each in + out (+ residual)
-        calls.append(("void conv_pair_kernel<%d, %s>(PairParams)" % (c_ // 32, "true" if a[12] else "false"), flops, nbytes,
+        calls.append(("void conv_pair_kernel<%d, %s, false>(PairParams)" % (c_ // 32, "true" if a[12] else "false"), flops, nbytes,
                       (lambda a=a: orig_pair(*a[:15], L.current_stream(dev)))))
+    for a in paircv2_calls:  # (x, y0, n, h, w, ldx, w1, b1, w2, b2, residual, wc_std, wc_b, bc, out, ldout, act, dtype, stream)
+        npx = a[2] * a[3] * a[4]
+        flops = 2.0 * npx * (2 * 9 * 32 * 32 + 96 * 64)
+        nbytes = npx * (64 + 64) * 2 + (18 * 32 * 32 + 96 * 64) * 2  # y0 | y1 in, 64 channels out, weights
+        calls.append(("void conv_pair_kernel<1, %s, true>(PairParams)" % ("true" if a[10] else "false"), flops, nbytes,
+                      (lambda a=a: orig_paircv2(*a[:18], L.current_stream(dev)))))
     for a in c2f_calls:  # (x, n, h, w, c1, ldx, c, nb, shortcut, w1, b1, wm, bm, w2, b2, y, c2, ldy, act, dtype, stream)
         npx, c1_, c_, nb_, c2_ = a[1] * a[2] * a[3], a[4], a[6], a[7], a[16]
         wts = c1_ * 2 * c_ + nb_ * 18 * c_ * c_ + (2 + nb_) * c_ * c2_

@@ -129,6 +129,16 @@ int upa_detect_tail(const void* x, int n, int h, int w, int cin, int ldx, const 
 int upa_conv1x1_upcat(const void* x, int n, int h, int w, int cin, int ldx, const void* up, int up_c, int up_ld,
                       const void* w_packed, const float* bias, void* y, int cout, int ldy, int act, int dtype, void* stream);
 
+/* C2f(.., 64, n = 1) with a 32-channel Bottleneck (yolov8n model.15): the Bottleneck (both 3x3 convs [+ shortcut]) AND the
+ * C2f's cv2 in one launch (bf16, SiLU); the Bottleneck's output only exists as MFMA operands.   block.py:457-488, 644-668.
+ * x = the y1 slice (channels [32, 64)) of the C2f concat buffer, y0 = its y0 slice (channels [0, 32)), same pixel stride ldx;
+ * w1 / w2 = the Bottleneck's convs (upa_pack_conv_weight); wc_std = cv2's input columns [0, 64) as
+ * upa_pack_conv_weight(64 -> 64, k = 1), wc_b = columns [64, 96) as upa_pack_tail_weight(64, 32), bc = cv2's bias (BN folded);
+ * out = (n, h, w, 64) view.  UPA_EUNSUPPORTED outside the form (callers run upa_bottleneck_pair + upa_conv2d_bias_act). */
+int upa_bottleneck_pair_cv2(const void* x, const void* y0, int n, int h, int w, int ldx, const void* w1_packed, const float* b1,
+                            const void* w2_packed, const float* b2, int residual, const void* wc_std, const void* wc_b,
+                            const float* bc, void* out, int ldout, int act, int dtype, void* stream);
+
 /* A whole C2f block in one launch (bf16, SiLU): cv1 -> nb x Bottleneck(3x3, 3x3, [+ input]) -> cv2 with the intermediates in
  * LDS / registers only.                            nn/modules/block.py:457-488 (C2f.forward), :644-668 (Bottleneck.forward).
  * c1 / c2: channels in / out, c: hidden width (c2 * e), nb: Bottlenecks; w1,b1 = cv1; wm[2i], wm[2i+1] (bm likewise) =

@@ -245,6 +245,42 @@ def test_conv1x1_virtual_upsample_concat(case):
     assert (y - ref).abs().max().item() <= 3e-2 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("case", [(192, True, (2, 37, 50)), (192, False, (2, 80, 80)), (64, False, (1, 14, 14)), (96, True, (3, 5, 9))],
+                         ids=["c192s_37x50", "c192_80x80", "c64_14x14", "c96s_5x9"])
+def test_c2f_pair_cv2_kernel(case):
+    """`upa_bottleneck_pair_cv2` (bf16): C2f(c1, 64, n=1) with its 32-channel Bottleneck and cv2 as ONE launch after cv1
+    (block.py:457-488, 644-668; yolov8n model.15 = C2f(192, 64, 1, shortcut=False)) vs the oracle C2f with the intermediates
+    rounded to bf16 where the kernels round them, and vs the product's own path with the fusion switched off (cv1, pair kernel,
+    cv2 as three launches).  Ragged tiles, maps smaller than a tile, with and without the shortcut, a strided output view."""
+    from tests.hip_utils import DEV, bf16_round, to_cpu_nchw, to_dev_nhwc
+    from ultralytics_pro_amd.engine import runtime as R
+    pm, _ = _mods()
+    c1, sc, (N, H, W) = case
+    o, m = _pair(om.C2f, pm.C2f, (c1, 64, 1, sc), f"c2f_paircv2{c1}")
+    x = bf16_round(P.uniform(f"c2fpc{case}", (N, c1, H, W), -1.5, 1.5))
+    with torch.no_grad():
+        ys = list(bf16_round(o.cv1(x)).chunk(2, 1))
+        t = bf16_round(o.m[0].cv1(ys[-1]))
+        ys.append(bf16_round((ys[-1] if sc else 0) + o.m[0].cv2(t)))
+        ref = o.cv2(torch.cat(ys, 1))
+        buf = R.alloc_nhwc(N, 128, H, W, torch.bfloat16, DEV)
+        buf.zero_()
+        xd = to_dev_nhwc(x, torch.bfloat16)
+        m.fuse_pair_cv2 = True
+        y = to_cpu_nchw(m(xd, out=buf[:, 64:]))
+        m.fuse_pair_cv2 = False
+        y2 = to_cpu_nchw(m(xd))
+        m.fuse_pair_cv2 = True
+        cat = R.alloc_nhwc(N, 96, H, W, torch.bfloat16, DEV)
+        m.cv1(xd, out=cat[:, :64])
+        assert m._pair_cv2(cat, None) is not None, "the fused form was not dispatched"
+    scale = max(1.0, ref.abs().max().item())
+    assert (y - ref).abs().max().item() <= 3e-2 * scale, (y - ref).abs().max().item()
+    d = (y - y2).abs()
+    assert d.max().item() <= 3e-2 * scale and (d > 1e-6).float().mean().item() <= 0.03, (d.max().item(), (d > 1e-6).float().mean().item())
+    assert float(to_cpu_nchw(buf[:, :64]).abs().max()) == 0.0  # nothing written outside the output slice
+
+
 C2F_CASES = [
     # c1, n, shortcut, (N, H, W)
     (32, 1, True, (2, 37, 50)), (32, 1, True, (1, 16, 16)), (32, 1, True, (3, 5, 9)), (32, 1, True, (2, 160, 160)),

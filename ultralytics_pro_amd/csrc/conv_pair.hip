@@ -35,8 +35,13 @@ __device__ __forceinline__ float pair_act(float v) {
 }  // namespace
 
 // CK = k-tiles (32 channels) of C: 1 (C = 32) or 2 (C = 64); NT = C / 16 n-tiles, all in every wave
-template <int CK, bool RES>
+// CV2 (CK = 1 only): the Bottleneck is the single one of a C2f(.., 64, n = 1) and the C2f's cv2 follows at once - its input
+// cat(y0, y1, b) is three 32-channel k-steps: y0 straight from global memory in B-fragment order, y1 = this kernel's own input
+// (the halo tile's centre, still in LDS), b = the bf16-packed accumulators (the D layout of two 16-channel tiles IS an MFMA B
+// operand in the k order of upa_pack_tail_weight, see conv_big.hip).  b is never written; one launch and 2 x 13 MB less.
+template <int CK, bool RES, bool CV2 = false>
 __global__ __launch_bounds__(512, 4) void conv_pair_kernel(const PairParams p) {
+  static_assert(!CV2 || CK == 1, "the cv2 tail is built for 32-channel Bottlenecks");
   constexpr int NT = CK * 2;
   constexpr int G16 = CK * 4;              // 16-byte groups per pixel
   constexpr int PB = G16 * 16;             // bytes per pixel in the LDS images
@@ -190,6 +195,63 @@ __global__ __launch_bounds__(512, 4) void conv_pair_kernel(const PairParams p) {
   f32x4 bv[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) bv[j] = *reinterpret_cast<const f32x4*>(p.b2 + j * 16 + g * 4);
+  if constexpr (CV2) {
+    f32x4 bcv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bcv[j] = *reinterpret_cast<const f32x4*>(p.bc + j * 16 + g * 4);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int oy = oy0 + ty[i], ox = ox0 + tx[i];
+      const bool pok = ty[i] < p.TH && oy < p.OH && ox < p.OW;
+      const size_t pixoff = ((size_t)n * p.OH + (pok ? oy : 0)) * p.OW + (pok ? ox : 0);
+      const int hp = ty[i] < p.TH ? (ty[i] + 2) * IW + tx[i] + 2 : 0;  // this output pixel in the input halo
+      // b = SiLU(conv2 + b2) (+ y1): two 16-channel tiles -> one B operand (k order of upa_pack_tail_weight)
+      float v0[4], v1[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v0[q] = pair_act<UPA_ACT_SILU>(acc[i][0][q] + bv[0][q]);
+        v1[q] = pair_act<UPA_ACT_SILU>(acc[i][1][q] + bv[1][q]);
+      }
+      if constexpr (RES) {
+        const char* xrow = hal + hp * PB;
+        const int xsw = swz(hp);
+        const u32x2 r0 = *reinterpret_cast<const u32x2*>(xrow + (((g >> 1) ^ xsw) << 4) + (g & 1) * 8);
+        const u32x2 r1 = *reinterpret_cast<const u32x2*>(xrow + (((2 + (g >> 1)) ^ xsw) << 4) + (g & 1) * 8);
+        v0[0] += __uint_as_float(r0[0] << 16); v0[1] += __uint_as_float(r0[0] & 0xFFFF0000u);
+        v0[2] += __uint_as_float(r0[1] << 16); v0[3] += __uint_as_float(r0[1] & 0xFFFF0000u);
+        v1[0] += __uint_as_float(r1[0] << 16); v1[1] += __uint_as_float(r1[0] & 0xFFFF0000u);
+        v1[2] += __uint_as_float(r1[1] << 16); v1[3] += __uint_as_float(r1[1] & 0xFFFF0000u);
+      }
+      const u32x4 opb = u32x4{pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])};
+      const u32x4 opy1 = *reinterpret_cast<const u32x4*>(hal + hp * PB + ((g ^ swz(hp)) << 4));
+      const u32x4 opy0 = *reinterpret_cast<const u32x4*>(p.y0 + (pixoff * (size_t)p.ldx) * 2 + g * 16);
+      f32x4 o[4] = {bcv[0], bcv[1], bcv[2], bcv[3]};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u32x4 a0 = *reinterpret_cast<const u32x4*>(p.wc_std + ((size_t)(0 * 4 + j) * 64 + lane) * 16);
+        const u32x4 a1 = *reinterpret_cast<const u32x4*>(p.wc_std + ((size_t)(1 * 4 + j) * 64 + lane) * 16);
+        const u32x4 a2 = *reinterpret_cast<const u32x4*>(p.wc_b + ((size_t)j * 64 + lane) * 16);
+        o[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a0), *reinterpret_cast<const bf16x8*>(&opy0), o[j], 0, 0, 0);
+        o[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a1), *reinterpret_cast<const bf16x8*>(&opy1), o[j], 0, 0, 0);
+        o[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a2), *reinterpret_cast<const bf16x8*>(&opb), o[j], 0, 0, 0);
+      }
+      char* yrow = p.out + pixoff * (size_t)p.ldout * 2;
+#pragma unroll
+      for (int j = 0; j < 4; j += 2) {
+        float w0[4], w1[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          w0[q] = pair_act<UPA_ACT_SILU>(o[j][q]);
+          w1[q] = pair_act<UPA_ACT_SILU>(o[j + 1][q]);
+        }
+        auto lo = __builtin_amdgcn_permlane16_swap(pack_bf16x2(w0[0], w0[1]), pack_bf16x2(w1[0], w1[1]), false, false);
+        auto hi = __builtin_amdgcn_permlane16_swap(pack_bf16x2(w0[2], w0[3]), pack_bf16x2(w1[2], w1[3]), false, false);
+        const int cb = 16 * (j + (g & 1)) + 8 * (g >> 1);
+        if (pok) *reinterpret_cast<u32x4*>(yrow + cb * 2) = u32x4{lo[0], hi[0], lo[1], hi[1]};
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int oy = oy0 + ty[i], ox = ox0 + tx[i];
@@ -234,6 +296,19 @@ int pair_env(const char* name, int dflt) {
 template <int CK>
 int pair_launch(const PairParams& p, size_t lds, bool res, hipStream_t s) {
   const dim3 grid((unsigned)((long)p.tilesX * p.tilesY * p.N));
+  if constexpr (CK == 1) {
+    if (p.out) {  // Bottleneck + the C2f's cv2
+      if (res) {
+        if (upa_full_lds<conv_pair_kernel<1, true, true>>() != hipSuccess) return UPA_ELAUNCH;
+        hipLaunchKernelGGL((conv_pair_kernel<1, true, true>), grid, dim3(512), lds, s, p);
+      } else {
+        if (upa_full_lds<conv_pair_kernel<1, false, true>>() != hipSuccess) return UPA_ELAUNCH;
+        hipLaunchKernelGGL((conv_pair_kernel<1, false, true>), grid, dim3(512), lds, s, p);
+      }
+      UPA_LAUNCH_CHECK();
+      return UPA_OK;
+    }
+  }
   if (res) {
     auto kern = conv_pair_kernel<CK, true>;
     if (upa_full_lds<conv_pair_kernel<CK, true>>() != hipSuccess) return UPA_ELAUNCH;
@@ -248,9 +323,9 @@ int pair_launch(const PairParams& p, size_t lds, bool res, hipStream_t s) {
 }
 }  // namespace
 
-extern "C" int upa_bottleneck_pair(const void* x, int n, int h, int w, int c, int ldx, const void* w1_packed, const float* b1,
-                                   const void* w2_packed, const float* b2, void* y, int ldy, int residual, int act, int dtype,
-                                   void* stream) {
+static int pair_impl(const void* x, int n, int h, int w, int c, int ldx, const void* w1_packed, const float* b1,
+                     const void* w2_packed, const float* b2, void* y, int ldy, int residual, int act, int dtype,
+                     const PairParams* cv2, void* stream) {
   UPA_CHECK_ARG(x && w1_packed && b1 && w2_packed && b2 && y && n > 0 && h > 0 && w > 0, "bottleneck_pair: bad args");
   // 1: never; 2: not for C = 64 (the default); 3: not for C = 32; 0: both.  Measured on MI355X (yolov8n bs 32, four steps in
   // flight): C = 32 pairs at 80x80 28.7 us against 16.4 + 19.1 us as two launches, step 0.800 -> 0.773 ms; C = 64 pairs at
@@ -266,6 +341,7 @@ extern "C" int upa_bottleneck_pair(const void* x, int n, int h, int w, int c, in
   memset(&p, 0, sizeof(p));
   p.x = (const char*)x; p.y = (char*)y; p.w1 = (const char*)w1_packed; p.w2 = (const char*)w2_packed; p.b1 = b1; p.b2 = b2;
   p.N = n; p.H = h; p.W = w; p.OH = h; p.OW = w; p.ldx = ldx; p.ldy = ldy;
+  if (cv2) { p.y0 = cv2->y0; p.wc_std = cv2->wc_std; p.wc_b = cv2->wc_b; p.bc = cv2->bc; p.out = cv2->out; p.ldout = cv2->ldout; }
   const int ck = c / 32;
   const int pb = ck * 64;
   // output tile TH x TW with (TH+2)(TW+2) <= 256 mid pixels: fewest tiles per image, then the squarest
@@ -293,4 +369,31 @@ extern "C" int upa_bottleneck_pair(const void* x, int n, int h, int w, int c, in
   if (lds > 160 * 1024) return UPA_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   return ck == 1 ? pair_launch<1>(p, lds, residual != 0, s) : pair_launch<2>(p, lds, residual != 0, s);
+}
+
+extern "C" int upa_bottleneck_pair(const void* x, int n, int h, int w, int c, int ldx, const void* w1_packed, const float* b1,
+                                   const void* w2_packed, const float* b2, void* y, int ldy, int residual, int act, int dtype,
+                                   void* stream) {
+  return pair_impl(x, n, h, w, c, ldx, w1_packed, b1, w2_packed, b2, y, ldy, residual, act, dtype, nullptr, stream);
+}
+
+// C2f(.., 64, n = 1) with a 32-channel Bottleneck: Bottleneck (both 3x3 convs [+ shortcut]) AND the C2f's cv2 in one launch.
+// x = the y1 slice (channels [32, 64)) of the C2f concat buffer, y0 = its y0 slice (channels [0, 32)), same pixel stride ldx;
+// wc_std = cv2's columns [0, 64) packed by upa_pack_conv_weight(64 -> 64, k = 1), wc_b = columns [64, 96) packed by
+// upa_pack_tail_weight(64, 32), bc = cv2's bias; out = (n, h, w, 64) view.  nn/modules/block.py:457-488, 644-668.
+extern "C" int upa_bottleneck_pair_cv2(const void* x, const void* y0, int n, int h, int w, int ldx, const void* w1_packed,
+                                       const float* b1, const void* w2_packed, const float* b2, int residual,
+                                       const void* wc_std, const void* wc_b, const float* bc, void* out, int ldout, int act,
+                                       int dtype, void* stream) {
+  UPA_CHECK_ARG(y0 && wc_std && wc_b && bc && out, "bottleneck_pair_cv2: null pointer");
+  static const int off = pair_env("UPA_NO_PAIR_CV2", 0);
+  if (off || ldout % 8 != 0 || ((uintptr_t)out % 16) != 0 || ((uintptr_t)y0 % 16) != 0) {
+    upa_set_error("bottleneck_pair_cv2: outside the fused form");
+    return UPA_EUNSUPPORTED;
+  }
+  PairParams cv2;
+  memset(&cv2, 0, sizeof(cv2));
+  cv2.y0 = (const char*)y0; cv2.wc_std = (const char*)wc_std; cv2.wc_b = (const char*)wc_b; cv2.bc = bc;
+  cv2.out = (char*)out; cv2.ldout = ldout;
+  return pair_impl(x, n, h, w, 32, ldx, w1_packed, b1, w2_packed, b2, out, ldout, residual, act, dtype, &cv2, stream);
 }

@@ -76,4 +76,10 @@ struct PairParams {
   int N, H, W, OH, OW, ldx, ldy;
   int TH, TW, tilesX, tilesY;
   unsigned magicIW, magicMW, magicTW;
+  // CV2 form (C2f with one Bottleneck of 32 channels): the C2f's cv2 (1x1 over cat(y0, y1, b) -> 64 channels) on the end
+  const char* y0;      // the y0 slice of the C2f concat buffer (same pixel stride ldx as x = the y1 slice)
+  const char* wc_std;  // cv2 columns [0, 64) = (y0 | y1): upa_pack_conv_weight(64 -> 64, k = 1) layout [2 k-tiles][4 n-tiles]
+  const char* wc_b;    // cv2 columns [64, 96) = b: upa_pack_tail_weight(64, 32) layout [1 k-step][4 n-tiles] (accumulator k order)
+  const float* bc;     // cv2 bias (64)
+  char* out; int ldout;
 };

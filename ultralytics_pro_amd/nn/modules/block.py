@@ -11,7 +11,7 @@ import torch.nn as nn
 
 from ... import _lib as L
 from ...engine import runtime as R
-from .conv import Conv, _HipConvMixin, hip_conv2d
+from .conv import Conv, PackedConv, _HipConvMixin, fold_bn, hip_conv2d, version_key
 
 __all__ = ("DFL", "SPPF", "C2f", "C3", "Bottleneck", "MHSA", "BottleneckTransformer", "BoT3")
 
@@ -125,9 +125,49 @@ class C2f(nn.Module):
         c, nb = self.c, len(self.m)
         cat = R.alloc_nhwc(n, (2 + nb) * c, h, w, x.dtype, x.device, key=(id(self), "cat"))
         self.cv1(x, out=cat[:, : 2 * c], up=up)
+        y = self._pair_cv2(cat, out)
+        if y is not None:
+            return y
         for i, m in enumerate(self.m):
             m(cat[:, (1 + i) * c: (2 + i) * c], out=cat[:, (2 + i) * c: (3 + i) * c])
         return self.cv2(cat, out=out)
+
+    fuse_pair_cv2 = True  # bf16, one 32-channel Bottleneck, 64 outputs: Bottleneck + cv2 as one launch (upa_bottleneck_pair_cv2)
+
+    def _pair_cv2(self, cat, out):
+        """[Bottleneck + cv2] in one launch after cv1 has filled cat[:, :2c]; None when the block is outside that form."""
+        m = self.m[0] if len(self.m) == 1 else None
+        if not (self.fuse_pair_cv2 and m is not None and self.c == 32 and self.cv2.conv.out_channels == 64
+                and cat.dtype == torch.bfloat16 and not self.training and m._pair_ok(cat[:, 32:64])
+                and isinstance(self.cv2.act, nn.SiLU) and self.cv2.conv.kernel_size == (1, 1) and hasattr(self.cv2, "bn")):
+            return None
+        n, _, h, w = cat.shape
+        dev = cat.device
+        y = out if out is not None else R.alloc_nhwc(n, 64, h, w, cat.dtype, dev, key=(id(self), "y"))
+        p1 = m.cv1._packed(m.cv1.conv, m.cv1.bn, dev, cat.dtype, False)
+        p2 = m.cv2._packed(m.cv2.conv, m.cv2.bn, dev, cat.dtype, False)
+        cache = self.__dict__.setdefault("_pc_cache", {})
+        cv = self.cv2
+        ver = version_key(cv.conv.weight, cv.conv.bias, cv.bn.weight, cv.bn.bias, cv.bn.running_mean, cv.bn.running_var) + (cv.bn.eps,)
+        hit = cache.get(str(dev))
+        if hit is None or hit[0] != ver:
+            wf, bf = fold_bn(cv.conv, cv.bn)  # (64, 96, 1, 1), (64,)
+            std = PackedConv(wf[:, :64].contiguous(), bf, 1, dev, cat.dtype, False)
+            wb = wf[:, 64:96].reshape(64, 32).contiguous().float()
+            host = torch.empty(L.lib().upa_tail_packed_weight_bytes(64, 32), dtype=torch.uint8)
+            L.check(L.lib().upa_pack_tail_weight(wb.data_ptr(), 64, 32, host.data_ptr()), "pack_tail_weight")
+            hit = (ver, std, host.to(dev))
+            cache[str(dev)] = hit
+        _, std, wb_d = hit
+        vx, v0, vy = R.view_of(cat[:, 32:64]), R.view_of(cat[:, :32]), R.view_of(y)
+        rc = L.lib().upa_bottleneck_pair_cv2(vx.ptr, v0.ptr, vx.n, vx.h, vx.w, vx.ld, p1.w.data_ptr(), p1.bias.data_ptr(),
+                                             p2.w.data_ptr(), p2.bias.data_ptr(), int(m.add), std.w.data_ptr(), wb_d.data_ptr(),
+                                             std.bias.data_ptr(), vy.ptr, vy.ld, L.ACT_SILU, vx.dtype, L.current_stream(dev))
+        if rc == 0:
+            return y
+        if rc != L.UPA_EUNSUPPORTED:
+            L.check(rc, "bottleneck_pair_cv2")
+        return None
 
 
 class C3(nn.Module):
