@@ -19,6 +19,8 @@
 // Rounding points (bf16 y0, y1, t, b, out; f32 accumulation and f32 residual add) are those of the four separate launches.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 typedef __attribute__((address_space(1))) const void* cgptr_t;
@@ -127,38 +129,51 @@ __global__ __launch_bounds__(NW * 64) void c2f16_fused_kernel(const C2fParams p)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  // ---- A. y1 on the 400 halo pixels
-  for (int mt = wave; mt < XPX / 16; mt += NW) {
-    const int q = mt * 16 + r;
-    const u32x4 b = *reinterpret_cast<const u32x4*>(xs + q * 64 + g * 16);
-    const f32x4 acc = mfma32(w_y1, b, bias_y1);
-    const int hy = q / XW, hx = q - hy * XW;
-    const int iy = oy0 - 2 + hy, ix = ox0 - 2 + hx;
-    const bool in = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-    float v[4];
+  // interior tiles (the 20 x 20 halo inside the image: 64 % of the tiles at 160 x 160) skip the zero-padding masks of A and B
+  const bool interior = oy0 >= 2 && ox0 >= 2 && oy0 + TH + 2 <= p.H && ox0 + TW + 2 <= p.W;  // workgroup-uniform
+  auto stage_ab = [&](auto masked_tag) __attribute__((always_inline)) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
+    // ---- A. y1 on the 400 halo pixels
+    for (int mt = wave; mt < XPX / 16; mt += NW) {
+      const int q = mt * 16 + r;
+      const u32x4 b = *reinterpret_cast<const u32x4*>(xs + q * 64 + g * 16);
+      const f32x4 acc = mfma32(w_y1, b, bias_y1);
+      bool in = true;
+      if constexpr (MASKED) {
+        const int hy = q / XW, hx = q - hy * XW;
+        const int iy = oy0 - 2 + hy, ix = ox0 - 2 + hx;
+        in = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      }
+      float v[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = in ? silu(acc[e]) : 0.f;
-    *reinterpret_cast<u32x2*>(y1s + q * 32 + g * 8) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-  }
-  __syncthreads();
+      for (int e = 0; e < 4; ++e) v[e] = in ? silu(acc[e]) : 0.f;
+      *reinterpret_cast<u32x2*>(y1s + q * 32 + g * 8) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    }
+    __syncthreads();
 
-  // ---- B. t on the 18 x 18 inner pixels
-  for (int mt = wave; mt < MT_B; mt += NW) {
-    const int q = mt * 16 + r;
-    const int qc = q < MPX ? q : MPX - 1;
-    const int ty = qc / MW, tx = qc - ty * MW;
-    const char* base = y1s + (ty * XW + tx) * 32;
-    f32x4 acc = bias_a;
+    // ---- B. t on the 18 x 18 inner pixels
+    for (int mt = wave; mt < MT_B; mt += NW) {
+      const int q = mt * 16 + r;
+      const int qc = q < MPX ? q : MPX - 1;
+      const int ty = qc / MW, tx = qc - ty * MW;
+      const char* base = y1s + (ty * XW + tx) * 32;
+      f32x4 acc = bias_a;
 #pragma unroll
-    for (int s = 0; s < 5; ++s) acc = mfma32(w_a[s], *reinterpret_cast<const u32x4*>(base + offB[s]), acc);
-    const int iy = oy0 - 1 + ty, ix = ox0 - 1 + tx;
-    const bool in = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-    float v[4];
+      for (int s = 0; s < 5; ++s) acc = mfma32(w_a[s], *reinterpret_cast<const u32x4*>(base + offB[s]), acc);
+      bool in = true;
+      if constexpr (MASKED) {
+        const int iy = oy0 - 1 + ty, ix = ox0 - 1 + tx;
+        in = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      }
+      float v[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = in ? silu(acc[e]) : 0.f;
-    *reinterpret_cast<u32x2*>(ts + q * 32 + g * 8) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-  }
-  __syncthreads();
+      for (int e = 0; e < 4; ++e) v[e] = in ? silu(acc[e]) : 0.f;
+      *reinterpret_cast<u32x2*>(ts + q * 32 + g * 8) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    }
+    __syncthreads();
+  };
+  if (interior) stage_ab(std::false_type{});
+  else stage_ab(std::true_type{});
 
   // ---- C + D. a wave owns TH / NW tile rows (one m-tile each)
 #pragma unroll 1

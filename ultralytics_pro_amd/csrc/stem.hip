@@ -7,6 +7,8 @@
 // one contiguous CO_T*esize store per thread.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 struct StemParams {
@@ -544,32 +546,44 @@ __global__ __launch_bounds__(NW * 64) void stem_conv_fused_kernel(const StemFuse
     const int tyi = t2 / p.tilesX, txi = t2 - tyi * p.tilesX;
     const int oy0 = tyi * T1H, ox0 = txi * T1W;
     const int sy0 = 2 * oy0 - 1, sx0 = 2 * ox0 - 1;  // stem coordinates of the stem tile origin
+    // the 17 x 33 stem tile inside the stem map (72 % of the tiles at 640 x 640): no padding mask (workgroup-uniform)
+    const bool interior = sy0 >= 0 && sx0 >= 0 && sy0 + S0H <= p.H0 && sx0 + S0W <= p.W0;
     const char* pb = fsm + cur * PATCH;
-    // ---- stage 2: the 17 x 33 stem tile, 16 stem pixels per MFMA; segment = 16 consecutive pixels of the linearised tile
+    // ---- stage 2: the 17 x 33 stem tile, 16 stem pixels per MFMA; segment = 16 consecutive pixels of the linearised tile.
+    // Two copies of the loop: interior tiles (above) carry no padding mask and no tail-segment selects on the gather.
     constexpr int NSEG = (S0H * S0W + 15) / 16;  // 36
-    for (int sg = wave; sg < NSEG; sg += NW) {
-      const int q = sg * 16 + l16;
-      const int r = q / S0W, c = q - r * S0W;     // stem tile row / column of this lane's pixel (q may run past the tile)
-      unsigned e[8];
-      const char* base = pb + ((2 * r) * LS + 2 * c) * 2;
-      const bool qin = q < S0H * S0W;
+    auto stage2 = [&](auto masked_tag) __attribute__((always_inline)) {
+      constexpr bool MASKED = decltype(masked_tag)::value;
+      for (int sg = wave; sg < NSEG; sg += NW) {
+        const int q = sg * 16 + l16;
+        const bool qin = q < S0H * S0W;
+        const int qq = qin ? q : S0H * S0W - 1;     // lanes past the tile (last segment) gather the last pixel, never stored
+        const int r = qq / S0W, c = qq - r * S0W;   // stem tile row / column of this lane's pixel
+        unsigned e[8];
+        const char* base = pb + ((2 * r) * LS + 2 * c) * 2;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) e[j] = qin ? *reinterpret_cast<const unsigned short*>(base + goff[j]) : 0u;
-      u32x4 b = u32x4{e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
-      f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&a0), *reinterpret_cast<bf16x8*>(&b), bias0, 0, 0, 0);
-      // lane (kg, l16): channels 4kg..4kg+3 of stem pixel q; zero outside the stem map (padding of the second conv)
-      const int sy = sy0 + r, sx = sx0 + c;
-      const bool inmap = sy >= 0 && sy < p.H0 && sx >= 0 && sx < p.W0;
-      float v[4];
+        for (int j = 0; j < 8; ++j) e[j] = *reinterpret_cast<const unsigned short*>(base + goff[j]);
+        u32x4 b = u32x4{e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
+        f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&a0), *reinterpret_cast<bf16x8*>(&b), bias0, 0, 0, 0);
+        // lane (kg, l16): channels 4kg..4kg+3 of stem pixel q; zero outside the stem map (padding of the second conv)
+        bool inmap = true;
+        if constexpr (MASKED) {
+          const int sy = sy0 + r, sx = sx0 + c;
+          inmap = sy >= 0 && sy < p.H0 && sx >= 0 && sx < p.W0;
+        }
+        float v[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const float u = acc[t];
-        v[t] = inmap ? u * __builtin_amdgcn_rcpf(1.0f + __expf(-u)) : 0.f;
+        for (int t = 0; t < 4; ++t) {
+          const float u = acc[t];
+          v[t] = inmap ? u * __builtin_amdgcn_rcpf(1.0f + __expf(-u)) : 0.f;
+        }
+        if (qin)
+          *reinterpret_cast<u32x2*>(stile + ((r * 2 + (c & 1)) * S0WH + (c >> 1)) * SPITCH + kg * 8) =
+              u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
       }
-      if (qin)
-        *reinterpret_cast<u32x2*>(stile + ((r * 2 + (c & 1)) * S0WH + (c >> 1)) * SPITCH + kg * 8) =
-            u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-    }
+    };
+    if (interior) stage2(std::false_type{});
+    else stage2(std::true_type{});
     __syncthreads();
     // ---- stage 3: second conv, a wave owns T1H / NW output rows (16 pixels each) x 32 channels
 #pragma unroll
