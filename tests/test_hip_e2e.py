@@ -145,6 +145,15 @@ def test_e2e_bf16_nms_prefilter_is_exact(name, conf, multi_label):
         hot = [t.clone() for t in nms_raw(y1, conf, 0.7, multi_label=multi_label, key="hot")]
         for a, b in zip(full, hot):
             assert torch.equal(a, b)
+        if not multi_label:  # class filter (nms.py:100-101) on the key path: the mask is applied to the key's class
+            fc = [t.clone() for t in nms_raw(y1.clone(), conf, 0.7, classes=[0, 3, 17, 42, 79], key="fc")]
+            hc = [t.clone() for t in nms_raw(y1, conf, 0.7, classes=[0, 3, 17, 42, 79], key="hc")]
+            for a, b in zip(fc, hc):
+                assert torch.equal(a, b)
+            fa = [t.clone() for t in nms_raw(y1.clone(), conf, 0.7, agnostic=True, max_det=50, key="fa")]
+            ha = [t.clone() for t in nms_raw(y1, conf, 0.7, agnostic=True, max_det=50, key="ha")]
+            for a, b in zip(fa, ha):
+                assert torch.equal(a, b)
         low = [t.clone() for t in nms_raw(y1, 0.05, 0.7, key="low")]
         ref_low = [t.clone() for t in nms_raw(y1.clone(), 0.05, 0.7, key="low2")]  # a clone carries no keys: full scan
         for a, b in zip(low, ref_low):
