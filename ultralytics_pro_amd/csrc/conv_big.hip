@@ -435,7 +435,8 @@ extern "C" int upa_detect_branch_tail(const void* x, int n, int h, int w, int c,
   p.de.nc = nc; p.de.stride_px = stride_px;
   if (kind == 2 && best_keys && (long)a_total * nc < (1L << 31)) p.de.best_keys = best_keys;
   const long px = (long)n * h * w;
-  const int bm = (px + 255) / 256 < big_num_cu() ? 128 : 256;  // 128-pixel workgroups (one m-tile per wave) on the small levels
+  int bm = (px + 255) / 256 < big_num_cu() ? 128 : 256;  // 128-pixel workgroups (one m-tile per wave) on the small levels
+  if (const int f = big_env("UPA_BRANCH_TAIL_BM", 0); f == 128 || f == 256) bm = f;
   if (!big_pick_tile(p, bm, ntb, 80 * 1024 - 512) && !big_pick_tile(p, bm, ntb, 160 * 1024)) return UPA_EUNSUPPORTED;
   p.tilesX = cdiv(p.OW, p.TW);
   p.tilesY = cdiv(p.OH, p.TH);
