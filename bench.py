@@ -662,7 +662,7 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
         flops = 2.0 * npx * (9 * c_ * c_ + c_ * cout)
         nbytes = npx * c_ * 2 + npx * (4 if kind == 1 else nc_) * 4 + (9 * c_ * c_ + c_ * cout) * 2
         mt = 1 if (npx + 255) // 256 < torch.cuda.get_device_properties(dev).multi_processor_count else 2
-        calls.append(("void conv_big_kernel<3, 1, 8, 1, %d, %d, %d>(BigParams)" % (mt, 4 if kind == 1 else 6, kind), flops, nbytes,
+        calls.append(("void conv_big_kernel<3, 1, 8, 1, %d, %d, %d>(BigParams)" % (mt, 4 if kind == 1 else (5 if c_ == 80 else 6), kind), flops, nbytes,
                       (lambda a=a: orig_btail(*a[:18], L.current_stream(dev)))))
     torch.cuda.synchronize(dev)
     fam = {}

@@ -151,7 +151,8 @@ int upa_c2f_fused(const void* x, int n, int h, int w, int c1, int ldx, int c, in
 
 /* The whole back half of a Detect branch in one launch (bf16): second 3x3 conv (BN + SiLU folded) -> final 1x1 conv -> that
  * branch's half of the decode, the intermediate maps never leaving the registers.      head.py:94-100 (cv2/cv3), :116-126,
- * :151-169.  kind 1 = box branch (c = 64 = 4 * reg_max 16), 2 = class branch (c <= 96, nc <= 96).  With CP = 64 / 96:
+ * :151-169.  kind 1 = box branch (c = 64 = 4 * reg_max 16), 2 = class branch (c <= 96, nc <= 96).  With CP = 64 (box), 80 (class
+ * branch with c = 80) or 96 (class branch, any other c):
  * w3_packed / b3 = upa_pack_conv_weight of the 3x3 conv as c -> CP (zero filters and biases appended);
  * wt_packed = upa_pack_tail_weight(cout = CP, cin = CP) of the zero-padded 1x1 matrix, bt = CP biases.
  * Returns UPA_EUNSUPPORTED outside that form (callers then run conv2d + upa_detect_tail). */

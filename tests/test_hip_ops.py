@@ -593,7 +593,7 @@ def test_detect_branch_tail_vs_unfused_and_oracle(nc, c3, shape):
     best_keys = torch.full((n, a_total), -1, dtype=torch.int64, device=DEV)  # NMS prefilter: best-class sort keys (u64 bits)
     raws = []
     for kind, c, cout1 in ((1, 64, 64), (2, c3, nc)):
-        cp = 64 if kind == 1 else 96
+        cp = 64 if kind == 1 else (80 if c == 80 else 96)  # c = 80: the 5-tile form with a 16-wide last k-step
         x = bf16_round(unit_input(f"bt_x{kind}{nc}", (n, c, h, w), -1.5, 1.5))
         w3 = bf16_round(unit_input(f"bt_w3{kind}{nc}", (c, c, 3, 3), -0.12, 0.12))
         b3 = unit_input(f"bt_b3{kind}{nc}", (c,), -0.5, 0.5)

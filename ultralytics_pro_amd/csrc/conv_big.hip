@@ -50,7 +50,8 @@ __device__ __forceinline__ float big_act(float v) {
 template <int KS, int STRIDE, int WM, int WN, int MT, int NT, int TAIL = 0>
 __global__ __launch_bounds__(512, 4) void conv_big_kernel(const BigParams p) {
   static_assert(WM * WN == 8, "8 waves per workgroup");
-  static_assert(TAIL == 0 || (WN == 1 && (NT % 2) == 0), "a tail needs every channel of a pixel in one wave");
+  static_assert(TAIL == 0 || WN == 1, "a tail needs every channel of a pixel in one wave");
+  static_assert(TAIL != 1 || (NT % 2) == 0, "box branch: 64 channels");
   constexpr int NTB = WN * NT;            // n-tiles per workgroup
   constexpr int WBUF = 2 * NTB * 1024;    // one (tap, chunk) weight slab: 2 k-tiles x NTB n-tiles x 1 KiB
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -213,6 +214,29 @@ __global__ __launch_bounds__(512, 4) void conv_big_kernel(const BigParams p) {
         for (int i = 0; i < MT; ++i)
           acc2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a2),
                                                                *reinterpret_cast<const bf16x8*>(&hb[i]), acc2[i][j], 0, 0, 0);
+      }
+    }
+    if constexpr (NT & 1) {
+      // odd tile count (80 channels = 5 tiles): the last tile alone is a 16-wide k-step - its packed accumulators are the B
+      // operand of v_mfma_f32_16x16x16_bf16 (lane (g, r): channels 4g .. 4g + 3 of pixel r), and the A operand is the LOW
+      // half of the k-step's packed fragment (element e < 4 = channel 32s + 4g + e, see upa_pack_tail_weight)
+      typedef __attribute__((ext_vector_type(4))) short s16x4;
+      constexpr int j0 = NT - 1, s2 = NT / 2;
+      u32x2 hh[MT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        float v0[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v0[q] = big_act<UPA_ACT_SILU>(acc[i][j0][q] + bv[j0][q]);
+        hh[i] = u32x2{pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3])};
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const u32x2 a2 = *reinterpret_cast<const u32x2*>(p.tw + ((size_t)(s2 * NT + j) * 64 + lane) * 16);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+          acc2[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(*reinterpret_cast<const s16x4*>(&a2),
+                                                                 *reinterpret_cast<const s16x4*>(&hh[i]), acc2[i][j], 0, 0, 0);
       }
     }
     f32x4 tbv[NT];
@@ -407,7 +431,8 @@ extern "C" int upa_pack_tail_weight(const float* w, int cout, int cin, void* out
 }
 
 // Second 3x3 conv of a Detect branch + the final 1x1 conv + that branch's half of the decode in ONE launch (bf16).
-// x: (n, h, w, c) NHWC view, c = 64 (box branch, kind 1) or <= 96 (class branch, kind 2).  With CP = 64 (box) / 96 (class):
+// x: (n, h, w, c) NHWC view, c = 64 (box branch, kind 1) or <= 96 (class branch, kind 2).  With CP = 64 (box) / 80 (class, c = 80) /
+// 96 (class, any other c):
 // w3 / b3 = the 3x3 conv packed by upa_pack_conv_weight as c -> CP (BN folded, zero filters / biases appended up to CP);
 // wt = the 1x1 conv as upa_pack_tail_weight(cout = CP, cin = CP) of the zero-padded matrix, bt = its CP biases.
 extern "C" int upa_detect_branch_tail(const void* x, int n, int h, int w, int c, int ldx, const void* w3_packed, const float* b3,
@@ -417,9 +442,9 @@ extern "C" int upa_detect_branch_tail(const void* x, int n, int h, int w, int c,
   UPA_CHECK_ARG(kind == 1 || kind == 2, "detect_branch_tail: kind must be 1 (box) or 2 (class)");
   UPA_CHECK_ARG(n > 0 && h > 0 && w > 0 && a0 >= 0 && a0 + h * w <= a_total, "detect_branch_tail: level does not fit a_total");
   static const int off = big_env("UPA_NO_BRANCH_TAIL", 0);
-  const int ntb = kind == 1 ? 4 : 6;
+  const int ntb = kind == 1 ? 4 : (c == 80 ? 5 : 6);  // 80 class-branch channels (nc = 80 models): 5 tiles, no padded sixth
   if (off || dtype != UPA_BF16 || c % 8 != 0 || ldx % 8 != 0 || h * w < 2 || w < 2 || (kind == 1 && c != 64) ||
-      (kind == 2 && (c > 96 || nc > 96)) || ((uintptr_t)x % 16) != 0) {
+      (kind == 2 && (c > 96 || nc > ntb * 16)) || ((uintptr_t)x % 16) != 0) {
     upa_set_error("detect_branch_tail: outside the fused form (bf16; box c = 64; class c <= 96, nc <= 96)");
     return UPA_EUNSUPPORTED;
   }
@@ -447,6 +472,7 @@ extern "C" int upa_detect_branch_tail(const void* x, int n, int h, int w, int c,
   const size_t lds = halo + 2 * (size_t)(2 * ntb * 1024) + 256;
   hipStream_t s = (hipStream_t)stream;
   if (kind == 1) return bm == 256 ? big_launch_inst<3, 1, 8, 1, 2, 4, 1>(p, lds, s) : big_launch_inst<3, 1, 8, 1, 1, 4, 1>(p, lds, s);
+  if (ntb == 5) return bm == 256 ? big_launch_inst<3, 1, 8, 1, 2, 5, 2>(p, lds, s) : big_launch_inst<3, 1, 8, 1, 1, 5, 2>(p, lds, s);
   return bm == 256 ? big_launch_inst<3, 1, 8, 1, 2, 6, 2>(p, lds, s) : big_launch_inst<3, 1, 8, 1, 1, 6, 2>(p, lds, s);
 }
 

@@ -96,7 +96,7 @@ class Detect(nn.Module, _HipConvMixin):
     def _branch_tail(self, t: torch.Tensor, mid, conv: nn.Conv2d, kind: int, i: int, plan) -> bool:
         """[conv3x3 + SiLU + 1x1 + decode] in one launch; False when the branch is outside the fused form."""
         c = mid.conv.in_channels
-        cp = 64 if kind == 1 else 96
+        cp = 64 if kind == 1 else (80 if c == 80 else 96)  # padded channel count of the fused form (upa_detect_branch_tail)
         if not (isinstance(mid, Conv) and isinstance(mid.act, nn.SiLU) and mid.conv.kernel_size == (3, 3) and mid.conv.stride == (1, 1)
                 and mid.conv.padding == (1, 1) and mid.conv.groups == 1 and mid.conv.out_channels == c == conv.in_channels
                 and t.dtype == torch.bfloat16 and conv.kernel_size == (1, 1)
