@@ -545,6 +545,8 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
             wm, wn, nt = (8, 1, 4) if (ntb == 4 and mt == 4) else (4, 2, ntb // 2)
             if ntb == 4:
                 mt = 2
+            if ntb == 5:  # 80 output channels: 8 x 1 waves, 5 tiles each, MT = 2 (256 px) or 1 (128 px)
+                wm, wn, nt, mt = 8, 1, 5, (2 if (var & 15) == 2 else 1)
             return "void conv_big_kernel<%d, %d, %d, %d, %d, %d, 0>(BigParams)" % (pk.k, stride, wm, wn, mt, nt)
         if (var >> 22) & 1:  # streaming pointwise kernel (conv1x1.hip): <NTW, MT, WAVES, EPI>
             return "void conv1x1_stream_kernel<%d, %d, %d, 0>(C1Params)" % (var & 15, (var >> 4) & 15, (var >> 8) & 31)

@@ -524,6 +524,8 @@ int upa_conv_big_launch(BigParams p, int query_only, int* variant, void* stream)
   // workgroup columns: 128 channels, 96 for Cout in (64, 96], 64 for Cout <= 64 - and 64 for wider layers whose 128-pixel x
   // 128-channel workgroups would still be fewer than the CUs (20x20 maps: twice the workgroups, each with half the weights)
   int ntb = p.NTn <= 4 ? 4 : (p.NTn <= 6 ? 6 : 8);
+  static const int five = big_env("UPA_CONV_BIG_NT5", 1);
+  if (five && p.NTn == 5 && p.KS == 3 && p.stride == 1) ntb = 5;  // 80 output channels (Detect class branch): 8 x 1 waves x 5 tiles
   const long px = (long)p.N * p.OH * p.OW;
   static const int split = big_env("UPA_CONV_BIG_SPLIT", 1);
   if (split && ntb == 8 && p.NTn % 4 == 0 && (px + 127) / 128 * cdiv(p.NTn, 8) < big_num_cu()) ntb = 4;
@@ -551,6 +553,7 @@ int upa_conv_big_launch(BigParams p, int query_only, int* variant, void* stream)
   const size_t lds = halo + 2 * (size_t)(2 * ntb * 1024) + 256;
   if (lds > 160 * 1024) return UPA_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
+  if (ntb == 5) return bm == 256 ? big_launch_inst<3, 1, 8, 1, 2, 5>(p, lds, s) : big_launch_inst<3, 1, 8, 1, 1, 5>(p, lds, s);
   if (ntb == 8) return bm == 256 ? big_launch_ks<4, 2, 4, 4>(p, lds, s) : big_launch_ks<4, 2, 2, 4>(p, lds, s);
   if (ntb == 6) return bm == 256 ? big_launch_ks<4, 2, 4, 3>(p, lds, s) : big_launch_ks<4, 2, 2, 3>(p, lds, s);
   return bm == 256 ? big_launch_ks<8, 1, 2, 4>(p, lds, s) : big_launch_ks<4, 2, 2, 2>(p, lds, s);
