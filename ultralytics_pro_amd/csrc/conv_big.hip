@@ -20,7 +20,8 @@
 //   * tile shape chosen per layer on the host (TW need not be a power of two: 20 x 12 for 20x20 maps, 40 x 6 for 40x40), the
 //     pixel -> (row, column) split is done once per lane with a multiply-high.
 // Variants <WM, WN, MT, NT> (WM * WN = 8 waves): 4,2,4,4 = 256 px x 128 ch; 4,2,2,4 = 128 px x 128 ch (few-pixel layers: twice
-// the workgroups); 4,2,4,3 / 4,2,2,3 = x 96 ch (Cout 80 / 96); 8,1,2,4 = 256 px x 64 ch; 4,2,2,2 = 128 px x 64 ch.
+// the workgroups); 4,2,4,3 / 4,2,2,3 = x 96 ch (Cout 96, or 80 off the 3x3 stride-1 form); 8,1,2,5 / 8,1,1,5 = x 80 ch (the Detect class
+// branch: five tiles, nothing padded); 8,1,2,4 = 256 px x 64 ch; 4,2,2,2 = 128 px x 64 ch.
 // Epilogue straight from the accumulators (bias, SiLU by v_exp_f32 / v_rcp_f32, bf16 pack, v_permlane16_swap -> 16-byte
 // NHWC stores, residual read with the same shape), as conv.hip.
 #include <stdlib.h>
