@@ -468,6 +468,18 @@ __global__ __launch_bounds__(NW * 64) void stem_conv_fused_kernel(const StemFuse
   const int ntiles = p.tilesX * p.tilesY * p.N;
   const int tilesPerImg = p.tilesX * p.tilesY;
   const int plane = p.H * p.W;
+  // this thread's items of a patch (channel plane, row, 8-pixel column group) do not depend on the tile: decomposed once
+  constexpr int NIT = ITEMS_PAD / NTH;
+  int it_row[NIT], it_col[NIT], it_off[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int item = it * NTH + tid;
+    const int line = item / NCH, ch = item - line * NCH;
+    const int ci = line / PR, row = line - ci * PR;
+    it_row[it] = item < ITEMS ? row : (1 << 28);  // past the patch: never inside the image
+    it_col[it] = ch * 8;
+    it_off[it] = ci * plane + row * p.W + ch * 8;
+  }
   auto stage = [&](int tile, char* buf) __attribute__((always_inline)) {
     const int n = tile / tilesPerImg;
     const int t2 = tile - n * tilesPerImg;
@@ -476,15 +488,12 @@ __global__ __launch_bounds__(NW * 64) void stem_conv_fused_kernel(const StemFuse
     const int iy0 = 2 * (2 * tyi * T1H - 1) - 1, ix0 = 2 * (2 * txi * T1W - 1) - 1;
     const int ixa = ix0 & ~7;
     const bf16_t* xb = (const bf16_t*)p.x + (size_t)n * 3 * plane;
+    const bf16_t* xt = xb + iy0 * p.W + ixa;  // patch origin (may lie outside the image: only in-image items are read)
 #pragma unroll
-    for (int it = 0; it < ITEMS_PAD / NTH; ++it) {
-      const int item = it * NTH + tid;
-      const int line = item / NCH, ch = item - line * NCH;
-      const int ci = line / PR, row = line - ci * PR;
-      const int iy = iy0 + row, ix = ixa + ch * 8;
-      const bool in = item < ITEMS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-      const char* src = in ? reinterpret_cast<const char*>(xb + ci * plane + iy * p.W + ix)
-                           : reinterpret_cast<const char*>(g_stem_zero16);
+    for (int it = 0; it < NIT; ++it) {
+      const int iy = iy0 + it_row[it], ix = ixa + it_col[it];
+      const bool in = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      const char* src = in ? reinterpret_cast<const char*>(xt + it_off[it]) : reinterpret_cast<const char*>(g_stem_zero16);
       __builtin_amdgcn_global_load_lds((sgptr_t)src, (slptr_t)(buf + (it * NTH + wave * 64) * 16), 16, 0, 0);
     }
   };
