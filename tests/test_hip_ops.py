@@ -328,7 +328,7 @@ def test_c2f_fused_kernel(case, th, monkeypatch):
     assert (y - ref).abs().max().item() <= 3e-2 * scale, (y - ref).abs().max().item()
     # same rounding points as the separate launches; a bf16 tie that falls the other way in an intermediate moves few outputs
     # (measured: 0.02-0.03 % of the outputs differ with the shortcut, up to 1.4 % without it - nothing damps a flipped tie -; mean
-    # |error| against the plain-f32 oracle equal to 5 digits, experiments/c2f_err.py)
+    # |error| against the plain-f32 oracle equal to 5 digits, tools/experiments/c2f_err.py)
     d = (y - y2).abs()
     assert d.max().item() <= 3e-2 * scale and (d > 1e-6).float().mean().item() <= 0.03, (d.max().item(), (d > 1e-6).float().mean().item())
     assert float(to_cpu_nchw(buf[:, :c1]).abs().max()) == 0.0  # nothing written outside the output slice
