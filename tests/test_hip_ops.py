@@ -281,6 +281,34 @@ def test_c2f_pair_cv2_kernel(case):
     assert float(to_cpu_nchw(buf[:, :64]).abs().max()) == 0.0  # nothing written outside the output slice
 
 
+def test_c3_virtual_upsample_concat():
+    """C3 after Concat([Upsample(u), skip]) (yolov5 neck rows 12-14 / 16-18): both 1x1 convs that read the Concat (cv1, cv2;
+    block.py:509-532) take the half-resolution tensor through `upa_conv1x1_upcat` - bit-identical to the materialised path."""
+    from tests.hip_utils import DEV, bf16_round, to_cpu_nchw, to_dev_nhwc
+    from ultralytics_pro_amd.engine import runtime as R
+    from ultralytics_pro_amd.nn.modules.conv import VirtualUpsample
+    pm, rs = _mods()
+    n, cu, cs, h, w = 2, 128, 64, 10, 12
+    o, m = _pair(om.C3, pm.C3, (cu + cs, 64, 1, False), "c3_upcat")
+    u = bf16_round(P.uniform("c3up_u", (n, cu, h, w), -1, 1))
+    sk = bf16_round(P.uniform("c3up_s", (n, cs, 2 * h, 2 * w), -1, 1))
+    with torch.no_grad():
+        ud = to_dev_nhwc(u, torch.bfloat16)
+        buf = R.alloc_nhwc(n, cu + cs, 2 * h, 2 * w, torch.bfloat16, DEV)
+        buf.fill_(7.0)
+        buf[:, cu:].copy_(to_dev_nhwc(sk, torch.bfloat16))
+        up = rs.Upsample(None, 2, "nearest")
+        done = []
+        v = VirtualUpsample(ud, cu, lambda: done.append(up(ud, out=buf[:, :cu])))
+        y = to_cpu_nchw(m(buf, up=v))
+        assert not done and not v.done  # neither conv needed the materialised copy
+        up(ud, out=buf[:, :cu])
+        y2 = to_cpu_nchw(m(buf))
+        ref = o(torch.cat([torch.nn.functional.interpolate(u, scale_factor=2, mode="nearest"), sk], 1))
+    assert torch.equal(y, y2)
+    assert (y - ref).abs().max().item() <= 6e-2 * max(1.0, ref.abs().max().item())
+
+
 C2F_CASES = [
     # c1, n, shortcut, (N, H, W)
     (32, 1, True, (2, 37, 50)), (32, 1, True, (1, 16, 16)), (32, 1, True, (3, 5, 9)), (32, 1, True, (2, 160, 160)),

@@ -171,7 +171,8 @@ class C2f(nn.Module):
 
 
 class C3(nn.Module):
-    """CSP bottleneck with 3 convolutions (block.py:509-532): cv3(cat(m(cv1(x)), cv2(x)))."""
+    """CSP bottleneck with 3 convolutions (block.py:509-532): cv3(cat(m(cv1(x)), cv2(x))).
+    `up`: a conv.VirtualUpsample for the leading channels of x - both 1x1 convs that read x take it."""
 
     def __init__(self, c1, c2, n=1, shortcut=True, g=1, e=0.5):
         super().__init__()
@@ -181,13 +182,13 @@ class C3(nn.Module):
         self.cv3 = Conv(2 * c_, c2, 1)
         self.m = nn.Sequential(*(Bottleneck(c_, c_, shortcut, g, k=((1, 1), (3, 3)), e=1.0) for _ in range(n)))
 
-    def forward(self, x, out=None):
+    def forward(self, x, out=None, up=None):
         x = R.to_nhwc(x, x.dtype)
         n, _, h, w = x.shape
         c_ = self.cv1.conv.out_channels
         cat = R.alloc_nhwc(n, 2 * c_, h, w, x.dtype, x.device, key=(id(self), "cat"))
-        self.cv2(x, out=cat[:, c_:])
-        y = self.cv1(x) if len(self.m) else self.cv1(x, out=cat[:, :c_])
+        self.cv2(x, out=cat[:, c_:], up=up)
+        y = self.cv1(x, up=up) if len(self.m) else self.cv1(x, out=cat[:, :c_], up=up)
         for i, m in enumerate(self.m):
             y = m(y, out=cat[:, :c_] if i == len(self.m) - 1 else None)
         return self.cv3(cat, out=out)

@@ -76,7 +76,13 @@ class VirtualUpsample:
     Concat reads `src` at (y/2, x/2) instead (`upa_conv1x1_upcat`)."""
 
     def __init__(self, src: torch.Tensor, channels: int, materialize):
-        self.src, self.channels, self.materialize = src, int(channels), materialize
+        self.src, self.channels, self._materialize, self.done = src, int(channels), materialize, False
+
+    def materialize(self):
+        """Write the upsampled channels after all (once): later consumers then read the buffer like any other."""
+        if not self.done:
+            self._materialize()
+            self.done = True
 
 
 def hip_conv2d(x: torch.Tensor, pk: PackedConv, stride: int, pad: int, act: int, out: torch.Tensor | None = None,
@@ -118,7 +124,7 @@ def hip_conv2d(x: torch.Tensor, pk: PackedConv, stride: int, pad: int, act: int,
         if (vr.n, vr.h, vr.w, vr.c, vr.dtype) != (vy.n, vy.h, vy.w, vy.c, vy.dtype):
             raise L.UpaError("conv2d: residual shape/dtype mismatch")
         rp, rld = vr.ptr, vr.ld
-    if up is not None:
+    if up is not None and not up.done:
         # the leading channels of x were never written: read them from the half-resolution tensor, or write them now
         vu = R.view_of(up.src)
         rc = L.UPA_EUNSUPPORTED

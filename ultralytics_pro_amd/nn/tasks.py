@@ -269,11 +269,15 @@ class BaseModel(nn.Module):
 
     def _virtual_upsample_ok(self, m, li: int, c0: int, c1: int, x) -> bool:
         """An Upsample row may stay unlaunched when it fills the LEADING channels of a Concat that only the next row reads,
-        that row is a C2f (its cv1 is the 1x1 conv that can read the half-resolution tensor) and the data is bf16."""
+        that row is a C2f or a C3 (whose 1x1 convs can read the half-resolution tensor) and the data is bf16."""
         if not (self.virtual_upsample and isinstance(m, Upsample) and c0 == 0 and (c1 - c0) % 32 == 0
                 and x.dtype == torch.bfloat16 and li not in self.save and li + 1 < len(self.model)):
             return False
         nxt = self.model[li + 1]
+        if isinstance(nxt, HipSequential):  # n > 1 repeats of a C3: only the first one reads the Concat
+            return False
+        if isinstance(nxt, C3) and type(nxt) is C3:  # both 1x1 convs of a C3 read the Concat (cv1 and cv2)
+            return nxt.f == -1 and nxt.cv1.conv.kernel_size == (1, 1) and nxt.cv2.conv.kernel_size == (1, 1) and not self.training
         return isinstance(nxt, C2f) and nxt.f == -1 and nxt.cv1.conv.kernel_size == (1, 1) and not self.training
 
     def _static_hw(self, h: int, w: int):
