@@ -119,6 +119,50 @@ def test_e2e_bf16_matches_reference_golden(name, golden_dir):
     assert np.quantile(dbox, 0.99) <= max(bmax, 4.0) and dsc.max() <= 0.05
 
 
+@pytest.mark.parametrize("shape", [(1, 352, 416), (3, 320, 320), (2, 224, 640)], ids=["1x352x416", "3x320x320", "2x224x640"])
+def test_e2e_bf16_fused_paths_match_unfused_at_other_sizes(shape):
+    """yolov8n bf16 at input sizes other than 640 x 640 (ragged tiles in every fused kernel, rectangular maps, batch 1 / 3):
+    the default path - fused stem, whole-block C2f kernels, Bottleneck + cv2, virtual Upsample + Concat, Detect branch tails,
+    NMS keys - against the same model with every one of those switches off (one launch per conv, materialised upsample,
+    separate decode, full-scan NMS).  Same bf16 rounding points, so the decoded outputs agree to bf16 resolution and the
+    detection sets almost entirely."""
+    from tests.hip_utils import DEV, detection_agreement
+    from ultralytics_pro_amd.nn.modules import block as pblock
+    from ultralytics_pro_amd.nn.modules import head as phead
+    from ultralytics_pro_amd.utils.nms import non_max_suppression
+    n, h, w = shape
+    m = _build("yolov8n", torch.bfloat16)
+    det = m.model[-1]
+    x = P.synthetic_images(n, h=h, w=w).to(DEV).to(torch.bfloat16).contiguous()
+    saved = (pblock.C2f.fuse_block, pblock.C2f.fuse_pair_cv2, pblock.Bottleneck.fuse_pair, phead.Detect.fuse_branch,
+             phead.Detect.fuse_decode, type(m).virtual_upsample)
+    try:
+        with torch.no_grad():
+            det.keep_raw, det.nms_keys = False, True
+            y1 = m(x)[0]
+            d1 = [o.cpu().numpy() for o in non_max_suppression(y1, conf_thres=0.25, iou_thres=0.7, max_det=300)]
+            y1 = y1.float().cpu()
+            pblock.C2f.fuse_block = pblock.C2f.fuse_pair_cv2 = pblock.Bottleneck.fuse_pair = False
+            phead.Detect.fuse_branch = phead.Detect.fuse_decode = False
+            type(m).virtual_upsample = False
+            det.keep_raw, det.nms_keys = True, False
+            y0 = m(x)[0]
+            d0 = [o.cpu().numpy() for o in non_max_suppression(y0, conf_thres=0.25, iou_thres=0.7, max_det=300)]
+            y0 = y0.float().cpu()
+    finally:
+        (pblock.C2f.fuse_block, pblock.C2f.fuse_pair_cv2, pblock.Bottleneck.fuse_pair, phead.Detect.fuse_branch,
+         phead.Detect.fuse_decode, type(m).virtual_upsample) = saved
+    assert y1.shape == y0.shape == (n, 84, (h // 8) * (w // 8) + (h // 16) * (w // 16) + (h // 32) * (w // 32))
+    d = (y1 - y0).abs()
+    # the separate decode reads bf16-rounded logits, the fused one f32 accumulators: boxes differ by bf16 resolution of a DFL
+    # expectation x stride (<= a few px at stride 32), scores by one bf16 ulp of the logit
+    print(f"{shape}: box |d| p99={d[:, :4].flatten().quantile(0.99).item():.3f} max={d[:, :4].max().item():.3f}, "
+          f"score max={d[:, 4:].max().item():.4f}")
+    assert d[:, :4].flatten().quantile(0.99).item() <= 2.0 and d[:, :4].max().item() <= 8.0 and d[:, 4:].max().item() <= 0.03
+    a = detection_agreement(d1, d0, 0.5)
+    assert a["recall"] >= 0.9 and a["precision"] >= 0.9, a
+
+
 @pytest.mark.parametrize("name,conf,multi_label", [("yolov8n", 0.25, False), ("yolov8n", 0.4, False), ("yolov8n", 0.4, True),
                                                    ("yolov8s", 0.25, False)])
 def test_e2e_bf16_nms_prefilter_is_exact(name, conf, multi_label):
