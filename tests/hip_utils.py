@@ -35,6 +35,44 @@ def bf16_round(x: torch.Tensor) -> torch.Tensor:
     return x.to(torch.bfloat16).float()
 
 
+def bf16_weight_oracle(o):
+    """A copy of an oracle module with the operands the bf16 kernels really multiply: every Conv's BatchNorm folded into its
+    weights (utils/torch_utils.py:236-266, the operation order of `oracle.modules.fuse_conv_and_bn` = the product's `fold_bn`)
+    and every conv weight - folded or plain nn.Conv2d (Detect's last 1x1, MHSA q / k / v) - rounded to bf16; biases stay f32
+    as in the product.  With inputs and intermediates rounded to bf16 where the kernels round them, what is left between
+    this oracle and a bf16 kernel is f32 summation order and one bf16 rounding of the output."""
+    import copy
+
+    from oracle import modules as om
+    o = copy.deepcopy(o).eval()
+    for m in o.modules():
+        if isinstance(m, om.Conv) and hasattr(m, "bn"):
+            om.fuse_conv_and_bn(m.conv, m.bn)
+            del m.bn
+            m.forward = m.forward_fuse
+    for m in o.modules():
+        if isinstance(m, torch.nn.Conv2d):
+            m.weight.data = bf16_round(m.weight.data)
+    return o
+
+
+BF16_REL, BF16_ABS = 2.0 ** -7, 2.0 ** -8
+
+
+def assert_bf16_close(y: torch.Tensor, ref: torch.Tensor, what: str = "", rel: float = BF16_REL, abs_: float = BF16_ABS):
+    """Elementwise |y - ref| <= 2^-7 |ref| + 2^-8 max|ref|: two bf16 ulps of the element plus one ulp of the largest one
+    (round-2 review item 2a; the old gate was 3e-2 * max|ref| ~ 15 output ulps, wide enough to hide a dropped input channel)."""
+    assert y.shape == ref.shape, (y.shape, ref.shape)
+    d = (y.float() - ref.float()).abs()
+    bound = rel * ref.float().abs() + abs_ * float(ref.float().abs().max())
+    bad = d > bound
+    if bool(bad.any()):
+        i = int(torch.argmax(d - bound))
+        raise AssertionError(f"{what}: {int(bad.sum())} of {d.numel()} elements outside 2^-7|ref| + 2^-8 max|ref| "
+                             f"(worst: |d| = {float(d.flatten()[i]):.4g}, ref = {float(ref.flatten()[i]):.4g}, "
+                             f"bound = {float(bound.flatten()[i]):.4g}, max|ref| = {float(ref.abs().max()):.4g})")
+
+
 def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
     return float((a - b).abs().max() / (b.abs().max() + 1e-12))
 

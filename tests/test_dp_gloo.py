@@ -55,6 +55,46 @@ def test_world2_gloo_sharding_and_gather():
     assert sorted(q.get(timeout=5) for _ in range(2)) == [0, 1]
 
 
+def _ragged_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from ultralytics_pro_amd.parallel import gather_ragged, init_distributed
+
+    init_distributed("gloo")
+    # rank 0: 3 images, gt width 4; rank 1: 2 images, one of them with 70 boxes (wider padding than rank 0's)
+    imgs, width = (3, 4) if rank == 0 else (2, 70)
+    gcls = torch.arange(imgs * width, dtype=torch.float32).view(imgs, width) + 1000 * rank
+    ngt = torch.tensor([1, 2, 3][:imgs] if rank == 0 else [70, 5], dtype=torch.int32)
+    g, n = gather_ragged(gcls, ngt)
+    assert g.shape == (5, 70) and n.tolist() == [1, 2, 3, 70, 5]
+    assert torch.equal(g[:3, :4], torch.arange(12, dtype=torch.float32).view(3, 4)) and float(g[:3, 4:].abs().sum()) == 0.0
+    assert torch.equal(g[3:], torch.arange(140, dtype=torch.float32).view(2, 70) + 1000)
+    # 3-D rows (the detection statistics) with uneven image counts only
+    rows = torch.full((imgs, 6, 12), float(rank + 1))
+    cnt = torch.full((imgs,), rank + 4, dtype=torch.int32)
+    gr, gc = gather_ragged(rows, cnt)
+    assert gr.shape == (5, 6, 12) and gc.tolist() == [4, 4, 4, 5, 5]
+    assert float(gr[:3].min()) == 1.0 and float(gr[3:].min()) == 2.0
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put(rank)
+
+
+def test_world2_gloo_ragged_gather_uneven_shards_and_gt_width():
+    """engine/validator.gather_stats: ranks with different image counts and different padded gt widths (an image with more
+    than max_gt boxes on one rank only) must still issue equal-shape collectives and get the same ordered result."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ragged_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(2)) == [0, 1]
+
+
 def _train_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))

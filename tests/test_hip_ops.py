@@ -55,19 +55,22 @@ def _pair(ocls, pcls, args, name, family="default"):
 @pytest.mark.parametrize("case", CONV_CASES, ids=[f"c{c[0]}-{c[1]}k{c[2]}s{c[3]}_{c[5]}x{c[6]}" for c in CONV_CASES])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_conv(case, dtype):
-    from tests.hip_utils import bf16_round, to_cpu_nchw, to_dev_nhwc, unit_input
+    from tests.hip_utils import assert_bf16_close, bf16_round, bf16_weight_oracle, to_cpu_nchw, to_dev_nhwc, unit_input
     pm, _ = _mods()
     c1, c2, k, s, p, H, W, N = case
     o, m = _pair(om.Conv, pm.Conv, (c1, c2, k, s, p), "conv")
     x = unit_input(f"conv{case}", (N, c1, H, W))
     if dtype == torch.bfloat16:
         x = bf16_round(x)
+        o = bf16_weight_oracle(o)
     with torch.no_grad():
         ref = o(x)
         y = to_cpu_nchw(m(to_dev_nhwc(x, dtype)))
     assert y.shape == ref.shape
-    tol = 2e-5 if dtype == torch.float32 else 3e-2
-    assert (y - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+    if dtype == torch.float32:
+        assert (y - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    else:  # bf16-rounded inputs AND weights on the oracle side: what is left is summation order + the output rounding
+        assert_bf16_close(y, ref, f"conv{case}")
 
 
 PIPE_CASES = [
@@ -90,7 +93,7 @@ PIPE_CASES = [
 def test_conv_pipe_kernel(case):
     """bf16 3x3 s1 convs through the persistent pipelined kernel vs the oracle Conv (conv.py:188-197) on bf16-rounded
     inputs; includes image borders (zero padding by the DMA zero page), partial k-tiles and split output-channel launches."""
-    from tests.hip_utils import bf16_round, to_cpu_nchw, to_dev_nhwc
+    from tests.hip_utils import assert_bf16_close, bf16_round, bf16_weight_oracle, to_cpu_nchw, to_dev_nhwc
     from ultralytics_pro_amd import _lib as L
     pm, _ = _mods()
     c1, c2, H, W, N = case
@@ -99,11 +102,9 @@ def test_conv_pipe_kernel(case):
     o, m = _pair(om.Conv, pm.Conv, (c1, c2, 3, 1), "conv_pipe")
     x = bf16_round(P.uniform(f"pipe{case}", (N, c1, H, W), -1, 1))
     with torch.no_grad():
-        ref = o(x)
+        ref = bf16_weight_oracle(o)(x)
         y = to_cpu_nchw(m(to_dev_nhwc(x, torch.bfloat16)))
-    assert y.shape == ref.shape
-    err = (y - ref).abs().max().item()
-    assert err <= 3e-2 * max(1.0, ref.abs().max().item()), err
+    assert_bf16_close(y, ref, f"conv_pipe{case}")
 
 
 BIG_CASES = [
@@ -132,7 +133,7 @@ def test_conv_big_kernel(case, act):
     """bf16 convs forced through conv_big_kernel (upa_conv_big_mode(2)) vs the oracle Conv (conv.py:188-197) on
     bf16-rounded inputs: image borders (zero page), tiles that are not powers of two, ragged last tiles, partial k-tiles and
     odd chunk counts, masked output-channel columns, pointwise layers, the fused residual add (block.py:668)."""
-    from tests.hip_utils import bf16_round, to_cpu_nchw, to_dev_nhwc
+    from tests.hip_utils import assert_bf16_close, bf16_round, bf16_weight_oracle, to_cpu_nchw, to_dev_nhwc
     from ultralytics_pro_amd import _lib as L
     pm, _ = _mods()
     c1, c2, k, H, W, N, res = case[:7]
@@ -145,13 +146,11 @@ def test_conv_big_kernel(case, act):
         x = bf16_round(P.uniform(f"big{case}", (N, c1, H, W), -1, 1))
         rsd = bf16_round(P.uniform(f"bigres{case}", (N, c2, (H - 1) // st + 1, (W - 1) // st + 1), -1, 1)) if res else None
         with torch.no_grad():
-            ref = o(x) + (rsd if res else 0)
+            ref = bf16_weight_oracle(o)(x) + (rsd if res else 0)
             y = to_cpu_nchw(m(to_dev_nhwc(x, torch.bfloat16), residual=to_dev_nhwc(rsd, torch.bfloat16) if res else None))
     finally:
         L.lib().upa_conv_big_mode(prev)
-    assert y.shape == ref.shape
-    err = (y - ref).abs().max().item()
-    assert err <= 3e-2 * max(1.0, ref.abs().max().item()), err
+    assert_bf16_close(y, ref, f"conv_big{case}")
 
 
 PAIR_CASES = [
@@ -173,15 +172,16 @@ def test_bottleneck_pair_kernel(case):
     to bf16 as the kernel stores it; then vs the product's own two-launch path (same weights), which it must match to bf16
     resolution.  Zero padding of the SECOND conv at the image border (mid pixels outside the image must be zero, not
     act(bias)), ragged tiles, strided input / output views (channel slices of a wider buffer as inside C2f)."""
-    from tests.hip_utils import DEV, bf16_round, to_cpu_nchw, to_dev_nhwc
+    from tests.hip_utils import DEV, assert_bf16_close, bf16_round, bf16_weight_oracle, to_cpu_nchw, to_dev_nhwc
     from ultralytics_pro_amd.engine import runtime as R
     pm, _ = _mods()
     c, H, W, N, sc = case
     o, m = _pair(om.Bottleneck, pm.Bottleneck, (c, c, sc, 1, (3, 3), 1.0), "pair")
     x = bf16_round(P.uniform(f"pair{case}", (N, c, H, W), -1, 1))
     with torch.no_grad():
-        t = bf16_round(o.cv1(x))
-        ref = o.cv2(t) + (x if sc else 0)
+        ob = bf16_weight_oracle(o)
+        t = bf16_round(ob.cv1(x))
+        ref = ob.cv2(t) + (x if sc else 0)
     # x and y are channel slices [c, 2c) and [2c, 3c) of one 3c-channel buffer, as C2f lays them out
     buf = R.alloc_nhwc(N, 3 * c, H, W, torch.bfloat16, DEV)
     buf.zero_()
@@ -208,7 +208,9 @@ def test_bottleneck_pair_kernel(case):
         y2 = to_cpu_nchw(m(xin))
     assert y.shape == ref.shape
     scale = max(1.0, ref.abs().max().item())
-    assert (y - ref).abs().max().item() <= 3e-2 * scale, (y - ref).abs().max().item()
+    # rounding points shared with the oracle (bf16 x, weights, mid tile); a mid value whose f32 sum lands within summation-order
+    # noise of a bf16 tie may round the other way and moves its 9 x C consumers by one mid ulp x weight: allowed for in `abs_`
+    assert_bf16_close(y, ref, f"pair{case}", abs_=2.0 ** -7)
     assert (y - y2).abs().max().item() <= 2e-2 * scale  # one bf16 ulp of the output
     assert float(to_cpu_nchw(buf[:, :c]).abs().max()) == 0.0  # nothing written outside the output slice
 
@@ -229,8 +231,9 @@ def test_conv1x1_virtual_upsample_concat(case):
     o, m = _pair(om.Conv, pm.Conv, (cu + cs, cout, 1, 1), "upcat")
     u = bf16_round(P.uniform(f"upcat_u{case}", (n, cu, h, w), -1, 1))
     sk = bf16_round(P.uniform(f"upcat_s{case}", (n, cs, 2 * h, 2 * w), -1, 1))
+    from tests.hip_utils import assert_bf16_close, bf16_weight_oracle
     with torch.no_grad():
-        ref = o(torch.cat([torch.nn.functional.interpolate(u, scale_factor=2, mode="nearest"), sk], 1))
+        ref = bf16_weight_oracle(o)(torch.cat([torch.nn.functional.interpolate(u, scale_factor=2, mode="nearest"), sk], 1))
         ud = to_dev_nhwc(u, torch.bfloat16)
         buf = R.alloc_nhwc(n, cu + cs, 2 * h, 2 * w, torch.bfloat16, DEV)
         buf.fill_(7.0)  # the leading channels must not be read on the fused path
@@ -242,7 +245,7 @@ def test_conv1x1_virtual_upsample_concat(case):
         up(ud, out=buf[:, :cu])
         y2 = to_cpu_nchw(m(buf))
     assert torch.equal(y, y2)
-    assert (y - ref).abs().max().item() <= 3e-2 * max(1.0, ref.abs().max().item())
+    assert_bf16_close(y, ref, f"upcat{case}")
 
 
 @pytest.mark.parametrize("case", [(192, True, (2, 37, 50)), (192, False, (2, 80, 80)), (64, False, (1, 14, 14)), (96, True, (3, 5, 9))],
@@ -252,11 +255,12 @@ def test_c2f_pair_cv2_kernel(case):
     (block.py:457-488, 644-668; yolov8n model.15 = C2f(192, 64, 1, shortcut=False)) vs the oracle C2f with the intermediates
     rounded to bf16 where the kernels round them, and vs the product's own path with the fusion switched off (cv1, pair kernel,
     cv2 as three launches).  Ragged tiles, maps smaller than a tile, with and without the shortcut, a strided output view."""
-    from tests.hip_utils import DEV, bf16_round, to_cpu_nchw, to_dev_nhwc
+    from tests.hip_utils import DEV, assert_bf16_close, bf16_round, bf16_weight_oracle, to_cpu_nchw, to_dev_nhwc
     from ultralytics_pro_amd.engine import runtime as R
     pm, _ = _mods()
     c1, sc, (N, H, W) = case
     o, m = _pair(om.C2f, pm.C2f, (c1, 64, 1, sc), f"c2f_paircv2{c1}")
+    o = bf16_weight_oracle(o)
     x = bf16_round(P.uniform(f"c2fpc{case}", (N, c1, H, W), -1.5, 1.5))
     with torch.no_grad():
         ys = list(bf16_round(o.cv1(x)).chunk(2, 1))
@@ -275,7 +279,7 @@ def test_c2f_pair_cv2_kernel(case):
         m.cv1(xd, out=cat[:, :64])
         assert m._pair_cv2(cat, None) is not None, "the fused form was not dispatched"
     scale = max(1.0, ref.abs().max().item())
-    assert (y - ref).abs().max().item() <= 3e-2 * scale, (y - ref).abs().max().item()
+    assert_bf16_close(y, ref, f"c2f_pair_cv2{case}", abs_=2.0 ** -7)  # (flipped ties of three bf16 intermediates: see the pair test)
     d = (y - y2).abs()
     assert d.max().item() <= 3e-2 * scale and (d > 1e-6).float().mean().item() <= 0.03, (d.max().item(), (d > 1e-6).float().mean().item())
     assert float(to_cpu_nchw(buf[:, :64]).abs().max()) == 0.0  # nothing written outside the output slice
@@ -336,6 +340,8 @@ def test_c2f_fused_kernel(case, th, monkeypatch):
     if th:
         monkeypatch.setenv("UPA_C2F32_TH", str(th))  # 16 x 16 or 10 x 16 output tiles (the host picks by workgroup rounds otherwise)
     o, m = _pair(om.C2f, pm.C2f, (c1, c1, nb, sc), f"c2f_fused{c1}{nb}")
+    from tests.hip_utils import assert_bf16_close, bf16_weight_oracle
+    o = bf16_weight_oracle(o)
     x = bf16_round(P.uniform(f"c2f{case}", (N, c1, H, W), -1.5, 1.5))
     with torch.no_grad():
         y01 = bf16_round(o.cv1(x))
@@ -353,7 +359,7 @@ def test_c2f_fused_kernel(case, th, monkeypatch):
         m.fuse_block = False
         y2 = to_cpu_nchw(m(xd))
     scale = max(1.0, ref.abs().max().item())
-    assert (y - ref).abs().max().item() <= 3e-2 * scale, (y - ref).abs().max().item()
+    assert_bf16_close(y, ref, f"c2f_fused{case}", abs_=2.0 ** -7)  # (flipped ties of up to six bf16 intermediates: see the pair test)
     # same rounding points as the separate launches; a bf16 tie that falls the other way in an intermediate moves few outputs
     # (measured: 0.02-0.03 % of the outputs differ with the shortcut, up to 1.4 % without it - nothing damps a flipped tie -; mean
     # |error| against the plain-f32 oracle equal to 5 digits, tools/experiments/c2f_err.py)
@@ -382,7 +388,7 @@ def test_conv1x1_stream_kernel(case, monkeypatch):
     """bf16 pointwise convs through the streaming kernel vs the oracle Conv (conv.py:188-197) on bf16-rounded inputs:
     ragged pixel counts, partial k-tiles, odd / split / masked output-channel tiles, every (MT, waves) shape of the
     kernel and few workgroups (many ring rounds per wave: the counted vmcnt waits)."""
-    from tests.hip_utils import bf16_round, to_cpu_nchw, to_dev_nhwc
+    from tests.hip_utils import assert_bf16_close, bf16_round, bf16_weight_oracle, to_cpu_nchw, to_dev_nhwc
     from ultralytics_pro_amd import _lib as L
     pm, _ = _mods()
     c1, c2, H, W, N, act, env = case
@@ -393,11 +399,9 @@ def test_conv1x1_stream_kernel(case, monkeypatch):
     o, m = _pair(om.Conv, pm.Conv, (c1, c2, 1, 1, None, 1, 1, act), "conv1x1")
     x = bf16_round(P.uniform(f"c1{case[:5]}", (N, c1, H, W), -1, 1))
     with torch.no_grad():
-        ref = o(x)
+        ref = bf16_weight_oracle(o)(x)
         y = to_cpu_nchw(m(to_dev_nhwc(x, torch.bfloat16)))
-    assert y.shape == ref.shape
-    err = (y - ref).abs().max().item()
-    assert err <= 3e-2 * max(1.0, ref.abs().max().item()), err
+    assert_bf16_close(y, ref, f"conv1x1{case[:5]}")
 
 
 def test_conv_pipe_residual_and_concat_views():
@@ -854,9 +858,10 @@ def test_fused_stem_and_second_conv_equals_the_two_layers(shape):
         two = to_cpu_nchw(m.model[1](m.model[0](xd)))
         o = ot.DetectionModel("yolov8n.yaml")
         P.apply_procedural_weights(o)
-        o.fuse()
-        ref = o.model[1](o.model[0](x))
+        from tests.hip_utils import assert_bf16_close, bf16_weight_oracle
+        l0, l1 = bf16_weight_oracle(o.model[0]), bf16_weight_oracle(o.model[1])
+        ref = l1(bf16_round(l0(x)))  # the stem tile is rounded to bf16 in LDS, as the separate layers round it in HBM
     assert fused.shape == two.shape == ref.shape
     scale = max(1.0, float(ref.abs().max()))
     assert float((fused - two).abs().max()) <= 2e-2 * scale
-    assert float((fused - ref).abs().max()) <= 3e-2 * scale
+    assert_bf16_close(fused, ref, f"fused_stem{shape}", abs_=2.0 ** -7)  # (flipped ties of the bf16 stem tile: see the pair test)

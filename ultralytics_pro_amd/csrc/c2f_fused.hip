@@ -43,7 +43,11 @@ constexpr int MH = TH + 2, MW = TW + 2;      // t tile 18 x 18
 constexpr int XPX = XH * XW, MPX = MH * MW;  // 400, 324
 constexpr int XITEMS = XPX * 4;              // 16-byte items of the x tile (a multiple of 64: whole waves)
 constexpr int XS_BYTES = XITEMS * 16;        // 25600
-constexpr int Y1_BYTES = XPX * 32;           // 12800
+// y1 tile: 32 B / px records with a pixel PITCH of 26 instead of 20.  Stage B enumerates its 18 x 18 pixels row-major in 16-pixel
+// m-tiles; an m-tile that straddles rows reads pixels whose indices collide mod 8 (= the same banks for ds_read_b128) unless the
+// row step is right for the width: upa_lds_pick_pitch(20, 18, 324, 1) = 26 (round 2 measured 48 % conflict cycles at pitch 20)
+constexpr int Y1P = 26;
+constexpr int Y1_BYTES = XH * Y1P * 32;      // 16640
 constexpr int MT_B = (MPX + 15) / 16;        // 21 m-tiles of t
 constexpr int TS_BYTES = MT_B * 16 * 32;     // 10752
 constexpr int LDS = XS_BYTES + Y1_BYTES + TS_BYTES;
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(NW * 64) void c2f16_fused_kernel(const C2fParams p)
     w_b[s] = tap < 9 ? *reinterpret_cast<const u32x4*>(p.wb + o) : u32x4{0u, 0u, 0u, 0u};
     const int tc = tap < 9 ? tap : 8;
     const int kh = tc / 3, kw = tc - kh * 3;
-    offB[s] = (kh * XW + kw) * 32 + (g & 1) * 16;  // into the y1 tile
+    offB[s] = (kh * Y1P + kw) * 32 + (g & 1) * 16;  // into the y1 tile
     offC[s] = (kh * MW + kw) * 32 + (g & 1) * 16;  // into the t tile
   }
   // cv2 as 16-wide k-steps: lane (g, r) of k-step ks, n-tile nt = W2[co = 16 nt + r][ci = 16 ks + 4g .. + 3]
@@ -138,16 +142,16 @@ __global__ __launch_bounds__(NW * 64) void c2f16_fused_kernel(const C2fParams p)
       const int q = mt * 16 + r;
       const u32x4 b = *reinterpret_cast<const u32x4*>(xs + q * 64 + g * 16);
       const f32x4 acc = mfma32(w_y1, b, bias_y1);
+      const int hy = (int)__umulhi((unsigned)q, 0x0CCCCCCDu), hx = q - hy * XW;  // q / 20 (exact for q < 2^17)
       bool in = true;
       if constexpr (MASKED) {
-        const int hy = q / XW, hx = q - hy * XW;
         const int iy = oy0 - 2 + hy, ix = ox0 - 2 + hx;
         in = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
       }
       float v[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = in ? silu(acc[e]) : 0.f;
-      *reinterpret_cast<u32x2*>(y1s + q * 32 + g * 8) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+      *reinterpret_cast<u32x2*>(y1s + (hy * Y1P + hx) * 32 + g * 8) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
     }
     __syncthreads();
 
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(NW * 64) void c2f16_fused_kernel(const C2fParams p)
       const int q = mt * 16 + r;
       const int qc = q < MPX ? q : MPX - 1;
       const int ty = qc / MW, tx = qc - ty * MW;
-      const char* base = y1s + (ty * XW + tx) * 32;
+      const char* base = y1s + (ty * Y1P + tx) * 32;
       f32x4 acc = bias_a;
 #pragma unroll
       for (int s = 0; s < 5; ++s) acc = mfma32(w_a[s], *reinterpret_cast<const u32x4*>(base + offB[s]), acc);
@@ -183,8 +187,8 @@ __global__ __launch_bounds__(NW * 64) void c2f16_fused_kernel(const C2fParams p)
     f32x4 acc = bias_b;
 #pragma unroll
     for (int s = 0; s < 5; ++s) acc = mfma32(w_b[s], *reinterpret_cast<const u32x4*>(base + offC[s]), acc);
-    const int cpx = (i + 2) * XW + r + 2;  // this pixel in the halo tiles
-    const u32x2 y1c = *reinterpret_cast<const u32x2*>(y1s + cpx * 32 + g * 8);
+    const int cpx = (i + 2) * XW + r + 2;  // this pixel in the x halo tile
+    const u32x2 y1c = *reinterpret_cast<const u32x2*>(y1s + ((i + 2) * Y1P + r + 2) * 32 + g * 8);
     const float bv0 = silu(acc[0]) + __uint_as_float(y1c[0] << 16);
     const float bv1 = silu(acc[1]) + __uint_as_float(y1c[0] & 0xFFFF0000u);
     const float bv2 = silu(acc[2]) + __uint_as_float(y1c[1] << 16);
@@ -247,9 +251,14 @@ using c2f::silu;
 constexpr int T = 16;
 constexpr int NW = 16;  // waves per workgroup
 __device__ __forceinline__ int swz64(int px) { return (px >> 1) & 3; }  // 64-byte pixel records: 4 groups of 16 B
+// (An m-tile of a 3x3 stage that straddles two rows of its (pitch - 2)-wide output reads pixel indices that collide mod 8: with
+// 64-byte records and four slots no swizzle of (pixel, row) removes that - searched exhaustively, tools/experiments/lds_swizzle_search.py -
+// only a padded pitch does (upa_lds_pick_pitch: 30 / 28 / 26 for the 22 / 20 / 18-wide stages), which the 153 KB of tiles leave
+// no room for.  PMC: 34 % of this kernel's LDS cycles are conflict cycles; it is VALU-bound on SiLU, not LDS-bound.)
 
 // address of the 8 bytes holding channels 16j + 4g .. + 3 of pixel px in a 64 B / px tile
 __device__ __forceinline__ int quad_addr(int px, int j, int g) { return px * 64 + (((2 * j + (g >> 1)) ^ swz64(px)) << 4) + (g & 1) * 8; }
+
 
 // the nine A fragments (one per tap) of n-tile j of a 3x3 conv 32 -> 32: packed [tap][1 k-tile][2 n-tiles][lane][16 B]
 __device__ __forceinline__ void load_w9(u32x4 (&w)[9], const char* src, int j, int lane) {

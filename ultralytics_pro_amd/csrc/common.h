@@ -90,5 +90,39 @@ inline void upa_zero_words(void* p, int n_words, hipStream_t s) {
   hipLaunchKernelGGL(upa_zero_words_kernel, dim3((n_words + 255) / 256), dim3(256), 0, s, (unsigned*)p, n_words);
 }
 
+// ---- LDS pixel pitch of a [pixel][64 | 128 B] image whose 16-byte groups are XOR-swizzled by the pixel index and read back as
+// MFMA B fragments (ds_read_b128: lane (g, r) reads group g of the r-th pixel of a 16-pixel m-tile; m-tiles enumerate a W-wide
+// tile row-major, so one may straddle two or three image rows).  The hardware serves a ds_read_b128 in four groups of 16 lanes
+// - rows {0..3, 12..15} of one g with rows {4..11} of its neighbour - and with the swizzles used here (conv_big / conv_pair /
+// c2f_fused) a group is conflict-free exactly when the 8 pixel indices of each row set are distinct mod 8.  Consecutive pixels
+// always are; a straddling m-tile is when the image's row step is right for the tile width (W = 40: step = 0 mod 8; W = 20: 4
+// mod 8).  These helpers count the extra LDS cycles of one tap over a tile and pick the smallest pitch >= min_pitch with the
+// fewest (0 for every tile width the dispatchers use).  row_mult: image rows between consecutive tile rows (the conv stride).
+static inline int upa_lds_conflict_cycles(int W, int npix, int row_step) {
+  int extra = 0;
+  for (int m0 = 0; m0 < npix; m0 += 16) {
+    for (int set = 0; set < 2; ++set) {
+      int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, worst = 1;
+      for (int r = 0; r < 16; ++r) {
+        if ((set == 0) != (r < 4 || r >= 12)) continue;
+        const int pp = m0 + r;
+        if (pp >= npix) continue;
+        const int q = ((pp / W) * row_step + pp % W) & 7;
+        if (++cnt[q] > worst) worst = cnt[q];
+      }
+      extra += worst - 1;
+    }
+  }
+  return extra;
+}
+static inline int upa_lds_pick_pitch(int min_pitch, int W, int npix, int row_mult) {
+  int best = min_pitch, best_cost = 1 << 30;
+  for (int P = min_pitch; P < min_pitch + 8; ++P) {
+    const int c = upa_lds_conflict_cycles(W, npix, (P * row_mult) & 7);
+    if (c < best_cost) { best_cost = c; best = P; }
+  }
+  return best;
+}
+
 static inline int upa_elem_size(int dtype) { return dtype == UPA_BF16 ? 2 : 4; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

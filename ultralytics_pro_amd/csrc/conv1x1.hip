@@ -149,14 +149,18 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_stream_kernel(const C1Para
         f32x4 v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = acc[i][j] + biasv[j];
-        upa_detect_box_store(p.de, v, pix < p.P ? pix : p.P - 1, pok, kg);
+        int db, da;
+        upa_detect_split(p.de, pix < p.P ? pix : p.P - 1, db, da);
+        upa_detect_box_store(p.de, v, db, da, pok, kg);
         ++seq;
       } else if constexpr (EPI == 2) {  // Detect class branch: sigmoid, channel-major f32 rows
+        int db, da;
+        upa_detect_split(p.de, pix < p.P ? pix : p.P - 1, db, da);
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
           float best_ = -1.f;
           int bc_ = 0;  // (the NMS key array is produced by the conv_big tail only)
-          upa_detect_cls_store(p.de, acc[i][j] + biasv[j], j, pix < p.P ? pix : p.P - 1, pok, kg, best_, bc_);
+          upa_detect_cls_store(p.de, acc[i][j] + biasv[j], j, db, da, pok, kg, best_, bc_);
           seq += 16 * j + 3 < p.de.nc ? 4 : 0;  // only stores that lane row 0 certainly issues are counted (the count may
                                                // only be too small: a wait for more than needed is always safe)
           if (16 * j + 3 >= p.de.nc)
@@ -383,7 +387,9 @@ extern "C" int upa_detect_tail(const void* x, int n, int h, int w, int cin, int 
   UPA_CHECK_ARG(x && w_packed && y, "detect_tail: null pointer");
   UPA_CHECK_ARG(kind == 1 || kind == 2, "detect_tail: kind must be 1 (box) or 2 (class)");
   UPA_CHECK_ARG(n > 0 && h > 0 && w > 0 && a0 >= 0 && a0 + h * w <= a_total, "detect_tail: level does not fit a_total");
+  // (the flat pixel -> (image, anchor) split of detect_epi.h must be exact up to the last pixel)
   if (dtype != UPA_BF16 || h * w < 2 || w < 2 || (kind == 1 && cout != 64) || (kind == 2 && (cout < nc || cout > 128)) ||
+      !upa_magic_exact((long)n * h * w - 1, h * w) || !upa_magic_exact((long)h * w - 1, w) ||
       !upa_conv1x1_eligible(n, h, w, cin, ldx, cout, raw ? ldraw : cout, false, 1, 1, 0, UPA_ACT_NONE, dtype)) {
     upa_set_error("detect_tail: shape / dtype outside the fused form (bf16, reg_max 16, nc <= 128)");
     return UPA_EUNSUPPORTED;  // the caller runs the conv and upa_detect_decode separately
@@ -410,7 +416,8 @@ extern "C" int upa_conv1x1_upcat(const void* x, int n, int h, int w, int cin, in
   UPA_CHECK_ARG(x && up && w_packed && y && n > 0 && h > 0 && w > 0, "conv1x1_upcat: bad args");
   static const bool off = getenv("UPA_NO_UPCAT") != nullptr;
   if (off || (h & 1) || (w & 1) || up_c <= 0 || up_c % 32 != 0 || up_c >= cin || up_ld % 8 != 0 || ((uintptr_t)up % 16) != 0 ||
-      (long)n * (h / 2) * (w / 2) * up_ld * 2 >= (1L << 31) - 4096 ||
+      (long)n * (h / 2) * (w / 2) * up_ld * 2 >= (1L << 31) - 4096 || !upa_magic_exact((long)n * h * w - 1, w) ||
+      !upa_magic_exact((long)n * h - 1, h) ||
       !upa_conv1x1_eligible(n, h, w, cin, ldx, cout, ldy, false, 1, 1, 0, act, dtype)) {
     upa_set_error("conv1x1_upcat: outside the fused form (bf16 streaming 1x1, even h / w, up_c %% 32 == 0)");
     return UPA_EUNSUPPORTED;

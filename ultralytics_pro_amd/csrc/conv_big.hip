@@ -8,8 +8,11 @@
 // that saturates the CU's 64 B/clk vector-memory path and the kernel sits at 14-17 % of the MFMA peak.  Here a workgroup of
 // 8 waves (2 per SIMD) owns BM = 256 (or 128) output pixels x NTB * 16 output channels:
 //   * B (pixels): the halo tile of a 64-channel chunk, ((TH-1)s+k) x ((TW-1)s+k) pixels x 128 B, staged once per chunk by
-//     LDS-DMA (global_load_lds_dwordx4, zero page outside the image / past Cin), XOR-swizzled so ds_read_b128 is
-//     conflict-free; every tap reads it at a shifted pixel offset;
+//     LDS-DMA (global_load_lds_dwordx4, zero page outside the image / past Cin), XOR-swizzled by the pixel index; every tap
+//     reads it at a shifted pixel offset.  The image's pixel pitch IWp is chosen on the host (upa_lds_pick_pitch) so that
+//     m-tiles that straddle tile rows (TW = 20, 40: not powers of two) still read 8 distinct pixel residues per lane set =
+//     conflict-free ds_read_b128; at stride 2 the columns are stored de-interleaved (even | odd) so that the pixels of an
+//     m-tile are consecutive again instead of every other one (which used half the banks: 45 % conflict cycles in round 2);
 //   * A (weights): the slab of one (tap, chunk) - 2 k-tiles x NTB n-tiles of 1 KiB in exact fragment order - DMA'd into one
 //     of two LDS buffers while the previous tap is multiplied: coalesced 1 KiB wave-instructions, once per WORKGROUP,
 //     i.e. 64 B of weight traffic per MFMA instead of 128-256 B;
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(512, 4) void conv_big_kernel(const BigParams p) {
   const int iy0 = oy0 * STRIDE - p.pad, ix0 = ox0 * STRIDE - p.pad;
   const int ntb0 = blockIdx.y * NTB;  // first n-tile of the workgroup
 
-  const int haloItems = p.IH * p.IW * 8;  // 16-byte items: 8 per pixel (64 channels)
+  const int haloItems = p.IH * p.IWp * 8;  // 16-byte items: 8 per pixel (64 channels)
   const int haloPadded = (haloItems + 63) & ~63;
   char* hal = smem;
   char* wbuf = smem + (size_t)haloPadded * 16;
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(512, 4) void conv_big_kernel(const BigParams p) {
     if (ty >= p.TH) { ty = p.TH; tx = 0; }  // past the tile (TH * TW < BM): multiplied on halo pixel 0, never stored
     pty[i] = ty;
     ptx[i] = tx;
-    pl0[i] = ty < p.TH ? (ty * STRIDE) * p.IW + tx * STRIDE : 0;
+    pl0[i] = ty < p.TH ? (ty * STRIDE) * p.IWp + tx : 0;  // (stride 2: column 2 tx of the de-interleaved image is slot tx)
   }
 
   f32x4 acc[MT][NT];
@@ -107,11 +110,13 @@ __global__ __launch_bounds__(512, 4) void conv_big_kernel(const BigParams p) {
       const int slot = idx & 7;
       const int cg = slot ^ (pix & 7);
       const int py = (int)__umulhi((unsigned)pix, p.magicIW);
-      const int px = pix - py * p.IW;
+      const int qx = pix - py * p.IWp;  // column slot of the LDS image
+      int px = qx;                      // halo column it holds
+      if constexpr (STRIDE == 2) px = qx < p.HALF ? 2 * qx : 2 * (qx - p.HALF) + 1;
       const int iy = iy0 + py, ix = ix0 + px;
       const int ch = c0 + cg * 8;
       const char* src = reinterpret_cast<const char*>(g_big_zero16);
-      if (idx < haloItems && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && ch < p.Cin)
+      if (idx < haloItems && px < p.IW && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && ch < p.Cin)
         src = p.x + ((((size_t)n * p.H + iy) * p.W + ix) * (size_t)p.ldx + ch) * 2;
       __builtin_amdgcn_global_load_lds((bgptr_t)src, (blptr_t)(hal + base * 16), 16, 0, 0);
     }
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(512, 4) void conv_big_kernel(const BigParams p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of slab (c, tap) (and of the halo) has landed
       __syncthreads();                                  // ... everyone's; everyone is done with the other weight buffer
       if (tap + 1 < TAPS) stage_w(c, tap + 1, buf ^ 1);
-      const int tapshift = kh * p.IW + kw;
+      const int tapshift = kh * p.IWp + (STRIDE == 2 ? (kw >> 1) + (kw & 1) * p.HALF : kw);
       const char* wb = wbuf + buf * WBUF + (wn * NT) * 1024 + lane * 16;
       int paddr[MT], pswz[MT];
 #pragma unroll
@@ -247,19 +252,19 @@ __global__ __launch_bounds__(512, 4) void conv_big_kernel(const BigParams p) {
     for (int i = 0; i < MT; ++i) {
       const int oy = oy0 + pty[i], ox = ox0 + ptx[i];
       const bool pok = pty[i] < p.TH && oy < p.OH && ox < p.OW;
-      const int pix = pok ? (n * p.OH + oy) * p.OW + ox : 0;
+      const int al = pok ? oy * p.OW + ox : 0;  // level-local anchor; the image index n comes with the tile (no division)
       if constexpr (TAIL == 1) {
         static_assert(TAIL != 1 || NT == 4, "box branch = 4 sides x 16 bins");
         f32x4 v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = acc2[i][j] + tbv[j];
-        upa_detect_box_store(p.de, v, pix, pok, g);
+        upa_detect_box_store(p.de, v, n, al, pok, g);
       } else {
         float best = -1.f;
         int bc = 0;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) upa_detect_cls_store(p.de, acc2[i][j] + tbv[j], j, pix, pok, g, best, bc);
-        if (p.de.best_keys) upa_detect_best_key_store(p.de, best, bc, pix, pok, lane);  // uniform
+        for (int j = 0; j < NT; ++j) upa_detect_cls_store(p.de, acc2[i][j] + tbv[j], j, n, al, pok, g, best, bc);
+        if (p.de.best_keys) upa_detect_best_key_store(p.de, best, bc, n, al, pok, lane);  // uniform
       }
     }
     return;
@@ -360,19 +365,51 @@ int big_num_cu() {
 
 // Tile shape for a BM-pixel workgroup: fewest tiles per image first (least padding waste), then the smallest halo; the
 // halo of a 64-channel chunk plus the two weight buffers must fit `lds_cap` bytes.  Returns false if nothing fits.
+// LDS geometry of the halo image for a TH x TW tile: valid size IH x IW, column slots (stride 2: de-interleaved halves of
+// HALF), pixel pitch IWp = the conflict-free one (upa_lds_pick_pitch) or, with `tight`, the smallest.
+void big_halo_geometry(BigParams& p, bool tight = false) {
+  p.IH = (p.TH - 1) * p.stride + p.KS;
+  p.IW = (p.TW - 1) * p.stride + p.KS;
+  p.HALF = p.stride == 2 ? (p.IW + 1) / 2 : 0;
+  const int minp = p.stride == 2 ? 2 * p.HALF : p.IW;
+  p.IWp = tight ? minp : upa_lds_pick_pitch(minp, p.TW, p.TH * p.TW, p.stride);
+  p.magicTW = (unsigned)((0x100000000ULL + p.TW - 1) / p.TW);
+  p.magicIW = (unsigned)((0x100000000ULL + p.IWp - 1) / p.IWp);
+}
+size_t big_halo_bytes(const BigParams& p) { return (((size_t)p.IH * p.IWp * 8 + 63) & ~(size_t)63) * 16; }
+
+// Tile shape for a BM-pixel workgroup: fewest tiles per image first (least padding waste), then the smallest halo; the
+// halo of a 64-channel chunk plus the two weight buffers must fit `lds_cap` bytes.  Tile heights tried per width: all the
+// rows BM allows, and that many rows spread evenly over the tiles of a column (80 rows at 25 per tile = 4 tiles -> 20 rows each:
+// same tile count, smaller halo, equal workgroups).  The conflict-free halo pitch is taken when it fits the cap, the tight one
+// otherwise (occupancy first: measured in round 3, removing every bank conflict of the 64-column family changed its time by
+// less than the run-to-run noise).  Returns false if nothing fits.
 bool big_pick_tile(BigParams& p, int bm, int ntb, size_t lds_cap) {
   long best = -1;
+  int bth = 0, btw = 0;
+  bool btight = false;
   for (int tw = 2; tw <= 256 && tw <= ((p.OW + 1) & ~1); ++tw) {
-    int th = bm / tw;
-    if (th > p.OH) th = p.OH;
-    if (th < 1) continue;
-    const int ih = (th - 1) * p.stride + p.KS, iw = (tw - 1) * p.stride + p.KS;
-    const size_t lds = (((size_t)ih * iw * 8 + 63) & ~(size_t)63) * 16 + 2 * (size_t)(2 * ntb * 1024) + 256;
-    if (lds > lds_cap) continue;
-    const long tiles = (long)cdiv(p.OW, tw) * cdiv(p.OH, th);
-    const long cost = tiles * 65536 + (long)ih * iw;
-    if (best < 0 || cost < best) { best = cost; p.TH = th; p.TW = tw; }
+    int th0 = bm / tw;
+    if (th0 > p.OH) th0 = p.OH;
+    if (th0 < 1) continue;
+    const int thb = cdiv(p.OH, cdiv(p.OH, th0));  // balanced rows
+    for (int pass = 0; pass < 2; ++pass) {
+      const int th = pass ? thb : th0;
+      if (pass && thb == th0) break;
+      for (int tight = 0; tight < 2; ++tight) {
+        p.TH = th; p.TW = tw;
+        big_halo_geometry(p, tight != 0);
+        const size_t lds = big_halo_bytes(p) + 2 * (size_t)(2 * ntb * 1024) + 256;
+        if (lds > lds_cap) continue;
+        const long tiles = (long)cdiv(p.OW, tw) * cdiv(p.OH, th);
+        const long cost = tiles * 65536 + (long)p.IH * p.IWp;
+        if (best < 0 || cost < best) { best = cost; bth = th; btw = tw; btight = tight != 0; }
+        break;  // the conflict-free pitch fits: no need for the tight one
+      }
+    }
   }
+  p.TH = bth; p.TW = btw;
+  if (best >= 0) big_halo_geometry(p, btight);
   return best >= 0;
 }
 
@@ -445,7 +482,7 @@ extern "C" int upa_detect_branch_tail(const void* x, int n, int h, int w, int c,
   static const int off = big_env("UPA_NO_BRANCH_TAIL", 0);
   const int ntb = kind == 1 ? 4 : (c == 80 ? 5 : 6);  // 80 class-branch channels (nc = 80 models): 5 tiles, no padded sixth
   if (off || dtype != UPA_BF16 || c % 8 != 0 || ldx % 8 != 0 || h * w < 2 || w < 2 || (kind == 1 && c != 64) ||
-      (kind == 2 && (c > 96 || nc > ntb * 16)) || ((uintptr_t)x % 16) != 0) {
+      (kind == 2 && (c > 96 || nc > ntb * 16)) || ((uintptr_t)x % 16) != 0 || !upa_magic_exact((long)h * w - 1, w)) {
     upa_set_error("detect_branch_tail: outside the fused form (bf16; box c = 64; class c <= 96, nc <= 96)");
     return UPA_EUNSUPPORTED;
   }
@@ -466,11 +503,7 @@ extern "C" int upa_detect_branch_tail(const void* x, int n, int h, int w, int c,
   if (!big_pick_tile(p, bm, ntb, 80 * 1024 - 512) && !big_pick_tile(p, bm, ntb, 160 * 1024)) return UPA_EUNSUPPORTED;
   p.tilesX = cdiv(p.OW, p.TW);
   p.tilesY = cdiv(p.OH, p.TH);
-  p.IH = p.TH + 2; p.IW = p.TW + 2;
-  p.magicTW = (unsigned)((0x100000000ULL + p.TW - 1) / p.TW);
-  p.magicIW = (unsigned)((0x100000000ULL + p.IW - 1) / p.IW);
-  const size_t halo = (((size_t)p.IH * p.IW * 8 + 63) & ~(size_t)63) * 16;
-  const size_t lds = halo + 2 * (size_t)(2 * ntb * 1024) + 256;
+  const size_t lds = big_halo_bytes(p) + 2 * (size_t)(2 * ntb * 1024) + 256;
   hipStream_t s = (hipStream_t)stream;
   if (kind == 1) return bm == 256 ? big_launch_inst<3, 1, 8, 1, 2, 4, 1>(p, lds, s) : big_launch_inst<3, 1, 8, 1, 1, 4, 1>(p, lds, s);
   if (ntb == 5) return bm == 256 ? big_launch_inst<3, 1, 8, 1, 2, 5, 2>(p, lds, s) : big_launch_inst<3, 1, 8, 1, 1, 5, 2>(p, lds, s);
@@ -534,26 +567,23 @@ int upa_conv_big_launch(BigParams p, int query_only, int* variant, void* stream)
   // 256-pixel workgroups unless that leaves most of the chip idle (fewer workgroups than CUs): then 128-pixel ones
   int bm = 256;
   if ((px + 255) / 256 * cols < big_num_cu()) bm = 128;
-  if (const int f = big_env("UPA_CONV_BIG_BM", 0); f == 128 || f == 256) bm = f;
-  if (variant) *variant = (1 << 23) | (ntb << 4) | (bm >> 7);
+  if (const int f = big_env("UPA_CONV_BIG_BM", 0); f == 128 || f == 256 || (f == 512 && p.KS == 3 && p.stride == 1 && (ntb == 4 || ntb == 5))) bm = f;
+  if (variant) *variant = (1 << 23) | (ntb << 4) | (bm >> 7);  // (bm >> 7: 1 = 128, 2 = 256, 4 = 512 pixels)
   if (query_only) return UPA_OK;
   if (p.KS == 1) {  // pointwise: an NHWC view has one uniform pixel stride - flatten (n, h, w) into one row
     p.N = 1; p.H = 1; p.W = (int)px; p.OH = 1; p.OW = (int)px;
     p.TH = 1; p.TW = bm;
+    big_halo_geometry(p, true);
   } else if (!big_pick_tile(p, bm, ntb, 80 * 1024 - 512) && !big_pick_tile(p, bm, ntb, 160 * 1024)) {
     // (first try: two workgroups per CU; stride-2 halos may need the whole LDS)
     return UPA_EUNSUPPORTED;
   }
   p.tilesX = cdiv(p.OW, p.TW);
   p.tilesY = cdiv(p.OH, p.TH);
-  p.IH = (p.TH - 1) * p.stride + p.KS;
-  p.IW = (p.TW - 1) * p.stride + p.KS;
-  p.magicTW = (unsigned)((0x100000000ULL + p.TW - 1) / p.TW);
-  p.magicIW = (unsigned)((0x100000000ULL + p.IW - 1) / p.IW);
-  const size_t halo = (((size_t)p.IH * p.IW * 8 + 63) & ~(size_t)63) * 16;
-  const size_t lds = halo + 2 * (size_t)(2 * ntb * 1024) + 256;
+  const size_t lds = big_halo_bytes(p) + 2 * (size_t)(2 * ntb * 1024) + 256;
   if (lds > 160 * 1024) return UPA_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
+  if (bm == 512) return ntb == 5 ? big_launch_inst<3, 1, 8, 1, 4, 5>(p, lds, s) : big_launch_inst<3, 1, 8, 1, 4, 4>(p, lds, s);
   if (ntb == 5) return bm == 256 ? big_launch_inst<3, 1, 8, 1, 2, 5>(p, lds, s) : big_launch_inst<3, 1, 8, 1, 1, 5>(p, lds, s);
   if (ntb == 8) return bm == 256 ? big_launch_ks<4, 2, 4, 4>(p, lds, s) : big_launch_ks<4, 2, 2, 4>(p, lds, s);
   if (ntb == 6) return bm == 256 ? big_launch_ks<4, 2, 4, 3>(p, lds, s) : big_launch_ks<4, 2, 2, 3>(p, lds, s);

@@ -60,12 +60,13 @@ __global__ __launch_bounds__(512, 4) void conv_pair_kernel(const PairParams p) {
   const int txi = bid - tyi * p.tilesX;
   const int oy0 = tyi * p.TH, ox0 = txi * p.TW;
   const int IH = p.TH + 4, IW = p.TW + 4, MH = p.TH + 2, MW = p.TW + 2;
+  const int IWp = p.IWp, MWp = p.MWp;  // LDS pitches (>= IW, MW): chosen so that m-tiles straddling tile rows stay conflict-free
 
   auto swz = [](int pix) __attribute__((always_inline)) { return (CK == 1 ? (pix >> 1) : pix) & (G16 - 1); };
 
-  const int haloItems = IH * IW * G16;
+  const int haloItems = IH * IWp * G16;
   const int haloPadded = (haloItems + 63) & ~63;
-  const int midBytes = ((MH * MW * PB) + 1023) & ~1023;
+  const int midBytes = ((MH * MWp * PB) + 1023) & ~1023;
   char* hal = smem;
   char* mid = smem + (size_t)haloPadded * 16;
   char* wbuf = mid + midBytes;
@@ -77,10 +78,10 @@ __global__ __launch_bounds__(512, 4) void conv_pair_kernel(const PairParams p) {
     const int slot = idx & (G16 - 1);
     const int cg = slot ^ swz(pix);
     const int py = (int)__umulhi((unsigned)pix, p.magicIW);
-    const int px = pix - py * IW;
+    const int px = pix - py * IWp;
     const int iy = oy0 - 2 + py, ix = ox0 - 2 + px;
     const char* src = reinterpret_cast<const char*>(g_pair_zero16);
-    if (idx < haloItems && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+    if (idx < haloItems && px < IW && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
       src = p.x + ((((size_t)n * p.H + iy) * p.W + ix) * (size_t)p.ldx + cg * 8) * 2;
     __builtin_amdgcn_global_load_lds((pgptr_t)src, (plptr_t)(hal + base * 16), 16, 0, 0);
   }
@@ -149,10 +150,10 @@ __global__ __launch_bounds__(512, 4) void conv_pair_kernel(const PairParams p) {
     if (y_ >= MH) { y_ = MH; x_ = 0; }
     my[i] = y_;
     mx[i] = x_;
-    pl1[i] = y_ < MH ? y_ * IW + x_ : 0;
+    pl1[i] = y_ < MH ? y_ * IWp + x_ : 0;
   }
   int buf = 0;
-  conv_stage(hal, IW, pl1, p.w1, p.w2, buf);
+  conv_stage(hal, IWp, pl1, p.w1, p.w2, buf);
   {
     f32x4 bv[NT];
 #pragma unroll
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(512, 4) void conv_pair_kernel(const PairParams p) {
       if (my[i] >= MH) continue;
       const int gy = oy0 - 1 + my[i], gx = ox0 - 1 + mx[i];
       const bool inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-      const int mp = my[i] * MW + mx[i];
+      const int mp = my[i] * MWp + mx[i];
       char* row = mid + mp * PB;
       const int sw = swz(mp);
 #pragma unroll
@@ -188,9 +189,9 @@ __global__ __launch_bounds__(512, 4) void conv_pair_kernel(const PairParams p) {
     if (y_ >= p.TH) { y_ = p.TH; x_ = 0; }
     ty[i] = y_;
     tx[i] = x_;
-    pl2[i] = y_ < p.TH ? y_ * MW + x_ : 0;
+    pl2[i] = y_ < p.TH ? y_ * MWp + x_ : 0;
   }
-  conv_stage(mid, MW, pl2, p.w2, nullptr, buf);
+  conv_stage(mid, MWp, pl2, p.w2, nullptr, buf);
 
   f32x4 bv[NT];
 #pragma unroll
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(512, 4) void conv_pair_kernel(const PairParams p) {
       const int oy = oy0 + ty[i], ox = ox0 + tx[i];
       const bool pok = ty[i] < p.TH && oy < p.OH && ox < p.OW;
       const size_t pixoff = ((size_t)n * p.OH + (pok ? oy : 0)) * p.OW + (pok ? ox : 0);
-      const int hp = ty[i] < p.TH ? (ty[i] + 2) * IW + tx[i] + 2 : 0;  // this output pixel in the input halo
+      const int hp = ty[i] < p.TH ? (ty[i] + 2) * IWp + tx[i] + 2 : 0;  // this output pixel in the input halo
       // b = SiLU(conv2 + b2) (+ y1): two 16-channel tiles -> one B operand (k order of upa_pack_tail_weight)
       float v0[4], v1[4];
 #pragma unroll
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(512, 4) void conv_pair_kernel(const PairParams p) {
     const int oy = oy0 + ty[i], ox = ox0 + tx[i];
     const bool pok = ty[i] < p.TH && oy < p.OH && ox < p.OW;
     char* yrow = p.y + (((size_t)n * p.OH + oy) * p.OW + ox) * (size_t)p.ldy * 2;
-    const int hp = (ty[i] + 2) * IW + tx[i] + 2;  // this output pixel in the input halo (residual)
+    const int hp = (ty[i] + 2) * IWp + tx[i] + 2;  // this output pixel in the input halo (residual)
     const char* xrow = hal + (ty[i] < p.TH ? hp : 0) * PB;
     const int xsw = swz(ty[i] < p.TH ? hp : 0);
 #pragma unroll
@@ -360,11 +361,14 @@ static int pair_impl(const void* x, int n, int h, int w, int c, int ldx, const v
   p.tilesX = cdiv(w, p.TW);
   p.tilesY = cdiv(h, p.TH);
   const int IH = p.TH + 4, IW = p.TW + 4, MH = p.TH + 2, MW = p.TW + 2;
-  p.magicIW = (unsigned)((0x100000000ULL + IW - 1) / IW);
+  // pitches: stage 1 enumerates the MH x MW mid pixels over the halo image, stage 2 the TH x TW outputs over the mid tile
+  p.IWp = upa_lds_pick_pitch(IW, MW, MH * MW, 1);
+  p.MWp = upa_lds_pick_pitch(MW, p.TW, p.TH * p.TW, 1);
+  p.magicIW = (unsigned)((0x100000000ULL + p.IWp - 1) / p.IWp);
   p.magicMW = (unsigned)((0x100000000ULL + MW - 1) / MW);
   p.magicTW = (unsigned)((0x100000000ULL + p.TW - 1) / p.TW);
-  const size_t halo = (((size_t)IH * IW * (ck * 4) + 63) & ~(size_t)63) * 16;
-  const size_t mid = (((size_t)MH * MW * pb) + 1023) & ~(size_t)1023;
+  const size_t halo = (((size_t)IH * p.IWp * (ck * 4) + 63) & ~(size_t)63) * 16;
+  const size_t mid = (((size_t)MH * p.MWp * pb) + 1023) & ~(size_t)1023;
   const size_t lds = halo + mid + 2 * (size_t)(ck * ck * 2 * 1024) + 256;
   if (lds > 160 * 1024) return UPA_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;

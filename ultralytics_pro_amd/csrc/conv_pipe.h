@@ -53,9 +53,11 @@ struct BigParams {
   int N, H, W, Cin, ldx, OH, OW, Cout, ldy, ldr;
   int KS, stride, pad;
   int TH, TW, tilesX, tilesY, IH, IW;
+  int IWp;             // LDS pixel pitch of the halo image (>= IW, or >= 2 * HALF at stride 2): upa_lds_pick_pitch
+  int HALF;            // stride 2: the halo columns are stored de-interleaved, even columns at [0, HALF), odd at [HALF, 2 HALF)
   int KTT, NTn;
   int act;
-  unsigned magicTW, magicIW;
+  unsigned magicTW, magicIW;   // magicIW divides by IWp
   const char* tw;      // Detect branch tail: final 1x1 conv packed by upa_pack_tail_weight
   const float* tb;     // ... its bias (zero-padded to 16 * n-tiles)
   DetectEpi de;        // ... and the decode it feeds (detect_epi.h)
@@ -75,7 +77,8 @@ struct PairParams {
   const float* b2;
   int N, H, W, OH, OW, ldx, ldy;
   int TH, TW, tilesX, tilesY;
-  unsigned magicIW, magicMW, magicTW;
+  int IWp, MWp;        // LDS pixel pitches of the input halo (>= TW + 4) and of the mid tile (>= TW + 2): upa_lds_pick_pitch
+  unsigned magicIW, magicMW, magicTW;  // divide by IWp (halo staging), TW + 2 (mid pixel slots), TW
   // CV2 form (C2f with one Bottleneck of 32 channels): the C2f's cv2 (1x1 over cat(y0, y1, b) -> 64 channels) on the end
   const char* y0;      // the y0 slice of the C2f concat buffer (same pixel stride ldx as x = the y1 slice)
   const char* wc_std;  // cv2 columns [0, 64) = (y0 | y1): upa_pack_conv_weight(64 -> 64, k = 1) layout [2 k-tiles][4 n-tiles]

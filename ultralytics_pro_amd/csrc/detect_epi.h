@@ -17,7 +17,7 @@ struct DetectEpi {
   int a_total;     // anchors of all levels
   int a0;          // first anchor of this level
   int HW, W;       // pixels per image / row width of this level
-  unsigned magicHW;  // floor(2^32 / HW) + 1: pix / HW == umulhi(pix, magicHW) for pix < 2^32 / HW
+  unsigned magicHW;  // floor(2^32 / HW) + 1: pix / HW == umulhi(pix, magicHW) while pix * (magicHW * HW - 2^32) < 2^32 (host-checked)
   unsigned magicW;
   int nc;
   float stride_px;
@@ -41,7 +41,8 @@ __device__ __forceinline__ float upa_row_max4(float v) {
 }
 
 // Box branch of one 16-pixel tile.  v[j] = logits (bias added) of side j: bins 4kg + q of pixel `pix`.
-__device__ __forceinline__ void upa_detect_box_store(const DetectEpi& d, const f32x4 (&v)[4], int pix, bool ok, int kg) {
+// (b, a) = image and level-local anchor of the lane's pixel (upa_detect_split, or straight from the tile coordinates).
+__device__ __forceinline__ void upa_detect_box_store(const DetectEpi& d, const f32x4 (&v)[4], int b, int a, bool ok, int kg) {
   constexpr float LOG2E = 1.44269504088896340736f;
   float dist[4];
 #pragma unroll
@@ -58,8 +59,6 @@ __device__ __forceinline__ void upa_detect_box_store(const DetectEpi& d, const f
     e = upa_row_sum4(e);
     dist[s] = e * __builtin_amdgcn_rcpf(sum);
   }
-  const int b = (int)__umulhi((unsigned)pix, d.magicHW);
-  const int a = pix - b * d.HW;
   const int ay = (int)__umulhi((unsigned)a, d.magicW);
   const int ax = a - ay * d.W;
   const float cx = (float)ax + 0.5f, cy = (float)ay + 0.5f;
@@ -77,11 +76,9 @@ __device__ __forceinline__ int upa_row_min4i(int v) {  // min over the 4 lane ro
 
 // Class branch: n-tile j of one 16-pixel tile; v = logits (bias added) of classes 16j + 4kg + q.  (best, bc) = running first
 // maximum over this lane's classes (call with ascending j: within a lane the classes ascend with (j, q)).
-__device__ __forceinline__ void upa_detect_cls_store(const DetectEpi& d, const f32x4& v, int j, int pix, bool ok, int kg, float& best,
-                                                     int& bc) {
+__device__ __forceinline__ void upa_detect_cls_store(const DetectEpi& d, const f32x4& v, int j, int b, int a, bool ok, int kg,
+                                                     float& best, int& bc) {
   constexpr float LOG2E = 1.44269504088896340736f;
-  const int b = (int)__umulhi((unsigned)pix, d.magicHW);
-  const int a = pix - b * d.HW;
   float* yb = d.y + ((size_t)b * (4 + d.nc) + 4) * d.a_total + d.a0 + a;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -97,14 +94,26 @@ __device__ __forceinline__ void upa_detect_cls_store(const DetectEpi& d, const f
 // After the class rows of one 16-pixel tile: (best, bc) = this lane's first maximum (lane (kg, p16): classes 4kg + q of every
 // n-tile of pixel p16).  The pixel's first maximum over all classes = the row maximum of the scores and, among the lane rows
 // that hold it, the smallest class index; lane row 0 stores the anchor's NMS key (no atomics, no counters: a dense array).
-__device__ __forceinline__ void upa_detect_best_key_store(const DetectEpi& d, float best, int bc, int pix, bool ok, int lane) {
+__device__ __forceinline__ void upa_detect_best_key_store(const DetectEpi& d, float best, int bc, int b, int al, bool ok, int lane) {
   const float m = upa_row_max4(best);
   const int c = upa_row_min4i(best == m ? bc : 0x7FFFFFFF);
   if (lane < 16 && ok) {
-    const int b = (int)__umulhi((unsigned)pix, d.magicHW);
-    const int a = d.a0 + pix - b * d.HW;
+    const int a = d.a0 + al;
     d.best_keys[(size_t)b * d.a_total + a] = ((unsigned long long)(~__float_as_uint(m)) << 32) | (unsigned)(a * d.nc + c);
   }
 }
 
+// flat pixel index (n, h, w flattened) -> (image, level-local anchor).  Exact for every pix the launch can produce: the host
+// refuses shapes outside upa_magic_exact(n * h * w - 1, h * w).
+__device__ __forceinline__ void upa_detect_split(const DetectEpi& d, int pix, int& b, int& a) {
+  b = (int)__umulhi((unsigned)pix, d.magicHW);
+  a = pix - b * d.HW;
+}
+
 static inline unsigned upa_magic_div(int d) { return (unsigned)(0x100000000ULL / (unsigned long long)d) + 1u; }
+// umulhi(x, upa_magic_div(d)) == x / d for every 0 <= x <= xmax  <=>  xmax * (magic * d - 2^32) < 2^32
+static inline bool upa_magic_exact(long xmax, int d) {
+  if (xmax < 0 || d <= 0 || xmax > 0xFFFFFFFFL) return false;
+  const unsigned long long e = (unsigned long long)upa_magic_div(d) * (unsigned long long)d - 0x100000000ULL;
+  return (unsigned long long)xmax * e < 0x100000000ULL;
+}

@@ -59,9 +59,14 @@ class LetterBox:
         left, right = round(dw - 0.1) if self.center else 0, round(dw + 0.1)
         return (int(new_unpad[0]), int(new_unpad[1])), (int(top), int(bottom), int(left), int(right)), ratio
 
-    def __call__(self, labels=None, image=None):
+    def __call__(self, labels=None, image=None, slot: int = 0):
         """image: uint8 CUDA tensor (h, w, 3) or a batch (n, h, w, 3) of equally sized frames (rows may be strided, e.g. a crop
-        of a larger frame).  Returns the letterboxed uint8 tensor of the same rank, or `labels` updated like the reference."""
+        of a larger frame).  Returns the letterboxed uint8 tensor of the same rank, or `labels` updated like the reference.
+
+        Inside a static-buffer context (`runtime.static_buffers`, `compile()`) the result is a pooled buffer keyed by
+        (this instance, slot, output shape): two calls with the same slot return the SAME storage.  The reference idiom
+        `[letterbox(image=x) for x in ims]` (predictor.py:147) must therefore pass `slot=i` there (or hand over the frames as
+        one (n, h, w, 3) batch); outside such a context every call allocates."""
         if labels is None:
             labels = {}
         img = labels.get("img") if image is None else image
@@ -78,7 +83,7 @@ class LetterBox:
         new_shape = labels.pop("rect_shape", self.new_shape)
         (nw, nh), (top, bottom, left, right), ratio = self.geometry((h0, w0), new_shape)
         H, W = nh + top + bottom, nw + left + right
-        out = R.alloc_plain((n, H, W, 3), torch.uint8, x.device, key=(id(self), "letterbox", n, H, W))
+        out = R.alloc_plain((n, H, W, 3), torch.uint8, x.device, key=(id(self), "letterbox", int(slot), n, H, W))
         L.check(L.lib().upa_letterbox_u8(x.data_ptr(), n, h0, w0, x.stride(0) if n > 1 else h0 * x.stride(1), x.stride(1),
                                          out.data_ptr(), H, W, nh, nw, top, left, int(self.padding_value),
                                          L.current_stream(x.device)), "letterbox_u8")

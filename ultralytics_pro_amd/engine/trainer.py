@@ -643,6 +643,9 @@ class DetectionTrainer:
         if self.ERB is not None and self.nbuf:
             L.check(lib.upa_ema_update(self.ERB.data_ptr(), self.RB.data_ptr(), self.nbuf, d, dp, st), "ema_buffers")
         self.first_step = False
+        # parameters and BN buffers were just rewritten through raw pointers: no `_version` moved, so every packed-weight
+        # cache of the inference path (Conv / Detect / C2f) is told explicitly
+        CV.bump_weights_generation()
 
     def step(self, img, labels):
         """One training step. After `compile()` the step is replayed as hipGraphs (one graph on a single GPU; forward +
@@ -702,7 +705,8 @@ class DetectionTrainer:
                 self._graphs = (g1, g2)
         finally:
             self._capturing = False
-        self.updates -= 1  # the capture itself executed nothing
+        if self._graphs[-1] is not None:
+            self.updates -= 1  # a captured optimizer_step counted an update, but the capture itself executed nothing
         return self
 
     def _replay(self, img, labels):
@@ -716,6 +720,7 @@ class DetectionTrainer:
             self.updates += 1
             self.ema_d_dev.fill_(h["ema_decay"] * (1 - math.exp(-self.updates / h["ema_tau"])))
 
+        CV.bump_weights_generation()  # a replayed optimizer writes the weights through raw pointers as well
         if len(self._graphs) == 1:  # forward + backward + optimizer in one graph (single GPU, no schedule)
             stage_decay()
             self._graphs[0].replay(self.device)

@@ -77,8 +77,10 @@ class DetectionValidator:
     def gather_stats(self):
         """All ranks' statistics on every rank, ordered by rank (= by global image index for contiguous shards)."""
         rows, cnt, gcls, ngt = self.local_stats()
-        rows, cnt = dp.gather_detections(rows, cnt)
-        gcls, ngt = dp.gather_detections(gcls, ngt)
+        # shards may differ in image count (uneven split) and in the padded gt width (`pack_labels` grows it to the rank's
+        # largest image, COCO has images with > max_gt boxes): the ranks agree on both before anything is gathered
+        rows, cnt = dp.gather_ragged(rows, cnt)
+        gcls, ngt = dp.gather_ragged(gcls, ngt)
         return rows, cnt, gcls, ngt
 
     def get_stats(self):

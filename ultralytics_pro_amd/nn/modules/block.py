@@ -134,6 +134,14 @@ class C2f(nn.Module):
 
     fuse_pair_cv2 = True  # bf16, one 32-channel Bottleneck, 64 outputs: Bottleneck + cv2 as one launch (upa_bottleneck_pair_cv2)
 
+    def invalidate_packed(self):
+        """Drop the split cv2 weights of `_pair_cv2` (utils/weights.py and `train()` call this on every module that has it)."""
+        self.__dict__.pop("_pc_cache", None)
+
+    def train(self, mode: bool = True):
+        self.invalidate_packed()
+        return super().train(mode)
+
     def _pair_cv2(self, cat, out):
         """[Bottleneck + cv2] in one launch after cv1 has filled cat[:, :2c]; None when the block is outside that form."""
         m = self.m[0] if len(self.m) == 1 else None

@@ -16,7 +16,7 @@ import torch.nn as nn
 from ... import _lib as L
 from ...engine import runtime as R
 
-__all__ = ("autopad", "Conv", "Concat", "hip_conv2d", "PackedConv", "version_key")
+__all__ = ("autopad", "Conv", "Concat", "hip_conv2d", "PackedConv", "version_key", "bump_weights_generation")
 
 
 def autopad(k, p=None, d=1):
@@ -142,10 +142,22 @@ def hip_conv2d(x: torch.Tensor, pk: PackedConv, stride: int, pad: int, act: int,
     return y
 
 
+_WEIGHTS_GEN = [0]
+
+
+def bump_weights_generation() -> int:
+    """Invalidate every packed-weight cache of the process.  For writers that change parameters through raw device
+    pointers, where neither `data_ptr()` nor `_version` moves: the HIP optimizer (`upa_sgd_nesterov_ema` / `upa_ema_update`
+    on the trainer's flat buffers) calls this after every step."""
+    _WEIGHTS_GEN[0] += 1
+    return _WEIGHTS_GEN[0]
+
+
 def version_key(*tensors):
-    """Identity + in-place version of parameter tensors: changes on `load_state_dict` / `copy_` / optimizer steps
-    (`_version` bump) and on `.to(device)` / `.data = ...` (new storage), so a cache keyed on it can never go stale."""
-    return tuple(None if t is None else (t.data_ptr(), t._version, t.device.type) for t in tensors)
+    """Identity + in-place version of parameter tensors + the process-wide weights generation: changes on
+    `load_state_dict` / `copy_` / torch optimizer steps (`_version` bump), on `.to(device)` / `.data = ...` (new storage)
+    and on `bump_weights_generation()` (raw-pointer writers: engine/trainer.py), so a cache keyed on it cannot go stale."""
+    return (_WEIGHTS_GEN[0],) + tuple(None if t is None else (t.data_ptr(), t._version, t.device.type) for t in tensors)
 
 
 class _HipConvMixin:

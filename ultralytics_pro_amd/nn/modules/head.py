@@ -15,6 +15,14 @@ from .conv import Conv, _HipConvMixin, hip_conv2d, version_key
 __all__ = ("Detect",)
 
 
+def _magic_exact(xmax: int, d: int) -> bool:
+    """csrc/detect_epi.h upa_magic_exact: umulhi(x, floor(2^32 / d) + 1) == x // d for every 0 <= x <= xmax."""
+    if xmax < 0 or d <= 0 or xmax > 0xFFFFFFFF:
+        return False
+    e = ((1 << 32) // d + 1) * d - (1 << 32)
+    return xmax * e < (1 << 32)
+
+
 class Detect(nn.Module, _HipConvMixin):
     """YOLO Detect head (head.py:28-191), legacy v3/v5/v8 class branch (:98-100).
 
@@ -70,7 +78,10 @@ class Detect(nn.Module, _HipConvMixin):
             a0.append(tot)
             tot += int(h) * int(w)
         fused = bool(self.fuse_decode and dtype == torch.bfloat16 and self.reg_max == 16 and self.nc <= 128
-                     and all(h * w >= 2 and w >= 2 for h, w in level_hw))
+                     and all(h * w >= 2 and w >= 2 for h, w in level_hw)
+                     # the fused tails split a flat pixel index into (image, anchor) with a multiply-high: only exact up to a
+                     # bound (1280x1280 bs 8 is past it) - larger shapes take conv + upa_detect_decode
+                     and all(_magic_exact(n * h * w - 1, h * w) and _magic_exact(h * w - 1, w) for h, w in level_hw))
         y = R.alloc_plain((n, 4 + self.nc, tot), torch.float32, device, key=(id(self), "y"))
         plan = dict(y=y, a0=a0, a_total=tot, fused=fused, hw=[(int(h), int(w)) for h, w in level_hw], n=int(n), decoded=set(),
                     hot=None, hot_levels=set())

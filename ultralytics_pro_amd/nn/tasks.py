@@ -269,9 +269,10 @@ class BaseModel(nn.Module):
 
     def _virtual_upsample_ok(self, m, li: int, c0: int, c1: int, x) -> bool:
         """An Upsample row may stay unlaunched when it fills the LEADING channels of a Concat that only the next row reads,
-        that row is a C2f or a C3 (whose 1x1 convs can read the half-resolution tensor) and the data is bf16."""
+        that row is a C2f or a C3 (whose 1x1 convs can read the half-resolution tensor), nothing else reads the Upsample row
+        itself (a custom YAML may route it elsewhere: then it is materialised) and the data is bf16."""
         if not (self.virtual_upsample and isinstance(m, Upsample) and c0 == 0 and (c1 - c0) % 32 == 0
-                and x.dtype == torch.bfloat16 and li not in self.save and li + 1 < len(self.model)):
+                and x.dtype == torch.bfloat16 and li not in self.save and m.i not in self.save and li + 1 < len(self.model)):
             return False
         nxt = self.model[li + 1]
         if isinstance(nxt, HipSequential):  # n > 1 repeats of a C3: only the first one reads the Concat

@@ -61,6 +61,32 @@ def gather_detections(out: torch.Tensor, counts: torch.Tensor):
     return g_out, g_cnt
 
 
+def gather_ragged(rows: torch.Tensor, counts: torch.Tensor):
+    """`gather_detections` for shards that need NOT agree in shape: rank r holds (I_r, W_r, ...) rows + (I_r,) counts with its
+    own image count I_r (uneven shards) and its own padded row width W_r (e.g. gt classes padded to that rank's largest
+    image).  The ranks first agree on max I and max W (one MAX all-reduce of two integers), pad to that, all-gather, and the
+    padding images are dropped again, so the result is ordered by rank like `gather_detections`' and every collective has
+    the same shape on every rank (an RCCL all-gather with differing shapes hangs or corrupts)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return rows, counts
+    world = dist.get_world_size()
+    dims = torch.tensor([rows.shape[0], rows.shape[1]], dtype=torch.int64, device=rows.device)
+    mx = dims.clone()
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    imax, wmax = int(mx[0]), int(mx[1])
+    pad = torch.zeros((imax, wmax, *rows.shape[2:]), dtype=rows.dtype, device=rows.device)
+    pad[:rows.shape[0], :rows.shape[1]] = rows
+    cpad = torch.zeros((imax,), dtype=counts.dtype, device=counts.device)
+    cpad[:counts.shape[0]] = counts
+    nimg = torch.empty((world,), dtype=torch.int64, device=rows.device)
+    dist.all_gather_into_tensor(nimg, dims[:1].contiguous())
+    g_rows, g_cnt = gather_detections(pad, cpad)
+    if bool((nimg == imax).all()):
+        return g_rows, g_cnt
+    keep = torch.cat([torch.arange(r * imax, r * imax + int(k), device=rows.device) for r, k in enumerate(nimg.tolist())])
+    return g_rows[keep], g_cnt[keep]
+
+
 def allreduce_gradients_(flat_grads: torch.Tensor) -> torch.Tensor:
     """The one exchange step of the batch-DP training step: in-place SUM all-reduce of the flat f32 gradient
     buffer (RCCL on the GPU, gloo in the CPU tests).  The reference multiplies each rank's loss by world_size and lets
