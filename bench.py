@@ -49,9 +49,15 @@ def parse():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--model", default=None, help="default: yolov8n (infer), yolov8s (train)")
-    ap.add_argument("--workload", default="infer", choices=["infer", "train"],
+    ap.add_argument("--workload", default="infer", choices=["infer", "train", "val"],
                     help="infer = BASELINE config 2 (the headline metric); train = config 3: one batch-DP training step "
-                         "(forward, v8DetectionLoss, backward, gradient all-reduce over RCCL, clip + SGD nesterov + EMA)")
+                         "(forward, v8DetectionLoss, backward, gradient all-reduce over RCCL, clip + SGD nesterov + EMA); "
+                         "val = the validate path: model -> NMS(conf 0.001, multi_label) -> upa_match_predictions per batch shard, "
+                         "then the all-gather of the per-image statistics and ap_per_class on every rank")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = every GPU keeps --batch images per step (global batch N x --batch); strong = the global "
+                         "batch stays --batch and each GPU takes --batch / N of it (the reference's trainer.py:317 "
+                         "`batch // world_size`); the JSON line reports which")
     ap.add_argument("--imgsz", type=int, default=640)
     ap.add_argument("--in-flight", type=int, default=0,
                     help="steps in flight: consecutive steps are replayed round-robin on this many HIP streams (each with its "
@@ -60,6 +66,12 @@ def parse():
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: run only the multi-rank plumbing (gloo rendezvous, barriers, max-over-ranks, the JSON line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opts", default="",
+                    help="dispatch overrides of the model's kernel calls (upa_opts fields, include/upa.h) as name=value,... - A/B "
+                         "measurements only, e.g. --opts conv_big_bm=128,c2f32_th=10; `env` = take them from UPA_* variables")
+    ap.add_argument("--no-host-results", action="store_true",
+                    help="leave the detections in HBM (round-2 behaviour); default: every captured step ends with a kernel that "
+                         "copies (B, max_det, 6) rows + counts into pinned host memory, so `value` counts host-visible detections")
     ap.add_argument("--no-kernel-profile", action="store_true",
                     help="skip the per-layer roofline timing (counter-collection runs: tools/pmc_step.sh)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = the plan of BASELINE.md section 3 (8, 32, physical cores)")
@@ -108,6 +120,27 @@ def main_dry_run(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo")
         dist.barrier()
+    pb = per_rank_batch(args, world)
+    extra = {}
+    if args.workload == "val":
+        # the end-of-run exchange of the validate path on gloo: every rank holds the statistics of ITS shard (stand-in rows: the
+        # GPU kernels are not involved), `gather_stats` all-gathers them and every rank integrates the same AP table
+        from ultralytics_pro_amd.engine.validator import DetectionValidator
+        v = DetectionValidator()
+        for bi in range(2):
+            out = torch.zeros(pb, 300, 6)
+            n = 5 + rank + bi
+            out[:, :n, 4] = torch.linspace(0.9, 0.3, n)
+            out[:, :n, 5] = torch.arange(n) % 3
+            tp = torch.zeros(pb, 300, 10, dtype=torch.uint8)
+            tp[:, :n:2] = 1
+            v._det.append(out); v._cnt.append(torch.full((pb,), n, dtype=torch.int32)); v._tp.append(tp)
+            g = torch.zeros(pb, 4 + 60 * rank)  # ranks deliberately disagree on the padded gt width
+            g[:, :3] = torch.tensor([0.0, 1.0, 2.0])
+            v._gt.append(g); v._ngt.append(torch.full((pb,), 3, dtype=torch.int32))
+        st = v.get_stats()
+        extra = {"map50_95": round(float(st["mean"][3]), 6), "images_validated": int(2 * pb * world),
+                 "detection_rows_gathered": int(st["tp"].shape[0])}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         time.sleep(0.001 * (1 + rank))  # ranks deliberately uneven: the reported time must be the slowest rank's
@@ -118,16 +151,36 @@ def main_dry_run(args):
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    seen = ranks_seen(dist if world > 1 else None, torch.device("cpu"))
     if rank == 0:
-        print(json.dumps({"metric": "dry-run (no GPU work)", "value": round(args.batch * world * args.steps / dt, 1),
+        print(json.dumps({"metric": "dry-run (no GPU work)", "value": round(pb * world * args.steps / dt, 1),
                           "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-                          "vs_baseline": None, "dtype": args.dtype, "data": "none (dry run)",
-                          "config": {"workload": f"dry-run of --workload {args.workload}", "global_batch": args.batch * world,
-                                     "per_gpu_batch": args.batch, "parallelism": f"dp{world}"}}))
+                          "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
+                          "vs_baseline": None, "dtype": args.dtype, "data": "none (dry run)", "rccl_ranks_seen": seen,
+                          "config": {"workload": f"dry-run of --workload {args.workload}", "global_batch": pb * world,
+                                     "per_gpu_batch": pb, "parallelism": f"dp{world}"}, **extra}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def per_rank_batch(args, world: int) -> int:
+    """Images per GPU and step: --batch (weak scaling) or --batch / N (strong: trainer.py:317 `batch // world_size`)."""
+    if args.scaling == "strong":
+        if args.batch % world:
+            raise SystemExit(f"--scaling strong: the global batch {args.batch} is not divisible by {world} ranks")
+        return args.batch // world
+    return args.batch
+
+
+def ranks_seen(dist, dev) -> int:
+    """How many ranks the process group's collective actually reached: a SUM all-reduce of one 1 per rank (RCCL on the GPUs,
+    gloo in the dry run) - the driver checks it against --gpus."""
+    if dist is None:
+        return 1
+    t = torch.ones(1, device=dev, dtype=torch.float32)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(round(float(t.item())))
 
 
 _T0 = time.perf_counter()
@@ -152,6 +205,8 @@ def main():
         return cpu_baseline_child(args)
     if args.workload == "train":
         return main_train(args)
+    if args.workload == "val":
+        return main_val(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -167,6 +222,7 @@ def main():
     torch.cuda.set_device(dev)
 
     from ultralytics_pro_amd import _lib as L
+    from ultralytics_pro_amd.engine import runtime as R
     from ultralytics_pro_amd.nn.modules import conv as pconv
     from ultralytics_pro_amd.nn.tasks import DetectionModel
     from ultralytics_pro_amd.utils import procedural as P
@@ -177,6 +233,9 @@ def main():
     P.apply_procedural_weights(model)
     model = model.to(dev).eval()
     model.set_compute_dtype(dtype)
+    if args.opts:  # every kernel call of this process runs under them (also the per-layer profile's direct replays)
+        R.set_default_opts(L.Opts.from_env() if args.opts == "env" else
+                           L.Opts(**{k: int(v) for k, v in (kv.split("=") for kv in args.opts.split(","))}))
     if args.serial:
         model.model[-1].concurrent = False
     if not args.keep_raw and hasattr(model.model[-1], "keep_raw"):
@@ -185,9 +244,10 @@ def main():
             model.model[-1].nms_keys = True   # the class tails also write every anchor's best-class NMS key for the NMS below
     # per-rank shard of the global stream: rank r owns batches r*K .. r*K+K-1 (K = --input-batches) of the procedural images
     nin = max(1, args.input_batches)
+    pb = per_rank_batch(args, world)
     xs = []
     for j in range(nin):
-        xj = P.synthetic_images(args.batch, first=(rank * nin + j) * args.batch).to(dev)
+        xj = P.synthetic_images(pb, first=(rank * nin + j) * pb).to(dev)
         if dtype == torch.bfloat16:
             xj = xj.to(torch.bfloat16)  # the reference's `im.half()` for a half model (predictor.py:151-173)
         xs.append(xj.contiguous())
@@ -206,6 +266,22 @@ def main():
     else:
         def post(o):
             return nms_raw(o[0], 0.25, 0.7, max_det=300, key="bench")
+
+    if not args.no_host_results:
+        # hand the detections to the host inside the captured step: one kernel writes the fixed-shape rows and the counts
+        # into pinned host memory (one pair of buffers per compiled copy: keyed by the static device buffer it mirrors)
+        post_dev, host_bufs = post, {}
+
+        def post(o):
+            out, counts, keep = post_dev(o)
+            hb = host_bufs.get(out.data_ptr())
+            if hb is None:
+                hb = (torch.empty(out.shape, dtype=out.dtype, pin_memory=True), torch.empty(counts.shape, dtype=counts.dtype, pin_memory=True))
+                host_bufs[out.data_ptr()] = hb
+            st = L.current_stream(out.device)
+            L.check(L.lib().upa_copy_to_host(out.data_ptr(), hb[0].data_ptr(), out.numel() * out.element_size(), st), "copy_to_host")
+            L.check(L.lib().upa_copy_to_host(counts.data_ptr(), hb[1].data_ptr(), counts.numel() * counts.element_size(), st), "copy_to_host")
+            return out, counts, keep
 
     from ultralytics_pro_amd.engine.pipeline import PipelinedRunner, autotune
     tuned = None
@@ -250,9 +326,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
-    value = args.batch * world * args.steps / dt
+    value = pb * world * args.steps / dt
     results = run.result if args.micro_batches > 1 else [run.result]
     ndet = [c for (_, counts, _) in results for c in counts.tolist()]
+    if not args.no_host_results:  # the host copies the step itself wrote must equal the device results
+        for (o_, c_, _) in results:
+            hb = host_bufs[o_.data_ptr()]
+            assert torch.equal(hb[1], c_.cpu()) and torch.equal(hb[0], o_.cpu()), "host-visible detections differ from the device rows"
+    seen = ranks_seen(dist, dev)
 
     roofline, kernels, cpu_baseline = None, None, None
     serial_ms = latency_ms = None
@@ -286,8 +367,8 @@ def main():
             # `value` is the whole-job total over n_gpus ranks of per-GPU batch 32 (the contract); the per-GPU figure of
             # BASELINE.json's "images/sec/GPU" is `images_per_sec_per_gpu` = value / n_gpus
             "metric": ("images/sec (whole job = n_gpus x per-GPU bs=32) YOLOv8n 640x640 (forward + Detect decode + NMS)"
-                       if args.model == "yolov8n" and args.batch == 32
-                       else f"images/sec (whole job) {args.model} {args.imgsz}x{args.imgsz} per-GPU bs={args.batch} "
+                       if args.model == "yolov8n" and pb == 32
+                       else f"images/sec (whole job) {args.model} {args.imgsz}x{args.imgsz} per-GPU bs={pb} "
                             f"(forward + {'RT-DETR decoder + postprocess' if rtdetr else 'Detect decode + NMS'})"),
             "value": round(value, 1),
             "unit": "images/s",
@@ -296,11 +377,12 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic (procedural images + procedural weights, resident in HBM)",
-            "config": {"workload": f"{args.model} detect 640x640 bs={args.batch} {args.dtype} inference, 1 hipGraph/step: "
+            "rccl_ranks_seen": seen,
+            "config": {"workload": f"{args.model} detect 640x640 bs={pb} {args.dtype} inference, 1 hipGraph/step: "
                                    + ("forward+RT-DETR decoder (f32)+postprocess(conf .25, max_det 300)" if rtdetr else
                                       "forward+decode+NMS(conf .25, iou .7, max_det 300)"),
                        "micro_batches": args.micro_batches, "intra_step_concurrency": not (args.serial or runner.linear),
@@ -308,9 +390,12 @@ def main():
                        "autotune_ms_per_step": tuned,
                        "input_batches_rotated": nin, "input_bytes_resident": int(sum(t.numel() * t.element_size() for t in xs)),
                        "detect_raw_maps_written": bool(args.keep_raw),
-                       "global_batch": args.batch * world, "per_gpu_batch": args.batch, "parallelism": f"dp{world} replicas"},
+                       "detections_host_visible": not args.no_host_results, "dispatch_opts": args.opts or None,
+                       "global_batch": pb * world, "per_gpu_batch": pb, "parallelism": f"dp{world} replicas"},
             "images_per_sec_per_gpu": round(value / world, 1),
             "serial_ms_per_step": None if serial_ms is None else round(serial_ms, 4),
+            # strict one-batch-at-a-time rate: per-GPU batch / the serial step (no steps in flight, no intra-step concurrency)
+            "value_one_step_in_flight": None if serial_ms is None else round(pb / (serial_ms * 1e-3), 1),
             "latency_ms_per_batch": None if latency_ms is None else round(latency_ms, 4),
             "detections_per_image_mean": round(sum(ndet) / max(1, len(ndet)), 1),
             "model_tflops": round(value / world * GFLOP_OTHER.get(args.model, GFLOP_PER_IMG) / 1e3, 2),
@@ -320,6 +405,115 @@ def main():
             "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main_val(args):
+    """The validate path across N GPUs (reference engine/validator.py:195-260, models/yolo/detect/val.py:168-240):
+    every rank owns a contiguous shard of a synthetic validation set (K batches of per-GPU batch images + synthetic labels); a
+    step = one batch through model forward -> NMS(conf 0.001, iou 0.7, multi_label, max_det 300: the validator defaults) ->
+    `upa_match_predictions` (TP matrices at the 10 IoU thresholds), captured as ONE hipGraph per batch; after the timed steps
+    the per-image statistics are all-gathered over RCCL (two fixed-shape collectives) and every rank integrates the AP table."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+    from ultralytics_pro_amd.engine import runtime as R
+    from ultralytics_pro_amd.engine.validator import DetectionValidator
+    from ultralytics_pro_amd.nn.tasks import DetectionModel
+    from ultralytics_pro_amd.utils import metrics as M
+    from ultralytics_pro_amd.utils import procedural as P
+    from ultralytics_pro_amd.utils.nms import nms_raw
+
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    args.model = args.model or "yolov8n"
+    model = DetectionModel(args.model + ".yaml")
+    P.apply_procedural_weights(model)
+    model = model.to(dev).eval()
+    model.set_compute_dtype(dtype)
+    model.model[-1].concurrent = False  # linear graphs, one stream per step in flight (as the inference bench)
+    if hasattr(model.model[-1], "keep_raw"):
+        model.model[-1].keep_raw = False
+    pb = per_rank_batch(args, world)
+    nb = max(1, args.input_batches)
+    v = DetectionValidator(model)
+    runs, labels = [], []
+    with torch.no_grad():
+        for j in range(nb):
+            first = (rank * nb + j) * pb
+            xj = P.synthetic_images(pb, first=first).to(dev)
+            xj = (xj.to(torch.bfloat16) if dtype == torch.bfloat16 else xj).contiguous()
+            gt, ngt = v.pack_labels(P.synthetic_labels(pb, first=first), pb, (args.imgsz, args.imgsz), dev)
+            labels.append((gt, ngt))
+
+            def post(o, gt=gt, ngt=ngt, j=j):
+                out, counts, _ = nms_raw(o[0], v.conf, v.iou, multi_label=True, max_det=v.max_det, key=("val", j))
+                tp = R.alloc_plain((pb, v.max_det, len(M.IOUV)), torch.uint8, dev, key=("val_tp", j))
+                M.match_predictions_batched(out, counts, gt, ngt, out=tp)
+                return out, counts, tp
+            runs.append(model.compile(xj, post=post))
+    lanes = [torch.cuda.Stream(device=dev) for _ in range(4)]
+
+    def step(i):
+        with torch.cuda.stream(lanes[i % len(lanes)]):
+            runs[i % nb]()
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    # end of run: one pass over the set = the statistics of the K compiled batches; gather + AP on every rank
+    for (out, counts, tp), (gt, ngt) in zip((r.result for r in runs), labels):
+        v.add_batch_stats(out, counts, tp, gt, ngt)
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    st = v.get_stats()
+    t_gather = time.perf_counter() - t1
+    seen = ranks_seen(dist, dev)
+    if rank == 0:
+        value = pb * world * args.steps / dt
+        print(json.dumps({
+            "metric": f"images/sec (whole job) {args.model} {args.imgsz}x{args.imgsz} validate path, per-GPU bs={pb} "
+                      "(forward + NMS conf .001 multi_label + TP matching per step; statistics all-gather + AP at the end)",
+            "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic (procedural images, labels and weights, resident in HBM)",
+            "rccl_ranks_seen": seen,
+            "config": {"workload": f"{args.model} validate {args.imgsz}x{args.imgsz} bs={pb} {args.dtype}: 1 hipGraph/step = forward + "
+                                   "NMS(conf .001, iou .7, multi_label, max_det 300) + upa_match_predictions",
+                       "global_batch": pb * world, "per_gpu_batch": pb, "parallelism": f"dp{world} replicas",
+                       "val_set": f"{nb} batches per rank = {nb * pb * world} images", "steps_in_flight": len(lanes),
+                       "exchange": "end of run: all_gather_into_tensor of (rows, counts) and (gt classes, counts) over RCCL"},
+            "images_per_sec_per_gpu": round(value / world, 1),
+            "gather_and_map_ms": round(t_gather * 1e3, 3),
+            "images_in_map": int(len(v._cnt) * pb * world), "detection_rows_gathered": int(st["tp"].shape[0]),
+            "map": {"precision": float(st["mean"][0]), "recall": float(st["mean"][1]), "map50": float(st["mean"][2]),
+                    "map50_95": float(st["mean"][3])},
+            "roofline": None, "cpu_baseline": None}))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -352,8 +546,12 @@ def main_train(args):
     model = DetectionModel(args.model + ".yaml")
     P.apply_procedural_weights(model)
     tr = DetectionTrainer(model, dtype=dtype, device=dev, world_size=world)
-    x = P.synthetic_images(args.batch, h=args.imgsz, w=args.imgsz, first=rank * args.batch).to(dev)
-    lab = P.synthetic_labels(args.batch, first=rank * args.batch)
+    pb = per_rank_batch(args, world)
+    x = P.synthetic_images(pb, h=args.imgsz, w=args.imgsz, first=rank * pb).to(dev)
+    lab = P.synthetic_labels(pb, first=rank * pb)
+    buckets = None
+    if world > 1:  # eager steps exchange the gradients in buckets while backward runs (the graph mode keeps one all-reduce)
+        buckets = tr.enable_overlapped_allreduce()
     # eager launches (weight gradients overlap the data-gradient chain on a side stream) vs hipGraph replay of the
     # same step: time a few steps of each and keep the faster mode
     def _time(n=4):
@@ -371,8 +569,13 @@ def main_train(args):
     tr.step(x, lab)
     t_graph = _time()
     mode = "hipGraph replay" if t_graph <= t_eager else "eager launches"
-    if t_graph > t_eager:
+    if dist is not None:  # every rank must run the same mode (the collectives differ): rank 0 decides
+        flag = torch.tensor([1.0 if t_graph <= t_eager else 0.0], device=dev)
+        dist.broadcast(flag, 0)
+        mode = "hipGraph replay" if float(flag.item()) > 0.5 else "eager launches"
+    if mode == "eager launches":
         tr._graphs = None
+    tr.allreduce_exposed_ms()  # drop the records of the tuning steps
     for _ in range(max(args.warmup, 1)):
         items = tr.step(x, lab)
     torch.cuda.synchronize(dev)
@@ -391,7 +594,9 @@ def main_train(args):
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    value = args.batch * world * args.steps / dt
+    value = pb * world * args.steps / dt
+    exposed = tr.allreduce_exposed_ms()
+    seen = ranks_seen(dist, dev)
     roofline = cpu_baseline = None
     if rank == 0:
         roofline = wgrad_profile(tr, L, R, dev, dtype)
@@ -399,15 +604,21 @@ def main_train(args):
             cpu_baseline = run_cpu_baseline_bounded(args)
         nparam = sum(n for _, n, _ in tr.groups)
         print(json.dumps({
-            "metric": f"images/sec {args.model} {args.imgsz}x{args.imgsz} training step, per-GPU batch {args.batch} "
+            "metric": f"images/sec {args.model} {args.imgsz}x{args.imgsz} training step, per-GPU batch {pb} "
                       "(forward + v8DetectionLoss + backward + gradient all-reduce + clip/SGD-nesterov/EMA)",
             "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic (procedural images, labels and initial weights, resident in HBM)",
+            "rccl_ranks_seen": seen,
+            # time the optimizer waited for the bucketed all-reduce after backward had finished (eager mode, N > 1)
+            "allreduce_exposed_ms": None if exposed is None else round(exposed, 4),
             "config": {"workload": f"{args.model} detect {args.imgsz}x{args.imgsz} batch-DP training step, per-GPU batch "
-                                   f"{args.batch}, {args.dtype} activations / f32 master weights and gradients",
-                       "global_batch": args.batch * world, "per_gpu_batch": args.batch, "parallelism": f"dp{world}",
-                       "exchange": f"1 all-reduce(SUM) of {nparam * 4 / 1e6:.1f} MB f32 gradients per step (RCCL)",
+                                   f"{pb}, {args.dtype} activations / f32 master weights and gradients",
+                       "global_batch": pb * world, "per_gpu_batch": pb, "parallelism": f"dp{world}",
+                       "exchange": (f"all-reduce(SUM) of {nparam * 4 / 1e6:.1f} MB f32 gradients per step (RCCL): "
+                                    + (f"{len(buckets)} buckets issued during backward on a communication stream "
+                                       f"(first layers {[b[0] for b in buckets]})" if buckets and mode == "eager launches"
+                                       else "one collective between the backward and optimizer graphs")),
                        "optimizer": "SGD(lr 0.01, momentum 0.9, nesterov, wd 5e-4) + clip 10.0 + EMA",
                        "execution": mode, "tuning_ms_per_step": {"eager": round(t_eager * 1e3, 3), "graph": round(t_graph * 1e3, 3)}},
             "images_per_sec_per_gpu": round(value / world, 1),
@@ -539,7 +750,7 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
         if pk.stem:
             return (f"void stem_mfma_kernel<{pk.cout // 16}, {pk.k}, {stride}, {'true' if act == 1 else 'false'}>(StemParams)" if es == 2 else
                     f"void stem_conv_kernel<{tname}, 16, {'true' if act == 1 else 'false'}>(StemParams)")
-        var = L.lib().upa_conv_variant(n, h, w, cin, pk.cout, pk.k, stride, pad, code)
+        var = L.lib().upa_conv_variant(n, h, w, cin, pk.cout, pk.k, stride, pad, code, R.opts_ptr())
         if (var >> 23) & 1:  # large-tile LDS-shared-operand kernel (conv_big.hip): <KS, STRIDE, WM, WN, MT, NT>
             ntb, mt = (var >> 4) & 15, 4 if (var & 15) == 2 else 2
             wm, wn, nt = (8, 1, 4) if (ntb == 4 and mt == 4) else (4, 2, ntb // 2)
@@ -577,7 +788,7 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
         cout = conv.out_channels
         plan_keep = dict(plan)
         # the fused 1x1 + decode launch (conv1x1.hip EPI 1 / 2): reads t once, writes 4 or nc f32 rows per anchor
-        var = L.lib().upa_conv_variant(n, h, w, cin, 64 if kind == 1 else max(16, (cout + 7) // 8 * 8), 1, 1, 0, code)
+        var = L.lib().upa_conv_variant(n, h, w, cin, 64 if kind == 1 else max(16, (cout + 7) // 8 * 8), 1, 1, 0, code, R.opts_ptr())
         name = "void conv1x1_stream_kernel<%d, %d, %d, %d>(C1Params)" % (var & 15, (var >> 4) & 15, (var >> 8) & 31, kind)
         flops = 2.0 * n * h * w * cout * cin
         nbytes = n * h * w * cin * 2 + n * h * w * (4 if kind == 1 else self.nc) * 4 + cout * cin * 2 + \
@@ -638,34 +849,35 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
             m.hip_conv2d = orig
         phead.Detect._tail_call = orig_tail
         L.lib = orig_libfn
-    for a in pair_calls:  # (x, n, h, w, c, ldx, w1, b1, w2, b2, y, ldy, residual, act, dtype, stream)
+    for a in pair_calls:  # (x, n, h, w, c, ldx, w1, b1, w2, b2, y, ldy, residual, act, dtype, opts, stream)
         n_, h_, w_, c_ = a[1], a[2], a[3], a[4]
         flops = 2 * 2.0 * n_ * h_ * w_ * c_ * c_ * 9
         nbytes = 2 * (n_ * h_ * w_ * c_ * 2 * (2 + (0.5 if a[12] else 0)) + c_ * c_ * 9 * 2)  # two convs, each in + out (+ residual)
         calls.append(("void conv_pair_kernel<%d, %s, false>(PairParams)" % (c_ // 32, "true" if a[12] else "false"), flops, nbytes,
-                      (lambda a=a: orig_pair(*a[:15], L.current_stream(dev)))))
-    for a in paircv2_calls:  # (x, y0, n, h, w, ldx, w1, b1, w2, b2, residual, wc_std, wc_b, bc, out, ldout, act, dtype, stream)
+                      (lambda a=a: orig_pair(*a[:16], L.current_stream(dev)))))
+    for a in paircv2_calls:  # (x, y0, n, h, w, ldx, w1, b1, w2, b2, residual, wc_std, wc_b, bc, out, ldout, act, dtype, opts, stream)
         npx = a[2] * a[3] * a[4]
         flops = 2.0 * npx * (2 * 9 * 32 * 32 + 96 * 64)
         nbytes = npx * (64 + 64) * 2 + (18 * 32 * 32 + 96 * 64) * 2  # y0 | y1 in, 64 channels out, weights
         calls.append(("void conv_pair_kernel<1, %s, true>(PairParams)" % ("true" if a[10] else "false"), flops, nbytes,
-                      (lambda a=a: orig_paircv2(*a[:18], L.current_stream(dev)))))
-    for a in c2f_calls:  # (x, n, h, w, c1, ldx, c, nb, shortcut, w1, b1, wm, bm, w2, b2, y, c2, ldy, act, dtype, stream)
+                      (lambda a=a: orig_paircv2(*a[:19], L.current_stream(dev)))))
+    for a in c2f_calls:  # (x, n, h, w, c1, ldx, c, nb, shortcut, w1, b1, wm, bm, w2, b2, y, c2, ldy, act, dtype, opts, stream)
         npx, c1_, c_, nb_, c2_ = a[1] * a[2] * a[3], a[4], a[6], a[7], a[16]
         wts = c1_ * 2 * c_ + nb_ * 18 * c_ * c_ + (2 + nb_) * c_ * c2_
         flops = 2.0 * npx * wts
         nbytes = npx * (c1_ + c2_) * 2 + wts * 2  # block input + block output + weights
-        th = 10 if (c_ != 16 and nb_ == 2 and os.environ.get("UPA_C2F32_TH") == "10") else 16
-        name = "void c2f16_fused_kernel<%d>(C2fParams)" % int(os.environ.get("UPA_C2F16_WAVES", "4")) if c_ == 16 else "void c2f32_fused_kernel<%d, %d>(C2f32Params)" % (nb_, th)
-        calls.append((name, flops, nbytes, (lambda a=a: orig_c2f(*a[:20], L.current_stream(dev)))))
-    for a in btail_calls:  # (x, n, h, w, c, ldx, w3, b3, wt, bt, kind, nc, stride, y, a_total, a0, best_keys, dtype, stream)
+        o_ = R.current_opts()
+        th = 10 if (c_ != 16 and nb_ == 2 and o_ is not None and o_.c2f32_th == 10) else 16
+        name = "void c2f16_fused_kernel<%d>(C2fParams)" % (8 if (o_ is not None and o_.c2f16_waves == 8) else 4) if c_ == 16 else "void c2f32_fused_kernel<%d, %d>(C2f32Params)" % (nb_, th)
+        calls.append((name, flops, nbytes, (lambda a=a: orig_c2f(*a[:21], L.current_stream(dev)))))
+    for a in btail_calls:  # (x, n, h, w, c, ldx, w3, b3, wt, bt, kind, nc, stride, y, a_total, a0, best_keys, dtype, opts, stream)
         npx, c_, kind, nc_ = a[1] * a[2] * a[3], a[4], a[10], a[11]
         cout = 64 if kind == 1 else nc_
         flops = 2.0 * npx * (9 * c_ * c_ + c_ * cout)
         nbytes = npx * c_ * 2 + npx * (4 if kind == 1 else nc_) * 4 + (9 * c_ * c_ + c_ * cout) * 2
         mt = 1 if (npx + 255) // 256 < torch.cuda.get_device_properties(dev).multi_processor_count else 2
         calls.append(("void conv_big_kernel<3, 1, 8, 1, %d, %d, %d>(BigParams)" % (mt, 4 if kind == 1 else (5 if c_ == 80 else 6), kind), flops, nbytes,
-                      (lambda a=a: orig_btail(*a[:18], L.current_stream(dev)))))
+                      (lambda a=a: orig_btail(*a[:19], L.current_stream(dev)))))
     torch.cuda.synchronize(dev)
     fam = {}
     with torch.no_grad():
@@ -707,7 +919,8 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
             torch.cuda.synchronize(dev)
         fl = 2.0 * n_ * ((h_ // 2) * (w_ // 2) * 16 * 27 + (h_ // 4) * (w_ // 4) * 32 * 144)
         by = n_ * 3 * h_ * w_ * es + n_ * (h_ // 4) * (w_ // 4) * 32 * es
-        fam["void stem_conv_fused_kernel<%d>(StemFusedParams)" % int(os.environ.get("UPA_STEMF_WAVES", "8"))] = dict(launches=1, ms=e0.elapsed_time(e1) / reps, flops=fl, bytes=float(by))
+        o_ = R.current_opts()
+        fam["void stem_conv_fused_kernel<%d>(StemFusedParams)" % (4 if (o_ is not None and o_.stemf_waves == 4) else 8)] = dict(launches=1, ms=e0.elapsed_time(e1) / reps, flops=fl, bytes=float(by))
     conv_ms = sum(d["ms"] for d in fam.values())
     conv_flops = sum(d["flops"] for d in fam.values())
     conv_bytes = sum(d["bytes"] for d in fam.values())

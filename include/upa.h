@@ -7,7 +7,10 @@
  *
  * Conventions
  *  - every function returns 0 on success, a negative UPA_E* code otherwise; no exceptions, no hidden allocation,
- *    no global state; all work is enqueued on `stream` (a hipStream_t passed as void*) and is graph-capturable.
+ *    no global state (the library reads no environment variable and keeps no mode: dispatch overrides travel with the
+ *    call as a caller-owned `upa_opts`, NULL = defaults; the only statics are per-kernel one-time LDS-limit
+ *    attributes and the cached CU count); all work is enqueued on `stream` (a hipStream_t passed as void*) and is
+ *    graph-capturable; re-entrant per stream and per thread (the error string is thread-local).
  *  - activations are NHWC "views": element (n,h,w,c) of a view lives at ptr + ((n*H + h)*W + w)*ld + c, where
  *    `ld` (pixel stride, elements) may exceed C, so a view can be a channel slice of a wider concat buffer
  *    (concat-by-construction, C2f/SPPF/Concat).  Channel offsets and C must be multiples of 16 bytes.
@@ -28,9 +31,38 @@ enum { UPA_F32 = 0, UPA_BF16 = 1, UPA_U8_BGR_HWC = 2 /* stem input only: uint8 (
 enum { UPA_ACT_NONE = 0, UPA_ACT_SILU = 1, UPA_ACT_RELU = 2 };
 enum { UPA_OK = 0, UPA_EINVAL = -1, UPA_EUNSUPPORTED = -2, UPA_EWORKSPACE = -3, UPA_ELAUNCH = -4 };
 
+/* Dispatch / tuning overrides of ONE call (round 3: replaces the process-global UPA_* environment switches and
+ * upa_conv_big_mode of rounds 1-2, so two models in one process can choose differently).  Caller-owned, read during the
+ * call only; NULL or an all-zero struct = production defaults; `size` = sizeof(upa_opts) of the caller's header (fields
+ * past it read as 0, so the struct can grow).  Used by the parity tests (force a kernel family onto small shapes), by
+ * tools/bench_conv.py sweeps and by A/B measurements; production code passes NULL. */
+typedef struct upa_opts {
+  uint32_t size;
+  int32_t conv_big;        /* csrc/conv_big.hip inside upa_conv2d_bias_act: 0 = by the size rule, 1 = never, 2 = every shape it can run */
+  int32_t conv_big_bm;     /* its workgroup pixels: 0 = auto | 128 | 256 | 512 */
+  int32_t conv_force[4];   /* conv_igemm variant WM, WN, MT, NT for every conv whose Cout fits it (0 = none) */
+  int32_t conv_ckt;        /* conv_igemm k-tiles per chunk: 0 = auto | 1 | 2 | 4 */
+  int32_t no_ws, no_pipe, no_1x1, no_c16, no_upcat;  /* 1 = never dispatch conv_ws / conv3x3_pipe / conv1x1_stream / conv3x3_c16 / the virtual upsample */
+  int32_t pipe_all;        /* conv3x3_pipe on every eligible channel count (default: the measured winners) */
+  int32_t pipe_min_tiles;  /* ... from this many wave tiles (0 = 1024) */
+  int32_t pipe_wgs, c16_wgs;        /* persistent workgroups of conv3x3_pipe (0 = 256) / conv3x3_c16 (0 = 512) */
+  int32_t c1_mt, c1_waves, c1_wgs;  /* conv1x1_stream: pixel tiles per wave step, waves per workgroup, workgroup cap (0 = auto) */
+  int32_t pair;            /* upa_bottleneck_pair: 0 = C = 32 only (default), 1 = never, 2 = C = 32 and 64, 3 = C = 64 only */
+  int32_t pair_tile64, pair_tile32;  /* its square output tile edge per width (0 = auto) */
+  int32_t no_pair_cv2;     /* upa_bottleneck_pair_cv2: 1 = never */
+  int32_t c2f;             /* upa_c2f_fused: 0 = both forms, 1 = never, 2 = not the 16-wide, 3 = not the 32-wide */
+  int32_t c2f16_waves;     /* 0 = 4 | 8 */
+  int32_t c2f32_th;        /* output tile rows of the C2f(64, 64, n = 2) form: 0 = 16 | 10 */
+  int32_t no_branch_tail;  /* upa_detect_branch_tail: 1 = never */
+  int32_t branch_tail_bm;  /* its workgroup pixels: 0 = auto | 128 | 256 */
+  int32_t stem_wgs, stemf_wgs, stemf_waves, stem_no_mfma;  /* stem kernels: workgroup caps (0 = 1024 / 512), fused-stem waves (0 = 8 | 4) */
+  int32_t ablate_conv, ablate_pipe, ablate_c1, ablate_stem;  /* kernel ablation bit masks: honoured by the -DUPA_ABLATE build only (make ablate) */
+} upa_opts;
+
 /* Library / device info. Returns the ABI version (int); fills name with the kernel target ("gfx950"). */
 int upa_version(void);
 const char* upa_last_error(void);
+size_t upa_opts_size(void); /* sizeof(upa_opts) the library was built with (bindings check their mirror of the struct) */
 
 /* ---- convolution -------------------------------------------------------------------------------------------------
  * y = act(conv2d(x, W) + bias) [+ residual]          nn/modules/conv.py:188-197 (Conv.forward_fuse), block.py:668
@@ -43,14 +75,10 @@ int upa_conv2d_bias_act(const void* x, int n, int h, int w, int cin, int ldx,
                         const void* w_packed, const float* bias /* f32[cout padded to 16] or NULL */,
                         void* y, int cout, int ldy,
                         const void* residual /* NULL or view shaped like y */, int ldr,
-                        int k, int stride, int pad, int act, int dtype, void* stream);
+                        int k, int stride, int pad, int act, int dtype, const upa_opts* opts, void* stream);
 
 /* Introspection for benchmarks: the kernel instantiation (WM<<12 | WN<<8 | MTW<<4 | NTW) the call above would use. */
-int upa_conv_variant(int n, int h, int w, int cin, int cout, int k, int stride, int pad, int dtype);
-/* Dispatch mode of the large-tile LDS-shared-operand kernel (csrc/conv_big.hip) inside upa_conv2d_bias_act: 0 = never,
- * 1 = MFMA-bound layers only (bf16, stride 1, k 1|3, Cin >= 128, Cout % 128 == 0; the default, or env UPA_CONV_BIG),
- * 2 = every shape it can run (parity tests / per-layer benchmarks).  Returns the previous mode; mode < 0 only queries. */
-int upa_conv_big_mode(int mode);
+int upa_conv_variant(int n, int h, int w, int cin, int cout, int k, int stride, int pad, int dtype, const upa_opts* opts);
 
 /* Bottleneck as one kernel (nn/modules/block.py:644-668 with k = (3, 3), e = 1.0 as C2f builds it, block.py:475):
  * y = [x +] SiLU(conv3x3(SiLU(conv3x3(x, w1) + b1), w2) + b2), C -> C -> C channels, BN folded, the intermediate tile kept
@@ -58,7 +86,8 @@ int upa_conv_big_mode(int mode);
  * buffer).  Returns UPA_EUNSUPPORTED outside the fused form (bf16, SiLU, c = 32 | 64): the caller then runs two
  * upa_conv2d_bias_act launches. */
 int upa_bottleneck_pair(const void* x, int n, int h, int w, int c, int ldx, const void* w1_packed, const float* b1,
-                        const void* w2_packed, const float* b2, void* y, int ldy, int residual, int act, int dtype, void* stream);
+                        const void* w2_packed, const float* b2, void* y, int ldy, int residual, int act, int dtype,
+                        const upa_opts* opts, void* stream);
 
 
 /* First layer: reads the model input NCHW (f32 or bf16, 1..4 channels) directly, writes NHWC.   conv.py:188-197
@@ -67,13 +96,13 @@ size_t upa_stem_packed_weight_bytes(int cout, int cin, int k);
 int upa_pack_stem_weight(const float* w_oihw, int cout, int cin, int k, float* out /* host */);
 int upa_conv2d_stem_nchw(const void* x_nchw, int x_dtype, int n, int cin, int h, int w,
                          const float* w_oihw, const float* bias, void* y, int cout, int ldy,
-                         int k, int stride, int pad, int act, int dtype, void* stream);
+                         int k, int stride, int pad, int act, int dtype, const upa_opts* opts, void* stream);
 
 /* Conv(3,16,3,2,1)+SiLU -> Conv(16,32,3,2,1)+SiLU fused (yolov8n rows 0-1, cfg/models/v8/yolov8.yaml): bf16 NCHW input
  * (w % 8 == 0, h % 4 == 0), the 16-channel stem output only ever exists as an LDS tile.  w0 / b0: upa_pack_stem_weight
  * layout + folded bias; w1 / b1: upa_pack_conv_weight(UPA_BF16) layout + folded bias; y: NHWC bf16 (n, h/4, w/4, 32). */
 int upa_stem_conv_fused(const void* x, int n, int h, int w, const float* w0, const float* b0, const void* w1,
-                        const float* b1, void* y, int ldy, void* stream);
+                        const float* b1, void* y, int ldy, const upa_opts* opts, void* stream);
 
 /* ---- pooling / resampling / concat (HBM-bound) --------------------------------------------------------------- */
 /* nn.MaxPool2d(k, s, p) with -inf padding; pad_br>0 emulates nn.ZeroPad2d([0,pad_br,0,pad_br]) in front of it
@@ -87,6 +116,10 @@ int upa_sppf_pool3(const void* x, int n, int h, int w, int c, int ldx, void* y1,
 int upa_upsample2x(const void* x, int n, int h, int w, int c, int ldx, void* y, int ldy, int dtype, void* stream);
 /* view -> view copy (Concat of tensors that could not be produced in place)                conv.py:874 */
 int upa_copy_view(const void* x, int n, int h, int w, int c, int ldx, void* y, int ldy, int dtype, void* stream);
+/* device -> PINNED host copy issued as a kernel (capturable into a hipGraph without a memcpy node): the hand-over of the
+ * fixed-shape detections (B, max_det, 6) + counts to the host at the end of a step - the reference's results leave the GPU
+ * in `Results(...)` construction, engine/results.py via models/yolo/detect/predict.py:53-120.  bytes % 4 == 0. */
+int upa_copy_to_host(const void* src_dev, void* dst_pinned, size_t bytes, void* stream);
 /* y = a + b (views)                                                                        block.py:6091 */
 int upa_add_view(const void* a, int lda, const void* b, int ldb, void* y, int ldy, int n, int h, int w, int c,
                  int dtype, void* stream);
@@ -119,7 +152,7 @@ int upa_detect_decode(const void* box, int ldb, const void* cls, int ldc, int n,
  * mode, reg_max != 16, nc > 128): the caller then runs upa_conv2d_bias_act + upa_detect_decode.  head.py:151-169 */
 int upa_detect_tail(const void* x, int n, int h, int w, int cin, int ldx, const void* w_packed, const float* bias, int cout,
                     int kind, int nc, float stride_px, float* y, int a_total, int a0, void* raw, int ldraw, int dtype,
-                    void* stream);
+                    const upa_opts* opts, void* stream);
 
 /* 1x1 conv over Concat([Upsample(2x nearest)(up), skip]) with the upsample read on the fly (bf16): the first up_c channels of a
  * pixel come from pixel (y/2, x/2) of `up` (n, h/2, w/2, up_c; pixel stride up_ld), the other cin - up_c from the concat buffer x
@@ -127,7 +160,8 @@ int upa_detect_tail(const void* x, int n, int h, int w, int cin, int ldx, const 
  * nn.Upsample + Concat + C2f.cv1: yolov8.yaml rows 10-12 / 13-15, nn/modules/conv.py (Concat), block.py:479.
  * UPA_EUNSUPPORTED outside the streaming 1x1 form (callers then write the upsample and call upa_conv2d_bias_act). */
 int upa_conv1x1_upcat(const void* x, int n, int h, int w, int cin, int ldx, const void* up, int up_c, int up_ld,
-                      const void* w_packed, const float* bias, void* y, int cout, int ldy, int act, int dtype, void* stream);
+                      const void* w_packed, const float* bias, void* y, int cout, int ldy, int act, int dtype,
+                      const upa_opts* opts, void* stream);
 
 /* C2f(.., 64, n = 1) with a 32-channel Bottleneck (yolov8n model.15): the Bottleneck (both 3x3 convs [+ shortcut]) AND the
  * C2f's cv2 in one launch (bf16, SiLU); the Bottleneck's output only exists as MFMA operands.   block.py:457-488, 644-668.
@@ -137,7 +171,7 @@ int upa_conv1x1_upcat(const void* x, int n, int h, int w, int cin, int ldx, cons
  * out = (n, h, w, 64) view.  UPA_EUNSUPPORTED outside the form (callers run upa_bottleneck_pair + upa_conv2d_bias_act). */
 int upa_bottleneck_pair_cv2(const void* x, const void* y0, int n, int h, int w, int ldx, const void* w1_packed, const float* b1,
                             const void* w2_packed, const float* b2, int residual, const void* wc_std, const void* wc_b,
-                            const float* bc, void* out, int ldout, int act, int dtype, void* stream);
+                            const float* bc, void* out, int ldout, int act, int dtype, const upa_opts* opts, void* stream);
 
 /* A whole C2f block in one launch (bf16, SiLU): cv1 -> nb x Bottleneck(3x3, 3x3, [+ input]) -> cv2 with the intermediates in
  * LDS / registers only.                            nn/modules/block.py:457-488 (C2f.forward), :644-668 (Bottleneck.forward).
@@ -147,7 +181,7 @@ int upa_bottleneck_pair_cv2(const void* x, const void* y0, int n, int h, int w, 
  * without shortcut (yolov8n model.4, yolov8s model.2); UPA_EUNSUPPORTED otherwise (callers run the separate convolutions). */
 int upa_c2f_fused(const void* x, int n, int h, int w, int c1, int ldx, int c, int nb, int shortcut, const void* w1,
                   const float* b1, const void* const* wm, const float* const* bm, const void* w2, const float* b2, void* y,
-                  int c2, int ldy, int act, int dtype, void* stream);
+                  int c2, int ldy, int act, int dtype, const upa_opts* opts, void* stream);
 
 /* The whole back half of a Detect branch in one launch (bf16): second 3x3 conv (BN + SiLU folded) -> final 1x1 conv -> that
  * branch's half of the decode, the intermediate maps never leaving the registers.      head.py:94-100 (cv2/cv3), :116-126,
@@ -163,7 +197,7 @@ int upa_pack_tail_weight(const float* w, int cout, int cin, void* out);
  * Consumed by upa_nms_batched_hot. */
 int upa_detect_branch_tail(const void* x, int n, int h, int w, int c, int ldx, const void* w3_packed, const float* b3,
                            const void* wt_packed, const float* bt, int kind, int nc, float stride_px, float* y, int a_total,
-                           int a0, unsigned long long* best_keys, int dtype, void* stream);
+                           int a0, unsigned long long* best_keys, int dtype, const upa_opts* opts, void* stream);
 
 
 /* ---- NMS ----------------------------------------------------------------------------------------------------------

@@ -7,6 +7,7 @@ Outputs are data only (inputs are re-derivable from the hash; expected outputs a
   tests/golden/ops_unit.npz         per-op outputs on small procedural tensors                   (§8c b)
   tests/golden/nms_cases.npz        NMS inputs + reference outputs                               (§8c c)
   tests/golden/e2e_<cfg>.npz        head-output slices/statistics + post-NMS rows, B=2            (§8c d)
+  tests/golden/e2e_<cfg>_smooth.npz the same on the "smooth" weight family (bf16-exact weights; the bf16 e2e gate)
   tests/golden/map_yolov8n.npz      synthetic-GT validation set: detections, labels, TP matrices, AP (§8f rank 1)
   tests/golden/letterbox.npz        LetterBox frames in / out (cv2.resize restated, see oracle/letterbox.py)          (§8f rank 3)
   tests/golden/train_<cfg>.npz      training step(s): loss items, gradient norms / slices, updated state, EMA (§8f rank 2)
@@ -325,6 +326,41 @@ def e2e(rt):
         np.savez_compressed(GOLD / f"e2e_{name}.npz", **G)
 
 
+def e2e_smooth(rt):
+    """tests/golden/e2e_<cfg>_smooth.npz: the four Detect configs on the "smooth" procedural family
+    (utils/procedural.py SMOOTH_RECIPE: bf16-exact weights, unit BatchNorm scale, small non-competing boxes) - the imported
+    reference's f32 output (head slice + predict-mode NMS rows), with oracle == reference asserted as in e2e()."""
+    from ultralytics.utils.nms import non_max_suppression as r_nms
+
+    for name in ["yolov3-tiny", "yolov8n", "yolov8s", "yolov5-BoT3"]:
+        fam = "smooth:" + P.model_family(ot.DetectionModel(name + ".yaml"))
+        ref = rt.DetectionModel(REF_CFG[name], ch=3, nc=80, verbose=False)
+        P.apply_procedural_weights(ref, family=fam)
+        ref.eval().fuse(verbose=False)
+        mine = ot.DetectionModel(name + ".yaml")
+        P.apply_procedural_weights(mine, family=fam)
+        mine.fuse()
+        x = P.synthetic_images(2)
+        with torch.no_grad():
+            yr = ref(x.clone())[0]
+            yo = mine(x.clone())[0]
+        d = maxdiff(yr, yo)
+        print(f"e2e smooth {name}: y {tuple(yr.shape)} oracle-vs-ref max|d| = {d:.3e}")
+        assert d <= 2e-3, d
+        A = yr.shape[-1]
+        sel = np.unique(np.concatenate([np.arange(0, A, max(1, A // 256)), np.arange(64), np.arange(A - 64, A)]))
+        G = {"oracle_vs_ref_maxdiff": np.array([d]), "anchor_sel": sel, "y_sel": yr[:, :, sel].numpy()}
+        kw = dict(conf_thres=0.25, iou_thres=0.7, max_det=300)
+        out_r = r_nms(yr.clone(), max_time_img=1e9, **kw)
+        out_oo = onms.non_max_suppression(yr.clone(), **kw)
+        for a, b_ in zip(out_r, out_oo):
+            assert torch.equal(a, b_), f"{name}/smooth: oracle NMS != reference NMS on identical input"
+        G["predict_n"] = np.array([o.shape[0] for o in out_r])
+        G["predict_rows"] = torch.cat(out_r, 0).numpy()
+        print(f"   predict: n={[o.shape[0] for o in out_r]}")
+        np.savez_compressed(GOLD / f"e2e_{name}_smooth.npz", **G)
+
+
 def synthetic_ground_truth(dets, image_index):
     """GT for the synthetic mAP set: a jittered subset of one image's own detections (so mAP is non-trivial and identical
     pipelines give identical mAP). dets: (n,6) val-mode NMS rows. Returns (boxes (m,4), cls (m,))."""
@@ -531,6 +567,8 @@ def main():
             nms_cases(rt)
         if "e2e" in which:
             e2e(rt)
+        if "e2e" in which or "e2e_smooth" in which:
+            e2e_smooth(rt)
         if "map" in which:
             map_golden(rt)
         if "letterbox" in which:

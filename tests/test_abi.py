@@ -52,6 +52,40 @@ def test_host_side_weight_packing_layout():
             assert float(vals[tap, kt, nt, g, r, j]) == exp
 
 
+def test_dispatch_options_travel_with_the_call_and_the_library_reads_no_environment(monkeypatch):
+    """Round-2 review item 4: include/upa.h promises no global state.  The dispatch query (host logic only, no launch) must follow
+    the caller's `upa_opts`, two different option sets must not influence each other, and UPA_* environment variables must be
+    ignored by the library (they were process-global switches in rounds 1-2)."""
+    import ctypes as C
+    import subprocess
+    from ultralytics_pro_amd import _lib as L
+    lib = L.lib()
+    assert lib.upa_opts_size() == C.sizeof(L.Opts)
+    q = (32, 40, 40, 64, 64, 3, 1, 1, L.UPA_BF16)  # yolov8n model.6's Bottleneck convs: 64 -> 64 3x3 at 40x40, bs 32
+    big = lambda v: (v >> 23) & 1  # noqa: E731
+    default = lib.upa_conv_variant(*q, None)
+    assert big(default)
+    never, always = L.Opts(conv_big=1), L.Opts(conv_big=2)
+    assert not big(lib.upa_conv_variant(*q, C.pointer(never)))
+    assert lib.upa_conv_variant(*q, None) == default                      # the previous call left no mode behind
+    small = (1, 16, 16, 64, 64, 3, 1, 1, L.UPA_BF16)                      # too few pixels for the size rule ...
+    assert not big(lib.upa_conv_variant(*small, None)) and big(lib.upa_conv_variant(*small, C.pointer(always)))  # ... forced
+    v128 = lib.upa_conv_variant(*q, C.pointer(L.Opts(conv_big_bm=128)))
+    v256 = lib.upa_conv_variant(*q, C.pointer(L.Opts(conv_big_bm=256)))
+    assert (v128 & 15, v256 & 15) == (1, 2)                                # pixels per workgroup / 128
+    short = L.Opts(conv_big=1)
+    short.size = 8                                                         # an older caller whose struct ends after conv_big
+    assert not big(lib.upa_conv_variant(*q, C.pointer(short)))
+    monkeypatch.setenv("UPA_CONV_BIG", "0")                                # the round-2 switch for "never": must be ignored now
+    monkeypatch.setenv("UPA_CONV_BIG_BM", "128")
+    assert lib.upa_conv_variant(*q, None) == default
+    src = (ROOT / "ultralytics_pro_amd" / "csrc")
+    hits = subprocess.run(["grep", "-ln", "getenv", *[str(f) for f in sorted(src.glob("*.hip")) + sorted(src.glob("*.h"))]],
+                          capture_output=True, text=True).stdout.split()
+    assert hits == [], f"getenv in the library sources: {hits}"
+    assert L.Opts.from_env({"UPA_NO_PAIR": "0", "UPA_C1_MT": "4", "UPA_CONV_FORCE": "4,1,2,4"}).pair == 2  # tool-side mapping only
+
+
 def test_product_builds_on_cpu_but_refuses_to_run_there():
     from ultralytics_pro_amd._lib import UpaError
     from ultralytics_pro_amd.nn.tasks import DetectionModel

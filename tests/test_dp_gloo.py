@@ -95,6 +95,49 @@ def test_world2_gloo_ragged_gather_uneven_shards_and_gt_width():
     assert sorted(q.get(timeout=5) for _ in range(2)) == [0, 1]
 
 
+def _bucket_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from ultralytics_pro_amd.parallel import BucketedAllReduce, allreduce_gradients_, init_distributed
+    from ultralytics_pro_amd.utils import procedural as P
+
+    init_distributed("gloo")
+    n = 100_003
+    g = P.uniform(f"bucketgrad{rank}", (n,), -3.0, 3.0) * (10.0 ** (P.uniform(f"bucketexp{rank}", (n,), -6, 6)))  # wide range
+    whole = allreduce_gradients_(g.clone())
+    # three "layer spans", each with one range in each of three "optimizer groups" [0, 1000) | [1000, 90000) | [90000, n)
+    buckets = [[(700, 1000), (60000, 90000), (97000, n)], [(300, 700), (20000, 60000), (93000, 97000)],
+               [(0, 300), (1000, 20000), (90000, 93000)]]
+    flat = g.clone()
+    b = BucketedAllReduce(flat, buckets)
+    assert b.covered() == n
+    b.issue(0)
+    b.issue(0)  # issuing a bucket twice must not reduce it twice
+    b.issue(1)
+    assert b.wait() == 2
+    b.issue(2)
+    b.wait()
+    assert torch.equal(flat, whole)  # bit for bit: SUM over disjoint ranges == SUM over the whole buffer
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put(rank)
+
+
+def test_world2_gloo_bucketed_allreduce_equals_single_allreduce():
+    """engine/trainer.enable_overlapped_allreduce: the gradient buffer exchanged as per-span buckets (issued while backward
+    runs) must equal the single SUM all-reduce bit for bit."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(2)) == [0, 1]
+
+
 def _train_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
@@ -165,15 +208,20 @@ def test_bench_gpus_flag_launches_ranks_itself():
     from pathlib import Path
     root = Path(__file__).resolve().parents[1]
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    for wl in ("infer", "train"):
+    for wl, scaling in (("infer", "weak"), ("train", "weak"), ("infer", "strong"), ("val", "weak")):
         r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--dry-run",
-                            "--workload", wl], env=env, capture_output=True, text=True, timeout=300)
+                            "--workload", wl, "--scaling", scaling], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         assert len(lines) == 1, r.stdout
         rec = json.loads(lines[0])
-        assert rec["n_gpus"] == 2 and rec["config"]["parallelism"] == "dp2" and rec["config"]["global_batch"] == 64
+        gb = 64 if scaling == "weak" else 32  # strong scaling: the global batch stays 32, 16 per rank
+        assert rec["n_gpus"] == 2 and rec["config"]["parallelism"] == "dp2" and rec["config"]["global_batch"] == gb
+        assert rec["scaling"] == scaling and rec["config"]["per_gpu_batch"] == gb // 2
+        assert rec["rccl_ranks_seen"] == 2  # a SUM all-reduce of one 1 per rank went through the process group
         assert rec["ms_per_step"] >= 2.0  # the slower rank (2 ms per step) sets the time
+        if wl == "val":  # both ranks' statistics reached the AP integration (rank 0: 2 x 32 x (5 + 6) rows, rank 1: (6 + 7))
+            assert rec["images_validated"] == 128 and rec["detection_rows_gathered"] == 32 * (5 + 6 + 6 + 7)
 
 
 def _validator_rank(rank, world, port, golden, q):

@@ -17,11 +17,11 @@ TOL = 1e-3
 BOX_TOL = {"yolov8s": 3e-3}
 
 
-def _build(name, dtype):
+def _build(name, dtype, family=None):
     from tests.hip_utils import DEV
     from ultralytics_pro_amd.nn.tasks import DetectionModel
     m = DetectionModel(name + ".yaml")
-    P.apply_procedural_weights(m)
+    P.apply_procedural_weights(m, family=family)
     m = m.to(DEV).eval()
     m.set_compute_dtype(dtype)
     return m
@@ -117,6 +117,70 @@ def test_e2e_bf16_matches_reference_golden(name, golden_dir):
     assert a5["recall"] >= r5 and a5["precision"] >= p5
     assert a["box_p99"] <= bp99 and a["box_max"] <= bmax and a["score_p99"] <= sp99
     assert np.quantile(dbox, 0.99) <= max(bmax, 4.0) and dsc.max() <= 0.05
+
+
+# ---- the "smooth" weight family: bf16 pinned at the reference's own AMP tolerance -----------------------------------------
+# utils/procedural.py SMOOTH_RECIPE: bf16-exact conv weights (what a half-precision checkpoint holds), BatchNorm scale exactly
+# 1, small boxes that do not compete in NMS.  On it the bf16 pipeline must reproduce the f32 REFERENCE detections
+# (tests/golden/e2e_<cfg>_smooth.npz, generated from the imported reference): every matched box within 0.5 px - the reference's
+# AMP self-check, utils/checks.py:780 `torch.allclose(a.boxes.data, b.boxes.data, atol=0.5)` - and the detection sets equal
+# except for rows whose score lies within +-SMOOTH_BAND of conf_thres: a detection's presence is a step function of its score,
+# so a row the reference scores 0.2508 can legitimately come out at 0.2493 (bf16 activations move scores by up to 3e-3).
+# Bounds: (raw recall, raw precision) at IoU >= 0.9.  Measured on MI355X (round 3): yolov8s, yolov3-tiny, yolov5-BoT3 1.000 / 1.000
+# (171, 42, 166 rows; matched boxes <= 0.02 px, scores <= 0.0015); yolov8n 0.985 / 0.939 (214 vs 204 rows) with EVERY mismatch a
+# threshold-band row (outside the band 1.0 / 1.0, matched boxes <= 0.025 px): the narrow network's class map is nearly flat in
+# space at any conv gain below the onset of chaos (6.5 -> 6.7: score noise x 10, tools/experiments/smooth_scan.py), so 40 % of
+# its 204 reference rows score within +-0.005 of 0.25 - its raw bound is what that crowding allows, the band-excluded and the
+# 0.5 px gates below are the same for all four.
+SMOOTH_BAND = 0.005
+SMOOTH_BOUNDS = {"yolov8n": (0.93, 0.90), "yolov8s": (0.97, 0.97), "yolov3-tiny": (0.97, 0.97), "yolov5-BoT3": (0.97, 0.97)}
+
+
+@pytest.mark.parametrize("name", list(SMOOTH_BOUNDS))
+def test_e2e_bf16_smooth_family_matches_reference_golden(name, golden_dir):
+    from tests.hip_utils import DEV, detection_agreement, split_rows
+    from ultralytics_pro_amd.utils.nms import non_max_suppression
+    g = np.load(golden_dir / f"e2e_{name}_smooth.npz")
+    m = _build(name, torch.bfloat16, family="smooth:" + name)
+    x = P.synthetic_images(2).to(DEV).to(torch.bfloat16).contiguous()
+    with torch.no_grad():
+        y = m(x)[0]
+    torch.cuda.synchronize()
+    d = np.abs(y.cpu()[:, :, g["anchor_sel"]].numpy() - g["y_sel"])
+    out = [o.cpu().numpy() for o in non_max_suppression(y, conf_thres=0.25, iou_thres=0.7, max_det=300)]
+    ref = split_rows(g["predict_rows"], g["predict_n"])
+    a = detection_agreement(out, ref, 0.9)
+    ref_x = [r[np.abs(r[:, 4] - 0.25) > SMOOTH_BAND] for r in ref]
+    out_x = [r[np.abs(r[:, 4] - 0.25) > SMOOTH_BAND] for r in out]
+    rec_x = detection_agreement(out, ref_x, 0.9)["recall"]       # every reference row outside the band is found ...
+    prec_x = detection_agreement(out_x, ref, 0.9)["precision"]   # ... and every row of mine outside it exists in the reference
+    print(f"{name} smooth bf16 vs reference golden: head box max|d| {d[:, :4].max():.3f} px score max|d| {d[:, 4:].max():.4f}; detections "
+          f"{a['n_mine']} vs {a['n_ref']}: recall {a['recall']:.3f} precision {a['precision']:.3f} (outside the +-{SMOOTH_BAND} band: "
+          f"{rec_x:.4f} / {prec_x:.4f}; band rows ref {sum(map(len, ref)) - sum(map(len, ref_x))} mine {sum(map(len, out)) - sum(map(len, out_x))}), "
+          f"matched box p99 {a['box_p99']:.3f} max {a['box_max']:.3f} px, score max {a['score_max']:.4f}")
+    r9, p9 = SMOOTH_BOUNDS[name]
+    assert a["recall"] >= r9 and a["precision"] >= p9
+    assert rec_x >= 0.995 and prec_x >= 0.995
+    assert a["box_max"] <= 0.5 and a["score_max"] <= SMOOTH_BAND       # the reference's AMP tolerance on every matched row
+    assert d[:, :4].max() <= 0.5 and d[:, 4:].max() <= SMOOTH_BAND     # ... and on the sampled head outputs
+
+
+@pytest.mark.parametrize("name", ["yolov8n", "yolov5-BoT3"])
+def test_e2e_f32_smooth_family_matches_reference_golden(name, golden_dir):
+    """f32 parity mode on the smooth family: the 1e-3 north_star tolerance, rows identical."""
+    from tests.hip_utils import DEV
+    from ultralytics_pro_amd.utils.nms import non_max_suppression
+    g = np.load(golden_dir / f"e2e_{name}_smooth.npz")
+    m = _build(name, torch.float32, family="smooth:" + name)
+    with torch.no_grad():
+        y = m(P.synthetic_images(2).to(DEV))[0]
+    torch.cuda.synchronize()
+    d = np.abs(y.cpu()[:, :, g["anchor_sel"]].numpy() - g["y_sel"])
+    assert d[:, :4].max() <= TOL and d[:, 4:].max() <= TOL
+    out = non_max_suppression(y, conf_thres=0.25, iou_thres=0.7, max_det=300)
+    assert [o.shape[0] for o in out] == list(g["predict_n"])
+    rows = torch.cat(out, 0).cpu().numpy()
+    assert np.abs(rows[:, :5] - g["predict_rows"][:, :5]).max() <= TOL and np.array_equal(rows[:, 5], g["predict_rows"][:, 5])
 
 
 @pytest.mark.parametrize("shape", [(1, 352, 416), (3, 320, 320), (2, 224, 640)], ids=["1x352x416", "3x320x320", "2x224x640"])

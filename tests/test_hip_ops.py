@@ -97,7 +97,8 @@ def test_conv_pipe_kernel(case):
     from ultralytics_pro_amd import _lib as L
     pm, _ = _mods()
     c1, c2, H, W, N = case
-    var = L.lib().upa_conv_variant(N, H, W, c1, c2, 3, 1, 1, 1)
+    from ultralytics_pro_amd.engine import runtime as R
+    var = L.lib().upa_conv_variant(N, H, W, c1, c2, 3, 1, 1, 1, R.opts_ptr())
     assert (var >> 21) & 1, "case is not dispatched to the pipelined kernel"
     o, m = _pair(om.Conv, pm.Conv, (c1, c2, 3, 1), "conv_pipe")
     x = bf16_round(P.uniform(f"pipe{case}", (N, c1, H, W), -1, 1))
@@ -128,9 +129,10 @@ BIG_CASES = [
 
 
 @pytest.mark.parametrize("case", BIG_CASES, ids=[f"c{c[0]}-{c[1]}k{c[2]}s{c[7] if len(c) > 7 else 1}_{c[3]}x{c[4]}n{c[5]}{'r' if c[6] else ''}" for c in BIG_CASES])
+@pytest.mark.parametrize("bm", [0, 512], ids=["auto", "bm512"])
 @pytest.mark.parametrize("act", [True, False], ids=["silu", "noact"])
-def test_conv_big_kernel(case, act):
-    """bf16 convs forced through conv_big_kernel (upa_conv_big_mode(2)) vs the oracle Conv (conv.py:188-197) on
+def test_conv_big_kernel(case, act, bm):
+    """bf16 convs forced through conv_big_kernel (upa_opts.conv_big = 2) vs the oracle Conv (conv.py:188-197) on
     bf16-rounded inputs: image borders (zero page), tiles that are not powers of two, ragged last tiles, partial k-tiles and
     odd chunk counts, masked output-channel columns, pointwise layers, the fused residual add (block.py:668)."""
     from tests.hip_utils import assert_bf16_close, bf16_round, bf16_weight_oracle, to_cpu_nchw, to_dev_nhwc
@@ -138,9 +140,11 @@ def test_conv_big_kernel(case, act):
     pm, _ = _mods()
     c1, c2, k, H, W, N, res = case[:7]
     st = case[7] if len(case) > 7 else 1
-    prev = L.lib().upa_conv_big_mode(2)
-    try:
-        var = L.lib().upa_conv_variant(N, H, W, c1, c2, k, st, k // 2, 1)
+    if bm == 512 and not (k == 3 and st == 1 and c2 in (64, 80)):
+        pytest.skip("512-pixel workgroups exist for the 64- and 80-channel 3x3 stride-1 forms only")
+    from ultralytics_pro_amd.engine import runtime as R
+    with R.use_opts(conv_big=2, conv_big_bm=bm):
+        var = L.lib().upa_conv_variant(N, H, W, c1, c2, k, st, k // 2, 1, R.opts_ptr())
         assert (var >> 23) & 1, "case is not dispatched to the large-tile kernel"
         o, m = _pair(om.Conv, pm.Conv, (c1, c2, k, st, None, 1, 1, act), "conv_big")
         x = bf16_round(P.uniform(f"big{case}", (N, c1, H, W), -1, 1))
@@ -148,8 +152,6 @@ def test_conv_big_kernel(case, act):
         with torch.no_grad():
             ref = bf16_weight_oracle(o)(x) + (rsd if res else 0)
             y = to_cpu_nchw(m(to_dev_nhwc(x, torch.bfloat16), residual=to_dev_nhwc(rsd, torch.bfloat16) if res else None))
-    finally:
-        L.lib().upa_conv_big_mode(prev)
     assert_bf16_close(y, ref, f"conv_big{case}")
 
 
@@ -191,15 +193,14 @@ def test_bottleneck_pair_kernel(case):
     from ultralytics_pro_amd.engine import runtime as R2
     with torch.no_grad():
         m.fuse_pair = True
-        if c == 64:  # not dispatched by default (UPA_NO_PAIR=2): call the kernel directly so the 64-channel form stays covered
+        if c == 64:  # not dispatched in production (upa_opts.pair = 0): call the kernel directly so the 64-channel form stays covered
             p1 = m.cv1._packed(m.cv1.conv, m.cv1.bn, DEV, torch.bfloat16, False)
             p2 = m.cv2._packed(m.cv2.conv, m.cv2.bn, DEV, torch.bfloat16, False)
             vx, vy = R2.view_of(xin), R2.view_of(buf[:, 2 * c:])
             rc = L.lib().upa_bottleneck_pair(vx.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, p1.w.data_ptr(), p1.bias.data_ptr(),
                                              p2.w.data_ptr(), p2.bias.data_ptr(), vy.ptr, vy.ld, int(sc), L.ACT_SILU, vx.dtype,
-                                             L.current_stream(DEV))
-            if rc == L.UPA_EUNSUPPORTED:
-                pytest.skip("64-channel pair disabled in this build (UPA_NO_PAIR)")
+                                             R2.opts_ptr(), L.current_stream(DEV))
+            assert rc != L.UPA_EUNSUPPORTED, "the 64-channel pair must be dispatched under the test options (pair = 2)"
             L.check(rc, "bottleneck_pair")
             y = to_cpu_nchw(buf[:, 2 * c:])
         else:
@@ -324,7 +325,7 @@ C2F_CASES = [
 
 @pytest.mark.parametrize("th", [0, 16, 10], ids=["auto", "th16", "th10"])
 @pytest.mark.parametrize("case", C2F_CASES, ids=[f"c{c[0]}n{c[1]}{'s' if c[2] else ''}_{c[3][0]}x{c[3][1]}x{c[3][2]}" for c in C2F_CASES])
-def test_c2f_fused_kernel(case, th, monkeypatch):
+def test_c2f_fused_kernel(case, th):
     """`upa_c2f_fused` (bf16): a whole C2f block (block.py:457-488 with the Bottlenecks of :644-668 inside) as one kernel -
     C2f(32, 32, n=1) = model.2 of yolov8n, C2f(64, 64, n=2) = its model.4, C2f(64, 64, n=1) = model.2 of yolov8s - vs the
     oracle C2f with every intermediate (cv1 output, each Bottleneck's mid tensor and output) rounded to bf16 where the
@@ -337,8 +338,6 @@ def test_c2f_fused_kernel(case, th, monkeypatch):
     c1, nb, sc, (N, H, W) = case
     if th and not (c1 == 64 and nb == 2):
         pytest.skip("the output-tile height is a choice of the C2f(64, 64, n=2) form only")
-    if th:
-        monkeypatch.setenv("UPA_C2F32_TH", str(th))  # 16 x 16 or 10 x 16 output tiles (the host picks by workgroup rounds otherwise)
     o, m = _pair(om.C2f, pm.C2f, (c1, c1, nb, sc), f"c2f_fused{c1}{nb}")
     from tests.hip_utils import assert_bf16_close, bf16_weight_oracle
     o = bf16_weight_oracle(o)
@@ -354,8 +353,9 @@ def test_c2f_fused_kernel(case, th, monkeypatch):
         buf.zero_()
         xd = to_dev_nhwc(x, torch.bfloat16)
         m.fuse_block = True
-        assert m._fused(xd, None) is not None, "the fused form was not dispatched"
-        y = to_cpu_nchw(m(xd, out=buf[:, c1:]))
+        with R.use_opts(c2f32_th=th):  # 16 x 16 (0 / 16) or 10 x 16 output tiles
+            assert m._fused(xd, None) is not None, "the fused form was not dispatched"
+            y = to_cpu_nchw(m(xd, out=buf[:, c1:]))
         m.fuse_block = False
         y2 = to_cpu_nchw(m(xd))
     scale = max(1.0, ref.abs().max().item())
@@ -374,33 +374,33 @@ C1_CASES = [
     (48, 32, 9, 7, 3, True, {}),                                     # 189 pixels: ragged last tile; Cin 48: half a k-tile
     (80, 80, 20, 20, 2, False, {}),                                  # NTW 5 (odd tail store), KTT 3 partial, no activation
     (384, 256, 10, 10, 2, True, {}),                                 # 16 n-tiles: two workgroup rows of 8; KTT 12
-    (192, 128, 12, 20, 1, True, {"UPA_C1_MT": "2", "UPA_C1_WAVES": "8"}),
-    (32, 32, 40, 48, 2, True, {"UPA_C1_MT": "4", "UPA_C1_WGS": "3"}),   # many rounds per persistent wave, ring wraps
-    (32, 16, 33, 9, 1, True, {"UPA_C1_MT": "4", "UPA_C1_WGS": "2"}),    # KTT 1: an epilogue every step (store counting)
-    (128, 192, 8, 8, 1, False, {"UPA_C1_MT": "2", "UPA_C1_WGS": "1"}),  # 12 n-tiles: second row half masked
-    (256, 128, 5, 5, 1, True, {"UPA_C1_WAVES": "4"}),                # KTT 8 = the whole ring of an MT 1 wave
-    (96, 64, 30, 30, 1, True, {"UPA_C1_MT": "1", "UPA_C1_WAVES": "4", "UPA_C1_WGS": "2"}),
+    (192, 128, 12, 20, 1, True, {"c1_mt": 2, "c1_waves": 8}),
+    (32, 32, 40, 48, 2, True, {"c1_mt": 4, "c1_wgs": 3}),   # many rounds per persistent wave, ring wraps
+    (32, 16, 33, 9, 1, True, {"c1_mt": 4, "c1_wgs": 2}),    # KTT 1: an epilogue every step (store counting)
+    (128, 192, 8, 8, 1, False, {"c1_mt": 2, "c1_wgs": 1}),  # 12 n-tiles: second row half masked
+    (256, 128, 5, 5, 1, True, {"c1_waves": 4}),                # KTT 8 = the whole ring of an MT 1 wave
+    (96, 64, 30, 30, 1, True, {"c1_mt": 1, "c1_waves": 4, "c1_wgs": 2}),
 ]
 
 
-@pytest.mark.parametrize("case", C1_CASES, ids=[f"c{c[0]}-{c[1]}_{c[2]}x{c[3]}n{c[4]}{'' if c[5] else '_lin'}{'_' + '_'.join(v for v in c[6].values()) if c[6] else ''}" for c in C1_CASES])
-def test_conv1x1_stream_kernel(case, monkeypatch):
+@pytest.mark.parametrize("case", C1_CASES, ids=[f"c{c[0]}-{c[1]}_{c[2]}x{c[3]}n{c[4]}{'' if c[5] else '_lin'}{'_' + '_'.join(str(v) for v in c[6].values()) if c[6] else ''}" for c in C1_CASES])
+def test_conv1x1_stream_kernel(case):
     """bf16 pointwise convs through the streaming kernel vs the oracle Conv (conv.py:188-197) on bf16-rounded inputs:
     ragged pixel counts, partial k-tiles, odd / split / masked output-channel tiles, every (MT, waves) shape of the
     kernel and few workgroups (many ring rounds per wave: the counted vmcnt waits)."""
     from tests.hip_utils import assert_bf16_close, bf16_round, bf16_weight_oracle, to_cpu_nchw, to_dev_nhwc
     from ultralytics_pro_amd import _lib as L
     pm, _ = _mods()
-    c1, c2, H, W, N, act, env = case
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    var = L.lib().upa_conv_variant(N, H, W, c1, c2, 1, 1, 0, 1)
-    assert (var >> 22) & 1, "case is not dispatched to the streaming 1x1 kernel"
-    o, m = _pair(om.Conv, pm.Conv, (c1, c2, 1, 1, None, 1, 1, act), "conv1x1")
-    x = bf16_round(P.uniform(f"c1{case[:5]}", (N, c1, H, W), -1, 1))
-    with torch.no_grad():
-        ref = bf16_weight_oracle(o)(x)
-        y = to_cpu_nchw(m(to_dev_nhwc(x, torch.bfloat16)))
+    from ultralytics_pro_amd.engine import runtime as R
+    c1, c2, H, W, N, act, fields = case
+    with R.use_opts(**fields) if fields else R.use_opts(R.current_opts()):
+        var = L.lib().upa_conv_variant(N, H, W, c1, c2, 1, 1, 0, 1, R.opts_ptr())
+        assert (var >> 22) & 1, "case is not dispatched to the streaming 1x1 kernel"
+        o, m = _pair(om.Conv, pm.Conv, (c1, c2, 1, 1, None, 1, 1, act), "conv1x1")
+        x = bf16_round(P.uniform(f"c1{case[:5]}", (N, c1, H, W), -1, 1))
+        with torch.no_grad():
+            ref = bf16_weight_oracle(o)(x)
+            y = to_cpu_nchw(m(to_dev_nhwc(x, torch.bfloat16)))
     assert_bf16_close(y, ref, f"conv1x1{case[:5]}")
 
 
@@ -592,7 +592,7 @@ def test_detect_tail_fused_decode_vs_oracle(nc, shape):
             vr = R.view_of(rv)
             L.check(L.lib().upa_detect_tail(vt.ptr, vt.n, vt.h, vt.w, vt.c, vt.ld, pk.w.data_ptr(), pk.bias.data_ptr(), cout, kind, nc,
                                             16.0, y.data_ptr(), a_total, a0, vr.ptr if keep_raw else None, vr.ld if keep_raw else 0,
-                                            L.UPA_BF16, L.current_stream(DEV)), "detect_tail")
+                                            L.UPA_BF16, R.opts_ptr(), L.current_stream(DEV)), "detect_tail")
         torch.cuda.synchronize()
         got = y[:, :, a0:a0 + h * w].cpu()
         d = (got - ref).abs()
@@ -649,7 +649,7 @@ def test_detect_branch_tail_vs_unfused_and_oracle(nc, c3, shape):
         L.check(L.lib().upa_detect_branch_tail(vx.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, pk3.w.data_ptr(), pk3.bias.data_ptr(),
                                                wtd.data_ptr(), btd.data_ptr(), kind, nc, 16.0, y.data_ptr(), a_total, a0,
                                                best_keys.data_ptr() if kind == 2 else None,
-                                               L.UPA_BF16, L.current_stream(DEV)), "detect_branch_tail")
+                                               L.UPA_BF16, R.opts_ptr(), L.current_stream(DEV)), "detect_branch_tail")
         # two launches
         pk3u = PackedConv(w3, b3, 3, DEV, torch.bfloat16, False)
         t = hip_conv2d(xd, pk3u, 1, 1, L.ACT_SILU)
@@ -659,7 +659,8 @@ def test_detect_branch_tail_vs_unfused_and_oracle(nc, c3, shape):
         pk1 = PackedConv(w1p, b1p, 1, DEV, torch.bfloat16, False)
         vt = R.view_of(t)
         L.check(L.lib().upa_detect_tail(vt.ptr, vt.n, vt.h, vt.w, vt.c, vt.ld, pk1.w.data_ptr(), pk1.bias.data_ptr(), cout, kind, nc,
-                                        16.0, y2.data_ptr(), a_total, a0, None, 0, L.UPA_BF16, L.current_stream(DEV)), "detect_tail")
+                                        16.0, y2.data_ptr(), a_total, a0, None, 0, L.UPA_BF16, R.opts_ptr(), L.current_stream(DEV)),
+                "detect_tail")
     torch.cuda.synchronize()
     got, two = y[:, :, a0:a0 + h * w].cpu(), y2[:, :, a0:a0 + h * w].cpu()
     d = (got - two).abs()

@@ -168,6 +168,21 @@ def test_e2e_detect(name, golden_dir):
     assert np.abs(torch.cat(out, 0).numpy() - g["predict_rows"]).max() <= 1e-3
 
 
+def test_e2e_detect_smooth_family(golden_dir):
+    """The "smooth" weight family (utils/procedural.py SMOOTH_RECIPE) is pinned the same way: the oracle on those weights
+    equals the imported reference's recorded output (tests/golden/e2e_yolov8n_smooth.npz)."""
+    g = np.load(golden_dir / "e2e_yolov8n_smooth.npz")
+    m = ot.DetectionModel("yolov8n.yaml")
+    P.apply_procedural_weights(m, family="smooth:yolov8n")
+    m.fuse()
+    with torch.no_grad():
+        y = m(P.synthetic_images(2))[0]
+    assert np.abs(y[:, :, g["anchor_sel"]].numpy() - g["y_sel"]).max() <= 1e-4
+    out = onms.non_max_suppression(y, conf_thres=0.25, iou_thres=0.7, max_det=300)
+    assert [o.shape[0] for o in out] == list(g["predict_n"])
+    assert np.abs(torch.cat(out, 0).numpy() - g["predict_rows"]).max() <= 1e-3
+
+
 def test_e2e_rtdetr(golden_dir):
     g = np.load(golden_dir / "e2e_yolov3-rtdetr.npz")
     m = ot.DetectionModel("yolov3-rtdetr.yaml")

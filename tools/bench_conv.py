@@ -25,11 +25,14 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="", help="cin,cout,k,H filter, e.g. 64,64,3,80")
-    ap.add_argument("--big-mode", type=int, default=-1, help="upa_conv_big_mode: 0 never, 1 size rule, 2 every eligible shape")
+    ap.add_argument("--big-mode", type=int, default=-1, help="upa_opts.conv_big: 0 size rule, 1 never, 2 every eligible shape")
+    ap.add_argument("--opts", default="env", help="upa_opts fields as name=value,... or `env` (UPA_* variables, the default)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
+    opts = L.Opts.from_env() if args.opts == "env" else L.Opts(**{k: int(v) for k, v in (kv.split("=") for kv in args.opts.split(","))})
     if args.big_mode >= 0:
-        L.lib().upa_conv_big_mode(args.big_mode)
+        opts.conv_big = args.big_mode
+    R.set_default_opts(opts)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     es = 2 if dtype == torch.bfloat16 else 4
     m = DetectionModel(args.model + ".yaml")
@@ -85,7 +88,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.iters
-        var = -1 if pk.stem else L.lib().upa_conv_variant(n, h, w, cin, pk.cout, pk.k, stride, pad, L.dtype_code(dtype))
+        var = -1 if pk.stem else L.lib().upa_conv_variant(n, h, w, cin, pk.cout, pk.k, stride, pad, L.dtype_code(dtype), R.opts_ptr())
         key = (cin, pk.cout, pk.k, stride, h, w, residual is not None, var)
         d = agg.setdefault(key, [0, 0.0, fl, by])
         d[0] += 1

@@ -1,5 +1,5 @@
 #!/bin/bash
-b() { echo "$* : $(env "$@" python bench.py --no-cpu-baseline --no-kernel-profile 2>/dev/null | grep -o '"ms_per_step": [0-9.]*' | head -1)  serial $(env "$@" python bench.py --serial --no-cpu-baseline --no-kernel-profile 2>/dev/null | grep -o '"ms_per_step": [0-9.]*' | head -1)"; }
+b() { echo "$* : $(env "$@" python bench.py --opts env --no-cpu-baseline --no-kernel-profile 2>/dev/null | grep -o '"ms_per_step": [0-9.]*' | head -1)  serial $(env "$@" python bench.py --opts env --serial --no-cpu-baseline --no-kernel-profile 2>/dev/null | grep -o '"ms_per_step": [0-9.]*' | head -1)"; }
 b A=1
 b UPA_CONV_CKT=1
 b UPA_CONV_CKT=2

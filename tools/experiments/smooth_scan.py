@@ -17,11 +17,10 @@ box_gain = float(sys.argv[5]) if len(sys.argv) > 5 else 2.0
 res_gain = float(sys.argv[6]) if len(sys.argv) > 6 else 0.3
 x = P.synthetic_images(2)
 for g in gains:
-    P.CONV_GAIN2 = g
-    P.RES_GAIN2 = res_gain
-    P.HEAD_RECIPE["scan"] = (cls_gain, 0.0, box_gain)
+    P.SMOOTH_RECIPE["scan"] = (g, cls_gain, 0.0, box_gain)
+    P.SMOOTH_DFL_SLOPE = res_gain  # (7th argument reused: DFL bias slope)
     m = ot.DetectionModel(name + ".yaml")
-    P.apply_procedural_weights(m, family="scan")
+    P.apply_procedural_weights(m, family="smooth:scan")
     m.eval()
     with torch.no_grad():
         y = m(x)[0]
@@ -30,9 +29,9 @@ for g in gains:
     mx = logit.max(1).values.flatten()
     thr = float(torch.quantile(mx, 1 - target_above))
     shift = float(np.log(0.25 / 0.75)) - thr
-    P.HEAD_RECIPE["scan"] = (cls_gain, round(shift, 2), box_gain)
+    P.SMOOTH_RECIPE["scan"] = (g, cls_gain, round(shift, 2), box_gain)
     m = ot.DetectionModel(name + ".yaml")
-    P.apply_procedural_weights(m, family="scan")
+    P.apply_procedural_weights(m, family="smooth:scan")
     m.eval()
     with torch.no_grad():
         y = m(x)[0]
@@ -40,6 +39,15 @@ for g in gains:
     ref = [o.numpy() for o in onms.non_max_suppression(y, 0.25, 0.7, max_det=300)]
     mine = [o.numpy() for o in onms.non_max_suppression(yb, 0.25, 0.7, max_det=300)]
     a9, a5 = detection_agreement(mine, ref, 0.9), detection_agreement(mine, ref, 0.5)
+    # threshold-band-excluded agreement: rows whose score lies within +-band of conf are not counted on either side
+    band = 0.005
+    def drop(rows_a, rows_b):
+        return [a[np.abs(a[:, 4] - 0.25) > band] for a in rows_a], rows_b
+    refx = [r[np.abs(r[:, 4] - 0.25) > band] for r in ref]
+    minex = [r[np.abs(r[:, 4] - 0.25) > band] for r in mine]
+    rec = detection_agreement(mine, refx, 0.9)["recall"]      # reference rows outside the band must be found
+    prec = detection_agreement(minex, ref, 0.9)["precision"]  # my rows outside the band must exist in the reference
+    print(f"   band-excluded (+-{band}): recall {rec:.4f} precision {prec:.4f}; rows in band ref {sum(len(r) for r in ref) - sum(len(r) for r in refx)} mine {sum(len(r) for r in mine) - sum(len(r) for r in minex)}")
     d = (y - yb).abs()
     lg = torch.logit(y[:, 4:].clamp(1e-7, 1 - 1e-7))
     box = y[:, :4]

@@ -1,6 +1,6 @@
 #!/bin/bash
 # persistent-kernel grid sizes vs throughput of the pipelined default run
-b() { echo "$* : $(env "$@" python bench.py --no-cpu-baseline --no-kernel-profile 2>/dev/null | grep -o '"value": [0-9.]*' | head -1)"; }
+b() { echo "$* : $(env "$@" python bench.py --opts env --no-cpu-baseline --no-kernel-profile 2>/dev/null | grep -o '"value": [0-9.]*' | head -1)"; }
 b A=1
 b A=1
 b UPA_PIPE_WGS=128

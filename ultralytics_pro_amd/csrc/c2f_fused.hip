@@ -466,9 +466,9 @@ __global__ __launch_bounds__(1024) void c2f32_fused_kernel(const C2f32Params p) 
 // (c -> c); w2 / b2: cv2 (1x1, (2 + nb) c -> c2) - all packed by upa_pack_conv_weight(bf16) with BN folded; y: (n, h, w, c2).
 extern "C" int upa_c2f_fused(const void* x, int n, int h, int w, int c1, int ldx, int c, int nb, int shortcut, const void* w1,
                              const float* b1, const void* const* wm, const float* const* bm, const void* w2, const float* b2,
-                             void* y, int c2, int ldy, int act, int dtype, void* stream) {
+                             void* y, int c2, int ldy, int act, int dtype, const upa_opts* opts, void* stream) {
   UPA_CHECK_ARG(x && y && w1 && b1 && wm && bm && w2 && b2 && n > 0 && h > 0 && w > 0 && nb >= 1, "c2f_fused: bad args");
-  static const int off = getenv("UPA_NO_C2F") ? atoi(getenv("UPA_NO_C2F")) : 0;  // 1: never, 2: not the 16-wide, 3: not the 32-wide
+  const int off = UPA_OPT(opts, c2f);  // 1: never, 2: not the 16-wide, 3: not the 32-wide
   const bool f16 = c1 == 32 && c == 16 && c2 == 32 && nb == 1 && shortcut && off != 2;
   const bool f32 = c1 == 64 && c == 32 && c2 == 64 && (nb == 1 || nb == 2) && off != 3;
   if (off == 1 || dtype != UPA_BF16 || act != UPA_ACT_SILU || !(f16 || f32) || ldx % 8 != 0 || ldy % 8 != 0 ||
@@ -488,7 +488,7 @@ extern "C" int upa_c2f_fused(const void* x, int n, int h, int w, int c1, int ldx
     p.w1 = (const char*)w1; p.wa = (const char*)wm[0]; p.wb = (const char*)wm[1]; p.w2 = (const char*)w2;
     p.b1 = b1; p.ba = bm[0]; p.bb = bm[1]; p.b2 = b2;
     p.N = n; p.H = h; p.W = w; p.ldx = ldx; p.ldy = ldy; p.tilesX = tx; p.tilesY = ty;
-    static const int nw = getenv("UPA_C2F16_WAVES") ? atoi(getenv("UPA_C2F16_WAVES")) : 4;
+    const int nw = UPA_OPT(opts, c2f16_waves) == 8 ? 8 : 4;
     if (nw == 4) hipLaunchKernelGGL(c2f16_fused_kernel<4>, dim3((unsigned)tiles), dim3(256), c2f::LDS, s, p);
     else hipLaunchKernelGGL(c2f16_fused_kernel<8>, dim3((unsigned)tiles), dim3(512), c2f::LDS, s, p);
     UPA_LAUNCH_CHECK();
@@ -507,11 +507,10 @@ extern "C" int upa_c2f_fused(const void* x, int n, int h, int w, int c1, int ldx
     return b;
   };
   if (nb == 2) {
-    // 10-row tiles only on request (UPA_C2F32_TH=10): measured 80.1 against 83 us for model.4 alone and 0.636 against 0.626 ms
+    // 10-row tiles only on request (upa_opts.c2f32_th = 10): measured 80.1 against 83 us for model.4 alone and 0.636 against 0.626 ms
     // per step with four steps in flight - a tile's time is set by its six barrier-separated stages and the DMA wait more than
     // by its (m-tile, n-tile) unit count (222 against 354), so five balanced rounds do not beat 3.125 ragged ones
-    const char* fe = getenv("UPA_C2F32_TH");  // read per call: the parity tests run both tilings in one process
-    const bool th10 = fe && atoi(fe) == 10;
+    const bool th10 = UPA_OPT(opts, c2f32_th) == 10;
     p.tilesY = th10 ? cdiv(h, 10) : cdiv(h, 16);
     tiles = (long)tx * p.tilesY * n;
     if (th10) {

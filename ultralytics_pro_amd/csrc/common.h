@@ -14,6 +14,19 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 typedef unsigned short bf16_t;  // raw bf16 bits
 
+// A field of the caller's upa_opts (NULL, or shorter than this header's struct: 0 = the default)
+#include <stddef.h>
+#define UPA_OPT(o, field) \
+  (((o) != nullptr && (o)->size >= offsetof(upa_opts, field) + sizeof((o)->field)) ? (int)(o)->field : 0)
+
+// Kernel ablation switches (no loads / no MFMA / no stores ...: tools/experiments/ablate_sweep.sh) exist only in the
+// -DUPA_ABLATE build (`make ablate` -> libupa_hip_ablate.so); the product kernels carry neither the tests nor the field.
+#ifdef UPA_ABLATE
+#define UPA_ABL(p, bits) ((p).ablate & (bits))
+#else
+#define UPA_ABL(p, bits) (0)
+#endif
+
 void upa_set_error(const char* fmt, ...);
 
 #define UPA_CHECK_ARG(cond, ...)      \

@@ -47,7 +47,10 @@ struct ConvParams {
   int stageRows;     // halo rows covered per staging pass = NTHREADS / (IW * G16) (>= 1)
   int numTiles;      // ws kernel: spatial tiles in total (over all images)
   int wsNTB;         // ws kernel: n-tiles per workgroup
-  int ablate;        // debug: 1 = no input loads, 2 = no weight loads, 4 = no stores, 8 = no MFMA
+#ifdef UPA_ABLATE
+  int ablate;        // debug build only: 1 = no input loads, 2 = no weight loads, 4 = no stores, 8 = no MFMA, 32 = return at once
+#endif
+  const upa_opts* opts;  // HOST side only (dispatch overrides of this call); never read by a kernel
 };
 
 // 16 zero bytes in device memory: source of every out-of-image / padded-channel 16-byte group of the halo DMA
@@ -73,7 +76,7 @@ __device__ __forceinline__ float act_fn(float v) {
 template <typename T, int WM, int WN, int MTW, int NTW, int CKT>
 __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  if (p.ablate & 32) return;  // debug: launch + workgroup dispatch only
+  if UPA_ABL(p, 32) return;  // debug: launch + workgroup dispatch only
   constexpr int ES = sizeof(T);
   constexpr int E = 16 / ES;      // elements per 16 bytes
   constexpr int KT_CH = 64 / ES;  // channels per k-tile
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
   // n-tiles past the packed weights (Cout 80 run as 96) contribute zeros; the common case - every n-tile of the wave
   // exists - is decided once, so a tap's fragment loads are straight-line code (the per-fragment test compiled into a
   // uniform branch and a block of register moves per load)
-  const bool wfull = nt0 + NTW <= p.NTn && !(p.ablate & 2);
+  const bool wfull = nt0 + NTW <= p.NTn && !UPA_ABL(p, 2);
   auto fetch_tap = [&](u32x4(&dst)[CKT][NTW], int c, int tap) {
     const char* wb = wuni + (size_t)(tap * p.KTT + c * CKT) * wTileStride;
     if (wfull) {
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
 #pragma unroll
         for (int j = 0; j < NTW; ++j) dst[kt][j] = *reinterpret_cast<const u32x4*>(wb + kt * wTileStride + j * 1024 + lane16);
     } else {
-      if (p.ablate & 2) return;
+      if UPA_ABL(p, 2) return;
 #pragma unroll
       for (int kt = 0; kt < CKT; ++kt)
 #pragma unroll
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
   // LDS halo image: pixel-major, G16 16-byte slots per pixel, NO padding (the DMA writes 1 KiB contiguous per wave);
   // the 16-byte group cg of pixel pl sits in slot cg ^ swz(pl): conflict-free ds_read_b128 for CKT 1 / 2 (2-way CKT 4)
   auto compute_tap = [&](u32x4(&A)[CKT][NTW], int tapshift) {
-    if (p.ablate & 8) return;
+    if UPA_ABL(p, 8) return;
     int paddr[MTW], pswz[MTW];
 #pragma unroll
     for (int i = 0; i < MTW; ++i) {
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
         const int iy = iy0 + py, ix = ix0 + px;
         const int ch = c0 + cg * E;
         const char* src = reinterpret_cast<const char*>(g_zero16);
-        if (idx < haloItems && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && ch < p.Cin && !(p.ablate & 1))
+        if (idx < haloItems && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && ch < p.Cin && !UPA_ABL(p, 1))
           src = p.x + ((((size_t)n * p.H + iy) * p.W + ix) * (size_t)p.ldx + ch) * ES;
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + wbase * 16), 16, 0, 0);
       }
@@ -277,17 +280,17 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
   // ---- bf16 epilogue straight from the accumulators (as conv_pipe.hip): bias, activation, bf16 pack, a
   // v_permlane16_swap pairs neighbouring channel quads so every lane stores 16 contiguous bytes (64 B per pixel per
   // instruction); the residual is read with the same shape.  No LDS round trip, no barrier, and the workgroup needs LDS
-  // for its halo only (one more co-resident workgroup per CU on most layers).  UPA_CONV_LDS_EPILOGUE=1 (p.ablate bit 6)
-  // keeps the two-phase LDS form below, which the f32 parity mode always uses.
+  // for its halo only (one more co-resident workgroup per CU on most layers).  The f32 parity mode uses the two-phase
+  // LDS form below.
   if constexpr (ES == 2) {
-    if (!(p.ablate & 64)) {
+    if (true) {
       auto direct = [&](auto act_tag) __attribute__((always_inline)) {
         constexpr int ACT = decltype(act_tag)::value;
         const int cw = (blockIdx.y * WN + wn) * NTW * 16;  // first channel of this wave
 #pragma unroll
         for (int i = 0; i < MTW; ++i) {
           const int oy = oy0 + pty[i], ox = ox0 + ptx[i];
-          const bool pok = pty[i] < p.TH && oy < p.OH && ox < p.OW && !(p.ablate & 4);
+          const bool pok = pty[i] < p.TH && oy < p.OH && ox < p.OW && !UPA_ABL(p, 4);
           const size_t pixoff = ((size_t)n * p.OH + oy) * p.OW + ox;
           char* yrow = p.y + (pixoff * p.ldy + cw) * 2;
           const char* rrow = p.res ? p.res + (pixoff * p.ldr + cw) * 2 : nullptr;
@@ -386,7 +389,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
       const int ty = pp >> p.tw_shift, tx = pp & (p.TW - 1);
       const int oy = oy0 + ty, ox = ox0 + tx;
       const int co = cbase + gq * E;
-      if (ty >= p.TH || oy >= p.OH || ox >= p.OW || co >= p.Cout || (p.ablate & 4)) continue;
+      if (ty >= p.TH || oy >= p.OH || ox >= p.OW || co >= p.Cout || UPA_ABL(p, 4)) continue;
       const size_t pixoff = ((size_t)n * p.OH + oy) * p.OW + ox;
       const float* src = otile + pp * OROW + gq * E;
       if constexpr (ES == 4) {
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvParam
 template <typename T, int WM, int WN, int MTW, int NTW, int KTT>
 __global__ __launch_bounds__(WM* WN * 64) void conv_ws_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  if (p.ablate & 32) return;  // debug: launch + workgroup dispatch only
+  if UPA_ABL(p, 32) return;  // debug: launch + workgroup dispatch only
   constexpr int ES = sizeof(T);
   constexpr int E = 16 / ES;
   constexpr int NTHREADS = WM * WN * 64;
@@ -698,10 +701,8 @@ int launch_conv_ckt(ConvParams& p, hipStream_t stream) {
   p.stageRows = (WM * WN * 64) / (p.IW * CKT * 4);
   if (p.stageRows < 1) p.stageRows = 1;  // halo row wider than the workgroup: threads stride over its columns
   size_t lds = (((size_t)IHalloc * p.IW * (p.CKT * 4) + 63) & ~(size_t)63) * 16 + 1024;
-  static const bool lds_epilogue = getenv("UPA_CONV_LDS_EPILOGUE") != nullptr;
-  if (lds_epilogue) p.ablate |= 64;
   const size_t ldsOut = (size_t)BM * (BN + 4) * sizeof(float);
-  if ((sizeof(T) == 4 || lds_epilogue) && ldsOut > lds) lds = ldsOut;  // the bf16 epilogue does not go through LDS
+  if (sizeof(T) == 4 && ldsOut > lds) lds = ldsOut;  // the bf16 epilogue does not go through LDS
   if (lds > 160 * 1024) return UPA_EUNSUPPORTED;
   dim3 grid((unsigned)((long)p.tilesX * p.tilesY * p.N), (unsigned)cdiv(p.NTn * 16, BN));
   auto kern = conv_igemm_kernel<T, WM, WN, MTW, NTW, CKT>;
@@ -799,8 +800,7 @@ int dispatch_ws_ktt(ConvParams p, hipStream_t stream) {  // p by value: launch_w
 
 template <typename T>
 int dispatch_ws(const ConvParams& p, hipStream_t stream) {
-  static const int off = getenv("UPA_CONV_NO_WS") ? atoi(getenv("UPA_CONV_NO_WS")) : 0;
-  if (off) return UPA_EUNSUPPORTED;
+  if (UPA_OPT(p.opts, no_ws)) return UPA_EUNSUPPORTED;
   if (p.KS != 3 || p.stride != 1) return UPA_EUNSUPPORTED;  // 1x1 and stride-2 layers measured faster on the igemm kernel
   if (p.KTT == 1) return dispatch_ws_ktt<T, 1>(p, stream);
   if (p.KTT == 2) return dispatch_ws_ktt<T, 2>(p, stream);
@@ -808,15 +808,15 @@ int dispatch_ws(const ConvParams& p, hipStream_t stream) {
   return UPA_EUNSUPPORTED;
 }
 
-// Tuning hook (development): UPA_CONV_FORCE="WM,WN,MTW,NTW" forces one of the extra bf16 instantiations below for every
-// conv whose Cout fits it; used by tools/bench_conv.py sweeps, never set in production.
+// Tuning hook (development): upa_opts.conv_force = {WM, WN, MTW, NTW} forces one of the extra bf16 instantiations below for
+// every conv whose Cout fits it; used by tools/bench_conv.py sweeps, never set in production.
 template <typename T>
 int dispatch_forced(ConvParams& p, hipStream_t stream) {
   if constexpr (sizeof(T) == 2) {
-    static const char* f = getenv("UPA_CONV_FORCE");
-    if (!f) return UPA_EUNSUPPORTED;
-    int wm = 0, wn = 0, mt = 0, nt = 0;
-    if (sscanf(f, "%d,%d,%d,%d", &wm, &wn, &mt, &nt) != 4) return UPA_EUNSUPPORTED;
+    const upa_opts* o = p.opts;
+    if (!o || o->size < offsetof(upa_opts, conv_force) + sizeof(o->conv_force) || o->conv_force[0] == 0) return UPA_EUNSUPPORTED;
+    const int wm = o->conv_force[0], wn = o->conv_force[1], mt = o->conv_force[2], nt = o->conv_force[3];
+    if (wn <= 0 || nt <= 0) return UPA_EUNSUPPORTED;
     if (p.NTn % (wn * nt) != 0 && p.NTn > wn * nt) return UPA_EUNSUPPORTED;
     if (p.NTn < wn * nt) return UPA_EUNSUPPORTED;
 #define UPA_TRY(A, B, C, D) if (wm == A && wn == B && mt == C && nt == D) return launch_conv<T, A, B, C, D>(p, stream);
@@ -843,8 +843,6 @@ int dispatch_conv(ConvParams& p, hipStream_t stream) {
   if (ntn == 2) return launch_conv<T, 4, 1, 2, 2>(p, stream);                     // BN=32,  BM=128
   if (ntn == 3) return launch_conv<T, 4, 1, 2, 3>(p, stream);                     // BN=48
   if (ntn == 5) {  // Cout = 80 (Detect class branch): run as 96 = 2 x 3 n-tiles, the 6th tile is zero-filled
-    static const int old5 = getenv("UPA_CONV_OLD5") ? atoi(getenv("UPA_CONV_OLD5")) : 0;
-    if (old5) return launch_conv<T, 4, 1, 2, 5>(p, stream);
     if (M >= 128 * 1024) return launch_conv<T, 2, 2, 4, 3>(p, stream);            // BN=96, BM=128
     return launch_conv<T, 2, 2, 2, 3>(p, stream);                                 // BN=96, BM=64
   }
@@ -859,24 +857,25 @@ int dispatch_conv(ConvParams& p, hipStream_t stream) {
 }  // namespace
 
 extern "C" int upa_conv2d_bias_act(const void*, int, int, int, int, int, const void*, const float*, void*, int, int,
-                                   const void*, int, int, int, int, int, int, void*);
+                                   const void*, int, int, int, int, int, int, const upa_opts*, void*);
 
 // Which template instantiation (WM<<12 | WN<<8 | MTW<<4 | NTW) upa_conv2d_bias_act would launch for this problem;
 // lets bench.py attribute algorithmic FLOPs to the kernel names rocprofv3 reports.
-extern "C" int upa_conv_variant(int n, int h, int w, int cin, int cout, int k, int stride, int pad, int dtype) {
+extern "C" int upa_conv_variant(int n, int h, int w, int cin, int cout, int k, int stride, int pad, int dtype,
+                                const upa_opts* opts) {
   static char dummy[64];
   g_query_only = 1;
   g_last_variant = 0;
   const int E = 16 / upa_elem_size(dtype);
   int rc = upa_conv2d_bias_act(dummy, n, h, w, cin, (cin + E - 1) / E * E, dummy, nullptr, dummy, cout, cout, nullptr, 0, k,
-                               stride, pad, 0, dtype, nullptr);
+                               stride, pad, 0, dtype, opts, nullptr);
   g_query_only = 0;
   return rc == UPA_OK ? g_last_variant : rc;
 }
 
 extern "C" int upa_conv2d_bias_act(const void* x, int n, int h, int w, int cin, int ldx, const void* w_packed,
                                    const float* bias, void* y, int cout, int ldy, const void* residual, int ldr, int k,
-                                   int stride, int pad, int act, int dtype, void* stream) {
+                                   int stride, int pad, int act, int dtype, const upa_opts* opts, void* stream) {
   UPA_CHECK_ARG(x && w_packed && y, "conv2d: null pointer");
   UPA_CHECK_ARG(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, "conv2d: bad shape");
   UPA_CHECK_ARG(k >= 1 && k <= 7 && stride >= 1 && stride <= 2 && pad >= 0 && pad < k, "conv2d: unsupported k/s/p");
@@ -888,7 +887,7 @@ extern "C" int upa_conv2d_bias_act(const void* x, int n, int h, int w, int cin, 
                 "conv2d: cout/ldy/ldr must be multiples of %d elements (16-byte row stores)", E);
   UPA_CHECK_ARG(g_query_only || (((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) &&
                                  (!residual || (uintptr_t)residual % 16 == 0)), "conv2d: misaligned view");
-  if (upa_conv_big_eligible(n, h, w, cin, ldx, cout, ldy, residual ? ldr : 0, k, stride, pad, act, dtype)) {
+  if (upa_conv_big_eligible(n, h, w, cin, ldx, cout, ldy, residual ? ldr : 0, k, stride, pad, act, dtype, opts)) {
     BigParams q;
     memset(&q, 0, sizeof(q));
     q.x = (const char*)x; q.y = (char*)y; q.res = (const char*)residual; q.w = (const char*)w_packed; q.bias = bias;
@@ -896,22 +895,22 @@ extern "C" int upa_conv2d_bias_act(const void* x, int n, int h, int w, int cin, 
     q.OH = (h + 2 * pad - k) / stride + 1;
     q.OW = (w + 2 * pad - k) / stride + 1;
     q.KS = k; q.stride = stride; q.pad = pad; q.act = act;
-    const int rc = upa_conv_big_launch(q, g_query_only, &g_last_variant, stream);
+    const int rc = upa_conv_big_launch(q, g_query_only, &g_last_variant, stream, opts);
     if (rc != UPA_EUNSUPPORTED) return rc;
   }
-  if (upa_conv_pipe_eligible(n, h, w, cin, ldx, cout, ldy, residual ? ldr : 0, k, stride, pad, act, dtype)) {
+  if (upa_conv_pipe_eligible(n, h, w, cin, ldx, cout, ldy, residual ? ldr : 0, k, stride, pad, act, dtype, opts)) {
     PipeParams q;
     memset(&q, 0, sizeof(q));
     q.x = (const char*)x; q.y = (char*)y; q.res = (const char*)residual; q.w = (const char*)w_packed; q.bias = bias;
     q.N = n; q.H = h; q.W = w; q.Cin = cin; q.ldx = ldx; q.Cout = cout; q.ldy = ldy; q.ldr = ldr; q.act = act;
-    return upa_conv_pipe_launch(q, g_query_only, &g_last_variant, stream);
+    return upa_conv_pipe_launch(q, g_query_only, &g_last_variant, stream, opts);
   }
-  if (upa_conv1x1_eligible(n, h, w, cin, ldx, cout, ldy, residual != nullptr, k, stride, pad, act, dtype)) {
+  if (upa_conv1x1_eligible(n, h, w, cin, ldx, cout, ldy, residual != nullptr, k, stride, pad, act, dtype, opts)) {
     C1Params q;
     memset(&q, 0, sizeof(q));
     q.x = (const char*)x; q.y = (char*)y; q.w = (const char*)w_packed; q.bias = bias;
     q.Cin = cin; q.ldx = ldx; q.Cout = cout; q.ldy = ldy; q.act = act;
-    return upa_conv1x1_launch(q, n * h * w, g_query_only, &g_last_variant, stream);
+    return upa_conv1x1_launch(q, n * h * w, g_query_only, &g_last_variant, stream, opts);
   }
   ConvParams p;
   memset(&p, 0, sizeof(p));
@@ -921,8 +920,10 @@ extern "C" int upa_conv2d_bias_act(const void* x, int n, int h, int w, int cin, 
   p.OW = (w + 2 * pad - k) / stride + 1;
   p.Cout = cout; p.ldy = ldy; p.ldr = ldr;
   p.KS = k; p.stride = stride; p.pad = pad; p.act = act;
-  static const int ablate = getenv("UPA_CONV_ABLATE") ? atoi(getenv("UPA_CONV_ABLATE")) : 0;
-  p.ablate = ablate;
+  p.opts = opts;
+#ifdef UPA_ABLATE
+  p.ablate = UPA_OPT(opts, ablate_conv);
+#endif
   const int ktch = 64 / es;
   p.KTT = cdiv(cin, ktch);
   p.NTn = cdiv(cout, 16);
@@ -932,19 +933,7 @@ extern "C" int upa_conv2d_bias_act(const void* x, int n, int h, int w, int cin, 
   int ckt = (p.KTT % 4 == 0) ? 4 : ((p.KTT % 2 == 0) ? 2 : 1);
   if ((stride == 2 || p.NTn == 5 || p.NTn == 3) && ckt > 2) ckt = 2;
   if (k > 3 && ckt > 1) ckt = 1;
-  {
-    // Tuning knob, off by default: UPA_CONV_CKT2_MAXPX=<pixels> caps the chunk at 2 k-tiles for layers with at most that
-    // many output pixels.  4 k-tiles win a layer timed alone (fewer barriers: serial step 1.512 vs 1.544 ms); 2 leave room
-    // for a co-resident workgroup: 0.948 vs 0.960 ms per step with four steps in flight, 15.19 vs 15.42 ms per yolov8s
-    // training step.  Not the default: the different summation order moves the bf16 training losses of the yolov8n golden
-    // test from 10 % to 13 % off the f32 reference (assigner flips), past that test's statistical bound.
-    static const long ckt2_maxpx = getenv("UPA_CONV_CKT2_MAXPX") ? atol(getenv("UPA_CONV_CKT2_MAXPX")) : 0;
-    if (ckt == 4 && (long)n * p.OH * p.OW <= ckt2_maxpx) ckt = 2;
-  }
-  if (const char* e = getenv("UPA_CONV_CKT")) {  // tuning override (must still divide KTT)
-    const int v = atoi(e);
-    if ((v == 1 || v == 2 || v == 4) && p.KTT % v == 0 && v <= ckt) ckt = v;
-  }
+  if (const int v = UPA_OPT(opts, conv_ckt); (v == 1 || v == 2 || v == 4) && p.KTT % v == 0 && v <= ckt) ckt = v;  // tuning override
   p.CKT = ckt;
   hipStream_t s = (hipStream_t)stream;
   int rc = dtype == UPA_BF16 ? dispatch_conv<bf16_t>(p, s) : dispatch_conv<float>(p, s);

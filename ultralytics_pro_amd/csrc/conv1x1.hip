@@ -61,7 +61,7 @@ __device__ __forceinline__ void vm_wait(int n) {
 template <int NTW, int MT, int WAVES, int EPI = 0>
 __global__ __launch_bounds__(WAVES * 64) void conv1x1_stream_kernel(const C1Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  if (p.ablate & 32) return;  // debug: launch + workgroup dispatch only
+  if UPA_ABL(p, 32) return;  // debug: launch + workgroup dispatch only
   constexpr int RING = ring_of(MT);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_stream_kernel(const C1Para
       const char* xk = (fromUp ? p.up : p.x) + ikt * 64;
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        const char* src = (chok && ioff[i] != 0xffffffffu && !(p.ablate & 1)) ? xk + (fromUp ? uoff[i] : ioff[i])
+        const char* src = (chok && ioff[i] != 0xffffffffu && !UPA_ABL(p, 1)) ? xk + (fromUp ? uoff[i] : ioff[i])
                                                                             : reinterpret_cast<const char*>(g_c1_zero16);
         __builtin_amdgcn_global_load_lds((c1gptr_t)src, (c1lptr_t)(ring + (stage * MT + i) * 1024), 16, 0, 0);
       }
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_stream_kernel(const C1Para
       const int tb = (g * MT + i) * 16;  // uniform
       if (tb >= p.P) continue;
       const int pix = tb + p16;
-      const bool pok = pix < p.P && !(p.ablate & 4);
+      const bool pok = pix < p.P && !UPA_ABL(p, 4);
       if constexpr (EPI == 1) {  // Detect box branch: DFL + dist2bbox + stride on the accumulators (detect_epi.h)
         static_assert(EPI != 1 || NTW == 4, "box branch = 4 sides x 16 bins");
         f32x4 v[4];
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_stream_kernel(const C1Para
     // stores per epilogue in steady state: bf16 rows (two n-tiles per 16-byte store) / one box row / one f32 row per class
     constexpr int SE = EPI == 0 ? MT * ((NTW + 1) / 2) : (EPI == 1 ? MT : MT * 4 * NTW);
     vm_wait<(RING - 1) * MT, SE>(seq - mark[S]);
-    if (!(p.ablate & 8)) {
+    if (!UPA_ABL(p, 8)) {
       const char* st = ring + S * MT * 1024 + lane * 16;
       const char* wk = wl + ckt * (NTW * 1024) + lane * 16;
       u32x4 b[MT], a[NTW];
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_stream_kernel(const C1Para
   for (int q = wave; q < p.KTT * NTW; q += WAVES) {
     const int kt = q / NTW, j = q - kt * NTW;
     const char* src = reinterpret_cast<const char*>(g_c1_zero16);
-    if (nt0 + j < p.NTn && !(p.ablate & 2)) src = p.w + ((size_t)(kt * p.NTn + nt0 + j) * 1024 + lane * 16);
+    if (nt0 + j < p.NTn && !UPA_ABL(p, 2)) src = p.w + ((size_t)(kt * p.NTn + nt0 + j) * 1024 + lane * 16);
     __builtin_amdgcn_global_load_lds((c1gptr_t)src, (c1lptr_t)(wl + q * 1024), 16, 0, 0);
   }
   // bias slice -> LDS (read back per epilogue: keeps NTW*4 registers free for the accumulators)
@@ -282,17 +282,11 @@ int launch_c1_ntw(const C1Params& p, int mt, int waves, dim3 grid, size_t lds, h
   return launch_c1_inst<NTW, 1, 4, EPI>(p, grid, lds, s);
 }
 
-int env_int(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
-
 }  // namespace
 
 bool upa_conv1x1_eligible(int n, int h, int w, int cin, int ldx, int cout, int ldy, bool residual, int k, int stride,
-                          int pad, int act, int dtype) {
-  static const bool off = getenv("UPA_CONV_NO_1X1") != nullptr;
-  if (off) return false;
+                          int pad, int act, int dtype, const upa_opts* opts) {
+  if (UPA_OPT(opts, no_1x1)) return false;
   if (dtype != UPA_BF16 || k != 1 || stride != 1 || pad != 0 || residual) return false;
   if (act != UPA_ACT_SILU && act != UPA_ACT_NONE) return false;
   if (cin % 8 != 0 || cout % 8 != 0 || ldx % 8 != 0 || ldy % 8 != 0) return false;
@@ -304,12 +298,13 @@ bool upa_conv1x1_eligible(int n, int h, int w, int cin, int ldx, int cout, int l
   return true;
 }
 
-int upa_conv1x1_launch(C1Params p, int n_pixels, int query_only, int* variant, void* stream) {
+int upa_conv1x1_launch(C1Params p, int n_pixels, int query_only, int* variant, void* stream, const upa_opts* opts) {
   p.P = n_pixels;
   p.KTT = (p.Cin + 31) / 32;
   p.NTn = (p.Cout + 15) / 16;
-  static const int ablate = env_int("UPA_C1_ABLATE", 0);
-  p.ablate = ablate;
+#ifdef UPA_ABLATE
+  p.ablate = UPA_OPT(opts, ablate_c1);
+#endif
   const int ntw = p.NTn > 8 ? 8 : p.NTn;
   const int gridY = (p.NTn + ntw - 1) / ntw;
   const size_t wbytes = (size_t)p.KTT * ntw * 1024;
@@ -321,7 +316,7 @@ int upa_conv1x1_launch(C1Params p, int n_pixels, int query_only, int* variant, v
     if (hipDeviceGetAttribute(&numCU, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || numCU <= 0) numCU = 256;
   }
   // pixel tiles per wave and step: enough groups that every SIMD of the chip has a few to pipeline
-  const int f_mt = env_int("UPA_C1_MT", 0), f_waves = env_int("UPA_C1_WAVES", 0), f_wgs = env_int("UPA_C1_WGS", 0);  // tuning / tests
+  const int f_mt = UPA_OPT(opts, c1_mt), f_waves = UPA_OPT(opts, c1_waves), f_wgs = UPA_OPT(opts, c1_wgs);  // tuning / tests
   int mt = tiles >= 8192 ? 4 : (tiles >= 2048 ? 2 : 1);
   if (mt * ntw > 32) mt = 32 / ntw;  // accumulator budget: MT * NTW tiles of 4 registers
   if (mt == 3) mt = 2;
@@ -383,14 +378,14 @@ int upa_conv1x1_launch(C1Params p, int n_pixels, int query_only, int* variant, v
 // upa_conv2d_bias_act(k = 1, act none) + that branch's half of upa_detect_decode.
 extern "C" int upa_detect_tail(const void* x, int n, int h, int w, int cin, int ldx, const void* w_packed, const float* bias,
                                int cout, int kind, int nc, float stride_px, float* y, int a_total, int a0, void* raw, int ldraw,
-                               int dtype, void* stream) {
+                               int dtype, const upa_opts* opts, void* stream) {
   UPA_CHECK_ARG(x && w_packed && y, "detect_tail: null pointer");
   UPA_CHECK_ARG(kind == 1 || kind == 2, "detect_tail: kind must be 1 (box) or 2 (class)");
   UPA_CHECK_ARG(n > 0 && h > 0 && w > 0 && a0 >= 0 && a0 + h * w <= a_total, "detect_tail: level does not fit a_total");
   // (the flat pixel -> (image, anchor) split of detect_epi.h must be exact up to the last pixel)
   if (dtype != UPA_BF16 || h * w < 2 || w < 2 || (kind == 1 && cout != 64) || (kind == 2 && (cout < nc || cout > 128)) ||
       !upa_magic_exact((long)n * h * w - 1, h * w) || !upa_magic_exact((long)h * w - 1, w) ||
-      !upa_conv1x1_eligible(n, h, w, cin, ldx, cout, raw ? ldraw : cout, false, 1, 1, 0, UPA_ACT_NONE, dtype)) {
+      !upa_conv1x1_eligible(n, h, w, cin, ldx, cout, raw ? ldraw : cout, false, 1, 1, 0, UPA_ACT_NONE, dtype, opts)) {
     upa_set_error("detect_tail: shape / dtype outside the fused form (bf16, reg_max 16, nc <= 128)");
     return UPA_EUNSUPPORTED;  // the caller runs the conv and upa_detect_decode separately
   }
@@ -402,7 +397,7 @@ extern "C" int upa_detect_tail(const void* x, int n, int h, int w, int cin, int 
   q.de.y = y; q.de.a_total = a_total; q.de.a0 = a0; q.de.HW = h * w; q.de.W = w;
   q.de.magicHW = upa_magic_div(h * w); q.de.magicW = upa_magic_div(w);
   q.de.nc = nc; q.de.stride_px = stride_px;
-  return upa_conv1x1_launch(q, n * h * w, 0, nullptr, stream);
+  return upa_conv1x1_launch(q, n * h * w, 0, nullptr, stream, opts);
 }
 
 // 1x1 conv whose input is Concat([Upsample(2x nearest)(up), skip]) WITHOUT the upsampled tensor ever being written: the first
@@ -412,13 +407,12 @@ extern "C" int upa_detect_tail(const void* x, int n, int h, int w, int cin, int 
 // Returns UPA_EUNSUPPORTED when the shape is not the streaming kernel's (callers then write the upsample and run the conv).
 extern "C" int upa_conv1x1_upcat(const void* x, int n, int h, int w, int cin, int ldx, const void* up, int up_c, int up_ld,
                                  const void* w_packed, const float* bias, void* y, int cout, int ldy, int act, int dtype,
-                                 void* stream) {
+                                 const upa_opts* opts, void* stream) {
   UPA_CHECK_ARG(x && up && w_packed && y && n > 0 && h > 0 && w > 0, "conv1x1_upcat: bad args");
-  static const bool off = getenv("UPA_NO_UPCAT") != nullptr;
-  if (off || (h & 1) || (w & 1) || up_c <= 0 || up_c % 32 != 0 || up_c >= cin || up_ld % 8 != 0 || ((uintptr_t)up % 16) != 0 ||
+  if (UPA_OPT(opts, no_upcat) || (h & 1) || (w & 1) || up_c <= 0 || up_c % 32 != 0 || up_c >= cin || up_ld % 8 != 0 || ((uintptr_t)up % 16) != 0 ||
       (long)n * (h / 2) * (w / 2) * up_ld * 2 >= (1L << 31) - 4096 || !upa_magic_exact((long)n * h * w - 1, w) ||
       !upa_magic_exact((long)n * h - 1, h) ||
-      !upa_conv1x1_eligible(n, h, w, cin, ldx, cout, ldy, false, 1, 1, 0, act, dtype)) {
+      !upa_conv1x1_eligible(n, h, w, cin, ldx, cout, ldy, false, 1, 1, 0, act, dtype, opts)) {
     upa_set_error("conv1x1_upcat: outside the fused form (bf16 streaming 1x1, even h / w, up_c %% 32 == 0)");
     return UPA_EUNSUPPORTED;
   }
@@ -428,5 +422,5 @@ extern "C" int upa_conv1x1_upcat(const void* x, int n, int h, int w, int cin, in
   q.Cin = cin; q.ldx = ldx; q.Cout = cout; q.ldy = ldy; q.act = act;
   q.up = (const char*)up; q.upKT = up_c / 32; q.up_ld = up_ld; q.upH = h; q.upW = w;
   q.upMagicW = upa_magic_div(w); q.upMagicH = upa_magic_div(h);
-  return upa_conv1x1_launch(q, n * h * w, 0, nullptr, stream);
+  return upa_conv1x1_launch(q, n * h * w, 0, nullptr, stream, opts);
 }

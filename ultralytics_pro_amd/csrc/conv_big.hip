@@ -29,7 +29,9 @@
 // NHWC stores, residual read with the same shape), as conv.hip.
 #include <stdlib.h>
 
+#include <mutex>
 #include <type_traits>
+#include <unordered_map>
 
 #include "common.h"
 #include "conv_pipe.h"
@@ -348,11 +350,6 @@ __global__ __launch_bounds__(512, 4) void conv_big_kernel(const BigParams p) {
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
-int big_env(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
-
 int big_num_cu() {
   static int numCU = 0;
   if (!numCU) {
@@ -385,6 +382,24 @@ size_t big_halo_bytes(const BigParams& p) { return (((size_t)p.IH * p.IWp * 8 + 
 // otherwise (occupancy first: measured in round 3, removing every bank conflict of the 64-column family changed its time by
 // less than the run-to-run noise).  Returns false if nothing fits.
 bool big_pick_tile(BigParams& p, int bm, int ntb, size_t lds_cap) {
+  // the search is a pure function of (map size, kernel, stride, workgroup shape, LDS cap): memoised - an eager (uncaptured)
+  // training step launches a hundred convolutions and the search costs ~0.3 ms of host time per call
+  struct Pick { int th, tw, tight; };
+  static std::mutex mu;
+  static std::unordered_map<unsigned long long, Pick> memo;
+  const unsigned long long key = ((unsigned long long)p.OH << 48) ^ ((unsigned long long)p.OW << 32) ^ ((unsigned long long)bm << 20) ^
+                                 ((unsigned long long)ntb << 12) ^ ((unsigned long long)(lds_cap >> 9) << 3) ^ (p.KS == 3 ? 4u : 0u) ^
+                                 (p.stride == 2 ? 2u : 0u);
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = memo.find(key);
+    if (it != memo.end()) {
+      if (it->second.th <= 0) return false;
+      p.TH = it->second.th; p.TW = it->second.tw;
+      big_halo_geometry(p, it->second.tight != 0);
+      return true;
+    }
+  }
   long best = -1;
   int bth = 0, btw = 0;
   bool btight = false;
@@ -410,6 +425,10 @@ bool big_pick_tile(BigParams& p, int bm, int ntb, size_t lds_cap) {
   }
   p.TH = bth; p.TW = btw;
   if (best >= 0) big_halo_geometry(p, btight);
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    memo[key] = Pick{best >= 0 ? bth : 0, btw, btight ? 1 : 0};
+  }
   return best >= 0;
 }
 
@@ -475,11 +494,12 @@ extern "C" int upa_pack_tail_weight(const float* w, int cout, int cin, void* out
 // wt = the 1x1 conv as upa_pack_tail_weight(cout = CP, cin = CP) of the zero-padded matrix, bt = its CP biases.
 extern "C" int upa_detect_branch_tail(const void* x, int n, int h, int w, int c, int ldx, const void* w3_packed, const float* b3,
                                       const void* wt_packed, const float* bt, int kind, int nc, float stride_px, float* y,
-                                      int a_total, int a0, unsigned long long* best_keys, int dtype, void* stream) {
+                                      int a_total, int a0, unsigned long long* best_keys, int dtype, const upa_opts* opts,
+                                      void* stream) {
   UPA_CHECK_ARG(x && w3_packed && b3 && wt_packed && bt && y, "detect_branch_tail: null pointer");
   UPA_CHECK_ARG(kind == 1 || kind == 2, "detect_branch_tail: kind must be 1 (box) or 2 (class)");
   UPA_CHECK_ARG(n > 0 && h > 0 && w > 0 && a0 >= 0 && a0 + h * w <= a_total, "detect_branch_tail: level does not fit a_total");
-  static const int off = big_env("UPA_NO_BRANCH_TAIL", 0);
+  const int off = UPA_OPT(opts, no_branch_tail);
   const int ntb = kind == 1 ? 4 : (c == 80 ? 5 : 6);  // 80 class-branch channels (nc = 80 models): 5 tiles, no padded sixth
   if (off || dtype != UPA_BF16 || c % 8 != 0 || ldx % 8 != 0 || h * w < 2 || w < 2 || (kind == 1 && c != 64) ||
       (kind == 2 && (c > 96 || nc > ntb * 16)) || ((uintptr_t)x % 16) != 0 || !upa_magic_exact((long)h * w - 1, w)) {
@@ -499,7 +519,7 @@ extern "C" int upa_detect_branch_tail(const void* x, int n, int h, int w, int c,
   if (kind == 2 && best_keys && (long)a_total * nc < (1L << 31)) p.de.best_keys = best_keys;
   const long px = (long)n * h * w;
   int bm = (px + 255) / 256 < big_num_cu() ? 128 : 256;  // 128-pixel workgroups (one m-tile per wave) on the small levels
-  if (const int f = big_env("UPA_BRANCH_TAIL_BM", 0); f == 128 || f == 256) bm = f;
+  if (const int f = UPA_OPT(opts, branch_tail_bm); f == 128 || f == 256) bm = f;
   if (!big_pick_tile(p, bm, ntb, 80 * 1024 - 512) && !big_pick_tile(p, bm, ntb, 160 * 1024)) return UPA_EUNSUPPORTED;
   p.tilesX = cdiv(p.OW, p.TW);
   p.tilesY = cdiv(p.OH, p.TH);
@@ -510,19 +530,12 @@ extern "C" int upa_detect_branch_tail(const void* x, int n, int h, int w, int c,
   return bm == 256 ? big_launch_inst<3, 1, 8, 1, 2, 6, 2>(p, lds, s) : big_launch_inst<3, 1, 8, 1, 1, 6, 2>(p, lds, s);
 }
 
-// Dispatch mode of the large-tile kernel: 0 = never, 1 = by the size rule of upa_conv_big_eligible (default), 2 = every
-// shape the kernel can run (parity tests, tools/bench_conv.py).  Initialised from UPA_CONV_BIG; mode < 0 only queries.
-extern "C" int upa_conv_big_mode(int mode) {
-  static int cur = big_env("UPA_CONV_BIG", 1);
-  const int prev = cur;
-  if (mode >= 0) cur = mode;
-  return prev;
-}
-
 bool upa_conv_big_eligible(int n, int h, int w, int cin, int ldx, int cout, int ldy, int ldr, int k, int stride, int pad,
-                           int act, int dtype) {
-  const int mode = upa_conv_big_mode(-1);
-  if (mode == 0) return false;
+                           int act, int dtype, const upa_opts* opts) {
+  // upa_opts.conv_big: 0 = by the size rule below (default), 1 = never, 2 = every shape the kernel can run (parity tests,
+  // tools/bench_conv.py)
+  const int mode = UPA_OPT(opts, conv_big);
+  if (mode == 1) return false;
   if (dtype != UPA_BF16 || !((k == 1 && stride == 1) || (k == 3 && (stride == 1 || stride == 2))) || pad != k / 2) return false;
   if (cin % 8 != 0 || ldx % 8 != 0 || cout % 8 != 0 || ldy % 8 != 0 || ldr % 8 != 0) return false;
   if (act != UPA_ACT_SILU && act != UPA_ACT_NONE && act != UPA_ACT_RELU) return false;
@@ -536,15 +549,14 @@ bool upa_conv_big_eligible(int n, int h, int w, int cin, int ldx, int cout, int 
     // 134400 x 1536 x 256), where the streaming kernel would re-read its input once per 128-column row of workgroups
     if (cout % 128 != 0 || px < 2048) return false;
     if (cout >= 1024 && cin >= 128 && px >= 32 * 1024) return true;
-    return cin >= 512 && !upa_conv1x1_eligible(n, h, w, cin, ldx, cout, ldy, ldr != 0, k, stride, pad, act, dtype);
+    return cin >= 512 && !upa_conv1x1_eligible(n, h, w, cin, ldx, cout, ldy, ldr != 0, k, stride, pad, act, dtype, opts);
   }
   // measured on MI355X (tools/bench_conv.py, yolov3-rtdetr bs 16 / yolov8n bs 32, round 2): 3x3 layers with whole 128-channel
   // output columns run at 800-1000 TFLOP/s here against 430-615 on the per-wave-weights kernel; the 80-channel class
   // branch of Detect (96-channel variant: 64->80 @80x80 45.6 -> 33.7 us, 128->80 @40x40 31.7 -> 19.9, 256->80 @20x20
   // 31.7 -> 25.8) and the 64-channel layers (64->64 @40x40 13.3 -> 11.5 us, @80x80 31.5 -> 27.9, 64->128 stride 2 @80x80
   // 27.5 -> 21.4) win from 64 input channels; narrower inputs (32->64) and 1x1 layers stay where they are
-  static const int min_cin = big_env("UPA_CONV_BIG_MIN_CIN", 64);
-  if (cin < min_cin || px < 2048) return false;
+  if (cin < 64 || px < 2048) return false;
   if (cout % 128 == 0) return cin >= 128 || (px >= 8192 && (stride == 2 || px >= 200 * 1024));
   if (px < 8192) return false;
   if (cout == 80 || cout == 96) return stride == 1;
@@ -552,22 +564,20 @@ bool upa_conv_big_eligible(int n, int h, int w, int cin, int ldx, int cout, int 
   return false;
 }
 
-int upa_conv_big_launch(BigParams p, int query_only, int* variant, void* stream) {
+int upa_conv_big_launch(BigParams p, int query_only, int* variant, void* stream, const upa_opts* opts) {
   p.KTT = (p.Cin + 31) / 32;
   p.NTn = (p.Cout + 15) / 16;
   // workgroup columns: 128 channels, 96 for Cout in (64, 96], 64 for Cout <= 64 - and 64 for wider layers whose 128-pixel x
   // 128-channel workgroups would still be fewer than the CUs (20x20 maps: twice the workgroups, each with half the weights)
   int ntb = p.NTn <= 4 ? 4 : (p.NTn <= 6 ? 6 : 8);
-  static const int five = big_env("UPA_CONV_BIG_NT5", 1);
-  if (five && p.NTn == 5 && p.KS == 3 && p.stride == 1) ntb = 5;  // 80 output channels (Detect class branch): 8 x 1 waves x 5 tiles
+  if (p.NTn == 5 && p.KS == 3 && p.stride == 1) ntb = 5;  // 80 output channels (Detect class branch): 8 x 1 waves x 5 tiles
   const long px = (long)p.N * p.OH * p.OW;
-  static const int split = big_env("UPA_CONV_BIG_SPLIT", 1);
-  if (split && ntb == 8 && p.NTn % 4 == 0 && (px + 127) / 128 * cdiv(p.NTn, 8) < big_num_cu()) ntb = 4;
+  if (ntb == 8 && p.NTn % 4 == 0 && (px + 127) / 128 * cdiv(p.NTn, 8) < big_num_cu()) ntb = 4;
   const int cols = cdiv(p.NTn, ntb);
   // 256-pixel workgroups unless that leaves most of the chip idle (fewer workgroups than CUs): then 128-pixel ones
   int bm = 256;
   if ((px + 255) / 256 * cols < big_num_cu()) bm = 128;
-  if (const int f = big_env("UPA_CONV_BIG_BM", 0); f == 128 || f == 256 || (f == 512 && p.KS == 3 && p.stride == 1 && (ntb == 4 || ntb == 5))) bm = f;
+  if (const int f = UPA_OPT(opts, conv_big_bm); f == 128 || f == 256 || (f == 512 && p.KS == 3 && p.stride == 1 && (ntb == 4 || ntb == 5))) bm = f;
   if (variant) *variant = (1 << 23) | (ntb << 4) | (bm >> 7);  // (bm >> 7: 1 = 128, 2 = 256, 4 = 512 pixels)
   if (query_only) return UPA_OK;
   if (p.KS == 1) {  // pointwise: an NHWC view has one uniform pixel stride - flatten (n, h, w) into one row

@@ -289,11 +289,6 @@ __global__ __launch_bounds__(512, 4) void conv_pair_kernel(const PairParams p) {
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
-int pair_env(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
-
 template <int CK>
 int pair_launch(const PairParams& p, size_t lds, bool res, hipStream_t s) {
   const dim3 grid((unsigned)((long)p.tilesX * p.tilesY * p.N));
@@ -326,14 +321,14 @@ int pair_launch(const PairParams& p, size_t lds, bool res, hipStream_t s) {
 
 static int pair_impl(const void* x, int n, int h, int w, int c, int ldx, const void* w1_packed, const float* b1,
                      const void* w2_packed, const float* b2, void* y, int ldy, int residual, int act, int dtype,
-                     const PairParams* cv2, void* stream) {
+                     const PairParams* cv2, const upa_opts* opts, void* stream) {
   UPA_CHECK_ARG(x && w1_packed && b1 && w2_packed && b2 && y && n > 0 && h > 0 && w > 0, "bottleneck_pair: bad args");
-  // 1: never; 2: not for C = 64 (the default); 3: not for C = 32; 0: both.  Measured on MI355X (yolov8n bs 32, four steps in
+  // upa_opts.pair: 0 = C = 32 only (the default), 1 = never, 2 = both widths, 3 = C = 64 only.  Measured on MI355X (yolov8n bs 32, four steps in
   // flight): C = 32 pairs at 80x80 28.7 us against 16.4 + 19.1 us as two launches, step 0.800 -> 0.773 ms; C = 64 pairs at
   // 40x40 30.9-32.2 us against 11.5 + 12.2 us (288 one-per-CU workgroups = two rounds; 12 x 12 / 10 x 10 tiles no better),
   // step 0.773 -> 0.790 ms - the 64-channel form stays available but is not dispatched
-  static const int off = pair_env("UPA_NO_PAIR", 2);
-  if (off == 1 || (off == 2 && c == 64) || (off == 3 && c == 32) || dtype != UPA_BF16 || act != UPA_ACT_SILU || !(c == 32 || c == 64) || ldx % 8 != 0 || ldy % 8 != 0 ||
+  const int mode = UPA_OPT(opts, pair);
+  if (mode == 1 || (mode == 0 && c == 64) || (mode == 3 && c == 32) || dtype != UPA_BF16 || act != UPA_ACT_SILU || !(c == 32 || c == 64) || ldx % 8 != 0 || ldy % 8 != 0 ||
       ((uintptr_t)x % 16) != 0 || ((uintptr_t)y % 16) != 0) {
     upa_set_error("bottleneck_pair: outside the fused form (bf16, SiLU, C = 32 | 64)");
     return UPA_EUNSUPPORTED;  // the caller runs the two convolutions separately
@@ -346,7 +341,7 @@ static int pair_impl(const void* x, int n, int h, int w, int c, int ldx, const v
   const int ck = c / 32;
   const int pb = ck * 64;
   // output tile TH x TW with (TH+2)(TW+2) <= 256 mid pixels: fewest tiles per image, then the squarest
-  static const int fth64 = pair_env("UPA_PAIR_T64", 0), fth32 = pair_env("UPA_PAIR_T32", 0);  // square tile edge per width
+  const int fth64 = UPA_OPT(opts, pair_tile64), fth32 = UPA_OPT(opts, pair_tile32);  // square tile edge per width
   const int fth = c == 64 ? fth64 : fth32, ftw = fth;
   long best = -1;
   for (int tw = 2; tw <= 62 && tw <= ((w + 1) & ~1); ++tw) {
@@ -377,8 +372,8 @@ static int pair_impl(const void* x, int n, int h, int w, int c, int ldx, const v
 
 extern "C" int upa_bottleneck_pair(const void* x, int n, int h, int w, int c, int ldx, const void* w1_packed, const float* b1,
                                    const void* w2_packed, const float* b2, void* y, int ldy, int residual, int act, int dtype,
-                                   void* stream) {
-  return pair_impl(x, n, h, w, c, ldx, w1_packed, b1, w2_packed, b2, y, ldy, residual, act, dtype, nullptr, stream);
+                                   const upa_opts* opts, void* stream) {
+  return pair_impl(x, n, h, w, c, ldx, w1_packed, b1, w2_packed, b2, y, ldy, residual, act, dtype, nullptr, opts, stream);
 }
 
 // C2f(.., 64, n = 1) with a 32-channel Bottleneck: Bottleneck (both 3x3 convs [+ shortcut]) AND the C2f's cv2 in one launch.
@@ -388,10 +383,9 @@ extern "C" int upa_bottleneck_pair(const void* x, int n, int h, int w, int c, in
 extern "C" int upa_bottleneck_pair_cv2(const void* x, const void* y0, int n, int h, int w, int ldx, const void* w1_packed,
                                        const float* b1, const void* w2_packed, const float* b2, int residual,
                                        const void* wc_std, const void* wc_b, const float* bc, void* out, int ldout, int act,
-                                       int dtype, void* stream) {
+                                       int dtype, const upa_opts* opts, void* stream) {
   UPA_CHECK_ARG(y0 && wc_std && wc_b && bc && out, "bottleneck_pair_cv2: null pointer");
-  static const int off = pair_env("UPA_NO_PAIR_CV2", 0);
-  if (off || ldout % 8 != 0 || ((uintptr_t)out % 16) != 0 || ((uintptr_t)y0 % 16) != 0) {
+  if (UPA_OPT(opts, no_pair_cv2) || ldout % 8 != 0 || ((uintptr_t)out % 16) != 0 || ((uintptr_t)y0 % 16) != 0) {
     upa_set_error("bottleneck_pair_cv2: outside the fused form");
     return UPA_EUNSUPPORTED;
   }
@@ -399,5 +393,10 @@ extern "C" int upa_bottleneck_pair_cv2(const void* x, const void* y0, int n, int
   memset(&cv2, 0, sizeof(cv2));
   cv2.y0 = (const char*)y0; cv2.wc_std = (const char*)wc_std; cv2.wc_b = (const char*)wc_b; cv2.bc = bc;
   cv2.out = (char*)out; cv2.ldout = ldout;
-  return pair_impl(x, n, h, w, 32, ldx, w1_packed, b1, w2_packed, b2, out, ldout, residual, act, dtype, &cv2, stream);
+  // (the cv2 form is a 32-channel pair whatever upa_opts.pair says about the plain Bottleneck dispatch)
+  upa_opts o2;
+  memset(&o2, 0, sizeof(o2));
+  o2.size = sizeof(o2);
+  o2.pair_tile32 = UPA_OPT(opts, pair_tile32);
+  return pair_impl(x, n, h, w, 32, ldx, w1_packed, b1, w2_packed, b2, out, ldout, residual, act, dtype, &cv2, &o2, stream);
 }

@@ -10,12 +10,14 @@ struct PipeParams {
   int KTT, NTn, nt0;   // k-tiles (32 bf16 channels), packed n-tiles, first n-tile of this launch
   int tilesX, tilesY, numTiles;
   int act;
-  int ablate;  // debug (UPA_PIPE_ABLATE): 1 no halo DMA, 2 no weight loads, 4 no stores, 8 no MFMA, 16 no epilogue
+#ifdef UPA_ABLATE
+  int ablate;  // debug build only (upa_opts.ablate_pipe): 1 no halo DMA, 2 no weight loads, 4 no stores, 8 no MFMA, 16 no epilogue
+#endif
 };
 bool upa_conv_pipe_eligible(int n, int h, int w, int cin, int ldx, int cout, int ldy, int ldr, int k, int stride, int pad,
-                            int act, int dtype);
+                            int act, int dtype, const upa_opts* opts);
 // variant (if non-null) receives (1 << 21) | NTW of the first launch; query_only = 1 skips the launches
-int upa_conv_pipe_launch(PipeParams p, int query_only, int* variant, void* stream);
+int upa_conv_pipe_launch(PipeParams p, int query_only, int* variant, void* stream, const upa_opts* opts);
 
 // ---- conv1x1.hip: streaming pointwise convolution (bf16, k1 s1 p0, no residual)
 #include "detect_epi.h"
@@ -28,7 +30,9 @@ struct C1Params {
   int Cin, ldx, Cout, ldy;
   int KTT, NTn, groups;
   int act;
-  int ablate;  // debug (UPA_C1_ABLATE): 1 no input DMA, 2 no weight loads, 4 no stores, 8 no MFMA
+#ifdef UPA_ABLATE
+  int ablate;  // debug build only (upa_opts.ablate_c1): 1 no input DMA, 2 no weight loads, 4 no stores, 8 no MFMA
+#endif
   int epi;     // 0: y = act(conv + bias) as bf16 rows; 1 / 2: Detect box / class decode fused on the end (detect_epi.h), the
                // bf16 rows are written too when y != nullptr
   DetectEpi de;
@@ -39,9 +43,9 @@ struct C1Params {
   unsigned upMagicW, upMagicH;
 };
 bool upa_conv1x1_eligible(int n, int h, int w, int cin, int ldx, int cout, int ldy, bool residual, int k, int stride,
-                          int pad, int act, int dtype);
+                          int pad, int act, int dtype, const upa_opts* opts);
 // variant (if non-null) receives (1 << 22) | waves << 8 | MT << 4 | NTW; query_only = 1 skips the launch
-int upa_conv1x1_launch(C1Params p, int n_pixels, int query_only, int* variant, void* stream);
+int upa_conv1x1_launch(C1Params p, int n_pixels, int query_only, int* variant, void* stream, const upa_opts* opts);
 
 // ---- conv_big.hip: large-tile implicit GEMM with both operands shared through LDS (bf16, k 1 | 3, stride 1 | 2)
 struct BigParams {
@@ -63,9 +67,9 @@ struct BigParams {
   DetectEpi de;        // ... and the decode it feeds (detect_epi.h)
 };
 bool upa_conv_big_eligible(int n, int h, int w, int cin, int ldx, int cout, int ldy, int ldr, int k, int stride, int pad,
-                           int act, int dtype);
+                           int act, int dtype, const upa_opts* opts);
 // variant (if non-null) receives (1 << 23) | n-tiles per workgroup << 4 | pixels per workgroup / 128; query_only = 1 skips the launch
-int upa_conv_big_launch(BigParams p, int query_only, int* variant, void* stream);
+int upa_conv_big_launch(BigParams p, int query_only, int* variant, void* stream, const upa_opts* opts);
 
 // ---- conv_pair.hip: Bottleneck (3x3 -> 3x3 [+ x]) as one kernel, the intermediate tile in LDS (bf16, C = 32 | 64)
 struct PairParams {

@@ -41,7 +41,7 @@ constexpr int WAVES = 4;
 template <int NTW, int ACT, bool RES>
 __global__ __launch_bounds__(WAVES * 64, 1) void conv3x3_pipe_kernel(const PipeParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  if (p.ablate & 32) return;  // debug: launch + workgroup dispatch only
+  if UPA_ABL(p, 32) return;  // debug: launch + workgroup dispatch only
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   char* hb = smem + wave * (2 * HB);  // wave-private double buffer
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void conv3x3_pipe_kernel(const PipeP
   auto issue_dma = [&](const char* xbase, int emask, int kt, int buf) __attribute__((always_inline)) {
     const int grpmax = (p.Cin - kt * 32 + 7) >> 3;  // valid 16-byte channel groups of this k-tile (>= 4: all)
     const char* xk = xbase + kt * 64;
-    if (p.ablate & 1) return;
+    if UPA_ABL(p, 1) return;
 #pragma unroll
     for (int k = 0; k < NDMA; ++k) {
       const int m = meta[k];
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void conv3x3_pipe_kernel(const PipeP
   const int wTile = p.NTn * 1024;
   u32x4 A[2][3][NTW];
   auto load_A = [&](u32x4(&dst)[3][NTW], int kt, int dx) __attribute__((always_inline)) {
-    if (p.ablate & 2) return;
+    if UPA_ABL(p, 2) return;
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
       const char* wb = wl + (size_t)((dy * 3 + dx) * p.KTT + kt) * wTile;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void conv3x3_pipe_kernel(const PipeP
 
   // one tap column (dx) of one chunk: 10 halo-row fragments x 3 vertical taps
   auto group = [&](const u32x4(&Ac)[3][NTW], const char* hbuf, int dx) __attribute__((always_inline)) {
-    if (p.ablate & 8) return;
+    if UPA_ABL(p, 8) return;
 #pragma unroll
     for (int r = 0; r < IH; ++r) {
       u32x4 b = *reinterpret_cast<const u32x4*>(hbuf + bfrag + (r * IW + dx) * PS);
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void conv3x3_pipe_kernel(const PipeP
     else return v;
   };
   auto epilogue = [&](const TileCtx& c) __attribute__((always_inline)) {
-    if (p.ablate & 16) return;
+    if UPA_ABL(p, 16) return;
     const int co0 = p.nt0 * 16;
     unsigned pix = (unsigned)((c.n * p.H + c.oy0) * p.W + c.ox0 + p16);
 #pragma unroll
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void conv3x3_pipe_kernel(const PipeP
         } else {
           auto lo = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v1[0], v1[1]), false, false);
           auto hi = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[2], v1[3]), false, false);
-          if (!(p.ablate & 4)) *reinterpret_cast<u32x4*>(yrow + cb * 2) = u32x4{lo[0], hi[0], lo[1], hi[1]};
+          if (!UPA_ABL(p, 4)) *reinterpret_cast<u32x4*>(yrow + cb * 2) = u32x4{lo[0], hi[0], lo[1], hi[1]};
         }
       }
       if constexpr (NTW & 1) {
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_c16_kernel(const PipePa
     return c;
   };
   auto issue_dma = [&](const TileCtx& c, int buf) __attribute__((always_inline)) {
-    if (p.ablate & 1) return;
+    if UPA_ABL(p, 1) return;
 #pragma unroll
     for (int k = 0; k < c16::NDMA; ++k) {
       const bool valid = (meta[k] & (c.em | 16)) == 0;
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_c16_kernel(const PipePa
   for (int s2 = 0; s2 < 5; ++s2) {
     const int tap = 2 * s2 + (kg >> 1);
     const int tapc = tap < 9 ? tap : 8;
-    A[s2] = (tap < 9 && !(p.ablate & 2))
+    A[s2] = (tap < 9 && !UPA_ABL(p, 2))
                 ? *reinterpret_cast<const u32x4*>(p.w + ((size_t)tap * p.NTn * 1024 + ((kg & 1) * 16 + p16) * 16))
                 : u32x4{0u, 0u, 0u, 0u};
     const int dy = tapc / 3, dx = tapc - dy * 3;
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_c16_kernel(const PipePa
     TileCtx nxt = cur;
     // this tile's halo must have landed; the TH / 2 stores of the previous tile are the youngest vector-memory operations of
     // the wave (operations retire in issue order) and may stay in flight
-    if (first || (p.ablate & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (first || UPA_ABL(p, 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     first = false;
     static_assert(TH == 8, "vmcnt(4) above = TH / 2 epilogue stores");
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_c16_kernel(const PipePa
     f32x4 acc[TH];
 #pragma unroll
     for (int i = 0; i < TH; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (!(p.ablate & 8)) {
+    if (!UPA_ABL(p, 8)) {
 #pragma unroll
       for (int i = 0; i < TH; ++i) {
 #pragma unroll
@@ -388,13 +388,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_c16_kernel(const PipePa
           x8[2 * q] += __uint_as_float(rv[q] << 16);
           x8[2 * q + 1] += __uint_as_float(rv[q] & 0xFFFF0000u);
         }
-        if (!(p.ablate & 4))
+        if (!UPA_ABL(p, 4))
           *reinterpret_cast<u32x4*>(ydst) = u32x4{pack_bf16x2(x8[0], x8[1]), pack_bf16x2(x8[2], x8[3]),
                                                   pack_bf16x2(x8[4], x8[5]), pack_bf16x2(x8[6], x8[7])};
       } else {
         auto lo = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v1[0], v1[1]), false, false);
         auto hi = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[2], v1[3]), false, false);
-        if (!(p.ablate & 4)) *reinterpret_cast<u32x4*>(ydst) = u32x4{lo[0], hi[0], lo[1], hi[1]};
+        if (!UPA_ABL(p, 4)) *reinterpret_cast<u32x4*>(ydst) = u32x4{lo[0], hi[0], lo[1], hi[1]};
       }
     }
     if (!hasNext) break;
@@ -404,9 +404,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_c16_kernel(const PipePa
   }
 }
 
-static int launch_c16(const PipeParams& p, hipStream_t s) {
+static int launch_c16(const PipeParams& p, hipStream_t s, const upa_opts* opts) {
   const size_t lds = (size_t)WAVES * 2 * c16::HB;
-  static const int max_wgs = getenv("UPA_C16_WGS") ? atoi(getenv("UPA_C16_WGS")) : 512;
+  const int max_wgs = UPA_OPT(opts, c16_wgs) > 0 ? UPA_OPT(opts, c16_wgs) : 512;
   int grid = (p.numTiles + WAVES - 1) / WAVES;
   if (grid > max_wgs) grid = max_wgs;
 #define UPA_C16_LAUNCH(ACT_, RES_)                                                                        \
@@ -448,9 +448,8 @@ static int launch_pipe(const PipeParams& p, int grid, hipStream_t s) {
 }
 
 bool upa_conv_pipe_eligible(int n, int h, int w, int cin, int ldx, int cout, int ldy, int ldr, int k, int stride, int pad,
-                            int act, int dtype) {
-  static const bool off = getenv("UPA_CONV_NO_PIPE") != nullptr;
-  if (off) return false;
+                            int act, int dtype, const upa_opts* opts) {
+  if (UPA_OPT(opts, no_pipe)) return false;
   if (dtype != UPA_BF16 || k != 3 || stride != 1 || pad != 1) return false;
   if (act != UPA_ACT_SILU && act != UPA_ACT_NONE) return false;
   if (h % TH != 0 || w % TW != 0 || cin % 8 != 0 || cout % 16 != 0) return false;
@@ -459,33 +458,33 @@ bool upa_conv_pipe_eligible(int n, int h, int w, int cin, int ldx, int cout, int
   // 28.9 vs 29.4) and for 80->80 (59.1 vs 64.8); 16-channel launches (16->16, the +16 tail of 64->80) re-read the
   // input for too little work (31.3 vs 28.6, 46.9 vs 41.0)
   const int ntn = (cout + 15) / 16;
-  static const bool all_shapes = getenv("UPA_PIPE_ALL") != nullptr;
-  static const bool no_c16 = getenv("UPA_CONV_NO_C16") != nullptr;
+  const bool all_shapes = UPA_OPT(opts, pipe_all) != 0;
+  const bool no_c16 = UPA_OPT(opts, no_c16) != 0;
   const bool c16_shape = cin == 16 && cout == 16 && !no_c16;  // conv3x3_c16_kernel
   if (!all_shapes && !c16_shape && (ntn & 1) && !(ntn >= 5 && cin >= 80)) return false;
   const long px = (long)n * h * w;
   if (px * ldx * 2 >= (1L << 31) || px * ldy * 2 >= (1L << 31) || px * ldr * 2 >= (1L << 31)) return false;
   // enough wave tiles to fill the chip; low-resolution layers stay on the tile-per-workgroup kernel
-  static const int min_tiles = getenv("UPA_PIPE_MIN_TILES") ? atoi(getenv("UPA_PIPE_MIN_TILES")) : 1024;
+  const int min_tiles = UPA_OPT(opts, pipe_min_tiles) > 0 ? UPA_OPT(opts, pipe_min_tiles) : 1024;
   if (px / (TH * TW) < min_tiles) return false;
   return true;
 }
 
-int upa_conv_pipe_launch(PipeParams p, int query_only, int* variant, void* stream) {
+int upa_conv_pipe_launch(PipeParams p, int query_only, int* variant, void* stream, const upa_opts* opts) {
   hipStream_t s = (hipStream_t)stream;
   p.tilesX = p.W / TW;
   p.tilesY = p.H / TH;
   p.numTiles = p.tilesX * p.tilesY * p.N;
   p.KTT = (p.Cin + 31) / 32;
   p.NTn = (p.Cout + 15) / 16;
-  static const int ablate = getenv("UPA_PIPE_ABLATE") ? atoi(getenv("UPA_PIPE_ABLATE")) : 0;
-  p.ablate = ablate;
-  static const bool no_c16 = getenv("UPA_CONV_NO_C16") != nullptr;
-  if (p.Cin == 16 && p.Cout == 16 && !no_c16) {
+#ifdef UPA_ABLATE
+  p.ablate = UPA_OPT(opts, ablate_pipe);
+#endif
+  if (p.Cin == 16 && p.Cout == 16 && !UPA_OPT(opts, no_c16)) {
     if (variant) *variant = (1 << 21) | (1 << 8) | 1;
-    return query_only ? UPA_OK : launch_c16(p, s);
+    return query_only ? UPA_OK : launch_c16(p, s, opts);
   }
-  static const int max_wgs = getenv("UPA_PIPE_WGS") ? atoi(getenv("UPA_PIPE_WGS")) : 256;
+  const int max_wgs = UPA_OPT(opts, pipe_wgs) > 0 ? UPA_OPT(opts, pipe_wgs) : 256;
   int grid = (p.numTiles + WAVES - 1) / WAVES;
   if (grid > max_wgs) grid = max_wgs;
   // output channels in launches of 64 / 32 / 16 (NTW 4 / 2 / 1); 80 = 64 + 16, 48 = 32 + 16

@@ -20,7 +20,27 @@ __global__ void upa_zero_words_kernel(unsigned* p, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n) p[i] = 0u;
 }
-extern "C" int upa_version(void) { return 1; }
+extern "C" int upa_version(void) { return 2; }  // 2: upa_opts argument on the dispatching entry points (round 3)
+extern "C" size_t upa_opts_size(void) { return sizeof(upa_opts); }
+
+// Device -> pinned host copy as a KERNEL (the device writes the host-mapped allocation through its unified address): a step
+// captured into a hipGraph can hand its detections to the host with no memcpy node (with several graphs of the step in flight
+// the runtime's memset / memcpy nodes have misbehaved, see upa_zero_words) and no extra host call per step.
+__global__ void upa_copy_words_kernel(const unsigned* __restrict__ src, unsigned* __restrict__ dst, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = src[i];
+}
+extern "C" int upa_copy_to_host(const void* src_dev, void* dst_pinned, size_t bytes, void* stream) {
+  UPA_CHECK_ARG(src_dev && dst_pinned && bytes % 4 == 0 && ((uintptr_t)src_dev % 4) == 0 && ((uintptr_t)dst_pinned % 4) == 0,
+                "copy_to_host: pointers and size must be 4-byte aligned");
+  if (bytes == 0) return UPA_OK;
+  const long n = (long)(bytes / 4);
+  long blocks = (n + 255) / 256;
+  if (blocks > 64) blocks = 64;  // a few hundred KB over the host link: more workgroups only add launch ramp
+  hipLaunchKernelGGL(upa_copy_words_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned*)src_dev,
+                     (unsigned*)dst_pinned, n);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
 
 extern "C" int upa_graph_begin(void* stream) {
   hipError_t e = hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal);

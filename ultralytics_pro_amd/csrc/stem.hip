@@ -18,7 +18,10 @@ struct StemParams {
   char* y;
   int N, Cin, H, W, OH, OW, Cout, ldy, KS, stride, pad, act, x_bf16;
   int TH, TW, tilesX, tilesY, PR, PC, PCS;  // output tile, patch rows/cols, padded LDS row stride
-  int ablate;
+  int wgs;  // stem_mfma_kernel: persistent workgroup cap
+#ifdef UPA_ABLATE
+  int ablate;  // debug build only (upa_opts.ablate_stem)
+#endif
 };
 
 // One workgroup = TH x TW output pixels (TH*TW = 256, one per lane) x 16 output channels of one image.
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p) {
         if (i < npix) {
           const int row = i / p.PC, col = i - row * p.PC;
           const int iy = iy0 + row, ix = ix0 + col;
-          if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && !(p.ablate & 1)) {
+          if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && !UPA_ABL(p, 1)) {
             const unsigned char* px = xu + (((size_t)n * p.H + iy) * p.W + ix) * 3;
             v[q][0] = px[2]; v[q][1] = px[1]; v[q][2] = px[0];  // channel reversal
           }
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p) {
         lci[q] = ci;
         lrow[q] = row;
         const int iy = iy0 + row;
-        if (colOK && line + q * LSTEP < nlines && iy >= 0 && iy < p.H && !(p.ablate & 1)) {
+        if (colOK && line + q * LSTEP < nlines && iy >= 0 && iy < p.H && !UPA_ABL(p, 1)) {
           const size_t rb = ((size_t)n * p.Cin + ci) * plane + (size_t)iy * p.W;
           if (bf) {
             if (pairFast) {
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p) {
   for (int c = 0; c < CO_T; ++c) acc[c] = (p.bias && co0 + c < p.Cout) ? p.bias[co0 + c] : 0.f;
   const float* wg = p.w + (size_t)blockIdx.y * CO_T;  // [tap][ci][groups*16]: uniform addresses -> scalar loads
   const int wstride = ((p.Cout + CO_T - 1) / CO_T) * CO_T;
-  for (int kh = 0; kh < ((p.ablate & 2) ? 0 : p.KS); ++kh) {
+  for (int kh = 0; kh < (UPA_ABL(p, 2) ? 0 : p.KS); ++kh) {
     for (int kw = 0; kw < p.KS; ++kw) {
       for (int ci = 0; ci < p.Cin; ++ci) {
         const float xv = patch[(ci * p.PR + ty * p.stride + kh) * p.PCS + tx * p.stride + kw];
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p) {
       }
     }
   }
-  if (oy >= p.OH || ox >= p.OW || (p.ablate & 4)) return;
+  if (oy >= p.OH || ox >= p.OW || UPA_ABL(p, 4)) return;
   const size_t pix = ((size_t)n * p.OH + oy) * p.OW + ox;
   char* dst = p.y + (pix * p.ldy + co0) * sizeof(TO);
   constexpr bool F32 = sizeof(TO) == 4;
@@ -214,7 +217,7 @@ __device__ __forceinline__ void stem_stage(const StemParams& p, int tile, unsign
   const int iy0 = tyi * G::TH * S - p.pad, ix0 = txi * G::TW * S - p.pad;
   const int ixa = ix0 & ~7;                     // two's complement: floors negatives too
   const int plane = p.H * p.W;                  // 3 * plane < 2^31 (checked by the launcher)
-  if (p.x_bf16 == 1 && (p.W & 7) == 0 && !(p.ablate & 16)) {
+  if (p.x_bf16 == 1 && (p.W & 7) == 0 && !UPA_ABL(p, 16)) {
     // lane = one 16-byte chunk (8 pixels of one line); chunks are entirely inside or outside the image
     const bf16_t* xb = (const bf16_t*)p.x + (size_t)n * 3 * plane;
 #pragma unroll
@@ -223,7 +226,7 @@ __device__ __forceinline__ void stem_stage(const StemParams& p, int tile, unsign
       const int line = item / G::NCH, ch = item - line * G::NCH;
       const int ci = line / G::PR, row = line - ci * G::PR;
       const int iy = iy0 + row, ix = ixa + ch * 8;
-      const bool in = item < G::ITEMS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && !(p.ablate & 1);
+      const bool in = item < G::ITEMS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && !UPA_ABL(p, 1);
       const char* src = in ? reinterpret_cast<const char*>(xb + ci * plane + iy * p.W + ix)
                            : reinterpret_cast<const char*>(g_stem_zero16);
       __builtin_amdgcn_global_load_lds((sgptr_t)src, (slptr_t)((char*)buf + (it * 256 + wave * 64) * 16), 16, 0, 0);
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemParams p) {
     const char* pb = stem_sm + cur * PATCH_BYTES;
 #pragma unroll
     for (int rr = 0; rr < G::TH / 4; ++rr) {
-      if (p.ablate & 2) break;
+      if UPA_ABL(p, 2) break;
       f32x4 acc[SEGS][NT];
       u32x4 b[SEGS][KSTEPS];
 #pragma unroll
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemParams p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float t = acc[sx][nt][r];
-            if constexpr (SILU) if (!(p.ablate & 4)) t = t * __builtin_amdgcn_rcpf(1.0f + __expf(-t));
+            if constexpr (SILU) if (!UPA_ABL(p, 4)) t = t * __builtin_amdgcn_rcpf(1.0f + __expf(-t));
             v[r] = t;
           }
           *reinterpret_cast<u32x2*>(ostage + (sx * 16 + l16) * (NT * 32) + nt * 32 + kg * 8) =
@@ -375,7 +378,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemParams p) {
         }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       const int oy = oy0 + wave + rr * 4;
-      if (oy < p.OH && !(p.ablate & 8)) {
+      if (oy < p.OH && !UPA_ABL(p, 8)) {
         const unsigned rowpix = ((unsigned)n * p.OH + oy) * p.OW + ox0;  // < 2^31 pixels per tensor
 #pragma unroll
         for (int c = 0; c < NT * 2; ++c) {
@@ -400,7 +403,7 @@ static void launch_stem_mfma(const StemParams& p, int n, hipStream_t st) {
   q.tilesX = cdiv(p.OW, G::TW);
   q.tilesY = cdiv(p.OH, G::TH);
   const long ntiles = (long)q.tilesX * q.tilesY * n;
-  static const int wgs = getenv("UPA_STEM_WGS") ? atoi(getenv("UPA_STEM_WGS")) : 1024;
+  const int wgs = p.wgs > 0 ? p.wgs : 1024;
   dim3 grid((unsigned)(ntiles < wgs ? ntiles : wgs));
   const size_t lds = (size_t)2 * G::ITEMS_PAD * 16 + 4 * G::TW * NT * 32;
   if (p.act == UPA_ACT_SILU) {
@@ -647,7 +650,7 @@ extern "C" int upa_pack_stem_weight(const float* w_oihw, int cout, int cin, int 
 
 extern "C" int upa_conv2d_stem_nchw(const void* x, int x_dtype, int n, int cin, int h, int w, const float* wt,
                                     const float* bias, void* y, int cout, int ldy, int k, int stride, int pad, int act,
-                                    int dtype, void* stream) {
+                                    int dtype, const upa_opts* opts, void* stream) {
   UPA_CHECK_ARG(x && wt && y, "stem: null pointer");
   UPA_CHECK_ARG(x_dtype == UPA_F32 || x_dtype == UPA_BF16 || (x_dtype == UPA_U8_BGR_HWC && cin == 3),
                 "stem: input must be NCHW f32/bf16 or NHWC uint8 BGR with 3 channels");
@@ -667,9 +670,11 @@ extern "C" int upa_conv2d_stem_nchw(const void* x, int x_dtype, int n, int cin, 
   p.PR = (p.TH - 1) * stride + k;
   p.PC = (p.TW - 1) * stride + k;
   p.PCS = p.PC + 1;
-  static const int ablate = getenv("UPA_STEM_ABLATE") ? atoi(getenv("UPA_STEM_ABLATE")) : 0;
-  p.ablate = ablate;
-  static const bool no_mfma = getenv("UPA_STEM_NO_MFMA") != nullptr;
+  p.wgs = UPA_OPT(opts, stem_wgs);
+#ifdef UPA_ABLATE
+  p.ablate = UPA_OPT(opts, ablate_stem);
+#endif
+  const bool no_mfma = UPA_OPT(opts, stem_no_mfma) != 0;
   const int nt16 = cout / 16;
   if (dtype == UPA_BF16 && !no_mfma && cin == 3 && cout % 16 == 0 && (nt16 == 1 || nt16 == 2 || nt16 == 4) &&
       ((k == 3 && (stride == 1 || stride == 2)) || (k == 6 && stride == 2)) && (long)cin * h * w < (1L << 31) &&
@@ -703,7 +708,7 @@ extern "C" int upa_conv2d_stem_nchw(const void* x, int x_dtype, int n, int cin, 
  * reaches HBM.  w0 / b0: stem weights packed by upa_pack_stem_weight (+ folded bias); w1 / b1: second conv packed by
  * upa_pack_conv_weight(bf16) (+ folded bias).  y: NHWC bf16 view (n, h/4, w/4, 32). */
 extern "C" int upa_stem_conv_fused(const void* x, int n, int h, int w, const float* w0, const float* b0, const void* w1,
-                                   const float* b1, void* y, int ldy, void* stream) {
+                                   const float* b1, void* y, int ldy, const upa_opts* opts, void* stream) {
   UPA_CHECK_ARG(x && w0 && w1 && y, "stem_conv_fused: null pointer");
   UPA_CHECK_ARG(w % 8 == 0 && h % 4 == 0 && w % 4 == 0 && (long)3 * h * w < (1L << 31), "stem_conv_fused: w %% 8, h %% 4 == 0 required");
   UPA_CHECK_ARG(ldy % 8 == 0 && (uintptr_t)y % 16 == 0, "stem_conv_fused: output view must be 16-byte aligned");
@@ -712,8 +717,8 @@ extern "C" int upa_stem_conv_fused(const void* x, int n, int h, int w, const flo
   p.N = n; p.H = h; p.W = w; p.H0 = h / 2; p.W0 = w / 2; p.OH = h / 4; p.OW = w / 4; p.ldy = ldy;
   p.tilesX = cdiv(p.OW, sf::T1W); p.tilesY = cdiv(p.OH, sf::T1H);
   const long ntiles = (long)p.tilesX * p.tilesY * n;
-  static const int wgs = getenv("UPA_STEMF_WGS") ? atoi(getenv("UPA_STEMF_WGS")) : 512;
-  static const int nw = getenv("UPA_STEMF_WAVES") ? atoi(getenv("UPA_STEMF_WAVES")) : 8;
+  const int wgs = UPA_OPT(opts, stemf_wgs) > 0 ? UPA_OPT(opts, stemf_wgs) : 512;
+  const int nw = UPA_OPT(opts, stemf_waves) == 4 ? 4 : 8;
   const dim3 grid((unsigned)(ntiles < wgs ? ntiles : wgs));
   if (nw == 4) {
     (void)upa_full_lds<stem_conv_fused_kernel<4>>();

@@ -971,12 +971,11 @@ __global__ void cast_view_kernel(const char* src, int lds_, char* dst, int ldd, 
 
 int grid_for(long total, int per_block, int cap);
 int reduce_grid(long npix) {
-  static const int ppb = getenv("UPA_RED_PPB") ? atoi(getenv("UPA_RED_PPB")) : 64;
+  constexpr int ppb = 64;
   // measured on MI355X (tools/bench_bn.py, stats / whole backward in us): 512 blocks beat 2048 on every mid-size layer
   // (204800 px x 128 ch: 14.0 / 61 vs 22.8 / 79; 819200 x 32: 14.6 / 62 vs 22.7 / 74 - fewer per-block prologues, LDS
   // folds and partial rows); only the 3.3 M-pixel stem output prefers 1024 (35.5 vs 39.7)
-  static const int cap_env = getenv("UPA_RED_CAP") ? atoi(getenv("UPA_RED_CAP")) : 0;
-  const int cap = cap_env > 0 ? cap_env : (npix > 1500000 ? 1024 : 512);
+  const int cap = npix > 1500000 ? 1024 : 512;
   return grid_for(npix, ppb, cap < 2048 ? cap : 2048);  // the workspace holds 2048 block partials
 }
 
@@ -1170,7 +1169,7 @@ static int launch_wgrad_bf16_k1(WgradParams& p, int accumulate, void* ws, size_t
   const long ntiles = (P + 127) / 128;
   const int bco = cdiv(p.Cout, BCO), bci = cdiv(p.Cin, BCI);
   // 128 workgroups: 15.68 ms per yolov8s step against 15.88 at 256 (overlapped on the side stream; alone 256 is faster)
-  static const int k1_budget = getenv("UPA_WGRAD_K1_WGS") ? atoi(getenv("UPA_WGRAD_K1_WGS")) : 128;
+  constexpr int k1_budget = 128;
   long wgs = (k1_budget > 0 && k1_budget <= 256 ? k1_budget : 128) / (bco * bci);
   if (wgs < 1) wgs = 1;
   if (wgs > ntiles) wgs = ntiles;
@@ -1201,10 +1200,10 @@ static int launch_wgrad_bf16_k3_t(WgradParams& p, int accumulate, void* ws, size
   // 512 (two 3-wave workgroups per CU) 16.16 ms, 256: 15.89, 128: 15.81 with the weight gradients overlapped on the side
   // stream; 17.14 / 16.78 / 18.79 without overlap - fewer slices halve the partial-sum traffic (75 MB per layer at 512)
   // and leave CUs to the main stream; 256 is the best of both
-  static const int wg_budget = getenv("UPA_WGRAD_WGS") ? atoi(getenv("UPA_WGRAD_WGS")) : 256;
+  constexpr int wg_budget = 256;
   // ... except the stem (3.3 M output pixels): its weight gradient is the last kernel of the backward pass, nothing is
   // left to overlap it with, and alone it takes 280 us at 512 workgroups against 480 at 256 (15.42 vs 15.63 ms per step)
-  static const long big_px = getenv("UPA_WGRAD_BIG_PX") ? atol(getenv("UPA_WGRAD_BIG_PX")) : 3000000;
+  constexpr long big_px = 3000000;
   int budget = wg_budget > 0 && wg_budget <= 512 ? wg_budget : 256;
   if (big_px > 0 && (long)p.N * p.OH * p.OW >= big_px) budget = 512;  // the first layers run last in the backward pass
   int wgs = budget / (bco * bci);
@@ -1268,7 +1267,7 @@ extern "C" int upa_conv2d_wgrad(const void* x, int n, int h, int w, int cin, int
   p.OH = (h + 2 * pad - k) / stride + 1; p.OW = (w + 2 * pad - k) / stride + 1;
   p.KS = k; p.stride = stride; p.pad = pad;
   const bool small = wgrad_small(cin, cout);
-  static const bool no_bf16_mfma = getenv("UPA_WGRAD_F32_MFMA") != nullptr;
+  constexpr bool no_bf16_mfma = false;
   if (dtype == UPA_BF16 && k == 3 && cout >= 16 && !no_bf16_mfma && (cin % 8 == 0 || (cin < 8 && ldx >= 8)))
     return launch_wgrad_bf16_k3(p, accumulate, workspace, workspace_bytes, s);
   if (dtype == UPA_BF16 && k == 1 && stride == 1 && pad == 0 && cin >= 32 && cout >= 32 && !no_bf16_mfma && cin % 8 == 0)

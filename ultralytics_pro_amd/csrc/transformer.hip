@@ -389,10 +389,10 @@ extern "C" int upa_msdeform_attn(const float* value, const int32_t* shapes_hw, i
 // nn.Linear on token rows = 1x1 convolution over a (1, 1, M, K) NHWC view on the f32 MFMA kernel (exact f32 chain).
 // ---------------------------------------------------------------------------------------------------------------------
 extern "C" int upa_conv2d_bias_act(const void*, int, int, int, int, int, const void*, const float*, void*, int, int,
-                                   const void*, int, int, int, int, int, int, void*);
+                                   const void*, int, int, int, int, int, int, const upa_opts*, void*);
 
 extern "C" int upa_linear(const float* x, long m, int k, int ldx, const void* w_packed, const float* bias, float* y, int n,
                           int ldy, const float* residual, int ldr, int act, void* stream) {
   UPA_CHECK_ARG(m > 0 && m < (1L << 31), "linear: bad row count");
-  return upa_conv2d_bias_act(x, 1, 1, (int)m, k, ldx, w_packed, bias, y, n, ldy, residual, ldr, 1, 1, 0, act, UPA_F32, stream);
+  return upa_conv2d_bias_act(x, 1, 1, (int)m, k, ldx, w_packed, bias, y, n, ldy, residual, ldr, 1, 1, 0, act, UPA_F32, nullptr, stream);
 }

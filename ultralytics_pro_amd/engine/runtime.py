@@ -16,6 +16,43 @@ import torch
 from .. import _lib as L
 
 
+# ---- dispatch options of the calls being made (upa_opts, include/upa.h) -------------------------------------------------
+# The C library keeps no mode: every entry point that dispatches among kernel families takes a caller-owned `upa_opts*`.
+# On the Python side the options in force are a stack: BaseModel._predict_once pushes its model's `opts` (two models in one
+# process can differ), the parity tests and sweep tools wrap calls in `use_opts(L.Opts(...))`; the bottom of the stack is
+# `_DEFAULT_OPTS` (None = the library defaults; tests/conftest.py sets one so that every kernel family sees small shapes).
+_OPTS = []
+_DEFAULT_OPTS = [None]
+
+
+def set_default_opts(opts):
+    """Process-wide default of THIS PYTHON PACKAGE (not of the C library): the options used when no `use_opts` is active."""
+    _DEFAULT_OPTS[0] = opts
+
+
+def current_opts():
+    return _OPTS[-1] if _OPTS else _DEFAULT_OPTS[0]
+
+
+def opts_ptr():
+    """`const upa_opts*` argument for a C call: pointer to the options in force, or None (NULL = defaults)."""
+    o = current_opts()
+    return None if o is None else C.pointer(o)
+
+
+@contextlib.contextmanager
+def use_opts(opts=None, **fields):
+    """Run the enclosed calls with `opts` (an `_lib.Opts`), or with the options in force changed by `fields`."""
+    if fields:
+        base = opts if opts is not None else current_opts()
+        opts = (base.replace(**fields) if base is not None else L.Opts(**fields))
+    _OPTS.append(opts)
+    try:
+        yield opts
+    finally:
+        _OPTS.pop()
+
+
 @dataclass
 class View:
     ptr: int

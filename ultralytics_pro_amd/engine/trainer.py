@@ -48,7 +48,7 @@ def _s(dev):
 class _Ctx:
     """Per-trainer scratch shared by all layers."""
 
-    def __init__(self, device, dtype):
+    def __init__(self, device, dtype, wgrad_streams: int = 1):
         self.device, self.dtype = device, dtype
         self.code = L.dtype_code(dtype)
         self.es = 2 if dtype == torch.bfloat16 else 4
@@ -58,10 +58,8 @@ class _Ctx:
         self.wgrad_ws = torch.empty(0, dtype=torch.uint8, device=device)  # weight-gradient partial sums (largest layer)
         # weight gradients run on a side stream (a parallel branch of the captured graph): a layer's dW only needs its
         # input and dz, so it overlaps the data-gradient / BN-backward chain of the layers in front of it
-        import os
-        nws = int(os.environ.get("UPA_WGRAD_STREAMS", "1"))
-        self.wgrad_streams = [] if os.environ.get("UPA_TRAIN_NO_OVERLAP") else \
-            [torch.cuda.Stream(device=device) for _ in range(nws)]
+        # (wgrad_streams = 0: weight gradients on the main stream, no overlap - the A/B switch of that measurement)
+        self.wgrad_streams = [torch.cuda.Stream(device=device) for _ in range(max(0, int(wgrad_streams)))]
         self.wgrad_wss = [self.wgrad_ws for _ in self.wgrad_streams]  # one partial-sum workspace per stream
         self.wgrad_rr = 0
         self.wgrad_pending = False
@@ -145,7 +143,7 @@ class ConvT:
             rp, rld = vr.ptr, vr.ld
         L.check(L.lib().upa_conv2d_bias_act(vx.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, wp.data_ptr(),
                                             None if bias is None else bias.data_ptr(), vy.ptr, cout, vy.ld, rp, rld, k, s, p,
-                                            L.ACT_NONE, vx.dtype, _s(x.device)), f"conv2d[{self.name}]")
+                                            L.ACT_NONE, vx.dtype, R.opts_ptr(), _s(x.device)), f"conv2d[{self.name}]")
 
     def forward(self, x, out=None, residual=None):
         c, lib = self.ctx, L.lib()
@@ -363,18 +361,19 @@ class _Node:
 class DetectionTrainer:
     """One-process-per-GPU trainer for a DetectionModel (reference: engine/trainer.py BaseTrainer._do_train inner loop)."""
 
-    def __init__(self, model, dtype=torch.bfloat16, hyp=None, device=None, world_size=1, ema=True):
+    def __init__(self, model, dtype=torch.bfloat16, hyp=None, device=None, world_size=1, ema=True, wgrad_streams: int = 1):
         self.model = model
         self.hyp = dict(HYP, **(hyp or {}))
         self.device = torch.device(device or "cuda:0")
         self.dtype = dtype
         self.world_size = world_size
-        self.ctx = _Ctx(self.device, dtype)
+        self.ctx = _Ctx(self.device, dtype, wgrad_streams)
         self.pool = R.BufferPool()
         self.updates = 0
         self.first_step = True
         self._graphs = None
         self._capturing = False
+        self._issue_buckets = False
         self._imgsz = None
         self.gt_d = self.ngt_d = None
         self.schedule = None      # set_schedule(): warm-up interpolation + gradient accumulation of the reference's loop
@@ -397,6 +396,8 @@ class DetectionTrainer:
                 full = f"{mname}.{pname}" if mname else pname
                 (g2 if "bias" in full else g1 if isinstance(mod, norm) else g0).append(p)
         self.groups = []
+        self._param_meta = []  # (state_dict name, flat offset, numel) in flat order: gradient buckets are cut by layer from it
+        names = {id(p): n for n, p in self.model.named_parameters()}
         total = sum(p.numel() for g in (g2, g0, g1) for p in g)
         dev = self.device
         self.P = torch.empty(total, dtype=torch.float32, device=dev)
@@ -410,6 +411,7 @@ class DetectionTrainer:
                 self.P[off:off + n].copy_(p.detach().reshape(-1))  # plumbing: one-time gather of the initial weights
                 p.data = self.P[off:off + n].view(p.shape)
                 p.grad = self.G[off:off + n].view(p.shape)
+                self._param_meta.append((names.get(id(p), ""), off, n))
                 off += n
             self.groups.append((start, off - start, wd))
         self.E = self.P.clone() if ema else None  # ModelEMA copy of the parameters
@@ -523,9 +525,11 @@ class DetectionTrainer:
                 x = y
                 ys.append(y)
             items = self.detect.loss_backward(labels, img.shape[0])
+            self._bucket_hook(self.nodes[-1].i)
             # ---- backward over the layer list in reverse
             for nd in reversed(self.nodes[:-1]):
                 if nd.g is None:
+                    self._bucket_hook(nd.i)
                     continue  # output unused by the loss
                 dy = nd.g
                 if nd.kind in ("conv", "c2f", "sppf"):
@@ -552,6 +556,7 @@ class DetectionTrainer:
                         else:
                             copy_into(ctx, dy[:, c0:c0 + cj], dx)
                         c0 += cj
+                self._bucket_hook(nd.i)
             self._join_wgrad()
         return items
 
@@ -578,14 +583,94 @@ class DetectionTrainer:
                                   _s(self.device)), "sumsq")
         return self.sumsq
 
+    # ---- gradient exchange -------------------------------------------------------------------------------------------
+    def gradient_buckets(self, target_bytes: int = 16 << 20):
+        """Layer spans, last layer first, of at least `target_bytes` of f32 gradients each (DDP's bucket_cap_mb idea; yolov8s:
+        three spans of its 44.7 MB), as (first layer of the span, [flat ranges]).  Within each optimizer group the parameters
+        lie in layer order, so a span of layers is ONE contiguous range per group.  A span is complete - every gradient kernel
+        of its layers enqueued - once the backward walk has passed its first layer."""
+        per_layer = {}
+        for name, off, n in self._param_meta:
+            parts = name.split(".")
+            li = int(parts[1]) if len(parts) > 1 and parts[0] == "model" and parts[1].isdigit() else -1
+            per_layer.setdefault(li, []).append((off, off + n))
+        layers = sorted(per_layer, reverse=True)
+        spans, cur, cur_bytes = [], [], 0
+        for li in layers:
+            cur.append(li)
+            cur_bytes += 4 * sum(b - a for a, b in per_layer[li])
+            if cur_bytes >= target_bytes:
+                spans.append(cur)
+                cur, cur_bytes = [], 0
+        if cur:
+            spans.append(cur)
+        out = []
+        for sp in spans:
+            ranges = []
+            for gstart, gn, _ in self.groups:  # merge the span's parameters of one group into one range
+                inside = [(a, b) for li in sp for a, b in per_layer[li] if gstart <= a < gstart + gn]
+                if inside:
+                    ranges.append((min(a for a, _ in inside), max(b for _, b in inside)))
+            out.append((min(sp), ranges))
+        return out
+
+    def enable_overlapped_allreduce(self, target_bytes: int = 16 << 20):
+        """Issue the gradient all-reduce per bucket DURING backward on a communication stream (eager steps only: a collective
+        cannot sit inside the captured backward graph, so `compile()`d multi-GPU steps keep the single all-reduce between their
+        two graphs).  Returns the bucket table [(first layer, [ranges])]."""
+        from ..parallel import BucketedAllReduce
+        table = self.gradient_buckets(target_bytes)
+        self._bucket_first = {first: k for k, (first, _) in enumerate(table)}
+        self._buckets = BucketedAllReduce(self.G, [r for _, r in table])
+        ntot = self.groups[-1][0] + self.groups[-1][1]
+        assert self._buckets.covered() == ntot, "gradient buckets must cover the flat buffer exactly once"
+        self._exposed = []
+        return table
+
+    def _bucket_hook(self, layer_i: int):
+        """Called by the backward walk after layer `layer_i` has enqueued its gradient kernels."""
+        b = self.__dict__.get("_buckets")
+        if b is None or not self._issue_buckets or layer_i not in self._bucket_first:
+            return
+        evs = []
+        for st in [torch.cuda.current_stream(self.device)] + list(self.ctx.wgrad_streams):
+            ev = torch.cuda.Event()
+            ev.record(st)
+            evs.append(ev)
+        b.issue(self._bucket_first[layer_i], evs)
+
     def all_reduce_gradients(self):
-        """Batch-DP exchange step: one SUM all-reduce of the flat f32 gradient buffer over RCCL.
+        """Batch-DP exchange step: SUM all-reduce of the flat f32 gradient buffer over RCCL - one collective, or
+        the buckets `enable_overlapped_allreduce` issued during backward (then only the wait is left here, and the time the
+        optimizer had to wait for them is recorded: `allreduce_exposed_ms`).
         The reference multiplies the loss by world_size and lets DDP average the gradients (trainer.py:424-425), i.e.
         every rank ends up with sum_over_ranks d(loss_rank) - exactly the SUM of the unscaled per-rank gradients."""
         if self.world_size > 1:
+            b = self.__dict__.get("_buckets")
+            if b is not None and b.issued:
+                main = torch.cuda.current_stream(self.device)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(main)
+                for k in range(len(b.buckets)):  # (a span the walk never reached - a layer without gradient - goes now)
+                    b.issue(k)
+                b.wait()
+                e1.record(main)
+                self._exposed.append((e0, e1))
+                return
             from ..parallel import allreduce_gradients_
             n = self.groups[-1][0] + self.groups[-1][1]
             allreduce_gradients_(self.G[:n])
+
+    def allreduce_exposed_ms(self):
+        """Mean time (ms) the main stream spent waiting for the overlapped all-reduce after backward had finished, over the
+        steps since the last call (None if nothing was recorded).  Synchronises."""
+        ex = self.__dict__.get("_exposed") or []
+        if not ex:
+            return None
+        torch.cuda.synchronize(self.device)
+        ms = [a.elapsed_time(b) for a, b in ex]
+        self._exposed = []
+        return sum(ms) / len(ms)
 
     def set_schedule(self, batches_per_epoch: int, global_batch: int | None = None, **overrides):
         """Enable the reference's warm-up and gradient accumulation (engine/trainer.py:337-338, 392-413):
@@ -652,7 +737,12 @@ class DetectionTrainer:
         backward | all-reduce | optimizer on several)."""
         if self._graphs is not None:
             return self._replay(img, labels)
+        # buckets go out during backward only on an iteration that ends in an optimizer step (gradient accumulation adds
+        # several backward passes into the flat buffer before it is exchanged once)
+        acc = self.schedule_at(self.ni, img.shape[0])[0]
+        self._issue_buckets = self.world_size > 1 and self.ni - self.last_opt_step >= acc
         items = self.forward_backward(img, labels)
+        self._issue_buckets = False
         self._maybe_optimize(img.shape[0])
         return items
 

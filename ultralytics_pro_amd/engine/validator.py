@@ -63,6 +63,14 @@ class DetectionValidator:
         self._gt.append(gt[:, :, 0].clone())
         self._ngt.append(ngt.clone())
 
+    def add_batch_stats(self, out: torch.Tensor, counts: torch.Tensor, tp: torch.Tensor, gt: torch.Tensor, ngt: torch.Tensor):
+        """Statistics of a batch whose matching already ran (e.g. inside a captured step: `bench.py --workload val`)."""
+        self._det.append(out.clone())
+        self._cnt.append(counts.clone())
+        self._tp.append(tp.clone())
+        self._gt.append(gt[:, :, 0].clone())
+        self._ngt.append(ngt.clone())
+
     # ---- end of run -----------------------------------------------------------------------------------------------------
     def local_stats(self):
         """This rank's fixed-shape statistics: (conf|cls|tp rows (I, max_det, 12) f32, counts (I,), gt classes (I, G) f32,

@@ -61,7 +61,7 @@ class Bottleneck(nn.Module):
             vx, vy = R.view_of(x), R.view_of(y)
             rc = L.lib().upa_bottleneck_pair(vx.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, p1.w.data_ptr(), p1.bias.data_ptr(),
                                              p2.w.data_ptr(), p2.bias.data_ptr(), vy.ptr, vy.ld, int(self.add), L.ACT_SILU,
-                                             vx.dtype, L.current_stream(x.device))
+                                             vx.dtype, R.opts_ptr(), L.current_stream(x.device))
             if rc == 0:
                 return y
             if rc != L.UPA_EUNSUPPORTED:
@@ -105,7 +105,8 @@ class C2f(nn.Module):
         vx, vy = R.view_of(x), R.view_of(y)
         rc = L.lib().upa_c2f_fused(vx.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, self.c, nb, int(self.m[0].add), pk[0].w.data_ptr(),
                                    pk[0].bias.data_ptr(), C.cast(wm, C.c_void_p), C.cast(bm, C.c_void_p), pk[1].w.data_ptr(),
-                                   pk[1].bias.data_ptr(), vy.ptr, vy.c, vy.ld, L.ACT_SILU, vx.dtype, L.current_stream(x.device))
+                                   pk[1].bias.data_ptr(), vy.ptr, vy.c, vy.ld, L.ACT_SILU, vx.dtype, R.opts_ptr(),
+                                   L.current_stream(x.device))
         if rc == 0:
             return y
         if rc != L.UPA_EUNSUPPORTED:
@@ -170,7 +171,8 @@ class C2f(nn.Module):
         vx, v0, vy = R.view_of(cat[:, 32:64]), R.view_of(cat[:, :32]), R.view_of(y)
         rc = L.lib().upa_bottleneck_pair_cv2(vx.ptr, v0.ptr, vx.n, vx.h, vx.w, vx.ld, p1.w.data_ptr(), p1.bias.data_ptr(),
                                              p2.w.data_ptr(), p2.bias.data_ptr(), int(m.add), std.w.data_ptr(), wb_d.data_ptr(),
-                                             std.bias.data_ptr(), vy.ptr, vy.ld, L.ACT_SILU, vx.dtype, L.current_stream(dev))
+                                             std.bias.data_ptr(), vy.ptr, vy.ld, L.ACT_SILU, vx.dtype, R.opts_ptr(),
+                                             L.current_stream(dev))
         if rc == 0:
             return y
         if rc != L.UPA_EUNSUPPORTED:

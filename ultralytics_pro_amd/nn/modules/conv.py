@@ -110,7 +110,7 @@ def hip_conv2d(x: torch.Tensor, pk: PackedConv, stride: int, pad: int, act: int,
         vy = R.view_of(y)
         L.check(lib.upa_conv2d_stem_nchw(x.data_ptr(), xcode, n, cin, h, w, pk.w.data_ptr(),
                                          pk.bias.data_ptr(), vy.ptr, pk.cout, vy.ld, pk.k, stride, pad, act, vy.dtype,
-                                         stream), "conv2d_stem")
+                                         R.opts_ptr(), stream), "conv2d_stem")
         return y
     vx = R.view_of(x)
     oh, ow = (vx.h + 2 * pad - pk.k) // stride + 1, (vx.w + 2 * pad - pk.k) // stride + 1
@@ -131,14 +131,14 @@ def hip_conv2d(x: torch.Tensor, pk: PackedConv, stride: int, pad: int, act: int,
         if pk.k == 1 and stride == 1 and pad == 0 and residual is None and vu.dtype == vx.dtype and vu.c == up.channels \
                 and (vu.n, 2 * vu.h, 2 * vu.w) == (vx.n, vx.h, vx.w):
             rc = lib.upa_conv1x1_upcat(vx.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, vu.ptr, vu.c, vu.ld, pk.w.data_ptr(),
-                                       pk.bias.data_ptr(), vy.ptr, pk.cout, vy.ld, act, vx.dtype, stream)
+                                       pk.bias.data_ptr(), vy.ptr, pk.cout, vy.ld, act, vx.dtype, R.opts_ptr(), stream)
         if rc == 0:
             return y
         if rc != L.UPA_EUNSUPPORTED:
             L.check(rc, "conv1x1_upcat")
         up.materialize()
     L.check(lib.upa_conv2d_bias_act(vx.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, pk.w.data_ptr(), pk.bias.data_ptr(), vy.ptr,
-                                    pk.cout, vy.ld, rp, rld, pk.k, stride, pad, act, vx.dtype, stream), "conv2d")
+                                    pk.cout, vy.ld, rp, rld, pk.k, stride, pad, act, vx.dtype, R.opts_ptr(), stream), "conv2d")
     return y
 
 

@@ -134,7 +134,8 @@ class Detect(nn.Module, _HipConvMixin):
         rc = L.lib().upa_detect_branch_tail(vt.ptr, vt.n, vt.h, vt.w, vt.c, vt.ld, pk3.w.data_ptr(), pk3.bias.data_ptr(),
                                             wt.data_ptr(), bt.data_ptr(), kind, self.nc, float(self.stride[i]),
                                             plan["y"].data_ptr(), plan["a_total"], plan["a0"][i],
-                                            hot.data_ptr() if hot is not None else None, vt.dtype, L.current_stream(t.device))
+                                            hot.data_ptr() if hot is not None else None, vt.dtype, R.opts_ptr(),
+                                            L.current_stream(t.device))
         if rc == L.UPA_EUNSUPPORTED:
             return False
         L.check(rc, "detect_branch_tail")
@@ -153,7 +154,7 @@ class Detect(nn.Module, _HipConvMixin):
             rp, rld = vr.ptr, vr.ld
         L.check(L.lib().upa_detect_tail(vt.ptr, vt.n, vt.h, vt.w, vt.c, vt.ld, pk.w.data_ptr(), pk.bias.data_ptr(), cout, kind,
                                         self.nc, float(self.stride[i]), plan["y"].data_ptr(), plan["a_total"], plan["a0"][i],
-                                        rp, rld, vt.dtype, L.current_stream(t.device)), "detect_tail")
+                                        rp, rld, vt.dtype, R.opts_ptr(), L.current_stream(t.device)), "detect_tail")
 
     def _branch(self, seq: nn.Sequential, x: torch.Tensor, out: torch.Tensor) -> None:
         t = seq[1](seq[0](x))

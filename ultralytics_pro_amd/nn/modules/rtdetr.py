@@ -365,7 +365,7 @@ class RTDETRDecoder(nn.Module):
             v = R.view_of(t)
             L.check(lib.upa_conv2d_bias_act(v.ptr, v.n, v.h, v.w, v.c, v.ld, pk.w.data_ptr(), pk.bias.data_ptr(),
                                             feats.data_ptr() + row0 * hd * 4, hd, hd, None, 0, 1, 1, 0, L.ACT_NONE,
-                                            L.UPA_F32, st_), "input_proj")
+                                            L.UPA_F32, R.opts_ptr(), st_), "input_proj")
             row0 += bs * v.h * v.w
         # ---- _get_decoder_input (head.py:2143-2200)
         masked = _Rows.new(bs * T, hd, dev, key=(id(self), "masked"))

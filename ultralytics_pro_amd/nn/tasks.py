@@ -171,9 +171,6 @@ class HipSequential(nn.Sequential):
 _OUT_CAPABLE = (Conv, C2f, C3, SPPF, BoT3, Bottleneck, Upsample, MaxPool2d, HipSequential)
 
 
-_EXTRA_LAUNCHES = int(__import__("os").environ.get("UPA_EXTRA_LAUNCHES", "0"))
-
-
 class BaseModel(nn.Module):
     """Base class: forward -> predict -> _predict_once (tasks.py:987-1134)."""
 
@@ -190,7 +187,16 @@ class BaseModel(nn.Module):
             raise L.UpaError("augment / visualize / embed / profile are outside the hot-path scope")
         return self._predict_once(x)
 
+    opts = None  # _lib.Opts: dispatch overrides of THIS model's kernel calls (None = the options in force / library defaults)
+
     def _predict_once(self, x):
+        """The layer loop (see `_predict_once_impl`), run under this model's dispatch options when it has any."""
+        if self.opts is None:
+            return self._predict_once_impl(x)
+        with R.use_opts(self.opts):
+            return self._predict_once_impl(x)
+
+    def _predict_once_impl(self, x):
         """The layer loop: route `m.f`, run, save if in `save` (tasks.py:1046-1085).
 
         Concat-by-construction: a layer whose output feeds a `Concat` row writes straight into its channel slice of
@@ -257,10 +263,6 @@ class BaseModel(nn.Module):
             if virt and not isinstance(m, (Upsample, Concat)):
                 raise L.UpaError(f"virtual Upsample of Concat row(s) {sorted(virt)} was not consumed by row {m.i}")
             y.append(x if m.i in self.save else None)
-            if _EXTRA_LAUNCHES and torch.is_tensor(x):  # experiment: what does one more tiny dependent launch cost a step?
-                d = R.alloc_plain((64,), torch.float32, x.device, key=("extra_launch", m.i))
-                for _ in range(_EXTRA_LAUNCHES):
-                    L.check(L.lib().upa_sigmoid(d.data_ptr(), d.data_ptr(), 64, L.current_stream(x.device)), "extra")
             if m.i in det_level and torch.is_tensor(x):  # a Detect input is ready: start that level's branches now
                 det.start_level(det_level[m.i], x)
         return x
@@ -321,7 +323,8 @@ class BaseModel(nn.Module):
         y = R.alloc_nhwc(n, 32, h // 4, w // 4, torch.bfloat16, x.device, key=(id(b), "y"))
         vy = R.view_of(y)
         L.check(L.lib().upa_stem_conv_fused(x.data_ptr(), n, h, w, pa.w.data_ptr(), pa.bias.data_ptr(), pb.w.data_ptr(),
-                                            pb.bias.data_ptr(), vy.ptr, vy.ld, L.current_stream(x.device)), "stem_conv_fused")
+                                            pb.bias.data_ptr(), vy.ptr, vy.ld, R.opts_ptr(), L.current_stream(x.device)),
+                "stem_conv_fused")
         return y
 
     def _concat_placement(self):

@@ -95,3 +95,52 @@ def allreduce_gradients_(flat_grads: torch.Tensor) -> torch.Tensor:
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM)
     return flat_grads
+
+
+class BucketedAllReduce:
+    """The gradient exchange of the batch-DP training step issued in BUCKETS while backward is still running (the reference's
+    DDP overlaps 25 MB buckets with backward, engine/trainer.py:305).  A bucket is a list of [start, end) ranges of the flat
+    f32 gradient buffer - the parameters of a span of layers in each of the three optimizer groups - and is reduced (SUM, the
+    same exchange as `allreduce_gradients_`) the moment the last gradient kernel of that span has been enqueued:
+
+        issue(k, events)   comm stream waits for `events` (the streams that produced the span's gradients), then every range of
+                           bucket k is all-reduced asynchronously (RCCL runs it on its own stream, ordered after the comm stream)
+        wait()             the CURRENT stream waits for every issued bucket (stream-level wait, the host does not block);
+                           returns the number of buckets that were in flight
+
+    SUM all-reduces of disjoint ranges equal one all-reduce of the whole buffer bit for bit (tests/test_dp_gloo.py).  On CPU
+    tensors (gloo, the tests) there are no streams: `issue` starts the asynchronous collectives, `wait` blocks on them."""
+
+    def __init__(self, flat: torch.Tensor, buckets):
+        self.flat = flat
+        self.buckets = [[(int(a), int(b)) for a, b in rs if b > a] for rs in buckets]
+        self.pending = []
+        self.issued = set()
+        self.comm = torch.cuda.Stream(device=flat.device) if flat.is_cuda else None
+
+    def active(self) -> bool:
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def issue(self, k: int, events=()):
+        if not self.active() or k in self.issued:
+            return
+        self.issued.add(k)
+        if self.comm is not None:
+            for ev in events:
+                self.comm.wait_event(ev)
+            with torch.cuda.stream(self.comm):
+                for a, b in self.buckets[k]:
+                    self.pending.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, async_op=True))
+        else:
+            for a, b in self.buckets[k]:
+                self.pending.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, async_op=True))
+
+    def wait(self) -> int:
+        n = len(self.issued)
+        for w in self.pending:
+            w.wait()
+        self.pending, self.issued = [], set()
+        return n
+
+    def covered(self) -> int:
+        return sum(b - a for rs in self.buckets for a, b in rs)

@@ -114,6 +114,35 @@ HEAD_RECIPE = {
 RTDETR_SCORE_BIAS = -6.5
 RTDETR_SCORE_GAIN = 1.5
 
+# --------------------------------------------------------------------------------------------------------------------
+# "smooth" families (`family="smooth:<model>"`, round 3): the same hash draws with a recipe under which bf16 arithmetic
+# reproduces the f32 DETECTIONS, not just the head outputs.  What breaks set agreement with the default recipe is not the size
+# of the bf16 error (a few 1e-3 in score, < 1 px) but the structure of a random-weight head: neighbouring anchors predict
+# large, heavily overlapping boxes with nearly equal scores, so a 1e-3 score change flips which of them survives NMS and the
+# surviving box jumps by a stride.  A trained head does not do that (neighbours regress to the same object box); the smooth
+# recipe removes the competition instead:
+#   * DFL bias falls linearly with the bin index (SMOOTH_DFL_SLOPE per bin), so the expected side distances are 0.3 - 2.5
+#     cells and boxes of adjacent anchors overlap with IoU < 0.7: NMS suppresses almost nothing and the detection set is the
+#     threshold set;
+#   * conv gain a little below the default (perturbations decay instead of growing through the 20+ layers), moderate head
+#     gains;
+#   * the class bias puts ~1 % of the anchors above conf = 0.25 (fewer threshold-straddling anchors per image);
+#   * conv weights are the default draws rounded to bf16 and every BatchNorm has scale exactly 1 (gamma = 1, var = 0.999,
+#     eps = 1e-3), so the BN-folded weights ARE bf16 numbers: the bf16 pipeline multiplies exactly the weights the f32
+#     reference multiplies (what a checkpoint stored in half precision gives) and the comparison isolates the rounding of
+#     the activations - the weight-rounding error has its own per-kernel tests (tests/test_hip_ops.py, bf16_weight_oracle).
+# Per model: (conv gain^2, final cls 1x1 weight gain, mean final cls bias, final box 1x1 weight gain).
+SMOOTH_DFL_SLOPE = 0.8
+# Tuned with tools/experiments/smooth_scan.py (oracle f32 vs a bf16 emulation of it, CPU): the class bias is the 1 % quantile of
+# the per-anchor best logit of the two golden images; constants are part of the fixture definition (tests/golden/e2e_*_smooth.npz).
+SMOOTH_RECIPE = {
+    "default": (6.5, 4.0, -4.0, 1.5),
+    "yolov8n": (6.5, 4.0, -4.09, 1.5),
+    "yolov8s": (6.5, 4.0, -3.08, 1.5),
+    "yolov3-tiny": (5.5, 4.0, -3.16, 1.5),
+    "yolov5-BoT3": (6.5, 4.0, -3.75, 1.5),
+}
+
 
 def _fan_in(shape) -> int:
     return int(np.prod(shape[1:])) if len(shape) > 1 else int(shape[0])
@@ -127,7 +156,12 @@ def procedural_tensor(key: str, ref: torch.Tensor, kind: str, seed: int = 0, res
     """
     shape = tuple(ref.shape)
     leaf = key.rsplit(".", 1)[-1]
-    cls_w_gain, cls_bias_shift, box_w_gain = HEAD_RECIPE.get(family, HEAD_RECIPE["default"])
+    smooth = family.startswith("smooth:")
+    conv_gain2 = CONV_GAIN2
+    if smooth:
+        conv_gain2, cls_w_gain, cls_bias_shift, box_w_gain = SMOOTH_RECIPE.get(family[7:], SMOOTH_RECIPE["default"])
+    else:
+        cls_w_gain, cls_bias_shift, box_w_gain = HEAD_RECIPE.get(family, HEAD_RECIPE["default"])
     if not ref.dtype.is_floating_point:  # num_batches_tracked
         return None
     if key.endswith("dfl.conv.weight"):  # DFL expectation weights arange(16): block.py:245-248
@@ -135,6 +169,10 @@ def procedural_tensor(key: str, ref: torch.Tensor, kind: str, seed: int = 0, res
     if "sampling_offsets.bias" in key:  # deterministic grid init: transformer.py:491-502
         return None
     if kind == "norm":
+        if smooth and leaf in ("running_var", "weight") and len(shape) == 1:
+            # BatchNorm scale gamma / sqrt(var + eps) = 1 / sqrt(0.999 + 1e-3) = 1 exactly: folding leaves the (bf16-exact)
+            # conv weights untouched, see SMOOTH_RECIPE
+            return torch.full(shape, 0.999 if leaf == "running_var" else 1.0)
         if leaf == "running_var":
             return uniform(key, shape, 0.5, 1.5, seed)
         if leaf == "weight":
@@ -146,7 +184,7 @@ def procedural_tensor(key: str, ref: torch.Tensor, kind: str, seed: int = 0, res
     if len(shape) >= 2:  # conv / linear / in_proj weights
         g2 = 3.0
         if kind == "conv" and not det_final:
-            g2 = RES_GAIN2 if residual_tail else CONV_GAIN2
+            g2 = RES_GAIN2 if residual_tail else conv_gain2
             if parts[-2] in ("query", "key", "value"):  # MHSA 1x1 convs: keep the unscaled q^T k energies O(1)
                 g2 = ATTN_GAIN2
         a = math.sqrt(g2 / _fan_in(shape))
@@ -157,10 +195,16 @@ def procedural_tensor(key: str, ref: torch.Tensor, kind: str, seed: int = 0, res
             gain = RTDETR_SCORE_GAIN
         if "sampling_offsets" in key:
             gain = 0.5
-        return uniform(key, shape, -a * gain, a * gain, seed)
+        w = uniform(key, shape, -a * gain, a * gain, seed)
+        if smooth and kind == "conv":  # weights a bf16 model stores exactly (round-to-nearest-even of the same draws)
+            w = w.to(torch.bfloat16).to(torch.float32)
+        return w
     if det_final and parts[-4] == "cv3":
         return uniform(key, shape, cls_bias_shift - CLS_BIAS_SPREAD, cls_bias_shift + CLS_BIAS_SPREAD, seed)
     if det_final and parts[-4] == "cv2":
+        if smooth:  # 4 sides x reg_max bins: the bias of bin k falls with k (small expected distances, see SMOOTH_RECIPE)
+            k = torch.arange(shape[0], dtype=torch.float32) % 16
+            return uniform(key, shape, -0.2, 0.2, seed) - SMOOTH_DFL_SLOPE * k
         return uniform(key, shape, 0.5, 1.5, seed)
     if "score_head" in key:
         return uniform(key, shape, RTDETR_SCORE_BIAS - 0.5, RTDETR_SCORE_BIAS + 0.5, seed)
