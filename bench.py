@@ -799,7 +799,8 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
     orig_c2f = L.lib().upa_c2f_fused
     orig_btail = L.lib().upa_detect_branch_tail
     orig_paircv2 = L.lib().upa_bottleneck_pair_cv2
-    pair_calls, c2f_calls, btail_calls, paircv2_calls = [], [], [], []
+    orig_c2f64 = L.lib().upa_c2f64_fused
+    pair_calls, c2f_calls, btail_calls, paircv2_calls, c2f64_calls = [], [], [], [], []
 
     class _LibProxy:
         """Forwards every C entry to the real library, recording the fused-block launches (Bottleneck / C2f / Detect call
@@ -824,6 +825,12 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
             rc = orig_c2f(*a)
             if rc == 0:
                 c2f_calls.append(a)
+            return rc
+
+        def upa_c2f64_fused(self, *a):
+            rc = orig_c2f64(*a)
+            if rc == 0:
+                c2f64_calls.append(a)
             return rc
 
         def upa_detect_branch_tail(self, *a):
@@ -870,6 +877,13 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
         th = 10 if (c_ != 16 and nb_ == 2 and o_ is not None and o_.c2f32_th == 10) else 16
         name = "void c2f16_fused_kernel<%d>(C2fParams)" % (8 if (o_ is not None and o_.c2f16_waves == 8) else 4) if c_ == 16 else "void c2f32_fused_kernel<%d, %d>(C2f32Params)" % (nb_, th)
         calls.append((name, flops, nbytes, (lambda a=a: orig_c2f(*a[:21], L.current_stream(dev)))))
+    for a in c2f64_calls:  # (x, n, h, w, c1, ldx, up, up_c, up_ld, nb, shortcut, w1, b1, wm, bm, w2, b2, y, c2, ldy, act, dtype, opts, stream)
+        npx, c1_, upc_, nb_, c2_ = a[1] * a[2] * a[3], a[4], a[7], a[9], a[18]
+        wts = c1_ * 128 + nb_ * 18 * 64 * 64 + (2 + nb_) * 64 * c2_
+        flops = 2.0 * npx * wts
+        nbytes = npx * (c1_ - upc_ * 3 // 4 + c2_) * 2 + wts * 2  # block input (the upsampled channels at quarter size) + output + weights
+        calls.append(("void c2f64_fused_kernel<%d, 10, %d>(C2f64Params)" % (nb_, 10 if nb_ == 2 else 20), flops, nbytes,
+                      (lambda a=a: orig_c2f64(*a[:23], L.current_stream(dev)))))
     for a in btail_calls:  # (x, n, h, w, c, ldx, w3, b3, wt, bt, kind, nc, stride, y, a_total, a0, best_keys, dtype, opts, stream)
         npx, c_, kind, nc_ = a[1] * a[2] * a[3], a[4], a[10], a[11]
         cout = 64 if kind == 1 else nc_

@@ -50,7 +50,7 @@ typedef struct upa_opts {
   int32_t pair;            /* upa_bottleneck_pair: 0 = C = 32 only (default), 1 = never, 2 = C = 32 and 64, 3 = C = 64 only */
   int32_t pair_tile64, pair_tile32;  /* its square output tile edge per width (0 = auto) */
   int32_t no_pair_cv2;     /* upa_bottleneck_pair_cv2: 1 = never */
-  int32_t c2f;             /* upa_c2f_fused: 0 = both forms, 1 = never, 2 = not the 16-wide, 3 = not the 32-wide */
+  int32_t c2f;             /* upa_c2f_fused / upa_c2f64_fused: 0 = every form, 1 = never, 2 = not the 16-wide, 3 = not the 32-wide, 4 = not the 64-wide */
   int32_t c2f16_waves;     /* 0 = 4 | 8 */
   int32_t c2f32_th;        /* output tile rows of the C2f(64, 64, n = 2) form: 0 = 16 | 10 */
   int32_t no_branch_tail;  /* upa_detect_branch_tail: 1 = never */
@@ -182,6 +182,14 @@ int upa_bottleneck_pair_cv2(const void* x, const void* y0, int n, int h, int w, 
 int upa_c2f_fused(const void* x, int n, int h, int w, int c1, int ldx, int c, int nb, int shortcut, const void* w1,
                   const float* b1, const void* const* wm, const float* const* bm, const void* w2, const float* b2, void* y,
                   int c2, int ldy, int act, int dtype, const upa_opts* opts, void* stream);
+
+/* The same for the 64-channel-half blocks (csrc/c2f64.hip): C2f(c1 -> 128, c = 64, n = nb in {1, 2}), c1 % 64 == 0 - yolov8n
+ * model.6 / model.12 / model.18 at 40 x 40, yolov8s model.4 / model.15 at 80 x 80.  `up` (may be NULL): a (n, h/2, w/2, up_c) tensor
+ * holding the first up_c (% 64 == 0) channels of every pixel at half resolution - the nn.Upsample(2x nearest) + Concat in front
+ * of the block read on the fly (yolov8.yaml rows 10-12), x's first up_c channels are then never read.   block.py:457-488, :644-668 */
+int upa_c2f64_fused(const void* x, int n, int h, int w, int c1, int ldx, const void* up, int up_c, int up_ld, int nb, int shortcut,
+                    const void* w1, const float* b1, const void* const* wm, const float* const* bm, const void* w2,
+                    const float* b2, void* y, int c2, int ldy, int act, int dtype, const upa_opts* opts, void* stream);
 
 /* The whole back half of a Detect branch in one launch (bf16): second 3x3 conv (BN + SiLU folded) -> final 1x1 conv -> that
  * branch's half of the decode, the intermediate maps never leaving the registers.      head.py:94-100 (cv2/cv3), :116-126,

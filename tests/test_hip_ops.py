@@ -368,6 +368,74 @@ def test_c2f_fused_kernel(case, th):
     assert float(to_cpu_nchw(buf[:, :c1]).abs().max()) == 0.0  # nothing written outside the output slice
 
 
+C2F64_CASES = [
+    # c1, n, shortcut, (N, H, W), up_c  (C2f(c1, 128, n) with 64-channel halves as one kernel, csrc/c2f64.hip)
+    (128, 2, True, (2, 40, 40), 0),     # yolov8n model.6: 10 x 10 tiles, no ragged edge
+    (128, 2, False, (1, 23, 17), 0),    # ragged tiles, no shortcut
+    (128, 2, True, (1, 10, 10), 0),     # exactly one tile: every ring is image border
+    (128, 2, True, (3, 9, 5), 0),       # a map smaller than a tile
+    (384, 1, False, (2, 40, 40), 256),  # yolov8n model.12: virtual Upsample + Concat in front, six 64-channel chunks, 10 x 20 tiles
+    (192, 1, False, (2, 20, 36), 0),    # yolov8n model.18: three chunks, ragged 20-wide tiles
+    (192, 1, True, (1, 14, 22), 128),   # up_c = 128 of 192, shortcut, odd tile counts
+    (64, 1, True, (2, 12, 12), 0),      # a single chunk
+]
+
+
+@pytest.mark.parametrize("case", C2F64_CASES, ids=[f"c{c[0]}n{c[1]}{'s' if c[2] else ''}_{c[3][0]}x{c[3][1]}x{c[3][2]}{'_up' + str(c[4]) if c[4] else ''}" for c in C2F64_CASES])
+def test_c2f64_fused_kernel(case):
+    """`upa_c2f64_fused` (bf16): a whole C2f block with 64-channel halves (block.py:457-488, Bottlenecks :644-668) as one kernel -
+    yolov8n model.6 / model.12 / model.18 - vs the oracle C2f on BN-folded bf16 weights with every intermediate (cv1 output, each
+    Bottleneck's mid tensor and output) rounded to bf16 where the kernel rounds it, and vs the product's own multi-launch path.
+    The input may be Concat([Upsample(2x)(u), skip]) with the upsample read on the fly (yolov8.yaml rows 10-12): the leading channels
+    of the concat buffer are then filled with a sentinel that must never be read.  Ragged tiles, maps smaller than a tile (every
+    ring is image border: the 3x3 convs' zero padding must be zero, not SiLU(bias)), 1 / 2 / 3 / 6 input chunks, strided output."""
+    from tests.hip_utils import DEV, assert_bf16_close, bf16_round, bf16_weight_oracle, to_cpu_nchw, to_dev_nhwc
+    from ultralytics_pro_amd.engine import runtime as R
+    from ultralytics_pro_amd.nn.modules.conv import VirtualUpsample
+    pm, rs = _mods()
+    c1, nb, sc, (N, H, W), upc = case
+    o, m = _pair(om.C2f, pm.C2f, (c1, 128, nb, sc), f"c2f64_{c1}{nb}")
+    o = bf16_weight_oracle(o)
+    if upc:
+        u = bf16_round(P.uniform(f"c2f64u{case}", (N, upc, H // 2, W // 2), -1.5, 1.5))
+        sk = bf16_round(P.uniform(f"c2f64s{case}", (N, c1 - upc, H, W), -1.5, 1.5))
+        x = torch.cat([torch.nn.functional.interpolate(u, scale_factor=2, mode="nearest"), sk], 1)
+    else:
+        x = bf16_round(P.uniform(f"c2f64{case}", (N, c1, H, W), -1.5, 1.5))
+    with torch.no_grad():
+        ys = list(bf16_round(o.cv1(x)).chunk(2, 1))
+        for bt in o.m:
+            t = bf16_round(bt.cv1(ys[-1]))
+            ys.append(bf16_round((ys[-1] if sc else 0) + bt.cv2(t)))
+        ref = o.cv2(torch.cat(ys, 1))
+        buf = R.alloc_nhwc(N, 256, H, W, torch.bfloat16, DEV)
+        buf.zero_()
+        xd = to_dev_nhwc(x, torch.bfloat16)
+        up = None
+        if upc:
+            ud = to_dev_nhwc(u, torch.bfloat16)
+            xd[:, :upc].fill_(77.0)  # never read on the fused path
+            mat = []
+            upm = rs.Upsample(None, 2, "nearest")
+            up = VirtualUpsample(ud, upc, lambda: mat.append(upm(ud, out=xd[:, :upc])))
+        m.fuse_block = True
+        assert m._form64()
+        y = to_cpu_nchw(m(xd, out=buf[:, 128:], up=up))
+        if upc:
+            assert not mat and not up.done, "the fused block must read the half-resolution tensor itself"
+            up.materialize()
+        m.fuse_block = False
+        y2 = to_cpu_nchw(m(xd))
+    scale = max(1.0, ref.abs().max().item())
+    assert_bf16_close(y, ref, f"c2f64{case}", abs_=2.0 ** -7)  # (flipped ties of up to six bf16 intermediates: see the pair test)
+    # vs the product's own launches: same rounding points, other f32 summation orders - a flipped bf16 tie of an intermediate moves
+    # its consumers by an ulp; without the shortcut nothing damps it (measured: 3.6 % of the outputs one ulp apart with the shortcut, 5.5 % without, n = 2)
+    d = (y - y2).abs()
+    assert d.max().item() <= 3e-2 * scale and (d > 1e-6).float().mean().item() <= (0.05 if sc else 0.10), \
+        (d.max().item(), (d > 1e-6).float().mean().item())
+    assert float(to_cpu_nchw(buf[:, :128]).abs().max()) == 0.0  # nothing written outside the output slice
+
+
 C1_CASES = [
     # c1, c2, H, W, N, act, env  (1x1 s1: the streaming pointwise kernel, csrc/conv1x1.hip)
     (64, 64, 16, 16, 2, True, {}),                                   # KTT 2, NTW 4

@@ -1,0 +1,24 @@
+"""Candidate counts per image of the bench batch and the time of the NMS launches (HIP events)."""
+import sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+import torch
+from ultralytics_pro_amd.nn.tasks import DetectionModel
+from ultralytics_pro_amd.utils import procedural as P
+from ultralytics_pro_amd.utils.nms import nms_raw
+dev = torch.device("cuda:0")
+m = DetectionModel("yolov8n.yaml"); P.apply_procedural_weights(m); m = m.to(dev).eval(); m.set_compute_dtype(torch.bfloat16)
+det = m.model[-1]; det.keep_raw = False; det.nms_keys = True
+x = P.synthetic_images(32).to(dev).to(torch.bfloat16).contiguous()
+with torch.no_grad():
+    y = m(x)[0]
+    torch.cuda.synchronize()
+    n = (y[:, 4:].max(1).values > 0.25).sum(1)
+    print("candidates per image: min %d mean %.1f max %d" % (int(n.min()), float(n.float().mean()), int(n.max())), n.tolist())
+    for rep in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            out, counts, keep = nms_raw(y, 0.25, 0.7, max_det=300, key="t")
+        e1.record(); torch.cuda.synchronize()
+        print("nms_raw (sort + greedy): %.1f us per call; kept mean %.1f" % (e0.elapsed_time(e1) / 20 * 1e3, float(counts.float().mean())))

@@ -111,7 +111,7 @@ inline void upa_zero_words(void* p, int n_words, hipStream_t s) {
 // always are; a straddling m-tile is when the image's row step is right for the tile width (W = 40: step = 0 mod 8; W = 20: 4
 // mod 8).  These helpers count the extra LDS cycles of one tap over a tile and pick the smallest pitch >= min_pitch with the
 // fewest (0 for every tile width the dispatchers use).  row_mult: image rows between consecutive tile rows (the conv stride).
-static inline int upa_lds_conflict_cycles(int W, int npix, int row_step) {
+static constexpr int upa_lds_conflict_cycles(int W, int npix, int row_step) {
   int extra = 0;
   for (int m0 = 0; m0 < npix; m0 += 16) {
     for (int set = 0; set < 2; ++set) {
@@ -128,7 +128,7 @@ static inline int upa_lds_conflict_cycles(int W, int npix, int row_step) {
   }
   return extra;
 }
-static inline int upa_lds_pick_pitch(int min_pitch, int W, int npix, int row_mult) {
+static constexpr int upa_lds_pick_pitch(int min_pitch, int W, int npix, int row_mult) {
   int best = min_pitch, best_cost = 1 << 30;
   for (int P = min_pitch; P < min_pitch + 8; ++P) {
     const int c = upa_lds_conflict_cycles(W, npix, (P * row_mult) & 7);

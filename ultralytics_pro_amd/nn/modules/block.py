@@ -80,16 +80,23 @@ class C2f(nn.Module):
         self.cv2 = Conv((2 + n) * self.c, c2, 1)
         self.m = nn.ModuleList(Bottleneck(self.c, self.c, shortcut, g, k=((3, 3), (3, 3)), e=1.0) for _ in range(n))
 
-    fuse_block = True  # bf16 C2f(32, 32, n=1, shortcut) / C2f(64, 64, n=1|2): the whole block as one kernel (upa_c2f_fused)
+    # bf16 C2f(32, 32, n=1, shortcut) / C2f(64, 64, n=1|2) (upa_c2f_fused) and C2f(c1 % 64 == 0, 128, n=1|2) with 64-channel halves
+    # (upa_c2f64_fused): the whole block as one kernel
+    fuse_block = True
 
-    def _fused(self, x, out):
-        """One launch for the whole block when it has a fused form; None otherwise."""
+    def _form64(self) -> bool:
+        return self.c == 64 and self.cv2.conv.out_channels == 128 and self.cv1.conv.in_channels % 64 == 0 and len(self.m) in (1, 2)
+
+    def _fused(self, x, out, up=None):
+        """One launch for the whole block when it has a fused form; None otherwise.  `up`: a conv.VirtualUpsample for the
+        leading channels of x (the 64-channel form reads the half-resolution tensor itself)."""
         import ctypes as C
         nb = len(self.m)
         c1, c2 = self.cv1.conv.in_channels, self.cv2.conv.out_channels
         form = (c1, self.c, c2)
+        f64 = self._form64()
         if not (self.fuse_block and x.dtype == torch.bfloat16 and not self.training
-                and ((form == (32, 16, 32) and nb == 1 and self.m[0].add) or (form == (64, 32, 64) and nb in (1, 2)))):
+                and ((form == (32, 16, 32) and nb == 1 and self.m[0].add) or (form == (64, 32, 64) and nb in (1, 2)) or f64)):
             return None
         convs = [self.cv1, self.cv2] + [cv for m in self.m for cv in (m.cv1, m.cv2)]
         if not (all(isinstance(cv.act, nn.SiLU) and cv.conv.groups == 1 and cv.conv.stride == (1, 1) and hasattr(cv, "bn")
@@ -103,6 +110,25 @@ class C2f(nn.Module):
         wm = (C.c_void_p * (2 * nb))(*[q.w.data_ptr() for q in pk[2:]])
         bm = (C.c_void_p * (2 * nb))(*[q.bias.data_ptr() for q in pk[2:]])
         vx, vy = R.view_of(x), R.view_of(y)
+        if f64:
+            upp, upc, upld = None, 0, 0
+            if up is not None and not up.done:
+                vu = R.view_of(up.src)
+                if vu.dtype == vx.dtype and vu.c == up.channels and up.channels % 64 == 0 and (vu.n, 2 * vu.h, 2 * vu.w) == (vx.n, vx.h, vx.w):
+                    upp, upc, upld = vu.ptr, vu.c, vu.ld
+                else:
+                    up.materialize()
+            rc = L.lib().upa_c2f64_fused(vx.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, upp, upc, upld, nb, int(self.m[0].add),
+                                         pk[0].w.data_ptr(), pk[0].bias.data_ptr(), C.cast(wm, C.c_void_p), C.cast(bm, C.c_void_p),
+                                         pk[1].w.data_ptr(), pk[1].bias.data_ptr(), vy.ptr, vy.c, vy.ld, L.ACT_SILU, vx.dtype,
+                                         R.opts_ptr(), L.current_stream(x.device))
+            if rc == 0:
+                return y
+            if rc != L.UPA_EUNSUPPORTED:
+                L.check(rc, "c2f64_fused")
+            if upp is not None:
+                up.materialize()  # the separate convolutions below read the concat buffer
+            return None
         rc = L.lib().upa_c2f_fused(vx.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, self.c, nb, int(self.m[0].add), pk[0].w.data_ptr(),
                                    pk[0].bias.data_ptr(), C.cast(wm, C.c_void_p), C.cast(bm, C.c_void_p), pk[1].w.data_ptr(),
                                    pk[1].bias.data_ptr(), vy.ptr, vy.c, vy.ld, L.ACT_SILU, vx.dtype, R.opts_ptr(),
@@ -116,12 +142,14 @@ class C2f(nn.Module):
     def forward(self, x, out=None, up=None):
         """`up`: a conv.VirtualUpsample for the leading channels of x (see BaseModel._predict_once) - consumed by cv1."""
         x = R.to_nhwc(x, x.dtype)
-        if up is not None and self.fuse_block and self.cv1.conv.in_channels in (32, 64):
-            up.materialize()  # the whole-block kernels read x themselves
+        if up is not None and self.fuse_block and self.cv1.conv.in_channels in (32, 64) and not self._form64():
+            up.materialize()  # the narrow whole-block kernels read x themselves
             up = None
-        y = self._fused(x, out)
+        y = self._fused(x, out, up)
         if y is not None:
             return y
+        if up is not None and up.done:
+            up = None
         n, _, h, w = x.shape
         c, nb = self.c, len(self.m)
         cat = R.alloc_nhwc(n, (2 + nb) * c, h, w, x.dtype, x.device, key=(id(self), "cat"))
