@@ -751,6 +751,8 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
             return (f"void stem_mfma_kernel<{pk.cout // 16}, {pk.k}, {stride}, {'true' if act == 1 else 'false'}>(StemParams)" if es == 2 else
                     f"void stem_conv_kernel<{tname}, 16, {'true' if act == 1 else 'false'}>(StemParams)")
         var = L.lib().upa_conv_variant(n, h, w, cin, pk.cout, pk.k, stride, pad, code, R.opts_ptr())
+        if (var >> 24) & 1:  # persistent weights-stationary 3x3 (conv_ws3.hip): <NT, MT>
+            return "void conv_ws3_kernel<%d, %d>(BigParams)" % ((var >> 4) & 15, var & 15)
         if (var >> 23) & 1:  # large-tile LDS-shared-operand kernel (conv_big.hip): <KS, STRIDE, WM, WN, MT, NT>
             ntb, mt = (var >> 4) & 15, 4 if (var & 15) == 2 else 2
             wm, wn, nt = (8, 1, 4) if (ntb == 4 and mt == 4) else (4, 2, ntb // 2)
@@ -967,10 +969,10 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
     # HBM traffic per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see profiles/): only valid for
     # the configuration they were collected on
     try:
-        pmc = json.loads((ROOT / "profiles" / "r02_pmc_hbm_summary.json").read_text())
+        pmc = json.loads((ROOT / "profiles" / "r03_pmc_hbm_summary.json").read_text())
         if pmc.get("config") == f"{args.model} bs={args.batch} {args.dtype}" and dom_name in pmc["kernels"]:
             roofline["traffic"] = round(pmc["kernels"][dom_name]["hbm_bytes_per_launch"])
-            roofline["traffic_source"] = "profiles/r02_pmc_hbm_summary.json (rocprofv3 --pmc, separate passes)"
+            roofline["traffic_source"] = "profiles/r03_pmc_hbm_summary.json (rocprofv3 --pmc, separate passes)"
     except (OSError, KeyError, ValueError):
         pass
     kernels = {

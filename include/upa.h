@@ -57,6 +57,8 @@ typedef struct upa_opts {
   int32_t branch_tail_bm;  /* its workgroup pixels: 0 = auto | 128 | 256 */
   int32_t stem_wgs, stemf_wgs, stemf_waves, stem_no_mfma;  /* stem kernels: workgroup caps (0 = 1024 / 512), fused-stem waves (0 = 8 | 4) */
   int32_t ablate_conv, ablate_pipe, ablate_c1, ablate_stem;  /* kernel ablation bit masks: honoured by the -DUPA_ABLATE build only (make ablate) */
+  int32_t c2f64_max_px;    /* upa_c2f64_fused only up to this many pixels n * h * w (0 = 100000: the 40 x 40 maps at batch 32; -1 = any size) */
+  int32_t conv_ws3;        /* csrc/conv_ws3.hip (persistent 3x3 with register-resident weights, Cin <= 64, Cout 64): 0 = by the size rule, 1 = never, 2 = every shape it can run */
 } upa_opts;
 
 /* Library / device info. Returns the ABI version (int); fills name with the kernel target ("gfx950"). */

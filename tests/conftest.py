@@ -17,7 +17,7 @@ GOLDEN = ROOT / "tests" / "golden"
 from ultralytics_pro_amd import _lib as _L  # noqa: E402
 from ultralytics_pro_amd.engine import runtime as _R  # noqa: E402
 
-TEST_OPTS = _L.Opts(pipe_min_tiles=1, pipe_all=1, pair=2)
+TEST_OPTS = _L.Opts(pipe_min_tiles=1, pipe_all=1, pair=2, c2f64_max_px=-1)
 _R.set_default_opts(TEST_OPTS)
 
 

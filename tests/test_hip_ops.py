@@ -155,6 +155,38 @@ def test_conv_big_kernel(case, act, bm):
     assert_bf16_close(y, ref, f"conv_big{case}")
 
 
+WS3_CASES = [
+    # c1, c2, H, W, N, act  (persistent weights-stationary 3x3, csrc/conv_ws3.hip)
+    (64, 64, 80, 80, 2, True),     # 16 x 16 tiles, 25 per image: several tiles per persistent workgroup when few CUs are... (50 tiles)
+    (64, 64, 40, 48, 3, True),
+    (64, 64, 33, 47, 1, False),    # ragged right / bottom tiles, no activation
+    (32, 64, 20, 20, 2, True),     # Cin 32: one k-tile, the second zero
+    (48, 64, 9, 5, 1, True),       # a map smaller than a tile, partial channel group
+    (64, 64, 160, 160, 2, True),   # 200 tiles: every workgroup walks several (double-buffered halo, buffer reuse)
+]
+
+
+@pytest.mark.parametrize("case", WS3_CASES, ids=[f"c{c[0]}-{c[1]}_{c[2]}x{c[3]}n{c[4]}{'' if c[5] else '_lin'}" for c in WS3_CASES])
+def test_conv_ws3_kernel(case):
+    """bf16 3x3 convs forced through the persistent weights-stationary kernel (upa_opts.conv_ws3 = 2) vs the oracle Conv
+    (conv.py:188-197) on BN-folded bf16 weights: image borders, ragged tiles, partial k-tiles, 64 and 80 output channels, more tiles
+    than workgroups (the halo double buffer is reused)."""
+    from tests.hip_utils import assert_bf16_close, bf16_round, bf16_weight_oracle, to_cpu_nchw, to_dev_nhwc
+    from ultralytics_pro_amd import _lib as L
+    from ultralytics_pro_amd.engine import runtime as R
+    pm, _ = _mods()
+    c1, c2, H, W, N, act = case
+    with R.use_opts(conv_ws3=2):
+        var = L.lib().upa_conv_variant(N, H, W, c1, c2, 3, 1, 1, 1, R.opts_ptr())
+        assert (var >> 24) & 1, "case is not dispatched to the weights-stationary kernel"
+        o, m = _pair(om.Conv, pm.Conv, (c1, c2, 3, 1, None, 1, 1, act), "conv_ws3")
+        x = bf16_round(P.uniform(f"ws3{case}", (N, c1, H, W), -1, 1))
+        with torch.no_grad():
+            ref = bf16_weight_oracle(o)(x)
+            y = to_cpu_nchw(m(to_dev_nhwc(x, torch.bfloat16)))
+    assert_bf16_close(y, ref, f"conv_ws3{case}")
+
+
 PAIR_CASES = [
     # c, H, W, N, shortcut  (Bottleneck(c, c, shortcut, k=(3,3), e=1.0) as one kernel, csrc/conv_pair.hip)
     (64, 40, 40, 2, True),     # 14 x 14 tiles, 3 x 3 per image, ragged right / bottom tiles, residual
@@ -720,7 +752,8 @@ def test_detect_branch_tail_vs_unfused_and_oracle(nc, c3, shape):
                                                L.UPA_BF16, R.opts_ptr(), L.current_stream(DEV)), "detect_branch_tail")
         # two launches
         pk3u = PackedConv(w3, b3, 3, DEV, torch.bfloat16, False)
-        t = hip_conv2d(xd, pk3u, 1, 1, L.ACT_SILU)
+        with R.use_opts(conv_ws3=1):  # the 3x3 conv in conv_big's summation order, as inside the fused launch (conv_ws3 has its own test)
+            t = hip_conv2d(xd, pk3u, 1, 1, L.ACT_SILU)
         cout = 64 if kind == 1 else ncp
         w1p = torch.cat([w1, torch.zeros(cout - cout1, c, 1, 1)], 0)
         b1p = torch.cat([b1, torch.zeros(cout - cout1)], 0)

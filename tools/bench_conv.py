@@ -7,6 +7,7 @@ import sys
 from pathlib import Path
 
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(Path(__file__).resolve().parent))
 import torch  # noqa: E402
 
 from ultralytics_pro_amd import _lib as L  # noqa: E402
@@ -18,6 +19,13 @@ from ultralytics_pro_amd.nn.tasks import DetectionModel  # noqa: E402
 from ultralytics_pro_amd.utils import procedural as P  # noqa: E402
 
 
+def stamp_report(launch):
+    from stamps import report
+    if R.current_opts().conv_ws3 != 1:
+        report(launch, "conv_ws3", ["halo 0 + weights", "tile 0 (whole)", "tile 1: issue next halo", "tile 1: MFMA loop", "tile 1: vmcnt wait", "tile 1: epilogue", "rest"])
+    report(launch, "conv_big", ["halo+slab0 wait"] + [f"tap {i}" for i in range(9)] + ["epilogue", "store drain"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="yolov8n")
@@ -27,6 +35,7 @@ def main():
     ap.add_argument("--only", default="", help="cin,cout,k,H filter, e.g. 64,64,3,80")
     ap.add_argument("--big-mode", type=int, default=-1, help="upa_opts.conv_big: 0 size rule, 1 never, 2 every eligible shape")
     ap.add_argument("--opts", default="env", help="upa_opts fields as name=value,... or `env` (UPA_* variables, the default)")
+    ap.add_argument("--stamps", action="store_true", help="with a -DUPA_STAMP library (UPA_HIP_LIB): phase times of conv_big workgroups")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     opts = L.Opts.from_env() if args.opts == "env" else L.Opts(**{k: int(v) for k, v in (kv.split("=") for kv in args.opts.split(","))})
@@ -88,6 +97,8 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.iters
+        if args.stamps:
+            stamp_report(lambda: orig(xx, pk, stride, pad, act, out=y, residual=residual, out_dtype=odt))
         var = -1 if pk.stem else L.lib().upa_conv_variant(n, h, w, cin, pk.cout, pk.k, stride, pad, L.dtype_code(dtype), R.opts_ptr())
         key = (cin, pk.cout, pk.k, stride, h, w, residual is not None, var)
         d = agg.setdefault(key, [0, 0.0, fl, by])

@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic per kernel launch of `bench.py --serial` from rocprofv3 PMC counters, as MI355X_MICROARCH.md prescribes:
 # FETCH_SIZE and WRITE_SIZE in separate passes (never combined with trace domains), both in KB; on gfx950 FETCH_SIZE
-# counts 64 B per 128-B request and is doubled.  Writes profiles/r02_pmc_hbm_summary.json.
+# counts 64 B per 128-B request and is doubled.  Writes profiles/r03_pmc_hbm_summary.json.
 # usage (GPU box): tools/pmc_hbm.sh [extra bench.py args]
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/pmc_hbm
@@ -30,7 +30,7 @@ summary = {"command": "tools/pmc_hbm.sh = rocprofv3 --pmc FETCH_SIZE | --pmc WRI
                       "python3 bench.py --serial --steps 3 --warmup 1 --input-batches 1 --no-cpu-baseline",
            "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request -> doubled (MI355X_MICROARCH.md HBM); WRITE_SIZE exact; both in KB",
            "config": "yolov8n bs=32 bf16", "kernels": kern}
-json.dump(summary, open("profiles/r02_pmc_hbm_summary.json", "w"), indent=1)
+json.dump(summary, open("profiles/r03_pmc_hbm_summary.json", "w"), indent=1)
 json.dump(summary, open(f"{out}/summary.json", "w"), indent=1)  # gpurun merges gpurun_out/ back, not profiles/
 print("kernels:", len(kern))
 PY

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Regenerates the numbers profiles/ holds (run on the GPU box; outputs under gpurun_out/final_r02/, copied into profiles/ by hand).
+# Regenerates the numbers profiles/ holds (run on the GPU box; outputs under gpurun_out/final_r03/, copied into profiles/ by hand).
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/final_r02
+O=$R/gpurun_out/final_r03
 mkdir -p $O
 cd $R
 timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err
@@ -10,11 +10,15 @@ timeout 600 python bench.py --dtype f32 --no-cpu-baseline --steps 200 > $O/bench
 for m in yolov8s yolov3-tiny yolov5-BoT3; do timeout 600 python bench.py --model $m --no-cpu-baseline --no-kernel-profile --steps 300 > $O/bench_$m.json 2>/dev/null; done
 timeout 600 python bench.py --model yolov3-rtdetr --batch 16 --no-cpu-baseline --no-kernel-profile > $O/bench_yolov3-rtdetr.json 2>/dev/null
 timeout 600 python bench.py --workload train > $O/bench_train.json 2> $O/bench_train.err
+timeout 600 python bench.py --workload val --steps 300 > $O/bench_val.json 2> $O/bench_val.err
+timeout 600 python bench.py --no-cpu-baseline --opts c2f=4 > $O/bench_default_no_c2f64.json 2>/dev/null   # A/B: the 40x40 blocks as separate launches
 timeout 900 bash tools/pmc_hbm.sh --no-kernel-profile > /dev/null 2>&1
 cp $R/gpurun_out/pmc_hbm/summary.json $O/pmc_hbm_summary.json
 timeout 600 python bench.py --no-cpu-baseline > $O/bench_default_with_traffic.json 2>/dev/null   # roofline.traffic from the PMC summary written just above
 timeout 1200 bash tools/pmc_step.sh gpurun_out/pmc_step > /dev/null 2>&1
 cp $R/gpurun_out/pmc_step/summary.txt $O/pmc_step_summary.txt
+for m in yolov8n yolov8s yolov3-tiny; do timeout 300 python tools/bench_conv.py --model $m > $O/conv_layers_$m.txt 2>/dev/null; done
+timeout 300 python tools/bench_conv.py --model yolov3-rtdetr --batch 16 > $O/conv_layers_yolov3-rtdetr.txt 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -- python3 $R/bench.py --no-cpu-baseline --no-kernel-profile --steps 200 --warmup 10 > /dev/null 2>&1
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_serial -- python3 $R/bench.py --serial --no-cpu-baseline --steps 60 --warmup 5 > $O/bench_serial_profiled.json 2>/dev/null

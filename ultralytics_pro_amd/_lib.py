@@ -37,7 +37,7 @@ class Opts(C.Structure):
                 ("c2f", _i), ("c2f16_waves", _i), ("c2f32_th", _i),
                 ("no_branch_tail", _i), ("branch_tail_bm", _i),
                 ("stem_wgs", _i), ("stemf_wgs", _i), ("stemf_waves", _i), ("stem_no_mfma", _i),
-                ("ablate_conv", _i), ("ablate_pipe", _i), ("ablate_c1", _i), ("ablate_stem", _i)]
+                ("ablate_conv", _i), ("ablate_pipe", _i), ("ablate_c1", _i), ("ablate_stem", _i), ("c2f64_max_px", _i), ("conv_ws3", _i)]
 
     def __init__(self, **kw):
         super().__init__()
@@ -63,7 +63,7 @@ class Opts(C.Structure):
         return o
 
     # name of the round-1/2 environment switch -> (field, value transform)
-    _ENV = {"UPA_CONV_BIG": ("conv_big", lambda v: {0: 1, 1: 0, 2: 2}[int(v)]), "UPA_CONV_BIG_BM": ("conv_big_bm", int),
+    _ENV = {"UPA_CONV_BIG": ("conv_big", lambda v: {0: 1, 1: 0, 2: 2}[int(v)]), "UPA_CONV_BIG_BM": ("conv_big_bm", int), "UPA_CONV_WS3": ("conv_ws3", int),
             "UPA_CONV_CKT": ("conv_ckt", int), "UPA_CONV_NO_WS": ("no_ws", lambda v: 1), "UPA_CONV_NO_PIPE": ("no_pipe", lambda v: 1),
             "UPA_CONV_NO_1X1": ("no_1x1", lambda v: 1), "UPA_CONV_NO_C16": ("no_c16", lambda v: 1), "UPA_NO_UPCAT": ("no_upcat", lambda v: 1),
             "UPA_PIPE_ALL": ("pipe_all", lambda v: 1), "UPA_PIPE_MIN_TILES": ("pipe_min_tiles", int), "UPA_PIPE_WGS": ("pipe_wgs", int),

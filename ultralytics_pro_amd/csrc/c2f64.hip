@@ -24,6 +24,7 @@
 #include <type_traits>
 
 #include "common.h"
+UPA_STAMP_DEFINE(c2f64)
 
 typedef __attribute__((address_space(1))) const void* c6gptr_t;
 typedef __attribute__((address_space(3))) void* c6lptr_t;
@@ -164,6 +165,8 @@ __global__ __launch_bounds__(512, 2) void c2f64_fused_kernel(const C2f64Params p
       __builtin_amdgcn_global_load_lds((c6gptr_t)src, (c6lptr_t)(buf + (it * 512 + wave * 64) * 16), 16, 0, 0);
     }
   };
+  UPA_STAMP_AT(0);
+  UPA_STAMP_HWID();
   stage_chunk(0);
 
   // cv1 fragments: packed [k-tile][8 n-tiles][lane][16 B]; this wave's n-tiles j (y0) and 4 + j (y1)
@@ -197,6 +200,7 @@ __global__ __launch_bounds__(512, 2) void c2f64_fused_kernel(const C2f64Params p
   for (int c = 0; c < nch; ++c) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of chunk c (and its fragments) has landed
     __syncthreads();                                  // ... everyone's; everyone is done with the other buffer
+    if (c == 0) UPA_STAMP_AT(1);
     if (c + 1 < nch) {
       stage_chunk(c + 1);
       load_w1(w1n, c + 1);
@@ -246,10 +250,12 @@ __global__ __launch_bounds__(512, 2) void c2f64_fused_kernel(const C2f64Params p
   f32x4 bA = *reinterpret_cast<const f32x4*>(p.bm[0] + j * 16 + 4 * g);
   f32x4 bB = *reinterpret_cast<const f32x4*>(p.bm[1] + j * 16 + 4 * g);
   __syncthreads();  // y1, y0 complete; the chunk buffers are dead
+  UPA_STAMP_AT(2);
 
   // ---- B. t1 = SiLU(conv3x3(y1)) on ring R - 1 (into the chunk region)
   conv3x3_stage<H1, W1, R - 1, PY1, PT1, 1, 0>(y1s, t1s, wA, bA, nullptr, oy0, ox0, p.H, p.W, j, mg, g, r);
   __syncthreads();
+  UPA_STAMP_AT(3);
   const char* sc1 = p.shortcut ? y1s : nullptr;
   if constexpr (NB == 2) {
     load_w18(wA, p.wm[2], j, lane);
@@ -257,11 +263,13 @@ __global__ __launch_bounds__(512, 2) void c2f64_fused_kernel(const C2f64Params p
     // b1 = y1 + SiLU(conv3x3(t1)) on ring 2
     conv3x3_stage<H2, W2, R - 2, PT1, PB1, PY1, 2>(t1s, b1s, wB, bB, sc1, oy0, ox0, p.H, p.W, j, mg, g, r);
     __syncthreads();
+    UPA_STAMP_AT(4);
     load_w18(wB, p.wm[3], j, lane);
     bB = *reinterpret_cast<const f32x4*>(p.bm[3] + j * 16 + 4 * g);
     // t2 = SiLU(conv3x3(b1)) on ring 1
     conv3x3_stage<H3, W3, 1, PB1, PT2, 1, 0>(b1s, t2s, wA, bA, nullptr, oy0, ox0, p.H, p.W, j, mg, g, r);
     __syncthreads();
+    UPA_STAMP_AT(5);
   }
   // cv2 fragments (into the registers of the finished stage's weights): packed [k-tile][8 n-tiles][lane][16 B]; this wave's
   // n-tiles 2 j, 2 j + 1 over all K2 = 2 (2 + NB) k-tiles
@@ -280,6 +288,7 @@ __global__ __launch_bounds__(512, 2) void c2f64_fused_kernel(const C2f64Params p
     conv3x3_stage<TH, TW, 0, PT1, TW, PY1, 2>(t1s, bls, wB, bB, sc1, oy0, ox0, p.H, p.W, j, mg, g, r);
   }
   __syncthreads();
+  UPA_STAMP_AT(6);
 
   // ---- C. cv2 over [y0 | y1 | b1 (| b2)] of the tile's own pixels: a wave owns output channels 32 j .. 32 j + 31 of every second m-tile
   for (int mt = mg; mt < NMT0; mt += 2) {
@@ -312,6 +321,11 @@ __global__ __launch_bounds__(512, 2) void c2f64_fused_kernel(const C2f64Params p
     if (q < TPX && oy < p.H && ox < p.W)
       *reinterpret_cast<u32x4*>(p.y + ((((size_t)n * p.H + oy) * p.W + ox) * (size_t)p.ldy + cb) * 2) = u32x4{lo[0], hi[0], lo[1], hi[1]};
   }
+  UPA_STAMP_AT(7);
+#ifdef UPA_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  UPA_STAMP_AT(8);
+#endif
 }
 
 namespace {
@@ -351,7 +365,11 @@ extern "C" int upa_c2f64_fused(const void* x, int n, int h, int w, int c1, int l
                                void* stream) {
   UPA_CHECK_ARG(x && y && w1 && b1 && wm && bm && w2 && b2 && n > 0 && h > 0 && w > 0, "c2f64_fused: bad args");
   const int off = UPA_OPT(opts, c2f);  // 1: never, 4: not this form
-  if (off == 1 || off == 4 || dtype != UPA_BF16 || act != UPA_ACT_SILU || c2 != 128 || c1 <= 0 || c1 % 64 != 0 || !(nb == 1 || nb == 2) ||
+  // measured on MI355X (round 3): at 40 x 40 (51 k pixels at batch 32) the fused block replaces 4-6 launches that are each one
+  // latency-bound round of the chip (yolov8n serial step 1.08 -> 1.02 ms); at 80 x 80 (yolov8s model.4 / model.15, 205 k pixels)
+  // the separate launches fill the chip on their own and the tile-ring recompute loses: 20.2 k -> 19.2 k images/s
+  const long max_px = UPA_OPT(opts, c2f64_max_px) == 0 ? 100000 : (UPA_OPT(opts, c2f64_max_px) < 0 ? (1L << 40) : UPA_OPT(opts, c2f64_max_px));
+  if (off == 1 || off == 4 || (long)n * h * w > max_px || dtype != UPA_BF16 || act != UPA_ACT_SILU || c2 != 128 || c1 <= 0 || c1 % 64 != 0 || !(nb == 1 || nb == 2) ||
       ldx % 8 != 0 || ldy % 8 != 0 || ((uintptr_t)x % 16) != 0 || ((uintptr_t)y % 16) != 0 ||
       (long)n * h * w * ldx * 2 >= (1L << 32) - 4096 ||
       (up && (up_c <= 0 || up_c % 64 != 0 || up_c >= c1 || up_ld % 8 != 0 || ((uintptr_t)up % 16) != 0 || (h & 1) || (w & 1) ||

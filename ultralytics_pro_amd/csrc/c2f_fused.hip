@@ -22,6 +22,7 @@
 #include <type_traits>
 
 #include "common.h"
+UPA_STAMP_DEFINE(c2f)
 
 typedef __attribute__((address_space(1))) const void* cgptr_t;
 typedef __attribute__((address_space(3))) void* clptr_t;
@@ -340,6 +341,8 @@ __global__ __launch_bounds__(1024) void c2f32_fused_kernel(const C2f32Params p) 
   const int tyi = bid / p.tilesX, txi = bid - tyi * p.tilesX;
   const int oy0 = tyi * TH, ox0 = txi * T;
 
+  UPA_STAMP_AT(0);
+  UPA_STAMP_HWID();
   // ---- x halo tile: 128 B / px, 16-byte group cg of pixel px at slot cg ^ (px & 7)
 #pragma unroll
   for (int it = 0; it < XIT; ++it) {
@@ -366,6 +369,7 @@ __global__ __launch_bounds__(1024) void c2f32_fused_kernel(const C2f32Params p) 
   load_w9(wA, p.wm[0], j, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  UPA_STAMP_AT(1);
   f32x4 bA = *reinterpret_cast<const f32x4*>(p.bm[0] + j * 16 + 4 * g);
   f32x4 bB = *reinterpret_cast<const f32x4*>(p.bm[1] + j * 16 + 4 * g);
 
@@ -394,10 +398,12 @@ __global__ __launch_bounds__(1024) void c2f32_fused_kernel(const C2f32Params p) 
   }
   load_w9(wB, p.wm[1], j, lane);  // every later stage's weights are fetched one stage ahead
   __syncthreads();  // y1 complete; x is dead
+  UPA_STAMP_AT(2);
 
   // ---- B. t1 = SiLU(conv3x3(y1)) on ring R - 1 (into the x region)
   conv3x3_stage<H_T1, S_T1, R - 1, 1, 0>(y1s, t1s, wA, bA, nullptr, oy0, ox0, p.H, p.W, wave, g, r);
   __syncthreads();
+  UPA_STAMP_AT(3);
   const char* sc1 = p.shortcut ? y1s : nullptr;
   constexpr int K2 = 2 + NB;
   u32x4 w2f[K2][2];  // cv2 [k-tile][4 n-tiles]: this wave's n-tiles 2j, 2j + 1
@@ -407,11 +413,13 @@ __global__ __launch_bounds__(1024) void c2f32_fused_kernel(const C2f32Params p) 
     // ---- C. b1 = y1 + SiLU(conv3x3(t1)) on ring 2
     conv3x3_stage<H_B1, S_B1, R - 2, SX, 2>(t1s, b1s, wB, bB, sc1, oy0, ox0, p.H, p.W, wave, g, r);
     __syncthreads();
+    UPA_STAMP_AT(4);
     load_w9(wB, p.wm[3], j, lane);
     bB = *reinterpret_cast<const f32x4*>(p.bm[3] + j * 16 + 4 * g);
     // ---- D. t2 = SiLU(conv3x3(b1)) on ring 1
     conv3x3_stage<H_T2, S_T2, 1, 1, 0>(b1s, t2s, wA, bA, nullptr, oy0, ox0, p.H, p.W, wave, g, r);
     __syncthreads();
+    UPA_STAMP_AT(5);
   }
 #pragma unroll
   for (int kt = 0; kt < K2; ++kt)
@@ -426,6 +434,7 @@ __global__ __launch_bounds__(1024) void c2f32_fused_kernel(const C2f32Params p) 
     conv3x3_stage<TH, T, 0, SX, 2>(t1s, bls, wB, bB, sc1, oy0, ox0, p.H, p.W, wave, g, r);
   }
   __syncthreads();
+  UPA_STAMP_AT(6);
 
   // ---- F. cv2 over [y0 | y1 | b1 (| b2)] of the tile's own pixels: a wave owns output channels 32j .. 32j + 31 of two rows
   for (int i = wave >> 1; i < TH; i += NW / 2) {
@@ -460,6 +469,11 @@ __global__ __launch_bounds__(1024) void c2f32_fused_kernel(const C2f32Params p) 
     if (oy < p.H && ox < p.W)
       *reinterpret_cast<u32x4*>(p.y + ((((size_t)n * p.H + oy) * p.W + ox) * (size_t)p.ldy + cb) * 2) = u32x4{lo[0], hi[0], lo[1], hi[1]};
   }
+  UPA_STAMP_AT(7);
+#ifdef UPA_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  UPA_STAMP_AT(8);
+#endif
 }
 
 // x: (n, h, w, c1) NHWC bf16 view; w1 / b1: cv1 (1x1, c1 -> 2c); wm[2i], wm[2i + 1] / bm[..]: Bottleneck i's two 3x3 convs

@@ -139,3 +139,41 @@ static constexpr int upa_lds_pick_pitch(int min_pitch, int W, int npix, int row_
 
 static inline int upa_elem_size(int dtype) { return dtype == UPA_BF16 ? 2 : 4; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- profiling build only (-DUPA_STAMP, tools/bench_conv.py --stamps, tools/experiments/c2f_stamps.py): wave 0 of each of the
+// first 4096 workgroups records s_memtime at its phase boundaries (slot 15: hardware id); UPA_STAMP_DEFINE(tag) in a translation
+// unit gives it the buffer and the reader upa_debug_stamps_<tag>(out, count).
+#ifdef UPA_STAMP
+#define UPA_STAMP_DEFINE(tag)                                                                                  \
+  __device__ unsigned long long g_upa_stamps[4096 * 16];                                                       \
+  extern "C" int upa_debug_stamps_##tag(unsigned long long* out, int count) {                                  \
+    const int rc = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_upa_stamps), (size_t)count * 8) == hipSuccess ? 0 : -1; \
+    return rc;                                                                                                 \
+  }                                                                                                            \
+  extern "C" int upa_debug_stamps_clear_##tag() {                                                              \
+    void* d = nullptr;                                                                                         \
+    if (hipGetSymbolAddress(&d, HIP_SYMBOL(g_upa_stamps)) != hipSuccess) return -1;                            \
+    return hipMemset(d, 0, sizeof(unsigned long long) * 4096 * 16) == hipSuccess ? 0 : -1;                     \
+  }
+#define UPA_STAMP_AT(k)                                                                                        \
+  do {                                                                                                         \
+    if ((threadIdx.x >> 6) == 0 && blockIdx.x < 4096 && blockIdx.y == 0) {                                     \
+      unsigned long long t_;                                                                                   \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                               \
+      if ((threadIdx.x & 63) == 0) g_upa_stamps[blockIdx.x * 16 + (k)] = t_;                                   \
+    }                                                                                                          \
+  } while (0)
+#define UPA_STAMP_HWID()                                                                                       \
+  do {                                                                                                         \
+    if (threadIdx.x == 0 && blockIdx.x < 4096 && blockIdx.y == 0) {                                            \
+      unsigned hw_, xcc_;                                                                                      \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                                        \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                                      \
+      g_upa_stamps[blockIdx.x * 16 + 15] = ((unsigned long long)xcc_ << 32) | hw_;                             \
+    }                                                                                                          \
+  } while (0)
+#else
+#define UPA_STAMP_DEFINE(tag)
+#define UPA_STAMP_AT(k) do {} while (0)
+#define UPA_STAMP_HWID() do {} while (0)
+#endif

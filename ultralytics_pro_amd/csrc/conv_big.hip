@@ -35,6 +35,7 @@
 
 #include "common.h"
 #include "conv_pipe.h"
+UPA_STAMP_DEFINE(conv_big)
 
 typedef __attribute__((address_space(1))) const void* bgptr_t;
 typedef __attribute__((address_space(3))) void* blptr_t;
@@ -139,6 +140,8 @@ __global__ __launch_bounds__(512, 4) void conv_big_kernel(const BigParams p) {
     }
   };
 
+  UPA_STAMP_AT(0);
+  UPA_STAMP_HWID();
   stage_halo(0);
   stage_w(0, 0, 0);
   int buf = 0;
@@ -148,6 +151,7 @@ __global__ __launch_bounds__(512, 4) void conv_big_kernel(const BigParams p) {
     for (int tap = 0; tap < TAPS; ++tap) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of slab (c, tap) (and of the halo) has landed
       __syncthreads();                                  // ... everyone's; everyone is done with the other weight buffer
+      if (c == 0) UPA_STAMP_AT(1 + tap);
       if (tap + 1 < TAPS) stage_w(c, tap + 1, buf ^ 1);
       const int tapshift = kh * p.IWp + (STRIDE == 2 ? (kw >> 1) + (kw & 1) * p.HALF : kw);
       const char* wb = wbuf + buf * WBUF + (wn * NT) * 1024 + lane * 16;
@@ -186,6 +190,7 @@ __global__ __launch_bounds__(512, 4) void conv_big_kernel(const BigParams p) {
       stage_w(c + 1, 0, buf);
     }
   }
+  UPA_STAMP_AT(10);
 
   if constexpr (TAIL != 0) {
     // ---- Detect branch tail (head.py:94-100, 116-126, 151-169): h = SiLU(conv3x3 + b) never leaves the registers.
@@ -344,6 +349,11 @@ __global__ __launch_bounds__(512, 4) void conv_big_kernel(const BigParams p) {
   if (p.act == UPA_ACT_SILU) epilogue(std::integral_constant<int, UPA_ACT_SILU>{});
   else if (p.act == UPA_ACT_RELU) epilogue(std::integral_constant<int, UPA_ACT_RELU>{});
   else epilogue(std::integral_constant<int, UPA_ACT_NONE>{});
+  UPA_STAMP_AT(11);
+#ifdef UPA_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  UPA_STAMP_AT(12);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

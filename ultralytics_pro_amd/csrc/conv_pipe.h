@@ -71,6 +71,12 @@ bool upa_conv_big_eligible(int n, int h, int w, int cin, int ldx, int cout, int 
 // variant (if non-null) receives (1 << 23) | n-tiles per workgroup << 4 | pixels per workgroup / 128; query_only = 1 skips the launch
 int upa_conv_big_launch(BigParams p, int query_only, int* variant, void* stream, const upa_opts* opts);
 
+// ---- conv_ws3.hip: persistent weights-stationary 3x3 (bf16, stride 1, pad 1, Cin <= 64, Cout = 64); BigParams as conv_big
+bool upa_conv_ws3_eligible(int n, int h, int w, int cin, int ldx, int cout, int ldy, bool residual, int k, int stride, int pad,
+                           int act, int dtype, const upa_opts* opts);
+// variant (if non-null) receives (1 << 24) | NT << 4 | MT; query_only = 1 skips the launch
+int upa_conv_ws3_launch(BigParams p, int query_only, int* variant, void* stream, const upa_opts* opts);
+
 // ---- conv_pair.hip: Bottleneck (3x3 -> 3x3 [+ x]) as one kernel, the intermediate tile in LDS (bf16, C = 32 | 64)
 struct PairParams {
   const char* x;
