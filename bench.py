@@ -276,11 +276,11 @@ def main():
             out, counts, keep = post_dev(o)
             hb = host_bufs.get(out.data_ptr())
             if hb is None:
-                hb = (torch.empty(out.shape, dtype=out.dtype, pin_memory=True), torch.empty(counts.shape, dtype=counts.dtype, pin_memory=True))
+                hb = (torch.zeros(out.shape, dtype=out.dtype, pin_memory=True), torch.zeros(counts.shape, dtype=counts.dtype, pin_memory=True))
                 host_bufs[out.data_ptr()] = hb
             st = L.current_stream(out.device)
-            L.check(L.lib().upa_copy_to_host(out.data_ptr(), hb[0].data_ptr(), out.numel() * out.element_size(), st), "copy_to_host")
-            L.check(L.lib().upa_copy_to_host(counts.data_ptr(), hb[1].data_ptr(), counts.numel() * counts.element_size(), st), "copy_to_host")
+            L.check(L.lib().upa_results_to_host(out.data_ptr(), counts.data_ptr(), out.shape[0], out.shape[1], out.shape[2] * out.element_size(),
+                                                hb[0].data_ptr(), hb[1].data_ptr(), st), "results_to_host")
             return out, counts, keep
 
     from ultralytics_pro_amd.engine.pipeline import PipelinedRunner, autotune
@@ -332,7 +332,9 @@ def main():
     if not args.no_host_results:  # the host copies the step itself wrote must equal the device results
         for (o_, c_, _) in results:
             hb = host_bufs[o_.data_ptr()]
-            assert torch.equal(hb[1], c_.cpu()) and torch.equal(hb[0], o_.cpu()), "host-visible detections differ from the device rows"
+            cc, oc = c_.cpu(), o_.cpu()
+            assert torch.equal(hb[1], cc) and all(torch.equal(hb[0][b, :int(cc[b])], oc[b, :int(cc[b])]) for b in range(cc.numel())), \
+                "host-visible detections differ from the device rows"
     seen = ranks_seen(dist, dev)
 
     roofline, kernels, cpu_baseline = None, None, None
@@ -391,6 +393,9 @@ def main():
                        "input_batches_rotated": nin, "input_bytes_resident": int(sum(t.numel() * t.element_size() for t in xs)),
                        "detect_raw_maps_written": bool(args.keep_raw),
                        "detections_host_visible": not args.no_host_results, "dispatch_opts": args.opts or None,
+                       "dispatch_by_mode": ({"steps in flight > 1 (engine/pipeline.py)": runner.throughput_opts,
+                                             "serial / one-step-in-flight legs": "library defaults (whole-block c2f64, conv_ws3)"}
+                                            if getattr(runner, "throughput_opts", None) else None),
                        "global_batch": pb * world, "per_gpu_batch": pb, "parallelism": f"dp{world} replicas"},
             "images_per_sec_per_gpu": round(value / world, 1),
             "serial_ms_per_step": None if serial_ms is None else round(serial_ms, 4),

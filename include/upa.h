@@ -122,6 +122,11 @@ int upa_copy_view(const void* x, int n, int h, int w, int c, int ldx, void* y, i
  * fixed-shape detections (B, max_det, 6) + counts to the host at the end of a step - the reference's results leave the GPU
  * in `Results(...)` construction, engine/results.py via models/yolo/detect/predict.py:53-120.  bytes % 4 == 0. */
 int upa_copy_to_host(const void* src_dev, void* dst_pinned, size_t bytes, void* stream);
+/* The same hand-over in ONE launch for the NMS / RT-DETR result layout: counts (batch) int32 and, per image, only the first
+ * counts[b] of its max_rows rows of row_bytes (6 floats: xyxy, conf, cls) go to pinned host memory; rows past the count are not
+ * transferred.  results.py (`Results.boxes` on the CPU), predict.py:53-120. */
+int upa_results_to_host(const void* rows_dev, const int* counts_dev, int batch, int max_rows, int row_bytes,
+                        void* rows_pinned, int* counts_pinned, void* stream);
 /* y = a + b (views)                                                                        block.py:6091 */
 int upa_add_view(const void* a, int lda, const void* b, int ldb, void* y, int ldy, int n, int h, int w, int c,
                  int dtype, void* stream);

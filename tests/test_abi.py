@@ -61,14 +61,14 @@ def test_dispatch_options_travel_with_the_call_and_the_library_reads_no_environm
     from ultralytics_pro_amd import _lib as L
     lib = L.lib()
     assert lib.upa_opts_size() == C.sizeof(L.Opts)
-    q = (32, 40, 40, 64, 64, 3, 1, 1, L.UPA_BF16)  # yolov8n model.6's Bottleneck convs: 64 -> 64 3x3 at 40x40, bs 32
+    q = (32, 40, 40, 128, 64, 3, 1, 1, L.UPA_BF16)  # yolov8n Detect cv2[1][0]: 128 -> 64 3x3 at 40x40, bs 32
     big = lambda v: (v >> 23) & 1  # noqa: E731
     default = lib.upa_conv_variant(*q, None)
     assert big(default)
     never, always = L.Opts(conv_big=1), L.Opts(conv_big=2)
     assert not big(lib.upa_conv_variant(*q, C.pointer(never)))
     assert lib.upa_conv_variant(*q, None) == default                      # the previous call left no mode behind
-    small = (1, 16, 16, 64, 64, 3, 1, 1, L.UPA_BF16)                      # too few pixels for the size rule ...
+    small = (1, 16, 16, 128, 64, 3, 1, 1, L.UPA_BF16)                     # too few pixels for the size rule ...
     assert not big(lib.upa_conv_variant(*small, None)) and big(lib.upa_conv_variant(*small, C.pointer(always)))  # ... forced
     v128 = lib.upa_conv_variant(*q, C.pointer(L.Opts(conv_big_bm=128)))
     v256 = lib.upa_conv_variant(*q, C.pointer(L.Opts(conv_big_bm=256)))
@@ -83,6 +83,9 @@ def test_dispatch_options_travel_with_the_call_and_the_library_reads_no_environm
     hits = subprocess.run(["grep", "-ln", "getenv", *[str(f) for f in sorted(src.glob("*.hip")) + sorted(src.glob("*.h"))]],
                           capture_output=True, text=True).stdout.split()
     assert hits == [], f"getenv in the library sources: {hits}"
+    ws3 = lambda v: (v >> 24) & 1  # noqa: E731
+    q64 = (32, 40, 40, 64, 64, 3, 1, 1, L.UPA_BF16)                        # 64 -> 64 3x3: the persistent kernel by default ...
+    assert ws3(lib.upa_conv_variant(*q64, None)) and big(lib.upa_conv_variant(*q64, C.pointer(L.Opts(conv_ws3=1))))  # ... conv_big on request
     assert L.Opts.from_env({"UPA_NO_PAIR": "0", "UPA_C1_MT": "4", "UPA_CONV_FORCE": "4,1,2,4"}).pair == 2  # tool-side mapping only
 
 

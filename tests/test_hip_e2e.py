@@ -470,14 +470,18 @@ def test_e2e_micro_batched_graph_equals_single_graph():
 
 def test_e2e_pipelined_runner_copies_equal_single_graph():
     """engine.pipeline.PipelinedRunner: three compiled copies of the step in flight on separate streams (each split into
-    two concurrent sub-batches) - every copy reproduces the single-graph detections bit for bit, repeatedly."""
+    two concurrent sub-batches) - every copy reproduces the single-graph detections bit for bit, repeatedly.  The runner picks its
+    kernels for throughput (`PipelinedRunner.throughput_opts`: the 40 x 40 C2f blocks as separate launches, conv_big instead of the
+    persistent 3x3), so the single graph it is compared with is compiled under the same options."""
     from tests.hip_utils import DEV
+    from ultralytics_pro_amd.engine import runtime as R
     from ultralytics_pro_amd.engine.pipeline import PipelinedRunner
     from ultralytics_pro_amd.utils.nms import nms_raw
     m = _build("yolov8n", torch.bfloat16)
     x = P.synthetic_images(4).to(DEV).to(torch.bfloat16).contiguous()
     with torch.no_grad():
-        run1 = m.compile(x, post=lambda o: nms_raw(o[0], 0.25, 0.7, key="ref"))
+        with R.use_opts(c2f=4, conv_ws3=1):
+            run1 = m.compile(x, post=lambda o: nms_raw(o[0], 0.25, 0.7, key="ref"))
         out1, cnt1, _ = run1()
         torch.cuda.synchronize()
         out1, cnt1 = out1.clone(), cnt1.clone()
@@ -488,6 +492,7 @@ def test_e2e_pipelined_runner_copies_equal_single_graph():
             lin.step()
         torch.cuda.synchronize()
     assert runner.i == 7 and len(runner.results()) == 3 and len(lin.results()) == 4
+    assert runner.throughput_opts == lin.throughput_opts == {"c2f": 4, "conv_ws3": 1}
     assert m.model[-1].concurrent  # the linear runner restored the head's concurrency flag
     for parts in runner.results():
         out = torch.cat([p_[0] for p_ in parts], 0)
@@ -514,13 +519,15 @@ def test_e2e_full_size_properties():
     reference's NMS on its own output would keep all of them; and an image's detections do not depend on the batch it
     is in (f32 parity mode: the same four images as a batch of 4, boxes / scores to 1e-3, equal classes)."""
     from tests.hip_utils import DEV
+    from ultralytics_pro_amd.engine import runtime as R
     from ultralytics_pro_amd.engine.pipeline import PipelinedRunner
     from ultralytics_pro_amd.utils.nms import nms_raw
     m = _build("yolov8n", torch.bfloat16)
     x32 = P.synthetic_images(32).to(DEV)
     x = x32.to(torch.bfloat16).contiguous()
     with torch.no_grad():
-        run1 = m.compile(x, post=lambda o: nms_raw(o[0], 0.25, 0.7, key="ref"))
+        with R.use_opts(c2f=4, conv_ws3=1):  # the runner's throughput dispatch (PipelinedRunner.throughput_opts)
+            run1 = m.compile(x, post=lambda o: nms_raw(o[0], 0.25, 0.7, key="ref"))
         out1, cnt1, _ = run1()
         torch.cuda.synchronize()
         out1, cnt1 = out1.clone(), cnt1.clone()

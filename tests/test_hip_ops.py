@@ -156,34 +156,36 @@ def test_conv_big_kernel(case, act, bm):
 
 
 WS3_CASES = [
-    # c1, c2, H, W, N, act  (persistent weights-stationary 3x3, csrc/conv_ws3.hip)
-    (64, 64, 80, 80, 2, True),     # 16 x 16 tiles, 25 per image: several tiles per persistent workgroup when few CUs are... (50 tiles)
-    (64, 64, 40, 48, 3, True),
-    (64, 64, 33, 47, 1, False),    # ragged right / bottom tiles, no activation
-    (32, 64, 20, 20, 2, True),     # Cin 32: one k-tile, the second zero
-    (48, 64, 9, 5, 1, True),       # a map smaller than a tile, partial channel group
-    (64, 64, 160, 160, 2, True),   # 200 tiles: every workgroup walks several (double-buffered halo, buffer reuse)
+    # c1, c2, H, W, N, act, residual  (persistent 3x3 with register-resident weights, csrc/conv_ws3.hip; 16 x 8 pixel tiles)
+    (64, 64, 80, 80, 2, True, False),     # 50 tiles per image
+    (64, 64, 40, 48, 3, True, True),      # Bottleneck shortcut
+    (64, 64, 33, 47, 1, False, False),    # ragged right / bottom tiles, no activation
+    (32, 64, 20, 20, 2, True, False),     # Cin 32: one k-tile, the second zero
+    (48, 64, 9, 5, 1, True, True),        # a map smaller than a tile, partial channel group, shortcut
+    (64, 64, 160, 160, 2, True, False),   # 400 tiles: every workgroup walks several (double-buffered halo, buffer reuse)
+    (64, 64, 96, 96, 16, True, True),     # 1152 tiles on 512 workgroups with the shortcut
 ]
 
 
-@pytest.mark.parametrize("case", WS3_CASES, ids=[f"c{c[0]}-{c[1]}_{c[2]}x{c[3]}n{c[4]}{'' if c[5] else '_lin'}" for c in WS3_CASES])
+@pytest.mark.parametrize("case", WS3_CASES, ids=[f"c{c[0]}-{c[1]}_{c[2]}x{c[3]}n{c[4]}{'' if c[5] else '_lin'}{'_res' if c[6] else ''}" for c in WS3_CASES])
 def test_conv_ws3_kernel(case):
-    """bf16 3x3 convs forced through the persistent weights-stationary kernel (upa_opts.conv_ws3 = 2) vs the oracle Conv
-    (conv.py:188-197) on BN-folded bf16 weights: image borders, ragged tiles, partial k-tiles, 64 and 80 output channels, more tiles
-    than workgroups (the halo double buffer is reused)."""
+    """bf16 3x3 convs forced through the persistent register-resident-weights kernel (upa_opts.conv_ws3 = 2) vs the oracle Conv
+    (conv.py:188-197, + the Bottleneck add block.py:668) on BN-folded bf16 weights: image borders, ragged tiles, partial k-tiles,
+    more tiles than workgroups (the halo double buffer is reused), the shortcut read."""
     from tests.hip_utils import assert_bf16_close, bf16_round, bf16_weight_oracle, to_cpu_nchw, to_dev_nhwc
     from ultralytics_pro_amd import _lib as L
     from ultralytics_pro_amd.engine import runtime as R
     pm, _ = _mods()
-    c1, c2, H, W, N, act = case
+    c1, c2, H, W, N, act, res = case
     with R.use_opts(conv_ws3=2):
         var = L.lib().upa_conv_variant(N, H, W, c1, c2, 3, 1, 1, 1, R.opts_ptr())
-        assert (var >> 24) & 1, "case is not dispatched to the weights-stationary kernel"
+        assert (var >> 24) & 1, "case is not dispatched to the register-resident-weights kernel"
         o, m = _pair(om.Conv, pm.Conv, (c1, c2, 3, 1, None, 1, 1, act), "conv_ws3")
         x = bf16_round(P.uniform(f"ws3{case}", (N, c1, H, W), -1, 1))
+        rsd = bf16_round(P.uniform(f"ws3res{case}", (N, c2, H, W), -1, 1)) if res else None
         with torch.no_grad():
-            ref = bf16_weight_oracle(o)(x)
-            y = to_cpu_nchw(m(to_dev_nhwc(x, torch.bfloat16)))
+            ref = bf16_weight_oracle(o)(x) + (rsd if res else 0)
+            y = to_cpu_nchw(m(to_dev_nhwc(x, torch.bfloat16), residual=to_dev_nhwc(rsd, torch.bfloat16) if res else None))
     assert_bf16_close(y, ref, f"conv_ws3{case}")
 
 
@@ -967,3 +969,23 @@ def test_fused_stem_and_second_conv_equals_the_two_layers(shape):
     scale = max(1.0, float(ref.abs().max()))
     assert float((fused - two).abs().max()) <= 2e-2 * scale
     assert_bf16_close(fused, ref, f"fused_stem{shape}", abs_=2.0 ** -7)  # (flipped ties of the bf16 stem tile: see the pair test)
+
+
+def test_results_to_host_kernel():
+    """`upa_results_to_host`: counts + only the first counts[b] rows of every image reach pinned host memory, in one launch
+    (capturable: no memcpy node); rows past the count are left untouched on the host."""
+    from tests.hip_utils import DEV
+    from ultralytics_pro_amd import _lib as L
+    b, m = 5, 300
+    rows = torch.arange(b * m * 6, dtype=torch.float32, device=DEV).reshape(b, m, 6)
+    counts = torch.tensor([0, 1, 300, 57, 299], dtype=torch.int32, device=DEV)
+    hrows = torch.full((b, m, 6), -1.0, pin_memory=True)
+    hcounts = torch.full((b,), -1, dtype=torch.int32, pin_memory=True)
+    L.check(L.lib().upa_results_to_host(rows.data_ptr(), counts.data_ptr(), b, m, 24, hrows.data_ptr(), hcounts.data_ptr(),
+                                        L.current_stream(DEV)), "results_to_host")
+    torch.cuda.synchronize()
+    assert torch.equal(hcounts, counts.cpu())
+    rc = rows.cpu()
+    for i, c in enumerate(counts.tolist()):
+        assert torch.equal(hrows[i, :c], rc[i, :c]) and bool((hrows[i, c:] == -1.0).all())
+

@@ -111,6 +111,7 @@ PROTOTYPES = {
     "upa_upsample2x": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "upa_copy_view": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "upa_copy_to_host": (_i, [_vp, _vp, _sz, _vp]),
+    "upa_results_to_host": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "upa_add_view": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "upa_nchw_to_nhwc": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "upa_nhwc_to_nchw": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),

@@ -890,8 +890,8 @@ extern "C" int upa_conv2d_bias_act(const void* x, int n, int h, int w, int cin, 
   if (upa_conv_ws3_eligible(n, h, w, cin, ldx, cout, ldy, residual != nullptr, k, stride, pad, act, dtype, opts)) {
     BigParams q;
     memset(&q, 0, sizeof(q));
-    q.x = (const char*)x; q.y = (char*)y; q.w = (const char*)w_packed; q.bias = bias;
-    q.N = n; q.H = h; q.W = w; q.Cin = cin; q.ldx = ldx; q.Cout = cout; q.ldy = ldy; q.OH = h; q.OW = w;
+    q.x = (const char*)x; q.y = (char*)y; q.res = (const char*)residual; q.w = (const char*)w_packed; q.bias = bias;
+    q.N = n; q.H = h; q.W = w; q.Cin = cin; q.ldx = ldx; q.Cout = cout; q.ldy = ldy; q.ldr = ldr; q.OH = h; q.OW = w;
     q.KS = 3; q.stride = 1; q.pad = 1; q.act = act;
     const int rc = upa_conv_ws3_launch(q, g_query_only, &g_last_variant, stream, opts);
     if (rc != UPA_EUNSUPPORTED) return rc;

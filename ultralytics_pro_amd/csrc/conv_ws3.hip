@@ -68,35 +68,38 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_ws3_kernel(const BigParams p)
   UPA_STAMP_AT(0);
   UPA_STAMP_HWID();
 
-  // this thread's halo items (pixel, channel group) are the same for every tile: packed (row | column << 8 | channel group << 16)
-  int hitem[HPASS];
+  // this thread's halo items (pixel, channel group) are the same for every tile: packed (row | column << 8 | channel group << 16) for
+  // the bounds test, and as a byte offset from the tile's first halo pixel (32-bit arithmetic: an image is far below 4 GB)
+  int hitem[HPASS], hoff[HPASS];
 #pragma unroll
   for (int it = 0; it < HPASS; ++it) {
     const int idx = it * NTHR + tid;
     const int pix = idx >> 3, slot = idx & 7;
-    const int py = pix / IW;
-    hitem[it] = (idx >= HIT ? 255 : py) | ((pix - py * IW) << 8) | ((slot ^ (pix & 7)) << 16);  // row 255: never inside the image
+    const int py = pix / IW, pxc = pix - py * IW, cg = slot ^ (pix & 7);
+    hitem[it] = (idx >= HIT ? 255 : py) | (pxc << 8) | (cg << 16);  // row 255: never inside the image
+    hoff[it] = ((py * p.W + pxc) * p.ldx + cg * 8) * 2;
   }
+  const size_t imgBytes = (size_t)p.H * p.W * (size_t)p.ldx * 2;
   auto stage_halo = [&](int t, int b) __attribute__((always_inline)) {
     const int n = t / tilesPerImg;
     const int t2 = t - n * tilesPerImg;
     const int tyi = t2 / p.tilesX, txi = t2 - tyi * p.tilesX;
     const int iy0 = tyi * TH - 1, ix0 = txi * 16 - 1;
-    const char* xb = p.x + (size_t)n * p.H * p.W * (size_t)p.ldx * 2;
+    // (scalar) the tile's first halo pixel; may lie outside the image - lanes that would read there take the zero page
+    const char* xt = p.x + (size_t)n * imgBytes + ((long)iy0 * p.W + ix0) * (long)p.ldx * 2;
 #pragma unroll
     for (int it = 0; it < HPASS; ++it) {
       if (it * NTHR + wave * 64 >= HITP) break;  // wave-uniform: the last pass is partial
-      const int hrow = hitem[it] & 255, cg = hitem[it] >> 16;
-      const int iy = iy0 + hrow, ix = ix0 + ((hitem[it] >> 8) & 255);
-      const char* src = reinterpret_cast<const char*>(g_ws3_zero16);
-      if (hrow != 255 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && cg * 8 < p.Cin)
-        src = xb + (((size_t)iy * p.W + ix) * (size_t)p.ldx + cg * 8) * 2;
+      const int iy = iy0 + (hitem[it] & 255), ix = ix0 + ((hitem[it] >> 8) & 255);
+      const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && (hitem[it] >> 16) * 8 < p.Cin;  // (row 255 fails iy < H)
+      const char* src = ok ? xt + hoff[it] : reinterpret_cast<const char*>(g_ws3_zero16);
       __builtin_amdgcn_global_load_lds((wgptr_t)src, (wlptr_t)(hal + b * HB + (it * NTHR + wave * 64) * 16), 16, 0, 0);
     }
   };
 
   int t = blockIdx.x;
   if (t >= numTiles) return;
+  const f32x4 biasv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + wave * 16 + g * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
   stage_halo(t, 0);
   // this wave's weights: fragment (tap, kt) of n-tile `wave`  <-  packed [tap][KTT][NTn][lane][16 B]; 18 x 16 B per lane
   u32x4 wr[9][2];
@@ -109,11 +112,12 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_ws3_kernel(const BigParams p)
                                    : reinterpret_cast<const char*>(g_ws3_zero16);
       wr[tap][kt] = *reinterpret_cast<const u32x4*>(src);
     }
-  const f32x4 biasv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + wave * 16 + g * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
 
   // vmcnt also counts STORES on gfx9 and mixed loads / stores retire out of order, so a wait for the next halo must not sit behind
   // freshly issued epilogue stores (their acknowledgements take ~1 us): the wait for halo t + 1 comes BEFORE the stores of tile t.
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the first halo and its weights have landed
+  // First tile: wait for the halo only - the 18 weight loads were issued after it (loads retire in order), and the MFMA loop's own
+  // counted waits let step 0 start on its three fragments while the other fifteen are still in flight.
+  asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
   int buf = 0;
   for (; t < numTiles; t += gridDim.x) {
     __syncthreads();  // every wave's share of halo t has landed (each waited before its stores); the other buffer is free
@@ -178,19 +182,33 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_ws3_kernel(const BigParams p)
     const int n = t / tilesPerImg;
     const int t2 = t - n * tilesPerImg;
     const int tyi = t2 / p.tilesX, txi = t2 - tyi * p.tilesX;
+    const int ox = txi * 16 + r;
+    const int cb = 16 * wave + 4 * g;
+    const bool colok = ox < p.OW && cb < p.Cout;
+    const size_t pix0 = ((size_t)n * p.OH + (size_t)tyi * TH) * p.OW;  // (scalar) first pixel of the tile's first row
+    char* yt = p.y + pix0 * (size_t)p.ldy * 2;
+    const int yoff = (ox * p.ldy + cb) * 2, yrow = p.OW * p.ldy * 2;
+    u32x2 rv[TH];
+    if (p.res) {  // Bottleneck shortcut: same shape as y; all eight row loads in flight before the activation math
+      const char* rt = p.res + pix0 * (size_t)p.ldr * 2;
+      const int roff = (ox * p.ldr + cb) * 2, rrow = p.OW * p.ldr * 2;
+#pragma unroll
+      for (int i = 0; i < TH; ++i)
+        rv[i] = (colok && tyi * TH + i < p.OH) ? *reinterpret_cast<const u32x2*>(rt + i * rrow + roff) : u32x2{0u, 0u};
+    }
     auto epilogue = [&](auto act_tag) __attribute__((always_inline)) {
       constexpr int ACT = decltype(act_tag)::value;
-      const int ox = txi * 16 + r;
-      const int cb = 16 * wave + 4 * g;
 #pragma unroll
       for (int i = 0; i < TH; ++i) {
-        const int oy = tyi * TH + i;
         float v[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = act<ACT>(acc[i][q] + biasv[q]);
-        if (oy < p.OH && ox < p.OW && cb < p.Cout)
-          *reinterpret_cast<u32x2*>(p.y + ((((size_t)n * p.OH + oy) * p.OW + ox) * (size_t)p.ldy + cb) * 2) =
-              u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        if (p.res) {
+          v[0] += __uint_as_float(rv[i][0] << 16); v[1] += __uint_as_float(rv[i][0] & 0xFFFF0000u);
+          v[2] += __uint_as_float(rv[i][1] << 16); v[3] += __uint_as_float(rv[i][1] & 0xFFFF0000u);
+        }
+        if (colok && tyi * TH + i < p.OH)
+          *reinterpret_cast<u32x2*>(yt + i * yrow + yoff) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
       }
     };
     if (p.act == UPA_ACT_SILU) epilogue(std::integral_constant<int, UPA_ACT_SILU>{});
@@ -221,12 +239,12 @@ bool upa_conv_ws3_eligible(int n, int h, int w, int cin, int ldx, int cout, int 
                            int act, int dtype, const upa_opts* opts) {
   const int mode = UPA_OPT(opts, conv_ws3);
   if (mode == 1) return false;
-  if (dtype != UPA_BF16 || k != 3 || stride != 1 || pad != 1 || residual) return false;
+  if (dtype != UPA_BF16 || k != 3 || stride != 1 || pad != 1) return false;
   if (cin > 64 || cin % 8 != 0 || ldx % 8 != 0 || ldy % 8 != 0 || cout != 64) return false;
   if (act != UPA_ACT_SILU && act != UPA_ACT_NONE && act != UPA_ACT_RELU) return false;
   if (mode == 2) return true;
-  // enough tiles for every CU to amortise its register-resident weights over several: the 80 x 80 level at batch >= 16
-  return cin == 64 && (long)n * h * w >= 100000;
+  // measured against conv_big at batch 32 (tools/bench_conv.py): 64 -> 64 @80x80 23.6 vs 27.0 us, @40x40 11.0 vs 12.0, @20x20 8.4 vs 9.0
+  return cin == 64 && (long)n * h * w >= 8192;
 }
 
 int upa_conv_ws3_launch(BigParams p, int query_only, int* variant, void* stream, const upa_opts* opts) {

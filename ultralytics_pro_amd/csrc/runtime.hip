@@ -42,6 +42,28 @@ extern "C" int upa_copy_to_host(const void* src_dev, void* dst_pinned, size_t by
   return UPA_OK;
 }
 
+// One workgroup per image: the count, then only the rows that hold detections (the rest of the fixed-shape buffer never crosses the
+// host link).  Rows past the count keep whatever the host buffer held - the count says how many are valid, as on the device.
+__global__ void upa_results_to_host_kernel(const unsigned* __restrict__ rows, const int* __restrict__ counts, int max_rows,
+                                           int row_words, unsigned* __restrict__ dst_rows, int* __restrict__ dst_counts) {
+  const int b = blockIdx.x;
+  int c = counts[b];
+  if (threadIdx.x == 0) dst_counts[b] = c;
+  c = c < 0 ? 0 : (c > max_rows ? max_rows : c);
+  const long base = (long)b * max_rows * row_words;
+  for (int i = threadIdx.x; i < c * row_words; i += blockDim.x) dst_rows[base + i] = rows[base + i];
+}
+extern "C" int upa_results_to_host(const void* rows_dev, const int* counts_dev, int batch, int max_rows, int row_bytes,
+                                   void* rows_pinned, int* counts_pinned, void* stream) {
+  UPA_CHECK_ARG(rows_dev && counts_dev && rows_pinned && counts_pinned && batch > 0 && max_rows > 0 && row_bytes > 0 && row_bytes % 4 == 0 &&
+                    ((uintptr_t)rows_dev % 4) == 0 && ((uintptr_t)rows_pinned % 4) == 0,
+                "results_to_host: bad args (rows of whole 4-byte words)");
+  hipLaunchKernelGGL(upa_results_to_host_kernel, dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream, (const unsigned*)rows_dev,
+                     counts_dev, max_rows, row_bytes / 4, (unsigned*)rows_pinned, counts_pinned);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
 extern "C" int upa_graph_begin(void* stream) {
   hipError_t e = hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal);
   if (e != hipSuccess) { upa_set_error("graph_begin: %s", hipGetErrorString(e)); return UPA_ELAUNCH; }

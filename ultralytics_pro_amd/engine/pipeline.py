@@ -9,6 +9,7 @@ streams overlap depends on how the HIP runtime maps them onto hardware queues (G
 
 from __future__ import annotations
 
+import contextlib
 import os
 import sys
 import time
@@ -36,8 +37,24 @@ class PipelinedRunner:
         saved = getattr(det, "concurrent", None)
         if self.linear and saved is not None:
             det.concurrent = False
+        # Dispatch by execution mode.  With several steps in flight the chip is shared by kernels of different steps and what counts is
+        # the LDS / register time a launch holds, not its latency alone:
+        #   * the whole-block kernel of the 40 x 40 C2f blocks (csrc/c2f64.hip) spends 1.74x the useful MFMAs on its tile rings: 2 % less
+        #     throughput in flight (51.6 k vs 50.5 k img/s, same box), 4 % faster with one step at a time (1.012 vs 1.054 ms);
+        #   * the persistent 3x3 kernel (csrc/conv_ws3.hip) is 12 % faster than conv_big launch for launch, but its resident workgroups
+        #     keep their CUs until the launch ends: -0.7 % in flight (51.6 k vs 52.0 k), neutral to +0.2 % one step at a time.
+        # So: in flight > 1 -> upa_opts.c2f = 4 and conv_ws3 = 1 for the compiled copies, unless the caller's options already set them.
+        from . import runtime as R
+        cur = R.current_opts()
+        mode = {}
+        if self.in_flight > 1 and getattr(model, "opts", None) is None:
+            if cur is None or cur.c2f == 0:
+                mode["c2f"] = 4
+            if cur is None or cur.conv_ws3 == 0:
+                mode["conv_ws3"] = 1
+        self.throughput_opts = dict(mode)
         try:
-            with torch.no_grad():
+            with torch.no_grad(), (R.use_opts(**mode) if mode else contextlib.nullcontext()):
                 ncopies = max(self.in_flight, len(examples))
                 self.runs = [model.compile(examples[j % len(examples)], post=post, micro_batches=micro_batches,
                                            stream_priority=sub_priority) for j in range(ncopies)]

@@ -126,9 +126,7 @@ class C2f(nn.Module):
                 return y
             if rc != L.UPA_EUNSUPPORTED:
                 L.check(rc, "c2f64_fused")
-            if upp is not None:
-                up.materialize()  # the separate convolutions below read the concat buffer
-            return None
+            return None  # nothing was launched: the separate convolutions follow, cv1 still reading `up` virtually
         rc = L.lib().upa_c2f_fused(vx.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, self.c, nb, int(self.m[0].add), pk[0].w.data_ptr(),
                                    pk[0].bias.data_ptr(), C.cast(wm, C.c_void_p), C.cast(bm, C.c_void_p), pk[1].w.data_ptr(),
                                    pk[1].bias.data_ptr(), vy.ptr, vy.c, vy.ld, L.ACT_SILU, vx.dtype, R.opts_ptr(),
