@@ -14,6 +14,7 @@ Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, timed live with 
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -72,6 +73,9 @@ def parse():
     ap.add_argument("--no-host-results", action="store_true",
                     help="leave the detections in HBM (round-2 behaviour); default: every captured step ends with a kernel that "
                          "copies (B, max_det, 6) rows + counts into pinned host memory, so `value` counts host-visible detections")
+    ap.add_argument("--no-mode-dispatch", action="store_true",
+                    help="A/B: compile the in-flight copies with the library's default kernels (whole-block c2f64, persistent 3x3) "
+                         "instead of the throughput choice of engine/pipeline.py")
     ap.add_argument("--no-kernel-profile", action="store_true",
                     help="skip the per-layer roofline timing (counter-collection runs: tools/pmc_step.sh)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = the plan of BASELINE.md section 3 (8, 32, physical cores)")
@@ -298,12 +302,13 @@ def main():
                 # construct that has misbehaved on this runtime (DESIGN "Two rules for graphs in flight"); `--in-flight` /
                 # `--micro-batches` / `--linear-graphs 0` still select them explicitly
                 cands = [(4, 1, 0, 1), (3, 1, 0, 1)]
-            runner, table = autotune(model, xs, post, candidates=cands)
+            runner, table = autotune(model, xs, post, candidates=cands, mode_dispatch=not args.no_mode_dispatch)
             tuned = {f"in_flight={k[0]},micro_batches={k[1]},lane_priority={k[2]},linear_graphs={k[3]}": round(t * 1e3, 4)
                      for k, t in table.items()}
             args.in_flight, args.micro_batches = runner.in_flight, runner.micro_batches
         else:
             runner = PipelinedRunner(model, xs, post, micro_batches=args.micro_batches, in_flight=args.in_flight,
+                                     mode_dispatch=not args.no_mode_dispatch,
                                      linear=bool(args.serial or (args.linear_graphs and args.micro_batches == 1)))
         run = runner.runs[0]
         _crumb("graphs compiled" + (" (autotuned)" if tuned else ""))
@@ -359,7 +364,12 @@ def main():
     if rank == 0:
         _crumb("timed region + serial / latency legs done")
         if not args.no_kernel_profile:
-            roofline, kernels = kernel_profile(model, x, dtype, dev, args, pconv, L, post)
+            # per-kernel timing of the launches the TIMED region replayed: under the runner's throughput dispatch, if it has one
+            mode = getattr(runner, "throughput_opts", None) or {}
+            with (R.use_opts(**mode) if mode else contextlib.nullcontext()):
+                roofline, kernels = kernel_profile(model, x, dtype, dev, args, pconv, L, post)
+            if roofline is not None and mode:
+                roofline["dispatch"] = f"as the timed region: upa_opts {mode}"
             _crumb("kernel profile done")
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
             cpu_baseline = run_cpu_baseline_bounded(args)

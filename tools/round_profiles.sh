@@ -11,7 +11,7 @@ for m in yolov8s yolov3-tiny yolov5-BoT3; do timeout 600 python bench.py --model
 timeout 600 python bench.py --model yolov3-rtdetr --batch 16 --no-cpu-baseline --no-kernel-profile > $O/bench_yolov3-rtdetr.json 2>/dev/null
 timeout 600 python bench.py --workload train > $O/bench_train.json 2> $O/bench_train.err
 timeout 600 python bench.py --workload val --steps 300 > $O/bench_val.json 2> $O/bench_val.err
-timeout 600 python bench.py --no-cpu-baseline --opts c2f=4 > $O/bench_default_no_c2f64.json 2>/dev/null   # A/B: the 40x40 blocks as separate launches
+timeout 600 python bench.py --no-cpu-baseline --no-kernel-profile --no-mode-dispatch > $O/bench_default_no_mode_dispatch.json 2>/dev/null   # A/B: the one-step-at-a-time kernels (c2f64, conv_ws3) kept with four steps in flight
 timeout 900 bash tools/pmc_hbm.sh --no-kernel-profile > /dev/null 2>&1
 cp $R/gpurun_out/pmc_hbm/summary.json $O/pmc_hbm_summary.json
 timeout 600 python bench.py --no-cpu-baseline > $O/bench_default_with_traffic.json 2>/dev/null   # roofline.traffic from the PMC summary written just above

@@ -24,7 +24,7 @@ class PipelinedRunner:
     real HBM read and not a replay of one cache-resident batch."""
 
     def __init__(self, model, example, post=None, micro_batches: int = 2, in_flight: int = 2, priority: int = 0,
-                 sub_priority: int = 0, linear: bool = False):
+                 sub_priority: int = 0, linear: bool = False, mode_dispatch: bool = True):
         examples = list(example) if isinstance(example, (list, tuple)) else [example]
         example = examples[0]
         self.model, self.example, self.post = model, example, post
@@ -47,7 +47,7 @@ class PipelinedRunner:
         from . import runtime as R
         cur = R.current_opts()
         mode = {}
-        if self.in_flight > 1 and getattr(model, "opts", None) is None:
+        if mode_dispatch and self.in_flight > 1 and getattr(model, "opts", None) is None:
             if cur is None or cur.c2f == 0:
                 mode["c2f"] = 4
             if cur is None or cur.conv_ws3 == 0:
@@ -91,7 +91,8 @@ def _trace(msg):
         print(f"[pipeline] {msg}", file=sys.stderr, flush=True)
 
 
-def autotune(model, example, post=None, candidates=((4, 1, 0, 1), (2, 2, -1, 0), (3, 2, 0, 0), (1, 2, 0, 0)), steps: int = 20):
+def autotune(model, example, post=None, candidates=((4, 1, 0, 1), (2, 2, -1, 0), (3, 2, 0, 0), (1, 2, 0, 0)), steps: int = 20,
+             mode_dispatch: bool = True):
     """Try (in_flight, micro_batches, lane priority, linear) candidates; returns (best runner, {candidate: s/step})."""
     best, best_t, table = None, float("inf"), {}
     for cand in candidates:
@@ -101,7 +102,8 @@ def autotune(model, example, post=None, candidates=((4, 1, 0, 1), (2, 2, -1, 0),
         if (example[0] if isinstance(example, (list, tuple)) else example).shape[0] % mb:
             continue
         _trace(f"candidate {cand}: compile")
-        r = PipelinedRunner(model, example, post, micro_batches=mb, in_flight=in_flight, priority=prio, linear=linear)
+        r = PipelinedRunner(model, example, post, micro_batches=mb, in_flight=in_flight, priority=prio, linear=linear,
+                            mode_dispatch=mode_dispatch)
         _trace(f"candidate {cand}: measure")
         t = r.measure(steps)
         _trace(f"candidate {cand}: {t * 1e3:.3f} ms")
