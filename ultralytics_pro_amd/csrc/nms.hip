@@ -248,69 +248,88 @@ __global__ __launch_bounds__(GREEDY_NT) void nms_greedy_kernel(const float* pred
     for (int i = threadIdx.x; i < max_det; i += GREEDY_NT) keep_idx[(size_t)b * max_det + i] = -1;
   if (threadIdx.x == 0) s_kept = 0;
   __syncthreads();
-  for (int base = 0; base < n; base += 64) {
-    const int kept = s_kept;
-    if (kept >= max_det) break;
-    const int ci = base + lane;
-    const bool valid = ci < n;
-    float rx1 = 0, ry1 = 0, rx2 = 0, ry2 = 0, score = 0, clsf = 0;  // raw (un-offset) box
-    float x1 = 0, y1 = 0, x2 = 0, y2 = 0, area = 0;
-    int anchor = 0;
-    if (valid) {
-      const u64 key = sb[ci];
-      const unsigned ok = (unsigned)(key & 0xFFFFFFFFull);
-      anchor = (int)(ok / (unsigned)nc);
-      const int c = (int)(ok - (unsigned)anchor * (unsigned)nc);
-      score = __uint_as_float(~(unsigned)(key >> 32));
-      clsf = (float)c;
-      const float cx = pb[anchor], cy = pb[(size_t)A + anchor], w = pb[(size_t)2 * A + anchor],
-                  h = pb[(size_t)3 * A + anchor];
-      const float hw = w / 2.f, hh = h / 2.f;  // xywh2xyxy, utils/ops.py:268-284
-      rx1 = cx - hw; ry1 = cy - hh; rx2 = cx + hw; ry2 = cy + hh;
-      const float off = clsf * (agnostic ? 0.f : max_wh);  // nms.py:143
-      x1 = rx1 + off; y1 = ry1 + off; x2 = rx2 + off; y2 = ry2 + off;
-      area = (x2 - x1) * (y2 - y1);
-    }
-    // phase 1: this wave tests the chunk against its slice of the kept list
-    bool sup = false;
-    for (int k = wave; k < kept; k += GREEDY_NW)
-      sup |= iou_gt(kx1[k], ky1[k], kx2[k], ky2[k], kar[k], x1, y1, x2, y2, area, iou_thr);
-    const u64 am = __ballot(valid && !sup);
-    if (lane == 0) alive_w[wave] = am;
-    __syncthreads();
-    if (wave == 0) {
-      u64 alive = alive_w[0];
-#pragma unroll
-      for (int q = 1; q < GREEDY_NW; ++q) alive &= alive_w[q];
-      // phase 2: resolve the chunk greedily over the SET bits only: take the lowest alive lane, keep it, broadcast its
-      // box, drop every later alive lane it suppresses.  Iterations = boxes kept from this chunk (usually a handful),
-      // not 64 + 64 as a full suppression matrix + scan would cost.
-      u64 rem = alive, keepmask = 0ull;
-      while (rem) {
-        const int i = __ffsll((unsigned long long)rem) - 1;
-        keepmask |= 1ull << i;
-        rem &= rem - 1ull;
-        if (kept + __popcll(keepmask) >= max_det) break;
-        const float ix1 = __shfl(x1, i), iy1 = __shfl(y1, i), ix2 = __shfl(x2, i), iy2 = __shfl(y2, i),
-                    iar = __shfl(area, i);
-        const bool sup = ((rem >> lane) & 1ull) && iou_gt(ix1, iy1, ix2, iy2, iar, x1, y1, x2, y2, area, iou_thr);
-        rem &= ~__ballot(sup);
+  // Candidates are staged 512 at a time: every thread decodes ONE key and gathers its box (two dependent global round trips, paid
+  // once per 512 candidates instead of once per 64-candidate chunk - the gathers were most of this kernel's time: a typical image
+  // has 100-500 candidates and the chunks are resolved one after the other), then the eight chunks of the stage run out of LDS.
+  __shared__ float c_rx1[GREEDY_NT], c_ry1[GREEDY_NT], c_rx2[GREEDY_NT], c_ry2[GREEDY_NT], c_score[GREEDY_NT], c_cls[GREEDY_NT];
+  __shared__ int c_anchor[GREEDY_NT];
+  for (int stage = 0; stage < n; stage += GREEDY_NT) {
+    if (s_kept >= max_det) break;
+    {
+      const int ci = stage + (int)threadIdx.x;
+      if (ci < n) {
+        const u64 key = sb[ci];
+        const unsigned ok = (unsigned)(key & 0xFFFFFFFFull);
+        const int anchor = (int)(ok / (unsigned)nc);
+        const int c = (int)(ok - (unsigned)anchor * (unsigned)nc);
+        const float cx = pb[anchor], cy = pb[(size_t)A + anchor], w = pb[(size_t)2 * A + anchor],
+                    h = pb[(size_t)3 * A + anchor];
+        const float hw = w / 2.f, hh = h / 2.f;  // xywh2xyxy, utils/ops.py:268-284
+        c_rx1[threadIdx.x] = cx - hw; c_ry1[threadIdx.x] = cy - hh; c_rx2[threadIdx.x] = cx + hw; c_ry2[threadIdx.x] = cy + hh;
+        c_score[threadIdx.x] = __uint_as_float(~(unsigned)(key >> 32));
+        c_cls[threadIdx.x] = (float)c;
+        c_anchor[threadIdx.x] = anchor;
       }
-      if ((keepmask >> lane) & 1ull) {
-        const int idx = kept + __popcll(keepmask & ((1ull << lane) - 1ull));
-        if (idx < max_det) {
-          kx1[idx] = x1; ky1[idx] = y1; kx2[idx] = x2; ky2[idx] = y2; kar[idx] = area;
-          float* o = ob + (size_t)idx * 6;
-          o[0] = rx1; o[1] = ry1; o[2] = rx2; o[3] = ry2; o[4] = score; o[5] = clsf;
-          if (keep_idx) keep_idx[(size_t)b * max_det + idx] = anchor;
+    }
+    __syncthreads();
+    const int stage_n = n - stage < GREEDY_NT ? n - stage : GREEDY_NT;
+    for (int base = 0; base < stage_n; base += 64) {
+      const int kept = s_kept;
+      if (kept >= max_det) break;
+      const int li = base + lane;
+      const bool valid = li < stage_n;
+      float rx1 = 0, ry1 = 0, rx2 = 0, ry2 = 0, score = 0, clsf = 0;  // raw (un-offset) box
+      float x1 = 0, y1 = 0, x2 = 0, y2 = 0, area = 0;
+      int anchor = 0;
+      if (valid) {
+        rx1 = c_rx1[li]; ry1 = c_ry1[li]; rx2 = c_rx2[li]; ry2 = c_ry2[li]; score = c_score[li]; clsf = c_cls[li];
+        anchor = c_anchor[li];
+        const float off = clsf * (agnostic ? 0.f : max_wh);  // nms.py:143
+        x1 = rx1 + off; y1 = ry1 + off; x2 = rx2 + off; y2 = ry2 + off;
+        area = (x2 - x1) * (y2 - y1);
+      }
+      // phase 1: this wave tests the chunk against its slice of the kept list
+      bool sup = false;
+      for (int k = wave; k < kept; k += GREEDY_NW)
+        sup |= iou_gt(kx1[k], ky1[k], kx2[k], ky2[k], kar[k], x1, y1, x2, y2, area, iou_thr);
+      const u64 am = __ballot(valid && !sup);
+      if (lane == 0) alive_w[wave] = am;
+      __syncthreads();
+      if (wave == 0) {
+        u64 alive = alive_w[0];
+#pragma unroll
+        for (int q = 1; q < GREEDY_NW; ++q) alive &= alive_w[q];
+        // phase 2: resolve the chunk greedily over the SET bits only: take the lowest alive lane, keep it, broadcast its
+        // box, drop every later alive lane it suppresses.  Iterations = boxes kept from this chunk (usually a handful),
+        // not 64 + 64 as a full suppression matrix + scan would cost.
+        u64 rem = alive, keepmask = 0ull;
+        while (rem) {
+          const int i = __ffsll((unsigned long long)rem) - 1;
+          keepmask |= 1ull << i;
+          rem &= rem - 1ull;
+          if (kept + __popcll(keepmask) >= max_det) break;
+          const float ix1 = __shfl(x1, i), iy1 = __shfl(y1, i), ix2 = __shfl(x2, i), iy2 = __shfl(y2, i),
+                      iar = __shfl(area, i);
+          const bool sup2 = ((rem >> lane) & 1ull) && iou_gt(ix1, iy1, ix2, iy2, iar, x1, y1, x2, y2, area, iou_thr);
+          rem &= ~__ballot(sup2);
+        }
+        if ((keepmask >> lane) & 1ull) {
+          const int idx = kept + __popcll(keepmask & ((1ull << lane) - 1ull));
+          if (idx < max_det) {
+            kx1[idx] = x1; ky1[idx] = y1; kx2[idx] = x2; ky2[idx] = y2; kar[idx] = area;
+            float* o = ob + (size_t)idx * 6;
+            o[0] = rx1; o[1] = ry1; o[2] = rx2; o[3] = ry2; o[4] = score; o[5] = clsf;
+            if (keep_idx) keep_idx[(size_t)b * max_det + idx] = anchor;
+          }
+        }
+        if (lane == 0) {
+          const int nk = kept + __popcll(keepmask);
+          s_kept = nk < max_det ? nk : max_det;
         }
       }
-      if (lane == 0) {
-        const int nk = kept + __popcll(keepmask);
-        s_kept = nk < max_det ? nk : max_det;
-      }
+      __syncthreads();
     }
-    __syncthreads();
+    __syncthreads();  // the stage buffers are rewritten by the next stage
   }
   if (threadIdx.x == 0) counts[b] = s_kept;
 }
