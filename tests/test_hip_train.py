@@ -341,10 +341,13 @@ def test_training_step_yolov8n_matches_reference_golden(dtype, golden_dir):
         norm = tr.grad_norm()
         torch.cuda.synchronize()
         ref_items, ref_norm = G[f"loss_items_{step}"], float(G[f"grad_norm_{step}"][0])
-        # bf16: a statistical bound (see the note at the end).  Three kernel configurations that differ only in the f32
-        # summation order inside the convs landed 10 %, 13 % and 14.5 % off the f32 reference on this 4-image batch.
-        np.testing.assert_allclose(items.cpu().numpy(), ref_items, rtol=2e-3 if f32 else 0.2)
-        assert abs(norm - ref_norm) <= (3e-3 if f32 else 0.15) * ref_norm
+        # bf16: a statistical bound (see the note at the end), per step.  Step 0 starts from the reference's weights: measured on
+        # MI355X (tools/experiments/train_bf16_err.py, round 3) loss items 1.4-4.7 %, gradient norm 8 % off the f32 reference.  Step 1
+        # runs on weights that already differ by one bf16-gradient update and train-mode BatchNorm renormalises every layer: 9-14.5 % /
+        # 14.7 % (three kernel configurations that differ only in the f32 summation order inside the convs landed 10, 13 and 14.5 %).
+        rt_items, rt_norm = (2e-3, 3e-3) if f32 else ((0.08, 0.12) if step == 0 else (0.2, 0.2))
+        np.testing.assert_allclose(items.cpu().numpy(), ref_items, rtol=rt_items)
+        assert abs(norm - ref_norm) <= rt_norm * ref_norm
         # per-parameter gradient norms (the golden stores them after clipping)
         coef = min(1.0, 10.0 / (ref_norm + 1e-6))
         l2 = np.array([float(named[k].grad.double().norm()) * coef for k in keys])
