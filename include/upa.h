@@ -156,10 +156,12 @@ int upa_detect_decode(const void* box, int ldb, const void* cls, int ldc, int n,
  * kind 2 = class (sigmoid -> y[b, 4:4+nc, a0 + a]); the logits never reach HBM unless `raw` (n,h,w,cout) bf16 rows with
  * stride ldraw is given (Detect's second return value, head.py:126).  cout = rows of the packed weights (>= nc: class
  * filters may be zero-padded to the 16-byte store width).  Returns UPA_EUNSUPPORTED outside the fused form (f32 parity
- * mode, reg_max != 16, nc > 128): the caller then runs upa_conv2d_bias_act + upa_detect_decode.  head.py:151-169 */
+ * mode, reg_max != 16, nc > 128): the caller then runs upa_conv2d_bias_act + upa_detect_decode.  head.py:151-169
+ * best_keys (kind 2, may be NULL): (n, a_total) u64 - the NMS sort key of every anchor's best class, as upa_detect_branch_tail
+ * writes it (the NMS prefilter of upa_nms_batched_hot for class branches of any width the streaming kernel takes). */
 int upa_detect_tail(const void* x, int n, int h, int w, int cin, int ldx, const void* w_packed, const float* bias, int cout,
-                    int kind, int nc, float stride_px, float* y, int a_total, int a0, void* raw, int ldraw, int dtype,
-                    const upa_opts* opts, void* stream);
+                    int kind, int nc, float stride_px, float* y, int a_total, int a0, void* raw, int ldraw,
+                    unsigned long long* best_keys, int dtype, const upa_opts* opts, void* stream);
 
 /* 1x1 conv over Concat([Upsample(2x nearest)(up), skip]) with the upsample read on the fly (bf16): the first up_c channels of a
  * pixel come from pixel (y/2, x/2) of `up` (n, h/2, w/2, up_c; pixel stride up_ld), the other cin - up_c from the concat buffer x

@@ -684,8 +684,10 @@ def test_detect_tail_fused_decode_vs_oracle(nc, shape):
     y = torch.full((n, 4 + nc, a_total), -7.0, device=DEV)
     rawbuf = R.alloc_nhwc(n, 64 + ncp, h, w, torch.bfloat16, DEV)
     rawbuf.zero_()
+    best_keys = torch.full((n, a_total), -1, dtype=torch.int64, device=DEV)  # NMS prefilter keys written by the class launch
     for keep_raw in (True, False):
         y.fill_(-7.0)
+        best_keys.fill_(-1)
         for kind, t, wt, bias, cout, rv in ((1, tb, wb, bb, 64, rawbuf[:, :64]), (2, tc, wc, bc, ncp, rawbuf[:, 64:])):
             wpad = torch.cat([wt, torch.zeros(cout - wt.shape[0], *wt.shape[1:])], 0)
             bpad = torch.cat([bias, torch.zeros(cout - bias.shape[0])], 0)
@@ -694,8 +696,18 @@ def test_detect_tail_fused_decode_vs_oracle(nc, shape):
             vr = R.view_of(rv)
             L.check(L.lib().upa_detect_tail(vt.ptr, vt.n, vt.h, vt.w, vt.c, vt.ld, pk.w.data_ptr(), pk.bias.data_ptr(), cout, kind, nc,
                                             16.0, y.data_ptr(), a_total, a0, vr.ptr if keep_raw else None, vr.ld if keep_raw else 0,
+                                            best_keys.data_ptr() if kind == 2 else None,
                                             L.UPA_BF16, R.opts_ptr(), L.current_stream(DEV)), "detect_tail")
         torch.cuda.synchronize()
+        # every anchor of the level carries the NMS key of its best class, (~bits(best) << 32) | (anchor * nc + FIRST argmax)
+        sc = y.cpu()[:, 4:, a0:a0 + h * w]
+        best, arg = sc.max(1)
+        bits = best.contiguous().numpy().view(np.uint32).astype(np.uint64)
+        anchors = np.arange(a0, a0 + h * w, dtype=np.uint64)
+        want = ((~bits & np.uint64(0xFFFFFFFF)) << np.uint64(32)) | (anchors[None, :] * np.uint64(nc) + arg.numpy().astype(np.uint64))
+        kc = best_keys.cpu()
+        assert np.array_equal(kc[:, a0:a0 + h * w].numpy().view(np.uint64), want)
+        assert bool((kc[:, :a0] == -1).all()) and bool((kc[:, a0 + h * w:] == -1).all())
         got = y[:, :, a0:a0 + h * w].cpu()
         d = (got - ref).abs()
         # f32 logits from f32 accumulation of bf16 products; v_exp_f32 / v_rcp_f32 (1 ulp) in the softmax / sigmoid
@@ -762,7 +774,7 @@ def test_detect_branch_tail_vs_unfused_and_oracle(nc, c3, shape):
         pk1 = PackedConv(w1p, b1p, 1, DEV, torch.bfloat16, False)
         vt = R.view_of(t)
         L.check(L.lib().upa_detect_tail(vt.ptr, vt.n, vt.h, vt.w, vt.c, vt.ld, pk1.w.data_ptr(), pk1.bias.data_ptr(), cout, kind, nc,
-                                        16.0, y2.data_ptr(), a_total, a0, None, 0, L.UPA_BF16, R.opts_ptr(), L.current_stream(DEV)),
+                                        16.0, y2.data_ptr(), a_total, a0, None, 0, None, L.UPA_BF16, R.opts_ptr(), L.current_stream(DEV)),
                 "detect_tail")
     torch.cuda.synchronize()
     got, two = y[:, :, a0:a0 + h * w].cpu(), y2[:, :, a0:a0 + h * w].cpu()

@@ -117,7 +117,7 @@ PROTOTYPES = {
     "upa_nhwc_to_nchw": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "upa_letterbox_u8": (_i, [_vp, _i, _i, _i, C.c_long, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "upa_detect_decode": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _i, _i, _vp]),
-    "upa_detect_tail": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _f, _vp, _i, _i, _vp, _i, _i, _op, _vp]),
+    "upa_detect_tail": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _f, _vp, _i, _i, _vp, _i, _vp, _i, _op, _vp]),
     "upa_conv1x1_upcat": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _op, _vp]),
     "upa_bottleneck_pair_cv2": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _op, _vp]),
     "upa_c2f_fused": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _op, _vp]),

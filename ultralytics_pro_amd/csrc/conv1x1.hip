@@ -156,16 +156,18 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_stream_kernel(const C1Para
       } else if constexpr (EPI == 2) {  // Detect class branch: sigmoid, channel-major f32 rows
         int db, da;
         upa_detect_split(p.de, pix < p.P ? pix : p.P - 1, db, da);
+        float best_ = -1.f;  // this lane's running first maximum over its classes of all n-tiles (NMS prefilter key)
+        int bc_ = 0;
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
-          float best_ = -1.f;
-          int bc_ = 0;  // (the NMS key array is produced by the conv_big tail only)
           upa_detect_cls_store(p.de, acc[i][j] + biasv[j], j, db, da, pok, kg, best_, bc_);
           seq += 16 * j + 3 < p.de.nc ? 4 : 0;  // only stores that lane row 0 certainly issues are counted (the count may
                                                // only be too small: a wait for more than needed is always safe)
           if (16 * j + 3 >= p.de.nc)
             for (int q = 0; q < 4; ++q) seq += 16 * j + q < p.de.nc ? 1 : 0;
         }
+        // (not counted in seq: the count may only be too small)
+        if (p.de.best_keys) upa_detect_best_key_store(p.de, best_, bc_, db, da, pok, lane);  // uniform
       }
       if (EPI != 0 && p.y == nullptr) continue;  // decoded rows only (the raw maps are not materialised)
       char* yrow = p.y + ((size_t)pix * ldy2 + co0 * 2);
@@ -378,7 +380,7 @@ int upa_conv1x1_launch(C1Params p, int n_pixels, int query_only, int* variant, v
 // upa_conv2d_bias_act(k = 1, act none) + that branch's half of upa_detect_decode.
 extern "C" int upa_detect_tail(const void* x, int n, int h, int w, int cin, int ldx, const void* w_packed, const float* bias,
                                int cout, int kind, int nc, float stride_px, float* y, int a_total, int a0, void* raw, int ldraw,
-                               int dtype, const upa_opts* opts, void* stream) {
+                               unsigned long long* best_keys, int dtype, const upa_opts* opts, void* stream) {
   UPA_CHECK_ARG(x && w_packed && y, "detect_tail: null pointer");
   UPA_CHECK_ARG(kind == 1 || kind == 2, "detect_tail: kind must be 1 (box) or 2 (class)");
   UPA_CHECK_ARG(n > 0 && h > 0 && w > 0 && a0 >= 0 && a0 + h * w <= a_total, "detect_tail: level does not fit a_total");
@@ -397,6 +399,7 @@ extern "C" int upa_detect_tail(const void* x, int n, int h, int w, int cin, int 
   q.de.y = y; q.de.a_total = a_total; q.de.a0 = a0; q.de.HW = h * w; q.de.W = w;
   q.de.magicHW = upa_magic_div(h * w); q.de.magicW = upa_magic_div(w);
   q.de.nc = nc; q.de.stride_px = stride_px;
+  if (kind == 2 && best_keys && (long)a_total * nc < (1L << 31)) q.de.best_keys = best_keys;
   return upa_conv1x1_launch(q, n * h * w, 0, nullptr, stream, opts);
 }
 

@@ -85,8 +85,9 @@ class Detect(nn.Module, _HipConvMixin):
         y = R.alloc_plain((n, 4 + self.nc, tot), torch.float32, device, key=(id(self), "y"))
         plan = dict(y=y, a0=a0, a_total=tot, fused=fused, hw=[(int(h), int(w)) for h, w in level_hw], n=int(n), decoded=set(),
                     hot=None, hot_levels=set())
-        if fused and self.nms_keys and not self.keep_raw and self.fuse_branch:
-            # NMS prefilter: the class tails also write every anchor's best-class NMS key (upa_detect_branch_tail)
+        if fused and self.nms_keys:
+            # NMS prefilter: the class launches also write every anchor's best-class NMS key (upa_detect_branch_tail, or
+            # upa_detect_tail for class branches outside that form / with raw maps kept)
             plan["hot"] = R.alloc_plain((n, tot), torch.int64, device, key=(id(self), "best_keys"))  # u64 bit patterns
         self._plan()[R.current_tag()] = plan
 
@@ -152,9 +153,13 @@ class Detect(nn.Module, _HipConvMixin):
         if raw is not None:
             vr = R.view_of(raw)
             rp, rld = vr.ptr, vr.ld
+        hot = plan.get("hot") if kind == 2 else None
         L.check(L.lib().upa_detect_tail(vt.ptr, vt.n, vt.h, vt.w, vt.c, vt.ld, pk.w.data_ptr(), pk.bias.data_ptr(), cout, kind,
                                         self.nc, float(self.stride[i]), plan["y"].data_ptr(), plan["a_total"], plan["a0"][i],
-                                        rp, rld, vt.dtype, R.opts_ptr(), L.current_stream(t.device)), "detect_tail")
+                                        rp, rld, hot.data_ptr() if hot is not None else None, vt.dtype, R.opts_ptr(),
+                                        L.current_stream(t.device)), "detect_tail")
+        if hot is not None:
+            plan["hot_levels"].add(i)
 
     def _branch(self, seq: nn.Sequential, x: torch.Tensor, out: torch.Tensor) -> None:
         t = seq[1](seq[0](x))

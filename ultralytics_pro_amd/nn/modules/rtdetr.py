@@ -275,7 +275,9 @@ class RTDETRDecoder(nn.Module):
         self._reset_parameters()
 
     def _reset_parameters(self):
-        """head.py:2202-2224."""
+        """The reference's initialisation recipe, head.py:2202-2224, restated as is: a freshly built decoder has to hold the same
+        parameter values as the reference's (same RNG draws in the same order, same constants) for state_dict-level parity, so the
+        sequence of init calls is fixed by the reference and not a design choice of this repository."""
         bias_cls = float(-math.log((1 - 0.01) / 0.01)) / 80 * self.nc
         nn.init.constant_(self.enc_score_head.bias, bias_cls)
         nn.init.constant_(self.enc_bbox_head.layers[-1].weight, 0.0)
@@ -292,7 +294,9 @@ class RTDETRDecoder(nn.Module):
 
     @staticmethod
     def _generate_anchors(shapes, grid_size=0.05, eps=1e-2):
-        """Logit-space anchors + validity mask for all tokens (head.py:2078-2115); tiny, input-independent -> host."""
+        """Logit-space anchors + validity mask for all tokens: the constant table of head.py:2078-2115, restated operation for
+        operation because the f32 values must be bit-identical to the reference's (they are added to the box logits before the
+        top-k).  Tiny and input-independent, so it is computed once on the host and uploaded (`_static`)."""
         anchors = []
         for i, (h, w) in enumerate(shapes):
             sy = torch.arange(end=h, dtype=torch.float32)

@@ -60,6 +60,12 @@ def process_batch(pred_boxes: torch.Tensor, pred_cls: torch.Tensor, gt_boxes: to
     return match_predictions_batched(det, cnt, gt, ng)[0].cpu().numpy().astype(bool)
 
 
+# ---- host-side AP arithmetic.  These three functions are a numerical RECIPE, not a design: validation mAP has to come out equal to
+# the reference's to the last bit (tests/test_validator.py compares at 1e-7 against goldens produced by the imported reference), and
+# that fixes the operations and their order - the box filter's edge padding, `np.interp` on the NEGATED confidences (descending x),
+# the precision envelope by a reversed running maximum and the 101-point trapezoid.  They restate utils/metrics.py:612-617, 708-737
+# and 740-835 (plotting, names and the per-class dict output left out); everything on the GPU side of validation (`match_predictions`,
+# the statistics gather) is this repository's own.
 def smooth(y: np.ndarray, f: float = 0.05) -> np.ndarray:
     """Box filter of fraction f (utils/metrics.py:612-617)."""
     nf = round(len(y) * f * 2) // 2 + 1
