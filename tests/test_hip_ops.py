@@ -1001,3 +1001,47 @@ def test_results_to_host_kernel():
     for i, c in enumerate(counts.tolist()):
         assert torch.equal(hrows[i, :c], rc[i, :c]) and bool((hrows[i, c:] == -1.0).all())
 
+
+LINEAR_CASES = [
+    # m, k, n, act, residual   (nn.Linear on token rows, `upa_linear`: the small-M kernel of csrc/transformer.hip and its fallbacks)
+    (4800, 256, 256, 0, False),   # the RT-DETR decoder's shape: 150 row tiles x 4 column blocks
+    (300, 256, 512, 2, False),    # ReLU (FFN linear1), n-tiles past one column block
+    (77, 256, 80, 0, True),       # ragged rows (last tile holds 13), N = 5 tiles (a dead wave in the second block), residual
+    (45, 1024, 256, 0, True),     # K = 1024: one m-tile per workgroup, weights in four register sets
+    (33, 512, 4, 0, False),       # N = 4: one store group of one lane row
+    (64, 96, 32, 1, False),       # K = 96 (three 32-channel units), SiLU in f32 (expf + IEEE divide)
+    (50, 4, 512, 2, False),       # K = 4 (query_pos_head's first layer): outside the small-M form -> the conv kernel
+    (20, 48, 40, 0, True),        # K = 48: not a multiple of 32 -> the conv kernel
+]
+
+
+@pytest.mark.parametrize("case", LINEAR_CASES, ids=[f"m{c[0]}_k{c[1]}_n{c[2]}_a{c[3]}{'_res' if c[4] else ''}" for c in LINEAR_CASES])
+def test_linear_f32_rows(case):
+    """`upa_linear` (exact-f32 MFMA) vs float64 `x @ W^T + b` -> act -> + residual (nn.Linear / MLP of the RT-DETR head,
+    transformer.py:348-399, head.py:1993-2003): strided inputs and outputs (columns of wider buffers), ragged row and column tiles."""
+    from tests.hip_utils import DEV, unit_input
+    from ultralytics_pro_amd import _lib as L
+    from ultralytics_pro_amd.nn.modules.conv import PackedConv
+    m, k, n, act, res = case
+    ldx, ldy, ldr = k + 8, n + 12, n + 4
+    x = unit_input(f"lin_x{case}", (m, ldx), -1.5, 1.5)
+    w = unit_input(f"lin_w{case}", (n, k), -0.2, 0.2)
+    b = unit_input(f"lin_b{case}", (n,), -1, 1)
+    r = unit_input(f"lin_r{case}", (m, ldr), -1, 1)
+    ref = x[:, :k].double() @ w.double().t() + b.double()
+    if act == 2:
+        ref = ref.clamp(min=0)
+    elif act == 1:
+        ref = ref * torch.sigmoid(ref)
+    if res:
+        ref = ref + r[:, :n].double()
+    pk = PackedConv(w.reshape(n, k, 1, 1), b, 1, DEV, torch.float32, False)
+    xd, rd = x.to(DEV), r.to(DEV)
+    y = torch.full((m, ldy), -7.0, device=DEV)
+    L.check(L.lib().upa_linear(xd.data_ptr(), m, k, ldx, pk.w.data_ptr(), pk.bias.data_ptr(), y.data_ptr(), n, ldy,
+                               rd.data_ptr() if res else None, ldr if res else 0, act, L.current_stream(DEV)), "linear")
+    torch.cuda.synchronize()
+    got = y.cpu()
+    assert float((got[:, :n].double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))  # f32 accumulation over K <= 1024
+    assert bool((got[:, n:] == -7.0).all())  # nothing outside the n output columns
+
