@@ -38,7 +38,7 @@ enum { UPA_OK = 0, UPA_EINVAL = -1, UPA_EUNSUPPORTED = -2, UPA_EWORKSPACE = -3, 
  * tools/bench_conv.py sweeps and by A/B measurements; production code passes NULL. */
 typedef struct upa_opts {
   uint32_t size;
-  int32_t conv_big;        /* csrc/conv_big.hip inside upa_conv2d_bias_act: 0 = by the size rule, 1 = never, 2 = every shape it can run */
+  int32_t conv_big;        /* csrc/conv_big.hip inside upa_conv2d_bias_act: 0 = by the size rule, 1 = never, 2 = every shape it can run, 3 = the rule restricted to maps of < 100000 pixels (at most one tile per workgroup) */
   int32_t conv_big_bm;     /* its workgroup pixels: 0 = auto | 128 | 256 | 512 */
   int32_t conv_force[4];   /* conv_igemm variant WM, WN, MT, NT for every conv whose Cout fits it (0 = none) */
   int32_t conv_ckt;        /* conv_igemm k-tiles per chunk: 0 = auto | 1 | 2 | 4 */
@@ -58,7 +58,7 @@ typedef struct upa_opts {
   int32_t stem_wgs, stemf_wgs, stemf_waves, stem_no_mfma;  /* stem kernels: workgroup caps (0 = 1024 / 512), fused-stem waves (0 = 8 | 4) */
   int32_t ablate_conv, ablate_pipe, ablate_c1, ablate_stem;  /* kernel ablation bit masks: honoured by the -DUPA_ABLATE build only (make ablate) */
   int32_t c2f64_max_px;    /* upa_c2f64_fused only up to this many pixels n * h * w (0 = 100000: the 40 x 40 maps at batch 32; -1 = any size) */
-  int32_t conv_ws3;        /* csrc/conv_ws3.hip (persistent 3x3 with register-resident weights, Cin <= 64, Cout 64): 0 = by the size rule, 1 = never, 2 = every shape it can run */
+  int32_t conv_ws3;        /* csrc/conv_ws3.hip (persistent 3x3 with register-resident weights, Cin <= 64, Cout 64): 0 = by the size rule, 1 = never, 2 = every shape it can run, 3 = the rule restricted to maps of < 100000 pixels (at most one tile per workgroup) */
 } upa_opts;
 
 /* Library / device info. Returns the ABI version (int); fills name with the kernel target ("gfx950"). */

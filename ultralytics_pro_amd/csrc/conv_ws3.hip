@@ -243,6 +243,7 @@ bool upa_conv_ws3_eligible(int n, int h, int w, int cin, int ldx, int cout, int 
   if (cin > 64 || cin % 8 != 0 || ldx % 8 != 0 || ldy % 8 != 0 || cout != 64) return false;
   if (act != UPA_ACT_SILU && act != UPA_ACT_NONE && act != UPA_ACT_RELU) return false;
   if (mode == 2) return true;
+  if (mode == 3) return cin == 64 && (long)n * h * w >= 8192 && (long)n * h * w < 100000;  // one tile per workgroup at most: no resident walk
   // measured against conv_big at batch 32 (tools/bench_conv.py): 64 -> 64 @80x80 23.6 vs 27.0 us, @40x40 11.0 vs 12.0, @20x20 8.4 vs 9.0
   return cin == 64 && (long)n * h * w >= 8192;
 }

@@ -105,7 +105,10 @@ def autotune(model, example, post=None, candidates=((4, 1, 0, 1), (2, 2, -1, 0),
         r = PipelinedRunner(model, example, post, micro_batches=mb, in_flight=in_flight, priority=prio, linear=linear,
                             mode_dispatch=mode_dispatch)
         _trace(f"candidate {cand}: measure")
-        t = r.measure(steps)
+        # best of three short measurements: a single 20-step sample is sometimes 5x off (a one-time runtime hiccup inside the
+        # window: 4.08 ms instead of 0.71 in one of eight otherwise identical processes), which made the tuner pick a slower
+        # configuration and the whole run land 8 % low
+        t = min(r.measure(steps) for _ in range(3))
         _trace(f"candidate {cand}: {t * 1e3:.3f} ms")
         table[(in_flight, mb, prio, int(linear))] = t
         if t < best_t:
