@@ -343,7 +343,7 @@ def main():
     seen = ranks_seen(dist, dev)
 
     roofline, kernels, cpu_baseline = None, None, None
-    serial_ms = latency_ms = None
+    serial_ms = latency_ms = forked_ms = None
     if rank == 0 and not args.serial:
         # the same step with no concurrency at all (one linear graph, one stream): back-to-back ms/step, and the latency of
         # ONE batch from enqueue to host-visible results
@@ -359,6 +359,18 @@ def main():
                 lat.append(time.perf_counter() - t1)
             latency_ms = sorted(lat)[len(lat) // 2] * 1e3
             del one
+            # ... and one step at a time WITH the concurrency a single step has: the six Detect branches as parallel branches of
+            # its graph (independent chains on the 80 / 40 / 20-pixel maps: the small ones fill the rounds the large ones leave
+            # open).  Forked graphs do not combine with several steps in flight on this runtime (0.89 ms against 0.62), so this is a
+            # one-step figure only.
+            forked_ms = None
+            if not rtdetr:
+                try:
+                    fk = PipelinedRunner(model, xs[:2], post, micro_batches=1, in_flight=1, linear=False)
+                    forked_ms = fk.measure(steps=60, warmup=6) * 1e3
+                    del fk
+                except Exception as e:  # noqa: BLE001 - an extra measurement must not cost the run its headline line
+                    print(f"[bench] forked one-step leg skipped: {e}", file=sys.stderr)
     elif rank == 0:
         serial_ms = ms_per_step
     if rank == 0:
@@ -411,6 +423,8 @@ def main():
             "serial_ms_per_step": None if serial_ms is None else round(serial_ms, 4),
             # strict one-batch-at-a-time rate: per-GPU batch / the serial step (no steps in flight, no intra-step concurrency)
             "value_one_step_in_flight": None if serial_ms is None else round(pb / (serial_ms * 1e-3), 1),
+            # one step at a time with its Detect branches as parallel graph branches (intra-step concurrency only)
+            "one_step_forked_ms": None if forked_ms is None else round(forked_ms, 4),
             "latency_ms_per_batch": None if latency_ms is None else round(latency_ms, 4),
             "detections_per_image_mean": round(sum(ndet) / max(1, len(ndet)), 1),
             "model_tflops": round(value / world * GFLOP_OTHER.get(args.model, GFLOP_PER_IMG) / 1e3, 2),
