@@ -59,6 +59,7 @@ typedef struct upa_opts {
   int32_t ablate_conv, ablate_pipe, ablate_c1, ablate_stem;  /* kernel ablation bit masks: honoured by the -DUPA_ABLATE build only (make ablate) */
   int32_t c2f64_max_px;    /* upa_c2f64_fused only up to this many pixels n * h * w (0 = 100000: the 40 x 40 maps at batch 32; -1 = any size) */
   int32_t conv_ws3;        /* csrc/conv_ws3.hip (persistent 3x3 with register-resident weights, Cin <= 64, Cout 64): 0 = by the size rule, 1 = never, 2 = every shape it can run, 3 = the rule restricted to maps of < 100000 pixels (at most one tile per workgroup) */
+  int32_t no_group;        /* upa_conv2d_bias_act_group / upa_detect_branch_tail_group: 1 = one launch per problem (A/B) */
 } upa_opts;
 
 /* Library / device info. Returns the ABI version (int); fills name with the kernel target ("gfx950"). */
@@ -78,6 +79,17 @@ int upa_conv2d_bias_act(const void* x, int n, int h, int w, int cin, int ldx,
                         void* y, int cout, int ldy,
                         const void* residual /* NULL or view shaped like y */, int ldr,
                         int k, int stride, int pad, int act, int dtype, const upa_opts* opts, void* stream);
+/* Several INDEPENDENT convolutions that share k / stride / pad / act / dtype (the first convs of a Detect head's branches on
+ * different levels): the same results as one upa_conv2d_bias_act per problem; neighbours in the list that land on the same
+ * 128-pixel large-tile instantiation share one grid.  conv.py:188-197 */
+typedef struct upa_conv_problem {
+  const void* x; int32_t n, h, w, cin, ldx;
+  const void* w_packed; const float* bias;
+  void* y; int32_t cout, ldy;
+  const void* residual; int32_t ldr;
+} upa_conv_problem;
+int upa_conv2d_bias_act_group(const upa_conv_problem* probs, int count, int k, int stride, int pad, int act, int dtype,
+                              const upa_opts* opts, void* stream);
 
 /* Introspection for benchmarks: the kernel instantiation (WM<<12 | WN<<8 | MTW<<4 | NTW) the call above would use. */
 int upa_conv_variant(int n, int h, int w, int cin, int cout, int k, int stride, int pad, int dtype, const upa_opts* opts);
@@ -215,6 +227,18 @@ int upa_pack_tail_weight(const float* w, int cout, int cin, void* out);
 int upa_detect_branch_tail(const void* x, int n, int h, int w, int c, int ldx, const void* w3_packed, const float* b3,
                            const void* wt_packed, const float* bt, int kind, int nc, float stride_px, float* y, int a_total,
                            int a0, unsigned long long* best_keys, int dtype, const upa_opts* opts, void* stream);
+/* The same for several levels of ONE Detect head (same kind, shared y / best_keys): identical results, but levels whose problems
+ * land on the same 128-pixel kernel instantiation are launched two per grid (the 40 x 40 and 20 x 20 levels at batch 32: 400 + 100
+ * workgroups, one partial round instead of two launches).  UPA_EUNSUPPORTED (nothing launched) if any level is outside the fused
+ * form: the caller then goes level by level.  head.py:94-100, 116-126, 151-169 */
+typedef struct upa_branch_level {
+  const void* x; int32_t n, h, w, c, ldx;                 /* the branch's mid tensor (NHWC view) */
+  const void* w3_packed; const float* b3;                 /* second 3x3 conv (as upa_detect_branch_tail) */
+  const void* wt_packed; const float* bt;                 /* final 1x1 conv (upa_pack_tail_weight) */
+  float stride_px; int32_t a0;                            /* the level's stride and first anchor */
+} upa_branch_level;
+int upa_detect_branch_tail_group(const upa_branch_level* levels, int count, int kind, int nc, float* y, int a_total,
+                                 unsigned long long* best_keys, int dtype, const upa_opts* opts, void* stream);
 
 
 /* ---- NMS ----------------------------------------------------------------------------------------------------------

@@ -1045,3 +1045,64 @@ def test_linear_f32_rows(case):
     assert float((got[:, :n].double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))  # f32 accumulation over K <= 1024
     assert bool((got[:, n:] == -7.0).all())  # nothing outside the n output columns
 
+
+def test_grouped_launches_equal_single_launches():
+    """`upa_conv2d_bias_act_group` / `upa_detect_branch_tail_group`: several independent problems in one call - neighbours on the same
+    128-pixel conv_big instantiation share ONE grid (conv_big_pair_kernel) - must give bit-identical results to one call per problem:
+    the Detect head's first convs and branch tails of a 40 x 40 and a 20 x 20 level (+ an 80 x 80 level that takes the 256-pixel
+    variant and is launched alone), box and class kinds, with `no_group` as the A/B switch."""
+    import ctypes as C
+    from tests.hip_utils import DEV, bf16_round, to_dev_nhwc, unit_input
+    from ultralytics_pro_amd import _lib as L
+    from ultralytics_pro_amd.engine import runtime as R
+    from ultralytics_pro_amd.nn.modules.conv import PackedConv
+    lib, st = L.lib(), L.current_stream(DEV)
+    n, nc = 16, 80
+    levels = [(80, 80, 64), (40, 40, 128), (20, 20, 256)]  # (h, w, cin) of the level's feature map
+    for kind, cmid in ((1, 64), (2, 80)):
+        xs, pks, outs_g, outs_s = [], [], [], []
+        for li, (h, w, cin) in enumerate(levels):
+            x = to_dev_nhwc(bf16_round(unit_input(f"grp_x{kind}{li}", (n, cin, h, w), -1, 1)), torch.bfloat16)
+            wgt = bf16_round(unit_input(f"grp_w{kind}{li}", (cmid, cin, 3, 3), -0.1, 0.1))
+            pk = PackedConv(wgt, unit_input(f"grp_b{kind}{li}", (cmid,), -0.5, 0.5), 3, DEV, torch.bfloat16, False)
+            xs.append(x); pks.append(pk)
+            outs_g.append(R.alloc_nhwc(n, cmid, h, w, torch.bfloat16, DEV)); outs_s.append(R.alloc_nhwc(n, cmid, h, w, torch.bfloat16, DEV))
+        for outs, opts in ((outs_g, None), (outs_s, L.Opts(no_group=1))):
+            probs = (L.ConvProblem * 3)()
+            for j in range(3):
+                vx, vy = R.view_of(xs[j]), R.view_of(outs[j])
+                probs[j] = L.ConvProblem(vx.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, pks[j].w.data_ptr(), pks[j].bias.data_ptr(), vy.ptr, cmid, vy.ld, None, 0)
+            L.check(lib.upa_conv2d_bias_act_group(C.cast(probs, C.c_void_p), 3, 3, 1, 1, L.ACT_SILU, L.UPA_BF16,
+                                                  C.pointer(opts) if opts is not None else None, st), "conv2d_group")
+        torch.cuda.synchronize()
+        for a, b in zip(outs_g, outs_s):
+            assert torch.equal(a, b)
+        # the branch tails on those mid tensors
+        cp = 64 if kind == 1 else 80
+        a0s, tot = [0, 6400, 8000], 8400
+        ys = [torch.full((n, 4 + nc, tot), -7.0, device=DEV) for _ in range(2)]
+        keys = [torch.full((n, tot), -1, dtype=torch.int64, device=DEV) for _ in range(2)]
+        packed = []
+        for li, (h, w, _) in enumerate(levels):
+            w3 = bf16_round(unit_input(f"grp_w3{kind}{li}", (cp, cmid, 3, 3), -0.1, 0.1))
+            pk3 = PackedConv(w3, unit_input(f"grp_b3{kind}{li}", (cp,), -0.5, 0.5), 3, DEV, torch.bfloat16, False)
+            wt = bf16_round(unit_input(f"grp_wt{kind}{li}", (cp, cp), -0.4, 0.4))
+            bt = unit_input(f"grp_bt{kind}{li}", (cp,), -2, 1)
+            host = torch.empty(lib.upa_tail_packed_weight_bytes(cp, cp), dtype=torch.uint8)
+            L.check(lib.upa_pack_tail_weight(wt.data_ptr(), cp, cp, host.data_ptr()), "pack_tail_weight")
+            packed.append((pk3, host.to(DEV), bt.to(DEV)))
+        for which, opts in ((0, None), (1, L.Opts(no_group=1))):
+            lv = (L.BranchLevel * 3)()
+            for j, (h, w, _) in enumerate(levels):
+                vt = R.view_of(outs_g[j])
+                pk3, wt, bt = packed[j]
+                lv[j] = L.BranchLevel(vt.ptr, vt.n, vt.h, vt.w, vt.c, vt.ld, pk3.w.data_ptr(), pk3.bias.data_ptr(), wt.data_ptr(), bt.data_ptr(),
+                                      float(8 << j), a0s[j])
+            L.check(lib.upa_detect_branch_tail_group(C.cast(lv, C.c_void_p), 3, kind, nc, ys[which].data_ptr(), tot,
+                                                     keys[which].data_ptr() if kind == 2 else None, L.UPA_BF16,
+                                                     C.pointer(opts) if opts is not None else None, st), "branch_tail_group")
+        torch.cuda.synchronize()
+        assert torch.equal(ys[0], ys[1]) and torch.equal(keys[0], keys[1])
+        rows = slice(0, 4) if kind == 1 else slice(4, 4 + nc)
+        assert int((ys[0][:, rows] == -7.0).sum()) == 0  # every anchor of the three levels was written
+

@@ -37,7 +37,7 @@ class Opts(C.Structure):
                 ("c2f", _i), ("c2f16_waves", _i), ("c2f32_th", _i),
                 ("no_branch_tail", _i), ("branch_tail_bm", _i),
                 ("stem_wgs", _i), ("stemf_wgs", _i), ("stemf_waves", _i), ("stem_no_mfma", _i),
-                ("ablate_conv", _i), ("ablate_pipe", _i), ("ablate_c1", _i), ("ablate_stem", _i), ("c2f64_max_px", _i), ("conv_ws3", _i)]
+                ("ablate_conv", _i), ("ablate_pipe", _i), ("ablate_c1", _i), ("ablate_stem", _i), ("c2f64_max_px", _i), ("conv_ws3", _i), ("no_group", _i)]
 
     def __init__(self, **kw):
         super().__init__()
@@ -90,6 +90,18 @@ class Opts(C.Structure):
         return o
 
 
+class BranchLevel(C.Structure):
+    """`upa_branch_level` (upa_detect_branch_tail_group)."""
+    _fields_ = [("x", C.c_void_p), ("n", _i), ("h", _i), ("w", _i), ("c", _i), ("ldx", _i), ("w3_packed", C.c_void_p), ("b3", C.c_void_p),
+                ("wt_packed", C.c_void_p), ("bt", C.c_void_p), ("stride_px", C.c_float), ("a0", _i)]
+
+
+class ConvProblem(C.Structure):
+    """`upa_conv_problem` (upa_conv2d_bias_act_group)."""
+    _fields_ = [("x", C.c_void_p), ("n", _i), ("h", _i), ("w", _i), ("cin", _i), ("ldx", _i), ("w_packed", C.c_void_p), ("bias", C.c_void_p),
+                ("y", C.c_void_p), ("cout", _i), ("ldy", _i), ("residual", C.c_void_p), ("ldr", _i)]
+
+
 _op = C.POINTER(Opts)
 
 # name -> (restype, argtypes); must list every prototype of include/upa.h (tests/test_abi.py checks this)
@@ -117,6 +129,8 @@ PROTOTYPES = {
     "upa_nhwc_to_nchw": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "upa_letterbox_u8": (_i, [_vp, _i, _i, _i, C.c_long, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "upa_detect_decode": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _i, _i, _vp]),
+    "upa_detect_branch_tail_group": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _op, _vp]),
+    "upa_conv2d_bias_act_group": (_i, [_vp, _i, _i, _i, _i, _i, _i, _op, _vp]),
     "upa_detect_tail": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _f, _vp, _i, _i, _vp, _i, _vp, _i, _op, _vp]),
     "upa_conv1x1_upcat": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _op, _vp]),
     "upa_bottleneck_pair_cv2": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _op, _vp]),

@@ -949,3 +949,40 @@ extern "C" int upa_conv2d_bias_act(const void* x, int n, int h, int w, int cin, 
   if (rc == UPA_EUNSUPPORTED) upa_set_error("conv2d: tile does not fit LDS (k=%d s=%d cin=%d)", k, stride, cin);
   return rc;
 }
+
+// Several independent convolutions with the same kernel size / stride / padding / activation (the first convs of a Detect head's
+// branches on different levels): identical to one upa_conv2d_bias_act per problem, but neighbours that land on the same 128-pixel
+// conv_big instantiation share ONE grid (conv_big.hip: conv_big_pair_kernel) - a 400- and a 100-workgroup launch become one partial round.
+extern "C" int upa_conv2d_bias_act_group(const upa_conv_problem* probs, int count, int k, int stride, int pad, int act, int dtype,
+                                         const upa_opts* opts, void* stream) {
+  UPA_CHECK_ARG(probs && count >= 1 && count <= 8, "conv2d_group: 1..8 problems");
+  auto big_ok = [&](const upa_conv_problem& q) {
+    return q.x && q.y && q.w_packed && ((uintptr_t)q.x % 16) == 0 && ((uintptr_t)q.y % 16) == 0 && !q.residual &&
+           !upa_conv_ws3_eligible(q.n, q.h, q.w, q.cin, q.ldx, q.cout, q.ldy, false, k, stride, pad, act, dtype, opts) &&
+           upa_conv_big_eligible(q.n, q.h, q.w, q.cin, q.ldx, q.cout, q.ldy, 0, k, stride, pad, act, dtype, opts);
+  };
+  auto fill = [&](const upa_conv_problem& q) {
+    BigParams b;
+    memset(&b, 0, sizeof(b));
+    b.x = (const char*)q.x; b.y = (char*)q.y; b.w = (const char*)q.w_packed; b.bias = q.bias;
+    b.N = q.n; b.H = q.h; b.W = q.w; b.Cin = q.cin; b.ldx = q.ldx; b.Cout = q.cout; b.ldy = q.ldy;
+    b.OH = (q.h + 2 * pad - k) / stride + 1;
+    b.OW = (q.w + 2 * pad - k) / stride + 1;
+    b.KS = k; b.stride = stride; b.pad = pad; b.act = act;
+    return b;
+  };
+  for (int i = 0; i < count;) {
+    if (i + 1 < count && k == 3 && stride == 1 && big_ok(probs[i]) && big_ok(probs[i + 1])) {
+      const int rc = upa_conv_big_launch_pair(fill(probs[i]), fill(probs[i + 1]), stream, opts);
+      if (rc == UPA_OK) { i += 2; continue; }
+      if (rc != UPA_EUNSUPPORTED) return rc;
+    }
+    const upa_conv_problem& q = probs[i];
+    if (const int rc = upa_conv2d_bias_act(q.x, q.n, q.h, q.w, q.cin, q.ldx, q.w_packed, q.bias, q.y, q.cout, q.ldy, q.residual, q.ldr,
+                                           k, stride, pad, act, dtype, opts, stream); rc != UPA_OK)
+      return rc;
+    ++i;
+  }
+  return UPA_OK;
+}
+

@@ -54,8 +54,10 @@ __device__ __forceinline__ float big_act(float v) {
 // TAIL != 0 (Detect branches, WN = 1 so that a wave holds every channel of its pixels): the SiLU'd result of this 3x3 conv is
 // not stored but fed, from the accumulators, into the branch's final 1x1 conv and that conv's half of the decode - see the
 // tail section below.  TAIL 1 = box branch (DFL + dist2bbox), 2 = class branch (sigmoid).
+// The kernel body: `bid0` = the workgroup's tile index within ITS problem (blockIdx.x for a single launch; a paired launch -
+// conv_big_pair_kernel below - runs two problems of the same instantiation in one grid).
 template <int KS, int STRIDE, int WM, int WN, int MT, int NT, int TAIL = 0>
-__global__ __launch_bounds__(512, 4) void conv_big_kernel(const BigParams p) {
+__device__ __forceinline__ void conv_big_body(const BigParams& p, const int bid0) {
   static_assert(WM * WN == 8, "8 waves per workgroup");
   static_assert(TAIL == 0 || WN == 1, "a tail needs every channel of a pixel in one wave");
   static_assert(TAIL != 1 || (NT % 2) == 0, "box branch: 64 channels");
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(512, 4) void conv_big_kernel(const BigParams p) {
   const int r = lane & 15, g = lane >> 4;
   const int wm = wave / WN, wn = wave % WN;
 
-  int bid = blockIdx.x;
+  int bid = bid0;
   const int tilesPerImg = p.tilesX * p.tilesY;
   const int n = bid / tilesPerImg;
   bid -= n * tilesPerImg;
@@ -356,6 +358,20 @@ __global__ __launch_bounds__(512, 4) void conv_big_kernel(const BigParams p) {
 #endif
 }
 
+template <int KS, int STRIDE, int WM, int WN, int MT, int NT, int TAIL = 0>
+__global__ __launch_bounds__(512, 4) void conv_big_kernel(const BigParams p) {
+  conv_big_body<KS, STRIDE, WM, WN, MT, NT, TAIL>(p, (int)blockIdx.x);
+}
+
+// Two problems of one instantiation in ONE grid: workgroups [0, split) belong to p0, the rest to p1 (same column count).  The small
+// maps' launches (40 x 40 and 20 x 20 levels of the Detect head: 400 and 100 workgroups) are a fraction of a round each and mostly
+// launch ramp + halo latency; side by side the smaller one rides inside the larger one's round.
+template <int KS, int STRIDE, int WM, int WN, int MT, int NT, int TAIL = 0>
+__global__ __launch_bounds__(512, 4) void conv_big_pair_kernel(const BigParams p0, const BigParams p1, const int split) {
+  if ((int)blockIdx.x < split) conv_big_body<KS, STRIDE, WM, WN, MT, NT, TAIL>(p0, (int)blockIdx.x);
+  else conv_big_body<KS, STRIDE, WM, WN, MT, NT, TAIL>(p1, (int)blockIdx.x - split);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
@@ -456,6 +472,21 @@ int big_launch_inst(const BigParams& p, size_t lds, hipStream_t s) {
   return UPA_OK;
 }
 
+template <int KS, int STRIDE, int WM, int WN, int MT, int NT, int TAIL = 0>
+int big_launch_pair_inst(const BigParams& p0, const BigParams& p1, size_t lds, hipStream_t s) {
+  constexpr int NTB = WN * NT;
+  const long t0 = (long)p0.tilesX * p0.tilesY * p0.N, t1 = (long)p1.tilesX * p1.tilesY * p1.N;
+  if (cdiv(p0.NTn, NTB) != cdiv(p1.NTn, NTB) || t0 + t1 >= (1L << 31)) return UPA_EUNSUPPORTED;
+  const dim3 grid((unsigned)(t0 + t1), (unsigned)cdiv(p0.NTn, NTB));
+  if (hipError_t e = upa_full_lds<conv_big_pair_kernel<KS, STRIDE, WM, WN, MT, NT, TAIL>>(); e != hipSuccess) {
+    upa_set_error("conv_big: cannot raise LDS limit: %s", hipGetErrorString(e));
+    return UPA_ELAUNCH;
+  }
+  hipLaunchKernelGGL((conv_big_pair_kernel<KS, STRIDE, WM, WN, MT, NT, TAIL>), grid, dim3(512), lds, s, p0, p1, (int)t0);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
 template <int WM, int WN, int MT, int NT>
 int big_launch_ks(const BigParams& p, size_t lds, hipStream_t s) {
   if (p.KS == 1) return big_launch_inst<1, 1, WM, WN, MT, NT>(p, lds, s);
@@ -497,26 +528,21 @@ extern "C" int upa_pack_tail_weight(const float* w, int cout, int cin, void* out
   return UPA_OK;
 }
 
-// Second 3x3 conv of a Detect branch + the final 1x1 conv + that branch's half of the decode in ONE launch (bf16).
-// x: (n, h, w, c) NHWC view, c = 64 (box branch, kind 1) or <= 96 (class branch, kind 2).  With CP = 64 (box) / 80 (class, c = 80) /
-// 96 (class, any other c):
-// w3 / b3 = the 3x3 conv packed by upa_pack_conv_weight as c -> CP (BN folded, zero filters / biases appended up to CP);
-// wt = the 1x1 conv as upa_pack_tail_weight(cout = CP, cin = CP) of the zero-padded matrix, bt = its CP biases.
-extern "C" int upa_detect_branch_tail(const void* x, int n, int h, int w, int c, int ldx, const void* w3_packed, const float* b3,
-                                      const void* wt_packed, const float* bt, int kind, int nc, float stride_px, float* y,
-                                      int a_total, int a0, unsigned long long* best_keys, int dtype, const upa_opts* opts,
-                                      void* stream) {
+namespace {
+// Fills p for one Detect branch tail and picks its workgroup size / tile; UPA_EUNSUPPORTED outside the fused form.
+int branch_tail_prepare(BigParams& p, int& ntb, int& bm, size_t& lds, const void* x, int n, int h, int w, int c, int ldx,
+                        const void* w3_packed, const float* b3, const void* wt_packed, const float* bt, int kind, int nc,
+                        float stride_px, float* y, int a_total, int a0, unsigned long long* best_keys, int dtype, const upa_opts* opts) {
   UPA_CHECK_ARG(x && w3_packed && b3 && wt_packed && bt && y, "detect_branch_tail: null pointer");
   UPA_CHECK_ARG(kind == 1 || kind == 2, "detect_branch_tail: kind must be 1 (box) or 2 (class)");
   UPA_CHECK_ARG(n > 0 && h > 0 && w > 0 && a0 >= 0 && a0 + h * w <= a_total, "detect_branch_tail: level does not fit a_total");
   const int off = UPA_OPT(opts, no_branch_tail);
-  const int ntb = kind == 1 ? 4 : (c == 80 ? 5 : 6);  // 80 class-branch channels (nc = 80 models): 5 tiles, no padded sixth
+  ntb = kind == 1 ? 4 : (c == 80 ? 5 : 6);  // 80 class-branch channels (nc = 80 models): 5 tiles, no padded sixth
   if (off || dtype != UPA_BF16 || c % 8 != 0 || ldx % 8 != 0 || h * w < 2 || w < 2 || (kind == 1 && c != 64) ||
       (kind == 2 && (c > 96 || nc > ntb * 16)) || ((uintptr_t)x % 16) != 0 || !upa_magic_exact((long)h * w - 1, w)) {
     upa_set_error("detect_branch_tail: outside the fused form (bf16; box c = 64; class c <= 96, nc <= 96)");
     return UPA_EUNSUPPORTED;
   }
-  BigParams p;
   memset(&p, 0, sizeof(p));
   p.x = (const char*)x; p.w = (const char*)w3_packed; p.bias = b3; p.tw = (const char*)wt_packed; p.tb = bt;
   p.N = n; p.H = h; p.W = w; p.Cin = c; p.ldx = ldx; p.OH = h; p.OW = w; p.Cout = ntb * 16; p.KS = 3; p.stride = 1; p.pad = 1;
@@ -528,16 +554,68 @@ extern "C" int upa_detect_branch_tail(const void* x, int n, int h, int w, int c,
   p.de.nc = nc; p.de.stride_px = stride_px;
   if (kind == 2 && best_keys && (long)a_total * nc < (1L << 31)) p.de.best_keys = best_keys;
   const long px = (long)n * h * w;
-  int bm = (px + 255) / 256 < big_num_cu() ? 128 : 256;  // 128-pixel workgroups (one m-tile per wave) on the small levels
+  bm = (px + 255) / 256 < big_num_cu() ? 128 : 256;  // 128-pixel workgroups (one m-tile per wave) on the small levels
   if (const int f = UPA_OPT(opts, branch_tail_bm); f == 128 || f == 256) bm = f;
   if (!big_pick_tile(p, bm, ntb, 80 * 1024 - 512) && !big_pick_tile(p, bm, ntb, 160 * 1024)) return UPA_EUNSUPPORTED;
   p.tilesX = cdiv(p.OW, p.TW);
   p.tilesY = cdiv(p.OH, p.TH);
-  const size_t lds = big_halo_bytes(p) + 2 * (size_t)(2 * ntb * 1024) + 256;
-  hipStream_t s = (hipStream_t)stream;
+  lds = big_halo_bytes(p) + 2 * (size_t)(2 * ntb * 1024) + 256;
+  return UPA_OK;
+}
+int branch_tail_launch(const BigParams& p, int kind, int ntb, int bm, size_t lds, hipStream_t s) {
   if (kind == 1) return bm == 256 ? big_launch_inst<3, 1, 8, 1, 2, 4, 1>(p, lds, s) : big_launch_inst<3, 1, 8, 1, 1, 4, 1>(p, lds, s);
   if (ntb == 5) return bm == 256 ? big_launch_inst<3, 1, 8, 1, 2, 5, 2>(p, lds, s) : big_launch_inst<3, 1, 8, 1, 1, 5, 2>(p, lds, s);
   return bm == 256 ? big_launch_inst<3, 1, 8, 1, 2, 6, 2>(p, lds, s) : big_launch_inst<3, 1, 8, 1, 1, 6, 2>(p, lds, s);
+}
+}  // namespace
+
+// Second 3x3 conv of a Detect branch + the final 1x1 conv + that branch's half of the decode in ONE launch (bf16).
+// x: (n, h, w, c) NHWC view, c = 64 (box branch, kind 1) or <= 96 (class branch, kind 2).  With CP = 64 (box) / 80 (class, c = 80) /
+// 96 (class, any other c):
+// w3 / b3 = the 3x3 conv packed by upa_pack_conv_weight as c -> CP (BN folded, zero filters / biases appended up to CP);
+// wt = the 1x1 conv as upa_pack_tail_weight(cout = CP, cin = CP) of the zero-padded matrix, bt = its CP biases.
+extern "C" int upa_detect_branch_tail(const void* x, int n, int h, int w, int c, int ldx, const void* w3_packed, const float* b3,
+                                      const void* wt_packed, const float* bt, int kind, int nc, float stride_px, float* y,
+                                      int a_total, int a0, unsigned long long* best_keys, int dtype, const upa_opts* opts,
+                                      void* stream) {
+  BigParams p;
+  int ntb = 0, bm = 0;
+  size_t lds = 0;
+  if (const int rc = branch_tail_prepare(p, ntb, bm, lds, x, n, h, w, c, ldx, w3_packed, b3, wt_packed, bt, kind, nc, stride_px, y,
+                                         a_total, a0, best_keys, dtype, opts); rc != UPA_OK)
+    return rc;
+  return branch_tail_launch(p, kind, ntb, bm, lds, (hipStream_t)stream);
+}
+
+// The same for several levels of one Detect head (same kind): levels whose problems land on the same kernel instantiation are
+// launched TWO PER GRID (conv_big_pair_kernel) - the 40 x 40 and 20 x 20 levels at batch 32 are 400 + 100 workgroups of the 128-pixel
+// variant, one partial round together instead of two launches.  Results are identical to per-level calls.  Any level outside the
+// fused form -> UPA_EUNSUPPORTED with nothing launched.
+extern "C" int upa_detect_branch_tail_group(const upa_branch_level* levels, int count, int kind, int nc, float* y, int a_total,
+                                            unsigned long long* best_keys, int dtype, const upa_opts* opts, void* stream) {
+  UPA_CHECK_ARG(levels && count >= 1 && count <= 8, "detect_branch_tail_group: 1..8 levels");
+  BigParams ps[8];
+  int ntb[8], bm[8];
+  size_t lds[8];
+  for (int i = 0; i < count; ++i) {
+    const upa_branch_level& v = levels[i];
+    if (const int rc = branch_tail_prepare(ps[i], ntb[i], bm[i], lds[i], v.x, v.n, v.h, v.w, v.c, v.ldx, v.w3_packed, v.b3, v.wt_packed,
+                                           v.bt, kind, nc, v.stride_px, y, a_total, v.a0, best_keys, dtype, opts); rc != UPA_OK)
+      return rc;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  for (int i = 0; i < count;) {
+    if (i + 1 < count && ntb[i] == ntb[i + 1] && bm[i] == 128 && bm[i + 1] == 128 && ntb[i] != 6 && !UPA_OPT(opts, no_group)) {
+      const size_t l2 = lds[i] > lds[i + 1] ? lds[i] : lds[i + 1];
+      const int rc = kind == 1 ? big_launch_pair_inst<3, 1, 8, 1, 1, 4, 1>(ps[i], ps[i + 1], l2, s)
+                               : big_launch_pair_inst<3, 1, 8, 1, 1, 5, 2>(ps[i], ps[i + 1], l2, s);
+      if (rc == UPA_OK) { i += 2; continue; }
+      if (rc != UPA_EUNSUPPORTED) return rc;
+    }
+    if (const int rc = branch_tail_launch(ps[i], kind, ntb[i], bm[i], lds[i], s); rc != UPA_OK) return rc;
+    ++i;
+  }
+  return UPA_OK;
 }
 
 bool upa_conv_big_eligible(int n, int h, int w, int cin, int ldx, int cout, int ldy, int ldr, int k, int stride, int pad,
@@ -574,21 +652,22 @@ bool upa_conv_big_eligible(int n, int h, int w, int cin, int ldx, int cout, int 
   return false;
 }
 
-int upa_conv_big_launch(BigParams p, int query_only, int* variant, void* stream, const upa_opts* opts) {
+namespace {
+// Workgroup shape, tile and LDS of one conv_big problem (p.KTT / NTn filled in here).
+int big_prepare(BigParams& p, int& ntb, int& bm, size_t& lds, const upa_opts* opts, bool query_only) {
   p.KTT = (p.Cin + 31) / 32;
   p.NTn = (p.Cout + 15) / 16;
   // workgroup columns: 128 channels, 96 for Cout in (64, 96], 64 for Cout <= 64 - and 64 for wider layers whose 128-pixel x
   // 128-channel workgroups would still be fewer than the CUs (20x20 maps: twice the workgroups, each with half the weights)
-  int ntb = p.NTn <= 4 ? 4 : (p.NTn <= 6 ? 6 : 8);
+  ntb = p.NTn <= 4 ? 4 : (p.NTn <= 6 ? 6 : 8);
   if (p.NTn == 5 && p.KS == 3 && p.stride == 1) ntb = 5;  // 80 output channels (Detect class branch): 8 x 1 waves x 5 tiles
   const long px = (long)p.N * p.OH * p.OW;
   if (ntb == 8 && p.NTn % 4 == 0 && (px + 127) / 128 * cdiv(p.NTn, 8) < big_num_cu()) ntb = 4;
   const int cols = cdiv(p.NTn, ntb);
   // 256-pixel workgroups unless that leaves most of the chip idle (fewer workgroups than CUs): then 128-pixel ones
-  int bm = 256;
+  bm = 256;
   if ((px + 255) / 256 * cols < big_num_cu()) bm = 128;
   if (const int f = UPA_OPT(opts, conv_big_bm); f == 128 || f == 256 || (f == 512 && p.KS == 3 && p.stride == 1 && (ntb == 4 || ntb == 5))) bm = f;
-  if (variant) *variant = (1 << 23) | (ntb << 4) | (bm >> 7);  // (bm >> 7: 1 = 128, 2 = 256, 4 = 512 pixels)
   if (query_only) return UPA_OK;
   if (p.KS == 1) {  // pointwise: an NHWC view has one uniform pixel stride - flatten (n, h, w) into one row
     p.N = 1; p.H = 1; p.W = (int)px; p.OH = 1; p.OW = (int)px;
@@ -600,12 +679,42 @@ int upa_conv_big_launch(BigParams p, int query_only, int* variant, void* stream,
   }
   p.tilesX = cdiv(p.OW, p.TW);
   p.tilesY = cdiv(p.OH, p.TH);
-  const size_t lds = big_halo_bytes(p) + 2 * (size_t)(2 * ntb * 1024) + 256;
+  lds = big_halo_bytes(p) + 2 * (size_t)(2 * ntb * 1024) + 256;
   if (lds > 160 * 1024) return UPA_EUNSUPPORTED;
-  hipStream_t s = (hipStream_t)stream;
+  return UPA_OK;
+}
+int big_dispatch(const BigParams& p, int ntb, int bm, size_t lds, hipStream_t s) {
   if (bm == 512) return ntb == 5 ? big_launch_inst<3, 1, 8, 1, 4, 5>(p, lds, s) : big_launch_inst<3, 1, 8, 1, 4, 4>(p, lds, s);
   if (ntb == 5) return bm == 256 ? big_launch_inst<3, 1, 8, 1, 2, 5>(p, lds, s) : big_launch_inst<3, 1, 8, 1, 1, 5>(p, lds, s);
   if (ntb == 8) return bm == 256 ? big_launch_ks<4, 2, 4, 4>(p, lds, s) : big_launch_ks<4, 2, 2, 4>(p, lds, s);
   if (ntb == 6) return bm == 256 ? big_launch_ks<4, 2, 4, 3>(p, lds, s) : big_launch_ks<4, 2, 2, 3>(p, lds, s);
   return bm == 256 ? big_launch_ks<8, 1, 2, 4>(p, lds, s) : big_launch_ks<4, 2, 2, 2>(p, lds, s);
+}
+}  // namespace
+
+int upa_conv_big_launch(BigParams p, int query_only, int* variant, void* stream, const upa_opts* opts) {
+  int ntb = 0, bm = 0;
+  size_t lds = 0;
+  const int rc = big_prepare(p, ntb, bm, lds, opts, query_only != 0);
+  if (variant) *variant = (1 << 23) | (ntb << 4) | (bm >> 7);  // (bm >> 7: 1 = 128, 2 = 256, 4 = 512 pixels)
+  if (query_only || rc != UPA_OK) return rc;
+  return big_dispatch(p, ntb, bm, lds, (hipStream_t)stream);
+}
+
+// Two conv_big problems: one grid when they land on the same 128-pixel 3x3 stride-1 instantiation (see conv_big_pair_kernel), else
+// two launches.  Returns UPA_EUNSUPPORTED (nothing launched) if either problem cannot run on conv_big at all.
+int upa_conv_big_launch_pair(BigParams p0, BigParams p1, void* stream, const upa_opts* opts) {
+  int ntb0 = 0, bm0 = 0, ntb1 = 0, bm1 = 0;
+  size_t lds0 = 0, lds1 = 0;
+  if (const int rc = big_prepare(p0, ntb0, bm0, lds0, opts, false); rc != UPA_OK) return rc;
+  if (const int rc = big_prepare(p1, ntb1, bm1, lds1, opts, false); rc != UPA_OK) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (ntb0 == ntb1 && bm0 == 128 && bm1 == 128 && p0.KS == 3 && p1.KS == 3 && p0.stride == 1 && p1.stride == 1 && (ntb0 == 4 || ntb0 == 5) &&
+      !UPA_OPT(opts, no_group)) {
+    const size_t l2 = lds0 > lds1 ? lds0 : lds1;
+    const int rc = ntb0 == 4 ? big_launch_pair_inst<3, 1, 4, 2, 2, 2>(p0, p1, l2, s) : big_launch_pair_inst<3, 1, 8, 1, 1, 5>(p0, p1, l2, s);
+    if (rc != UPA_EUNSUPPORTED) return rc;
+  }
+  if (const int rc = big_dispatch(p0, ntb0, bm0, lds0, s); rc != UPA_OK) return rc;
+  return big_dispatch(p1, ntb1, bm1, lds1, s);
 }

@@ -105,15 +105,15 @@ class Detect(nn.Module, _HipConvMixin):
             return
         self._tail_call(seq[1](t), seq[2], raw, kind, i, plan)
 
-    def _branch_tail(self, t: torch.Tensor, mid, conv: nn.Conv2d, kind: int, i: int, plan) -> bool:
-        """[conv3x3 + SiLU + 1x1 + decode] in one launch; False when the branch is outside the fused form."""
+    def _branch_tail_args(self, t: torch.Tensor, mid, conv: nn.Conv2d, kind: int):
+        """(view of t, packed 3x3, packed 1x1 tail, its bias) for `upa_detect_branch_tail`, or None outside the fused form."""
         c = mid.conv.in_channels
         cp = 64 if kind == 1 else (80 if c == 80 else 96)  # padded channel count of the fused form (upa_detect_branch_tail)
         if not (isinstance(mid, Conv) and isinstance(mid.act, nn.SiLU) and mid.conv.kernel_size == (3, 3) and mid.conv.stride == (1, 1)
                 and mid.conv.padding == (1, 1) and mid.conv.groups == 1 and mid.conv.out_channels == c == conv.in_channels
                 and t.dtype == torch.bfloat16 and conv.kernel_size == (1, 1)
                 and (c == 64 if kind == 1 else (c <= 96 and c % 8 == 0 and self.nc <= 96))):
-            return False
+            return None
         pk3 = self._packed(mid.conv, mid.bn, t.device, t.dtype, False, pad_cout=cp)
         cache = self.__dict__.setdefault("_pk_cache", {})
         key = (id(conv), str(t.device), "tail", cp)
@@ -130,7 +130,14 @@ class Detect(nn.Module, _HipConvMixin):
             hit = (ver, (host.to(t.device), b.to(t.device)))
             cache[key] = hit
         wt, bt = hit[1]
-        vt = R.view_of(t)
+        return R.view_of(t), pk3, wt, bt
+
+    def _branch_tail(self, t: torch.Tensor, mid, conv: nn.Conv2d, kind: int, i: int, plan) -> bool:
+        """[conv3x3 + SiLU + 1x1 + decode] in one launch; False when the branch is outside the fused form."""
+        args = self._branch_tail_args(t, mid, conv, kind)
+        if args is None:
+            return False
+        vt, pk3, wt, bt = args
         hot = plan.get("hot") if kind == 2 else None
         rc = L.lib().upa_detect_branch_tail(vt.ptr, vt.n, vt.h, vt.w, vt.c, vt.ld, pk3.w.data_ptr(), pk3.bias.data_ptr(),
                                             wt.data_ptr(), bt.data_ptr(), kind, self.nc, float(self.stride[i]),
@@ -142,6 +149,62 @@ class Detect(nn.Module, _HipConvMixin):
         L.check(rc, "detect_branch_tail")
         if hot is not None:
             plan["hot_levels"].add(i)
+        return True
+
+    # ---- several levels per launch (linear graphs: the levels run one after the other on one stream anyway) ---------------------
+    # The 40 x 40 and 20 x 20 levels' launches are 400 and 100 workgroups at batch 32 - a fraction of a round each, mostly launch
+    # ramp and halo latency.  `upa_conv2d_bias_act_group` / `upa_detect_branch_tail_group` put problems that use the same kernel
+    # instantiation into ONE grid, so the smaller level rides inside the larger one's partial round: 4 launches fewer per step.
+    group_levels = True
+
+    def _levels_grouped(self, idx, xs, plan) -> bool:
+        """Both branches of the levels `idx` (inputs `xs`, NHWC) through the group entry points; False (nothing launched) when a
+        level is outside the fused forms."""
+        import ctypes as C
+        lib = L.lib()
+        dev = xs[0].device
+        stream = L.current_stream(dev)
+        todo = []
+        for kind, seqs in ((1, self.cv2), (2, self.cv3)):  # check everything before the first launch
+            for i in idx:
+                c0 = seqs[i][0]
+                if not (isinstance(c0, Conv) and not c0.training and c0.conv.kernel_size == (3, 3) and c0.conv.stride == (1, 1)
+                        and c0.conv.padding == (1, 1) and c0.conv.groups == 1 and isinstance(c0.act, nn.SiLU) and hasattr(c0, "bn")):
+                    return False
+            todo.append((kind, seqs))
+        for kind, seqs in todo:
+            probs = (L.ConvProblem * len(idx))()
+            mids = []
+            for j, i in enumerate(idx):
+                c0, x = seqs[i][0], xs[j]
+                pk = c0._packed(c0.conv, c0.bn, dev, x.dtype, False)
+                vx = R.view_of(x)
+                t = R.alloc_nhwc(vx.n, pk.cout, vx.h, vx.w, x.dtype, dev, key=(id(c0), "y"))
+                vy = R.view_of(t)
+                probs[j] = L.ConvProblem(vx.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, pk.w.data_ptr(), pk.bias.data_ptr(), vy.ptr, pk.cout, vy.ld,
+                                         None, 0)
+                mids.append(t)
+            L.check(lib.upa_conv2d_bias_act_group(C.cast(probs, C.c_void_p), len(idx), 3, 1, 1, L.ACT_SILU, L.dtype_code(xs[0].dtype),
+                                                  R.opts_ptr(), stream), "conv2d_group")
+            args = [self._branch_tail_args(t, seqs[i][1], seqs[i][2], kind) for t, i in zip(mids, idx)]
+            hot = plan.get("hot") if kind == 2 else None
+            rc = L.UPA_EUNSUPPORTED
+            if all(a is not None for a in args):
+                lv = (L.BranchLevel * len(idx))()
+                for j, (i, (vt, pk3, wt, bt)) in enumerate(zip(idx, args)):
+                    lv[j] = L.BranchLevel(vt.ptr, vt.n, vt.h, vt.w, vt.c, vt.ld, pk3.w.data_ptr(), pk3.bias.data_ptr(), wt.data_ptr(),
+                                          bt.data_ptr(), float(self.stride[i]), plan["a0"][i])
+                rc = lib.upa_detect_branch_tail_group(C.cast(lv, C.c_void_p), len(idx), kind, self.nc, plan["y"].data_ptr(),
+                                                      plan["a_total"], hot.data_ptr() if hot is not None else None,
+                                                      L.dtype_code(xs[0].dtype), R.opts_ptr(), stream)
+            if rc == L.UPA_EUNSUPPORTED:  # a level outside the branch-tail form: its second half level by level
+                for t, i in zip(mids, idx):
+                    if not self._branch_tail(t, seqs[i][1], seqs[i][2], kind, i, plan):
+                        self._tail_call(seqs[i][1](t), seqs[i][2], None, kind, i, plan)
+            else:
+                L.check(rc, "detect_branch_tail_group")
+                if hot is not None:
+                    plan["hot_levels"].update(idx)
         return True
 
     def _tail_call(self, t: torch.Tensor, conv: nn.Conv2d, raw, kind: int, i: int, plan) -> None:
@@ -193,9 +256,10 @@ class Detect(nn.Module, _HipConvMixin):
     def _pend(self):
         return self.__dict__.setdefault("_pending", {}).setdefault(R.current_tag(), {})
 
-    def start_level(self, i: int, x: torch.Tensor) -> None:
+    def start_level(self, i: int, x: torch.Tensor, defer_ok: bool = True) -> None:
         """Launch level i's two branches (asynchronously when `concurrent`); results land in the level's raw buffer and /
-        or, with the fused decode, directly in the decoded output."""
+        or, with the fused decode, directly in the decoded output.  On one stream (linear graphs) the levels after the first are left
+        to `forward`, which runs them several per launch (`_levels_grouped`)."""
         pend = self._pend()
         x = R.to_nhwc(x, x.dtype)
         nb = 4 * self.reg_max
@@ -218,9 +282,12 @@ class Detect(nn.Module, _HipConvMixin):
             else:
                 self._branch(seq, x, outs[k])
 
+        linear = not self.concurrent or R.current_tag() != 0
+        if defer_ok and linear and i >= 1 and fused and self.group_levels and self.fuse_branch and not self.keep_raw:
+            return  # `forward` picks it up (grouped with the other small levels)
         if fused:
             plan["decoded"].add(i)
-        if not self.concurrent or R.current_tag() != 0:
+        if linear:
             # inside a concurrently scheduled sub-batch (BaseModel.compile(micro_batches>1)) the branches stay on the
             # sub-batch's stream: the sub-batches already overlap each other, and nesting a second level of event
             # forks inside a forked capture stream crashed hipStreamEndCapture on ROCm 7.2 (segfault, not an error code)
@@ -249,9 +316,20 @@ class Detect(nn.Module, _HipConvMixin):
         pend = self._pend()
         if not pend:  # called directly (not through BaseModel._predict_once): the level shapes come with the inputs
             self.begin(x[0].shape[0], [(t.shape[2], t.shape[3]) for t in x], x[0].dtype, x[0].device)
+        rest = [i for i in range(self.nl) if i not in pend]
+        plan = self._plan().get(R.current_tag())
+        linear = not self.concurrent or R.current_tag() != 0
+        grp = [i for i in rest if i >= 1]
+        if (len(grp) >= 2 and linear and self.group_levels and self.fuse_branch and not self.keep_raw and plan is not None and plan["fused"]
+                and all(x[i].dtype == torch.bfloat16 and plan["n"] == x[i].shape[0] and plan["hw"][i] == tuple(x[i].shape[2:])
+                        and plan["y"].device == x[i].device for i in grp)):
+            if self._levels_grouped(grp, [R.to_nhwc(x[i], x[i].dtype) for i in grp], plan):
+                for i in grp:
+                    plan["decoded"].add(i)
+                    pend[i] = (None, [])
         for i in range(self.nl):
             if i not in pend:
-                self.start_level(i, x[i])
+                self.start_level(i, x[i], defer_ok=False)
         main = torch.cuda.current_stream(x[0].device)
         raw = []
         for i in range(self.nl):
