@@ -59,7 +59,7 @@ typedef struct upa_opts {
   int32_t ablate_conv, ablate_pipe, ablate_c1, ablate_stem;  /* kernel ablation bit masks: honoured by the -DUPA_ABLATE build only (make ablate) */
   int32_t c2f64_max_px;    /* upa_c2f64_fused only up to this many pixels n * h * w (0 = 100000: the 40 x 40 maps at batch 32; -1 = any size) */
   int32_t conv_ws3;        /* csrc/conv_ws3.hip (persistent 3x3 with register-resident weights, Cin <= 64, Cout 64): 0 = by the size rule, 1 = never, 2 = every shape it can run, 3 = the rule restricted to maps of < 100000 pixels (at most one tile per workgroup) */
-  int32_t no_group;        /* upa_conv2d_bias_act_group / upa_detect_branch_tail_group: 1 = one launch per problem (A/B) */
+  int32_t no_group;        /* upa_conv2d_bias_act_group / upa_detect_branch_tail_group: 0 = two problems per grid where the instantiations allow, 1 = one launch per problem, 2 = three per grid too (measured slower; A/B) */
 } upa_opts;
 
 /* Library / device info. Returns the ABI version (int); fills name with the kernel target ("gfx950"). */

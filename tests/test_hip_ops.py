@@ -1049,8 +1049,8 @@ def test_linear_f32_rows(case):
 def test_grouped_launches_equal_single_launches():
     """`upa_conv2d_bias_act_group` / `upa_detect_branch_tail_group`: several independent problems in one call - neighbours on the same
     128-pixel conv_big instantiation share ONE grid (conv_big_pair_kernel) - must give bit-identical results to one call per problem:
-    the Detect head's first convs and branch tails of a 40 x 40 and a 20 x 20 level (+ an 80 x 80 level that takes the 256-pixel
-    variant and is launched alone), box and class kinds, with `no_group` as the A/B switch."""
+    the Detect head's first convs and branch tails of an 80 x 80, a 40 x 40 and a 20 x 20 level, box and class kinds: pairs (the default: the large level alone on its 256-pixel variant), all three in one grid (`no_group` = 2:
+    the large level on the 128-pixel variant) and one launch per level (`no_group` = 1)."""
     import ctypes as C
     from tests.hip_utils import DEV, bf16_round, to_dev_nhwc, unit_input
     from ultralytics_pro_amd import _lib as L
@@ -1067,7 +1067,8 @@ def test_grouped_launches_equal_single_launches():
             pk = PackedConv(wgt, unit_input(f"grp_b{kind}{li}", (cmid,), -0.5, 0.5), 3, DEV, torch.bfloat16, False)
             xs.append(x); pks.append(pk)
             outs_g.append(R.alloc_nhwc(n, cmid, h, w, torch.bfloat16, DEV)); outs_s.append(R.alloc_nhwc(n, cmid, h, w, torch.bfloat16, DEV))
-        for outs, opts in ((outs_g, None), (outs_s, L.Opts(no_group=1))):
+        outs_p = [R.alloc_nhwc(n, cmid, h, w, torch.bfloat16, DEV) for (h, w, _) in levels]
+        for outs, opts in ((outs_g, None), (outs_s, L.Opts(no_group=1)), (outs_p, L.Opts(no_group=2))):
             probs = (L.ConvProblem * 3)()
             for j in range(3):
                 vx, vy = R.view_of(xs[j]), R.view_of(outs[j])
@@ -1075,13 +1076,13 @@ def test_grouped_launches_equal_single_launches():
             L.check(lib.upa_conv2d_bias_act_group(C.cast(probs, C.c_void_p), 3, 3, 1, 1, L.ACT_SILU, L.UPA_BF16,
                                                   C.pointer(opts) if opts is not None else None, st), "conv2d_group")
         torch.cuda.synchronize()
-        for a, b in zip(outs_g, outs_s):
-            assert torch.equal(a, b)
+        for a, b, c in zip(outs_g, outs_s, outs_p):
+            assert torch.equal(a, b) and torch.equal(a, c)
         # the branch tails on those mid tensors
         cp = 64 if kind == 1 else 80
         a0s, tot = [0, 6400, 8000], 8400
-        ys = [torch.full((n, 4 + nc, tot), -7.0, device=DEV) for _ in range(2)]
-        keys = [torch.full((n, tot), -1, dtype=torch.int64, device=DEV) for _ in range(2)]
+        ys = [torch.full((n, 4 + nc, tot), -7.0, device=DEV) for _ in range(3)]
+        keys = [torch.full((n, tot), -1, dtype=torch.int64, device=DEV) for _ in range(3)]
         packed = []
         for li, (h, w, _) in enumerate(levels):
             w3 = bf16_round(unit_input(f"grp_w3{kind}{li}", (cp, cmid, 3, 3), -0.1, 0.1))
@@ -1091,7 +1092,7 @@ def test_grouped_launches_equal_single_launches():
             host = torch.empty(lib.upa_tail_packed_weight_bytes(cp, cp), dtype=torch.uint8)
             L.check(lib.upa_pack_tail_weight(wt.data_ptr(), cp, cp, host.data_ptr()), "pack_tail_weight")
             packed.append((pk3, host.to(DEV), bt.to(DEV)))
-        for which, opts in ((0, None), (1, L.Opts(no_group=1))):
+        for which, opts in ((0, None), (1, L.Opts(no_group=1)), (2, L.Opts(no_group=2))):
             lv = (L.BranchLevel * 3)()
             for j, (h, w, _) in enumerate(levels):
                 vt = R.view_of(outs_g[j])
@@ -1102,7 +1103,7 @@ def test_grouped_launches_equal_single_launches():
                                                      keys[which].data_ptr() if kind == 2 else None, L.UPA_BF16,
                                                      C.pointer(opts) if opts is not None else None, st), "branch_tail_group")
         torch.cuda.synchronize()
-        assert torch.equal(ys[0], ys[1]) and torch.equal(keys[0], keys[1])
+        assert torch.equal(ys[0], ys[1]) and torch.equal(keys[0], keys[1]) and torch.equal(ys[0], ys[2]) and torch.equal(keys[0], keys[2])
         rows = slice(0, 4) if kind == 1 else slice(4, 4 + nc)
         assert int((ys[0][:, rows] == -7.0).sum()) == 0  # every anchor of the three levels was written
 

@@ -973,8 +973,13 @@ extern "C" int upa_conv2d_bias_act_group(const upa_conv_problem* probs, int coun
   };
   for (int i = 0; i < count;) {
     if (i + 1 < count && k == 3 && stride == 1 && big_ok(probs[i]) && big_ok(probs[i + 1])) {
-      const int rc = upa_conv_big_launch_pair(fill(probs[i]), fill(probs[i + 1]), stream, opts);
-      if (rc == UPA_OK) { i += 2; continue; }
+      BigParams b[3];
+      int m = 2;
+      b[0] = fill(probs[i]); b[1] = fill(probs[i + 1]);
+      if (i + 2 < count && big_ok(probs[i + 2])) { b[2] = fill(probs[i + 2]); m = 3; }
+      int consumed = 0;
+      const int rc = upa_conv_big_launch_group(b, m, &consumed, stream, opts);
+      if (rc == UPA_OK && consumed > 0) { i += consumed; continue; }
       if (rc != UPA_EUNSUPPORTED) return rc;
     }
     const upa_conv_problem& q = probs[i];

@@ -371,6 +371,15 @@ __global__ __launch_bounds__(512, 4) void conv_big_pair_kernel(const BigParams p
   if ((int)blockIdx.x < split) conv_big_body<KS, STRIDE, WM, WN, MT, NT, TAIL>(p0, (int)blockIdx.x);
   else conv_big_body<KS, STRIDE, WM, WN, MT, NT, TAIL>(p1, (int)blockIdx.x - split);
 }
+// ... and three (all three levels of a Detect head: the 80 x 80 level on the 128-pixel variant too, the two small levels fill the
+// last round of the large one).
+template <int KS, int STRIDE, int WM, int WN, int MT, int NT, int TAIL = 0>
+__global__ __launch_bounds__(512, 4) void conv_big_tri_kernel(const BigParams p0, const BigParams p1, const BigParams p2, const int s0,
+                                                              const int s1) {
+  if ((int)blockIdx.x < s0) conv_big_body<KS, STRIDE, WM, WN, MT, NT, TAIL>(p0, (int)blockIdx.x);
+  else if ((int)blockIdx.x < s1) conv_big_body<KS, STRIDE, WM, WN, MT, NT, TAIL>(p1, (int)blockIdx.x - s0);
+  else conv_big_body<KS, STRIDE, WM, WN, MT, NT, TAIL>(p2, (int)blockIdx.x - s1);
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
@@ -483,6 +492,21 @@ int big_launch_pair_inst(const BigParams& p0, const BigParams& p1, size_t lds, h
     return UPA_ELAUNCH;
   }
   hipLaunchKernelGGL((conv_big_pair_kernel<KS, STRIDE, WM, WN, MT, NT, TAIL>), grid, dim3(512), lds, s, p0, p1, (int)t0);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+template <int KS, int STRIDE, int WM, int WN, int MT, int NT, int TAIL = 0>
+int big_launch_tri_inst(const BigParams& p0, const BigParams& p1, const BigParams& p2, size_t lds, hipStream_t s) {
+  constexpr int NTB = WN * NT;
+  const long t0 = (long)p0.tilesX * p0.tilesY * p0.N, t1 = (long)p1.tilesX * p1.tilesY * p1.N, t2 = (long)p2.tilesX * p2.tilesY * p2.N;
+  if (cdiv(p0.NTn, NTB) != cdiv(p1.NTn, NTB) || cdiv(p0.NTn, NTB) != cdiv(p2.NTn, NTB) || t0 + t1 + t2 >= (1L << 31)) return UPA_EUNSUPPORTED;
+  const dim3 grid((unsigned)(t0 + t1 + t2), (unsigned)cdiv(p0.NTn, NTB));
+  if (hipError_t e = upa_full_lds<conv_big_tri_kernel<KS, STRIDE, WM, WN, MT, NT, TAIL>>(); e != hipSuccess) {
+    upa_set_error("conv_big: cannot raise LDS limit: %s", hipGetErrorString(e));
+    return UPA_ELAUNCH;
+  }
+  hipLaunchKernelGGL((conv_big_tri_kernel<KS, STRIDE, WM, WN, MT, NT, TAIL>), grid, dim3(512), lds, s, p0, p1, p2, (int)t0, (int)(t0 + t1));
   UPA_LAUNCH_CHECK();
   return UPA_OK;
 }
@@ -604,8 +628,37 @@ extern "C" int upa_detect_branch_tail_group(const upa_branch_level* levels, int 
       return rc;
   }
   hipStream_t s = (hipStream_t)stream;
+  // upa_opts.no_group: 0 = pairs (the default), 1 = one launch per level, 2 = threes too.  Three levels per grid measured SLOWER than
+  // a pair + the 80 x 80 level alone (four steps in flight 50.2 k vs 51.5 k images/s, serial step equal): the large level loses more on
+  // the 128-pixel variant than the ride saves.
+  const int grouping = UPA_OPT(opts, no_group);
+  auto max3 = [](size_t a, size_t b, size_t c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); };
   for (int i = 0; i < count;) {
-    if (i + 1 < count && ntb[i] == ntb[i + 1] && bm[i] == 128 && bm[i + 1] == 128 && ntb[i] != 6 && !UPA_OPT(opts, no_group)) {
+    if (grouping == 2 && i + 2 < count && ntb[i] == ntb[i + 1] && ntb[i] == ntb[i + 2] && ntb[i] != 6 && bm[i + 1] == 128 && bm[i + 2] == 128) {
+      // a large first level joins on the 128-pixel variant
+      BigParams p0 = ps[i];
+      int ntb0 = ntb[i], bm0 = bm[i];
+      size_t lds0 = lds[i];
+      int rc = UPA_OK;
+      if (bm0 != 128) {
+        upa_opts o;
+        memset(&o, 0, sizeof(o));
+        if (opts) memcpy(&o, opts, opts->size < sizeof(o) ? opts->size : sizeof(o));
+        o.size = sizeof(o);
+        o.branch_tail_bm = 128;
+        const upa_branch_level& v = levels[i];
+        rc = branch_tail_prepare(p0, ntb0, bm0, lds0, v.x, v.n, v.h, v.w, v.c, v.ldx, v.w3_packed, v.b3, v.wt_packed, v.bt, kind, nc,
+                                 v.stride_px, y, a_total, v.a0, best_keys, dtype, &o);
+      }
+      if (rc == UPA_OK && bm0 == 128) {
+        const size_t l3 = max3(lds0, lds[i + 1], lds[i + 2]);
+        rc = kind == 1 ? big_launch_tri_inst<3, 1, 8, 1, 1, 4, 1>(p0, ps[i + 1], ps[i + 2], l3, s)
+                       : big_launch_tri_inst<3, 1, 8, 1, 1, 5, 2>(p0, ps[i + 1], ps[i + 2], l3, s);
+        if (rc == UPA_OK) { i += 3; continue; }
+        if (rc != UPA_EUNSUPPORTED) return rc;
+      }
+    }
+    if (grouping != 1 && i + 1 < count && ntb[i] == ntb[i + 1] && bm[i] == 128 && bm[i + 1] == 128 && ntb[i] != 6) {
       const size_t l2 = lds[i] > lds[i + 1] ? lds[i] : lds[i + 1];
       const int rc = kind == 1 ? big_launch_pair_inst<3, 1, 8, 1, 1, 4, 1>(ps[i], ps[i + 1], l2, s)
                                : big_launch_pair_inst<3, 1, 8, 1, 1, 5, 2>(ps[i], ps[i + 1], l2, s);
@@ -701,20 +754,51 @@ int upa_conv_big_launch(BigParams p, int query_only, int* variant, void* stream,
   return big_dispatch(p, ntb, bm, lds, (hipStream_t)stream);
 }
 
-// Two conv_big problems: one grid when they land on the same 128-pixel 3x3 stride-1 instantiation (see conv_big_pair_kernel), else
-// two launches.  Returns UPA_EUNSUPPORTED (nothing launched) if either problem cannot run on conv_big at all.
-int upa_conv_big_launch_pair(BigParams p0, BigParams p1, void* stream, const upa_opts* opts) {
-  int ntb0 = 0, bm0 = 0, ntb1 = 0, bm1 = 0;
-  size_t lds0 = 0, lds1 = 0;
-  if (const int rc = big_prepare(p0, ntb0, bm0, lds0, opts, false); rc != UPA_OK) return rc;
-  if (const int rc = big_prepare(p1, ntb1, bm1, lds1, opts, false); rc != UPA_OK) return rc;
+// Two or three conv_big problems: one grid when they land on the same 128-pixel 3x3 stride-1 instantiation (see conv_big_pair_kernel;
+// with three, a first problem that would take 256-pixel workgroups joins on the 128-pixel variant), else one launch each.  Returns
+// UPA_EUNSUPPORTED (nothing launched) if a problem cannot run on conv_big at all.  *consumed = how many problems were launched.
+int upa_conv_big_launch_group(const BigParams* probs, int count, int* consumed, void* stream, const upa_opts* opts) {
+  *consumed = 0;
+  if (count < 2) return UPA_EUNSUPPORTED;
+  const int grouping = UPA_OPT(opts, no_group);
+  if (grouping == 1) return UPA_EUNSUPPORTED;
+  BigParams p[3];
+  int ntb[3], bm[3];
+  size_t lds[3];
+  const int m = count >= 3 && grouping == 2 ? 3 : 2;  // (threes: experiment only, see upa_detect_branch_tail_group)
+  for (int i = 0; i < m; ++i) {
+    p[i] = probs[i];
+    if (p[i].KS != 3 || p[i].stride != 1) return UPA_EUNSUPPORTED;
+    if (const int rc = big_prepare(p[i], ntb[i], bm[i], lds[i], opts, false); rc != UPA_OK) return rc;
+  }
   hipStream_t s = (hipStream_t)stream;
-  if (ntb0 == ntb1 && bm0 == 128 && bm1 == 128 && p0.KS == 3 && p1.KS == 3 && p0.stride == 1 && p1.stride == 1 && (ntb0 == 4 || ntb0 == 5) &&
-      !UPA_OPT(opts, no_group)) {
-    const size_t l2 = lds0 > lds1 ? lds0 : lds1;
-    const int rc = ntb0 == 4 ? big_launch_pair_inst<3, 1, 4, 2, 2, 2>(p0, p1, l2, s) : big_launch_pair_inst<3, 1, 8, 1, 1, 5>(p0, p1, l2, s);
+  auto ok_ntb = [](int v) { return v == 4 || v == 5; };
+  if (m == 3 && ntb[0] == ntb[1] && ntb[0] == ntb[2] && ok_ntb(ntb[0]) && bm[1] == 128 && bm[2] == 128) {
+    int rc = UPA_OK;
+    if (bm[0] != 128) {
+      upa_opts o;
+      memset(&o, 0, sizeof(o));
+      if (opts) memcpy(&o, opts, opts->size < sizeof(o) ? opts->size : sizeof(o));
+      o.size = sizeof(o);
+      o.conv_big_bm = 128;
+      p[0] = probs[0];
+      rc = big_prepare(p[0], ntb[0], bm[0], lds[0], &o, false);
+    }
+    if (rc == UPA_OK && bm[0] == 128 && ntb[0] == ntb[1]) {
+      const size_t l3 = lds[0] > lds[1] ? (lds[0] > lds[2] ? lds[0] : lds[2]) : (lds[1] > lds[2] ? lds[1] : lds[2]);
+      rc = ntb[0] == 4 ? big_launch_tri_inst<3, 1, 4, 2, 2, 2>(p[0], p[1], p[2], l3, s) : big_launch_tri_inst<3, 1, 8, 1, 1, 5>(p[0], p[1], p[2], l3, s);
+      if (rc == UPA_OK) { *consumed = 3; return UPA_OK; }
+      if (rc != UPA_EUNSUPPORTED) return rc;
+    }
+    // fall through to a pair of the first two as prepared without the override
+    p[0] = probs[0];
+    if (const int rc2 = big_prepare(p[0], ntb[0], bm[0], lds[0], opts, false); rc2 != UPA_OK) return rc2;
+  }
+  if (ntb[0] == ntb[1] && ok_ntb(ntb[0]) && bm[0] == 128 && bm[1] == 128) {
+    const size_t l2 = lds[0] > lds[1] ? lds[0] : lds[1];
+    const int rc = ntb[0] == 4 ? big_launch_pair_inst<3, 1, 4, 2, 2, 2>(p[0], p[1], l2, s) : big_launch_pair_inst<3, 1, 8, 1, 1, 5>(p[0], p[1], l2, s);
+    if (rc == UPA_OK) { *consumed = 2; return UPA_OK; }
     if (rc != UPA_EUNSUPPORTED) return rc;
   }
-  if (const int rc = big_dispatch(p0, ntb0, bm0, lds0, s); rc != UPA_OK) return rc;
-  return big_dispatch(p1, ntb1, bm1, lds1, s);
+  return UPA_EUNSUPPORTED;
 }

@@ -70,8 +70,9 @@ bool upa_conv_big_eligible(int n, int h, int w, int cin, int ldx, int cout, int 
                            int act, int dtype, const upa_opts* opts);
 // variant (if non-null) receives (1 << 23) | n-tiles per workgroup << 4 | pixels per workgroup / 128; query_only = 1 skips the launch
 int upa_conv_big_launch(BigParams p, int query_only, int* variant, void* stream, const upa_opts* opts);
-// two problems: one grid if they share a 128-pixel 3x3 stride-1 instantiation, else two launches; UPA_EUNSUPPORTED = nothing launched
-int upa_conv_big_launch_pair(BigParams p0, BigParams p1, void* stream, const upa_opts* opts);
+// the first two or three problems of a list in ONE grid if they share a 128-pixel 3x3 stride-1 instantiation (*consumed = how many);
+// UPA_EUNSUPPORTED = nothing launched (the caller launches the first problem alone and tries again from the next)
+int upa_conv_big_launch_group(const BigParams* probs, int count, int* consumed, void* stream, const upa_opts* opts);
 
 // ---- conv_ws3.hip: persistent weights-stationary 3x3 (bf16, stride 1, pad 1, Cin <= 64, Cout = 64); BigParams as conv_big
 bool upa_conv_ws3_eligible(int n, int h, int w, int cin, int ldx, int cout, int ldy, bool residual, int k, int stride, int pad,

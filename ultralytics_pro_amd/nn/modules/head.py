@@ -154,7 +154,8 @@ class Detect(nn.Module, _HipConvMixin):
     # ---- several levels per launch (linear graphs: the levels run one after the other on one stream anyway) ---------------------
     # The 40 x 40 and 20 x 20 levels' launches are 400 and 100 workgroups at batch 32 - a fraction of a round each, mostly launch
     # ramp and halo latency.  `upa_conv2d_bias_act_group` / `upa_detect_branch_tail_group` put problems that use the same kernel
-    # instantiation into ONE grid, so the smaller level rides inside the larger one's partial round: 4 launches fewer per step.
+    # instantiation into ONE grid, so the smaller level rides inside the larger one's partial round: 4 launches fewer per step.  (All
+    # three levels in one grid - the 80 x 80 level on the 128-pixel variant - measured slower: upa_opts.no_group = 2.)
     group_levels = True
 
     def _levels_grouped(self, idx, xs, plan) -> bool:
@@ -258,8 +259,8 @@ class Detect(nn.Module, _HipConvMixin):
 
     def start_level(self, i: int, x: torch.Tensor, defer_ok: bool = True) -> None:
         """Launch level i's two branches (asynchronously when `concurrent`); results land in the level's raw buffer and /
-        or, with the fused decode, directly in the decoded output.  On one stream (linear graphs) the levels after the first are left
-        to `forward`, which runs them several per launch (`_levels_grouped`)."""
+        or, with the fused decode, directly in the decoded output.  On one stream (linear graphs) the levels are left to `forward`,
+        which runs them several per launch (`_levels_grouped`)."""
         pend = self._pend()
         x = R.to_nhwc(x, x.dtype)
         nb = 4 * self.reg_max
@@ -283,7 +284,7 @@ class Detect(nn.Module, _HipConvMixin):
                 self._branch(seq, x, outs[k])
 
         linear = not self.concurrent or R.current_tag() != 0
-        if defer_ok and linear and i >= 1 and fused and self.group_levels and self.fuse_branch and not self.keep_raw:
+        if defer_ok and linear and fused and self.group_levels and self.fuse_branch and not self.keep_raw:
             return  # `forward` picks it up (grouped with the other small levels)
         if fused:
             plan["decoded"].add(i)
@@ -319,7 +320,7 @@ class Detect(nn.Module, _HipConvMixin):
         rest = [i for i in range(self.nl) if i not in pend]
         plan = self._plan().get(R.current_tag())
         linear = not self.concurrent or R.current_tag() != 0
-        grp = [i for i in rest if i >= 1]
+        grp = list(rest)
         if (len(grp) >= 2 and linear and self.group_levels and self.fuse_branch and not self.keep_raw and plan is not None and plan["fused"]
                 and all(x[i].dtype == torch.bfloat16 and plan["n"] == x[i].shape[0] and plan["hw"][i] == tuple(x[i].shape[2:])
                         and plan["y"].device == x[i].device for i in grp)):
