@@ -1058,6 +1058,23 @@ def test_grouped_launches_equal_single_launches():
     from ultralytics_pro_amd.nn.modules.conv import PackedConv
     lib, st = L.lib(), L.current_stream(DEV)
     n, nc = 16, 80
+    # a 64- and an 80-channel conv on the SAME input and workgroup size (the two first convs of a Detect level): one grid on the five-tile
+    # instantiation (the 64-channel problem's fifth n-tile multiplies zero weights and is not stored)
+    for (h, w) in ((80, 80), (40, 40)):
+        x = to_dev_nhwc(bf16_round(unit_input(f"grp2_x{h}", (n, 64, h, w), -1, 1)), torch.bfloat16)
+        pks = [PackedConv(bf16_round(unit_input(f"grp2_w{h}{c}", (c, 64, 3, 3), -0.1, 0.1)), unit_input(f"grp2_b{h}{c}", (c,), -0.5, 0.5), 3, DEV,
+                          torch.bfloat16, False) for c in (64, 80)]
+        res = {}
+        for tag, opts in (("g", L.Opts(conv_ws3=1)), ("s", L.Opts(conv_ws3=1, no_group=1))):
+            outs = [R.alloc_nhwc(n, c, h, w, torch.bfloat16, DEV) for c in (64, 80)]
+            probs = (L.ConvProblem * 2)()
+            for j, c in enumerate((64, 80)):
+                vx, vy = R.view_of(x), R.view_of(outs[j])
+                probs[j] = L.ConvProblem(vx.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, pks[j].w.data_ptr(), pks[j].bias.data_ptr(), vy.ptr, c, vy.ld, None, 0)
+            L.check(lib.upa_conv2d_bias_act_group(C.cast(probs, C.c_void_p), 2, 3, 1, 1, L.ACT_SILU, L.UPA_BF16, C.pointer(opts), st), "conv2d_group")
+            res[tag] = outs
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(res["g"], res["s"]))
     levels = [(80, 80, 64), (40, 40, 128), (20, 20, 256)]  # (h, w, cin) of the level's feature map
     for kind, cmid in ((1, 64), (2, 80)):
         xs, pks, outs_g, outs_s = [], [], [], []

@@ -707,13 +707,14 @@ bool upa_conv_big_eligible(int n, int h, int w, int cin, int ldx, int cout, int 
 
 namespace {
 // Workgroup shape, tile and LDS of one conv_big problem (p.KTT / NTn filled in here).
-int big_prepare(BigParams& p, int& ntb, int& bm, size_t& lds, const upa_opts* opts, bool query_only) {
+int big_prepare(BigParams& p, int& ntb, int& bm, size_t& lds, const upa_opts* opts, bool query_only, int force_ntb = 0) {
   p.KTT = (p.Cin + 31) / 32;
   p.NTn = (p.Cout + 15) / 16;
   // workgroup columns: 128 channels, 96 for Cout in (64, 96], 64 for Cout <= 64 - and 64 for wider layers whose 128-pixel x
   // 128-channel workgroups would still be fewer than the CUs (20x20 maps: twice the workgroups, each with half the weights)
   ntb = p.NTn <= 4 ? 4 : (p.NTn <= 6 ? 6 : 8);
   if (p.NTn == 5 && p.KS == 3 && p.stride == 1) ntb = 5;  // 80 output channels (Detect class branch): 8 x 1 waves x 5 tiles
+  if (force_ntb == 5 && p.NTn <= 5 && p.KS == 3 && p.stride == 1) ntb = 5;  // a 64-channel problem sharing a grid with an 80-channel one
   const long px = (long)p.N * p.OH * p.OW;
   if (ntb == 8 && p.NTn % 4 == 0 && (px + 127) / 128 * cdiv(p.NTn, 8) < big_num_cu()) ntb = 4;
   const int cols = cdiv(p.NTn, ntb);
@@ -794,9 +795,21 @@ int upa_conv_big_launch_group(const BigParams* probs, int count, int* consumed, 
     p[0] = probs[0];
     if (const int rc2 = big_prepare(p[0], ntb[0], bm[0], lds[0], opts, false); rc2 != UPA_OK) return rc2;
   }
-  if (ntb[0] == ntb[1] && ok_ntb(ntb[0]) && bm[0] == 128 && bm[1] == 128) {
+  // a pair: same workgroup size (128 or 256 pixels) and 64 | 80 output channels; a 64-channel problem next to an 80-channel one runs on
+  // the five-tile instantiation too (its fifth n-tile multiplies zero weights and is not stored: +25 % MFMAs on that problem, one
+  // grid instead of two - the two first convs of a Detect level read the same input)
+  if (ok_ntb(ntb[0]) && ok_ntb(ntb[1]) && bm[0] == bm[1] && (bm[0] == 128 || bm[0] == 256)) {
+    if (ntb[0] != ntb[1]) {
+      const int lo = ntb[0] < ntb[1] ? 0 : 1;
+      p[lo] = probs[lo];
+      int bmf = 0;
+      if (const int rc = big_prepare(p[lo], ntb[lo], bmf, lds[lo], opts, false, 5); rc != UPA_OK) return rc;
+      if (bmf != bm[1 - lo] || ntb[lo] != 5) return UPA_EUNSUPPORTED;
+    }
     const size_t l2 = lds[0] > lds[1] ? lds[0] : lds[1];
-    const int rc = ntb[0] == 4 ? big_launch_pair_inst<3, 1, 4, 2, 2, 2>(p[0], p[1], l2, s) : big_launch_pair_inst<3, 1, 8, 1, 1, 5>(p[0], p[1], l2, s);
+    int rc;
+    if (bm[0] == 128) rc = ntb[0] == 4 ? big_launch_pair_inst<3, 1, 4, 2, 2, 2>(p[0], p[1], l2, s) : big_launch_pair_inst<3, 1, 8, 1, 1, 5>(p[0], p[1], l2, s);
+    else rc = ntb[0] == 4 ? big_launch_pair_inst<3, 1, 8, 1, 2, 4>(p[0], p[1], l2, s) : big_launch_pair_inst<3, 1, 8, 1, 2, 5>(p[0], p[1], l2, s);
     if (rc == UPA_OK) { *consumed = 2; return UPA_OK; }
     if (rc != UPA_EUNSUPPORTED) return rc;
   }

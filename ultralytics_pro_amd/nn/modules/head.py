@@ -173,20 +173,24 @@ class Detect(nn.Module, _HipConvMixin):
                         and c0.conv.padding == (1, 1) and c0.conv.groups == 1 and isinstance(c0.act, nn.SiLU) and hasattr(c0, "bn")):
                     return False
             todo.append((kind, seqs))
+        # stage 1: the first convs of all branches in ONE group call.  Order = which neighbours may share a grid: the two branches of
+        # the first (largest) level read the same input and use the same workgroup size, then each kind's remaining levels
+        order = [(kind, seqs, idx[0]) for kind, seqs in todo] + [(kind, seqs, i) for kind, seqs in todo for i in idx[1:]]
+        probs = (L.ConvProblem * len(order))()
+        mid_of = {}
+        for j, (kind, seqs, i) in enumerate(order):
+            c0, x = seqs[i][0], xs[idx.index(i)]
+            pk = c0._packed(c0.conv, c0.bn, dev, x.dtype, False)
+            vx = R.view_of(x)
+            t = R.alloc_nhwc(vx.n, pk.cout, vx.h, vx.w, x.dtype, dev, key=(id(c0), "y"))
+            vy = R.view_of(t)
+            probs[j] = L.ConvProblem(vx.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, pk.w.data_ptr(), pk.bias.data_ptr(), vy.ptr, pk.cout, vy.ld, None, 0)
+            mid_of[(kind, i)] = t
+        L.check(lib.upa_conv2d_bias_act_group(C.cast(probs, C.c_void_p), len(order), 3, 1, 1, L.ACT_SILU, L.dtype_code(xs[0].dtype),
+                                              R.opts_ptr(), stream), "conv2d_group")
+        # stage 2: the branch tails, one group call per kind
         for kind, seqs in todo:
-            probs = (L.ConvProblem * len(idx))()
-            mids = []
-            for j, i in enumerate(idx):
-                c0, x = seqs[i][0], xs[j]
-                pk = c0._packed(c0.conv, c0.bn, dev, x.dtype, False)
-                vx = R.view_of(x)
-                t = R.alloc_nhwc(vx.n, pk.cout, vx.h, vx.w, x.dtype, dev, key=(id(c0), "y"))
-                vy = R.view_of(t)
-                probs[j] = L.ConvProblem(vx.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, pk.w.data_ptr(), pk.bias.data_ptr(), vy.ptr, pk.cout, vy.ld,
-                                         None, 0)
-                mids.append(t)
-            L.check(lib.upa_conv2d_bias_act_group(C.cast(probs, C.c_void_p), len(idx), 3, 1, 1, L.ACT_SILU, L.dtype_code(xs[0].dtype),
-                                                  R.opts_ptr(), stream), "conv2d_group")
+            mids = [mid_of[(kind, i)] for i in idx]
             args = [self._branch_tail_args(t, seqs[i][1], seqs[i][2], kind) for t, i in zip(mids, idx)]
             hot = plan.get("hot") if kind == 2 else None
             rc = L.UPA_EUNSUPPORTED
