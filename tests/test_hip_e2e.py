@@ -570,3 +570,32 @@ def test_e2e_full_size_properties():
         a, b = o32[8 + j, :n].cpu(), o4[j, :n].cpu()
         assert (a[:, :5] - b[:, :5]).abs().max().item() <= TOL if n else True
         assert torch.equal(a[:, 5], b[:, 5])
+
+
+@pytest.mark.parametrize("name", ["yolov8n", "yolov8s", "yolov3-tiny", "yolov5-BoT3"])
+def test_e2e_grouped_detect_levels_equal_level_by_level(name):
+    """`Detect.group_levels` (the head's levels through `upa_conv2d_bias_act_group` / `upa_detect_branch_tail_group` when its branches
+    run on one stream, as in the linear graphs of the throughput runner): the decoded output is bit-identical to the level-by-level
+    walk, for every Detect config - including heads whose class branch is outside the branch-tail form (yolov8s: c3 = 128 goes
+    level by level inside the grouped walk) and two-level heads (yolov3-tiny)."""
+    from tests.hip_utils import DEV
+    m = _build(name, torch.bfloat16)
+    det = m.model[-1]
+    det.keep_raw = False
+    x = P.synthetic_images(4).to(DEV).to(torch.bfloat16).contiguous()
+    saved = det.concurrent
+    try:
+        with torch.no_grad():
+            det.concurrent = False  # one stream: the grouped walk
+            det.group_levels = True
+            y_grouped = m(x)[0].clone()
+            det.group_levels = False
+            y_levels = m(x)[0].clone()
+            det.concurrent = True   # forked branches (the default eager walk)
+            y_forked = m(x)[0].clone()
+    finally:
+        det.concurrent = saved
+        det.group_levels = True
+    torch.cuda.synchronize()
+    assert torch.equal(y_grouped, y_levels) and torch.equal(y_grouped, y_forked)
+
