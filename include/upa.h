@@ -239,6 +239,10 @@ typedef struct upa_branch_level {
 } upa_branch_level;
 int upa_detect_branch_tail_group(const upa_branch_level* levels, int count, int kind, int nc, float* y, int a_total,
                                  unsigned long long* best_keys, int dtype, const upa_opts* opts, void* stream);
+/* Both kinds at once: box[i] and cls[i] = the two branch tails of level i.  As two upa_detect_branch_tail_group calls, but box and
+ * class problems share grids as well (two kernel instantiations per grid): the six tails of a three-level head are two launches. */
+int upa_detect_head_tails(const upa_branch_level* box, const upa_branch_level* cls, int count, int nc, float* y, int a_total,
+                          unsigned long long* best_keys, int dtype, const upa_opts* opts, void* stream);
 
 
 /* ---- NMS ----------------------------------------------------------------------------------------------------------

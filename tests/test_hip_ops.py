@@ -1124,3 +1124,52 @@ def test_grouped_launches_equal_single_launches():
         rows = slice(0, 4) if kind == 1 else slice(4, 4 + nc)
         assert int((ys[0][:, rows] == -7.0).sum()) == 0  # every anchor of the three levels was written
 
+
+def test_detect_head_tails_equal_single_launches():
+    """`upa_detect_head_tails`: the box and class branch tails of three levels in one call - problems of two kernel instantiations per
+    grid (conv_big_mix_kernel: the 80 x 80 level's two tails as one launch, the 40 x 40 and 20 x 20 levels' four as another) - must equal
+    one `upa_detect_branch_tail` per branch and level bit for bit, decoded rows and NMS keys."""
+    import ctypes as C
+    from tests.hip_utils import DEV, bf16_round, to_dev_nhwc, unit_input
+    from ultralytics_pro_amd import _lib as L
+    from ultralytics_pro_amd.engine import runtime as R
+    from ultralytics_pro_amd.nn.modules.conv import PackedConv
+    lib, st = L.lib(), L.current_stream(DEV)
+    n, nc, tot = 16, 80, 8400
+    levels = [(80, 80, 0), (40, 40, 6400), (20, 20, 8000)]
+    packed = {}
+    for kind, c in ((1, 64), (2, 80)):
+        for li, (h, w, a0) in enumerate(levels):
+            t = to_dev_nhwc(bf16_round(unit_input(f"ht_t{kind}{li}", (n, c, h, w), -1.5, 1.5)), torch.bfloat16)
+            pk3 = PackedConv(bf16_round(unit_input(f"ht_w3{kind}{li}", (c, c, 3, 3), -0.1, 0.1)), unit_input(f"ht_b3{kind}{li}", (c,), -0.5, 0.5),
+                             3, DEV, torch.bfloat16, False)
+            wt = bf16_round(unit_input(f"ht_wt{kind}{li}", (c, c), -0.4, 0.4))
+            bt = unit_input(f"ht_bt{kind}{li}", (c,), -2, 1)
+            host = torch.empty(lib.upa_tail_packed_weight_bytes(c, c), dtype=torch.uint8)
+            L.check(lib.upa_pack_tail_weight(wt.data_ptr(), c, c, host.data_ptr()), "pack_tail_weight")
+            packed[(kind, li)] = (t, pk3, host.to(DEV), bt.to(DEV))
+    ys = [torch.full((n, 4 + nc, tot), -7.0, device=DEV) for _ in range(3)]
+    keys = [torch.full((n, tot), -1, dtype=torch.int64, device=DEV) for _ in range(3)]
+    for which, opts in ((0, None), (1, L.Opts(no_group=1))):
+        lvs = {}
+        for kind in (1, 2):
+            lv = (L.BranchLevel * 3)()
+            for j, (h, w, a0) in enumerate(levels):
+                t, pk3, wt, bt = packed[(kind, j)]
+                vt = R.view_of(t)
+                lv[j] = L.BranchLevel(vt.ptr, vt.n, vt.h, vt.w, vt.c, vt.ld, pk3.w.data_ptr(), pk3.bias.data_ptr(), wt.data_ptr(), bt.data_ptr(),
+                                      float(8 << j), a0)
+            lvs[kind] = lv
+        L.check(lib.upa_detect_head_tails(C.cast(lvs[1], C.c_void_p), C.cast(lvs[2], C.c_void_p), 3, nc, ys[which].data_ptr(), tot,
+                                          keys[which].data_ptr(), L.UPA_BF16, C.pointer(opts) if opts is not None else None, st), "head_tails")
+    for kind in (1, 2):  # one launch per branch and level
+        for j, (h, w, a0) in enumerate(levels):
+            t, pk3, wt, bt = packed[(kind, j)]
+            vt = R.view_of(t)
+            L.check(lib.upa_detect_branch_tail(vt.ptr, vt.n, vt.h, vt.w, vt.c, vt.ld, pk3.w.data_ptr(), pk3.bias.data_ptr(), wt.data_ptr(),
+                                               bt.data_ptr(), kind, nc, float(8 << j), ys[2].data_ptr(), tot, a0,
+                                               keys[2].data_ptr() if kind == 2 else None, L.UPA_BF16, None, st), "branch_tail")
+    torch.cuda.synchronize()
+    assert torch.equal(ys[0], ys[2]) and torch.equal(ys[1], ys[2]) and torch.equal(keys[0], keys[2]) and torch.equal(keys[1], keys[2])
+    assert int((ys[0] == -7.0).sum()) == 0 and int((keys[0] == -1).sum()) == 0
+

@@ -130,6 +130,7 @@ PROTOTYPES = {
     "upa_letterbox_u8": (_i, [_vp, _i, _i, _i, C.c_long, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "upa_detect_decode": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _i, _i, _vp]),
     "upa_detect_branch_tail_group": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _op, _vp]),
+    "upa_detect_head_tails": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _i, _op, _vp]),
     "upa_conv2d_bias_act_group": (_i, [_vp, _i, _i, _i, _i, _i, _i, _op, _vp]),
     "upa_detect_tail": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _f, _vp, _i, _i, _vp, _i, _vp, _i, _op, _vp]),
     "upa_conv1x1_upcat": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _op, _vp]),

@@ -973,10 +973,11 @@ extern "C" int upa_conv2d_bias_act_group(const upa_conv_problem* probs, int coun
   };
   for (int i = 0; i < count;) {
     if (i + 1 < count && k == 3 && stride == 1 && big_ok(probs[i]) && big_ok(probs[i + 1])) {
-      BigParams b[3];
+      BigParams b[4];
       int m = 2;
       b[0] = fill(probs[i]); b[1] = fill(probs[i + 1]);
       if (i + 2 < count && big_ok(probs[i + 2])) { b[2] = fill(probs[i + 2]); m = 3; }
+      if (m == 3 && i + 3 < count && big_ok(probs[i + 3])) { b[3] = fill(probs[i + 3]); m = 4; }
       int consumed = 0;
       const int rc = upa_conv_big_launch_group(b, m, &consumed, stream, opts);
       if (rc == UPA_OK && consumed > 0) { i += consumed; continue; }

@@ -381,6 +381,23 @@ __global__ __launch_bounds__(512, 4) void conv_big_tri_kernel(const BigParams p0
   else conv_big_body<KS, STRIDE, WM, WN, MT, NT, TAIL>(p2, (int)blockIdx.x - s1);
 }
 
+// ... and problems of TWO instantiations in one grid (box and class branches of the same Detect levels: independent chains whose
+// kernels differ in the number of n-tiles or in the tail): up to two problems each.  Registers and LDS are the larger of the two.
+template <int KS_, int STRIDE_, int WM_, int WN_, int MT_, int NT_, int TAIL_>
+struct BigCfg {
+  static constexpr int NTB = WN_ * NT_;
+  __device__ static __forceinline__ void run(const BigParams& p, int bid) { conv_big_body<KS_, STRIDE_, WM_, WN_, MT_, NT_, TAIL_>(p, bid); }
+};
+template <class CA, class CB>
+__global__ __launch_bounds__(512, 4) void conv_big_mix_kernel(const BigParams a0, const BigParams a1, const BigParams b0, const BigParams b1,
+                                                              const int s0, const int s1, const int s2) {
+  const int b = (int)blockIdx.x;
+  if (b < s0) CA::run(a0, b);
+  else if (b < s1) CA::run(a1, b - s0);
+  else if (b < s2) CB::run(b0, b - s1);
+  else CB::run(b1, b - s2);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
@@ -507,6 +524,24 @@ int big_launch_tri_inst(const BigParams& p0, const BigParams& p1, const BigParam
     return UPA_ELAUNCH;
   }
   hipLaunchKernelGGL((conv_big_tri_kernel<KS, STRIDE, WM, WN, MT, NT, TAIL>), grid, dim3(512), lds, s, p0, p1, p2, (int)t0, (int)(t0 + t1));
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+// na, nb = 1 | 2 problems of each instantiation; every problem must be a single column block of its instantiation
+template <class CA, class CB>
+int big_launch_mix(const BigParams* pa, int na, const BigParams* pb, int nb, size_t lds, hipStream_t s) {
+  long t[4] = {0, 0, 0, 0};
+  for (int i = 0; i < na; ++i) { t[i] = (long)pa[i].tilesX * pa[i].tilesY * pa[i].N; if (pa[i].NTn > CA::NTB) return UPA_EUNSUPPORTED; }
+  for (int i = 0; i < nb; ++i) { t[2 + i] = (long)pb[i].tilesX * pb[i].tilesY * pb[i].N; if (pb[i].NTn > CB::NTB) return UPA_EUNSUPPORTED; }
+  const long tot = t[0] + t[1] + t[2] + t[3];
+  if (tot >= (1L << 31)) return UPA_EUNSUPPORTED;
+  if (hipError_t e = upa_full_lds<conv_big_mix_kernel<CA, CB>>(); e != hipSuccess) {
+    upa_set_error("conv_big: cannot raise LDS limit: %s", hipGetErrorString(e));
+    return UPA_ELAUNCH;
+  }
+  hipLaunchKernelGGL((conv_big_mix_kernel<CA, CB>), dim3((unsigned)tot), dim3(512), lds, s, pa[0], pa[na > 1 ? 1 : 0], pb[0], pb[nb > 1 ? 1 : 0],
+                     (int)t[0], (int)(t[0] + t[1]), (int)(t[0] + t[1] + t[2]));
   UPA_LAUNCH_CHECK();
   return UPA_OK;
 }
@@ -671,6 +706,54 @@ extern "C" int upa_detect_branch_tail_group(const upa_branch_level* levels, int 
   return UPA_OK;
 }
 
+// Box AND class branch tails of several levels of one Detect head: as two upa_detect_branch_tail_group calls, but the two kinds share
+// grids too (conv_big_mix_kernel: two instantiations per grid) - a level pair on 128-pixel workgroups becomes ONE launch of four
+// problems, a single level one launch of two.  yolov8n at batch 32: the six tails are two launches.  Identical results.
+extern "C" int upa_detect_head_tails(const upa_branch_level* box, const upa_branch_level* cls, int count, int nc, float* y, int a_total,
+                                     unsigned long long* best_keys, int dtype, const upa_opts* opts, void* stream) {
+  UPA_CHECK_ARG(box && cls && count >= 1 && count <= 8, "detect_head_tails: 1..8 levels");
+  BigParams pb[8], pc[8];
+  int ntbb[8], bmb[8], ntbc[8], bmc[8];
+  size_t ldsb[8], ldsc[8];
+  for (int i = 0; i < count; ++i) {
+    const upa_branch_level& b = box[i];
+    const upa_branch_level& c = cls[i];
+    if (const int rc = branch_tail_prepare(pb[i], ntbb[i], bmb[i], ldsb[i], b.x, b.n, b.h, b.w, b.c, b.ldx, b.w3_packed, b.b3, b.wt_packed, b.bt,
+                                           1, nc, b.stride_px, y, a_total, b.a0, nullptr, dtype, opts); rc != UPA_OK)
+      return rc;
+    if (const int rc = branch_tail_prepare(pc[i], ntbc[i], bmc[i], ldsc[i], c.x, c.n, c.h, c.w, c.c, c.ldx, c.w3_packed, c.b3, c.wt_packed, c.bt,
+                                           2, nc, c.stride_px, y, a_total, c.a0, best_keys, dtype, opts); rc != UPA_OK)
+      return rc;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int grouping = UPA_OPT(opts, no_group);
+  auto mx = [](size_t a, size_t b) { return a > b ? a : b; };
+  using Box128 = BigCfg<3, 1, 8, 1, 1, 4, 1>;
+  using Cls128 = BigCfg<3, 1, 8, 1, 1, 5, 2>;
+  using Box256 = BigCfg<3, 1, 8, 1, 2, 4, 1>;
+  using Cls256 = BigCfg<3, 1, 8, 1, 2, 5, 2>;
+  for (int i = 0; i < count;) {
+    if (grouping != 1 && ntbc[i] == 5) {
+      if (i + 1 < count && ntbc[i + 1] == 5 && bmb[i] == 128 && bmb[i + 1] == 128 && bmc[i] == 128 && bmc[i + 1] == 128) {
+        const size_t l = mx(mx(ldsb[i], ldsb[i + 1]), mx(ldsc[i], ldsc[i + 1]));
+        const int rc = big_launch_mix<Box128, Cls128>(pb + i, 2, pc + i, 2, l, s);
+        if (rc == UPA_OK) { i += 2; continue; }
+        if (rc != UPA_EUNSUPPORTED) return rc;
+      }
+      if (bmb[i] == bmc[i]) {
+        const size_t l = mx(ldsb[i], ldsc[i]);
+        const int rc = bmb[i] == 128 ? big_launch_mix<Box128, Cls128>(pb + i, 1, pc + i, 1, l, s) : big_launch_mix<Box256, Cls256>(pb + i, 1, pc + i, 1, l, s);
+        if (rc == UPA_OK) { ++i; continue; }
+        if (rc != UPA_EUNSUPPORTED) return rc;
+      }
+    }
+    if (const int rc = branch_tail_launch(pb[i], 1, ntbb[i], bmb[i], ldsb[i], s); rc != UPA_OK) return rc;
+    if (const int rc = branch_tail_launch(pc[i], 2, ntbc[i], bmc[i], ldsc[i], s); rc != UPA_OK) return rc;
+    ++i;
+  }
+  return UPA_OK;
+}
+
 bool upa_conv_big_eligible(int n, int h, int w, int cin, int ldx, int cout, int ldy, int ldr, int k, int stride, int pad,
                            int act, int dtype, const upa_opts* opts) {
   // upa_opts.conv_big: 0 = by the size rule below (default), 1 = never, 2 = every shape the kernel can run (parity tests,
@@ -763,6 +846,23 @@ int upa_conv_big_launch_group(const BigParams* probs, int count, int* consumed, 
   if (count < 2) return UPA_EUNSUPPORTED;
   const int grouping = UPA_OPT(opts, no_group);
   if (grouping == 1) return UPA_EUNSUPPORTED;
+  if (count >= 4) {  // two 64-channel and two 80-channel problems on 128-pixel workgroups (the small levels' first convs): one grid
+    BigParams q[4];
+    int nt4[4], bm4[4];
+    size_t l4[4];
+    bool ok = true;
+    for (int i = 0; i < 4 && ok; ++i) {
+      q[i] = probs[i];
+      ok = q[i].KS == 3 && q[i].stride == 1 && big_prepare(q[i], nt4[i], bm4[i], l4[i], opts, false) == UPA_OK && bm4[i] == 128;
+    }
+    if (ok && nt4[0] == 4 && nt4[1] == 4 && nt4[2] == 5 && nt4[3] == 5) {
+      size_t l = l4[0];
+      for (int i = 1; i < 4; ++i) l = l4[i] > l ? l4[i] : l;
+      const int rc = big_launch_mix<BigCfg<3, 1, 4, 2, 2, 2, 0>, BigCfg<3, 1, 8, 1, 1, 5, 0>>(q, 2, q + 2, 2, l, (hipStream_t)stream);
+      if (rc == UPA_OK) { *consumed = 4; return UPA_OK; }
+      if (rc != UPA_EUNSUPPORTED) return rc;
+    }
+  }
   BigParams p[3];
   int ntb[3], bm[3];
   size_t lds[3];

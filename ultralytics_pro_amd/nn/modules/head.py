@@ -188,28 +188,31 @@ class Detect(nn.Module, _HipConvMixin):
             mid_of[(kind, i)] = t
         L.check(lib.upa_conv2d_bias_act_group(C.cast(probs, C.c_void_p), len(order), 3, 1, 1, L.ACT_SILU, L.dtype_code(xs[0].dtype),
                                               R.opts_ptr(), stream), "conv2d_group")
-        # stage 2: the branch tails, one group call per kind
-        for kind, seqs in todo:
-            mids = [mid_of[(kind, i)] for i in idx]
-            args = [self._branch_tail_args(t, seqs[i][1], seqs[i][2], kind) for t, i in zip(mids, idx)]
-            hot = plan.get("hot") if kind == 2 else None
-            rc = L.UPA_EUNSUPPORTED
-            if all(a is not None for a in args):
+        # stage 2: the branch tails of both kinds in one call (box and class problems share grids where their workgroup sizes agree)
+        args = {kind: [self._branch_tail_args(mid_of[(kind, i)], seqs[i][1], seqs[i][2], kind) for i in idx] for kind, seqs in todo}
+        hot = plan.get("hot")
+        rc = L.UPA_EUNSUPPORTED
+        if all(a is not None for k in args for a in args[k]):
+            lvs = {}
+            for kind in (1, 2):
                 lv = (L.BranchLevel * len(idx))()
-                for j, (i, (vt, pk3, wt, bt)) in enumerate(zip(idx, args)):
+                for j, (i, (vt, pk3, wt, bt)) in enumerate(zip(idx, args[kind])):
                     lv[j] = L.BranchLevel(vt.ptr, vt.n, vt.h, vt.w, vt.c, vt.ld, pk3.w.data_ptr(), pk3.bias.data_ptr(), wt.data_ptr(),
                                           bt.data_ptr(), float(self.stride[i]), plan["a0"][i])
-                rc = lib.upa_detect_branch_tail_group(C.cast(lv, C.c_void_p), len(idx), kind, self.nc, plan["y"].data_ptr(),
-                                                      plan["a_total"], hot.data_ptr() if hot is not None else None,
-                                                      L.dtype_code(xs[0].dtype), R.opts_ptr(), stream)
-            if rc == L.UPA_EUNSUPPORTED:  # a level outside the branch-tail form: its second half level by level
-                for t, i in zip(mids, idx):
+                lvs[kind] = lv
+            rc = lib.upa_detect_head_tails(C.cast(lvs[1], C.c_void_p), C.cast(lvs[2], C.c_void_p), len(idx), self.nc, plan["y"].data_ptr(),
+                                           plan["a_total"], hot.data_ptr() if hot is not None else None, L.dtype_code(xs[0].dtype),
+                                           R.opts_ptr(), stream)
+        if rc == L.UPA_EUNSUPPORTED:  # a branch outside the branch-tail form: the second halves level by level
+            for kind, seqs in todo:
+                for i in idx:
+                    t = mid_of[(kind, i)]
                     if not self._branch_tail(t, seqs[i][1], seqs[i][2], kind, i, plan):
                         self._tail_call(seqs[i][1](t), seqs[i][2], None, kind, i, plan)
-            else:
-                L.check(rc, "detect_branch_tail_group")
-                if hot is not None:
-                    plan["hot_levels"].update(idx)
+        else:
+            L.check(rc, "detect_head_tails")
+            if hot is not None:
+                plan["hot_levels"].update(idx)
         return True
 
     def _tail_call(self, t: torch.Tensor, conv: nn.Conv2d, raw, kind: int, i: int, plan) -> None:
