@@ -2,6 +2,7 @@
 # Regenerates the numbers profiles/ holds (run on the GPU box; outputs under gpurun_out/final_r03/, copied into profiles/ by hand).
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/final_r03
+rm -rf $O/prof_default $O/prof_serial $O/prof_train   # stale traces of earlier calls would shadow this one's stats
 mkdir -p $O
 cd $R
 timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err
