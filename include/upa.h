@@ -50,7 +50,7 @@ typedef struct upa_opts {
   int32_t pair;            /* upa_bottleneck_pair: 0 = C = 32 only (default), 1 = never, 2 = C = 32 and 64, 3 = C = 64 only */
   int32_t pair_tile64, pair_tile32;  /* its square output tile edge per width (0 = auto) */
   int32_t no_pair_cv2;     /* upa_bottleneck_pair_cv2: 1 = never */
-  int32_t c2f;             /* upa_c2f_fused / upa_c2f64_fused: 0 = every form, 1 = never, 2 = not the 16-wide, 3 = not the 32-wide, 4 = not the 64-wide */
+  int32_t c2f;             /* upa_c2f_fused / upa_c2f64_fused / upa_c2f32_up_fused: 0 = every form, 1 = never, 2 = not the 16-wide, 3 = not the 32-wide, 4 = not the 64-wide */
   int32_t c2f16_waves;     /* 0 = 4 | 8 */
   int32_t c2f32_th;        /* output tile rows of the C2f(64, 64, n = 2) form: 0 = 16 | 10 */
   int32_t no_branch_tail;  /* upa_detect_branch_tail: 1 = never */
@@ -60,6 +60,7 @@ typedef struct upa_opts {
   int32_t c2f64_max_px;    /* upa_c2f64_fused only up to this many pixels n * h * w (0 = 100000: the 40 x 40 maps at batch 32; -1 = any size) */
   int32_t conv_ws3;        /* csrc/conv_ws3.hip (persistent 3x3 with register-resident weights, Cin <= 64, Cout 64): 0 = by the size rule, 1 = never, 2 = every shape it can run, 3 = the rule restricted to maps of < 100000 pixels (at most one tile per workgroup) */
   int32_t no_group;        /* upa_conv2d_bias_act_group / upa_detect_branch_tail_group: 0 = two problems per grid where the instantiations allow, 1 = one launch per problem, 2 = three per grid too (measured slower; A/B) */
+  int32_t no_c2f32_up;     /* 1 = upa_c2f32_up_fused refuses (the block then runs as upa_conv1x1_upcat + upa_bottleneck_pair_cv2; A/B) */
 } upa_opts;
 
 /* Library / device info. Returns the ABI version (int); fills name with the kernel target ("gfx950"). */
@@ -211,6 +212,12 @@ int upa_c2f_fused(const void* x, int n, int h, int w, int c1, int ldx, int c, in
 int upa_c2f64_fused(const void* x, int n, int h, int w, int c1, int ldx, const void* up, int up_c, int up_ld, int nb, int shortcut,
                     const void* w1, const float* b1, const void* const* wm, const float* const* bm, const void* w2,
                     const float* b2, void* y, int c2, int ldy, int act, int dtype, const upa_opts* opts, void* stream);
+/* C2f(c1, 64, n = 1) with 32-channel halves and c1 = 64 k >= 128 input channels (yolov8n model.15: C2f(192, 64) behind nn.Upsample +
+ * Concat) as one launch: cv1 streamed over 64-channel chunks, the first up_c channels read from the half-resolution tensor `up`
+ * (NULL: everything from x).  Arguments as upa_c2f64_fused; UPA_EUNSUPPORTED outside the form.  block.py:457-488, conv.py:850-875 */
+int upa_c2f32_up_fused(const void* x, int n, int h, int w, int c1, int ldx, const void* up, int up_c, int up_ld, int nb, int shortcut,
+                       const void* w1, const float* b1, const void* const* wm, const float* const* bm, const void* w2, const float* b2,
+                       void* y, int c2, int ldy, int act, int dtype, const upa_opts* opts, void* stream);
 
 /* The whole back half of a Detect branch in one launch (bf16): second 3x3 conv (BN + SiLU folded) -> final 1x1 conv -> that
  * branch's half of the decode, the intermediate maps never leaving the registers.      head.py:94-100 (cv2/cv3), :116-126,

@@ -402,6 +402,66 @@ def test_c2f_fused_kernel(case, th):
     assert float(to_cpu_nchw(buf[:, :c1]).abs().max()) == 0.0  # nothing written outside the output slice
 
 
+C2F32UP_CASES = [
+    # c1, shortcut, (N, H, W), up_c  (C2f(c1, 64, n = 1) with 32-channel halves, cv1 streamed over 64-channel chunks: upa_c2f32_up_fused)
+    (192, False, (2, 80, 80), 128),   # yolov8n model.15: virtual Upsample(128) + Concat(64) in front, three chunks
+    (192, False, (1, 26, 38), 128),   # ragged 16 x 16 tiles
+    (128, True, (2, 16, 16), 64),     # two chunks, shortcut, exactly one tile
+    (256, False, (1, 10, 6), 0),      # four chunks from x alone, a map smaller than a tile
+    (192, True, (3, 20, 20), 0),      # three chunks, no half-resolution source
+]
+
+
+@pytest.mark.parametrize("case", C2F32UP_CASES, ids=[f"c{c[0]}{'s' if c[1] else ''}_{c[2][0]}x{c[2][1]}x{c[2][2]}{'_up' + str(c[3]) if c[3] else ''}" for c in C2F32UP_CASES])
+def test_c2f32_up_fused_kernel(case):
+    """`upa_c2f32_up_fused` (bf16): C2f(64 k, 64, n = 1) (block.py:457-488) as one kernel with cv1's input streamed in 64-channel chunks,
+    the leading channels optionally read from the half-resolution tensor of a virtual nn.Upsample + Concat (yolov8.yaml rows 13-15) - vs
+    the oracle C2f on BN-folded bf16 weights with the intermediates rounded where the kernel rounds them, and vs the product's own
+    multi-launch path.  The upsampled slice of the concat buffer holds a sentinel that must never be read."""
+    from tests.hip_utils import DEV, assert_bf16_close, bf16_round, bf16_weight_oracle, to_cpu_nchw, to_dev_nhwc
+    from ultralytics_pro_amd.engine import runtime as R
+    from ultralytics_pro_amd.nn.modules.conv import VirtualUpsample
+    pm, rs = _mods()
+    c1, sc, (N, H, W), upc = case
+    o, m = _pair(om.C2f, pm.C2f, (c1, 64, 1, sc), f"c2f32up_{c1}")
+    o = bf16_weight_oracle(o)
+    if upc:
+        u = bf16_round(P.uniform(f"c2f32upu{case}", (N, upc, H // 2, W // 2), -1.5, 1.5))
+        sk = bf16_round(P.uniform(f"c2f32ups{case}", (N, c1 - upc, H, W), -1.5, 1.5))
+        x = torch.cat([torch.nn.functional.interpolate(u, scale_factor=2, mode="nearest"), sk], 1)
+    else:
+        x = bf16_round(P.uniform(f"c2f32up{case}", (N, c1, H, W), -1.5, 1.5))
+    with torch.no_grad():
+        ys = list(bf16_round(o.cv1(x)).chunk(2, 1))
+        t = bf16_round(o.m[0].cv1(ys[-1]))
+        ys.append(bf16_round((ys[-1] if sc else 0) + o.m[0].cv2(t)))
+        ref = o.cv2(torch.cat(ys, 1))
+        buf = R.alloc_nhwc(N, 128, H, W, torch.bfloat16, DEV)
+        buf.zero_()
+        xd = to_dev_nhwc(x, torch.bfloat16)
+        up = None
+        if upc:
+            ud = to_dev_nhwc(u, torch.bfloat16)
+            xd[:, :upc].fill_(77.0)  # never read on the fused path
+            mat = []
+            upm = rs.Upsample(None, 2, "nearest")
+            up = VirtualUpsample(ud, upc, lambda: mat.append(upm(ud, out=xd[:, :upc])))
+        m.fuse_block = True
+        assert m._form32up()
+        y = to_cpu_nchw(m(xd, out=buf[:, 64:], up=up))
+        if upc:
+            assert not mat and not up.done, "the fused block must read the half-resolution tensor itself"
+            up.materialize()
+        m.fuse_block = False
+        y2 = to_cpu_nchw(m(xd))
+    scale = max(1.0, ref.abs().max().item())
+    assert_bf16_close(y, ref, f"c2f32up{case}", abs_=2.0 ** -7)
+    d = (y - y2).abs()
+    assert d.max().item() <= 3e-2 * scale and (d > 1e-6).float().mean().item() <= (0.05 if sc else 0.10), \
+        (d.max().item(), (d > 1e-6).float().mean().item())
+    assert float(to_cpu_nchw(buf[:, :64]).abs().max()) == 0.0  # nothing written outside the output slice
+
+
 C2F64_CASES = [
     # c1, n, shortcut, (N, H, W), up_c  (C2f(c1, 128, n) with 64-channel halves as one kernel, csrc/c2f64.hip)
     (128, 2, True, (2, 40, 40), 0),     # yolov8n model.6: 10 x 10 tiles, no ragged edge

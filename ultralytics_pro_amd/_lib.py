@@ -37,7 +37,7 @@ class Opts(C.Structure):
                 ("c2f", _i), ("c2f16_waves", _i), ("c2f32_th", _i),
                 ("no_branch_tail", _i), ("branch_tail_bm", _i),
                 ("stem_wgs", _i), ("stemf_wgs", _i), ("stemf_waves", _i), ("stem_no_mfma", _i),
-                ("ablate_conv", _i), ("ablate_pipe", _i), ("ablate_c1", _i), ("ablate_stem", _i), ("c2f64_max_px", _i), ("conv_ws3", _i), ("no_group", _i)]
+                ("ablate_conv", _i), ("ablate_pipe", _i), ("ablate_c1", _i), ("ablate_stem", _i), ("c2f64_max_px", _i), ("conv_ws3", _i), ("no_group", _i), ("no_c2f32_up", _i)]
 
     def __init__(self, **kw):
         super().__init__()
@@ -137,6 +137,7 @@ PROTOTYPES = {
     "upa_bottleneck_pair_cv2": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _op, _vp]),
     "upa_c2f_fused": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _op, _vp]),
     "upa_c2f64_fused": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _op, _vp]),
+    "upa_c2f32_up_fused": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _op, _vp]),
     "upa_tail_packed_weight_bytes": (_sz, [_i, _i]),
     "upa_pack_tail_weight": (_i, [_vp, _i, _i, _vp]),
     "upa_detect_branch_tail": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _i, _i, _vp, _i, _op, _vp]),

@@ -244,6 +244,9 @@ struct C2f32Params {
   const float *b1, *b2;
   const float* bm[4];
   int N, H, W, ldx, ldy, tilesX, tilesY, shortcut;
+  // CHUNKED form (cv1 with c1 = 64 * nch input channels, streamed in 64-channel chunks): the first upC channels of a pixel come from
+  // pixel (y / 2, x / 2) of the half-resolution tensor `up` (a virtual nn.Upsample + Concat), the rest from x itself
+  const char* up; int c1, upC, up_ld;
 };
 
 namespace c2f32 {
@@ -304,7 +307,7 @@ __device__ __forceinline__ void conv3x3_stage(const char* src, char* dst, const 
 
 // TH = output tile rows (16 columns always).  16 x 16 is the default; 10 rows balance the one-per-CU workgroups of yolov8n
 // model.4 (1280 tiles = 5.0 rounds instead of 800 = 3.125) but measured no faster - kept as an experiment switch (host side).
-template <int NB, int TH>
+template <int NB, int TH, bool CHUNKED = false>
 __global__ __launch_bounds__(1024) void c2f32_fused_kernel(const C2f32Params p) {
   using namespace c2f32;
   constexpr int R = 2 * NB;
@@ -343,58 +346,161 @@ __global__ __launch_bounds__(1024) void c2f32_fused_kernel(const C2f32Params p) 
 
   UPA_STAMP_AT(0);
   UPA_STAMP_HWID();
-  // ---- x halo tile: 128 B / px, 16-byte group cg of pixel px at slot cg ^ (px & 7)
+  u32x4 wA[9], wB[9];
+  f32x4 bA, bB;
+  if constexpr (!CHUNKED) {
+    // ---- x halo tile: 128 B / px, 16-byte group cg of pixel px at slot cg ^ (px & 7)
 #pragma unroll
-  for (int it = 0; it < XIT; ++it) {
-    const int idx = it * 1024 + tid;
-    if (it * 1024 + wave * 64 < XITEMS) {
+    for (int it = 0; it < XIT; ++it) {
+      const int idx = it * 1024 + tid;
+      if (it * 1024 + wave * 64 < XITEMS) {
+        const int px = idx >> 3, slot = idx & 7;
+        const int cg = slot ^ (px & 7);
+        const int hy = px / SX, hx = px - hy * SX;
+        const int iy = oy0 - R + hy, ix = ox0 - R + hx;
+        const char* src = reinterpret_cast<const char*>(g_c2f_zero16);
+        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) src = p.x + ((((size_t)n * p.H + iy) * p.W + ix) * (size_t)p.ldx + cg * 8) * 2;
+        __builtin_amdgcn_global_load_lds((cgptr_t)src, (clptr_t)(xs + (it * 1024 + wave * 64) * 16), 16, 0, 0);
+      }
+    }
+    // cv1 (64 -> 64: [2 k-tiles][4 n-tiles]): this wave's n-tiles j (y0) and 2 + j (y1); the first 3x3 conv's fragments
+    u32x4 w1f[2][2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) w1f[kt][h2] = *reinterpret_cast<const u32x4*>(p.w1 + ((size_t)(kt * 4 + 2 * h2 + j) * 64 + lane) * 16);
+    const f32x4 b1y0 = *reinterpret_cast<const f32x4*>(p.b1 + j * 16 + 4 * g);
+    const f32x4 b1y1 = *reinterpret_cast<const f32x4*>(p.b1 + (2 + j) * 16 + 4 * g);
+    load_w9(wA, p.wm[0], j, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    UPA_STAMP_AT(1);
+    bA = *reinterpret_cast<const f32x4*>(p.bm[0] + j * 16 + 4 * g);
+    bB = *reinterpret_cast<const f32x4*>(p.bm[1] + j * 16 + 4 * g);
+
+    // ---- A. cv1: y1 on every halo pixel, y0 on the tile's own pixels
+    for (int mt = wave >> 1; mt < XPX / 16; mt += NW / 2) {
+      const int q = mt * 16 + r;
+      f32x4 a = b1y1;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+        a = mfma32(w1f[kt][1], *reinterpret_cast<const u32x4*>(xs + q * 128 + (((kt * 4 + g) ^ (q & 7)) << 4)), a);
+      const int hy = q / SX, hx = q - hy * SX;
+      const int gy = oy0 - R + hy, gx = ox0 - R + hx;
+      const bool in = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = in ? silu(a[e]) : 0.f;
+      *reinterpret_cast<u32x2*>(y1s + quad_addr(q, j, g)) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    }
+    for (int i = wave >> 1; i < TH; i += NW / 2) {
+      const int q = (i + R) * SX + R + r;
+      f32x4 a = b1y0;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+        a = mfma32(w1f[kt][0], *reinterpret_cast<const u32x4*>(xs + q * 128 + (((kt * 4 + g) ^ (q & 7)) << 4)), a);
+      *reinterpret_cast<u32x2*>(y0s + quad_addr(i * T + r, j, g)) = u32x2{pack_bf16x2(silu(a[0]), silu(a[1])), pack_bf16x2(silu(a[2]), silu(a[3]))};
+    }
+  } else {
+    // ---- cv1 over nch 64-channel chunks of the input (c1 = 64 nch; yolov8n model.15: 192 = upsampled 128 + skip 64).  Two chunk
+    // buffers: xs and a second x-sized region behind the other tiles; the DMA of chunk c + 1 lands under the MFMAs of chunk c; a wave
+    // keeps its accumulators (y1: every 8th m-tile of the halo'd tile, y0: two tile rows) across the chunks.
+    char* xb2 = b1s + (NB == 2 ? ((H_B1 * S_B1 + 15) / 16) * 16 * 64 : 0);
+    unsigned xoff[XIT], uoff[XIT];
+#pragma unroll
+    for (int it = 0; it < XIT; ++it) {
+      const int idx = it * 1024 + tid;
       const int px = idx >> 3, slot = idx & 7;
       const int cg = slot ^ (px & 7);
       const int hy = px / SX, hx = px - hy * SX;
       const int iy = oy0 - R + hy, ix = ox0 - R + hx;
-      const char* src = reinterpret_cast<const char*>(g_c2f_zero16);
-      if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) src = p.x + ((((size_t)n * p.H + iy) * p.W + ix) * (size_t)p.ldx + cg * 8) * 2;
-      __builtin_amdgcn_global_load_lds((cgptr_t)src, (clptr_t)(xs + (it * 1024 + wave * 64) * 16), 16, 0, 0);
+      const bool ok = idx < XITEMS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      xoff[it] = ok ? (unsigned)((((size_t)n * p.H + iy) * p.W + ix) * (size_t)p.ldx + cg * 8) * 2u : 0xffffffffu;
+      uoff[it] = (ok && p.up) ? (unsigned)((((size_t)n * (p.H >> 1) + (iy >> 1)) * (p.W >> 1) + (ix >> 1)) * (size_t)p.up_ld + cg * 8) * 2u : 0u;
     }
-  }
-  // cv1 (64 -> 64: [2 k-tiles][4 n-tiles]): this wave's n-tiles j (y0) and 2 + j (y1); the first 3x3 conv's fragments
-  u32x4 w1f[2][2];
+    const int nch = p.c1 >> 6;
+    auto stage_chunk = [&](int c) __attribute__((always_inline)) {
+      char* buf = (c & 1) ? xb2 : xs;
+      const bool fromUp = c * 64 < p.upC;  // uniform: whole chunks come from one tensor (upC % 64 == 0)
+      const char* base = fromUp ? p.up : p.x;
 #pragma unroll
-  for (int kt = 0; kt < 2; ++kt)
+      for (int it = 0; it < XIT; ++it) {
+        if (it * 1024 + wave * 64 < XITEMS) {
+          const char* src = xoff[it] != 0xffffffffu ? base + (size_t)(fromUp ? uoff[it] : xoff[it]) + c * 128
+                                                    : reinterpret_cast<const char*>(g_c2f_zero16);
+          __builtin_amdgcn_global_load_lds((cgptr_t)src, (clptr_t)(buf + (it * 1024 + wave * 64) * 16), 16, 0, 0);
+        }
+      }
+    };
+    stage_chunk(0);
+    auto load_w1 = [&](u32x4 (&a)[2][2], int c) __attribute__((always_inline)) {
 #pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2) w1f[kt][h2] = *reinterpret_cast<const u32x4*>(p.w1 + ((size_t)(kt * 4 + 2 * h2 + j) * 64 + lane) * 16);
-  const f32x4 b1y0 = *reinterpret_cast<const f32x4*>(p.b1 + j * 16 + 4 * g);
-  const f32x4 b1y1 = *reinterpret_cast<const f32x4*>(p.b1 + (2 + j) * 16 + 4 * g);
-  u32x4 wA[9], wB[9];
-  load_w9(wA, p.wm[0], j, lane);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  UPA_STAMP_AT(1);
-  f32x4 bA = *reinterpret_cast<const f32x4*>(p.bm[0] + j * 16 + 4 * g);
-  f32x4 bB = *reinterpret_cast<const f32x4*>(p.bm[1] + j * 16 + 4 * g);
-
-  // ---- A. cv1: y1 on every halo pixel, y0 on the tile's own pixels
-  for (int mt = wave >> 1; mt < XPX / 16; mt += NW / 2) {
-    const int q = mt * 16 + r;
-    f32x4 a = b1y1;
+      for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-      a = mfma32(w1f[kt][1], *reinterpret_cast<const u32x4*>(xs + q * 128 + (((kt * 4 + g) ^ (q & 7)) << 4)), a);
-    const int hy = q / SX, hx = q - hy * SX;
-    const int gy = oy0 - R + hy, gx = ox0 - R + hx;
-    const bool in = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-    float v[4];
+        for (int h2 = 0; h2 < 2; ++h2)
+          a[kt][h2] = *reinterpret_cast<const u32x4*>(p.w1 + ((size_t)((c * 2 + kt) * 4 + 2 * h2 + j) * 64 + lane) * 16);
+    };
+    u32x4 w1c[2][2], w1n[2][2];
+    load_w1(w1c, 0);
+    const f32x4 b1y0 = *reinterpret_cast<const f32x4*>(p.b1 + j * 16 + 4 * g);
+    const f32x4 b1y1 = *reinterpret_cast<const f32x4*>(p.b1 + (2 + j) * 16 + 4 * g);
+    bA = *reinterpret_cast<const f32x4*>(p.bm[0] + j * 16 + 4 * g);
+    bB = *reinterpret_cast<const f32x4*>(p.bm[1] + j * 16 + 4 * g);
+    constexpr int NMT1 = XPX / 16, A1 = (NMT1 + NW / 2 - 1) / (NW / 2), A0 = (TH + NW / 2 - 1) / (NW / 2);
+    f32x4 acc1[A1], acc0[A0];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = in ? silu(a[e]) : 0.f;
-    *reinterpret_cast<u32x2*>(y1s + quad_addr(q, j, g)) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-  }
-  for (int i = wave >> 1; i < TH; i += NW / 2) {
-    const int q = (i + R) * SX + R + r;
-    f32x4 a = b1y0;
+    for (int k = 0; k < A1; ++k) acc1[k] = b1y1;
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-      a = mfma32(w1f[kt][0], *reinterpret_cast<const u32x4*>(xs + q * 128 + (((kt * 4 + g) ^ (q & 7)) << 4)), a);
-    *reinterpret_cast<u32x2*>(y0s + quad_addr(i * T + r, j, g)) = u32x2{pack_bf16x2(silu(a[0]), silu(a[1])), pack_bf16x2(silu(a[2]), silu(a[3]))};
+    for (int k = 0; k < A0; ++k) acc0[k] = b1y0;
+    for (int c = 0; c < nch; ++c) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of chunk c (and its fragments) has landed
+      __syncthreads();                                  // ... everyone's; everyone is done with the other buffer
+      if (c == 0) UPA_STAMP_AT(1);
+      if (c + 1 < nch) {
+        stage_chunk(c + 1);
+        load_w1(w1n, c + 1);
+      }
+      const char* buf = (c & 1) ? xb2 : xs;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+        for (int k = 0; k < A1; ++k) {
+          const int q = ((wave >> 1) + k * (NW / 2)) * 16 + r;
+          if (q < XPX) acc1[k] = mfma32(w1c[kt][1], *reinterpret_cast<const u32x4*>(buf + q * 128 + (((kt * 4 + g) ^ (q & 7)) << 4)), acc1[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < A0; ++k) {
+          const int i = (wave >> 1) + k * (NW / 2);
+          const int q = (i + R) * SX + R + r;
+          if (i < TH) acc0[k] = mfma32(w1c[kt][0], *reinterpret_cast<const u32x4*>(buf + q * 128 + (((kt * 4 + g) ^ (q & 7)) << 4)), acc0[k]);
+        }
+      }
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) w1c[kt][h2] = w1n[kt][h2];
+    }
+    load_w9(wA, p.wm[0], j, lane);  // the first 3x3 stage's fragments arrive under the SiLU / store epilogue below
+#pragma unroll
+    for (int k = 0; k < A1; ++k) {
+      const int mt = (wave >> 1) + k * (NW / 2);
+      if (mt >= NMT1) break;  // uniform
+      const int q = mt * 16 + r;
+      const int hy = q / SX, hx = q - hy * SX;
+      const int gy = oy0 - R + hy, gx = ox0 - R + hx;
+      const bool in = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = in ? silu(acc1[k][e]) : 0.f;
+      *reinterpret_cast<u32x2*>(y1s + quad_addr(q, j, g)) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    }
+#pragma unroll
+    for (int k = 0; k < A0; ++k) {
+      const int i = (wave >> 1) + k * (NW / 2);
+      if (i >= TH) break;  // uniform
+      *reinterpret_cast<u32x2*>(y0s + quad_addr(i * T + r, j, g)) =
+          u32x2{pack_bf16x2(silu(acc0[k][0]), silu(acc0[k][1])), pack_bf16x2(silu(acc0[k][2]), silu(acc0[k][3]))};
+    }
   }
   load_w9(wB, p.wm[1], j, lane);  // every later stage's weights are fetched one stage ahead
   __syncthreads();  // y1 complete; x is dead
@@ -541,3 +647,38 @@ extern "C" int upa_c2f_fused(const void* x, int n, int h, int w, int c1, int ldx
   UPA_LAUNCH_CHECK();
   return UPA_OK;
 }
+
+// C2f(c1, 64, n = 1) with 32-channel halves and c1 = 64 * nch input channels (yolov8n model.15: 192 = nn.Upsample(128) + Concat(64)) as
+// ONE launch: the c2f32 kernel with cv1 streamed over 64-channel chunks; the first up_c channels of a pixel are read from pixel (y / 2,
+// x / 2) of `up` (n, h / 2, w / 2, up_c) - the upsampled tensor and the concat never exist (up = NULL: all channels from x).  Replaces
+// upa_conv1x1_upcat + upa_bottleneck_pair_cv2 for that block.  Arguments as upa_c2f64_fused.
+extern "C" int upa_c2f32_up_fused(const void* x, int n, int h, int w, int c1, int ldx, const void* up, int up_c, int up_ld, int nb,
+                                  int shortcut, const void* w1, const float* b1, const void* const* wm, const float* const* bm,
+                                  const void* w2, const float* b2, void* y, int c2, int ldy, int act, int dtype, const upa_opts* opts,
+                                  void* stream) {
+  UPA_CHECK_ARG(x && y && w1 && b1 && wm && bm && w2 && b2 && n > 0 && h > 0 && w > 0, "c2f32_up_fused: bad args");
+  const int off = UPA_OPT(opts, c2f);  // 1: never, 3: not the 32-wide forms
+  if (off == 1 || off == 3 || UPA_OPT(opts, no_c2f32_up) || dtype != UPA_BF16 || act != UPA_ACT_SILU || nb != 1 || c2 != 64 || c1 % 64 != 0 || c1 < 128 || c1 > 512 ||
+      ldx % 8 != 0 || ldy % 8 != 0 || ((uintptr_t)x % 16) != 0 || ((uintptr_t)y % 16) != 0 ||
+      (up && (up_c % 64 != 0 || up_c <= 0 || up_c > c1 || up_ld % 8 != 0 || (h & 1) || (w & 1) || ((uintptr_t)up % 16) != 0)) ||
+      (long)n * h * w * (long)(ldx > up_ld ? ldx : up_ld) * 2 >= (1L << 32)) {
+    upa_set_error("c2f32_up_fused: outside the fused form (bf16, SiLU; C2f(64 k, 64, n = 1), even map for the half-resolution source)");
+    return UPA_EUNSUPPORTED;
+  }
+  for (int i = 0; i < 2; ++i) UPA_CHECK_ARG(wm[i] && bm[i], "c2f32_up_fused: null Bottleneck weights");
+  C2f32Params p;
+  memset(&p, 0, sizeof(p));
+  p.x = (const char*)x; p.y = (char*)y; p.w1 = (const char*)w1; p.w2 = (const char*)w2; p.b1 = b1; p.b2 = b2;
+  for (int i = 0; i < 2; ++i) { p.wm[i] = (const char*)wm[i]; p.bm[i] = bm[i]; }
+  p.N = n; p.H = h; p.W = w; p.ldx = ldx; p.ldy = ldy; p.tilesX = cdiv(w, 16); p.tilesY = cdiv(h, 16); p.shortcut = shortcut ? 1 : 0;
+  p.up = (const char*)up; p.c1 = c1; p.upC = up ? up_c : 0; p.up_ld = up_ld;
+  const long tiles = (long)p.tilesX * p.tilesY * n;
+  UPA_CHECK_ARG(tiles < (1L << 31) / 2, "c2f32_up_fused: too many tiles");
+  // LDS of <1, 16>: x region + y1 + y0, + the second chunk buffer
+  const size_t lds = (size_t)20 * 20 * (128 + 64) + (size_t)16 * 16 * 64 + (size_t)20 * 20 * 128;
+  if (upa_full_lds<c2f32_fused_kernel<1, 16, true>>() != hipSuccess) return UPA_ELAUNCH;
+  hipLaunchKernelGGL((c2f32_fused_kernel<1, 16, true>), dim3((unsigned)tiles), dim3(1024), lds, (hipStream_t)stream, p);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+

@@ -87,6 +87,11 @@ class C2f(nn.Module):
     def _form64(self) -> bool:
         return self.c == 64 and self.cv2.conv.out_channels == 128 and self.cv1.conv.in_channels % 64 == 0 and len(self.m) in (1, 2)
 
+    def _form32up(self) -> bool:
+        """C2f(64 k >= 128, 64, n = 1): the 32-channel kernel with cv1 streamed over 64-channel chunks (yolov8n model.15)."""
+        return self.c == 32 and self.cv2.conv.out_channels == 64 and self.cv1.conv.in_channels % 64 == 0 and \
+            128 <= self.cv1.conv.in_channels <= 512 and len(self.m) == 1
+
     def _fused(self, x, out, up=None):
         """One launch for the whole block when it has a fused form; None otherwise.  `up`: a conv.VirtualUpsample for the
         leading channels of x (the 64-channel form reads the half-resolution tensor itself)."""
@@ -94,7 +99,8 @@ class C2f(nn.Module):
         nb = len(self.m)
         c1, c2 = self.cv1.conv.in_channels, self.cv2.conv.out_channels
         form = (c1, self.c, c2)
-        f64 = self._form64()
+        f64 = self._form64() or self._form32up()  # the forms that read a virtual Upsample + Concat themselves
+        fn = L.lib().upa_c2f64_fused if self._form64() else L.lib().upa_c2f32_up_fused
         if not (self.fuse_block and x.dtype == torch.bfloat16 and not self.training
                 and ((form == (32, 16, 32) and nb == 1 and self.m[0].add) or (form == (64, 32, 64) and nb in (1, 2)) or f64)):
             return None
@@ -118,14 +124,14 @@ class C2f(nn.Module):
                     upp, upc, upld = vu.ptr, vu.c, vu.ld
                 else:
                     up.materialize()
-            rc = L.lib().upa_c2f64_fused(vx.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, upp, upc, upld, nb, int(self.m[0].add),
-                                         pk[0].w.data_ptr(), pk[0].bias.data_ptr(), C.cast(wm, C.c_void_p), C.cast(bm, C.c_void_p),
-                                         pk[1].w.data_ptr(), pk[1].bias.data_ptr(), vy.ptr, vy.c, vy.ld, L.ACT_SILU, vx.dtype,
-                                         R.opts_ptr(), L.current_stream(x.device))
+            rc = fn(vx.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, upp, upc, upld, nb, int(self.m[0].add),
+                    pk[0].w.data_ptr(), pk[0].bias.data_ptr(), C.cast(wm, C.c_void_p), C.cast(bm, C.c_void_p),
+                    pk[1].w.data_ptr(), pk[1].bias.data_ptr(), vy.ptr, vy.c, vy.ld, L.ACT_SILU, vx.dtype,
+                    R.opts_ptr(), L.current_stream(x.device))
             if rc == 0:
                 return y
             if rc != L.UPA_EUNSUPPORTED:
-                L.check(rc, "c2f64_fused")
+                L.check(rc, "c2f64_fused / c2f32_up_fused")
             return None  # nothing was launched: the separate convolutions follow, cv1 still reading `up` virtually
         rc = L.lib().upa_c2f_fused(vx.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, self.c, nb, int(self.m[0].add), pk[0].w.data_ptr(),
                                    pk[0].bias.data_ptr(), C.cast(wm, C.c_void_p), C.cast(bm, C.c_void_p), pk[1].w.data_ptr(),
@@ -140,7 +146,7 @@ class C2f(nn.Module):
     def forward(self, x, out=None, up=None):
         """`up`: a conv.VirtualUpsample for the leading channels of x (see BaseModel._predict_once) - consumed by cv1."""
         x = R.to_nhwc(x, x.dtype)
-        if up is not None and self.fuse_block and self.cv1.conv.in_channels in (32, 64) and not self._form64():
+        if up is not None and self.fuse_block and self.cv1.conv.in_channels in (32, 64) and not (self._form64() or self._form32up()):
             up.materialize()  # the narrow whole-block kernels read x themselves
             up = None
         y = self._fused(x, out, up)
