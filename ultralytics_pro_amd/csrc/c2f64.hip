@@ -364,12 +364,12 @@ extern "C" int upa_c2f64_fused(const void* x, int n, int h, int w, int c1, int l
                                const void* w2, const float* b2, void* y, int c2, int ldy, int act, int dtype, const upa_opts* opts,
                                void* stream) {
   UPA_CHECK_ARG(x && y && w1 && b1 && wm && bm && w2 && b2 && n > 0 && h > 0 && w > 0, "c2f64_fused: bad args");
-  const int off = UPA_OPT(opts, c2f);  // 1: never, 4: not this form
+  const int off = UPA_OPT(opts, c2f);  // 1: never, 4: not this form, 6: only the n = 1 blocks (1.16x ring recompute; n = 2: 1.74x)
   // measured on MI355X (round 3): at 40 x 40 (51 k pixels at batch 32) the fused block replaces 4-6 launches that are each one
   // latency-bound round of the chip (yolov8n serial step 1.08 -> 1.02 ms); at 80 x 80 (yolov8s model.4 / model.15, 205 k pixels)
   // the separate launches fill the chip on their own and the tile-ring recompute loses: 20.2 k -> 19.2 k images/s
   const long max_px = UPA_OPT(opts, c2f64_max_px) == 0 ? 100000 : (UPA_OPT(opts, c2f64_max_px) < 0 ? (1L << 40) : UPA_OPT(opts, c2f64_max_px));
-  if (off == 1 || off == 4 || (long)n * h * w > max_px || dtype != UPA_BF16 || act != UPA_ACT_SILU || c2 != 128 || c1 <= 0 || c1 % 64 != 0 || !(nb == 1 || nb == 2) ||
+  if (off == 1 || off == 4 || (off == 6 && nb != 1) || (long)n * h * w > max_px || dtype != UPA_BF16 || act != UPA_ACT_SILU || c2 != 128 || c1 <= 0 || c1 % 64 != 0 || !(nb == 1 || nb == 2) ||
       ldx % 8 != 0 || ldy % 8 != 0 || ((uintptr_t)x % 16) != 0 || ((uintptr_t)y % 16) != 0 ||
       (long)n * h * w * ldx * 2 >= (1L << 32) - 4096 ||
       (up && (up_c <= 0 || up_c % 64 != 0 || up_c >= c1 || up_ld % 8 != 0 || ((uintptr_t)up % 16) != 0 || (h & 1) || (w & 1) ||
