@@ -736,13 +736,14 @@ extern "C" int upa_detect_head_tails(const upa_branch_level* box, const upa_bran
     if (grouping != 1 && ntbc[i] == 5) {
       if (i + 1 < count && ntbc[i + 1] == 5 && bmb[i] == 128 && bmb[i + 1] == 128 && bmc[i] == 128 && bmc[i + 1] == 128) {
         const size_t l = mx(mx(ldsb[i], ldsb[i + 1]), mx(ldsc[i], ldsc[i + 1]));
-        const int rc = big_launch_mix<Box128, Cls128>(pb + i, 2, pc + i, 2, l, s);
+        // longest workgroups first (blockIdx order is dispatch order): class problems (five n-tiles, two channel chunks) before box
+        const int rc = big_launch_mix<Cls128, Box128>(pc + i, 2, pb + i, 2, l, s);
         if (rc == UPA_OK) { i += 2; continue; }
         if (rc != UPA_EUNSUPPORTED) return rc;
       }
       if (bmb[i] == bmc[i]) {
         const size_t l = mx(ldsb[i], ldsc[i]);
-        const int rc = bmb[i] == 128 ? big_launch_mix<Box128, Cls128>(pb + i, 1, pc + i, 1, l, s) : big_launch_mix<Box256, Cls256>(pb + i, 1, pc + i, 1, l, s);
+        const int rc = bmb[i] == 128 ? big_launch_mix<Cls128, Box128>(pc + i, 1, pb + i, 1, l, s) : big_launch_mix<Cls256, Box256>(pc + i, 1, pb + i, 1, l, s);
         if (rc == UPA_OK) { ++i; continue; }
         if (rc != UPA_EUNSUPPORTED) return rc;
       }
@@ -858,7 +859,11 @@ int upa_conv_big_launch_group(const BigParams* probs, int count, int* consumed, 
     if (ok && nt4[0] == 4 && nt4[1] == 4 && nt4[2] == 5 && nt4[3] == 5) {
       size_t l = l4[0];
       for (int i = 1; i < 4; ++i) l = l4[i] > l ? l4[i] : l;
-      const int rc = big_launch_mix<BigCfg<3, 1, 4, 2, 2, 2, 0>, BigCfg<3, 1, 8, 1, 1, 5, 0>>(q, 2, q + 2, 2, l, (hipStream_t)stream);
+      // longest workgroups first: the 80-channel problems before the 64-channel ones, and within a kind the one with more input
+      // channels (more chunks per workgroup: the 20 x 20 level) before the other - blockIdx order is dispatch order
+      const bool sw0 = q[1].Cin > q[0].Cin, sw1 = q[3].Cin > q[2].Cin;
+      const BigParams a[2] = {sw1 ? q[3] : q[2], sw1 ? q[2] : q[3]}, b[2] = {sw0 ? q[1] : q[0], sw0 ? q[0] : q[1]};
+      const int rc = big_launch_mix<BigCfg<3, 1, 8, 1, 1, 5, 0>, BigCfg<3, 1, 4, 2, 2, 2, 0>>(a, 2, b, 2, l, (hipStream_t)stream);
       if (rc == UPA_OK) { *consumed = 4; return UPA_OK; }
       if (rc != UPA_EUNSUPPORTED) return rc;
     }
