@@ -82,6 +82,10 @@ def parse():
     ap.add_argument("--cpu-baseline-child", default=None, metavar="OUT.json",
                     help="internal: run only the CPU baseline leg (no GPU is touched) and keep OUT.json up to date after every "
                          "measured line - bench.py starts itself this way as a child process with a wall-clock limit")
+    ap.add_argument("--parity-out", default=None, metavar="OUT.pt",
+                    help="internal (CPU baseline child): also save the oracle's head output and detections of the headline config's "
+                         "batch - the same procedural images as the GPU's first resident batch - for the parent's `parity` object")
+    ap.add_argument("--no-parity", action="store_true", help="skip the GPU-vs-oracle comparison of the bench line")
     ap.add_argument("--serial", action="store_true",
                     help="no intra-step concurrency (Detect branches on the main stream): per-kernel durations in a "
                          "rocprofv3 trace of this mode are directly comparable with roofline.avg_launch_us")
@@ -342,7 +346,7 @@ def main():
                 "host-visible detections differ from the device rows"
     seen = ranks_seen(dist, dev)
 
-    roofline, kernels, cpu_baseline = None, None, None
+    roofline, kernels, cpu_baseline, parity, gpu_speed = None, None, None, None, None
     serial_ms = latency_ms = forked_ms = None
     if rank == 0 and not args.serial:
         # the same step with no concurrency at all (one linear graph, one stream): back-to-back ms/step, and the latency of
@@ -359,6 +363,37 @@ def main():
                 lat.append(time.perf_counter() - t1)
             latency_ms = sorted(lat)[len(lat) // 2] * 1e3
             del one
+            # the reference's per-stage report (engine/validator.py:253-256 `Speed: ... per image`): the same serial step cut in two -
+            # a graph of the model alone (Detect decode included: it is fused into the head's last convs) timed with events on its
+            # stream, the rest of the serial step (NMS + the copy of the rows to the host) as the difference
+            try:
+                det_, conc_ = model.model[-1], getattr(model.model[-1], "concurrent", None)
+                if conc_ is not None:
+                    det_.concurrent = False  # one chain of launches, as the serial step it is a part of
+                try:
+                    fwd = model.compile(xs[0], post=None)
+                finally:
+                    if conc_ is not None:
+                        det_.concurrent = conc_
+                for _ in range(5):
+                    fwd()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize(dev)
+                e0.record()
+                for _ in range(40):
+                    fwd()
+                e1.record()
+                torch.cuda.synchronize(dev)
+                fwd_ms = e0.elapsed_time(e1) / 40
+                del fwd
+                post_ms = max(serial_ms - fwd_ms, 0.0)
+                gpu_speed = {"forward_ms_per_batch": round(fwd_ms, 4), "postprocess_ms_per_batch": round(post_ms, 4),
+                             "speed": "Speed: %.4fms preprocess, %.4fms inference, %.4fms loss, %.4fms postprocess per image" % (
+                                 0.0, fwd_ms / pb, 0.0, post_ms / pb),
+                             "how": "one step at a time: hipGraph of the model (forward + fused Detect decode) between HIP events; "
+                                    "postprocess = serial_ms_per_step - forward (NMS + detections to pinned host memory)"}
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench] Speed split skipped: {e}", file=sys.stderr)
             # ... and one step at a time WITH the concurrency a single step has: the six Detect branches as parallel branches of
             # its graph (independent chains on the 80 / 40 / 20-pixel maps: the small ones fill the rounds the large ones leave
             # open).  Forked graphs do not combine with several steps in flight on this runtime (0.89 ms against 0.62), so this is a
@@ -384,8 +419,23 @@ def main():
                 roofline["dispatch"] = f"as the timed region: upa_opts {mode}"
             _crumb("kernel profile done")
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
-            cpu_baseline = run_cpu_baseline_bounded(args)
+            import tempfile
+            pdir = tempfile.mkdtemp(prefix="upa_parity_")
+            ppath = os.path.join(pdir, "oracle.pt") if not (args.no_parity or rtdetr) else None
+            cpu_baseline = run_cpu_baseline_bounded(args, parity_out=ppath)
             _crumb("cpu baseline done")
+            if ppath:
+                try:
+                    parity = gpu_parity(args, dev, ppath, model, xs[0], results, pb)
+                except Exception as e:  # noqa: BLE001 - the comparison must never cost the run its throughput line
+                    parity = {"error": f"{type(e).__name__}: {e}"}
+                _crumb("parity vs the oracle done")
+            import shutil
+            shutil.rmtree(pdir, ignore_errors=True)
+    timed_s = ms_per_step * 1e-3 * args.steps
+    if rank == 0 and timed_s < 0.25:
+        print(f"[bench] WARNING: the timed region is {timed_s * 1e3:.1f} ms ({args.steps} steps x {ms_per_step:.3f} ms): below 0.25 s a single "
+              "runtime hiccup moves `value` by several percent; the default (--steps 0) times >= 1 s", file=sys.stderr)
     if rank == 0:
         line = {
             # `value` is the whole-job total over n_gpus ranks of per-GPU batch 32 (the contract); the per-GPU figure of
@@ -400,12 +450,16 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
+            "timed_region_s": round(timed_s, 4),
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic (procedural images + procedural weights, resident in HBM)",
             "rccl_ranks_seen": seen,
+            # the "box/cls match vs CPU ref" half of the metric: this run's GPU output against the oracle's on the same images
+            "parity": parity,
+            "speed": gpu_speed,
             "config": {"workload": f"{args.model} detect 640x640 bs={pb} {args.dtype} inference, 1 hipGraph/step: "
                                    + ("forward+RT-DETR decoder (f32)+postprocess(conf .25, max_det 300)" if rtdetr else
                                       "forward+decode+NMS(conf .25, iou .7, max_det 300)"),
@@ -997,13 +1051,15 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
     }
     # HBM traffic per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see profiles/): only valid for
     # the configuration they were collected on
-    try:
-        pmc = json.loads((ROOT / "profiles" / "r03_pmc_hbm_summary.json").read_text())
-        if pmc.get("config") == f"{args.model} bs={args.batch} {args.dtype}" and dom_name in pmc["kernels"]:
-            roofline["traffic"] = round(pmc["kernels"][dom_name]["hbm_bytes_per_launch"])
-            roofline["traffic_source"] = "profiles/r03_pmc_hbm_summary.json (rocprofv3 --pmc, separate passes)"
-    except (OSError, KeyError, ValueError):
-        pass
+    for pf in sorted((ROOT / "profiles").glob("r*_pmc_hbm_summary.json"), reverse=True):  # the latest round that measured this kernel
+        try:
+            pmc = json.loads(pf.read_text())
+            if pmc.get("config") == f"{args.model} bs={args.batch} {args.dtype}" and dom_name in pmc["kernels"]:
+                roofline["traffic"] = round(pmc["kernels"][dom_name]["hbm_bytes_per_launch"])
+                roofline["traffic_source"] = f"profiles/{pf.name} (rocprofv3 --pmc, separate passes)"
+                break
+        except (OSError, KeyError, ValueError):
+            pass
     kernels = {
         "conv_ms_per_step": round(conv_ms, 4),
         "conv_tflops": round(conv_flops / (conv_ms * 1e-3) / 1e12, 1),
@@ -1016,6 +1072,60 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
                              gbs=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)) for k, v in sorted(fam.items())},
     }
     return roofline, kernels
+
+
+def gpu_parity(args, dev, ppath, model, x0, results, pb):
+    """GPU output vs the oracle's on the SAME batch (rank 0's first resident batch = procedural images 0 .. pb - 1), in the same run:
+      f32  - the parity mode (`--dtype f32`: exact-f32 MFMA): one extra forward + NMS of an f32 copy of the model after the timed
+             region; max |box| / |score| over every anchor of the head output, and the detections row by row (north_star: 1e-3);
+      bf16 - the mode the throughput is quoted in: the detections the TIMED region itself produced for that batch (the static result
+             of compiled copy 0) as a set against the oracle's (one-to-one same-class matches at IoU >= 0.9 / 0.5), plus the head
+             output of one eager forward.
+    The oracle's tensors come from the CPU-baseline child (`--parity-out`); nothing of oracle/ is imported here."""
+    import numpy as np
+
+    from ultralytics_pro_amd.nn.tasks import DetectionModel
+    from ultralytics_pro_amd.utils import parity as PA
+    from ultralytics_pro_amd.utils import procedural as P
+    from ultralytics_pro_amd.utils.nms import non_max_suppression
+
+    if not os.path.exists(ppath):
+        return {"error": "the CPU leg produced no oracle output (cut at its wall-clock limit?)"}
+    ref = torch.load(ppath)
+    y_ref = ref["y"]
+    ref_rows = PA.split_rows(ref["rows"].numpy(), ref["n"])
+    out = {"images": int(y_ref.shape[0]), "oracle": f"oracle (CPU f32, fused eval, {ref['threads']} threads) on procedural images 0..{pb - 1}",
+           "reference_detections": int(sum(ref["n"]))}
+    with torch.no_grad():
+        mf = DetectionModel(args.model + ".yaml")
+        P.apply_procedural_weights(mf)
+        mf = mf.to(dev).eval()
+        mf.set_compute_dtype(torch.float32)
+        x32 = P.synthetic_images(pb, first=0).to(dev)
+        yf = mf(x32)[0]
+        det = [d.cpu().numpy() for d in non_max_suppression(yf, 0.25, 0.7, max_det=300)]
+        d = (yf.cpu() - y_ref).abs()
+        eq, rb, rs = PA.rows_identical(det, ref_rows, 1e-3)
+        out["f32"] = {"max_box_abs_px": float(d[:, :4].max()), "max_score_abs": float(d[:, 4:].max()), "rows_equal": eq,
+                      "rows_max_box_abs_px": rb, "rows_max_score_abs": rs, "detections": int(sum(len(r) for r in det)),
+                      "tolerance": 1e-3, "within_tolerance": bool(d[:, :4].max() <= 1e-3 and d[:, 4:].max() <= 1e-3 and eq)}
+        del mf, yf
+        if args.dtype == "bf16":
+            mine = []
+            for (o_, c_, _) in results:
+                oc, cc = o_.cpu().numpy(), c_.cpu().tolist()
+                mine += [oc[i, :int(cc[i])] for i in range(len(cc))]
+            a9, a5 = PA.detection_agreement(mine, ref_rows, 0.9), PA.detection_agreement(mine, ref_rows, 0.5)
+            yb = model(x0)[0].float().cpu()
+            db = (yb - y_ref).abs()
+            out["bf16"] = {"detections": a9["n_mine"], "recall_iou90": round(a9["recall"], 4), "precision_iou90": round(a9["precision"], 4),
+                           "recall_iou50": round(a5["recall"], 4), "precision_iou50": round(a5["precision"], 4),
+                           "matched_box_p99_px": round(a9["box_p99"], 4), "matched_box_max_px": round(a9["box_max"], 4),
+                           "matched_score_max": round(a9["score_max"], 5),
+                           "head_box_p99_px": float(np.quantile(db[:, :4].numpy().ravel()[::7], 0.99)), "head_box_max_px": float(db[:, :4].max()),
+                           "head_score_max": float(db[:, 4:].max()),
+                           "source": "detections: the timed region's own result for this batch (compiled copy 0); head: one eager forward"}
+    return out
 
 
 def physical_cores() -> int:
@@ -1037,13 +1147,13 @@ def physical_cores() -> int:
 def cpu_baseline_child(args):
     """Child-process entry of the CPU baseline leg: never touches the GPU; the result file is rewritten after every line."""
     out = args.cpu_baseline_child
-    res = run_cpu_train_baseline(args) if args.workload == "train" else run_cpu_baseline(args, progress=out)
+    res = run_cpu_train_baseline(args) if args.workload == "train" else run_cpu_baseline(args, progress=out, parity_out=args.parity_out)
     with open(out, "w") as f:
         json.dump(res, f)
     return 0
 
 
-def run_cpu_baseline_bounded(args, limit_s: float = 150.0):
+def run_cpu_baseline_bounded(args, limit_s: float = 150.0, parity_out: str | None = None):
     """Run the CPU baseline leg as a child process (`bench.py --cpu-baseline-child`) with a hard wall-clock limit.
 
     The leg times torch CPU convolutions at up to all physical cores of a host that bench.py does not own: on a busy or
@@ -1056,6 +1166,8 @@ def run_cpu_baseline_bounded(args, limit_s: float = 150.0):
     os.close(fd)
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", out, "--workload", args.workload, "--model", args.model,
            "--batch", str(args.batch), "--imgsz", str(args.imgsz), "--cpu-threads", str(args.cpu_threads)]
+    if parity_out:
+        cmd += ["--parity-out", parity_out]
     env = dict(os.environ, OMP_WAIT_POLICY="passive", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
     truncated = False
     try:
@@ -1092,7 +1204,7 @@ def _cpu_baseline_result(args, lines, logical, phys):
             "host_logical_cores": logical, "host_physical_cores": phys, "lines": lines}
 
 
-def run_cpu_baseline(args, budget_s: float = 45.0, progress: str | None = None):
+def run_cpu_baseline(args, budget_s: float = 45.0, progress: str | None = None, parity_out: str | None = None):
     """the oracle (CPU restatement, validated bit for bit against the imported reference) on THIS
     host's cores - fused eval, fp32 - for C2 (yolov8n, 32 x 3 x 640 x 640) and C1 (yolov3-tiny, 8 x 3 x 640 x 640), with
     N = 8 threads (the reference's own cap NUM_THREADS = min(8, cpus - 1), utils/__init__.py:43), N = 32 and N = all physical
@@ -1133,6 +1245,12 @@ def run_cpu_baseline(args, budget_s: float = 45.0, progress: str | None = None):
                     onms.non_max_suppression(y, 0.25, 0.7, max_det=300)
                     t2 = time.perf_counter()
                     best_f, best_n = min(best_f, t1 - t0), min(best_n, t2 - t1)
+                    if parity_out and name == args.model and not os.path.exists(parity_out):
+                        # the oracle's answer on the GPU's first resident batch (same procedural images and weights): the parent compares
+                        det = onms.non_max_suppression(y, 0.25, 0.7, max_det=300)
+                        torch.save({"y": y, "rows": torch.cat(det, 0), "n": [int(d.shape[0]) for d in det], "threads": nthr,
+                                    "first_image": 0, "batch": b}, parity_out + ".tmp")
+                        os.replace(parity_out + ".tmp", parity_out)
             per_img_best = min(per_img_best or 1e30, best_f / b)
             lines.append({"config": name, "batch": b, "threads": nthr, "best_of": reps,
                           "forward_img_s": round(b / best_f, 2), "forward_nms_img_s": round(b / (best_f + best_n), 2),

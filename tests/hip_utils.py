@@ -77,59 +77,6 @@ def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
     return float((a - b).abs().max() / (b.abs().max() + 1e-12))
 
 
-def box_iou_np(a: np.ndarray, b: np.ndarray) -> np.ndarray:
-    """IoU matrix of xyxy boxes (n,4) x (m,4)."""
-    area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
-    area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
-    lt = np.maximum(a[:, None, :2], b[None, :, :2])
-    rb = np.minimum(a[:, None, 2:], b[None, :, 2:])
-    inter = np.clip(rb - lt, 0, None).prod(2)
-    return inter / (area_a[:, None] + area_b[None, :] - inter + 1e-12)
-
-
-def match_detections(mine: np.ndarray, ref: np.ndarray, iou_thr: float = 0.9):
-    """One-to-one matching of two detection sets of ONE image (rows [x1,y1,x2,y2,score,cls]): pairs are taken greedily by
-    decreasing IoU among pairs of the SAME class with IoU >= iou_thr.  Returns (pairs [(i_mine, j_ref)], iou of pairs)."""
-    if mine.shape[0] == 0 or ref.shape[0] == 0:
-        return [], np.zeros(0)
-    iou = box_iou_np(mine[:, :4], ref[:, :4])
-    iou = np.where(mine[:, 5][:, None] == ref[:, 5][None, :], iou, 0.0)
-    order = np.dstack(np.unravel_index(np.argsort(-iou, axis=None), iou.shape))[0]
-    used_i, used_j, pairs, vals = set(), set(), [], []
-    for i, j in order:
-        if iou[i, j] < iou_thr:
-            break
-        if i in used_i or j in used_j:
-            continue
-        used_i.add(i)
-        used_j.add(j)
-        pairs.append((int(i), int(j)))
-        vals.append(iou[i, j])
-    return pairs, np.asarray(vals)
-
-
-def detection_agreement(mine_list, ref_list, iou_thr: float = 0.9):
-    """Set agreement of per-image detection lists: recall (matched / reference rows), precision (matched / my rows) and the
-    |box| / |score| deviations of the matched pairs, pooled over the images."""
-    nm = nr = nmatch = 0
-    dbox, dscore = [], []
-    for a, b in zip(mine_list, ref_list):
-        a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
-        pairs, _ = match_detections(a, b, iou_thr)
-        nm, nr, nmatch = nm + a.shape[0], nr + b.shape[0], nmatch + len(pairs)
-        for i, j in pairs:
-            dbox.append(np.abs(a[i, :4] - b[j, :4]))
-            dscore.append(abs(a[i, 4] - b[j, 4]))
-    dbox = np.concatenate(dbox) if dbox else np.zeros(1)
-    dscore = np.asarray(dscore) if dscore else np.zeros(1)
-    return dict(recall=nmatch / max(nr, 1), precision=nmatch / max(nm, 1), n_ref=nr, n_mine=nm,
-                box_p50=float(np.median(dbox)), box_p99=float(np.quantile(dbox, 0.99)), box_max=float(dbox.max()),
-                score_p99=float(np.quantile(dscore, 0.99)), score_max=float(dscore.max()))
-
-
-def split_rows(rows: np.ndarray, counts) -> list:
-    out, o = [], 0
-    for n in counts:
-        out.append(rows[o:o + int(n)])
-        o += int(n)
-    return out
+# detection-set agreement measures: shared with bench.py's `parity` object (ultralytics_pro_amd/utils/parity.py)
+from ultralytics_pro_amd.utils.parity import (box_iou_np, detection_agreement, match_detections, rows_identical,  # noqa: E402,F401
+                                              split_rows)

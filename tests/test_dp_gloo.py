@@ -208,7 +208,7 @@ def test_bench_gpus_flag_launches_ranks_itself():
     from pathlib import Path
     root = Path(__file__).resolve().parents[1]
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    for wl, scaling in (("infer", "weak"), ("train", "weak"), ("infer", "strong"), ("val", "weak")):
+    for wl, scaling in (("infer", "weak"), ("train", "weak"), ("infer", "strong"), ("val", "weak"), ("train", "strong")):
         r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--dry-run",
                             "--workload", wl, "--scaling", scaling], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]

@@ -1072,6 +1072,8 @@ LINEAR_CASES = [
     (64, 96, 32, 1, False),       # K = 96 (three 32-channel units), SiLU in f32 (expf + IEEE divide)
     (50, 4, 512, 2, False),       # K = 4 (query_pos_head's first layer): outside the small-M form -> the conv kernel
     (20, 48, 40, 0, True),        # K = 48: not a multiple of 32 -> the conv kernel
+    (20000, 256, 1024, 2, False), # many rows AND wide N (16 column blocks): gated off the small-M form -> the conv kernel
+    (20000, 256, 256, 0, True),   # many rows, 4 column blocks: stays on the small-M form (the RT-DETR encoder's shape class)
 ]
 
 

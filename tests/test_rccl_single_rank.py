@@ -56,3 +56,58 @@ def test_rccl_initialises_and_runs_the_exchange_primitives_on_one_rank():
     except subprocess.TimeoutExpired:
         pytest.skip("RCCL initialisation did not complete within 240 s on this box")
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+TRAIN_CHILD = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["UPA_ROOT"])
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", device_id=torch.device("cuda:0"))
+from ultralytics_pro_amd.engine.trainer import DetectionTrainer
+from ultralytics_pro_amd.nn.tasks import DetectionModel
+from ultralytics_pro_amd.utils import procedural as P
+dev = torch.device("cuda:0")
+x = P.synthetic_images(4, h=256, w=256).to(dev)
+lab = P.synthetic_labels(4)
+
+def run(bucketed):
+    m = DetectionModel("yolov8n.yaml")
+    P.apply_procedural_weights(m)
+    tr = DetectionTrainer(m, dtype=torch.float32, device=dev, world_size=2)   # the N > 1 code path on the one rank there is
+    table = None
+    if bucketed:
+        table = tr.enable_overlapped_allreduce(target_bytes=2 << 20)           # several buckets on yolov8n's 12.6 MB of gradients
+        tr._buckets.active = lambda: True
+        assert len(table) >= 3
+    items = [tr.step(x, lab).clone() for _ in range(3)]
+    torch.cuda.synchronize()
+    exposed = tr.allreduce_exposed_ms()
+    n = tr.groups[-1][0] + tr.groups[-1][1]
+    return torch.stack(items).cpu(), tr.P[:n].clone().cpu(), exposed, table
+
+it_b, p_b, exposed, table = run(True)
+it_s, p_s, none_, _ = run(False)
+assert none_ is None                                   # nothing is recorded without buckets
+assert exposed is not None and exposed >= 0.0, exposed  # the eager bucketed mode reports the wait it exposed (bench: allreduce_exposed_ms)
+assert torch.equal(it_b, it_s) and torch.equal(p_b, p_s), "bucketed exchange (SUM over one rank) must leave the step bit-identical"
+# every layer span was issued from the backward walk or by the late path; none is left pending
+dist.barrier(); dist.destroy_process_group()
+print("TRAIN_RCCL_OK buckets", [t[0] for t in table], "exposed_ms", round(exposed, 4))
+"""
+
+
+def test_trainer_bucketed_exchange_over_rccl_reports_exposed_time_and_equals_single_allreduce():
+    """engine/trainer.py on RCCL with the one rank of this box: eager steps with `enable_overlapped_allreduce` (buckets issued from the
+    backward walk on the communication stream behind events of the main and weight-gradient streams, late spans behind the same
+    events) give bit-identical loss items and weights to the single all-reduce, and `allreduce_exposed_ms()` - the figure
+    `bench.py --workload train --gpus N` prints - is populated in that mode."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", UPA_ROOT=str(ROOT))
+    try:
+        r = subprocess.run([sys.executable, "-c", TRAIN_CHILD], env=env, capture_output=True, text=True, timeout=420)
+    except subprocess.TimeoutExpired:
+        pytest.skip("RCCL initialisation / the training child did not complete within 420 s on this box")
+    assert r.returncode == 0 and "TRAIN_RCCL_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])

@@ -1,7 +1,10 @@
 #!/bin/bash
-# Regenerates the numbers profiles/ holds (run on the GPU box; outputs under gpurun_out/final_r03/, copied into profiles/ by hand).
+# Regenerates the numbers profiles/ holds (run on the GPU box; outputs under gpurun_out/final_<round>/, copied into profiles/ as
+# <round>_* by tools/copy_profiles.sh).  ROUND=r04 by default.  This script and the copy step only ever ADD files named after the
+# current round: rows and files of earlier rounds in profiles/ (and in profiles/README.md) are history and are never rewritten.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/final_r03
+ROUND=${ROUND:-r04}
+O=$R/gpurun_out/final_$ROUND
 rm -rf $O/prof_default $O/prof_serial $O/prof_train   # stale traces of earlier calls would shadow this one's stats
 mkdir -p $O
 cd $R

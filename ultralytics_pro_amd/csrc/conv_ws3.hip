@@ -101,6 +101,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_ws3_kernel(const BigParams p)
   if (t >= numTiles) return;
   const f32x4 biasv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + wave * 16 + g * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
   stage_halo(t, 0);
+  // The first-tile wait below counts on program order "halo DMA, then exactly 18 weight loads": pin it.  The empty asm with a memory
+  // clobber keeps IR passes from hoisting a weight load above the DMA, the scheduling barrier keeps the machine scheduler from it.
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
   // this wave's weights: fragment (tap, kt) of n-tile `wave`  <-  packed [tap][KTT][NTn][lane][16 B]; 18 x 16 B per lane
   u32x4 wr[9][2];
 #pragma unroll

@@ -500,6 +500,10 @@ extern "C" int upa_linear(const float* x, long m, int k, int ldx, const void* w_
   const bool small = x && w_packed && y && k % 32 == 0 && k <= 1024 && n % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 &&
                      (!residual || ldr % 4 == 0) && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
                      (!residual || (uintptr_t)residual % 16 == 0) && (!bias || (uintptr_t)bias % 16 == 0) && m <= (1 << 20) &&
+                     // every 64-column block of the grid re-stages the workgroup's x rows: measured a win for the decoder's 4800-row
+                     // GEMMs at any N and for the encoder's 134 k-row ones at N <= 256 (4 column blocks); beyond both - many rows AND
+                     // many column blocks - x would be read N / 64 times, so those go to the conv kernel
+                     (m <= 16384 || n <= 256) &&
                      (act == UPA_ACT_NONE || act == UPA_ACT_RELU || act == UPA_ACT_SILU);
   if (small) {
     LinParams p;

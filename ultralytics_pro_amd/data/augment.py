@@ -41,14 +41,14 @@ class LetterBox:
         if isinstance(new_shape, int):
             new_shape = (new_shape, new_shape)
         r = min(new_shape[0] / shape[0], new_shape[1] / shape[1])
-        if not self.scaleup:  # only scale down, do not scale up (for better val mAP)
+        if not self.scaleup:  # never enlarge a frame, shrink only
             r = min(r, 1.0)
         ratio = r, r
         new_unpad = round(shape[1] * r), round(shape[0] * r)
         dw, dh = new_shape[1] - new_unpad[0], new_shape[0] - new_unpad[1]
-        if self.auto:  # minimum rectangle
+        if self.auto:  # pad just up to the next multiple of the stride
             dw, dh = np.mod(dw, self.stride), np.mod(dh, self.stride)
-        elif self.scale_fill:  # stretch
+        elif self.scale_fill:  # fill the target exactly: independent x / y ratios, no border
             dw, dh = 0.0, 0.0
             new_unpad = (new_shape[1], new_shape[0])
             ratio = new_shape[1] / shape[1], new_shape[0] / shape[0]

@@ -18,11 +18,22 @@ from .. import _lib as L
 
 # ---- dispatch options of the calls being made (upa_opts, include/upa.h) -------------------------------------------------
 # The C library keeps no mode: every entry point that dispatches among kernel families takes a caller-owned `upa_opts*`.
-# On the Python side the options in force are a stack: BaseModel._predict_once pushes its model's `opts` (two models in one
-# process can differ), the parity tests and sweep tools wrap calls in `use_opts(L.Opts(...))`; the bottom of the stack is
-# `_DEFAULT_OPTS` (None = the library defaults; tests/conftest.py sets one so that every kernel family sees small shapes).
-_OPTS = []
+# On the Python side the options in force are a stack PER THREAD (upa.h promises per-thread re-entrancy, and two models walked by two
+# Python threads must not see each other's pushes or pop each other's entries): BaseModel._predict_once pushes its model's `opts`
+# (two models in one process can differ), the parity tests and sweep tools wrap calls in `use_opts(L.Opts(...))`; below every
+# thread's stack sits the process-wide `_DEFAULT_OPTS` (None = the library defaults; tests/conftest.py sets one so that every
+# kernel family sees small shapes).
+import threading
+
+_TLS = threading.local()
 _DEFAULT_OPTS = [None]
+
+
+def _stack():
+    st = getattr(_TLS, "opts", None)
+    if st is None:
+        st = _TLS.opts = []
+    return st
 
 
 def set_default_opts(opts):
@@ -31,7 +42,8 @@ def set_default_opts(opts):
 
 
 def current_opts():
-    return _OPTS[-1] if _OPTS else _DEFAULT_OPTS[0]
+    st = _stack()
+    return st[-1] if st else _DEFAULT_OPTS[0]
 
 
 def opts_ptr():
@@ -42,15 +54,16 @@ def opts_ptr():
 
 @contextlib.contextmanager
 def use_opts(opts=None, **fields):
-    """Run the enclosed calls with `opts` (an `_lib.Opts`), or with the options in force changed by `fields`."""
+    """Run the enclosed calls of THIS thread with `opts` (an `_lib.Opts`), or with the options in force changed by `fields`."""
     if fields:
         base = opts if opts is not None else current_opts()
         opts = (base.replace(**fields) if base is not None else L.Opts(**fields))
-    _OPTS.append(opts)
+    st = _stack()
+    st.append(opts)
     try:
         yield opts
     finally:
-        _OPTS.pop()
+        st.pop()
 
 
 @dataclass

@@ -651,8 +651,18 @@ class DetectionTrainer:
                 main = torch.cuda.current_stream(self.device)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(main)
-                for k in range(len(b.buckets)):  # (a span the walk never reached - a layer without gradient - goes now)
-                    b.issue(k)
+                # a span the walk never hooked (parameters outside `model.<N>.*`: layer -1, or a layer without gradient) goes now:
+                # backward has finished on the HOST side only, so the communication stream is ordered behind the main stream and
+                # every weight-gradient stream first, exactly as `_bucket_hook` does
+                late = [k for k in range(len(b.buckets)) if k not in b.issued]
+                if late:
+                    evs = []
+                    for st in [main] + list(self.ctx.wgrad_streams):
+                        ev = torch.cuda.Event()
+                        ev.record(st)
+                        evs.append(ev)
+                    for k in late:
+                        b.issue(k, evs)
                 b.wait()
                 e1.record(main)
                 self._exposed.append((e0, e1))
