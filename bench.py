@@ -1105,10 +1105,14 @@ def gpu_parity(args, dev, ppath, model, x0, results, pb):
         yf = mf(x32)[0]
         det = [d.cpu().numpy() for d in non_max_suppression(yf, 0.25, 0.7, max_det=300)]
         d = (yf.cpu() - y_ref).abs()
-        eq, rb, rs = PA.rows_identical(det, ref_rows, 1e-3)
-        out["f32"] = {"max_box_abs_px": float(d[:, :4].max()), "max_score_abs": float(d[:, 4:].max()), "rows_equal": eq,
-                      "rows_max_box_abs_px": rb, "rows_max_score_abs": rs, "detections": int(sum(len(r) for r in det)),
-                      "tolerance": 1e-3, "within_tolerance": bool(d[:, :4].max() <= 1e-3 and d[:, 4:].max() <= 1e-3 and eq)}
+        eq, _, _ = PA.rows_identical(det, ref_rows, 1e-3)
+        rq = PA.rows_equivalent(det, ref_rows, 1e-3, 0.25, 0.7)
+        out["f32"] = {"max_box_abs_px": float(d[:, :4].max()), "max_score_abs": float(d[:, 4:].max()),
+                      "detections": int(sum(len(r) for r in det)), "rows_equal": eq,
+                      # rows whose presence a threshold decides within the tolerance (score within 1e-3 of conf, IoU within 1e-3 of
+                      # iou_thres, or overlapping such a row) are counted and excused; every other row must have its partner
+                      "rows": rq, "tolerance": 1e-3,
+                      "within_tolerance": bool(d[:, :4].max() <= 1e-3 and d[:, 4:].max() <= 1e-3 and rq["equivalent"])}
         del mf, yf
         if args.dtype == "bf16":
             mine = []

@@ -78,5 +78,5 @@ def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
 
 
 # detection-set agreement measures: shared with bench.py's `parity` object (ultralytics_pro_amd/utils/parity.py)
-from ultralytics_pro_amd.utils.parity import (box_iou_np, detection_agreement, match_detections, rows_identical,  # noqa: E402,F401
-                                              split_rows)
+from ultralytics_pro_amd.utils.parity import (box_iou_np, detection_agreement, match_detections, rows_equivalent,  # noqa: E402,F401
+                                              rows_identical, split_rows)

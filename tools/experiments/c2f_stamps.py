@@ -20,7 +20,12 @@ def main():
     ap.add_argument("--layer", type=int, default=6)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--no-stamps", action="store_true", help="timing only (any library)")
+    ap.add_argument("--opts", default="", help="upa_opts fields as name=value,... for every call of this process (A/B)")
     args = ap.parse_args()
+    if args.opts:
+        from ultralytics_pro_amd import _lib as L
+        from ultralytics_pro_amd.engine import runtime as R
+        R.set_default_opts(L.Opts(**{k: int(v) for k, v in (kv.split("=") for kv in args.opts.split(","))}))
     dev = torch.device("cuda:0")
     m = DetectionModel(args.model + ".yaml")
     P.apply_procedural_weights(m)

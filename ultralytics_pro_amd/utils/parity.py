@@ -82,3 +82,46 @@ def rows_identical(mine_list, ref_list, tol: float = 1e-3):
             dbox = max(dbox, float(np.abs(a[:, :4] - b[:, :4]).max()))
             dscore = max(dscore, float(np.abs(a[:, 4] - b[:, 4]).max()))
     return bool(equal and dbox <= tol and dscore <= tol), dbox, dscore
+
+
+def rows_equivalent(mine_list, ref_list, tol: float = 1e-3, conf_thres: float = 0.25, iou_thres: float = 0.7, iou_tol: float = 1e-3):
+    """The f32 parity statement for whole batches: both sides ran the same arithmetic to within `tol`, so every row of one side must
+    have a partner on the other (same class, IoU >= 0.99, box and score within `tol`) EXCEPT rows whose presence is decided by a
+    threshold within that tolerance - NMS output is a step function of its inputs:
+      (a) the row's score is within `tol` of `conf_thres` (nms.py:76: kept on one side, filtered on the other);
+      (b) the row's IoU with a same-class row (of either side) is within `iou_tol` of `iou_thres` (nms.py:283: `iou <= thr` keeps);
+      (c) the row overlaps (IoU > iou_thres, same class) a row that is itself unmatched and excused: it was suppressed by / survives
+          because of a row of kind (a) - (d);
+      (d) the row overlaps (IoU > iou_thres, same class) a row whose score is within `tol` of its own: greedy NMS visits candidates
+          in score order (nms.py:264), so which of two overlapping near-ties survives is decided below the tolerance.
+    Returns a dict: equivalent (bool), matched, unmatched, explained, max |box| / |score| deviation of the matched pairs."""
+    matched = unmatched = explained = 0
+    dbox = dscore = 0.0
+    for a, b in zip(mine_list, ref_list):
+        a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+        pairs, _ = match_detections(a, b, 0.99)
+        matched += len(pairs)
+        for i, j in pairs:
+            dbox = max(dbox, float(np.abs(a[i, :4] - b[j, :4]).max()))
+            dscore = max(dscore, abs(float(a[i, 4] - b[j, 4])))
+        ui = sorted(set(range(a.shape[0])) - {i for i, _ in pairs})
+        uj = sorted(set(range(b.shape[0])) - {j for _, j in pairs})
+        if not ui and not uj:
+            continue
+        rows = np.concatenate([a, b], 0)                       # every row of either side
+        um = np.zeros(rows.shape[0], dtype=bool)
+        um[ui] = True
+        um[[a.shape[0] + j for j in uj]] = True
+        iou = box_iou_np(rows[:, :4], rows[:, :4])
+        iou = np.where(rows[:, 5][:, None] == rows[:, 5][None, :], iou, 0.0)
+        np.fill_diagonal(iou, 0.0)
+        ok = np.zeros(rows.shape[0], dtype=bool)
+        ok |= um & (np.abs(rows[:, 4] - conf_thres) <= tol)                                 # (a)
+        ok |= um & (np.abs(iou - iou_thres) <= iou_tol).any(1)                              # (b)
+        ok |= um & ((iou > iou_thres) & (np.abs(rows[:, 4][:, None] - rows[:, 4][None, :]) <= tol)).any(1)  # (d)
+        for _ in range(4):                                                                  # (c), a few rounds of propagation
+            ok |= um & ((iou > iou_thres) & (um & ok)[None, :]).any(1)
+        unmatched += int(um.sum())
+        explained += int((um & ok).sum())
+    return dict(equivalent=bool(unmatched == explained and dbox <= tol and dscore <= tol), matched=matched, unmatched=unmatched,
+                explained_by_threshold_ties=explained, max_box_abs_px=dbox, max_score_abs=dscore)
