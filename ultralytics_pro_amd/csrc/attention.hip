@@ -111,6 +111,149 @@ __global__ __launch_bounds__(64 * KP) void mhsa_kernel(const char* q, const char
   }
 }
 
+// =====================================================================================================================
+// bf16, d = 32 (BoT3's MHSA on the hot path: 4 heads x 32 dims, 400 keys): the same attention on the matrix cores.
+// One wave owns 16 queries and walks the keys in blocks of 32 with an online softmax; both GEMMs are transposed so that a lane
+// keeps ONE query for the whole walk:
+//   S^T (keys x queries)  = K . Q^T   A = 16 keys x 32 dims from the K image in LDS ([key][64 B], 16-byte groups XOR-swizzled by
+//                                     key >> 1: conflict-free ds_read_b128), B = the wave's 16 queries (registers, loaded once);
+//                                     D: lane (g, r) holds keys 4g .. 4g + 3 of the tile for query r: the softmax statistics of a
+//                                     query live in its four lanes (two butterfly steps), none cross queries;
+//   O^T (dims x queries) += V^T . P^T  B = P^T: the exponentials of two S^T tiles packed to bf16 ARE a B operand (k order: keys
+//                                     4g + e of the first tile, then of the second - the conv_big tail trick), A = 16 dims x those 32
+//                                     keys from a TRANSPOSED V image in LDS ([dim][key], pitch = 4 mod 8 dwords: conflict-free
+//                                     ds_read_b64); D: lane (g, r): dims 4g .. 4g + 3 of query r, so the running rescale
+//                                     exp2(m_old - m_new) of query r multiplies registers of the lane that computed it.
+// 4 MFMAs per 32 keys x 16 queries instead of ~2 k FMAs + 2 accurate expf per (query, key) on the vector ALU: 176 us -> see DESIGN.md.
+// exp via v_exp_f32 on log2(e)-scaled scores (the scale of nn.MultiheadAttention folds into the same multiply), P rounded to bf16
+// (the values being averaged are bf16 already); f32 accumulation, f32 residual add, one rounding of the output as before.
+// =====================================================================================================================
+typedef __attribute__((address_space(1))) const void* agptr_t;
+typedef __attribute__((address_space(3))) void* alptr_t;
+__device__ __attribute__((aligned(16))) unsigned g_mhsa_zero16[4] = {0u, 0u, 0u, 0u};
+
+__global__ __launch_bounds__(512) void mhsa_mfma_bf16_d32_kernel(const char* q, const char* k, const char* v, int ld, int L, int Lp, int VP,
+                                                                 int heads, const char* res, int ldr, char* y, int ldy, float c_log2) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  char* ks = sm;                       // [Lp][64 B]
+  char* vt = sm + (size_t)Lp * 64;     // [32][VP dwords]
+  const int tid = threadIdx.x, lane = tid & 63, NT = blockDim.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, r = lane & 15;
+  const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+  const size_t pix0 = (size_t)b * L;
+  // ---- K by LDS-DMA (slot i of the image = 16-byte group (i & 3) ^ swz of key i >> 2; zero page past L)
+  for (int base = wave * 64; base < Lp * 4; base += NT) {
+    const int i = base + lane, key = i >> 2, cg = (i & 3) ^ ((key >> 1) & 3);
+    const char* src = key < L ? k + ((pix0 + key) * (size_t)ld + h * 32 + cg * 8) * 2 : reinterpret_cast<const char*>(g_mhsa_zero16);
+    __builtin_amdgcn_global_load_lds((agptr_t)src, (alptr_t)(ks + base * 16), 16, 0, 0);
+  }
+  // ---- V transposed: item = (key, 8 dims) -> eight 2-byte stores
+  for (int i = tid; i < Lp * 4; i += NT) {
+    const int key = i >> 2, dg = i & 3;
+    u32x4 x = u32x4{0u, 0u, 0u, 0u};
+    if (key < L) x = *reinterpret_cast<const u32x4*>(v + ((pix0 + key) * (size_t)ld + h * 32 + dg * 8) * 2);
+    unsigned short* col = reinterpret_cast<unsigned short*>(vt) + key;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      col[(size_t)(dg * 8 + 2 * e) * VP * 2] = (unsigned short)(x[e] & 0xFFFFu);
+      col[(size_t)(dg * 8 + 2 * e + 1) * VP * 2] = (unsigned short)(x[e] >> 16);
+    }
+  }
+  // this wave's queries
+  const int q0 = (blockIdx.y * (NT >> 6) + wave) * 16;
+  const int qi = q0 + r;
+  u32x4 qB = u32x4{0u, 0u, 0u, 0u};
+  if (qi < L) qB = *reinterpret_cast<const u32x4*>(q + ((pix0 + qi) * (size_t)ld + h * 32 + g * 8) * 2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (q0 >= L) return;  // (after the barrier: every wave takes part in the staging)
+
+  float m = -INFINITY, l = 0.f;
+  f32x4 o0 = f32x4{0.f, 0.f, 0.f, 0.f}, o1 = o0;
+  const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+  const char* vrow0 = vt + ((size_t)r * VP + 2 * g) * 4;          // dims r / 16 + r, keys 4g .. of a block
+  const char* vrow1 = vt + ((size_t)(16 + r) * VP + 2 * g) * 4;
+  for (int kb = 0; kb < Lp; kb += 32) {
+    const int k0 = kb + r, k1 = kb + 16 + r;
+    const u32x4 a0 = *reinterpret_cast<const u32x4*>(ks + k0 * 64 + ((g ^ ((k0 >> 1) & 3)) << 4));
+    const u32x4 a1 = *reinterpret_cast<const u32x4*>(ks + k1 * 64 + ((g ^ ((k1 >> 1) & 3)) << 4));
+    f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a0), *reinterpret_cast<const bf16x8*>(&qB), z, 0, 0, 0);
+    f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a1), *reinterpret_cast<const bf16x8*>(&qB), z, 0, 0, 0);
+    // the V^T fragments of this block (independent of the softmax: issued early)
+    const u32x2 v00 = *reinterpret_cast<const u32x2*>(vrow0 + kb * 2), v01 = *reinterpret_cast<const u32x2*>(vrow0 + kb * 2 + 32);
+    const u32x2 v10 = *reinterpret_cast<const u32x2*>(vrow1 + kb * 2), v11 = *reinterpret_cast<const u32x2*>(vrow1 + kb * 2 + 32);
+    float t[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      t[e] = s0[e] * c_log2;
+      t[4 + e] = s1[e] * c_log2;
+    }
+    if (kb + 32 > L) {  // the last block: keys past L do not exist
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (kb + 4 * g + e >= L) t[e] = -INFINITY;
+        if (kb + 16 + 4 * g + e >= L) t[4 + e] = -INFINITY;
+      }
+    }
+    float bm = fmaxf(fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3])), fmaxf(fmaxf(t[4], t[5]), fmaxf(t[6], t[7])));
+    bm = fmaxf(bm, __shfl_xor(bm, 16));
+    bm = fmaxf(bm, __shfl_xor(bm, 32));
+    const float mn = fmaxf(m, bm);  // finite: the first block always holds a key
+    const float alpha = __builtin_amdgcn_exp2f(m - mn);
+    float pe[8], ps = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      pe[e] = __builtin_amdgcn_exp2f(t[e] - mn);
+      ps += pe[e];
+    }
+    l = l * alpha + ps;
+    m = mn;
+    o0 *= alpha;
+    o1 *= alpha;
+    const u32x4 pB = u32x4{pack_bf16x2(pe[0], pe[1]), pack_bf16x2(pe[2], pe[3]), pack_bf16x2(pe[4], pe[5]), pack_bf16x2(pe[6], pe[7])};
+    const u32x4 av0 = u32x4{v00[0], v00[1], v01[0], v01[1]}, av1 = u32x4{v10[0], v10[1], v11[0], v11[1]};
+    o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&av0), *reinterpret_cast<const bf16x8*>(&pB), o0, 0, 0, 0);
+    o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&av1), *reinterpret_cast<const bf16x8*>(&pB), o1, 0, 0, 0);
+  }
+  l += __shfl_xor(l, 16);
+  l += __shfl_xor(l, 32);
+  if (qi >= L) return;
+  const float inv = 1.0f / l;
+  const size_t row = pix0 + qi;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const f32x4 o = j ? o1 : o0;
+    float val[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) val[e] = o[e] * inv;
+    const int d0 = h * 32 + 16 * j + 4 * g;
+    if (res) {
+      const u32x2 rv = *reinterpret_cast<const u32x2*>(res + (row * (size_t)ldr + d0) * 2);
+      val[0] += __uint_as_float(rv[0] << 16); val[1] += __uint_as_float(rv[0] & 0xFFFF0000u);
+      val[2] += __uint_as_float(rv[1] << 16); val[3] += __uint_as_float(rv[1] & 0xFFFF0000u);
+    }
+    *reinterpret_cast<u32x2*>(y + (row * (size_t)ldy + d0) * 2) = u32x2{pack_bf16x2(val[0], val[1]), pack_bf16x2(val[2], val[3])};
+  }
+}
+
+static int launch_mhsa_mfma(const void* q, const void* k, const void* v, int ld, int n, int hw, int heads, const void* residual, int ldr,
+                            void* y, int ldy, float scale, hipStream_t s) {
+  const int Lp = (hw + 31) & ~31;
+  const int VP = Lp / 2 + 4;  // dwords per V^T row: = 4 mod 8 -> the 16 rows of a ds_read_b64 half hit 16 distinct bank quads
+  const size_t lds = (size_t)Lp * 64 + (size_t)32 * VP * 4;
+  if (lds > 158 * 1024) return UPA_EUNSUPPORTED;
+  const int tiles = cdiv(hw, 16);
+  const int chunks = cdiv(tiles, 8);              // query chunks per (image, head)
+  const int waves = cdiv(tiles, chunks);          // 25 tiles -> 4 chunks x 7 waves
+  (void)upa_full_lds<mhsa_mfma_bf16_d32_kernel>();
+  hipLaunchKernelGGL(mhsa_mfma_bf16_d32_kernel, dim3((unsigned)(n * heads), (unsigned)chunks), dim3(64 * waves), lds, s, (const char*)q,
+                     (const char*)k, (const char*)v, ld, hw, Lp, VP, heads, (const char*)residual, ldr, (char*)y, ldy,
+                     scale * 1.4426950408889634f);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
 template <typename T, int D>
 static int launch_mhsa(const void* q, const void* k, const void* v, int ld, int n, int hw, int heads, const void* residual,
                        int ldr, void* y, int ldy, float scale, hipStream_t s) {
@@ -135,6 +278,10 @@ extern "C" int upa_mhsa(const void* q, const void* k, const void* v, int ldqkv, 
   const int es = upa_elem_size(dtype);
   UPA_CHECK_ARG(ldqkv % (16 / es) == 0 && ldy % (16 / es) == 0, "mhsa: strides must be multiples of 16 bytes");
   hipStream_t s = (hipStream_t)stream;
+  if (dtype == UPA_BF16 && d == 32 && hw >= 16 && ldr % 4 == 0) {  // the matrix-core form (8-byte residual / output groups)
+    const int rc = launch_mhsa_mfma(q, k, v, ldqkv, n, hw, heads, residual, ldr, y, ldy, scale, s);
+    if (rc != UPA_EUNSUPPORTED) return rc;
+  }
 #define UPA_MHSA_CASE(DD)                                                                                         \
   if (d == DD)                                                                                                    \
     return dtype == UPA_BF16 ? launch_mhsa<bf16_t, DD>(q, k, v, ldqkv, n, hw, heads, residual, ldr, y, ldy, scale, s)     \
