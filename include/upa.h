@@ -92,6 +92,16 @@ typedef struct upa_conv_problem {
 int upa_conv2d_bias_act_group(const upa_conv_problem* probs, int count, int k, int stride, int pad, int act, int dtype,
                               const upa_opts* opts, void* stream);
 
+/* Conv(k 3, s 1, p 1) + SiLU followed by nn.MaxPool2d(2, 2, 0) as one launch (cfg/models/v3/Detect/yolov3-tiny.yaml:12-19; conv.py:188-197
+ * + torch.nn.MaxPool2d): y = the pooled (n, h / 2, w / 2, cout) view; the full-resolution activation is never written.  Bit-identical
+ * to upa_conv2d_bias_act + upa_maxpool2d.  UPA_EUNSUPPORTED outside the fused form (bf16, h % 8 == 0, w % 16 == 0, cin <= 128,
+ * cout % 32 == 0): the caller runs the two layers.  upa_conv2d_stem_nchw_pool2: the same for the first layer (NCHW / uint8 input). */
+int upa_conv2d_pool2(const void* x, int n, int h, int w, int cin, int ldx, const void* w_packed, const float* bias, void* y, int cout,
+                     int ldy, int k, int stride, int pad, int act, int dtype, const upa_opts* opts, void* stream);
+int upa_conv2d_stem_nchw_pool2(const void* x_nchw, int x_dtype, int n, int cin, int h, int w, const float* w_oihw, const float* bias,
+                               void* y, int cout, int ldy, int k, int stride, int pad, int act, int dtype, const upa_opts* opts,
+                               void* stream);
+
 /* Introspection for benchmarks: the kernel instantiation (WM<<12 | WN<<8 | MTW<<4 | NTW) the call above would use. */
 int upa_conv_variant(int n, int h, int w, int cin, int cout, int k, int stride, int pad, int dtype, const upa_opts* opts);
 

@@ -896,3 +896,28 @@ def test_e2e_bf16_layer_by_layer_vs_rounding_point_emulation():
     assert rows[1][0] >= 0.999 and rows[1][2] <= 4.0, "the fused stem must reproduce the emulation up to one-ulp boundary flips"
     assert rows[2][0] >= 0.995 and rows[3][0] >= 0.985 and rows[4][0] >= 0.88
     assert min(r[0] for r in rows.values()) >= 0.35 and min(r[1] for r in rows.values()) >= 0.70
+
+
+def test_e2e_yolov3_tiny_conv_pool_fusion_is_exact():
+    """yolov3-tiny in bf16: rows 0-7 alternate Conv and nn.MaxPool2d(2, 2, 0); `BaseModel.fuse_pool` runs each such pair whose conv
+    output nobody else reads as one launch (rows 0-1, 2-3, 4-5, 6-7; row 8 feeds the route, so 8-9 stay apart).  Same arithmetic,
+    same rounding points: the decoded head output must be bit-identical with the switch off, eagerly and in a replayed hipGraph."""
+    from tests.hip_utils import DEV
+    m = _build("yolov3-tiny", torch.bfloat16)
+    x = P.synthetic_images(3).to(DEV).to(torch.bfloat16).contiguous()
+    calls = []
+    for row in (0, 2, 4, 6, 8):
+        f = m.model[row].forward_pool2
+        m.model[row].forward_pool2 = (lambda xx, f=f, row=row: (calls.append(row), f(xx))[1])
+    try:
+        with torch.no_grad():
+            y_fused = m(x)[0].clone()
+            run = m.compile(x)
+            y_graph = run()[0].clone()
+            type(m).fuse_pool = False
+            y_plain = m(x)[0].clone()
+    finally:
+        type(m).fuse_pool = True
+    torch.cuda.synchronize()
+    assert sorted(set(calls)) == [0, 2, 4, 6], calls  # row 8's output is saved for the route: not offered
+    assert torch.equal(y_fused, y_plain) and torch.equal(y_graph, y_plain)

@@ -1242,3 +1242,44 @@ def test_detect_head_tails_equal_single_launches():
     assert torch.equal(ys[0], ys[2]) and torch.equal(ys[1], ys[2]) and torch.equal(keys[0], keys[2]) and torch.equal(keys[1], keys[2])
     assert int((ys[0] == -7.0).sum()) == 0 and int((keys[0] == -1).sum()) == 0
 
+
+
+POOL_CASES = [  # cin, cout, n, h, w  (cin 3 = the first layer on an NCHW image)
+    (3, 16, 2, 64, 128), (3, 16, 1, 40, 72), (3, 32, 1, 16, 64),
+    (16, 32, 2, 32, 48), (32, 64, 1, 24, 32), (64, 128, 2, 16, 16), (24, 96, 1, 8, 32),
+]
+
+
+@pytest.mark.parametrize("case", POOL_CASES, ids=[f"c{c[0]}-{c[1]}_{c[2]}x{c[3]}x{c[4]}" for c in POOL_CASES])
+def test_conv_maxpool_fused_equals_two_launches(case):
+    """`Conv.forward_pool2` (`upa_conv2d_stem_nchw_pool2` / `upa_conv2d_pool2`): Conv(k 3, s 1) + SiLU + nn.MaxPool2d(2, 2, 0) as one
+    launch must equal the conv launch followed by `upa_maxpool2d` BIT FOR BIT (the pool runs on the bf16-rounded activations), and
+    both must match the oracle's conv -> pool at bf16 resolution.  Tiles with ragged right / bottom edges included."""
+    from tests.hip_utils import DEV, assert_bf16_close, bf16_round, bf16_weight_oracle, to_cpu_nchw, to_dev_nhwc, unit_input
+    pm, rs = _mods()
+    cin, cout, n, h, w = case
+    o, m = _pair(om.Conv, pm.Conv, (cin, cout, 3, 1), f"pool{case}")
+    m.compute_dtype = torch.bfloat16
+    x = bf16_round(unit_input(f"poolx{case}", (n, cin, h, w)))
+    xd = x.to(DEV).to(torch.bfloat16).contiguous() if cin == 3 else to_dev_nhwc(x, torch.bfloat16)
+    with torch.no_grad():
+        two = to_cpu_nchw(rs.MaxPool2d(2, 2, 0)(m(xd)))
+        one = m.forward_pool2(xd)
+        assert one is not None, "the case is inside the fused form"
+        one = to_cpu_nchw(one)
+        ref = torch.nn.functional.max_pool2d(bf16_weight_oracle(o)(x), 2, 2, 0)
+    assert one.shape == two.shape == ref.shape
+    assert torch.equal(one, two)
+    assert_bf16_close(one, ref, f"conv+pool {case}")
+
+
+def test_conv_maxpool_fused_refuses_outside_the_form():
+    from tests.hip_utils import DEV, to_dev_nhwc, unit_input
+    pm, _ = _mods()
+    _, m = _pair(om.Conv, pm.Conv, (16, 32, 3, 1), "poolrefuse")
+    with torch.no_grad():
+        assert m.forward_pool2(to_dev_nhwc(unit_input("pr1", (1, 16, 16, 16)), torch.float32)) is None  # f32 mode
+        assert m.forward_pool2(to_dev_nhwc(unit_input("pr2", (1, 16, 12, 16)), torch.bfloat16)) is None  # h % 8 != 0
+    _, m2 = _pair(om.Conv, pm.Conv, (16, 32, 3, 2), "poolrefuse2")
+    with torch.no_grad():
+        assert m2.forward_pool2(to_dev_nhwc(unit_input("pr3", (1, 16, 16, 16)), torch.bfloat16)) is None  # stride 2

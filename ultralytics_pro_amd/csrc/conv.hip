@@ -950,6 +950,28 @@ extern "C" int upa_conv2d_bias_act(const void* x, int n, int h, int w, int cin, 
   return rc;
 }
 
+// Conv(k = 3, s = 1, p = 1) + SiLU followed by nn.MaxPool2d(2, 2, 0) as ONE launch (yolov3-tiny.yaml rows 2-7: the full-resolution
+// activation - 210 + 105 + 52 MB at batch 32 - is neither written nor read back): y = the pooled (n, h / 2, w / 2, cout) view.
+// Bit-identical to upa_conv2d_bias_act + upa_maxpool2d (the pool runs on the bf16-rounded activations in the conv epilogue,
+// csrc/conv_pipe.hip).  UPA_EUNSUPPORTED outside the fused form: the caller runs the two layers.
+extern "C" int upa_conv2d_pool2(const void* x, int n, int h, int w, int cin, int ldx, const void* w_packed, const float* bias, void* y,
+                                int cout, int ldy, int k, int stride, int pad, int act, int dtype, const upa_opts* opts, void* stream) {
+  UPA_CHECK_ARG(x && w_packed && y, "conv2d_pool2: null pointer");
+  UPA_CHECK_ARG(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, "conv2d_pool2: bad shape");
+  const long px = (long)n * h * w;
+  if (UPA_OPT(opts, no_pipe) || dtype != UPA_BF16 || k != 3 || stride != 1 || pad != 1 || act != UPA_ACT_SILU || h % 8 != 0 || w % 16 != 0 ||
+      cin % 8 != 0 || cin > 128 || cout % 32 != 0 || ldx % 8 != 0 || ldy % 8 != 0 || ((uintptr_t)x % 16) != 0 || ((uintptr_t)y % 16) != 0 ||
+      px * ldx * 2 >= (1L << 31) || px / 4 * ldy * 2 >= (1L << 31)) {
+    upa_set_error("conv2d_pool2: outside the fused form (bf16, k 3 s 1 p 1, SiLU, h %% 8 == 0, w %% 16 == 0, cin <= 128, cout %% 32 == 0)");
+    return UPA_EUNSUPPORTED;
+  }
+  PipeParams q;
+  memset(&q, 0, sizeof(q));
+  q.x = (const char*)x; q.y = (char*)y; q.w = (const char*)w_packed; q.bias = bias;
+  q.N = n; q.H = h; q.W = w; q.Cin = cin; q.ldx = ldx; q.Cout = cout; q.ldy = ldy; q.act = act; q.pool = 1;
+  return upa_conv_pipe_launch(q, 0, nullptr, stream, opts);
+}
+
 // Several independent convolutions with the same kernel size / stride / padding / activation (the first convs of a Detect head's
 // branches on different levels): identical to one upa_conv2d_bias_act per problem, but neighbours that land on the same 128-pixel
 // conv_big instantiation share ONE grid (conv_big.hip: conv_big_pair_kernel) - a 400- and a 100-workgroup launch become one partial round.

@@ -10,6 +10,7 @@ struct PipeParams {
   int KTT, NTn, nt0;   // k-tiles (32 bf16 channels), packed n-tiles, first n-tile of this launch
   int tilesX, tilesY, numTiles;
   int act;
+  int pool;            // 1 = y holds MaxPool2d(2, 2)(act(conv)) at (H / 2, W / 2): conv3x3_pipe_kernel<.., POOL>
 #ifdef UPA_ABLATE
   int ablate;  // debug build only (upa_opts.ablate_pipe): 1 no halo DMA, 2 no weight loads, 4 no stores, 8 no MFMA, 16 no epilogue
 #endif

@@ -38,7 +38,10 @@ constexpr int HB = NDMA * 1024;            // bytes per halo buffer
 constexpr int WAVES = 4;
 }  // namespace
 
-template <int NTW, int ACT, bool RES>
+// POOL: the layer is followed by nn.MaxPool2d(2, 2, 0) (yolov3-tiny.yaml rows 2-5): the epilogue rounds the activations to bf16 as
+// always, takes the maximum over the two rows of a pair in the lane's own registers and over the two pixels of a pair with one
+// lane exchange, and writes only the pooled (H / 2, W / 2) tensor - bit-identical to conv -> store -> maxpool.
+template <int NTW, int ACT, bool RES, bool POOL = false>
 __global__ __launch_bounds__(WAVES * 64, 1) void conv3x3_pipe_kernel(const PipeParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if UPA_ABL(p, 32) return;  // debug: launch + workgroup dispatch only
@@ -139,8 +142,38 @@ __global__ __launch_bounds__(WAVES * 64, 1) void conv3x3_pipe_kernel(const PipeP
     if constexpr (ACT == UPA_ACT_SILU) return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
     else return v;
   };
+  auto bf16r = [](float v) __attribute__((always_inline)) { return __uint_as_float(pack_bf16x2(v, 0.f) << 16); };
+  auto epilogue_pool = [&](const TileCtx& c) __attribute__((always_inline)) {
+    static_assert(!POOL || (!RES && (NTW % 2) == 0), "pooled form: no residual, channel tiles in pairs");
+    const int co0 = p.nt0 * 16;
+    const int HP = p.H >> 1, WP = p.W >> 1;
+#pragma unroll
+    for (int i = 0; i < TH; i += 2) {
+      const unsigned pixp = (unsigned)((c.n * HP + ((c.oy0 + i) >> 1)) * WP + ((c.ox0 + p16) >> 1));
+      char* yrow = p.y + ((size_t)pixp * p.ldy + co0) * 2;
+#pragma unroll
+      for (int j = 0; j + 1 < NTW; j += 2) {
+        const int cb = 16 * (j + (kg & 1)) + 8 * (kg >> 1);
+        float v0[4], v1[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float a = fmaxf(bf16r(act(acc[i][j][q] + biasv[j][q])), bf16r(act(acc[i + 1][j][q] + biasv[j][q])));
+          float b = fmaxf(bf16r(act(acc[i][j + 1][q] + biasv[j + 1][q])), bf16r(act(acc[i + 1][j + 1][q] + biasv[j + 1][q])));
+          v0[q] = fmaxf(a, __shfl_xor(a, 1));  // the neighbouring pixel of the pair (lanes p16 ^ 1 of the same 16-lane row)
+          v1[q] = fmaxf(b, __shfl_xor(b, 1));
+        }
+        auto lo = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v1[0], v1[1]), false, false);
+        auto hi = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[2], v1[3]), false, false);
+        if ((p16 & 1) == 0) *reinterpret_cast<u32x4*>(yrow + cb * 2) = u32x4{lo[0], hi[0], lo[1], hi[1]};
+      }
+    }
+  };
   auto epilogue = [&](const TileCtx& c) __attribute__((always_inline)) {
     if UPA_ABL(p, 16) return;
+    if constexpr (POOL) {
+      epilogue_pool(c);
+      return;
+    }
     const int co0 = p.nt0 * 16;
     unsigned pix = (unsigned)((c.n * p.H + c.oy0) * p.W + c.ox0 + p16);
 #pragma unroll
@@ -435,6 +468,15 @@ static int launch_pipe(const PipeParams& p, int grid, hipStream_t s) {
     (void)upa_full_lds<conv3x3_pipe_kernel<NTW, ACT_, RES_>>();                                                  \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, s, p);                                           \
   } while (0)
+  if constexpr (NTW == 2 || NTW == 4) {
+    if (p.pool) {  // SiLU, no residual (checked by upa_conv2d_pool2)
+      auto kern = conv3x3_pipe_kernel<NTW, UPA_ACT_SILU, false, true>;
+      (void)upa_full_lds<conv3x3_pipe_kernel<NTW, UPA_ACT_SILU, false, true>>();
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, s, p);
+      UPA_LAUNCH_CHECK();
+      return UPA_OK;
+    }
+  }
   if (p.act == UPA_ACT_SILU) {
     if (p.res) UPA_PIPE_LAUNCH(UPA_ACT_SILU, true);
     else UPA_PIPE_LAUNCH(UPA_ACT_SILU, false);

@@ -19,6 +19,7 @@ struct StemParams {
   int N, Cin, H, W, OH, OW, Cout, ldy, KS, stride, pad, act, x_bf16;
   int TH, TW, tilesX, tilesY, PR, PC, PCS;  // output tile, patch rows/cols, padded LDS row stride
   int wgs;  // stem_mfma_kernel: persistent workgroup cap
+  int pool; // stem_mfma_kernel: 1 = y holds MaxPool2d(2, 2)(act(conv)) at (OH / 2, OW / 2)
 #ifdef UPA_ABLATE
   int ablate;  // debug build only (upa_opts.ablate_stem)
 #endif
@@ -271,7 +272,18 @@ __device__ __forceinline__ void stem_stage(const StemParams& p, int tile, unsign
 // Persistent: a workgroup walks tiles blockIdx.x, +gridDim.x, ...; while tile i is computed from one LDS buffer the
 // DMA of tile i+1 is already in flight into the other, so neither the weight fetch (once per workgroup) nor the memory
 // round trip of a patch is exposed per tile.
-template <int NT, int KS, int S, bool SILU>
+// max of two packed bf16 pairs (as the floats they are; the result is one of the inputs, so re-packing is a shift)
+__device__ __forceinline__ unsigned stem_max_bf16x2(unsigned a, unsigned b) {
+  const float lo = fmaxf(__uint_as_float(a << 16), __uint_as_float(b << 16));
+  const float hi = fmaxf(__uint_as_float(a & 0xFFFF0000u), __uint_as_float(b & 0xFFFF0000u));
+  return (__float_as_uint(hi) & 0xFFFF0000u) | (__float_as_uint(lo) >> 16);
+}
+
+// POOL: the layer is followed by nn.MaxPool2d(2, 2, 0) (yolov3-tiny.yaml rows 0-1: 419 MB written and read back at bs 32) - the pool
+// runs on the bf16-rounded activations in the epilogue and only the pooled tensor is written: a wave owns the row PAIR (2 wave,
+// 2 wave + 1) of the tile, the second row is max-ed into the first in the wave's LDS strip, neighbouring pixels when the strip is
+// read back for the 16-byte stores.  Bit-identical to conv -> store -> maxpool (the max of bf16 values is exact).
+template <int NT, int KS, int S, bool SILU, bool POOL = false>
 __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemParams p) {
   using G = StemGeo<KS, S>;
   constexpr int KSTEPS = G::KSTEPS;
@@ -320,7 +332,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemParams p) {
         const int kh = tap / KS, kw = tap - kh * KS;
         o = (ci * G::PR + kh) * G::LS + kw;
       }
-      gat[ks][j] = (o + shift + (wave * S) * G::LS + l16 * S) * 2;
+      gat[ks][j] = (o + shift + ((POOL ? 2 * wave : wave) * S) * G::LS + l16 * S) * 2;
     }
   char* ostage = stem_sm + 2 * PATCH_BYTES + wave * OUT_ROW_BYTES;
   const int tilesPerImg = p.tilesX * p.tilesY;
@@ -347,7 +359,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemParams p) {
           unsigned e[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j)
-            e[j] = *reinterpret_cast<const unsigned short*>(pb + gat[ks][j] + (rr * 4 * S * G::LS + sx * 16 * S) * 2);
+            e[j] = *reinterpret_cast<const unsigned short*>(pb + gat[ks][j] + (rr * (POOL ? 1 : 4) * S * G::LS + sx * 16 * S) * 2);
           b[sx][ks] = u32x4{e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
         }
 #pragma unroll
@@ -373,10 +385,36 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemParams p) {
             if constexpr (SILU) if (!UPA_ABL(p, 4)) t = t * __builtin_amdgcn_rcpf(1.0f + __expf(-t));
             v[r] = t;
           }
-          *reinterpret_cast<u32x2*>(ostage + (sx * 16 + l16) * (NT * 32) + nt * 32 + kg * 8) =
-              u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          u32x2 pk = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          u32x2* slot = reinterpret_cast<u32x2*>(ostage + (sx * 16 + l16) * (NT * 32) + nt * 32 + kg * 8);
+          if constexpr (POOL) {
+            if (rr == 1) {  // the pair's second row: max with what this lane stored for the first
+              const u32x2 up = *slot;
+              pk = u32x2{stem_max_bf16x2(pk[0], up[0]), stem_max_bf16x2(pk[1], up[1])};
+            }
+          }
+          *slot = pk;
         }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if constexpr (POOL) {
+        if (rr == 0) continue;
+        const int oyp = (oy0 >> 1) + wave, oxp0 = ox0 >> 1;
+        if (oyp < (p.OH >> 1) && !UPA_ABL(p, 8)) {
+          const unsigned rowpix = ((unsigned)n * (p.OH >> 1) + oyp) * (p.OW >> 1) + oxp0;
+#pragma unroll
+          for (int c = 0; c < NT; ++c) {  // 32 pooled pixels x NT * 2 chunks
+            const int chunk = c * 64 + lane;
+            const int px = chunk / (NT * 2), part = chunk - px * (NT * 2);
+            const u32x4 a = *reinterpret_cast<const u32x4*>(ostage + (2 * px) * (NT * 32) + part * 16);
+            const u32x4 b = *reinterpret_cast<const u32x4*>(ostage + (2 * px + 1) * (NT * 32) + part * 16);
+            const u32x4 val = u32x4{stem_max_bf16x2(a[0], b[0]), stem_max_bf16x2(a[1], b[1]), stem_max_bf16x2(a[2], b[2]),
+                                    stem_max_bf16x2(a[3], b[3])};
+            if (oxp0 + px < (p.OW >> 1))
+              *reinterpret_cast<u32x4*>(p.y + ((size_t)(rowpix + px) * p.ldy + part * 8) * sizeof(bf16_t)) = val;
+          }
+        }
+        continue;
+      }
       const int oy = oy0 + wave + rr * 4;
       if (oy < p.OH && !UPA_ABL(p, 8)) {
         const unsigned rowpix = ((unsigned)n * p.OH + oy) * p.OW + ox0;  // < 2^31 pixels per tensor
@@ -406,6 +444,14 @@ static void launch_stem_mfma(const StemParams& p, int n, hipStream_t st) {
   const int wgs = p.wgs > 0 ? p.wgs : 1024;
   dim3 grid((unsigned)(ntiles < wgs ? ntiles : wgs));
   const size_t lds = (size_t)2 * G::ITEMS_PAD * 16 + 4 * G::TW * NT * 32;
+  if constexpr (S == 1 && KS == 3) {
+    if (p.pool) {  // (SiLU only: the launcher's caller checked)
+      auto kern = stem_mfma_kernel<NT, KS, S, true, true>;
+      (void)upa_full_lds<stem_mfma_kernel<NT, KS, S, true, true>>();
+      hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, q);
+      return;
+    }
+  }
   if (p.act == UPA_ACT_SILU) {
     auto kern = stem_mfma_kernel<NT, KS, S, true>;
     (void)upa_full_lds<stem_mfma_kernel<NT, KS, S, true>>();
@@ -648,9 +694,27 @@ extern "C" int upa_pack_stem_weight(const float* w_oihw, int cout, int cin, int 
   return UPA_OK;
 }
 
+static int stem_nchw_impl(const void* x, int x_dtype, int n, int cin, int h, int w, const float* wt, const float* bias, void* y,
+                          int cout, int ldy, int k, int stride, int pad, int act, int dtype, const upa_opts* opts, void* stream, int pool);
+
 extern "C" int upa_conv2d_stem_nchw(const void* x, int x_dtype, int n, int cin, int h, int w, const float* wt,
                                     const float* bias, void* y, int cout, int ldy, int k, int stride, int pad, int act,
                                     int dtype, const upa_opts* opts, void* stream) {
+  return stem_nchw_impl(x, x_dtype, n, cin, h, w, wt, bias, y, cout, ldy, k, stride, pad, act, dtype, opts, stream, 0);
+}
+
+/* The same first layer followed by nn.MaxPool2d(2, 2, 0) (yolov3-tiny.yaml rows 0-1) as ONE kernel: y = the pooled (n, oh / 2,
+ * ow / 2, cout) tensor, the full-resolution activation is never written.  Bit-identical to the two layers run separately.
+ * UPA_EUNSUPPORTED outside the fused form (bf16 output, 3 input channels, k = 3, stride 1, SiLU, cout 16 | 32 | 64, even oh / ow):
+ * the caller then runs upa_conv2d_stem_nchw and upa_maxpool2d. */
+extern "C" int upa_conv2d_stem_nchw_pool2(const void* x, int x_dtype, int n, int cin, int h, int w, const float* wt,
+                                          const float* bias, void* y, int cout, int ldy, int k, int stride, int pad, int act,
+                                          int dtype, const upa_opts* opts, void* stream) {
+  return stem_nchw_impl(x, x_dtype, n, cin, h, w, wt, bias, y, cout, ldy, k, stride, pad, act, dtype, opts, stream, 1);
+}
+
+static int stem_nchw_impl(const void* x, int x_dtype, int n, int cin, int h, int w, const float* wt, const float* bias, void* y,
+                          int cout, int ldy, int k, int stride, int pad, int act, int dtype, const upa_opts* opts, void* stream, int pool) {
   UPA_CHECK_ARG(x && wt && y, "stem: null pointer");
   UPA_CHECK_ARG(x_dtype == UPA_F32 || x_dtype == UPA_BF16 || (x_dtype == UPA_U8_BGR_HWC && cin == 3),
                 "stem: input must be NCHW f32/bf16 or NHWC uint8 BGR with 3 channels");
@@ -671,11 +735,18 @@ extern "C" int upa_conv2d_stem_nchw(const void* x, int x_dtype, int n, int cin, 
   p.PC = (p.TW - 1) * stride + k;
   p.PCS = p.PC + 1;
   p.wgs = UPA_OPT(opts, stem_wgs);
+  p.pool = pool;
 #ifdef UPA_ABLATE
   p.ablate = UPA_OPT(opts, ablate_stem);
 #endif
   const bool no_mfma = UPA_OPT(opts, stem_no_mfma) != 0;
   const int nt16 = cout / 16;
+  if (pool && !(dtype == UPA_BF16 && !no_mfma && cin == 3 && cout % 16 == 0 && (nt16 == 1 || nt16 == 2 || nt16 == 4) && k == 3 &&
+                stride == 1 && act == UPA_ACT_SILU && p.OH % 2 == 0 && p.OW % 2 == 0 && (long)cin * h * w < (1L << 31) &&
+                (long)n * p.OH * p.OW < (1L << 31))) {
+    upa_set_error("stem + maxpool: outside the fused form (bf16, 3 -> 16 | 32 | 64 channels, k 3, stride 1, SiLU, even output size)");
+    return UPA_EUNSUPPORTED;
+  }
   if (dtype == UPA_BF16 && !no_mfma && cin == 3 && cout % 16 == 0 && (nt16 == 1 || nt16 == 2 || nt16 == 4) &&
       ((k == 3 && (stride == 1 || stride == 2)) || (k == 6 && stride == 2)) && (long)cin * h * w < (1L << 31) &&
       (long)n * p.OH * p.OW < (1L << 31)) {

@@ -235,6 +235,52 @@ class Conv(nn.Module, _HipConvMixin):
 
     forward_fuse = forward  # BN is always folded on the HIP path (tasks.py:1134 rebinding is a no-op here)
 
+    def forward_pool2(self, x):
+        """MaxPool2d(2, 2, 0)(self(x)) as ONE launch when the layer has the fused form (bf16, k 3 s 1 p 1, SiLU: `upa_conv2d_pool2`,
+        or the first layer: `upa_conv2d_stem_nchw_pool2`), else None - the caller then runs the two rows separately.  The result is
+        bit-identical either way; the full-resolution activation is never written (yolov3-tiny.yaml rows 0-7)."""
+        if self.training or not isinstance(self.act, nn.SiLU):
+            return None
+        cv = self.conv
+        if (cv.kernel_size, cv.stride, cv.padding) != ((3, 3), (1, 1), (1, 1)):
+            return None
+        stem = _is_model_input(x, cv.in_channels)
+        dt = (self.compute_dtype or (torch.float32 if x.dtype == torch.uint8 else x.dtype)) if stem else x.dtype
+        if dt != torch.bfloat16:
+            return None
+        L.require_gpu(x, "conv2d_pool2")
+        lib, stream = L.lib(), L.current_stream(x.device)
+        pk = self._packed(cv, getattr(self, "bn", None), x.device, dt, stem)
+        if stem:
+            if x.dtype == torch.uint8:
+                n, h, w, cin = x.shape
+                xcode = L.UPA_U8_BGR_HWC
+            else:
+                if not (x.is_contiguous() and x.dtype in (torch.float32, torch.bfloat16)):
+                    return None
+                n, cin, h, w = x.shape
+                xcode = L.dtype_code(x.dtype)
+            if h % 2 or w % 2:
+                return None
+            y = R.alloc_nhwc(n, pk.cout, h // 2, w // 2, dt, x.device, key=(id(self), "ypool"))
+            vy = R.view_of(y)
+            rc = lib.upa_conv2d_stem_nchw_pool2(x.data_ptr(), xcode, n, cin, h, w, pk.w.data_ptr(), pk.bias.data_ptr(), vy.ptr, pk.cout,
+                                                vy.ld, 3, 1, 1, L.ACT_SILU, vy.dtype, R.opts_ptr(), stream)
+        else:
+            x = R.to_nhwc(x, x.dtype)
+            vx = R.view_of(x)
+            if vx.h % 2 or vx.w % 2:
+                return None
+            y = R.alloc_nhwc(vx.n, pk.cout, vx.h // 2, vx.w // 2, x.dtype, x.device, key=(id(self), "ypool"))
+            vy = R.view_of(y)
+            rc = lib.upa_conv2d_pool2(vx.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, pk.w.data_ptr(), pk.bias.data_ptr(), vy.ptr, pk.cout, vy.ld,
+                                      3, 1, 1, L.ACT_SILU, vx.dtype, R.opts_ptr(), stream)
+        if rc == 0:
+            return y
+        if rc != L.UPA_EUNSUPPORTED:
+            L.check(rc, "conv2d_pool2")
+        return None
+
     def train(self, mode: bool = True):
         self.invalidate_packed()
         return super().train(mode)

@@ -217,7 +217,19 @@ class BaseModel(nn.Module):
                 det.begin(int(x.shape[0]), [hw[j] for j in srcs], getattr(self, "compute_dtype", None) or x.dtype, x.device)
         fused_stem = self._stem_fusable(x, place)
         virt = {}  # concat layer index -> VirtualUpsample: an Upsample feeding that Concat which was not launched (see below)
+        pooled = None  # (row index of a MaxPool2d that the previous Conv row already applied, its output)
         for m in self.model:
+            if pooled is not None and m.i == pooled[0]:
+                x, pooled = pooled[1], None
+                y.append(x if m.i in self.save else None)
+                continue
+            if self._pool_fusable(m, place):  # Conv -> MaxPool2d(2, 2, 0): one launch, the conv output never reaches HBM
+                xin = x if m.f == -1 else y[m.f]
+                yp = m.forward_pool2(xin) if torch.is_tensor(xin) else None
+                if yp is not None:
+                    pooled = (m.i + 1, yp)
+                    y.append(None)
+                    continue
             if fused_stem and m.i == 0:  # layers 0 and 1 run as ONE kernel: the stem output never reaches HBM
                 x = self._fused_stem(x)
                 y.append(None)
@@ -297,6 +309,20 @@ class BaseModel(nn.Module):
                 out.append(_out_hw(m, ih, iw))
             cache[(h, w)] = out
         return out
+
+    fuse_pool = True  # Conv + MaxPool2d(2, 2, 0) rows as one launch where the conv kernel has the pooled epilogue (A/B switch)
+
+    def _pool_fusable(self, m, place) -> bool:
+        """Row m is a Conv whose ONLY reader is the next row, an nn.MaxPool2d(2, 2, 0) (yolov3-tiny.yaml rows 0-7): the pool can run in
+        the conv's epilogue (`Conv.forward_pool2`; bf16 only - it returns None otherwise and the rows run separately)."""
+        if not self.fuse_pool or type(m) is not Conv or m.i + 1 >= len(self.model) or isinstance(m.f, list):
+            return False
+        if getattr(self, "compute_dtype", None) != torch.bfloat16 or m.training:
+            return False
+        nxt = self.model[m.i + 1]
+        if type(nxt) is not MaxPool2d or nxt.f != -1 or (nxt.kernel_size, nxt.stride, nxt.padding) != (2, 2, 0):
+            return False
+        return m.i not in self.save and m.i not in place and (m.i + 1) not in place
 
     def _stem_fusable(self, x, place) -> bool:
         """yolov8n's first two rows (Conv(3,16,3,2), Conv(16,32,3,2), SiLU, bf16 NCHW input, neither output used by a later
