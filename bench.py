@@ -47,6 +47,9 @@ def parse():
                     help="NMS scans every anchor's scores again instead of the best-class keys the Detect class tails wrote (A/B switch)")
     ap.add_argument("--keep-raw", action="store_true",
                     help="also write Detect's raw per-level maps (the reference's second return value, unused by predict / NMS)")
+    ap.add_argument("--full-scores", action="store_true",
+                    help="write the (B, nc, A) class scores of the decoded head output as well (default with the NMS prefilter: only the "
+                         "boxes and every anchor's best-class key are written - all that single-label NMS reads; identical detections)")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--model", default=None, help="default: yolov8n (infer), yolov8s (train)")
@@ -250,6 +253,8 @@ def main():
         model.model[-1].keep_raw = False  # predict / NMS read only the decoded output; the raw maps stay in registers
         if hasattr(model.model[-1], "nms_keys") and not args.no_nms_prefilter:
             model.model[-1].nms_keys = True   # the class tails also write every anchor's best-class NMS key for the NMS below
+            if not args.full_scores and hasattr(model.model[-1], "scores_out"):
+                model.model[-1].scores_out = False  # ... and nothing else of the class branch: the NMS below reads boxes + keys only
     # per-rank shard of the global stream: rank r owns batches r*K .. r*K+K-1 (K = --input-batches) of the procedural images
     nin = max(1, args.input_batches)
     pb = per_rank_batch(args, world)
@@ -468,6 +473,7 @@ def main():
                        "autotune_ms_per_step": tuned,
                        "input_batches_rotated": nin, "input_bytes_resident": int(sum(t.numel() * t.element_size() for t in xs)),
                        "detect_raw_maps_written": bool(args.keep_raw),
+                       "detect_class_scores_written": bool(getattr(model.model[-1], "scores_out", True) or not getattr(model.model[-1], "nms_keys", False)),
                        "detections_host_visible": not args.no_host_results, "dispatch_opts": args.opts or None,
                        "dispatch_by_mode": ({"steps in flight > 1 (engine/pipeline.py)": runner.throughput_opts,
                                              "serial / one-step-in-flight legs": "library defaults (whole-block c2f64, conv_ws3)"}
@@ -1120,7 +1126,15 @@ def gpu_parity(args, dev, ppath, model, x0, results, pb):
                 oc, cc = o_.cpu().numpy(), c_.cpu().tolist()
                 mine += [oc[i, :int(cc[i])] for i in range(len(cc))]
             a9, a5 = PA.detection_agreement(mine, ref_rows, 0.9), PA.detection_agreement(mine, ref_rows, 0.5)
-            yb = model(x0)[0].float().cpu()
+            det_ = model.model[-1]
+            so_ = getattr(det_, "scores_out", True)
+            if hasattr(det_, "scores_out"):
+                det_.scores_out = True  # the head comparison reads the class rows
+            try:
+                yb = model(x0)[0].float().cpu()
+            finally:
+                if hasattr(det_, "scores_out"):
+                    det_.scores_out = so_
             db = (yb - y_ref).abs()
             out["bf16"] = {"detections": a9["n_mine"], "recall_iou90": round(a9["recall"], 4), "precision_iou90": round(a9["precision"], 4),
                            "recall_iou50": round(a5["recall"], 4), "precision_iou50": round(a5["precision"], 4),

@@ -921,3 +921,37 @@ def test_e2e_yolov3_tiny_conv_pool_fusion_is_exact():
     torch.cuda.synchronize()
     assert sorted(set(calls)) == [0, 2, 4, 6], calls  # row 8's output is saved for the route: not offered
     assert torch.equal(y_fused, y_plain) and torch.equal(y_graph, y_plain)
+
+
+@pytest.mark.parametrize("name", ["yolov8n", "yolov5-BoT3", "yolov3-tiny"])
+def test_e2e_bf16_keys_only_head_is_exact(name):
+    """`Detect.scores_out = False` (`upa_opts.keys_only`): the fused class tails write ONLY every anchor's best-class NMS key - no
+    (B, nc, A) score rows, one sigmoid per anchor instead of nc (the sigmoid of the largest logit when it is separated from the
+    runner-up for certain, else all of them as before).  Keys, box rows and detections must be BIT-identical to the score-writing
+    form at any confidence threshold, eagerly and in a replayed graph."""
+    from tests.hip_utils import DEV
+    from ultralytics_pro_amd.utils.nms import nms_raw
+    m = _build(name, torch.bfloat16)
+    det = m.model[-1]
+    det.keep_raw, det.nms_keys, det.concurrent = False, True, False
+    x = P.synthetic_images(5).to(DEV).to(torch.bfloat16).contiguous()
+    with torch.no_grad():
+        det.scores_out = True
+        y_full = m(x)[0]
+        keys_full = y_full._upa_hot.clone()
+        full = {c: [t.clone() for t in nms_raw(y_full, c, 0.7, key=("full", c))] for c in (0.25, 0.05, 0.6)}
+        y_full = y_full.clone()
+        det.scores_out = False
+        y_keys = m(x)[0]
+        assert torch.equal(y_keys._upa_hot, keys_full), "best-class keys differ"
+        assert torch.equal(y_keys[:, :4], y_full[:, :4]), "box rows differ"
+        for c in (0.25, 0.05, 0.6):
+            for a, b in zip(full[c], nms_raw(y_keys, c, 0.7, key=("keys", c))):
+                assert torch.equal(a, b)
+        run = m.compile(x, post=lambda o: nms_raw(o[0], 0.25, 0.7, key="graph"))
+        for _ in range(2):
+            out = run()
+            torch.cuda.synchronize()
+            for a, b in zip(full[0.25], out):
+                assert torch.equal(a, b)
+    det.scores_out = True

@@ -271,8 +271,15 @@ __device__ __forceinline__ void conv_big_body(const BigParams& p, const int bid0
       } else {
         float best = -1.f;
         int bc = 0;
+        if (p.de.keys_only) {  // uniform: boxes + best-class keys are all that single-label NMS reads
+          f32x4 lg[NT];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) upa_detect_cls_store(p.de, acc2[i][j] + tbv[j], j, n, al, pok, g, best, bc);
+          for (int j = 0; j < NT; ++j) lg[j] = acc2[i][j] + tbv[j];
+          upa_detect_cls_keys_only<NT>(p.de, lg, pok, g, best, bc);
+        } else {
+#pragma unroll
+          for (int j = 0; j < NT; ++j) upa_detect_cls_store(p.de, acc2[i][j] + tbv[j], j, n, al, pok, g, best, bc);
+        }
         if (p.de.best_keys) upa_detect_best_key_store(p.de, best, bc, n, al, pok, lane);  // uniform
       }
     }
@@ -612,6 +619,7 @@ int branch_tail_prepare(BigParams& p, int& ntb, int& bm, size_t& lds, const void
   p.de.magicHW = upa_magic_div(h * w); p.de.magicW = upa_magic_div(w);
   p.de.nc = nc; p.de.stride_px = stride_px;
   if (kind == 2 && best_keys && (long)a_total * nc < (1L << 31)) p.de.best_keys = best_keys;
+  p.de.keys_only = (p.de.best_keys && UPA_OPT(opts, keys_only)) ? 1 : 0;
   const long px = (long)n * h * w;
   bm = (px + 255) / 256 < big_num_cu() ? 128 : 256;  // 128-pixel workgroups (one m-tile per wave) on the small levels
   if (const int f = UPA_OPT(opts, branch_tail_bm); f == 128 || f == 256) bm = f;

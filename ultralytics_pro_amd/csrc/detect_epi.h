@@ -25,6 +25,10 @@ struct DetectEpi {
   // (~bits(best score) << 32) | (anchor * nc + best class), best class = FIRST maximum (torch.max order, nms.py:109), as a dense
   // (B, a_total) array - upa_nms_batched_hot takes its candidates from it instead of re-reading the (B, nc, A) score block
   unsigned long long* best_keys;
+  // 1 = the class rows of y are NOT written (upa_opts.keys_only, needs best_keys): single-label non_max_suppression reads only the
+  // boxes and the best-class keys (upa_nms_batched_hot), so the 4 * nc * A bytes per image of scores and all but one sigmoid per
+  // anchor are dead work on the predict path.  The keys are bit-identical to the ones computed next to the full score rows.
+  int keys_only;
 };
 
 __device__ __forceinline__ float upa_row_sum4(float v) {  // sum over the 4 lane rows (lanes l, l^16, l^32, l^48)
@@ -85,10 +89,50 @@ __device__ __forceinline__ void upa_detect_cls_store(const DetectEpi& d, const f
     const int c = 16 * j + 4 * kg + q;
     const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[q] * -LOG2E));
     if (ok && c < d.nc) {
-      yb[(size_t)c * d.a_total] = sg;
+      if (!d.keys_only) yb[(size_t)c * d.a_total] = sg;
       if (sg > best) { best = sg; bc = c; }
     }
   }
+}
+
+// keys_only form of a whole pixel tile: logits[j] = n-tile j (bias added), NTC n-tiles.  The score of the best class is the sigmoid
+// of the largest LOGIT when the sigmoid (v_exp_f32 + v_rcp_f32, each within ~1 ulp) separates it from the runner-up for certain:
+// largest logit <= 4 (slope of the sigmoid >= 0.017: no saturation) and a gap of >= 1e-4 to the second largest logit of the PIXEL
+// (relative score gap >= 1.8e-6, an order of magnitude above the two approximations' error) - then the first maximum of the scores
+// (torch.max order, nms.py:109) is that class and ONE sigmoid per lane replaces NTC * 4.  Any other pixel in the wave (uniform
+// test) sends the wave through the full per-class sigmoids exactly as the score-writing form does.  Returns (best, bc) of the lane.
+template <int NTC>
+__device__ __forceinline__ void upa_detect_cls_keys_only(const DetectEpi& d, const f32x4 (&logit)[NTC], bool ok, int kg, float& best, int& bc) {
+  constexpr float LOG2E = 1.44269504088896340736f;
+  float m1 = -INFINITY, m2 = -INFINITY;  // the lane's largest and second largest logit (valid classes only)
+  int c1 = 0;
+#pragma unroll
+  for (int j = 0; j < NTC; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = 16 * j + 4 * kg + q;
+      const float v = c < d.nc ? logit[j][q] : -INFINITY;
+      if (v > m1) { m2 = m1; m1 = v; c1 = c; }
+      else m2 = fmaxf(m2, v);
+    }
+  const float pm = upa_row_max4(m1);                            // the pixel's largest logit
+  const float ps = upa_row_max4(m1 == pm ? m2 : m1);            // ... and a lower bound of its second largest (exact unless two rows tie at pm)
+  const bool sure = !ok || (pm <= 4.0f && pm - ps >= 1e-4f && upa_row_sum4(m1 == pm ? 1.f : 0.f) == 1.f);
+  if (__all(sure)) {
+    best = ok && m1 == pm ? __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(m1 * -LOG2E)) : -1.f;
+    bc = c1;
+    return;
+  }
+  best = -1.f;
+  bc = 0;
+#pragma unroll
+  for (int j = 0; j < NTC; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = 16 * j + 4 * kg + q;
+      const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(logit[j][q] * -LOG2E));
+      if (ok && c < d.nc && sg > best) { best = sg; bc = c; }
+    }
 }
 
 // After the class rows of one 16-pixel tile: (best, bc) = this lane's first maximum (lane (kg, p16): classes 4kg + q of every

@@ -97,6 +97,15 @@ class Detect(nn.Module, _HipConvMixin):
     # NMS prefilter (off by default): the fused class tails also write the NMS sort key of every anchor's best class, a dense
     # (B, A) array that `utils.nms` compacts instead of re-reading the (B, nc, A) scores (upa_nms_batched_hot; single-label NMS)
     nms_keys = False
+    # `scores_out = False` (only with `nms_keys` and without `keep_raw`): the class rows of the decoded output are NOT written
+    # (`upa_opts.keys_only`) - single-label `non_max_suppression` takes every anchor's best class and score from the keys and the
+    # boxes from rows 0-3, so for predict the (B, nc, A) scores (86 MB per batch-32 step of yolov8n) and all but one sigmoid per
+    # anchor are dead work.  The detections are bit-identical; rows 4.. of the returned tensor are then UNDEFINED (a consumer
+    # that reads them - multi_label NMS, validation - must leave this at True).
+    scores_out = True
+
+    def _keys_only(self) -> bool:
+        return bool(self.nms_keys and not self.scores_out and not self.keep_raw)
 
     def _tail(self, seq: nn.Sequential, x: torch.Tensor, raw: torch.Tensor | None, kind: int, i: int, plan) -> None:
         """conv3x3 -> conv3x3 -> [1x1 + decode] of one branch (kind 1 = box, 2 = class) of level i."""
@@ -265,6 +274,12 @@ class Detect(nn.Module, _HipConvMixin):
         return self.__dict__.setdefault("_pending", {}).setdefault(R.current_tag(), {})
 
     def start_level(self, i: int, x: torch.Tensor, defer_ok: bool = True) -> None:
+        if self._keys_only() and (R.current_opts() is None or not R.current_opts().keys_only):
+            with R.use_opts(keys_only=1):
+                return self._start_level(i, x, defer_ok)
+        return self._start_level(i, x, defer_ok)
+
+    def _start_level(self, i: int, x: torch.Tensor, defer_ok: bool = True) -> None:
         """Launch level i's two branches (asynchronously when `concurrent`); results land in the level's raw buffer and /
         or, with the fused decode, directly in the decoded output.  On one stream (linear graphs) the levels are left to `forward`,
         which runs them several per launch (`_levels_grouped`)."""
@@ -319,6 +334,12 @@ class Detect(nn.Module, _HipConvMixin):
         pend[i] = (raw, joins)
 
     def forward(self, x):
+        if self._keys_only() and (R.current_opts() is None or not R.current_opts().keys_only):
+            with R.use_opts(keys_only=1):
+                return self._forward(x)
+        return self._forward(x)
+
+    def _forward(self, x):
         if self.training:
             raise L.UpaError("training-mode Detect is not on the HIP path yet (SURVEY §8f rank 2)")
         pend = self._pend()
