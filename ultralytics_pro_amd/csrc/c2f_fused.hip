@@ -35,6 +35,7 @@ struct C2fParams {
   const char *w1, *wa, *wb, *w2;
   const float *b1, *ba, *bb, *b2;
   int N, H, W, ldx, ldy, tilesX, tilesY;
+  int xcd;  // 1 = XCD-aware tile order (upa_xcd_tile, common.h)
 };
 
 namespace c2f {
@@ -77,8 +78,8 @@ __global__ __launch_bounds__(NW * 64) void c2f16_fused_kernel(const C2fParams p)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, r = lane & 15;
-  int bid = blockIdx.x;
   const int tilesPerImg = p.tilesX * p.tilesY;
+  int bid = p.xcd ? upa_xcd_tile((int)blockIdx.x, tilesPerImg * p.N) : (int)blockIdx.x;
   const int n = bid / tilesPerImg;
   bid -= n * tilesPerImg;
   const int tyi = bid / p.tilesX, txi = bid - tyi * p.tilesX;
@@ -247,6 +248,7 @@ struct C2f32Params {
   // CHUNKED form (cv1 with c1 = 64 * nch input channels, streamed in 64-channel chunks): the first upC channels of a pixel come from
   // pixel (y / 2, x / 2) of the half-resolution tensor `up` (a virtual nn.Upsample + Concat), the rest from x itself
   const char* up; int c1, upC, up_ld;
+  int xcd;  // 1 = XCD-aware tile order (upa_xcd_tile)
 };
 
 namespace c2f32 {
@@ -337,8 +339,8 @@ __global__ __launch_bounds__(1024) void c2f32_fused_kernel(const C2f32Params p) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, r = lane & 15;
   const int j = wave & 1;  // the n-tile (of a 32-channel tensor) this wave produces
-  int bid = blockIdx.x;
   const int tilesPerImg = p.tilesX * p.tilesY;
+  int bid = p.xcd ? upa_xcd_tile((int)blockIdx.x, tilesPerImg * p.N) : (int)blockIdx.x;
   const int n = bid / tilesPerImg;
   bid -= n * tilesPerImg;
   const int tyi = bid / p.tilesX, txi = bid - tyi * p.tilesX;
@@ -608,6 +610,7 @@ extern "C" int upa_c2f_fused(const void* x, int n, int h, int w, int c1, int ldx
     p.w1 = (const char*)w1; p.wa = (const char*)wm[0]; p.wb = (const char*)wm[1]; p.w2 = (const char*)w2;
     p.b1 = b1; p.ba = bm[0]; p.bb = bm[1]; p.b2 = b2;
     p.N = n; p.H = h; p.W = w; p.ldx = ldx; p.ldy = ldy; p.tilesX = tx; p.tilesY = ty;
+    p.xcd = UPA_OPT(opts, no_xcd) ? 0 : 1;
     const int nw = UPA_OPT(opts, c2f16_waves) == 8 ? 8 : 4;
     if (nw == 4) hipLaunchKernelGGL(c2f16_fused_kernel<4>, dim3((unsigned)tiles), dim3(256), c2f::LDS, s, p);
     else hipLaunchKernelGGL(c2f16_fused_kernel<8>, dim3((unsigned)tiles), dim3(512), c2f::LDS, s, p);
@@ -619,6 +622,7 @@ extern "C" int upa_c2f_fused(const void* x, int n, int h, int w, int c1, int ldx
   p.x = (const char*)x; p.y = (char*)y; p.w1 = (const char*)w1; p.w2 = (const char*)w2; p.b1 = b1; p.b2 = b2;
   for (int i = 0; i < 2 * nb; ++i) { p.wm[i] = (const char*)wm[i]; p.bm[i] = bm[i]; }
   p.N = n; p.H = h; p.W = w; p.ldx = ldx; p.ldy = ldy; p.tilesX = tx; p.tilesY = ty; p.shortcut = shortcut ? 1 : 0;
+  p.xcd = UPA_OPT(opts, no_xcd) ? 0 : 1;
   // LDS of <NB, TH>: x region + y1 + y0 (+ b1 on ring 2 for NB = 2)
   auto lds_of = [](int nbk, int th) {
     const int r = 2 * nbk, sxw = 16 + 2 * r, sxh = th + 2 * r;
@@ -672,6 +676,7 @@ extern "C" int upa_c2f32_up_fused(const void* x, int n, int h, int w, int c1, in
   for (int i = 0; i < 2; ++i) { p.wm[i] = (const char*)wm[i]; p.bm[i] = bm[i]; }
   p.N = n; p.H = h; p.W = w; p.ldx = ldx; p.ldy = ldy; p.tilesX = cdiv(w, 16); p.tilesY = cdiv(h, 16); p.shortcut = shortcut ? 1 : 0;
   p.up = (const char*)up; p.c1 = c1; p.upC = up ? up_c : 0; p.up_ld = up_ld;
+  p.xcd = UPA_OPT(opts, no_xcd) ? 0 : 1;
   const long tiles = (long)p.tilesX * p.tilesY * n;
   UPA_CHECK_ARG(tiles < (1L << 31) / 2, "c2f32_up_fused: too many tiles");
   // LDS of <1, 16>: x region + y1 + y0, + the second chunk buffer

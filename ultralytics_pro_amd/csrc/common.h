@@ -137,6 +137,16 @@ static constexpr int upa_lds_pick_pitch(int min_pitch, int W, int npix, int row_
   return best;
 }
 
+// XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (observed, MI355X_MICROARCH.md: blocks b and b + 8 share one;
+// speed only, never correctness), each with its own L2.  Neighbouring tiles share halo pixels, so a launch whose workgroup b takes
+// tile b scatters every neighbourhood over all eight L2s and each halo is fetched from the fabric by every tile that needs it.  This
+// maps workgroup b to tile start(b % 8) + b / 8, where XCD x owns the CONTIGUOUS tile range [start(x), start(x + 1)) (sizes differ
+// by at most one): a bijection on [0, total), and neighbours in the tile list now meet in one L2.
+__device__ __forceinline__ int upa_xcd_tile(int b, int total) {
+  const int q = total >> 3, r = total & 7, x = b & 7, i = b >> 3;
+  return x * q + (x < r ? x : r) + i;
+}
+
 static inline int upa_elem_size(int dtype) { return dtype == UPA_BF16 ? 2 : 4; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 

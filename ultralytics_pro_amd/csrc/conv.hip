@@ -991,6 +991,7 @@ extern "C" int upa_conv2d_bias_act_group(const upa_conv_problem* probs, int coun
     b.OH = (q.h + 2 * pad - k) / stride + 1;
     b.OW = (q.w + 2 * pad - k) / stride + 1;
     b.KS = k; b.stride = stride; b.pad = pad; b.act = act;
+    b.no_xcd = UPA_OPT(opts, no_xcd);
     return b;
   };
   for (int i = 0; i < count;) {

@@ -70,8 +70,10 @@ __device__ __forceinline__ void conv_big_body(const BigParams& p, const int bid0
   const int r = lane & 15, g = lane >> 4;
   const int wm = wave / WN, wn = wave % WN;
 
-  int bid = bid0;
   const int tilesPerImg = p.tilesX * p.tilesY;
+  // XCD-aware tile order (common.h: upa_xcd_tile): within one problem and one row of n-tile blocks the linear workgroup index is
+  // bid0 plus a constant, so "bid0 & 7" names the XCD up to a rotation - each XCD still walks one contiguous range of tiles
+  int bid = p.no_xcd ? bid0 : upa_xcd_tile(bid0, tilesPerImg * p.N);
   const int n = bid / tilesPerImg;
   bid -= n * tilesPerImg;
   const int tyi = bid / p.tilesX;
@@ -620,6 +622,7 @@ int branch_tail_prepare(BigParams& p, int& ntb, int& bm, size_t& lds, const void
   p.de.nc = nc; p.de.stride_px = stride_px;
   if (kind == 2 && best_keys && (long)a_total * nc < (1L << 31)) p.de.best_keys = best_keys;
   p.de.keys_only = (p.de.best_keys && UPA_OPT(opts, keys_only)) ? 1 : 0;
+  p.no_xcd = UPA_OPT(opts, no_xcd);
   const long px = (long)n * h * w;
   bm = (px + 255) / 256 < big_num_cu() ? 128 : 256;  // 128-pixel workgroups (one m-tile per wave) on the small levels
   if (const int f = UPA_OPT(opts, branch_tail_bm); f == 128 || f == 256) bm = f;
@@ -839,6 +842,7 @@ int big_dispatch(const BigParams& p, int ntb, int bm, size_t lds, hipStream_t s)
 }  // namespace
 
 int upa_conv_big_launch(BigParams p, int query_only, int* variant, void* stream, const upa_opts* opts) {
+  p.no_xcd = UPA_OPT(opts, no_xcd);
   int ntb = 0, bm = 0;
   size_t lds = 0;
   const int rc = big_prepare(p, ntb, bm, lds, opts, query_only != 0);

@@ -63,6 +63,7 @@ struct BigParams {
   int KTT, NTn;
   int act;
   unsigned magicTW, magicIW;   // magicIW divides by IWp
+  int no_xcd;          // 1 = workgroup b takes tile b (0: the XCD-aware order, upa_opts.no_xcd for A/B)
   const char* tw;      // Detect branch tail: final 1x1 conv packed by upa_pack_tail_weight
   const float* tb;     // ... its bias (zero-padded to 16 * n-tiles)
   DetectEpi de;        // ... and the decode it feeds (detect_epi.h)
