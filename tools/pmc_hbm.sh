@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic per kernel launch of `bench.py --serial` from rocprofv3 PMC counters, as MI355X_MICROARCH.md prescribes:
 # FETCH_SIZE and WRITE_SIZE in separate passes (never combined with trace domains), both in KB; on gfx950 FETCH_SIZE
-# counts 64 B per 128-B request and is doubled.  Writes profiles/r03_pmc_hbm_summary.json.  The pass runs one step at a time (counter
+# counts 64 B per 128-B request and is doubled.  Writes gpurun_out/pmc_hbm/summary.json (copied to profiles/<round>_pmc_hbm_summary.json by tools/copy_profiles.sh).  The pass runs one step at a time (counter
 # collection serialises kernels anyway) but with the kernel choice of the headline run's in-flight copies (upa_opts c2f=4, conv_ws3=1:
 # engine/pipeline.py), so that a family's per-launch average is over the launches the timed region replays.
 # usage (GPU box): tools/pmc_hbm.sh [extra bench.py args]
@@ -32,7 +32,9 @@ summary = {"command": "tools/pmc_hbm.sh = rocprofv3 --pmc FETCH_SIZE | --pmc WRI
                       "python3 bench.py --serial --opts c2f=4,conv_ws3=1 --steps 3 --warmup 1 --input-batches 1 --no-cpu-baseline",
            "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request -> doubled (MI355X_MICROARCH.md HBM); WRITE_SIZE exact; both in KB",
            "config": "yolov8n bs=32 bf16", "kernels": kern}
-json.dump(summary, open("profiles/r03_pmc_hbm_summary.json", "w"), indent=1)
+import os
+rnd = os.environ.get("ROUND", "r04")
+json.dump(summary, open(f"profiles/{rnd}_pmc_hbm_summary.json", "w"), indent=1)  # so that the bench runs after this one in the same call see it
 json.dump(summary, open(f"{out}/summary.json", "w"), indent=1)  # gpurun merges gpurun_out/ back, not profiles/
 print("kernels:", len(kern))
 PY
