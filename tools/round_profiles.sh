@@ -11,8 +11,8 @@ cd $R
 timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 timeout 600 python bench.py --serial --no-cpu-baseline > $O/bench_serial.json 2>/dev/null
 timeout 600 python bench.py --dtype f32 --no-cpu-baseline --steps 200 > $O/bench_f32.json 2>/dev/null
-for m in yolov8s yolov3-tiny yolov5-BoT3; do timeout 600 python bench.py --model $m --no-cpu-baseline --no-kernel-profile --steps 300 > $O/bench_$m.json 2>/dev/null; done
-timeout 600 python bench.py --model yolov3-rtdetr --batch 16 --no-cpu-baseline --no-kernel-profile > $O/bench_yolov3-rtdetr.json 2>/dev/null
+for m in yolov8s yolov3-tiny yolov5-BoT3; do timeout 600 python bench.py --model $m --no-cpu-baseline --steps 300 > $O/bench_$m.json 2>/dev/null; done
+timeout 600 python bench.py --model yolov3-rtdetr --batch 16 --no-cpu-baseline > $O/bench_yolov3-rtdetr.json 2>/dev/null
 timeout 600 python bench.py --workload train > $O/bench_train.json 2> $O/bench_train.err
 timeout 600 python bench.py --workload val --steps 300 > $O/bench_val.json 2> $O/bench_val.err
 timeout 600 python bench.py --no-cpu-baseline --no-kernel-profile --no-mode-dispatch > $O/bench_default_no_mode_dispatch.json 2>/dev/null   # A/B: the one-step-at-a-time kernels (c2f64, conv_ws3) kept with four steps in flight
