@@ -1283,3 +1283,33 @@ def test_conv_maxpool_fused_refuses_outside_the_form():
     _, m2 = _pair(om.Conv, pm.Conv, (16, 32, 3, 2), "poolrefuse2")
     with torch.no_grad():
         assert m2.forward_pool2(to_dev_nhwc(unit_input("pr3", (1, 16, 16, 16)), torch.bfloat16)) is None  # stride 2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("cls,args,xshape", [("C3", (64, 64, 2, True), (2, 64, 12, 20)), ("C3", (48, 32, 1, False), (1, 48, 9, 9)),
+                                             ("BoT3", (64, 64, 1, 0.5, 1, 6, 6), (2, 64, 6, 6))], ids=["c3_n2", "c3_48_32", "bot3"])
+def test_c3_stacked_cv1_cv2_equals_separate_launches(cls, args, xshape, dtype):
+    """C3 / BoT3 with cv1 and cv2 as ONE launch (their BN-folded filters stacked; `block._stacked_cv12`) and MHSA's query / key /
+    value likewise, against the same module with the switches off and against the oracle."""
+    from tests.hip_utils import assert_bf16_close, bf16_round, to_cpu_nchw, to_dev_nhwc, unit_input
+    pm, _ = _mods()
+    o, m = _pair(getattr(om, cls), getattr(pm, cls), args, f"stack_{cls}{args}")
+    x = unit_input(f"stackx{cls}{xshape}", xshape)
+    if dtype == torch.bfloat16:
+        x = bf16_round(x)
+    xd = to_dev_nhwc(x, dtype)
+    saved = (pm.C3.stack_cv12, pm.BoT3.stack_cv12, pm.MHSA.stack_qkv)
+    try:
+        with torch.no_grad():
+            y1 = to_cpu_nchw(m(xd))
+            pm.C3.stack_cv12 = pm.BoT3.stack_cv12 = pm.MHSA.stack_qkv = False
+            y0 = to_cpu_nchw(m(xd))
+            ref = o(x)
+    finally:
+        pm.C3.stack_cv12, pm.BoT3.stack_cv12, pm.MHSA.stack_qkv = saved
+    if dtype == torch.float32:
+        assert (y1 - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+        assert (y1 - y0).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    else:
+        tol = 4e-2 * max(1.0, ref.abs().max().item())  # three to five bf16 layers deep (the blocks' own golden tests use 6e-2)
+        assert (y1 - ref).abs().max().item() <= tol and (y1 - y0).abs().max().item() <= tol

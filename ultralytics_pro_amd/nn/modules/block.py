@@ -212,9 +212,32 @@ class C2f(nn.Module):
         return None
 
 
+def _stacked_cv12(self, x, up):
+    """cv1(x) and cv2(x) of a C3 / BoT3 (block.py:509-532, 6095-6109) as ONE launch: both are 1x1 Conv + SiLU on the same input, so
+    their folded filters are stacked ([cv2 | cv1] along the output channels) and the launch writes channels [c_, 3c_) of one
+    (n, 3c_, h, w) buffer laid out [m(cv1(x)) | cv2(x) | cv1(x)]: the concat that cv3 reads is its first 2c_ channels, the Bottleneck
+    chain reads the last c_ and its last member writes the first c_.  x is read once instead of twice.  Returns (buffer, c_), or None
+    outside the form (then the two convs run separately)."""
+    a, b = self.cv1, self.cv2
+    c_ = a.conv.out_channels
+    ok = (self.stack_cv12 and not self.training and x.dtype in (torch.float32, torch.bfloat16) and b.conv.out_channels == c_
+          and a.conv.kernel_size == (1, 1) and b.conv.kernel_size == (1, 1) and a.conv.stride == (1, 1) and b.conv.stride == (1, 1)
+          and isinstance(a.act, nn.SiLU) and isinstance(b.act, nn.SiLU) and hasattr(a, "bn") and hasattr(b, "bn")
+          and c_ % (8 if x.dtype == torch.bfloat16 else 4) == 0)
+    if not ok:
+        return None
+    n, _, h, w = x.shape
+    buf = R.alloc_nhwc(n, 3 * c_, h, w, x.dtype, x.device, key=(id(self), "cat3"))
+    pk = a._packed_stack([(b.conv, b.bn), (a.conv, a.bn)], x.device, x.dtype)
+    hip_conv2d(x, pk, 1, 0, L.ACT_SILU, out=buf[:, c_:], up=up)
+    return buf, c_
+
+
 class C3(nn.Module):
     """CSP bottleneck with 3 convolutions (block.py:509-532): cv3(cat(m(cv1(x)), cv2(x))).
     `up`: a conv.VirtualUpsample for the leading channels of x - both 1x1 convs that read x take it."""
+
+    stack_cv12 = True  # cv1 and cv2 as one launch (`_stacked_cv12`); A/B and test switch
 
     def __init__(self, c1, c2, n=1, shortcut=True, g=1, e=0.5):
         super().__init__()
@@ -228,6 +251,13 @@ class C3(nn.Module):
         x = R.to_nhwc(x, x.dtype)
         n, _, h, w = x.shape
         c_ = self.cv1.conv.out_channels
+        st = _stacked_cv12(self, x, up) if len(self.m) else None
+        if st is not None:
+            buf, _ = st
+            y = buf[:, 2 * c_:]
+            for i, m in enumerate(self.m):
+                y = m(y, out=buf[:, :c_] if i == len(self.m) - 1 else None)
+            return self.cv3(buf[:, : 2 * c_], out=out)
         cat = R.alloc_nhwc(n, 2 * c_, h, w, x.dtype, x.device, key=(id(self), "cat"))
         self.cv2(x, out=cat[:, c_:], up=up)
         y = self.cv1(x, up=up) if len(self.m) else self.cv1(x, out=cat[:, :c_], up=up)
@@ -277,13 +307,19 @@ class MHSA(nn.Module, _HipConvMixin):
         self.pos = pos_emb
         self.softmax = nn.Softmax(dim=-1)
 
+    stack_qkv = True
+
     def forward(self, x, out=None, residual=None):
         x = R.to_nhwc(x, x.dtype)
         n, c, h, w = x.shape
         qkv = R.alloc_nhwc(n, 3 * c, h, w, x.dtype, x.device, key=(id(self), "qkv"))
-        for i, conv in enumerate((self.query, self.key, self.value)):
-            pk = self._packed(conv, None, x.device, x.dtype, False)
-            hip_conv2d(x, pk, 1, 0, L.ACT_NONE, out=qkv[:, i * c: (i + 1) * c])
+        if self.stack_qkv:  # query / key / value read the same x: one launch with the three filters stacked
+            pk = self._packed_stack([(self.query, None), (self.key, None), (self.value, None)], x.device, x.dtype)
+            hip_conv2d(x, pk, 1, 0, L.ACT_NONE, out=qkv)
+        else:
+            for i, conv in enumerate((self.query, self.key, self.value)):
+                pk = self._packed(conv, None, x.device, x.dtype, False)
+                hip_conv2d(x, pk, 1, 0, L.ACT_NONE, out=qkv[:, i * c: (i + 1) * c])
         y = out if out is not None else R.alloc_nhwc(n, c, h, w, x.dtype, x.device, key=(id(self), "y"))
         vq, vy = R.view_of(qkv[:, :c]), R.view_of(y)
         rp, rld = (None, 0)
@@ -328,10 +364,19 @@ class BoT3(nn.Module):
             *[BottleneckTransformer(c_, c_, stride=1, heads=4, mhsa=True, resolution=(w, h), expansion=e2)
               for _ in range(n)])
 
+    stack_cv12 = True
+
     def forward(self, x, out=None):
         x = R.to_nhwc(x, x.dtype)
         n, _, h, w = x.shape
         c_ = self.cv1.conv.out_channels
+        st = _stacked_cv12(self, x, None) if len(self.m) else None
+        if st is not None:
+            buf, _ = st
+            y = buf[:, 2 * c_:]
+            for i, m in enumerate(self.m):
+                y = m(y, out=buf[:, :c_] if i == len(self.m) - 1 else None)
+            return self.cv3(buf[:, : 2 * c_], out=out)
         cat = R.alloc_nhwc(n, 2 * c_, h, w, x.dtype, x.device, key=(id(self), "cat"))
         self.cv2(x, out=cat[:, c_:])
         y = self.cv1(x)

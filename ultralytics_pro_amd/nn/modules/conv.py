@@ -187,6 +187,32 @@ class _HipConvMixin:
         cache[key] = (ver, pk)
         return pk
 
+    def _packed_stack(self, pairs, device, dtype) -> PackedConv:
+        """ONE packed conv for several 1x1 convs that read the same input (C3's cv1 / cv2, block.py:509-532; MHSA's query / key /
+        value, block.py:6036-6062): the BN-folded filters and biases stacked along the output channels in the given order, so that a
+        single launch reads the input once and writes every branch's channel slice of one buffer.  `pairs`: [(nn.Conv2d, bn | None)];
+        same kernel size / stride / padding.  Cached like `_packed`, keyed on every member's parameters."""
+        cache = self.__dict__.setdefault("_pk_cache", {})
+        key = ("stack",) + tuple(id(c) for c, _ in pairs) + (str(device), dtype)
+        ver = ()
+        for conv, bn in pairs:
+            ver += version_key(conv.weight, conv.bias, *(() if bn is None else (bn.weight, bn.bias, bn.running_mean, bn.running_var)))
+            ver += ((bn.eps,) if bn is not None else ())
+        hit = cache.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        c0 = pairs[0][0]
+        for conv, _ in pairs:
+            if (conv.kernel_size, conv.stride, conv.padding, conv.in_channels) != (c0.kernel_size, c0.stride, c0.padding, c0.in_channels) \
+                    or conv.groups != 1 or conv.dilation != (1, 1):
+                raise L.UpaError("stacked convs must share kernel size / stride / padding / input channels (groups = 1)")
+        folded = [fold_bn(conv, bn) for conv, bn in pairs]
+        w = torch.cat([f[0] for f in folded], 0)
+        b = torch.cat([f[1] for f in folded], 0)
+        pk = PackedConv(w, b, c0.kernel_size[0], device, dtype, False)
+        cache[key] = (ver, pk)
+        return pk
+
     def invalidate_packed(self):
         self.__dict__.pop("_pk_cache", None)
 
