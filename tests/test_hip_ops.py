@@ -29,6 +29,7 @@ CONV_CASES = [
     (256, 64, 3, 1, None, 20, 20, 1),
     (128, 256, 3, 2, None, 40, 40, 1),
     (16, 16, 3, 1, None, 64, 64, 1),
+    (16, 32, 3, 1, None, 64, 48, 2),   # 16 -> 32 on whole 8 x 16 tiles: the two-n-tile form of conv3x3_c16_kernel (bf16, pipe_all)
     (32, 16, 1, 1, None, 33, 9, 1),
     (512, 1024, 3, 1, None, 10, 10, 1),
     (1024, 256, 1, 1, None, 10, 10, 1),
@@ -1246,7 +1247,7 @@ def test_detect_head_tails_equal_single_launches():
 
 POOL_CASES = [  # cin, cout, n, h, w  (cin 3 = the first layer on an NCHW image)
     (3, 16, 2, 64, 128), (3, 16, 1, 40, 72), (3, 32, 1, 16, 64),
-    (16, 32, 2, 32, 48), (32, 64, 1, 24, 32), (64, 128, 2, 16, 16), (24, 96, 1, 8, 32),
+    (16, 32, 2, 32, 48), (32, 64, 1, 24, 32), (64, 128, 2, 16, 16), (24, 96, 1, 8, 32), (16, 32, 3, 64, 64),
 ]
 
 

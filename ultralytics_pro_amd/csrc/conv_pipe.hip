@@ -295,8 +295,13 @@ constexpr int NDMA = (NSLOT + 63) / 64;      // 9
 constexpr int HB = NDMA * 1024;
 }  // namespace c16
 
-template <int ACT, bool RES>
+// NT = output n-tiles per wave: 1 (16 -> 16) or 2 (16 -> 32: yolov3-tiny row 2, 102 k pixels x 32 images at 320 x 320 - on the generic
+// pipelined kernel its 64-byte k-tiles are half padding and it ran at 1 TB/s); the B fragment of a tap pair feeds both n-tiles.
+// POOL (NT = 2): MaxPool2d(2, 2, 0) of the activations in the epilogue, as conv3x3_pipe_kernel<.., POOL>.
+template <int ACT, bool RES, int NT = 1, bool POOL = false>
 __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_c16_kernel(const PipeParams p) {
+  static_assert(NT == 1 || (NT == 2 && !RES), "two n-tiles: no residual form");
+  static_assert(!POOL || NT == 2, "pooled form: 32 output channels");
   using namespace c16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -342,19 +347,24 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_c16_kernel(const PipePa
     }
   };
   // A fragments of the five tap pairs (standard packing: [tap][ktile 0][ntile 0][lane][16 B], lanes kg 0/1 = channels 0-15)
-  u32x4 A[5];
+  u32x4 A[NT][5];
   int boffs[5];  // this lane's byte offset of its tap inside the halo, relative to (row 0, pixel p16)
 #pragma unroll
   for (int s2 = 0; s2 < 5; ++s2) {
     const int tap = 2 * s2 + (kg >> 1);
     const int tapc = tap < 9 ? tap : 8;
-    A[s2] = (tap < 9 && !UPA_ABL(p, 2))
-                ? *reinterpret_cast<const u32x4*>(p.w + ((size_t)tap * p.NTn * 1024 + ((kg & 1) * 16 + p16) * 16))
-                : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      A[nt][s2] = (tap < 9 && !UPA_ABL(p, 2))
+                      ? *reinterpret_cast<const u32x4*>(p.w + ((size_t)(tap * p.NTn + nt) * 1024 + ((kg & 1) * 16 + p16) * 16))
+                      : u32x4{0u, 0u, 0u, 0u};
     const int dy = tapc / 3, dx = tapc - dy * 3;
     boffs[s2] = ((dy * IW + dx + p16) * c16::PS) + (kg & 1) * 16;
   }
-  const f32x4 biasv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + kg * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 biasn[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) biasn[nt] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nt * 16 + kg * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4 biasv = biasn[0];
   auto act = [](float v) __attribute__((always_inline)) {
     if constexpr (ACT == UPA_ACT_SILU) return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
     else return v;
@@ -371,6 +381,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_c16_kernel(const PipePa
     // this tile's halo must have landed; the TH / 2 stores of the previous tile are the youngest vector-memory operations of
     // the wave (operations retire in issue order) and may stay in flight
     if (first || UPA_ABL(p, 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (NT == 2 && !POOL) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // TH stores per tile in that form
+    else if constexpr (POOL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // its stores are exec-masked (even pixels): not counted on
     else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     first = false;
     static_assert(TH == 8, "vmcnt(4) above = TH / 2 epilogue stores");
@@ -379,20 +391,69 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_c16_kernel(const PipePa
       issue_dma(nxt, buf ^ 1);
     }
     const char* hbuf = hb + buf * c16::HB;
-    f32x4 acc[TH];
+    f32x4 accn[NT][TH];
 #pragma unroll
-    for (int i = 0; i < TH; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int i = 0; i < TH; ++i) accn[nt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (!UPA_ABL(p, 8)) {
 #pragma unroll
       for (int i = 0; i < TH; ++i) {
 #pragma unroll
         for (int s2 = 0; s2 < 5; ++s2) {
           const u32x4 b = *reinterpret_cast<const u32x4*>(hbuf + boffs[s2] + i * (IW * c16::PS));
-          acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&A[s2]),
-                                                           *reinterpret_cast<const bf16x8*>(&b), acc[i], 0, 0, 0);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            accn[nt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&A[nt][s2]),
+                                                                  *reinterpret_cast<const bf16x8*>(&b), accn[nt][i], 0, 0, 0);
         }
       }
     }
+    if constexpr (NT == 2) {
+      // two n-tiles: lanes of 16-lane row kg hold channels 4kg..+3 (tile 0) and 16 + 4kg..+3 (tile 1) of pixel p16; after the swap
+      // even rows own 8 consecutive channels of tile 0, odd rows 8 of tile 1 (as conv3x3_pipe_kernel)
+      const int cb = 16 * (kg & 1) + 8 * (kg >> 1);
+      if constexpr (POOL) {
+        auto bf16r = [](float v) __attribute__((always_inline)) { return __uint_as_float(pack_bf16x2(v, 0.f) << 16); };
+        const int HP = p.H >> 1, WP = p.W >> 1;
+#pragma unroll
+        for (int i = 0; i < TH; i += 2) {
+          const unsigned pixp = (unsigned)((cur.n * HP + ((cur.oy0 + i) >> 1)) * WP + ((cur.ox0 + p16) >> 1));
+          float v0[4], v1[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float a = fmaxf(bf16r(act(accn[0][i][q] + biasn[0][q])), bf16r(act(accn[0][i + 1][q] + biasn[0][q])));
+            const float b = fmaxf(bf16r(act(accn[1][i][q] + biasn[1][q])), bf16r(act(accn[1][i + 1][q] + biasn[1][q])));
+            v0[q] = fmaxf(a, __shfl_xor(a, 1));
+            v1[q] = fmaxf(b, __shfl_xor(b, 1));
+          }
+          auto lo = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v1[0], v1[1]), false, false);
+          auto hi = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[2], v1[3]), false, false);
+          if ((p16 & 1) == 0 && !UPA_ABL(p, 4))
+            *reinterpret_cast<u32x4*>(p.y + ((size_t)pixp * p.ldy + cb) * 2) = u32x4{lo[0], hi[0], lo[1], hi[1]};
+        }
+      } else {
+        unsigned pix = (unsigned)((cur.n * p.H + cur.oy0) * p.W + cur.ox0 + p16);
+#pragma unroll
+        for (int i = 0; i < TH; ++i, pix += p.W) {
+          float v0[4], v1[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            v0[q] = act(accn[0][i][q] + biasn[0][q]);
+            v1[q] = act(accn[1][i][q] + biasn[1][q]);
+          }
+          auto lo = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v1[0], v1[1]), false, false);
+          auto hi = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[2], v1[3]), false, false);
+          if (!UPA_ABL(p, 4)) *reinterpret_cast<u32x4*>(p.y + ((size_t)pix * p.ldy + cb) * 2) = u32x4{lo[0], hi[0], lo[1], hi[1]};
+        }
+      }
+      if (!hasNext) break;
+      cur = nxt;
+      tile = ntile;
+      buf ^= 1;
+      continue;
+    }
+    f32x4 (&acc)[TH] = accn[0];
     // epilogue: rows i (even) and i+1 swap halves - even 16-lane groups end up with 8 consecutive channels of row i, odd
     // groups with 8 of row i+1
     const unsigned pixbase = (unsigned)((cur.n * p.H + cur.oy0) * p.W + cur.ox0 + p16);
@@ -442,6 +503,20 @@ static int launch_c16(const PipeParams& p, hipStream_t s, const upa_opts* opts) 
   const int max_wgs = UPA_OPT(opts, c16_wgs) > 0 ? UPA_OPT(opts, c16_wgs) : 512;
   int grid = (p.numTiles + WAVES - 1) / WAVES;
   if (grid > max_wgs) grid = max_wgs;
+  if (p.Cout == 32) {  // two n-tiles per wave (no residual form: the dispatcher keeps those on the generic kernel)
+    if (p.pool) {
+      (void)upa_full_lds<conv3x3_c16_kernel<UPA_ACT_SILU, false, 2, true>>();
+      hipLaunchKernelGGL((conv3x3_c16_kernel<UPA_ACT_SILU, false, 2, true>), dim3(grid), dim3(WAVES * 64), lds, s, p);
+    } else if (p.act == UPA_ACT_SILU) {
+      (void)upa_full_lds<conv3x3_c16_kernel<UPA_ACT_SILU, false, 2, false>>();
+      hipLaunchKernelGGL((conv3x3_c16_kernel<UPA_ACT_SILU, false, 2, false>), dim3(grid), dim3(WAVES * 64), lds, s, p);
+    } else {
+      (void)upa_full_lds<conv3x3_c16_kernel<UPA_ACT_NONE, false, 2, false>>();
+      hipLaunchKernelGGL((conv3x3_c16_kernel<UPA_ACT_NONE, false, 2, false>), dim3(grid), dim3(WAVES * 64), lds, s, p);
+    }
+    UPA_LAUNCH_CHECK();
+    return UPA_OK;
+  }
 #define UPA_C16_LAUNCH(ACT_, RES_)                                                                        \
   do {                                                                                                    \
     (void)upa_full_lds<conv3x3_c16_kernel<ACT_, RES_>>();                                                 \
@@ -522,8 +597,8 @@ int upa_conv_pipe_launch(PipeParams p, int query_only, int* variant, void* strea
 #ifdef UPA_ABLATE
   p.ablate = UPA_OPT(opts, ablate_pipe);
 #endif
-  if (p.Cin == 16 && p.Cout == 16 && !UPA_OPT(opts, no_c16)) {
-    if (variant) *variant = (1 << 21) | (1 << 8) | 1;
+  if (p.Cin == 16 && (p.Cout == 16 || (p.Cout == 32 && !p.res)) && !UPA_OPT(opts, no_c16)) {
+    if (variant) *variant = (1 << 21) | (1 << 8) | (p.Cout == 32 ? 2 : 1);
     return query_only ? UPA_OK : launch_c16(p, s, opts);
   }
   const int max_wgs = UPA_OPT(opts, pipe_wgs) > 0 ? UPA_OPT(opts, pipe_wgs) : 256;
