@@ -130,6 +130,9 @@ int upa_conv2d_stem_nchw(const void* x_nchw, int x_dtype, int n, int cin, int h,
  * layout + folded bias; w1 / b1: upa_pack_conv_weight(UPA_BF16) layout + folded bias; y: NHWC bf16 (n, h/4, w/4, 32). */
 int upa_stem_conv_fused(const void* x, int n, int h, int w, const float* w0, const float* b0, const void* w1,
                         const float* b1, void* y, int ldy, const upa_opts* opts, void* stream);
+/* ... with the first conv's kernel size given: k0 = 3 (pad 1) | 6 (pad 2: yolov5's Conv(3, 16, 6, 2, 2), cfg/models/v5/Detect/yolov5-BoT3.yaml:15) */
+int upa_stem_conv_fused_k(const void* x, int n, int h, int w, int k0, const float* w0, const float* b0, const void* w1,
+                          const float* b1, void* y, int ldy, const upa_opts* opts, void* stream);
 
 /* ---- pooling / resampling / concat (HBM-bound) --------------------------------------------------------------- */
 /* nn.MaxPool2d(k, s, p) with -inf padding; pad_br>0 emulates nn.ZeroPad2d([0,pad_br,0,pad_br]) in front of it

@@ -88,7 +88,11 @@ BF16_BOUNDS = {  # name: (recall@.9, precision@.9, recall@.5, precision@.5, matc
     # the two-taps-per-k-step kernel (another f32 summation order, same rounding points: its unit tests are bit-exact / bf16-close)
     # .902 .939 | .941 .980 | 2.36 4.45 0.0100.  A report on the chaotic family; the gate is the smooth-family test below.
     "yolov3-tiny": (0.85, 0.85, 0.90, 0.93, 3.5, 6.0, 0.015),
-    "yolov5-BoT3": (0.80, 0.80, 0.95, 0.95, 2.5, 20.0, 0.035),  # measured .857 .866 | .979 .989 | 1.56 14.4 0.0243
+    # rounds 2-3 measured .857 .866 | .979 .989 | 1.56 14.4 0.0243; round 4 with rows 0-1 on the fused stem kernel (99.958 % of the stem
+    # output bit-identical to the rounding-point emulation, test_e2e_bf16_layer_by_layer...[yolov5-BoT3]) .725 .745 | .952 .978 | 1.68 2.69
+    # 0.0307: on this chaotic family a different f32 summation order in the FIRST layer reshuffles which boxes agree to IoU 0.9 (the
+    # matched-box median is 0.2 px on boxes a few pixels wide); the IoU 0.5 agreement and the deviations are what they were.
+    "yolov5-BoT3": (0.65, 0.65, 0.93, 0.95, 2.5, 20.0, 0.04),
 }
 
 
@@ -850,7 +854,8 @@ def test_e2e_bf16_matches_rounding_point_emulation(family, batch):
         assert a["recall"] >= 0.85 and a["precision"] >= 0.85
 
 
-def test_e2e_bf16_layer_by_layer_vs_rounding_point_emulation():
+@pytest.mark.parametrize("name", ["yolov8n", "yolov5-BoT3"])
+def test_e2e_bf16_layer_by_layer_vs_rounding_point_emulation(name):
     """Where the two bf16 implementations part: every layer output of ONE full HIP bf16 forward (yolov8n, smooth family, bs 2: fused
     stem, whole-block C2f kernels, virtual Upsample + Concat) against the same layer of the CPU emulation (oracle/bf16_emul.py).
     Both store bf16 at the same tensors, so the first layers must agree BIT FOR BIT except where an f32 sum lands on a rounding
@@ -858,9 +863,9 @@ def test_e2e_bf16_layer_by_layer_vs_rounding_point_emulation():
     statement about the bf16 mode: fraction of bit-identical elements and the largest deviation in bf16 ulps, per layer."""
     from oracle.bf16_emul import bf16_ulp, emulate_bf16
     from tests.hip_utils import DEV
-    fam = "smooth:yolov8n"
+    fam = "smooth:" + name
     x = P.synthetic_images(2)
-    o = ot.DetectionModel("yolov8n.yaml")
+    o = ot.DetectionModel(name + ".yaml")
     P.apply_procedural_weights(o, family=fam)
     o.eval()
     e = emulate_bf16(o)
@@ -869,7 +874,7 @@ def test_e2e_bf16_layer_by_layer_vs_rounding_point_emulation():
         mod.register_forward_hook(lambda m_, _i, out: em.__setitem__(m_.i, out) if torch.is_tensor(out) else None)
     with torch.no_grad():
         e(x)
-    m = _build("yolov8n", torch.bfloat16, family=fam)
+    m = _build(name, torch.bfloat16, family=fam)
     m.model[-1].keep_raw = False
     hip = {}
 
@@ -896,9 +901,13 @@ def test_e2e_bf16_layer_by_layer_vs_rounding_point_emulation():
     # Measured on MI355X (round 4): bit-identical 0.99975 (fused stem) -> 0.9984 (model.2) -> 0.994 -> 0.927 (model.4) -> 0.84 -> 0.65 ->
     # 0.53 -> ~0.45 from the SPPF on; within one ulp 0.99995 -> 0.9997 -> 0.9987 -> 0.98 -> 0.96 -> 0.90 -> ~0.77-0.80.  The first layers are
     # the pin: a missed or misplaced rounding point in the stem / model.2 / model.3 kernels would drop them far below these bounds.
-    assert rows[1][0] >= 0.999 and rows[1][2] <= 4.0, "the fused stem must reproduce the emulation up to one-ulp boundary flips"
-    assert rows[2][0] >= 0.995 and rows[3][0] >= 0.985 and rows[4][0] >= 0.88
-    assert min(r[0] for r in rows.values()) >= 0.35 and min(r[1] for r in rows.values()) >= 0.70
+    # (yolov5's 6x6 first conv sums 108 products per output: 99.958 % bit-identical, largest deviation 5.5 floored ulps)
+    assert rows[1][0] >= 0.999 and rows[1][2] <= (4.0 if name == "yolov8n" else 8.0), "the fused stem must reproduce the emulation up to boundary flips"
+    if name == "yolov8n":
+        assert rows[2][0] >= 0.995 and rows[3][0] >= 0.985 and rows[4][0] >= 0.88
+        assert min(r[0] for r in rows.values()) >= 0.35 and min(r[1] for r in rows.values()) >= 0.70
+    else:  # (the emulation does not model MHSA's internal roundings: the rows before the BoT3 block are the statement)
+        assert rows[2][0] >= 0.99 and rows[3][0] >= 0.98
 
 
 def test_e2e_yolov3_tiny_conv_pool_fusion_is_exact():

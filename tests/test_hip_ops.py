@@ -1023,24 +1023,26 @@ def test_scale_boxes_matches_reference_formula():
         assert torch.equal(got.cpu(), ref)
 
 
+@pytest.mark.parametrize("cfg", ["yolov8n", "yolov5-BoT3"], ids=["k3", "k6"])
 @pytest.mark.parametrize("shape", [(2, 3, 128, 128), (3, 3, 100, 136), (1, 3, 64, 256)], ids=["sq", "ragged", "wide"])
-def test_fused_stem_and_second_conv_equals_the_two_layers(shape):
-    """yolov8n rows 0-1 as one kernel (upa_stem_conv_fused: the stem output stays in LDS) vs the two separate HIP layers
-    and vs the oracle (Conv, conv.py:188-197) on a bf16 NCHW input; image borders, partial tiles, odd tile counts."""
+def test_fused_stem_and_second_conv_equals_the_two_layers(shape, cfg):
+    """Rows 0-1 of yolov8n (Conv(3,16,3,2) -> Conv(16,32,3,2)) and of the yolov5 family (Conv(3,16,6,2,2) -> Conv(16,32,3,2)) as one
+    kernel (upa_stem_conv_fused_k: the stem output stays in LDS) vs the two separate HIP layers and vs the oracle (Conv,
+    conv.py:188-197) on a bf16 NCHW input; image borders, partial tiles, odd tile counts."""
     from tests.hip_utils import DEV, bf16_round, to_cpu_nchw
     from ultralytics_pro_amd.nn.tasks import DetectionModel
     from oracle import tasks as ot
-    m = DetectionModel("yolov8n.yaml")
+    m = DetectionModel(cfg + ".yaml")
     P.apply_procedural_weights(m)
     m = m.to(DEV).eval()
     m.set_compute_dtype(torch.bfloat16)
     x = bf16_round(P.uniform(f"fstem{shape}", shape, 0, 1))
     xd = x.to(DEV).to(torch.bfloat16).contiguous()
     with torch.no_grad():
-        assert m._stem_fusable(xd, m._concat_placement())
+        assert m._stem_fusable(xd, m._concat_placement()), cfg
         fused = to_cpu_nchw(m._fused_stem(xd))
         two = to_cpu_nchw(m.model[1](m.model[0](xd)))
-        o = ot.DetectionModel("yolov8n.yaml")
+        o = ot.DetectionModel(cfg + ".yaml")
         P.apply_procedural_weights(o)
         from tests.hip_utils import assert_bf16_close, bf16_weight_oracle
         l0, l1 = bf16_weight_oracle(o.model[0]), bf16_weight_oracle(o.model[1])

@@ -493,21 +493,30 @@ constexpr int S0H = 2 * T1H + 1, S0W = 2 * T1W + 1;  // stem tile 17 x 33
 constexpr int S0WH = (S0W + 1) / 2;            // 17 columns per parity
 constexpr int SPITCH = 48;                     // bytes per stem pixel in LDS (32 used)
 constexpr int STILE = S0H * 2 * S0WH * SPITCH; // 27744
-constexpr int PR = 2 * S0H + 1, PC = 2 * S0W + 1;  // input patch 35 x 67
-constexpr int NCH = (PC + 7 + 7) / 8;          // 16-byte chunks per patch line (origin rounded down to 8 pixels)
-constexpr int LS = NCH * 8;
-constexpr int ITEMS = 3 * PR * NCH;
-constexpr int items_pad(int nw) { return (ITEMS + nw * 64 - 1) / (nw * 64) * (nw * 64); }
-constexpr int patch_bytes(int nw) { return items_pad(nw) * 16; }
+// first conv k = KS0 (3: yolov8, pad 1 | 6: yolov5, pad 2), stride 2: input patch (2 (S0H - 1) + KS0) x (2 (S0W - 1) + KS0) = 35 x 67 | 38 x 70
+template <int KS0>
+struct Geo {
+  static constexpr int PAD0 = KS0 == 3 ? 1 : 2;
+  static constexpr int PR = 2 * (S0H - 1) + KS0, PC = 2 * (S0W - 1) + KS0;
+  static constexpr int NCH = (PC + 7 + 7) / 8;   // 16-byte chunks per patch line (origin rounded down to 8 pixels)
+  static constexpr int LS = NCH * 8;
+  static constexpr int ITEMS = 3 * PR * NCH;
+  static constexpr int KTOT = 3 * KS0 * KS0, KSTEPS = (KTOT + 31) / 32;   // im2col depth of a stem pixel: 27 -> 1 k-step, 108 -> 4
+  static constexpr int SHIFT = (-(2 + PAD0)) & 7;  // input origin 4 * (16 txi) - 2 - PAD0, rounded down to 8 pixels
+  static constexpr int items_pad(int nw) { return (ITEMS + nw * 64 - 1) / (nw * 64) * (nw * 64); }
+  static constexpr int patch_bytes(int nw) { return items_pad(nw) * 16; }
+};
 }  // namespace sf
 
 // NW waves per workgroup: 4 (two workgroups = two waves per SIMD) or 8 (four per SIMD: the segments of stage 2 and the rows of
 // stage 3 are spread over twice the waves, the same LDS).
-template <int NW>
+template <int NW, int KS0 = 3>
 __global__ __launch_bounds__(NW * 64) void stem_conv_fused_kernel(const StemFusedParams p) {
   using namespace sf;
-  constexpr int ITEMS_PAD = items_pad(NW);
-  constexpr int PATCH = patch_bytes(NW);
+  using G0 = Geo<KS0>;
+  constexpr int PR = G0::PR, NCH = G0::NCH, LS = G0::LS, ITEMS = G0::ITEMS, KS0STEPS = G0::KSTEPS;
+  constexpr int ITEMS_PAD = G0::items_pad(NW);
+  constexpr int PATCH = G0::patch_bytes(NW);
   constexpr int NTH = NW * 64;
   extern __shared__ __attribute__((aligned(16))) char fsm[];  // [2][PATCH] input patches, [STILE] stem tile
   char* stile = fsm + 2 * PATCH;
@@ -534,7 +543,7 @@ __global__ __launch_bounds__(NW * 64) void stem_conv_fused_kernel(const StemFuse
     const int t2 = tile - n * tilesPerImg;
     const int tyi = t2 / p.tilesX, txi = t2 - tyi * p.tilesX;
     // output tile origin (oy0, ox0) -> stem origin (2*oy0 - 1, 2*ox0 - 1) -> input origin (2*sy0 - 1, 2*sx0 - 1)
-    const int iy0 = 2 * (2 * tyi * T1H - 1) - 1, ix0 = 2 * (2 * txi * T1W - 1) - 1;
+    const int iy0 = 2 * (2 * tyi * T1H - 1) - G0::PAD0, ix0 = 2 * (2 * txi * T1W - 1) - G0::PAD0;
     const int ixa = ix0 & ~7;
     const bf16_t* xb = (const bf16_t*)p.x + (size_t)n * 3 * plane;
     const bf16_t* xt = xb + iy0 * p.W + ixa;  // patch origin (may lie outside the image: only in-image items are read)
@@ -549,16 +558,17 @@ __global__ __launch_bounds__(NW * 64) void stem_conv_fused_kernel(const StemFuse
   int tile = blockIdx.x;
   if (tile >= ntiles) return;
   stage(tile, fsm);
-  // ---- stem weights -> one A fragment; k = (kh*3 + kw)*3 + ci (packed [tap][ci][co16] f32)
-  u32x4 a0;
-  {
+  // ---- stem weights -> KS0STEPS A fragments; k = (kh*KS0 + kw)*3 + ci (packed [tap][ci][co16] f32)
+  u32x4 a0[KS0STEPS];
+#pragma unroll
+  for (int ks = 0; ks < KS0STEPS; ++ks) {
     float wv[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int k = kg * 8 + j;
-      wv[j] = k < 27 ? p.w0[k * 16 + l16] : 0.f;
+      const int k = ks * 32 + kg * 8 + j;
+      wv[j] = k < G0::KTOT ? p.w0[k * 16 + l16] : 0.f;
     }
-    a0 = u32x4{pack_bf16x2(wv[0], wv[1]), pack_bf16x2(wv[2], wv[3]), pack_bf16x2(wv[4], wv[5]), pack_bf16x2(wv[6], wv[7])};
+    a0[ks] = u32x4{pack_bf16x2(wv[0], wv[1]), pack_bf16x2(wv[2], wv[3]), pack_bf16x2(wv[4], wv[5]), pack_bf16x2(wv[6], wv[7])};
   }
   f32x4 bias0;
 #pragma unroll
@@ -581,19 +591,21 @@ __global__ __launch_bounds__(NW * 64) void stem_conv_fused_kernel(const StemFuse
 #pragma unroll
     for (int r = 0; r < 4; ++r) bias1[nt][r] = p.b1 ? p.b1[nt * 16 + kg * 4 + r] : 0.f;
   // stem gather offsets (elements inside a patch buffer): k -> (tap, ci) -> patch[ci][kh][kw + shift]
-  const int shift = 5;  // input origin 4*(16*txi) - 3: (-3) & 7
-  int goff[8];
+  constexpr int shift = G0::SHIFT;  // 5 (k 3: origin 4 * 16 txi - 3) | 4 (k 6: - 4)
+  int goff[KS0STEPS][8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int k = kg * 8 + j;
-    int o = 0;
-    if (k < 27) {
-      const int tap = k / 3, ci = k - tap * 3;
-      const int kh = tap / 3, kw = tap - kh * 3;
-      o = (ci * PR + kh) * LS + kw;
+  for (int ks = 0; ks < KS0STEPS; ++ks)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = ks * 32 + kg * 8 + j;
+      int o = 0;
+      if (k < G0::KTOT) {
+        const int tap = k / 3, ci = k - tap * 3;
+        const int kh = tap / KS0, kw = tap - kh * KS0;
+        o = (ci * PR + kh) * LS + kw;
+      }
+      goff[ks][j] = (o + shift) * 2;
     }
-    goff[j] = (o + shift) * 2;
-  }
   for (int cur = 0;; cur ^= 1) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // patch `cur` landed; everyone is done with the stem tile and the other patch buffer
@@ -617,12 +629,16 @@ __global__ __launch_bounds__(NW * 64) void stem_conv_fused_kernel(const StemFuse
         const bool qin = q < S0H * S0W;
         const int qq = qin ? q : S0H * S0W - 1;     // lanes past the tile (last segment) gather the last pixel, never stored
         const int r = qq / S0W, c = qq - r * S0W;   // stem tile row / column of this lane's pixel
-        unsigned e[8];
         const char* base = pb + ((2 * r) * LS + 2 * c) * 2;
+        f32x4 acc = bias0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) e[j] = *reinterpret_cast<const unsigned short*>(base + goff[j]);
-        u32x4 b = u32x4{e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
-        f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&a0), *reinterpret_cast<bf16x8*>(&b), bias0, 0, 0, 0);
+        for (int ks = 0; ks < KS0STEPS; ++ks) {
+          unsigned e[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) e[j] = *reinterpret_cast<const unsigned short*>(base + goff[ks][j]);
+          u32x4 b = u32x4{e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&a0[ks]), *reinterpret_cast<bf16x8*>(&b), acc, 0, 0, 0);
+        }
         // lane (kg, l16): channels 4kg..4kg+3 of stem pixel q; zero outside the stem map (padding of the second conv)
         bool inmap = true;
         if constexpr (MASKED) {
@@ -775,12 +791,14 @@ static int stem_nchw_impl(const void* x, int x_dtype, int n, int cin, int h, int
   return UPA_OK;
 }
 
-/* Fused Conv(3,16,3,2,1)+SiLU -> Conv(16,32,3,2,1)+SiLU on a bf16 NCHW input (W % 8 == 0): the 16-channel intermediate never
- * reaches HBM.  w0 / b0: stem weights packed by upa_pack_stem_weight (+ folded bias); w1 / b1: second conv packed by
+/* Fused Conv(3,16,k0,2)+SiLU -> Conv(16,32,3,2,1)+SiLU on a bf16 NCHW input (W % 8 == 0): the 16-channel intermediate never
+ * reaches HBM.  k0 = 3 (pad 1: yolov8.yaml rows 0-1) or 6 (pad 2: yolov5 rows 0-1, cfg/models/v5/Detect/yolov5-BoT3.yaml:15-16).
+ * w0 / b0: stem weights packed by upa_pack_stem_weight (+ folded bias); w1 / b1: second conv packed by
  * upa_pack_conv_weight(bf16) (+ folded bias).  y: NHWC bf16 view (n, h/4, w/4, 32). */
-extern "C" int upa_stem_conv_fused(const void* x, int n, int h, int w, const float* w0, const float* b0, const void* w1,
-                                   const float* b1, void* y, int ldy, const upa_opts* opts, void* stream) {
+static int stem_conv_fused_impl(const void* x, int n, int h, int w, int k0, const float* w0, const float* b0, const void* w1,
+                                const float* b1, void* y, int ldy, const upa_opts* opts, void* stream) {
   UPA_CHECK_ARG(x && w0 && w1 && y, "stem_conv_fused: null pointer");
+  UPA_CHECK_ARG(k0 == 3 || k0 == 6, "stem_conv_fused: first conv k = 3 (pad 1) or 6 (pad 2)");
   UPA_CHECK_ARG(w % 8 == 0 && h % 4 == 0 && w % 4 == 0 && (long)3 * h * w < (1L << 31), "stem_conv_fused: w %% 8, h %% 4 == 0 required");
   UPA_CHECK_ARG(ldy % 8 == 0 && (uintptr_t)y % 16 == 0, "stem_conv_fused: output view must be 16-byte aligned");
   StemFusedParams p{};
@@ -791,13 +809,26 @@ extern "C" int upa_stem_conv_fused(const void* x, int n, int h, int w, const flo
   const int wgs = UPA_OPT(opts, stemf_wgs) > 0 ? UPA_OPT(opts, stemf_wgs) : 512;
   const int nw = UPA_OPT(opts, stemf_waves) == 4 ? 4 : 8;
   const dim3 grid((unsigned)(ntiles < wgs ? ntiles : wgs));
-  if (nw == 4) {
-    (void)upa_full_lds<stem_conv_fused_kernel<4>>();
-    hipLaunchKernelGGL(stem_conv_fused_kernel<4>, grid, dim3(256), (size_t)2 * sf::patch_bytes(4) + sf::STILE, (hipStream_t)stream, p);
+  hipStream_t st = (hipStream_t)stream;
+  if (k0 == 6) {  // 4 waves: the 4 x 8 gather offsets + 4 A fragments of the 108-deep im2col row do not fit 128 registers
+    (void)upa_full_lds<stem_conv_fused_kernel<4, 6>>();
+    hipLaunchKernelGGL((stem_conv_fused_kernel<4, 6>), grid, dim3(256), (size_t)2 * sf::Geo<6>::patch_bytes(4) + sf::STILE, st, p);
+  } else if (nw == 4) {
+    (void)upa_full_lds<stem_conv_fused_kernel<4, 3>>();
+    hipLaunchKernelGGL((stem_conv_fused_kernel<4, 3>), grid, dim3(256), (size_t)2 * sf::Geo<3>::patch_bytes(4) + sf::STILE, st, p);
   } else {
-    (void)upa_full_lds<stem_conv_fused_kernel<8>>();
-    hipLaunchKernelGGL(stem_conv_fused_kernel<8>, grid, dim3(512), (size_t)2 * sf::patch_bytes(8) + sf::STILE, (hipStream_t)stream, p);
+    (void)upa_full_lds<stem_conv_fused_kernel<8, 3>>();
+    hipLaunchKernelGGL((stem_conv_fused_kernel<8, 3>), grid, dim3(512), (size_t)2 * sf::Geo<3>::patch_bytes(8) + sf::STILE, st, p);
   }
   UPA_LAUNCH_CHECK();
   return UPA_OK;
+}
+extern "C" int upa_stem_conv_fused(const void* x, int n, int h, int w, const float* w0, const float* b0, const void* w1,
+                                   const float* b1, void* y, int ldy, const upa_opts* opts, void* stream) {
+  return stem_conv_fused_impl(x, n, h, w, 3, w0, b0, w1, b1, y, ldy, opts, stream);
+}
+/* The same with the first conv's kernel size given: k0 = 3 | 6 (yolov5's Conv(3, 16, 6, 2, 2)). */
+extern "C" int upa_stem_conv_fused_k(const void* x, int n, int h, int w, int k0, const float* w0, const float* b0, const void* w1,
+                                     const float* b1, void* y, int ldy, const upa_opts* opts, void* stream) {
+  return stem_conv_fused_impl(x, n, h, w, k0, w0, b0, w1, b1, y, ldy, opts, stream);
 }

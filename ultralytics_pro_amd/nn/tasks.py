@@ -335,7 +335,8 @@ class BaseModel(nn.Module):
         if getattr(self, "compute_dtype", None) != torch.bfloat16 or x.dtype != torch.bfloat16 or x.dim() != 4:
             return False
         ca, cb = a.conv, b.conv
-        ok = (ca.in_channels, ca.out_channels, ca.kernel_size, ca.stride, ca.padding) == (3, 16, (3, 3), (2, 2), (1, 1)) and \
+        first = (ca.in_channels, ca.out_channels, ca.kernel_size, ca.stride, ca.padding)
+        ok = first in ((3, 16, (3, 3), (2, 2), (1, 1)), (3, 16, (6, 6), (2, 2), (2, 2))) and \
             (cb.in_channels, cb.out_channels, cb.kernel_size, cb.stride, cb.padding) == (16, 32, (3, 3), (2, 2), (1, 1)) and \
             isinstance(a.act, nn.SiLU) and isinstance(b.act, nn.SiLU) and not a.training
         n, c, h, w = x.shape
@@ -348,9 +349,9 @@ class BaseModel(nn.Module):
         n, _, h, w = x.shape
         y = R.alloc_nhwc(n, 32, h // 4, w // 4, torch.bfloat16, x.device, key=(id(b), "y"))
         vy = R.view_of(y)
-        L.check(L.lib().upa_stem_conv_fused(x.data_ptr(), n, h, w, pa.w.data_ptr(), pa.bias.data_ptr(), pb.w.data_ptr(),
-                                            pb.bias.data_ptr(), vy.ptr, vy.ld, R.opts_ptr(), L.current_stream(x.device)),
-                "stem_conv_fused")
+        L.check(L.lib().upa_stem_conv_fused_k(x.data_ptr(), n, h, w, int(a.conv.kernel_size[0]), pa.w.data_ptr(), pa.bias.data_ptr(),
+                                              pb.w.data_ptr(), pb.bias.data_ptr(), vy.ptr, vy.ld, R.opts_ptr(),
+                                              L.current_stream(x.device)), "stem_conv_fused")
         return y
 
     def _concat_placement(self):
