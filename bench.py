@@ -840,6 +840,10 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
             return (f"void stem_mfma_kernel<{pk.cout // 16}, {pk.k}, {stride}, {'true' if act == 1 else 'false'}>(StemParams)" if es == 2 else
                     f"void stem_conv_kernel<{tname}, 16, {'true' if act == 1 else 'false'}>(StemParams)")
         var = L.lib().upa_conv_variant(n, h, w, cin, pk.cout, pk.k, stride, pad, code, R.opts_ptr())
+        if (var >> 26) & 1:  # 8-wave two-group phased kernel for the MFMA-bound 3x3 stride-1 layers (conv_p8.hip)
+            return "conv_p8_kernel(BigParams)"
+        if (var >> 25) & 1:  # 4-wave 32x32x16-MFMA kernel for the MFMA-bound 3x3 layers (conv_mm.hip): <ACT, RES>
+            return "void conv_mm_kernel<%d, %s>(MmParams)" % (act, "true" if residual is not None else "false")
         if (var >> 24) & 1:  # persistent weights-stationary 3x3 (conv_ws3.hip): <NT, MT>
             return "void conv_ws3_kernel<%d, %d>(BigParams)" % ((var >> 4) & 15, var & 15)
         if (var >> 23) & 1:  # large-tile LDS-shared-operand kernel (conv_big.hip): <KS, STRIDE, WM, WN, MT, NT>

@@ -61,8 +61,10 @@ typedef struct upa_opts {
   int32_t conv_ws3;        /* csrc/conv_ws3.hip (persistent 3x3 with register-resident weights, Cin <= 64, Cout 64): 0 = by the size rule, 1 = never, 2 = every shape it can run, 3 = the rule restricted to maps of < 100000 pixels (at most one tile per workgroup) */
   int32_t no_group;        /* upa_conv2d_bias_act_group / upa_detect_branch_tail_group: 0 = two problems per grid where the instantiations allow, 1 = one launch per problem, 2 = three per grid too (measured slower; A/B) */
   int32_t no_c2f32_up;     /* 1 = upa_c2f32_up_fused refuses (the block then runs as upa_conv1x1_upcat + upa_bottleneck_pair_cv2; A/B) */
+  int32_t conv_mm;         /* csrc/conv_mm.hip (4-wave 32x32x16-MFMA 3x3 kernel for Cin % 64 == 0, Cout % 128 == 0) inside upa_conv2d_bias_act: 2 = every shape it can run (experiment: measured slower than conv_big, see its header), 0 / 1 = never */
   int32_t no_xcd;          /* 1 = tile kernels take tile blockIdx.x instead of the XCD-aware order (each XCD a contiguous tile range: neighbouring halos meet in one L2); A/B */
   int32_t keys_only;       /* upa_detect_branch_tail* / upa_detect_head_tails with best_keys: 1 = the class rows of y are NOT written - only the boxes and the best-class NMS keys, which is all single-label NMS reads (upa_nms_batched_hot); rows 4.. of y are then undefined */
+  int32_t conv_p8;         /* csrc/conv_p8.hip (8-wave two-group phased 3x3 stride-1 kernel for Cin % 64 == 0, Cout % 128 == 0: counted vmcnt, 4-slab weight ring, double-buffered halo) inside upa_conv2d_bias_act: 0 = by the size rule, 1 = never, 2 = every shape it can run */
 } upa_opts;
 
 /* Library / device info. Returns the ABI version (int); fills name with the kernel target ("gfx950"). */

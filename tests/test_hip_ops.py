@@ -1316,3 +1316,91 @@ def test_c3_stacked_cv1_cv2_equals_separate_launches(cls, args, xshape, dtype):
     else:
         tol = 4e-2 * max(1.0, ref.abs().max().item())  # three to five bf16 layers deep (the blocks' own golden tests use 6e-2)
         assert (y1 - ref).abs().max().item() <= tol and (y1 - y0).abs().max().item() <= tol
+
+
+MM_CASES = [
+    # c1, c2, H, W, N, act, residual  (4-wave 32x32x16-MFMA kernel, csrc/conv_mm.hip: Cin % 64 == 0, Cout % 128 == 0, 3x3 stride 1)
+    (128, 128, 80, 80, 1, True, False),    # 16 x 16 tiles, two chunks
+    (256, 512, 40, 40, 2, True, False),    # 40 x 6 tiles (7 per image, the last ragged), four workgroup columns, four chunks
+    (512, 256, 20, 20, 2, True, True),     # 20 x 10 tiles (200 of 256 pixel slots), the Bottleneck shortcut
+    (64, 128, 33, 47, 1, False, False),    # one chunk, ragged right / bottom tiles, no activation
+    (128, 256, 9, 11, 3, True, True),      # a map smaller than a tile (99 of 256 slots), shortcut
+    (192, 128, 24, 56, 1, True, False),    # three chunks, 56-pixel-wide tiles
+]
+
+
+@pytest.mark.parametrize("case", MM_CASES, ids=[f"c{c[0]}-{c[1]}_{c[2]}x{c[3]}n{c[4]}{'' if c[5] else '_lin'}{'_res' if c[6] else ''}" for c in MM_CASES])
+def test_conv_mm_kernel(case):
+    """bf16 3x3 convs forced through conv_mm_kernel (upa_opts.conv_mm = 2) vs the oracle Conv (conv.py:188-197, + the Bottleneck add
+    block.py:668) on BN-folded bf16 weights: every tile shape the host picks (16 x 16, 40 x 6, 20 x 10, ragged and undersized maps),
+    1 - 4 chunks, 1 - 4 workgroup columns, the shortcut read, the lane remap of the 32 x 32 x 16 fragments and the permlane32 epilogue."""
+    from tests.hip_utils import assert_bf16_close, bf16_round, bf16_weight_oracle, to_cpu_nchw, to_dev_nhwc
+    from ultralytics_pro_amd import _lib as L
+    from ultralytics_pro_amd.engine import runtime as R
+    pm, _ = _mods()
+    c1, c2, H, W, N, act, res = case
+    with R.use_opts(conv_mm=2):
+        var = L.lib().upa_conv_variant(N, H, W, c1, c2, 3, 1, 1, 1, R.opts_ptr())
+        assert (var >> 25) & 1, "case is not dispatched to conv_mm"
+        o, m = _pair(om.Conv, pm.Conv, (c1, c2, 3, 1, None, 1, 1, act), "conv_mm")
+        x = bf16_round(P.uniform(f"mm{case}", (N, c1, H, W), -1, 1))
+        rsd = bf16_round(P.uniform(f"mmres{case}", (N, c2, H, W), -1, 1)) if res else None
+        with torch.no_grad():
+            ref = bf16_weight_oracle(o)(x) + (rsd if res else 0)
+            y = to_cpu_nchw(m(to_dev_nhwc(x, torch.bfloat16), residual=to_dev_nhwc(rsd, torch.bfloat16) if res else None))
+    assert_bf16_close(y, ref, f"conv_mm{case}")
+
+
+P8_CASES = MM_CASES + [
+    (1024, 128, 20, 20, 1, True, False),   # sixteen chunks: the halo double buffer and the weight ring wrap many times
+    (64, 256, 16, 16, 2, True, True),      # ONE chunk: the prefetch of a chunk that does not exist (zero pieces), shortcut
+]
+
+
+@pytest.mark.parametrize("case", P8_CASES, ids=[f"c{c[0]}-{c[1]}_{c[2]}x{c[3]}n{c[4]}{'' if c[5] else '_lin'}{'_res' if c[6] else ''}" for c in P8_CASES])
+def test_conv_p8_kernel(case):
+    """bf16 3x3 convs forced through conv_p8_kernel (upa_opts.conv_p8 = 2: the 8-wave two-group phased kernel, csrc/conv_p8.hip) vs the
+    oracle Conv (conv.py:188-197, + the Bottleneck add block.py:668) on BN-folded bf16 weights: every tile shape the host picks, 1 - 16
+    chunks (halo double buffer, 4-slab weight ring, counted vmcnt), 1 - 4 workgroup columns, the shortcut read."""
+    from tests.hip_utils import assert_bf16_close, bf16_round, bf16_weight_oracle, to_cpu_nchw, to_dev_nhwc
+    from ultralytics_pro_amd import _lib as L
+    from ultralytics_pro_amd.engine import runtime as R
+    pm, _ = _mods()
+    c1, c2, H, W, N, act, res = case
+    with R.use_opts(conv_p8=2):
+        var = L.lib().upa_conv_variant(N, H, W, c1, c2, 3, 1, 1, 1, R.opts_ptr())
+        assert (var >> 26) & 1, "case is not dispatched to conv_p8"
+        o, m = _pair(om.Conv, pm.Conv, (c1, c2, 3, 1, None, 1, 1, act), "conv_p8")
+        x = bf16_round(P.uniform(f"p8{case}", (N, c1, H, W), -1, 1))
+        rsd = bf16_round(P.uniform(f"p8res{case}", (N, c2, H, W), -1, 1)) if res else None
+        with torch.no_grad():
+            ref = bf16_weight_oracle(o)(x) + (rsd if res else 0)
+            y = to_cpu_nchw(m(to_dev_nhwc(x, torch.bfloat16), residual=to_dev_nhwc(rsd, torch.bfloat16) if res else None))
+    assert_bf16_close(y, ref, f"conv_p8{case}")
+
+
+@pytest.mark.parametrize("shape", [(512, 256, 40, 40, 16), (128, 256, 80, 80, 16), (512, 1024, 20, 20, 16)],
+                         ids=["512-256_40", "128-256_80", "512-1024_20"])
+def test_conv_p8_equals_conv_big_full_size(shape):
+    """At the yolov3-rtdetr batch-16 layer sizes conv_p8 must be BIT-IDENTICAL to conv_big (same fragments, same accumulation order:
+    chunk, tap, k-tile) - and stay so over 30 back-to-back launches with other work in flight (a screen for the races a phased kernel
+    can have: a fragment read before its DMA landed, a buffer re-staged under a reader)."""
+    from tests.hip_utils import bf16_round, to_dev_nhwc
+    from ultralytics_pro_amd import _lib as L
+    from ultralytics_pro_amd.engine import runtime as R
+    pm, _ = _mods()
+    c1, c2, H, W, N = shape
+    _, m = _pair(om.Conv, pm.Conv, (c1, c2, 3, 1, None, 1, 1, True), "conv_p8_full")
+    x = to_dev_nhwc(bf16_round(P.uniform(f"p8full{shape}", (N, c1, H, W), -1, 1)), torch.bfloat16)
+    with torch.no_grad():
+        with R.use_opts(conv_p8=1):
+            var = L.lib().upa_conv_variant(N, H, W, c1, c2, 3, 1, 1, 1, R.opts_ptr())
+            assert (var >> 23) & 1 and not (var >> 26) & 1
+            ref = m(x).clone()
+        with R.use_opts(conv_p8=2):
+            var = L.lib().upa_conv_variant(N, H, W, c1, c2, 3, 1, 1, 1, R.opts_ptr())
+            assert (var >> 26) & 1
+            outs = [m(x).clone() for _ in range(30)]
+    torch.cuda.synchronize()
+    bad = [i for i, y in enumerate(outs) if not torch.equal(y, ref)]
+    assert not bad, f"conv_p8 differs from conv_big in launches {bad}: max|d| {max((outs[i].float() - ref.float()).abs().max().item() for i in bad)}"

@@ -896,6 +896,22 @@ extern "C" int upa_conv2d_bias_act(const void* x, int n, int h, int w, int cin, 
     const int rc = upa_conv_ws3_launch(q, g_query_only, &g_last_variant, stream, opts);
     if (rc != UPA_EUNSUPPORTED) return rc;
   }
+  if (upa_conv_p8_eligible(n, h, w, cin, ldx, cout, ldy, residual ? ldr : 0, k, stride, pad, act, dtype, opts)) {
+    BigParams q;
+    memset(&q, 0, sizeof(q));
+    q.x = (const char*)x; q.y = (char*)y; q.res = (const char*)residual; q.w = (const char*)w_packed; q.bias = bias;
+    q.N = n; q.H = h; q.W = w; q.Cin = cin; q.ldx = ldx; q.Cout = cout; q.ldy = ldy; q.ldr = ldr; q.act = act;
+    const int rc = upa_conv_p8_launch(q, g_query_only, &g_last_variant, stream, opts);
+    if (rc != UPA_EUNSUPPORTED) return rc;
+  }
+  if (upa_conv_mm_eligible(n, h, w, cin, ldx, cout, ldy, residual ? ldr : 0, k, stride, pad, act, dtype, opts)) {
+    BigParams q;
+    memset(&q, 0, sizeof(q));
+    q.x = (const char*)x; q.y = (char*)y; q.res = (const char*)residual; q.w = (const char*)w_packed; q.bias = bias;
+    q.N = n; q.H = h; q.W = w; q.Cin = cin; q.ldx = ldx; q.Cout = cout; q.ldy = ldy; q.ldr = ldr; q.act = act;
+    const int rc = upa_conv_mm_launch(q, g_query_only, &g_last_variant, stream, opts);
+    if (rc != UPA_EUNSUPPORTED) return rc;
+  }
   if (upa_conv_big_eligible(n, h, w, cin, ldx, cout, ldy, residual ? ldr : 0, k, stride, pad, act, dtype, opts)) {
     BigParams q;
     memset(&q, 0, sizeof(q));

@@ -766,6 +766,8 @@ extern "C" int upa_detect_head_tails(const upa_branch_level* box, const upa_bran
   return UPA_OK;
 }
 
+bool upa_conv_big_pick_tile(BigParams& p, int bm, int ntb, size_t lds_cap) { return big_pick_tile(p, bm, ntb, lds_cap); }
+
 bool upa_conv_big_eligible(int n, int h, int w, int cin, int ldx, int cout, int ldy, int ldr, int k, int stride, int pad,
                            int act, int dtype, const upa_opts* opts) {
   // upa_opts.conv_big: 0 = by the size rule below (default), 1 = never, 2 = every shape the kernel can run (parity tests,

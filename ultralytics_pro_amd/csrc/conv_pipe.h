@@ -76,6 +76,22 @@ int upa_conv_big_launch(BigParams p, int query_only, int* variant, void* stream,
 // UPA_EUNSUPPORTED = nothing launched (the caller launches the first problem alone and tries again from the next)
 int upa_conv_big_launch_group(const BigParams* probs, int count, int* consumed, void* stream, const upa_opts* opts);
 
+// tile shape + halo geometry (TH, TW, IH, IW, IWp, HALF, magicTW, magicIW) of a bm-pixel x ntb-n-tile workgroup whose halo + two weight slabs
+// + 256 B fit lds_cap (conv_big.hip's search, memoised); false if nothing fits.  p.OH / OW / KS / stride must be set.
+bool upa_conv_big_pick_tile(BigParams& p, int bm, int ntb, size_t lds_cap);
+
+// ---- conv_p8.hip: 8-wave two-group phased kernel for the MFMA-bound 3x3 stride-1 layers (bf16, Cin % 64 == 0, Cout % 128 == 0); BigParams as conv_big
+bool upa_conv_p8_eligible(int n, int h, int w, int cin, int ldx, int cout, int ldy, int ldr, int k, int stride, int pad, int act,
+                          int dtype, const upa_opts* opts);
+// variant (if non-null) receives (1 << 26) | 8 << 4 | 2; query_only = 1 skips the launch
+int upa_conv_p8_launch(BigParams p, int query_only, int* variant, void* stream, const upa_opts* opts);
+
+// ---- conv_mm.hip: 4-wave 32x32x16-MFMA kernel for the MFMA-bound 3x3 stride-1 layers (bf16, Cin % 64 == 0, Cout % 128 == 0); BigParams as conv_big
+bool upa_conv_mm_eligible(int n, int h, int w, int cin, int ldx, int cout, int ldy, int ldr, int k, int stride, int pad, int act,
+                          int dtype, const upa_opts* opts);
+// variant (if non-null) receives (1 << 25) | 8 << 4 | 2; query_only = 1 skips the launch
+int upa_conv_mm_launch(BigParams p, int query_only, int* variant, void* stream, const upa_opts* opts);
+
 // ---- conv_ws3.hip: persistent weights-stationary 3x3 (bf16, stride 1, pad 1, Cin <= 64, Cout = 64); BigParams as conv_big
 bool upa_conv_ws3_eligible(int n, int h, int w, int cin, int ldx, int cout, int ldy, bool residual, int k, int stride, int pad,
                            int act, int dtype, const upa_opts* opts);

@@ -20,6 +20,7 @@ struct StemParams {
   int TH, TW, tilesX, tilesY, PR, PC, PCS;  // output tile, patch rows/cols, padded LDS row stride
   int wgs;  // stem_mfma_kernel: persistent workgroup cap
   int pool; // stem_mfma_kernel: 1 = y holds MaxPool2d(2, 2)(act(conv)) at (OH / 2, OW / 2)
+  int no_xcd;  // 1 = tiles walked in slot order (upa_opts.no_xcd: A/B of the XCD-aware walk)
 #ifdef UPA_ABLATE
   int ablate;  // debug build only (upa_opts.ablate_stem)
 #endif
@@ -292,8 +293,10 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemParams p) {
   extern __shared__ __attribute__((aligned(16))) char stem_sm[];  // [2][PATCH_BYTES] + [4 waves][OUT_ROW_BYTES]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ntiles = p.tilesX * p.tilesY * p.N;
-  int tile = blockIdx.x;
-  if (tile >= ntiles) return;
+  const bool xcd = !p.no_xcd && ((gridDim.x & 7) == 0 || (int)gridDim.x >= ntiles);  // XCD-aware walk, as the fused kernel below
+  int slot = blockIdx.x;
+  if (slot >= ntiles) return;
+  int tile = xcd ? upa_xcd_tile(slot, ntiles) : slot;
   stem_stage<KS, S>(p, tile, reinterpret_cast<unsigned short*>(stem_sm), tid, wave);
   // ---- weights -> A fragments (lane: cout row lane%16, k = ks*32 + (lane/16)*8 + j), kept for the whole kernel;
   // k = (kh*KS + kw)*3 + ci matches the packed [tap][ci][co] order
@@ -340,7 +343,8 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemParams p) {
   for (int cur = 0;; cur ^= 1) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // patch `cur` landed for every wave; every wave is done reading the other buffer
-    const int next = tile + gridDim.x;
+    slot += gridDim.x;
+    const int next = slot < ntiles ? (xcd ? upa_xcd_tile(slot, ntiles) : slot) : ntiles;
     if (next < ntiles) stem_stage<KS, S>(p, next, reinterpret_cast<unsigned short*>(stem_sm + (cur ^ 1) * PATCH_BYTES), tid, wave);
     const int n = tile / tilesPerImg;
     const int t2 = tile - n * tilesPerImg;
@@ -485,6 +489,7 @@ struct StemFusedParams {
   const void* x; const float* w0; const float* b0; const char* w1; const float* b1; char* y;
   int N, H, W, H0, W0, OH, OW, ldy, x_bf16;
   int tilesX, tilesY;
+  int no_xcd;
 };
 
 namespace sf {
@@ -555,8 +560,13 @@ __global__ __launch_bounds__(NW * 64) void stem_conv_fused_kernel(const StemFuse
       __builtin_amdgcn_global_load_lds((sgptr_t)src, (slptr_t)(buf + (it * NTH + wave * 64) * 16), 16, 0, 0);
     }
   };
-  int tile = blockIdx.x;
-  if (tile >= ntiles) return;
+  // XCD-aware walk (common.h: upa_xcd_tile): slot = blockIdx.x + i * gridDim.x names the XCD by slot & 7 when the grid is a multiple
+  // of 8 (or one round), and XCD x then owns a contiguous range of tiles - neighbouring patches share their 128-byte lines in ONE L2
+  const bool xcd = !p.no_xcd && ((gridDim.x & 7) == 0 || (int)gridDim.x >= ntiles);
+  auto tile_of = [&](int slot) __attribute__((always_inline)) { return xcd ? upa_xcd_tile(slot, ntiles) : slot; };
+  int slot = blockIdx.x;
+  if (slot >= ntiles) return;
+  int tile = tile_of(slot);
   stage(tile, fsm);
   // ---- stem weights -> KS0STEPS A fragments; k = (kh*KS0 + kw)*3 + ci (packed [tap][ci][co16] f32)
   u32x4 a0[KS0STEPS];
@@ -609,7 +619,8 @@ __global__ __launch_bounds__(NW * 64) void stem_conv_fused_kernel(const StemFuse
   for (int cur = 0;; cur ^= 1) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // patch `cur` landed; everyone is done with the stem tile and the other patch buffer
-    const int next = tile + gridDim.x;
+    slot += gridDim.x;
+    const int next = slot < ntiles ? tile_of(slot) : ntiles;
     if (next < ntiles) stage(next, fsm + (cur ^ 1) * PATCH);
     const int n = tile / tilesPerImg;
     const int t2 = tile - n * tilesPerImg;
@@ -752,6 +763,7 @@ static int stem_nchw_impl(const void* x, int x_dtype, int n, int cin, int h, int
   p.PCS = p.PC + 1;
   p.wgs = UPA_OPT(opts, stem_wgs);
   p.pool = pool;
+  p.no_xcd = UPA_OPT(opts, no_xcd);
 #ifdef UPA_ABLATE
   p.ablate = UPA_OPT(opts, ablate_stem);
 #endif
@@ -805,6 +817,7 @@ static int stem_conv_fused_impl(const void* x, int n, int h, int w, int k0, cons
   p.x = x; p.w0 = w0; p.b0 = b0; p.w1 = (const char*)w1; p.b1 = b1; p.y = (char*)y;
   p.N = n; p.H = h; p.W = w; p.H0 = h / 2; p.W0 = w / 2; p.OH = h / 4; p.OW = w / 4; p.ldy = ldy;
   p.tilesX = cdiv(p.OW, sf::T1W); p.tilesY = cdiv(p.OH, sf::T1H);
+  p.no_xcd = UPA_OPT(opts, no_xcd);
   const long ntiles = (long)p.tilesX * p.tilesY * n;
   const int wgs = UPA_OPT(opts, stemf_wgs) > 0 ? UPA_OPT(opts, stemf_wgs) : 512;
   const int nw = UPA_OPT(opts, stemf_waves) == 4 ? 4 : 8;
