@@ -135,6 +135,10 @@ int upa_stem_conv_fused(const void* x, int n, int h, int w, const float* w0, con
 /* ... with the first conv's kernel size given: k0 = 3 (pad 1) | 6 (pad 2: yolov5's Conv(3, 16, 6, 2, 2), cfg/models/v5/Detect/yolov5-BoT3.yaml:15) */
 int upa_stem_conv_fused_k(const void* x, int n, int h, int w, int k0, const float* w0, const float* b0, const void* w1,
                           const float* b1, void* y, int ldy, const upa_opts* opts, void* stream);
+/* The same with the first conv's channel count given: c0 = 16 (-> 32 channels out, k0 = 3 | 6) or 32 (-> 64, k0 = 3: yolov8s rows 0-1,
+ * cfg/models/v8/yolov8.yaml:18-19 at width 0.50). */
+int upa_stem_conv_fused_c(const void* x, int n, int h, int w, int k0, int c0, const float* w0, const float* b0, const void* w1,
+                          const float* b1, void* y, int ldy, const upa_opts* opts, void* stream);
 
 /* ---- pooling / resampling / concat (HBM-bound) --------------------------------------------------------------- */
 /* nn.MaxPool2d(k, s, p) with -inf padding; pad_br>0 emulates nn.ZeroPad2d([0,pad_br,0,pad_br]) in front of it

@@ -705,6 +705,179 @@ __global__ __launch_bounds__(NW * 64) void stem_conv_fused_kernel(const StemFuse
   }
 }
 
+// ---- The same fusion for yolov8s' stem pair: Conv(3, 32, 3, 2) -> Conv(32, 64, 3, 2), both SiLU (yolov8.yaml rows 0-1 at width 0.5).
+// The 32-channel intermediate (210 MB at bs 32: written by one launch, read back by the next at 83 + 106 us) stays in LDS.  Same patch,
+// same 8 x 16 output tile and the same stem-tile layout [row][column parity][column / 2] as above, with 64-byte pixel records at an
+// 80-byte pitch; what changes is the shape of the two GEMMs:
+//   * stage 2: the gathered im2col fragment of 16 stem pixels feeds TWO MFMAs (32 stem channels = 2 n-tiles);
+//   * stage 3: 32 input channels are exactly one k-step per tap (9 k-steps, no tap pairing) and there are 4 n-tiles of output channels.
+//     16 waves: wave = (n-tile, row pair), so a wave keeps only ITS n-tile's nine A fragments (36 registers) for the whole kernel and
+//     reads 9 pixel fragments per output row; lane (kg, l16) stores channels 16 nt + 4 kg .. + 3 of its pixel as 8 bytes.
+namespace sf32 {
+using namespace sf;
+constexpr int NW = 8, NTH = NW * 64;
+constexpr int SP = 80;                               // bytes per stem pixel in LDS (64 used)
+constexpr int STILE32 = S0H * 2 * S0WH * SP;         // 46240
+}  // namespace sf32
+
+__global__ __launch_bounds__(512, 4) void stem_conv_fused32_kernel(const StemFusedParams p) {
+  using namespace sf32;
+  using G0 = Geo<3>;
+  constexpr int PR = G0::PR, NCH = G0::NCH, LS = G0::LS, ITEMS = G0::ITEMS;
+  constexpr int ITEMS_PAD = G0::items_pad(NW);
+  constexpr int PATCH = G0::patch_bytes(NW);
+  extern __shared__ __attribute__((aligned(16))) char fsm[];  // [PATCH] input patch, [STILE32] stem tile
+  char* stile = fsm + PATCH;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kg = lane >> 4, l16 = lane & 15;
+  const int ntiles = p.tilesX * p.tilesY * p.N;
+  const int tilesPerImg = p.tilesX * p.tilesY;
+  const int plane = p.H * p.W;
+  constexpr int NIT = ITEMS_PAD / NTH;
+  int it_row[NIT], it_col[NIT], it_off[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int item = it * NTH + tid;
+    const int line = item / NCH, ch = item - line * NCH;
+    const int ci = line / PR, row = line - ci * PR;
+    it_row[it] = item < ITEMS ? row : (1 << 28);
+    it_col[it] = ch * 8;
+    it_off[it] = ci * plane + row * p.W + ch * 8;
+  }
+  auto stage = [&](int tile, char* buf) __attribute__((always_inline)) {
+    const int n = tile / tilesPerImg;
+    const int t2 = tile - n * tilesPerImg;
+    const int tyi = t2 / p.tilesX, txi = t2 - tyi * p.tilesX;
+    const int iy0 = 2 * (2 * tyi * T1H - 1) - G0::PAD0, ix0 = 2 * (2 * txi * T1W - 1) - G0::PAD0;
+    const int ixa = ix0 & ~7;
+    const bf16_t* xb = (const bf16_t*)p.x + (size_t)n * 3 * plane;
+    const bf16_t* xt = xb + iy0 * p.W + ixa;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int iy = iy0 + it_row[it], ix = ixa + it_col[it];
+      const bool in = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      const char* src = in ? reinterpret_cast<const char*>(xt + it_off[it]) : reinterpret_cast<const char*>(g_stem_zero16);
+      __builtin_amdgcn_global_load_lds((sgptr_t)src, (slptr_t)(buf + (it * NTH + wave * 64) * 16), 16, 0, 0);
+    }
+  };
+  const bool xcd = !p.no_xcd && ((gridDim.x & 7) == 0 || (int)gridDim.x >= ntiles);
+  auto tile_of = [&](int slot) __attribute__((always_inline)) { return xcd ? upa_xcd_tile(slot, ntiles) : slot; };
+  int slot = blockIdx.x;
+  if (slot >= ntiles) return;
+  int tile = tile_of(slot);
+  stage(tile, fsm);
+  // ---- stem weights: A fragments of the two 16-channel n-tiles; k = (kh*3 + kw)*3 + ci (packed [tap][ci][co32] f32)
+  u32x4 a0[2];
+  f32x4 bias0[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    float wv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = kg * 8 + j;
+      wv[j] = k < G0::KTOT ? p.w0[k * 32 + nt * 16 + l16] : 0.f;
+    }
+    a0[nt] = u32x4{pack_bf16x2(wv[0], wv[1]), pack_bf16x2(wv[2], wv[3]), pack_bf16x2(wv[4], wv[5]), pack_bf16x2(wv[6], wv[7])};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias0[nt][r] = p.b0 ? p.b0[nt * 16 + kg * 4 + r] : 0.f;
+  }
+  // second conv: this wave's n-tile, one A fragment per tap from the standard packed layout [tap][1 k-tile][4 n-tiles][lane][16 B]
+  const int nt1 = wave & 3, rp = wave >> 2;
+  u32x4 a1[9];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) a1[tap] = *reinterpret_cast<const u32x4*>(p.w1 + ((size_t)(tap * 4 + nt1) * 64 + lane) * 16);
+  f32x4 bias1;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bias1[r] = p.b1 ? p.b1[nt1 * 16 + kg * 4 + r] : 0.f;
+  constexpr int shift = G0::SHIFT;
+  int goff[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = kg * 8 + j;
+    int o = 0;
+    if (k < G0::KTOT) {
+      const int tap = k / 3, ci = k - tap * 3;
+      const int kh = tap / 3, kw = tap - kh * 3;
+      o = (ci * PR + kh) * LS + kw;
+    }
+    goff[j] = (o + shift) * 2;
+  }
+  for (;;) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // the patch landed; everyone is done with the stem tile
+    slot += gridDim.x;
+    const int next = slot < ntiles ? tile_of(slot) : ntiles;
+    const int n = tile / tilesPerImg;
+    const int t2 = tile - n * tilesPerImg;
+    const int tyi = t2 / p.tilesX, txi = t2 - tyi * p.tilesX;
+    const int oy0 = tyi * T1H, ox0 = txi * T1W;
+    const int sy0 = 2 * oy0 - 1, sx0 = 2 * ox0 - 1;
+    const bool interior = sy0 >= 0 && sx0 >= 0 && sy0 + S0H <= p.H0 && sx0 + S0W <= p.W0;
+    const char* pb = fsm;
+    // ---- stage 2: the 17 x 33 stem tile x 32 channels, 16 stem pixels per MFMA pair
+    constexpr int NSEG = (S0H * S0W + 15) / 16;  // 36
+    auto stage2 = [&](auto masked_tag) __attribute__((always_inline)) {
+      constexpr bool MASKED = decltype(masked_tag)::value;
+      for (int sg = wave; sg < NSEG; sg += NW) {
+        const int q = sg * 16 + l16;
+        const bool qin = q < S0H * S0W;
+        const int qq = qin ? q : S0H * S0W - 1;
+        const int r = qq / S0W, c = qq - r * S0W;
+        const char* base = pb + ((2 * r) * LS + 2 * c) * 2;
+        unsigned e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = *reinterpret_cast<const unsigned short*>(base + goff[j]);
+        u32x4 b = u32x4{e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
+        bool inmap = true;
+        if constexpr (MASKED) {
+          const int sy = sy0 + r, sx = sx0 + c;
+          inmap = sy >= 0 && sy < p.H0 && sx >= 0 && sx < p.W0;
+        }
+        char* dst = stile + ((r * 2 + (c & 1)) * S0WH + (c >> 1)) * SP + kg * 8;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&a0[nt]), *reinterpret_cast<bf16x8*>(&b), bias0[nt], 0, 0, 0);
+          float v[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const float u = acc[t];
+            v[t] = inmap ? u * __builtin_amdgcn_rcpf(1.0f + __expf(-u)) : 0.f;
+          }
+          if (qin) *reinterpret_cast<u32x2*>(dst + nt * 32) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        }
+      }
+    };
+    if (interior) stage2(std::false_type{});
+    else stage2(std::true_type{});
+    __syncthreads();
+    // the patch is dead from here (stage 3 reads the stem tile only): the next tile's patch is fetched under stage 3 into the SAME buffer
+    if (next < ntiles) stage(next, fsm);
+    // ---- stage 3: second conv; this wave: output rows 4 rp .. 4 rp + 3 (16 pixels each) x its 16 channels
+#pragma unroll 2
+    for (int rr = 0; rr < 4; ++rr) {
+      const int i = 4 * rp + rr;
+      f32x4 acc = bias1;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int kh = tap / 3, kw = tap - kh * 3;
+        const int sr = 2 * i + kh, sc = 2 * l16 + kw;
+        const u32x4 b = *reinterpret_cast<const u32x4*>(stile + ((sr * 2 + (sc & 1)) * S0WH + (sc >> 1)) * SP + kg * 16);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&a1[tap]), *reinterpret_cast<const bf16x8*>(&b), acc, 0, 0, 0);
+      }
+      const int oy = oy0 + i, ox = ox0 + l16;
+      float v[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) v[t] = acc[t] * __builtin_amdgcn_rcpf(1.0f + __expf(-acc[t]));
+      if (oy < p.OH && ox < p.OW)
+        *reinterpret_cast<u32x2*>(p.y + ((size_t)((n * p.OH + oy) * p.OW + ox) * p.ldy + nt1 * 16 + kg * 4) * 2) =
+            u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    }
+    tile = next;
+    if (tile >= ntiles) break;
+  }
+}
+
 // Host-side repack of OIHW f32 weights into [tap][ci][co padded to 16] (HOST memory in, HOST memory out).
 extern "C" size_t upa_stem_packed_weight_bytes(int cout, int cin, int k) {
   return (size_t)k * k * cin * ((cout + 15) / 16 * 16) * sizeof(float);
@@ -807,10 +980,11 @@ static int stem_nchw_impl(const void* x, int x_dtype, int n, int cin, int h, int
  * reaches HBM.  k0 = 3 (pad 1: yolov8.yaml rows 0-1) or 6 (pad 2: yolov5 rows 0-1, cfg/models/v5/Detect/yolov5-BoT3.yaml:15-16).
  * w0 / b0: stem weights packed by upa_pack_stem_weight (+ folded bias); w1 / b1: second conv packed by
  * upa_pack_conv_weight(bf16) (+ folded bias).  y: NHWC bf16 view (n, h/4, w/4, 32). */
-static int stem_conv_fused_impl(const void* x, int n, int h, int w, int k0, const float* w0, const float* b0, const void* w1,
+static int stem_conv_fused_impl(const void* x, int n, int h, int w, int k0, int c0, const float* w0, const float* b0, const void* w1,
                                 const float* b1, void* y, int ldy, const upa_opts* opts, void* stream) {
   UPA_CHECK_ARG(x && w0 && w1 && y, "stem_conv_fused: null pointer");
   UPA_CHECK_ARG(k0 == 3 || k0 == 6, "stem_conv_fused: first conv k = 3 (pad 1) or 6 (pad 2)");
+  UPA_CHECK_ARG(c0 == 16 || (c0 == 32 && k0 == 3), "stem_conv_fused: 3 -> 16 -> 32 channels (k 3 | 6) or 3 -> 32 -> 64 (k 3)");
   UPA_CHECK_ARG(w % 8 == 0 && h % 4 == 0 && w % 4 == 0 && (long)3 * h * w < (1L << 31), "stem_conv_fused: w %% 8, h %% 4 == 0 required");
   UPA_CHECK_ARG(ldy % 8 == 0 && (uintptr_t)y % 16 == 0, "stem_conv_fused: output view must be 16-byte aligned");
   StemFusedParams p{};
@@ -823,6 +997,12 @@ static int stem_conv_fused_impl(const void* x, int n, int h, int w, int k0, cons
   const int nw = UPA_OPT(opts, stemf_waves) == 4 ? 4 : 8;
   const dim3 grid((unsigned)(ntiles < wgs ? ntiles : wgs));
   hipStream_t st = (hipStream_t)stream;
+  if (c0 == 32) {  // two 8-wave workgroups per CU (71 KB of LDS each)
+    (void)upa_full_lds<stem_conv_fused32_kernel>();
+    hipLaunchKernelGGL(stem_conv_fused32_kernel, grid, dim3(512), (size_t)sf::Geo<3>::patch_bytes(8) + sf32::STILE32, st, p);
+    UPA_LAUNCH_CHECK();
+    return UPA_OK;
+  }
   if (k0 == 6) {  // 4 waves: the 4 x 8 gather offsets + 4 A fragments of the 108-deep im2col row do not fit 128 registers
     (void)upa_full_lds<stem_conv_fused_kernel<4, 6>>();
     hipLaunchKernelGGL((stem_conv_fused_kernel<4, 6>), grid, dim3(256), (size_t)2 * sf::Geo<6>::patch_bytes(4) + sf::STILE, st, p);
@@ -838,10 +1018,16 @@ static int stem_conv_fused_impl(const void* x, int n, int h, int w, int k0, cons
 }
 extern "C" int upa_stem_conv_fused(const void* x, int n, int h, int w, const float* w0, const float* b0, const void* w1,
                                    const float* b1, void* y, int ldy, const upa_opts* opts, void* stream) {
-  return stem_conv_fused_impl(x, n, h, w, 3, w0, b0, w1, b1, y, ldy, opts, stream);
+  return stem_conv_fused_impl(x, n, h, w, 3, 16, w0, b0, w1, b1, y, ldy, opts, stream);
 }
 /* The same with the first conv's kernel size given: k0 = 3 | 6 (yolov5's Conv(3, 16, 6, 2, 2)). */
 extern "C" int upa_stem_conv_fused_k(const void* x, int n, int h, int w, int k0, const float* w0, const float* b0, const void* w1,
                                      const float* b1, void* y, int ldy, const upa_opts* opts, void* stream) {
-  return stem_conv_fused_impl(x, n, h, w, k0, w0, b0, w1, b1, y, ldy, opts, stream);
+  return stem_conv_fused_impl(x, n, h, w, k0, 16, w0, b0, w1, b1, y, ldy, opts, stream);
+}
+/* The same with the channel count of the first conv given too: c0 = 16 (-> 32 output channels; k0 = 3 | 6) or 32 (-> 64; k0 = 3:
+ * yolov8s' Conv(3, 32, 3, 2) -> Conv(32, 64, 3, 2)).  y: NHWC bf16 view (n, h/4, w/4, 2 * c0). */
+extern "C" int upa_stem_conv_fused_c(const void* x, int n, int h, int w, int k0, int c0, const float* w0, const float* b0, const void* w1,
+                                     const float* b1, void* y, int ldy, const upa_opts* opts, void* stream) {
+  return stem_conv_fused_impl(x, n, h, w, k0, c0, w0, b0, w1, b1, y, ldy, opts, stream);
 }

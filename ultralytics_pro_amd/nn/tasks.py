@@ -325,8 +325,9 @@ class BaseModel(nn.Module):
         return m.i not in self.save and m.i not in place and (m.i + 1) not in place
 
     def _stem_fusable(self, x, place) -> bool:
-        """yolov8n's first two rows (Conv(3,16,3,2), Conv(16,32,3,2), SiLU, bf16 NCHW input, neither output used by a later
-        row other than the next one): `upa_stem_conv_fused` runs them as one kernel (csrc/stem.hip)."""
+        """yolov8n's / yolov8s' / yolov5's first two rows (Conv(3,16,3|6,2) -> Conv(16,32,3,2) or Conv(3,32,3,2) -> Conv(32,64,3,2), SiLU,
+        bf16 NCHW input, neither output used by a later row other than the next one): `upa_stem_conv_fused_c` runs them as one kernel
+        (csrc/stem.hip)."""
         if self.__dict__.get("_no_stem_fusion") or len(self.model) < 3 or not torch.is_tensor(x):
             return False
         a, b = self.model[0], self.model[1]
@@ -336,8 +337,8 @@ class BaseModel(nn.Module):
             return False
         ca, cb = a.conv, b.conv
         first = (ca.in_channels, ca.out_channels, ca.kernel_size, ca.stride, ca.padding)
-        ok = first in ((3, 16, (3, 3), (2, 2), (1, 1)), (3, 16, (6, 6), (2, 2), (2, 2))) and \
-            (cb.in_channels, cb.out_channels, cb.kernel_size, cb.stride, cb.padding) == (16, 32, (3, 3), (2, 2), (1, 1)) and \
+        ok = first in ((3, 16, (3, 3), (2, 2), (1, 1)), (3, 16, (6, 6), (2, 2), (2, 2)), (3, 32, (3, 3), (2, 2), (1, 1))) and \
+            (cb.in_channels, cb.out_channels, cb.kernel_size, cb.stride, cb.padding) == (first[1], 2 * first[1], (3, 3), (2, 2), (1, 1)) and \
             isinstance(a.act, nn.SiLU) and isinstance(b.act, nn.SiLU) and not a.training
         n, c, h, w = x.shape
         return bool(ok and c == 3 and x.is_contiguous() and w % 8 == 0 and h % 4 == 0 and w % 4 == 0)
@@ -347,9 +348,10 @@ class BaseModel(nn.Module):
         pa = a._packed(a.conv, getattr(a, "bn", None), x.device, torch.bfloat16, True)
         pb = b._packed(b.conv, getattr(b, "bn", None), x.device, torch.bfloat16, False)
         n, _, h, w = x.shape
-        y = R.alloc_nhwc(n, 32, h // 4, w // 4, torch.bfloat16, x.device, key=(id(b), "y"))
+        c0 = int(a.conv.out_channels)
+        y = R.alloc_nhwc(n, 2 * c0, h // 4, w // 4, torch.bfloat16, x.device, key=(id(b), "y"))
         vy = R.view_of(y)
-        L.check(L.lib().upa_stem_conv_fused_k(x.data_ptr(), n, h, w, int(a.conv.kernel_size[0]), pa.w.data_ptr(), pa.bias.data_ptr(),
+        L.check(L.lib().upa_stem_conv_fused_c(x.data_ptr(), n, h, w, int(a.conv.kernel_size[0]), c0, pa.w.data_ptr(), pa.bias.data_ptr(),
                                               pb.w.data_ptr(), pb.bias.data_ptr(), vy.ptr, vy.ld, R.opts_ptr(),
                                               L.current_stream(x.device)), "stem_conv_fused")
         return y
