@@ -295,8 +295,10 @@ bool upa_conv_p8_eligible(int n, int h, int w, int cin, int ldx, int cout, int l
   // epilogue - 512->256 @40x40 (200 tiles) 73.4 -> 59.6 us, 512->1024 @20x20 (256) 75.0 -> 65.3, 768->256 @40x40 (200) 108.5 -> 86.7.
   // With more tiles than CUs (400: 256->512 @40x40 65.1 -> 68.9, 256->128 @80x80 60.7 -> 64.1; 800: 128->256 @80x80 70.9 -> 85.7) the
   // second round is half empty and conv_big's two co-resident workgroups hide each other's prologue; with too few (128: 1024->512
-  // @20x20 87.3 -> 98.0) half the chip idles.
-  if (cin < 512) return false;
+  // @20x20 87.3 -> 98.0) half the chip idles.  One-round layers with K = 2304 win less but still win (yolov3-tiny bs 32 256->512 @20x20,
+  // 256 tiles: 45.1 -> 40.6 us; yolov8s 256->128 @40x40, 200 tiles: 40.4 -> 35.9); at K = 1152 (128->128 @40x40: 26.0 -> 24.4, with
+  // the shortcut 26.1 -> 26.0) the prologue and epilogue are half the tile and the rule stops.
+  if (cin < 256) return false;
   BigParams q;
   memset(&q, 0, sizeof(q));
   q.N = n; q.H = h; q.W = w; q.Cin = cin; q.Cout = cout;
