@@ -303,6 +303,12 @@ int upa_mhsa(const void* q, const void* k, const void* v, int ldqkv, int n, int 
  *                                                                     transformer.py:348-399, head.py:1993-2003 */
 int upa_linear(const float* x, long m, int k, int ldx, const void* w_packed, const float* bias, float* y, int n, int ldy,
                const float* residual, int ldr, int act, void* stream);
+/* The same with the PRODUCT on the bf16 matrix cores (perf mode of the RT-DETR decoder, = the reference's half-precision predict where
+ * every nn.Linear multiplies 16-bit operands: engine/predictor.py:151-173 `model.half()`): float32 rows in and out, every element of x
+ * rounded to bf16 on the way into the MFMA, w_packed = upa_pack_conv_weight(UPA_BF16) of the (n, k, 1, 1) weight, float32
+ * accumulation / bias / activation / residual.  UPA_EUNSUPPORTED outside the form (k % 32 == 0, k <= 1024, n % 4 == 0, 16-byte rows). */
+int upa_linear_bf16(const float* x, long m, int k, int ldx, const void* w_packed, const float* bias, float* y, int n,
+                    int ldy, const float* residual, int ldr, int act, void* stream);
 /* y = LayerNorm(x (+ residual))                                                  transformer.py:660-685 */
 int upa_layer_norm(const float* x, const float* residual, int m, int c, const float* gamma, const float* beta, float eps,
                    float* y, void* stream);

@@ -1404,3 +1404,38 @@ def test_conv_p8_equals_conv_big_full_size(shape):
     torch.cuda.synchronize()
     bad = [i for i, y in enumerate(outs) if not torch.equal(y, ref)]
     assert not bad, f"conv_p8 differs from conv_big in launches {bad}: max|d| {max((outs[i].float() - ref.float()).abs().max().item() for i in bad)}"
+
+
+LINEAR_BF16_CASES = [c for c in LINEAR_CASES if c[1] % 32 == 0 and c[1] <= 1024]
+
+
+@pytest.mark.parametrize("case", LINEAR_BF16_CASES, ids=[f"m{c[0]}_k{c[1]}_n{c[2]}_a{c[3]}{'_res' if c[4] else ''}" for c in LINEAR_BF16_CASES])
+def test_linear_bf16_product_rows(case):
+    """`upa_linear_bf16` (the RT-DETR decoder's perf mode: float32 rows in and out, the product on the bf16 matrix cores) vs float64
+    `bf16(x) @ bf16(W)^T + b` -> act -> + residual: with BOTH operands rounded as the kernel rounds them the only difference left is the
+    order of the f32 accumulation, so the f32-GEMM bound holds; same strided / ragged shapes as the exact-f32 test."""
+    from tests.hip_utils import DEV, bf16_round, unit_input
+    from ultralytics_pro_amd import _lib as L
+    from ultralytics_pro_amd.nn.modules.conv import PackedConv
+    m, k, n, act, res = case
+    ldx, ldy, ldr = k + 8, n + 12, n + 4
+    x = unit_input(f"lin_x{case}", (m, ldx), -1.5, 1.5)
+    w = unit_input(f"lin_w{case}", (n, k), -0.2, 0.2)
+    b = unit_input(f"lin_b{case}", (n,), -1, 1)
+    r = unit_input(f"lin_r{case}", (m, ldr), -1, 1)
+    ref = bf16_round(x[:, :k]).double() @ bf16_round(w).double().t() + b.double()
+    if act == 2:
+        ref = ref.clamp(min=0)
+    elif act == 1:
+        ref = ref * torch.sigmoid(ref)
+    if res:
+        ref = ref + r[:, :n].double()
+    pk = PackedConv(w.reshape(n, k, 1, 1), b, 1, DEV, torch.bfloat16, False)
+    xd, rd = x.to(DEV), r.to(DEV)
+    y = torch.full((m, ldy), -7.0, device=DEV)
+    L.check(L.lib().upa_linear_bf16(xd.data_ptr(), m, k, ldx, pk.w.data_ptr(), pk.bias.data_ptr(), y.data_ptr(), n, ldy,
+                                    rd.data_ptr() if res else None, ldr if res else 0, act, L.current_stream(DEV)), "linear_bf16")
+    torch.cuda.synchronize()
+    got = y.cpu()
+    assert float((got[:, :n].double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    assert bool((got[:, n:] == -7.0).all())

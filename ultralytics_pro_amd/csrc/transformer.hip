@@ -492,6 +492,125 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const LinParams p) {
   }
 }
 
+// The same GEMM with the PRODUCT on the bf16 matrix cores (perf mode of the RT-DETR decoder): x stays float32 in memory and in LDS (no
+// layout or neighbour kernel changes), every lane rounds its 8 consecutive k of a row to bf16 on the way into the B fragment (two
+// 16-byte reads + four v_cvt_pk_bf16_f32), the weights come packed as bf16 (upa_pack_conv_weight(UPA_BF16): k-tiles of 32), one
+// v_mfma_f32_16x16x32_bf16 replaces eight exact-f32 MFMAs; accumulation, bias, activation, residual and the stored result are float32.
+// This is the arithmetic of the reference's half-precision predict (`model.half()`, engine/predictor.py:151-173: every nn.Linear of the
+// decoder multiplies 16-bit operands) with the activations kept in f32 between the layers.
+template <int MT>
+__global__ __launch_bounds__(256) void linear_bf16_kernel(const LinParams p) {
+  constexpr int LR = MT * 16;
+  extern __shared__ __attribute__((aligned(16))) char lsm[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, r = lane & 15;
+  const int row0 = blockIdx.x * LR;
+  const int nt = blockIdx.y * 4 + wave;
+  const int G = p.K >> 2;  // 16-byte groups (4 floats) per row
+  const int items = LR * G;
+  for (int base = wave * 64; base < items; base += 256) {
+    const int it = base + lane;
+    const int row = it / G, slot = it - row * G;
+    const int cg = slot ^ (row & 7);
+    const char* src = reinterpret_cast<const char*>(g_lin_zero16);
+    if (row0 + row < p.M) src = p.x + ((size_t)(row0 + row) * p.ldx + cg * 4) * 4;
+    __builtin_amdgcn_global_load_lds((lgptr_t)src, (llptr_t)(lsm + base * 16), 16, 0, 0);
+  }
+  const bool live = nt < p.NTn;
+  // A fragments of this n-tile: [k-tile of 32][n-tile][lane][16 B]; 8 k-tiles (256 channels) per register set
+  u32x4 a0[8], a1[8];
+  auto fetch = [&](u32x4(&dst)[8], int kt0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      dst[q] = (live && kt0 + q < p.KTT) ? *reinterpret_cast<const u32x4*>(p.w + (((size_t)(kt0 + q) * p.NTn + nt) * 64 + lane) * 16)
+                                         : u32x4{0u, 0u, 0u, 0u};
+  };
+  fetch(a0, 0);
+  f32x4 acc[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  auto mult = [&](const u32x4(&a)[8], int kt0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if (kt0 + q >= p.KTT) break;  // uniform
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int row = i * 16 + r;
+        const int g0 = ((kt0 + q) << 3) + 2 * g;  // this lane's 8 k = float groups g0, g0 + 1 of the row
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(lsm + ((size_t)row * G + (g0 ^ (row & 7))) * 16);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(lsm + ((size_t)row * G + ((g0 + 1) ^ (row & 7))) * 16);
+        const u32x4 b = u32x4{pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3])};
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a[q]), *reinterpret_cast<const bf16x8*>(&b), acc[i], 0, 0, 0);
+      }
+    }
+  };
+  for (int kt0 = 0; kt0 < p.KTT; kt0 += 16) {
+    if (kt0 + 8 < p.KTT) fetch(a1, kt0 + 8);
+    mult(a0, kt0);
+    if (kt0 + 8 < p.KTT) {
+      if (kt0 + 16 < p.KTT) fetch(a0, kt0 + 16);
+      mult(a1, kt0 + 8);
+    }
+  }
+  if (!live) return;
+  const int col = nt * 16 + 4 * g;
+  if (col >= p.N) return;
+  const f32x4 bv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int row = row0 + i * 16 + r;
+    if (row >= p.M) continue;
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float t = acc[i][e] + bv[e];
+      if (p.act == UPA_ACT_RELU) t = fmaxf(t, 0.0f);
+      else if (p.act == UPA_ACT_SILU) t = t / (1.0f + expf(-t));
+      v[e] = t;
+    }
+    if (p.res) {
+      const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + ((size_t)row * p.ldr + col) * 4);
+      v += rv;
+    }
+    *reinterpret_cast<f32x4*>(p.y + ((size_t)row * p.ldy + col) * 4) = v;
+  }
+}
+
+/* y = act(x W^T + b) (+ residual) with float32 rows in and out and the product on the bf16 matrix cores: w_packed =
+ * upa_pack_conv_weight(UPA_BF16) of the (n, k, 1, 1) weight.  UPA_EUNSUPPORTED outside the form (k % 32, k <= 1024, n % 4, 16-byte rows;
+ * more than 16384 rows only up to 1024 columns): the caller then uses upa_linear with float32-packed weights. */
+extern "C" int upa_linear_bf16(const float* x, long m, int k, int ldx, const void* w_packed, const float* bias, float* y, int n,
+                               int ldy, const float* residual, int ldr, int act, void* stream) {
+  UPA_CHECK_ARG(x && w_packed && y && m > 0 && m < (1L << 31), "linear_bf16: bad args");
+  const bool ok = k % 32 == 0 && k <= 1024 && n % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (!residual || ldr % 4 == 0) &&
+                  ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && (!residual || (uintptr_t)residual % 16 == 0) &&
+                  (!bias || (uintptr_t)bias % 16 == 0) && m <= (1 << 20) && (m <= 16384 || n <= 1024) &&
+                  (act == UPA_ACT_NONE || act == UPA_ACT_RELU || act == UPA_ACT_SILU);
+  if (!ok) {
+    upa_set_error("linear_bf16: outside the form (k %% 32 == 0, k <= 1024, n %% 4 == 0, 16-byte aligned float32 rows)");
+    return UPA_EUNSUPPORTED;
+  }
+  LinParams p;
+  p.x = (const char*)x; p.w = (const char*)w_packed; p.bias = bias; p.res = (const char*)residual; p.y = (char*)y;
+  p.M = (int)m; p.K = k; p.N = n; p.ldx = ldx; p.ldy = ldy; p.ldr = ldr; p.act = act;
+  p.KTT = k / 32; p.NTn = (n + 15) / 16;
+  const int mt = k <= 512 ? 2 : 1;
+  const size_t lds = (size_t)mt * 16 * k * 4;
+  const dim3 grid((unsigned)((m + mt * 16 - 1) / (mt * 16)), (unsigned)((p.NTn + 3) / 4));
+  if (mt == 2) {
+    if (upa_full_lds<linear_bf16_kernel<2>>() != hipSuccess) return UPA_ELAUNCH;
+    hipLaunchKernelGGL(linear_bf16_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, p);
+  } else {
+    if (upa_full_lds<linear_bf16_kernel<1>>() != hipSuccess) return UPA_ELAUNCH;
+    hipLaunchKernelGGL(linear_bf16_kernel<1>, grid, dim3(256), lds, (hipStream_t)stream, p);
+  }
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
 extern "C" int upa_linear(const float* x, long m, int k, int ldx, const void* w_packed, const float* bias, float* y, int n,
                           int ldy, const float* residual, int ldr, int act, void* stream) {
   UPA_CHECK_ARG(m > 0 && m < (1L << 31), "linear: bad row count");

@@ -34,30 +34,48 @@ class _Rows:
         return R.alloc_plain((m, c), torch.float32, device, key=key)
 
 
-def _packed_linear(owner: nn.Module, name: str, weight: torch.Tensor, bias, device) -> PackedConv:
-    """Packed f32 GEMM weights of one nn.Linear, cached on `owner` and validated against the parameters' storage / in-place
-    version on every use (`version_key`): load_state_dict / load_weights / .to() can never leave a stale copy."""
+# Perf mode of the decoder's nn.Linear layers (set by RTDETRDecoder.forward while a bf16 backbone feeds it): the product runs on the bf16
+# matrix cores (upa_linear_bf16: x rounded to bf16 on the way into the MFMA, bf16 weights, float32 accumulate / bias / activation /
+# residual / storage) - the arithmetic of the reference's half-precision predict, where the whole RTDETRDecoder is `.half()`.  In
+# parity mode (float32 backbone) every product stays exact float32.
+_LINEAR_BF16 = [False]
+
+
+def _packed_linear(owner: nn.Module, name: str, weight: torch.Tensor, bias, device, dtype=torch.float32) -> PackedConv:
+    """Packed GEMM weights (float32, or bf16 for the perf mode) of one nn.Linear, cached on `owner` and validated against the
+    parameters' storage / in-place version on every use (`version_key`): load_state_dict / load_weights / .to() can never leave a
+    stale copy."""
     cache = owner.__dict__.setdefault("_pk_cache", {})
-    key = (name, str(device))
+    key = (name, str(device)) if dtype == torch.float32 else (name, str(device), "bf16")
     ver = version_key(weight, bias)
     hit = cache.get(key)
     if hit is not None and hit[0] == ver:
         return hit[1]
     w = weight.detach().float().cpu().reshape(weight.shape[0], weight.shape[1], 1, 1)
     b = torch.zeros(weight.shape[0]) if bias is None else bias.detach().float().cpu()
-    pk = PackedConv(w, b, 1, device, torch.float32, False)
+    pk = PackedConv(w, b, 1, device, dtype, False)
     cache[key] = (ver, pk)
     return pk
 
 
 def linear(owner, name, weight, bias, x, act=L.ACT_NONE, residual=None, key=None):
-    """y = act(x W^T + b) (+ residual) through upa_linear (MFMA f32 GEMM)."""
+    """y = act(x W^T + b) (+ residual): exact float32 MFMA GEMM (upa_linear), or in the decoder's perf mode the bf16-product form
+    (upa_linear_bf16) wherever the shape allows it."""
     m, k = x.shape
+    st = L.current_stream(x.device)
+    rp, rld = (None, 0) if residual is None else (residual.data_ptr(), residual.stride(0))
+    if _LINEAR_BF16[0] and k % 32 == 0 and k <= 1024 and weight.shape[0] % 4 == 0:
+        pk = _packed_linear(owner, name, weight, bias, x.device, torch.bfloat16)
+        y = _Rows.new(m, pk.cout, x.device, key=key)
+        rc = L.lib().upa_linear_bf16(x.data_ptr(), m, k, x.stride(0), pk.w.data_ptr(), pk.bias.data_ptr(), y.data_ptr(), pk.cout,
+                                     y.stride(0), rp, rld, act, st)
+        if rc != L.UPA_EUNSUPPORTED:
+            L.check(rc, "linear_bf16")
+            return y
     pk = _packed_linear(owner, name, weight, bias, x.device)
     y = _Rows.new(m, pk.cout, x.device, key=key)
     L.check(L.lib().upa_linear(x.data_ptr(), m, k, x.stride(0), pk.w.data_ptr(), pk.bias.data_ptr(), y.data_ptr(), pk.cout,
-                               y.stride(0), None if residual is None else residual.data_ptr(),
-                               0 if residual is None else residual.stride(0), act, L.current_stream(x.device)), "linear")
+                               y.stride(0), rp, rld, act, st), "linear")
     return y
 
 
@@ -181,12 +199,15 @@ class DeformableTransformerDecoderLayer(nn.Module):
         # in-projection: q,k from (embed + pos), v from embed (transformer.py:670-673), into one (rows, 3C) buffer
         qkv = _Rows.new(embed.shape[0], 3 * e, embed.device, key=(key, "qkv"))
         lib, st = L.lib(), L.current_stream(embed.device)
-        pk_qk = _packed_linear(self, "in_qk", w[: 2 * e], b[: 2 * e], embed.device)
-        pk_v = _packed_linear(self, "in_v", w[2 * e:], b[2 * e:], embed.device)
-        L.check(lib.upa_linear(qk_in.data_ptr(), qk_in.shape[0], e, e, pk_qk.w.data_ptr(), pk_qk.bias.data_ptr(),
-                               qkv.data_ptr(), 2 * e, 3 * e, None, 0, L.ACT_NONE, st), "in_proj_qk")
-        L.check(lib.upa_linear(embed.data_ptr(), embed.shape[0], e, e, pk_v.w.data_ptr(), pk_v.bias.data_ptr(),
-                               qkv.data_ptr() + 2 * e * 4, e, 3 * e, None, 0, L.ACT_NONE, st), "in_proj_v")
+        fast = _LINEAR_BF16[0] and e % 32 == 0 and e <= 1024
+        wdt = torch.bfloat16 if fast else torch.float32
+        lin = lib.upa_linear_bf16 if fast else lib.upa_linear
+        pk_qk = _packed_linear(self, "in_qk", w[: 2 * e], b[: 2 * e], embed.device, wdt)
+        pk_v = _packed_linear(self, "in_v", w[2 * e:], b[2 * e:], embed.device, wdt)
+        L.check(lin(qk_in.data_ptr(), qk_in.shape[0], e, e, pk_qk.w.data_ptr(), pk_qk.bias.data_ptr(),
+                    qkv.data_ptr(), 2 * e, 3 * e, None, 0, L.ACT_NONE, st), "in_proj_qk")
+        L.check(lin(embed.data_ptr(), embed.shape[0], e, e, pk_v.w.data_ptr(), pk_v.bias.data_ptr(),
+                    qkv.data_ptr() + 2 * e * 4, e, 3 * e, None, 0, L.ACT_NONE, st), "in_proj_v")
         attn = _Rows.new(embed.shape[0], e, embed.device, key=(key, "attn"))
         d = e // nh
         L.check(lib.upa_mhsa(qkv.data_ptr(), qkv.data_ptr() + e * 4, qkv.data_ptr() + 2 * e * 4, 3 * e, bs, nq, nh, d,
@@ -372,6 +393,17 @@ class RTDETRDecoder(nn.Module):
                                             L.UPA_F32, R.opts_ptr(), st_), "input_proj")
             row0 += bs * v.h * v.w
         # ---- _get_decoder_input (head.py:2143-2200)
+        saved_lin = _LINEAR_BF16[0]
+        _LINEAR_BF16[0] = bool(perf and self.linear_bf16)
+        try:
+            return self._decode(feats, st, bs, hd, T, perf, dev, st_, lib)
+        finally:
+            _LINEAR_BF16[0] = saved_lin
+
+    # perf mode (bf16 backbone): the decoder's nn.Linear products on the bf16 matrix cores (see `_LINEAR_BF16`); False = exact float32
+    linear_bf16 = True
+
+    def _decode(self, feats, st, bs, hd, T, perf, dev, st_, lib):
         masked = _Rows.new(bs * T, hd, dev, key=(id(self), "masked"))
         L.check(lib.upa_rows_scale(feats.data_ptr(), st["rowmask"].data_ptr(), masked.data_ptr(), bs * T, hd, st_), "mask")
         eo = self.enc_output
