@@ -309,6 +309,10 @@ int upa_linear(const float* x, long m, int k, int ldx, const void* w_packed, con
  * accumulation / bias / activation / residual.  UPA_EUNSUPPORTED outside the form (k % 32 == 0, k <= 1024, n % 4 == 0, 16-byte rows). */
 int upa_linear_bf16(const float* x, long m, int k, int ldx, const void* w_packed, const float* bias, float* y, int n,
                     int ldy, const float* residual, int ldr, int act, void* stream);
+/* ... and with the row types given: x float32 (rounded into the MFMA) or bf16 (k % 64 == 0), y float32 or bf16 - q, k, v of the decoder's
+ * self-attention are written as bf16 rows for the matrix-core attention kernel (upa_mhsa), whose bf16 output feeds out_proj. */
+int upa_linear_mixed(const void* x, int x_dtype, long m, int k, int ldx, const void* w_packed, const float* bias, void* y,
+                     int y_dtype, int n, int ldy, const float* residual, int ldr, int act, void* stream);
 /* y = LayerNorm(x (+ residual))                                                  transformer.py:660-685 */
 int upa_layer_norm(const float* x, const float* residual, int m, int c, const float* gamma, const float* beta, float eps,
                    float* y, void* stream);

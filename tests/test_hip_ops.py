@@ -1439,3 +1439,39 @@ def test_linear_bf16_product_rows(case):
     got = y.cpu()
     assert float((got[:, :n].double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
     assert bool((got[:, n:] == -7.0).all())
+
+
+@pytest.mark.parametrize("xb,yb", [(False, True), (True, False), (True, True)], ids=["f32_to_bf16", "bf16_to_f32", "bf16_to_bf16"])
+@pytest.mark.parametrize("case", [(300, 256, 512, 0, False), (77, 256, 256, 0, True), (45, 1024, 256, 2, False), (4800, 256, 768, 0, False)],
+                         ids=["m300", "m77_res", "k1024_relu", "m4800"])
+def test_linear_mixed_row_types(case, xb, yb):
+    """`upa_linear_mixed`: bf16 rows in (no conversion: the attention output feeding out_proj) and / or bf16 rows out (q, k, v for the
+    matrix-core attention kernel) vs float64 on the bf16-rounded operands; a bf16 result must be the nearest bf16 of the float32 one
+    up to the accumulation-order noise (half a bf16 ulp + the f32 bound)."""
+    from tests.hip_utils import DEV, bf16_round, unit_input
+    from ultralytics_pro_amd import _lib as L
+    from ultralytics_pro_amd.nn.modules.conv import PackedConv
+    m, k, n, act, res = case
+    ldx, ldy, ldr = k + 8, n + 12, n + 4
+    x = bf16_round(unit_input(f"linm_x{case}", (m, ldx), -1.5, 1.5))
+    w = unit_input(f"linm_w{case}", (n, k), -0.2, 0.2)
+    b = unit_input(f"linm_b{case}", (n,), -1, 1)
+    r = unit_input(f"linm_r{case}", (m, ldr), -1, 1)
+    ref = x[:, :k].double() @ bf16_round(w).double().t() + b.double()
+    if act == 2:
+        ref = ref.clamp(min=0)
+    if res:
+        ref = ref + r[:, :n].double()
+    pk = PackedConv(w.reshape(n, k, 1, 1), b, 1, DEV, torch.bfloat16, False)
+    xd = x.to(DEV).to(torch.bfloat16) if xb else x.to(DEV)
+    rd = r.to(DEV)
+    y = torch.full((m, ldy), -7.0, device=DEV, dtype=torch.bfloat16 if yb else torch.float32)
+    code = lambda f: L.UPA_BF16 if f else L.UPA_F32
+    L.check(L.lib().upa_linear_mixed(xd.data_ptr(), code(xb), m, k, ldx, pk.w.data_ptr(), pk.bias.data_ptr(), y.data_ptr(), code(yb), n, ldy,
+                                     rd.data_ptr() if res else None, ldr if res else 0, act, L.current_stream(DEV)), "linear_mixed")
+    torch.cuda.synchronize()
+    got = y.float().cpu()
+    scale = max(1.0, float(ref.abs().max()))
+    tol = 2e-5 * scale + ((2.0 ** -8) * scale if yb else 0.0)
+    assert float((got[:, :n].double() - ref).abs().max()) <= tol
+    assert bool((got[:, n:] == -7.0).all())

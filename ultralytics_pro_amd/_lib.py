@@ -151,6 +151,7 @@ PROTOTYPES = {
     "upa_mhsa": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _i, _vp]),
     "upa_linear": (_i, [_vp, C.c_long, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp]),
     "upa_linear_bf16": (_i, [_vp, C.c_long, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp]),
+    "upa_linear_mixed": (_i, [_vp, _i, C.c_long, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp]),
     "upa_layer_norm": (_i, [_vp, _vp, _i, _i, _vp, _vp, _f, _vp, _vp]),
     "upa_rows_add": (_i, [_vp, _vp, _vp, C.c_long, _i, _vp]),
     "upa_rows_scale": (_i, [_vp, _vp, _vp, C.c_long, _i, _vp]),

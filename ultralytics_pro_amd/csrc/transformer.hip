@@ -498,23 +498,26 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const LinParams p) {
 // v_mfma_f32_16x16x32_bf16 replaces eight exact-f32 MFMAs; accumulation, bias, activation, residual and the stored result are float32.
 // This is the arithmetic of the reference's half-precision predict (`model.half()`, engine/predictor.py:151-173: every nn.Linear of the
 // decoder multiplies 16-bit operands) with the activations kept in f32 between the layers.
-template <int MT>
+// XB: x rows are bf16 already (the attention output feeding out_proj): 16-byte groups of 8 values, no conversion.  YB: the result is
+// stored as bf16 rows (q, k, v for the matrix-core attention kernel).
+template <int MT, bool XB, bool YB>
 __global__ __launch_bounds__(256) void linear_bf16_kernel(const LinParams p) {
   constexpr int LR = MT * 16;
+  constexpr int GE = XB ? 8 : 4;  // elements per 16-byte group
   extern __shared__ __attribute__((aligned(16))) char lsm[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, r = lane & 15;
   const int row0 = blockIdx.x * LR;
   const int nt = blockIdx.y * 4 + wave;
-  const int G = p.K >> 2;  // 16-byte groups (4 floats) per row
+  const int G = p.K / GE;  // 16-byte groups per row
   const int items = LR * G;
   for (int base = wave * 64; base < items; base += 256) {
     const int it = base + lane;
     const int row = it / G, slot = it - row * G;
     const int cg = slot ^ (row & 7);
     const char* src = reinterpret_cast<const char*>(g_lin_zero16);
-    if (row0 + row < p.M) src = p.x + ((size_t)(row0 + row) * p.ldx + cg * 4) * 4;
+    if (row0 + row < p.M) src = p.x + ((size_t)(row0 + row) * p.ldx + cg * GE) * (XB ? 2 : 4);
     __builtin_amdgcn_global_load_lds((lgptr_t)src, (llptr_t)(lsm + base * 16), 16, 0, 0);
   }
   const bool live = nt < p.NTn;
@@ -539,10 +542,15 @@ __global__ __launch_bounds__(256) void linear_bf16_kernel(const LinParams p) {
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         const int row = i * 16 + r;
-        const int g0 = ((kt0 + q) << 3) + 2 * g;  // this lane's 8 k = float groups g0, g0 + 1 of the row
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(lsm + ((size_t)row * G + (g0 ^ (row & 7))) * 16);
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(lsm + ((size_t)row * G + ((g0 + 1) ^ (row & 7))) * 16);
-        const u32x4 b = u32x4{pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3])};
+        u32x4 b;
+        if constexpr (XB) {
+          b = *reinterpret_cast<const u32x4*>(lsm + ((size_t)row * G + ((((kt0 + q) << 2) + g) ^ (row & 7))) * 16);
+        } else {
+          const int g0 = ((kt0 + q) << 3) + 2 * g;  // this lane's 8 k = float groups g0, g0 + 1 of the row
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(lsm + ((size_t)row * G + (g0 ^ (row & 7))) * 16);
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(lsm + ((size_t)row * G + ((g0 + 1) ^ (row & 7))) * 16);
+          b = u32x4{pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3])};
+        }
         acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a[q]), *reinterpret_cast<const bf16x8*>(&b), acc[i], 0, 0, 0);
       }
     }
@@ -575,22 +583,26 @@ __global__ __launch_bounds__(256) void linear_bf16_kernel(const LinParams p) {
       const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + ((size_t)row * p.ldr + col) * 4);
       v += rv;
     }
-    *reinterpret_cast<f32x4*>(p.y + ((size_t)row * p.ldy + col) * 4) = v;
+    if constexpr (YB) *reinterpret_cast<u32x2*>(p.y + ((size_t)row * p.ldy + col) * 2) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    else *reinterpret_cast<f32x4*>(p.y + ((size_t)row * p.ldy + col) * 4) = v;
   }
 }
 
-/* y = act(x W^T + b) (+ residual) with float32 rows in and out and the product on the bf16 matrix cores: w_packed =
- * upa_pack_conv_weight(UPA_BF16) of the (n, k, 1, 1) weight.  UPA_EUNSUPPORTED outside the form (k % 32, k <= 1024, n % 4, 16-byte rows;
- * more than 16384 rows only up to 1024 columns): the caller then uses upa_linear with float32-packed weights. */
-extern "C" int upa_linear_bf16(const float* x, long m, int k, int ldx, const void* w_packed, const float* bias, float* y, int n,
-                               int ldy, const float* residual, int ldr, int act, void* stream) {
-  UPA_CHECK_ARG(x && w_packed && y && m > 0 && m < (1L << 31), "linear_bf16: bad args");
-  const bool ok = k % 32 == 0 && k <= 1024 && n % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (!residual || ldr % 4 == 0) &&
-                  ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && (!residual || (uintptr_t)residual % 16 == 0) &&
+/* y = act(x W^T + b) (+ residual) with the product on the bf16 matrix cores: w_packed = upa_pack_conv_weight(UPA_BF16) of the (n, k, 1, 1)
+ * weight; x rows float32 (rounded to bf16 into the MFMA) or bf16, y rows float32 or bf16 (x_dtype / y_dtype = UPA_F32 | UPA_BF16; strides
+ * in elements), residual float32.  UPA_EUNSUPPORTED outside the form (k % 32 - bf16 x: % 64 -, k <= 1024, n % 4, 16-byte rows; more than
+ * 16384 rows only up to 1024 columns): the caller then uses upa_linear with float32-packed weights. */
+extern "C" int upa_linear_mixed(const void* x, int x_dtype, long m, int k, int ldx, const void* w_packed, const float* bias, void* y,
+                                int y_dtype, int n, int ldy, const float* residual, int ldr, int act, void* stream) {
+  UPA_CHECK_ARG(x && w_packed && y && m > 0 && m < (1L << 31), "linear_mixed: bad args");
+  UPA_CHECK_ARG((x_dtype == UPA_F32 || x_dtype == UPA_BF16) && (y_dtype == UPA_F32 || y_dtype == UPA_BF16), "linear_mixed: dtypes are f32 | bf16");
+  const bool xb = x_dtype == UPA_BF16, yb = y_dtype == UPA_BF16;
+  const bool ok = k % (xb ? 64 : 32) == 0 && k <= 1024 && n % 4 == 0 && ldx % (xb ? 8 : 4) == 0 && ldy % 4 == 0 && (!residual || ldr % 4 == 0) &&
+                  ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % (yb ? 8 : 16)) == 0 && (!residual || (uintptr_t)residual % 16 == 0) &&
                   (!bias || (uintptr_t)bias % 16 == 0) && m <= (1 << 20) && (m <= 16384 || n <= 1024) &&
                   (act == UPA_ACT_NONE || act == UPA_ACT_RELU || act == UPA_ACT_SILU);
   if (!ok) {
-    upa_set_error("linear_bf16: outside the form (k %% 32 == 0, k <= 1024, n %% 4 == 0, 16-byte aligned float32 rows)");
+    upa_set_error("linear_mixed: outside the form (k %% 32 == 0 (bf16 x: %% 64), k <= 1024, n %% 4 == 0, 16-byte aligned rows)");
     return UPA_EUNSUPPORTED;
   }
   LinParams p;
@@ -598,17 +610,29 @@ extern "C" int upa_linear_bf16(const float* x, long m, int k, int ldx, const voi
   p.M = (int)m; p.K = k; p.N = n; p.ldx = ldx; p.ldy = ldy; p.ldr = ldr; p.act = act;
   p.KTT = k / 32; p.NTn = (n + 15) / 16;
   const int mt = k <= 512 ? 2 : 1;
-  const size_t lds = (size_t)mt * 16 * k * 4;
+  const size_t lds = (size_t)mt * 16 * k * (xb ? 2 : 4);
   const dim3 grid((unsigned)((m + mt * 16 - 1) / (mt * 16)), (unsigned)((p.NTn + 3) / 4));
+  hipStream_t s = (hipStream_t)stream;
+#define UPA_LIN_LAUNCH(MT_, XB_, YB_)                                                                  \
+  do {                                                                                               \
+    if (upa_full_lds<linear_bf16_kernel<MT_, XB_, YB_>>() != hipSuccess) return UPA_ELAUNCH;           \
+    hipLaunchKernelGGL((linear_bf16_kernel<MT_, XB_, YB_>), grid, dim3(256), lds, s, p);               \
+  } while (0)
   if (mt == 2) {
-    if (upa_full_lds<linear_bf16_kernel<2>>() != hipSuccess) return UPA_ELAUNCH;
-    hipLaunchKernelGGL(linear_bf16_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, p);
+    if (xb) { if (yb) UPA_LIN_LAUNCH(2, true, true); else UPA_LIN_LAUNCH(2, true, false); }
+    else { if (yb) UPA_LIN_LAUNCH(2, false, true); else UPA_LIN_LAUNCH(2, false, false); }
   } else {
-    if (upa_full_lds<linear_bf16_kernel<1>>() != hipSuccess) return UPA_ELAUNCH;
-    hipLaunchKernelGGL(linear_bf16_kernel<1>, grid, dim3(256), lds, (hipStream_t)stream, p);
+    if (xb) { if (yb) UPA_LIN_LAUNCH(1, true, true); else UPA_LIN_LAUNCH(1, true, false); }
+    else { if (yb) UPA_LIN_LAUNCH(1, false, true); else UPA_LIN_LAUNCH(1, false, false); }
   }
+#undef UPA_LIN_LAUNCH
   UPA_LAUNCH_CHECK();
   return UPA_OK;
+}
+/* = upa_linear_mixed with float32 rows in and out. */
+extern "C" int upa_linear_bf16(const float* x, long m, int k, int ldx, const void* w_packed, const float* bias, float* y, int n,
+                               int ldy, const float* residual, int ldr, int act, void* stream) {
+  return upa_linear_mixed(x, UPA_F32, m, k, ldx, w_packed, bias, y, UPA_F32, n, ldy, residual, ldr, act, stream);
 }
 
 extern "C" int upa_linear(const float* x, long m, int k, int ldx, const void* w_packed, const float* bias, float* y, int n,

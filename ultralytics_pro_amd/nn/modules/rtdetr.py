@@ -197,22 +197,40 @@ class DeformableTransformerDecoderLayer(nn.Module):
         w, b = mha.in_proj_weight, mha.in_proj_bias
         qk_in = rows_add(embed, query_pos, key=(key, "qk_in"))
         # in-projection: q,k from (embed + pos), v from embed (transformer.py:670-673), into one (rows, 3C) buffer
-        qkv = _Rows.new(embed.shape[0], 3 * e, embed.device, key=(key, "qkv"))
         lib, st = L.lib(), L.current_stream(embed.device)
-        fast = _LINEAR_BF16[0] and e % 32 == 0 and e <= 1024
-        wdt = torch.bfloat16 if fast else torch.float32
-        lin = lib.upa_linear_bf16 if fast else lib.upa_linear
-        pk_qk = _packed_linear(self, "in_qk", w[: 2 * e], b[: 2 * e], embed.device, wdt)
-        pk_v = _packed_linear(self, "in_v", w[2 * e:], b[2 * e:], embed.device, wdt)
-        L.check(lin(qk_in.data_ptr(), qk_in.shape[0], e, e, pk_qk.w.data_ptr(), pk_qk.bias.data_ptr(),
-                    qkv.data_ptr(), 2 * e, 3 * e, None, 0, L.ACT_NONE, st), "in_proj_qk")
-        L.check(lin(embed.data_ptr(), embed.shape[0], e, e, pk_v.w.data_ptr(), pk_v.bias.data_ptr(),
-                    qkv.data_ptr() + 2 * e * 4, e, 3 * e, None, 0, L.ACT_NONE, st), "in_proj_v")
-        attn = _Rows.new(embed.shape[0], e, embed.device, key=(key, "attn"))
         d = e // nh
-        L.check(lib.upa_mhsa(qkv.data_ptr(), qkv.data_ptr() + e * 4, qkv.data_ptr() + 2 * e * 4, 3 * e, bs, nq, nh, d,
-                             1.0 / math.sqrt(d), None, 0, attn.data_ptr(), e, L.UPA_F32, st), "self_attn")
-        tgt = linear(self, "out_proj", mha.out_proj.weight, mha.out_proj.bias, attn, residual=embed, key=(key, "sa_out"))
+        fast = _LINEAR_BF16[0] and e % 64 == 0 and e <= 1024 and d == 32 and nq >= 16
+        if fast:
+            # perf mode: q, k, v written as bf16 rows by the bf16-product GEMM, attention on the matrix cores (csrc/attention.hip:
+            # mhsa_mfma_bf16_d32_kernel, the BoT3 kernel with nn.MultiheadAttention's 1/sqrt(d)), its bf16 output straight into out_proj
+            qkv = R.alloc_plain((embed.shape[0], 3 * e), torch.bfloat16, embed.device, key=(key, "qkv16"))
+            pk_qk = _packed_linear(self, "in_qk", w[: 2 * e], b[: 2 * e], embed.device, torch.bfloat16)
+            pk_v = _packed_linear(self, "in_v", w[2 * e:], b[2 * e:], embed.device, torch.bfloat16)
+            L.check(lib.upa_linear_mixed(qk_in.data_ptr(), L.UPA_F32, qk_in.shape[0], e, e, pk_qk.w.data_ptr(), pk_qk.bias.data_ptr(),
+                                         qkv.data_ptr(), L.UPA_BF16, 2 * e, 3 * e, None, 0, L.ACT_NONE, st), "in_proj_qk")
+            L.check(lib.upa_linear_mixed(embed.data_ptr(), L.UPA_F32, embed.shape[0], e, e, pk_v.w.data_ptr(), pk_v.bias.data_ptr(),
+                                         qkv.data_ptr() + 2 * e * 2, L.UPA_BF16, e, 3 * e, None, 0, L.ACT_NONE, st), "in_proj_v")
+            attn = R.alloc_plain((embed.shape[0], e), torch.bfloat16, embed.device, key=(key, "attn16"))
+            L.check(lib.upa_mhsa(qkv.data_ptr(), qkv.data_ptr() + e * 2, qkv.data_ptr() + 2 * e * 2, 3 * e, bs, nq, nh, d,
+                                 1.0 / math.sqrt(d), None, 0, attn.data_ptr(), e, L.UPA_BF16, st), "self_attn")
+            pk_o = _packed_linear(self, "out_proj", mha.out_proj.weight, mha.out_proj.bias, embed.device, torch.bfloat16)
+            tgt = _Rows.new(embed.shape[0], e, embed.device, key=(key, "sa_out"))
+            L.check(lib.upa_linear_mixed(attn.data_ptr(), L.UPA_BF16, attn.shape[0], e, e, pk_o.w.data_ptr(), pk_o.bias.data_ptr(),
+                                         tgt.data_ptr(), L.UPA_F32, e, e, embed.data_ptr(), embed.stride(0), L.ACT_NONE, st), "out_proj")
+        else:
+            qkv = _Rows.new(embed.shape[0], 3 * e, embed.device, key=(key, "qkv"))
+            lin = lib.upa_linear_bf16 if (_LINEAR_BF16[0] and e % 32 == 0 and e <= 1024) else lib.upa_linear
+            wdt = torch.bfloat16 if lin is lib.upa_linear_bf16 else torch.float32
+            pk_qk = _packed_linear(self, "in_qk", w[: 2 * e], b[: 2 * e], embed.device, wdt)
+            pk_v = _packed_linear(self, "in_v", w[2 * e:], b[2 * e:], embed.device, wdt)
+            L.check(lin(qk_in.data_ptr(), qk_in.shape[0], e, e, pk_qk.w.data_ptr(), pk_qk.bias.data_ptr(),
+                        qkv.data_ptr(), 2 * e, 3 * e, None, 0, L.ACT_NONE, st), "in_proj_qk")
+            L.check(lin(embed.data_ptr(), embed.shape[0], e, e, pk_v.w.data_ptr(), pk_v.bias.data_ptr(),
+                        qkv.data_ptr() + 2 * e * 4, e, 3 * e, None, 0, L.ACT_NONE, st), "in_proj_v")
+            attn = _Rows.new(embed.shape[0], e, embed.device, key=(key, "attn"))
+            L.check(lib.upa_mhsa(qkv.data_ptr(), qkv.data_ptr() + e * 4, qkv.data_ptr() + 2 * e * 4, 3 * e, bs, nq, nh, d,
+                                 1.0 / math.sqrt(d), None, 0, attn.data_ptr(), e, L.UPA_F32, st), "self_attn")
+            tgt = linear(self, "out_proj", mha.out_proj.weight, mha.out_proj.bias, attn, residual=embed, key=(key, "sa_out"))
         embed = layer_norm(self.norm1, tgt, key=(key, "n1"))
         # cross attention
         q2 = rows_add(embed, query_pos, key=(key, "q2"))
@@ -365,10 +383,34 @@ class RTDETRDecoder(nn.Module):
         feats = _Rows.new(bs * T, hd, dev, key=(id(self), "feats"))
         row0 = 0
         perf = any(t.dtype == torch.bfloat16 for t in x)
+        fb = None
+        if perf and self.proj_bf16 and all(t.dtype == torch.bfloat16 for t in x) and hd % 8 == 0:
+            # perf mode: the three input projections (1x1 conv + folded BN, head.py:2117-2141) run as bf16 convs on the bf16 feature maps
+            # and write the bf16 token matrix the value projections read; the float32 copy the ranking path works on is ONE widening
+            # pass over it (before: three widening passes over the feature maps + three exact-f32 convs, 3 x (20 + 130) us at bs 16)
+            fb = R.alloc_nhwc(1, hd, 1, bs * T, torch.bfloat16, dev, key=(id(self), "feats_bf16"))
+            vfb = R.view_of(fb)
+            for i, t in enumerate(x):
+                conv, bn = self.input_proj[i][0], self.input_proj[i][1]
+                cache = self.__dict__.setdefault("_pk_cache", {})
+                ver = version_key(conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+                hit = cache.get(("proj16", i, str(dev)))
+                if hit is not None and hit[0] == ver:
+                    pk = hit[1]
+                else:
+                    w, b = fold_bn(conv, bn)
+                    pk = PackedConv(w, b, 1, dev, torch.bfloat16, False)
+                    cache[("proj16", i, str(dev))] = (ver, pk)
+                v = R.view_of(t)
+                L.check(lib.upa_conv2d_bias_act(v.ptr, v.n, v.h, v.w, v.c, v.ld, pk.w.data_ptr(), pk.bias.data_ptr(),
+                                                vfb.ptr + row0 * vfb.ld * 2, hd, vfb.ld, None, 0, 1, 1, 0, L.ACT_NONE,
+                                                L.UPA_BF16, R.opts_ptr(), st_), "input_proj")
+                row0 += bs * v.h * v.w
+            L.check(lib.upa_cast_view(vfb.ptr, L.UPA_BF16, vfb.ld, feats.data_ptr(), L.UPA_F32, hd, bs * T, hd, st_), "widen_tokens")
+            x = []
         for i, t in enumerate(x):
             if t.dtype == torch.bfloat16:
-                # bf16 backbone (perf mode): the decoder itself stays in float32 - its 300-query attention stack is < 5 %
-                # of the model's FLOPs and carries the score ranking - so the three feature maps are widened once here
+                # bf16 backbone with `proj_bf16` off: the decoder input stays float32 - the three feature maps are widened once here
                 vt = R.view_of(t)
                 tf = R.alloc_nhwc(vt.n, vt.c, vt.h, vt.w, torch.float32, dev, key=(id(self), "widen", i))
                 vf = R.view_of(tf)
@@ -396,14 +438,16 @@ class RTDETRDecoder(nn.Module):
         saved_lin = _LINEAR_BF16[0]
         _LINEAR_BF16[0] = bool(perf and self.linear_bf16)
         try:
-            return self._decode(feats, st, bs, hd, T, perf, dev, st_, lib)
+            return self._decode(feats, st, bs, hd, T, perf, dev, st_, lib, fb)
         finally:
             _LINEAR_BF16[0] = saved_lin
 
     # perf mode (bf16 backbone): the decoder's nn.Linear products on the bf16 matrix cores (see `_LINEAR_BF16`); False = exact float32
     linear_bf16 = True
+    # perf mode: the input projections as bf16 convs straight into the bf16 token matrix; False = widen + exact-f32 convs
+    proj_bf16 = True
 
-    def _decode(self, feats, st, bs, hd, T, perf, dev, st_, lib):
+    def _decode(self, feats, st, bs, hd, T, perf, dev, st_, lib, fb=None):
         masked = _Rows.new(bs * T, hd, dev, key=(id(self), "masked"))
         L.check(lib.upa_rows_scale(feats.data_ptr(), st["rowmask"].data_ptr(), masked.data_ptr(), bs * T, hd, st_), "mask")
         eo = self.enc_output
@@ -430,9 +474,10 @@ class RTDETRDecoder(nn.Module):
             # instead of ndl exact-f32 GEMMs of 134400 x 256 x 256 (6 x 254 us at bs 16); the deformable sampling reads the
             # bf16 rows with the layer's column offset.  Everything that ranks or refines queries stays float32.
             nl_ = self.num_decoder_layers if self.decoder.eval_idx < 0 else self.decoder.eval_idx + 1
-            fb = R.alloc_nhwc(1, hd, 1, bs * T, torch.bfloat16, dev, key=(id(self), "feats_bf16"))
-            vf = R.view_of(fb)
-            L.check(lib.upa_cast_view(feats.data_ptr(), L.UPA_F32, hd, vf.ptr, L.UPA_BF16, vf.ld, bs * T, hd, st_), "cast_feats")
+            if fb is None:
+                fb = R.alloc_nhwc(1, hd, 1, bs * T, torch.bfloat16, dev, key=(id(self), "feats_bf16"))
+                vf = R.view_of(fb)
+                L.check(lib.upa_cast_view(feats.data_ptr(), L.UPA_F32, hd, vf.ptr, L.UPA_BF16, vf.ld, bs * T, hd, st_), "cast_feats")
             cache = self.__dict__.setdefault("_pk_cache", {})
             ws = [self.decoder.layers[i].cross_attn.value_proj for i in range(nl_)]
             ver = version_key(*[t for m_ in ws for t in (m_.weight, m_.bias)])
