@@ -1475,3 +1475,39 @@ def test_linear_mixed_row_types(case, xb, yb):
     tol = 2e-5 * scale + ((2.0 ** -8) * scale if yb else 0.0)
     assert float((got[:, :n].double() - ref).abs().max()) <= tol
     assert bool((got[:, n:] == -7.0).all())
+
+
+def test_rtdetr_decoder_layer_perf_mode_close_to_exact():
+    """One DeformableTransformerDecoderLayer at the model's width (d_model 256, 8 heads of 32, d_ffn 1024, 300 queries) with the perf-mode
+    arithmetic of round 4 - nn.Linear products on the bf16 matrix cores (`upa_linear_mixed`), self-attention on the matrix-core kernel
+    with bf16 q / k / v rows - against the same layer in exact float32 on the same inputs: the three post-LayerNorm outputs are O(1) and
+    must agree to bf16-product accuracy (operands carry 8 bits; K = 256 / 1024 sums)."""
+    from tests.hip_utils import DEV, unit_input
+    from ultralytics_pro_amd.nn.modules import rtdetr as RT
+    torch.manual_seed(0)
+    layer = RT.DeformableTransformerDecoderLayer(256, 8, 1024, 0.0, torch.nn.ReLU(), 3, 4).eval()
+    P.apply_procedural_weights(layer)
+    layer = layer.to(DEV)
+    bs, nq = 2, 300
+    embed = unit_input("dl_embed", (bs * nq, 256), -1, 1).to(DEV)
+    qpos = unit_input("dl_qpos", (bs * nq, 256), -1, 1).to(DEV)
+    ref_b = unit_input("dl_ref", (bs * nq, 4), 0.1, 0.9).to(DEV)
+    shapes = [[16, 16], [8, 8], [4, 4]]
+    T = sum(h * w for h, w in shapes)
+    feats = unit_input("dl_feats", (bs * T, 256), -1, 1).to(DEV)
+    shp = torch.tensor([d for s_ in shapes for d in s_], dtype=torch.int32)
+    outs = []
+    for fast in (False, True):
+        RT._LINEAR_BF16[0] = fast
+        try:
+            with torch.no_grad():
+                outs.append(layer(embed, ref_b, feats, {"host_ptr": shp.data_ptr()}, bs, qpos, key=("t", fast)).clone())
+        finally:
+            RT._LINEAR_BF16[0] = False
+    torch.cuda.synchronize()
+    exact, perf = outs[0].cpu(), outs[1].cpu()
+    assert torch.isfinite(perf).all() and float(exact.abs().max()) > 0.5
+    d = (perf - exact).abs()
+    print(f"decoder layer perf vs exact: max {float(d.max()):.4f} mean {float(d.mean()):.5f} (|exact| max {float(exact.abs().max()):.2f})")
+    # measured on MI355X: max 0.0124, mean 0.0017 with |exact| up to 5.8
+    assert float(d.max()) <= 0.03 and float(d.mean()) <= 0.004
