@@ -139,6 +139,10 @@ int upa_stem_conv_fused_k(const void* x, int n, int h, int w, int k0, const floa
  * cfg/models/v8/yolov8.yaml:18-19 at width 0.50). */
 int upa_stem_conv_fused_c(const void* x, int n, int h, int w, int k0, int c0, const float* w0, const float* b0, const void* w1,
                           const float* b1, void* y, int ldy, const upa_opts* opts, void* stream);
+/* ... and the first conv's stride: s0 = 2, or 1 for the 3 -> 32 -> 64 form (darknet53's Conv(3, 32, 3, 1) -> Conv(32, 64, 3, 2): yolov3-rtdetr
+ * rows 0-1, cfg/models/v3/Detect/yolov3-rtdetr.yaml).  y: NHWC bf16 view (n, h / (2 s0), w / (2 s0), 2 * c0). */
+int upa_stem_conv_fused_s(const void* x, int n, int h, int w, int k0, int s0, int c0, const float* w0, const float* b0,
+                          const void* w1, const float* b1, void* y, int ldy, const upa_opts* opts, void* stream);
 
 /* ---- pooling / resampling / concat (HBM-bound) --------------------------------------------------------------- */
 /* nn.MaxPool2d(k, s, p) with -inf padding; pad_br>0 emulates nn.ZeroPad2d([0,pad_br,0,pad_br]) in front of it

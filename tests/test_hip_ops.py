@@ -1023,11 +1023,11 @@ def test_scale_boxes_matches_reference_formula():
         assert torch.equal(got.cpu(), ref)
 
 
-@pytest.mark.parametrize("cfg", ["yolov8n", "yolov5-BoT3", "yolov8s"], ids=["k3", "k6", "c32"])
+@pytest.mark.parametrize("cfg", ["yolov8n", "yolov5-BoT3", "yolov8s", "yolov3-rtdetr"], ids=["k3", "k6", "c32", "c32s1"])
 @pytest.mark.parametrize("shape", [(2, 3, 128, 128), (3, 3, 100, 136), (1, 3, 64, 256)], ids=["sq", "ragged", "wide"])
 def test_fused_stem_and_second_conv_equals_the_two_layers(shape, cfg):
     """Rows 0-1 of yolov8n (Conv(3,16,3,2) -> Conv(16,32,3,2)), of the yolov5 family (Conv(3,16,6,2,2) -> Conv(16,32,3,2)) and of yolov8s
-    (Conv(3,32,3,2) -> Conv(32,64,3,2)) as one kernel (upa_stem_conv_fused_c: the stem output stays in LDS) vs the two separate HIP layers and vs the oracle (Conv,
+    (Conv(3,32,3,2) -> Conv(32,64,3,2)) and darknet53 (yolov3-rtdetr: Conv(3,32,3,1) -> Conv(32,64,3,2)) as one kernel (upa_stem_conv_fused_c: the stem output stays in LDS) vs the two separate HIP layers and vs the oracle (Conv,
     conv.py:188-197) on a bf16 NCHW input; image borders, partial tiles, odd tile counts."""
     from tests.hip_utils import DEV, bf16_round, to_cpu_nchw
     from ultralytics_pro_amd.nn.tasks import DetectionModel

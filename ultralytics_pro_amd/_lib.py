@@ -122,6 +122,7 @@ PROTOTYPES = {
     "upa_stem_conv_fused": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _op, _vp]),
     "upa_stem_conv_fused_k": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _op, _vp]),
     "upa_stem_conv_fused_c": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _op, _vp]),
+    "upa_stem_conv_fused_s": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _op, _vp]),
     "upa_maxpool2d": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "upa_sppf_pool3": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "upa_upsample2x": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),

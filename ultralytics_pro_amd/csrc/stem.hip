@@ -718,11 +718,26 @@ using namespace sf;
 constexpr int NW = 8, NTH = NW * 64;
 constexpr int SP = 80;                               // bytes per stem pixel in LDS (64 used)
 constexpr int STILE32 = S0H * 2 * S0WH * SP;         // 46240
+// first conv k = 3, pad 1, stride ST0 (2: yolov8s; 1: darknet53's Conv(3, 32, 3, 1) -> Conv(32, 64, 3, 2), yolov3-rtdetr rows 0-1): the
+// input patch of the 17 x 33 stem tile is (ST0 * 16 + 3) x (ST0 * 32 + 3) pixels
+template <int ST0>
+struct GeoS {
+  static constexpr int PAD0 = 1;
+  static constexpr int PR = ST0 * (S0H - 1) + 3, PC = ST0 * (S0W - 1) + 3;
+  static constexpr int NCH = (PC + 7 + 7) / 8;
+  static constexpr int LS = NCH * 8;
+  static constexpr int ITEMS = 3 * PR * NCH;
+  static constexpr int KTOT = 27;
+  static constexpr int SHIFT = (-(ST0 + PAD0)) & 7;  // input origin ST0 * (32 txi - 1) - PAD0, rounded down to 8 pixels
+  static constexpr int items_pad(int nw) { return (ITEMS + nw * 64 - 1) / (nw * 64) * (nw * 64); }
+  static constexpr int patch_bytes(int nw) { return items_pad(nw) * 16; }
+};
 }  // namespace sf32
 
+template <int ST0>
 __global__ __launch_bounds__(512, 4) void stem_conv_fused32_kernel(const StemFusedParams p) {
   using namespace sf32;
-  using G0 = Geo<3>;
+  using G0 = GeoS<ST0>;
   constexpr int PR = G0::PR, NCH = G0::NCH, LS = G0::LS, ITEMS = G0::ITEMS;
   constexpr int ITEMS_PAD = G0::items_pad(NW);
   constexpr int PATCH = G0::patch_bytes(NW);
@@ -749,7 +764,7 @@ __global__ __launch_bounds__(512, 4) void stem_conv_fused32_kernel(const StemFus
     const int n = tile / tilesPerImg;
     const int t2 = tile - n * tilesPerImg;
     const int tyi = t2 / p.tilesX, txi = t2 - tyi * p.tilesX;
-    const int iy0 = 2 * (2 * tyi * T1H - 1) - G0::PAD0, ix0 = 2 * (2 * txi * T1W - 1) - G0::PAD0;
+    const int iy0 = ST0 * (2 * tyi * T1H - 1) - G0::PAD0, ix0 = ST0 * (2 * txi * T1W - 1) - G0::PAD0;
     const int ixa = ix0 & ~7;
     const bf16_t* xb = (const bf16_t*)p.x + (size_t)n * 3 * plane;
     const bf16_t* xt = xb + iy0 * p.W + ixa;
@@ -824,7 +839,7 @@ __global__ __launch_bounds__(512, 4) void stem_conv_fused32_kernel(const StemFus
         const bool qin = q < S0H * S0W;
         const int qq = qin ? q : S0H * S0W - 1;
         const int r = qq / S0W, c = qq - r * S0W;
-        const char* base = pb + ((2 * r) * LS + 2 * c) * 2;
+        const char* base = pb + ((ST0 * r) * LS + ST0 * c) * 2;
         unsigned e[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) e[j] = *reinterpret_cast<const unsigned short*>(base + goff[j]);
@@ -981,15 +996,16 @@ static int stem_nchw_impl(const void* x, int x_dtype, int n, int cin, int h, int
  * w0 / b0: stem weights packed by upa_pack_stem_weight (+ folded bias); w1 / b1: second conv packed by
  * upa_pack_conv_weight(bf16) (+ folded bias).  y: NHWC bf16 view (n, h/4, w/4, 32). */
 static int stem_conv_fused_impl(const void* x, int n, int h, int w, int k0, int c0, const float* w0, const float* b0, const void* w1,
-                                const float* b1, void* y, int ldy, const upa_opts* opts, void* stream) {
+                                const float* b1, void* y, int ldy, const upa_opts* opts, void* stream, int s0 = 2) {
   UPA_CHECK_ARG(x && w0 && w1 && y, "stem_conv_fused: null pointer");
   UPA_CHECK_ARG(k0 == 3 || k0 == 6, "stem_conv_fused: first conv k = 3 (pad 1) or 6 (pad 2)");
   UPA_CHECK_ARG(c0 == 16 || (c0 == 32 && k0 == 3), "stem_conv_fused: 3 -> 16 -> 32 channels (k 3 | 6) or 3 -> 32 -> 64 (k 3)");
-  UPA_CHECK_ARG(w % 8 == 0 && h % 4 == 0 && w % 4 == 0 && (long)3 * h * w < (1L << 31), "stem_conv_fused: w %% 8, h %% 4 == 0 required");
+  UPA_CHECK_ARG(s0 == 2 || (s0 == 1 && c0 == 32), "stem_conv_fused: first conv stride 2, or 1 for the 3 -> 32 -> 64 form");
+  UPA_CHECK_ARG(w % 8 == 0 && h % (2 * s0) == 0 && w % (2 * s0) == 0 && (long)3 * h * w < (1L << 31), "stem_conv_fused: w %% 8, h %% (2 s0) == 0 required");
   UPA_CHECK_ARG(ldy % 8 == 0 && (uintptr_t)y % 16 == 0, "stem_conv_fused: output view must be 16-byte aligned");
   StemFusedParams p{};
   p.x = x; p.w0 = w0; p.b0 = b0; p.w1 = (const char*)w1; p.b1 = b1; p.y = (char*)y;
-  p.N = n; p.H = h; p.W = w; p.H0 = h / 2; p.W0 = w / 2; p.OH = h / 4; p.OW = w / 4; p.ldy = ldy;
+  p.N = n; p.H = h; p.W = w; p.H0 = h / s0; p.W0 = w / s0; p.OH = h / (2 * s0); p.OW = w / (2 * s0); p.ldy = ldy;
   p.tilesX = cdiv(p.OW, sf::T1W); p.tilesY = cdiv(p.OH, sf::T1H);
   p.no_xcd = UPA_OPT(opts, no_xcd);
   const long ntiles = (long)p.tilesX * p.tilesY * n;
@@ -997,9 +1013,15 @@ static int stem_conv_fused_impl(const void* x, int n, int h, int w, int k0, int 
   const int nw = UPA_OPT(opts, stemf_waves) == 4 ? 4 : 8;
   const dim3 grid((unsigned)(ntiles < wgs ? ntiles : wgs));
   hipStream_t st = (hipStream_t)stream;
+  if (c0 == 32 && s0 == 1) {  // (patch 8 KB + stem tile 46 KB: two to three 8-wave workgroups per CU)
+    (void)upa_full_lds<stem_conv_fused32_kernel<1>>();
+    hipLaunchKernelGGL(stem_conv_fused32_kernel<1>, grid, dim3(512), (size_t)sf32::GeoS<1>::patch_bytes(8) + sf32::STILE32, st, p);
+    UPA_LAUNCH_CHECK();
+    return UPA_OK;
+  }
   if (c0 == 32) {  // two 8-wave workgroups per CU (71 KB of LDS each)
-    (void)upa_full_lds<stem_conv_fused32_kernel>();
-    hipLaunchKernelGGL(stem_conv_fused32_kernel, grid, dim3(512), (size_t)sf::Geo<3>::patch_bytes(8) + sf32::STILE32, st, p);
+    (void)upa_full_lds<stem_conv_fused32_kernel<2>>();
+    hipLaunchKernelGGL(stem_conv_fused32_kernel<2>, grid, dim3(512), (size_t)sf32::GeoS<2>::patch_bytes(8) + sf32::STILE32, st, p);
     UPA_LAUNCH_CHECK();
     return UPA_OK;
   }
@@ -1030,4 +1052,11 @@ extern "C" int upa_stem_conv_fused_k(const void* x, int n, int h, int w, int k0,
 extern "C" int upa_stem_conv_fused_c(const void* x, int n, int h, int w, int k0, int c0, const float* w0, const float* b0, const void* w1,
                                      const float* b1, void* y, int ldy, const upa_opts* opts, void* stream) {
   return stem_conv_fused_impl(x, n, h, w, k0, c0, w0, b0, w1, b1, y, ldy, opts, stream);
+}
+/* ... and the first conv's stride: s0 = 2, or 1 for the 3 -> 32 -> 64 form (darknet53's Conv(3, 32, 3, 1) -> Conv(32, 64, 3, 2),
+ * cfg/models/v3/Detect/yolov3-rtdetr.yaml rows 0-1).  y: NHWC bf16 view (n, h / (2 s0), w / (2 s0), 2 * c0). */
+extern "C" int upa_stem_conv_fused_s(const void* x, int n, int h, int w, int k0, int s0, int c0, const float* w0, const float* b0,
+                                     const void* w1, const float* b1, void* y, int ldy, const upa_opts* opts, void* stream) {
+  UPA_CHECK_ARG(s0 == 1 || s0 == 2, "stem_conv_fused: first conv stride 1 | 2");
+  return stem_conv_fused_impl(x, n, h, w, k0, c0, w0, b0, w1, b1, y, ldy, opts, stream, s0);
 }

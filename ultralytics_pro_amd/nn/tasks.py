@@ -337,21 +337,23 @@ class BaseModel(nn.Module):
             return False
         ca, cb = a.conv, b.conv
         first = (ca.in_channels, ca.out_channels, ca.kernel_size, ca.stride, ca.padding)
-        ok = first in ((3, 16, (3, 3), (2, 2), (1, 1)), (3, 16, (6, 6), (2, 2), (2, 2)), (3, 32, (3, 3), (2, 2), (1, 1))) and \
+        ok = first in ((3, 16, (3, 3), (2, 2), (1, 1)), (3, 16, (6, 6), (2, 2), (2, 2)), (3, 32, (3, 3), (2, 2), (1, 1)),
+                       (3, 32, (3, 3), (1, 1), (1, 1))) and \
             (cb.in_channels, cb.out_channels, cb.kernel_size, cb.stride, cb.padding) == (first[1], 2 * first[1], (3, 3), (2, 2), (1, 1)) and \
             isinstance(a.act, nn.SiLU) and isinstance(b.act, nn.SiLU) and not a.training
         n, c, h, w = x.shape
-        return bool(ok and c == 3 and x.is_contiguous() and w % 8 == 0 and h % 4 == 0 and w % 4 == 0)
+        s0 = int(ca.stride[0])
+        return bool(ok and c == 3 and x.is_contiguous() and w % 8 == 0 and h % (2 * s0) == 0 and w % (2 * s0) == 0)
 
     def _fused_stem(self, x):
         a, b = self.model[0], self.model[1]
         pa = a._packed(a.conv, getattr(a, "bn", None), x.device, torch.bfloat16, True)
         pb = b._packed(b.conv, getattr(b, "bn", None), x.device, torch.bfloat16, False)
         n, _, h, w = x.shape
-        c0 = int(a.conv.out_channels)
-        y = R.alloc_nhwc(n, 2 * c0, h // 4, w // 4, torch.bfloat16, x.device, key=(id(b), "y"))
+        c0, s0 = int(a.conv.out_channels), int(a.conv.stride[0])
+        y = R.alloc_nhwc(n, 2 * c0, h // (2 * s0), w // (2 * s0), torch.bfloat16, x.device, key=(id(b), "y"))
         vy = R.view_of(y)
-        L.check(L.lib().upa_stem_conv_fused_c(x.data_ptr(), n, h, w, int(a.conv.kernel_size[0]), c0, pa.w.data_ptr(), pa.bias.data_ptr(),
+        L.check(L.lib().upa_stem_conv_fused_s(x.data_ptr(), n, h, w, int(a.conv.kernel_size[0]), s0, c0, pa.w.data_ptr(), pa.bias.data_ptr(),
                                               pb.w.data_ptr(), pb.bias.data_ptr(), vy.ptr, vy.ld, R.opts_ptr(),
                                               L.current_stream(x.device)), "stem_conv_fused")
         return y
