@@ -107,12 +107,12 @@ def main():
         tot_ms += ms
         tot_fl += fl
         tot_by += by
-    print(f"{'cin':>4} {'cout':>4} k s {'HxW':>9} res {'var':>5} calls {'us/call':>8} {'TFLOP/s':>8} {'GB/s':>7} {'t_hbm':>6} {'t_mfma':>6}")
+    print(f"{'cin':>4} {'cout':>4} k s {'HxW':>9} res {'var':>7} calls {'us/call':>8} {'TFLOP/s':>8} {'GB/s':>7} {'t_hbm':>6} {'t_mfma':>6}")
     peak = 2500e12 if es == 2 else 157e12
     for key, (cnt, ms, fl, by) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         cin, cout, k, s, h, w, res, var = key
         us = ms / cnt * 1e3
-        print(f"{cin:4d} {cout:4d} {k} {s} {h:4d}x{w:<4d} {int(res):3d} {var & 0xffffff:6x} {cnt:5d} {us:8.1f} {fl / (us * 1e-6) / 1e12:8.1f} "
+        print(f"{cin:4d} {cout:4d} {k} {s} {h:4d}x{w:<4d} {int(res):3d} {(var & 0xfffffff) if var >= 0 else 0xffffff:7x} {cnt:5d} {us:8.1f} {fl / (us * 1e-6) / 1e12:8.1f} "
               f"{by / (us * 1e-6) / 1e9:7.0f} {by / 6.0e12 * 1e6:6.1f} {fl / peak * 1e6:6.1f}")
     print(f"TOTAL conv {tot_ms:.3f} ms/step  {tot_fl / tot_ms / 1e9:.1f} TFLOP/s  {tot_by / tot_ms / 1e6:.0f} GB/s  "
           f"(hbm floor {tot_by / 6.0e12 * 1e3:.3f} ms, mfma floor {tot_fl / peak * 1e3:.3f} ms)")
