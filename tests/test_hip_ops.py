@@ -1511,3 +1511,38 @@ def test_rtdetr_decoder_layer_perf_mode_close_to_exact():
     print(f"decoder layer perf vs exact: max {float(d.max()):.4f} mean {float(d.mean()):.5f} (|exact| max {float(exact.abs().max()):.2f})")
     # measured on MI355X: max 0.0124, mean 0.0017 with |exact| up to 5.8
     assert float(d.max()) <= 0.03 and float(d.mean()) <= 0.004
+
+
+def test_msdeform_attn_bf16_values_match_exact_path():
+    """`upa_msdeform_attn_strided` on bf16 value rows (perf mode: the decoder's batched value projection; softmax on v_exp_f32 / v_rcp_f32,
+    unconditional clamped corner fetches) vs the exact-f32 instantiation on the SAME bf16-rounded values (transformer.py:510-558): model
+    shapes (3 levels 80/40/20, 8 heads of 32, 300 queries), offsets that throw a share of the sampling points outside the maps, a strided
+    value matrix (one layer's columns of the six-layer projection)."""
+    from tests.hip_utils import DEV, bf16_round, unit_input
+    from ultralytics_pro_amd import _lib as L
+    lib = L.lib()
+    bs, nq, heads, d, npnt = 2, 300, 8, 32, 4
+    shapes = [[80, 80], [40, 40], [20, 20]]
+    T = sum(h * w for h, w in shapes)
+    C = heads * d
+    ldv = 3 * C
+    vals = bf16_round(unit_input("msd16_v", (bs * T, ldv), -1, 1))
+    off = unit_input("msd16_off", (bs * nq, heads * 3 * npnt * 2), -6, 6)
+    lg = unit_input("msd16_lg", (bs * nq, heads * 3 * npnt), -3, 3)
+    ref = torch.cat([unit_input("msd16_ref", (bs * nq, 2), 0.02, 0.98), unit_input("msd16_wh", (bs * nq, 2), 0.05, 0.6)], 1).contiguous()
+    shp = torch.tensor([v for s_ in shapes for v in s_], dtype=torch.int32)
+    st = L.current_stream(DEV)
+    v32 = vals.to(DEV)
+    v16 = vals.to(DEV).to(torch.bfloat16)
+    offd, lgd, refd = off.to(DEV), lg.to(DEV), ref.to(DEV)
+    y32 = torch.empty(bs * nq, C, device=DEV)
+    y16 = torch.empty(bs * nq, C, device=DEV)
+    col0 = C  # the middle layer's columns
+    L.check(lib.upa_msdeform_attn_strided(v32.data_ptr() + col0 * 4, L.UPA_F32, ldv, shp.data_ptr(), 3, bs, heads, d, offd.data_ptr(),
+                                          lgd.data_ptr(), refd.data_ptr(), nq, npnt, y32.data_ptr(), st), "msdeform f32")
+    L.check(lib.upa_msdeform_attn_strided(v16.data_ptr() + col0 * 2, L.UPA_BF16, ldv, shp.data_ptr(), 3, bs, heads, d, offd.data_ptr(),
+                                          lgd.data_ptr(), refd.data_ptr(), nq, npnt, y16.data_ptr(), st), "msdeform bf16")
+    torch.cuda.synchronize()
+    a, b = y32.cpu(), y16.cpu()
+    assert float(a.abs().max()) > 0.05 and float((a == 0).float().mean()) < 0.5
+    assert float((a - b).abs().max()) <= 2e-5  # same values, same weights up to v_exp_f32 / v_rcp_f32 (1 ulp) and the order of 48 f32 adds

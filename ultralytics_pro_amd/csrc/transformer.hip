@@ -315,10 +315,59 @@ __global__ __launch_bounds__(256) void msdeform_kernel(const VT* value, int ldv,
   const float rx = ref[bq * 4 + 0], ry = ref[bq * 4 + 1], rw = ref[bq * 4 + 2], rh = ref[bq * 4 + 3];
   float mx = lg[0];
   for (int i = 1; i < NLP; ++i) mx = fmaxf(mx, lg[i]);
-  float den = 0.f;
-  for (int i = 0; i < NLP; ++i) den += expf(lg[i] - mx);
   const int C = heads * D;
   float acc = 0.f;
+  if constexpr (sizeof(VT) == 2) {
+    // perf mode (bf16 value rows): the softmax of the <= 16 sampling logits once per lane on v_exp_f32 / v_rcp_f32, and the four corner
+    // fetches of a point UNCONDITIONAL (clamped address, weight zeroed outside the map) so that the 4 NP loads of a level are issued
+    // together instead of one dependent branch each - the exact-f32 instantiation below keeps the reference's arithmetic order
+    float e[16];
+    float den = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      e[i] = i < NLP ? __expf(lg[i] - mx) : 0.f;
+      den += e[i];
+    }
+    const float inv = __builtin_amdgcn_rcpf(den);
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      if (l >= lv.n_levels) break;  // uniform
+      const int H = lv.h[l], W = lv.w[l];
+      const VT* vbase = value + ((size_t)lv.row0[l] + (size_t)b * H * W) * (size_t)ldv + head * D + ch;
+      float v[NP][4], wc[NP][4];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int i = l * NP + p;
+        const float lx = rx + of[2 * i] / (float)NP * rw * 0.5f;
+        const float ly = ry + of[2 * i + 1] / (float)NP * rh * 0.5f;
+        const float gx = 2.f * lx - 1.f, gy = 2.f * ly - 1.f;
+        const float ix = ((gx + 1.f) * (float)W - 1.f) / 2.f, iy = ((gy + 1.f) * (float)H - 1.f) / 2.f;
+        const float x0f = floorf(ix), y0f = floorf(iy);
+        // (clamped before the int conversion: a wild offset must not overflow it)
+        const int x0 = (int)fminf(fmaxf(x0f, -2.f), (float)W), y0 = (int)fminf(fmaxf(y0f, -2.f), (float)H);
+        const float tx = ix - x0f, ty = iy - y0f;
+        const bool xin0 = x0 >= 0 && x0 < W, xin1 = x0 + 1 >= 0 && x0 + 1 < W;
+        const bool yin0 = y0 >= 0 && y0 < H, yin1 = y0 + 1 >= 0 && y0 + 1 < H;
+        const int xa = min(max(x0, 0), W - 1), xb = min(max(x0 + 1, 0), W - 1);
+        const int ya = min(max(y0, 0), H - 1), yb = min(max(y0 + 1, 0), H - 1);
+        const float wgt = e[i] * inv;
+        wc[p][0] = (yin0 && xin0) ? wgt * (1.f - tx) * (1.f - ty) : 0.f;
+        wc[p][1] = (yin0 && xin1) ? wgt * tx * (1.f - ty) : 0.f;
+        wc[p][2] = (yin1 && xin0) ? wgt * (1.f - tx) * ty : 0.f;
+        wc[p][3] = (yin1 && xin1) ? wgt * tx * ty : 0.f;
+        v[p][0] = ldval(vbase + ((size_t)ya * W + xa) * ldv);
+        v[p][1] = ldval(vbase + ((size_t)ya * W + xb) * ldv);
+        v[p][2] = ldval(vbase + ((size_t)yb * W + xa) * ldv);
+        v[p][3] = ldval(vbase + ((size_t)yb * W + xb) * ldv);
+      }
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) acc += wc[p][c4] * v[p][c4];
+    }
+  } else {
+  float den = 0.f;
+  for (int i = 0; i < NLP; ++i) den += expf(lg[i] - mx);
   for (int l = 0; l < lv.n_levels; ++l) {
     const int H = lv.h[l], W = lv.w[l];
     const VT* vbase = value + ((size_t)lv.row0[l] + (size_t)b * H * W) * (size_t)ldv + head * D + ch;
@@ -342,6 +391,7 @@ __global__ __launch_bounds__(256) void msdeform_kernel(const VT* value, int ldv,
       if (yin1 && xin1) s += ldval(vbase + ((size_t)(y0 + 1) * W + x0 + 1) * ldv) * tx * ty;
       acc += wgt * s;
     }
+  }
   }
   y[bq * C + head * D + ch] = acc;
 }
