@@ -466,7 +466,7 @@ def main():
             "parity": parity,
             "speed": gpu_speed,
             "config": {"workload": f"{args.model} detect 640x640 bs={pb} {args.dtype} inference, 1 hipGraph/step: "
-                                   + ("forward+RT-DETR decoder (f32)+postprocess(conf .25, max_det 300)" if rtdetr else
+                                   + (("forward+RT-DETR decoder (f32 rows; " + ("bf16-product linears, matrix-core self-attention" if args.dtype == "bf16" else "exact f32") + ")+postprocess(conf .25, max_det 300)") if rtdetr else
                                       "forward+decode+NMS(conf .25, iou .7, max_det 300)"),
                        "micro_batches": args.micro_batches, "intra_step_concurrency": not (args.serial or runner.linear),
                        "steps_in_flight": max(1, args.in_flight), "lane_priority": runner.priority, "linear_graphs": runner.linear, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
