@@ -126,6 +126,9 @@ BIG_CASES = [
     (1024, 256, 1, 10, 10, 2, False),  # pointwise: 200 pixels flattened, 16 chunks
     (256, 128, 1, 33, 9, 1, True),     # pointwise, ragged pixel count, residual
     (128, 384, 1, 20, 20, 1, False),   # three workgroup columns
+    (128, 64, 2, 80, 80, 2, False),    # 2 x 2 kernel, pad 1 (output 81 x 81): the phase kernels of a stride-2 data gradient (train.hip)
+    (256, 128, 2, 40, 40, 1, False),   # 2 x 2, 128-channel column, 41 x 41 output
+    (512, 256, 2, 21, 19, 2, False),   # 2 x 2, odd sizes, two columns
 ]
 
 
@@ -149,7 +152,8 @@ def test_conv_big_kernel(case, act, bm):
         assert (var >> 23) & 1, "case is not dispatched to the large-tile kernel"
         o, m = _pair(om.Conv, pm.Conv, (c1, c2, k, st, None, 1, 1, act), "conv_big")
         x = bf16_round(P.uniform(f"big{case}", (N, c1, H, W), -1, 1))
-        rsd = bf16_round(P.uniform(f"bigres{case}", (N, c2, (H - 1) // st + 1, (W - 1) // st + 1), -1, 1)) if res else None
+        oh, ow = (H + 2 * (k // 2) - k) // st + 1, (W + 2 * (k // 2) - k) // st + 1
+        rsd = bf16_round(P.uniform(f"bigres{case}", (N, c2, oh, ow), -1, 1)) if res else None
         with torch.no_grad():
             ref = bf16_weight_oracle(o)(x) + (rsd if res else 0)
             y = to_cpu_nchw(m(to_dev_nhwc(x, torch.bfloat16), residual=to_dev_nhwc(rsd, torch.bfloat16) if res else None))

@@ -449,7 +449,7 @@ bool big_pick_tile(BigParams& p, int bm, int ntb, size_t lds_cap) {
   static std::mutex mu;
   static std::unordered_map<unsigned long long, Pick> memo;
   const unsigned long long key = ((unsigned long long)p.OH << 48) ^ ((unsigned long long)p.OW << 32) ^ ((unsigned long long)bm << 20) ^
-                                 ((unsigned long long)ntb << 12) ^ ((unsigned long long)(lds_cap >> 9) << 3) ^ (p.KS == 3 ? 4u : 0u) ^
+                                 ((unsigned long long)ntb << 12) ^ ((unsigned long long)(lds_cap >> 9) << 3) ^ ((unsigned long long)p.KS << 56) ^ (p.KS == 3 ? 4u : 0u) ^
                                  (p.stride == 2 ? 2u : 0u);
   {
     std::lock_guard<std::mutex> lk(mu);
@@ -558,6 +558,7 @@ int big_launch_mix(const BigParams* pa, int na, const BigParams* pb, int nb, siz
 template <int WM, int WN, int MT, int NT>
 int big_launch_ks(const BigParams& p, size_t lds, hipStream_t s) {
   if (p.KS == 1) return big_launch_inst<1, 1, WM, WN, MT, NT>(p, lds, s);
+  if (p.KS == 2) return big_launch_inst<2, 1, WM, WN, MT, NT>(p, lds, s);  // (2 x 2, pad 1: the phase kernels of a stride-2 data gradient, train.hip)
   if (p.stride == 2) return big_launch_inst<3, 2, WM, WN, MT, NT>(p, lds, s);
   return big_launch_inst<3, 1, WM, WN, MT, NT>(p, lds, s);
 }
@@ -774,7 +775,7 @@ bool upa_conv_big_eligible(int n, int h, int w, int cin, int ldx, int cout, int 
   // tools/bench_conv.py)
   const int mode = UPA_OPT(opts, conv_big);
   if (mode == 1) return false;
-  if (dtype != UPA_BF16 || !((k == 1 && stride == 1) || (k == 3 && (stride == 1 || stride == 2))) || pad != k / 2) return false;
+  if (dtype != UPA_BF16 || !((k == 1 && stride == 1) || (k == 2 && stride == 1) || (k == 3 && (stride == 1 || stride == 2))) || pad != k / 2) return false;
   if (cin % 8 != 0 || ldx % 8 != 0 || cout % 8 != 0 || ldy % 8 != 0 || ldr % 8 != 0) return false;
   if (act != UPA_ACT_SILU && act != UPA_ACT_NONE && act != UPA_ACT_RELU) return false;
   if (mode == 2) return cout >= 64;
@@ -797,7 +798,7 @@ bool upa_conv_big_eligible(int n, int h, int w, int cin, int ldx, int cout, int 
   if (cin < 64 || px < 2048) return false;
   if (cout % 128 == 0) return cin >= 128 || (px >= 8192 && (stride == 2 || px >= 200 * 1024));
   if (px < 8192) return false;
-  if (cout == 80 || cout == 96) return stride == 1;
+  if (cout == 80 || cout == 96) return stride == 1 && k == 3;
   if (cout == 64) return stride == 1;
   return false;
 }
