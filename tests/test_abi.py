@@ -89,6 +89,30 @@ def test_dispatch_options_travel_with_the_call_and_the_library_reads_no_environm
     assert L.Opts.from_env({"UPA_NO_PAIR": "0", "UPA_C1_MT": "4", "UPA_CONV_FORCE": "4,1,2,4"}).pair == 2  # tool-side mapping only
 
 
+def test_conv_p8_size_rule_is_host_logic():
+    """The round-4 dispatch rule of the two-group phased kernel (csrc/conv_p8.hip: one-round layers of 256-pixel x 128-channel tiles with
+    Cin >= 256) is pure host logic behind `upa_conv_variant`: the layers it was measured on pick it, their neighbours stay on conv_big,
+    `upa_opts.conv_p8` = 1 / 2 switch it off / force it, and conv_mm is never chosen by default."""
+    import ctypes as C
+    from ultralytics_pro_amd import _lib as L
+    lib = L.lib()
+    p8 = lambda v: (v >> 26) & 1   # noqa: E731
+    big = lambda v: (v >> 23) & 1  # noqa: E731
+    mm = lambda v: (v >> 25) & 1   # noqa: E731
+    one_round = [(16, 40, 40, 512, 256), (16, 20, 20, 512, 1024), (16, 40, 40, 768, 256), (32, 20, 20, 256, 512), (32, 40, 40, 256, 128)]
+    others = [(16, 40, 40, 256, 512), (16, 80, 80, 256, 128), (16, 80, 80, 128, 256), (16, 20, 20, 1024, 512), (32, 40, 40, 128, 128)]
+    for n, h, w, c1, c2 in one_round:
+        v = lib.upa_conv_variant(n, h, w, c1, c2, 3, 1, 1, L.UPA_BF16, None)
+        assert p8(v) and not mm(v), (n, h, w, c1, c2, hex(v))
+        assert big(lib.upa_conv_variant(n, h, w, c1, c2, 3, 1, 1, L.UPA_BF16, C.pointer(L.Opts(conv_p8=1))))
+    for n, h, w, c1, c2 in others:
+        v = lib.upa_conv_variant(n, h, w, c1, c2, 3, 1, 1, L.UPA_BF16, None)
+        assert big(v) and not p8(v) and not mm(v), (n, h, w, c1, c2, hex(v))
+        assert p8(lib.upa_conv_variant(n, h, w, c1, c2, 3, 1, 1, L.UPA_BF16, C.pointer(L.Opts(conv_p8=2))))
+    assert not p8(lib.upa_conv_variant(16, 40, 40, 512, 256, 3, 2, 1, L.UPA_BF16, C.pointer(L.Opts(conv_p8=2))))  # stride 2: never
+    assert mm(lib.upa_conv_variant(16, 40, 40, 512, 256, 3, 1, 1, L.UPA_BF16, C.pointer(L.Opts(conv_mm=2, conv_p8=1))))
+
+
 def test_product_builds_on_cpu_but_refuses_to_run_there():
     from ultralytics_pro_amd._lib import UpaError
     from ultralytics_pro_amd.nn.tasks import DetectionModel
