@@ -935,7 +935,7 @@ def test_e2e_yolov3_tiny_conv_pool_fusion_is_exact():
     assert torch.equal(y_fused, y_plain) and torch.equal(y_graph, y_plain)
 
 
-@pytest.mark.parametrize("name", ["yolov8n", "yolov5-BoT3", "yolov3-tiny"])
+@pytest.mark.parametrize("name", ["yolov8n", "yolov5-BoT3", "yolov3-tiny", "yolov8s"])  # (tiny / yolov8s: class tails on the streaming 1x1 kernel)
 def test_e2e_bf16_keys_only_head_is_exact(name):
     """`Detect.scores_out = False` (`upa_opts.keys_only`): the fused class tails write ONLY every anchor's best-class NMS key - no
     (B, nc, A) score rows, one sigmoid per anchor instead of nc (the sigmoid of the largest logit when it is separated from the

@@ -158,6 +158,13 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_stream_kernel(const C1Para
         upa_detect_split(p.de, pix < p.P ? pix : p.P - 1, db, da);
         float best_ = -1.f;  // this lane's running first maximum over its classes of all n-tiles (NMS prefilter key)
         int bc_ = 0;
+        if (p.de.keys_only) {  // uniform: only the best-class keys leave the kernel (upa_opts.keys_only, as the conv_big class tail): no
+                               // score rows, one sigmoid per pixel, and nothing to add to `seq` (a count that is too small only waits more)
+          f32x4 lg[NTW];
+#pragma unroll
+          for (int j = 0; j < NTW; ++j) lg[j] = acc[i][j] + biasv[j];
+          upa_detect_cls_keys_only<NTW>(p.de, lg, pok, kg, best_, bc_);
+        } else {
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
           upa_detect_cls_store(p.de, acc[i][j] + biasv[j], j, db, da, pok, kg, best_, bc_);
@@ -165,6 +172,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_stream_kernel(const C1Para
                                                // only be too small: a wait for more than needed is always safe)
           if (16 * j + 3 >= p.de.nc)
             for (int q = 0; q < 4; ++q) seq += 16 * j + q < p.de.nc ? 1 : 0;
+        }
         }
         // (not counted in seq: the count may only be too small)
         if (p.de.best_keys) upa_detect_best_key_store(p.de, best_, bc_, db, da, pok, lane);  // uniform
@@ -400,6 +408,7 @@ extern "C" int upa_detect_tail(const void* x, int n, int h, int w, int cin, int 
   q.de.magicHW = upa_magic_div(h * w); q.de.magicW = upa_magic_div(w);
   q.de.nc = nc; q.de.stride_px = stride_px;
   if (kind == 2 && best_keys && (long)a_total * nc < (1L << 31)) q.de.best_keys = best_keys;
+  q.de.keys_only = (q.de.best_keys && UPA_OPT(opts, keys_only) && raw == nullptr) ? 1 : 0;  // (with raw maps requested the rows are wanted too)
   return upa_conv1x1_launch(q, n * h * w, 0, nullptr, stream, opts);
 }
 
