@@ -957,6 +957,20 @@ def test_nms_large_multilabel_vs_oracle():
         for a, b in zip(out, ref):
             assert a.shape == b.shape
             assert torch.equal(a.cpu(), b), kw
+    # the two-stage sort (round 4): with more than 16384 candidates only the top 16384 are sorted first (in LDS); an image whose
+    # greedy pass exhausts them before max_det boxes are kept must come out of the second, full pass.  Image 0: 300 anchors share ONE
+    # box and carry the highest scores in every class (24000 candidates - more than the 16384 of the first pass, fewer than max_nms -
+    # that keep one box per class = 80 < max_det) in front of 900 distinct low-score boxes; image 1: the ordinary scene; image 2: few candidates.
+    q = p.clone()
+    q[0, 0, :300], q[0, 1, :300], q[0, 2, :300], q[0, 3, :300] = 300.0, 300.0, 50.0, 40.0
+    q[0, 4:, :300] = 0.5 + 0.5 * P.uniform("nmsbig:dup", (80, 300), 0, 1)
+    q[0, 4:, 300:] = 0.002 + 0.4 * P.uniform("nmsbig:low", (80, 900), 0, 1) ** 6
+    kw = dict(conf_thres=0.001, iou_thres=0.7, multi_label=True, max_det=300, max_nms=30000)
+    ref = onms.non_max_suppression(q.clone(), **kw)
+    out = non_max_suppression(q.to(DEV), **kw)
+    assert ref[0].shape[0] > 80  # the distinct boxes behind the duplicates are needed: the first pass alone would stop at 80
+    for a, b in zip(out, ref):
+        assert a.shape == b.shape and torch.equal(a.cpu(), b)
 
 
 def test_cpu_tensor_fails_loudly():

@@ -77,18 +77,32 @@ __global__ __launch_bounds__(256) void nms_candidates_kernel(const float* pred, 
       if (slot >= 0 && slot < cap) kb[slot] = ((u64)(~__float_as_uint(best)) << 32) | (unsigned)(a * nc + bc);
     }
   } else {
-    for (int c = 0; c < nc; ++c) {
-      const float v = valid ? pb[(size_t)c * A] : -INFINITY;
-      const bool cand = valid && v > conf && (!cmask || cmask[c]);
-      const u64 m = __ballot(cand);
-      if (m) {
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&count[b], __popcll(m));
-        base = __shfl(base, 0);
-        if (cand) {
-          const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
-          if (slot >= 0 && slot < cap) kb[slot] = ((u64)(~__float_as_uint(v)) << 32) | (unsigned)(a * nc + c);
+    // eight class rows in flight per lane, and ONE reservation in count[b] per wave and group of eight classes (the wave counts its
+    // candidates of the group first): a load and a same-address global atomic per class left this loop at two memory round trips per
+    // class (2.0 ms per validation batch)
+    for (int c0 = 0; c0 < nc; c0 += 8) {
+      float v[8];
+      u64 m[8];
+      int tot = 0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = (valid && c0 + q < nc) ? pb[(size_t)(c0 + q) * A] : -INFINITY;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const bool cand = valid && c0 + q < nc && v[q] > conf && (!cmask || cmask[c0 + q]);
+        m[q] = __ballot(cand);
+        tot += __popcll(m[q]);
+      }
+      if (tot == 0) continue;  // uniform
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&count[b], tot);
+      base = __shfl(base, 0);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if ((m[q] >> lane) & 1ull) {
+          const int slot = base + __popcll(m[q] & ((1ull << lane) - 1ull));
+          if (slot >= 0 && slot < cap) kb[slot] = ((u64)(~__float_as_uint(v[q])) << 32) | (unsigned)(a * nc + c0 + q);
         }
+        base += __popcll(m[q]);
       }
     }
   }
@@ -118,9 +132,17 @@ constexpr int LDS_SORT_CAP = 16384;  // u64 -> 128 KiB of dynamic LDS (covers ev
 // (single-label rule: best class of an anchor, nms.py:109) - this workgroup, which owns the image, first filters them by
 // conf_thres / class mask and compacts them into `keys` (slot counter in LDS, wave-aggregated: no global atomics - with a few
 // hundred candidates per image the atomics on count[b] were what the scan kernels spent their time on), then sorts as usual.
+// Two-stage form for long candidate lists (multi-label validation: up to A * nc candidates per image, max_nms = 30000): with `prefix`
+// > 0 the kernel selects and sorts only the top `prefix` (<= LDS_SORT_CAP, so the sort runs in LDS) and sets partial[b]; the greedy
+// pass stops at max_det kept boxes long before that list ends in all but pathological images, and flags redo[b] when it does not -
+// a second (sort, greedy) pair with prefix = 0 then runs the full top-max_nms path for the flagged images only (`only_redo`: every
+// other workgroup returns at once).  The result is the reference's in every case: greedy NMS over the score-ordered candidates cut
+// at max_nms, cut at max_det.
 __global__ __launch_bounds__(SORT_NT) void nms_sort_kernel(const int* count, int* nsorted, u64* keys, u64* sel, long cap,
                                                            int selcap, int max_nms, const u64* best_keys, int nc, int A,
-                                                           float conf, const uint8_t* cmask) {
+                                                           float conf, const uint8_t* cmask, int prefix, int* partial,
+                                                           const int* only_redo) {
+  if (only_redo && !only_redo[blockIdx.x]) return;
   extern __shared__ __attribute__((aligned(16))) u64 lbuf[];  // LDS_SORT_CAP keys
   __shared__ int hist[256];
   __shared__ u64 s_prefix;
@@ -161,17 +183,34 @@ __global__ __launch_bounds__(SORT_NT) void nms_sort_kernel(const int* count, int
     n = count[b];
   }
   if (n > cap) n = (int)cap;
-  if (n > max_nms) {
-    // exact threshold key K*: exactly max_nms keys are <= K* (keys are unique)
-    if (threadIdx.x == 0) { s_prefix = 0ull; s_remaining = max_nms; s_n = 0; }
+  const int target = (prefix > 0 && prefix < max_nms) ? prefix : max_nms;  // how many of the best candidates this call keeps
+  if (partial && threadIdx.x == 0) partial[b] = (prefix > 0 && n > target && target < max_nms) ? 1 : 0;
+  if (n > target) {
+    // exact threshold key K*: exactly `target` keys are <= K* (keys are unique)
+    if (threadIdx.x == 0) { s_prefix = 0ull; s_remaining = target; s_n = 0; }
+    // Every pass reads all n keys (up to A * nc = 672 k per image in multi-label validation) through ONE workgroup: the loads are issued
+    // eight deep per thread (one load per iteration behind an LDS atomic left the loop at a memory round trip per key: 7 of the 8.4 ms
+    // this kernel took per validation batch), and the digit loop stops as soon as the chosen bin is taken whole (the low digits only
+    // order keys of equal score: usually three or four passes instead of eight).
+    constexpr int U = 8;
+    u64 done_mask = 0ull;  // low bits of K* once the loop stops early (uniform)
     for (int shift = 56; shift >= 0; shift -= 8) {
       for (int i = threadIdx.x; i < 256; i += SORT_NT) hist[i] = 0;
       __syncthreads();
       const u64 prefix = s_prefix;
       const u64 himask = shift == 56 ? 0ull : (~0ull << (shift + 8));
-      for (int i = threadIdx.x; i < n; i += SORT_NT) {
-        const u64 k = kb[i];
-        if ((k & himask) == (prefix & himask)) atomicAdd(&hist[(int)((k >> shift) & 255ull)], 1);
+      for (int i0 = threadIdx.x; i0 < n; i0 += U * SORT_NT) {
+        u64 k[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int i = i0 + u * SORT_NT;
+          k[u] = i < n ? kb[i] : ~0ull;  // (the all-ones key can match no prefix of a real key's range: real keys have a clear low part < a * nc)
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int i = i0 + u * SORT_NT;
+          if (i < n && (k[u] & himask) == (prefix & himask)) atomicAdd(&hist[(int)((k[u] >> shift) & 255ull)], 1);
+        }
       }
       __syncthreads();
       if (threadIdx.x == 0) {
@@ -182,19 +221,44 @@ __global__ __launch_bounds__(SORT_NT) void nms_sort_kernel(const int* count, int
         }
         s_remaining = rem - cum;
         s_prefix = prefix | ((u64)d << shift);
+        s_n = (cum + hist[d] == rem) ? 1 : 0;  // the whole bin is needed: every key with this prefix is below K*
       }
       __syncthreads();
-    }
-    const u64 kstar = s_prefix;
-    for (int i = threadIdx.x; i < n; i += SORT_NT) {
-      const u64 k = kb[i];
-      if (k <= kstar) {
-        const int slot = atomicAdd(&s_n, 1);
-        if (slot < selcap) sb[slot] = k;
+      if (s_n) {  // uniform
+        done_mask = shift == 0 ? 0ull : ((1ull << shift) - 1ull);
+        break;
       }
     }
     __syncthreads();
-    n = s_n < max_nms ? s_n : max_nms;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const u64 kstar = s_prefix | done_mask;
+    const int lane_ = threadIdx.x & 63;
+    for (int i0 = threadIdx.x; i0 < n; i0 += U * SORT_NT) {
+      u64 k[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * SORT_NT;
+        k[u] = i < n ? kb[i] : ~0ull;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * SORT_NT;
+        const bool take = i < n && k[u] <= kstar;
+        const u64 m = __ballot(take);  // one LDS atomic per wave and iteration, not one per key
+        if (m) {
+          int base = 0;
+          if (lane_ == 0) base = atomicAdd(&s_n, __popcll(m));
+          base = __shfl(base, 0);
+          if (take) {
+            const int slot = base + __popcll(m & ((1ull << lane_) - 1ull));
+            if (slot < selcap) sb[slot] = k[u];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    n = s_n < target ? s_n : target;
     kb = sb;  // source is now the compacted list
     __syncthreads();
   }
@@ -232,7 +296,8 @@ constexpr int MAX_DET_CAP = 1024;
 __global__ __launch_bounds__(GREEDY_NT) void nms_greedy_kernel(const float* pred, int nc, int A, const int* nsorted,
                                                                const u64* sel, int selcap, float iou_thr, int agnostic,
                                                                float max_wh, int max_det, float* out, int* counts,
-                                                               int* keep_idx) {
+                                                               int* keep_idx, const int* partial, int* redo, const int* only_redo) {
+  if (only_redo && !only_redo[blockIdx.x]) return;
   __shared__ float kx1[MAX_DET_CAP], ky1[MAX_DET_CAP], kx2[MAX_DET_CAP], ky2[MAX_DET_CAP], kar[MAX_DET_CAP];
   __shared__ u64 alive_w[GREEDY_NW];
   __shared__ int s_kept;
@@ -331,7 +396,12 @@ __global__ __launch_bounds__(GREEDY_NT) void nms_greedy_kernel(const float* pred
     }
     __syncthreads();  // the stage buffers are rewritten by the next stage
   }
-  if (threadIdx.x == 0) counts[b] = s_kept;
+  if (threadIdx.x == 0) {
+    counts[b] = s_kept;
+    // the sorted list was only the top part of the candidates and ran out before max_det boxes were kept: this image goes through
+    // the full path (second pair of launches)
+    if (redo) redo[b] = (partial && partial[b] && s_kept < max_det) ? 1 : 0;
+  }
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -346,7 +416,7 @@ inline int pow2_ge(int v) {
 extern "C" size_t upa_nms_workspace_bytes(int b, int nc, int a, int multi_label, int max_nms) {
   const size_t cap = (size_t)a * (multi_label ? nc : 1);
   const size_t selcap = (size_t)pow2_ge(max_nms < 2 ? 2 : max_nms);
-  return 256 + align_up((size_t)b * 2 * sizeof(int), 256) + (size_t)b * cap * 8 + (size_t)b * selcap * 8;
+  return 256 + align_up((size_t)b * 4 * sizeof(int), 256) + (size_t)b * cap * 8 + (size_t)b * selcap * 8;  // count, nsorted, partial, redo
 }
 
 static int nms_batched_impl(const float* pred, int b, int nc, int a, float conf_thres, float iou_thres, int multi_label,
@@ -372,7 +442,9 @@ static int nms_batched_impl(const float* pred, int b, int nc, int a, float conf_
   ws = (char*)align_up((size_t)ws, 256);
   int* count = (int*)ws;
   int* nsorted = count + b;
-  ws += align_up((size_t)b * 2 * sizeof(int), 256);
+  int* partial = count + 2 * b;
+  int* redo = count + 3 * b;
+  ws += align_up((size_t)b * 4 * sizeof(int), 256);
   u64* keys = (u64*)ws;
   u64* sel = keys + (size_t)b * cap;
   hipStream_t s = (hipStream_t)stream;
@@ -387,12 +459,25 @@ static int nms_batched_impl(const float* pred, int b, int nc, int a, float conf_
     hipError_t e = upa_full_lds<nms_sort_kernel>();
     if (e != hipSuccess) { upa_set_error("nms: cannot raise LDS limit: %s", hipGetErrorString(e)); return UPA_ELAUNCH; }
   }
+  // long candidate lists (multi-label validation): first only the top LDS_SORT_CAP candidates, sorted in LDS - the full top-max_nms
+  // select + global-memory sort (8.4 ms per batch-32 call, two thirds of the validate step's GPU time) only for images whose greedy
+  // pass ran out of candidates before max_det boxes were kept
+  const bool two_stage = cap > LDS_SORT_CAP && max_nms > LDS_SORT_CAP;
   hipLaunchKernelGGL(nms_sort_kernel, dim3((unsigned)b), dim3(SORT_NT), LDS_SORT_CAP * 8, s, count, nsorted, keys, sel,
-                     cap, selcap, max_nms, best_keys, nc, a, conf_thres, classes_mask);
+                     cap, selcap, max_nms, best_keys, nc, a, conf_thres, classes_mask, two_stage ? LDS_SORT_CAP : 0, partial,
+                     (const int*)nullptr);
   UPA_LAUNCH_CHECK();
   hipLaunchKernelGGL(nms_greedy_kernel, dim3((unsigned)b), dim3(GREEDY_NT), 0, s, pred, nc, a, nsorted, sel, selcap,
-                     iou_thres, agnostic, max_wh, max_det, out, counts, keep_idx);
+                     iou_thres, agnostic, max_wh, max_det, out, counts, keep_idx, (const int*)partial, two_stage ? redo : (int*)nullptr,
+                     (const int*)nullptr);
   UPA_LAUNCH_CHECK();
+  if (two_stage) {
+    hipLaunchKernelGGL(nms_sort_kernel, dim3((unsigned)b), dim3(SORT_NT), LDS_SORT_CAP * 8, s, count, nsorted, keys, sel,
+                       cap, selcap, max_nms, best_keys, nc, a, conf_thres, classes_mask, 0, partial, (const int*)redo);
+    hipLaunchKernelGGL(nms_greedy_kernel, dim3((unsigned)b), dim3(GREEDY_NT), 0, s, pred, nc, a, nsorted, sel, selcap,
+                       iou_thres, agnostic, max_wh, max_det, out, counts, keep_idx, (const int*)nullptr, (int*)nullptr, (const int*)redo);
+    UPA_LAUNCH_CHECK();
+  }
   return UPA_OK;
 }
 
