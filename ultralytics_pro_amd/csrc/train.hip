@@ -415,6 +415,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 // 32 ds_read_tr per 32-pixel step.  The next tile's global loads are in flight (in registers) while the current tile is
 // multiplied.  Partial blocks go through the same two-stage reduction as the f32 kernel.
 typedef short v4s16 __attribute__((ext_vector_type(4)));
+#ifndef WG_EXP
+#define WG_EXP 0
+#endif
 
 // BCI = input channels per block: 64, or 16 for narrow inputs (the 3-channel stem, padded to one 16-byte group).
 template <int S, int BCI>
@@ -506,14 +509,20 @@ __global__ __launch_bounds__(192) void wgrad_bf16_k3_kernel(const WgradParams p)
     commit();
     __syncthreads();
     const int next = tile + gridDim.x;
+#if WG_EXP != 2
     if (next < p.numTiles) fetch(next);  // in flight during the MFMAs below
+#endif
     const int ksteps = npx >> 5;
     for (int ks = 0; ks < ksteps; ++ks) {
       // the two 4-pixel halves of this lane block's 8 pixels
       int zoff[2], xoff[2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
+#if WG_EXP >= 1
+        const int px = ks * 32 + h * 16 + kg * 4 + (r16 >> 2);
+#else
         const int px = ks * 32 + kg * 8 + h * 4 + (r16 >> 2);
+#endif
         const int ty = px >> 4, tx = px & 15;
         zoff[h] = px * PZ + (r16 & 3) * 8;
         xoff[h] = ((ty * S + kh) * IW + tx * S) * PX + (r16 & 3) * 8;
@@ -544,8 +553,12 @@ __global__ __launch_bounds__(192) void wgrad_bf16_k3_kernel(const WgradParams p)
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j)
+#if WG_EXP == 3
+            acc[kw][i][j][0] += __uint_as_float(a[i][0] ^ b[kw][j][0]);
+#else
             acc[kw][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&a[i]), *reinterpret_cast<bf16x8*>(&b[kw][j]),
                                                                     acc[kw][i][j], 0, 0, 0);
+#endif
     }
   }
   // flush this wave's three taps of the 64 x 64 block: D[row = co][col = ci], lane holds rows 4*kg..+3 of column r16
@@ -618,12 +631,18 @@ __global__ __launch_bounds__(256) void wgrad_bf16_k1_kernel(const WgradParams p)
     __syncthreads();
     commit();
     __syncthreads();
+#if WG_EXP != 2
     if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
+#endif
 #pragma unroll
     for (int ks = 0; ks < NPX / 32; ++ks) {
       int off[2];
 #pragma unroll
+#if WG_EXP >= 1
+      for (int h = 0; h < 2; ++h) off[h] = (ks * 32 + h * 16 + kg * 4 + (r16 >> 2)) * PZ + (r16 & 3) * 8;
+#else
       for (int h = 0; h < 2; ++h) off[h] = (ks * 32 + kg * 8 + h * 4 + (r16 >> 2)) * PZ + (r16 & 3) * 8;
+#endif
       u32x4 a[4], b[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -641,8 +660,12 @@ __global__ __launch_bounds__(256) void wgrad_bf16_k1_kernel(const WgradParams p)
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
+#if WG_EXP == 3
+          acc[i][j][0] += __uint_as_float(a[i][0] ^ b[j][0]);
+#else
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&a[i]), *reinterpret_cast<bf16x8*>(&b[j]),
                                                               acc[i][j], 0, 0, 0);
+#endif
     }
   }
   float* part = p.partial + (((size_t)blockIdx.y * gridDim.z + blockIdx.z) * gridDim.x + blockIdx.x) * (BCO * BCI);
@@ -656,50 +679,62 @@ __global__ __launch_bounds__(256) void wgrad_bf16_k1_kernel(const WgradParams p)
 }
 
 // dW[co][ci][t] (+)= sum over the workgroups of a block of their partial sums (fixed order: deterministic).
-// Block = 16 consecutive elements x 16 slices of the workgroup axis: a thread adds its slice with 8 independent loads in
-// flight (the one-thread-per-element form ran 512 dependent-latency loads per thread: 120 us for 75 MB), the slices
-// meet in LDS.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial, int wgs, int bco, int bci, int BCO, int BCI, int kk2,
-                                                           float* dw, int Cout, int Cin, int accumulate) {
-  __shared__ float red[16][17];
-  const long per_wg = (long)kk2 * BCO * BCI;
-  const long total = (long)bco * bci * per_wg;
-  const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  for (long base = (long)blockIdx.x * 16; base < total; base += (long)gridDim.x * 16) {
-    const long idx = base + e;  // BCI is a multiple of 16: the 16 elements share (block, tap, co row)
-    long t_ = idx;
-    const int cil = (int)(t_ % BCI); t_ /= BCI;
-    const int col = (int)(t_ % BCO); t_ /= BCO;
-    const int t = (int)(t_ % kk2); t_ /= kk2;
-    const int bz = (int)(t_ % bci);
-    const int by = (int)(t_ / bci);
-    const float* src = partial + (((size_t)by * bci + bz) * wgs) * per_wg + ((size_t)t * BCO + col) * BCI + cil;
-    const int per = (wgs + 15) / 16;
-    const int w0 = sl * per, w1 = (w0 + per < wgs) ? w0 + per : wgs;
-    float s = 0.f;
+// Workgroup = one (block, co row): its kk2 * BCI partial values (kk2 segments of BCI floats per slice) as EG float4 groups x
+// SG groups of slices; a thread adds its slices with 8 independent 16-byte loads in flight, the slice groups meet in LDS
+// and the row leaves as one contiguous run of dW (the [t][ci] -> [ci][t] turn happens in LDS, not as 4-byte scatter).
+// (The first form - 16 elements x 16 slice groups per 256 threads, two barriers per 16 elements - took 40 us for the
+// 256 -> 256 3x3 layers and 27 us for a 5-slice pointwise layer: more than the products it summed.)
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* partial, int wgs, int bci, int BCO, int BCI, int kk2, int EG,
+                                                            int SG, float* dw, int Cout, int Cin, int accumulate) {
+  __shared__ float red[4096];
+  const int R = kk2 * BCI;
+  const int col = blockIdx.x % BCO;
+  const int blk = blockIdx.x / BCO;   // by * bci + bz
+  const int by = blk / bci, bz = blk - by * bci;
+  const size_t per_wg = (size_t)kk2 * BCO * BCI;
+  const int tid = threadIdx.x;
+  const int eg = tid % EG, sg = tid / EG;
+  if (sg < SG) {
+    const int e0 = eg * 4;                 // element of the row: [t][cil]
+    const int t = e0 / BCI, cil = e0 - t * BCI;
+    const float* src = partial + (size_t)blk * wgs * per_wg + ((size_t)t * BCO + col) * BCI + cil;
+    const int per = (wgs + SG - 1) / SG;
+    const int w0 = sg * per, w1 = (w0 + per < wgs) ? w0 + per : wgs;
+    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
     int w = w0;
     for (; w + 8 <= w1; w += 8) {
-      float v[8];
+      f32x4 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(w + u) * per_wg];
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (size_t)(w + u) * per_wg);
 #pragma unroll
       for (int u = 0; u < 8; ++u) s += v[u];
     }
-    for (; w < w1; ++w) s += src[(size_t)w * per_wg];
-    red[sl][e] = s;
-    __syncthreads();
-    if (sl == 0) {
-      float tot = 0.f;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) tot += red[q][e];
-      const int co = by * BCO + col, ci = bz * BCI + cil;
-      if (co < Cout && ci < Cin) {
-        float* d = dw + ((size_t)co * Cin + ci) * kk2 + t;
-        *d = accumulate ? *d + tot : tot;
-      }
-    }
-    __syncthreads();
+    for (; w < w1; ++w) s += *reinterpret_cast<const f32x4*>(src + (size_t)w * per_wg);
+    *reinterpret_cast<f32x4*>(&red[sg * R + e0]) = s;
   }
+  __syncthreads();
+  const int co = by * BCO + col;
+  if (co >= Cout) return;
+  for (int j = tid; j < R; j += blockDim.x) {
+    const int cil = j / kk2, t = j - cil * kk2;
+    const int ci = bz * BCI + cil;
+    if (ci >= Cin) continue;
+    float tot = 0.f;
+    for (int q = 0; q < SG; ++q) tot += red[q * R + t * BCI + cil];
+    float* d = dw + ((size_t)co * Cin + ci) * kk2 + t;
+    *d = accumulate ? *d + tot : tot;
+  }
+}
+
+static void launch_wgrad_reduce(const float* partial, int wgs, int bco, int bci, int BCO, int BCI, int kk2, float* dw, int Cout, int Cin,
+                                int accumulate, hipStream_t s) {
+  const int EG = kk2 * BCI / 4;
+  int SG = 1024 / EG;
+  if (SG > wgs) SG = wgs;
+  if (SG > 16) SG = 16;
+  int thr = (EG * SG + 63) / 64 * 64;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(bco * bci * BCO)), dim3(thr), 0, s, partial, wgs, bci, BCO, BCI, kk2, EG, SG, dw,
+                     Cout, Cin, accumulate);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1154,9 +1189,7 @@ static int launch_wgrad(WgradParams& p, int accumulate, void* ws, size_t ws_byte
     else { upa_set_error("wgrad: 128x128 blocks are built for k = 1 only"); return UPA_EUNSUPPORTED; }
   } else { upa_set_error("wgrad: kernel size %d not built (1 and 3 are)", p.KS); return UPA_EUNSUPPORTED; }
 #undef UPA_WG_LAUNCH
-  const long total = (long)bco * bci * p.KS * p.KS * BCO * BCI;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(total, 16, 8192)), dim3(256), 0, s, p.partial, wgs, bco, bci, BCO, BCI, p.KS * p.KS,
-                     p.dw, p.Cout, p.Cin, accumulate);
+  launch_wgrad_reduce(p.partial, wgs, bco, bci, BCO, BCI, p.KS * p.KS, p.dw, p.Cout, p.Cin, accumulate, s);
   UPA_LAUNCH_CHECK();
   return UPA_OK;
 }
@@ -1180,9 +1213,7 @@ static int launch_wgrad_bf16_k1(WgradParams& p, int accumulate, void* ws, size_t
   auto kern = wgrad_bf16_k1_kernel;
   (void)upa_full_lds<wgrad_bf16_k1_kernel>();
   hipLaunchKernelGGL(kern, dim3((unsigned)wgs, bco, bci), dim3(256), lds, s, p);
-  const long total = (long)bco * bci * BCO * BCI;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(total, 16, 8192)), dim3(256), 0, s, p.partial, (int)wgs, bco, bci, BCO, BCI, 1, p.dw,
-                     p.Cout, p.Cin, accumulate);
+  launch_wgrad_reduce(p.partial, (int)wgs, bco, bci, BCO, BCI, 1, p.dw, p.Cout, p.Cin, accumulate, s);
   UPA_LAUNCH_CHECK();
   return UPA_OK;
 }
@@ -1224,9 +1255,7 @@ static int launch_wgrad_bf16_k3_t(WgradParams& p, int accumulate, void* ws, size
     (void)upa_full_lds<wgrad_bf16_k3_kernel<2, BCI>>();
     hipLaunchKernelGGL(kern, grid, dim3(192), lds, s, p);
   }
-  const long total = (long)bco * bci * 9 * BCO * BCI;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(total, 16, 8192)), dim3(256), 0, s, p.partial, wgs, bco, bci, BCO, BCI, 9, p.dw,
-                     p.Cout, p.Cin, accumulate);
+  launch_wgrad_reduce(p.partial, wgs, bco, bci, BCO, BCI, 9, p.dw, p.Cout, p.Cin, accumulate, s);
   UPA_LAUNCH_CHECK();
   return UPA_OK;
 }
