@@ -415,9 +415,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 // 32 ds_read_tr per 32-pixel step.  The next tile's global loads are in flight (in registers) while the current tile is
 // multiplied.  Partial blocks go through the same two-stage reduction as the f32 kernel.
 typedef short v4s16 __attribute__((ext_vector_type(4)));
-#ifndef WG_EXP
-#define WG_EXP 0
-#endif
 
 // BCI = input channels per block: 64, or 16 for narrow inputs (the 3-channel stem, padded to one 16-byte group).
 template <int S, int BCI>
@@ -509,20 +506,14 @@ __global__ __launch_bounds__(192) void wgrad_bf16_k3_kernel(const WgradParams p)
     commit();
     __syncthreads();
     const int next = tile + gridDim.x;
-#if WG_EXP != 2
     if (next < p.numTiles) fetch(next);  // in flight during the MFMAs below
-#endif
     const int ksteps = npx >> 5;
     for (int ks = 0; ks < ksteps; ++ks) {
       // the two 4-pixel halves of this lane block's 8 pixels
       int zoff[2], xoff[2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-#if WG_EXP >= 1
-        const int px = ks * 32 + h * 16 + kg * 4 + (r16 >> 2);
-#else
         const int px = ks * 32 + kg * 8 + h * 4 + (r16 >> 2);
-#endif
         const int ty = px >> 4, tx = px & 15;
         zoff[h] = px * PZ + (r16 & 3) * 8;
         xoff[h] = ((ty * S + kh) * IW + tx * S) * PX + (r16 & 3) * 8;
@@ -553,12 +544,8 @@ __global__ __launch_bounds__(192) void wgrad_bf16_k3_kernel(const WgradParams p)
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j)
-#if WG_EXP == 3
-            acc[kw][i][j][0] += __uint_as_float(a[i][0] ^ b[kw][j][0]);
-#else
             acc[kw][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&a[i]), *reinterpret_cast<bf16x8*>(&b[kw][j]),
                                                                     acc[kw][i][j], 0, 0, 0);
-#endif
     }
   }
   // flush this wave's three taps of the 64 x 64 block: D[row = co][col = ci], lane holds rows 4*kg..+3 of column r16
@@ -631,18 +618,12 @@ __global__ __launch_bounds__(256) void wgrad_bf16_k1_kernel(const WgradParams p)
     __syncthreads();
     commit();
     __syncthreads();
-#if WG_EXP != 2
     if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
-#endif
 #pragma unroll
     for (int ks = 0; ks < NPX / 32; ++ks) {
       int off[2];
 #pragma unroll
-#if WG_EXP >= 1
-      for (int h = 0; h < 2; ++h) off[h] = (ks * 32 + h * 16 + kg * 4 + (r16 >> 2)) * PZ + (r16 & 3) * 8;
-#else
       for (int h = 0; h < 2; ++h) off[h] = (ks * 32 + kg * 8 + h * 4 + (r16 >> 2)) * PZ + (r16 & 3) * 8;
-#endif
       u32x4 a[4], b[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -660,14 +641,132 @@ __global__ __launch_bounds__(256) void wgrad_bf16_k1_kernel(const WgradParams p)
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-#if WG_EXP == 3
-          acc[i][j][0] += __uint_as_float(a[i][0] ^ b[j][0]);
-#else
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&a[i]), *reinterpret_cast<bf16x8*>(&b[j]),
                                                               acc[i][j], 0, 0, 0);
-#endif
     }
   }
+  float* part = p.partial + (((size_t)blockIdx.y * gridDim.z + blockIdx.z) * gridDim.x + blockIdx.x) * (BCO * BCI);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        part[(size_t)((wm * 4 + i) * 16 + kg * 4 + r) * BCI + (wn * 4 + j) * 16 + r16] = acc[i][j][r];
+}
+
+// ---- ring forms of the two bf16 kernels: the operands go global -> LDS by DMA (global_load_lds, 16 bytes per lane) into a
+// ring of stages, RING - 1 of them in flight per workgroup, instead of through one register-staged tile.  The weight
+// gradient is a streaming product (its MFMA floor is below its HBM floor on every yolov8s layer) and the register form
+// kept ONE tile (41 - 64 KB) per workgroup in flight: 1.7 TB/s on the 160x160 layers, a tile every ~3 us for 0.4 us of
+// MFMA (tools/experiments/r04_p2.sh: without the refetch the calls ran 20 - 45 % shorter, without the MFMAs 10 %).
+// A DMA image is lane-linear (1 KB per wave instruction), so rows cannot be padded; the 32-byte units (16 channels) of a
+// pixel row are XORed with pixel bits instead, which keeps the 8 pixels x 32 bytes of each 32-lane ds_read_b64_tr_b16
+// group on 64 different banks.  Pixels / channels outside the tensors are fetched from a zero page.
+typedef __attribute__((address_space(1))) const void* wg_gptr_t;
+typedef __attribute__((address_space(3))) void* wg_lptr_t;
+__device__ __attribute__((aligned(16))) unsigned g_wg_zero16[4] = {0u, 0u, 0u, 0u};
+
+// The DMA is issued from inline asm: through the builtin the compiler knows that it writes LDS and puts s_waitcnt vmcnt(0)
+// in front of the next LDS read - with stages in flight behind the one being read that wait is the whole pipeline.  Issued
+// this way the loads are invisible to its counters; the counted waits below and the barrier order them against the reads.
+__device__ __forceinline__ void wg_dma16(const char* src, const char* lds_dst) {
+  const unsigned m = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) const char*)lds_dst);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m) : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wg_wait_vm() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+constexpr int R1_NPX = 64;                   // pixels per stage
+constexpr int R1_IMG = R1_NPX * 256;         // one operand image: [px][128 channels], 16 KB
+constexpr int R1_STAGE = 2 * R1_IMG;         // dz image, x image
+constexpr int R1_RING = 4;                   // 128 KB of LDS, 96 KB in flight
+constexpr int R1_SLOTS = R1_STAGE / 1024 / 4;  // DMA instructions per wave and stage (8)
+
+// Pointwise (1x1, stride 1): 128 x 128 (co, ci) block, 4 waves = 4 quadrants of 4 x 4 MFMA tiles, 64-pixel stages.
+__global__ __launch_bounds__(256) void wgrad_k1_ring_kernel(const WgradParams p) {
+  extern __shared__ __attribute__((aligned(1024))) char wsm_r1[];
+  constexpr int BCO = 128, BCI = 128;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int kg = lane >> 4, r16 = lane & 15;
+  const int co0 = blockIdx.y * BCO, ci0 = blockIdx.z * BCI;
+  const long P = (long)p.N * p.H * p.W;
+  const long ntiles = (P + R1_NPX - 1) / R1_NPX;
+  const int G = gridDim.x;
+  const int nT = blockIdx.x < ntiles ? (int)((ntiles - 1 - blockIdx.x) / G) + 1 : 0;
+  // DMA slot q of this wave = chunks ((q * 4 + wave) * 64 + lane) of the stage: operand q >> 2, pixel (q & 3) * 16 + wave * 4 + kg,
+  // physical 16-byte chunk lane & 15 holding logical chunk (unit ^ (pixel & 7)) * 2 + half
+  const int pxb = wave * 4 + kg;
+  const int cl = ((((lane & 15) >> 1) ^ (pxb & 7)) << 1) | (lane & 1);
+  const bool zok = co0 + cl * 8 < p.Cout, xok = ci0 + cl * 8 < p.Cin;
+  const char* const zero = reinterpret_cast<const char*>(g_wg_zero16);
+  const char* const zsrc = p.dz + ((size_t)pxb * p.lddz + co0 + cl * 8) * 2;
+  const char* const xsrc = p.x + ((size_t)pxb * p.ldx + ci0 + cl * 8) * 2;
+  auto stage = [&](int i) __attribute__((always_inline)) {   // tile i of this workgroup -> ring slot i % RING (past the end: zeros)
+    const long p0 = ((long)blockIdx.x + (long)i * G) * R1_NPX;
+    char* const dst = wsm_r1 + (size_t)(i % R1_RING) * R1_STAGE + wave * 1024;
+#pragma unroll
+    for (int q = 0; q < R1_SLOTS; ++q) {
+      const long pp = p0 + (q & 3) * 16 + pxb;
+      const char* src = zero;
+      if (i < nT && pp < P) {
+        if (q < 4) { if (zok) src = zsrc + (size_t)(p0 + (q & 3) * 16) * p.lddz * 2; }
+        else       { if (xok) src = xsrc + (size_t)(p0 + (q & 3) * 16) * p.ldx * 2; }
+      }
+      wg_dma16(src, dst + q * 4096);
+    }
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // fragment addresses inside an operand image: the lane's pixel of a 32-pixel step is h * 16 + kg * 4 + (r16 >> 2) (the K order
+  // is free as long as both operands use it; this one puts 8 consecutive pixels in each 32-lane group)
+  const int sw = (kg & 1) * 4 + (r16 >> 2);
+  int offa[4], offb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    offa[i] = (kg * 4 + (r16 >> 2)) * 256 + (((wm * 4 + i) ^ sw) << 5) + (r16 & 3) * 8;
+    offb[i] = (kg * 4 + (r16 >> 2)) * 256 + (((wn * 4 + i) ^ sw) << 5) + (r16 & 3) * 8 + R1_IMG;
+  }
+#pragma unroll
+  for (int i = 0; i < R1_RING - 1; ++i) stage(i);
+  for (int i = 0; i < nT; ++i) {
+    wg_wait_vm<R1_SLOTS * (R1_RING - 2)>();   // this thread's share of stage i has landed ...
+    __builtin_amdgcn_s_barrier();             // ... and everyone's; everyone is also done reading stage i - 1
+    stage(i + R1_RING - 1);                   // into the slot stage i - 1 used
+    const char* const img = wsm_r1 + (size_t)(i % R1_RING) * R1_STAGE;
+#pragma unroll
+    for (int ks = 0; ks < R1_NPX / 32; ++ks) {
+      u32x4 a[4], b[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(img + offa[t] + ks * 32 * 256));
+        const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(img + offa[t] + (ks * 32 + 16) * 256));
+        a[t] = u32x4{((const unsigned*)&lo)[0], ((const unsigned*)&lo)[1], ((const unsigned*)&hi)[0], ((const unsigned*)&hi)[1]};
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(img + offb[t] + ks * 32 * 256));
+        const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(img + offb[t] + (ks * 32 + 16) * 256));
+        b[t] = u32x4{((const unsigned*)&lo)[0], ((const unsigned*)&lo)[1], ((const unsigned*)&hi)[0], ((const unsigned*)&hi)[1]};
+      }
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&a[ii]), *reinterpret_cast<bf16x8*>(&b[j]),
+                                                               acc[ii][j], 0, 0, 0);
+    }
+  }
+  wg_wait_vm<0>();  // the zero stages issued past the last tile
   float* part = p.partial + (((size_t)blockIdx.y * gridDim.z + blockIdx.z) * gridDim.x + blockIdx.x) * (BCO * BCI);
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -1194,6 +1293,10 @@ static int launch_wgrad(WgradParams& p, int accumulate, void* ws, size_t ws_byte
   return UPA_OK;
 }
 
+// UPA_WGRAD_RING=0: the register-staged kernels (the A/B switch of the ring forms; read once)
+static const bool g_wgrad_ring = [] { const char* e = getenv("UPA_WGRAD_RING"); return !(e && e[0] == '0'); }();
+static const int g_wgrad_k1_wgs = [] { const char* e = getenv("UPA_WGRAD_K1_WGS"); return e ? atoi(e) : 0; }();
+
 static bool wgrad_small(int cin, int cout) { return cin <= 32 || cout <= 32; }
 
 static int launch_wgrad_bf16_k1(WgradParams& p, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
@@ -1203,16 +1306,22 @@ static int launch_wgrad_bf16_k1(WgradParams& p, int accumulate, void* ws, size_t
   const int bco = cdiv(p.Cout, BCO), bci = cdiv(p.Cin, BCI);
   // 128 workgroups: 15.68 ms per yolov8s step against 15.88 at 256 (overlapped on the side stream; alone 256 is faster)
   constexpr int k1_budget = 128;
-  long wgs = (k1_budget > 0 && k1_budget <= 256 ? k1_budget : 128) / (bco * bci);
+  long wgs = (g_wgrad_k1_wgs > 0 ? g_wgrad_k1_wgs : (k1_budget > 0 && k1_budget <= 256 ? k1_budget : 128)) / (bco * bci);
   if (wgs < 1) wgs = 1;
   if (wgs > ntiles) wgs = ntiles;
   const size_t need = wgrad_partial_bytes(bco, bci, (int)wgs, BCO, BCI, 1);
   UPA_CHECK_ARG(ws && ws_bytes >= need, "wgrad: workspace too small (%zu < %zu bytes)", ws_bytes, need);
   p.partial = (float*)ws;
-  const size_t lds = (size_t)128 * (BCO * 2 + 32) + (size_t)128 * (BCI * 2 + 32);
-  auto kern = wgrad_bf16_k1_kernel;
-  (void)upa_full_lds<wgrad_bf16_k1_kernel>();
-  hipLaunchKernelGGL(kern, dim3((unsigned)wgs, bco, bci), dim3(256), lds, s, p);
+  if (g_wgrad_ring) {
+    auto kern = wgrad_k1_ring_kernel;
+    (void)upa_full_lds<wgrad_k1_ring_kernel>();
+    hipLaunchKernelGGL(kern, dim3((unsigned)wgs, bco, bci), dim3(256), (size_t)R1_RING * R1_STAGE, s, p);
+  } else {
+    const size_t lds = (size_t)128 * (BCO * 2 + 32) + (size_t)128 * (BCI * 2 + 32);
+    auto kern = wgrad_bf16_k1_kernel;
+    (void)upa_full_lds<wgrad_bf16_k1_kernel>();
+    hipLaunchKernelGGL(kern, dim3((unsigned)wgs, bco, bci), dim3(256), lds, s, p);
+  }
   launch_wgrad_reduce(p.partial, (int)wgs, bco, bci, BCO, BCI, 1, p.dw, p.Cout, p.Cin, accumulate, s);
   UPA_LAUNCH_CHECK();
   return UPA_OK;
