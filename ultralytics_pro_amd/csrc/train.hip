@@ -663,6 +663,14 @@ __global__ __launch_bounds__(256) void wgrad_bf16_k1_kernel(const WgradParams p)
 // A DMA image is lane-linear (1 KB per wave instruction), so rows cannot be padded; the 32-byte units (16 channels) of a
 // pixel row are XORed with pixel bits instead, which keeps the 8 pixels x 32 bytes of each 32-lane ds_read_b64_tr_b16
 // group on 64 different banks.  Pixels / channels outside the tensors are fetched from a zero page.
+UPA_STAMP_DEFINE(train)
+#ifdef UPA_STAMP
+#define WG_T(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
+#define WG_ACC(a, t0_, t1_) do { WG_T(t1_); a += t1_ - t0_; t0_ = t1_; } while (0)
+#else
+#define WG_T(v) do {} while (0)
+#define WG_ACC(a, t0_, t1_) do {} while (0)
+#endif
 typedef __attribute__((address_space(1))) const void* wg_gptr_t;
 typedef __attribute__((address_space(3))) void* wg_lptr_t;
 __device__ __attribute__((aligned(16))) unsigned g_wg_zero16[4] = {0u, 0u, 0u, 0u};
@@ -775,6 +783,174 @@ __global__ __launch_bounds__(256) void wgrad_k1_ring_kernel(const WgradParams p)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         part[(size_t)((wm * 4 + i) * 16 + kg * 4 + r) * BCI + (wn * 4 + j) * 16 + r16] = acc[i][j][r];
+}
+
+// 3x3 (stride S): 64 x 64 (co, ci) block, 12 waves = 3 kernel rows x 4 ci tiles (each: 3 taps x 4 co tiles = 12 MFMAs per
+// 14 ds_read_tr per 32-pixel step; three waves per SIMD cover each other's LDS latency and DMA address arithmetic - at
+// one wave per SIMD issuing a stage's DMA took a third to two thirds of the tile, tools/experiments/r04_t2.py).
+// Stage = one TH x 16 output tile: the dz image [TH*16 px][64 co] then the x halo image [IH*IW px][64 ci], 128-byte rows
+// whose four 32-byte units are XORed with (position >> 1) & 3.  At stride 2 the halo columns are stored de-interleaved
+// (even columns, then odd) so that the 8 pixels of a 32-lane read group are consecutive positions again.
+constexpr int R3_NW = 12;
+template <int S> struct R3Geo {
+  static constexpr int TH = S == 1 ? 8 : 4, TW = 16;
+  static constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
+  static constexpr int NPX = TH * TW, NHX = IH * IW;
+  static constexpr int NZC = NPX * 8, NCH = NZC + NHX * 8;      // 16-byte chunks: dz, then x
+  static constexpr int NSLOT = (NCH + 63) / 64;                  // DMA instructions per stage, dealt round-robin over the waves
+  static constexpr int SPW = (NSLOT + R3_NW - 1) / R3_NW;        // ... per wave: SPW for waves < NFULL, SPW - 1 for the rest
+  static constexpr int NFULL = NSLOT - (SPW - 1) * R3_NW;
+  static constexpr int STAGE = NSLOT * 1024;
+  static constexpr int RING = (160 * 1024) / STAGE < 4 ? (160 * 1024) / STAGE : 4;
+  static constexpr int NEV = (IW + 1) / 2;                       // even halo columns (stride 2)
+  static_assert(RING >= 3, "ring of at least 3 stages");
+  static_assert(NZC % 64 == 0, "a DMA instruction is all dz or all x");
+};
+
+template <int S>
+__global__ __launch_bounds__(R3_NW * 64) void wgrad_k3_ring_kernel(const WgradParams p) {
+  extern __shared__ __attribute__((aligned(1024))) char wsm_r3[];
+  using G = R3Geo<S>;
+  constexpr int BCO = 64, BCI = 64;
+  constexpr int KS = G::NPX / 32;       // 32-pixel steps per tile
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kh = wave % 3, cq = wave / 3;
+  const int kg = lane >> 4, r16 = lane & 15;
+  const int co0 = blockIdx.y * BCO, ci0 = blockIdx.z * BCI;
+  const int tilesPerImg = p.tilesX * p.tilesY;
+  const int Gx = gridDim.x;
+  const int nT = (int)blockIdx.x < p.numTiles ? (p.numTiles - 1 - (int)blockIdx.x) / Gx + 1 : 0;
+  // DMA slot q of this wave = chunks ((q * 12 + wave) * 64 + lane), a whole slot is dz or x: decoded once into the byte offset
+  // from the tile's dz / x origin pixel (channel block included) and the row / column inside the tile / halo (a lane with
+  // nothing to fetch gets a row no tile reaches)
+  int rel[G::SPW], rr[G::SPW], cc[G::SPW];
+#pragma unroll
+  for (int q = 0; q < G::SPW; ++q) {
+    const int c = (q * R3_NW + wave) * 64 + lane;
+    const int cp = c & 7;
+    rel[q] = 0; rr[q] = 0x40000000; cc[q] = 0;
+    if (c < G::NZC) {
+      const int px = c >> 3;
+      const int cl = (((cp >> 1) ^ ((px >> 1) & 3)) << 1) | (cp & 1);
+      const int ty = px >> 4, tx = px & 15;
+      rel[q] = ((ty * p.OW + tx) * p.lddz + co0 + cl * 8) * 2;
+      cc[q] = tx;
+      if (co0 + cl * 8 < p.Cout) rr[q] = ty;
+    } else if (c < G::NCH) {
+      const int hp = (c - G::NZC) >> 3;
+      const int cl = (((cp >> 1) ^ ((hp >> 1) & 3)) << 1) | (cp & 1);
+      const int py = hp / G::IW, pc = hp - py * G::IW;
+      const int col = S == 1 ? pc : (pc < G::NEV ? 2 * pc : 2 * (pc - G::NEV) + 1);
+      rel[q] = ((py * p.W + col) * p.ldx + ci0 + cl * 8) * 2;
+      cc[q] = col;
+      if (ci0 + cl * 8 < p.Cin) rr[q] = py;
+    }
+  }
+  const char* const zero = reinterpret_cast<const char*>(g_wg_zero16);
+  auto stage = [&](int i) __attribute__((always_inline)) {   // tile i of this workgroup -> ring slot i % RING (past the end: zeros)
+    const int tile = (int)blockIdx.x + i * Gx;
+    const int n = tile / tilesPerImg;
+    const int t2 = tile - n * tilesPerImg;
+    const int tyi = t2 / p.tilesX, txi = t2 - tyi * p.tilesX;
+    const int oy0 = tyi * G::TH, ox0 = txi * G::TW;
+    const int iy0 = oy0 * S - p.pad, ix0 = ox0 * S - p.pad;
+    const char* const zb = p.dz + ((size_t)(n * p.OH + oy0) * p.OW + ox0) * p.lddz * 2;
+    const char* const xb = p.x + ((long)(n * p.H + iy0) * p.W + ix0) * p.ldx * 2;  // may point before the tensor: masked
+    const int zrl = i < nT ? p.OH : 0, xrl = i < nT ? p.H : 0;
+    char* const sdst = wsm_r3 + (size_t)(i % G::RING) * G::STAGE + wave * 1024;
+#pragma unroll
+    for (int q = 0; q < G::SPW; ++q) {
+      if (q == G::SPW - 1 && wave >= G::NFULL) break;   // wave-uniform
+      const bool isx = q * R3_NW + wave >= G::NZC / 64;  // wave-uniform
+      const int rb = isx ? iy0 : oy0, rl = isx ? xrl : zrl, cb = isx ? ix0 : ox0, cl = isx ? p.W : p.OW;
+      const char* const base = isx ? xb : zb;
+      const bool ok = (unsigned)(rr[q] + rb) < (unsigned)rl && (unsigned)(cc[q] + cb) < (unsigned)cl;
+      wg_dma16(ok ? base + rel[q] : zero, sdst + q * (R3_NW * 1024));
+    }
+  };
+  f32x4 acc[3][4];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // the lane's pixel of a 32-pixel step: row ks * 2 + h, column tx = kg * 4 + (r16 >> 2) (8 consecutive columns per 32-lane group)
+  const int tx = kg * 4 + (r16 >> 2);
+  const int sub = (r16 & 3) * 8;
+  int offa[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) offa[i] = tx * 128 + ((i ^ ((tx >> 1) & 3)) << 5) + sub;
+#pragma unroll
+  for (int i = 0; i < G::RING - 1; ++i) stage(i);
+#ifdef UPA_STAMP
+  unsigned long long tq0 = 0, tq1 = 0, tStart = 0, aW = 0, aB = 0, aS = 0, aC = 0;
+  WG_T(tStart); tq0 = tStart;
+#endif
+  for (int i = 0; i < nT; ++i) {
+    if (wave < G::NFULL) wg_wait_vm<G::SPW * (G::RING - 2)>();
+    else wg_wait_vm<(G::SPW - 1) * (G::RING - 2)>();
+    WG_ACC(aW, tq0, tq1);
+    __builtin_amdgcn_s_barrier();
+    WG_ACC(aB, tq0, tq1);
+    stage(i + G::RING - 1);   // into the ring slot stage i - 1 used
+    WG_ACC(aS, tq0, tq1);
+    const char* const zt = wsm_r3 + (size_t)(i % G::RING) * G::STAGE;
+    const char* const xt = zt + G::NZC * 16;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      u32x4 a[4], b[3];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(zt + offa[t] + (ks * 32) * 128));
+        const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(zt + offa[t] + (ks * 32 + 16) * 128));
+        a[t] = u32x4{((const unsigned*)&lo)[0], ((const unsigned*)&lo)[1], ((const unsigned*)&hi)[0], ((const unsigned*)&hi)[1]};
+      }
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        int hoff[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int row = ((ks * 2 + h) * S + kh) * G::IW;
+          const int hp = S == 1 ? row + tx + kw : row + ((kw & 1) ? G::NEV + tx : tx + (kw >> 1));
+          hoff[h] = hp * 128 + sub + ((cq ^ ((hp >> 1) & 3)) << 5);
+        }
+        const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(xt + hoff[0]));
+        const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(xt + hoff[1]));
+        b[kw] = u32x4{((const unsigned*)&lo)[0], ((const unsigned*)&lo)[1], ((const unsigned*)&hi)[0], ((const unsigned*)&hi)[1]};
+      }
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+          acc[kw][ii] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&a[ii]), *reinterpret_cast<bf16x8*>(&b[kw]),
+                                                                acc[kw][ii], 0, 0, 0);
+    }
+#ifdef UPA_STAMP
+    asm volatile("s_nop 0" ::"v"(acc[2][3]));   // the tile's last MFMA has issued
+    WG_ACC(aC, tq0, tq1);
+#endif
+  }
+  wg_wait_vm<0>();
+  float* part = p.partial + ((((size_t)blockIdx.y * gridDim.z + blockIdx.z) * gridDim.x + blockIdx.x) * 9) * (BCO * BCI);
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        part[((size_t)(kh * 3 + kw) * BCO + i * 16 + kg * 4 + r) * BCI + cq * 16 + r16] = acc[kw][i][r];
+#ifdef UPA_STAMP
+  if (wave == 0 && blockIdx.x < 4096 && blockIdx.y == 0 && blockIdx.z == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long tEnd; WG_T(tEnd);
+    if (lane == 0) {   // synthetic boundaries: prologue | DMA waits | barriers | DMA issue | reads + MFMA | flush
+      unsigned long long* o = g_upa_stamps + blockIdx.x * 16;
+      const unsigned long long pro = tq0 - tStart - aW - aB - aS - aC;
+      o[0] = tStart; o[1] = o[0] + pro; o[2] = o[1] + aW; o[3] = o[2] + aB; o[4] = o[3] + aS; o[5] = o[4] + aC; o[6] = tEnd;
+    }
+  }
+  UPA_STAMP_HWID();
+#endif
 }
 
 // dW[co][ci][t] (+)= sum over the workgroups of a block of their partial sums (fixed order: deterministic).
@@ -1355,7 +1531,17 @@ static int launch_wgrad_bf16_k3_t(WgradParams& p, int accumulate, void* ws, size
   const size_t lds = (size_t)p.TH * p.TW * PZ + (size_t)p.IH * p.IW * PX;
   UPA_CHECK_ARG(p.TH * p.TW * 8 + p.IH * p.IW * (BCI / 8) <= 16 * 192, "wgrad: staging registers too few for this tile");
   dim3 grid(wgs, bco, bci);
-  if (p.stride == 1) {
+  if (BCI == 64 && g_wgrad_ring) {
+    if (p.stride == 1) {
+      auto kern = wgrad_k3_ring_kernel<1>;
+      (void)upa_full_lds<wgrad_k3_ring_kernel<1>>();
+      hipLaunchKernelGGL(kern, grid, dim3(R3_NW * 64), (size_t)R3Geo<1>::RING * R3Geo<1>::STAGE, s, p);
+    } else {
+      auto kern = wgrad_k3_ring_kernel<2>;
+      (void)upa_full_lds<wgrad_k3_ring_kernel<2>>();
+      hipLaunchKernelGGL(kern, grid, dim3(R3_NW * 64), (size_t)R3Geo<2>::RING * R3Geo<2>::STAGE, s, p);
+    }
+  } else if (p.stride == 1) {
     auto kern = wgrad_bf16_k3_kernel<1, BCI>;
     (void)upa_full_lds<wgrad_bf16_k3_kernel<1, BCI>>();
     hipLaunchKernelGGL(kern, grid, dim3(192), lds, s, p);
