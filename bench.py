@@ -748,10 +748,12 @@ def wgrad_profile(tr, L, R, dev, dtype, reps=5):
         bf = dtype == torch.bfloat16
         # the dispatch of upa_conv2d_wgrad (csrc/train.hip): bf16 MFMA kernels where the channel counts allow
         if bf and cv.k == 3 and cv.cout >= 16 and (cv.cin % 8 == 0 or cv.cin < 8):
-            name, peak = "void (anonymous namespace)::wgrad_bf16_k3_kernel<%d, %d>((anonymous namespace)::WgradParams)" % (
-                cv.s, 16 if cv.cin <= 16 else 64), PEAK_BF16_TFLOPS
+            # LDS-DMA ring kernels; 9 - 16 input channels keep the register-staged narrow form
+            fam_ = "wgrad_bf16_k3_kernel" if 8 < cv.cin <= 16 else "wgrad_k3_ring_kernel"
+            name, peak = "void (anonymous namespace)::%s<%d, %d>((anonymous namespace)::WgradParams)" % (
+                fam_, cv.s, 16 if cv.cin <= 16 else 64), PEAK_BF16_TFLOPS
         elif bf and cv.k == 1 and cv.s == 1 and cv.p == 0 and cv.cin >= 32 and cv.cout >= 32 and cv.cin % 8 == 0:
-            name, peak = "(anonymous namespace)::wgrad_bf16_k1_kernel((anonymous namespace)::WgradParams)", PEAK_BF16_TFLOPS
+            name, peak = "(anonymous namespace)::wgrad_k1_ring_kernel((anonymous namespace)::WgradParams)", PEAK_BF16_TFLOPS
         else:
             small = cv.cin <= 32 or cv.cout <= 32
             mt = 4 if (cv.k == 1 and cv.cin >= 128 and cv.cout >= 128) else (1 if small else 2)
@@ -769,8 +771,9 @@ def wgrad_profile(tr, L, R, dev, dtype, reps=5):
             "frac": round(tf / d["peak"], 4), "traffic": None, "launches_per_step": d["launches"],
             "avg_launch_us": round(avg_s * 1e6, 1),
             "algorithmic_flops_per_launch": d["flops"] / d["launches"],
-            "note": "weight gradient: bf16 MFMA (v_mfma_f32_16x16x32_bf16, operands via ds_read_b64_tr_b16) where channel "
-                    "counts allow, exact-f32 MFMA otherwise; the time includes the partial-sum reduction kernel",
+            "note": "weight gradient: bf16 MFMA (v_mfma_f32_16x16x32_bf16, operands DMAed into an LDS ring and read with "
+                    "ds_read_b64_tr_b16) where channel counts allow, exact-f32 MFMA otherwise; the time includes the "
+                    "partial-sum reduction kernel",
             "wgrad_ms_per_step": round(sum(v["ms"] for v in fam.values()), 3),
             "families": {k: dict(launches=v["launches"], avg_us=round(v["ms"] / v["launches"] * 1e3, 1),
                                  tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)) for k, v in sorted(fam.items())}}

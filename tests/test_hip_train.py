@@ -90,6 +90,65 @@ def test_conv_bn_silu_forward_backward(case, dtype):
     assert _rel(to_cpu_nchw(dx), 2 * xr.grad) <= tol
 
 
+WGRAD_CASES = [
+    # cin, cout, k, s, N, H, W, ldx (channels of the tensor x is a slice of), accumulate
+    (96, 64, 1, 1, 2, 20, 20, 96, 0),      # pointwise ring: one 128 x 128 block, half of it outside the tensors
+    (768, 512, 1, 1, 3, 5, 7, 768, 1),     # 24 blocks, 105 pixels (less than two 64-pixel stages per workgroup), accumulate
+    (40, 200, 1, 1, 1, 9, 9, 64, 0),       # ragged channel counts, x a channel slice of a wider tensor
+    (128, 128, 1, 1, 2, 80, 80, 128, 0),   # more stages than the ring holds
+    (64, 64, 3, 1, 2, 20, 20, 64, 0),      # 3x3 ring: image edge inside every tile, 20 columns = one tile and a quarter
+    (72, 136, 3, 1, 3, 13, 17, 96, 1),     # ragged channels (2 x 3 blocks), odd map, slice view, accumulate
+    (128, 64, 3, 1, 2, 5, 5, 128, 0),      # map smaller than a tile
+    (64, 64, 3, 1, 4, 40, 48, 64, 0),      # interior tiles, several stages per workgroup
+    (32, 64, 3, 2, 2, 32, 32, 32, 0),      # stride 2: de-interleaved halo columns
+    (64, 128, 3, 2, 2, 15, 21, 64, 1),     # stride 2, odd sizes
+    (3, 32, 3, 2, 2, 40, 56, 8, 0),        # the stem: 3 channels stored as 8, narrow ring form
+    (16, 32, 3, 1, 2, 12, 20, 16, 0),      # 16 input channels: two 16-byte groups, register-staged narrow form
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES, ids=[f"c{c[0]}-{c[1]}k{c[2]}s{c[3]}_{c[5]}x{c[6]}" for c in WGRAD_CASES])
+def test_weight_gradient_bf16_matches_torch(case):
+    """upa_conv2d_wgrad (bf16 operands, f32 sums: LDS-DMA ring kernels + partial-sum reduce) against torch's conv2d_weight on
+    the same bf16-rounded operands in f32.  Products of bf16 values are exact in f32, only the summation order differs:
+    tolerance 2e-5 of the largest |dW|."""
+    from tests.hip_utils import DEV
+    from ultralytics_pro_amd import _lib as L
+    from ultralytics_pro_amd.engine import runtime as R
+    cin, cout, k, s, N, H, W, ldx, accumulate = case
+    pad = k // 2
+    OH, OW = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+    g = torch.Generator().manual_seed(cin * 1000 + cout + H)
+    xw = torch.zeros(N, H, W, ldx, dtype=torch.bfloat16)
+    xw[..., :cin] = torch.randn(N, H, W, cin, generator=g).to(torch.bfloat16)
+    if ldx > cin and cin >= 8:
+        xw[..., cin:] = 7.0  # neighbours of the slice must not leak into dW
+    dzc = torch.randn(N, OH, OW, cout, generator=g).to(torch.bfloat16)
+    x = xw.to(DEV)[..., :cin].permute(0, 3, 1, 2)
+    dz = dzc.to(DEV).permute(0, 3, 1, 2)
+    dw0 = torch.randn(cout, cin, k, k, generator=g)
+    dw = dw0.clone().to(DEV) if accumulate else torch.full((cout, cin, k, k), float("nan"), device=DEV)
+    vx, vz = R.view_of(x), R.view_of(dz)
+    assert vx.ld == ldx
+    lib = L.lib()
+    ws = torch.empty(lib.upa_conv2d_wgrad_workspace_bytes(cin, cout, k), dtype=torch.uint8, device=DEV)
+    L.check(lib.upa_conv2d_wgrad(vx.ptr, N, H, W, cin, vx.ld, vz.ptr, cout, vz.ld, dw.data_ptr(), k, s, pad, accumulate, vx.dtype,
+                                 ws.data_ptr(), ws.numel(), L.current_stream(DEV)), "wgrad")
+    torch.cuda.synchronize()
+    ref = torch.nn.grad.conv2d_weight(xw[..., :cin].permute(0, 3, 1, 2).float(), (cout, cin, k, k), dzc.permute(0, 3, 1, 2).float(),
+                                      stride=s, padding=pad)
+    if accumulate:
+        ref = ref + dw0
+    got = dw.cpu()
+    assert torch.isfinite(got).all()
+    assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    # the same call again gives the same bits (fixed summation order)
+    dw2 = dw0.clone().to(DEV) if accumulate else torch.zeros_like(dw)
+    L.check(lib.upa_conv2d_wgrad(vx.ptr, N, H, W, cin, vx.ld, vz.ptr, cout, vz.ld, dw2.data_ptr(), k, s, pad, accumulate, vx.dtype,
+                                 ws.data_ptr(), ws.numel(), L.current_stream(DEV)), "wgrad")
+    assert torch.equal(dw2.cpu(), got)
+
+
 def test_head_conv_with_bias_and_stem_input():
     """Plain nn.Conv2d(+bias) head outputs (head.py:98-100) and the 3-channel stem (padded NHWC input, no dx)."""
     from tests.hip_utils import DEV, to_cpu_nchw, to_dev_nhwc

@@ -791,43 +791,47 @@ __global__ __launch_bounds__(256) void wgrad_k1_ring_kernel(const WgradParams p)
 // Stage = one TH x 16 output tile: the dz image [TH*16 px][64 co] then the x halo image [IH*IW px][64 ci], 128-byte rows
 // whose four 32-byte units are XORed with (position >> 1) & 3.  At stride 2 the halo columns are stored de-interleaved
 // (even columns, then odd) so that the 8 pixels of a 32-lane read group are consecutive positions again.
-constexpr int R3_NW = 12;
-template <int S> struct R3Geo {
+// Narrow inputs (the 3-channel stem, one 16-byte group per pixel): BCI = 16, 3 waves = the 3 kernel rows, the halo image is
+// [IH*IW px][16 bytes]; MFMA columns 8 - 15 re-read columns 0 - 7 and are never stored.
+template <int S, int BCI> struct R3Geo {
+  static constexpr int NW = BCI == 64 ? 12 : 3;
+  static constexpr int XCH = BCI == 64 ? 8 : 1;                  // 16-byte chunks per halo pixel
   static constexpr int TH = S == 1 ? 8 : 4, TW = 16;
   static constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
   static constexpr int NPX = TH * TW, NHX = IH * IW;
-  static constexpr int NZC = NPX * 8, NCH = NZC + NHX * 8;      // 16-byte chunks: dz, then x
+  static constexpr int NZC = NPX * 8, NCH = NZC + NHX * XCH;      // 16-byte chunks: dz, then x
   static constexpr int NSLOT = (NCH + 63) / 64;                  // DMA instructions per stage, dealt round-robin over the waves
-  static constexpr int SPW = (NSLOT + R3_NW - 1) / R3_NW;        // ... per wave: SPW for waves < NFULL, SPW - 1 for the rest
-  static constexpr int NFULL = NSLOT - (SPW - 1) * R3_NW;
+  static constexpr int SPW = (NSLOT + NW - 1) / NW;        // ... per wave: SPW for waves < NFULL, SPW - 1 for the rest
+  static constexpr int NFULL = NSLOT - (SPW - 1) * NW;
   static constexpr int STAGE = NSLOT * 1024;
   static constexpr int RING = (160 * 1024) / STAGE < 4 ? (160 * 1024) / STAGE : 4;
   static constexpr int NEV = (IW + 1) / 2;                       // even halo columns (stride 2)
   static_assert(RING >= 3, "ring of at least 3 stages");
   static_assert(NZC % 64 == 0, "a DMA instruction is all dz or all x");
+  static_assert(SPW * (RING - 1) < 64, "vmcnt is a 6-bit counter");
 };
 
-template <int S>
-__global__ __launch_bounds__(R3_NW * 64) void wgrad_k3_ring_kernel(const WgradParams p) {
+template <int S, int BCI>
+__global__ __launch_bounds__((R3Geo<S, BCI>::NW * 64)) void wgrad_k3_ring_kernel(const WgradParams p) {
   extern __shared__ __attribute__((aligned(1024))) char wsm_r3[];
-  using G = R3Geo<S>;
-  constexpr int BCO = 64, BCI = 64;
+  using G = R3Geo<S, BCI>;
+  constexpr int BCO = 64, NW = G::NW;
   constexpr int KS = G::NPX / 32;       // 32-pixel steps per tile
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kh = wave % 3, cq = wave / 3;
+  const int kh = NW == 12 ? wave % 3 : wave, cq = NW == 12 ? wave / 3 : 0;
   const int kg = lane >> 4, r16 = lane & 15;
   const int co0 = blockIdx.y * BCO, ci0 = blockIdx.z * BCI;
   const int tilesPerImg = p.tilesX * p.tilesY;
   const int Gx = gridDim.x;
   const int nT = (int)blockIdx.x < p.numTiles ? (p.numTiles - 1 - (int)blockIdx.x) / Gx + 1 : 0;
-  // DMA slot q of this wave = chunks ((q * 12 + wave) * 64 + lane), a whole slot is dz or x: decoded once into the byte offset
+  // DMA slot q of this wave = chunks ((q * NW + wave) * 64 + lane), a whole slot is dz or x: decoded once into the byte offset
   // from the tile's dz / x origin pixel (channel block included) and the row / column inside the tile / halo (a lane with
   // nothing to fetch gets a row no tile reaches)
   int rel[G::SPW], rr[G::SPW], cc[G::SPW];
 #pragma unroll
   for (int q = 0; q < G::SPW; ++q) {
-    const int c = (q * R3_NW + wave) * 64 + lane;
+    const int c = (q * NW + wave) * 64 + lane;
     const int cp = c & 7;
     rel[q] = 0; rr[q] = 0x40000000; cc[q] = 0;
     if (c < G::NZC) {
@@ -838,8 +842,8 @@ __global__ __launch_bounds__(R3_NW * 64) void wgrad_k3_ring_kernel(const WgradPa
       cc[q] = tx;
       if (co0 + cl * 8 < p.Cout) rr[q] = ty;
     } else if (c < G::NCH) {
-      const int hp = (c - G::NZC) >> 3;
-      const int cl = (((cp >> 1) ^ ((hp >> 1) & 3)) << 1) | (cp & 1);
+      const int hp = BCI == 64 ? (c - G::NZC) >> 3 : c - G::NZC;
+      const int cl = BCI == 64 ? (((cp >> 1) ^ ((hp >> 1) & 3)) << 1) | (cp & 1) : 0;
       const int py = hp / G::IW, pc = hp - py * G::IW;
       const int col = S == 1 ? pc : (pc < G::NEV ? 2 * pc : 2 * (pc - G::NEV) + 1);
       rel[q] = ((py * p.W + col) * p.ldx + ci0 + cl * 8) * 2;
@@ -862,11 +866,11 @@ __global__ __launch_bounds__(R3_NW * 64) void wgrad_k3_ring_kernel(const WgradPa
 #pragma unroll
     for (int q = 0; q < G::SPW; ++q) {
       if (q == G::SPW - 1 && wave >= G::NFULL) break;   // wave-uniform
-      const bool isx = q * R3_NW + wave >= G::NZC / 64;  // wave-uniform
+      const bool isx = q * NW + wave >= G::NZC / 64;  // wave-uniform
       const int rb = isx ? iy0 : oy0, rl = isx ? xrl : zrl, cb = isx ? ix0 : ox0, cl = isx ? p.W : p.OW;
       const char* const base = isx ? xb : zb;
       const bool ok = (unsigned)(rr[q] + rb) < (unsigned)rl && (unsigned)(cc[q] + cb) < (unsigned)cl;
-      wg_dma16(ok ? base + rel[q] : zero, sdst + q * (R3_NW * 1024));
+      wg_dma16(ok ? base + rel[q] : zero, sdst + q * (NW * 1024));
     }
   };
   f32x4 acc[3][4];
@@ -912,7 +916,7 @@ __global__ __launch_bounds__(R3_NW * 64) void wgrad_k3_ring_kernel(const WgradPa
         for (int h = 0; h < 2; ++h) {
           const int row = ((ks * 2 + h) * S + kh) * G::IW;
           const int hp = S == 1 ? row + tx + kw : row + ((kw & 1) ? G::NEV + tx : tx + (kw >> 1));
-          hoff[h] = hp * 128 + sub + ((cq ^ ((hp >> 1) & 3)) << 5);
+          hoff[h] = BCI == 64 ? hp * 128 + sub + ((cq ^ ((hp >> 1) & 3)) << 5) : hp * 16 + (r16 & 1) * 8;
         }
         const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(xt + hoff[0]));
         const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(xt + hoff[1]));
@@ -1471,6 +1475,7 @@ static int launch_wgrad(WgradParams& p, int accumulate, void* ws, size_t ws_byte
 
 // UPA_WGRAD_RING=0: the register-staged kernels (the A/B switch of the ring forms; read once)
 static const bool g_wgrad_ring = [] { const char* e = getenv("UPA_WGRAD_RING"); return !(e && e[0] == '0'); }();
+static const int g_wgrad_stem_wgs = [] { const char* e = getenv("UPA_WGRAD_STEM_WGS"); return e ? atoi(e) : 0; }();
 static const int g_wgrad_k1_wgs = [] { const char* e = getenv("UPA_WGRAD_K1_WGS"); return e ? atoi(e) : 0; }();
 
 static bool wgrad_small(int cin, int cout) { return cin <= 32 || cout <= 32; }
@@ -1521,7 +1526,7 @@ static int launch_wgrad_bf16_k3_t(WgradParams& p, int accumulate, void* ws, size
   // left to overlap it with, and alone it takes 280 us at 512 workgroups against 480 at 256 (15.42 vs 15.63 ms per step)
   constexpr long big_px = 3000000;
   int budget = wg_budget > 0 && wg_budget <= 512 ? wg_budget : 256;
-  if (big_px > 0 && (long)p.N * p.OH * p.OW >= big_px) budget = 512;  // the first layers run last in the backward pass
+  if (big_px > 0 && (long)p.N * p.OH * p.OW >= big_px) budget = g_wgrad_stem_wgs > 0 ? g_wgrad_stem_wgs : (g_wgrad_ring && BCI == 16 && p.Cin <= 8 ? 768 : 512);  // the first layers run last in the backward pass
   int wgs = budget / (bco * bci);
   if (wgs < 1) wgs = 1;
   if (wgs > p.numTiles) wgs = p.numTiles;
@@ -1531,15 +1536,17 @@ static int launch_wgrad_bf16_k3_t(WgradParams& p, int accumulate, void* ws, size
   const size_t lds = (size_t)p.TH * p.TW * PZ + (size_t)p.IH * p.IW * PX;
   UPA_CHECK_ARG(p.TH * p.TW * 8 + p.IH * p.IW * (BCI / 8) <= 16 * 192, "wgrad: staging registers too few for this tile");
   dim3 grid(wgs, bco, bci);
-  if (BCI == 64 && g_wgrad_ring) {
+  if (g_wgrad_ring && (BCI == 64 || p.Cin <= 8)) {   // the narrow ring form holds one 16-byte group (8 channels) per halo pixel
     if (p.stride == 1) {
-      auto kern = wgrad_k3_ring_kernel<1>;
-      (void)upa_full_lds<wgrad_k3_ring_kernel<1>>();
-      hipLaunchKernelGGL(kern, grid, dim3(R3_NW * 64), (size_t)R3Geo<1>::RING * R3Geo<1>::STAGE, s, p);
+      auto kern = wgrad_k3_ring_kernel<1, BCI>;
+      (void)upa_full_lds<(wgrad_k3_ring_kernel<1, BCI>)>();
+      using G1 = R3Geo<1, BCI>;
+      hipLaunchKernelGGL(kern, grid, dim3(G1::NW * 64), (size_t)G1::RING * G1::STAGE, s, p);
     } else {
-      auto kern = wgrad_k3_ring_kernel<2>;
-      (void)upa_full_lds<wgrad_k3_ring_kernel<2>>();
-      hipLaunchKernelGGL(kern, grid, dim3(R3_NW * 64), (size_t)R3Geo<2>::RING * R3Geo<2>::STAGE, s, p);
+      auto kern = wgrad_k3_ring_kernel<2, BCI>;
+      (void)upa_full_lds<(wgrad_k3_ring_kernel<2, BCI>)>();
+      using G2 = R3Geo<2, BCI>;
+      hipLaunchKernelGGL(kern, grid, dim3(G2::NW * 64), (size_t)G2::RING * G2::STAGE, s, p);
     }
   } else if (p.stride == 1) {
     auto kern = wgrad_bf16_k3_kernel<1, BCI>;
@@ -1568,7 +1575,7 @@ extern "C" size_t upa_conv2d_wgrad_workspace_bytes(int cin, int cout, int k) {
   for (int b = 0; b < 3; ++b) {
     const int B = Bs[b];
     const int bco = cdiv(cout, B), bci = cdiv(cin, B);
-    int wgs = (k == 3 && B == 64 ? 512 : 256) / (bco * bci);
+    int wgs = (k == 3 && B == 64 ? 1024 : 256) / (bco * bci);
     if (wgs < 1) wgs = 1;
     const size_t n = wgrad_partial_bytes(bco, bci, wgs, B, B, k);
     if (n > best) best = n;
