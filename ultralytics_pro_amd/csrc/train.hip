@@ -1476,6 +1476,7 @@ static int launch_wgrad(WgradParams& p, int accumulate, void* ws, size_t ws_byte
 // UPA_WGRAD_RING=0: the register-staged kernels (the A/B switch of the ring forms; read once)
 static const bool g_wgrad_ring = [] { const char* e = getenv("UPA_WGRAD_RING"); return !(e && e[0] == '0'); }();
 static const int g_wgrad_stem_wgs = [] { const char* e = getenv("UPA_WGRAD_STEM_WGS"); return e ? atoi(e) : 0; }();
+static const int g_wgrad_k3_wgs = [] { const char* e = getenv("UPA_WGRAD_K3_WGS"); return e ? atoi(e) : 0; }();
 static const int g_wgrad_k1_wgs = [] { const char* e = getenv("UPA_WGRAD_K1_WGS"); return e ? atoi(e) : 0; }();
 
 static bool wgrad_small(int cin, int cout) { return cin <= 32 || cout <= 32; }
@@ -1525,7 +1526,7 @@ static int launch_wgrad_bf16_k3_t(WgradParams& p, int accumulate, void* ws, size
   // ... except the stem (3.3 M output pixels): its weight gradient is the last kernel of the backward pass, nothing is
   // left to overlap it with, and alone it takes 280 us at 512 workgroups against 480 at 256 (15.42 vs 15.63 ms per step)
   constexpr long big_px = 3000000;
-  int budget = wg_budget > 0 && wg_budget <= 512 ? wg_budget : 256;
+  int budget = g_wgrad_k3_wgs > 0 ? g_wgrad_k3_wgs : (wg_budget > 0 && wg_budget <= 512 ? wg_budget : 256);
   if (big_px > 0 && (long)p.N * p.OH * p.OW >= big_px) budget = g_wgrad_stem_wgs > 0 ? g_wgrad_stem_wgs : (g_wgrad_ring && BCI == 16 && p.Cin <= 8 ? 768 : 512);  // the first layers run last in the backward pass
   int wgs = budget / (bco * bci);
   if (wgs < 1) wgs = 1;
