@@ -312,6 +312,14 @@ def test_detection_loss_and_gradient_match_oracle(case):
     _check_loss_vs_oracle(B, hw, P.synthetic_labels(B, seed=3))
 
 
+def test_detection_loss_class_count_not_a_multiple_of_four():
+    """6 classes: the class term takes the element-per-thread kernel (the four-classes-per-thread form needs nc % 4 == 0 and
+    16-byte aligned rows), vs the oracle."""
+    labels = P.synthetic_labels(2, seed=3)
+    labels = dict(labels, cls=labels["cls"] % 6)
+    _check_loss_vs_oracle(2, [(16, 16), (8, 8), (4, 4)], labels, nc=6)
+
+
 def _crowded_labels(B, per_image, seed=5):
     """`per_image[j]` boxes in image j (mosaic-like crowding, > 64 per image), plus two all-zero boxes that the reference
     masks out (mask_gt, loss.py:489)."""
@@ -338,17 +346,17 @@ def test_detection_loss_more_than_64_boxes_per_image_matches_oracle():
     _check_loss_vs_oracle(3, [(20, 12), (10, 6), (5, 3)], labels)
 
 
-def _check_loss_vs_oracle(B, hw, labels):
+def _check_loss_vs_oracle(B, hw, labels, nc=80):
     from oracle.loss import v8_detection_loss
     from tests.hip_utils import DEV, to_cpu_nchw, to_dev_nhwc
     from ultralytics_pro_amd import _lib as L
     from ultralytics_pro_amd.engine import runtime as R
     from ultralytics_pro_amd.engine import trainer as T
     import ctypes as C
-    feats = _loss_inputs(B, hw)
+    feats = _loss_inputs(B, hw, nc=nc)
     strides = torch.tensor([8.0, 16.0, 32.0])
     fr = [f.clone().requires_grad_(True) for f in feats]
-    loss, items = v8_detection_loss(fr, labels, strides)
+    loss, items = v8_detection_loss(fr, labels, strides, nc=nc)
     loss.sum().backward()
     # HIP
     fd = [to_dev_nhwc(f) for f in feats]
@@ -368,7 +376,7 @@ def _check_loss_vs_oracle(B, hw, labels):
     wsb = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
     out = torch.zeros(3, device=DEV)
     L.check(L.lib().upa_detection_loss(C.cast(fp, C.c_void_p), C.cast(gp, C.c_void_p), C.cast(hs, C.c_void_p), C.cast(ws, C.c_void_p),
-                                       C.cast(lds, C.c_void_p), C.cast(st_, C.c_void_p), nl, B, 80, 16, gt_d.data_ptr(),
+                                       C.cast(lds, C.c_void_p), C.cast(st_, C.c_void_p), nl, B, nc, 16, gt_d.data_ptr(),
                                        ngt_d.data_ptr(), max_gt, 7.5, 0.5, 1.5, 1.0, out.data_ptr(), wsb.data_ptr(), nbytes,
                                        L.current_stream(DEV)), "detection_loss")
     torch.cuda.synchronize()
