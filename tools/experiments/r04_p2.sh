@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: the UPA_WGRAD_* / WG_EXP switches this script sets existed only in the A/B builds of round 4 (git history: "3x3 weight gradient: 12-wave
+# LDS-DMA ring kernel" .. "Narrow-input (stem) weight gradient"); the library reads no environment, so they were removed afterwards.
 # weight-gradient kernel variants (WG_EXP builds of train.hip: 0 product, 1 conflict-free K order, 2 = 1 + no refetch, 3 = 1 + no MFMA)
 for v in ${VARIANTS:-0 1 2 3}; do
   echo "== variant $v"

@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: the UPA_WGRAD_* / WG_EXP switches this script sets existed only in the A/B builds of round 4 (git history: "3x3 weight gradient: 12-wave
+# LDS-DMA ring kernel" .. "Narrow-input (stem) weight gradient"); the library reads no environment, so they were removed afterwards.
 run() {
 python - <<'PY' 2>&1 | grep -v amdgpu.ids
 import sys; sys.path.insert(0, "tools")

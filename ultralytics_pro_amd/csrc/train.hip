@@ -416,7 +416,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 // multiplied.  Partial blocks go through the same two-stage reduction as the f32 kernel.
 typedef short v4s16 __attribute__((ext_vector_type(4)));
 
-// BCI = input channels per block: 64, or 16 for narrow inputs (the 3-channel stem, padded to one 16-byte group).
+// BCI = input channels per block.  Since round 4 only the BCI = 16 instantiation is launched, for 9 - 16 input channels: every
+// other bf16 3x3 layer (and the pointwise layers, whose register-staged kernel is gone) takes the ring forms below.
 template <int S, int BCI>
 __global__ __launch_bounds__(192) void wgrad_bf16_k3_kernel(const WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) char wsm_b[];
@@ -561,101 +562,8 @@ __global__ __launch_bounds__(192) void wgrad_bf16_k3_kernel(const WgradParams p)
           part[((size_t)(kh * 3 + kw) * BCO + i * 16 + kg * 4 + r) * BCI + j * 16 + r16] = acc[kw][i][j][r];
 }
 
-// Pointwise (1x1, stride 1) form: dW[co][ci] = sum over pixels dz[p][co] * x[p][ci], a plain GEMM with the pixel axis as K.
-// 128 x 128 (co, ci) block per workgroup, 4 waves = 4 quadrants of 4 x 4 MFMA tiles, 128-pixel tiles, same transposing
-// LDS reads and register prefetch as above.
-__global__ __launch_bounds__(256) void wgrad_bf16_k1_kernel(const WgradParams p) {
-  extern __shared__ __attribute__((aligned(16))) char wsm_c[];
-  constexpr int BCO = 128, BCI = 128;
-  constexpr int PZ = BCO * 2 + 32, PX = BCI * 2 + 32;
-  constexpr int NPX = 128;
-  constexpr int NTHR = 256;
-  char* zt = wsm_c;
-  char* xt = wsm_c + (size_t)NPX * PZ;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int kg = lane >> 4, r16 = lane & 15;
-  const int co0 = blockIdx.y * BCO, ci0 = blockIdx.z * BCI;
-  const long P = (long)p.N * p.H * p.W;  // pixels (views have a uniform pixel stride)
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  constexpr int MAXQ = 16;  // 128 pixels * 16 chunks * 2 operands / 256 threads
-  u32x4 stg[MAXQ];
-  auto fetch = [&](long tile) __attribute__((always_inline)) {
-    const long p0 = tile * NPX;
-#pragma unroll
-    for (int q = 0; q < MAXQ; ++q) {
-      const int c = tid + q * NTHR;       // [operand][pixel][16 chunks]
-      const int op = c >> 11, px = (c >> 4) & 127, g = c & 15;
-      u32x4 v = u32x4{0u, 0u, 0u, 0u};
-      const long pp = p0 + px;
-      if (pp < P) {
-        if (op == 0) {
-          if (co0 + g * 8 < p.Cout) v = *reinterpret_cast<const u32x4*>(p.dz + ((size_t)pp * p.lddz + co0 + g * 8) * 2);
-        } else {
-          if (ci0 + g * 8 < p.Cin) v = *reinterpret_cast<const u32x4*>(p.x + ((size_t)pp * p.ldx + ci0 + g * 8) * 2);
-        }
-      }
-      stg[q] = v;
-    }
-  };
-  auto commit = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int q = 0; q < MAXQ; ++q) {
-      const int c = tid + q * NTHR;
-      const int op = c >> 11, px = (c >> 4) & 127, g = c & 15;
-      *reinterpret_cast<u32x4*>((op == 0 ? zt + px * PZ : xt + px * PX) + g * 16) = stg[q];
-    }
-  };
-  const long ntiles = (P + NPX - 1) / NPX;
-  long tile = blockIdx.x;
-  if (tile < ntiles) fetch(tile);
-  for (; tile < ntiles; tile += gridDim.x) {
-    __syncthreads();
-    commit();
-    __syncthreads();
-    if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
-#pragma unroll
-    for (int ks = 0; ks < NPX / 32; ++ks) {
-      int off[2];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) off[h] = (ks * 32 + kg * 8 + h * 4 + (r16 >> 2)) * PZ + (r16 & 3) * 8;
-      u32x4 a[4], b[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(zt + off[0] + (wm * 4 + i) * 32));
-        const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(zt + off[1] + (wm * 4 + i) * 32));
-        a[i] = u32x4{((const unsigned*)&lo)[0], ((const unsigned*)&lo)[1], ((const unsigned*)&hi)[0], ((const unsigned*)&hi)[1]};
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(xt + off[0] + (wn * 4 + j) * 32));
-        const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(xt + off[1] + (wn * 4 + j) * 32));
-        b[j] = u32x4{((const unsigned*)&lo)[0], ((const unsigned*)&lo)[1], ((const unsigned*)&hi)[0], ((const unsigned*)&hi)[1]};
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&a[i]), *reinterpret_cast<bf16x8*>(&b[j]),
-                                                              acc[i][j], 0, 0, 0);
-    }
-  }
-  float* part = p.partial + (((size_t)blockIdx.y * gridDim.z + blockIdx.z) * gridDim.x + blockIdx.x) * (BCO * BCI);
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        part[(size_t)((wm * 4 + i) * 16 + kg * 4 + r) * BCI + (wn * 4 + j) * 16 + r16] = acc[i][j][r];
-}
-
-// ---- ring forms of the two bf16 kernels: the operands go global -> LDS by DMA (global_load_lds, 16 bytes per lane) into a
+// ---- ring forms of the bf16 kernels (the pointwise one replaced a 128 x 128-block register-staged kernel of the same MFMA
+// layout): the operands go global -> LDS by DMA (global_load_lds, 16 bytes per lane) into a
 // ring of stages, RING - 1 of them in flight per workgroup, instead of through one register-staged tile.  The weight
 // gradient is a streaming product (its MFMA floor is below its HBM floor on every yolov8s layer) and the register form
 // kept ONE tile (41 - 64 KB) per workgroup in flight: 1.7 TB/s on the 160x160 layers, a tile every ~3 us for 0.4 us of
@@ -1473,37 +1381,25 @@ static int launch_wgrad(WgradParams& p, int accumulate, void* ws, size_t ws_byte
   return UPA_OK;
 }
 
-// UPA_WGRAD_RING=0: the register-staged kernels (the A/B switch of the ring forms; read once)
-static const bool g_wgrad_ring = [] { const char* e = getenv("UPA_WGRAD_RING"); return !(e && e[0] == '0'); }();
-static const int g_wgrad_stem_wgs = [] { const char* e = getenv("UPA_WGRAD_STEM_WGS"); return e ? atoi(e) : 0; }();
-static const int g_wgrad_k3_wgs = [] { const char* e = getenv("UPA_WGRAD_K3_WGS"); return e ? atoi(e) : 0; }();
-static const int g_wgrad_k1_wgs = [] { const char* e = getenv("UPA_WGRAD_K1_WGS"); return e ? atoi(e) : 0; }();
-
 static bool wgrad_small(int cin, int cout) { return cin <= 32 || cout <= 32; }
 
 static int launch_wgrad_bf16_k1(WgradParams& p, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
   constexpr int BCO = 128, BCI = 128;
   const long P = (long)p.N * p.H * p.W;
-  const long ntiles = (P + 127) / 128;
   const int bco = cdiv(p.Cout, BCO), bci = cdiv(p.Cin, BCI);
-  // 128 workgroups: 15.68 ms per yolov8s step against 15.88 at 256 (overlapped on the side stream; alone 256 is faster)
+  // 128 workgroups (half the CUs): in the yolov8s step, where these run on the side stream beside the main chain, 64 / 128 / 256
+  // are within 0.1 ms of each other (tools/experiments/r04_z2.sh); alone 256 is faster on the 160x160 layers (47 vs 88 us)
   constexpr int k1_budget = 128;
-  long wgs = (g_wgrad_k1_wgs > 0 ? g_wgrad_k1_wgs : (k1_budget > 0 && k1_budget <= 256 ? k1_budget : 128)) / (bco * bci);
+  long wgs = k1_budget / (bco * bci);
   if (wgs < 1) wgs = 1;
-  if (wgs > ntiles) wgs = ntiles;
+  const long nst = (P + R1_NPX - 1) / R1_NPX;
+  if (wgs > nst) wgs = nst;
   const size_t need = wgrad_partial_bytes(bco, bci, (int)wgs, BCO, BCI, 1);
   UPA_CHECK_ARG(ws && ws_bytes >= need, "wgrad: workspace too small (%zu < %zu bytes)", ws_bytes, need);
   p.partial = (float*)ws;
-  if (g_wgrad_ring) {
-    auto kern = wgrad_k1_ring_kernel;
-    (void)upa_full_lds<wgrad_k1_ring_kernel>();
-    hipLaunchKernelGGL(kern, dim3((unsigned)wgs, bco, bci), dim3(256), (size_t)R1_RING * R1_STAGE, s, p);
-  } else {
-    const size_t lds = (size_t)128 * (BCO * 2 + 32) + (size_t)128 * (BCI * 2 + 32);
-    auto kern = wgrad_bf16_k1_kernel;
-    (void)upa_full_lds<wgrad_bf16_k1_kernel>();
-    hipLaunchKernelGGL(kern, dim3((unsigned)wgs, bco, bci), dim3(256), lds, s, p);
-  }
+  auto kern = wgrad_k1_ring_kernel;
+  (void)upa_full_lds<wgrad_k1_ring_kernel>();
+  hipLaunchKernelGGL(kern, dim3((unsigned)wgs, bco, bci), dim3(256), (size_t)R1_RING * R1_STAGE, s, p);
   launch_wgrad_reduce(p.partial, (int)wgs, bco, bci, BCO, BCI, 1, p.dw, p.Cout, p.Cin, accumulate, s);
   UPA_LAUNCH_CHECK();
   return UPA_OK;
@@ -1518,26 +1414,23 @@ static int launch_wgrad_bf16_k3_t(WgradParams& p, int accumulate, void* ws, size
   p.numTiles = p.tilesX * p.tilesY * p.N;
   p.IH = (p.TH - 1) * p.stride + 3; p.IW = (p.TW - 1) * p.stride + 3;
   const int bco = cdiv(p.Cout, BCO), bci = cdiv(p.Cin, BCI);
-  // workgroups per launch (= slices of the pixel axis x channel blocks).  Measured on MI355X, yolov8s batch 32 step:
-  // 512 (two 3-wave workgroups per CU) 16.16 ms, 256: 15.89, 128: 15.81 with the weight gradients overlapped on the side
-  // stream; 17.14 / 16.78 / 18.79 without overlap - fewer slices halve the partial-sum traffic (75 MB per layer at 512)
-  // and leave CUs to the main stream; 256 is the best of both
+  // workgroups per launch (= slices of the pixel axis x channel blocks): 256, one 12-wave ring workgroup per CU (64 - 256 are
+  // within 0.1 ms of each other in the yolov8s step, tools/experiments/r04_z2.sh; more slices = more partial-sum traffic)
   constexpr int wg_budget = 256;
   // ... except the stem (3.3 M output pixels): its weight gradient is the last kernel of the backward pass, nothing is
-  // left to overlap it with, and alone it takes 280 us at 512 workgroups against 480 at 256 (15.42 vs 15.63 ms per step)
+  // left to overlap it with: 768 three-wave workgroups of the narrow ring form (121 us; 130 at 512 and at 1024)
   constexpr long big_px = 3000000;
-  int budget = g_wgrad_k3_wgs > 0 ? g_wgrad_k3_wgs : (wg_budget > 0 && wg_budget <= 512 ? wg_budget : 256);
-  if (big_px > 0 && (long)p.N * p.OH * p.OW >= big_px) budget = g_wgrad_stem_wgs > 0 ? g_wgrad_stem_wgs : (g_wgrad_ring && BCI == 16 && p.Cin <= 8 ? 768 : 512);  // the first layers run last in the backward pass
+  const bool ring = BCI == 64 || p.Cin <= 8;   // the narrow ring form holds one 16-byte group (8 channels) per halo pixel
+  int budget = wg_budget;
+  if ((long)p.N * p.OH * p.OW >= big_px) budget = ring && BCI == 16 ? 768 : 512;  // the first layers run last in the backward pass
   int wgs = budget / (bco * bci);
   if (wgs < 1) wgs = 1;
   if (wgs > p.numTiles) wgs = p.numTiles;
   const size_t need = wgrad_partial_bytes(bco, bci, wgs, BCO, BCI, 3);
   UPA_CHECK_ARG(ws && ws_bytes >= need, "wgrad: workspace too small (%zu < %zu bytes)", ws_bytes, need);
   p.partial = (float*)ws;
-  const size_t lds = (size_t)p.TH * p.TW * PZ + (size_t)p.IH * p.IW * PX;
-  UPA_CHECK_ARG(p.TH * p.TW * 8 + p.IH * p.IW * (BCI / 8) <= 16 * 192, "wgrad: staging registers too few for this tile");
   dim3 grid(wgs, bco, bci);
-  if (g_wgrad_ring && (BCI == 64 || p.Cin <= 8)) {   // the narrow ring form holds one 16-byte group (8 channels) per halo pixel
+  if (ring) {
     if (p.stride == 1) {
       auto kern = wgrad_k3_ring_kernel<1, BCI>;
       (void)upa_full_lds<(wgrad_k3_ring_kernel<1, BCI>)>();
@@ -1549,14 +1442,18 @@ static int launch_wgrad_bf16_k3_t(WgradParams& p, int accumulate, void* ws, size
       using G2 = R3Geo<2, BCI>;
       hipLaunchKernelGGL(kern, grid, dim3(G2::NW * 64), (size_t)G2::RING * G2::STAGE, s, p);
     }
-  } else if (p.stride == 1) {
-    auto kern = wgrad_bf16_k3_kernel<1, BCI>;
-    (void)upa_full_lds<wgrad_bf16_k3_kernel<1, BCI>>();
-    hipLaunchKernelGGL(kern, grid, dim3(192), lds, s, p);
-  } else {
-    auto kern = wgrad_bf16_k3_kernel<2, BCI>;
-    (void)upa_full_lds<wgrad_bf16_k3_kernel<2, BCI>>();
-    hipLaunchKernelGGL(kern, grid, dim3(192), lds, s, p);
+  } else if constexpr (BCI == 16) {   // 9 - 16 input channels: the register-staged narrow form (two 16-byte groups per halo pixel)
+    const size_t lds = (size_t)p.TH * p.TW * PZ + (size_t)p.IH * p.IW * PX;
+    UPA_CHECK_ARG(p.TH * p.TW * 8 + p.IH * p.IW * (BCI / 8) <= 16 * 192, "wgrad: staging registers too few for this tile");
+    if (p.stride == 1) {
+      auto kern = wgrad_bf16_k3_kernel<1, 16>;
+      (void)upa_full_lds<wgrad_bf16_k3_kernel<1, 16>>();
+      hipLaunchKernelGGL(kern, grid, dim3(192), lds, s, p);
+    } else {
+      auto kern = wgrad_bf16_k3_kernel<2, 16>;
+      (void)upa_full_lds<wgrad_bf16_k3_kernel<2, 16>>();
+      hipLaunchKernelGGL(kern, grid, dim3(192), lds, s, p);
+    }
   }
   launch_wgrad_reduce(p.partial, wgs, bco, bci, BCO, BCI, 9, p.dw, p.Cout, p.Cin, accumulate, s);
   UPA_LAUNCH_CHECK();
