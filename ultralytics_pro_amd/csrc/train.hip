@@ -601,22 +601,25 @@ constexpr int R1_NPX = 64;                   // pixels per stage
 constexpr int R1_IMG = R1_NPX * 256;         // one operand image: [px][128 channels], 16 KB
 constexpr int R1_STAGE = 2 * R1_IMG;         // dz image, x image
 constexpr int R1_RING = 4;                   // 128 KB of LDS, 96 KB in flight
-constexpr int R1_SLOTS = R1_STAGE / 1024 / 4;  // DMA instructions per wave and stage (8)
+constexpr int R1_NW = 8;                       // waves: 4 quadrants x 2 pixel halves of a stage
+constexpr int R1_SLOTS = R1_STAGE / 1024 / R1_NW;  // DMA instructions per wave and stage (4)
 
-// Pointwise (1x1, stride 1): 128 x 128 (co, ci) block, 4 waves = 4 quadrants of 4 x 4 MFMA tiles, 64-pixel stages.
-__global__ __launch_bounds__(256) void wgrad_k1_ring_kernel(const WgradParams p) {
+// Pointwise (1x1, stride 1): 128 x 128 (co, ci) block, 8 waves = 4 quadrants of 4 x 4 MFMA tiles x the two 32-pixel halves of a
+// 64-pixel stage (each half keeps its own accumulators and leaves as its own partial block: 2 * gridDim.x slices).  With 4
+// waves (one per SIMD, 8 DMA instructions + 32 MFMAs per wave and stage) issuing the DMA took longer than the MFMAs.
+__global__ __launch_bounds__(R1_NW * 64) void wgrad_k1_ring_kernel(const WgradParams p) {
   extern __shared__ __attribute__((aligned(1024))) char wsm_r1[];
   constexpr int BCO = 128, BCI = 128;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = (wave >> 1) & 1, wn = wave & 1, kh2 = wave >> 2;
   const int kg = lane >> 4, r16 = lane & 15;
   const int co0 = blockIdx.y * BCO, ci0 = blockIdx.z * BCI;
   const long P = (long)p.N * p.H * p.W;
   const long ntiles = (P + R1_NPX - 1) / R1_NPX;
   const int G = gridDim.x;
   const int nT = blockIdx.x < ntiles ? (int)((ntiles - 1 - blockIdx.x) / G) + 1 : 0;
-  // DMA slot q of this wave = chunks ((q * 4 + wave) * 64 + lane) of the stage: operand q >> 2, pixel (q & 3) * 16 + wave * 4 + kg,
+  // DMA slot q of this wave = chunks ((q * 8 + wave) * 64 + lane) of the stage: operand q >> 1, pixel (q & 1) * 32 + wave * 4 + kg,
   // physical 16-byte chunk lane & 15 holding logical chunk (unit ^ (pixel & 7)) * 2 + half
   const int pxb = wave * 4 + kg;
   const int cl = ((((lane & 15) >> 1) ^ (pxb & 7)) << 1) | (lane & 1);
@@ -629,13 +632,13 @@ __global__ __launch_bounds__(256) void wgrad_k1_ring_kernel(const WgradParams p)
     char* const dst = wsm_r1 + (size_t)(i % R1_RING) * R1_STAGE + wave * 1024;
 #pragma unroll
     for (int q = 0; q < R1_SLOTS; ++q) {
-      const long pp = p0 + (q & 3) * 16 + pxb;
+      const long pp = p0 + (q & 1) * 32 + pxb;
       const char* src = zero;
       if (i < nT && pp < P) {
-        if (q < 4) { if (zok) src = zsrc + (size_t)(p0 + (q & 3) * 16) * p.lddz * 2; }
-        else       { if (xok) src = xsrc + (size_t)(p0 + (q & 3) * 16) * p.ldx * 2; }
+        if (q < 2) { if (zok) src = zsrc + (size_t)(p0 + (q & 1) * 32) * p.lddz * 2; }
+        else       { if (xok) src = xsrc + (size_t)(p0 + (q & 1) * 32) * p.ldx * 2; }
       }
-      wg_dma16(src, dst + q * 4096);
+      wg_dma16(src, dst + q * (R1_NW * 1024));
     }
   };
   f32x4 acc[4][4];
@@ -649,41 +652,38 @@ __global__ __launch_bounds__(256) void wgrad_k1_ring_kernel(const WgradParams p)
   int offa[4], offb[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    offa[i] = (kg * 4 + (r16 >> 2)) * 256 + (((wm * 4 + i) ^ sw) << 5) + (r16 & 3) * 8;
-    offb[i] = (kg * 4 + (r16 >> 2)) * 256 + (((wn * 4 + i) ^ sw) << 5) + (r16 & 3) * 8 + R1_IMG;
+    offa[i] = (kh2 * 32 + kg * 4 + (r16 >> 2)) * 256 + (((wm * 4 + i) ^ sw) << 5) + (r16 & 3) * 8;
+    offb[i] = (kh2 * 32 + kg * 4 + (r16 >> 2)) * 256 + (((wn * 4 + i) ^ sw) << 5) + (r16 & 3) * 8 + R1_IMG;
   }
 #pragma unroll
   for (int i = 0; i < R1_RING - 1; ++i) stage(i);
   for (int i = 0; i < nT; ++i) {
     wg_wait_vm<R1_SLOTS * (R1_RING - 2)>();   // this thread's share of stage i has landed ...
     __builtin_amdgcn_s_barrier();             // ... and everyone's; everyone is also done reading stage i - 1
-    stage(i + R1_RING - 1);                   // into the slot stage i - 1 used
     const char* const img = wsm_r1 + (size_t)(i % R1_RING) * R1_STAGE;
+    u32x4 a[4], b[4];
 #pragma unroll
-    for (int ks = 0; ks < R1_NPX / 32; ++ks) {
-      u32x4 a[4], b[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(img + offa[t] + ks * 32 * 256));
-        const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(img + offa[t] + (ks * 32 + 16) * 256));
-        a[t] = u32x4{((const unsigned*)&lo)[0], ((const unsigned*)&lo)[1], ((const unsigned*)&hi)[0], ((const unsigned*)&hi)[1]};
-      }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(img + offb[t] + ks * 32 * 256));
-        const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(img + offb[t] + (ks * 32 + 16) * 256));
-        b[t] = u32x4{((const unsigned*)&lo)[0], ((const unsigned*)&lo)[1], ((const unsigned*)&hi)[0], ((const unsigned*)&hi)[1]};
-      }
-#pragma unroll
-      for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&a[ii]), *reinterpret_cast<bf16x8*>(&b[j]),
-                                                               acc[ii][j], 0, 0, 0);
+    for (int t = 0; t < 4; ++t) {
+      const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(img + offa[t]));
+      const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(img + offa[t] + 16 * 256));
+      a[t] = u32x4{((const unsigned*)&lo)[0], ((const unsigned*)&lo)[1], ((const unsigned*)&hi)[0], ((const unsigned*)&hi)[1]};
     }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(img + offb[t]));
+      const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(img + offb[t] + 16 * 256));
+      b[t] = u32x4{((const unsigned*)&lo)[0], ((const unsigned*)&lo)[1], ((const unsigned*)&hi)[0], ((const unsigned*)&hi)[1]};
+    }
+    stage(i + R1_RING - 1);                   // into the slot stage i - 1 used; its address arithmetic runs under the LDS latency
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&a[ii]), *reinterpret_cast<bf16x8*>(&b[j]),
+                                                             acc[ii][j], 0, 0, 0);
   }
   wg_wait_vm<0>();  // the zero stages issued past the last tile
-  float* part = p.partial + (((size_t)blockIdx.y * gridDim.z + blockIdx.z) * gridDim.x + blockIdx.x) * (BCO * BCI);
+  float* part = p.partial + (((size_t)blockIdx.y * gridDim.z + blockIdx.z) * (2 * gridDim.x) + blockIdx.x * 2 + kh2) * (BCO * BCI);
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -804,7 +804,7 @@ __global__ __launch_bounds__((R3Geo<S, BCI>::NW * 64)) void wgrad_k3_ring_kernel
     WG_ACC(aW, tq0, tq1);
     __builtin_amdgcn_s_barrier();
     WG_ACC(aB, tq0, tq1);
-    stage(i + G::RING - 1);   // into the ring slot stage i - 1 used
+    stage(i + G::RING - 1);   // into the ring slot stage i - 1 used (issued after the tile's products instead: no faster)
     WG_ACC(aS, tq0, tq1);
     const char* const zt = wsm_r3 + (size_t)(i % G::RING) * G::STAGE;
     const char* const xt = zt + G::NZC * 16;
@@ -1394,13 +1394,13 @@ static int launch_wgrad_bf16_k1(WgradParams& p, int accumulate, void* ws, size_t
   if (wgs < 1) wgs = 1;
   const long nst = (P + R1_NPX - 1) / R1_NPX;
   if (wgs > nst) wgs = nst;
-  const size_t need = wgrad_partial_bytes(bco, bci, (int)wgs, BCO, BCI, 1);
+  const size_t need = wgrad_partial_bytes(bco, bci, 2 * (int)wgs, BCO, BCI, 1);   // two pixel halves per workgroup
   UPA_CHECK_ARG(ws && ws_bytes >= need, "wgrad: workspace too small (%zu < %zu bytes)", ws_bytes, need);
   p.partial = (float*)ws;
   auto kern = wgrad_k1_ring_kernel;
   (void)upa_full_lds<wgrad_k1_ring_kernel>();
-  hipLaunchKernelGGL(kern, dim3((unsigned)wgs, bco, bci), dim3(256), (size_t)R1_RING * R1_STAGE, s, p);
-  launch_wgrad_reduce(p.partial, (int)wgs, bco, bci, BCO, BCI, 1, p.dw, p.Cout, p.Cin, accumulate, s);
+  hipLaunchKernelGGL(kern, dim3((unsigned)wgs, bco, bci), dim3(R1_NW * 64), (size_t)R1_RING * R1_STAGE, s, p);
+  launch_wgrad_reduce(p.partial, 2 * (int)wgs, bco, bci, BCO, BCI, 1, p.dw, p.Cout, p.Cin, accumulate, s);
   UPA_LAUNCH_CHECK();
   return UPA_OK;
 }
@@ -1474,7 +1474,7 @@ extern "C" size_t upa_conv2d_wgrad_workspace_bytes(int cin, int cout, int k) {
     const int B = Bs[b];
     const int bco = cdiv(cout, B), bci = cdiv(cin, B);
     int wgs = (k == 3 && B == 64 ? 1024 : 256) / (bco * bci);
-    if (wgs < 1) wgs = 1;
+    if (wgs < 2) wgs = 2;   // the pointwise ring kernel leaves two partial blocks per workgroup
     const size_t n = wgrad_partial_bytes(bco, bci, wgs, B, B, k);
     if (n > best) best = n;
   }
