@@ -231,22 +231,27 @@ def test_pool_upsample_backward(dtype):
     from ultralytics_pro_amd.engine import runtime as R
     x = P.uniform("px", (2, 16, 9, 11), -1, 1)
     x = (x * 4).round() / 4  # plenty of ties: the first-maximum rule matters
-    xr = x.clone().requires_grad_(True)
-    ref = F.max_pool2d(xr, 5, 1, 2)
-    dy = P.uniform("pdy", tuple(ref.shape), -1, 1)
-    if dtype == torch.bfloat16:
-        dy = bf16_round(dy)
-    ref.backward(dy)
-    xd, dyd = to_dev_nhwc(x, dtype), to_dev_nhwc(dy, dtype)  # keep the device tensors alive: views are raw pointers
-    vx, vdy = R.view_of(xd), R.view_of(dyd)
-    dx = R.alloc_nhwc(2, 16, 9, 11, dtype, DEV)
-    vdx = R.view_of(dx)
     st = L.current_stream(DEV)
-    nws = L.lib().upa_maxpool2d_bwd_workspace_bytes(2, 9, 11, 16, 5, 1, 2)
-    wsb = torch.empty(nws, dtype=torch.uint8, device=DEV)
-    L.check(L.lib().upa_maxpool2d_bwd(vx.ptr, vdy.ptr, 2, 9, 11, 16, vx.ld, vdy.ld, 5, 1, 2, vdx.ptr, vdx.ld, 0, vx.dtype,
-                                      wsb.data_ptr(), nws, st))
-    assert _rel(to_cpu_nchw(dx), xr.grad) <= (1e-6 if dtype == torch.float32 else 2e-2)
+    for k, pad in ((5, 2), (3, 1)):  # 5 / 1 / 2 in bf16: the unrolled SPPF kernels; everything else: the generic window walk
+        xr = x.clone().requires_grad_(True)
+        ref = F.max_pool2d(xr, k, 1, pad)
+        dy = P.uniform(f"pdy{k}", tuple(ref.shape), -1, 1)
+        if dtype == torch.bfloat16:
+            dy = bf16_round(dy)
+        ref.backward(dy)
+        xd, dyd = to_dev_nhwc(x, dtype), to_dev_nhwc(dy, dtype)  # keep the device tensors alive: views are raw pointers
+        vx, vdy = R.view_of(xd), R.view_of(dyd)
+        dx = R.alloc_nhwc(2, 16, 9, 11, dtype, DEV)
+        vdx = R.view_of(dx)
+        nws = L.lib().upa_maxpool2d_bwd_workspace_bytes(2, 9, 11, 16, k, 1, pad)
+        wsb = torch.empty(nws, dtype=torch.uint8, device=DEV)
+        L.check(L.lib().upa_maxpool2d_bwd(vx.ptr, vdy.ptr, 2, 9, 11, 16, vx.ld, vdy.ld, k, 1, pad, vdx.ptr, vdx.ld, 0, vx.dtype,
+                                          wsb.data_ptr(), nws, st))
+        assert _rel(to_cpu_nchw(dx), xr.grad) <= (1e-6 if dtype == torch.float32 else 2e-2)
+        if dtype == torch.bfloat16 and k == 5:  # ... and accumulating into an existing gradient
+            L.check(L.lib().upa_maxpool2d_bwd(vx.ptr, vdy.ptr, 2, 9, 11, 16, vx.ld, vdy.ld, k, 1, pad, vdx.ptr, vdx.ld, 1, vx.dtype,
+                                              wsb.data_ptr(), nws, st))
+            assert _rel(to_cpu_nchw(dx), 2 * xr.grad) <= 3e-2
     # nearest 2x upsample backward
     u = P.uniform("ux", (2, 16, 5, 7), -1, 1).requires_grad_(True)
     up = F.interpolate(u, scale_factor=2, mode="nearest")

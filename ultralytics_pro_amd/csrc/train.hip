@@ -1057,6 +1057,102 @@ __global__ void maxpool_bwd_kernel(const unsigned char* arg, const char* dy, int
   }
 }
 
+// k = 5, stride 1, pad 2 (SPPF's three pools, nn/modules/block.py:167-181), bf16: the two kernels above with the window unrolled -
+// all 25 loads of a thread in flight, 32-bit indices, no divisions in the loop.  (The generic kernels walk the window with
+// dependent branches: 35 + 31 us per pool for a 6.5 MB map; same scan order, same results.)
+__global__ __launch_bounds__(256) void maxpool5_argmax_kernel(const char* x, int n, int h, int w, int cg, int ldx, unsigned char* arg) {
+  const unsigned total = (unsigned)n * h * w * cg;
+  for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    unsigned t = idx;
+    const int g = (int)(t % (unsigned)cg); t /= (unsigned)cg;
+    const int ox = (int)(t % (unsigned)w); t /= (unsigned)w;
+    const int oy = (int)(t % (unsigned)h);
+    const int b = (int)(t / (unsigned)h);
+    // clamped row / column byte offsets once (5 + 5 multiplies instead of 25 address computations)
+    unsigned ro[5], co[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      const int yy = oy - 2 + q, xx = ox - 2 + q;
+      const int yc = yy < 0 ? 0 : (yy >= h ? h - 1 : yy), xc = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
+      ro[q] = (unsigned)((b * h + yc) * w) * (unsigned)(ldx * 2);
+      co[q] = (unsigned)xc * (unsigned)(ldx * 2) + (unsigned)g * 16u;
+    }
+    u32x4 v[25];
+#pragma unroll
+    for (int kk = 0; kk < 25; ++kk) v[kk] = *reinterpret_cast<const u32x4*>(x + ro[kk / 5] + co[kk % 5]);
+    // strict > in scan order from -inf, the index starting at the first tap inside the image: what the generic kernel's
+    // "first valid, then strictly greater" rule gives (32-bit index registers: byte-sized ones tripled the instruction count)
+    float best[8];
+    int bi[8];
+    const int first = (oy < 2 ? 2 - oy : 0) * 5 + (ox < 2 ? 2 - ox : 0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; bi[e] = first; }
+#pragma unroll
+    for (int kk = 0; kk < 25; ++kk) {
+      const int yy = oy - 2 + kk / 5, xx = ox - 2 + kk % 5;
+      const bool in = yy >= 0 && yy < h && xx >= 0 && xx < w;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const unsigned wd = v[kk][e >> 1];
+        const float f = __uint_as_float((e & 1) ? (wd & 0xFFFF0000u) : (wd << 16));
+        const bool up = in && f > best[e];
+        best[e] = up ? f : best[e];
+        bi[e] = up ? kk : bi[e];
+      }
+    }
+    const unsigned lo = (unsigned)bi[0] | ((unsigned)bi[1] << 8) | ((unsigned)bi[2] << 16) | ((unsigned)bi[3] << 24);
+    const unsigned hi = (unsigned)bi[4] | ((unsigned)bi[5] << 8) | ((unsigned)bi[6] << 16) | ((unsigned)bi[7] << 24);
+    *reinterpret_cast<u32x2*>(arg + (size_t)idx * 8) = u32x2{lo, hi};   // [n][h][w][c] bytes, c = 8 cg
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool5_bwd_kernel(const unsigned char* arg, const char* dy, int n, int h, int w, int cg, int lddy,
+                                                            char* dx, int lddx, int accumulate) {
+  const unsigned total = (unsigned)n * h * w * cg;
+  for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    unsigned t = idx;
+    const int g = (int)(t % (unsigned)cg); t /= (unsigned)cg;
+    const int ix = (int)(t % (unsigned)w); t /= (unsigned)w;
+    const int iy = (int)(t % (unsigned)h);
+    const int b = (int)(t / (unsigned)h);
+    unsigned ra[5], ca[5], rd[5], cd[5];   // clamped row / column byte offsets into arg and dy
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      const int oy = iy + 2 - q, ox = ix + 2 - q;
+      const int yc = oy < 0 ? 0 : (oy >= h ? h - 1 : oy), xc = ox < 0 ? 0 : (ox >= w ? w - 1 : ox);
+      const unsigned row = (unsigned)((b * h + yc) * w);
+      ra[q] = row * (unsigned)(cg * 8);
+      ca[q] = (unsigned)xc * (unsigned)(cg * 8) + (unsigned)g * 8u;
+      rd[q] = row * (unsigned)(lddy * 2);
+      cd[q] = (unsigned)xc * (unsigned)(lddy * 2) + (unsigned)g * 16u;
+    }
+    u32x2 a8[25];
+    u32x4 d[25];
+#pragma unroll
+    for (int kk = 0; kk < 25; ++kk) {   // the window (oy, ox) = (iy + 2 - kh, ix + 2 - kw) elected this pixel if its index is kk
+      a8[kk] = *reinterpret_cast<const u32x2*>(arg + ra[kk / 5] + ca[kk % 5]);
+      d[kk] = *reinterpret_cast<const u32x4*>(dy + rd[kk / 5] + cd[kk % 5]);
+    }
+    float acc[8];
+    char* dst = dx + ((((size_t)b * h + iy) * w + ix) * lddx + g * 8) * 2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    if (accumulate) load16<bf16_t>(dst, acc);
+#pragma unroll
+    for (int kk = 0; kk < 25; ++kk) {
+      const int oy = iy + 2 - kk / 5, ox = ix + 2 - kk % 5;
+      if (oy < 0 || oy >= h || ox < 0 || ox >= w) continue;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const unsigned ab = (a8[kk][e >> 2] >> (8 * (e & 3))) & 255u;
+        const unsigned wd = d[kk][e >> 1];
+        if (ab == (unsigned)kk) acc[e] += __uint_as_float((e & 1) ? (wd & 0xFFFF0000u) : (wd << 16));
+      }
+    }
+    store16<bf16_t>(dst, acc);
+  }
+}
+
 // ---- data gradient of a 3x3 stride-2 pad-1 convolution by output parity ------------------------------------------------
 // dx[2i+py][2j+px] only receives the taps with kh = py+1 (mod 2), kw = px+1 (mod 2): four small stride-1 correlations
 // over dz with 1, 2, 2 and 4 taps instead of a 9-tap correlation over a 4x zero-inserted dz.  Each phase is expressed as a
@@ -1556,7 +1652,12 @@ extern "C" int upa_maxpool2d_bwd(const void* x, const void* dy, int n, int h, in
   const long tot_o = (long)n * oh * ow * (c / E), tot_i = (long)n * h * w * (c / E);
   unsigned char* arg = (unsigned char*)workspace;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == UPA_BF16) {
+  if (dtype == UPA_BF16 && k == 5 && stride == 1 && pad == 2 &&
+      (long)n * h * w * (ldx > lddy ? ldx : lddy) * 2 < (1L << 32) && (long)n * h * w * c < (1L << 32)) {   // 32-bit byte offsets
+    hipLaunchKernelGGL(maxpool5_argmax_kernel, dim3(grid_for(tot_o)), dim3(256), 0, s, (const char*)x, n, h, w, c / 8, ldx, arg);
+    hipLaunchKernelGGL(maxpool5_bwd_kernel, dim3(grid_for(tot_i)), dim3(256), 0, s, arg, (const char*)dy, n, h, w, c / 8, lddy, (char*)dx,
+                       lddx, accumulate);
+  } else if (dtype == UPA_BF16) {
     hipLaunchKernelGGL((maxpool_argmax_kernel<bf16_t>), dim3(grid_for(tot_o)), dim3(256), 0, s, (const char*)x, n, h, w, c, ldx, k, stride,
                        pad, oh, ow, arg);
     hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t>), dim3(grid_for(tot_i)), dim3(256), 0, s, arg, (const char*)dy, n, h, w, c, lddy, k,
