@@ -1105,6 +1105,53 @@ LINEAR_CASES = [
 ]
 
 
+TOPK_CASES = [
+    # levels (h*w each), classes, batch, k, score pattern
+    ([6400, 1600, 400], 80, 3, 300, "random"),      # yolov3-rtdetr at 640 x 640: radix select + sort of the survivors
+    ([400, 100, 25], 80, 2, 300, "ties"),           # quantised scores: many equal keys around the k-th
+    ([6400, 1600, 400], 80, 2, 300, "flat"),        # every token the same score: more candidates than the cap -> full sort
+    ([100, 25], 6, 2, 50, "random"),                # class count not a multiple of four: scalar row reads
+    ([64], 4, 1, 64, "random"),                     # k = all tokens
+]
+
+
+@pytest.mark.parametrize("case", TOPK_CASES, ids=[f"T{sum(c[0])}_nc{c[1]}_b{c[2]}_k{c[3]}_{c[4]}" for c in TOPK_CASES])
+def test_topk_tokens_matches_stable_sort(case):
+    """upa_topk_tokens (RTDETRDecoder._get_decoder_input, nn/modules/head.py: topk of the best-class score per token) against a
+    stable descending sort of the same scores on the CPU: the same tokens in the same order (ties by token index), and the
+    row of each token in the level-major token matrix."""
+    import ctypes as C
+    from tests.hip_utils import DEV
+    from ultralytics_pro_amd import _lib as L
+    hw, nc, B, K, pattern = case
+    T = sum(hw)
+    g = torch.Generator().manual_seed(T + nc)
+    rows_total = B * T
+    sc = torch.randn(rows_total, nc, generator=g) * 3
+    if pattern == "ties":
+        sc = (sc * 2).round() / 2
+    elif pattern == "flat":
+        sc = torch.zeros(rows_total, nc)
+    scd = sc.to(DEV)
+    out_rows = torch.zeros(B * K, dtype=torch.int32, device=DEV)
+    out_tok = torch.zeros(B * K, dtype=torch.int32, device=DEV)
+    hw_arr = (C.c_int32 * len(hw))(*hw)
+    L.check(L.lib().upa_topk_tokens(scd.data_ptr(), nc, len(hw), hw_arr, B, K, out_rows.data_ptr(), out_tok.data_ptr(),
+                                    L.current_stream(DEV)), "topk_tokens")
+    torch.cuda.synchronize()
+    # level-major token matrix: level l occupies rows row0[l] + b * hw[l] + p
+    row0, tok0 = [], []
+    r = t = 0
+    for n in hw:
+        row0.append(r); tok0.append(t); r += n * B; t += n
+    for b in range(B):
+        rows_of_tok = torch.cat([torch.arange(hw[l]) + row0[l] + b * hw[l] for l in range(len(hw))])
+        best = sc[rows_of_tok].max(1).values
+        order = torch.sort(best, descending=True, stable=True).indices[:K]
+        assert torch.equal(out_tok[b * K:(b + 1) * K].cpu().long(), order)
+        assert torch.equal(out_rows[b * K:(b + 1) * K].cpu().long(), rows_of_tok[order])
+
+
 @pytest.mark.parametrize("case", LINEAR_CASES, ids=[f"m{c[0]}_k{c[1]}_n{c[2]}_a{c[3]}{'_res' if c[4] else ''}" for c in LINEAR_CASES])
 def test_linear_f32_rows(case):
     """`upa_linear` (exact-f32 MFMA) vs float64 `x @ W^T + b` -> act -> + residual (nn.Linear / MLP of the RT-DETR head,

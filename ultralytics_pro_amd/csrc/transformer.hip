@@ -95,42 +95,134 @@ struct LevelTable {
   int tok0[4];  // first reference token index of the level
 };
 
+// One workgroup per image.  (1) key of every token = (descending best-class score, token index), four lanes per token with
+// 16-byte loads when nc % 4 == 0; (2) the K smallest keys: radix select of the K-th score (four 8-bit passes over the LDS
+// keys), the tokens at or above it compacted and bitonic-sorted (<= TOPK_CAP of them; ties included, the index half of the
+// key orders them); more candidates than that (a flat score map) take the full sort of all tokens.  (The first form sorted
+// all 16384 padded keys - 105 barrier-separated passes - and read the class rows one float at a time: 357 us per call.)
+constexpr int TOPK_CAP = 2048;
+
 __global__ __launch_bounds__(1024) void topk_tokens_kernel(const float* scores, int nc, LevelTable lt, int B, int T, int K,
                                                            int npad, int32_t* out_rows, int32_t* out_tok) {
-  extern __shared__ __attribute__((aligned(16))) u64 keys[];
+  extern __shared__ __attribute__((aligned(16))) u64 keys[];   // [max(npad, T + TOPK_CAP)]
+  __shared__ int hist[256];
+  __shared__ unsigned s_prefix, s_remaining;
+  __shared__ int s_count;
   const int b = blockIdx.x;
-  for (int t = threadIdx.x; t < npad; t += 1024) {
-    u64 key = ~0ull;
-    if (t < T) {
+  const int tid = threadIdx.x;
+  const bool vec = (nc & 3) == 0 && ((uintptr_t)scores & 15) == 0;
+  if (vec) {
+    const int sub = tid & 3, nq = nc >> 2;
+    for (int t0 = 0; t0 < T; t0 += 256) {
+      const int t = t0 + (tid >> 2);
+      float m = -INFINITY;
+      if (t < T) {
+        int l = 0;
+        while (l + 1 < lt.n_levels && t >= lt.tok0[l + 1]) ++l;
+        const size_t row = (size_t)lt.row0[l] + (size_t)b * lt.hw[l] + (t - lt.tok0[l]);
+        const f32x4* s4 = reinterpret_cast<const f32x4*>(scores + row * nc);
+        for (int q = sub; q < nq; q += 4) {
+          const f32x4 v = s4[q];
+          m = fmaxf(m, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+        }
+      }
+      m = fmaxf(m, __shfl_xor(m, 1));
+      m = fmaxf(m, __shfl_xor(m, 2));
+      if (t < T && sub == 0) {
+        unsigned u = __float_as_uint(m);   // order-preserving float -> uint (handles negatives), descending
+        u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+        keys[t] = ((u64)(~u) << 32) | (unsigned)t;
+      }
+    }
+  } else {
+    for (int t = tid; t < T; t += 1024) {
       int l = 0;
       while (l + 1 < lt.n_levels && t >= lt.tok0[l + 1]) ++l;
-      const int p = t - lt.tok0[l];
-      const size_t row = (size_t)lt.row0[l] + (size_t)b * lt.hw[l] + p;
+      const size_t row = (size_t)lt.row0[l] + (size_t)b * lt.hw[l] + (t - lt.tok0[l]);
       const float* s = scores + row * nc;
       float m = s[0];
       for (int c = 1; c < nc; ++c) m = fmaxf(m, s[c]);
-      // order-preserving float -> uint (handles negatives), descending
       unsigned u = __float_as_uint(m);
       u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-      key = ((u64)(~u) << 32) | (unsigned)t;
+      keys[t] = ((u64)(~u) << 32) | (unsigned)t;
     }
-    keys[t] = key;
+  }
+  if (tid == 0) { s_prefix = 0u; s_remaining = (unsigned)K; s_count = 0; }
+  __syncthreads();
+  // ---- the K-th smallest score word (the high half of the keys)
+  unsigned mask = 0u;
+  for (int pass = 3; pass >= 0; --pass) {
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    const unsigned prefix = s_prefix;
+    for (int t = tid; t < T; t += 1024) {
+      const unsigned hi = (unsigned)(keys[t] >> 32);
+      if ((hi & mask) == prefix) atomicAdd(&hist[(hi >> (8 * pass)) & 255u], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned rem = s_remaining, acc = 0u;
+      int bin = 0;
+      for (; bin < 255; ++bin) {
+        const unsigned h = (unsigned)hist[bin];
+        if (acc + h >= rem) break;
+        acc += h;
+      }
+      s_remaining = rem - acc;
+      s_prefix = prefix | ((unsigned)bin << (8 * pass));
+    }
+    mask |= 255u << (8 * pass);
+    __syncthreads();
+  }
+  const unsigned thr = s_prefix;
+  // ---- candidates: every token whose score word is <= the K-th one (ties included)
+  u64* cand = keys + T;
+  for (int t = tid; t < T; t += 1024) {
+    const u64 k = keys[t];
+    if ((unsigned)(k >> 32) <= thr) {
+      const int slot = atomicAdd(&s_count, 1);
+      if (slot < TOPK_CAP) cand[slot] = k;
+    }
   }
   __syncthreads();
-  for (int k = 2; k <= npad; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = threadIdx.x; t < (npad >> 1); t += 1024) {
-        const int i = 2 * t - (t & (j - 1));
-        const int l = i + j;
-        const bool up = (i & k) == 0;
-        const u64 x = keys[i], y = keys[l];
-        if ((x > y) == up) { keys[i] = y; keys[l] = x; }
+  const int ncand = s_count;
+  u64* sorted = cand;
+  if (ncand <= TOPK_CAP) {
+    int n2 = 2;
+    while (n2 < ncand) n2 <<= 1;
+    for (int t = ncand + tid; t < n2; t += 1024) cand[t] = ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= n2; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int t = tid; t < (n2 >> 1); t += 1024) {
+          const int i = 2 * t - (t & (j - 1));
+          const int l = i + j;
+          const bool up = (i & k) == 0;
+          const u64 x = cand[i], y = cand[l];
+          if ((x > y) == up) { cand[i] = y; cand[l] = x; }
+        }
+        __syncthreads();
       }
-      __syncthreads();
+    }
+  } else {   // a flat score map: sort everything
+    sorted = keys;
+    for (int t = T + tid; t < npad; t += 1024) keys[t] = ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= npad; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int t = tid; t < (npad >> 1); t += 1024) {
+          const int i = 2 * t - (t & (j - 1));
+          const int l = i + j;
+          const bool up = (i & k) == 0;
+          const u64 x = keys[i], y = keys[l];
+          if ((x > y) == up) { keys[i] = y; keys[l] = x; }
+        }
+        __syncthreads();
+      }
     }
   }
-  for (int q = threadIdx.x; q < K; q += 1024) {
-    const int t = (int)(keys[q] & 0xFFFFFFFFull);
+  for (int q = tid; q < K; q += 1024) {
+    const int t = (int)(sorted[q] & 0xFFFFFFFFull);
     int l = 0;
     while (l + 1 < lt.n_levels && t >= lt.tok0[l + 1]) ++l;
     out_rows[(size_t)b * K + q] = lt.row0[l] + b * lt.hw[l] + (t - lt.tok0[l]);
@@ -156,7 +248,7 @@ extern "C" int upa_topk_tokens(const float* scores, int nc, int n_levels, const 
   UPA_CHECK_ARG(k <= T, "topk_tokens: k > tokens");
   int npad = 2;
   while (npad < T) npad <<= 1;
-  const size_t lds = (size_t)npad * 8;
+  const size_t lds = (size_t)(npad > T + TOPK_CAP ? npad : T + TOPK_CAP) * 8;
   UPA_CHECK_ARG(lds <= 150 * 1024, "topk_tokens: %d tokens do not fit LDS", T);
   (void)upa_full_lds<topk_tokens_kernel>();
   hipLaunchKernelGGL(topk_tokens_kernel, dim3((unsigned)b), dim3(1024), lds, (hipStream_t)stream, scores, nc, lt, b, T, k,
