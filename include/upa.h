@@ -117,6 +117,12 @@ int upa_conv_variant(int n, int h, int w, int cin, int cout, int k, int stride, 
 int upa_bottleneck_pair(const void* x, int n, int h, int w, int c, int ldx, const void* w1_packed, const float* b1,
                         const void* w2_packed, const float* b2, void* y, int ldy, int residual, int act, int dtype,
                         const upa_opts* opts, void* stream);
+/* The same with the hidden width given: cmid = c (above) or c / 2 for c = 64 - the e = 0.5 Bottleneck of the darknet backbones
+ * (block.py:644-668 with the default e; cfg/models/v3/Detect/yolov3-rtdetr.yaml: Bottleneck(64) at 320 x 320).
+ * w1_packed = upa_pack_conv_weight(c -> cmid, k = 3), w2_packed = (cmid -> c, k = 3). */
+int upa_bottleneck_pair_e(const void* x, int n, int h, int w, int c, int cmid, int ldx, const void* w1_packed, const float* b1,
+                          const void* w2_packed, const float* b2, void* y, int ldy, int residual, int act, int dtype,
+                          const upa_opts* opts, void* stream);
 
 
 /* First layer: reads the model input NCHW (f32 or bf16, 1..4 channels) directly, writes NHWC.   conv.py:188-197

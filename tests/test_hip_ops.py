@@ -194,6 +194,60 @@ def test_conv_ws3_kernel(case):
     assert_bf16_close(y, ref, f"conv_ws3{case}")
 
 
+PAIR_HALF_CASES = [
+    # H, W, N, shortcut  (Bottleneck(64, 64, shortcut, k=(3,3), e=0.5): 64 -> 32 -> 64, the darknet block of yolov3-rtdetr rows 2 / 4)
+    (40, 40, 2, True),
+    (33, 47, 3, False),    # odd sizes, ragged tiles
+    (9, 5, 1, True),       # smaller than one tile
+    (14, 14, 1, True),     # exactly one tile
+    (96, 96, 2, True),     # many tiles per image
+]
+
+
+@pytest.mark.parametrize("case", PAIR_HALF_CASES, ids=[f"{c[0]}x{c[1]}n{c[2]}{'r' if c[3] else ''}" for c in PAIR_HALF_CASES])
+def test_bottleneck_pair_half_width_kernel(case):
+    """`upa_bottleneck_pair_e` with cmid = c / 2 (bf16): x + cv2(cv1(x)) of an e = 0.5 Bottleneck (block.py:644-668) as one kernel with
+    the 32-channel intermediate tile in LDS, vs the oracle Bottleneck on bf16-rounded inputs with the intermediate rounded to bf16 as
+    the kernel stores it, and vs the product's own two-launch path."""
+    from tests.hip_utils import DEV, assert_bf16_close, bf16_round, bf16_weight_oracle, to_cpu_nchw, to_dev_nhwc
+    from ultralytics_pro_amd import _lib as L
+    from ultralytics_pro_amd.engine import runtime as R
+    pm, _ = _mods()
+    H, W, N, sc = case
+    c = 64
+    o, m = _pair(om.Bottleneck, pm.Bottleneck, (c, c, sc, 1, (3, 3), 0.5), "pairh")
+    assert m.cv1.conv.out_channels == 32
+    x = bf16_round(P.uniform(f"pairh{case}", (N, c, H, W), -1, 1))
+    with torch.no_grad():
+        ob = bf16_weight_oracle(o)
+        t = bf16_round(ob.cv1(x))
+        ref = ob.cv2(t) + (x if sc else 0)
+    buf = R.alloc_nhwc(N, 3 * c, H, W, torch.bfloat16, DEV)
+    buf.zero_()
+    xin = buf[:, c:2 * c]
+    xin.copy_(to_dev_nhwc(x, torch.bfloat16))
+    with torch.no_grad():
+        # the kernel itself (the module would fall back silently if the dispatch refused)
+        p1 = m.cv1._packed(m.cv1.conv, m.cv1.bn, DEV, torch.bfloat16, False)
+        p2 = m.cv2._packed(m.cv2.conv, m.cv2.bn, DEV, torch.bfloat16, False)
+        vx, vy = R.view_of(xin), R.view_of(buf[:, 2 * c:])
+        rc = L.lib().upa_bottleneck_pair_e(vx.ptr, vx.n, vx.h, vx.w, vx.c, 32, vx.ld, p1.w.data_ptr(), p1.bias.data_ptr(),
+                                           p2.w.data_ptr(), p2.bias.data_ptr(), vy.ptr, vy.ld, int(sc), L.ACT_SILU, vx.dtype,
+                                           R.opts_ptr(), L.current_stream(DEV))
+        assert rc != L.UPA_EUNSUPPORTED, "64 -> 32 -> 64 must be inside the fused form"
+        L.check(rc, "bottleneck_pair_e")
+        y = to_cpu_nchw(buf[:, 2 * c:])
+        m.fuse_pair = True
+        y1 = to_cpu_nchw(m(xin))          # the module's own dispatch: the same kernel
+        m.fuse_pair = False
+        y2 = to_cpu_nchw(m(xin))          # two launches
+    scale = max(1.0, ref.abs().max().item())
+    assert_bf16_close(y, ref, f"pairh{case}", abs_=2.0 ** -7)
+    assert torch.equal(y1, y)
+    assert (y - y2).abs().max().item() <= 2e-2 * scale  # one bf16 ulp of the output
+    assert float(to_cpu_nchw(buf[:, :c]).abs().max()) == 0.0  # nothing written outside the output slice
+
+
 PAIR_CASES = [
     # c, H, W, N, shortcut  (Bottleneck(c, c, shortcut, k=(3,3), e=1.0) as one kernel, csrc/conv_pair.hip)
     (64, 40, 40, 2, True),     # 14 x 14 tiles, 3 x 3 per image, ragged right / bottom tiles, residual

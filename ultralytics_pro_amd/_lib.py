@@ -114,6 +114,7 @@ PROTOTYPES = {
     "upa_conv2d_bias_act": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _op, _vp]),
     "upa_conv_variant": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _op]),
     "upa_bottleneck_pair": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _op, _vp]),
+    "upa_bottleneck_pair_e": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _op, _vp]),
     "upa_stem_packed_weight_bytes": (_sz, [_i, _i, _i]),
     "upa_pack_stem_weight": (_i, [_vp, _i, _i, _i, _vp]),
     "upa_conv2d_stem_nchw": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _op, _vp]),

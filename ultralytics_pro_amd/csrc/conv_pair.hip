@@ -39,13 +39,19 @@ __device__ __forceinline__ float pair_act(float v) {
 // cat(y0, y1, b) is three 32-channel k-steps: y0 straight from global memory in B-fragment order, y1 = this kernel's own input
 // (the halo tile's centre, still in LDS), b = the bf16-packed accumulators (the D layout of two 16-channel tiles IS an MFMA B
 // operand in the k order of upa_pack_tail_weight, see conv_big.hip).  b is never written; one launch and 2 x 13 MB less.
-template <int CK, bool RES, bool CV2 = false>
+// CKM < CK (round 4): the e = 0.5 Bottleneck of the darknet backbones, C -> C / 2 -> C (cfg/models/v3/Detect/yolov3-rtdetr.yaml rows 2, 4:
+// Bottleneck(64) at 320 x 320, block.py:644-668 with the default e): CKM k-tiles in the mid tile, CK in the halo and the output; a tap's weight
+// slab has CK * CKM * 2 fragments in either stage.
+template <int CK, bool RES, bool CV2 = false, int CKM = CK>
 __global__ __launch_bounds__(512, 4) void conv_pair_kernel(const PairParams p) {
-  static_assert(!CV2 || CK == 1, "the cv2 tail is built for 32-channel Bottlenecks");
-  constexpr int NT = CK * 2;
-  constexpr int G16 = CK * 4;              // 16-byte groups per pixel
-  constexpr int PB = G16 * 16;             // bytes per pixel in the LDS images
-  constexpr int WBUF = CK * NT * 1024;     // one tap's weight slab
+  static_assert(!CV2 || (CK == 1 && CKM == 1), "the cv2 tail is built for 32-channel Bottlenecks");
+  constexpr int NT = CK * 2;               // n-tiles of the output (stage 2)
+  constexpr int NTM = CKM * 2;             // n-tiles of the mid tile (stage 1)
+  constexpr int NTX = NT > NTM ? NT : NTM;
+  constexpr int G16 = CK * 4;              // 16-byte groups per pixel of the halo image
+  constexpr int PB = G16 * 16;             // bytes per pixel of the halo image
+  constexpr int G16M = CKM * 4, PBM = G16M * 16;   // ... of the mid tile
+  constexpr int WBUF = CK * NTM * 1024;    // one tap's weight slab (= CKM * NT fragments in stage 2)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -62,11 +68,12 @@ __global__ __launch_bounds__(512, 4) void conv_pair_kernel(const PairParams p) {
   const int IH = p.TH + 4, IW = p.TW + 4, MH = p.TH + 2, MW = p.TW + 2;
   const int IWp = p.IWp, MWp = p.MWp;  // LDS pitches (>= IW, MW): chosen so that m-tiles straddling tile rows stay conflict-free
 
-  auto swz = [](int pix) __attribute__((always_inline)) { return (CK == 1 ? (pix >> 1) : pix) & (G16 - 1); };
+  auto swz = [](int pix) __attribute__((always_inline)) { return (CK == 1 ? (pix >> 1) : pix) & (G16 - 1); };        // halo image
+  auto swzm = [](int pix) __attribute__((always_inline)) { return (CKM == 1 ? (pix >> 1) : pix) & (G16M - 1); };  // mid tile
 
   const int haloItems = IH * IWp * G16;
   const int haloPadded = (haloItems + 63) & ~63;
-  const int midBytes = ((MH * MWp * PB) + 1023) & ~1023;
+  const int midBytes = ((MH * MWp * PBM) + 1023) & ~1023;
   char* hal = smem;
   char* mid = smem + (size_t)haloPadded * 16;
   char* wbuf = mid + midBytes;
@@ -88,23 +95,26 @@ __global__ __launch_bounds__(512, 4) void conv_pair_kernel(const PairParams p) {
   // weight slab of one tap: CK * NT fragments of 1 KiB, wave w brings fragments w, w + 8, ...
   auto stage_w = [&](const char* w, int tap, int b) __attribute__((always_inline)) {
 #pragma unroll
-    for (int f0 = 0; f0 < CK * NT; f0 += 8) {
+    for (int f0 = 0; f0 < CK * NTM; f0 += 8) {
       const int f = f0 + wave;
-      if (f < CK * NT)
-        __builtin_amdgcn_global_load_lds((pgptr_t)(w + (((size_t)tap * CK * NT + f) * 64 + lane) * 16),
+      if (f < CK * NTM)
+        __builtin_amdgcn_global_load_lds((pgptr_t)(w + (((size_t)tap * CK * NTM + f) * 64 + lane) * 16),
                                          (plptr_t)(wbuf + b * WBUF + f * 1024), 16, 0, 0);
     }
   };
   stage_w(p.w1, 0, 0);
 
   // one conv over an LDS image: this wave's two m-tiles (pixel slots wave*32 .. +31) x all NT n-tiles
-  f32x4 acc[2][NT];
-  auto conv_stage = [&](const char* img, int imgW, const int (&pl0)[2], const char* wcur, const char* wnext, int& buf)
-      __attribute__((always_inline)) {
+  f32x4 acc[2][NTX];
+  // KT_ k-tiles of the image (CKI_ = the image's k-tiles per pixel record: its swizzle), NT_ n-tiles
+  auto conv_stage = [&](auto kt_c, auto nt_c, const char* img, int imgW, const int (&pl0)[2], const char* wcur, const char* wnext,
+                        int& buf) __attribute__((always_inline)) {
+    constexpr int KT_ = decltype(kt_c)::value, NT_ = decltype(nt_c)::value;
+    constexpr int PB_ = KT_ * 64;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NT_; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     int kh = 0, kw = 0;
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
@@ -118,20 +128,20 @@ __global__ __launch_bounds__(512, 4) void conv_pair_kernel(const PairParams p) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int pl = pl0[i] + tapshift;
-        paddr[i] = pl * PB;
-        pswz[i] = swz(pl);
+        paddr[i] = pl * PB_;
+        pswz[i] = (KT_ == 1 ? (pl >> 1) : pl) & (KT_ * 4 - 1);
       }
 #pragma unroll
-      for (int kt = 0; kt < CK; ++kt) {
-        u32x4 a[NT], b[2];
+      for (int kt = 0; kt < KT_; ++kt) {
+        u32x4 a[NT_], b[2];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) a[j] = *reinterpret_cast<const u32x4*>(wb + (kt * NT + j) * 1024);
+        for (int j = 0; j < NT_; ++j) a[j] = *reinterpret_cast<const u32x4*>(wb + (kt * NT_ + j) * 1024);
 #pragma unroll
         for (int i = 0; i < 2; ++i) b[i] = *reinterpret_cast<const u32x4*>(img + paddr[i] + (((kt * 4 + g) ^ pswz[i]) << 4));
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < NT; ++j)
+          for (int j = 0; j < NT_; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a[j]),
                                                                 *reinterpret_cast<const bf16x8*>(&b[i]), acc[i][j], 0, 0, 0);
       }
@@ -153,21 +163,21 @@ __global__ __launch_bounds__(512, 4) void conv_pair_kernel(const PairParams p) {
     pl1[i] = y_ < MH ? y_ * IWp + x_ : 0;
   }
   int buf = 0;
-  conv_stage(hal, IWp, pl1, p.w1, p.w2, buf);
+  conv_stage(std::integral_constant<int, CK>{}, std::integral_constant<int, NTM>{}, hal, IWp, pl1, p.w1, p.w2, buf);
   {
-    f32x4 bv[NT];
+    f32x4 bv[NTM];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) bv[j] = *reinterpret_cast<const f32x4*>(p.b1 + j * 16 + g * 4);
+    for (int j = 0; j < NTM; ++j) bv[j] = *reinterpret_cast<const f32x4*>(p.b1 + j * 16 + g * 4);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       if (my[i] >= MH) continue;
       const int gy = oy0 - 1 + my[i], gx = ox0 - 1 + mx[i];
       const bool inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
       const int mp = my[i] * MWp + mx[i];
-      char* row = mid + mp * PB;
-      const int sw = swz(mp);
+      char* row = mid + mp * PBM;
+      const int sw = swzm(mp);
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
+      for (int j = 0; j < NTM; ++j) {
         float v[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = inside ? pair_act<UPA_ACT_SILU>(acc[i][j][q] + bv[j][q]) : 0.f;
@@ -191,7 +201,7 @@ __global__ __launch_bounds__(512, 4) void conv_pair_kernel(const PairParams p) {
     tx[i] = x_;
     pl2[i] = y_ < p.TH ? y_ * MWp + x_ : 0;
   }
-  conv_stage(mid, MWp, pl2, p.w2, nullptr, buf);
+  conv_stage(std::integral_constant<int, CKM>{}, std::integral_constant<int, NT>{}, mid, MWp, pl2, p.w2, nullptr, buf);
 
   f32x4 bv[NT];
 #pragma unroll
@@ -289,6 +299,22 @@ __global__ __launch_bounds__(512, 4) void conv_pair_kernel(const PairParams p) {
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
+template <int CK, int CKM>
+int pair_launch_e(const PairParams& p, size_t lds, bool res, hipStream_t s) {
+  const dim3 grid((unsigned)((long)p.tilesX * p.tilesY * p.N));
+  if (res) {
+    auto kern = conv_pair_kernel<CK, true, false, CKM>;
+    if (upa_full_lds<(conv_pair_kernel<CK, true, false, CKM>)>() != hipSuccess) return UPA_ELAUNCH;
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, p);
+  } else {
+    auto kern = conv_pair_kernel<CK, false, false, CKM>;
+    if (upa_full_lds<(conv_pair_kernel<CK, false, false, CKM>)>() != hipSuccess) return UPA_ELAUNCH;
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, p);
+  }
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
 template <int CK>
 int pair_launch(const PairParams& p, size_t lds, bool res, hipStream_t s) {
   const dim3 grid((unsigned)((long)p.tilesX * p.tilesY * p.N));
@@ -319,7 +345,7 @@ int pair_launch(const PairParams& p, size_t lds, bool res, hipStream_t s) {
 }
 }  // namespace
 
-static int pair_impl(const void* x, int n, int h, int w, int c, int ldx, const void* w1_packed, const float* b1,
+static int pair_impl(const void* x, int n, int h, int w, int c, int cmid, int ldx, const void* w1_packed, const float* b1,
                      const void* w2_packed, const float* b2, void* y, int ldy, int residual, int act, int dtype,
                      const PairParams* cv2, const upa_opts* opts, void* stream) {
   UPA_CHECK_ARG(x && w1_packed && b1 && w2_packed && b2 && y && n > 0 && h > 0 && w > 0, "bottleneck_pair: bad args");
@@ -328,9 +354,13 @@ static int pair_impl(const void* x, int n, int h, int w, int c, int ldx, const v
   // 40x40 30.9-32.2 us against 11.5 + 12.2 us (288 one-per-CU workgroups = two rounds; 12 x 12 / 10 x 10 tiles no better),
   // step 0.773 -> 0.790 ms - the 64-channel form stays available but is not dispatched
   const int mode = UPA_OPT(opts, pair);
-  if (mode == 1 || (mode == 0 && c == 64) || (mode == 3 && c == 32) || dtype != UPA_BF16 || act != UPA_ACT_SILU || !(c == 32 || c == 64) || ldx % 8 != 0 || ldy % 8 != 0 ||
-      ((uintptr_t)x % 16) != 0 || ((uintptr_t)y % 16) != 0) {
-    upa_set_error("bottleneck_pair: outside the fused form (bf16, SiLU, C = 32 | 64)");
+  // C -> C / 2 -> C (64 -> 32 -> 64): dispatched unless pair = 1.  Measured on MI355X (yolov3-rtdetr bs 16, model.2 at 320 x 320): see
+  // DESIGN section 4
+  const bool half = c == 64 && cmid == 32;
+  const bool equal = cmid == c && (c == 32 || c == 64);
+  if (mode == 1 || (equal && ((mode == 0 && c == 64) || (mode == 3 && c == 32))) || dtype != UPA_BF16 || act != UPA_ACT_SILU ||
+      !(equal || half) || ldx % 8 != 0 || ldy % 8 != 0 || ((uintptr_t)x % 16) != 0 || ((uintptr_t)y % 16) != 0 || (half && cv2)) {
+    upa_set_error("bottleneck_pair: outside the fused form (bf16, SiLU, C = 32 | 64, or 64 -> 32 -> 64)");
     return UPA_EUNSUPPORTED;  // the caller runs the two convolutions separately
   }
   PairParams p;
@@ -338,8 +368,8 @@ static int pair_impl(const void* x, int n, int h, int w, int c, int ldx, const v
   p.x = (const char*)x; p.y = (char*)y; p.w1 = (const char*)w1_packed; p.w2 = (const char*)w2_packed; p.b1 = b1; p.b2 = b2;
   p.N = n; p.H = h; p.W = w; p.OH = h; p.OW = w; p.ldx = ldx; p.ldy = ldy;
   if (cv2) { p.y0 = cv2->y0; p.wc_std = cv2->wc_std; p.wc_b = cv2->wc_b; p.bc = cv2->bc; p.out = cv2->out; p.ldout = cv2->ldout; }
-  const int ck = c / 32;
-  const int pb = ck * 64;
+  const int ck = c / 32, ckm = cmid / 32;
+  const int pb = ckm * 64;   // bytes per pixel of the mid tile
   // output tile TH x TW with (TH+2)(TW+2) <= 256 mid pixels: fewest tiles per image, then the squarest
   const int fth64 = UPA_OPT(opts, pair_tile64), fth32 = UPA_OPT(opts, pair_tile32);  // square tile edge per width
   const int fth = c == 64 ? fth64 : fth32, ftw = fth;
@@ -364,16 +394,25 @@ static int pair_impl(const void* x, int n, int h, int w, int c, int ldx, const v
   p.magicTW = (unsigned)((0x100000000ULL + p.TW - 1) / p.TW);
   const size_t halo = (((size_t)IH * p.IWp * (ck * 4) + 63) & ~(size_t)63) * 16;
   const size_t mid = (((size_t)MH * p.MWp * pb) + 1023) & ~(size_t)1023;
-  const size_t lds = halo + mid + 2 * (size_t)(ck * ck * 2 * 1024) + 256;
+  const size_t lds = halo + mid + 2 * (size_t)(ck * ckm * 2 * 1024) + 256;
   if (lds > 160 * 1024) return UPA_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
+  if (half) return pair_launch_e<2, 1>(p, lds, residual != 0, s);
   return ck == 1 ? pair_launch<1>(p, lds, residual != 0, s) : pair_launch<2>(p, lds, residual != 0, s);
 }
 
 extern "C" int upa_bottleneck_pair(const void* x, int n, int h, int w, int c, int ldx, const void* w1_packed, const float* b1,
                                    const void* w2_packed, const float* b2, void* y, int ldy, int residual, int act, int dtype,
                                    const upa_opts* opts, void* stream) {
-  return pair_impl(x, n, h, w, c, ldx, w1_packed, b1, w2_packed, b2, y, ldy, residual, act, dtype, nullptr, opts, stream);
+  return pair_impl(x, n, h, w, c, c, ldx, w1_packed, b1, w2_packed, b2, y, ldy, residual, act, dtype, nullptr, opts, stream);
+}
+
+// ... with the hidden width given: cmid = c (the C2f inner blocks above) or c / 2 for c = 64 (the e = 0.5 Bottleneck of the darknet
+// backbones, block.py:644-668).  w1_packed: upa_pack_conv_weight(c -> cmid, k = 3), w2_packed: (cmid -> c, k = 3).
+extern "C" int upa_bottleneck_pair_e(const void* x, int n, int h, int w, int c, int cmid, int ldx, const void* w1_packed, const float* b1,
+                                     const void* w2_packed, const float* b2, void* y, int ldy, int residual, int act, int dtype,
+                                     const upa_opts* opts, void* stream) {
+  return pair_impl(x, n, h, w, c, cmid, ldx, w1_packed, b1, w2_packed, b2, y, ldy, residual, act, dtype, nullptr, opts, stream);
 }
 
 // C2f(.., 64, n = 1) with a 32-channel Bottleneck: Bottleneck (both 3x3 convs [+ shortcut]) AND the C2f's cv2 in one launch.
@@ -398,5 +437,5 @@ extern "C" int upa_bottleneck_pair_cv2(const void* x, const void* y0, int n, int
   memset(&o2, 0, sizeof(o2));
   o2.size = sizeof(o2);
   o2.pair_tile32 = UPA_OPT(opts, pair_tile32);
-  return pair_impl(x, n, h, w, 32, ldx, w1_packed, b1, w2_packed, b2, out, ldout, residual, act, dtype, &cv2, &o2, stream);
+  return pair_impl(x, n, h, w, 32, 32, ldx, w1_packed, b1, w2_packed, b2, out, ldout, residual, act, dtype, &cv2, &o2, stream);
 }

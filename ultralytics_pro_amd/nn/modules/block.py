@@ -47,7 +47,8 @@ class Bottleneck(nn.Module):
         return bool(self.fuse_pair and x.dtype == torch.bfloat16 and not self.training
                     and a.kernel_size == (3, 3) and b.kernel_size == (3, 3) and a.stride == (1, 1) and b.stride == (1, 1)
                     and a.padding == (1, 1) and b.padding == (1, 1) and a.groups == 1 and b.groups == 1
-                    and a.in_channels == a.out_channels == b.out_channels and a.in_channels in (32, 64)
+                    and a.in_channels == b.out_channels and b.in_channels == a.out_channels
+                    and (a.in_channels, a.out_channels) in ((32, 32), (64, 64), (64, 32))  # (64, 32): the e = 0.5 darknet block
                     and isinstance(self.cv1.act, nn.SiLU) and isinstance(self.cv2.act, nn.SiLU)
                     and hasattr(self.cv1, "bn") and hasattr(self.cv2, "bn"))
 
@@ -59,9 +60,9 @@ class Bottleneck(nn.Module):
             p1 = self.cv1._packed(self.cv1.conv, self.cv1.bn, x.device, x.dtype, False)
             p2 = self.cv2._packed(self.cv2.conv, self.cv2.bn, x.device, x.dtype, False)
             vx, vy = R.view_of(x), R.view_of(y)
-            rc = L.lib().upa_bottleneck_pair(vx.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, p1.w.data_ptr(), p1.bias.data_ptr(),
-                                             p2.w.data_ptr(), p2.bias.data_ptr(), vy.ptr, vy.ld, int(self.add), L.ACT_SILU,
-                                             vx.dtype, R.opts_ptr(), L.current_stream(x.device))
+            rc = L.lib().upa_bottleneck_pair_e(vx.ptr, vx.n, vx.h, vx.w, vx.c, self.cv1.conv.out_channels, vx.ld, p1.w.data_ptr(),
+                                               p1.bias.data_ptr(), p2.w.data_ptr(), p2.bias.data_ptr(), vy.ptr, vy.ld, int(self.add),
+                                               L.ACT_SILU, vx.dtype, R.opts_ptr(), L.current_stream(x.device))
             if rc == 0:
                 return y
             if rc != L.UPA_EUNSUPPORTED:
