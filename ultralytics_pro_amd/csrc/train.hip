@@ -804,7 +804,7 @@ __global__ __launch_bounds__((R3Geo<S, BCI>::NW * 64)) void wgrad_k3_ring_kernel
     WG_ACC(aW, tq0, tq1);
     __builtin_amdgcn_s_barrier();
     WG_ACC(aB, tq0, tq1);
-    stage(i + G::RING - 1);   // into the ring slot stage i - 1 used (issued after the tile's products instead: no faster)
+    stage(i + G::RING - 1);   // into the ring slot stage i - 1 used (issued after the tile's products, or under the first step's LDS reads, instead: no faster)
     WG_ACC(aS, tq0, tq1);
     const char* const zt = wsm_r3 + (size_t)(i % G::RING) * G::STAGE;
     const char* const xt = zt + G::NZC * 16;
