@@ -13,6 +13,8 @@ cpf $O/bench_serial_profiled.json bench_serial_profiled_bf16.json
 cpf $O/bench_f32.json bench_default_f32.json
 cpf $O/bench_train.json bench_train_bf16.json
 cpf $O/bench_val.json bench_val_bf16.json
+cpf $O/bench_yolov3-rtdetr_serial.json bench_yolov3-rtdetr_serial.json
+cpf $O/wgrad_layers_yolov8s.txt wgrad_layers_yolov8s.txt
 cpf $O/bench_default_no_mode_dispatch.json bench_default_no_mode_dispatch.json
 for m in yolov8s yolov3-tiny yolov5-BoT3 yolov3-rtdetr; do cpf $O/bench_$m.json bench_$m.json; done
 for m in yolov8n yolov8s yolov3-tiny yolov3-rtdetr; do cpf $O/conv_layers_$m.txt conv_layers_$m.txt; done
