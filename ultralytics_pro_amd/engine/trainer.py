@@ -89,10 +89,12 @@ class ConvT:
             self.mean = torch.empty(self.cout, dtype=torch.float32, device=dev)
             self.var = torch.empty(self.cout, dtype=torch.float32, device=dev)
         self.phase = None
-        if self.s == 2 and self.k == 3 and self.p == 1:  # data gradient by output parity: four packed 2x2 kernels
-            nph = L.lib().upa_conv_packed_weight_bytes(self.cin, self.cout, 2, code)
+        if self.s == 2 and self.k == 3 and self.p == 1:
+            # data gradient by output parity: four 2x2 kernels, stacked along the output channels into ONE cout -> 4 * cin conv
+            # (V is [phase][cin][cout][2][2] = a (4 cin, cout, 2, 2) weight): dz is read once and the four phases are one launch
+            nph = L.lib().upa_conv_packed_weight_bytes(4 * self.cin, self.cout, 2, code)
             self.phase_v = torch.empty(4 * self.cin * self.cout * 4, dtype=torch.float32, device=dev)
-            self.phase = [torch.empty(nph, dtype=torch.uint8, device=dev) for _ in range(4)]
+            self.phase = torch.empty(nph, dtype=torch.uint8, device=dev)
         self.x = self.z = None
         nws = L.lib().upa_conv2d_wgrad_workspace_bytes(self.cin, self.cout, self.k)
         if nws > ctx.wgrad_ws.numel():
@@ -111,10 +113,8 @@ class ConvT:
         else:
             L.check(lib.upa_dgrad_s2_phase_weights(w.data_ptr(), self.cout, self.cin, self.phase_v.data_ptr(), _s(c.device)),
                     "phase_weights")
-            per = self.cin * self.cout * 4 * 4  # bytes of one V[phase]
-            for ph in range(4):
-                L.check(lib.upa_pack_conv_weight_dev(self.phase_v.data_ptr() + ph * per, self.cin, self.cout, 2, c.code, 0,
-                                                     self.phase[ph].data_ptr(), _s(c.device)), "pack_phase")
+            L.check(lib.upa_pack_conv_weight_dev(self.phase_v.data_ptr(), 4 * self.cin, self.cout, 2, c.code, 0,
+                                                 self.phase.data_ptr(), _s(c.device)), "pack_phase")
 
     def pack_descs(self):
         """(w_ptr, out_ptr, cout, cin, k, dtype, transpose_flip) of every repack `pack()` launches, for the batched form
@@ -125,9 +125,7 @@ class ConvT:
         if self.phase is None:
             d.append((w.data_ptr(), self.wpt.data_ptr(), self.cout, self.cin, self.k, c.code, 1))
         else:
-            per = self.cin * self.cout * 4 * 4
-            d += [(self.phase_v.data_ptr() + ph * per, self.phase[ph].data_ptr(), self.cin, self.cout, 2, c.code, 0)
-                  for ph in range(4)]
+            d.append((self.phase_v.data_ptr(), self.phase.data_ptr(), 4 * self.cin, self.cout, 2, c.code, 0))
         return d
 
     def pack_phase_weights(self):
@@ -214,13 +212,11 @@ class ConvT:
         if dx is None:
             return
         if self.phase is not None:
-            # stride 2: four 2x2 stride-1 correlations over dz (one per output parity) + one interleave pass
-            ts, keep = [], []
-            for ph in range(4):
-                t = _new(vdz.n, self.cin, vdz.h + 1, vdz.w + 1, c.dtype, c.device, (id(self), "phase", ph))
-                self._conv(dz, self.phase[ph], self.cin, 2, 1, 1, t)
-                keep.append(t)  # views are raw pointers: the tensors must outlive the interleave launch
-                ts.append(R.view_of(t))
+            # stride 2: the four 2x2 stride-1 correlations over dz (one per output parity) as one conv with 4 * cin output
+            # channels + one interleave pass over its four channel blocks
+            t = _new(vdz.n, 4 * self.cin, vdz.h + 1, vdz.w + 1, c.dtype, c.device, (id(self), "phases"))
+            self._conv(dz, self.phase, 4 * self.cin, 2, 1, 1, t)
+            ts = [R.view_of(t[:, ph * self.cin:(ph + 1) * self.cin]) for ph in range(4)]  # raw pointers: `t` outlives the launch below
             vdx = R.view_of(dx)
             L.check(lib.upa_interleave2x(ts[0].ptr, ts[1].ptr, ts[2].ptr, ts[3].ptr, vdz.n, vdz.h + 1, vdz.w + 1, self.cin, ts[0].ld,
                                          vdx.ptr, vdx.h, vdx.w, vdx.ld, int(accumulate), vdx.dtype, st), "interleave2x")
