@@ -453,6 +453,35 @@ class DetectionTrainer:
                 self.convs += op.convs() if hasattr(op, "convs") else [op]
             self.nodes.append(_Node(m.i, m.f, kind, op))
         self.detect = self.nodes[-1].op
+        self._plan_concats()
+
+    def _plan_concats(self):
+        """nn.Concat without copies: a layer whose output feeds exactly one Concat writes it straight into its channel slice of the
+        Concat's buffer (every kernel takes a pixel stride), and in backward that slice of the Concat's gradient IS the layer's
+        gradient buffer when the Concat is the first consumer the reverse walk meets.  {producer index: (concat index, first
+        channel, channels, channels of the concat)}."""
+        cout = {}
+        for nd in self.nodes[:-1]:
+            src = (lambda j: j if j != -1 else nd.i - 1)
+            if nd.kind == "conv":
+                cout[nd.i] = nd.op.cout
+            elif nd.kind in ("c2f", "sppf"):
+                cout[nd.i] = nd.op.cv2.cout
+            elif nd.kind == "upsample":
+                cout[nd.i] = cout[src(nd.f)]
+            elif nd.kind == "concat":
+                cout[nd.i] = sum(cout[src(j)] for j in nd.f)
+        self._cat_slot = {}
+        for nd in self.nodes[:-1]:
+            if nd.kind != "concat":
+                continue
+            idx = [j if j != -1 else nd.i - 1 for j in nd.f]
+            c0 = 0
+            for j in idx:
+                if j not in self._cat_slot and idx.count(j) == 1 and self.nodes[j].i == j and \
+                        self.nodes[j].kind in ("conv", "c2f", "sppf", "upsample"):
+                    self._cat_slot[j] = (nd.i, c0, cout[j], cout[nd.i])
+                c0 += cout[j]
 
     # ---- one step -----------------------------------------------------------------------------------------------------
     def _input_nhwc(self, img):
@@ -498,11 +527,21 @@ class DetectionTrainer:
             for nd in self.nodes:
                 xin = x if nd.f == -1 else (ys[nd.f] if isinstance(nd.f, int) else [x if j == -1 else ys[j] for j in nd.f])
                 nd.xin = xin
+                out = None
+                slot = self._cat_slot.get(nd.i)
+                if slot is not None:  # this layer's output lives in its slice of the Concat's buffer
+                    cat_i, c0, cj, ctot = slot
+                    n, _, h, w = xin.shape
+                    if nd.kind == "conv":
+                        h, w = (h + 2 * nd.op.p - nd.op.k) // nd.op.s + 1, (w + 2 * nd.op.p - nd.op.k) // nd.op.s + 1
+                    elif nd.kind == "upsample":
+                        h, w = 2 * h, 2 * w
+                    out = _new(n, ctot, h, w, ctx.dtype, dev, (id(self.nodes[cat_i]), "y"))[:, c0:c0 + cj]
                 if nd.kind in ("conv", "c2f", "sppf"):
-                    y = nd.op.forward(xin)
+                    y = nd.op.forward(xin, out=out)
                 elif nd.kind == "upsample":
                     n, c, h, w = xin.shape
-                    y = _new(n, c, 2 * h, 2 * w, ctx.dtype, dev, (id(nd), "y"))
+                    y = out if out is not None else _new(n, c, 2 * h, 2 * w, ctx.dtype, dev, (id(nd), "y"))
                     vs, vd = R.view_of(xin), R.view_of(y)
                     L.check(L.lib().upa_upsample2x(vs.ptr, vs.n, vs.h, vs.w, vs.c, vs.ld, vd.ptr, vd.ld, vs.dtype, _s(dev)),
                             "upsample2x")
@@ -510,8 +549,10 @@ class DetectionTrainer:
                     n, _, h, w = xin[0].shape
                     y = _new(n, sum(int(t.shape[1]) for t in xin), h, w, ctx.dtype, dev, (id(nd), "y"))
                     c0 = 0
-                    for t in xin:
-                        copy_into(ctx, t, y[:, c0:c0 + t.shape[1]])
+                    for j, t in zip(nd.f, xin):
+                        j = j if j != -1 else nd.i - 1
+                        if self._cat_slot.get(j, (None,))[0] != nd.i:  # not written in place by its producer
+                            copy_into(ctx, t, y[:, c0:c0 + t.shape[1]])
                         c0 += t.shape[1]
                 else:  # detect
                     y = nd.op.forward(xin)
@@ -546,11 +587,10 @@ class DetectionTrainer:
                     for j in nd.f:
                         src = self.nodes[j] if j != -1 else self.nodes[nd.i - 1]
                         cj = int(src.y.shape[1])
-                        dx, acc = self._grad_of(src)
-                        if acc:
-                            add_into(ctx, dy[:, c0:c0 + cj], dx)
+                        if src.g is None:   # the Concat is the first consumer met: its slice IS the gradient buffer, later ones accumulate
+                            src.g = dy[:, c0:c0 + cj]
                         else:
-                            copy_into(ctx, dy[:, c0:c0 + cj], dx)
+                            add_into(ctx, dy[:, c0:c0 + cj], src.g)
                         c0 += cj
                 self._bucket_hook(nd.i)
             self._join_wgrad()
