@@ -48,12 +48,15 @@ __device__ __forceinline__ void pack_weight_body(const float* w, int cout, int c
   const int lc_out = transpose_flip ? cin : cout, lc_in = transpose_flip ? cout : cin;
   const int ktch = 4 * E;
   const int ktt = (lc_in + ktch - 1) / ktch, ntn = (lc_out + 15) / 16;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    long t = idx;
-    const int j = (int)(t % E); t /= E;
-    const int lane = (int)(t % 64); t /= 64;
-    const int nt = (int)(t % ntn); t /= ntn;
-    const int kt = (int)(t % ktt); t /= ktt;
+  // 32-bit index arithmetic (a conv weight has far fewer than 2^31 packed elements; E and 64 are powers of two): with `long`
+  // the five divisions per element made the whole-model repack 107 us at the head of every training step
+  const unsigned tot = (unsigned)total, eshift = E == 8 ? 3u : 2u;
+  for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < tot; idx += gridDim.x * blockDim.x) {
+    unsigned t = idx;
+    const int j = (int)(t & (unsigned)(E - 1)); t >>= eshift;
+    const int lane = (int)(t & 63u); t >>= 6;
+    const int nt = (int)(t % (unsigned)ntn); t /= (unsigned)ntn;
+    const int kt = (int)(t % (unsigned)ktt); t /= (unsigned)ktt;
     const int tap = (int)t;
     const int kh = tap / k, kw = tap - kh * k;
     const int g = lane >> 4, r = lane & 15;
@@ -1320,7 +1323,7 @@ extern "C" int upa_pack_conv_weight_dev(const float* w_oihw, int cout, int cin, 
 
 extern "C" int upa_pack_conv_weights_batched(const UpaPackDesc* descs_dev, int n, void* stream) {
   UPA_CHECK_ARG(descs_dev && n > 0 && n <= 65535, "pack_conv_weights_batched: bad args");
-  hipLaunchKernelGGL(pack_weight_batched_kernel, dim3(64, (unsigned)n), dim3(256), 0, (hipStream_t)stream, descs_dev);
+  hipLaunchKernelGGL(pack_weight_batched_kernel, dim3(128, (unsigned)n), dim3(256), 0, (hipStream_t)stream, descs_dev);
   UPA_LAUNCH_CHECK();
   return UPA_OK;
 }
