@@ -321,10 +321,15 @@ class SPPFT(_Seq):
         cm = self.cv1.cout
         cat = _new(n, 4 * cm, h, w, c.dtype, c.device, (id(self), "cat"))
         self.cv1.forward(x, out=cat[:, :cm])
-        for i in range(3):  # three chained MaxPool2d(k, 1, k//2) (block.py:402-406)
-            vs, vd = R.view_of(cat[:, i * cm:(i + 1) * cm]), R.view_of(cat[:, (i + 1) * cm:(i + 2) * cm])
-            L.check(L.lib().upa_maxpool2d(vs.ptr, vs.n, vs.h, vs.w, vs.c, vs.ld, vd.ptr, vd.h, vd.w, vd.ld, self.k, 1,
-                                          self.k // 2, 0, vs.dtype, _s(c.device)), "maxpool2d")
+        if self.k == 5:  # the three chained MaxPool2d(5, 1, 2) (block.py:402-406) as one launch (5 / 9 / 13 windows)
+            v = [R.view_of(cat[:, i * cm:(i + 1) * cm]) for i in range(4)]
+            L.check(L.lib().upa_sppf_pool3(v[0].ptr, v[0].n, v[0].h, v[0].w, v[0].c, v[0].ld, v[1].ptr, v[2].ptr, v[3].ptr, v[0].ld,
+                                           v[0].dtype, _s(c.device)), "sppf_pool3")
+        else:
+            for i in range(3):
+                vs, vd = R.view_of(cat[:, i * cm:(i + 1) * cm]), R.view_of(cat[:, (i + 1) * cm:(i + 2) * cm])
+                L.check(L.lib().upa_maxpool2d(vs.ptr, vs.n, vs.h, vs.w, vs.c, vs.ld, vd.ptr, vd.h, vd.w, vd.ld, self.k, 1,
+                                              self.k // 2, 0, vs.dtype, _s(c.device)), "maxpool2d")
         self.cat = cat
         return self.cv2.forward(cat, out=out)
 
