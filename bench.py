@@ -688,7 +688,7 @@ def main_train(args):
     seen = ranks_seen(dist, dev)
     roofline = cpu_baseline = None
     if rank == 0:
-        roofline = wgrad_profile(tr, L, R, dev, dtype)
+        roofline = wgrad_profile(tr, L, R, dev, dtype, cfg_key=f"{args.model} bs={pb} {args.dtype} train")
         if not args.no_cpu_baseline and world == 1:
             cpu_baseline = run_cpu_baseline_bounded(args)
         nparam = sum(n for _, n, _ in tr.groups)
@@ -718,7 +718,7 @@ def main_train(args):
         dist.destroy_process_group()
 
 
-def wgrad_profile(tr, L, R, dev, dtype, reps=5):
+def wgrad_profile(tr, L, R, dev, dtype, reps=5, cfg_key=None):
     """Dominant kernel of the training step = the weight-gradient MFMA kernel: every layer's launch re-issued `reps` times
     back to back on the current stream between HIP events (its operands are still resident from the last step)."""
     fam = {}
@@ -767,8 +767,20 @@ def wgrad_profile(tr, L, R, dev, dtype, reps=5):
     name, d = max(fam.items(), key=lambda kv: kv[1]["ms"])
     avg_s = d["ms"] / d["launches"] * 1e-3
     tf = d["flops"] / d["launches"] / avg_s / 1e12
+    # HBM bytes per launch of the dominant family from the committed PMC passes (tools/pmc_wgrad.sh: FETCH_SIZE x 2 + WRITE_SIZE,
+    # separate passes); only valid for the configuration they were collected on
+    traffic, traffic_src = None, None
+    for pf in sorted((ROOT / "profiles").glob("r*_pmc_wgrad_summary.json"), reverse=True):
+        try:
+            pmc = json.loads(pf.read_text())
+            if pmc.get("config") == cfg_key and name in pmc["kernels"]:
+                traffic = round(pmc["kernels"][name]["hbm_bytes_per_launch"])
+                traffic_src = f"profiles/{pf.name} (rocprofv3 --pmc, separate passes)"
+                break
+        except (OSError, KeyError, ValueError):
+            pass
     return {"kernel": name, "bound": "mfma", "achieved": round(tf, 2), "peak": d["peak"], "unit": "TFLOP/s",
-            "frac": round(tf / d["peak"], 4), "traffic": None, "launches_per_step": d["launches"],
+            "frac": round(tf / d["peak"], 4), "traffic": traffic, "traffic_source": traffic_src, "launches_per_step": d["launches"],
             "avg_launch_us": round(avg_s * 1e6, 1),
             "algorithmic_flops_per_launch": d["flops"] / d["launches"],
             "note": "weight gradient: bf16 MFMA (v_mfma_f32_16x16x32_bf16, operands DMAed into an LDS ring and read with "

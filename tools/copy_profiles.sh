@@ -19,6 +19,7 @@ cpf $O/bench_default_no_mode_dispatch.json bench_default_no_mode_dispatch.json
 for m in yolov8s yolov3-tiny yolov5-BoT3 yolov3-rtdetr; do cpf $O/bench_$m.json bench_$m.json; done
 for m in yolov8n yolov8s yolov3-tiny yolov3-rtdetr; do cpf $O/conv_layers_$m.txt conv_layers_$m.txt; done
 cpf $O/pmc_hbm_summary.json pmc_hbm_summary.json
+cpf $O/pmc_wgrad_summary.json pmc_wgrad_summary.json
 cpf $O/pmc_step_summary.txt pmc_step_budget.txt
 for k in default serial train; do
   f=$(find $O/prof_$k -name "*kernel_stats.csv" 2>/dev/null | head -1)

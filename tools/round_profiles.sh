@@ -20,6 +20,8 @@ timeout 600 python bench.py --workload val --steps 300 > $O/bench_val.json 2> $O
 timeout 600 python bench.py --no-cpu-baseline --no-kernel-profile --no-mode-dispatch > $O/bench_default_no_mode_dispatch.json 2>/dev/null   # A/B: the one-step-at-a-time kernels (c2f64, conv_ws3) kept with four steps in flight
 timeout 900 bash tools/pmc_hbm.sh --no-kernel-profile > /dev/null 2>&1
 cp $R/gpurun_out/pmc_hbm/summary.json $O/pmc_hbm_summary.json
+timeout 600 bash tools/pmc_wgrad.sh > /dev/null 2>&1
+cp $R/gpurun_out/pmc_wgrad/summary.json $O/pmc_wgrad_summary.json
 timeout 600 python bench.py --no-cpu-baseline > $O/bench_default_with_traffic.json 2>/dev/null   # roofline.traffic from the PMC summary written just above
 timeout 1200 bash tools/pmc_step.sh gpurun_out/pmc_step > /dev/null 2>&1
 cp $R/gpurun_out/pmc_step/summary.txt $O/pmc_step_summary.txt
