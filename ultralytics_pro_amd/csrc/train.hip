@@ -1488,7 +1488,10 @@ static int launch_wgrad_bf16_k1(WgradParams& p, int accumulate, void* ws, size_t
   const int bco = cdiv(p.Cout, BCO), bci = cdiv(p.Cin, BCI);
   // 128 workgroups (half the CUs): in the yolov8s step, where these run on the side stream beside the main chain, 64 / 128 / 256
   // are within 0.1 ms of each other (tools/experiments/r04_z2.sh); alone 256 is faster on the 160x160 layers (47 vs 88 us)
-  constexpr int k1_budget = 128;
+#ifndef UPA_WGRAD_K1_BUDGET
+#define UPA_WGRAD_K1_BUDGET 128
+#endif
+  constexpr int k1_budget = UPA_WGRAD_K1_BUDGET;
   long wgs = k1_budget / (bco * bci);
   if (wgs < 1) wgs = 1;
   const long nst = (P + R1_NPX - 1) / R1_NPX;
@@ -1513,9 +1516,16 @@ static int launch_wgrad_bf16_k3_t(WgradParams& p, int accumulate, void* ws, size
   p.numTiles = p.tilesX * p.tilesY * p.N;
   p.IH = (p.TH - 1) * p.stride + 3; p.IW = (p.TW - 1) * p.stride + 3;
   const int bco = cdiv(p.Cout, BCO), bci = cdiv(p.Cin, BCI);
-  // workgroups per launch (= slices of the pixel axis x channel blocks): 256, one 12-wave ring workgroup per CU (64 - 256 are
-  // within 0.1 ms of each other in the yolov8s step, tools/experiments/r04_z2.sh; more slices = more partial-sum traffic)
-  constexpr int wg_budget = 256;
+  // workgroups per launch (= slices of the pixel axis x channel blocks): 128 twelve-wave ring workgroups = half the CUs.  A ring
+  // workgroup fills its CU (156 KB of LDS, 504 of 512 registers per lane), so in the training step - where these run on the side
+  // stream beside the main chain - every CU a launch takes is one the main chain waits for, and each slice costs a 147 KB partial
+  // block (PMC: 93 MB of HBM traffic per launch at 256 slices, 41 MB of it operands).  Same-box A/B of the yolov8s step, two
+  // interleaved rounds on two boxes (tools/experiments/r04_e3.sh, compile-time variants): 256: 12.23 / 11.80 ms, 192: 12.00,
+  // 160: 11.48, 128: 11.85 / 11.45, 96: 11.56, 64: 11.91; pointwise kernel at 64 / 128 / 192: 11.91 / 11.85 / 11.58 (second box: 128 best)
+#ifndef UPA_WGRAD_K3_BUDGET
+#define UPA_WGRAD_K3_BUDGET 128
+#endif
+  constexpr int wg_budget = UPA_WGRAD_K3_BUDGET;
   // ... except the stem (3.3 M output pixels): its weight gradient is the last kernel of the backward pass, nothing is
   // left to overlap it with: 768 three-wave workgroups of the narrow ring form (121 us; 130 at 512 and at 1024)
   constexpr long big_px = 3000000;
