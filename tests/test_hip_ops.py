@@ -461,6 +461,51 @@ def test_c2f_fused_kernel(case, th):
     assert float(to_cpu_nchw(buf[:, :c1]).abs().max()) == 0.0  # nothing written outside the output slice
 
 
+C2F_STREAM_CASES = [
+    # shortcut, (N, H, W), rows per workgroup (0 = auto)
+    (True, (2, 80, 80), 0), (True, (2, 80, 80), 40), (True, (1, 37, 50), 0), (True, (2, 37, 50), 8), (True, (1, 16, 16), 0), (True, (3, 5, 9), 0),
+    (True, (1, 41, 23), 4), (False, (2, 18, 16), 6), (True, (1, 64, 100), 22),
+]
+
+
+@pytest.mark.parametrize("case", C2F_STREAM_CASES, ids=[f"{'s' if c[0] else 'n'}_{c[1][0]}x{c[1][1]}x{c[1][2]}_r{c[2]}" for c in C2F_STREAM_CASES])
+def test_c2f_stream_kernel(case):
+    """`upa_c2f_fused` on its line-buffer kernel (csrc/c2f_stream.hip: C2f(64, 64, n = 2), block.py:457-488 / 644-668): strips of 20 columns
+    streamed two rows per step through LDS ring buffers, fixed wave roles.  Against the oracle with bf16 rounding points, against the
+    16 x 16 tile form (`c2f_stream=1`) and against the separate launches; whole and ragged strips, parts that end mid-image, maps smaller
+    than one strip, every ring of the halo on the image border, with and without the shortcut, nothing written outside the output slice."""
+    from tests.hip_utils import DEV, assert_bf16_close, bf16_round, bf16_weight_oracle, to_cpu_nchw, to_dev_nhwc
+    from ultralytics_pro_amd.engine import runtime as R
+    pm, _ = _mods()
+    sc, (N, H, W), rows = case
+    o, m = _pair(om.C2f, pm.C2f, (64, 64, 2, sc), "c2f_stream")
+    o = bf16_weight_oracle(o)
+    x = bf16_round(P.uniform(f"c2fs{case}", (N, 64, H, W), -1.5, 1.5))
+    with torch.no_grad():
+        y01 = bf16_round(o.cv1(x))
+        ys = list(y01.chunk(2, 1))
+        for bt in o.m:
+            t = bf16_round(bt.cv1(ys[-1]))
+            ys.append(bf16_round((ys[-1] if sc else 0) + bt.cv2(t)))
+        ref = o.cv2(torch.cat(ys, 1))
+        buf = R.alloc_nhwc(N, 128, H, W, torch.bfloat16, DEV)
+        buf.zero_()
+        xd = to_dev_nhwc(x, torch.bfloat16)
+        m.fuse_block = True
+        with R.use_opts(c2f_stream_rows=rows):
+            y = to_cpu_nchw(m(xd, out=buf[:, 64:]))
+        with R.use_opts(c2f_stream=1):
+            y_tile = to_cpu_nchw(m(xd))
+        m.fuse_block = False
+        y2 = to_cpu_nchw(m(xd))
+    scale = max(1.0, ref.abs().max().item())
+    assert_bf16_close(y, ref, f"c2f_stream{case}", abs_=2.0 ** -7)
+    for other, name in ((y_tile, "tile form"), (y2, "separate launches")):
+        d = (y - other).abs()
+        assert d.max().item() <= 3e-2 * scale and (d > 1e-6).float().mean().item() <= 0.03, (name, d.max().item(), (d > 1e-6).float().mean().item())
+    assert float(to_cpu_nchw(buf[:, :64]).abs().max()) == 0.0  # nothing written outside the output slice
+
+
 C2F32UP_CASES = [
     # c1, shortcut, (N, H, W), up_c  (C2f(c1, 64, n = 1) with 32-channel halves, cv1 streamed over 64-channel chunks: upa_c2f32_up_fused)
     (192, False, (2, 80, 80), 128),   # yolov8n model.15: virtual Upsample(128) + Concat(64) in front, three chunks
