@@ -35,6 +35,25 @@ struct C2fsParams {
   int N, H, W, ldx, ldy, strips, parts, L, shortcut, xcd;
 };
 
+// profiling build (-DUPA_STAMP): every wave of the first 8 workgroups records s_memtime at the start of each step and before its barrier
+#ifdef UPA_STAMP
+#define C2FS_STAMP_STEPS 48
+__device__ unsigned long long g_c2fs_stamps[8 * 16 * C2FS_STAMP_STEPS * 2];
+extern "C" int upa_debug_stamps_c2fs(unsigned long long* out, int count) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_c2fs_stamps), (size_t)count * 8) == hipSuccess ? 0 : -1;
+}
+#define C2FS_STAMP(step, which)                                                                              \
+  do {                                                                                                       \
+    if (blockIdx.x < 8 && (step) < C2FS_STAMP_STEPS) {                                                       \
+      unsigned long long t_;                                                                                 \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                             \
+      if ((threadIdx.x & 63) == 0) g_c2fs_stamps[((blockIdx.x * 16 + (threadIdx.x >> 6)) * C2FS_STAMP_STEPS + (step)) * 2 + (which)] = t_; \
+    }                                                                                                        \
+  } while (0)
+#else
+#define C2FS_STAMP(step, which) do {} while (0)
+#endif
+
 namespace c2fs {
 constexpr int WS = 20;  // output columns of a strip
 constexpr int npow2(int v) { int q = 1; while (q < v) q <<= 1; return q; }
@@ -56,18 +75,28 @@ struct Geo {
   static constexpr int plane(int j) { return ring(j) * ROWB; }
   static constexpr int base(int j) { int o = 0; for (int i = 0; i < j; ++i) o += 4 * plane(i); return o; }
   static constexpr int NY1 = (RS * XW + 15) / 16, NF = (RS * WS + 15) / 16;  // cv1 / cv2 units per step
-  static constexpr int W2S = base(NTEN);                 // cv2 A fragments [k-tile][4 n-tiles][lane][16 B]
-  static constexpr int W2B = (2 + NB) * 4 * 1024;
-  static constexpr int XS = W2S + W2B;                   // cv1 input staging: 2 slots of RS x XW pixels x 128 B
+  static constexpr int PY1 = (RS * XW + 7) / 8, PF = (RS * WS + 7) / 8;      // 8-pixel DMA pieces of the two input bands
+  static constexpr int NSLOT = 3;                        // input bands in flight: the DMA runs two steps ahead of its readers
+  static constexpr int XS = base(NTEN);                  // cv1 input staging: NSLOT slots of RS x XW pixels x 128 B
   static constexpr int XSLOT = NY1 * 16 * 128;
-  static constexpr int XF = XS + 2 * XSLOT;              // y0 input staging: 2 slots of RS x WS pixels
+  static constexpr int XF = XS + NSLOT * XSLOT;          // y0 input staging: NSLOT slots of RS x WS pixels
   static constexpr int FSLOT = NF * 16 * 128;
-  static constexpr int BIAS = XF + 2 * FSLOT;            // f32: b1[64], b2[64], bm[NST][32]
-  static constexpr int LDS = BIAS + (128 + NST * 32) * 4;
+  static constexpr int BIAS = XF + NSLOT * FSLOT;        // f32: bm[NST][32]
+  static constexpr int LDS = BIAS + NST * 32 * 4;
 };
 
+#if defined(C2FS_EXP) && (C2FS_EXP == 1 || C2FS_EXP == 5)   // timing experiments only (tools/experiments/r05_c2fs_variants.sh): not SiLU
+__device__ __forceinline__ float silu(float v) { return v * 0.5f; }
+#elif defined(C2FS_EXP) && C2FS_EXP == 2
+__device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + v * v); }
+#else
 __device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+#endif
 __device__ __forceinline__ f32x4 mfma32(const u32x4& a, const u32x4& b, f32x4 c) {
+#if defined(C2FS_EXP) && (C2FS_EXP == 3 || C2FS_EXP == 5)  // timing experiment: no matrix instructions (operands still loaded)
+  asm volatile("" ::"v"(a), "v"(b));
+  return c;
+#endif
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
 }
 __device__ __forceinline__ f32x4 mfma16(const u32x2& a, const u32x2& b, f32x4 c) {
@@ -76,21 +105,26 @@ __device__ __forceinline__ f32x4 mfma16(const u32x2& a, const u32x2& b, f32x4 c)
 __device__ __forceinline__ u32x2 silu_pack(const f32x4& a) {
   return u32x2{pack_bf16x2(silu(a[0]), silu(a[1])), pack_bf16x2(silu(a[2]), silu(a[3]))};
 }
+#if defined(C2FS_EXP) && C2FS_EXP == 4  // timing experiment: no LDS reads of the 3x3 taps / cv2 operands
+__device__ __forceinline__ u32x4 lds128(const char* sm, int off) { return u32x4{(unsigned)off, 1u, 2u, 3u}; }
+#else
+__device__ __forceinline__ u32x4 lds128(const char* sm, int off) { return *reinterpret_cast<const u32x4*>(sm + off); }
+#endif
 
-// ---- one 3x3 stage, one unit: the wave's whole life
-template <int NB, int K>
+// ---- a 3x3 stage K: the wave owns unit `unit` (and unit + 1 if TWO) of the stage's RS-row band for the life of the workgroup.
+// A unit = 16 consecutive pixels of the band (row-major over the stage's SD valid columns) x all 32 output channels.
+template <int NB, int K, bool TWO>
 __device__ __forceinline__ void stage_role(const C2fsParams& p, char* sm, int unit, int lane, int S, int py0, int sx0, int LP) {
   using G = Geo<NB>;
   constexpr int SD = G::sd(K), C0 = K + 1, LAG = G::lag(K);
   constexpr int RIN = G::ring(K), ROUT = G::ring(K + 1);
   constexpr bool HAS_RES = (K & 1) != 0;
   constexpr int RRES = HAS_RES ? G::ring(K - 1) : 1;
+  constexpr int PRES = HAS_RES ? G::plane(K - 1) : 0;
+  constexpr int NU = TWO ? 2 : 1;
+  constexpr int NBUF = 5;  // B fragments in flight
+  static_assert(G::RS == 2, "the lane -> row map below assumes two rows per step");
   const int g = lane >> 4, r = lane & 15;
-  const int q = unit * 16 + r;
-  const bool act = q < G::RS * SD;
-  const int qq = act ? q : 0;
-  const int rr = qq >= SD ? 1 : 0, cc = C0 + qq - rr * SD;
-  static_assert(G::RS == 2, "the lane -> row map above assumes two rows per step");
 
   u32x4 w[9][2];
 #pragma unroll
@@ -98,255 +132,310 @@ __device__ __forceinline__ void stage_role(const C2fsParams& p, char* sm, int un
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) w[tap][nt] = *reinterpret_cast<const u32x4*>(p.wm[K] + ((size_t)(tap * 2 + nt) * 64 + lane) * 16);
 
-  const int in_const = G::base(K) + g * G::plane(K) + (cc - 1) * 16;
-  const int out_const = G::base(K + 1) + (g >> 1) * G::plane(K + 1) + cc * 16 + (g & 1) * 8;
-  const int res_const = HAS_RES ? G::base(K - 1) + (g >> 1) * G::plane(K - 1) + cc * 16 + (g & 1) * 8 : 0;
-  const int bias_off = G::BIAS + (128 + K * 32 + 4 * g) * 4;
-  const int gx = sx0 - G::R + cc;
-  const bool colok = gx >= 0 && gx < p.W;
+  // lane constants per unit: row within the band, byte offsets of the lane's pixel in the input / output / shortcut rings, validity
+  int u_rr[NU], u_in[NU];
+  unsigned u_colm[NU];
+  bool u_act[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int q = (unit + u) * 16 + r;
+    u_act[u] = q < G::RS * SD;
+    const int qq = u_act[u] ? q : 0;
+    u_rr[u] = qq >= SD ? 1 : 0;
+    const int cc = C0 + qq - u_rr[u] * SD;
+    u_in[u] = G::base(K) + g * G::plane(K) + (cc - 1) * 16;
+    const int gx = sx0 - G::R + cc;
+    u_colm[u] = (gx >= 0 && gx < p.W) ? 0xFFFFFFFFu : 0u;
+  }
+  // the lane's 8 bytes in the output / shortcut rings sit at a lane-constant distance from its input address (same pixel, another ring)
+  const int out_d = G::base(K + 1) - G::base(K) + (g >> 1) * G::plane(K + 1) - g * G::plane(K) + 16 + (g & 1) * 8;
+  const int res_d = HAS_RES ? G::base(K - 1) - G::base(K) + (g >> 1) * PRES - g * G::plane(K) + 16 + (g & 1) * 8 : 0;
+  const int bias_off = G::BIAS + (K * 32 + 4 * g) * 4;
   const int lo = K + 1, hi = LP - (K + 1);
   const bool use_res = HAS_RES && p.shortcut;
 
   for (int s = 0; s < S; ++s) {
+    C2FS_STAMP(s, 0);
     const int r0 = G::RS * s - LAG;
     if (r0 + G::RS > lo && r0 < hi) {  // wave-uniform
-      const int row = r0 + rr;
-      int rb[3];
+      int rb[NU][3];
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy) rb[dy] = in_const + ((row + dy - 1) & (RIN - 1)) * G::ROWB;
-      f32x4 acc0 = *reinterpret_cast<const f32x4*>(sm + bias_off);
-      f32x4 acc1 = *reinterpret_cast<const f32x4*>(sm + bias_off + 64);
-      u32x2 rs0 = {0u, 0u}, rs1 = {0u, 0u};
-      if (use_res) {
-        const int ra = res_const + (row & (RRES - 1)) * G::ROWB;
-        rs0 = *reinterpret_cast<const u32x2*>(sm + ra);
-        rs1 = *reinterpret_cast<const u32x2*>(sm + ra + 2 * G::plane(HAS_RES ? K - 1 : 0));
-      }
+      for (int u = 0; u < NU; ++u)
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const u32x4 b = *reinterpret_cast<const u32x4*>(sm + rb[tap / 3] + (tap % 3) * 16);
-        acc0 = mfma32(w[tap][0], b, acc0);
-        acc1 = mfma32(w[tap][1], b, acc1);
-      }
-      const int gy = py0 - G::R + row;
-      const unsigned m = (colok && gy >= 0 && gy < p.H) ? 0xFFFFFFFFu : 0u;  // the tensor is ZERO outside the image (the next conv's padding)
-      float v0[4], v1[4];
+        for (int dy = 0; dy < 3; ++dy) rb[u][dy] = u_in[u] + ((r0 + u_rr[u] + dy - 1) & (RIN - 1)) * G::ROWB;
+      auto rd = [&](int t) __attribute__((always_inline)) { return lds128(sm, rb[t / 9][(t % 9) / 3] + (t % 3) * 16); };
+      constexpr int NTAP = 9 * NU;
+      u32x4 buf[NBUF];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { v0[e] = silu(acc0[e]); v1[e] = silu(acc1[e]); }
-      if (use_res) {
-        v0[0] += __uint_as_float(rs0[0] << 16); v0[1] += __uint_as_float(rs0[0] & 0xFFFF0000u);
-        v0[2] += __uint_as_float(rs0[1] << 16); v0[3] += __uint_as_float(rs0[1] & 0xFFFF0000u);
-        v1[0] += __uint_as_float(rs1[0] << 16); v1[1] += __uint_as_float(rs1[0] & 0xFFFF0000u);
-        v1[2] += __uint_as_float(rs1[1] << 16); v1[3] += __uint_as_float(rs1[1] & 0xFFFF0000u);
+      for (int t = 0; t < NBUF; ++t) buf[t] = rd(t);
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const int row = r0 + u_rr[u];
+        u32x2 rs0 = {0u, 0u}, rs1 = {0u, 0u};
+        f32x4 acc0 = *reinterpret_cast<const f32x4*>(sm + bias_off);
+        f32x4 acc1 = *reinterpret_cast<const f32x4*>(sm + bias_off + 64);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int t = u * 9 + tap;
+          const u32x4 b = buf[t % NBUF];
+          acc0 = mfma32(w[tap][0], b, acc0);
+          acc1 = mfma32(w[tap][1], b, acc1);
+          if (t + NBUF < NTAP) buf[t % NBUF] = rd(t + NBUF);
+          if (tap == 4 && use_res) {  // the shortcut operand arrives under the remaining taps
+            const int ra = u_in[u] + res_d + (row & (RRES - 1)) * G::ROWB;
+            rs0 = *reinterpret_cast<const u32x2*>(sm + ra);
+            rs1 = *reinterpret_cast<const u32x2*>(sm + ra + 2 * PRES);
+          }
+        }
+        const int gy = py0 - G::R + row;
+        const unsigned m = (gy >= 0 && gy < p.H) ? u_colm[u] : 0u;  // the tensor is ZERO outside the image (the next conv's padding)
+        float v0[4], v1[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v0[e] = silu(acc0[e]); v1[e] = silu(acc1[e]); }
+        if (use_res) {
+          v0[0] += __uint_as_float(rs0[0] << 16); v0[1] += __uint_as_float(rs0[0] & 0xFFFF0000u);
+          v0[2] += __uint_as_float(rs0[1] << 16); v0[3] += __uint_as_float(rs0[1] & 0xFFFF0000u);
+          v1[0] += __uint_as_float(rs1[0] << 16); v1[1] += __uint_as_float(rs1[0] & 0xFFFF0000u);
+          v1[2] += __uint_as_float(rs1[1] << 16); v1[3] += __uint_as_float(rs1[1] & 0xFFFF0000u);
+        }
+        const u32x2 o0 = u32x2{pack_bf16x2(v0[0], v0[1]) & m, pack_bf16x2(v0[2], v0[3]) & m};
+        const u32x2 o1 = u32x2{pack_bf16x2(v1[0], v1[1]) & m, pack_bf16x2(v1[2], v1[3]) & m};
+        if (u_act[u] && row >= lo && row < hi) {
+          const int oa = u_in[u] + out_d + (row & (ROUT - 1)) * G::ROWB;
+          *reinterpret_cast<u32x2*>(sm + oa) = o0;
+          *reinterpret_cast<u32x2*>(sm + oa + 2 * G::plane(K + 1)) = o1;
+        }
       }
-      const u32x2 o0 = u32x2{pack_bf16x2(v0[0], v0[1]) & m, pack_bf16x2(v0[2], v0[3]) & m};
-      const u32x2 o1 = u32x2{pack_bf16x2(v1[0], v1[1]) & m, pack_bf16x2(v1[2], v1[3]) & m};
-      if (act && row >= lo && row < hi) {
-        const int oa = out_const + (row & (ROUT - 1)) * G::ROWB;
-        *reinterpret_cast<u32x2*>(sm + oa) = o0;
-        *reinterpret_cast<u32x2*>(sm + oa + 2 * G::plane(K + 1)) = o1;
+    }
+    C2FS_STAMP(s, 1);
+    __syncthreads();
+  }
+}
+
+// ---- cv1's upper half (y1 into its ring) on two units of the band, and the LDS-DMA of the NEXT step's input rows for everybody:
+// Y wave yi of 2.  Pieces of 8 pixels x 128 B; this wave's share lands before its barrier (s_waitcnt vmcnt(0): a Y wave has no stores
+// in flight), the readers run after it.
+template <int NB>
+__device__ __forceinline__ void y_role(const C2fsParams& p, char* sm, int yi, int lane, int S, int n, int py0, int sx0, int LP) {
+  using G = Geo<NB>;
+  static_assert(G::NY1 <= 4 && G::RS == 2, "two Y waves x two units; lane -> row maps assume two rows per step");
+  constexpr int PCS = (G::PY1 + 1) / 2 + (G::PF + 1) / 2;  // DMA pieces per Y wave
+  static_assert(PCS <= 7, "the vmcnt switch below covers up to seven pieces in flight");
+  const int g = lane >> 4, r = lane & 15;
+  const unsigned rowpitch = (unsigned)p.W * (unsigned)p.ldx * 2u;
+  const char* ximg = p.x + (size_t)n * p.H * rowpitch;
+
+  u32x4 w1f[2][2];  // [k-tile][n-tile 2, 3]
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) w1f[kt][nt] = *reinterpret_cast<const u32x4*>(p.w1 + ((size_t)(kt * 4 + 2 + nt) * 64 + lane) * 16);
+  const f32x4 bias0 = *reinterpret_cast<const f32x4*>(p.b1 + 32 + 4 * g), bias1 = *reinterpret_cast<const f32x4*>(p.b1 + 48 + 4 * g);
+
+  int u_q[2], u_rr[2], u_out[2];
+  unsigned u_colm[2];
+  bool u_act[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int q = (2 * yi + u) * 16 + r;
+    u_q[u] = q;
+    u_act[u] = (2 * yi + u) < G::NY1 && q < G::RS * G::XW;
+    const int qq = u_act[u] ? q : 0;
+    u_rr[u] = qq >= G::XW ? 1 : 0;
+    const int col = qq - u_rr[u] * G::XW;
+    u_out[u] = G::base(0) + (g >> 1) * G::plane(0) + col * 16 + (g & 1) * 8;
+    const int gx = sx0 - G::R + col;
+    u_colm[u] = (gx >= 0 && gx < p.W) ? 0xFFFFFFFFu : 0u;
+  }
+  // DMA pieces: cv1 band pieces [yi * ceil(PY1 / 2), ...), cv2 band pieces likewise; lane (lane >> 3) = pixel of the piece, (lane & 7) = 16-byte slot
+  unsigned d_col[PCS];
+  int d_rr[PCS], d_dst[PCS];
+  bool d_ok[PCS], d_isf[PCS];
+#pragma unroll
+  for (int i = 0; i < PCS; ++i) {
+    const bool isf = i >= (G::PY1 + 1) / 2;
+    const int pc = isf ? yi * ((G::PF + 1) / 2) + (i - (G::PY1 + 1) / 2) : yi * ((G::PY1 + 1) / 2) + i;
+    const int npc = isf ? G::PF : G::PY1, width = isf ? WS : G::XW, npx = G::RS * width;
+    d_isf[i] = isf;
+    d_ok[i] = pc < npc && (isf ? i - (G::PY1 + 1) / 2 < (G::PF + 1) / 2 : true);
+    const int pd = pc * 8 + (lane >> 3);
+    const int pq = pd < npx ? pd : 0;
+    d_rr[i] = pq >= width ? 1 : 0;
+    const int dcol = pq - d_rr[i] * width;
+    int dgx = sx0 + dcol - (isf ? 0 : G::R);
+    dgx = dgx < 0 ? 0 : (dgx >= p.W ? p.W - 1 : dgx);
+    const int cg = (lane & 7) ^ (pd & 7);
+    d_col[i] = (unsigned)dgx * (unsigned)p.ldx * 2u + (unsigned)cg * 16u;
+    d_dst[i] = (isf ? G::XF : G::XS) + pc * 1024;
+  }
+  auto stage_in = [&](int st) __attribute__((always_inline)) {  // returns the number of pieces issued
+    const int slot = st % G::NSLOT;
+    int issued = 0;
+    const int y0r = py0 - G::R + G::RS * st;             // image row of the cv1 band's first row
+    const int f0r = y0r - G::LAGF;                       // ... of the cv2 band's
+    const bool yon = G::RS * st < LP;
+    const int o0 = G::RS * st - G::LAGF;
+    const bool fon = o0 + G::RS > G::R && o0 < LP - G::R;
+    unsigned yro[2], fro[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      int a = y0r + k, b = f0r + k;
+      a = a < 0 ? 0 : (a >= p.H ? p.H - 1 : a);
+      b = b < 0 ? 0 : (b >= p.H ? p.H - 1 : b);
+      yro[k] = (unsigned)a * rowpitch;
+      fro[k] = (unsigned)b * rowpitch;
+    }
+#pragma unroll
+    for (int i = 0; i < PCS; ++i) {
+      if (!d_ok[i] || !(d_isf[i] ? fon : yon)) continue;  // wave-uniform
+      const unsigned off = d_col[i] + (d_isf[i] ? (d_rr[i] ? fro[1] : fro[0]) : (d_rr[i] ? yro[1] : yro[0]));
+      __builtin_amdgcn_global_load_lds((cgptr_t)(ximg + off), (clptr_t)(sm + d_dst[i] + slot * (d_isf[i] ? G::FSLOT : G::XSLOT)), 16, 0, 0);
+      ++issued;
+    }
+    return issued;
+  };
+
+  stage_in(0);
+  stage_in(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int s = 0; s < S; ++s) {
+    C2FS_STAMP(s, 0);
+    const int inflight = stage_in(s + 2);  // lands during the NEXT step; the band of step s + 1 went out a step ago
+    if (s == 12) C2FS_STAMP(32, 0);
+    if (G::RS * s < LP) {
+      const char* xb = sm + G::XS + (s % G::NSLOT) * G::XSLOT;
+      u32x4 bx[2][2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) bx[u][kt] = *reinterpret_cast<const u32x4*>(xb + u_q[u] * 128 + (((kt * 4 + g) ^ (u_q[u] & 7)) << 4));
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (2 * yi + u >= G::NY1) break;  // wave-uniform
+        f32x4 a0 = bias0, a1 = bias1;
+        if (s == 12 && u == 0) C2FS_STAMP(32, 1);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+          a0 = mfma32(w1f[kt][0], bx[u][kt], a0);
+          a1 = mfma32(w1f[kt][1], bx[u][kt], a1);
+        }
+        const int row = G::RS * s + u_rr[u];
+        const int gy = py0 - G::R + row;
+        const unsigned m = (gy >= 0 && gy < p.H) ? u_colm[u] : 0u;
+        u32x2 o0 = silu_pack(a0), o1 = silu_pack(a1);
+        o0[0] &= m; o0[1] &= m; o1[0] &= m; o1[1] &= m;
+        if (u_act[u] && row < LP) {
+          const int oa = u_out[u] + (row & (G::ring(0) - 1)) * G::ROWB;
+          *reinterpret_cast<u32x2*>(sm + oa) = o0;
+          *reinterpret_cast<u32x2*>(sm + oa + 2 * G::plane(0)) = o1;
+        }
+        if (s == 12 && u == 0) C2FS_STAMP(33, 0);
       }
+    }
+    C2FS_STAMP(s, 1);
+    // the NEXT step's input pieces of this wave have landed: everything but the `inflight` youngest requests (a Y wave issues no other
+    // vector-memory operation, so the count is exact)
+    switch (inflight) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
     }
     __syncthreads();
   }
 }
 
-// ---- cv1 (y1 into its ring), y0 + cv2 (output rows): X wave xi of NX
+// ---- y0 + cv2 on unit fu of the output band, output n-tiles 2 fj, 2 fj + 1: every weight in registers, no LDS-DMA, stores never waited for
 template <int NB>
-__device__ __forceinline__ void x_role(const C2fsParams& p, char* sm, int xi, int lane, int S, int n, int py0, int sx0, int LP) {
+__device__ __forceinline__ void f_role(const C2fsParams& p, char* sm, int fu, int fj, int lane, int S, int n, int py0, int sx0, int LP) {
   using G = Geo<NB>;
-  constexpr int NX = 16 - (G::units(0) + G::units(1) + (NB == 2 ? G::units(2) + G::units(3) : 0));
-  static_assert(G::NY1 <= 2 * NX && G::NF <= NX, "cv1 / cv2 units must fit the X waves");
   static_assert(G::RS == 2, "lane -> row maps assume two rows per step");
   const int g = lane >> 4, r = lane & 15;
-  const size_t rowpitch = (size_t)p.W * p.ldx * 2;
-  const char* ximg = p.x + (size_t)n * p.H * rowpitch;
 
-  // cv1 fragments: [k-tile 0..1][n-tile 0..3] (n-tiles 0, 1 = y0, 2, 3 = y1)
-  u32x4 w1f[2][4];
+  u32x4 w1f[2][2];  // cv1 [k-tile][n-tile 0, 1] (y0)
 #pragma unroll
   for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) w1f[kt][nt] = *reinterpret_cast<const u32x4*>(p.w1 + ((size_t)(kt * 4 + nt) * 64 + lane) * 16);
+    for (int nt = 0; nt < 2; ++nt) w1f[kt][nt] = *reinterpret_cast<const u32x4*>(p.w1 + ((size_t)(kt * 4 + nt) * 64 + lane) * 16);
   // cv2's k-tile 0 (y0) as two 16-wide k-steps against the D layout of the y0 accumulators: lane (g, r) = W2[co = 16 nt + r][ci = 16 ks + 4g .. + 3]
-  u32x2 w2y0[2][4];
+  u32x2 w2y0[2][2];
+  u32x4 w2f[1 + NB][2];  // k-tiles 1.. (y1, b1 (, b2)) x this wave's two n-tiles
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks)
+  for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
+    for (int ks = 0; ks < 2; ++ks) {
       const int c0 = 16 * ks + 4 * g;
       const int gg = (c0 & 31) >> 3, half = (c0 & 7) >> 2;
-      w2y0[ks][nt] = *reinterpret_cast<const u32x2*>(p.w2 + ((size_t)(nt * 64 + gg * 16 + r)) * 16 + half * 8);
+      w2y0[ks][nt] = *reinterpret_cast<const u32x2*>(p.w2 + ((size_t)((2 * fj + nt) * 64 + gg * 16 + r)) * 16 + half * 8);
     }
-
-  // ---- lane constants of the (up to two) cv1 units and of the cv2 unit
-  int y1_q[2], y1_out[2], y1_row[2];
-  bool y1_act[2], y1_col[2];
-  unsigned y1_dma[2][2];  // per DMA piece: column part of the global offset
-  int y1_drow[2][2];
-  bool y1_dok[2][2];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int u = xi + t * NX;
-    const int q = u * 16 + r;
-    y1_q[t] = q;
-    y1_act[t] = u < G::NY1 && q < G::RS * G::XW;
-    const int qq = y1_act[t] ? q : 0;
-    const int rr = qq >= G::XW ? 1 : 0, col = qq - rr * G::XW;
-    y1_row[t] = rr;
-    y1_out[t] = G::base(0) + (g >> 1) * G::plane(0) + col * 16 + (g & 1) * 8;
-    const int gx = sx0 - G::R + col;
-    y1_col[t] = gx >= 0 && gx < p.W;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int pd = u * 16 + 8 * i + (lane >> 3);
-      y1_dok[t][i] = u < G::NY1 && (u * 16 + 8 * i) < G::RS * G::XW;  // wave-uniform: the piece holds at least one pixel
-      const int pq = pd < G::RS * G::XW ? pd : 0;
-      const int drr = pq >= G::XW ? 1 : 0, dcol = pq - drr * G::XW;
-      int dgx = sx0 - G::R + dcol;
-      dgx = dgx < 0 ? 0 : (dgx >= p.W ? p.W - 1 : dgx);
-      const int cg = (lane & 7) ^ (pd & 7);
-      y1_drow[t][i] = drr;
-      y1_dma[t][i] = (unsigned)dgx * (unsigned)p.ldx * 2u + (unsigned)cg * 16u;
-    }
+    for (int k = 0; k < 1 + NB; ++k) w2f[k][nt] = *reinterpret_cast<const u32x4*>(p.w2 + ((size_t)((k + 1) * 4 + 2 * fj + nt) * 64 + lane) * 16);
   }
-  const int fu = xi;  // the cv2 unit
+  const f32x4 by0a = *reinterpret_cast<const f32x4*>(p.b1 + 4 * g), by0b = *reinterpret_cast<const f32x4*>(p.b1 + 16 + 4 * g);
+  const f32x4 b2a = *reinterpret_cast<const f32x4*>(p.b2 + (2 * fj) * 16 + 4 * g), b2b = *reinterpret_cast<const f32x4*>(p.b2 + (2 * fj + 1) * 16 + 4 * g);
+
   const int fq = fu * 16 + r;
-  const bool f_act = fu < G::NF && fq < G::RS * WS;
+  const bool f_act = fq < G::RS * WS;
   const int fqq = f_act ? fq : 0;
   const int f_rr = fqq >= WS ? 1 : 0, f_oc = fqq - f_rr * WS;
-  const int f_col = G::R + f_oc;
   const bool f_colok = sx0 + f_oc < p.W;
-  unsigned f_dma[2];
-  int f_drow[2];
-  bool f_dok[2];
+  int f_in[1 + NB];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int pd = fu * 16 + 8 * i + (lane >> 3);
-    f_dok[i] = fu < G::NF && (fu * 16 + 8 * i) < G::RS * WS;
-    const int pq = pd < G::RS * WS ? pd : 0;
-    const int drr = pq >= WS ? 1 : 0, doc = pq - drr * WS;
-    int dgx = sx0 + doc;
-    dgx = dgx >= p.W ? p.W - 1 : dgx;
-    const int cg = (lane & 7) ^ (pd & 7);
-    f_drow[i] = drr;
-    f_dma[i] = (unsigned)dgx * (unsigned)p.ldx * 2u + (unsigned)cg * 16u;
-  }
-  int f_in[3];  // B fragments of y1, b1 (, b2) at the output pixel
-#pragma unroll
-  for (int k = 0; k < 1 + NB; ++k) f_in[k] = G::base(2 * k) + g * G::plane(2 * k) + f_col * 16;
-  const size_t f_store = ((size_t)n * p.H * p.W) * (size_t)p.ldy * 2 + (size_t)(sx0 + f_oc) * p.ldy * 2;
+  for (int k = 0; k < 1 + NB; ++k) f_in[k] = G::base(2 * k) + g * G::plane(2 * k) + (G::R + f_oc) * 16;
+  const int cb = 16 * (2 * fj + (g & 1)) + 8 * (g >> 1);
+  char* const ybase = p.y + (((size_t)n * p.H * p.W) + (size_t)(sx0 + f_oc)) * (size_t)p.ldy * 2 + cb * 2;
+  const size_t yrow = (size_t)p.W * p.ldy * 2;
 
-  // DMA of the rows step `st` consumes (cv1: y1 rows RS st ..; cv2: output rows RS st - LAGF ..) into staging slot st & 1
-  auto stage_in = [&](int st) __attribute__((always_inline)) {
-    const int slot = st & 1;
-    if (G::RS * st < LP) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-          if (y1_dok[t][i]) {
-            int gy = py0 - G::R + G::RS * st + y1_drow[t][i];
-            gy = gy < 0 ? 0 : (gy >= p.H ? p.H - 1 : gy);
-            const char* src = ximg + (size_t)gy * rowpitch + y1_dma[t][i];
-            __builtin_amdgcn_global_load_lds((cgptr_t)src, (clptr_t)(sm + G::XS + slot * G::XSLOT + ((xi + t * NX) * 16 + 8 * i) * 128), 16, 0, 0);
-          }
-    }
-    const int o0 = G::RS * st - G::LAGF;
-    if (o0 + G::RS > G::R && o0 < LP - G::R) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        if (f_dok[i]) {
-          int gy = py0 - G::R + o0 + f_drow[i];
-          gy = gy < 0 ? 0 : (gy >= p.H ? p.H - 1 : gy);
-          const char* src = ximg + (size_t)gy * rowpitch + f_dma[i];
-          __builtin_amdgcn_global_load_lds((cgptr_t)src, (clptr_t)(sm + G::XF + slot * G::FSLOT + (fu * 16 + 8 * i) * 128), 16, 0, 0);
-        }
-    }
-  };
-
-  stage_in(0);
   for (int s = 0; s < S; ++s) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's own pieces of step s have landed (nobody else reads them)
-    stage_in(s + 1);
-    const int slot = s & 1;
-    // ---- cv1 upper half -> y1 rows RS s, RS s + 1
-    if (G::RS * s < LP) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        if (xi + t * NX >= G::NY1) break;  // wave-uniform
-        const int q = y1_q[t];
-        const char* xb = sm + G::XS + slot * G::XSLOT + q * 128;
-        f32x4 a0 = *reinterpret_cast<const f32x4*>(sm + G::BIAS + (32 + 4 * g) * 4);
-        f32x4 a1 = *reinterpret_cast<const f32x4*>(sm + G::BIAS + (48 + 4 * g) * 4);
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-          const u32x4 b = *reinterpret_cast<const u32x4*>(xb + (((kt * 4 + g) ^ (q & 7)) << 4));
-          a0 = mfma32(w1f[kt][2], b, a0);
-          a1 = mfma32(w1f[kt][3], b, a1);
-        }
-        const int row = G::RS * s + y1_row[t];
-        const int gy = py0 - G::R + row;
-        const unsigned m = (y1_col[t] && gy >= 0 && gy < p.H) ? 0xFFFFFFFFu : 0u;
-        u32x2 o0 = silu_pack(a0), o1 = silu_pack(a1);
-        o0[0] &= m; o0[1] &= m; o1[0] &= m; o1[1] &= m;
-        if (y1_act[t] && row < LP) {
-          const int oa = y1_out[t] + (row & (G::ring(0) - 1)) * G::ROWB;
-          *reinterpret_cast<u32x2*>(sm + oa) = o0;
-          *reinterpret_cast<u32x2*>(sm + oa + 2 * G::plane(0)) = o1;
-        }
-      }
-    }
-    // ---- y0 and cv2 on output rows RS s - LAGF ..
+    C2FS_STAMP(s, 0);
     const int o0r = G::RS * s - G::LAGF;
-    if (fu < G::NF && o0r + G::RS > G::R && o0r < LP - G::R) {
+    if (o0r + G::RS > G::R && o0r < LP - G::R) {
       const int row = o0r + f_rr;
-      const char* xb = sm + G::XF + slot * G::FSLOT + fq * 128;
-      f32x4 y0a = *reinterpret_cast<const f32x4*>(sm + G::BIAS + (0 + 4 * g) * 4);
-      f32x4 y0b = *reinterpret_cast<const f32x4*>(sm + G::BIAS + (16 + 4 * g) * 4);
+      const char* xb = sm + G::XF + (s % G::NSLOT) * G::FSLOT + fq * 128;
+      u32x4 bx[2], opnd[1 + NB];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) bx[kt] = *reinterpret_cast<const u32x4*>(xb + (((kt * 4 + g) ^ (fq & 7)) << 4));
+#pragma unroll
+      for (int k = 0; k < 1 + NB; ++k) opnd[k] = lds128(sm, f_in[k] + (row & (G::ring(2 * k) - 1)) * G::ROWB);
+      f32x4 y0a = by0a, y0b = by0b;
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) {
-        const u32x4 b = *reinterpret_cast<const u32x4*>(xb + (((kt * 4 + g) ^ (fq & 7)) << 4));
-        y0a = mfma32(w1f[kt][0], b, y0a);
-        y0b = mfma32(w1f[kt][1], b, y0b);
+        y0a = mfma32(w1f[kt][0], bx[kt], y0a);
+        y0b = mfma32(w1f[kt][1], bx[kt], y0b);
       }
+      if (s == 12) C2FS_STAMP(32, 0);
       const u32x2 y0B[2] = {silu_pack(y0a), silu_pack(y0b)};
-      u32x4 opnd[1 + NB];
-#pragma unroll
-      for (int k = 0; k < 1 + NB; ++k) opnd[k] = *reinterpret_cast<const u32x4*>(sm + f_in[k] + (row & (G::ring(2 * k) - 1)) * G::ROWB);
-      f32x4 o[4];
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        o[nt] = *reinterpret_cast<const f32x4*>(sm + G::BIAS + (64 + nt * 16 + 4 * g) * 4);
-        o[nt] = mfma16(w2y0[0][nt], y0B[0], o[nt]);
-        o[nt] = mfma16(w2y0[1][nt], y0B[1], o[nt]);
-      }
+      if (s == 12) C2FS_STAMP(32, 1);
+      f32x4 o0 = b2a, o1 = b2b;
+      o0 = mfma16(w2y0[0][0], y0B[0], o0);
+      o1 = mfma16(w2y0[0][1], y0B[0], o1);
+      o0 = mfma16(w2y0[1][0], y0B[1], o0);
+      o1 = mfma16(w2y0[1][1], y0B[1], o1);
       // A 4-pass 16x16x16 MFMA whose result is the NEXT instruction's srcC of an 8-pass 16x16x32 MFMA came out wrong in rows 2, 3
       // of each lane's four (measured, ROCm 7.2 / gfx950: hipcc inserts no wait states between the two shapes on one accumulator):
-      // finish every 16-wide chain first, then wait out the short pipeline before the 32-wide chains start.
+      // finish the 16-wide chains first, then wait out the short pipeline before the 32-wide chains start.
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_nop 15" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-#pragma unroll
-        for (int k = 0; k < 1 + NB; ++k) {
-          const u32x4 a = *reinterpret_cast<const u32x4*>(sm + G::W2S + (((k + 1) * 4 + nt) * 64 + lane) * 16);
-          o[nt] = mfma32(a, opnd[k], o[nt]);
-        }
+      for (int k = 0; k < 1 + NB; ++k) {
+        o0 = mfma32(w2f[k][0], opnd[k], o0);
+        o1 = mfma32(w2f[k][1], opnd[k], o1);
       }
       const int gy = py0 - G::R + row;
-      const bool st_ok = f_act && f_colok && row >= G::R && row < LP - G::R && gy < p.H;
-      char* dst = p.y + f_store + (size_t)gy * p.W * p.ldy * 2;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const u32x2 a = silu_pack(o[2 * j]), b = silu_pack(o[2 * j + 1]);
-        auto lo = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
-        auto hi = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
-        const int cb = 16 * (2 * j + (g & 1)) + 8 * (g >> 1);
-        if (st_ok) *reinterpret_cast<u32x4*>(dst + cb * 2) = u32x4{lo[0], hi[0], lo[1], hi[1]};
-      }
+      if (s == 12) C2FS_STAMP(33, 0);
+      const u32x2 a = silu_pack(o0), b = silu_pack(o1);
+      auto lo = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+      auto hi = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+      if (f_act && f_colok && row >= G::R && row < LP - G::R && gy < p.H)
+        *reinterpret_cast<u32x4*>(ybase + (size_t)gy * yrow) = u32x4{lo[0], hi[0], lo[1], hi[1]};
     }
+    C2FS_STAMP(s, 1);
     __syncthreads();
   }
 }
@@ -370,21 +459,30 @@ __global__ __launch_bounds__(1024) void c2f32_stream_kernel(const C2fsParams p) 
   const int LP = leff + 2 * G::R;                              // rows of y1 this workgroup produces
   const int S = (leff + G::R + G::LAGF - 1) / G::RS + 1;       // steps until the last output row has left
 
-  // cv2 fragments and every bias -> LDS (read by the X waves each step: they have no registers to spare for them)
-  for (int i = tid; i < G::W2B / 16; i += 1024) *reinterpret_cast<u32x4*>(sm + G::W2S + i * 16) = *reinterpret_cast<const u32x4*>(p.w2 + (size_t)i * 16);
-  if (tid < 64) reinterpret_cast<float*>(sm + G::BIAS)[tid] = p.b1[tid];
-  else if (tid < 128) reinterpret_cast<float*>(sm + G::BIAS)[tid] = p.b2[tid - 64];
-  else if (tid < 128 + G::NST * 32) reinterpret_cast<float*>(sm + G::BIAS)[tid] = p.bm[(tid - 128) >> 5][(tid - 128) & 31];
-  __syncthreads();
+  // the 3x3 stages' biases -> LDS (their waves have no registers to spare)
+  if (tid < G::NST * 32) reinterpret_cast<float*>(sm + G::BIAS)[tid] = p.bm[tid >> 5][tid & 31];
+  if (wave != 11 && wave != 15) __syncthreads();  // (the Y waves arrive at this barrier with the first input band landed)
 
-  // wave -> role.  Waves w, w + 4, w + 8, w + 12 share a SIMD: each SIMD gets at most one X wave (the VALU-heavy role).
+  // wave -> role.  Waves w, w + 4, w + 8, w + 12 share a SIMD; MFMAs per step and SIMD: 82 / 82 / 82 / 88.
+  //   SIMD 0: t1 units 0-1, b1 unit 2, cv2 (0, 0), cv2 (1, 1)     SIMD 1: t1 units 2-3, t2 unit 2, cv2 (0, 1), cv2 (2, 0)
+  //   SIMD 2: b1 units 0-1, b2 unit 2, cv2 (1, 0), cv2 (2, 1)     SIMD 3: t2 units 0-1, b2 units 0-1, the two cv1 + DMA waves
   switch (wave) {
-    case 0: case 1: case 2: case 3: c2fs::stage_role<NB, 0>(p, sm, wave, lane, S, py0, sx0, LP); break;
-    case 4: case 5: case 6: c2fs::stage_role<NB, 1>(p, sm, wave - 4, lane, S, py0, sx0, LP); break;
-    case 7: case 8: case 9: c2fs::stage_role<NB, 2>(p, sm, wave - 7, lane, S, py0, sx0, LP); break;
-    case 10: case 11: c2fs::stage_role<NB, 3>(p, sm, wave - 10, lane, S, py0, sx0, LP); break;
-    case 15: c2fs::stage_role<NB, 3>(p, sm, 2, lane, S, py0, sx0, LP); break;
-    default: c2fs::x_role<NB>(p, sm, wave - 12, lane, S, n, py0, sx0, LP); break;
+    case 0: c2fs::stage_role<NB, 0, true>(p, sm, 0, lane, S, py0, sx0, LP); break;
+    case 1: c2fs::stage_role<NB, 0, true>(p, sm, 2, lane, S, py0, sx0, LP); break;
+    case 2: c2fs::stage_role<NB, 1, true>(p, sm, 0, lane, S, py0, sx0, LP); break;
+    case 3: c2fs::stage_role<NB, 2, true>(p, sm, 0, lane, S, py0, sx0, LP); break;
+    case 4: c2fs::stage_role<NB, 1, false>(p, sm, 2, lane, S, py0, sx0, LP); break;
+    case 5: c2fs::stage_role<NB, 2, false>(p, sm, 2, lane, S, py0, sx0, LP); break;
+    case 6: c2fs::stage_role<NB, 3, false>(p, sm, 2, lane, S, py0, sx0, LP); break;
+    case 7: c2fs::stage_role<NB, 3, true>(p, sm, 0, lane, S, py0, sx0, LP); break;
+    case 8: c2fs::f_role<NB>(p, sm, 0, 0, lane, S, n, py0, sx0, LP); break;
+    case 9: c2fs::f_role<NB>(p, sm, 0, 1, lane, S, n, py0, sx0, LP); break;
+    case 10: c2fs::f_role<NB>(p, sm, 1, 0, lane, S, n, py0, sx0, LP); break;
+    case 11: c2fs::y_role<NB>(p, sm, 0, lane, S, n, py0, sx0, LP); break;
+    case 12: c2fs::f_role<NB>(p, sm, 1, 1, lane, S, n, py0, sx0, LP); break;
+    case 13: c2fs::f_role<NB>(p, sm, 2, 0, lane, S, n, py0, sx0, LP); break;
+    case 14: c2fs::f_role<NB>(p, sm, 2, 1, lane, S, n, py0, sx0, LP); break;
+    default: c2fs::y_role<NB>(p, sm, 1, lane, S, n, py0, sx0, LP); break;
   }
 }
 
