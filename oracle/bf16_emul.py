@@ -11,7 +11,11 @@ rounds to bf16 at exactly these tensors and nowhere else -
   * Detect (nn/modules/head.py:94-126, 151-169): the two `Conv`s of a branch round as above; the final `nn.Conv2d` 1x1 multiplies
     bf16 weights and bf16 activations into f32 accumulators and the decode (DFL softmax expectation, dist2bbox, sigmoid) runs on
     those f32 values - the 144 logits are never rounded; the decoded output is f32;
-  * MaxPool / Upsample / Concat / chunk move bf16 values unchanged.
+  * MaxPool / Upsample / Concat / chunk move bf16 values unchanged;
+  * MHSA inside a BottleneckTransformer (nn/modules/block.py:6020-6092; csrc/attention.hip, the matrix-core kernel): q, k, v = the
+    three 1x1 convs (bf16 weights, f32 bias) rounded once each; the scores q^T k stay f32; the keys are walked in blocks of 32 with an
+    online softmax whose exponentials exp2((s - running max) log2 e) are rounded to bf16 as the second product's operand while their
+    f32 values feed the denominator; the output o / l plus the block input (the shortcut) is rounded once.
 
 `emulate_bf16(model)` returns a copy of an ORACLE model (oracle/tasks.py) that computes exactly that on the CPU: f32 torch ops on
 bf16-valued tensors with a rounding where the kernels round.  What is left between it and the HIP bf16 output is the order of f32
@@ -42,6 +46,30 @@ def bf16_ulp(v: torch.Tensor) -> torch.Tensor:
     return torch.exp2(torch.floor(torch.log2(a)) - 7.0)
 
 
+def _mhsa_bf16(mh: "om.MHSA", x: torch.Tensor) -> torch.Tensor:
+    """MHSA.forward (block.py:6036-6062) with the rounding points of csrc/attention.hip's bf16 matrix-core kernel; returns f32 (the
+    caller adds the shortcut and rounds)."""
+    b, c, w, h = x.shape
+    n, hd, d = w * h, mh.heads, c // mh.heads
+    q = bf16_round(mh.query(x)).view(b, hd, d, n)
+    k = bf16_round(mh.key(x)).view(b, hd, d, n)
+    v = bf16_round(mh.value(x)).view(b, hd, d, n)
+    t_all = torch.matmul(q.permute(0, 1, 3, 2), k) * torch.tensor(1.4426950408889634, dtype=torch.float32)  # (b, hd, queries, keys)
+    m = torch.full((b, hd, n), float("-inf"))
+    l = torch.zeros(b, hd, n)
+    o = torch.zeros(b, hd, n, d)
+    for kb in range(0, n, 32):
+        t = t_all[..., kb:kb + 32]
+        mn = torch.maximum(m, t.amax(-1))
+        alpha = torch.exp2(m - mn)
+        pe = torch.exp2(t - mn[..., None])
+        l = l * alpha + pe.sum(-1)
+        o = o * alpha[..., None] + torch.matmul(bf16_round(pe), v[..., kb:kb + 32].transpose(-1, -2))
+        m = mn
+    out = o * (1.0 / l)[..., None]
+    return out.permute(0, 1, 3, 2).reshape(b, c, w, h)
+
+
 def emulate_bf16(model: nn.Module) -> nn.Module:
     m = copy.deepcopy(model).eval()
     # BatchNorm folded in f32 (the oracle's own fold = the product's fold_bn), then every conv weight rounded once
@@ -58,6 +86,12 @@ def emulate_bf16(model: nn.Module) -> nn.Module:
         if isinstance(mod, om.Bottleneck) and mod.add:
             deferred.add(id(mod.cv2))          # rounded after the shortcut add, by the Bottleneck hook below
             mod.register_forward_hook(lambda _m, _i, out: bf16_round(out))
+    for mod in m.modules():
+        if isinstance(mod, om.BottleneckTransformer):  # x + MHSA(cv1(x)): the kernel adds the shortcut in f32 and rounds the sum
+            def bt_forward(x, mod=mod):
+                a = _mhsa_bf16(mod.cv2[0], mod.cv1(x))
+                return bf16_round(x + a if mod.shortcut else a)
+            mod.forward = bt_forward
     for mod in m.modules():
         if isinstance(mod, om.Conv) and id(mod) not in deferred:
             mod.register_forward_hook(lambda _m, _i, out: bf16_round(out))

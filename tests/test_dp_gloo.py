@@ -224,6 +224,37 @@ def test_bench_gpus_flag_launches_ranks_itself():
             assert rec["images_validated"] == 128 and rec["detection_rows_gathered"] == 32 * (5 + 6 + 6 + 7)
 
 
+def test_bench_world8_dry_run_of_config3_and_validate():
+    """The shape BASELINE config 3 is defined on - yolov8s, global batch 256 over 8 ranks (trainer.py:317: 32 per rank) - and the
+    validate path at 8 ranks, executed without a GPU: eight gloo ranks started by `bench.py --gpus 8` itself, shard offsets that tile
+    the image stream, the SAME gradient-bucket table on every rank (utils/dist.py:77-104 launches the ranks, trainer.py:424-425 the
+    exchange they perform), a bucket-by-bucket SUM all-reduce of a model-sized flat buffer, one JSON line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    for wl, extra in (("train", ["--model", "yolov8s", "--batch", "256", "--scaling", "strong"]), ("val", ["--batch", "32"])):
+        r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--dry-run",
+                            "--workload", wl] + extra, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        rec = json.loads(lines[0])
+        assert rec["n_gpus"] == 8 and rec["rccl_ranks_seen"] == 8 and rec["config"]["parallelism"] == "dp8"
+        assert rec["config"]["per_gpu_batch"] == 32 and rec["config"]["global_batch"] == 256
+        assert rec["shard_offsets"] == [32 * k for k in range(8)]
+        assert rec["ms_per_step"] >= 8.0  # the slowest rank (8 ms per step) sets the time
+        if wl == "train":
+            assert rec["scaling"] == "strong" and rec["bucket_tables_identical"] and rec["allreduce_sum_ok"]
+            assert rec["gradient_buckets"] == 3 and rec["bucket_coverage"] == rec["gradient_floats"] == 11166544
+        else:
+            assert rec["images_validated"] == 2 * 32 * 8
+
+
 def _validator_rank(rank, world, port, golden, q):
     import os
     import numpy as np

@@ -43,7 +43,11 @@ class PipelinedRunner:
         #     throughput in flight (51.6 k vs 50.5 k img/s, same box), 4 % faster with one step at a time (1.012 vs 1.054 ms);
         #   * the persistent 3x3 kernel (csrc/conv_ws3.hip) is 12 % faster than conv_big launch for launch, but its resident workgroups
         #     keep their CUs until the launch ends: -0.7 % in flight (51.6 k vs 52.0 k), neutral to +0.2 % one step at a time.
-        # So: in flight > 1 -> upa_opts.c2f = 4 and conv_ws3 = 1 for the compiled copies, unless the caller's options already set them.
+        #   * the line-buffer C2f kernel (csrc/c2f_stream.hip) pays 11 steps of pipeline fill per workgroup: whole-height strips (128 workgroups
+        #     for the 80 x 80 maps at batch 32: half the CUs, the other steps' kernels take the rest) hold 15 % less CU time than the two
+        #     parts per strip that fill the chip with one round: 56.0 k vs 55.4 k img/s in flight (same box), 90 vs 53 us one step at a time.
+        # So: in flight > 1 -> upa_opts.c2f = 4, conv_ws3 = 1 and c2f_stream_rows = -1 for the compiled copies, unless the caller's options
+        # already set them.
         from . import runtime as R
         cur = R.current_opts()
         mode = {}
@@ -52,6 +56,8 @@ class PipelinedRunner:
                 mode["c2f"] = 4
             if cur is None or cur.conv_ws3 == 0:
                 mode["conv_ws3"] = 1
+            if cur is None or cur.c2f_stream_rows == 0:
+                mode["c2f_stream_rows"] = -1
         self.throughput_opts = dict(mode)
         try:
             with torch.no_grad(), (R.use_opts(**mode) if mode else contextlib.nullcontext()):

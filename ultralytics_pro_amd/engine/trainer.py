@@ -388,33 +388,19 @@ class DetectionTrainer:
     # ---- parameters ---------------------------------------------------------------------------------------------------
     def _flatten_parameters(self, ema):
         """Flat f32 buffers [biases | decayed weights | norm weights] with model.parameters() viewing into them."""
-        g0, g1, g2 = [], [], []
-        norm = tuple(v for k, v in nn.__dict__.items() if "Norm" in k)
-        for mname, mod in self.model.named_modules():
-            for pname, p in mod.named_parameters(recurse=False):
-                if not p.requires_grad:
-                    continue
-                full = f"{mname}.{pname}" if mname else pname
-                (g2 if "bias" in full else g1 if isinstance(mod, norm) else g0).append(p)
-        self.groups = []
-        self._param_meta = []  # (state_dict name, flat offset, numel) in flat order: gradient buckets are cut by layer from it
-        names = {id(p): n for n, p in self.model.named_parameters()}
-        total = sum(p.numel() for g in (g2, g0, g1) for p in g)
+        from ..parallel import flat_parameter_layout
+        layout, meta = flat_parameter_layout(self.model)
+        total = sum(n for _, n, _ in layout)
         dev = self.device
         self.P = torch.empty(total, dtype=torch.float32, device=dev)
         self.G = torch.zeros(total, dtype=torch.float32, device=dev)
         self.M = torch.zeros(total, dtype=torch.float32, device=dev)
-        off = 0
-        for params, wd in ((g2, 0.0), (g0, self.hyp["weight_decay"]), (g1, 0.0)):
-            start = off
-            for p in params:
-                n = p.numel()
-                self.P[off:off + n].copy_(p.detach().reshape(-1))  # plumbing: one-time gather of the initial weights
-                p.data = self.P[off:off + n].view(p.shape)
-                p.grad = self.G[off:off + n].view(p.shape)
-                self._param_meta.append((names.get(id(p), ""), off, n))
-                off += n
-            self.groups.append((start, off - start, wd))
+        for _name, off, n, p in meta:
+            self.P[off:off + n].copy_(p.detach().reshape(-1))  # plumbing: one-time gather of the initial weights
+            p.data = self.P[off:off + n].view(p.shape)
+            p.grad = self.G[off:off + n].view(p.shape)
+        self.groups = [(start, n, self.hyp["weight_decay"] if wd else 0.0) for start, n, wd in layout]
+        self._param_meta = [(name, off, n) for name, off, n, _ in meta]  # flat order: gradient buckets are cut by layer from it
         self.E = self.P.clone() if ema else None  # ModelEMA copy of the parameters
         bufs = [b for b in self.model.buffers() if b.dtype.is_floating_point]
         nb = sum(b.numel() for b in bufs)
@@ -630,30 +616,8 @@ class DetectionTrainer:
         three spans of its 44.7 MB), as (first layer of the span, [flat ranges]).  Within each optimizer group the parameters
         lie in layer order, so a span of layers is ONE contiguous range per group.  A span is complete - every gradient kernel
         of its layers enqueued - once the backward walk has passed its first layer."""
-        per_layer = {}
-        for name, off, n in self._param_meta:
-            parts = name.split(".")
-            li = int(parts[1]) if len(parts) > 1 and parts[0] == "model" and parts[1].isdigit() else -1
-            per_layer.setdefault(li, []).append((off, off + n))
-        layers = sorted(per_layer, reverse=True)
-        spans, cur, cur_bytes = [], [], 0
-        for li in layers:
-            cur.append(li)
-            cur_bytes += 4 * sum(b - a for a, b in per_layer[li])
-            if cur_bytes >= target_bytes:
-                spans.append(cur)
-                cur, cur_bytes = [], 0
-        if cur:
-            spans.append(cur)
-        out = []
-        for sp in spans:
-            ranges = []
-            for gstart, gn, _ in self.groups:  # merge the span's parameters of one group into one range
-                inside = [(a, b) for li in sp for a, b in per_layer[li] if gstart <= a < gstart + gn]
-                if inside:
-                    ranges.append((min(a for a, _ in inside), max(b for _, b in inside)))
-            out.append((min(sp), ranges))
-        return out
+        from ..parallel import gradient_bucket_table
+        return gradient_bucket_table(self._param_meta, self.groups, target_bytes)
 
     def enable_overlapped_allreduce(self, target_bytes: int = 16 << 20):
         """Issue the gradient all-reduce per bucket DURING backward on a communication stream (eager steps only: a collective

@@ -398,6 +398,12 @@ class Detect(nn.Module, _HipConvMixin):
             y._upa_hot = hot
         elif hasattr(y, "_upa_hot"):
             del y._upa_hot
+        # keys-only mode (`scores_out = False`): rows 4.. of y were NOT written in this forward - mark the tensor so that every reader of
+        # class scores (multi-label NMS, the validator) refuses it instead of reading stale memory
+        if self._keys_only() and hasattr(y, "_upa_hot"):
+            y._upa_keys_only = True
+        elif hasattr(y, "_upa_keys_only"):
+            del y._upa_keys_only
         return y
 
     def bias_init(self):

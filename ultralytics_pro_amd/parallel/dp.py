@@ -40,6 +40,64 @@ def shard_first_image(rank: int, per_rank_batch: int) -> int:
     return rank * per_rank_batch
 
 
+def flat_parameter_layout(model):
+    """Order of the trainer's flat f32 parameter / gradient buffers, [biases | decayed weights | norm weights] (the reference's three
+    optimizer groups, engine/trainer.py:674-682 `build_optimizer`): (groups [(start, numel, has_weight_decay)], meta [(state_dict name,
+    flat offset, numel)] in flat order).  Pure bookkeeping on the module tree - no tensors are touched - so every rank of a job (and the
+    CPU dry run of `bench.py --gpus N`) derives the same table."""
+    import torch.nn as nn
+    g0, g1, g2 = [], [], []
+    norm = tuple(v for k, v in nn.__dict__.items() if "Norm" in k)
+    for mname, mod in model.named_modules():
+        for pname, p in mod.named_parameters(recurse=False):
+            if not p.requires_grad:
+                continue
+            full = f"{mname}.{pname}" if mname else pname
+            (g2 if "bias" in full else g1 if isinstance(mod, norm) else g0).append(p)
+    names = {id(p): n for n, p in model.named_parameters()}
+    groups, meta, off = [], [], 0
+    for params, wd in ((g2, False), (g0, True), (g1, False)):
+        start = off
+        for p in params:
+            meta.append((names.get(id(p), ""), off, p.numel(), p))
+            off += p.numel()
+        groups.append((start, off - start, wd))
+    return groups, meta
+
+
+def gradient_bucket_table(meta, groups, target_bytes: int = 16 << 20):
+    """Layer spans, last layer first, of at least `target_bytes` of f32 gradients each (DDP's bucket_cap_mb idea; yolov8s: three spans of
+    its 44.7 MB), as [(first layer of the span, [flat ranges])].  `meta` = (name, offset, numel, ...) rows in flat order, `groups` =
+    (start, numel, ...) rows: within each optimizer group the parameters lie in layer order, so a span of layers is ONE contiguous range
+    per group.  A span is complete - every gradient kernel of its layers enqueued - once the backward walk has passed its first layer."""
+    per_layer = {}
+    for row in meta:
+        name, off, n = row[0], row[1], row[2]
+        parts = name.split(".")
+        li = int(parts[1]) if len(parts) > 1 and parts[0] == "model" and parts[1].isdigit() else -1
+        per_layer.setdefault(li, []).append((off, off + n))
+    layers = sorted(per_layer, reverse=True)
+    spans, cur, cur_bytes = [], [], 0
+    for li in layers:
+        cur.append(li)
+        cur_bytes += 4 * sum(b - a for a, b in per_layer[li])
+        if cur_bytes >= target_bytes:
+            spans.append(cur)
+            cur, cur_bytes = [], 0
+    if cur:
+        spans.append(cur)
+    out = []
+    for sp in spans:
+        ranges = []
+        for g in groups:  # merge the span's parameters of one group into one range
+            gstart, gn = g[0], g[1]
+            inside = [(a, b) for li in sp for a, b in per_layer[li] if gstart <= a < gstart + gn]
+            if inside:
+                ranges.append((min(a for a, _ in inside), max(b for _, b in inside)))
+        out.append((min(sp), ranges))
+    return out
+
+
 def max_over_ranks(seconds: float, device=None) -> float:
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return seconds

@@ -41,6 +41,10 @@ def nms_raw(prediction: torch.Tensor, conf_thres=0.25, iou_thres=0.45, classes=N
     # Detect's fused class tails may have written the NMS key of every anchor's best class next to the scores
     # (head.Detect.nms_keys): single-label NMS compacts those (B, A) keys instead of re-reading the (B, nc, A) scores
     hot = getattr(prediction, "_upa_hot", None)
+    if getattr(prediction, "_upa_keys_only", False) and (hot is None or (multi_label and nc > 1)):
+        raise L.UpaError("this Detect output was produced in keys-only mode (Detect.scores_out = False): its class rows were not written, "
+                         "only single-label NMS (which reads the best-class keys) can consume it - set Detect.scores_out = True for "
+                         "multi-label NMS / validation")
     if hot is not None and tuple(hot.shape) == (b, a) and hot.device == dev and not (multi_label and nc > 1):
         L.check(lib.upa_nms_batched_hot(prediction.data_ptr(), b, nc, a, float(conf_thres), float(iou_thres),
                                         int(bool(multi_label)), int(bool(agnostic)), None if cmask is None else cmask.data_ptr(),
