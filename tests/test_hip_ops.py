@@ -461,6 +461,66 @@ def test_c2f_fused_kernel(case, th):
     assert float(to_cpu_nchw(buf[:, :c1]).abs().max()) == 0.0  # nothing written outside the output slice
 
 
+C2F_STREAM1_CASES = [
+    # c1, shortcut, (N, H, W), up_c, rows per workgroup (0 = auto, -1 = whole height)
+    (192, False, (2, 80, 80), 128, 0), (192, False, (2, 80, 80), 128, -1), (192, True, (1, 38, 50), 128, 8), (192, False, (2, 18, 24), 0, 0),
+    (64, True, (2, 33, 47), 0, 0), (64, False, (1, 20, 35), 0, 6), (64, True, (2, 160, 160), 0, 0), (128, True, (1, 40, 44), 64, 0),
+    (128, False, (3, 5, 9), 0, 0), (192, True, (1, 16, 16), 128, 0),
+]
+
+
+@pytest.mark.parametrize("case", C2F_STREAM1_CASES, ids=[f"c{c[0]}{'s' if c[1] else 'n'}_{c[2][0]}x{c[2][1]}x{c[2][2]}_u{c[3]}_r{c[4]}" for c in C2F_STREAM1_CASES])
+def test_c2f_stream1_kernel(case):
+    """The line-buffer kernel of the n = 1 block (csrc/c2f_stream.hip: C2f(64 k, 64, n = 1), block.py:457-488 / 644-668; k = 1, 2, 3),
+    reached through `upa_c2f_fused` (c1 = 64) and `upa_c2f32_up_fused` (c1 = 128 | 192, with and without the virtual nn.Upsample + Concat
+    in front): against the oracle with bf16 rounding points and against the 16 x 16 tile form (`c2f_stream=1`), which it must equal up
+    to flipped rounding ties; ragged strips and parts, tiny maps, both shortcut settings, nothing written outside the output slice."""
+    from tests.hip_utils import DEV, assert_bf16_close, bf16_round, bf16_weight_oracle, to_cpu_nchw, to_dev_nhwc
+    from ultralytics_pro_amd.engine import runtime as R
+    from ultralytics_pro_amd.nn.modules.conv import VirtualUpsample
+    import ultralytics_pro_amd.nn.modules as rs
+    pm, _ = _mods()
+    c1, sc, (N, H, W), upc, rows = case
+    o, m = _pair(om.C2f, pm.C2f, (c1, 64, 1, sc), f"c2f_stream1_{c1}")
+    o = bf16_weight_oracle(o)
+    if upc:
+        u = bf16_round(P.uniform(f"c2fs1u{case}", (N, upc, H // 2, W // 2), -1.5, 1.5))
+        sk = bf16_round(P.uniform(f"c2fs1s{case}", (N, c1 - upc, H, W), -1.5, 1.5))
+        x = torch.cat([torch.nn.functional.interpolate(u, scale_factor=2, mode="nearest"), sk], 1)
+    else:
+        x = bf16_round(P.uniform(f"c2fs1{case}", (N, c1, H, W), -1.5, 1.5))
+    with torch.no_grad():
+        y01 = bf16_round(o.cv1(x))
+        ys = list(y01.chunk(2, 1))
+        t = bf16_round(o.m[0].cv1(ys[-1]))
+        ys.append(bf16_round((ys[-1] if sc else 0) + o.m[0].cv2(t)))
+        ref = o.cv2(torch.cat(ys, 1))
+        out = R.alloc_nhwc(N, 128, H, W, torch.bfloat16, DEV)
+        out.zero_()
+        m.fuse_block = True
+
+        def run(**opts):
+            if upc:
+                ud = to_dev_nhwc(u, torch.bfloat16)
+                buf = R.alloc_nhwc(N, c1, H, W, torch.bfloat16, DEV)
+                buf.fill_(7.0)  # the virtual channels must never be read from the concat buffer
+                buf[:, upc:].copy_(to_dev_nhwc(sk, torch.bfloat16))
+                v = VirtualUpsample(ud, upc, lambda: rs.Upsample(None, 2, "nearest")(ud, out=buf[:, :upc]))
+                with R.use_opts(**opts):
+                    yy = to_cpu_nchw(m(buf, out=out[:, 64:], up=v))
+                assert not v.done, "the fused form must read the half-resolution tensor itself"
+                return yy
+            with R.use_opts(**opts):
+                return to_cpu_nchw(m(to_dev_nhwc(x, torch.bfloat16), out=out[:, 64:]))
+        y = run(c2f_stream_rows=rows)
+        y_tile = run(c2f_stream=1)
+    scale = max(1.0, ref.abs().max().item())
+    assert_bf16_close(y, ref, f"c2f_stream1{case}", abs_=2.0 ** -7)
+    d = (y - y_tile).abs()
+    assert d.max().item() <= 3e-2 * scale and (d > 1e-6).float().mean().item() <= 0.03, (d.max().item(), (d > 1e-6).float().mean().item())
+    assert float(to_cpu_nchw(out[:, :64]).abs().max()) == 0.0  # nothing written outside the output slice
+
+
 C2F_STREAM_CASES = [
     # shortcut, (N, H, W), rows per workgroup (0 = auto)
     (True, (2, 80, 80), 0), (True, (2, 80, 80), 40), (True, (1, 37, 50), 0), (True, (2, 37, 50), 8), (True, (1, 16, 16), 0), (True, (3, 5, 9), 0),

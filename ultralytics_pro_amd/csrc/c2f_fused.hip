@@ -588,6 +588,9 @@ __global__ __launch_bounds__(1024) void c2f32_fused_kernel(const C2f32Params p) 
 int upa_c2f32_stream_launch(const void* x, int n, int h, int w, int ldx, int shortcut, const void* w1, const float* b1,
                             const void* const* wm, const float* const* bm, const void* w2, const float* b2, void* y, int ldy,
                             const upa_opts* opts, hipStream_t s);
+int upa_c2f32_stream1_launch(const void* x, int n, int h, int w, int c1, int ldx, const void* up, int up_c, int up_ld, int shortcut,
+                             const void* w1, const float* b1, const void* const* wm, const float* const* bm, const void* w2, const float* b2,
+                             void* y, int ldy, const upa_opts* opts, hipStream_t s);
 
 // x: (n, h, w, c1) NHWC bf16 view; w1 / b1: cv1 (1x1, c1 -> 2c); wm[2i], wm[2i + 1] / bm[..]: Bottleneck i's two 3x3 convs
 // (c -> c); w2 / b2: cv2 (1x1, (2 + nb) c -> c2) - all packed by upa_pack_conv_weight(bf16) with BN folded; y: (n, h, w, c2).
@@ -640,6 +643,11 @@ extern "C" int upa_c2f_fused(const void* x, int n, int h, int w, int c1, int ldx
     if (rc == UPA_OK) { UPA_LAUNCH_CHECK(); return UPA_OK; }
     if (rc != UPA_EUNSUPPORTED) return rc;
   }
+  if (nb == 1 && UPA_OPT(opts, c2f_stream) != 1) {
+    const int rc = upa_c2f32_stream1_launch(x, n, h, w, 64, ldx, nullptr, 0, 0, shortcut, w1, b1, wm, bm, w2, b2, y, ldy, opts, s);
+    if (rc == UPA_OK) { UPA_LAUNCH_CHECK(); return UPA_OK; }
+    if (rc != UPA_EUNSUPPORTED) return rc;
+  }
   if (nb == 2) {
     // 10-row tiles only on request (upa_opts.c2f32_th = 10): measured 80.1 against 83 us for model.4 alone and 0.636 against 0.626 ms
     // per step with four steps in flight - a tile's time is set by its six barrier-separated stages and the DMA wait more than
@@ -680,6 +688,11 @@ extern "C" int upa_c2f32_up_fused(const void* x, int n, int h, int w, int c1, in
     return UPA_EUNSUPPORTED;
   }
   for (int i = 0; i < 2; ++i) UPA_CHECK_ARG(wm[i] && bm[i], "c2f32_up_fused: null Bottleneck weights");
+  if (UPA_OPT(opts, c2f_stream) != 1) {  // the line-buffer form (c2f_stream.hip) up to 192 input channels
+    const int rc = upa_c2f32_stream1_launch(x, n, h, w, c1, ldx, up, up_c, up_ld, shortcut, w1, b1, wm, bm, w2, b2, y, ldy, opts, (hipStream_t)stream);
+    if (rc == UPA_OK) { UPA_LAUNCH_CHECK(); return UPA_OK; }
+    if (rc != UPA_EUNSUPPORTED) return rc;
+  }
   C2f32Params p;
   memset(&p, 0, sizeof(p));
   p.x = (const char*)x; p.y = (char*)y; p.w1 = (const char*)w1; p.w2 = (const char*)w2; p.b1 = b1; p.b2 = b2;

@@ -33,6 +33,9 @@ struct C2fsParams {
   const float *b1, *b2;
   const float* bm[4];
   int N, H, W, ldx, ldy, strips, parts, L, shortcut, xcd;
+  // n = 1 form: cv1 reads c1 = 64 * NCH input channels; the first upC of them come from pixel (y / 2, x / 2) of the half-resolution tensor
+  // `up` (a virtual nn.Upsample + Concat), the rest from x itself (whose pixel record still starts at channel 0 of the concat)
+  const char* up; int c1, upC, up_ld;
 };
 
 // profiling build (-DUPA_STAMP): every wave of the first 8 workgroups records s_memtime at the start of each step and before its barrier
@@ -114,7 +117,7 @@ __device__ __forceinline__ u32x4 lds128(const char* sm, int off) { return *reint
 // ---- a 3x3 stage K: the wave owns unit `unit` (and unit + 1 if TWO) of the stage's RS-row band for the life of the workgroup.
 // A unit = 16 consecutive pixels of the band (row-major over the stage's SD valid columns) x all 32 output channels.
 template <int NB, int K, bool TWO>
-__device__ __forceinline__ void stage_role(const C2fsParams& p, char* sm, int unit, int lane, int S, int py0, int sx0, int LP) {
+__device__ __forceinline__ void stage_role(const C2fsParams& p, char* sm, int unit, int lane, int S, int py0, int sx0, int LP, int bias_base) {
   using G = Geo<NB>;
   constexpr int SD = G::sd(K), C0 = K + 1, LAG = G::lag(K);
   constexpr int RIN = G::ring(K), ROUT = G::ring(K + 1);
@@ -150,7 +153,7 @@ __device__ __forceinline__ void stage_role(const C2fsParams& p, char* sm, int un
   // the lane's 8 bytes in the output / shortcut rings sit at a lane-constant distance from its input address (same pixel, another ring)
   const int out_d = G::base(K + 1) - G::base(K) + (g >> 1) * G::plane(K + 1) - g * G::plane(K) + 16 + (g & 1) * 8;
   const int res_d = HAS_RES ? G::base(K - 1) - G::base(K) + (g >> 1) * PRES - g * G::plane(K) + 16 + (g & 1) * 8 : 0;
-  const int bias_off = G::BIAS + (K * 32 + 4 * g) * 4;
+  const int bias_off = bias_base + (K * 32 + 4 * g) * 4;
   const int lo = K + 1, hi = LP - (K + 1);
   const bool use_res = HAS_RES && p.shortcut;
 
@@ -439,6 +442,206 @@ __device__ __forceinline__ void f_role(const C2fsParams& p, char* sm, int fu, in
     __syncthreads();
   }
 }
+
+// =====================================================================================================================
+// The n = 1 block: C2f(64 NCH -> 64, one Bottleneck of 32 channels) - yolov8n model.15 (NCH = 3: 128 upsampled + 64 skip channels, read
+// through the virtual nn.Upsample + Concat) and yolov8s model.2 (NCH = 1).  Same strips, rings and 3x3 roles (halo 2: y1 24 columns,
+// t1 22, b1 20); cv1 is 1.7x - 5x the work of the n = 2 block's, so it gets six waves (unit x half: y0 | y1, weights 16 NCH registers) and
+// y0 goes through a ring of its own instead of being recomputed by cv2; the input band (NCH 64-channel chunks) is staged by three waves that
+// do nothing else; cv2 is three waves with all 12 fragments in registers.
+// =====================================================================================================================
+template <int NCH>
+struct Geo1 : Geo<1> {
+  using G = Geo<1>;
+  static constexpr int Y0B = G::base(G::NTEN);            // y0 ring: as y1 (same rows alive, same pitch)
+  static constexpr int XS1 = Y0B + 4 * G::plane(0);       // input staging: NSLOT slots x NCH chunks x (RS x XW pixels x 128 B)
+  static constexpr int XCH = G::NY1 * 16 * 128;
+  static constexpr int XSLOT1 = NCH * XCH;
+  static constexpr int BIAS1 = XS1 + G::NSLOT * XSLOT1;   // f32: bm[2][32]
+  static constexpr int LDS1 = BIAS1 + 2 * 32 * 4;
+  static constexpr int PCS = NCH * G::PY1;                // DMA pieces per step
+  static constexpr int PPW = (PCS + 2) / 3;               // ... per DMA wave
+};
+
+// cv1 on unit u of the band, output half h (0: y0 = n-tiles 0, 1 -> the y0 ring; 1: y1 = n-tiles 2, 3 -> the y1 ring, ZERO outside the image)
+template <int NCH>
+__device__ __forceinline__ void cv1_role(const C2fsParams& p, char* sm, int u, int h, int lane, int S, int py0, int sx0, int LP) {
+  using G = Geo<1>;
+  using G1 = Geo1<NCH>;
+  const int g = lane >> 4, r = lane & 15;
+  u32x4 w1f[2 * NCH][2];
+#pragma unroll
+  for (int kt = 0; kt < 2 * NCH; ++kt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) w1f[kt][nt] = *reinterpret_cast<const u32x4*>(p.w1 + ((size_t)(kt * 4 + 2 * h + nt) * 64 + lane) * 16);
+  const f32x4 bias0 = *reinterpret_cast<const f32x4*>(p.b1 + (2 * h) * 16 + 4 * g), bias1 = *reinterpret_cast<const f32x4*>(p.b1 + (2 * h + 1) * 16 + 4 * g);
+  const int q = u * 16 + r;
+  const bool act = q < G::RS * G::XW;
+  const int qq = act ? q : 0;
+  const int rr = qq >= G::XW ? 1 : 0, col = qq - rr * G::XW;
+  const int out_c = (h ? G::base(0) : G1::Y0B) + (g >> 1) * G::plane(0) + col * 16 + (g & 1) * 8;
+  const int gx = sx0 - G::R + col;
+  const unsigned colm = (gx >= 0 && gx < p.W) ? 0xFFFFFFFFu : 0u;
+  const int x_c = q * 128;
+  for (int s = 0; s < S; ++s) {
+    C2FS_STAMP(s, 0);
+    if (G::RS * s < LP) {
+      const char* xb = sm + G1::XS1 + (s % G::NSLOT) * G1::XSLOT1 + x_c;
+      u32x4 bx[2 * NCH];
+#pragma unroll
+      for (int kt = 0; kt < 2 * NCH; ++kt) bx[kt] = *reinterpret_cast<const u32x4*>(xb + (kt >> 1) * G1::XCH + ((((kt & 1) * 4 + g) ^ (q & 7)) << 4));
+      f32x4 a0 = bias0, a1 = bias1;
+#pragma unroll
+      for (int kt = 0; kt < 2 * NCH; ++kt) {
+        a0 = mfma32(w1f[kt][0], bx[kt], a0);
+        a1 = mfma32(w1f[kt][1], bx[kt], a1);
+      }
+      const int row = G::RS * s + rr;
+      const int gy = py0 - G::R + row;
+      const unsigned m = (gy >= 0 && gy < p.H) ? colm : 0u;
+      u32x2 o0 = silu_pack(a0), o1 = silu_pack(a1);
+      o0[0] &= m; o0[1] &= m; o1[0] &= m; o1[1] &= m;
+      if (act && row < LP) {
+        const int oa = out_c + (row & (G::ring(0) - 1)) * G::ROWB;
+        *reinterpret_cast<u32x2*>(sm + oa) = o0;
+        *reinterpret_cast<u32x2*>(sm + oa + 2 * G::plane(0)) = o1;
+      }
+    }
+    C2FS_STAMP(s, 1);
+    __syncthreads();
+  }
+}
+
+// cv2 over [y0 | y1 | b1] on unit fu of the output band: 12 fragments in registers, operands from the three rings
+template <int NCH>
+__device__ __forceinline__ void cv2_role(const C2fsParams& p, char* sm, int fu, int lane, int S, int n, int py0, int sx0, int LP) {
+  using G = Geo<1>;
+  using G1 = Geo1<NCH>;
+  const int g = lane >> 4, r = lane & 15;
+  u32x4 w2f[3][4];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) w2f[k][nt] = *reinterpret_cast<const u32x4*>(p.w2 + ((size_t)(k * 4 + nt) * 64 + lane) * 16);
+  f32x4 b2v[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) b2v[nt] = *reinterpret_cast<const f32x4*>(p.b2 + nt * 16 + 4 * g);
+  const int fq = fu * 16 + r;
+  const bool f_act = fq < G::RS * WS;
+  const int fqq = f_act ? fq : 0;
+  const int f_rr = fqq >= WS ? 1 : 0, f_oc = fqq - f_rr * WS;
+  const bool f_colok = sx0 + f_oc < p.W;
+  const int in_y0 = G1::Y0B + g * G::plane(0) + (G::R + f_oc) * 16;
+  const int in_y1 = G::base(0) + g * G::plane(0) + (G::R + f_oc) * 16;
+  const int in_b1 = G::base(2) + g * G::plane(2) + (G::R + f_oc) * 16;
+  char* const ybase = p.y + (((size_t)n * p.H * p.W) + (size_t)(sx0 + f_oc)) * (size_t)p.ldy * 2 + (16 * (g & 1) + 8 * (g >> 1)) * 2;
+  const size_t yrow = (size_t)p.W * p.ldy * 2;
+  for (int s = 0; s < S; ++s) {
+    C2FS_STAMP(s, 0);
+    const int o0r = G::RS * s - G::LAGF;
+    if (o0r + G::RS > G::R && o0r < LP - G::R) {
+      const int row = o0r + f_rr;
+      u32x4 opnd[3];
+      opnd[0] = lds128(sm, in_y0 + (row & (G::ring(0) - 1)) * G::ROWB);
+      opnd[1] = lds128(sm, in_y1 + (row & (G::ring(0) - 1)) * G::ROWB);
+      opnd[2] = lds128(sm, in_b1 + (row & (G::ring(2) - 1)) * G::ROWB);
+      f32x4 o[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) o[nt] = b2v[nt];
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) o[nt] = mfma32(w2f[k][nt], opnd[k], o[nt]);
+      const int gy = py0 - G::R + row;
+      const bool ok = f_act && f_colok && row >= G::R && row < LP - G::R && gy < p.H;
+      char* dst = ybase + (size_t)gy * yrow;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const u32x2 a = silu_pack(o[2 * j]), b = silu_pack(o[2 * j + 1]);
+        auto lo = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+        auto hi = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+        if (ok) *reinterpret_cast<u32x4*>(dst + j * 64) = u32x4{lo[0], hi[0], lo[1], hi[1]};
+      }
+    }
+    C2FS_STAMP(s, 1);
+    __syncthreads();
+  }
+}
+
+// the LDS-DMA of the input band two steps ahead: wave di of 3 owns pieces [di PPW, (di + 1) PPW) of the NCH x PY1 pieces of a band
+template <int NCH>
+__device__ __forceinline__ void dma_role(const C2fsParams& p, char* sm, int di, int lane, int S, int n, int py0, int sx0, int LP) {
+  using G = Geo<1>;
+  using G1 = Geo1<NCH>;
+  static_assert(G1::PPW <= 7, "the vmcnt switch covers up to seven pieces in flight");
+  const unsigned rowpitch = (unsigned)p.W * (unsigned)p.ldx * 2u;
+  const unsigned up_rowpitch = (unsigned)(p.W >> 1) * (unsigned)p.up_ld * 2u;
+  const char* ximg = p.x + (size_t)n * p.H * rowpitch;
+  const char* uimg = p.up ? p.up + (size_t)n * (p.H >> 1) * up_rowpitch : nullptr;
+  unsigned d_col[G1::PPW];
+  int d_rr[G1::PPW], d_dst[G1::PPW];
+  bool d_ok[G1::PPW], d_up[G1::PPW];
+#pragma unroll
+  for (int i = 0; i < G1::PPW; ++i) {
+    const int pi = di * G1::PPW + i;
+    d_ok[i] = pi < G1::PCS;
+    const int c = d_ok[i] ? pi / G::PY1 : 0, pc = d_ok[i] ? pi % G::PY1 : 0;
+    const int pd = pc * 8 + (lane >> 3);
+    const int pq = pd < G::RS * G::XW ? pd : 0;
+    d_rr[i] = pq >= G::XW ? 1 : 0;
+    const int dcol = pq - d_rr[i] * G::XW;
+    int dgx = sx0 + dcol - G::R;
+    dgx = dgx < 0 ? 0 : (dgx >= p.W ? p.W - 1 : dgx);
+    const int cg = (lane & 7) ^ (pd & 7);
+    d_up[i] = p.up != nullptr && c * 64 < p.upC;
+    d_col[i] = d_up[i] ? (unsigned)(dgx >> 1) * (unsigned)p.up_ld * 2u + (unsigned)c * 128u + (unsigned)cg * 16u
+                       : (unsigned)dgx * (unsigned)p.ldx * 2u + (unsigned)c * 128u + (unsigned)cg * 16u;
+    d_dst[i] = G1::XS1 + c * G1::XCH + pc * 1024;
+  }
+  auto stage_in = [&](int st) __attribute__((always_inline)) {
+    int issued = 0;
+    if (G::RS * st < LP) {
+      const int slot = st % G::NSLOT;
+      const int y0r = py0 - G::R + G::RS * st;
+      unsigned xro[2], uro[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        int a = y0r + k;
+        a = a < 0 ? 0 : (a >= p.H ? p.H - 1 : a);
+        xro[k] = (unsigned)a * rowpitch;
+        uro[k] = (unsigned)(a >> 1) * up_rowpitch;
+      }
+#pragma unroll
+      for (int i = 0; i < G1::PPW; ++i) {
+        if (!d_ok[i]) continue;  // wave-uniform
+        const char* src = d_up[i] ? uimg + (d_col[i] + (d_rr[i] ? uro[1] : uro[0])) : ximg + (d_col[i] + (d_rr[i] ? xro[1] : xro[0]));
+        __builtin_amdgcn_global_load_lds((cgptr_t)src, (clptr_t)(sm + d_dst[i] + slot * G1::XSLOT1), 16, 0, 0);
+        ++issued;
+      }
+    }
+    return issued;
+  };
+  stage_in(0);
+  stage_in(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int s = 0; s < S; ++s) {
+    C2FS_STAMP(s, 0);
+    const int inflight = stage_in(s + 2);
+    C2FS_STAMP(s, 1);
+    switch (inflight) {  // everything but this step's requests has landed (a DMA wave issues no other vector-memory operation)
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    }
+    __syncthreads();
+  }
+}
 }  // namespace c2fs
 
 template <int NB>
@@ -467,14 +670,14 @@ __global__ __launch_bounds__(1024) void c2f32_stream_kernel(const C2fsParams p) 
   //   SIMD 0: t1 units 0-1, b1 unit 2, cv2 (0, 0), cv2 (1, 1)     SIMD 1: t1 units 2-3, t2 unit 2, cv2 (0, 1), cv2 (2, 0)
   //   SIMD 2: b1 units 0-1, b2 unit 2, cv2 (1, 0), cv2 (2, 1)     SIMD 3: t2 units 0-1, b2 units 0-1, the two cv1 + DMA waves
   switch (wave) {
-    case 0: c2fs::stage_role<NB, 0, true>(p, sm, 0, lane, S, py0, sx0, LP); break;
-    case 1: c2fs::stage_role<NB, 0, true>(p, sm, 2, lane, S, py0, sx0, LP); break;
-    case 2: c2fs::stage_role<NB, 1, true>(p, sm, 0, lane, S, py0, sx0, LP); break;
-    case 3: c2fs::stage_role<NB, 2, true>(p, sm, 0, lane, S, py0, sx0, LP); break;
-    case 4: c2fs::stage_role<NB, 1, false>(p, sm, 2, lane, S, py0, sx0, LP); break;
-    case 5: c2fs::stage_role<NB, 2, false>(p, sm, 2, lane, S, py0, sx0, LP); break;
-    case 6: c2fs::stage_role<NB, 3, false>(p, sm, 2, lane, S, py0, sx0, LP); break;
-    case 7: c2fs::stage_role<NB, 3, true>(p, sm, 0, lane, S, py0, sx0, LP); break;
+    case 0: c2fs::stage_role<NB, 0, true>(p, sm, 0, lane, S, py0, sx0, LP, G::BIAS); break;
+    case 1: c2fs::stage_role<NB, 0, true>(p, sm, 2, lane, S, py0, sx0, LP, G::BIAS); break;
+    case 2: c2fs::stage_role<NB, 1, true>(p, sm, 0, lane, S, py0, sx0, LP, G::BIAS); break;
+    case 3: c2fs::stage_role<NB, 2, true>(p, sm, 0, lane, S, py0, sx0, LP, G::BIAS); break;
+    case 4: c2fs::stage_role<NB, 1, false>(p, sm, 2, lane, S, py0, sx0, LP, G::BIAS); break;
+    case 5: c2fs::stage_role<NB, 2, false>(p, sm, 2, lane, S, py0, sx0, LP, G::BIAS); break;
+    case 6: c2fs::stage_role<NB, 3, false>(p, sm, 2, lane, S, py0, sx0, LP, G::BIAS); break;
+    case 7: c2fs::stage_role<NB, 3, true>(p, sm, 0, lane, S, py0, sx0, LP, G::BIAS); break;
     case 8: c2fs::f_role<NB>(p, sm, 0, 0, lane, S, n, py0, sx0, LP); break;
     case 9: c2fs::f_role<NB>(p, sm, 0, 1, lane, S, n, py0, sx0, LP); break;
     case 10: c2fs::f_role<NB>(p, sm, 1, 0, lane, S, n, py0, sx0, LP); break;
@@ -483,6 +686,48 @@ __global__ __launch_bounds__(1024) void c2f32_stream_kernel(const C2fsParams p) 
     case 13: c2fs::f_role<NB>(p, sm, 2, 0, lane, S, n, py0, sx0, LP); break;
     case 14: c2fs::f_role<NB>(p, sm, 2, 1, lane, S, n, py0, sx0, LP); break;
     default: c2fs::y_role<NB>(p, sm, 1, lane, S, n, py0, sx0, LP); break;
+  }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(1024) void c2f32_stream1_kernel(const C2fsParams p) {
+  using G = c2fs::Geo<1>;
+  using G1 = c2fs::Geo1<NCH>;
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int total = p.N * p.parts * p.strips;
+  int bid = p.xcd ? upa_xcd_tile((int)blockIdx.x, total) : (int)blockIdx.x;
+  const int n = bid / (p.parts * p.strips);
+  bid -= n * (p.parts * p.strips);
+  const int part = bid / p.strips, strip = bid - part * p.strips;
+  const int py0 = part * p.L, sx0 = strip * c2fs::WS;
+  int leff = p.H - py0 < p.L ? p.H - py0 : p.L;
+  leff = (leff + G::RS - 1) / G::RS * G::RS;
+  const int LP = leff + 2 * G::R;
+  const int S = (leff + G::R + G::LAGF - 1) / G::RS + 1;
+  if (tid < 64) reinterpret_cast<float*>(sm + G1::BIAS1)[tid] = p.bm[tid >> 5][tid & 31];
+  if (wave != 12 && wave != 13 && wave != 15) __syncthreads();  // (the DMA waves arrive at this barrier with the first two bands landed)
+  // wave -> role.  Waves w, w + 4, w + 8, w + 12 share a SIMD.
+  //   SIMD 0: t1 units 0-1, cv1 (0, y0), cv1 (0, y1), DMA 0      SIMD 1: b1 units 0-1, cv1 (1, y0), cv1 (1, y1), DMA 1
+  //   SIMD 2: t1 unit 2, b1 unit 2, cv1 (2, y0), cv2 unit 0      SIMD 3: cv1 (2, y1), cv2 units 1, 2, DMA 2
+  switch (wave) {
+    case 0: c2fs::stage_role<1, 0, true>(p, sm, 0, lane, S, py0, sx0, LP, G1::BIAS1); break;
+    case 1: c2fs::stage_role<1, 1, true>(p, sm, 0, lane, S, py0, sx0, LP, G1::BIAS1); break;
+    case 2: c2fs::stage_role<1, 0, false>(p, sm, 2, lane, S, py0, sx0, LP, G1::BIAS1); break;
+    case 6: c2fs::stage_role<1, 1, false>(p, sm, 2, lane, S, py0, sx0, LP, G1::BIAS1); break;
+    case 4: c2fs::cv1_role<NCH>(p, sm, 0, 0, lane, S, py0, sx0, LP); break;
+    case 8: c2fs::cv1_role<NCH>(p, sm, 0, 1, lane, S, py0, sx0, LP); break;
+    case 5: c2fs::cv1_role<NCH>(p, sm, 1, 0, lane, S, py0, sx0, LP); break;
+    case 9: c2fs::cv1_role<NCH>(p, sm, 1, 1, lane, S, py0, sx0, LP); break;
+    case 10: c2fs::cv1_role<NCH>(p, sm, 2, 0, lane, S, py0, sx0, LP); break;
+    case 3: c2fs::cv1_role<NCH>(p, sm, 2, 1, lane, S, py0, sx0, LP); break;
+    case 14: c2fs::cv2_role<NCH>(p, sm, 0, lane, S, n, py0, sx0, LP); break;
+    case 7: c2fs::cv2_role<NCH>(p, sm, 1, lane, S, n, py0, sx0, LP); break;
+    case 11: c2fs::cv2_role<NCH>(p, sm, 2, lane, S, n, py0, sx0, LP); break;
+    case 12: c2fs::dma_role<NCH>(p, sm, 0, lane, S, n, py0, sx0, LP); break;
+    case 13: c2fs::dma_role<NCH>(p, sm, 1, lane, S, n, py0, sx0, LP); break;
+    default: c2fs::dma_role<NCH>(p, sm, 2, lane, S, n, py0, sx0, LP); break;
   }
 }
 
@@ -529,4 +774,43 @@ int upa_c2f32_stream_launch(const void* x, int n, int h, int w, int ldx, int sho
   if (upa_full_lds<c2f32_stream_kernel<2>>() != hipSuccess) return UPA_ELAUNCH;
   hipLaunchKernelGGL((c2f32_stream_kernel<2>), dim3((unsigned)wgs), dim3(1024), c2fs::Geo<2>::LDS, s, p);
   return UPA_OK;
+}
+
+template <int NCH>
+static int c2fs1_launch(const C2fsParams& p, long wgs, hipStream_t s) {
+  if (upa_full_lds<c2f32_stream1_kernel<NCH>>() != hipSuccess) return UPA_ELAUNCH;
+  hipLaunchKernelGGL((c2f32_stream1_kernel<NCH>), dim3((unsigned)wgs), dim3(1024), c2fs::Geo1<NCH>::LDS1, s, p);
+  return UPA_OK;
+}
+
+// The n = 1 form: called by upa_c2f_fused (c1 = 64) and upa_c2f32_up_fused (c1 = 64 k, optional virtual Upsample + Concat).
+// UPA_EUNSUPPORTED = the caller runs the tile form.
+int upa_c2f32_stream1_launch(const void* x, int n, int h, int w, int c1, int ldx, const void* up, int up_c, int up_ld, int shortcut,
+                             const void* w1, const float* b1, const void* const* wm, const float* const* bm, const void* w2, const float* b2,
+                             void* y, int ldy, const upa_opts* opts, hipStream_t s) {
+  const int nch = c1 / 64;
+  if (c1 % 64 != 0 || nch < 1 || nch > 3 || (up && (up_c % 64 != 0 || (h & 1) || (w & 1)))) return UPA_EUNSUPPORTED;
+  const long ldm = ldx > ldy ? (ldx > up_ld ? ldx : up_ld) : (ldy > up_ld ? ldy : up_ld);
+  if ((long)n * h * w * ldm * 2 >= (1L << 31) || (long)w * ldm * 2 >= (1L << 24)) return UPA_EUNSUPPORTED;
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return UPA_ELAUNCH;
+    cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+  }
+  C2fsParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = (const char*)x; p.y = (char*)y; p.w1 = (const char*)w1; p.w2 = (const char*)w2; p.b1 = b1; p.b2 = b2;
+  for (int i = 0; i < 2; ++i) { p.wm[i] = (const char*)wm[i]; p.bm[i] = bm[i]; }
+  p.N = n; p.H = h; p.W = w; p.ldx = ldx; p.ldy = ldy; p.shortcut = shortcut ? 1 : 0;
+  p.up = (const char*)up; p.c1 = c1; p.upC = up ? up_c : 0; p.up_ld = up_ld;
+  p.strips = cdiv(w, c2fs::WS);
+  const int rows = UPA_OPT(opts, c2f_stream_rows);
+  p.L = rows >= 4 ? (rows + 1) & ~1 : rows < 0 ? (h + 1) & ~1 : c2fs_pick_rows(n, h, w, cus);
+  p.parts = cdiv(h, p.L);
+  p.xcd = UPA_OPT(opts, no_xcd) ? 0 : 1;
+  const long wgs = (long)n * p.strips * p.parts;
+  if (wgs >= (1L << 31) / 2) return UPA_EUNSUPPORTED;
+  return nch == 1 ? c2fs1_launch<1>(p, wgs, s) : nch == 2 ? c2fs1_launch<2>(p, wgs, s) : c2fs1_launch<3>(p, wgs, s);
 }
