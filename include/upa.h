@@ -65,7 +65,7 @@ typedef struct upa_opts {
   int32_t no_xcd;          /* 1 = tile kernels take tile blockIdx.x instead of the XCD-aware order (each XCD a contiguous tile range: neighbouring halos meet in one L2); A/B */
   int32_t keys_only;       /* upa_detect_branch_tail* / upa_detect_head_tails with best_keys: 1 = the class rows of y are NOT written - only the boxes and the best-class NMS keys, which is all single-label NMS reads (upa_nms_batched_hot); rows 4.. of y are then undefined */
   int32_t conv_p8;         /* csrc/conv_p8.hip (8-wave two-group phased 3x3 stride-1 kernel for Cin % 64 == 0, Cout % 128 == 0: counted vmcnt, 4-slab weight ring, double-buffered halo) inside upa_conv2d_bias_act: 0 = by the size rule, 1 = never, 2 = every shape it can run */
-  int32_t c2f_stream;      /* csrc/c2f_stream.hip (line-buffer form of the C2f(64, 64, n = 2) block: fixed wave roles, LDS ring buffers) inside upa_c2f_fused: 0 = where it applies, 1 = never (the 16 x 16 tile form) */
+  int32_t c2f_stream;      /* csrc/c2f_stream.hip (line-buffer form of the C2f(64, 64, n = 2) block: fixed wave roles, LDS ring buffers) inside upa_c2f_fused: 0 = where it applies, 1 = never (the 16 x 16 tile form), 2 = the n = 2 block on its first wave-role set (A/B) */
   int32_t c2f_stream_rows; /* its output rows per workgroup: 0 = auto (one round of workgroups where possible) | even >= 4 | -1 = the whole image height (fewest pipeline fills: least total CU time, for several steps in flight) */
 } upa_opts;
 

@@ -556,11 +556,13 @@ def test_c2f_stream_kernel(case):
             y = to_cpu_nchw(m(xd, out=buf[:, 64:]))
         with R.use_opts(c2f_stream=1):
             y_tile = to_cpu_nchw(m(xd))
+        with R.use_opts(c2f_stream=2, c2f_stream_rows=rows):  # the first wave-role set (cv2 recomputes y0)
+            y_roles1 = to_cpu_nchw(m(xd))
         m.fuse_block = False
         y2 = to_cpu_nchw(m(xd))
     scale = max(1.0, ref.abs().max().item())
     assert_bf16_close(y, ref, f"c2f_stream{case}", abs_=2.0 ** -7)
-    for other, name in ((y_tile, "tile form"), (y2, "separate launches")):
+    for other, name in ((y_tile, "tile form"), (y2, "separate launches"), (y_roles1, "first role set")):
         d = (y - other).abs()
         assert d.max().item() <= 3e-2 * scale and (d > 1e-6).float().mean().item() <= 0.03, (name, d.max().item(), (d > 1e-6).float().mean().item())
     assert float(to_cpu_nchw(buf[:, :64]).abs().max()) == 0.0  # nothing written outside the output slice

@@ -19,11 +19,12 @@ from ultralytics_pro_amd.utils import procedural as P  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--wg", type=int, default=0)
 ap.add_argument("--batch", type=int, default=32)
+ap.add_argument("--n1", action="store_true", help="the n = 1 block C2f(192, 64) (yolov8n model.15) instead of C2f(64, 64, n = 2) (model.4)")
 args = ap.parse_args()
-m = bn_fix(pm.C2f(64, 64, 2, True))
+m = bn_fix(pm.C2f(192, 64, 1, False) if args.n1 else pm.C2f(64, 64, 2, True))
 P.apply_procedural_weights(m, family="default")
 m = m.to(DEV).eval()
-x = to_dev_nhwc(bf16_round(P.uniform("st", (args.batch, 64, 80, 80), -1.5, 1.5)), torch.bfloat16)
+x = to_dev_nhwc(bf16_round(P.uniform("st", (args.batch, 192 if args.n1 else 64, 80, 80), -1.5, 1.5)), torch.bfloat16)
 with torch.no_grad():
     for _ in range(3):
         m(x)
@@ -34,7 +35,9 @@ rd.argtypes = [C.c_void_p, C.c_int]
 buf = np.zeros(8 * 16 * STEPS * 2, dtype=np.uint64)
 assert rd(buf.ctypes.data, buf.size) == 0
 st = buf.reshape(8, 16, STEPS, 2).astype(np.int64)[args.wg]
-names = ["B01", "B23", "C01", "D01", "C2", "D2", "E2", "E01", "F00", "F01", "F10", "Y0", "F11", "F20", "F21", "Y1"]
+names = ["B01", "B23", "C01", "D01", "C2", "D2", "E2", "E01", "Y0", "Y1", "Y2", "Y3", "F0", "F1", "F2", "DMA"]
+if args.n1:
+    names = ["B01", "C01", "B2", "Y21", "Y00", "Y10", "C2", "F1", "Y01", "Y11", "Y20", "F2", "D0", "D1", "F0", "D2"]
 nsteps = int((st[0, :, 0] > 0).sum())
 t0 = st[:, 0, 0].min()
 print("workgroup", args.wg, "steps", nsteps, "life", int(st[:, nsteps - 1, 1].max() - t0), "cycles")
@@ -47,11 +50,3 @@ for s in range(nsteps):
     print(f"{s:3d} {int(nxt - start):6d} | " + " ".join(f"{int(b):5d}" for b in busy))
 
 
-print("step 12, cycles from the step's start.  Y: DMA issued, first unit's operands in registers, first unit written, before barrier")
-for w in (11, 15):
-    a = [st[w, 12, 0], st[w, 32, 0], st[w, 32, 1], st[w, 33, 0], st[w, 12, 1]]
-    print(names[w], [int(b - a[0]) for b in a][1:])
-print("F: y0 MFMAs issued, y0 SiLU done, cv2 MFMAs issued, before barrier")
-for w in (8, 9, 10, 12, 13, 14):
-    a = [st[w, 12, 0], st[w, 32, 0], st[w, 32, 1], st[w, 33, 0], st[w, 12, 1]]
-    print(names[w], [int(b - a[0]) for b in a][1:])

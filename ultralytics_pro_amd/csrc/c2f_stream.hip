@@ -450,36 +450,40 @@ __device__ __forceinline__ void f_role(const C2fsParams& p, char* sm, int fu, in
 // y0 goes through a ring of its own instead of being recomputed by cv2; the input band (NCH 64-channel chunks) is staged by three waves that
 // do nothing else; cv2 is three waves with all 12 fragments in registers.
 // =====================================================================================================================
-template <int NCH>
-struct Geo1 : Geo<1> {
-  using G = Geo<1>;
+template <int NB, int NCH, int ND>
+struct GeoS : Geo<NB> {
+  using G = Geo<NB>;
   static constexpr int Y0B = G::base(G::NTEN);            // y0 ring: as y1 (same rows alive, same pitch)
   static constexpr int XS1 = Y0B + 4 * G::plane(0);       // input staging: NSLOT slots x NCH chunks x (RS x XW pixels x 128 B)
   static constexpr int XCH = G::NY1 * 16 * 128;
   static constexpr int XSLOT1 = NCH * XCH;
-  static constexpr int BIAS1 = XS1 + G::NSLOT * XSLOT1;   // f32: bm[2][32]
-  static constexpr int LDS1 = BIAS1 + 2 * 32 * 4;
+  static constexpr int BIAS1 = XS1 + G::NSLOT * XSLOT1;   // f32: bm[NST][32]
+  static constexpr int LDS1 = BIAS1 + G::NST * 32 * 4;
   static constexpr int PCS = NCH * G::PY1;                // DMA pieces per step
-  static constexpr int PPW = (PCS + 2) / 3;               // ... per DMA wave
+  static constexpr int PPW = (PCS + ND - 1) / ND;         // ... per DMA wave
 };
+template <int NCH> using Geo1 = GeoS<1, NCH, 3>;
 
 // cv1 on unit u of the band, output half h (0: y0 = n-tiles 0, 1 -> the y0 ring; 1: y1 = n-tiles 2, 3 -> the y1 ring, ZERO outside the image)
-template <int NCH>
+// (NH = 2: both halves by one wave - the n = 2 block, whose cv1 is a quarter of the work)
+template <int NB, int NCH, int ND, int NH>
 __device__ __forceinline__ void cv1_role(const C2fsParams& p, char* sm, int u, int h, int lane, int S, int py0, int sx0, int LP) {
-  using G = Geo<1>;
-  using G1 = Geo1<NCH>;
+  using G = Geo<NB>;
+  using G1 = GeoS<NB, NCH, ND>;
   const int g = lane >> 4, r = lane & 15;
-  u32x4 w1f[2 * NCH][2];
+  u32x4 w1f[2 * NCH][2 * NH];
 #pragma unroll
   for (int kt = 0; kt < 2 * NCH; ++kt)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) w1f[kt][nt] = *reinterpret_cast<const u32x4*>(p.w1 + ((size_t)(kt * 4 + 2 * h + nt) * 64 + lane) * 16);
-  const f32x4 bias0 = *reinterpret_cast<const f32x4*>(p.b1 + (2 * h) * 16 + 4 * g), bias1 = *reinterpret_cast<const f32x4*>(p.b1 + (2 * h + 1) * 16 + 4 * g);
+    for (int nt = 0; nt < 2 * NH; ++nt) w1f[kt][nt] = *reinterpret_cast<const u32x4*>(p.w1 + ((size_t)(kt * 4 + 2 * h + nt) * 64 + lane) * 16);
+  f32x4 bias[2 * NH];
+#pragma unroll
+  for (int nt = 0; nt < 2 * NH; ++nt) bias[nt] = *reinterpret_cast<const f32x4*>(p.b1 + (2 * h + nt) * 16 + 4 * g);
   const int q = u * 16 + r;
   const bool act = q < G::RS * G::XW;
   const int qq = act ? q : 0;
   const int rr = qq >= G::XW ? 1 : 0, col = qq - rr * G::XW;
-  const int out_c = (h ? G::base(0) : G1::Y0B) + (g >> 1) * G::plane(0) + col * 16 + (g & 1) * 8;
+  const int out_rel = (g >> 1) * G::plane(0) + col * 16 + (g & 1) * 8;  // + the ring's base: y0 (half 0) | y1 (half 1)
   const int gx = sx0 - G::R + col;
   const unsigned colm = (gx >= 0 && gx < p.W) ? 0xFFFFFFFFu : 0u;
   const int x_c = q * 128;
@@ -490,21 +494,26 @@ __device__ __forceinline__ void cv1_role(const C2fsParams& p, char* sm, int u, i
       u32x4 bx[2 * NCH];
 #pragma unroll
       for (int kt = 0; kt < 2 * NCH; ++kt) bx[kt] = *reinterpret_cast<const u32x4*>(xb + (kt >> 1) * G1::XCH + ((((kt & 1) * 4 + g) ^ (q & 7)) << 4));
-      f32x4 a0 = bias0, a1 = bias1;
+      f32x4 a[2 * NH];
 #pragma unroll
-      for (int kt = 0; kt < 2 * NCH; ++kt) {
-        a0 = mfma32(w1f[kt][0], bx[kt], a0);
-        a1 = mfma32(w1f[kt][1], bx[kt], a1);
-      }
+      for (int nt = 0; nt < 2 * NH; ++nt) a[nt] = bias[nt];
+#pragma unroll
+      for (int kt = 0; kt < 2 * NCH; ++kt)
+#pragma unroll
+        for (int nt = 0; nt < 2 * NH; ++nt) a[nt] = mfma32(w1f[kt][nt], bx[kt], a[nt]);
       const int row = G::RS * s + rr;
       const int gy = py0 - G::R + row;
       const unsigned m = (gy >= 0 && gy < p.H) ? colm : 0u;
-      u32x2 o0 = silu_pack(a0), o1 = silu_pack(a1);
-      o0[0] &= m; o0[1] &= m; o1[0] &= m; o1[1] &= m;
-      if (act && row < LP) {
-        const int oa = out_c + (row & (G::ring(0) - 1)) * G::ROWB;
-        *reinterpret_cast<u32x2*>(sm + oa) = o0;
-        *reinterpret_cast<u32x2*>(sm + oa + 2 * G::plane(0)) = o1;
+      const int orow = out_rel + (row & (G::ring(0) - 1)) * G::ROWB;
+#pragma unroll
+      for (int hh = 0; hh < NH; ++hh) {
+        u32x2 o0 = silu_pack(a[2 * hh]), o1 = silu_pack(a[2 * hh + 1]);
+        o0[0] &= m; o0[1] &= m; o1[0] &= m; o1[1] &= m;
+        if (act && row < LP) {
+          const int oa = orow + ((h + hh) ? G::base(0) : G1::Y0B);
+          *reinterpret_cast<u32x2*>(sm + oa) = o0;
+          *reinterpret_cast<u32x2*>(sm + oa + 2 * G::plane(0)) = o1;
+        }
       }
     }
     C2FS_STAMP(s, 1);
@@ -513,14 +522,15 @@ __device__ __forceinline__ void cv1_role(const C2fsParams& p, char* sm, int u, i
 }
 
 // cv2 over [y0 | y1 | b1] on unit fu of the output band: 12 fragments in registers, operands from the three rings
-template <int NCH>
+template <int NB, int NCH, int ND>
 __device__ __forceinline__ void cv2_role(const C2fsParams& p, char* sm, int fu, int lane, int S, int n, int py0, int sx0, int LP) {
-  using G = Geo<1>;
-  using G1 = Geo1<NCH>;
+  using G = Geo<NB>;
+  using G1 = GeoS<NB, NCH, ND>;
+  constexpr int K2 = 2 + NB;  // operands y0, y1, b1 (, b2)
   const int g = lane >> 4, r = lane & 15;
-  u32x4 w2f[3][4];
+  u32x4 w2f[K2][4];
 #pragma unroll
-  for (int k = 0; k < 3; ++k)
+  for (int k = 0; k < K2; ++k)
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) w2f[k][nt] = *reinterpret_cast<const u32x4*>(p.w2 + ((size_t)(k * 4 + nt) * 64 + lane) * 16);
   f32x4 b2v[4];
@@ -531,9 +541,10 @@ __device__ __forceinline__ void cv2_role(const C2fsParams& p, char* sm, int fu, 
   const int fqq = f_act ? fq : 0;
   const int f_rr = fqq >= WS ? 1 : 0, f_oc = fqq - f_rr * WS;
   const bool f_colok = sx0 + f_oc < p.W;
-  const int in_y0 = G1::Y0B + g * G::plane(0) + (G::R + f_oc) * 16;
-  const int in_y1 = G::base(0) + g * G::plane(0) + (G::R + f_oc) * 16;
-  const int in_b1 = G::base(2) + g * G::plane(2) + (G::R + f_oc) * 16;
+  int f_in[K2];
+  f_in[0] = G1::Y0B + g * G::plane(0) + (G::R + f_oc) * 16;
+#pragma unroll
+  for (int k = 1; k < K2; ++k) f_in[k] = G::base(2 * (k - 1)) + g * G::plane(2 * (k - 1)) + (G::R + f_oc) * 16;
   char* const ybase = p.y + (((size_t)n * p.H * p.W) + (size_t)(sx0 + f_oc)) * (size_t)p.ldy * 2 + (16 * (g & 1) + 8 * (g >> 1)) * 2;
   const size_t yrow = (size_t)p.W * p.ldy * 2;
   for (int s = 0; s < S; ++s) {
@@ -541,15 +552,15 @@ __device__ __forceinline__ void cv2_role(const C2fsParams& p, char* sm, int fu, 
     const int o0r = G::RS * s - G::LAGF;
     if (o0r + G::RS > G::R && o0r < LP - G::R) {
       const int row = o0r + f_rr;
-      u32x4 opnd[3];
-      opnd[0] = lds128(sm, in_y0 + (row & (G::ring(0) - 1)) * G::ROWB);
-      opnd[1] = lds128(sm, in_y1 + (row & (G::ring(0) - 1)) * G::ROWB);
-      opnd[2] = lds128(sm, in_b1 + (row & (G::ring(2) - 1)) * G::ROWB);
+      u32x4 opnd[K2];
+      opnd[0] = lds128(sm, f_in[0] + (row & (G::ring(0) - 1)) * G::ROWB);
+#pragma unroll
+      for (int k = 1; k < K2; ++k) opnd[k] = lds128(sm, f_in[k] + (row & (G::ring(2 * (k - 1)) - 1)) * G::ROWB);
       f32x4 o[4];
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) o[nt] = b2v[nt];
 #pragma unroll
-      for (int k = 0; k < 3; ++k)
+      for (int k = 0; k < K2; ++k)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) o[nt] = mfma32(w2f[k][nt], opnd[k], o[nt]);
       const int gy = py0 - G::R + row;
@@ -569,10 +580,10 @@ __device__ __forceinline__ void cv2_role(const C2fsParams& p, char* sm, int fu, 
 }
 
 // the LDS-DMA of the input band two steps ahead: wave di of 3 owns pieces [di PPW, (di + 1) PPW) of the NCH x PY1 pieces of a band
-template <int NCH>
+template <int NB, int NCH, int ND>
 __device__ __forceinline__ void dma_role(const C2fsParams& p, char* sm, int di, int lane, int S, int n, int py0, int sx0, int LP) {
-  using G = Geo<1>;
-  using G1 = Geo1<NCH>;
+  using G = Geo<NB>;
+  using G1 = GeoS<NB, NCH, ND>;
   static_assert(G1::PPW <= 7, "the vmcnt switch covers up to seven pieces in flight");
   const unsigned rowpitch = (unsigned)p.W * (unsigned)p.ldx * 2u;
   const unsigned up_rowpitch = (unsigned)(p.W >> 1) * (unsigned)p.up_ld * 2u;
@@ -716,18 +727,62 @@ __global__ __launch_bounds__(1024) void c2f32_stream1_kernel(const C2fsParams p)
     case 1: c2fs::stage_role<1, 1, true>(p, sm, 0, lane, S, py0, sx0, LP, G1::BIAS1); break;
     case 2: c2fs::stage_role<1, 0, false>(p, sm, 2, lane, S, py0, sx0, LP, G1::BIAS1); break;
     case 6: c2fs::stage_role<1, 1, false>(p, sm, 2, lane, S, py0, sx0, LP, G1::BIAS1); break;
-    case 4: c2fs::cv1_role<NCH>(p, sm, 0, 0, lane, S, py0, sx0, LP); break;
-    case 8: c2fs::cv1_role<NCH>(p, sm, 0, 1, lane, S, py0, sx0, LP); break;
-    case 5: c2fs::cv1_role<NCH>(p, sm, 1, 0, lane, S, py0, sx0, LP); break;
-    case 9: c2fs::cv1_role<NCH>(p, sm, 1, 1, lane, S, py0, sx0, LP); break;
-    case 10: c2fs::cv1_role<NCH>(p, sm, 2, 0, lane, S, py0, sx0, LP); break;
-    case 3: c2fs::cv1_role<NCH>(p, sm, 2, 1, lane, S, py0, sx0, LP); break;
-    case 14: c2fs::cv2_role<NCH>(p, sm, 0, lane, S, n, py0, sx0, LP); break;
-    case 7: c2fs::cv2_role<NCH>(p, sm, 1, lane, S, n, py0, sx0, LP); break;
-    case 11: c2fs::cv2_role<NCH>(p, sm, 2, lane, S, n, py0, sx0, LP); break;
-    case 12: c2fs::dma_role<NCH>(p, sm, 0, lane, S, n, py0, sx0, LP); break;
-    case 13: c2fs::dma_role<NCH>(p, sm, 1, lane, S, n, py0, sx0, LP); break;
-    default: c2fs::dma_role<NCH>(p, sm, 2, lane, S, n, py0, sx0, LP); break;
+    case 4: c2fs::cv1_role<1, NCH, 3, 1>(p, sm, 0, 0, lane, S, py0, sx0, LP); break;
+    case 8: c2fs::cv1_role<1, NCH, 3, 1>(p, sm, 0, 1, lane, S, py0, sx0, LP); break;
+    case 5: c2fs::cv1_role<1, NCH, 3, 1>(p, sm, 1, 0, lane, S, py0, sx0, LP); break;
+    case 9: c2fs::cv1_role<1, NCH, 3, 1>(p, sm, 1, 1, lane, S, py0, sx0, LP); break;
+    case 10: c2fs::cv1_role<1, NCH, 3, 1>(p, sm, 2, 0, lane, S, py0, sx0, LP); break;
+    case 3: c2fs::cv1_role<1, NCH, 3, 1>(p, sm, 2, 1, lane, S, py0, sx0, LP); break;
+    case 14: c2fs::cv2_role<1, NCH, 3>(p, sm, 0, lane, S, n, py0, sx0, LP); break;
+    case 7: c2fs::cv2_role<1, NCH, 3>(p, sm, 1, lane, S, n, py0, sx0, LP); break;
+    case 11: c2fs::cv2_role<1, NCH, 3>(p, sm, 2, lane, S, n, py0, sx0, LP); break;
+    case 12: c2fs::dma_role<1, NCH, 3>(p, sm, 0, lane, S, n, py0, sx0, LP); break;
+    case 13: c2fs::dma_role<1, NCH, 3>(p, sm, 1, lane, S, n, py0, sx0, LP); break;
+    default: c2fs::dma_role<1, NCH, 3>(p, sm, 2, lane, S, n, py0, sx0, LP); break;
+  }
+}
+
+// The n = 2 block on the role set of the n = 1 kernel: cv1 (both halves, one unit per wave) writes y0 into a ring of its own instead of
+// each cv2 wave recomputing it from a second read of x; cv2 = three waves with all 16 fragments in registers; ONE wave stages the
+// input band.  Per step 216 SiLU wave-values and 318 MFMAs instead of 232 and 334, no cv1 wave issues LDS-DMA, 7 pieces instead of 12.
+__global__ __launch_bounds__(1024) void c2f32_stream2_kernel(const C2fsParams p) {
+  using G = c2fs::Geo<2>;
+  using G1 = c2fs::GeoS<2, 1, 1>;
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int total = p.N * p.parts * p.strips;
+  int bid = p.xcd ? upa_xcd_tile((int)blockIdx.x, total) : (int)blockIdx.x;
+  const int n = bid / (p.parts * p.strips);
+  bid -= n * (p.parts * p.strips);
+  const int part = bid / p.strips, strip = bid - part * p.strips;
+  const int py0 = part * p.L, sx0 = strip * c2fs::WS;
+  int leff = p.H - py0 < p.L ? p.H - py0 : p.L;
+  leff = (leff + G::RS - 1) / G::RS * G::RS;
+  const int LP = leff + 2 * G::R;
+  const int S = (leff + G::R + G::LAGF - 1) / G::RS + 1;
+  if (tid < G::NST * 32) reinterpret_cast<float*>(sm + G1::BIAS1)[tid] = p.bm[tid >> 5][tid & 31];
+  if (wave != 15) __syncthreads();  // (the DMA wave arrives at this barrier with the first two bands landed)
+  // wave -> role.  Waves w, w + 4, w + 8, w + 12 share a SIMD; MFMAs / SiLU wave-values per step and SIMD: 78 / 56, 78 / 56, 78 / 56, 80 / 48.
+  //   SIMD 0: t1 units 0-1, b1 unit 2, cv1 unit 0, cv2 unit 0     SIMD 1: t1 units 2-3, t2 unit 2, cv1 unit 1, cv2 unit 1
+  //   SIMD 2: b1 units 0-1, b2 unit 2, cv1 unit 2, cv2 unit 2     SIMD 3: t2 units 0-1, b2 units 0-1, cv1 unit 3, the DMA wave
+  switch (wave) {
+    case 0: c2fs::stage_role<2, 0, true>(p, sm, 0, lane, S, py0, sx0, LP, G1::BIAS1); break;
+    case 1: c2fs::stage_role<2, 0, true>(p, sm, 2, lane, S, py0, sx0, LP, G1::BIAS1); break;
+    case 2: c2fs::stage_role<2, 1, true>(p, sm, 0, lane, S, py0, sx0, LP, G1::BIAS1); break;
+    case 3: c2fs::stage_role<2, 2, true>(p, sm, 0, lane, S, py0, sx0, LP, G1::BIAS1); break;
+    case 4: c2fs::stage_role<2, 1, false>(p, sm, 2, lane, S, py0, sx0, LP, G1::BIAS1); break;
+    case 5: c2fs::stage_role<2, 2, false>(p, sm, 2, lane, S, py0, sx0, LP, G1::BIAS1); break;
+    case 6: c2fs::stage_role<2, 3, false>(p, sm, 2, lane, S, py0, sx0, LP, G1::BIAS1); break;
+    case 7: c2fs::stage_role<2, 3, true>(p, sm, 0, lane, S, py0, sx0, LP, G1::BIAS1); break;
+    case 8: c2fs::cv1_role<2, 1, 1, 2>(p, sm, 0, 0, lane, S, py0, sx0, LP); break;
+    case 9: c2fs::cv1_role<2, 1, 1, 2>(p, sm, 1, 0, lane, S, py0, sx0, LP); break;
+    case 10: c2fs::cv1_role<2, 1, 1, 2>(p, sm, 2, 0, lane, S, py0, sx0, LP); break;
+    case 11: c2fs::cv1_role<2, 1, 1, 2>(p, sm, 3, 0, lane, S, py0, sx0, LP); break;
+    case 12: c2fs::cv2_role<2, 1, 1>(p, sm, 0, lane, S, n, py0, sx0, LP); break;
+    case 13: c2fs::cv2_role<2, 1, 1>(p, sm, 1, lane, S, n, py0, sx0, LP); break;
+    case 14: c2fs::cv2_role<2, 1, 1>(p, sm, 2, lane, S, n, py0, sx0, LP); break;
+    default: c2fs::dma_role<2, 1, 1>(p, sm, 0, lane, S, n, py0, sx0, LP); break;
   }
 }
 
@@ -771,8 +826,14 @@ int upa_c2f32_stream_launch(const void* x, int n, int h, int w, int ldx, int sho
   p.xcd = UPA_OPT(opts, no_xcd) ? 0 : 1;
   const long wgs = (long)n * p.strips * p.parts;
   if (wgs >= (1L << 31) / 2) return UPA_EUNSUPPORTED;
-  if (upa_full_lds<c2f32_stream_kernel<2>>() != hipSuccess) return UPA_ELAUNCH;
-  hipLaunchKernelGGL((c2f32_stream_kernel<2>), dim3((unsigned)wgs), dim3(1024), c2fs::Geo<2>::LDS, s, p);
+  if (UPA_OPT(opts, c2f_stream) == 2) {  // the first role set (cv2 recomputes y0): kept for A/B
+    if (upa_full_lds<c2f32_stream_kernel<2>>() != hipSuccess) return UPA_ELAUNCH;
+    hipLaunchKernelGGL((c2f32_stream_kernel<2>), dim3((unsigned)wgs), dim3(1024), c2fs::Geo<2>::LDS, s, p);
+    return UPA_OK;
+  }
+  if (upa_full_lds<c2f32_stream2_kernel>() != hipSuccess) return UPA_ELAUNCH;
+  constexpr size_t lds2 = c2fs::GeoS<2, 1, 1>::LDS1;
+  hipLaunchKernelGGL(c2f32_stream2_kernel, dim3((unsigned)wgs), dim3(1024), lds2, s, p);
   return UPA_OK;
 }
 
