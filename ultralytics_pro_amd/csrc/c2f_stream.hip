@@ -88,15 +88,15 @@ struct Geo {
   static constexpr int LDS = BIAS + NST * 32 * 4;
 };
 
-#if defined(C2FS_EXP) && (C2FS_EXP == 1 || C2FS_EXP == 5)   // timing experiments only (tools/experiments/r05_c2fs_variants.sh): not SiLU
+#if defined(C2FS_EXP) && (C2FS_EXP == 11 || C2FS_EXP == 15)   // timing experiments only (tools/experiments/r05_c2fs_variants.sh): not SiLU
 __device__ __forceinline__ float silu(float v) { return v * 0.5f; }
-#elif defined(C2FS_EXP) && C2FS_EXP == 2
+#elif defined(C2FS_EXP) && C2FS_EXP == 12
 __device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + v * v); }
 #else
 __device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 #endif
 __device__ __forceinline__ f32x4 mfma32(const u32x4& a, const u32x4& b, f32x4 c) {
-#if defined(C2FS_EXP) && (C2FS_EXP == 3 || C2FS_EXP == 5)  // timing experiment: no matrix instructions (operands still loaded)
+#if defined(C2FS_EXP) && (C2FS_EXP == 13 || C2FS_EXP == 15)  // timing experiment: no matrix instructions (operands still loaded)
   asm volatile("" ::"v"(a), "v"(b));
   return c;
 #endif
@@ -108,7 +108,7 @@ __device__ __forceinline__ f32x4 mfma16(const u32x2& a, const u32x2& b, f32x4 c)
 __device__ __forceinline__ u32x2 silu_pack(const f32x4& a) {
   return u32x2{pack_bf16x2(silu(a[0]), silu(a[1])), pack_bf16x2(silu(a[2]), silu(a[3]))};
 }
-#if defined(C2FS_EXP) && C2FS_EXP == 4  // timing experiment: no LDS reads of the 3x3 taps / cv2 operands
+#if defined(C2FS_EXP) && C2FS_EXP == 14  // timing experiment: no LDS reads of the 3x3 taps / cv2 operands
 __device__ __forceinline__ u32x4 lds128(const char* sm, int off) { return u32x4{(unsigned)off, 1u, 2u, 3u}; }
 #else
 __device__ __forceinline__ u32x4 lds128(const char* sm, int off) { return *reinterpret_cast<const u32x4*>(sm + off); }
