@@ -524,6 +524,7 @@ def main():
             "model_tflops": round(value / world * GFLOP_OTHER.get(args.model, GFLOP_PER_IMG) / 1e3, 2),
             "step_roofline": step_roofline(value / world, ms_per_step, args, kernels),
             "roofline": roofline,
+            "critical_path": (kernels or {}).get("critical_path") if isinstance(kernels, dict) else None,
             "kernels": kernels,
             "cpu_baseline": cpu_baseline,
         }
@@ -944,6 +945,8 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
     orig_btail = L.lib().upa_detect_branch_tail
     orig_paircv2 = L.lib().upa_bottleneck_pair_cv2
     orig_c2f64 = L.lib().upa_c2f64_fused
+    orig_c2f32up = L.lib().upa_c2f32_up_fused
+    c2f32up_calls = []
     pair_calls, c2f_calls, btail_calls, paircv2_calls, c2f64_calls = [], [], [], [], []
 
     class _LibProxy:
@@ -975,6 +978,12 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
             rc = orig_c2f64(*a)
             if rc == 0:
                 c2f64_calls.append(a)
+            return rc
+
+        def upa_c2f32_up_fused(self, *a):
+            rc = orig_c2f32up(*a)
+            if rc == 0:
+                c2f32up_calls.append(a)
             return rc
 
         def upa_detect_branch_tail(self, *a):
@@ -1019,8 +1028,20 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
         nbytes = npx * (c1_ + c2_) * 2 + wts * 2  # block input + block output + weights
         o_ = R.current_opts()
         th = 10 if (c_ != 16 and nb_ == 2 and o_ is not None and o_.c2f32_th == 10) else 16
-        name = "void c2f16_fused_kernel<%d>(C2fParams)" % (8 if (o_ is not None and o_.c2f16_waves == 8) else 4) if c_ == 16 else "void c2f32_fused_kernel<%d, %d>(C2f32Params)" % (nb_, th)
+        stream_form = c_ == 32 and th == 16 and (o_ is None or o_.c2f_stream != 1)  # the line-buffer kernels (csrc/c2f_stream.hip)
+        name = ("void c2f16_fused_kernel<%d>(C2fParams)" % (8 if (o_ is not None and o_.c2f16_waves == 8) else 4) if c_ == 16 else
+                ("c2f32_stream2_kernel(C2fsParams)" if nb_ == 2 and (o_ is None or o_.c2f_stream != 2) else
+                 "void c2f32_stream_kernel<2>(C2fsParams)" if nb_ == 2 else "void c2f32_stream1_kernel<1>(C2fsParams)") if stream_form else
+                "void c2f32_fused_kernel<%d, %d>(C2f32Params)" % (nb_, th))
         calls.append((name, flops, nbytes, (lambda a=a: orig_c2f(*a[:21], L.current_stream(dev)))))
+    for a in c2f32up_calls:  # (x, n, h, w, c1, ldx, up, up_c, up_ld, nb, shortcut, w1, b1, wm, bm, w2, b2, y, c2, ldy, act, dtype, opts, stream)
+        npx, c1_, upc_, nb_, c2_ = a[1] * a[2] * a[3], a[4], a[7], a[9], a[18]
+        wts = c1_ * 64 + nb_ * 18 * 32 * 32 + (2 + nb_) * 32 * c2_
+        o_ = R.current_opts()
+        name = ("void c2f32_stream1_kernel<%d>(C2fsParams)" % (c1_ // 64) if (c1_ <= 192 and (o_ is None or o_.c2f_stream != 1)) else
+                "void c2f32_fused_kernel<1, 16, true>(C2f32Params)")
+        calls.append((name, 2.0 * npx * wts, npx * (c1_ - upc_ * 3 // 4 + c2_) * 2 + wts * 2,  # block input (the upsampled channels at quarter size) + output + weights
+                      (lambda a=a: orig_c2f32up(*a[:23], L.current_stream(dev)))))
     for a in c2f64_calls:  # (x, n, h, w, c1, ldx, up, up_c, up_ld, nb, shortcut, w1, b1, wm, bm, w2, b2, y, c2, ldy, act, dtype, opts, stream)
         npx, c1_, upc_, nb_, c2_ = a[1] * a[2] * a[3], a[4], a[7], a[9], a[18]
         wts = c1_ * 128 + nb_ * 18 * 64 * 64 + (2 + nb_) * 64 * c2_
@@ -1119,7 +1140,32 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
                 break
         except (OSError, KeyError, ValueError):
             pass
+    # What bounds the quoted mode: with several steps in flight the small-map launches of other steps hide under the chip-filling
+    # ones, so the step is (nearly) the SUM of the launches that fill the chip by themselves - listed here, each against the tighter
+    # of its two rooflines, with the vector-issue time of its instruction count (PMC INSTS_VALU per launch over 1024 SIMDs at the
+    # measured 2.5 cycles per wave-instruction and 2.1 GHz; transcendental instructions cost 8.2, so this is a lower bound)
+    valu = {}
+    for pf in sorted((ROOT / "profiles").glob("r*_pmc_step_budget.txt"), reverse=True):
+        try:
+            for ln in pf.read_text().splitlines()[1:]:
+                rest = ln[60:].split()  # (kernel name padded to 60 columns) calls INSTS_VALU INSTS_SALU ...
+                if len(rest) > 2 and rest[0].isdigit():
+                    valu.setdefault(ln[:60].strip(), float(rest[1]) / max(int(rest[0]), 1))
+        except (OSError, ValueError, IndexError):
+            pass
+        break
+    crit = []
+    for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"] / kv[1]["launches"]):
+        us = v["ms"] / v["launches"] * 1e3
+        if us < 25.0:
+            continue
+        tf, gb = v["flops"] / (v["ms"] * 1e-3) / 1e12, v["bytes"] / (v["ms"] * 1e-3) / 1e9
+        vi = next((valu[n_] for n_ in valu if k.startswith(n_) or n_.startswith(k[:58])), None)
+        crit.append({"kernel": k, "launches": v["launches"], "avg_us": round(us, 1), "frac_mfma": round(tf / peak, 3),
+                     "frac_hbm": round(gb / PEAK_HBM_GBS, 3), "frac_of_tighter_roofline": round(max(tf / peak, gb / PEAK_HBM_GBS), 3),
+                     "valu_issue_us": None if vi is None else round(vi / 1024 * 2.5 / 2.1e3, 1)})
     kernels = {
+        "critical_path": crit,
         "conv_ms_per_step": round(conv_ms, 4),
         "conv_tflops": round(conv_flops / (conv_ms * 1e-3) / 1e12, 1),
         "conv_algorithmic_gbs": round(conv_bytes / (conv_ms * 1e-3) / 1e9, 1),

@@ -3,7 +3,7 @@
 # <round>_* by tools/copy_profiles.sh).  ROUND=r04 by default.  This script and the copy step only ever ADD files named after the
 # current round: rows and files of earlier rounds in profiles/ (and in profiles/README.md) are history and are never rewritten.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r05}
 O=$R/gpurun_out/final_$ROUND
 rm -rf $O/prof_default $O/prof_serial $O/prof_train   # stale traces of earlier calls would shadow this one's stats
 mkdir -p $O
@@ -11,8 +11,10 @@ cd $R
 timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 timeout 600 python bench.py --serial --no-cpu-baseline > $O/bench_serial.json 2>/dev/null
 timeout 600 python bench.py --dtype f32 --no-cpu-baseline --steps 200 > $O/bench_f32.json 2>/dev/null
-for m in yolov8s yolov3-tiny yolov5-BoT3; do timeout 600 python bench.py --model $m --no-cpu-baseline --steps 300 > $O/bench_$m.json 2>/dev/null; done
-timeout 600 python bench.py --model yolov3-rtdetr --batch 16 --no-cpu-baseline > $O/bench_yolov3-rtdetr.json 2>/dev/null
+for m in yolov8s yolov3-tiny; do timeout 600 python bench.py --model $m --no-cpu-baseline --steps 300 > $O/bench_$m.json 2>/dev/null; done
+timeout 600 python bench.py --model yolov5-BoT3 --batch 16 --no-cpu-baseline --steps 300 > $O/bench_yolov5-BoT3.json 2>/dev/null   # BASELINE config 4: bs 16
+timeout 600 python bench.py --model yolov5-BoT3 --batch 32 --no-cpu-baseline --steps 300 > $O/bench_yolov5-BoT3_bs32.json 2>/dev/null   # (rounds 2-4 quoted bs 32)
+timeout 900 python bench.py --model yolov3-rtdetr --batch 16 > $O/bench_yolov3-rtdetr.json 2>/dev/null   # with the CPU leg: its parity object needs the oracle's output
 timeout 600 python bench.py --workload train > $O/bench_train.json 2> $O/bench_train.err
 timeout 600 python bench.py --model yolov3-rtdetr --batch 16 --serial --no-cpu-baseline --no-kernel-profile > $O/bench_yolov3-rtdetr_serial.json 2>/dev/null
 timeout 300 python tools/experiments/r04_o2.py > $O/wgrad_layers_yolov8s.txt 2>/dev/null   # per-layer weight-gradient table (both floors)
