@@ -1160,7 +1160,11 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
         if us < 25.0:
             continue
         tf, gb = v["flops"] / (v["ms"] * 1e-3) / 1e12, v["bytes"] / (v["ms"] * 1e-3) / 1e9
-        vi = next((valu[n_] for n_ in valu if k.startswith(n_) or n_.startswith(k[:58])), None)
+        kn = k.replace("void ", "").split("(")[0]  # the PMC table strips "void " and the parameter list and cuts names at 60 columns
+        vi = next((valu[n_] for n_ in valu if n_ and (kn == n_ or kn[:60].rstrip() == n_)), None)
+        if vi is None:  # same kernel template, one instantiation in the table (its template list may be spelled with defaults)
+            same = [n_ for n_ in valu if n_ and n_.split("<")[0] == kn.split("<")[0]]
+            vi = valu[same[0]] if len(same) == 1 else None
         crit.append({"kernel": k, "launches": v["launches"], "avg_us": round(us, 1), "frac_mfma": round(tf / peak, 3),
                      "frac_hbm": round(gb / PEAK_HBM_GBS, 3), "frac_of_tighter_roofline": round(max(tf / peak, gb / PEAK_HBM_GBS), 3),
                      "valu_issue_us": None if vi is None else round(vi / 1024 * 2.5 / 2.1e3, 1)})
