@@ -747,6 +747,10 @@ def main_train(args):
                        "execution": mode, "tuning_ms_per_step": {"eager": round(t_eager * 1e3, 3), "graph": round(t_graph * 1e3, 3)}},
             "images_per_sec_per_gpu": round(value / world, 1),
             "loss_items": [round(float(v), 4) for v in items.tolist()],
+            # the whole step against the matrix peak: forward + data gradient + weight gradient = 3 x the forward's 2 MAC count
+            "step_roofline": {"model_tflops": round(3 * GFLOP_OTHER.get(args.model, GFLOP_PER_IMG) * value / world / 1e3, 1),
+                              "frac_of_mfma_peak": round(3 * GFLOP_OTHER.get(args.model, GFLOP_PER_IMG) * value / world / 1e3 / PEAK_BF16_TFLOPS, 4),
+                              "algorithmic_gflop_per_image": round(3 * GFLOP_OTHER.get(args.model, GFLOP_PER_IMG), 2)},
             "roofline": roofline, "cpu_baseline": cpu_baseline}))
     if dist is not None:
         dist.barrier()
@@ -795,10 +799,12 @@ def wgrad_profile(tr, L, R, dev, dtype, reps=5, cfg_key=None):
             name = "void (anonymous namespace)::wgrad_kernel<%s, %d, %d, %d>((anonymous namespace)::WgradParams)" % (
                 "unsigned short" if bf else "float", mt, mt, cv.k)
             peak = PEAK_F32_TFLOPS
-        d = fam.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, peak=peak))
+        d = fam.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0, peak=peak))
         d["launches"] += 1
         d["ms"] += ms
         d["flops"] += 2.0 * vx.n * oh * ow * cv.cout * cv.cin * cv.k * cv.k
+        # algorithmic bytes: the layer input and the output gradient read once (activation dtype), the f32 weight gradient written once
+        d["bytes"] += vx.n * (vx.h * vx.w * cv.cin + oh * ow * cv.cout) * (2 if bf else 4) + 4.0 * cv.cout * cv.cin * cv.k * cv.k
     name, d = max(fam.items(), key=lambda kv: kv[1]["ms"])
     avg_s = d["ms"] / d["launches"] * 1e-3
     tf = d["flops"] / d["launches"] / avg_s / 1e12
@@ -818,6 +824,7 @@ def wgrad_profile(tr, L, R, dev, dtype, reps=5, cfg_key=None):
             "frac": round(tf / d["peak"], 4), "traffic": traffic, "traffic_source": traffic_src, "launches_per_step": d["launches"],
             "avg_launch_us": round(avg_s * 1e6, 1),
             "algorithmic_flops_per_launch": d["flops"] / d["launches"],
+            "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
             "note": "weight gradient: bf16 MFMA (v_mfma_f32_16x16x32_bf16, operands DMAed into an LDS ring and read with "
                     "ds_read_b64_tr_b16) where channel counts allow, exact-f32 MFMA otherwise; the time includes the "
                     "partial-sum reduction kernel",
