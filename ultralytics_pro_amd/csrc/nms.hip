@@ -366,15 +366,26 @@ __global__ __launch_bounds__(GREEDY_NT) void nms_greedy_kernel(const float* pred
         for (int q = 1; q < GREEDY_NW; ++q) alive &= alive_w[q];
         // phase 2: resolve the chunk greedily over the SET bits only: take the lowest alive lane, keep it, broadcast its
         // box, drop every later alive lane it suppresses.  Iterations = boxes kept from this chunk (usually a handful),
-        // not 64 + 64 as a full suppression matrix + scan would cost.
-        u64 rem = alive, keepmask = 0ull;
+        // not 64 + 64 as a full suppression matrix + scan would cost.  The mask and the kept count are wave-uniform: held in scalar
+        // registers (readfirstlane), so the lane index of the kept box is scalar too and its five values are broadcast by
+        // v_readlane_b32 - a few cycles each - instead of five ds_bpermute round trips (~600 cycles per kept box, most of this kernel's
+        // time: 55 -> see DESIGN.md).
+        u64 rem = ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(alive >> 32)) << 32) |
+                  (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)alive);  // (the builtin returns int: no sign extension)
+        u64 keepmask = 0ull;
+        const int kept_s = __builtin_amdgcn_readfirstlane(kept);
+        int nkeep = 0;
         while (rem) {
-          const int i = __ffsll((unsigned long long)rem) - 1;
+          const int i = __builtin_ctzll((unsigned long long)rem);
           keepmask |= 1ull << i;
           rem &= rem - 1ull;
-          if (kept + __popcll(keepmask) >= max_det) break;
-          const float ix1 = __shfl(x1, i), iy1 = __shfl(y1, i), ix2 = __shfl(x2, i), iy2 = __shfl(y2, i),
-                      iar = __shfl(area, i);
+          ++nkeep;
+          if (kept_s + nkeep >= max_det) break;
+          const float ix1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x1), i));
+          const float iy1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(y1), i));
+          const float ix2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x2), i));
+          const float iy2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(y2), i));
+          const float iar = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(area), i));
           const bool sup2 = ((rem >> lane) & 1ull) && iou_gt(ix1, iy1, ix2, iy2, iar, x1, y1, x2, y2, area, iou_thr);
           rem &= ~__ballot(sup2);
         }
