@@ -524,7 +524,7 @@ def test_c2f_stream1_kernel(case):
 C2F_STREAM_CASES = [
     # shortcut, (N, H, W), rows per workgroup (0 = auto)
     (True, (2, 80, 80), 0), (True, (2, 80, 80), 40), (True, (1, 37, 50), 0), (True, (2, 37, 50), 8), (True, (1, 16, 16), 0), (True, (3, 5, 9), 0),
-    (True, (1, 41, 23), 4), (False, (2, 18, 16), 6), (True, (1, 64, 100), 22),
+    (True, (1, 41, 23), 4), (False, (2, 18, 16), 6), (True, (1, 64, 100), 22), (True, (2, 80, 80), -1), (True, (1, 33, 20), -1),
 ]
 
 

@@ -786,6 +786,17 @@ __global__ __launch_bounds__(1024) void c2f32_stream2_kernel(const C2fsParams p)
   }
 }
 
+// CUs of the current device (C++11 static initialisation: thread safe; 0 = the query failed)
+static int c2fs_cus() {
+  static const int cus = [] {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 0;
+    return pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+  }();
+  return cus;
+}
+
 // rows per part for an (n, h, w) problem: one round of workgroups if possible, as few steps as possible
 static int c2fs_pick_rows(int n, int h, int w, int cus) {
   const int strips = cdiv(w, c2fs::WS);
@@ -807,13 +818,8 @@ int upa_c2f32_stream_launch(const void* x, int n, int h, int w, int ldx, int sho
                             const void* const* wm, const float* const* bm, const void* w2, const float* b2, void* y, int ldy,
                             const upa_opts* opts, hipStream_t s) {
   if ((long)n * h * w * (long)(ldx > ldy ? ldx : ldy) * 2 >= (1L << 31) || (long)w * ldx * 2 >= (1L << 24)) return UPA_EUNSUPPORTED;
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    hipDeviceProp_t pr;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return UPA_ELAUNCH;
-    cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
-  }
+  const int cus = c2fs_cus();
+  if (!cus) return UPA_ELAUNCH;
   C2fsParams p;
   memset(&p, 0, sizeof(p));
   p.x = (const char*)x; p.y = (char*)y; p.w1 = (const char*)w1; p.w2 = (const char*)w2; p.b1 = b1; p.b2 = b2;
@@ -853,13 +859,8 @@ int upa_c2f32_stream1_launch(const void* x, int n, int h, int w, int c1, int ldx
   if (c1 % 64 != 0 || nch < 1 || nch > 3 || (up && (up_c % 64 != 0 || (h & 1) || (w & 1)))) return UPA_EUNSUPPORTED;
   const long ldm = ldx > ldy ? (ldx > up_ld ? ldx : up_ld) : (ldy > up_ld ? ldy : up_ld);
   if ((long)n * h * w * ldm * 2 >= (1L << 31) || (long)w * ldm * 2 >= (1L << 24)) return UPA_EUNSUPPORTED;
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    hipDeviceProp_t pr;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return UPA_ELAUNCH;
-    cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
-  }
+  const int cus = c2fs_cus();
+  if (!cus) return UPA_ELAUNCH;
   C2fsParams p;
   memset(&p, 0, sizeof(p));
   p.x = (const char*)x; p.y = (char*)y; p.w1 = (const char*)w1; p.w2 = (const char*)w2; p.b1 = b1; p.b2 = b2;
