@@ -1231,6 +1231,12 @@ def gpu_parity(args, dev, ppath, model, x0, results, pb):
                       # iou_thres, or overlapping such a row) are counted and excused; every other row must have its partner
                       "rows": rq, "tolerance": 1e-3,
                       "within_tolerance": bool(d[:, :4].max() <= 1e-3 and d[:, 4:].max() <= 1e-3 and rq["equivalent"])}
+        if args.model == "yolov8s":
+            # the reference's OWN f32 output on this model moves by 2.2e-3 px between 8 and 1 CPU threads and sits 1.8e-3 .. 2.9e-3 px from
+            # its float64 run (tools/ref_noise_floor.py; tests/test_oracle_golden.py): 1e-3 px is below its reproducibility there
+            out["f32"]["box_tolerance_note"] = ("yolov8s: the reference's own f32 noise floor is 2.2e-3 - 2.9e-3 px (8 vs 1 threads, vs float64); "
+                                                "the tests gate its boxes at 3e-3 px, scores at 1e-3")
+            out["f32"]["within_reference_noise_floor"] = bool(d[:, :4].max() <= 3e-3 and d[:, 4:].max() <= 1e-3 and rq["equivalent"])
         del mf, yf
         if args.dtype == "bf16":
             mine = []
