@@ -1,0 +1,79 @@
+"""Which launches of the yolov8s training step are on its critical path?  Timing-only ablations (results are WRONG while a call is
+skipped): the eager step is timed with one family of C-ABI calls turned into a no-op at a time - the drop in ms/step is what removing
+those launches from the main stream could buy at most.
+
+    python3 tools/experiments/r05_train_ablate.py [--steps 12]
+"""
+import argparse
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+from ultralytics_pro_amd import _lib as L  # noqa: E402
+from ultralytics_pro_amd.engine.trainer import DetectionTrainer  # noqa: E402
+from ultralytics_pro_amd.nn.tasks import DetectionModel  # noqa: E402
+from ultralytics_pro_amd.utils import procedural as P  # noqa: E402
+
+
+class Proxy:
+    def __init__(self, real, skip):
+        self._real, self._skip = real, set(skip)
+
+    def __getattr__(self, name):
+        f = getattr(self._real, name)
+        if name in self._skip:
+            return lambda *a: 0
+        return f
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--model", default="yolov8s")
+    ap.add_argument("--batch", type=int, default=32)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    model = DetectionModel(a.model + ".yaml")
+    P.apply_procedural_weights(model)
+    tr = DetectionTrainer(model, dtype=torch.bfloat16, device=dev)
+    x = P.synthetic_images(a.batch, h=640, w=640).to(dev)
+    lab = P.synthetic_labels(a.batch)
+    for _ in range(3):
+        tr.step(x, lab)
+    real = L.lib()
+    orig = L.lib
+
+    def run(skip):
+        L.lib = (lambda: Proxy(real, skip)) if skip else orig
+        try:
+            tr.step(x, lab)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                tr.step(x, lab)
+            t_issue = time.perf_counter() - t0
+            torch.cuda.synchronize(dev)
+            return (time.perf_counter() - t0) / a.steps * 1e3, t_issue / a.steps * 1e3
+        finally:
+            L.lib = orig
+
+    cases = [("baseline", ()), ("no bn_stats (forward reduce)", ("upa_bn_stats",)), ("no bn_finalize (forward combine)", ("upa_bn_finalize",)),
+             ("no bn_stats + bn_finalize", ("upa_bn_stats", "upa_bn_finalize")), ("no bn_act_fwd", ("upa_bn_act_fwd",)),
+             ("no bn_act_bwd (reduce + combine + apply)", ("upa_bn_act_bwd",)), ("no wgrad", ("upa_conv2d_wgrad",)),
+             ("no forward/backward convs", ("upa_conv2d_bias_act",)), ("baseline again", ())]
+    for name, skip in cases:
+        ms, iss = run(skip)
+        print(f"{name:45s} {ms:7.3f} ms/step   (host issue {iss:6.3f} ms/step)", flush=True)
+    # A/B of the forward statistics as one launch (upa_bn_batch_stats) vs reduction + combine launches
+    for rep in range(3):
+        for two in (True, False):
+            tr.ctx.two_launch_stats = two
+            ms, iss = run(())
+            print(f"forward statistics as {'two launches' if two else 'one launch   '}              {ms:7.3f} ms/step   (host issue {iss:6.3f})", flush=True)
+
+
+if __name__ == "__main__":
+    main()
