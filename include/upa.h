@@ -67,6 +67,7 @@ typedef struct upa_opts {
   int32_t conv_p8;         /* csrc/conv_p8.hip (8-wave two-group phased 3x3 stride-1 kernel for Cin % 64 == 0, Cout % 128 == 0: counted vmcnt, 4-slab weight ring, double-buffered halo) inside upa_conv2d_bias_act: 0 = by the size rule, 1 = never, 2 = every shape it can run */
   int32_t c2f_stream;      /* csrc/c2f_stream.hip (line-buffer form of the C2f(64, 64, n = 2) block: fixed wave roles, LDS ring buffers) inside upa_c2f_fused: 0 = where it applies, 1 = never (the 16 x 16 tile form), 2 = the n = 2 block on its first wave-role set (A/B) */
   int32_t c2f_stream_rows; /* its output rows per workgroup: 0 = auto (one round of workgroups where possible) | even >= 4 | -1 = the whole image height (fewest pipeline fills: least total CU time, for several steps in flight) */
+  int32_t no_epi_stats;    /* upa_conv2d_bn_stats: 1 = the batch statistics always by a reduction pass over z (upa_bn_stats), never from the convolution's own workgroups; A/B */
 } upa_opts;
 
 /* Library / device info. Returns the ABI version (int); fills name with the kernel target ("gfx950"). */
@@ -407,6 +408,14 @@ size_t upa_channel_reduce_workspace_bytes(int c);
 int upa_bn_stats(const void* z, long npix, int c, int ldz, double* ws, int dtype, void* stream);
 int upa_bn_finalize(const double* ws, long npix, int c, float momentum, float* mean, float* var, float* running_mean,
                     float* running_var, void* stream);
+/* Training forward of Conv (conv.py:177-186 in train mode) up to the normalisation: z = conv2d(x) - no bias, no activation - AND the
+ * batch statistics of z (mean, biased var, running update as upa_bn_finalize) in one call.  On the kernels that have a statistics
+ * epilogue the per-channel sums are left by the convolution's own workgroups (of the rounded values they store; one f32 row per pixel
+ * tile, added in a fixed order by a combine launch): z is not read back.  Other shapes: upa_conv2d_bias_act + upa_bn_stats +
+ * upa_bn_finalize.  w_packed as upa_conv2d_bias_act; ws as above (upa_channel_reduce_workspace_bytes(cout)). */
+int upa_conv2d_bn_stats(const void* x, int n, int h, int w, int cin, int ldx, const void* w_packed, void* z, int cout, int ldz, int k,
+                        int stride, int pad, float momentum, float* mean, float* var, float* running_mean, float* running_var,
+                        double* ws, int dtype, const upa_opts* opts, void* stream);
 /* y = act(gamma * (z - mean) / sqrt(var + eps) + beta) (+ residual) */
 int upa_bn_act_fwd(const void* z, long npix, int c, int ldz, const float* mean, const float* var, const float* gamma,
                    const float* beta, float eps, int act, void* y, int ldy, const void* residual, int ldr, int dtype,

@@ -149,6 +149,75 @@ def test_weight_gradient_bf16_matches_torch(case):
     assert torch.equal(dw2.cpu(), got)
 
 
+EPI_STATS_CASES = [
+    # cin, cout, k, s, N, H, W: shapes of the yolov8s training step that run on kernels with a statistics epilogue, small batches
+    (128, 128, 3, 1, 4, 40, 40),   # conv_big 256 px x 128 ch (4 x 4 tiles per wave), 25 workgroups
+    (128, 128, 3, 1, 2, 20, 20),   # 128-px workgroups, ragged tile (20 x 20 = 3.1 tiles of 128)
+    (256, 256, 3, 1, 3, 20, 20),   # two column blocks of 128 channels: rows are filled by blockIdx.y slices
+    (64, 128, 3, 2, 2, 80, 80),    # stride 2
+    (128, 64, 3, 1, 2, 40, 40),    # 64-channel columns (8 x 1 waves)
+    (768, 512, 1, 1, 2, 20, 20),   # pointwise on conv_big (cin >= 512): flattened pixel row, ragged last tile
+    (256, 64, 3, 1, 1, 40, 40),    # 64 channels, 128-px workgroups (4 x 2 waves x 2 x 2 tiles)
+    (384, 256, 1, 1, 2, 40, 40),   # streaming pointwise kernel, two column blocks of eight n-tiles
+    (96, 64, 1, 1, 3, 32, 32),     # ... four n-tiles, three k-tiles
+    (64, 32, 1, 1, 2, 24, 24),     # ... two n-tiles
+    (64, 96, 1, 1, 1, 80, 80),     # ... six n-tiles
+    (256, 128, 1, 1, 32, 20, 20),  # ... persistent workgroups with several pixel groups per wave
+    (64, 64, 3, 1, 6, 40, 40),     # weights-stationary 3x3 (conv_ws3): every wave owns its channels
+    (64, 64, 3, 1, 9, 44, 52),     # ... ragged tiles (44 = 5.5 x 8 rows, 52 = 3.25 x 16 columns), more tiles than workgroups
+    (128, 80, 1, 1, 2, 20, 20),    # five n-tiles: no such epilogue - the library's conv -> reduce -> combine sequence
+    (32, 64, 3, 2, 2, 32, 32),     # ... and a shape on the generic kernel
+]
+
+
+@pytest.mark.parametrize("case", EPI_STATS_CASES, ids=[f"c{c[0]}-{c[1]}k{c[2]}s{c[3]}_{c[5]}x{c[6]}" for c in EPI_STATS_CASES])
+def test_conv_batch_statistics_from_the_convolution_epilogue(case):
+    """upa_conv2d_bn_stats (training forward of Conv up to the normalisation, conv.py:177-186): z bit-identical to the plain convolution
+    and mean / var / running statistics equal to a reduction pass over z (upa_opts.no_epi_stats = 1: the same call on the three-launch
+    sequence) to f32 rounding, against an f64 torch reduction of the stored z, and bit-reproducible."""
+    from tests.hip_utils import DEV, to_dev_nhwc
+    from ultralytics_pro_amd import _lib as L
+    from ultralytics_pro_amd.engine import runtime as R
+    cin, cout, k, s, N, H, W = case
+    lib = L.lib()
+    st = L.current_stream(DEV)
+    w = P.uniform(f"ew{case}", (cout, cin, k, k), -1, 1) * (2.0 / (cin * k * k)) ** 0.5
+    wp = torch.empty(lib.upa_conv_packed_weight_bytes(cout, cin, k, L.UPA_BF16), dtype=torch.uint8, device=DEV)
+    wd = w.to(DEV).contiguous()
+    L.check(lib.upa_pack_conv_weight_dev(wd.data_ptr(), cout, cin, k, L.UPA_BF16, 0, wp.data_ptr(), st))
+    x = to_dev_nhwc(P.uniform(f"ex{case}", (N, cin, H, W), -1, 1), torch.bfloat16)
+    vx = R.view_of(x)
+    oh, ow = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
+    npix = N * oh * ow
+    ws = torch.zeros(lib.upa_channel_reduce_workspace_bytes(cout) // 8, dtype=torch.float64, device=DEV)
+    rm0, rv0 = P.uniform(f"erm{case}", (cout,), -0.1, 0.1).to(DEV), P.uniform(f"erv{case}", (cout,), 0.5, 1.5).to(DEV)
+
+    def run(no_epi):
+        z = R.alloc_nhwc(N, cout, oh, ow, torch.bfloat16, DEV)
+        vz = R.view_of(z)
+        m, v, rm, rv = torch.empty(cout, device=DEV), torch.empty(cout, device=DEV), rm0.clone(), rv0.clone()
+        with R.use_opts(L.Opts(no_epi_stats=int(no_epi))):
+            L.check(lib.upa_conv2d_bn_stats(vx.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, wp.data_ptr(), vz.ptr, cout, vz.ld, k, s, k // 2, 0.03,
+                                            m.data_ptr(), v.data_ptr(), rm.data_ptr(), rv.data_ptr(), ws.data_ptr(), L.UPA_BF16,
+                                            R.opts_ptr(), st))
+        torch.cuda.synchronize()
+        return z, (m, v, rm, rv)
+
+    z_sep, st_sep = run(True)
+    z_epi, st_epi = run(False)
+    assert torch.equal(z_sep, z_epi)
+    for a, b in zip(st_epi, st_sep):
+        assert _rel(a.double(), b.double()) <= 2e-6
+    z64 = z_epi.permute(0, 2, 3, 1).reshape(-1, cout).double() if z_epi.dim() == 4 else z_epi.double()
+    assert z64.shape[0] == npix
+    m_ref, v_ref = z64.mean(0), z64.var(0, unbiased=False)
+    assert _rel(st_epi[0].double(), m_ref) <= 1e-5 and _rel(st_epi[1].double(), v_ref) <= 1e-5
+    assert _rel(st_epi[3].double(), 0.97 * rv0.double() + 0.03 * v_ref * npix / (npix - 1)) <= 1e-5
+    for _ in range(3):
+        z2, st2 = run(False)
+        assert torch.equal(z2, z_epi) and all(torch.equal(a, b) for a, b in zip(st2, st_epi))
+
+
 def test_head_conv_with_bias_and_stem_input():
     """Plain nn.Conv2d(+bias) head outputs (head.py:98-100) and the 3-channel stem (padded NHWC input, no dx)."""
     from tests.hip_utils import DEV, to_cpu_nchw, to_dev_nhwc

@@ -60,19 +60,21 @@ def main():
         finally:
             L.lib = orig
 
-    cases = [("baseline", ()), ("no bn_stats (forward reduce)", ("upa_bn_stats",)), ("no bn_finalize (forward combine)", ("upa_bn_finalize",)),
-             ("no bn_stats + bn_finalize", ("upa_bn_stats", "upa_bn_finalize")), ("no bn_act_fwd", ("upa_bn_act_fwd",)),
+    # (round 5, later: the forward conv + statistics became one C call, upa_conv2d_bn_stats - the first ablations of
+    # profiles/r05_train_ablation.txt were taken on the three-call form)
+    cases = [("baseline", ()), ("no bn_act_fwd", ("upa_bn_act_fwd",)),
              ("no bn_act_bwd (reduce + combine + apply)", ("upa_bn_act_bwd",)), ("no wgrad", ("upa_conv2d_wgrad",)),
              ("no forward/backward convs", ("upa_conv2d_bias_act",)), ("baseline again", ())]
     for name, skip in cases:
         ms, iss = run(skip)
         print(f"{name:45s} {ms:7.3f} ms/step   (host issue {iss:6.3f} ms/step)", flush=True)
-    # A/B of the forward statistics as one launch (upa_bn_batch_stats) vs reduction + combine launches
+    # A/B: batch statistics from the convolution's epilogue (default) vs a reduction pass over z (upa_opts.no_epi_stats = 1)
+    from ultralytics_pro_amd.engine import runtime as R
     for rep in range(3):
-        for two in (True, False):
-            tr.ctx.two_launch_stats = two
-            ms, iss = run(())
-            print(f"forward statistics as {'two launches' if two else 'one launch   '}              {ms:7.3f} ms/step   (host issue {iss:6.3f})", flush=True)
+        for off in (1, 0):
+            with R.use_opts(L.Opts(no_epi_stats=off)):
+                ms, iss = run(())
+            print(f"batch statistics {'by a pass over z          ' if off else 'from the conv epilogue    '}   {ms:7.3f} ms/step   (host issue {iss:6.3f})", flush=True)
 
 
 if __name__ == "__main__":

@@ -966,6 +966,65 @@ extern "C" int upa_conv2d_bias_act(const void* x, int n, int h, int w, int cin, 
   return rc;
 }
 
+// Training forward of Conv (conv.py:177-186 in train mode): z = conv2d(x) (no bias, no activation) AND nn.BatchNorm2d's batch statistics
+// of z - mean / biased variance + the running update - in one call.  Where the layer runs on a kernel with a statistics epilogue
+// (conv_big.hip TAIL 3; ...) the per-channel sums come from the convolution's own workgroups (sums of the bf16-rounded values they store,
+// one row per pixel tile) and a combine launch adds the rows in a fixed order: no pass over z.  Elsewhere: the convolution, then
+// upa_bn_stats + upa_bn_finalize.  ws: upa_channel_reduce_workspace_bytes(cout) bytes (shared with the other reductions, one stream).
+int upa_bn_finalize_rows(const float* rows, int nrows, int ld, long npix, int c, float momentum, float* mean, float* var,
+                         float* running_mean, float* running_var, void* stream);  // train.hip
+extern "C" size_t upa_channel_reduce_workspace_bytes(int c);
+extern "C" int upa_bn_stats(const void* z, long npix, int c, int ldz, double* ws, int dtype, void* stream);
+extern "C" int upa_bn_finalize(const double* ws, long npix, int c, float momentum, float* mean, float* var, float* running_mean,
+                               float* running_var, void* stream);
+extern "C" int upa_conv2d_bn_stats(const void* x, int n, int h, int w, int cin, int ldx, const void* w_packed, void* z, int cout, int ldz,
+                                   int k, int stride, int pad, float momentum, float* mean, float* var, float* running_mean,
+                                   float* running_var, double* ws, int dtype, const upa_opts* opts, void* stream) {
+  UPA_CHECK_ARG(x && w_packed && z && mean && var && ws, "conv2d_bn_stats: null pointer");
+  UPA_CHECK_ARG(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && k >= 1 && stride >= 1, "conv2d_bn_stats: bad shape");
+  const int oh = (h + 2 * pad - k) / stride + 1, ow = (w + 2 * pad - k) / stride + 1;
+  const long npix = (long)n * oh * ow;
+  const int mode = UPA_OPT(opts, no_epi_stats);  // 1 = always the separate reduction (A/B)
+  if (!mode && dtype == UPA_BF16 && cout % 16 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)z % 16) == 0) {
+    float* rows = reinterpret_cast<float*>(ws);
+    const long max_rows = (long)(upa_channel_reduce_workspace_bytes(cout) / ((size_t)2 * cout * sizeof(float)));
+    int nrows = 0, rc = UPA_EUNSUPPORTED;
+    if (upa_conv_ws3_eligible(n, h, w, cin, ldx, cout, ldz, false, k, stride, pad, UPA_ACT_NONE, dtype, opts)) {
+      BigParams q;
+      memset(&q, 0, sizeof(q));
+      q.x = (const char*)x; q.y = (char*)z; q.w = (const char*)w_packed;
+      q.N = n; q.H = h; q.W = w; q.Cin = cin; q.ldx = ldx; q.Cout = cout; q.ldy = ldz; q.OH = h; q.OW = w;
+      q.KS = 3; q.stride = 1; q.pad = 1; q.act = UPA_ACT_NONE;
+      q.stats = rows;
+      rc = upa_conv_ws3_launch_stats(q, &nrows, max_rows, stream, opts);
+    } else if (upa_conv_big_eligible(n, h, w, cin, ldx, cout, ldz, 0, k, stride, pad, UPA_ACT_NONE, dtype, opts)) {
+      BigParams q;
+      memset(&q, 0, sizeof(q));
+      q.x = (const char*)x; q.y = (char*)z; q.w = (const char*)w_packed;
+      q.N = n; q.H = h; q.W = w; q.Cin = cin; q.ldx = ldx; q.Cout = cout; q.ldy = ldz; q.OH = oh; q.OW = ow;
+      q.KS = k; q.stride = stride; q.pad = pad; q.act = UPA_ACT_NONE;
+      q.stats = rows;
+      rc = upa_conv_big_launch_stats(q, &nrows, max_rows, stream, opts);
+    } else if (!upa_conv_ws3_eligible(n, h, w, cin, ldx, cout, ldz, false, k, stride, pad, UPA_ACT_NONE, dtype, opts) &&
+               !upa_conv_pipe_eligible(n, h, w, cin, ldx, cout, ldz, 0, k, stride, pad, UPA_ACT_NONE, dtype, opts) &&
+               upa_conv1x1_eligible(n, h, w, cin, ldx, cout, ldz, false, k, stride, pad, UPA_ACT_NONE, dtype, opts)) {
+      C1Params q;
+      memset(&q, 0, sizeof(q));
+      q.x = (const char*)x; q.y = (char*)z; q.w = (const char*)w_packed;
+      q.Cin = cin; q.ldx = ldx; q.Cout = cout; q.ldy = ldz; q.act = UPA_ACT_NONE;
+      q.stats = rows;
+      rc = upa_conv1x1_launch_stats(q, n * h * w, &nrows, max_rows, stream, opts);
+    }
+    if (rc == UPA_OK) return upa_bn_finalize_rows(rows, nrows, cout, npix, cout, momentum, mean, var, running_mean, running_var, stream);
+    if (rc != UPA_EUNSUPPORTED) return rc;
+  }
+  if (const int rc = upa_conv2d_bias_act(x, n, h, w, cin, ldx, w_packed, nullptr, z, cout, ldz, nullptr, 0, k, stride, pad, UPA_ACT_NONE,
+                                         dtype, opts, stream); rc != UPA_OK)
+    return rc;
+  if (const int rc = upa_bn_stats(z, npix, cout, ldz, ws, dtype, stream); rc != UPA_OK) return rc;
+  return upa_bn_finalize(ws, npix, cout, momentum, mean, var, running_mean, running_var, stream);
+}
+
 // Conv(k = 3, s = 1, p = 1) + SiLU followed by nn.MaxPool2d(2, 2, 0) as ONE launch (yolov3-tiny.yaml rows 2-7: the full-resolution
 // activation - 210 + 105 + 52 MB at batch 32 - is neither written nor read back): y = the pooled (n, h / 2, w / 2, cout) view.
 // Bit-identical to upa_conv2d_bias_act + upa_maxpool2d (the pool runs on the bf16-rounded activations in the conv epilogue,

@@ -128,6 +128,15 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_stream_kernel(const C1Para
   };
   zero_acc();
 
+  // EPI 3 (training forward, act none, no bias): this wave's running per-channel sum / sum of squares of the bf16-ROUNDED values it
+  // stores, over all its pixel groups - lane (kg, p16) keeps the sums of its own pixel column; they meet at the end of the kernel
+  float ssum[EPI == 3 ? NTW : 1][4], ssq[EPI == 3 ? NTW : 1][4];
+  if constexpr (EPI == 3) {
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ssum[j][q] = ssq[j][q] = 0.f;
+  }
   auto epilogue = [&](int g, auto act_tag) __attribute__((always_inline)) {
     constexpr int ACT = decltype(act_tag)::value;
     auto act = [](float v) __attribute__((always_inline)) {
@@ -191,8 +200,20 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_stream_kernel(const C1Para
           v0[q] = act(acc[i][j][q] + biasv[j][q]);
           v1[q] = act(acc[i][j + 1][q] + biasv[j + 1][q]);
         }
-        auto lo = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v1[0], v1[1]), false, false);
-        auto hi = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[2], v1[3]), false, false);
+        const unsigned pk[2][2] = {{pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3])}, {pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])}};
+        if constexpr (EPI == 3) {
+          const float mk = pok ? 1.f : 0.f;
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+              const float a = __uint_as_float(pk[jj][h2] << 16) * mk, b = __uint_as_float(pk[jj][h2] & 0xFFFF0000u) * mk;
+              ssum[j + jj][2 * h2] += a; ssq[j + jj][2 * h2] = fmaf(a, a, ssq[j + jj][2 * h2]);
+              ssum[j + jj][2 * h2 + 1] += b; ssq[j + jj][2 * h2 + 1] = fmaf(b, b, ssq[j + jj][2 * h2 + 1]);
+            }
+        }
+        auto lo = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+        auto hi = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
         if (pok && co0 + cb < p.Cout) *reinterpret_cast<u32x4*>(yrow + cb * 2) = u32x4{lo[0], hi[0], lo[1], hi[1]};
         ++seq;  // lane (pixel tb, kg 0) is always active here: the store is certainly issued
       }
@@ -262,11 +283,47 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_stream_kernel(const C1Para
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  if (gw >= p.groups) return;
+  if (gw >= p.groups) {
+    if constexpr (EPI != 3) return;
+    running = false;  // (EPI 3: a wave without pixel groups still takes part in the workgroup's row of sums)
+  }
   auto guarded = [&](auto stage_tag) __attribute__((always_inline)) {
     if (running) step(stage_tag);
   };
   while (running) for_stages(guarded, std::make_integer_sequence<int, RING>{});
+  if constexpr (EPI == 3) {
+    static_assert(EPI != 3 || (NTW % 2) == 0, "the statistics epilogue pairs n-tiles");
+    // the lane's sums over the 16 pixel columns of its row group (fixed butterfly: xor 1, xor 2, mirror in 8, mirror in 16), then over the
+    // workgroup's waves in wave order through LDS (the weight slice is dead once every wave is here): row blockIdx.x of p.stats
+    auto row16 = [](float v) __attribute__((always_inline)) {
+      v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0xB1, 0xF, 0xF, true));
+      v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x4E, 0xF, 0xF, true));
+      v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x141, 0xF, 0xF, true));
+      v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x140, 0xF, 0xF, true));
+      return v;
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (zero-page pieces a wave may still have in flight into its ring)
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { ssum[j][q] = row16(ssum[j][q]); ssq[j][q] = row16(ssq[j][q]); }
+      if (p16 == 0) {
+        *reinterpret_cast<f32x4*>(red + (wave * 2 + 0) * (NTW * 16) + j * 16 + 4 * kg) = f32x4{ssum[j][0], ssum[j][1], ssum[j][2], ssum[j][3]};
+        *reinterpret_cast<f32x4*>(red + (wave * 2 + 1) * (NTW * 16) + j * 16 + 4 * kg) = f32x4{ssq[j][0], ssq[j][1], ssq[j][2], ssq[j][3]};
+      }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 2 * NTW * 16) {
+      const int k = (int)threadIdx.x / (NTW * 16), cl = (int)threadIdx.x - k * (NTW * 16);
+      float t = 0.f;
+#pragma unroll
+      for (int m = 0; m < WAVES; ++m) t += red[(m * 2 + k) * (NTW * 16) + cl];
+      const int ch = nt0 * 16 + cl;
+      if (ch < p.stats_ld) p.stats[((size_t)blockIdx.x * 2 + k) * p.stats_ld + ch] = t;
+    }
+  }
 }
 
 namespace {
@@ -308,7 +365,16 @@ bool upa_conv1x1_eligible(int n, int h, int w, int cin, int ldx, int cout, int l
   return true;
 }
 
+static int c1_launch(C1Params p, int n_pixels, int query_only, int* variant, int* rows, long max_rows, void* stream, const upa_opts* opts);
 int upa_conv1x1_launch(C1Params p, int n_pixels, int query_only, int* variant, void* stream, const upa_opts* opts) {
+  return c1_launch(p, n_pixels, query_only, variant, nullptr, 0, stream, opts);
+}
+int upa_conv1x1_launch_stats(C1Params p, int n_pixels, int* rows, long max_rows, void* stream, const upa_opts* opts) {
+  if (!p.stats || p.act != UPA_ACT_NONE || p.bias || p.up) return UPA_EUNSUPPORTED;
+  p.epi = 3;
+  return c1_launch(p, n_pixels, 0, nullptr, rows, max_rows, stream, opts);
+}
+static int c1_launch(C1Params p, int n_pixels, int query_only, int* variant, int* rows, long max_rows, void* stream, const upa_opts* opts) {
   p.P = n_pixels;
   p.KTT = (p.Cin + 31) / 32;
   p.NTn = (p.Cout + 15) / 16;
@@ -328,6 +394,7 @@ int upa_conv1x1_launch(C1Params p, int n_pixels, int query_only, int* variant, v
   // pixel tiles per wave and step: enough groups that every SIMD of the chip has a few to pipeline
   const int f_mt = UPA_OPT(opts, c1_mt), f_waves = UPA_OPT(opts, c1_waves), f_wgs = UPA_OPT(opts, c1_wgs);  // tuning / tests
   int mt = tiles >= 8192 ? 4 : (tiles >= 2048 ? 2 : 1);
+  if (p.epi == 3 && ntw > 4 && mt > 2) mt = 2;  // the statistics epilogue keeps 8 ntw running sums per lane: registers
   if (mt * ntw > 32) mt = 32 / ntw;  // accumulator budget: MT * NTW tiles of 4 registers
   if (mt == 3) mt = 2;
   int waves = 8;
@@ -358,6 +425,17 @@ int upa_conv1x1_launch(C1Params p, int n_pixels, int query_only, int* variant, v
   if (query_only) return UPA_OK;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)gx, (unsigned)gridY);
+  if (p.epi == 3) {  // training forward: rows + per-workgroup channel statistics (row blockIdx.x, channel slice blockIdx.y)
+    if ((ntw & 1) || gx > max_rows) return UPA_EUNSUPPORTED;
+    p.stats_ld = p.NTn * 16;
+    *rows = gx;
+    switch (ntw) {
+      case 2: return launch_c1_ntw<2, 3>(p, mt, waves, grid, lds, s);
+      case 4: return launch_c1_ntw<4, 3>(p, mt, waves, grid, lds, s);
+      case 6: return launch_c1_ntw<6, 3>(p, mt, waves, grid, lds, s);
+      default: return launch_c1_ntw<8, 3>(p, mt, waves, grid, lds, s);
+    }
+  }
   if (p.epi) {  // Detect tails: one workgroup row holds every output channel of a pixel
     if (gridY != 1 || (p.epi == 1 && ntw != 4)) { upa_set_error("conv1x1 detect tail: unsupported channel count"); return UPA_EUNSUPPORTED; }
     if (p.epi == 1) return launch_c1_ntw<4, 1>(p, mt, waves, grid, lds, s);

@@ -54,13 +54,17 @@ __device__ __forceinline__ float big_act(float v) {
 // TAIL != 0 (Detect branches, WN = 1 so that a wave holds every channel of its pixels): the SiLU'd result of this 3x3 conv is
 // not stored but fed, from the accumulators, into the branch's final 1x1 conv and that conv's half of the decode - see the
 // tail section below.  TAIL 1 = box branch (DFL + dist2bbox), 2 = class branch (sigmoid).
+// TAIL 3 (training forward, act = none, no residual): besides storing z the workgroup leaves the sum and the sum of squares of the
+// bf16-ROUNDED values it stored, per output channel, in row blockIdx.x of p.stats - the first stage of BatchNorm's batch statistics
+// (conv.py:177-186 in train mode) without a pass over z; a combine kernel adds the rows in a fixed order (train.hip).
 // The kernel body: `bid0` = the workgroup's tile index within ITS problem (blockIdx.x for a single launch; a paired launch -
 // conv_big_pair_kernel below - runs two problems of the same instantiation in one grid).
 template <int KS, int STRIDE, int WM, int WN, int MT, int NT, int TAIL = 0>
 __device__ __forceinline__ void conv_big_body(const BigParams& p, const int bid0) {
   static_assert(WM * WN == 8, "8 waves per workgroup");
-  static_assert(TAIL == 0 || WN == 1, "a tail needs every channel of a pixel in one wave");
+  static_assert(TAIL == 0 || TAIL == 3 || WN == 1, "a tail needs every channel of a pixel in one wave");
   static_assert(TAIL != 1 || (NT % 2) == 0, "box branch: 64 channels");
+  static_assert(TAIL != 3 || (NT % 2) == 0, "the statistics epilogue pairs n-tiles");
   constexpr int NTB = WN * NT;            // n-tiles per workgroup
   constexpr int WBUF = 2 * NTB * 1024;    // one (tap, chunk) weight slab: 2 k-tiles x NTB n-tiles x 1 KiB
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -196,7 +200,7 @@ __device__ __forceinline__ void conv_big_body(const BigParams& p, const int bid0
   }
   UPA_STAMP_AT(10);
 
-  if constexpr (TAIL != 0) {
+  if constexpr (TAIL == 1 || TAIL == 2) {
     // ---- Detect branch tail (head.py:94-100, 116-126, 151-169): h = SiLU(conv3x3 + b) never leaves the registers.
     // D layout: lane (g, r) holds channels 16j + 4g .. + 3 of pixel r; two neighbouring n-tiles (2s, 2s + 1) packed to bf16
     // ARE the B operand of a v_mfma_f32_16x16x32_bf16 k-step, in the k order (element e < 4: channel 32s + 4g + e, e >= 4:
@@ -284,6 +288,72 @@ __device__ __forceinline__ void conv_big_body(const BigParams& p, const int bid0
         }
         if (p.de.best_keys) upa_detect_best_key_store(p.de, best, bc, n, al, pok, lane);  // uniform
       }
+    }
+    return;
+  }
+
+  if constexpr (TAIL == 3) {
+    // ---- training forward: z = the accumulators rounded to bf16 (no bias, no activation, no residual), stored as below, AND the
+    // workgroup's per-channel sum / sum of squares of those rounded values.  Two n-tiles at a time (16 running sums live): over the
+    // wave's m-tiles in registers, over the 16 pixels of the lane's row group by a fixed butterfly (xor 1, xor 2, mirror in 8, mirror in
+    // 16), over the waves that share the channels in wave order through LDS (the halo image is dead behind the barrier).
+    const int cw = (blockIdx.y * NTB + wn * NT) * 16;
+    float* red = reinterpret_cast<float*>(smem);
+    auto row16 = [](float v) __attribute__((always_inline)) {
+      v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0xB1, 0xF, 0xF, true));
+      v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x4E, 0xF, 0xF, true));
+      v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x141, 0xF, 0xF, true));
+      v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x140, 0xF, 0xF, true));
+      return v;
+    };
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NT; j += 2) {
+      float ss[2][4], sq[2][4];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ss[jj][q] = sq[jj][q] = 0.f;
+      const int cb = 16 * (j + (g & 1)) + 8 * (g >> 1);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int oy = oy0 + pty[i], ox = ox0 + ptx[i];
+        const bool pok = pty[i] < p.TH && oy < p.OH && ox < p.OW;
+        const size_t pixoff = ((size_t)n * p.OH + oy) * p.OW + ox;
+        const unsigned pk[2][2] = {{pack_bf16x2(acc[i][j][0], acc[i][j][1]), pack_bf16x2(acc[i][j][2], acc[i][j][3])},
+                                   {pack_bf16x2(acc[i][j + 1][0], acc[i][j + 1][1]), pack_bf16x2(acc[i][j + 1][2], acc[i][j + 1][3])}};
+        const float mk = pok ? 1.f : 0.f;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            const float a = __uint_as_float(pk[jj][h2] << 16) * mk, b = __uint_as_float(pk[jj][h2] & 0xFFFF0000u) * mk;
+            ss[jj][2 * h2] += a; sq[jj][2 * h2] = fmaf(a, a, sq[jj][2 * h2]);
+            ss[jj][2 * h2 + 1] += b; sq[jj][2 * h2 + 1] = fmaf(b, b, sq[jj][2 * h2 + 1]);
+          }
+        auto lo = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+        auto hi = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+        if (pok && cw + cb < p.Cout) *reinterpret_cast<u32x4*>(p.y + (pixoff * p.ldy + cw + cb) * 2) = u32x4{lo[0], hi[0], lo[1], hi[1]};
+      }
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { ss[jj][q] = row16(ss[jj][q]); sq[jj][q] = row16(sq[jj][q]); }
+        if (r == 0) {
+          *reinterpret_cast<f32x4*>(red + (wave * 2 + 0) * (NT * 16) + (j + jj) * 16 + 4 * g) = f32x4{ss[jj][0], ss[jj][1], ss[jj][2], ss[jj][3]};
+          *reinterpret_cast<f32x4*>(red + (wave * 2 + 1) * (NT * 16) + (j + jj) * 16 + 4 * g) = f32x4{sq[jj][0], sq[jj][1], sq[jj][2], sq[jj][3]};
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * NTB * 16) {
+      const int k = tid / (NTB * 16), chw = tid - k * (NTB * 16);
+      const int wn_ = chw / (NT * 16), cl = chw - wn_ * (NT * 16);
+      float t = 0.f;
+#pragma unroll
+      for (int m = 0; m < WM; ++m) t += red[((m * WN + wn_) * 2 + k) * (NT * 16) + cl];
+      const int ch = blockIdx.y * NTB * 16 + chw;
+      if (ch < p.stats_ld) p.stats[((size_t)blockIdx.x * 2 + k) * p.stats_ld + ch] = t;
     }
     return;
   }
@@ -835,6 +905,20 @@ int big_prepare(BigParams& p, int& ntb, int& bm, size_t& lds, const upa_opts* op
   if (lds > 160 * 1024) return UPA_EUNSUPPORTED;
   return UPA_OK;
 }
+// the statistics epilogue (TAIL 3): forward convolutions of the training step - k 1 | 3 -, even n-tile counts per wave
+template <int WM, int WN, int MT, int NT>
+int big_launch_ks_stats(const BigParams& p, size_t lds, hipStream_t s) {
+  if (p.KS == 1) return big_launch_inst<1, 1, WM, WN, MT, NT, 3>(p, lds, s);
+  if (p.KS != 3) return UPA_EUNSUPPORTED;
+  if (p.stride == 2) return big_launch_inst<3, 2, WM, WN, MT, NT, 3>(p, lds, s);
+  return big_launch_inst<3, 1, WM, WN, MT, NT, 3>(p, lds, s);
+}
+int big_dispatch_stats(const BigParams& p, int ntb, int bm, size_t lds, hipStream_t s) {
+  if (bm != 128 && bm != 256) return UPA_EUNSUPPORTED;
+  if (ntb == 8) return bm == 256 ? big_launch_ks_stats<4, 2, 4, 4>(p, lds, s) : big_launch_ks_stats<4, 2, 2, 4>(p, lds, s);
+  if (ntb == 4) return bm == 256 ? big_launch_ks_stats<8, 1, 2, 4>(p, lds, s) : big_launch_ks_stats<4, 2, 2, 2>(p, lds, s);
+  return UPA_EUNSUPPORTED;
+}
 int big_dispatch(const BigParams& p, int ntb, int bm, size_t lds, hipStream_t s) {
   if (bm == 512) return ntb == 5 ? big_launch_inst<3, 1, 8, 1, 4, 5>(p, lds, s) : big_launch_inst<3, 1, 8, 1, 4, 4>(p, lds, s);
   if (ntb == 5) return bm == 256 ? big_launch_inst<3, 1, 8, 1, 2, 5>(p, lds, s) : big_launch_inst<3, 1, 8, 1, 1, 5>(p, lds, s);
@@ -852,6 +936,23 @@ int upa_conv_big_launch(BigParams p, int query_only, int* variant, void* stream,
   if (variant) *variant = (1 << 23) | (ntb << 4) | (bm >> 7);  // (bm >> 7: 1 = 128, 2 = 256, 4 = 512 pixels)
   if (query_only || rc != UPA_OK) return rc;
   return big_dispatch(p, ntb, bm, lds, (hipStream_t)stream);
+}
+
+// The convolution with the statistics epilogue: p.stats receives *rows rows of [2][p.stats_ld] floats (one per pixel tile; p.stats_ld is
+// set here to 16 * n-tiles).  UPA_EUNSUPPORTED (nothing launched) when the layer's workgroup shape has no such epilogue (80 / 96-channel
+// columns) or the rows would not fit max_rows.
+int upa_conv_big_launch_stats(BigParams p, int* rows, long max_rows, void* stream, const upa_opts* opts) {
+  p.no_xcd = UPA_OPT(opts, no_xcd);
+  if (!p.stats || p.res || p.act != UPA_ACT_NONE) return UPA_EUNSUPPORTED;
+  int ntb = 0, bm = 0;
+  size_t lds = 0;
+  if (const int rc = big_prepare(p, ntb, bm, lds, opts, false); rc != UPA_OK) return rc;
+  if ((ntb != 8 && ntb != 4) || (bm != 128 && bm != 256)) return UPA_EUNSUPPORTED;
+  const long nrows = (long)p.tilesX * p.tilesY * p.N;
+  if (nrows > max_rows) return UPA_EUNSUPPORTED;
+  p.stats_ld = p.NTn * 16;
+  *rows = (int)nrows;
+  return big_dispatch_stats(p, ntb, bm, lds, (hipStream_t)stream);
 }
 
 // Two or three conv_big problems: one grid when they land on the same 128-pixel 3x3 stride-1 instantiation (see conv_big_pair_kernel;

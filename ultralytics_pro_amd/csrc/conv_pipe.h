@@ -35,10 +35,12 @@ struct C1Params {
   int ablate;  // debug build only (upa_opts.ablate_c1): 1 no input DMA, 2 no weight loads, 4 no stores, 8 no MFMA
 #endif
   int epi;     // 0: y = act(conv + bias) as bf16 rows; 1 / 2: Detect box / class decode fused on the end (detect_epi.h), the
-               // bf16 rows are written too when y != nullptr
+               // bf16 rows are written too when y != nullptr; 3: the rows + the workgroup's per-channel statistics (stats)
   DetectEpi de;
   // virtual Upsample(2x nearest) + Concat in front of the conv (upa_conv1x1_upcat): the first upKT k-tiles of a pixel come from
   // pixel (y / 2, x / 2) of the half-resolution tensor `up`, the rest from x (the concat buffer, whose first channels stay unwritten)
+  float* stats;   // epi 3 (training forward): row blockIdx.x = [2][stats_ld] f32 sums / sums of squares of the stored values
+  int stats_ld;
   const char* up;
   int upKT, up_ld, upH, upW;       // k-tiles taken from `up`, its pixel stride (elements), FULL-resolution H and W
   unsigned upMagicW, upMagicH;
@@ -47,6 +49,9 @@ bool upa_conv1x1_eligible(int n, int h, int w, int cin, int ldx, int cout, int l
                           int pad, int act, int dtype, const upa_opts* opts);
 // variant (if non-null) receives (1 << 22) | waves << 8 | MT << 4 | NTW; query_only = 1 skips the launch
 int upa_conv1x1_launch(C1Params p, int n_pixels, int query_only, int* variant, void* stream, const upa_opts* opts);
+// p.stats != nullptr (act none, no bias): the convolution + the first stage of the batch statistics; *rows = rows written (one per
+// workgroup).  UPA_EUNSUPPORTED = nothing launched (odd n-tile count per workgroup, or more rows than max_rows)
+int upa_conv1x1_launch_stats(C1Params p, int n_pixels, int* rows, long max_rows, void* stream, const upa_opts* opts);
 
 // ---- conv_big.hip: large-tile implicit GEMM with both operands shared through LDS (bf16, k 1 | 3, stride 1 | 2)
 struct BigParams {
@@ -67,11 +72,17 @@ struct BigParams {
   const char* tw;      // Detect branch tail: final 1x1 conv packed by upa_pack_tail_weight
   const float* tb;     // ... its bias (zero-padded to 16 * n-tiles)
   DetectEpi de;        // ... and the decode it feeds (detect_epi.h)
+  // training forward (act none, no residual): per-workgroup sums of the stored values and of their squares, row blockIdx.x =
+  // [2][stats_ld] floats (stats_ld = 16 * n-tiles of the layer); nullptr = a plain convolution
+  float* stats;
+  int stats_ld;
 };
 bool upa_conv_big_eligible(int n, int h, int w, int cin, int ldx, int cout, int ldy, int ldr, int k, int stride, int pad,
                            int act, int dtype, const upa_opts* opts);
 // variant (if non-null) receives (1 << 23) | n-tiles per workgroup << 4 | pixels per workgroup / 128; query_only = 1 skips the launch
 int upa_conv_big_launch(BigParams p, int query_only, int* variant, void* stream, const upa_opts* opts);
+// p.stats != nullptr: the convolution + the first stage of the batch statistics (see BigParams::stats); *rows = rows written
+int upa_conv_big_launch_stats(BigParams p, int* rows, long max_rows, void* stream, const upa_opts* opts);
 // the first two or three problems of a list in ONE grid if they share a 128-pixel 3x3 stride-1 instantiation (*consumed = how many);
 // UPA_EUNSUPPORTED = nothing launched (the caller launches the first problem alone and tries again from the next)
 int upa_conv_big_launch_group(const BigParams* probs, int count, int* consumed, void* stream, const upa_opts* opts);
@@ -97,6 +108,7 @@ bool upa_conv_ws3_eligible(int n, int h, int w, int cin, int ldx, int cout, int 
                            int act, int dtype, const upa_opts* opts);
 // variant (if non-null) receives (1 << 24) | NT << 4 | MT; query_only = 1 skips the launch
 int upa_conv_ws3_launch(BigParams p, int query_only, int* variant, void* stream, const upa_opts* opts);
+int upa_conv_ws3_launch_stats(BigParams p, int* rows, long max_rows, void* stream, const upa_opts* opts);  // as upa_conv_big_launch_stats
 
 // ---- conv_pair.hip: Bottleneck (3x3 -> 3x3 [+ x]) as one kernel, the intermediate tile in LDS (bf16, C = 32 | 64)
 struct PairParams {

@@ -49,7 +49,10 @@ constexpr int IW = 18;           // halo pitch = tile width 16 + 2
 
 // NW waves = NW n-tiles (4: 64 output channels).  Wave w holds the weights of channels 16 w .. 16 w + 15 and computes them for ALL
 // 8 x 16 pixels of the tile.
-template <int NW>
+// STATS (training forward, act none, no residual): the lane also keeps the running sum / sum of squares of the bf16-ROUNDED values it
+// stores (its four channels, its pixel column, every tile the workgroup walks); at the end the 16 pixel columns of a row group meet by
+// a fixed butterfly and row blockIdx.x of p.stats receives the workgroup's sums - every wave owns its channels, nothing crosses waves.
+template <int NW, bool STATS = false>
 __global__ __launch_bounds__(NW * 64, 2) void conv_ws3_kernel(const BigParams p) {
   using namespace ws3;
   constexpr int NTHR = NW * 64;
@@ -99,6 +102,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_ws3_kernel(const BigParams p)
 
   int t = blockIdx.x;
   if (t >= numTiles) return;
+  float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
   const f32x4 biasv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + wave * 16 + g * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
   stage_halo(t, 0);
   // The first-tile wait below counts on program order "halo DMA, then exactly 18 weight loads": pin it.  The empty asm with a memory
@@ -211,8 +215,18 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_ws3_kernel(const BigParams p)
           v[0] += __uint_as_float(rv[i][0] << 16); v[1] += __uint_as_float(rv[i][0] & 0xFFFF0000u);
           v[2] += __uint_as_float(rv[i][1] << 16); v[3] += __uint_as_float(rv[i][1] & 0xFFFF0000u);
         }
-        if (colok && tyi * TH + i < p.OH)
-          *reinterpret_cast<u32x2*>(yt + i * yrow + yoff) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        const unsigned pk0 = pack_bf16x2(v[0], v[1]), pk1 = pack_bf16x2(v[2], v[3]);
+        const bool ok = colok && tyi * TH + i < p.OH;
+        if constexpr (STATS) {
+          const float mk = ok ? 1.f : 0.f;
+          const float a0 = __uint_as_float(pk0 << 16) * mk, a1 = __uint_as_float(pk0 & 0xFFFF0000u) * mk;
+          const float a2 = __uint_as_float(pk1 << 16) * mk, a3 = __uint_as_float(pk1 & 0xFFFF0000u) * mk;
+          ssum[0] += a0; ssq[0] = fmaf(a0, a0, ssq[0]);
+          ssum[1] += a1; ssq[1] = fmaf(a1, a1, ssq[1]);
+          ssum[2] += a2; ssq[2] = fmaf(a2, a2, ssq[2]);
+          ssum[3] += a3; ssq[3] = fmaf(a3, a3, ssq[3]);
+        }
+        if (ok) *reinterpret_cast<u32x2*>(yt + i * yrow + yoff) = u32x2{pk0, pk1};
       }
     };
     if (p.act == UPA_ACT_SILU) epilogue(std::integral_constant<int, UPA_ACT_SILU>{});
@@ -222,6 +236,22 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_ws3_kernel(const BigParams p)
     if (stamped) UPA_STAMP_AT(6);
 #endif
     buf ^= 1;
+  }
+  if constexpr (STATS) {
+    auto row16 = [](float v) __attribute__((always_inline)) {
+      v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0xB1, 0xF, 0xF, true));
+      v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x4E, 0xF, 0xF, true));
+      v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x141, 0xF, 0xF, true));
+      v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x140, 0xF, 0xF, true));
+      return v;
+    };
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { ssum[q] = row16(ssum[q]); ssq[q] = row16(ssq[q]); }
+    if (r == 0) {
+      float* row = p.stats + (size_t)blockIdx.x * 2 * p.stats_ld + 16 * wave + 4 * g;
+      *reinterpret_cast<f32x4*>(row) = f32x4{ssum[0], ssum[1], ssum[2], ssum[3]};
+      *reinterpret_cast<f32x4*>(row + p.stats_ld) = f32x4{ssq[0], ssq[1], ssq[2], ssq[3]};
+    }
   }
   UPA_STAMP_AT(7);
 }
@@ -252,7 +282,18 @@ bool upa_conv_ws3_eligible(int n, int h, int w, int cin, int ldx, int cout, int 
   return cin == 64 && (long)n * h * w >= 8192;
 }
 
+static int ws3_launch(BigParams p, int query_only, int* variant, int* rows, void* stream);
 int upa_conv_ws3_launch(BigParams p, int query_only, int* variant, void* stream, const upa_opts* opts) {
+  p.stats = nullptr;
+  return ws3_launch(p, query_only, variant, nullptr, stream);
+}
+// p.stats != nullptr (act none, no residual, no bias): the convolution + the first stage of the batch statistics; *rows = rows written
+// (one per workgroup, at most two per CU)
+int upa_conv_ws3_launch_stats(BigParams p, int* rows, long max_rows, void* stream, const upa_opts* opts) {
+  if (!p.stats || p.res || p.bias || p.act != UPA_ACT_NONE || max_rows < 2 * ws3_num_cu()) return UPA_EUNSUPPORTED;
+  return ws3_launch(p, 0, nullptr, rows, stream);
+}
+static int ws3_launch(BigParams p, int query_only, int* variant, int* rows, void* stream) {
   p.KTT = (p.Cin + 31) / 32;
   p.NTn = (p.Cout + 15) / 16;
   if (variant) *variant = (1 << 24) | (4 << 4) | 4;
@@ -270,7 +311,17 @@ int upa_conv_ws3_launch(BigParams p, int query_only, int* variant, void* stream,
   }
   const int cus = ws3_num_cu();
   const unsigned grid = (unsigned)(tiles < 2 * cus ? tiles : 2 * cus);
-  hipLaunchKernelGGL(conv_ws3_kernel<4>, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
+  if (p.stats) {
+    if (hipError_t e = upa_full_lds<conv_ws3_kernel<4, true>>(); e != hipSuccess) {
+      upa_set_error("conv_ws3: cannot raise LDS limit: %s", hipGetErrorString(e));
+      return UPA_ELAUNCH;
+    }
+    p.stats_ld = 64;
+    *rows = (int)grid;
+    hipLaunchKernelGGL((conv_ws3_kernel<4, true>), dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
+  } else {
+    hipLaunchKernelGGL(conv_ws3_kernel<4>, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
+  }
   UPA_LAUNCH_CHECK();
   return UPA_OK;
 }

@@ -245,6 +245,37 @@ __global__ __launch_bounds__(256) void combine_finalize_kernel(const CombinePara
   }
 }
 
+// The same second stage for the rows a convolution's statistics epilogue leaves (conv_big.hip TAIL 3, conv1x1.hip, conv_ws3.hip:
+// [nrows][2][ld] f32 - sums and sums of squares of the stored values per pixel tile): fixed order, f64, MODE 0's epilogue.
+__global__ __launch_bounds__(256) void combine_stats_rows_kernel(const float* rows, int nrows, int ld, const CombineParams p) {
+  __shared__ double red[2][256];
+  const int ch = blockIdx.x;
+  double s0 = 0.0, s1 = 0.0;
+  for (int b = threadIdx.x; b < nrows; b += 256) {
+    const float* q = rows + (size_t)b * 2 * ld;
+    s0 += (double)q[ch];
+    s1 += (double)q[ld + ch];
+  }
+  red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  s0 = red[0][0]; s1 = red[1][0];
+  const double m = s0 / (double)p.npix;
+  double v = s1 / (double)p.npix - m * m;
+  if (v < 0) v = 0;
+  p.mean[ch] = (float)m;
+  p.var[ch] = (float)v;
+  if (p.running_mean) {
+    const double unb = p.npix > 1 ? v * (double)p.npix / (double)(p.npix - 1) : v;
+    p.running_mean[ch] = (1.0f - p.momentum) * p.running_mean[ch] + p.momentum * (float)m;
+    p.running_var[ch] = (1.0f - p.momentum) * p.running_var[ch] + p.momentum * (float)unb;
+  }
+}
+
 struct BnApplyParams {
   const char* z; char* y; const char* aux;  // fwd: aux = residual; bwd: aux = dy
   long npix; int c, ldz, ldy, ldaux;
@@ -1372,6 +1403,16 @@ extern "C" int upa_bn_finalize(const double* ws, long npix, int c, float momentu
   q.part = ws; q.nblocks = reduce_grid(npix); q.c = c; q.npix = npix; q.momentum = momentum; q.mean = mean; q.var = var;
   q.running_mean = running_mean; q.running_var = running_var;
   hipLaunchKernelGGL((combine_finalize_kernel<0>), dim3(c), dim3(256), 0, (hipStream_t)stream, q);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+// (internal, conv.hip: upa_conv2d_bn_stats) batch statistics from the rows of a convolution's statistics epilogue
+int upa_bn_finalize_rows(const float* rows, int nrows, int ld, long npix, int c, float momentum, float* mean, float* var,
+                         float* running_mean, float* running_var, void* stream) {
+  CombineParams q{};
+  q.c = c; q.npix = npix; q.momentum = momentum; q.mean = mean; q.var = var; q.running_mean = running_mean; q.running_var = running_var;
+  hipLaunchKernelGGL(combine_stats_rows_kernel, dim3(c), dim3(256), 0, (hipStream_t)stream, rows, nrows, ld, q);
   UPA_LAUNCH_CHECK();
   return UPA_OK;
 }

@@ -153,15 +153,15 @@ class ConvT:
             self._conv(x, self.wp, self.cout, self.k, self.s, self.p, y, bias=self.conv.bias)
             return y
         z = _new(n, self.cout, oh, ow, c.dtype, c.device, (id(self), "z"))
-        self._conv(x, self.wp, self.cout, self.k, self.s, self.p, z)
-        vz = R.view_of(z)
+        vx, vz = R.view_of(x), R.view_of(z)
         npix = vz.n * vz.h * vz.w
-        ws = c.ws
-        L.check(lib.upa_bn_stats(vz.ptr, npix, vz.c, vz.ld, ws.data_ptr(), vz.dtype, _s(c.device)), "bn_stats")
         bn = self.bn
-        L.check(lib.upa_bn_finalize(ws.data_ptr(), npix, self.cout, float(bn.momentum),
-                                    self.mean.data_ptr(), self.var.data_ptr(), bn.running_mean.data_ptr(),
-                                    bn.running_var.data_ptr(), _s(c.device)), "bn_finalize")
+        # conv + batch statistics in one call: on the kernels with a statistics epilogue the sums come from the convolution's own
+        # workgroups (no pass over z), elsewhere the library runs conv -> reduce -> combine itself
+        L.check(lib.upa_conv2d_bn_stats(vx.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, self.wp.data_ptr(), vz.ptr, self.cout, vz.ld,
+                                        self.k, self.s, self.p, float(bn.momentum), self.mean.data_ptr(), self.var.data_ptr(),
+                                        bn.running_mean.data_ptr(), bn.running_var.data_ptr(), c.ws.data_ptr(), vx.dtype,
+                                        R.opts_ptr(), _s(c.device)), f"conv2d_bn_stats[{self.name}]")
         y = out if out is not None else _new(n, self.cout, oh, ow, c.dtype, c.device, (id(self), "y"))
         vy = R.view_of(y)
         rp, rld = (None, 0)
