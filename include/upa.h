@@ -461,6 +461,18 @@ int upa_sumsq(const float* g, long n, double* out, int accumulate, void* workspa
 int upa_sgd_nesterov_ema(float* p, float* g, float* momentum_buf, float* ema, long n, const double* grad_sumsq, float max_norm,
                          float lr, float momentum, float weight_decay, int first_step, float ema_d, const float* ema_d_dev,
                          int zero_grad, void* stream);
+/* The same under an AMP GradScaler (engine/trainer.py:301-302, 429, 676-679; torch/amp/grad_scaler.py), kept entirely on the device:
+ * scaler_state = 4 floats {loss scale, growth tracker, found_inf of the last update, 0}.  g holds gradients of loss * scale (see
+ * upa_detection_loss_scaled), grad_sumsq the squared norm of those scaled gradients.  unscale_ + clip_grad_norm_ + scaler.step: the
+ * norm and the update use g / scale; if grad_sumsq is inf / NaN the step leaves p and the momentum buffer untouched (gradients are
+ * still zeroed and the EMA still updates, as the reference's optimizer_step does).  upa_grad_scaler_update = scaler.update(): an
+ * overflowing step multiplies the scale by backoff_factor and clears the tracker, growth_interval clean steps in a row multiply it by
+ * growth_factor.  No host synchronisation anywhere (the reference's scaler.step() reads found_inf on the host). */
+int upa_sgd_nesterov_ema_scaled(float* p, float* g, float* momentum_buf, float* ema, long n, const double* grad_sumsq, float max_norm,
+                                float lr, float momentum, float weight_decay, int first_step, float ema_d, const float* ema_d_dev,
+                                int zero_grad, const float* scaler_state, void* stream);
+int upa_grad_scaler_update(float* scaler_state, const double* grad_sumsq, float growth_factor, float backoff_factor,
+                           int growth_interval, void* stream);
 int upa_ema_update(float* ema, const float* v, long n, float d, const float* d_dev, void* stream);
 /* dst view = src view converted between f32 and bf16 (head maps enter the loss as f32; c, strides multiples of 8). */
 int upa_cast_view(const void* src, int src_dtype, int lds, void* dst, int dst_dtype, int ldd, long npix, int c, void* stream);
@@ -474,6 +486,12 @@ int upa_detection_loss(const float* const* feats, float* const* grads, const int
                        const float* strides, int n_levels, int b, int nc, int reg_max, const float* gt, const int* n_gt,
                        int max_gt, float gain_box, float gain_cls, float gain_dfl, float grad_scale, float* loss_items,
                        void* workspace, size_t workspace_bytes, void* stream);
+/* ... with the gradients multiplied by *grad_scale_dev (device memory; NULL = 1) as well: scaler.scale(loss).backward(),
+ * engine/trainer.py:429.  loss_items stay unscaled. */
+int upa_detection_loss_scaled(const float* const* feats, float* const* grads, const int* hs, const int* ws, const int* lds,
+                              const float* strides, int n_levels, int b, int nc, int reg_max, const float* gt, const int* n_gt,
+                              int max_gt, float gain_box, float gain_cls, float gain_dfl, float grad_scale,
+                              const float* grad_scale_dev, float* loss_items, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- HIP graph helpers (capture a launch sequence once, replay per batch) -------------------------------------
  * upa_graph_begin / _end bracket a stream capture of upa_* launches; upa_graph_launch replays the instantiated graph.

@@ -556,6 +556,72 @@ def test_compiled_training_step_equals_eager(world):
     np.testing.assert_allclose(ea.numpy(), eb.numpy(), rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_amp_grad_scaler_follows_torch_semantics(dtype):
+    """DetectionTrainer(amp_scaler=True) = the reference's `torch.amp.GradScaler` loop (engine/trainer.py:301-302, 429, 676-679;
+    torch/amp/grad_scaler.py) with the scaler state on the device:
+      * a scaled step lands where the unscaled one does (the scale is a power of two: loss gradients x 2**16, divided out in the
+        optimizer - exact in f32 / bf16 short of overflow) and the reported gradient norm is the unscaled one;
+      * `growth_interval` clean steps in a row double the scale;
+      * a step whose gradients hold an inf is skipped - parameters and momentum untouched, gradients zeroed, EMA still updated
+        (optimizer_step calls ema.update regardless) - the scale halves and the growth tracker restarts;
+      * state_dict / load_state_dict carry torch's keys."""
+    from tests.hip_utils import DEV
+    from ultralytics_pro_amd.engine.trainer import DetectionTrainer
+    from ultralytics_pro_amd.nn.tasks import DetectionModel
+    bs, sz = 2, 128
+    batches = [(P.synthetic_images(bs, h=sz, w=sz, seed=s).to(DEV), P.synthetic_labels(bs, seed=s)) for s in range(3)]
+
+    def make(scaled):
+        m = DetectionModel("yolov8n.yaml")
+        P.apply_procedural_weights(m)
+        tr = DetectionTrainer(m, dtype=dtype, device=DEV, amp_scaler=scaled)
+        if scaled:
+            tr.scaler.growth_interval = 2
+        return m, tr
+
+    (m0, t0), (m1, t1) = make(False), make(True)
+    assert t1.scaler.get_scale() == 65536.0 and t0.scaler.ptr() is None
+    for k, b in enumerate(batches[:2]):
+        i0, i1 = t0.step(*b).cpu(), t1.step(*b).cpu()
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(i1.numpy(), i0.numpy(), rtol=1e-6)  # loss items are unscaled
+        rtol = 1e-5 if dtype == torch.float32 else 2e-3  # bf16: 2**16 x is exact, but sums of scaled bf16 products round elsewhere
+        np.testing.assert_allclose(t1.P.cpu().numpy(), t0.P.cpu().numpy(), rtol=rtol, atol=1e-6)
+        np.testing.assert_allclose(t1.E.cpu().numpy(), t0.E.cpu().numpy(), rtol=rtol, atol=1e-6)
+        assert not t1.scaler.found_inf()
+        assert t1.scaler.get_scale() == (65536.0 if k == 0 else 131072.0)  # two clean steps: x growth_factor
+    sd = t1.scaler.state_dict()
+    assert sd == {"scale": 131072.0, "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 2, "_growth_tracker": 0}
+    # an overflowing step: forward + backward, one gradient made inf, then the reference's optimizer_step
+    t1.forward_backward(*batches[2])
+    t1._join_wgrad() if hasattr(t1, "_join_wgrad") else None
+    torch.cuda.synchronize()
+    t1.G[12345 % t1.G.numel()] = float("inf")
+    p_before, m_before, e_before = t1.P.clone(), t1.M.clone(), t1.E.clone()
+    t1.optimizer_step()
+    torch.cuda.synchronize()
+    assert torch.equal(t1.P, p_before) and torch.equal(t1.M, m_before)
+    assert float(t1.G.abs().max()) == 0.0
+    assert not torch.equal(t1.E, e_before)  # EMA of the (unchanged) weights still moves towards them
+    assert t1.scaler.found_inf() and t1.scaler.get_scale() == 65536.0 and t1.scaler.state_dict()["_growth_tracker"] == 0
+    # the next clean step trains again with the smaller scale
+    t1.step(*batches[2])
+    torch.cuda.synchronize()
+    assert not torch.equal(t1.P, p_before) and not t1.scaler.found_inf() and t1.scaler.state_dict()["_growth_tracker"] == 1
+    t2 = make(True)[1]
+    t2.scaler.load_state_dict(sd)
+    assert t2.scaler.state_dict() == sd
+    # the reported gradient norm is that of the unscaled gradients
+    t0.forward_backward(*batches[0]); t1.forward_backward(*batches[0])
+    for t in (t0, t1):
+        if hasattr(t, "_join_wgrad"):
+            t._join_wgrad()
+    torch.cuda.synchronize()
+    # (t0 and t1 differ by the skipped step; compare t1's norm with its own scaled buffer instead)
+    assert abs(t1.grad_norm() - float(t1.G.double().norm()) / t1.scaler.get_scale()) <= 1e-3 * t1.grad_norm()
+
+
 def test_training_step_yolov8s_f32_matches_reference_golden(golden_dir):
     """BASELINE config 3's model (yolov8s), one f32 training step vs the imported reference's record
     (tests/golden/train_yolov8s.npz: bs 2, 256 x 256): loss items, gradient norm, per-parameter gradient norms, updated

@@ -193,6 +193,9 @@ PROTOTYPES = {
     "upa_cast_view": (_i, [_vp, _i, _i, _vp, _i, _i, C.c_long, _i, _vp]),
     "upa_detection_loss_workspace_bytes": (_sz, [_i, _i, _i]),
     "upa_detection_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp, _sz, _vp]),
+    "upa_detection_loss_scaled": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp, _vp, _sz, _vp]),
+    "upa_sgd_nesterov_ema_scaled": (_i, [_vp, _vp, _vp, _vp, C.c_long, _vp, _f, _f, _f, _f, _i, _f, _vp, _i, _vp, _vp]),
+    "upa_grad_scaler_update": (_i, [_vp, _vp, _f, _f, _i, _vp]),
     "upa_graph_begin": (_i, [_vp]),
     "upa_graph_end": (_i, [_vp, C.POINTER(_vp)]),
     "upa_graph_launch": (_i, [_vp, _vp]),

@@ -257,7 +257,8 @@ __global__ __launch_bounds__(256) void tal_resolve_kernel(const LossLevels L, co
 
 // ---- 4a. classification term, one thread per (anchor, class): SlideLoss(BCEWithLogits) (loss.py:21-46, auto_iou = 0.5)
 __global__ __launch_bounds__(256) void loss_cls_kernel(const LossLevels L, const float* gt, const Assign* asg, const double* tss_p,
-                                                        double* out, float gain_cls, float grad_scale) {
+                                                        double* out, float gain_cls, float grad_scale, const float* gs_dev) {
+  if (gs_dev) grad_scale *= *gs_dev;  // AMP loss scale, kept on the device (GradScaler.scale(loss).backward())
   const float tss = fmaxf((float)*tss_p, 1.f);
   const float gs = grad_scale * (float)L.B / tss;
   double l_cls = 0.0;
@@ -297,7 +298,8 @@ __global__ __launch_bounds__(256) void loss_cls_kernel(const LossLevels L, const
 // (sigmoid and softplus both from e = exp(-|x|)), hardware transcendentals.  The element-per-thread form above took 144 us for yolov8s' 21.5 M
 // scores (two 64-bit divisions and three exponentials per element) against a 21 us traffic floor.
 __global__ __launch_bounds__(256) void loss_cls4_kernel(const LossLevels L, const float* gt, const Assign* asg, const double* tss_p,
-                                                         double* out, float gain_cls, float grad_scale) {
+                                                         double* out, float gain_cls, float grad_scale, const float* gs_dev) {
+  if (gs_dev) grad_scale *= *gs_dev;
   const float tss = fmaxf((float)*tss_p, 1.f);
   const float gs = gain_cls * grad_scale * (float)L.B / tss;
   double l_cls = 0.0;
@@ -366,7 +368,8 @@ __global__ __launch_bounds__(256) void loss_cls4_kernel(const LossLevels L, cons
 // gain * batch_size * grad_scale / max(tss, 1).
 __global__ __launch_bounds__(256) void loss_grad_kernel(const LossLevels L, const float* pbox, const float* gt, const Assign* asg,
                                                          const double* tss_p, double* out, float gain_box, float gain_cls,
-                                                         float gain_dfl, float grad_scale) {
+                                                         float gain_dfl, float grad_scale, const float* gs_dev) {
+  if (gs_dev) grad_scale *= *gs_dev;
   const float tss = fmaxf((float)*tss_p, 1.f);
   double l_box = 0.0, l_cls = 0.0, l_dfl = 0.0;
   const long total = (long)L.B * L.A;
@@ -493,10 +496,26 @@ extern "C" size_t upa_detection_loss_workspace_bytes(int b, int a, int max_gt) {
   return (size_t)b * a * 16 + (size_t)b * max_gt * TOPK * 4 + (size_t)b * a * 8 + (size_t)b * a * 4 + 64;
 }
 
+extern "C" int upa_detection_loss_scaled(const float* const* feats, float* const* grads, const int* hs, const int* ws, const int* lds_,
+                                         const float* strides, int n_levels, int b, int nc, int reg_max, const float* gt, const int* n_gt,
+                                         int max_gt, float gain_box, float gain_cls, float gain_dfl, float grad_scale,
+                                         const float* grad_scale_dev, float* loss_items, void* workspace, size_t workspace_bytes,
+                                         void* stream);
 extern "C" int upa_detection_loss(const float* const* feats, float* const* grads, const int* hs, const int* ws, const int* lds_,
                                   const float* strides, int n_levels, int b, int nc, int reg_max, const float* gt, const int* n_gt,
                                   int max_gt, float gain_box, float gain_cls, float gain_dfl, float grad_scale, float* loss_items,
                                   void* workspace, size_t workspace_bytes, void* stream) {
+  return upa_detection_loss_scaled(feats, grads, hs, ws, lds_, strides, n_levels, b, nc, reg_max, gt, n_gt, max_gt, gain_box, gain_cls,
+                                   gain_dfl, grad_scale, nullptr, loss_items, workspace, workspace_bytes, stream);
+}
+
+// ... with the gradients multiplied by a scale read from DEVICE memory as well (the AMP GradScaler's loss scale, engine/trainer.py:429:
+// the scale changes on the device when a step overflows - the host never reads it); the loss items are unscaled.
+extern "C" int upa_detection_loss_scaled(const float* const* feats, float* const* grads, const int* hs, const int* ws, const int* lds_,
+                                         const float* strides, int n_levels, int b, int nc, int reg_max, const float* gt, const int* n_gt,
+                                         int max_gt, float gain_box, float gain_cls, float gain_dfl, float grad_scale,
+                                         const float* grad_scale_dev, float* loss_items, void* workspace, size_t workspace_bytes,
+                                         void* stream) {
   UPA_CHECK_ARG(feats && grads && hs && ws && lds_ && strides && gt && n_gt && loss_items && workspace, "detection_loss: null pointer");
   UPA_CHECK_ARG(n_levels >= 1 && n_levels <= 3 && reg_max == REG && nc >= 1, "detection_loss: unsupported shape (levels <= 3, "
                 "reg_max 16)");
@@ -541,13 +560,13 @@ extern "C" int upa_detection_loss(const float* const* feats, float* const* grads
   if (vec4) {
     const long t4 = tot_c / 4;
     hipLaunchKernelGGL(loss_cls4_kernel, dim3((int)((t4 + 255) / 256 > 1024 ? 1024 : (t4 + 255) / 256)), dim3(256), 0, s, L, gt, asg,
-                       scal, scal + 1, gain_cls, grad_scale);
+                       scal, scal + 1, gain_cls, grad_scale, grad_scale_dev);
   } else {
     hipLaunchKernelGGL(loss_cls_kernel, dim3((int)((tot_c + 255) / 256 > 8192 ? 8192 : (tot_c + 255) / 256)), dim3(256), 0, s, L, gt, asg,
-                       scal, scal + 1, gain_cls, grad_scale);
+                       scal, scal + 1, gain_cls, grad_scale, grad_scale_dev);
   }
   hipLaunchKernelGGL(loss_grad_kernel, dim3(grid), dim3(256), 0, s, L, pbox, gt, asg, scal, scal + 1, gain_box, gain_cls, gain_dfl,
-                     grad_scale);
+                     grad_scale, grad_scale_dev);
   hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1), 0, s, scal + 1, scal, gain_box, gain_cls, gain_dfl, loss_items);
   UPA_LAUNCH_CHECK();
   return UPA_OK;

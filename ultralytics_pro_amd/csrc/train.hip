@@ -1270,22 +1270,33 @@ __global__ void sumsq_fold_kernel(const double* partial, int nblocks, double* ou
 
 // torch.nn.utils.clip_grad_norm_ + torch.optim.SGD(nesterov) + ModelEMA.update over one flat parameter segment
 // (engine/trainer.py:674-682, utils/torch_utils.py:632-646).  sumsq = squared gradient norm of ALL parameters.
+// scaler (AMP GradScaler state on the device, or nullptr): [0] = the loss scale the gradients carry, see grad_scaler_update_kernel.
+// GradScaler.unscale_ + clip + GradScaler.step (trainer.py:676-678): the norm is that of the UNSCALED gradients, the gradients are
+// divided by the scale on the way into the update, and a step whose gradients hold an inf / NaN leaves parameters and momentum alone
+// (optimizer.zero_grad() and the EMA update still happen, as in the reference's optimizer_step).
 __global__ void sgd_nesterov_ema_kernel(float* p, float* g, float* buf, float* ema, long n, const double* sumsq, float max_norm,
                                         float lr, float momentum, float wd, int first_step, float ema_d, const float* ema_d_dev,
-                                        int zero_grad) {
+                                        int zero_grad, const float* scaler) {
   if (ema_d_dev) ema_d = *ema_d_dev;  // replayed graphs read the per-step decay from device memory
-  const float total = (float)sqrt(*sumsq);
+  const double ss = *sumsq;
+  const float inv_scale = scaler ? 1.0f / scaler[0] : 1.0f;
+  const bool skip = scaler != nullptr && !isfinite(ss);
+  const float total = (float)sqrt(ss) * inv_scale;
   float coef = max_norm / (total + 1e-6f);
   if (coef > 1.0f) coef = 1.0f;
+  coef *= inv_scale;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    float gi = g[i] * coef;
     const float pi = p[i];
-    if (wd != 0.f) gi = gi + wd * pi;
-    float b = first_step ? gi : momentum * buf[i] + gi;
-    buf[i] = b;
-    gi = gi + momentum * b;
-    const float pn = pi + (-lr) * gi;
-    p[i] = pn;
+    float pn = pi;
+    if (!skip) {
+      float gi = g[i] * coef;
+      if (wd != 0.f) gi = gi + wd * pi;
+      float b = first_step ? gi : momentum * buf[i] + gi;
+      buf[i] = b;
+      gi = gi + momentum * b;
+      pn = pi + (-lr) * gi;
+      p[i] = pn;
+    }
     if (ema) {
       float e = ema[i] * ema_d;
       e = e + (1.0f - ema_d) * pn;
@@ -1293,6 +1304,18 @@ __global__ void sgd_nesterov_ema_kernel(float* p, float* g, float* buf, float* e
     }
     if (zero_grad) g[i] = 0.f;
   }
+}
+
+// GradScaler.update() (torch/amp/grad_scaler.py): state = {scale, growth tracker, found_inf of the last step}.  An overflowing step
+// multiplies the scale by backoff and clears the tracker; `interval` clean steps in a row multiply it by growth.
+__global__ void grad_scaler_update_kernel(float* state, const double* sumsq, float growth, float backoff, int interval) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const bool inf = !isfinite(*sumsq);
+  float scale = state[0];
+  int tracker = (int)state[1];
+  if (inf) { scale *= backoff; tracker = 0; }
+  else if (++tracker == interval) { scale *= growth; tracker = 0; }
+  state[0] = scale; state[1] = (float)tracker; state[2] = inf ? 1.f : 0.f;
 }
 
 __global__ void ema_only_kernel(float* ema, const float* v, long n, float d, const float* d_dev) {
@@ -1743,7 +1766,30 @@ extern "C" int upa_sgd_nesterov_ema(float* p, float* g, float* momentum_buf, flo
                                     const float* ema_d_dev, int zero_grad, void* stream) {
   UPA_CHECK_ARG(p && g && momentum_buf && grad_sumsq && n > 0, "sgd: bad args");
   hipLaunchKernelGGL(sgd_nesterov_ema_kernel, dim3(grid_for(n, 1024, 2048)), dim3(256), 0, (hipStream_t)stream, p, g, momentum_buf,
-                     ema, n, grad_sumsq, max_norm, lr, momentum, weight_decay, first_step, ema_d, ema_d_dev, zero_grad);
+                     ema, n, grad_sumsq, max_norm, lr, momentum, weight_decay, first_step, ema_d, ema_d_dev, zero_grad,
+                     (const float*)nullptr);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+// The same step under an AMP GradScaler: g holds gradients of loss * scaler_state[0]; grad_sumsq is the squared norm of those SCALED
+// gradients (inf / NaN = an overflowing step, which leaves p and the momentum buffer untouched).  scaler_state: 4 floats on the device.
+extern "C" int upa_sgd_nesterov_ema_scaled(float* p, float* g, float* momentum_buf, float* ema, long n, const double* grad_sumsq,
+                                           float max_norm, float lr, float momentum, float weight_decay, int first_step, float ema_d,
+                                           const float* ema_d_dev, int zero_grad, const float* scaler_state, void* stream) {
+  UPA_CHECK_ARG(p && g && momentum_buf && grad_sumsq && scaler_state && n > 0, "sgd_scaled: bad args");
+  hipLaunchKernelGGL(sgd_nesterov_ema_kernel, dim3(grid_for(n, 1024, 2048)), dim3(256), 0, (hipStream_t)stream, p, g, momentum_buf,
+                     ema, n, grad_sumsq, max_norm, lr, momentum, weight_decay, first_step, ema_d, ema_d_dev, zero_grad, scaler_state);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+extern "C" int upa_grad_scaler_update(float* scaler_state, const double* grad_sumsq, float growth_factor, float backoff_factor,
+                                      int growth_interval, void* stream) {
+  UPA_CHECK_ARG(scaler_state && grad_sumsq && growth_factor >= 1.f && backoff_factor > 0.f && backoff_factor <= 1.f && growth_interval > 0,
+                "grad_scaler_update: bad args");
+  hipLaunchKernelGGL(grad_scaler_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scaler_state, grad_sumsq, growth_factor,
+                     backoff_factor, growth_interval);
   UPA_LAUNCH_CHECK();
   return UPA_OK;
 }

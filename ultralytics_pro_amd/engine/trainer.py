@@ -359,16 +359,61 @@ class _Node:
         self.g_ready = False
 
 
+class GradScaler:
+    """`torch.amp.GradScaler("cuda", enabled=amp)` of the reference (engine/trainer.py:301-302; used at :429 scale(loss).backward(),
+    :676 unscale_, :678 step, :679 update, :593 / :824-825 state_dict) with its state ON THE DEVICE: {scale, growth tracker, found_inf}.
+    The loss kernels multiply their gradients by the scale (upa_detection_loss_scaled), the optimizer kernel divides it out again, clips
+    on the unscaled norm and skips an overflowing step (upa_sgd_nesterov_ema_scaled), `upa_grad_scaler_update` adjusts the scale - the
+    host never reads it, so a scaled step stays one hipGraph.  Defaults = torch's (init 2**16, growth 2, backoff 0.5, interval 2000).
+    bf16 has f32's exponent range and needs no loss scaling; the scaler exists because the reference's AMP loop has one
+    (`DetectionTrainer(..., amp_scaler=True)`)."""
+
+    def __init__(self, device, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, enabled=True):
+        self.enabled = bool(enabled)
+        self.growth_factor, self.backoff_factor, self.growth_interval = float(growth_factor), float(backoff_factor), int(growth_interval)
+        self.state = torch.tensor([float(init_scale), 0.0, 0.0, 0.0], dtype=torch.float32, device=device)
+
+    def ptr(self):
+        return self.state.data_ptr() if self.enabled else None
+
+    def update(self, sumsq, stream):
+        if self.enabled:
+            L.check(L.lib().upa_grad_scaler_update(self.state.data_ptr(), sumsq.data_ptr(), self.growth_factor, self.backoff_factor,
+                                                   self.growth_interval, stream), "grad_scaler_update")
+
+    def get_scale(self) -> float:  # (host synchronisation: logging / tests only)
+        return float(self.state[0].item()) if self.enabled else 1.0
+
+    def found_inf(self) -> bool:
+        return bool(self.state[2].item() != 0.0) if self.enabled else False
+
+    def state_dict(self):
+        if not self.enabled:
+            return {}
+        st = self.state.cpu()
+        return {"scale": float(st[0]), "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
+                "growth_interval": self.growth_interval, "_growth_tracker": int(st[1])}
+
+    def load_state_dict(self, sd):
+        if not self.enabled or not sd:
+            return
+        self.growth_factor, self.backoff_factor = float(sd["growth_factor"]), float(sd["backoff_factor"])
+        self.growth_interval = int(sd["growth_interval"])
+        self.state.copy_(torch.tensor([float(sd["scale"]), float(sd["_growth_tracker"]), 0.0, 0.0]))
+
+
 class DetectionTrainer:
     """One-process-per-GPU trainer for a DetectionModel (reference: engine/trainer.py BaseTrainer._do_train inner loop)."""
 
-    def __init__(self, model, dtype=torch.bfloat16, hyp=None, device=None, world_size=1, ema=True, wgrad_streams: int = 1):
+    def __init__(self, model, dtype=torch.bfloat16, hyp=None, device=None, world_size=1, ema=True, wgrad_streams: int = 1,
+                 amp_scaler: bool = False):
         self.model = model
         self.hyp = dict(HYP, **(hyp or {}))
         self.device = torch.device(device or "cuda:0")
         self.dtype = dtype
         self.world_size = world_size
         self.ctx = _Ctx(self.device, dtype, wgrad_streams)
+        self.scaler = GradScaler(self.device, enabled=amp_scaler)  # trainer.py:301-302
         self.pool = R.BufferPool()
         self.updates = 0
         self.first_step = True
@@ -736,12 +781,20 @@ class DetectionTrainer:
             if wd and weight_decay is not None:
                 wd = weight_decay
             o = 4 * start
+            if self.scaler.enabled:  # unscale_ + clip + scaler.step in the same kernel (the momentum buffers start at zero, so the
+                # first-step form b = g equals momentum * 0 + g: a skipped first step needs no special case)
+                L.check(lib.upa_sgd_nesterov_ema_scaled(self.P.data_ptr() + o, self.G.data_ptr() + o, self.M.data_ptr() + o,
+                                                        (self.E.data_ptr() + o) if self.E is not None else None, n,
+                                                        self.sumsq.data_ptr(), h["max_norm"], lrs[gi], mom, wd, 0, d, dp, 1,
+                                                        self.scaler.ptr(), st), "sgd_scaled")
+                continue
             L.check(lib.upa_sgd_nesterov_ema(self.P.data_ptr() + o, self.G.data_ptr() + o, self.M.data_ptr() + o,
                                              (self.E.data_ptr() + o) if self.E is not None else None, n,
                                              self.sumsq.data_ptr(), h["max_norm"], lrs[gi], mom, wd,
                                              int(self.first_step), d, dp, 1, st), "sgd")
         if self.ERB is not None and self.nbuf:
             L.check(lib.upa_ema_update(self.ERB.data_ptr(), self.RB.data_ptr(), self.nbuf, d, dp, st), "ema_buffers")
+        self.scaler.update(self.sumsq, st)  # trainer.py:679
         self.first_step = False
         # parameters and BN buffers were just rewritten through raw pointers: no `_version` moved, so every packed-weight
         # cache of the inference path (Conv / Detect / C2f) is told explicitly
@@ -857,7 +910,8 @@ class DetectionTrainer:
         self.ngt_d.copy_(ngt, non_blocking=True)
 
     def grad_norm(self) -> float:
-        return float(torch.sqrt(self.grad_sumsq())[0])
+        """Norm of the (unscaled) gradients in the flat buffer."""
+        return float(torch.sqrt(self.grad_sumsq())[0]) / self.scaler.get_scale()
 
     def ema_state_dict(self):
         """The EMA weights under the reference's state_dict keys (for validation / checkpoints)."""
@@ -949,11 +1003,11 @@ class DetectT(_Seq):
         nbytes = lib.upa_detection_loss_workspace_bytes(batch_size, A, max_gt)
         wsb = tr.pool.get(("loss_ws", batch_size, A, max_gt), (nbytes,), torch.uint8, dev)
         items = tr.pool.get(("loss_items",), (3,), torch.float32, dev)
-        L.check(lib.upa_detection_loss(C.cast(feats, C.c_void_p), C.cast(grads, C.c_void_p), C.cast(hs, C.c_void_p),
-                                       C.cast(ws, C.c_void_p), C.cast(lds, C.c_void_p), C.cast(strides, C.c_void_p), nl,
-                                       batch_size, self.nc, self.reg_max, gt_d.data_ptr(), ngt_d.data_ptr(), max_gt, h["box"],
-                                       h["cls"], h["dfl"], 1.0, items.data_ptr(), wsb.data_ptr(), nbytes,
-                                       _s(dev)), "detection_loss")
+        L.check(lib.upa_detection_loss_scaled(C.cast(feats, C.c_void_p), C.cast(grads, C.c_void_p), C.cast(hs, C.c_void_p),
+                                              C.cast(ws, C.c_void_p), C.cast(lds, C.c_void_p), C.cast(strides, C.c_void_p), nl,
+                                              batch_size, self.nc, self.reg_max, gt_d.data_ptr(), ngt_d.data_ptr(), max_gt,
+                                              h["box"], h["cls"], h["dfl"], 1.0, tr.scaler.ptr(), items.data_ptr(), wsb.data_ptr(),
+                                              nbytes, _s(dev)), "detection_loss")
         nb = 4 * self.reg_max
         for i in range(nl):
             g32 = grads32[i]
