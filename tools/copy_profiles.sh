@@ -22,6 +22,6 @@ cpf $O/pmc_hbm_summary.json pmc_hbm_summary.json
 cpf $O/pmc_wgrad_summary.json pmc_wgrad_summary.json
 cpf $O/pmc_step_summary.txt pmc_step_budget.txt
 for k in default serial train; do
-  f=$(find $O/prof_$k -name "*kernel_stats.csv" 2>/dev/null | head -1)
+  f=$(ls -t $(find $O/prof_$k -name "*kernel_stats.csv" 2>/dev/null) 2>/dev/null | head -1)   # the newest: gpurun merges a call's files into the directory, traces of earlier calls stay
   [ -n "$f" ] && cpf "$f" bench_${k}_kernel_stats.csv
 done

@@ -300,7 +300,6 @@ __global__ __launch_bounds__(GREEDY_NT) void nms_greedy_kernel(const float* pred
   if (only_redo && !only_redo[blockIdx.x]) return;
   __shared__ float kx1[MAX_DET_CAP], ky1[MAX_DET_CAP], kx2[MAX_DET_CAP], ky2[MAX_DET_CAP], kar[MAX_DET_CAP];
   __shared__ u64 alive_w[GREEDY_NW];
-  __shared__ u64 smat[64];  // the current chunk's suppression matrix: bit j of smat[i] = candidate i suppresses candidate j
   __shared__ int s_kept;
   const int b = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -354,37 +353,23 @@ __global__ __launch_bounds__(GREEDY_NT) void nms_greedy_kernel(const float* pred
         x1 = rx1 + off; y1 = ry1 + off; x2 = rx2 + off; y2 = ry2 + off;
         area = (x2 - x1) * (y2 - y1);
       }
-      // phase 1: this wave tests the chunk against its slice of the kept list ...
+      // phase 1: this wave tests the chunk against its slice of the kept list
       bool sup = false;
       for (int k = wave; k < kept; k += GREEDY_NW)
         sup |= iou_gt(kx1[k], ky1[k], kx2[k], ky2[k], kar[k], x1, y1, x2, y2, area, iou_thr);
       const u64 am = __ballot(valid && !sup);
       if (lane == 0) alive_w[wave] = am;
-      // ... and computes its eight rows of the chunk's own suppression matrix: row i = the lanes whose box candidate i of the chunk
-      // suppresses (same operands in the same order as the serial form had: box i first).  All 64 rows cost each wave eight broadcasts
-      // + IoUs side by side; the serial resolution below then only combines bit masks.
-      const int wv = __builtin_amdgcn_readfirstlane(wave);
-      for (int t = 0; t < 64 / GREEDY_NW; ++t) {
-        const int i = wv + GREEDY_NW * t;  // wave-uniform
-        if (base + i >= stage_n) break;
-        const float ix1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x1), i));
-        const float iy1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(y1), i));
-        const float ix2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x2), i));
-        const float iy2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(y2), i));
-        const float iar = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(area), i));
-        const u64 row = __ballot(valid && iou_gt(ix1, iy1, ix2, iy2, iar, x1, y1, x2, y2, area, iou_thr));
-        if (lane == 0) smat[i] = row;
-      }
       __syncthreads();
       if (wave == 0) {
         u64 alive = alive_w[0];
 #pragma unroll
         for (int q = 1; q < GREEDY_NW; ++q) alive &= alive_w[q];
-        // phase 2: resolve the chunk greedily over the SET bits only: take the lowest alive lane, keep it, drop every later alive lane
-        // its matrix row names.  Iterations = boxes kept from this chunk (usually a handful); the mask and the kept count are
-        // wave-uniform (scalar registers), lane j holds row j and the row of the kept lane arrives by two v_readlane_b32.
-        const u64 myrow = valid ? smat[lane] : 0ull;
-        const unsigned rlo = (unsigned)myrow, rhi = (unsigned)(myrow >> 32);
+        // phase 2: resolve the chunk greedily over the SET bits only: take the lowest alive lane, keep it, broadcast its
+        // box, drop every later alive lane it suppresses.  Iterations = boxes kept from this chunk (usually a handful),
+        // not 64 + 64 as a full suppression matrix + scan would cost.  The mask and the kept count are wave-uniform: held in scalar
+        // registers (readfirstlane), so the lane index of the kept box is scalar too and its five values are broadcast by
+        // v_readlane_b32 - a few cycles each - instead of five ds_bpermute round trips (~600 cycles per kept box, most of this kernel's
+        // time: 55 -> see DESIGN.md).
         u64 rem = ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(alive >> 32)) << 32) |
                   (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)alive);  // (the builtin returns int: no sign extension)
         u64 keepmask = 0ull;
@@ -396,8 +381,13 @@ __global__ __launch_bounds__(GREEDY_NT) void nms_greedy_kernel(const float* pred
           rem &= rem - 1ull;
           ++nkeep;
           if (kept_s + nkeep >= max_det) break;
-          const u64 ri = ((u64)(unsigned)__builtin_amdgcn_readlane((int)rhi, i) << 32) | (u64)(unsigned)__builtin_amdgcn_readlane((int)rlo, i);
-          rem &= ~ri;
+          const float ix1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x1), i));
+          const float iy1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(y1), i));
+          const float ix2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x2), i));
+          const float iy2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(y2), i));
+          const float iar = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(area), i));
+          const bool sup2 = ((rem >> lane) & 1ull) && iou_gt(ix1, iy1, ix2, iy2, iar, x1, y1, x2, y2, area, iou_thr);
+          rem &= ~__ballot(sup2);
         }
         if ((keepmask >> lane) & 1ull) {
           const int idx = kept + __popcll(keepmask & ((1ull << lane) - 1ull));
