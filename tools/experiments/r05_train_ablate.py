@@ -68,6 +68,16 @@ def main():
     for name, skip in cases:
         ms, iss = run(skip)
         print(f"{name:45s} {ms:7.3f} ms/step   (host issue {iss:6.3f} ms/step)", flush=True)
+    # A/B: the step issued on a HIGH-priority stream (the weight-gradient side stream keeps normal priority)
+    hi = torch.cuda.Stream(device=dev, priority=-1)
+    for rep in range(3):
+        ms, iss = run(())
+        print(f"main stream: default priority                 {ms:7.3f} ms/step   (host issue {iss:6.3f})", flush=True)
+        hi.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(hi):
+            ms, iss = run(())
+        torch.cuda.current_stream(dev).wait_stream(hi)
+        print(f"main stream: high priority                    {ms:7.3f} ms/step   (host issue {iss:6.3f})", flush=True)
     # A/B: batch statistics from the convolution's epilogue (default) vs a reduction pass over z (upa_opts.no_epi_stats = 1)
     from ultralytics_pro_amd.engine import runtime as R
     for rep in range(3):
