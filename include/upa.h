@@ -67,6 +67,7 @@ typedef struct upa_opts {
   int32_t conv_p8;         /* csrc/conv_p8.hip (8-wave two-group phased 3x3 stride-1 kernel for Cin % 64 == 0, Cout % 128 == 0: counted vmcnt, 4-slab weight ring, double-buffered halo) inside upa_conv2d_bias_act: 0 = by the size rule, 1 = never, 2 = every shape it can run */
   int32_t c2f_stream;      /* csrc/c2f_stream.hip (line-buffer form of the C2f(64, 64, n = 2) block: fixed wave roles, LDS ring buffers) inside upa_c2f_fused: 0 = where it applies, 1 = never (the 16 x 16 tile form), 2 = the n = 2 block on its first wave-role set (A/B) */
   int32_t c2f_stream_rows; /* its output rows per workgroup: 0 = auto (one round of workgroups where possible) | even >= 4 | -1 = the whole image height (fewest pipeline fills: least total CU time, for several steps in flight) */
+  int32_t no_stack_first;  /* Detect (host side, nn/modules/head.py): 1 = the two first convs of the 80 x 80 level stay two problems of one grid instead of one stacked 144-channel convolution; A/B */
   int32_t no_epi_stats;    /* upa_conv2d_bn_stats: 1 = the batch statistics always by a reduction pass over z (upa_bn_stats), never from the convolution's own workgroups; A/B */
 } upa_opts;
 

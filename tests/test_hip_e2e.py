@@ -627,27 +627,38 @@ def test_e2e_grouped_detect_levels_equal_level_by_level(name):
     """`Detect.group_levels` (the head's levels through `upa_conv2d_bias_act_group` / `upa_detect_branch_tail_group` when its branches
     run on one stream, as in the linear graphs of the throughput runner): the decoded output is bit-identical to the level-by-level
     walk, for every Detect config - including heads whose class branch is outside the branch-tail form (yolov8s: c3 = 128 goes
-    level by level inside the grouped walk) and two-level heads (yolov3-tiny)."""
+    level by level inside the grouped walk) and two-level heads (yolov3-tiny).  Round 5: the grouped walk also STACKS the two first convs
+    of the first level into one 64 + 80 = 144-channel convolution (`Detect.stack_first`) - still bit-identical per output channel."""
     from tests.hip_utils import DEV
     m = _build(name, torch.bfloat16)
     det = m.model[-1]
     det.keep_raw = False
     x = P.synthetic_images(4).to(DEV).to(torch.bfloat16).contiguous()
+    from ultralytics_pro_amd import _lib as L
+    from ultralytics_pro_amd.engine import runtime as R
     saved = det.concurrent
+    res = {}
     try:
         with torch.no_grad():
-            det.concurrent = False  # one stream: the grouped walk
-            det.group_levels = True
-            y_grouped = m(x)[0].clone()
-            det.group_levels = False
-            y_levels = m(x)[0].clone()
-            det.concurrent = True   # forked branches (the default eager walk)
-            y_forked = m(x)[0].clone()
+            # (a) library defaults, the first level's first convs as two problems: grouping alone must not change a bit
+            # (b) the persistent 3x3 kernel off (as in the throughput runner; its accumulation order differs from conv_big's in the last
+            #     bit, and the stacked 144-channel first conv of the 80 x 80 level runs on conv_big): grouping + stacking vs level by level
+            for tag, kw in (("a", {"no_stack_first": 1}), ("b", {"conv_ws3": 1})):
+                with R.use_opts(L.Opts(**kw)):
+                    det.concurrent = False  # one stream: the grouped walk
+                    det.group_levels = True
+                    y_grouped = m(x)[0].clone()
+                    det.group_levels = False
+                    y_levels = m(x)[0].clone()
+                    det.concurrent = True   # forked branches (the default eager walk)
+                    y_forked = m(x)[0].clone()
+                res[tag] = (y_grouped, y_levels, y_forked)
     finally:
         det.concurrent = saved
         det.group_levels = True
     torch.cuda.synchronize()
-    assert torch.equal(y_grouped, y_levels) and torch.equal(y_grouped, y_forked)
+    for tag, (y_grouped, y_levels, y_forked) in res.items():
+        assert torch.equal(y_grouped, y_levels) and torch.equal(y_grouped, y_forked), tag
 
 
 

@@ -37,7 +37,7 @@ class Opts(C.Structure):
                 ("c2f", _i), ("c2f16_waves", _i), ("c2f32_th", _i),
                 ("no_branch_tail", _i), ("branch_tail_bm", _i),
                 ("stem_wgs", _i), ("stemf_wgs", _i), ("stemf_waves", _i), ("stem_no_mfma", _i),
-                ("ablate_conv", _i), ("ablate_pipe", _i), ("ablate_c1", _i), ("ablate_stem", _i), ("c2f64_max_px", _i), ("conv_ws3", _i), ("no_group", _i), ("no_c2f32_up", _i), ("conv_mm", _i), ("no_xcd", _i), ("keys_only", _i), ("conv_p8", _i), ("c2f_stream", _i), ("c2f_stream_rows", _i), ("no_epi_stats", _i)]
+                ("ablate_conv", _i), ("ablate_pipe", _i), ("ablate_c1", _i), ("ablate_stem", _i), ("c2f64_max_px", _i), ("conv_ws3", _i), ("no_group", _i), ("no_c2f32_up", _i), ("conv_mm", _i), ("no_xcd", _i), ("keys_only", _i), ("conv_p8", _i), ("c2f_stream", _i), ("c2f_stream_rows", _i), ("no_stack_first", _i), ("no_epi_stats", _i)]
 
     def __init__(self, **kw):
         super().__init__()

@@ -177,17 +177,42 @@ __device__ __forceinline__ void conv_big_body(const BigParams& p, const int bid0
         if constexpr (TAIL == 2) {
           if (kt == 1 && c * 2 + 1 >= p.KTT) break;
         }
-        u32x4 a[NT], b[MT];
+        if constexpr (NT <= 6) {
+          u32x4 a[NT], b[MT];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) a[j] = *reinterpret_cast<const u32x4*>(wb + (kt * NTB + j) * 1024);
+          for (int j = 0; j < NT; ++j) a[j] = *reinterpret_cast<const u32x4*>(wb + (kt * NTB + j) * 1024);
 #pragma unroll
-        for (int i = 0; i < MT; ++i) b[i] = *reinterpret_cast<const u32x4*>(hal + paddr[i] + (((kt * 4 + g) ^ pswz[i]) << 4));
+          for (int i = 0; i < MT; ++i) b[i] = *reinterpret_cast<const u32x4*>(hal + paddr[i] + (((kt * 4 + g) ^ pswz[i]) << 4));
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+          for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a[j]),
-                                                                *reinterpret_cast<const bf16x8*>(&b[i]), acc[i][j], 0, 0, 0);
+            for (int j = 0; j < NT; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a[j]),
+                                                                  *reinterpret_cast<const bf16x8*>(&b[i]), acc[i][j], 0, 0, 0);
+        } else {
+          // nine n-tiles (the stacked first convs of a Detect level): the weight fragments in two groups, so that 2 x 9 accumulator
+          // tiles + one group of fragments stay inside 128 registers (two workgroups per CU); every accumulator still sees its products
+          // in the same order
+          constexpr int GS = (NT + 1) / 2;
+          u32x4 b[MT];
+#pragma unroll
+          for (int i = 0; i < MT; ++i) b[i] = *reinterpret_cast<const u32x4*>(hal + paddr[i] + (((kt * 4 + g) ^ pswz[i]) << 4));
+#pragma unroll
+          for (int j0 = 0; j0 < NT; j0 += GS) {
+            u32x4 a[GS];
+#pragma unroll
+            for (int j = 0; j < GS; ++j)
+              if (j0 + j < NT) a[j] = *reinterpret_cast<const u32x4*>(wb + (kt * NTB + j0 + j) * 1024);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+              for (int j = 0; j < GS; ++j)
+                if (j0 + j < NT)
+                  acc[i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a[j]),
+                                                                           *reinterpret_cast<const bf16x8*>(&b[i]), acc[i][j0 + j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);  // keep the second group's loads behind the first group's products (register budget)
+          }
+        }
       }
       buf ^= 1;
       if (++kw == KS) { kw = 0; ++kh; }
@@ -361,11 +386,16 @@ __device__ __forceinline__ void conv_big_body(const BigParams& p, const int bid0
   // ---- epilogue from the accumulators (as conv.hip): lane (g, r) holds channels 16j + 4g .. + 3 of pixel r of m-tile i;
   // v_permlane16_swap pairs the quads of two neighbouring n-tiles so every lane stores 16 contiguous bytes
   const int cw = (blockIdx.y * NTB + wn * NT) * 16;  // first channel of this wave
-  f32x4 biasv[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
+  // (nine n-tiles: the bias quads are fetched where they are used - 36 more live registers would spill)
+  constexpr bool LAZY_BIAS = NT > 6;
+  auto bias_of = [&](int j) __attribute__((always_inline)) {
     const int co = cw + j * 16 + g * 4;
-    biasv[j] = (p.bias && co < p.Cout) ? *reinterpret_cast<const f32x4*>(p.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+    return (p.bias && co < p.Cout) ? *reinterpret_cast<const f32x4*>(p.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  f32x4 biasv[LAZY_BIAS ? 1 : NT];
+  if constexpr (!LAZY_BIAS) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) biasv[j] = bias_of(j);
   }
   auto epilogue = [&](auto act_tag) __attribute__((always_inline)) {
     constexpr int ACT = decltype(act_tag)::value;
@@ -379,11 +409,12 @@ __device__ __forceinline__ void conv_big_body(const BigParams& p, const int bid0
 #pragma unroll
       for (int j = 0; j + 1 < NT; j += 2) {
         const int cb = 16 * (j + (g & 1)) + 8 * (g >> 1);
+        const f32x4 bj0 = LAZY_BIAS ? bias_of(j) : biasv[LAZY_BIAS ? 0 : j], bj1 = LAZY_BIAS ? bias_of(j + 1) : biasv[LAZY_BIAS ? 0 : j + 1];
         float v0[4], v1[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          v0[q] = big_act<ACT>(acc[i][j][q] + biasv[j][q]);
-          v1[q] = big_act<ACT>(acc[i][j + 1][q] + biasv[j + 1][q]);
+          v0[q] = big_act<ACT>(acc[i][j][q] + bj0[q]);
+          v1[q] = big_act<ACT>(acc[i][j + 1][q] + bj1[q]);
         }
         const bool ok = pok && cw + cb < p.Cout;
         if (p.res) {
@@ -414,8 +445,9 @@ __device__ __forceinline__ void conv_big_body(const BigParams& p, const int bid0
         constexpr int j = NT - 1;
         const int cb = 16 * j + 4 * g;
         float v[4];
+        const f32x4 bj = LAZY_BIAS ? bias_of(j) : biasv[LAZY_BIAS ? 0 : j];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = big_act<ACT>(acc[i][j][q] + biasv[j][q]);
+        for (int q = 0; q < 4; ++q) v[q] = big_act<ACT>(acc[i][j][q] + bj[q]);
         if (pok && cw + cb < p.Cout) {
           if (p.res) {
             const u32x2 rv = *reinterpret_cast<const u32x2*>(rrow + cb * 2);
@@ -869,6 +901,7 @@ bool upa_conv_big_eligible(int n, int h, int w, int cin, int ldx, int cout, int 
   if (cout % 128 == 0) return cin >= 128 || (px >= 8192 && (stride == 2 || px >= 200 * 1024));
   if (px < 8192) return false;
   if (cout == 80 || cout == 96) return stride == 1 && k == 3;
+  if (cout == 144) return stride == 1 && k == 3;  // the two first convs of a Detect level stacked (64 box + 80 class channels, head.py)
   if (cout == 64) return stride == 1;
   return false;
 }
@@ -882,6 +915,7 @@ int big_prepare(BigParams& p, int& ntb, int& bm, size_t& lds, const upa_opts* op
   // 128-channel workgroups would still be fewer than the CUs (20x20 maps: twice the workgroups, each with half the weights)
   ntb = p.NTn <= 4 ? 4 : (p.NTn <= 6 ? 6 : 8);
   if (p.NTn == 5 && p.KS == 3 && p.stride == 1) ntb = 5;  // 80 output channels (Detect class branch): 8 x 1 waves x 5 tiles
+  if (p.NTn == 9 && p.KS == 3 && p.stride == 1) ntb = 9;  // 144 = 64 + 80: both first convs of a Detect level, one halo, nine tiles
   if (force_ntb == 5 && p.NTn <= 5 && p.KS == 3 && p.stride == 1) ntb = 5;  // a 64-channel problem sharing a grid with an 80-channel one
   const long px = (long)p.N * p.OH * p.OW;
   if (ntb == 8 && p.NTn % 4 == 0 && (px + 127) / 128 * cdiv(p.NTn, 8) < big_num_cu()) ntb = 4;
@@ -922,6 +956,7 @@ int big_dispatch_stats(const BigParams& p, int ntb, int bm, size_t lds, hipStrea
 int big_dispatch(const BigParams& p, int ntb, int bm, size_t lds, hipStream_t s) {
   if (bm == 512) return ntb == 5 ? big_launch_inst<3, 1, 8, 1, 4, 5>(p, lds, s) : big_launch_inst<3, 1, 8, 1, 4, 4>(p, lds, s);
   if (ntb == 5) return bm == 256 ? big_launch_inst<3, 1, 8, 1, 2, 5>(p, lds, s) : big_launch_inst<3, 1, 8, 1, 1, 5>(p, lds, s);
+  if (ntb == 9) return bm == 256 ? big_launch_inst<3, 1, 8, 1, 2, 9>(p, lds, s) : big_launch_inst<3, 1, 8, 1, 1, 9>(p, lds, s);
   if (ntb == 8) return bm == 256 ? big_launch_ks<4, 2, 4, 4>(p, lds, s) : big_launch_ks<4, 2, 2, 4>(p, lds, s);
   if (ntb == 6) return bm == 256 ? big_launch_ks<4, 2, 4, 3>(p, lds, s) : big_launch_ks<4, 2, 2, 3>(p, lds, s);
   return bm == 256 ? big_launch_ks<8, 1, 2, 4>(p, lds, s) : big_launch_ks<4, 2, 2, 2>(p, lds, s);

@@ -166,6 +166,7 @@ class Detect(nn.Module, _HipConvMixin):
     # instantiation into ONE grid, so the smaller level rides inside the larger one's partial round: 4 launches fewer per step.  (All
     # three levels in one grid - the 80 x 80 level on the 128-pixel variant - measured slower: upa_opts.no_group = 2.)
     group_levels = True
+    stack_first = True  # the first level's two first convs as one 144-channel convolution (see _levels_grouped)
 
     def _levels_grouped(self, idx, xs, plan) -> bool:
         """Both branches of the levels `idx` (inputs `xs`, NHWC) through the group entry points; False (nothing launched) when a
@@ -184,17 +185,37 @@ class Detect(nn.Module, _HipConvMixin):
             todo.append((kind, seqs))
         # stage 1: the first convs of all branches in ONE group call.  Order = which neighbours may share a grid: the two branches of
         # the first (largest) level read the same input and use the same workgroup size, then each kind's remaining levels
-        order = [(kind, seqs, idx[0]) for kind, seqs in todo] + [(kind, seqs, i) for kind, seqs in todo for i in idx[1:]]
+        # The two first convs of the first (largest) level read the same input: stacked along the output channels they are ONE 64 + 80 =
+        # 144-channel convolution (conv_big's nine-tile variant) - the halo of a tile is fetched once instead of once per branch, the box
+        # branch multiplies no padded fifth tile, half the workgroups - and each branch's second half reads its channel slice of the
+        # 144-channel tensor.  Same products in the same order per output channel: bit-identical.  Measured (yolov8n bs 32, round 5, same
+        # box, upa_opts.no_stack_first = 1 | 0): the stacked launch takes what the two-problem grid took (65.9 vs 66.1 us with four steps
+        # in flight, 58.46 k images/s either way; the serial step 0.810 -> 0.808 ms): the first convs are bound by their per-tap matrix /
+        # LDS work, not by the second halo fetch.  Kept: one launch and one tensor fewer, never slower.
+        o_ = R.current_opts()
+        i0 = idx[0]
+        b0, c0_ = self.cv2[i0][0], self.cv3[i0][0]
+        stacked = (self.stack_first and (o_ is None or not o_.no_stack_first) and xs[0].dtype == torch.bfloat16
+                   and b0.conv.out_channels == 64 and c0_.conv.out_channels == 80 and b0.conv.in_channels == c0_.conv.in_channels
+                   and b0.conv.in_channels >= 64)
+        order = ([("stack", None, i0)] if stacked else [(kind, seqs, i0) for kind, seqs in todo]) + \
+                [(kind, seqs, i) for kind, seqs in todo for i in idx[1:]]
         probs = (L.ConvProblem * len(order))()
         mid_of = {}
         for j, (kind, seqs, i) in enumerate(order):
-            c0, x = seqs[i][0], xs[idx.index(i)]
-            pk = c0._packed(c0.conv, c0.bn, dev, x.dtype, False)
+            x = xs[idx.index(i)]
             vx = R.view_of(x)
-            t = R.alloc_nhwc(vx.n, pk.cout, vx.h, vx.w, x.dtype, dev, key=(id(c0), "y"))
+            if kind == "stack":
+                pk = self._packed_stack([(b0.conv, b0.bn), (c0_.conv, c0_.bn)], dev, x.dtype)
+                t = R.alloc_nhwc(vx.n, pk.cout, vx.h, vx.w, x.dtype, dev, key=(id(b0), "y144"))
+                mid_of[(1, i)], mid_of[(2, i)] = t[:, :64], t[:, 64:]
+            else:
+                c0 = seqs[i][0]
+                pk = c0._packed(c0.conv, c0.bn, dev, x.dtype, False)
+                t = R.alloc_nhwc(vx.n, pk.cout, vx.h, vx.w, x.dtype, dev, key=(id(c0), "y"))
+                mid_of[(kind, i)] = t
             vy = R.view_of(t)
             probs[j] = L.ConvProblem(vx.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, pk.w.data_ptr(), pk.bias.data_ptr(), vy.ptr, pk.cout, vy.ld, None, 0)
-            mid_of[(kind, i)] = t
         L.check(lib.upa_conv2d_bias_act_group(C.cast(probs, C.c_void_p), len(order), 3, 1, 1, L.ACT_SILU, L.dtype_code(xs[0].dtype),
                                               R.opts_ptr(), stream), "conv2d_group")
         # stage 2: the branch tails of both kinds in one call (box and class problems share grids where their workgroup sizes agree)
