@@ -744,6 +744,9 @@ def main_train(args):
                                        f"(first layers {[b[0] for b in buckets]})" if buckets and mode == "eager launches"
                                        else "one collective between the backward and optimizer graphs")),
                        "optimizer": "SGD(lr 0.01, momentum 0.9, nesterov, wd 5e-4) + clip 10.0 + EMA",
+                       "batchnorm_statistics": "from the convolutions' own workgroups where the kernel has a statistics epilogue "
+                                               "(upa_conv2d_bn_stats: conv_big / conv1x1_stream / conv_ws3), a reduction pass elsewhere",
+                       "grad_scaler": bool(tr.scaler.enabled),
                        "execution": mode, "tuning_ms_per_step": {"eager": round(t_eager * 1e3, 3), "graph": round(t_graph * 1e3, 3)}},
             "images_per_sec_per_gpu": round(value / world, 1),
             "loss_items": [round(float(v), 4) for v in items.tolist()],
