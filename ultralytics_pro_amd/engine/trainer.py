@@ -555,6 +555,12 @@ class DetectionTrainer:
         ctx, dev = self.ctx, self.device
         L.require_gpu(img, "train")
         self.model.train()
+        if labels is not None:
+            # the labels go up BEFORE the forward launches (stream-ordered behind the previous step's loss kernels): packing them on the
+            # host overlaps the GPU's work on the previous step instead of standing between this step's forward and its loss
+            self._imgsz = (int(img.shape[2]), int(img.shape[3]))
+            self._upload_labels(labels, int(img.shape[0]))
+            labels = None
         with R.static_buffers(self.pool):
             self._pack_weights()
             x = self._input_nhwc(img.float().contiguous() if img.dtype != torch.float32 else img.contiguous())
@@ -906,8 +912,24 @@ class DetectionTrainer:
             self.max_gt = max(self.max_gt, need)
             self.gt_d = torch.zeros(batch_size, self.max_gt, 5, dtype=torch.float32, device=self.device)
             self.ngt_d = torch.zeros(batch_size, dtype=torch.int32, device=self.device)
-        self.gt_d[:, :need].copy_(gt, non_blocking=True)
-        self.ngt_d.copy_(ngt, non_blocking=True)
+        # through PINNED staging buffers (a ring of four, each guarded by the event of its last copy): a copy from pageable memory makes the
+        # host wait for the stream, and the step's launches then trail the GPU by the time `pack_targets` + the copy took (0.45 ms of idle
+        # GPU per yolov8s step in the kernel trace, tools/experiments/r05_train_gaps.py)
+        rows = int(self.gt_d.shape[1])
+        ring = self.__dict__.setdefault("_label_ring", [None] * 4)
+        self._label_slot = (self.__dict__.get("_label_slot", -1) + 1) % len(ring)
+        ent = ring[self._label_slot]
+        if ent is None or ent[0].shape != (batch_size, rows, 5):
+            ent = [torch.zeros(batch_size, rows, 5, dtype=torch.float32).pin_memory(), torch.zeros(batch_size, dtype=torch.int32).pin_memory(), None]
+            ring[self._label_slot] = ent
+        if ent[2] is not None:
+            ent[2].synchronize()
+        ent[0][:, :need].copy_(gt)
+        ent[1].copy_(ngt)
+        self.gt_d.copy_(ent[0], non_blocking=True)  # (rows past an image's count are never read: n_gt bounds them)
+        self.ngt_d.copy_(ent[1], non_blocking=True)
+        ent[2] = torch.cuda.Event()
+        ent[2].record(torch.cuda.current_stream(self.device))
 
     def grad_norm(self) -> float:
         """Norm of the (unscaled) gradients in the flat buffer."""
