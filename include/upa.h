@@ -417,6 +417,11 @@ int upa_bn_finalize(const double* ws, long npix, int c, float momentum, float* m
 int upa_conv2d_bn_stats(const void* x, int n, int h, int w, int cin, int ldx, const void* w_packed, void* z, int cout, int ldz, int k,
                         int stride, int pad, float momentum, float* mean, float* var, float* running_mean, float* running_var,
                         double* ws, int dtype, const upa_opts* opts, void* stream);
+/* ... followed by upa_bn_act_fwd (below) in the same call: the whole training forward of a Conv, one call per layer. */
+int upa_conv2d_bn_act_fwd(const void* x, int n, int h, int w, int cin, int ldx, const void* w_packed, void* z, int cout, int ldz, int k,
+                          int stride, int pad, float momentum, float* mean, float* var, float* running_mean, float* running_var,
+                          const float* gamma, const float* beta, float eps, int act, void* y, int ldy, const void* residual, int ldr,
+                          double* ws, int dtype, const upa_opts* opts, void* stream);
 /* y = act(gamma * (z - mean) / sqrt(var + eps) + beta) (+ residual) */
 int upa_bn_act_fwd(const void* z, long npix, int c, int ldz, const float* mean, const float* var, const float* gamma,
                    const float* beta, float eps, int act, void* y, int ldy, const void* residual, int ldr, int dtype,
@@ -426,6 +431,15 @@ int upa_bn_act_fwd(const void* z, long npix, int c, int ldz, const float* mean, 
 int upa_bn_act_bwd(const void* z, const void* dy, long npix, int c, int ldz, int lddy, const float* mean, const float* var,
                    const float* gamma, const float* beta, float eps, int act, void* dz, int lddz, float* dgamma, float* dbeta,
                    int accumulate, double* ws, int dtype, void* stream);
+/* The whole backward of a training-mode Conv with stride 1 in one call: upa_bn_act_bwd (dgamma / dbeta accumulated, dz written), the
+ * weight gradient (accumulated into dw_oihw; on side_stream if not NULL, ordered behind dz by an event), and - unless w_packed_t is NULL -
+ * the data gradient dx (+)= conv(dz, w_packed_t) with w_packed_t = the transposed + flipped packing (upa_pack_conv_weight_dev,
+ * transpose_flip 1).  x: the layer's input view (n, h, w, cin); z / dy / dz: output-side views (n, oh, ow, cout). */
+int upa_conv_bn_act_bwd(const void* x, int n, int h, int w, int cin, int ldx, const void* z, const void* dy, int cout, int ldz, int lddy,
+                        const float* mean, const float* var, const float* gamma, const float* beta, float eps, int act, void* dz,
+                        int lddz, float* dgamma, float* dbeta, double* ws, float* dw_oihw, void* wgrad_ws, size_t wgrad_ws_bytes,
+                        void* side_stream, const void* w_packed_t, void* dx, int lddx, int accumulate_dx, int k, int pad, int dtype,
+                        const upa_opts* opts, void* stream);
 /* out[c] (+)= sum over rows of z[:, c]  (bias gradient of the plain nn.Conv2d head outputs). ws as above. */
 int upa_channel_sum(const void* z, long npix, int c, int ldz, float* out, int accumulate, double* ws, int dtype, void* stream);
 /* dW[co][ci][kh][kw] (OIHW f32, optionally accumulated) = sum_{n,oy,ox} dz[n,oy,ox,co] * x[n,oy*s+kh-p,ox*s+kw-p,ci]

@@ -86,6 +86,7 @@ def test_conv_bn_silu_forward_backward(case, dtype):
     assert _rel(dbn.bias.grad.cpu(), bn.bias.grad) <= tol
     # accumulate: a second backward doubles the parameter gradients and adds into dx
     op.backward(to_dev_nhwc(dy, dtype), dx, True)
+    torch.cuda.synchronize()  # the weight gradient runs on the trainer context's side stream (the trainer joins it before the optimizer)
     assert _rel(dconv.weight.grad.cpu(), 2 * conv.weight.grad) <= tol
     assert _rel(to_cpu_nchw(dx), 2 * xr.grad) <= tol
 

@@ -173,9 +173,13 @@ PROTOTYPES = {
     "upa_channel_reduce_workspace_bytes": (_sz, [_i]),
     "upa_bn_stats": (_i, [_vp, C.c_long, _i, _i, _vp, _i, _vp]),
     "upa_bn_finalize": (_i, [_vp, C.c_long, _i, _f, _vp, _vp, _vp, _vp, _vp]),
+    "upa_conv2d_bn_act_fwd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _i, _vp, _i,
+                                    _vp, _i, _vp, _vp]),
     "upa_conv2d_bn_stats": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "upa_bn_act_fwd": (_i, [_vp, C.c_long, _i, _i, _vp, _vp, _vp, _vp, _f, _i, _vp, _i, _vp, _i, _i, _vp]),
     "upa_bn_act_bwd": (_i, [_vp, _vp, C.c_long, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp]),
+    "upa_conv_bn_act_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz,
+                                  _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "upa_channel_sum": (_i, [_vp, C.c_long, _i, _i, _vp, _i, _vp, _i, _vp]),
     "upa_conv2d_wgrad_workspace_bytes": (_sz, [_i, _i, _i]),
     "upa_conv2d_wgrad": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),

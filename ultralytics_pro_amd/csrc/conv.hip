@@ -1025,6 +1025,24 @@ extern "C" int upa_conv2d_bn_stats(const void* x, int n, int h, int w, int cin, 
   return upa_bn_finalize(ws, npix, cout, momentum, mean, var, running_mean, running_var, stream);
 }
 
+// The whole training forward of a Conv in ONE call (conv.py:177-186 in train mode): upa_conv2d_bn_stats, then
+// y = act(gamma * (z - mean) / sqrt(var + eps) + beta) (+ residual) = upa_bn_act_fwd - the same launches, one crossing of the language
+// boundary per layer instead of two (the eager training step issues ~600 launches from Python; its small-map phases are host-bound).
+extern "C" int upa_bn_act_fwd(const void* z, long npix, int c, int ldz, const float* mean, const float* var, const float* gamma,
+                              const float* beta, float eps, int act, void* y, int ldy, const void* residual, int ldr, int dtype,
+                              void* stream);
+extern "C" int upa_conv2d_bn_act_fwd(const void* x, int n, int h, int w, int cin, int ldx, const void* w_packed, void* z, int cout, int ldz,
+                                     int k, int stride, int pad, float momentum, float* mean, float* var, float* running_mean,
+                                     float* running_var, const float* gamma, const float* beta, float eps, int act, void* y, int ldy,
+                                     const void* residual, int ldr, double* ws, int dtype, const upa_opts* opts, void* stream) {
+  UPA_CHECK_ARG(y && gamma && beta, "conv2d_bn_act_fwd: null pointer");
+  if (const int rc = upa_conv2d_bn_stats(x, n, h, w, cin, ldx, w_packed, z, cout, ldz, k, stride, pad, momentum, mean, var, running_mean,
+                                         running_var, ws, dtype, opts, stream); rc != UPA_OK)
+    return rc;
+  const int oh = (h + 2 * pad - k) / stride + 1, ow = (w + 2 * pad - k) / stride + 1;
+  return upa_bn_act_fwd(z, (long)n * oh * ow, cout, ldz, mean, var, gamma, beta, eps, act, y, ldy, residual, ldr, dtype, stream);
+}
+
 // Conv(k = 3, s = 1, p = 1) + SiLU followed by nn.MaxPool2d(2, 2, 0) as ONE launch (yolov3-tiny.yaml rows 2-7: the full-resolution
 // activation - 210 + 105 + 52 MB at batch 32 - is neither written nor read back): y = the pooled (n, h / 2, w / 2, cout) view.
 // Bit-identical to upa_conv2d_bias_act + upa_maxpool2d (the pool runs on the bf16-rounded activations in the conv epilogue,

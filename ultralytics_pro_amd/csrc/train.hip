@@ -1513,6 +1513,51 @@ extern "C" int upa_bn_act_bwd(const void* z, const void* dy, long npix, int c, i
   return UPA_OK;
 }
 
+// The whole backward of a training-mode Conv (conv.py:177-186) in ONE call, for the common form (stride 1): upa_bn_act_bwd (dgamma,
+// dbeta, dz), the weight gradient - on `side_stream` if given, ordered behind dz by an event, so that it overlaps the data-gradient chain
+// the caller continues with - and the data gradient dx = conv(dz, W^T flipped) (+= with accumulate_dx; skipped when w_packed_t is NULL).
+// The same launches as the separate calls; what it saves is host time: three library calls and an event record / wait from Python per
+// layer (the eager step issues ~600 launches, its small-map phases are bound by the launch loop).
+extern "C" int upa_conv2d_bias_act(const void*, int, int, int, int, int, const void*, const float*, void*, int, int, const void*, int, int,
+                                   int, int, int, int, const upa_opts*, void*);
+extern "C" int upa_conv2d_wgrad(const void* x, int n, int h, int w, int cin, int ldx, const void* dz, int cout, int lddz, float* dw_oihw,
+                                int k, int stride, int pad, int accumulate, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+extern "C" int upa_conv_bn_act_bwd(const void* x, int n, int h, int w, int cin, int ldx, const void* z, const void* dy, int cout, int ldz,
+                                   int lddy, const float* mean, const float* var, const float* gamma, const float* beta, float eps, int act,
+                                   void* dz, int lddz, float* dgamma, float* dbeta, double* ws, float* dw_oihw, void* wgrad_ws,
+                                   size_t wgrad_ws_bytes, void* side_stream, const void* w_packed_t, void* dx, int lddx, int accumulate_dx,
+                                   int k, int pad, int dtype, const upa_opts* opts, void* stream) {
+  UPA_CHECK_ARG(x && z && dy && dz && dw_oihw && wgrad_ws, "conv_bn_act_bwd: null pointer");
+  const int oh = h + 2 * pad - k + 1, ow = w + 2 * pad - k + 1;  // stride 1
+  const long npix = (long)n * oh * ow;
+  if (const int rc = upa_bn_act_bwd(z, dy, npix, cout, ldz, lddy, mean, var, gamma, beta, eps, act, dz, lddz, dgamma, dbeta, 1, ws, dtype,
+                                    stream); rc != UPA_OK)
+    return rc;
+  hipStream_t main_s = (hipStream_t)stream, side = (hipStream_t)side_stream;
+  if (side && side != main_s) {
+    // one event per thread is enough: a wait enqueued on the side stream refers to the record that precedes it, re-recording later does
+    // not move it
+    static thread_local hipEvent_t ev = nullptr;
+    if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+      upa_set_error("conv_bn_act_bwd: cannot create an event");
+      return UPA_ELAUNCH;
+    }
+    if (hipEventRecord(ev, main_s) != hipSuccess || hipStreamWaitEvent(side, ev, 0) != hipSuccess) {
+      upa_set_error("conv_bn_act_bwd: event record / wait failed");
+      return UPA_ELAUNCH;
+    }
+  } else {
+    side = main_s;
+  }
+  if (const int rc = upa_conv2d_wgrad(x, n, h, w, cin, ldx, dz, cout, lddz, dw_oihw, k, 1, pad, 1, dtype, wgrad_ws, wgrad_ws_bytes, side);
+      rc != UPA_OK)
+    return rc;
+  if (!w_packed_t) return UPA_OK;
+  UPA_CHECK_ARG(dx, "conv_bn_act_bwd: dx missing");
+  return upa_conv2d_bias_act(dz, n, oh, ow, cout, lddz, w_packed_t, nullptr, dx, cin, lddx, accumulate_dx ? dx : nullptr,
+                             accumulate_dx ? lddx : 0, k, 1, k - 1 - pad, UPA_ACT_NONE, dtype, opts, stream);
+}
+
 extern "C" int upa_channel_sum(const void* z, long npix, int c, int ldz, float* out, int accumulate, double* ws, int dtype,
                                void* stream) {
   UPA_CHECK_ARG(z && out && ws, "channel_sum: null pointer");

@@ -156,21 +156,19 @@ class ConvT:
         vx, vz = R.view_of(x), R.view_of(z)
         npix = vz.n * vz.h * vz.w
         bn = self.bn
-        # conv + batch statistics in one call: on the kernels with a statistics epilogue the sums come from the convolution's own
-        # workgroups (no pass over z), elsewhere the library runs conv -> reduce -> combine itself
-        L.check(lib.upa_conv2d_bn_stats(vx.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, self.wp.data_ptr(), vz.ptr, self.cout, vz.ld,
-                                        self.k, self.s, self.p, float(bn.momentum), self.mean.data_ptr(), self.var.data_ptr(),
-                                        bn.running_mean.data_ptr(), bn.running_var.data_ptr(), c.ws.data_ptr(), vx.dtype,
-                                        R.opts_ptr(), _s(c.device)), f"conv2d_bn_stats[{self.name}]")
+        # conv + batch statistics + normalisation / activation in ONE call: on the kernels with a statistics epilogue the sums come from
+        # the convolution's own workgroups (no pass over z), elsewhere the library runs conv -> reduce -> combine itself
         y = out if out is not None else _new(n, self.cout, oh, ow, c.dtype, c.device, (id(self), "y"))
         vy = R.view_of(y)
         rp, rld = (None, 0)
         if residual is not None:
             vr = R.view_of(residual)
             rp, rld = vr.ptr, vr.ld
-        L.check(lib.upa_bn_act_fwd(vz.ptr, npix, vz.c, vz.ld, self.mean.data_ptr(), self.var.data_ptr(), bn.weight.data_ptr(),
-                                   bn.bias.data_ptr(), float(bn.eps), self.act, vy.ptr, vy.ld, rp, rld, vz.dtype,
-                                   _s(c.device)), "bn_act_fwd")
+        L.check(lib.upa_conv2d_bn_act_fwd(vx.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, self.wp.data_ptr(), vz.ptr, self.cout, vz.ld,
+                                          self.k, self.s, self.p, float(bn.momentum), self.mean.data_ptr(), self.var.data_ptr(),
+                                          bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.weight.data_ptr(),
+                                          bn.bias.data_ptr(), float(bn.eps), self.act, vy.ptr, vy.ld, rp, rld, c.ws.data_ptr(),
+                                          vx.dtype, R.opts_ptr(), _s(c.device)), f"conv2d_bn_act_fwd[{self.name}]")
         self.z = z
         return y
 
@@ -180,6 +178,28 @@ class ConvT:
         vdy = R.view_of(dy)
         npix = vdy.n * vdy.h * vdy.w
         st = _s(c.device)
+        if self.bn is not None and self.s == 1 and self.phase is None:
+            # the common form in ONE library call: BN + activation backward, the weight gradient (on the side stream, behind an event),
+            # the data gradient
+            vz, vx = R.view_of(self.z), R.view_of(self.x)
+            dz = _new(vz.n, vz.c, vz.h, vz.w, c.dtype, c.device, (id(self), "dz"))
+            vdz = R.view_of(dz)
+            bn = self.bn
+            side_p, ws = None, c.wgrad_ws
+            if c.wgrad_streams:
+                j = c.wgrad_rr % len(c.wgrad_streams)
+                c.wgrad_rr += 1
+                side_p, ws = c.wgrad_streams[j].cuda_stream, c.wgrad_wss[j]
+                c.wgrad_pending = True
+            vdx = None if dx is None else R.view_of(dx)
+            L.check(lib.upa_conv_bn_act_bwd(vx.ptr, vx.n, vx.h, vx.w, self.cin, vx.ld, vz.ptr, vdy.ptr, self.cout, vz.ld, vdy.ld,
+                                            self.mean.data_ptr(), self.var.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(),
+                                            float(bn.eps), self.act, vdz.ptr, vdz.ld, bn.weight.grad.data_ptr(), bn.bias.grad.data_ptr(),
+                                            c.ws.data_ptr(), self.conv.weight.grad.data_ptr(), ws.data_ptr(), ws.numel(), side_p,
+                                            None if dx is None else self.wpt.data_ptr(), None if dx is None else vdx.ptr,
+                                            0 if dx is None else vdx.ld, int(accumulate), self.k, self.p, vz.dtype, R.opts_ptr(), st),
+                    f"conv_bn_act_bwd[{self.name}]")
+            return
         if self.bn is None:
             dz = dy
             L.check(lib.upa_channel_sum(vdy.ptr, npix, vdy.c, vdy.ld, self.conv.bias.grad.data_ptr(), 1, c.ws.data_ptr(),
