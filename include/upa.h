@@ -448,6 +448,11 @@ int upa_channel_sum(const void* z, long npix, int c, int ldz, float* out, int ac
 size_t upa_conv2d_wgrad_workspace_bytes(int cin, int cout, int k);
 int upa_conv2d_wgrad(const void* x, int n, int h, int w, int cin, int ldx, const void* dz, int cout, int lddz, float* dw_oihw,
                      int k, int stride, int pad, int accumulate, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+/* Data gradient of a 3x3 stride-2 pad-1 conv in one launch: dx (n,h,w,cin) (+)= the four 2x2 phase correlations over dz (n,oh,ow,cout),
+ * phase_w_packed = upa_dgrad_s2_phase_weights packed as a (cout -> 4 cin, k 2) conv; the convolution's epilogue writes dx's interleaved
+ * pixels itself.  UPA_EUNSUPPORTED (nothing launched) outside the fused form: run the phase conv + upa_interleave2x. */
+int upa_conv2d_dgrad_s2(const void* dz, int n, int oh, int ow, int cout, int lddz, const void* phase_w_packed, void* dx, int h, int w,
+                        int cin, int lddx, int accumulate, int dtype, const upa_opts* opts, void* stream);
 /* dst (n,h,w,c) = zero-inserted src (n,oh,ow,c): dst[y,x] = src[y/2,x/2] for even y, x (data gradient of stride 2). */
 int upa_dilate2x(const void* src, int n, int oh, int ow, int c, int lds, void* dst, int h, int w, int ldd, int dtype,
                  void* stream);

@@ -32,6 +32,8 @@ CONV_TRAIN_CASES = [
     (80, 144, 1, 1, 2, 8, 8),
     (256, 128, 1, 1, 3, 9, 11),   # pointwise bf16 MFMA weight gradient: 2 x 1 blocks of 128, ragged pixel count
     (192, 136, 1, 1, 1, 16, 16),  # channel counts that are not multiples of the 128 block
+    (64, 128, 3, 2, 2, 64, 64),   # stride 2, large enough for the one-launch data gradient (phase conv with the interleaving epilogue)
+    (64, 128, 3, 2, 3, 46, 62),   # ... odd output map (23 x 31): phase pixels past dx's last row / column are dropped
 ]
 
 

@@ -18,6 +18,9 @@ from ultralytics_pro_amd.nn.tasks import DetectionModel  # noqa: E402
 from ultralytics_pro_amd.utils import procedural as P  # noqa: E402
 
 
+UNSUPPORTED = {"upa_conv2d_dgrad_s2"}  # calls answered with "outside the fused form" instead of being skipped (an A/B, results stay right)
+
+
 class Proxy:
     def __init__(self, real, skip):
         self._real, self._skip = real, set(skip)
@@ -25,7 +28,7 @@ class Proxy:
     def __getattr__(self, name):
         f = getattr(self._real, name)
         if name in self._skip:
-            return lambda *a: 0
+            return lambda *a: (-2 if name in UNSUPPORTED else 0)  # -2 = UPA_EUNSUPPORTED: the caller takes its fallback path
         return f
 
 
@@ -68,6 +71,11 @@ def main():
     for name, skip in cases:
         ms, iss = run(skip)
         print(f"{name:45s} {ms:7.3f} ms/step   (host issue {iss:6.3f} ms/step)", flush=True)
+    # A/B: the stride-2 data gradients as phase conv + interleave pass (the fused call answered UPA_EUNSUPPORTED) vs one launch
+    for rep in range(3):
+        for skip in (("upa_conv2d_dgrad_s2",), ()):
+            ms, iss = run(skip)
+            print(f"stride-2 data gradient {'conv + interleave pass' if skip else 'one launch            '}   {ms:7.3f} ms/step   (host issue {iss:6.3f})", flush=True)
     # A/B: the step issued on a HIGH-priority stream (the weight-gradient side stream keeps normal priority)
     hi = torch.cuda.Stream(device=dev, priority=-1)
     for rep in range(3):

@@ -180,6 +180,7 @@ PROTOTYPES = {
     "upa_bn_act_bwd": (_i, [_vp, _vp, C.c_long, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp]),
     "upa_conv_bn_act_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz,
                                   _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "upa_conv2d_dgrad_s2": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "upa_channel_sum": (_i, [_vp, C.c_long, _i, _i, _vp, _i, _vp, _i, _vp]),
     "upa_conv2d_wgrad_workspace_bytes": (_sz, [_i, _i, _i]),
     "upa_conv2d_wgrad": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),

@@ -1025,6 +1025,25 @@ extern "C" int upa_conv2d_bn_stats(const void* x, int n, int h, int w, int cin, 
   return upa_bn_finalize(ws, npix, cout, momentum, mean, var, running_mean, running_var, stream);
 }
 
+// Data gradient of a 3x3 stride-2 pad-1 convolution (training): dx (n, h, w, cin) (+)= the four 2x2 phase correlations over dz
+// (n, oh, ow, cout) with the stacked phase weights (upa_dgrad_s2_phase_weights packed as a cout -> 4 cin, k = 2 conv), written straight into
+// dx's interleaved pixels by the convolution's epilogue - no (n, oh + 1, ow + 1, 4 cin) phase tensor, no upa_interleave2x pass.
+// UPA_EUNSUPPORTED (nothing launched) outside conv_big's 128-channel-column shapes: the caller runs conv + upa_interleave2x.
+extern "C" int upa_conv2d_dgrad_s2(const void* dz, int n, int oh, int ow, int cout, int lddz, const void* phase_w_packed, void* dx, int h,
+                                   int w, int cin, int lddx, int accumulate, int dtype, const upa_opts* opts, void* stream) {
+  UPA_CHECK_ARG(dz && phase_w_packed && dx, "conv2d_dgrad_s2: null pointer");
+  if (dtype != UPA_BF16 || cin % 8 != 0 || lddx % 8 != 0 || lddz % 8 != 0 || ((uintptr_t)dz % 16) != 0 || ((uintptr_t)dx % 16) != 0 ||
+      !upa_conv_big_eligible(n, oh, ow, cout, lddz, 4 * cin, 4 * cin, 0, 2, 1, 1, UPA_ACT_NONE, dtype, opts))
+    return UPA_EUNSUPPORTED;
+  BigParams q;
+  memset(&q, 0, sizeof(q));
+  q.x = (const char*)dz; q.y = (char*)dx; q.w = (const char*)phase_w_packed; q.res = accumulate ? (const char*)dx : nullptr;
+  q.N = n; q.H = oh; q.W = ow; q.Cin = cout; q.ldx = lddz; q.Cout = 4 * cin; q.ldy = lddx; q.ldr = lddx; q.OH = oh + 1; q.OW = ow + 1;
+  q.KS = 2; q.stride = 1; q.pad = 1; q.act = UPA_ACT_NONE;
+  q.il_h = h; q.il_w = w; q.il_c = cin;
+  return upa_conv_big_launch_interleave(q, stream, opts);
+}
+
 // The whole training forward of a Conv in ONE call (conv.py:177-186 in train mode): upa_conv2d_bn_stats, then
 // y = act(gamma * (z - mean) / sqrt(var + eps) + beta) (+ residual) = upa_bn_act_fwd - the same launches, one crossing of the language
 // boundary per layer instead of two (the eager training step issues ~600 launches from Python; its small-map phases are host-bound).

@@ -57,14 +57,18 @@ __device__ __forceinline__ float big_act(float v) {
 // TAIL 3 (training forward, act = none, no residual): besides storing z the workgroup leaves the sum and the sum of squares of the
 // bf16-ROUNDED values it stored, per output channel, in row blockIdx.x of p.stats - the first stage of BatchNorm's batch statistics
 // (conv.py:177-186 in train mode) without a pass over z; a combine kernel adds the rows in a fixed order (train.hip).
+// TAIL 4 (training: data gradient of a 3x3 stride-2 convolution as four 2x2 phase correlations stacked along the output channels, train.hip
+// dgrad_s2_phase_weights): the epilogue stores phase (py, px)'s value of pixel (i, j) straight to dx[2 (i - 1) + py][2 (j - 1) + px] (+= with
+// p.res = dx) - the (n, oh + 1, ow + 1, 4 cin) phase tensor and the interleaving pass over it are gone.
 // The kernel body: `bid0` = the workgroup's tile index within ITS problem (blockIdx.x for a single launch; a paired launch -
 // conv_big_pair_kernel below - runs two problems of the same instantiation in one grid).
 template <int KS, int STRIDE, int WM, int WN, int MT, int NT, int TAIL = 0>
 __device__ __forceinline__ void conv_big_body(const BigParams& p, const int bid0) {
   static_assert(WM * WN == 8, "8 waves per workgroup");
-  static_assert(TAIL == 0 || TAIL == 3 || WN == 1, "a tail needs every channel of a pixel in one wave");
+  static_assert(TAIL == 0 || TAIL == 3 || TAIL == 4 || WN == 1, "a tail needs every channel of a pixel in one wave");
   static_assert(TAIL != 1 || (NT % 2) == 0, "box branch: 64 channels");
   static_assert(TAIL != 3 || (NT % 2) == 0, "the statistics epilogue pairs n-tiles");
+  static_assert(TAIL != 4 || ((NT % 2) == 0 && KS == 2 && STRIDE == 1), "the interleaving epilogue: 2 x 2 phase kernels, paired n-tiles");
   constexpr int NTB = WN * NT;            // n-tiles per workgroup
   constexpr int WBUF = 2 * NTB * 1024;    // one (tap, chunk) weight slab: 2 k-tiles x NTB n-tiles x 1 KiB
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -416,7 +420,18 @@ __device__ __forceinline__ void conv_big_body(const BigParams& p, const int bid0
           v0[q] = big_act<ACT>(acc[i][j][q] + bj0[q]);
           v1[q] = big_act<ACT>(acc[i][j + 1][q] + bj1[q]);
         }
-        const bool ok = pok && cw + cb < p.Cout;
+        bool ok = pok && cw + cb < p.Cout;
+        char* dst = yrow + cb * 2;
+        const char* rsrc = rrow ? rrow + cb * 2 : nullptr;
+        if constexpr (TAIL == 4) {  // this lane's 8 channels belong to ONE phase (cin % 8 == 0): its pixel of dx
+          const int ch = cw + cb;
+          const int ph = ch / p.il_c, c = ch - ph * p.il_c;
+          const int y = 2 * (oy - 1) + (ph >> 1), x = 2 * (ox - 1) + (ph & 1);
+          ok = ok && y >= 0 && y < p.il_h && x >= 0 && x < p.il_w;
+          const size_t off = ((((size_t)n * p.il_h + y) * p.il_w + x) * p.ldy + c) * 2;
+          dst = p.y + off;
+          rsrc = p.res ? p.res + off : nullptr;  // (accumulating: p.res = dx itself, same pitch)
+        }
         if (p.res) {
           float x8[8];
 #pragma unroll
@@ -426,19 +441,19 @@ __device__ __forceinline__ void conv_big_body(const BigParams& p, const int bid0
             x8[4 + q] = __uint_as_float(sw[1]);
           }
           if (ok) {
-            const u32x4 rv = *reinterpret_cast<const u32x4*>(rrow + cb * 2);
+            const u32x4 rv = *reinterpret_cast<const u32x4*>(rsrc);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               x8[2 * q] += __uint_as_float(rv[q] << 16);
               x8[2 * q + 1] += __uint_as_float(rv[q] & 0xFFFF0000u);
             }
-            *reinterpret_cast<u32x4*>(yrow + cb * 2) = u32x4{pack_bf16x2(x8[0], x8[1]), pack_bf16x2(x8[2], x8[3]),
-                                                            pack_bf16x2(x8[4], x8[5]), pack_bf16x2(x8[6], x8[7])};
+            *reinterpret_cast<u32x4*>(dst) = u32x4{pack_bf16x2(x8[0], x8[1]), pack_bf16x2(x8[2], x8[3]),
+                                                   pack_bf16x2(x8[4], x8[5]), pack_bf16x2(x8[6], x8[7])};
           }
         } else {
           auto lo = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v1[0], v1[1]), false, false);
           auto hi = __builtin_amdgcn_permlane16_swap(pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[2], v1[3]), false, false);
-          if (ok) *reinterpret_cast<u32x4*>(yrow + cb * 2) = u32x4{lo[0], hi[0], lo[1], hi[1]};
+          if (ok) *reinterpret_cast<u32x4*>(dst) = u32x4{lo[0], hi[0], lo[1], hi[1]};
         }
       }
       if constexpr (NT & 1) {  // odd tile count: the last n-tile goes out as 8-byte channel quads
@@ -971,6 +986,20 @@ int upa_conv_big_launch(BigParams p, int query_only, int* variant, void* stream,
   if (variant) *variant = (1 << 23) | (ntb << 4) | (bm >> 7);  // (bm >> 7: 1 = 128, 2 = 256, 4 = 512 pixels)
   if (query_only || rc != UPA_OK) return rc;
   return big_dispatch(p, ntb, bm, lds, (hipStream_t)stream);
+}
+
+// The four stacked 2x2 phase correlations of a stride-2 data gradient with the interleaving epilogue (TAIL 4): p = the phase convolution
+// (dz (n, oh, ow, cout) -> 4 cin channels at (oh + 1, ow + 1), KS 2, pad 1), p.y / p.ldy = dx and its pixel pitch, p.il_h / il_w / il_c = dx's
+// height, width and channel count, p.res = dx when accumulating.  UPA_EUNSUPPORTED outside the 128-channel-column variants.
+int upa_conv_big_launch_interleave(BigParams p, void* stream, const upa_opts* opts) {
+  p.no_xcd = UPA_OPT(opts, no_xcd);
+  if (p.KS != 2 || p.stride != 1 || p.act != UPA_ACT_NONE || p.bias || p.il_c % 8 != 0 || p.Cout != 4 * p.il_c) return UPA_EUNSUPPORTED;
+  int ntb = 0, bm = 0;
+  size_t lds = 0;
+  if (const int rc = big_prepare(p, ntb, bm, lds, opts, false); rc != UPA_OK) return rc;
+  if (ntb != 8 || (bm != 128 && bm != 256)) return UPA_EUNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  return bm == 256 ? big_launch_inst<2, 1, 4, 2, 4, 4, 4>(p, lds, s) : big_launch_inst<2, 1, 4, 2, 2, 4, 4>(p, lds, s);
 }
 
 // The convolution with the statistics epilogue: p.stats receives *rows rows of [2][p.stats_ld] floats (one per pixel tile; p.stats_ld is

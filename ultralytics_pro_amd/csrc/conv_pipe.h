@@ -76,6 +76,7 @@ struct BigParams {
   // [2][stats_ld] floats (stats_ld = 16 * n-tiles of the layer); nullptr = a plain convolution
   float* stats;
   int stats_ld;
+  int il_h, il_w, il_c;  // interleaving epilogue (conv_big TAIL 4): dx's height, width, channels
 };
 bool upa_conv_big_eligible(int n, int h, int w, int cin, int ldx, int cout, int ldy, int ldr, int k, int stride, int pad,
                            int act, int dtype, const upa_opts* opts);
@@ -83,6 +84,7 @@ bool upa_conv_big_eligible(int n, int h, int w, int cin, int ldx, int cout, int 
 int upa_conv_big_launch(BigParams p, int query_only, int* variant, void* stream, const upa_opts* opts);
 // p.stats != nullptr: the convolution + the first stage of the batch statistics (see BigParams::stats); *rows = rows written
 int upa_conv_big_launch_stats(BigParams p, int* rows, long max_rows, void* stream, const upa_opts* opts);
+int upa_conv_big_launch_interleave(BigParams p, void* stream, const upa_opts* opts);  // see conv_big.hip
 // the first two or three problems of a list in ONE grid if they share a 128-pixel 3x3 stride-1 instantiation (*consumed = how many);
 // UPA_EUNSUPPORTED = nothing launched (the caller launches the first problem alone and tries again from the next)
 int upa_conv_big_launch_group(const BigParams* probs, int count, int* consumed, void* stream, const upa_opts* opts);

@@ -234,6 +234,12 @@ class ConvT:
         if self.phase is not None:
             # stride 2: the four 2x2 stride-1 correlations over dz (one per output parity) as one conv with 4 * cin output
             # channels + one interleave pass over its four channel blocks
+            vdx = R.view_of(dx)
+            rc = lib.upa_conv2d_dgrad_s2(vdz.ptr, vdz.n, vdz.h, vdz.w, self.cout, vdz.ld, self.phase.data_ptr(), vdx.ptr, vdx.h, vdx.w,
+                                         self.cin, vdx.ld, int(accumulate), vdx.dtype, R.opts_ptr(), st)
+            if rc != L.UPA_EUNSUPPORTED:  # one launch: the phase conv's epilogue writes dx's interleaved pixels itself
+                L.check(rc, "conv2d_dgrad_s2")
+                return
             t = _new(vdz.n, 4 * self.cin, vdz.h + 1, vdz.w + 1, c.dtype, c.device, (id(self), "phases"))
             self._conv(dz, self.phase, 4 * self.cin, 2, 1, 1, t)
             ts = [R.view_of(t[:, ph * self.cin:(ph + 1) * self.cin]) for ph in range(4)]  # raw pointers: `t` outlives the launch below
