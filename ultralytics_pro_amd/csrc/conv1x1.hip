@@ -394,7 +394,13 @@ static int c1_launch(C1Params p, int n_pixels, int query_only, int* variant, int
   // pixel tiles per wave and step: enough groups that every SIMD of the chip has a few to pipeline
   const int f_mt = UPA_OPT(opts, c1_mt), f_waves = UPA_OPT(opts, c1_waves), f_wgs = UPA_OPT(opts, c1_wgs);  // tuning / tests
   int mt = tiles >= 8192 ? 4 : (tiles >= 2048 ? 2 : 1);
-  if (p.epi == 3 && ntw > 4 && mt > 2) mt = 2;  // the statistics epilogue keeps 8 ntw running sums per lane: registers
+  // the statistics epilogue keeps 8 ntw running sums per lane on top of the 4 mt ntw accumulators: eight n-tiles leave room for one pixel
+  // tile per wave (two spill: 128 -> 128 @80x80 bs 32 45.0 -> 37.0 us, 256 -> 256 @40x40 38.0 -> 27.6, tools/experiments/r05_c1_stats_time.py),
+  // six for two
+  if (p.epi == 3 && !f_mt) {
+    if (ntw > 6 && mt > 1) mt = 1;
+    else if (ntw > 4 && mt > 2) mt = 2;
+  }
   if (mt * ntw > 32) mt = 32 / ntw;  // accumulator budget: MT * NTW tiles of 4 registers
   if (mt == 3) mt = 2;
   int waves = 8;
