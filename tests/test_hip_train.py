@@ -658,6 +658,33 @@ def test_amp_grad_scaler_follows_torch_semantics(dtype):
     assert abs(t1.grad_norm() - float(t1.G.double().norm()) / t1.scaler.get_scale()) <= 1e-3 * t1.grad_norm()
 
 
+def test_amp_grad_scaler_inside_the_compiled_step():
+    """The scaler's state lives on the device, so a scaled step is still ONE hipGraph (the reference's `scaler.step` reads `found_inf`
+    on the host): the replayed steps land where the eager scaled steps do, and the scale doubles after `growth_interval` replays."""
+    from tests.hip_utils import DEV
+    from ultralytics_pro_amd.engine.trainer import DetectionTrainer
+    from ultralytics_pro_amd.nn.tasks import DetectionModel
+    bs, sz = 2, 128
+    batches = [(P.synthetic_images(bs, h=sz, w=sz, seed=s).to(DEV), P.synthetic_labels(bs, seed=s)) for s in range(4)]
+    runs = []
+    for compiled in (False, True):
+        m = DetectionModel("yolov8n.yaml")
+        P.apply_procedural_weights(m)
+        tr = DetectionTrainer(m, dtype=torch.bfloat16, device=DEV, amp_scaler=True)
+        tr.scaler.growth_interval = 3
+        tr.step(*batches[0])
+        if compiled:
+            tr.compile(*batches[0], warm_steps=0)
+            assert len(tr._graphs) == 1
+        for b in batches[1:]:
+            tr.step(*b)
+        torch.cuda.synchronize()
+        runs.append((tr.P.cpu().clone(), tr.scaler.get_scale(), tr.scaler.state_dict()["_growth_tracker"]))
+    (pa, sa, ta), (pb, sb, tb) = runs
+    assert sa == sb == 131072.0 and ta == tb == 1  # four clean steps at interval 3: one doubling, tracker at 1
+    np.testing.assert_allclose(pa.numpy(), pb.numpy(), rtol=1e-5, atol=1e-7)
+
+
 def test_training_step_yolov8s_f32_matches_reference_golden(golden_dir):
     """BASELINE config 3's model (yolov8s), one f32 training step vs the imported reference's record
     (tests/golden/train_yolov8s.npz: bs 2, 256 x 256): loss items, gradient norm, per-parameter gradient norms, updated
