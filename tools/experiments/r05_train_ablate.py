@@ -71,6 +71,12 @@ def main():
     for name, skip in cases:
         ms, iss = run(skip)
         print(f"{name:45s} {ms:7.3f} ms/step   (host issue {iss:6.3f} ms/step)", flush=True)
+    # A/B: the Detect head's small levels on the main stream vs beside the 80 x 80 level on a second stream
+    for rep in range(3):
+        for fk in (False, True):
+            tr.detect.fork_levels = fk
+            ms, iss = run(())
+            print(f"Detect levels {'two streams' if fk else 'one stream '}                        {ms:7.3f} ms/step   (host issue {iss:6.3f})", flush=True)
     # A/B: the stride-2 data gradients as phase conv + interleave pass (the fused call answered UPA_EUNSUPPORTED) vs one launch
     for rep in range(3):
         for skip in (("upa_conv2d_dgrad_s2",), ()):

@@ -54,7 +54,11 @@ class _Ctx:
         self.es = 2 if dtype == torch.bfloat16 else 4
         self.E = 16 // self.es
         # channel-reduction scratch (per-block partial sums + combined sums), sized for c <= 1024
-        self.ws = torch.zeros(L.lib().upa_channel_reduce_workspace_bytes(1024) // 8, dtype=torch.float64, device=device)
+        self._ws = [torch.zeros(L.lib().upa_channel_reduce_workspace_bytes(1024) // 8, dtype=torch.float64, device=device) for _ in range(2)]
+        # the Detect head's 40 x 40 / 20 x 20 levels run beside the 80 x 80 level on a second stream (`DetectT`): its own reduction
+        # workspace (the reductions of one workspace must be stream-ordered)
+        self.level_stream = torch.cuda.Stream(device=device)
+        self._ws_sel = 0
         self.wgrad_ws = torch.empty(0, dtype=torch.uint8, device=device)  # weight-gradient partial sums (largest layer)
         # weight gradients run on a side stream (a parallel branch of the captured graph): a layer's dW only needs its
         # input and dz, so it overlaps the data-gradient / BN-backward chain of the layers in front of it
@@ -63,6 +67,13 @@ class _Ctx:
         self.wgrad_wss = [self.wgrad_ws for _ in self.wgrad_streams]  # one partial-sum workspace per stream
         self.wgrad_rr = 0
         self.wgrad_pending = False
+
+
+def _ctx_ws(self):
+    return self._ws[self._ws_sel]
+
+
+_Ctx.ws = property(_ctx_ws)
 
 
 def _new(n, c, h, w, dtype, dev, key):
@@ -1003,23 +1014,52 @@ class DetectT(_Seq):
         dev = c.device
         nb = 4 * self.reg_max
         self.xs = list(xs)
-        self.raw, self.raw32 = [], []
-        for i, x in enumerate(xs):
+        self.raw, self.raw32 = [None] * len(xs), [None] * len(xs)
+
+        def level(i, x):
             n, _, h, w = x.shape
             raw = _new(n, self.no, h, w, c.dtype, dev, (id(self), "raw", i))
             for k, (seq, out) in enumerate(zip(self.br[i], (raw[:, :nb], raw[:, nb:]))):
                 t = seq[1].forward(seq[0].forward(x))
                 seq[2].forward(t, out=out)
-            self.raw.append(raw)
+            self.raw[i] = raw
             if c.dtype == torch.float32:
-                self.raw32.append(raw)
+                self.raw32[i] = raw
             else:  # the loss reads f32 maps
                 r32 = _new(n, self.no, h, w, torch.float32, dev, (id(self), "raw32", i))
                 vs, vd = R.view_of(raw), R.view_of(r32)
                 L.check(L.lib().upa_cast_view(vs.ptr, vs.dtype, vs.ld, vd.ptr, vd.dtype, vd.ld, vs.n * vs.h * vs.w, vs.c,
                                               _s(dev)), "cast_view")
-                self.raw32.append(r32)
+                self.raw32[i] = r32
+
+        # The levels are independent chains (head.py:116-126).  The 40 x 40 / 20 x 20 levels are strings of 5-15 us launches (a few
+        # hundred workgroups each): on a second stream they run beside the 80 x 80 level's chip-filling launches instead of after them.
+        self._fork_levels(lambda: level(0, xs[0]), lambda: [level(i, xs[i]) for i in range(1, len(xs))], len(xs) > 1)
         return self.raw
+
+    def _fork_levels(self, first, rest, fork: bool):
+        """`first()` on the current stream, `rest()` on the context's level stream (own reduction workspace), joined at the end."""
+        c = self.ctx
+        if not (fork and self.fork_levels):
+            first()
+            rest()
+            return
+        main = torch.cuda.current_stream(c.device)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        c.level_stream.wait_event(ev)
+        c._ws_sel = 1
+        try:
+            with torch.cuda.stream(c.level_stream):
+                rest()
+                done = torch.cuda.Event()
+                done.record(c.level_stream)
+        finally:
+            c._ws_sel = 0
+        first()
+        main.wait_event(done)
+
+    fork_levels = True  # (False: every level on the main stream, as before round 5 - the A/B switch)
 
     def loss_backward(self, labels, batch_size):
         """v8DetectionLoss (utils/loss.py:471-528) + gradient; then backward through the head into the neck outputs."""
@@ -1057,7 +1097,8 @@ class DetectT(_Seq):
                                               h["box"], h["cls"], h["dfl"], 1.0, tr.scaler.ptr(), items.data_ptr(), wsb.data_ptr(),
                                               nbytes, _s(dev)), "detection_loss")
         nb = 4 * self.reg_max
-        for i in range(nl):
+
+        def level_bwd(i):
             g32 = grads32[i]
             if c.dtype == torch.float32:
                 graw = g32
@@ -1077,6 +1118,9 @@ class DetectT(_Seq):
                 seq[2].backward(dy, d1, False)
                 seq[1].backward(d1, d0, False)
                 seq[0].backward(d0, dx, acc or k > 0)
+
+        # as in the forward pass: the small levels' chains beside the 80 x 80 level's (they write the gradients of different neck outputs)
+        self._fork_levels(lambda: level_bwd(0), lambda: [level_bwd(i) for i in range(1, nl)], nl > 1)
         return items
 
 
