@@ -1132,6 +1132,19 @@ def test_nms_large_multilabel_vs_oracle():
     assert ref[0].shape[0] > 80  # the distinct boxes behind the duplicates are needed: the first pass alone would stop at 80
     for a, b in zip(out, ref):
         assert a.shape == b.shape and torch.equal(a.cpu(), b)
+    # the first stage picks its prefix from a coarse score histogram (round 5): scores that all fall in ONE coarse bin leave no usable
+    # prefix (the exact radix select runs instead).  Image 0: 24000 candidates with the SAME score (order = candidate index), image 1:
+    # scores inside one bin (0.75 .. 0.7529), image 2: the ordinary scene
+    r = p.clone()
+    r[2] = p[1]
+    r[0, 4:, :300] = 0.6
+    r[0, 4:, 300:] = 0.0
+    r[1, 4:, :400] = 0.75 + 0.0029 * P.uniform("nmsbig:onebin", (80, 400), 0, 1)
+    r[1, 4:, 400:] = 0.0005
+    ref = onms.non_max_suppression(r.clone(), **kw)
+    out = non_max_suppression(r.to(DEV), **kw)
+    for a, b in zip(out, ref):
+        assert a.shape == b.shape and torch.equal(a.cpu(), b)
 
 
 def test_cpu_tensor_fails_loudly():

@@ -29,9 +29,18 @@ struct NmsWs {
   u64* sel;     // [B][selcap]
 };
 
+// Coarse score digit of a key for the two-stage multi-label path: 128 bins per octave of the score counted down from 1.0 (sign, exponent
+// and 7 mantissa bits of the inverted score word), clamped to [0, COARSE_BINS) - a monotone function of the key, so "bin < b" is a
+// prefix of the score order.  conf = 0.001 .. 1 spans 1277 bins.
+constexpr int COARSE_BINS = 4096;
+__device__ __forceinline__ int coarse_bin(unsigned inv_score_bits) {
+  const int d = (int)(inv_score_bits >> 16) - 0xC07F;  // 0xC07F = (~bits(1.0f)) >> 16
+  return d < 0 ? 0 : (d > COARSE_BINS - 1 ? COARSE_BINS - 1 : d);
+}
+
 __global__ __launch_bounds__(256) void nms_candidates_kernel(const float* pred, int B, int nc, int A, float conf,
                                                              int multi_label, const uint8_t* cmask, int* count, u64* keys,
-                                                             long cap) {
+                                                             long cap, int* coarse) {
   const int b = blockIdx.y;
   const int a = blockIdx.x * 256 + threadIdx.x;
   const bool valid = a < A;
@@ -77,6 +86,13 @@ __global__ __launch_bounds__(256) void nms_candidates_kernel(const float* pred, 
       if (slot >= 0 && slot < cap) kb[slot] = ((u64)(~__float_as_uint(best)) << 32) | (unsigned)(a * nc + bc);
     }
   } else {
+    // `coarse` (two-stage sort): the workgroup also counts its candidates per coarse score bin in LDS and adds the non-empty bins to
+    // the image's histogram at the end - the sort kernel then knows which bins hold the top candidates before it reads a single key
+    __shared__ int lh[COARSE_BINS];
+    if (coarse) {
+      for (int i = threadIdx.x; i < COARSE_BINS; i += 256) lh[i] = 0;
+      __syncthreads();
+    }
     // eight class rows in flight per lane, and ONE reservation in count[b] per wave and group of eight classes (the wave counts its
     // candidates of the group first): a load and a same-address global atomic per class left this loop at two memory round trips per
     // class (2.0 ms per validation batch)
@@ -101,9 +117,16 @@ __global__ __launch_bounds__(256) void nms_candidates_kernel(const float* pred, 
         if ((m[q] >> lane) & 1ull) {
           const int slot = base + __popcll(m[q] & ((1ull << lane) - 1ull));
           if (slot >= 0 && slot < cap) kb[slot] = ((u64)(~__float_as_uint(v[q])) << 32) | (unsigned)(a * nc + c0 + q);
+          if (coarse) atomicAdd(&lh[coarse_bin(~__float_as_uint(v[q]))], 1);
         }
         base += __popcll(m[q]);
       }
+    }
+    if (coarse) {
+      __syncthreads();
+      int* gh = coarse + (size_t)b * COARSE_BINS;
+      for (int i = threadIdx.x; i < COARSE_BINS; i += 256)
+        if (lh[i]) atomicAdd(&gh[i], lh[i]);
     }
   }
 }
@@ -141,7 +164,7 @@ constexpr int LDS_SORT_CAP = 16384;  // u64 -> 128 KiB of dynamic LDS (covers ev
 __global__ __launch_bounds__(SORT_NT) void nms_sort_kernel(const int* count, int* nsorted, u64* keys, u64* sel, long cap,
                                                            int selcap, int max_nms, const u64* best_keys, int nc, int A,
                                                            float conf, const uint8_t* cmask, int prefix, int* partial,
-                                                           const int* only_redo) {
+                                                           const int* only_redo, const int* coarse) {
   if (only_redo && !only_redo[blockIdx.x]) return;
   extern __shared__ __attribute__((aligned(16))) u64 lbuf[];  // LDS_SORT_CAP keys
   __shared__ int hist[256];
@@ -185,6 +208,80 @@ __global__ __launch_bounds__(SORT_NT) void nms_sort_kernel(const int* count, int
   if (n > cap) n = (int)cap;
   const int target = (prefix > 0 && prefix < max_nms) ? prefix : max_nms;  // how many of the best candidates this call keeps
   if (partial && threadIdx.x == 0) partial[b] = (prefix > 0 && n > target && target < max_nms) ? 1 : 0;
+  // First stage with the image's coarse score histogram (filled by the candidates kernel): the sorted prefix need not be exactly
+  // `target` long - any prefix of the score order does, the greedy pass flags the image when it runs out.  So the prefix is "every key
+  // in the coarse bins before the one where the running count crosses target": found from the histogram alone, then ONE pass over the
+  // n keys compacts those (fewer than target <= LDS_SORT_CAP) straight into LDS, where they are sorted.  No radix select (three to five
+  // passes over up to A * nc keys through this one workgroup, then the compaction pass: 0.59 ms per validation batch).
+  if (coarse && prefix > 0 && n > target && target < max_nms && target <= LDS_SORT_CAP) {
+    __shared__ int wsum[SORT_NT / 64];
+    __shared__ int s_bstar, s_m;
+    const int* gh = coarse + (size_t)b * COARSE_BINS;
+    constexpr int PER = COARSE_BINS / SORT_NT;
+    int c[PER], t = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) { c[q] = gh[threadIdx.x * PER + q]; t += c[q]; }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = t;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d);
+      if (lane >= d) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    if (threadIdx.x == 0) { s_bstar = -1; s_m = 0; s_n = 0; }
+    __syncthreads();
+    int before = incl - t;
+    for (int w2 = 0; w2 < wave; ++w2) before += wsum[w2];
+    if (before < target && before + t >= target) {  // exactly one thread: the crossing bin is one of its PER
+      int cum = before, q = 0;
+      for (; q < PER; ++q) {
+        if (cum + c[q] >= target) break;
+        cum += c[q];
+      }
+      s_bstar = threadIdx.x * PER + q;
+      s_m = cum;
+    }
+    __syncthreads();
+    const int bstar = s_bstar, m = s_m;
+    if (bstar > 0 && m >= target / 4 && m <= LDS_SORT_CAP) {  // (uniform) else: the exact path below
+      constexpr int U = 8;
+      for (int i0 = threadIdx.x; i0 < n; i0 += U * SORT_NT) {
+        u64 k[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int i = i0 + u * SORT_NT;
+          k[u] = i < n ? kb[i] : ~0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int i = i0 + u * SORT_NT;
+          const bool take = i < n && coarse_bin((unsigned)(k[u] >> 32)) < bstar;
+          const u64 mk = __ballot(take);
+          if (mk) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_n, __popcll(mk));
+            base = __shfl(base, 0);
+            if (take) {
+              const int slot = base + __popcll(mk & ((1ull << lane) - 1ull));
+              if (slot < LDS_SORT_CAP) lbuf[slot] = k[u];
+            }
+          }
+        }
+      }
+      __syncthreads();
+      n = s_n < LDS_SORT_CAP ? s_n : LDS_SORT_CAP;  // (== m)
+      int npad = 2;
+      while (npad < n) npad <<= 1;
+      for (int i = n + threadIdx.x; i < npad; i += SORT_NT) lbuf[i] = ~0ull;
+      __syncthreads();
+      bitonic_sort<SORT_NT>(lbuf, npad);
+      for (int i = threadIdx.x; i < n; i += SORT_NT) sb[i] = lbuf[i];
+      if (threadIdx.x == 0) nsorted[b] = n;
+      return;
+    }
+    __syncthreads();
+  }
   if (n > target) {
     // exact threshold key K*: exactly `target` keys are <= K* (keys are unique)
     if (threadIdx.x == 0) { s_prefix = 0ull; s_remaining = target; s_n = 0; }
@@ -415,6 +512,10 @@ __global__ __launch_bounds__(GREEDY_NT) void nms_greedy_kernel(const float* pred
   }
 }
 
+inline bool no_coarse_env() {  // A/B switch for tools/: UPA_NMS_NO_COARSE=1 keeps the radix select in the first stage
+  static const bool v = [] { const char* e = getenv("UPA_NMS_NO_COARSE"); return e && e[0] == '1'; }();
+  return v;
+}
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline int pow2_ge(int v) {
   int p = 1;
@@ -427,7 +528,8 @@ inline int pow2_ge(int v) {
 extern "C" size_t upa_nms_workspace_bytes(int b, int nc, int a, int multi_label, int max_nms) {
   const size_t cap = (size_t)a * (multi_label ? nc : 1);
   const size_t selcap = (size_t)pow2_ge(max_nms < 2 ? 2 : max_nms);
-  return 256 + align_up((size_t)b * 4 * sizeof(int), 256) + (size_t)b * cap * 8 + (size_t)b * selcap * 8;  // count, nsorted, partial, redo
+  const size_t counters = (size_t)b * 4 + (multi_label ? (size_t)b * COARSE_BINS : 0);  // count, nsorted, partial, redo (+ coarse histograms)
+  return 256 + align_up(counters * sizeof(int), 256) + (size_t)b * cap * 8 + (size_t)b * selcap * 8;
 }
 
 static int nms_batched_impl(const float* pred, int b, int nc, int a, float conf_thres, float iou_thres, int multi_label,
@@ -446,6 +548,7 @@ static int nms_batched_impl(const float* pred, int b, int nc, int a, float conf_
     upa_set_error("nms: workspace too small");
     return UPA_EWORKSPACE;
   }
+  const bool ws_has_coarse = multi_label != 0;
   multi_label = multi_label && nc > 1;  // nms.py:82
   const long cap = (long)a * (multi_label ? nc : 1);
   const int selcap = pow2_ge(max_nms < 2 ? 2 : max_nms);
@@ -455,28 +558,29 @@ static int nms_batched_impl(const float* pred, int b, int nc, int a, float conf_
   int* nsorted = count + b;
   int* partial = count + 2 * b;
   int* redo = count + 3 * b;
-  ws += align_up((size_t)b * 4 * sizeof(int), 256);
+  ws += align_up(((size_t)b * 4 + (ws_has_coarse ? (size_t)b * COARSE_BINS : 0)) * sizeof(int), 256);
   u64* keys = (u64*)ws;
   u64* sel = keys + (size_t)b * cap;
   hipStream_t s = (hipStream_t)stream;
   // counters zeroed by a kernel, not hipMemsetAsync (see upa_zero_words, common.h); with best-class keys nothing counts in
   // global memory: the sort kernel compacts its own candidates and always writes nsorted[b]
-  if (!best_keys) upa_zero_words(count, 2 * b, s);
+  // long candidate lists (multi-label validation): first only a sorted prefix of at most LDS_SORT_CAP candidates, sorted in LDS - the
+  // full top-max_nms select + global-memory sort (8.4 ms per batch-32 call, two thirds of the validate step's GPU time) only for images
+  // whose greedy pass ran out of candidates before max_det boxes were kept
+  const bool two_stage = cap > LDS_SORT_CAP && max_nms > LDS_SORT_CAP;
+  int* coarse = (two_stage && multi_label && !best_keys && !no_coarse_env()) ? count + 4 * b : nullptr;
+  if (!best_keys) upa_zero_words(count, coarse ? 4 * b + b * COARSE_BINS : 2 * b, s);
   if (!best_keys)  // (with best-class keys the sort kernel compacts its own candidates)
     hipLaunchKernelGGL(nms_candidates_kernel, dim3((unsigned)cdiv(a, 256), (unsigned)b), dim3(256), 0, s, pred, b, nc, a,
-                       conf_thres, multi_label, classes_mask, count, keys, cap);
+                       conf_thres, multi_label, classes_mask, count, keys, cap, coarse);
   UPA_LAUNCH_CHECK();
   {
     hipError_t e = upa_full_lds<nms_sort_kernel>();
     if (e != hipSuccess) { upa_set_error("nms: cannot raise LDS limit: %s", hipGetErrorString(e)); return UPA_ELAUNCH; }
   }
-  // long candidate lists (multi-label validation): first only the top LDS_SORT_CAP candidates, sorted in LDS - the full top-max_nms
-  // select + global-memory sort (8.4 ms per batch-32 call, two thirds of the validate step's GPU time) only for images whose greedy
-  // pass ran out of candidates before max_det boxes were kept
-  const bool two_stage = cap > LDS_SORT_CAP && max_nms > LDS_SORT_CAP;
   hipLaunchKernelGGL(nms_sort_kernel, dim3((unsigned)b), dim3(SORT_NT), LDS_SORT_CAP * 8, s, count, nsorted, keys, sel,
                      cap, selcap, max_nms, best_keys, nc, a, conf_thres, classes_mask, two_stage ? LDS_SORT_CAP : 0, partial,
-                     (const int*)nullptr);
+                     (const int*)nullptr, (const int*)coarse);
   UPA_LAUNCH_CHECK();
   hipLaunchKernelGGL(nms_greedy_kernel, dim3((unsigned)b), dim3(GREEDY_NT), 0, s, pred, nc, a, nsorted, sel, selcap,
                      iou_thres, agnostic, max_wh, max_det, out, counts, keep_idx, (const int*)partial, two_stage ? redo : (int*)nullptr,
@@ -484,7 +588,8 @@ static int nms_batched_impl(const float* pred, int b, int nc, int a, float conf_
   UPA_LAUNCH_CHECK();
   if (two_stage) {
     hipLaunchKernelGGL(nms_sort_kernel, dim3((unsigned)b), dim3(SORT_NT), LDS_SORT_CAP * 8, s, count, nsorted, keys, sel,
-                       cap, selcap, max_nms, best_keys, nc, a, conf_thres, classes_mask, 0, partial, (const int*)redo);
+                       cap, selcap, max_nms, best_keys, nc, a, conf_thres, classes_mask, 0, partial, (const int*)redo,
+                       (const int*)nullptr);
     hipLaunchKernelGGL(nms_greedy_kernel, dim3((unsigned)b), dim3(GREEDY_NT), 0, s, pred, nc, a, nsorted, sel, selcap,
                        iou_thres, agnostic, max_wh, max_det, out, counts, keep_idx, (const int*)nullptr, (int*)nullptr, (const int*)redo);
     UPA_LAUNCH_CHECK();
