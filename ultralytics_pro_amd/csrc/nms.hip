@@ -93,35 +93,48 @@ __global__ __launch_bounds__(256) void nms_candidates_kernel(const float* pred, 
       for (int i = threadIdx.x; i < COARSE_BINS; i += 256) lh[i] = 0;
       __syncthreads();
     }
-    // eight class rows in flight per lane, and ONE reservation in count[b] per wave and group of eight classes (the wave counts its
-    // candidates of the group first): a load and a same-address global atomic per class left this loop at two memory round trips per
-    // class (2.0 ms per validation batch)
+    // Two sweeps over the workgroup's 256 x nc scores (the second one hits L2).  Sweep 1 counts: every wave adds up its candidates
+    // (ballots, scalar), the four waves reserve inside the workgroup (LDS) and the workgroup reserves ONCE in count[b] - one
+    // same-address global atomic per 256 anchors.  (One per wave and group of eight classes were 1320 serialised atomics per image at
+    // A = 8400: they, not the 86 MB of scores and 170 MB of keys, were the 0.29 ms this kernel took per validation batch.)  Sweep 2
+    // writes the keys: the lanes of a wave that hold a candidate of one class take adjacent slots.
+    __shared__ int blk_n, blk_base;
+    if (threadIdx.x == 0) blk_n = 0;
+    __syncthreads();
+    int wave_tot = 0;
     for (int c0 = 0; c0 < nc; c0 += 8) {
       float v[8];
-      u64 m[8];
-      int tot = 0;
 #pragma unroll
       for (int q = 0; q < 8; ++q) v[q] = (valid && c0 + q < nc) ? pb[(size_t)(c0 + q) * A] : -INFINITY;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const bool cand = valid && c0 + q < nc && v[q] > conf && (!cmask || cmask[c0 + q]);
-        m[q] = __ballot(cand);
-        tot += __popcll(m[q]);
-      }
-      if (tot == 0) continue;  // uniform
-      int base = 0;
-      if (lane == 0) base = atomicAdd(&count[b], tot);
-      base = __shfl(base, 0);
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        if ((m[q] >> lane) & 1ull) {
-          const int slot = base + __popcll(m[q] & ((1ull << lane) - 1ull));
-          if (slot >= 0 && slot < cap) kb[slot] = ((u64)(~__float_as_uint(v[q])) << 32) | (unsigned)(a * nc + c0 + q);
-          if (coarse) atomicAdd(&lh[coarse_bin(~__float_as_uint(v[q]))], 1);
-        }
-        base += __popcll(m[q]);
+        wave_tot += __popcll(__ballot(cand));
+        if (coarse && cand) atomicAdd(&lh[coarse_bin(~__float_as_uint(v[q]))], 1);
       }
     }
+    int base = 0;
+    if (lane == 0 && wave_tot) base = atomicAdd(&blk_n, wave_tot);
+    __syncthreads();
+    if (threadIdx.x == 0 && blk_n) blk_base = atomicAdd(&count[b], blk_n);
+    __syncthreads();
+    base = __shfl(base, 0) + blk_base;
+    if (wave_tot)  // uniform
+      for (int c0 = 0; c0 < nc; c0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = (valid && c0 + q < nc) ? pb[(size_t)(c0 + q) * A] : -INFINITY;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const bool cand = valid && c0 + q < nc && v[q] > conf && (!cmask || cmask[c0 + q]);
+          const u64 m = __ballot(cand);
+          if (cand) {
+            const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (slot >= 0 && slot < cap) kb[slot] = ((u64)(~__float_as_uint(v[q])) << 32) | (unsigned)(a * nc + c0 + q);
+          }
+          base += __popcll(m);
+        }
+      }
     if (coarse) {
       __syncthreads();
       int* gh = coarse + (size_t)b * COARSE_BINS;
