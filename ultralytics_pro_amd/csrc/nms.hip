@@ -40,8 +40,9 @@ __device__ __forceinline__ int coarse_bin(unsigned inv_score_bits) {
 
 __global__ __launch_bounds__(256) void nms_candidates_kernel(const float* pred, int B, int nc, int A, float conf,
                                                              int multi_label, const uint8_t* cmask, int* count, u64* keys,
-                                                             long cap, int* coarse) {
+                                                             long cap, int* coarse, const int* only_redo) {
   const int b = blockIdx.y;
+  if (only_redo && !only_redo[b]) return;
   const int a = blockIdx.x * 256 + threadIdx.x;
   const bool valid = a < A;
   const float* pb = pred + (size_t)b * (4 + nc) * A + (size_t)4 * A + (valid ? a : 0);
@@ -144,6 +145,134 @@ __global__ __launch_bounds__(256) void nms_candidates_kernel(const float* pred, 
   }
 }
 
+// Where the running count of an image's coarse histogram crosses `target`: bstar = the crossing bin, m = candidates in the bins before it
+// (bstar = -1: fewer than target candidates), total = all candidates.  Whole workgroup of NT threads.
+template <int NT>
+__device__ void coarse_split(const int* gh, int target, int& bstar, int& m, int& total) {
+  __shared__ int wsum[NT / 64];
+  __shared__ int s_b, s_m;
+  constexpr int PER = COARSE_BINS / NT;
+  int c[PER], t = 0;
+#pragma unroll
+  for (int q = 0; q < PER; ++q) { c[q] = gh[threadIdx.x * PER + q]; t += c[q]; }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = t;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(incl, d);
+    if (lane >= d) incl += o;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  if (threadIdx.x == 0) { s_b = -1; s_m = 0; }
+  __syncthreads();
+  int before = incl - t;
+  total = 0;
+  for (int w2 = 0; w2 < NT / 64; ++w2) {
+    if (w2 < wave) before += wsum[w2];
+    total += wsum[w2];
+  }
+  if (before < target && before + t >= target) {  // exactly one thread: the crossing bin is one of its PER
+    int cum = before, q = 0;
+    for (; q < PER; ++q) {
+      if (cum + c[q] >= target) break;
+      cum += c[q];
+    }
+    s_b = threadIdx.x * PER + q;
+    s_m = cum;
+  }
+  __syncthreads();
+  bstar = s_b;
+  m = s_m;
+  __syncthreads();  // (the shared words may be rewritten by a second call)
+}
+
+__device__ __forceinline__ bool coarse_prefix_usable(int total, int target, int bstar, int m) {
+  return total > target && bstar > 0 && m >= target / 4 && m <= target;
+}
+
+// Multi-label candidates of long lists, first half: ONLY the coarse score histogram of every image (no keys yet).
+__global__ __launch_bounds__(256) void nms_hist_kernel(const float* pred, int nc, int A, float conf, const uint8_t* cmask,
+                                                       int* coarse) {
+  const int b = blockIdx.y;
+  const int a = blockIdx.x * 256 + threadIdx.x;
+  const bool valid = a < A;
+  const float* pb = pred + (size_t)b * (4 + nc) * A + (size_t)4 * A + (valid ? a : 0);
+  __shared__ int lh[COARSE_BINS];
+  for (int i = threadIdx.x; i < COARSE_BINS; i += 256) lh[i] = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < nc; c0 += 8) {
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = (valid && c0 + q < nc) ? pb[(size_t)(c0 + q) * A] : -INFINITY;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (valid && c0 + q < nc && v[q] > conf && (!cmask || cmask[c0 + q])) atomicAdd(&lh[coarse_bin(~__float_as_uint(v[q]))], 1);
+  }
+  __syncthreads();
+  int* gh = coarse + (size_t)b * COARSE_BINS;
+  for (int i = threadIdx.x; i < COARSE_BINS; i += 256)
+    if (lh[i]) atomicAdd(&gh[i], lh[i]);
+}
+
+// Second half: every workgroup finds the image's prefix bin from the finished histogram (the same few hundred additions in each of the
+// image's workgroups - cheaper than another launch), then sweeps its 256 x nc scores again and writes keys ONLY for the candidates of
+// the prefix (coarse bin < bstar: fewer than `target` per image) - straight into the image's sorted-list buffer `sel`, where the sort
+// kernel picks them up.  The other candidates (up to A * nc = 672 k per image, 170 MB of keys per validation batch) are never
+// written unless the greedy pass flags the image (nms_candidates_kernel with `only_redo` then writes them all).  Images without a
+// usable prefix (few candidates, or one bin holds them all) get all their keys into `keys` here: mode[b] = 0.
+__global__ __launch_bounds__(256) void nms_emit_kernel(const float* pred, int nc, int A, float conf, const uint8_t* cmask,
+                                                       const int* coarse, int target, int* count, int* mode, int* pcount, u64* keys,
+                                                       long cap, u64* sel, int selcap) {
+  const int b = blockIdx.y;
+  const int a = blockIdx.x * 256 + threadIdx.x;
+  const bool valid = a < A;
+  const float* pb = pred + (size_t)b * (4 + nc) * A + (size_t)4 * A + (valid ? a : 0);
+  const int lane = threadIdx.x & 63;
+  int bstar, m, total;
+  coarse_split<256>(coarse + (size_t)b * COARSE_BINS, target, bstar, m, total);
+  const bool usable = coarse_prefix_usable(total, target, bstar, m) && m <= selcap;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { mode[b] = usable ? 1 : 0; count[b] = total; }
+  const int lim = usable ? bstar : COARSE_BINS;
+  u64* dst = usable ? sel + (size_t)b * selcap : keys + (size_t)b * cap;
+  const long dcap = usable ? (long)selcap : cap;
+  __shared__ int blk_n, blk_base;
+  if (threadIdx.x == 0) blk_n = 0;
+  __syncthreads();
+  int wave_tot = 0;
+  for (int c0 = 0; c0 < nc; c0 += 8) {
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = (valid && c0 + q < nc) ? pb[(size_t)(c0 + q) * A] : -INFINITY;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const bool cand = valid && c0 + q < nc && v[q] > conf && (!cmask || cmask[c0 + q]) && coarse_bin(~__float_as_uint(v[q])) < lim;
+      wave_tot += __popcll(__ballot(cand));
+    }
+  }
+  int base = 0;
+  if (lane == 0 && wave_tot) base = atomicAdd(&blk_n, wave_tot);
+  __syncthreads();
+  if (threadIdx.x == 0 && blk_n) blk_base = atomicAdd(&pcount[b], blk_n);
+  __syncthreads();
+  if (!wave_tot) return;  // uniform
+  base = __shfl(base, 0) + blk_base;
+  for (int c0 = 0; c0 < nc; c0 += 8) {
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = (valid && c0 + q < nc) ? pb[(size_t)(c0 + q) * A] : -INFINITY;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const bool cand = valid && c0 + q < nc && v[q] > conf && (!cmask || cmask[c0 + q]) && coarse_bin(~__float_as_uint(v[q])) < lim;
+      const u64 mk = __ballot(cand);
+      if (cand) {
+        const int slot = base + __popcll(mk & ((1ull << lane) - 1ull));
+        if (slot >= 0 && slot < dcap) dst[slot] = ((u64)(~__float_as_uint(v[q])) << 32) | (unsigned)(a * nc + c0 + q);
+      }
+      base += __popcll(mk);
+    }
+  }
+}
+
 // bitonic sort of `buf[0..npad)` (npad power of two) ascending, all threads of the workgroup
 template <int NT>
 __device__ void bitonic_sort(u64* buf, int npad) {
@@ -177,7 +306,8 @@ constexpr int LDS_SORT_CAP = 16384;  // u64 -> 128 KiB of dynamic LDS (covers ev
 __global__ __launch_bounds__(SORT_NT) void nms_sort_kernel(const int* count, int* nsorted, u64* keys, u64* sel, long cap,
                                                            int selcap, int max_nms, const u64* best_keys, int nc, int A,
                                                            float conf, const uint8_t* cmask, int prefix, int* partial,
-                                                           const int* only_redo, const int* coarse) {
+                                                           const int* only_redo, const int* coarse, const int* mode,
+                                                           const int* pcount) {
   if (only_redo && !only_redo[blockIdx.x]) return;
   extern __shared__ __attribute__((aligned(16))) u64 lbuf[];  // LDS_SORT_CAP keys
   __shared__ int hist[256];
@@ -221,43 +351,31 @@ __global__ __launch_bounds__(SORT_NT) void nms_sort_kernel(const int* count, int
   if (n > cap) n = (int)cap;
   const int target = (prefix > 0 && prefix < max_nms) ? prefix : max_nms;  // how many of the best candidates this call keeps
   if (partial && threadIdx.x == 0) partial[b] = (prefix > 0 && n > target && target < max_nms) ? 1 : 0;
-  // First stage with the image's coarse score histogram (filled by the candidates kernel): the sorted prefix need not be exactly
-  // `target` long - any prefix of the score order does, the greedy pass flags the image when it runs out.  So the prefix is "every key
-  // in the coarse bins before the one where the running count crosses target": found from the histogram alone, then ONE pass over the
-  // n keys compacts those (fewer than target <= LDS_SORT_CAP) straight into LDS, where they are sorted.  No radix select (three to five
-  // passes over up to A * nc keys through this one workgroup, then the compaction pass: 0.59 ms per validation batch).
+  // The prefix keys of this image were written by nms_emit_kernel (mode[b] = 1): pcount[b] of them (fewer than target), in `sb`
+  if (mode && mode[b] && prefix > 0) {
+    n = pcount[b];
+    if (n > LDS_SORT_CAP) n = LDS_SORT_CAP;  // (cannot happen: m <= target <= LDS_SORT_CAP)
+    int npad = 2;
+    while (npad < n) npad <<= 1;
+    for (int i = threadIdx.x; i < npad; i += SORT_NT) lbuf[i] = i < n ? sb[i] : ~0ull;
+    __syncthreads();
+    bitonic_sort<SORT_NT>(lbuf, npad);
+    for (int i = threadIdx.x; i < n; i += SORT_NT) sb[i] = lbuf[i];
+    if (threadIdx.x == 0) nsorted[b] = n;
+    return;
+  }
+  // A prefix from the image's coarse score histogram: the sorted prefix need not be exactly `target` long - any prefix of the score
+  // order does, the greedy pass flags the image when it runs out.  So the prefix is "every key in the coarse bins before the one where
+  // the running count crosses target": found from the histogram alone, then ONE pass over the n keys compacts those (fewer than target
+  // <= LDS_SORT_CAP) straight into LDS, where they are sorted.  No radix select (three to five passes over up to A * nc keys through
+  // this one workgroup, then the compaction pass: 0.59 ms per validation batch).
   if (coarse && prefix > 0 && n > target && target < max_nms && target <= LDS_SORT_CAP) {
-    __shared__ int wsum[SORT_NT / 64];
-    __shared__ int s_bstar, s_m;
-    const int* gh = coarse + (size_t)b * COARSE_BINS;
-    constexpr int PER = COARSE_BINS / SORT_NT;
-    int c[PER], t = 0;
-#pragma unroll
-    for (int q = 0; q < PER; ++q) { c[q] = gh[threadIdx.x * PER + q]; t += c[q]; }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int incl = t;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int o = __shfl_up(incl, d);
-      if (lane >= d) incl += o;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    if (threadIdx.x == 0) { s_bstar = -1; s_m = 0; s_n = 0; }
+    int bstar, m, total;
+    coarse_split<SORT_NT>(coarse + (size_t)b * COARSE_BINS, target, bstar, m, total);
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
-    int before = incl - t;
-    for (int w2 = 0; w2 < wave; ++w2) before += wsum[w2];
-    if (before < target && before + t >= target) {  // exactly one thread: the crossing bin is one of its PER
-      int cum = before, q = 0;
-      for (; q < PER; ++q) {
-        if (cum + c[q] >= target) break;
-        cum += c[q];
-      }
-      s_bstar = threadIdx.x * PER + q;
-      s_m = cum;
-    }
-    __syncthreads();
-    const int bstar = s_bstar, m = s_m;
-    if (bstar > 0 && m >= target / 4 && m <= LDS_SORT_CAP) {  // (uniform) else: the exact path below
+    if (coarse_prefix_usable(n, target, bstar, m)) {  // (uniform) else: the exact path below
       constexpr int U = 8;
       for (int i0 = threadIdx.x; i0 < n; i0 += U * SORT_NT) {
         u64 k[U];
@@ -529,6 +647,15 @@ inline bool no_coarse_env() {  // A/B switch for tools/: UPA_NMS_NO_COARSE=1 kee
   static const bool v = [] { const char* e = getenv("UPA_NMS_NO_COARSE"); return e && e[0] == '1'; }();
   return v;
 }
+inline bool no_emit_env() {  // UPA_NMS_NO_EMIT=1: all keys are written up front, the sort kernel's pass picks the prefix
+  static const bool v = [] { const char* e = getenv("UPA_NMS_NO_EMIT"); return e && e[0] == '1'; }();
+  return v;
+}
+inline int first_prefix_env() {  // A/B switch for tools/: UPA_NMS_FIRST_PREFIX=<n> (0: no short first stage)
+  static const int v = [] { const char* e = getenv("UPA_NMS_FIRST_PREFIX"); return e ? atoi(e) : 4096; }();
+  return v;
+}
+constexpr int NMS_COUNTERS = 8;  // int arrays of length B in front of the workspace: count, nsorted, partial, redo, redo (second stage), spare
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline int pow2_ge(int v) {
   int p = 1;
@@ -541,7 +668,7 @@ inline int pow2_ge(int v) {
 extern "C" size_t upa_nms_workspace_bytes(int b, int nc, int a, int multi_label, int max_nms) {
   const size_t cap = (size_t)a * (multi_label ? nc : 1);
   const size_t selcap = (size_t)pow2_ge(max_nms < 2 ? 2 : max_nms);
-  const size_t counters = (size_t)b * 4 + (multi_label ? (size_t)b * COARSE_BINS : 0);  // count, nsorted, partial, redo (+ coarse histograms)
+  const size_t counters = (size_t)b * NMS_COUNTERS + (multi_label ? (size_t)b * COARSE_BINS : 0);  // count, nsorted, partial, redo flags (+ coarse histograms)
   return 256 + align_up(counters * sizeof(int), 256) + (size_t)b * cap * 8 + (size_t)b * selcap * 8;
 }
 
@@ -571,7 +698,7 @@ static int nms_batched_impl(const float* pred, int b, int nc, int a, float conf_
   int* nsorted = count + b;
   int* partial = count + 2 * b;
   int* redo = count + 3 * b;
-  ws += align_up(((size_t)b * 4 + (ws_has_coarse ? (size_t)b * COARSE_BINS : 0)) * sizeof(int), 256);
+  ws += align_up(((size_t)b * NMS_COUNTERS + (ws_has_coarse ? (size_t)b * COARSE_BINS : 0)) * sizeof(int), 256);
   u64* keys = (u64*)ws;
   u64* sel = keys + (size_t)b * cap;
   hipStream_t s = (hipStream_t)stream;
@@ -581,30 +708,48 @@ static int nms_batched_impl(const float* pred, int b, int nc, int a, float conf_
   // full top-max_nms select + global-memory sort (8.4 ms per batch-32 call, two thirds of the validate step's GPU time) only for images
   // whose greedy pass ran out of candidates before max_det boxes were kept
   const bool two_stage = cap > LDS_SORT_CAP && max_nms > LDS_SORT_CAP;
-  int* coarse = (two_stage && multi_label && !best_keys && !no_coarse_env()) ? count + 4 * b : nullptr;
-  if (!best_keys) upa_zero_words(count, coarse ? 4 * b + b * COARSE_BINS : 2 * b, s);
-  if (!best_keys)  // (with best-class keys the sort kernel compacts its own candidates)
-    hipLaunchKernelGGL(nms_candidates_kernel, dim3((unsigned)cdiv(a, 256), (unsigned)b), dim3(256), 0, s, pred, b, nc, a,
-                       conf_thres, multi_label, classes_mask, count, keys, cap, coarse);
+  int* coarse = (two_stage && multi_label && !best_keys && !no_coarse_env()) ? count + NMS_COUNTERS * b : nullptr;
+  int prefixes[3], np = 0;
+  if (two_stage && coarse && first_prefix_env() > 0 && first_prefix_env() < LDS_SORT_CAP) prefixes[np++] = first_prefix_env();
+  if (two_stage) prefixes[np++] = LDS_SORT_CAP;
+  prefixes[np++] = 0;
+  // with the histogram, the first prefix's keys are the only ones written up front (nms_hist_kernel + nms_emit_kernel)
+  const bool emit = coarse && !no_emit_env();
+  int *redo2 = count + 4 * b, *mode = count + 5 * b, *pcount = count + 6 * b, *count2 = count + 7 * b;
+  if (!best_keys) upa_zero_words(count, coarse ? NMS_COUNTERS * b + b * COARSE_BINS : 2 * b, s);
+  const dim3 cgrid((unsigned)cdiv(a, 256), (unsigned)b);
+  if (emit) {
+    hipLaunchKernelGGL(nms_hist_kernel, cgrid, dim3(256), 0, s, pred, nc, a, conf_thres, classes_mask, coarse);
+    hipLaunchKernelGGL(nms_emit_kernel, cgrid, dim3(256), 0, s, pred, nc, a, conf_thres, classes_mask, (const int*)coarse, prefixes[0],
+                       count, mode, pcount, keys, cap, sel, selcap);
+  } else if (!best_keys) {  // (with best-class keys the sort kernel compacts its own candidates)
+    hipLaunchKernelGGL(nms_candidates_kernel, cgrid, dim3(256), 0, s, pred, b, nc, a, conf_thres, multi_label, classes_mask, count,
+                       keys, cap, coarse, (const int*)nullptr);
+  }
   UPA_LAUNCH_CHECK();
   {
     hipError_t e = upa_full_lds<nms_sort_kernel>();
     if (e != hipSuccess) { upa_set_error("nms: cannot raise LDS limit: %s", hipGetErrorString(e)); return UPA_ELAUNCH; }
   }
-  hipLaunchKernelGGL(nms_sort_kernel, dim3((unsigned)b), dim3(SORT_NT), LDS_SORT_CAP * 8, s, count, nsorted, keys, sel,
-                     cap, selcap, max_nms, best_keys, nc, a, conf_thres, classes_mask, two_stage ? LDS_SORT_CAP : 0, partial,
-                     (const int*)nullptr, (const int*)coarse);
-  UPA_LAUNCH_CHECK();
-  hipLaunchKernelGGL(nms_greedy_kernel, dim3((unsigned)b), dim3(GREEDY_NT), 0, s, pred, nc, a, nsorted, sel, selcap,
-                     iou_thres, agnostic, max_wh, max_det, out, counts, keep_idx, (const int*)partial, two_stage ? redo : (int*)nullptr,
-                     (const int*)nullptr);
-  UPA_LAUNCH_CHECK();
-  if (two_stage) {
-    hipLaunchKernelGGL(nms_sort_kernel, dim3((unsigned)b), dim3(SORT_NT), LDS_SORT_CAP * 8, s, count, nsorted, keys, sel,
-                       cap, selcap, max_nms, best_keys, nc, a, conf_thres, classes_mask, 0, partial, (const int*)redo,
-                       (const int*)nullptr);
+  // Stages: (sort a prefix of the score order, greedy pass) pairs over growing prefixes; a pair after the first only works on the
+  // images the greedy pass before it flagged (it ran out of candidates before max_det boxes were kept - every other workgroup returns
+  // at once), the last pair is the full top-max_nms path.  With the coarse histogram a prefix costs little, so the first one is short
+  // (about 4096 candidates: a bitonic sort a quarter the length of the LDS_SORT_CAP one).
+  int* flags[3] = {redo, redo2, nullptr};  // written by pair i, read by pair i + 1 (redo2 only exists zeroed: `coarse`)
+  for (int i = 0; i < np; ++i) {
+    const int* only = i ? flags[i - 1] : nullptr;
+    const bool last = i == np - 1;
+    if (emit && i == 1)  // flagged images: now all their keys (own slot counter: count[] already holds the images' totals)
+      hipLaunchKernelGGL(nms_candidates_kernel, cgrid, dim3(256), 0, s, pred, b, nc, a, conf_thres, multi_label, classes_mask, count2,
+                         keys, cap, (int*)nullptr, only);
+    hipLaunchKernelGGL(nms_sort_kernel, dim3((unsigned)b), dim3(SORT_NT), LDS_SORT_CAP * 8, s, (const int*)((emit && i) ? count2 : count),
+                       nsorted, keys, sel, cap, selcap, max_nms, best_keys, nc, a, conf_thres, classes_mask, prefixes[i], partial, only,
+                       (const int*)((last || (emit && i == 0)) ? nullptr : coarse), (const int*)((emit && i == 0) ? mode : nullptr),
+                       (const int*)pcount);
+    UPA_LAUNCH_CHECK();
     hipLaunchKernelGGL(nms_greedy_kernel, dim3((unsigned)b), dim3(GREEDY_NT), 0, s, pred, nc, a, nsorted, sel, selcap,
-                       iou_thres, agnostic, max_wh, max_det, out, counts, keep_idx, (const int*)nullptr, (int*)nullptr, (const int*)redo);
+                       iou_thres, agnostic, max_wh, max_det, out, counts, keep_idx, (const int*)(last ? nullptr : partial),
+                       last ? (int*)nullptr : flags[i], only);
     UPA_LAUNCH_CHECK();
   }
   return UPA_OK;
