@@ -18,7 +18,7 @@ python3 - $f <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 nb = max(int(r['Calls']) for r in rows if 'candidates' in r['Name'])
-for r in rows[:10]:
+for r in [r for r in rows if 'nms' in r['Name'] or 'zero' in r['Name']] + rows[:6]:
     print(f"{r['Name'][:70]:70s} {r['Calls']:>5s} calls {int(r['TotalDurationNs'])/1e3/nb:8.1f} us/batch  avg {float(r['AverageNs'])/1e3:7.1f} us")
 print("all kernels:", round(sum(int(r['TotalDurationNs']) for r in rows) / 1e3 / nb, 1), "us/batch")
 PY

@@ -191,8 +191,10 @@ __device__ __forceinline__ bool coarse_prefix_usable(int total, int target, int 
 }
 
 // Multi-label candidates of long lists, first half: ONLY the coarse score histogram of every image (no keys yet).
+// Also: the best (lowest) coarse bin among each wave's candidates, wave_best[b][wave] - the emit kernel skips the waves that hold no
+// candidate of the prefix without reading their scores again.
 __global__ __launch_bounds__(256) void nms_hist_kernel(const float* pred, int nc, int A, float conf, const uint8_t* cmask,
-                                                       int* coarse) {
+                                                       int* coarse, int* wave_best) {
   const int b = blockIdx.y;
   const int a = blockIdx.x * 256 + threadIdx.x;
   const bool valid = a < A;
@@ -200,14 +202,25 @@ __global__ __launch_bounds__(256) void nms_hist_kernel(const float* pred, int nc
   __shared__ int lh[COARSE_BINS];
   for (int i = threadIdx.x; i < COARSE_BINS; i += 256) lh[i] = 0;
   __syncthreads();
+  int best = COARSE_BINS;  // (no candidate)
   for (int c0 = 0; c0 < nc; c0 += 8) {
     float v[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) v[q] = (valid && c0 + q < nc) ? pb[(size_t)(c0 + q) * A] : -INFINITY;
 #pragma unroll
     for (int q = 0; q < 8; ++q)
-      if (valid && c0 + q < nc && v[q] > conf && (!cmask || cmask[c0 + q])) atomicAdd(&lh[coarse_bin(~__float_as_uint(v[q]))], 1);
+      if (valid && c0 + q < nc && v[q] > conf && (!cmask || cmask[c0 + q])) {
+        const int bin = coarse_bin(~__float_as_uint(v[q]));
+        atomicAdd(&lh[bin], 1);
+        best = bin < best ? bin : best;
+      }
   }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    const int o = __shfl_xor(best, d);
+    best = o < best ? o : best;
+  }
+  if ((threadIdx.x & 63) == 0) wave_best[((size_t)b * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)] = best;
   __syncthreads();
   int* gh = coarse + (size_t)b * COARSE_BINS;
   for (int i = threadIdx.x; i < COARSE_BINS; i += 256)
@@ -221,8 +234,8 @@ __global__ __launch_bounds__(256) void nms_hist_kernel(const float* pred, int nc
 // written unless the greedy pass flags the image (nms_candidates_kernel with `only_redo` then writes them all).  Images without a
 // usable prefix (few candidates, or one bin holds them all) get all their keys into `keys` here: mode[b] = 0.
 __global__ __launch_bounds__(256) void nms_emit_kernel(const float* pred, int nc, int A, float conf, const uint8_t* cmask,
-                                                       const int* coarse, int target, int* count, int* mode, int* pcount, u64* keys,
-                                                       long cap, u64* sel, int selcap) {
+                                                       const int* coarse, const int* wave_best, int target, int* count, int* mode,
+                                                       int* pcount, u64* keys, long cap, u64* sel, int selcap) {
   const int b = blockIdx.y;
   const int a = blockIdx.x * 256 + threadIdx.x;
   const bool valid = a < A;
@@ -235,42 +248,50 @@ __global__ __launch_bounds__(256) void nms_emit_kernel(const float* pred, int nc
   const int lim = usable ? bstar : COARSE_BINS;
   u64* dst = usable ? sel + (size_t)b * selcap : keys + (size_t)b * cap;
   const long dcap = usable ? (long)selcap : cap;
-  __shared__ int blk_n, blk_base;
-  if (threadIdx.x == 0) blk_n = 0;
+  // One sweep: the workgroup's prefix candidates (about target / workgroups-per-image of them) are collected in LDS, then the workgroup
+  // reserves their slots with ONE atomic in pcount[b] and copies them out.  Candidates beyond the LDS buffer (only when one workgroup holds
+  // a large part of the list: a few candidates in all, or the one-bin fallback) take slots straight from pcount[b], one atomic per ballot.
+  constexpr int LCAP = 1024;
+  __shared__ u64 staged[LCAP];
+  __shared__ int s_cnt, blk_base;
+  if (threadIdx.x == 0) s_cnt = 0;
   __syncthreads();
-  int wave_tot = 0;
-  for (int c0 = 0; c0 < nc; c0 += 8) {
-    float v[8];
+  const bool wave_has = wave_best[((size_t)b * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)] < lim;  // uniform per wave
+  if (wave_has)
+    for (int c0 = 0; c0 < nc; c0 += 8) {
+      float v[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = (valid && c0 + q < nc) ? pb[(size_t)(c0 + q) * A] : -INFINITY;
+      for (int q = 0; q < 8; ++q) v[q] = (valid && c0 + q < nc) ? pb[(size_t)(c0 + q) * A] : -INFINITY;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const bool cand = valid && c0 + q < nc && v[q] > conf && (!cmask || cmask[c0 + q]) && coarse_bin(~__float_as_uint(v[q])) < lim;
-      wave_tot += __popcll(__ballot(cand));
-    }
-  }
-  int base = 0;
-  if (lane == 0 && wave_tot) base = atomicAdd(&blk_n, wave_tot);
-  __syncthreads();
-  if (threadIdx.x == 0 && blk_n) blk_base = atomicAdd(&pcount[b], blk_n);
-  __syncthreads();
-  if (!wave_tot) return;  // uniform
-  base = __shfl(base, 0) + blk_base;
-  for (int c0 = 0; c0 < nc; c0 += 8) {
-    float v[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = (valid && c0 + q < nc) ? pb[(size_t)(c0 + q) * A] : -INFINITY;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const bool cand = valid && c0 + q < nc && v[q] > conf && (!cmask || cmask[c0 + q]) && coarse_bin(~__float_as_uint(v[q])) < lim;
-      const u64 mk = __ballot(cand);
-      if (cand) {
+      for (int q = 0; q < 8; ++q) {
+        const bool cand = valid && c0 + q < nc && v[q] > conf && (!cmask || cmask[c0 + q]) && coarse_bin(~__float_as_uint(v[q])) < lim;
+        const u64 mk = __ballot(cand);
+        if (!mk) continue;  // uniform
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&s_cnt, __popcll(mk));
+        base = __shfl(base, 0);
         const int slot = base + __popcll(mk & ((1ull << lane) - 1ull));
-        if (slot >= 0 && slot < dcap) dst[slot] = ((u64)(~__float_as_uint(v[q])) << 32) | (unsigned)(a * nc + c0 + q);
+        const u64 key = ((u64)(~__float_as_uint(v[q])) << 32) | (unsigned)(a * nc + c0 + q);
+        if (cand && slot < LCAP) staged[slot] = key;
+        const u64 over = __ballot(cand && slot >= LCAP);
+        if (over) {  // uniform
+          int gbase = 0;
+          if (lane == 0) gbase = atomicAdd(&pcount[b], __popcll(over));
+          gbase = __shfl(gbase, 0);
+          const int gs = gbase + __popcll(over & ((1ull << lane) - 1ull));
+          if (cand && slot >= LCAP && gs >= 0 && gs < dcap) dst[gs] = key;
+        }
       }
-      base += __popcll(mk);
     }
-  }
+  __syncthreads();
+  const int nl = s_cnt < LCAP ? s_cnt : LCAP;
+  if (threadIdx.x == 0 && nl) blk_base = atomicAdd(&pcount[b], nl);
+  __syncthreads();
+  if (nl)
+    for (int i = threadIdx.x; i < nl; i += 256) {
+      const int gs = blk_base + i;
+      if (gs >= 0 && gs < dcap) dst[gs] = staged[i];
+    }
 }
 
 // bitonic sort of `buf[0..npad)` (npad power of two) ascending, all threads of the workgroup
@@ -668,7 +689,8 @@ inline int pow2_ge(int v) {
 extern "C" size_t upa_nms_workspace_bytes(int b, int nc, int a, int multi_label, int max_nms) {
   const size_t cap = (size_t)a * (multi_label ? nc : 1);
   const size_t selcap = (size_t)pow2_ge(max_nms < 2 ? 2 : max_nms);
-  const size_t counters = (size_t)b * NMS_COUNTERS + (multi_label ? (size_t)b * COARSE_BINS : 0);  // count, nsorted, partial, redo flags (+ coarse histograms)
+  // count, nsorted, partial, redo flags (+ coarse histograms and per-wave best bins)
+  const size_t counters = (size_t)b * NMS_COUNTERS + (multi_label ? (size_t)b * (COARSE_BINS + 4 * (size_t)cdiv(a, 256)) : 0);
   return 256 + align_up(counters * sizeof(int), 256) + (size_t)b * cap * 8 + (size_t)b * selcap * 8;
 }
 
@@ -698,7 +720,7 @@ static int nms_batched_impl(const float* pred, int b, int nc, int a, float conf_
   int* nsorted = count + b;
   int* partial = count + 2 * b;
   int* redo = count + 3 * b;
-  ws += align_up(((size_t)b * NMS_COUNTERS + (ws_has_coarse ? (size_t)b * COARSE_BINS : 0)) * sizeof(int), 256);
+  ws += align_up(((size_t)b * NMS_COUNTERS + (ws_has_coarse ? (size_t)b * (COARSE_BINS + 4 * (size_t)cdiv(a, 256)) : 0)) * sizeof(int), 256);
   u64* keys = (u64*)ws;
   u64* sel = keys + (size_t)b * cap;
   hipStream_t s = (hipStream_t)stream;
@@ -715,13 +737,14 @@ static int nms_batched_impl(const float* pred, int b, int nc, int a, float conf_
   prefixes[np++] = 0;
   // with the histogram, the first prefix's keys are the only ones written up front (nms_hist_kernel + nms_emit_kernel)
   const bool emit = coarse && !no_emit_env();
+  int* wave_best = count + NMS_COUNTERS * b + b * COARSE_BINS;  // [B][4 * workgroups per image], every word written by nms_hist_kernel
   int *redo2 = count + 4 * b, *mode = count + 5 * b, *pcount = count + 6 * b, *count2 = count + 7 * b;
   if (!best_keys) upa_zero_words(count, coarse ? NMS_COUNTERS * b + b * COARSE_BINS : 2 * b, s);
   const dim3 cgrid((unsigned)cdiv(a, 256), (unsigned)b);
   if (emit) {
-    hipLaunchKernelGGL(nms_hist_kernel, cgrid, dim3(256), 0, s, pred, nc, a, conf_thres, classes_mask, coarse);
-    hipLaunchKernelGGL(nms_emit_kernel, cgrid, dim3(256), 0, s, pred, nc, a, conf_thres, classes_mask, (const int*)coarse, prefixes[0],
-                       count, mode, pcount, keys, cap, sel, selcap);
+    hipLaunchKernelGGL(nms_hist_kernel, cgrid, dim3(256), 0, s, pred, nc, a, conf_thres, classes_mask, coarse, wave_best);
+    hipLaunchKernelGGL(nms_emit_kernel, cgrid, dim3(256), 0, s, pred, nc, a, conf_thres, classes_mask, (const int*)coarse,
+                       (const int*)wave_best, prefixes[0], count, mode, pcount, keys, cap, sel, selcap);
   } else if (!best_keys) {  // (with best-class keys the sort kernel compacts its own candidates)
     hipLaunchKernelGGL(nms_candidates_kernel, cgrid, dim3(256), 0, s, pred, b, nc, a, conf_thres, multi_label, classes_mask, count,
                        keys, cap, coarse, (const int*)nullptr);
