@@ -573,7 +573,13 @@ def main_val(args):
     nb = max(1, args.input_batches)
     v = DetectionValidator(model)
     runs, labels = [], []
-    with torch.no_grad():
+    # four compiled steps in flight: the kernel selection of engine/pipeline.py's throughput mode (`--no-mode-dispatch`: library defaults)
+    from ultralytics_pro_amd import _lib as L
+    if args.opts:
+        R.set_default_opts(L.Opts.from_env() if args.opts == "env" else
+                           L.Opts(**{k: int(v) for k, v in (kv.split("=") for kv in args.opts.split(","))}))
+    mode = {} if (args.no_mode_dispatch or args.opts) else {"c2f": 4, "conv_ws3": 1, "c2f_stream_rows": -1}
+    with torch.no_grad(), (R.use_opts(**mode) if mode else contextlib.nullcontext()):
         for j in range(nb):
             first = (rank * nb + j) * pb
             xj = P.synthetic_images(pb, first=first).to(dev)
@@ -630,7 +636,7 @@ def main_val(args):
             "config": {"workload": f"{args.model} validate {args.imgsz}x{args.imgsz} bs={pb} {args.dtype}: 1 hipGraph/step = forward + "
                                    "NMS(conf .001, iou .7, multi_label, max_det 300) + upa_match_predictions",
                        "global_batch": pb * world, "per_gpu_batch": pb, "parallelism": f"dp{world} replicas",
-                       "val_set": f"{nb} batches per rank = {nb * pb * world} images", "steps_in_flight": len(lanes),
+                       "val_set": f"{nb} batches per rank = {nb * pb * world} images", "steps_in_flight": len(lanes), "dispatch_by_mode": mode or None, "dispatch_opts": args.opts or None,
                        "exchange": "end of run: all_gather_into_tensor of (rows, counts) and (gt classes, counts) over RCCL"},
             "images_per_sec_per_gpu": round(value / world, 1),
             "gather_and_map_ms": round(t_gather * 1e3, 3),

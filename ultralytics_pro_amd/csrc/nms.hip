@@ -6,13 +6,22 @@
 //  1. nms_candidates   (B x anchor-chunks workgroups)  per anchor: max/argmax over classes (first max wins) or every
 //                      class above conf (multi_label); survivors are appended as unique 64-bit keys
 //                        key = (~score_bits << 32) | (anchor*nc + cls)
-//                      with one wave-aggregated atomic per wave.  Ascending key order == score descending, ties by
+//                      with one slot reservation per workgroup.  Ascending key order == score descending, ties by
 //                      ascending candidate order == the stable sort of the reference's candidate list.
 //  2. nms_sort         (one 1024-thread workgroup per image)  if n > max_nms an MSB-first radix select finds the exact
 //                      max_nms-th key (keys are unique) and compacts; then a bitonic sort (LDS when it fits).
 //  3. nms_greedy       (one 512-thread workgroup per image)  walks the sorted candidates 64 at a time: every wave
 //                      tests the chunk against a slice of the kept list held in LDS, wave 0 resolves the in-chunk
-//                      dependencies with a 64x64 suppression bit matrix, appends survivors, stops at max_det.
+//                      dependencies over the chunk's set bits, appends survivors, stops at max_det.
+// Long multi-label lists (validation: conf 0.001, up to A * nc = 672 k candidates per image, max_nms 30000) run in stages instead:
+// the greedy pass almost always has its max_det boxes after the first thousand or so candidates, so (sort, greedy) pairs run over
+// growing PREFIXES of the score order and a pair after the first only touches the images the pass before it flagged (it ran out of
+// candidates before max_det boxes were kept).  A prefix is "the candidates in the coarse score bins before the one where the running
+// count crosses ~4096": nms_hist_kernel builds a 4096-bin score histogram per image (128 bins per octave), nms_emit_kernel finds that
+// bin and writes keys for the prefix only (one more sweep over the scores), nms_sort sorts them in LDS.  The full key list (170 MB per
+// batch of 32) is written only for flagged images (nms_candidates with `only_redo`), which then take the 16384-prefix and at last the
+// exact top-max_nms path.  The result is the reference's in every case: greedy NMS over the score-ordered candidates cut at max_nms,
+// cut at max_det.
 // IoU arithmetic follows the reference op for op in f32 (class offset added to the boxes first, areas from the offset
 // boxes, no eps, survivor iff iou <= thr); FP contraction is disabled so no FMA changes a keep/suppress decision.
 #include "common.h"
