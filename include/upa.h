@@ -69,6 +69,8 @@ typedef struct upa_opts {
   int32_t c2f_stream_rows; /* its output rows per workgroup: 0 = auto (one round of workgroups where possible) | even >= 4 | -1 = the whole image height (fewest pipeline fills: least total CU time, for several steps in flight) */
   int32_t no_stack_first;  /* Detect (host side, nn/modules/head.py): 1 = the two first convs of the 80 x 80 level stay two problems of one grid instead of one stacked 144-channel convolution; A/B */
   int32_t no_epi_stats;    /* upa_conv2d_bn_stats: 1 = the batch statistics always by a reduction pass over z (upa_bn_stats), never from the convolution's own workgroups; A/B */
+  int32_t nms_stages;      /* upa_nms_batched_opts, multi-label lists longer than 16384 (validation): 0 = prefix keys only (histogram + emit kernels), stages ~nms_first_prefix / ~16384 / exact | 1 = all keys written up front, the sort kernel's pass picks the prefix from the histogram | 2 = no histogram: radix select of the top 16384, then exact (the round-4 form); results identical, A/B */
+  int32_t nms_first_prefix; /* target length of the first sorted prefix there: 0 = 4096 | n in [256, 16384) | -1 = none (first prefix ~16384) */
 } upa_opts;
 
 /* Library / device info. Returns the ABI version (int); fills name with the kernel target ("gfx950"). */
@@ -300,6 +302,11 @@ int upa_nms_batched_hot(const float* pred, int b, int nc, int a, float conf_thre
                         int agnostic, const uint8_t* classes_mask, int max_det, int max_nms, float max_wh, float* out,
                         int32_t* counts, int32_t* keep_idx, void* workspace, size_t workspace_bytes,
                         const unsigned long long* best_keys, void* stream);
+/* upa_nms_batched with dispatch options (nms_stages, nms_first_prefix: how long multi-label lists are staged; NULL = defaults). */
+int upa_nms_batched_opts(const float* pred, int b, int nc, int a, float conf_thres, float iou_thres, int multi_label,
+                         int agnostic, const uint8_t* classes_mask, int max_det, int max_nms, float max_wh, float* out,
+                         int32_t* counts, int32_t* keep_idx, void* workspace, size_t workspace_bytes, const upa_opts* opts,
+                         void* stream);
 int upa_nms_batched(const float* pred, int b, int nc, int a, float conf_thres, float iou_thres, int multi_label,
                     int agnostic, const uint8_t* classes_mask, int max_det, int max_nms, float max_wh,
                     float* out, int32_t* counts, int32_t* keep_idx, void* workspace, size_t workspace_bytes,

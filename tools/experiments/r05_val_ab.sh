@@ -1,14 +1,14 @@
-# Validate-path A/Bs on one box (environment switches of csrc/nms.hip), then a kernel trace of the default.
+# Validate-path A/Bs on one box (upa_opts.nms_stages / nms_first_prefix), then a kernel trace of the default.
 #   gpurun -- 'bash tools/experiments/r05_val_ab.sh'
 mkdir -p gpurun_out/val_ab
-run() { python bench.py --workload val 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('$1', d['value'], d['ms_per_step'])"; }
+run() { l=$1; shift; python bench.py --workload val "$@" 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('$l', d['value'], d['ms_per_step'])"; }
 for r in 1 2; do
-  UPA_NMS_NO_COARSE=1 run "radix select in the first stage                     "
-  UPA_NMS_NO_EMIT=1 UPA_NMS_FIRST_PREFIX=0 run "coarse histogram, all keys, first prefix 16384      "
-  UPA_NMS_NO_EMIT=1 run "coarse histogram, all keys, first prefix 4096       "
-  UPA_NMS_FIRST_PREFIX=8192 run "coarse histogram, prefix keys only, prefix 8192     "
+  run "radix select in the first stage                     " --opts nms_stages=2
+  run "coarse histogram, all keys, first prefix 16384      " --opts nms_stages=1,nms_first_prefix=-1
+  run "coarse histogram, all keys, first prefix 4096       " --opts nms_stages=1
+  run "coarse histogram, prefix keys only, prefix 8192     " --opts nms_first_prefix=8192
   run "coarse histogram, prefix keys only, prefix 4096     "
-  UPA_NMS_FIRST_PREFIX=2048 run "coarse histogram, prefix keys only, prefix 2048     "
+  run "coarse histogram, prefix keys only, prefix 2048     " --opts nms_first_prefix=2048
 done
 R=$PWD; cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/val_ab/prof -- python3 $R/bench.py --workload val --steps 100 > $R/gpurun_out/val_ab/prof.log 2>&1

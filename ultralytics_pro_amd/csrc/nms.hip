@@ -673,18 +673,6 @@ __global__ __launch_bounds__(GREEDY_NT) void nms_greedy_kernel(const float* pred
   }
 }
 
-inline bool no_coarse_env() {  // A/B switch for tools/: UPA_NMS_NO_COARSE=1 keeps the radix select in the first stage
-  static const bool v = [] { const char* e = getenv("UPA_NMS_NO_COARSE"); return e && e[0] == '1'; }();
-  return v;
-}
-inline bool no_emit_env() {  // UPA_NMS_NO_EMIT=1: all keys are written up front, the sort kernel's pass picks the prefix
-  static const bool v = [] { const char* e = getenv("UPA_NMS_NO_EMIT"); return e && e[0] == '1'; }();
-  return v;
-}
-inline int first_prefix_env() {  // A/B switch for tools/: UPA_NMS_FIRST_PREFIX=<n> (0: no short first stage)
-  static const int v = [] { const char* e = getenv("UPA_NMS_FIRST_PREFIX"); return e ? atoi(e) : 4096; }();
-  return v;
-}
 constexpr int NMS_COUNTERS = 8;  // int arrays of length B in front of the workspace: count, nsorted, partial, redo, redo (second stage), spare
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline int pow2_ge(int v) {
@@ -706,8 +694,14 @@ extern "C" size_t upa_nms_workspace_bytes(int b, int nc, int a, int multi_label,
 static int nms_batched_impl(const float* pred, int b, int nc, int a, float conf_thres, float iou_thres, int multi_label,
                             int agnostic, const uint8_t* classes_mask, int max_det, int max_nms, float max_wh,
                             float* out, int32_t* counts, int32_t* keep_idx, void* workspace, size_t workspace_bytes,
-                            const u64* best_keys, void* stream) {
+                            const u64* best_keys, const upa_opts* opts, void* stream) {
   UPA_CHECK_ARG(pred && out && counts && workspace, "nms: null pointer");
+  const int stages_mode = UPA_OPT(opts, nms_stages);
+  const int first_prefix_opt = UPA_OPT(opts, nms_first_prefix);
+  UPA_CHECK_ARG(stages_mode >= 0 && stages_mode <= 2, "nms: opts.nms_stages must be 0, 1 or 2");
+  UPA_CHECK_ARG(first_prefix_opt == 0 || first_prefix_opt == -1 || (first_prefix_opt >= 256 && first_prefix_opt < LDS_SORT_CAP),
+                "nms: opts.nms_first_prefix must be 0, -1 or in [256, %d)", LDS_SORT_CAP);
+  const int first_prefix = first_prefix_opt == 0 ? 4096 : first_prefix_opt;
   UPA_CHECK_ARG(b > 0 && nc > 0 && a > 0, "nms: bad shape");
   UPA_CHECK_ARG(conf_thres >= 0.f && conf_thres <= 1.f, "Invalid Confidence threshold %f, valid values are between 0.0 and 1.0",
                 conf_thres);
@@ -739,13 +733,13 @@ static int nms_batched_impl(const float* pred, int b, int nc, int a, float conf_
   // full top-max_nms select + global-memory sort (8.4 ms per batch-32 call, two thirds of the validate step's GPU time) only for images
   // whose greedy pass ran out of candidates before max_det boxes were kept
   const bool two_stage = cap > LDS_SORT_CAP && max_nms > LDS_SORT_CAP;
-  int* coarse = (two_stage && multi_label && !best_keys && !no_coarse_env()) ? count + NMS_COUNTERS * b : nullptr;
+  int* coarse = (two_stage && multi_label && !best_keys && stages_mode != 2) ? count + NMS_COUNTERS * b : nullptr;
   int prefixes[3], np = 0;
-  if (two_stage && coarse && first_prefix_env() > 0 && first_prefix_env() < LDS_SORT_CAP) prefixes[np++] = first_prefix_env();
+  if (two_stage && coarse && first_prefix > 0) prefixes[np++] = first_prefix;
   if (two_stage) prefixes[np++] = LDS_SORT_CAP;
   prefixes[np++] = 0;
   // with the histogram, the first prefix's keys are the only ones written up front (nms_hist_kernel + nms_emit_kernel)
-  const bool emit = coarse && !no_emit_env();
+  const bool emit = coarse && stages_mode == 0;
   int* wave_best = count + NMS_COUNTERS * b + b * COARSE_BINS;  // [B][4 * workgroups per image], every word written by nms_hist_kernel
   int *redo2 = count + 4 * b, *mode = count + 5 * b, *pcount = count + 6 * b, *count2 = count + 7 * b;
   if (!best_keys) upa_zero_words(count, coarse ? NMS_COUNTERS * b + b * COARSE_BINS : 2 * b, s);
@@ -792,7 +786,15 @@ extern "C" int upa_nms_batched(const float* pred, int b, int nc, int a, float co
                                float* out, int32_t* counts, int32_t* keep_idx, void* workspace, size_t workspace_bytes,
                                void* stream) {
   return nms_batched_impl(pred, b, nc, a, conf_thres, iou_thres, multi_label, agnostic, classes_mask, max_det, max_nms, max_wh,
-                          out, counts, keep_idx, workspace, workspace_bytes, nullptr, stream);
+                          out, counts, keep_idx, workspace, workspace_bytes, nullptr, nullptr, stream);
+}
+
+extern "C" int upa_nms_batched_opts(const float* pred, int b, int nc, int a, float conf_thres, float iou_thres, int multi_label,
+                                    int agnostic, const uint8_t* classes_mask, int max_det, int max_nms, float max_wh,
+                                    float* out, int32_t* counts, int32_t* keep_idx, void* workspace, size_t workspace_bytes,
+                                    const upa_opts* opts, void* stream) {
+  return nms_batched_impl(pred, b, nc, a, conf_thres, iou_thres, multi_label, agnostic, classes_mask, max_det, max_nms, max_wh,
+                          out, counts, keep_idx, workspace, workspace_bytes, nullptr, opts, stream);
 }
 
 extern "C" int upa_nms_batched_hot(const float* pred, int b, int nc, int a, float conf_thres, float iou_thres, int multi_label,
@@ -802,5 +804,5 @@ extern "C" int upa_nms_batched_hot(const float* pred, int b, int nc, int a, floa
   UPA_CHECK_ARG(best_keys, "nms_hot: best-class keys missing");
   UPA_CHECK_ARG(!(multi_label && nc > 1), "nms_hot: the keys follow the single-label rule (best class per anchor)");
   return nms_batched_impl(pred, b, nc, a, conf_thres, iou_thres, multi_label, agnostic, classes_mask, max_det, max_nms, max_wh,
-                          out, counts, keep_idx, workspace, workspace_bytes, (const u64*)best_keys, stream);
+                          out, counts, keep_idx, workspace, workspace_bytes, (const u64*)best_keys, nullptr, stream);
 }

@@ -52,10 +52,10 @@ def nms_raw(prediction: torch.Tensor, conf_thres=0.25, iou_thres=0.45, classes=N
                                         keep.data_ptr(), ws.data_ptr(), ws_bytes, hot.data_ptr(), L.current_stream(dev)),
                 "nms_batched_hot")
         return out, counts, keep
-    L.check(lib.upa_nms_batched(prediction.data_ptr(), b, nc, a, float(conf_thres), float(iou_thres), int(bool(multi_label)),
-                                int(bool(agnostic)), None if cmask is None else cmask.data_ptr(), int(max_det),
-                                int(max_nms), float(max_wh), out.data_ptr(), counts.data_ptr(), keep.data_ptr(),
-                                ws.data_ptr(), ws_bytes, L.current_stream(dev)), "nms_batched")
+    L.check(lib.upa_nms_batched_opts(prediction.data_ptr(), b, nc, a, float(conf_thres), float(iou_thres), int(bool(multi_label)),
+                                     int(bool(agnostic)), None if cmask is None else cmask.data_ptr(), int(max_det),
+                                     int(max_nms), float(max_wh), out.data_ptr(), counts.data_ptr(), keep.data_ptr(),
+                                     ws.data_ptr(), ws_bytes, R.opts_ptr(), L.current_stream(dev)), "nms_batched")
     return out, counts, keep
 
 
