@@ -21,7 +21,7 @@ for m in yolov8n yolov8s yolov3-tiny yolov3-rtdetr; do cpf $O/conv_layers_$m.txt
 cpf $O/pmc_hbm_summary.json pmc_hbm_summary.json
 cpf $O/pmc_wgrad_summary.json pmc_wgrad_summary.json
 cpf $O/pmc_step_summary.txt pmc_step_budget.txt
-for k in default serial train; do
+for k in default serial train val; do
   f=$(ls -t $(find $O/prof_$k -name "*kernel_stats.csv" 2>/dev/null) 2>/dev/null | head -1)   # the newest: gpurun merges a call's files into the directory, traces of earlier calls stay
   [ -n "$f" ] && cpf "$f" bench_${k}_kernel_stats.csv
 done

@@ -5,7 +5,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 ROUND=${ROUND:-r05}
 O=$R/gpurun_out/final_$ROUND
-rm -rf $O/prof_default $O/prof_serial $O/prof_train   # stale traces of earlier calls would shadow this one's stats
+rm -rf $O/prof_default $O/prof_serial $O/prof_train $O/prof_val   # stale traces of earlier calls would shadow this one's stats
 mkdir -p $O
 cd $R
 timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err
@@ -33,6 +33,7 @@ cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -- python3 $R/bench.py --no-cpu-baseline --no-kernel-profile --steps 200 --warmup 10 > /dev/null 2>&1
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_serial -- python3 $R/bench.py --serial --no-cpu-baseline --steps 60 --warmup 5 > $O/bench_serial_profiled.json 2>/dev/null
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_train -- python3 $R/bench.py --workload train --no-cpu-baseline --steps 10 --warmup 3 > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_val -- python3 $R/bench.py --workload val --steps 100 > /dev/null 2>&1
 cd $R
 find $O -name "*kernel_trace.csv" -delete   # large; the stats CSVs are what profiles/ keeps
 echo done
