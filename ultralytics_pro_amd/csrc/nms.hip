@@ -38,12 +38,15 @@ struct NmsWs {
   u64* sel;     // [B][selcap]
 };
 
-// Coarse score digit of a key for the two-stage multi-label path: 128 bins per octave of the score counted down from 1.0 (sign, exponent
-// and 7 mantissa bits of the inverted score word), clamped to [0, COARSE_BINS) - a monotone function of the key, so "bin < b" is a
-// prefix of the score order.  conf = 0.001 .. 1 spans 1277 bins.
-constexpr int COARSE_BINS = 4096;
+// Coarse score digit of a key for the staged multi-label path: 128 >> (UPA_COARSE_SHIFT - 16) bins per octave of the score counted down
+// from 1.0 (sign, exponent and the top mantissa bits of the inverted score word), clamped to [0, COARSE_BINS) - a monotone function of
+// the key, so "bin < b" is a prefix of the score order.  At 128 bins per octave conf = 0.001 .. 1 spans 1277 bins.
+#ifndef UPA_COARSE_SHIFT
+#define UPA_COARSE_SHIFT 16
+#endif
+constexpr int COARSE_BINS = 4096 >> (UPA_COARSE_SHIFT - 16);
 __device__ __forceinline__ int coarse_bin(unsigned inv_score_bits) {
-  const int d = (int)(inv_score_bits >> 16) - 0xC07F;  // 0xC07F = (~bits(1.0f)) >> 16
+  const int d = (int)(inv_score_bits >> UPA_COARSE_SHIFT) - (int)(0xC07FFFFFu >> UPA_COARSE_SHIFT);  // 0xC07FFFFF = ~bits(1.0f)
   return d < 0 ? 0 : (d > COARSE_BINS - 1 ? COARSE_BINS - 1 : d);
 }
 
@@ -200,10 +203,11 @@ __device__ __forceinline__ bool coarse_prefix_usable(int total, int target, int 
 }
 
 // Multi-label candidates of long lists, first half: ONLY the coarse score histogram of every image (no keys yet).
-// Also: the best (lowest) coarse bin among each wave's candidates, wave_best[b][wave] - the emit kernel skips the waves that hold no
-// candidate of the prefix without reading their scores again.
+// Also: the best (lowest) coarse bin among each wave's candidates per group of eight classes, group_best[b][wave][group] - the emit
+// kernel reads again only the class rows of the (wave, group) pairs that hold a candidate of the prefix (the top few thousand candidates
+// of an image sit in a handful of classes).
 __global__ __launch_bounds__(256) void nms_hist_kernel(const float* pred, int nc, int A, float conf, const uint8_t* cmask,
-                                                       int* coarse, int* wave_best) {
+                                                       int* coarse, int* group_best) {
   const int b = blockIdx.y;
   const int a = blockIdx.x * 256 + threadIdx.x;
   const bool valid = a < A;
@@ -211,11 +215,13 @@ __global__ __launch_bounds__(256) void nms_hist_kernel(const float* pred, int nc
   __shared__ int lh[COARSE_BINS];
   for (int i = threadIdx.x; i < COARSE_BINS; i += 256) lh[i] = 0;
   __syncthreads();
-  int best = COARSE_BINS;  // (no candidate)
+  const int ng = (nc + 7) >> 3;
+  int* gb = group_best + (((size_t)b * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) * ng;
   for (int c0 = 0; c0 < nc; c0 += 8) {
     float v[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) v[q] = (valid && c0 + q < nc) ? pb[(size_t)(c0 + q) * A] : -INFINITY;
+    int best = COARSE_BINS;  // (no candidate)
 #pragma unroll
     for (int q = 0; q < 8; ++q)
       if (valid && c0 + q < nc && v[q] > conf && (!cmask || cmask[c0 + q])) {
@@ -223,13 +229,13 @@ __global__ __launch_bounds__(256) void nms_hist_kernel(const float* pred, int nc
         atomicAdd(&lh[bin], 1);
         best = bin < best ? bin : best;
       }
-  }
 #pragma unroll
-  for (int d = 32; d > 0; d >>= 1) {
-    const int o = __shfl_xor(best, d);
-    best = o < best ? o : best;
+    for (int d = 32; d > 0; d >>= 1) {
+      const int o = __shfl_xor(best, d);
+      best = o < best ? o : best;
+    }
+    if ((threadIdx.x & 63) == 0) gb[c0 >> 3] = best;
   }
-  if ((threadIdx.x & 63) == 0) wave_best[((size_t)b * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)] = best;
   __syncthreads();
   int* gh = coarse + (size_t)b * COARSE_BINS;
   for (int i = threadIdx.x; i < COARSE_BINS; i += 256)
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(256) void nms_hist_kernel(const float* pred, int nc
 // written unless the greedy pass flags the image (nms_candidates_kernel with `only_redo` then writes them all).  Images without a
 // usable prefix (few candidates, or one bin holds them all) get all their keys into `keys` here: mode[b] = 0.
 __global__ __launch_bounds__(256) void nms_emit_kernel(const float* pred, int nc, int A, float conf, const uint8_t* cmask,
-                                                       const int* coarse, const int* wave_best, int target, int* count, int* mode,
+                                                       const int* coarse, const int* group_best, int target, int* count, int* mode,
                                                        int* pcount, u64* keys, long cap, u64* sel, int selcap) {
   const int b = blockIdx.y;
   const int a = blockIdx.x * 256 + threadIdx.x;
@@ -265,9 +271,11 @@ __global__ __launch_bounds__(256) void nms_emit_kernel(const float* pred, int nc
   __shared__ int s_cnt, blk_base;
   if (threadIdx.x == 0) s_cnt = 0;
   __syncthreads();
-  const bool wave_has = wave_best[((size_t)b * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)] < lim;  // uniform per wave
-  if (wave_has)
+  const int ng = (nc + 7) >> 3;
+  const int* gb = group_best + (((size_t)b * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) * ng;
+  const int my_gb = (ng <= 64 && lane < ng) ? gb[lane] : 0;  // lane g holds the wave's best bin of class group g
     for (int c0 = 0; c0 < nc; c0 += 8) {
+      if (ng <= 64 && __shfl(my_gb, c0 >> 3) >= lim) continue;  // uniform: no candidate of the prefix in these eight class rows
       float v[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) v[q] = (valid && c0 + q < nc) ? pb[(size_t)(c0 + q) * A] : -INFINITY;
@@ -547,7 +555,10 @@ __device__ __forceinline__ bool iou_gt(float ax1, float ay1, float ax2, float ay
   return !(iou <= thr);  // reference keeps `iou <= thr`; NaN is not kept either
 }
 
-constexpr int GREEDY_NT = 512;
+#ifndef UPA_GREEDY_NT
+#define UPA_GREEDY_NT 512
+#endif
+constexpr int GREEDY_NT = UPA_GREEDY_NT;
 constexpr int GREEDY_NW = GREEDY_NT / 64;
 constexpr int MAX_DET_CAP = 1024;
 
@@ -687,7 +698,7 @@ extern "C" size_t upa_nms_workspace_bytes(int b, int nc, int a, int multi_label,
   const size_t cap = (size_t)a * (multi_label ? nc : 1);
   const size_t selcap = (size_t)pow2_ge(max_nms < 2 ? 2 : max_nms);
   // count, nsorted, partial, redo flags (+ coarse histograms and per-wave best bins)
-  const size_t counters = (size_t)b * NMS_COUNTERS + (multi_label ? (size_t)b * (COARSE_BINS + 4 * (size_t)cdiv(a, 256)) : 0);
+  const size_t counters = (size_t)b * NMS_COUNTERS + (multi_label ? (size_t)b * (COARSE_BINS + 4 * (size_t)cdiv(a, 256) * (size_t)cdiv(nc, 8)) : 0);
   return 256 + align_up(counters * sizeof(int), 256) + (size_t)b * cap * 8 + (size_t)b * selcap * 8;
 }
 
@@ -723,7 +734,7 @@ static int nms_batched_impl(const float* pred, int b, int nc, int a, float conf_
   int* nsorted = count + b;
   int* partial = count + 2 * b;
   int* redo = count + 3 * b;
-  ws += align_up(((size_t)b * NMS_COUNTERS + (ws_has_coarse ? (size_t)b * (COARSE_BINS + 4 * (size_t)cdiv(a, 256)) : 0)) * sizeof(int), 256);
+  ws += align_up(((size_t)b * NMS_COUNTERS + (ws_has_coarse ? (size_t)b * (COARSE_BINS + 4 * (size_t)cdiv(a, 256) * (size_t)cdiv(nc, 8)) : 0)) * sizeof(int), 256);
   u64* keys = (u64*)ws;
   u64* sel = keys + (size_t)b * cap;
   hipStream_t s = (hipStream_t)stream;
@@ -740,7 +751,7 @@ static int nms_batched_impl(const float* pred, int b, int nc, int a, float conf_
   prefixes[np++] = 0;
   // with the histogram, the first prefix's keys are the only ones written up front (nms_hist_kernel + nms_emit_kernel)
   const bool emit = coarse && stages_mode == 0;
-  int* wave_best = count + NMS_COUNTERS * b + b * COARSE_BINS;  // [B][4 * workgroups per image], every word written by nms_hist_kernel
+  int* wave_best = count + NMS_COUNTERS * b + b * COARSE_BINS;  // [B][4 * workgroups per image][class groups], every word written by nms_hist_kernel
   int *redo2 = count + 4 * b, *mode = count + 5 * b, *pcount = count + 6 * b, *count2 = count + 7 * b;
   if (!best_keys) upa_zero_words(count, coarse ? NMS_COUNTERS * b + b * COARSE_BINS : 2 * b, s);
   const dim3 cgrid((unsigned)cdiv(a, 256), (unsigned)b);
