@@ -17,7 +17,7 @@
 // the greedy pass almost always has its max_det boxes after the first thousand or so candidates, so (sort, greedy) pairs run over
 // growing PREFIXES of the score order and a pair after the first only touches the images the pass before it flagged (it ran out of
 // candidates before max_det boxes were kept).  A prefix is "the candidates in the coarse score bins before the one where the running
-// count crosses ~4096": nms_hist_kernel builds a 4096-bin score histogram per image (128 bins per octave), nms_emit_kernel finds that
+// count crosses ~4096": nms_hist_kernel builds a 2048-bin score histogram per image (64 bins per octave), nms_emit_kernel finds that
 // bin and writes keys for the prefix only (one more sweep over the scores), nms_sort sorts them in LDS.  The full key list (170 MB per
 // batch of 32) is written only for flagged images (nms_candidates with `only_redo`), which then take the 16384-prefix and at last the
 // exact top-max_nms path.  The result is the reference's in every case: greedy NMS over the score-ordered candidates cut at max_nms,
@@ -38,11 +38,12 @@ struct NmsWs {
   u64* sel;     // [B][selcap]
 };
 
-// Coarse score digit of a key for the staged multi-label path: 128 >> (UPA_COARSE_SHIFT - 16) bins per octave of the score counted down
-// from 1.0 (sign, exponent and the top mantissa bits of the inverted score word), clamped to [0, COARSE_BINS) - a monotone function of
-// the key, so "bin < b" is a prefix of the score order.  At 128 bins per octave conf = 0.001 .. 1 spans 1277 bins.
+// Coarse score digit of a key for the staged multi-label path: 64 bins per octave of the score counted down from 1.0 (sign, exponent and
+// the top 6 mantissa bits of the inverted score word), clamped to [0, COARSE_BINS) - a monotone function of the key, so "bin < b" is a
+// prefix of the score order.  conf = 0.001 .. 1 spans 639 bins.  (UPA_COARSE_SHIFT 16 / 18 = 4096 / 1024 bins: same-box A/B 52.6-52.8 k /
+// 52.85-52.99 k images/s against 52.87-52.93 k on the validate path - the histogram is zeroed per call.)
 #ifndef UPA_COARSE_SHIFT
-#define UPA_COARSE_SHIFT 16
+#define UPA_COARSE_SHIFT 17
 #endif
 constexpr int COARSE_BINS = 4096 >> (UPA_COARSE_SHIFT - 16);
 __device__ __forceinline__ int coarse_bin(unsigned inv_score_bits) {
@@ -555,10 +556,7 @@ __device__ __forceinline__ bool iou_gt(float ax1, float ay1, float ax2, float ay
   return !(iou <= thr);  // reference keeps `iou <= thr`; NaN is not kept either
 }
 
-#ifndef UPA_GREEDY_NT
-#define UPA_GREEDY_NT 512
-#endif
-constexpr int GREEDY_NT = UPA_GREEDY_NT;
+constexpr int GREEDY_NT = 512;  // (1024 threads = 16 waves per image measured equal: serial step 0.8174-0.8205 vs 0.8173-0.8189 ms, same box)
 constexpr int GREEDY_NW = GREEDY_NT / 64;
 constexpr int MAX_DET_CAP = 1024;
 
