@@ -594,7 +594,7 @@ def main_val(args):
                 M.match_predictions_batched(out, counts, gt, ngt, out=tp)
                 return out, counts, tp
             runs.append(model.compile(xj, post=post))
-    lanes = [torch.cuda.Stream(device=dev) for _ in range(4)]
+    lanes = [torch.cuda.Stream(device=dev) for _ in range(args.in_flight or 4)]
 
     def step(i):
         with torch.cuda.stream(lanes[i % len(lanes)]):
