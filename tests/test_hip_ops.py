@@ -1116,7 +1116,7 @@ def test_nms_large_multilabel_vs_oracle(staging):
             return _nms(*a, **k)
 
     def oracle(name, t, **k):  # (the same scenes for every staging: the oracle's Python loop runs once per scene)
-        key = (name, tuple(sorted(k.items())))
+        key = (name, repr(sorted(k.items())))
         if key not in _NMS_BIG_REF:
             _NMS_BIG_REF[key] = onms.non_max_suppression(t.clone(), **k)
         return _NMS_BIG_REF[key]
@@ -1132,6 +1132,8 @@ def test_nms_large_multilabel_vs_oracle(staging):
     p[2, 4:, 100:] = 0  # ragged: third image has few candidates
     for kw in (dict(conf_thres=0.001, iou_thres=0.7, multi_label=True, max_det=300, max_nms=30000),  # > LDS sort cap
                dict(conf_thres=0.05, iou_thres=0.5, multi_label=True, max_det=100, max_nms=2000),    # radix select
+               dict(conf_thres=0.001, iou_thres=0.6, multi_label=True, max_det=300, max_nms=30000, classes=[0, 3, 17, 42, 78, 79],
+                    agnostic=True),                                                                   # class filter inside the histogram / emit sweeps
                dict(conf_thres=0.25, iou_thres=0.45)):
         ref = oracle("p", p, **kw)
         out = non_max_suppression(p.to(DEV), **kw)
