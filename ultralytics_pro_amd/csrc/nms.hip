@@ -555,8 +555,43 @@ __device__ __forceinline__ bool iou_gt(float ax1, float ay1, float ax2, float ay
   const float iou = inter / (aarea + barea - inter);
   return !(iou <= thr);  // reference keeps `iou <= thr`; NaN is not kept either
 }
+// (A wave-uniform shortcut - skip the IEEE division when no lane's box overlaps the broadcast one at all, inter == 0 - was measured
+// SLOWER: the vote and the branch cost more than the division they save in one wave out of a few: phase 1 1744 -> 2501 cycles per chunk
+// on the headline batches, 4842 -> 9017 in validation, serial step +1.4 %.  profiles/r05_greedy_phases.txt)
 
-constexpr int GREEDY_NT = 512;  // (1024 threads = 16 waves per image measured equal: serial step 0.8174-0.8205 vs 0.8173-0.8189 ms, same box)
+// -DUPA_GREEDY_PROF (tools/experiments/r05_greedy_phases.sh builds it into a separate library): wave 0 adds the shader cycles it spends per
+// phase of the greedy kernel to g_greedy_prof (read and cleared by upa_debug_greedy_prof); the product build carries none of it.
+#ifdef UPA_GREEDY_PROF
+__device__ unsigned long long g_greedy_prof[12];  // init, stage load, phase 1, barrier 1, phase 2 rest, barrier 2, chunks, workgroups, alive mask, rows, resolve loop, output rows
+#define GP_DECL unsigned long long gp_t = __builtin_amdgcn_s_memtime(), gp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define GP_AT(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); gp_acc[i] += t_ - gp_t; gp_t = t_; } while (0)
+#define GP_COUNT(i) (gp_acc[i] += 1)
+#define GP_FLUSH do { if (threadIdx.x == 0) { for (int i_ = 0; i_ < 12; ++i_) if (i_ != 7) atomicAdd(&g_greedy_prof[i_], gp_acc[i_]); atomicAdd(&g_greedy_prof[7], 1ull); } } while (0)
+#else
+#define GP_DECL
+#define GP_AT(i)
+#define GP_COUNT(i)
+#define GP_FLUSH
+#endif
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for the wave's global STORES (s_waitcnt vmcnt(0)): in the greedy
+// kernel's chunk loop that made wave 0 sit out the acknowledgement of the kept boxes' output rows - ~1.5-2 us per chunk, what the phase
+// profile (tools/experiments/r05_greedy_phases.py) showed as "phase 2" - although nobody in the workgroup reads them back.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+#ifndef UPA_GREEDY_ROWS_MIN
+#define UPA_GREEDY_ROWS_MIN 8
+#endif
+constexpr int GREEDY_ROWS_MIN = UPA_GREEDY_ROWS_MIN;  // alive candidates in a chunk from which the suppression columns are computed by all waves
+#ifndef UPA_GREEDY_NT
+#define UPA_GREEDY_NT 512
+#endif
+constexpr int GREEDY_NT = UPA_GREEDY_NT;
+
 constexpr int GREEDY_NW = GREEDY_NT / 64;
 constexpr int MAX_DET_CAP = 1024;
 
@@ -567,9 +602,11 @@ __global__ __launch_bounds__(GREEDY_NT) void nms_greedy_kernel(const float* pred
   if (only_redo && !only_redo[blockIdx.x]) return;
   __shared__ float kx1[MAX_DET_CAP], ky1[MAX_DET_CAP], kx2[MAX_DET_CAP], ky2[MAX_DET_CAP], kar[MAX_DET_CAP];
   __shared__ u64 alive_w[GREEDY_NW];
+  __shared__ u64 colm[64];  // suppression-matrix columns of the chunk's candidates (phase 2), zero between chunks
   __shared__ int s_kept;
   const int b = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  GP_DECL;
   const int n = nsorted[b];
   const u64* sb = sel + (size_t)b * selcap;
   const float* pb = pred + (size_t)b * (4 + nc) * A;
@@ -579,7 +616,9 @@ __global__ __launch_bounds__(GREEDY_NT) void nms_greedy_kernel(const float* pred
   if (keep_idx)
     for (int i = threadIdx.x; i < max_det; i += GREEDY_NT) keep_idx[(size_t)b * max_det + i] = -1;
   if (threadIdx.x == 0) s_kept = 0;
+  if (threadIdx.x < 64) colm[threadIdx.x] = 0ull;
   __syncthreads();
+  GP_AT(0);
   // Candidates are staged 512 at a time: every thread decodes ONE key and gathers its box (two dependent global round trips, paid
   // once per 512 candidates instead of once per 64-candidate chunk - the gathers were most of this kernel's time: a typical image
   // has 100-500 candidates and the chunks are resolved one after the other), then the eight chunks of the stage run out of LDS.
@@ -604,6 +643,7 @@ __global__ __launch_bounds__(GREEDY_NT) void nms_greedy_kernel(const float* pred
       }
     }
     __syncthreads();
+    GP_AT(1);
     const int stage_n = n - stage < GREEDY_NT ? n - stage : GREEDY_NT;
     for (int base = 0; base < stage_n; base += 64) {
       const int kept = s_kept;
@@ -626,36 +666,95 @@ __global__ __launch_bounds__(GREEDY_NT) void nms_greedy_kernel(const float* pred
         sup |= iou_gt(kx1[k], ky1[k], kx2[k], ky2[k], kar[k], x1, y1, x2, y2, area, iou_thr);
       const u64 am = __ballot(valid && !sup);
       if (lane == 0) alive_w[wave] = am;
-      __syncthreads();
-      if (wave == 0) {
-        u64 alive = alive_w[0];
+      GP_AT(2);
+      lds_barrier();
+      GP_AT(3);
+      GP_COUNT(6);
+      // phase 2: resolve the chunk greedily: in candidate order, an alive candidate is kept unless an earlier KEPT candidate of the chunk
+      // suppresses it.  Walking the set bits one by one in a single wave - broadcast the kept box, evaluate its IoU against the 64
+      // lanes, drop the suppressed bits - was a serial chain of ~200 cycles per kept box: 60-65 % of this kernel's cycles on the
+      // headline batches, 48 % in validation (tools/experiments/r05_greedy_phases.py); even with precomputed suppression rows the walk
+      // cost ~100 cycles per kept box (scalar <-> vector register round trips).  Now:
+      //  a. all eight waves (each holds the chunk's 64 boxes in its lanes) evaluate the pairs: the alive candidates j are dealt
+      //     round-robin to the waves, two per loop trip (independent chains); for its j a wave sets bit j in the lanes i > j that j
+      //     would suppress - iou_gt(j, i), the same call the chain made - so lane i collects its COLUMN of the suppression matrix;
+      //     the waves' partial columns meet in LDS (ds_or_b64).
+      //  b. wave 0 solves  kept = alive & ~(some kept j in my column)  by iteration from kept = alive: one ballot per round, and the
+      //     bits settle from the low indices upward, so the rounds needed = the longest suppress chain in the chunk (2-4), not
+      //     the number of kept boxes.  The fixed point is unique (bit i depends on bits < i only) and equals the serial walk.
+      // Chunks with few alive candidates keep the serial walk (no second barrier).
+      u64 alive = alive_w[0];
 #pragma unroll
-        for (int q = 1; q < GREEDY_NW; ++q) alive &= alive_w[q];
-        // phase 2: resolve the chunk greedily over the SET bits only: take the lowest alive lane, keep it, broadcast its
-        // box, drop every later alive lane it suppresses.  Iterations = boxes kept from this chunk (usually a handful),
-        // not 64 + 64 as a full suppression matrix + scan would cost.  The mask and the kept count are wave-uniform: held in scalar
-        // registers (readfirstlane), so the lane index of the kept box is scalar too and its five values are broadcast by
-        // v_readlane_b32 - a few cycles each - instead of five ds_bpermute round trips (~600 cycles per kept box, most of this kernel's
-        // time: 55 -> see DESIGN.md).
-        u64 rem = ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(alive >> 32)) << 32) |
-                  (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)alive);  // (the builtin returns int: no sign extension)
+      for (int q = 1; q < GREEDY_NW; ++q) alive &= alive_w[q];
+      const u64 alive_s = ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(alive >> 32)) << 32) |
+                          (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)alive);  // (the builtin returns int: no sign extension)
+      const bool by_cols = __popcll(alive_s) >= GREEDY_ROWS_MIN;  // uniform over the workgroup
+      const bool me_alive = (alive_s >> lane) & 1ull;
+      GP_AT(8);
+      if (by_cols) {
+        const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+        auto hits = [&](int j) __attribute__((always_inline)) {  // would candidate j, if kept, suppress this lane's candidate?
+          const float jx1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x1), j));
+          const float jy1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(y1), j));
+          const float jx2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x2), j));
+          const float jy2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(y2), j));
+          const float jar = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(area), j));
+          return me_alive && lane > j && iou_gt(jx1, jy1, jx2, jy2, jar, x1, y1, x2, y2, area, iou_thr);
+        };
+        u64 col = 0ull;
+        u64 it = alive_s;
+        int turn = 0, j0 = -1;
+        while (it) {  // scalar walk over the alive bits; this wave's are those whose rank is wave_s modulo the wave count
+          const int j = __builtin_ctzll((unsigned long long)it);
+          it &= it - 1ull;
+          if ((turn++ & (GREEDY_NW - 1)) != wave_s) continue;
+          if (j0 < 0) { j0 = j; continue; }
+          const bool h0 = hits(j0), h1 = hits(j);  // two independent chains
+          col |= (h0 ? 1ull << j0 : 0ull) | (h1 ? 1ull << j : 0ull);
+          j0 = -1;
+        }
+        if (j0 >= 0 && hits(j0)) col |= 1ull << j0;
+        if (col) atomicOr((unsigned long long*)&colm[lane], (unsigned long long)col);
+        GP_AT(9);
+        lds_barrier();
+        GP_AT(5);
+      }
+      if (wave == 0) {
         u64 keepmask = 0ull;
         const int kept_s = __builtin_amdgcn_readfirstlane(kept);
-        int nkeep = 0;
-        while (rem) {
-          const int i = __builtin_ctzll((unsigned long long)rem);
-          keepmask |= 1ull << i;
-          rem &= rem - 1ull;
-          ++nkeep;
-          if (kept_s + nkeep >= max_det) break;
-          const float ix1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x1), i));
-          const float iy1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(y1), i));
-          const float ix2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x2), i));
-          const float iy2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(y2), i));
-          const float iar = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(area), i));
-          const bool sup2 = ((rem >> lane) & 1ull) && iou_gt(ix1, iy1, ix2, iy2, iar, x1, y1, x2, y2, area, iou_thr);
-          rem &= ~__ballot(sup2);
+        const int room = max_det - kept_s;  // >= 1 (the chunk loop stops at max_det)
+        if (by_cols) {
+          const u64 col = colm[lane];
+          colm[lane] = 0ull;  // for the next chunk (its columns are written after that chunk's first barrier)
+          u64 k = alive_s;
+          for (;;) {
+            const u64 kn = __ballot(me_alive && (col & k) == 0ull);
+            if (kn == k) break;
+            k = kn;
+          }
+          // the first `room` kept candidates (the serial walk stopped there)
+          keepmask = __ballot(((k >> lane) & 1ull) && __popcll(k & ((1ull << lane) - 1ull)) < room);
+        } else {
+          // (the serial walk: the mask and the kept count are wave-uniform, held in scalar registers, so the lane index of the kept box
+          // is scalar too and its five values are broadcast by v_readlane_b32 instead of five ds_bpermute round trips)
+          u64 rem = alive_s;
+          int nkeep = 0;
+          while (rem) {
+            const int i = __builtin_ctzll((unsigned long long)rem);
+            keepmask |= 1ull << i;
+            rem &= rem - 1ull;
+            ++nkeep;
+            if (nkeep >= room) break;
+            const float ix1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x1), i));
+            const float iy1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(y1), i));
+            const float ix2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x2), i));
+            const float iy2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(y2), i));
+            const float iar = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(area), i));
+            const bool sup2 = ((rem >> lane) & 1ull) && iou_gt(ix1, iy1, ix2, iy2, iar, x1, y1, x2, y2, area, iou_thr);
+            rem &= ~__ballot(sup2);
+          }
         }
+        GP_AT(10);
         if ((keepmask >> lane) & 1ull) {
           const int idx = kept + __popcll(keepmask & ((1ull << lane) - 1ull));
           if (idx < max_det) {
@@ -669,11 +768,15 @@ __global__ __launch_bounds__(GREEDY_NT) void nms_greedy_kernel(const float* pred
           const int nk = kept + __popcll(keepmask);
           s_kept = nk < max_det ? nk : max_det;
         }
+        GP_AT(11);
       }
-      __syncthreads();
+      GP_AT(4);
+      lds_barrier();
+      GP_AT(5);
     }
-    __syncthreads();  // the stage buffers are rewritten by the next stage
+    lds_barrier();  // the stage buffers are rewritten by the next stage
   }
+  GP_FLUSH;
   if (threadIdx.x == 0) {
     counts[b] = s_kept;
     // the sorted list was only the top part of the candidates and ran out before max_det boxes were kept: this image goes through
@@ -789,6 +892,15 @@ static int nms_batched_impl(const float* pred, int b, int nc, int a, float conf_
   }
   return UPA_OK;
 }
+
+#ifdef UPA_GREEDY_PROF
+extern "C" int upa_debug_greedy_prof(unsigned long long* out12) {
+  unsigned long long* out8 = out12;
+  unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_greedy_prof), sizeof(z)) != hipSuccess) return -1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_greedy_prof), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int upa_nms_batched(const float* pred, int b, int nc, int a, float conf_thres, float iou_thres, int multi_label,
                                int agnostic, const uint8_t* classes_mask, int max_det, int max_nms, float max_wh,
