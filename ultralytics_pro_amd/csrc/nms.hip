@@ -10,9 +10,9 @@
 //                      ascending candidate order == the stable sort of the reference's candidate list.
 //  2. nms_sort         (one 1024-thread workgroup per image)  if n > max_nms an MSB-first radix select finds the exact
 //                      max_nms-th key (keys are unique) and compacts; then a bitonic sort (LDS when it fits).
-//  3. nms_greedy       (one 512-thread workgroup per image)  walks the sorted candidates 64 at a time: every wave
-//                      tests the chunk against a slice of the kept list held in LDS, wave 0 resolves the in-chunk
-//                      dependencies over the chunk's set bits, appends survivors, stops at max_det.
+//  3. nms_greedy       (one 1024-thread workgroup per image)  walks the sorted candidates 64 at a time: every wave
+//                      tests the chunk against a slice of the kept list held in LDS, the waves build the chunk's suppression
+//                      matrix, wave 0 resolves the in-chunk dependencies by iteration, appends survivors, stops at max_det.
 // Long multi-label lists (validation: conf 0.001, up to A * nc = 672 k candidates per image, max_nms 30000) run in stages instead:
 // the greedy pass almost always has its max_det boxes after the first thousand or so candidates, so (sort, greedy) pairs run over
 // growing PREFIXES of the score order and a pair after the first only touches the images the pass before it flagged (it ran out of
@@ -557,7 +557,9 @@ __device__ __forceinline__ bool iou_gt(float ax1, float ay1, float ax2, float ay
 }
 // (A wave-uniform shortcut - skip the IEEE division when no lane's box overlaps the broadcast one at all, inter == 0 - was measured
 // SLOWER: the vote and the branch cost more than the division they save in one wave out of a few: phase 1 1744 -> 2501 cycles per chunk
-// on the headline batches, 4842 -> 9017 in validation, serial step +1.4 %.  profiles/r05_greedy_phases.txt)
+// on the headline batches, 4842 -> 9017 in validation, serial step +1.4 %.  Replacing the division by inter * rcp(den) with an exact
+// repeat for quotients within a few ulp of thr was slower too: 1788 -> 1897 (phase 1), 1689 -> 2066 (columns) cycles per chunk - the
+// margin test costs what the division's extra instructions do.  profiles/r05_greedy_phases.txt)
 
 // -DUPA_GREEDY_PROF (tools/experiments/r05_greedy_phases.sh builds it into a separate library): wave 0 adds the shader cycles it spends per
 // phase of the greedy kernel to g_greedy_prof (read and cleared by upa_debug_greedy_prof); the product build carries none of it.
@@ -586,11 +588,19 @@ __device__ __forceinline__ void lds_barrier() {
 #ifndef UPA_GREEDY_ROWS_MIN
 #define UPA_GREEDY_ROWS_MIN 8
 #endif
+#ifndef UPA_GREEDY_P1U
+#define UPA_GREEDY_P1U 2
+#endif
+#ifndef UPA_GREEDY_IL
+#define UPA_GREEDY_IL 2
+#endif
+constexpr int GREEDY_IL = UPA_GREEDY_IL;  // suppression columns: candidates evaluated per loop trip by a wave
 constexpr int GREEDY_ROWS_MIN = UPA_GREEDY_ROWS_MIN;  // alive candidates in a chunk from which the suppression columns are computed by all waves
 #ifndef UPA_GREEDY_NT
-#define UPA_GREEDY_NT 512
+#define UPA_GREEDY_NT 1024  // 16 waves per image: with the parallel phase 2, 3 us faster per serial step than 8 (0.8013-0.8029 vs 0.8043-0.8062 ms, same box)
 #endif
 constexpr int GREEDY_NT = UPA_GREEDY_NT;
+
 
 constexpr int GREEDY_NW = GREEDY_NT / 64;
 constexpr int MAX_DET_CAP = 1024;
@@ -611,10 +621,6 @@ __global__ __launch_bounds__(GREEDY_NT) void nms_greedy_kernel(const float* pred
   const u64* sb = sel + (size_t)b * selcap;
   const float* pb = pred + (size_t)b * (4 + nc) * A;
   float* ob = out + (size_t)b * max_det * 6;
-  // zero the fixed-shape output
-  for (int i = threadIdx.x; i < max_det * 6; i += GREEDY_NT) ob[i] = 0.f;
-  if (keep_idx)
-    for (int i = threadIdx.x; i < max_det; i += GREEDY_NT) keep_idx[(size_t)b * max_det + i] = -1;
   if (threadIdx.x == 0) s_kept = 0;
   if (threadIdx.x < 64) colm[threadIdx.x] = 0ull;
   __syncthreads();
@@ -662,6 +668,7 @@ __global__ __launch_bounds__(GREEDY_NT) void nms_greedy_kernel(const float* pred
       }
       // phase 1: this wave tests the chunk against its slice of the kept list
       bool sup = false;
+#pragma unroll UPA_GREEDY_P1U
       for (int k = wave; k < kept; k += GREEDY_NW)
         sup |= iou_gt(kx1[k], ky1[k], kx2[k], ky2[k], kar[k], x1, y1, x2, y2, area, iou_thr);
       const u64 am = __ballot(valid && !sup);
@@ -702,18 +709,23 @@ __global__ __launch_bounds__(GREEDY_NT) void nms_greedy_kernel(const float* pred
           return me_alive && lane > j && iou_gt(jx1, jy1, jx2, jy2, jar, x1, y1, x2, y2, area, iou_thr);
         };
         u64 col = 0ull;
-        u64 it = alive_s;
-        int turn = 0, j0 = -1;
-        while (it) {  // scalar walk over the alive bits; this wave's are those whose rank is wave_s modulo the wave count
-          const int j = __builtin_ctzll((unsigned long long)it);
-          it &= it - 1ull;
-          if ((turn++ & (GREEDY_NW - 1)) != wave_s) continue;
-          if (j0 < 0) { j0 = j; continue; }
-          const bool h0 = hits(j0), h1 = hits(j);  // two independent chains
-          col |= (h0 ? 1ull << j0 : 0ull) | (h1 ? 1ull << j : 0ull);
-          j0 = -1;
+        // this wave's candidates: the alive lanes whose rank among the alive ones is wave_s modulo the wave count (one ballot; the walk
+        // below then visits only them - walking all 64 alive bits in every wave cost more than the IoU tests: 3603 -> 1594 cycles per
+        // chunk), GREEDY_IL at a time (independent chains)
+        u64 it = __ballot(me_alive && (__popcll(alive_s & ((1ull << lane) - 1ull)) & (GREEDY_NW - 1)) == wave_s);
+        while (it) {
+          int j[GREEDY_IL];
+          bool h[GREEDY_IL];
+#pragma unroll
+          for (int q = 0; q < GREEDY_IL; ++q) {
+            j[q] = it ? __builtin_ctzll((unsigned long long)it) : -1;
+            it &= it - 1ull;  // (0 stays 0)
+          }
+#pragma unroll
+          for (int q = 0; q < GREEDY_IL; ++q) h[q] = j[q] >= 0 ? hits(j[q]) : false;
+#pragma unroll
+          for (int q = 0; q < GREEDY_IL; ++q) col |= h[q] ? 1ull << (j[q] & 63) : 0ull;
         }
-        if (j0 >= 0 && hits(j0)) col |= 1ull << j0;
         if (col) atomicOr((unsigned long long*)&colm[lane], (unsigned long long)col);
         GP_AT(9);
         lds_barrier();
@@ -777,6 +789,14 @@ __global__ __launch_bounds__(GREEDY_NT) void nms_greedy_kernel(const float* pred
     lds_barrier();  // the stage buffers are rewritten by the next stage
   }
   GP_FLUSH;
+  {
+    // the rest of the fixed-shape output: rows past the kept ones are zero (keep_idx: -1).  Written here, not up front: zeroing first
+    // meant a full barrier (with its wait for the stores) before the first kept row could be written over the zeros
+    const int k = s_kept;  // (final: every exit of the loops above is behind a barrier that follows its last update)
+    for (int i = k * 6 + (int)threadIdx.x; i < max_det * 6; i += GREEDY_NT) ob[i] = 0.f;
+    if (keep_idx)
+      for (int i = k + (int)threadIdx.x; i < max_det; i += GREEDY_NT) keep_idx[(size_t)b * max_det + i] = -1;
+  }
   if (threadIdx.x == 0) {
     counts[b] = s_kept;
     // the sorted list was only the top part of the candidates and ran out before max_det boxes were kept: this image goes through
