@@ -312,6 +312,19 @@ __global__ __launch_bounds__(256) void nms_emit_kernel(const float* pred, int nc
     }
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for the wave's global STORES (s_waitcnt vmcnt(0)): in the greedy
+// kernel's chunk loop that made wave 0 sit out the acknowledgement of the kept boxes' output rows - ~1.5-2 us per chunk, what the phase
+// profile (tools/experiments/r05_greedy_phases.py) showed as "phase 2" - although nobody in the workgroup reads them back.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+#ifndef UPA_GREEDY_ROWS_MIN
+#define UPA_GREEDY_ROWS_MIN 8
+#endif
 // bitonic sort of `buf[0..npad)` (npad power of two) ascending, all threads of the workgroup
 template <int NT>
 __device__ void bitonic_sort(u64* buf, int npad) {
@@ -329,6 +342,14 @@ __device__ void bitonic_sort(u64* buf, int npad) {
   }
 }
 
+#ifndef UPA_SORT_SCAN_U
+#define UPA_SORT_SCAN_U 8
+#endif
+#ifndef UPA_SORT_KEYS_IN_LDS
+#define UPA_SORT_KEYS_IN_LDS 1
+#endif
+constexpr int SORT_SCAN_U = UPA_SORT_SCAN_U;            // A/B build switches (tools/experiments/r05_nms_variants_ab.sh): 1 / 0 = the round-4 form
+constexpr bool SORT_KEYS_IN_LDS = UPA_SORT_KEYS_IN_LDS != 0;
 constexpr int SORT_NT = 1024;
 constexpr int LDS_SORT_CAP = 16384;  // u64 -> 128 KiB of dynamic LDS (covers every single-label case, A <= 16384)
 
@@ -360,26 +381,52 @@ __global__ __launch_bounds__(SORT_NT) void nms_sort_kernel(const int* count, int
     const int lane = threadIdx.x & 63;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
-    for (int a0 = 0; a0 < A; a0 += SORT_NT) {
-      const int a = a0 + threadIdx.x;
-      u64 k = 0;
-      bool cand = false;
-      if (a < A) {
-        k = best_keys[(size_t)b * A + a];
-        const float best = __uint_as_float(~(unsigned)(k >> 32));
-        const int bc = (int)((unsigned)k - (unsigned)a * (unsigned)nc);
-        cand = best > conf && (!cmask || cmask[bc]);
+    // every candidate list this call can produce fits the LDS sort buffer and stays under max_nms (the usual single-label call: A = 8400):
+    // the keys are compacted straight into LDS and sorted there - no trip through `keys` in global memory, no wait for those stores
+    const bool in_lds = SORT_KEYS_IN_LDS && prefix == 0 && A <= LDS_SORT_CAP && A <= max_nms && (long)A <= cap;
+    constexpr int U = SORT_SCAN_U;  // keys in flight per thread (one load per loop trip left the scan at a memory round trip per 1024 anchors)
+    for (int a0 = 0; a0 < A; a0 += U * SORT_NT) {
+      u64 kk[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int a = a0 + u * SORT_NT + (int)threadIdx.x;
+        kk[u] = a < A ? best_keys[(size_t)b * A + a] : 0ull;
       }
-      const u64 m = __ballot(cand);
-      if (m) {
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&s_n, __popcll(m));
-        base = __shfl(base, 0);
-        if (cand) {
-          const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
-          if (slot >= 0 && slot < cap) kb[slot] = k;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int a = a0 + u * SORT_NT + (int)threadIdx.x;
+        const u64 k = kk[u];
+        bool cand = false;
+        if (a < A) {
+          const float best = __uint_as_float(~(unsigned)(k >> 32));
+          const int bc = (int)((unsigned)k - (unsigned)a * (unsigned)nc);
+          cand = best > conf && (!cmask || cmask[bc]);
+        }
+        const u64 m = __ballot(cand);
+        if (m) {
+          int base = 0;
+          if (lane == 0) base = atomicAdd(&s_n, __popcll(m));
+          base = __shfl(base, 0);
+          if (cand) {
+            const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (in_lds) lbuf[slot] = k;  // (slot < A <= LDS_SORT_CAP)
+            else if (slot >= 0 && slot < cap) kb[slot] = k;
+          }
         }
       }
+    }
+    if (in_lds) {
+      lds_barrier();
+      n = s_n;
+      int npad = 2;
+      while (npad < n) npad <<= 1;
+      for (int i = n + threadIdx.x; i < npad; i += SORT_NT) lbuf[i] = ~0ull;
+      lds_barrier();
+      bitonic_sort<SORT_NT>(lbuf, npad);
+      for (int i = threadIdx.x; i < n; i += SORT_NT) sb[i] = lbuf[i];
+      if (threadIdx.x == 0) nsorted[b] = n;
+      if (partial && threadIdx.x == 0) partial[b] = 0;
+      return;
     }
     __syncthreads();  // the compacted keys (global) and the counter are visible to the whole workgroup
     n = s_n;
@@ -574,19 +621,6 @@ __device__ unsigned long long g_greedy_prof[12];  // init, stage load, phase 1, 
 #define GP_AT(i)
 #define GP_COUNT(i)
 #define GP_FLUSH
-#endif
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for the wave's global STORES (s_waitcnt vmcnt(0)): in the greedy
-// kernel's chunk loop that made wave 0 sit out the acknowledgement of the kept boxes' output rows - ~1.5-2 us per chunk, what the phase
-// profile (tools/experiments/r05_greedy_phases.py) showed as "phase 2" - although nobody in the workgroup reads them back.
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-}
-
-#ifndef UPA_GREEDY_ROWS_MIN
-#define UPA_GREEDY_ROWS_MIN 8
 #endif
 #ifndef UPA_GREEDY_P1U
 #define UPA_GREEDY_P1U 2
