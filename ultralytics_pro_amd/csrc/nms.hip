@@ -342,14 +342,6 @@ __device__ void bitonic_sort(u64* buf, int npad) {
   }
 }
 
-#ifndef UPA_SORT_SCAN_U
-#define UPA_SORT_SCAN_U 8
-#endif
-#ifndef UPA_SORT_KEYS_IN_LDS
-#define UPA_SORT_KEYS_IN_LDS 1
-#endif
-constexpr int SORT_SCAN_U = UPA_SORT_SCAN_U;            // A/B build switches (tools/experiments/r05_nms_variants_ab.sh): 1 / 0 = the round-4 form
-constexpr bool SORT_KEYS_IN_LDS = UPA_SORT_KEYS_IN_LDS != 0;
 constexpr int SORT_NT = 1024;
 constexpr int LDS_SORT_CAP = 16384;  // u64 -> 128 KiB of dynamic LDS (covers every single-label case, A <= 16384)
 
@@ -383,8 +375,8 @@ __global__ __launch_bounds__(SORT_NT) void nms_sort_kernel(const int* count, int
     __syncthreads();
     // every candidate list this call can produce fits the LDS sort buffer and stays under max_nms (the usual single-label call: A = 8400):
     // the keys are compacted straight into LDS and sorted there - no trip through `keys` in global memory, no wait for those stores
-    const bool in_lds = SORT_KEYS_IN_LDS && prefix == 0 && A <= LDS_SORT_CAP && A <= max_nms && (long)A <= cap;
-    constexpr int U = SORT_SCAN_U;  // keys in flight per thread (one load per loop trip left the scan at a memory round trip per 1024 anchors)
+    const bool in_lds = prefix == 0 && A <= LDS_SORT_CAP && A <= max_nms && (long)A <= cap;
+    constexpr int U = 8;  // keys in flight per thread (one load per loop trip left the scan at a memory round trip per 1024 anchors)
     for (int a0 = 0; a0 < A; a0 += U * SORT_NT) {
       u64 kk[U];
 #pragma unroll
@@ -622,13 +614,7 @@ __device__ unsigned long long g_greedy_prof[12];  // init, stage load, phase 1, 
 #define GP_COUNT(i)
 #define GP_FLUSH
 #endif
-#ifndef UPA_GREEDY_P1U
-#define UPA_GREEDY_P1U 2
-#endif
-#ifndef UPA_GREEDY_IL
-#define UPA_GREEDY_IL 2
-#endif
-constexpr int GREEDY_IL = UPA_GREEDY_IL;  // suppression columns: candidates evaluated per loop trip by a wave
+constexpr int GREEDY_IL = 2;  // suppression columns: candidates evaluated per loop trip by a wave (1 / 4: 1828 / 1679 against 1594 cycles per chunk)
 constexpr int GREEDY_ROWS_MIN = UPA_GREEDY_ROWS_MIN;  // alive candidates in a chunk from which the suppression columns are computed by all waves
 #ifndef UPA_GREEDY_NT
 #define UPA_GREEDY_NT 1024  // 16 waves per image: with the parallel phase 2, 3 us faster per serial step than 8 (0.8013-0.8029 vs 0.8043-0.8062 ms, same box)
@@ -702,7 +688,7 @@ __global__ __launch_bounds__(GREEDY_NT) void nms_greedy_kernel(const float* pred
       }
       // phase 1: this wave tests the chunk against its slice of the kept list
       bool sup = false;
-#pragma unroll UPA_GREEDY_P1U
+#pragma unroll 2
       for (int k = wave; k < kept; k += GREEDY_NW)
         sup |= iou_gt(kx1[k], ky1[k], kx2[k], ky2[k], kar[k], x1, y1, x2, y2, area, iou_thr);
       const u64 am = __ballot(valid && !sup);
