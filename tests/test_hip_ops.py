@@ -1169,6 +1169,20 @@ def test_nms_large_multilabel_vs_oracle(staging):
         assert a.shape == b.shape and torch.equal(a.cpu(), b)
 
 
+def test_nms_staging_options_are_validated():
+    """upa_opts.nms_stages / nms_first_prefix outside their documented ranges are refused (UPA_EINVAL), not silently clamped."""
+    from tests.hip_utils import DEV
+    from ultralytics_pro_amd import _lib as L
+    from ultralytics_pro_amd.engine import runtime as R
+    from ultralytics_pro_amd.utils.nms import non_max_suppression
+    p = torch.zeros(1, 84, 64, device=DEV)
+    for bad in ({"nms_stages": 3}, {"nms_stages": -1}, {"nms_first_prefix": 100}, {"nms_first_prefix": 16384}, {"nms_first_prefix": -2}):
+        with R.use_opts(L.Opts(**bad)), pytest.raises(L.UpaError):
+            non_max_suppression(p, multi_label=True)
+    with R.use_opts(L.Opts(nms_stages=2, nms_first_prefix=256)):
+        assert non_max_suppression(p, multi_label=True)[0].shape == (0, 6)
+
+
 def test_cpu_tensor_fails_loudly():
     from ultralytics_pro_amd._lib import UpaError
     pm, _ = _mods()
