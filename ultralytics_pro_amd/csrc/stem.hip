@@ -513,6 +513,24 @@ struct Geo {
 };
 }  // namespace sf
 
+// -DUPA_STEM_PROF (tools/experiments/r05_stem_phases.sh builds it into a separate library): wave 0 adds the shader cycles it spends per
+// phase of the fused stem kernel to g_stem_prof (read and cleared by upa_debug_stem_prof); the product build carries none of it.
+#ifdef UPA_STEM_PROF
+__device__ unsigned long long g_stem_prof[8];  // wait for the patch, issue the next patch, stage 2, barrier, stage 3, tiles, workgroups
+#define SP_DECL unsigned long long sp_t = __builtin_amdgcn_s_memtime(), sp_acc[6] = {0, 0, 0, 0, 0, 0}
+#define SP_AT(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); sp_acc[i] += t_ - sp_t; sp_t = t_; } while (0)
+#define SP_FLUSH do { if (threadIdx.x == 0) { for (int i_ = 0; i_ < 6; ++i_) atomicAdd(&g_stem_prof[i_], sp_acc[i_]); atomicAdd(&g_stem_prof[6], 1ull); } } while (0)
+extern "C" int upa_debug_stem_prof(unsigned long long* out8) {
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stem_prof), sizeof(z)) != hipSuccess) return -1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_stem_prof), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#else
+#define SP_DECL
+#define SP_AT(i)
+#define SP_FLUSH
+#endif
+
 // NW waves per workgroup: 4 (two workgroups = two waves per SIMD) or 8 (four per SIMD: the segments of stage 2 and the rows of
 // stage 3 are spread over twice the waves, the same LDS).
 template <int NW, int KS0 = 3>
@@ -616,12 +634,19 @@ __global__ __launch_bounds__(NW * 64) void stem_conv_fused_kernel(const StemFuse
       }
       goff[ks][j] = (o + shift) * 2;
     }
+  SP_DECL;
+  // (Two restructurings measured with the phase profile, tools/experiments/r05_stem_phases.py, and dropped - profiles/r05_stem_phases.txt:
+  // LDS-only barriers + the wait for the next patch moved behind the second conv's matrix work moved the waits, not the 11.2 k cycles a
+  // tile takes - the two workgroups of a CU fill each other's waits; requesting segment s + NW's gathers before segment s is multiplied
+  // made stage 2 slower, 3454 -> 3705 cycles per tile, the kernel 52.9 -> 56.8 us.)
   for (int cur = 0;; cur ^= 1) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // patch `cur` landed; everyone is done with the stem tile and the other patch buffer
+    SP_AT(0);
     slot += gridDim.x;
     const int next = slot < ntiles ? tile_of(slot) : ntiles;
     if (next < ntiles) stage(next, fsm + (cur ^ 1) * PATCH);
+    SP_AT(1);
     const int n = tile / tilesPerImg;
     const int t2 = tile - n * tilesPerImg;
     const int tyi = t2 / p.tilesX, txi = t2 - tyi * p.tilesX;
@@ -669,7 +694,9 @@ __global__ __launch_bounds__(NW * 64) void stem_conv_fused_kernel(const StemFuse
     };
     if (interior) stage2(std::false_type{});
     else stage2(std::true_type{});
+    SP_AT(2);
     __syncthreads();
+    SP_AT(3);
     // ---- stage 3: second conv, a wave owns T1H / NW output rows (16 pixels each) x 32 channels
 #pragma unroll
     for (int rr = 0; rr < T1H / NW; ++rr) {
@@ -700,9 +727,14 @@ __global__ __launch_bounds__(NW * 64) void stem_conv_fused_kernel(const StemFuse
       if (oy < p.OH && ox < p.OW)
         *reinterpret_cast<u32x4*>(p.y + ((size_t)((n * p.OH + oy) * p.OW + ox) * p.ldy + cb) * 2) = u32x4{lo[0], hi[0], lo[1], hi[1]};
     }
+    SP_AT(4);
+#ifdef UPA_STEM_PROF
+    sp_acc[5] += 1;
+#endif
     tile = next;
     if (tile >= ntiles) break;
   }
+  SP_FLUSH;
 }
 
 // ---- The same fusion for yolov8s' stem pair: Conv(3, 32, 3, 2) -> Conv(32, 64, 3, 2), both SiLU (yolov8.yaml rows 0-1 at width 0.5).
