@@ -1,5 +1,6 @@
-# Same-box A/B of the fused stem kernel's stage-2 software pipeline (compile-time UPA_STEM_PIPE of csrc/stem.hip; 0 = one segment at a time):
-# tests, phase profile of both builds, kernel time under rocprofv3 --stats, serial step.
+# The same-box A/B that measured the fused stem kernel's stage-2 software pipeline (a compile-time switch UPA_STEM_PIPE that csrc/stem.hip no
+# longer has: the pipeline was slower and is gone - profiles/r05_stem_phases.txt); kept as the recipe: tests, phase profile of both builds,
+# kernel time under rocprofv3 --stats, serial step.
 #   gpurun -- 'bash tools/experiments/r05_stem_ab.sh'
 python -m pytest tests/test_hip_ops.py -x -q -m gpu -k "stem" 2>&1 | tail -1
 bash tools/experiments/r05_stem_phases.sh
