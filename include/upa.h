@@ -71,6 +71,8 @@ typedef struct upa_opts {
   int32_t no_epi_stats;    /* upa_conv2d_bn_stats: 1 = the batch statistics always by a reduction pass over z (upa_bn_stats), never from the convolution's own workgroups; A/B */
   int32_t nms_stages;      /* upa_nms_batched_opts, multi-label lists longer than 16384 (validation): 0 = prefix keys only (histogram + emit kernels), stages ~nms_first_prefix / ~16384 / exact | 1 = all keys written up front, the sort kernel's pass picks the prefix from the histogram | 2 = no histogram: radix select of the top 16384, then exact (the round-4 form); results identical, A/B */
   int32_t nms_first_prefix; /* target length of the first sorted prefix there: 0 = 4096 | n in [256, 16384) | -1 = none (first prefix ~16384) */
+  int32_t detect_stream;   /* upa_detect_level_stream (csrc/detect_stream.hip: one Detect level, both branches, as one line-buffer launch): 0 / 1 = refuse (callers run the tile form: stacked first conv + upa_detect_head_tails - the default: measured slower, profiles/r06_detect_stream.txt), 2 = run wherever the form applies (A/B, tests) */
+  int32_t detect_stream_rows; /* its output rows per workgroup: 0 = the whole image height (one workgroup per strip and branch: least total CU time) | even >= 4 (more, shorter workgroups: a lower latency with one step at a time) */
 } upa_opts;
 
 /* Library / device info. Returns the ABI version (int); fills name with the kernel target ("gfx950"). */
@@ -287,6 +289,24 @@ int upa_detect_branch_tail_group(const upa_branch_level* levels, int count, int 
  * class problems share grids as well (two kernel instantiations per grid): the six tails of a three-level head are two launches. */
 int upa_detect_head_tails(const upa_branch_level* box, const upa_branch_level* cls, int count, int nc, float* y, int a_total,
                           unsigned long long* best_keys, int dtype, const upa_opts* opts, void* stream);
+/* ONE level of a Detect head, both branches and all three convolutions of each, in one launch (bf16; csrc/detect_stream.hip):
+ * cv2[i] = Conv(cin, 64, 3) -> Conv(64, 64, 3) -> Conv2d(64, 4 * 16, 1) -> DFL + dist2bbox * stride -> y[b, 0:4, a0 + a],
+ * cv3[i] = Conv(cin, 80, 3) -> Conv(80, 80, 3) -> Conv2d(80, nc, 1) -> sigmoid -> y[b, 4:4+nc, a0 + a] (+ best-class NMS keys),
+ * the intermediate maps only ever existing as a few rows in LDS (line-buffer form: a workgroup streams down a 20-column strip of one
+ * image, fixed wave roles, weights in registers).                     head.py:94-100 (cv2 / cv3), :116-126 (forward), :151-191 (_inference)
+ * A branch = its channel count c and three upa_pack_conv_weight(UPA_BF16) blobs with BN folded: w1 = 3x3 cin -> c, w2 = 3x3 c -> c,
+ * wt = 1x1 c -> 64 (box) | 80 (class, zero filters beyond nc), biases f32 padded to a multiple of 16.
+ * Form: cin = 64, box c = 64, class c = 80, nc <= 80 (yolov8n's 80 x 80 level).  UPA_EUNSUPPORTED otherwise (callers run
+ * upa_conv2d_bias_act_group + upa_detect_head_tails).  best_keys / upa_opts.keys_only as upa_detect_branch_tail. */
+typedef struct upa_detect_branch {
+  int32_t c, reserved;
+  const void* w1; const float* b1;
+  const void* w2; const float* b2;
+  const void* wt; const float* bt;
+} upa_detect_branch;
+int upa_detect_level_stream(const void* x, int n, int h, int w, int cin, int ldx, const upa_detect_branch* box,
+                            const upa_detect_branch* cls, int nc, float stride_px, float* y, int a_total, int a0,
+                            unsigned long long* best_keys, int dtype, const upa_opts* opts, void* stream);
 
 
 /* ---- NMS ----------------------------------------------------------------------------------------------------------

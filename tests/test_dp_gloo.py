@@ -332,3 +332,59 @@ def test_validator_stats_gather_two_ranks_matches_reference_map(golden_dir):
         assert nrows == sum(G[f"det{i}"].shape[0] for i in range(4))
         assert np.array_equal(np.asarray(ap), G["ap"]), rank
         assert np.allclose(mean, G["mean"], rtol=0, atol=1e-12), rank
+
+
+def _replicate_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from ultralytics_pro_amd.engine.trainer import DetectionTrainer
+    from ultralytics_pro_amd.engine.validator import DetectionValidator
+    from ultralytics_pro_amd.parallel import init_distributed
+    init_distributed("gloo")
+    # A trainer shell holding only what the replicate steps touch (the flat buffer tensors; building a real trainer needs a GPU):
+    # after a multi-rank training step the BatchNorm running statistics differ per rank - rank r's are offset by r here.
+    tr = DetectionTrainer.__new__(DetectionTrainer)
+    tr.device = torch.device("cpu")
+    tr.nbuf = 1000
+    base = torch.linspace(-1, 1, tr.nbuf)
+    tr.RB = torch.cat([base + 0.25 * rank, torch.zeros(7)])            # (the flat buffer is allowed to be longer than nbuf)
+    tr.ERB = torch.cat([0.5 * base + 0.125 * rank, torch.zeros(7)])
+    tail_rb, tail_erb = tr.RB[tr.nbuf:].clone(), tr.ERB[tr.nbuf:].clone()
+    tr.sync_ema_buffers()
+    assert torch.equal(tr.RB[:tr.nbuf], base) and torch.equal(tr.ERB[:tr.nbuf], 0.5 * base)   # every rank now holds rank 0's
+    assert torch.equal(tr.RB[tr.nbuf:], tail_rb) and torch.equal(tr.ERB[tr.nbuf:], tail_erb)
+    # the early-stopping flag is rank 0's on every rank, whatever the others decided locally (engine/trainer.py:505-508)
+    assert tr.broadcast_stop(rank == 0) is True
+    assert tr.broadcast_stop(rank != 0) is False
+    # the validation loss: accumulated per batch on every rank, averaged over the ranks on rank 0, None elsewhere
+    v = DetectionValidator()
+    assert v.reduce_loss() is None
+    for b in range(3):
+        v.add_loss(torch.tensor([1.0, 2.0, 3.0]) * (rank + 1) + b)
+    got = v.reduce_loss()
+    if rank == 0:
+        # rank r accumulates 3 * (r + 1) * [1, 2, 3] + (0 + 1 + 2); mean over ranks, then per batch
+        mean_r = sum(3 * (r + 1) for r in range(world)) / world
+        want = (mean_r * torch.tensor([1.0, 2.0, 3.0]) + 3.0) / 3
+        assert torch.allclose(got, want, rtol=0, atol=1e-6), (got, want)
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, float(tr.RB[:tr.nbuf].double().sum()), float(tr.ERB[:tr.nbuf].double().sum())))
+
+
+def test_world2_gloo_replicate_steps_ema_buffers_stop_flag_validation_loss():
+    """SURVEY 8e's "also replicate" clause on two gloo ranks: rank 0's EMA / BatchNorm buffers on every rank before a sharded validate
+    (engine/trainer.py:695-698), the stop-flag broadcast (:505-508) and the rank-averaged validation loss (engine/validator.py:243-245)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_replicate_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=5) for _ in range(2))
+    assert res[0][1:] == res[1][1:]   # identical buffers on both ranks after the sync

@@ -1,6 +1,8 @@
 """-m gpu: whole hot path (model forward -> Detect decode -> NMS) on the HIP path vs the oracle and the committed
 reference goldens (B=2 synthetic 640x640).  Tolerance from BASELINE.json north_star: 1e-3 on boxes/scores (f32 mode)."""
 
+import contextlib
+
 import numpy as np
 import pytest
 import torch
@@ -119,12 +121,13 @@ def test_e2e_bf16_matches_reference_golden(name, golden_dir):
           f"max={dbox.max():.3f} px, score max|d|={dsc.max():.4f}; detections {a['n_mine']} vs {a['n_ref']}: recall "
           f"{a['recall']:.3f} precision {a['precision']:.3f}, matched box p50={a['box_p50']:.3f} p99={a['box_p99']:.3f} "
           f"max={a['box_max']:.3f} px, score p99={a['score_p99']:.4f} max={a['score_max']:.4f}")
-    # The IoU >= 0.9 agreement on this CHAOTIC family is a report (one flipped threshold decision of ~50-130 rows is 1-2 %, and it moved
-    # with every kernel that changed an f32 summation order: see the table above) - what is asserted from this single sample are the
-    # coarse facts a broken kernel would violate; the gates proper are the per-seed test below, the smooth-family tests and the
-    # rounding-point emulation, layer by layer.
-    _r9, _p9, r5, p5, bp99, bmax, sp99 = BF16_BOUNDS[name]
+    # The IoU >= 0.9 agreement on this CHAOTIC family moves with every kernel that changes an f32 summation order (one flipped threshold
+    # decision of ~50-130 rows is 1-2 %: see the table above), so its floor sits well under the measured spread - but it IS a floor:
+    # a kernel that loses a tenth of the reference's boxes at IoU 0.9 fails here.  The tight gates are the per-seed test below, the
+    # smooth-family tests and the rounding-point emulation, layer by layer.
+    r9, p9, r5, p5, bp99, bmax, sp99 = BF16_BOUNDS[name]
     assert a5["recall"] >= r5 and a5["precision"] >= p5
+    assert a["recall"] >= r9 and a["precision"] >= p9   # hard floor on the IoU >= 0.9 agreement (round 6: a gate again, see the table)
     assert a["box_p99"] <= bp99 and a["box_max"] <= bmax and a["score_p99"] <= sp99
     assert np.quantile(dbox, 0.99) <= max(bmax, 4.0) and dsc.max() <= 0.05
 
@@ -185,14 +188,32 @@ SMOOTH_BAND = 0.005
 SMOOTH_BOUNDS = {"yolov8n": (0.93, 0.90), "yolov8s": (0.97, 0.97), "yolov3-tiny": (0.97, 0.97), "yolov5-BoT3": (0.97, 0.97)}
 
 
+def _dispatch(which):
+    """The option sets a model runs under: "session" = the test session's (tests/conftest.py: every eligible shape on the pipelined /
+    pair kernels), "serial" = the library defaults (`upa_opts` all zero: what `model(x)` and `bench.py --serial` run), "throughput" =
+    the library defaults + what `engine/pipeline.py: PipelinedRunner.throughput_opts` adds for copies in flight - the dispatch every
+    quoted images/s figure runs under."""
+    from ultralytics_pro_amd import _lib as L
+    from ultralytics_pro_amd.engine import runtime as R
+    if which == "session":
+        return contextlib.nullcontext()
+    if which == "serial":
+        return R.use_opts(L.Opts())
+    assert which == "throughput"
+    return R.use_opts(L.Opts(c2f=4, conv_ws3=1, c2f_stream_rows=-1))
+
+
+@pytest.mark.parametrize("dispatch", ["session", "serial", "throughput"])
 @pytest.mark.parametrize("name", list(SMOOTH_BOUNDS))
-def test_e2e_bf16_smooth_family_matches_reference_golden(name, golden_dir):
+def test_e2e_bf16_smooth_family_matches_reference_golden(name, dispatch, golden_dir):
+    """bf16 on the smooth family against the REFERENCE's f32 detections, under each of the three dispatches (round-5 review: only
+    yolov8n was compared under the throughput dispatch; the kernels a config runs on in the bench must be the kernels that are pinned)."""
     from tests.hip_utils import DEV, detection_agreement, split_rows
     from ultralytics_pro_amd.utils.nms import non_max_suppression
     g = np.load(golden_dir / f"e2e_{name}_smooth.npz")
     m = _build(name, torch.bfloat16, family="smooth:" + name)
     x = P.synthetic_images(2).to(DEV).to(torch.bfloat16).contiguous()
-    with torch.no_grad():
+    with torch.no_grad(), _dispatch(dispatch):
         y = m(x)[0]
     torch.cuda.synchronize()
     d = np.abs(y.cpu()[:, :, g["anchor_sel"]].numpy() - g["y_sel"])
@@ -203,7 +224,7 @@ def test_e2e_bf16_smooth_family_matches_reference_golden(name, golden_dir):
     out_x = [r[np.abs(r[:, 4] - 0.25) > SMOOTH_BAND] for r in out]
     rec_x = detection_agreement(out, ref_x, 0.9)["recall"]       # every reference row outside the band is found ...
     prec_x = detection_agreement(out_x, ref, 0.9)["precision"]   # ... and every row of mine outside it exists in the reference
-    print(f"{name} smooth bf16 vs reference golden: head box max|d| {d[:, :4].max():.3f} px score max|d| {d[:, 4:].max():.4f}; detections "
+    print(f"{name} smooth bf16 [{dispatch}] vs reference golden: head box max|d| {d[:, :4].max():.3f} px score max|d| {d[:, 4:].max():.4f}; detections "
           f"{a['n_mine']} vs {a['n_ref']}: recall {a['recall']:.3f} precision {a['precision']:.3f} (outside the +-{SMOOTH_BAND} band: "
           f"{rec_x:.4f} / {prec_x:.4f}; band rows ref {sum(map(len, ref)) - sum(map(len, ref_x))} mine {sum(map(len, out)) - sum(map(len, out_x))}), "
           f"matched box p99 {a['box_p99']:.3f} max {a['box_max']:.3f} px, score max {a['score_max']:.4f}")
@@ -378,7 +399,10 @@ def test_e2e_rtdetr_bf16_backbone_matches_reference_golden(golden_dir):
     # nearly flat, so WHICH 300 tokens are selected (head.py:2175) is decided by differences far below bf16 resolution: the
     # bf16 backbone picks a mostly different - equally valid - query set; the rows it shares with the reference agree.  The
     # order-exact comparison lives in the f32 test above; this one pins the bf16 behaviour as measured.
-    assert q["recall"] >= 0.2 and a["n_mine"] >= 0.8 * a["n_ref"] and a["n_mine"] <= 1.25 * a["n_ref"]
+    # Round 6: the query-set overlap is a REPORT here (it was gated at 0.2, a bound 80 % wrong rows pass).  What pins this mode against
+    # the oracle are `test_e2e_bf16_rtdetr_encoder_head_every_token_vs_oracle` (everything in front of the selection, token by token)
+    # and `test_e2e_bf16_rtdetr_decoder_with_oracle_queries_vs_oracle` (everything behind it, row by row) - both at >= 0.99.
+    assert a["n_mine"] >= 0.8 * a["n_ref"] and a["n_mine"] <= 1.25 * a["n_ref"]
     assert a["box_p99"] <= 4.0 and a["score_p99"] <= 0.04
 
 
@@ -710,7 +734,7 @@ def test_e2e_bf16_headline_batch_smooth_family_vs_oracle():
     det = m.model[-1]
     det.keep_raw, det.nms_keys, det.concurrent = False, True, False
     xb = x.to(DEV).to(torch.bfloat16).contiguous()
-    with torch.no_grad(), R.use_opts(c2f=4, conv_ws3=1, c2f_stream_rows=-1):
+    with torch.no_grad(), _dispatch("throughput"):
         run = m.compile(xb, post=lambda o: nms_raw(o[0], 0.25, 0.7, max_det=300, key="full"))
         o_, c_, _ = run()
         torch.cuda.synchronize()
@@ -764,9 +788,9 @@ def test_e2e_bf16_rtdetr_config_batch_vs_oracle():
     from tests.hip_utils import DEV
     from ultralytics_pro_amd.utils.nms import rtdetr_postprocess
     fam = RTDETR_BF16_FAMILY
-    x, y_ref = _oracle_full("yolov3-rtdetr", 16, family=fam)
+    x, y_ref, _ = _oracle_rtdetr_taps(16, fam)
     m = _build("yolov3-rtdetr", torch.bfloat16, family=fam)
-    with torch.no_grad():
+    with torch.no_grad(), _dispatch("throughput"):
         y = m(x.to(DEV).to(torch.bfloat16).contiguous())[0]
     torch.cuda.synchronize()
     yc = y.float().cpu()
@@ -784,11 +808,148 @@ def test_e2e_bf16_rtdetr_config_batch_vs_oracle():
     ref = onms.rtdetr_postprocess(y_ref, 0.25)
     print(f"yolov3-rtdetr bf16 bs 16 vs oracle: oracle rows with a partner within 0.5 px / 0.01: mean {np.mean(fr):.4f} min {min(fr):.4f}; "
           f"among them max box {worst_box * 640:.3f} px score {worst_sc:.4f}; detections {sum(a.shape[0] for a in mine)} vs {sum(r.shape[0] for r in ref)}")
-    assert np.mean(fr) >= RTDETR_BF16_MATCH[0] and min(fr) >= RTDETR_BF16_MATCH[1]
+    # A REPORT since round 6 (the 0.10 gate it carried passed 90 % wrong rows): with its OWN query selection the bf16 mode decodes
+    # mostly other tokens than the oracle - the 300 queries are the top of nearly flat random encoder scores - so this fraction
+    # measures the selection's sensitivity, not the arithmetic.  The arithmetic is pinned by the two tests below, in front of and
+    # behind the selection.  Asserted here: the detections the user sees are of the same number.
+    n_mine, n_ref = sum(a.shape[0] for a in mine), sum(r.shape[0] for r in ref)
+    assert 0.8 * n_ref <= n_mine <= 1.25 * n_ref + 4
 
 
 RTDETR_BF16_FAMILY = "smooth:yolov3-rtdetr"
-RTDETR_BF16_MATCH = (0.10, 0.04)  # (mean, least per image) fraction of oracle rows reproduced within the AMP tolerance - set from the measurement
+
+
+_RTDETR_ORACLE = {}
+
+
+def _oracle_rtdetr_taps(batch, family):
+    """The oracle's yolov3-rtdetr on `batch` images with the encoder-side tensors of `_get_decoder_input` (head.py:2143-2200) kept:
+    enc_output features and enc_score_head logits of ALL tokens, the top-300 token indices (head.py:2175), and the encoder box of
+    EVERY token, sigmoid(enc_bbox_head(features) + anchors) (head.py:2183-2185 applied to all 8400 tokens instead of the selected
+    300: the same arithmetic, nothing selected).  Cached per (batch, family): one CPU forward of 16 x 257 GFLOP serves both tests."""
+    key = (batch, family)
+    if key in _RTDETR_ORACLE:
+        return _RTDETR_ORACLE[key]
+    o = ot.DetectionModel("yolov3-rtdetr.yaml")
+    P.apply_procedural_weights(o, family=family)
+    o.fuse()
+    head = o.model[-1]
+    kept = {}
+    h1 = head.enc_output.register_forward_hook(lambda m, i, out: kept.__setitem__("features", out.detach()))
+    h2 = head.enc_score_head.register_forward_hook(lambda m, i, out: kept.__setitem__("scores", out.detach()))
+    x = P.synthetic_images(batch)
+    with torch.no_grad():
+        y = o(x)[0]
+        h1.remove()
+        h2.remove()
+        sz = [640 // 8, 640 // 16, 640 // 32]
+        anchors, valid = head._generate_anchors([[s, s] for s in sz])
+        kept["topk"] = torch.topk(kept["scores"].max(-1).values, head.num_queries, dim=1).indices
+        kept["enc_box"] = (head.enc_bbox_head(kept["features"]) + anchors).sigmoid()
+        kept["valid"] = valid.view(-1)
+    _RTDETR_ORACLE.clear()
+    _RTDETR_ORACLE[key] = (x, y, kept)
+    return _RTDETR_ORACLE[key]
+
+
+# Gates of the two bf16 pins of config 5.  The reference's AMP self-check (utils/checks.py:780) allows 0.5 px between an fp32 and an
+# fp16-autocast run: fp16 carries an 11-bit significand, bf16 an 8-bit one, so the same arithmetic in bf16 - the dtype BASELINE config 5
+# is measured in - moves boxes 2^3 times as far.  Measured on MI355X (tools/experiments/r06_rtdetr_bf16_sources.py, bs 16, smooth family;
+# gpurun_out -> profiles/r06_rtdetr_bf16_sources.txt): with ONLY the backbone in bf16 and the whole decoder in exact f32, 57 % of the
+# decoder rows and 84 % of the encoder tokens are inside 0.5 px (row p50 0.42 / p99 1.75 / max 4.1 px); the quoted mode (bf16 projections,
+# bf16-product linears, bf16 value rows) has 20 % / 71 % inside 0.5 px (row p50 0.89 / p99 3.0 / max 5.0 px), scores <= 0.005 either way.
+# So the fp16 tolerance is out of reach for ANY bf16 backbone; the gate is the fp16 tolerance scaled by those three bits on the boxes
+# (4 px of 640) and UNSCALED on the class probabilities (0.01) - and the fraction inside the unscaled 0.5 px is printed and floored at
+# what was measured, so a regression of the arithmetic shows.  On the default (chaotic) weight family the decoder amplifies the
+# backbone's bf16 noise to tens of pixels even on fixed queries (p99 35 px with an exact-f32 decoder too): a report, coarse floors only.
+RTDETR_BOX_TOL_PX = 0.5 * 2 ** (11 - 8)
+RTDETR_ENC_TOKENS_OK = 0.999   # encoder tokens inside (4 px, 0.01) on the smooth family; measured 1.0000
+RTDETR_DEC_ROWS_OK = 0.99      # decoder rows on the oracle's queries inside (4 px, 0.01) on the smooth family; measured 0.9983
+RTDETR_INSIDE_HALF_PX = {"enc": 0.65, "dec": 0.15}   # floors of the fractions inside the UNSCALED 0.5 px (measured 0.711 / 0.2015)
+
+
+@pytest.mark.parametrize("family", [None, RTDETR_BF16_FAMILY])
+def test_e2e_bf16_rtdetr_encoder_head_every_token_vs_oracle(family):
+    """Config 5 in the mode its throughput is quoted in, pinned BEFORE the chaotic top-300 selection: the bf16 darknet53 backbone +
+    bf16 input projections + enc_output / LayerNorm + enc_score_head + enc_bbox_head (head.py:2117-2172, 2183-2185) for EVERY one of
+    the 16 x 8400 tokens against the f32 oracle - class probabilities sigmoid(enc_score logits) and encoder boxes
+    sigmoid(enc_bbox_head(features) + anchors) in pixels of 640.  This comparison is token by token: no selection, nothing to flip."""
+    from tests.hip_utils import DEV
+    from ultralytics_pro_amd.nn.modules import rtdetr as RT
+    x, _, ref = _oracle_rtdetr_taps(16, family)
+    m = _build("yolov3-rtdetr", torch.bfloat16, family=family)
+    head = m.model[-1]
+    head.taps = {}
+    with torch.no_grad(), _dispatch("throughput"):
+        m(x.to(DEV).to(torch.bfloat16).contiguous())
+        t = head.taps
+        st, bs = t["static"], t["bs"]
+        sc = head.level_major_to_image(t["enc_scores"], st, bs).float().cpu()
+        # the encoder box of every token through the product's own enc_bbox_head in the perf mode's arithmetic (bf16 products)
+        saved = RT._LINEAR_BF16[0]
+        RT._LINEAR_BF16[0] = bool(head.linear_bf16)
+        try:
+            delta = head.enc_bbox_head(t["features"], key="all_tokens")
+        finally:
+            RT._LINEAR_BF16[0] = saved
+        delta = head.level_major_to_image(delta, st, bs).float().cpu()
+        torch.cuda.synchronize()
+    head.taps = None
+    anchors = st["anchors"].cpu().view(1, -1, 4)
+    box = (delta + anchors).sigmoid()
+    valid = ref["valid"]
+    dp = (sc.sigmoid() - ref["scores"].sigmoid()).abs()                     # (16, 8400, 80) class probabilities
+    db = (box - ref["enc_box"]).abs()[:, valid] * 640                       # (16, valid tokens, 4) px
+    # invalid tokens (border anchors, head.py:2113): the anchor is +inf, the box 1.0 on both sides whatever the features are
+    assert torch.equal(box[:, ~valid], ref["enc_box"][:, ~valid])
+    tok_ok = ((dp.amax(2) <= 0.01)[:, valid] & (db.amax(2) <= 0.5)).float().mean(1)
+    dl = (sc - ref["scores"]).abs()
+    # the ranking statistic itself (max class logit per token) and how flat it is: the spread of the oracle's top-300 cut
+    rank_ref = ref["scores"].max(-1).values
+    cut = torch.topk(rank_ref, 300, dim=1).values
+    print(f"yolov3-rtdetr bf16 encoder head, family {family}: tokens inside 0.5 px / 0.01: mean {tok_ok.mean():.5f} least image "
+          f"{tok_ok.min():.5f}; class prob |d| max {dp.max():.5f} p99.9 {dp.flatten()[::7].quantile(0.999):.5f}; logit |d| max "
+          f"{dl.max():.4f}; box |d| max {db.max():.4f} px p99.9 {db.flatten().quantile(0.999):.4f} px; oracle top-300 logit span "
+          f"{(cut[:, 0] - cut[:, -1]).mean():.4f}, rank-stat |d| mean {(sc.max(-1).values - rank_ref).abs().mean():.4f}")
+    tok_bf = ((dp.amax(2) <= 0.01)[:, valid] & (db.amax(2) <= RTDETR_BOX_TOL_PX)).float().mean(1)
+    print(f"  inside ({RTDETR_BOX_TOL_PX} px, 0.01): mean {tok_bf.mean():.5f} least image {tok_bf.min():.5f}")
+    if family is None:   # chaotic family: report + coarse floors (what a broken kernel would violate)
+        assert dp.max().item() <= 0.05 and db.flatten()[::3].quantile(0.99).item() <= 4.0
+        return
+    assert tok_bf.mean().item() >= RTDETR_ENC_TOKENS_OK and tok_bf.min().item() >= RTDETR_ENC_TOKENS_OK - 0.002
+    assert dp.max().item() <= 0.01 and db.flatten()[::3].quantile(0.99).item() <= 1.5
+    assert tok_ok.mean().item() >= RTDETR_INSIDE_HALF_PX["enc"]
+
+
+@pytest.mark.parametrize("family", [None, RTDETR_BF16_FAMILY])
+def test_e2e_bf16_rtdetr_decoder_with_oracle_queries_vs_oracle(family):
+    """Config 5's perf mode end to end with the ORACLE'S top-300 token indices injected (`RTDETRDecoder.query_override`, head.py:2175):
+    bf16 backbone, bf16-product decoder (6 deformable layers, transformer.py:719-773), output (16, 300, 84) compared with the oracle's
+    ROW BY ROW - same token in the same row on both sides, so no matching and no set semantics."""
+    from tests.hip_utils import DEV
+    x, y_ref, ref = _oracle_rtdetr_taps(16, family)
+    m = _build("yolov3-rtdetr", torch.bfloat16, family=family)
+    head = m.model[-1]
+    head.query_override = ref["topk"]
+    with torch.no_grad(), _dispatch("throughput"):
+        y = m(x.to(DEV).to(torch.bfloat16).contiguous())[0]
+    torch.cuda.synchronize()
+    head.query_override = None
+    yc = y.float().cpu()
+    db = (yc[..., :4] - y_ref[..., :4]).abs().amax(2) * 640        # (16, 300) px
+    ds = (yc[..., 4:] - y_ref[..., 4:]).abs().amax(2)
+    ok = ((db <= 0.5) & (ds <= 0.01)).float().mean(1)
+    print(f"yolov3-rtdetr bf16 decoder on the oracle's queries, family {family}: rows inside 0.5 px / 0.01: mean {ok.mean():.5f} least "
+          f"image {ok.min():.5f}; box |d| max {db.max():.4f} px p99 {db.flatten().quantile(0.99):.4f}; score |d| max {ds.max():.5f} p99 "
+          f"{ds.flatten().quantile(0.99):.5f}")
+    ok_bf = ((db <= RTDETR_BOX_TOL_PX) & (ds <= 0.01)).float().mean(1)
+    print(f"  inside ({RTDETR_BOX_TOL_PX} px, 0.01): mean {ok_bf.mean():.5f} least image {ok_bf.min():.5f}")
+    assert torch.isfinite(yc).all()
+    if family is None:   # chaotic family: the decoder amplifies the backbone's bf16 noise even on fixed queries - a report
+        return
+    assert ok_bf.mean().item() >= RTDETR_DEC_ROWS_OK and ok_bf.min().item() >= RTDETR_DEC_ROWS_OK - 0.02
+    assert ds.max().item() <= 0.01 and db.flatten().quantile(0.99).item() <= 4.0
+    assert ok.mean().item() >= RTDETR_INSIDE_HALF_PX["dec"]
 
 
 def test_e2e_f32_bot3_config_batch_vs_oracle():
@@ -1108,3 +1269,31 @@ def test_e2e_bf16_keys_only_head_is_exact(name):
             for a, b in zip(full[0.25], out):
                 assert torch.equal(a, b)
     det.scores_out = True
+
+
+def test_e2e_detect_level_stream_follows_the_tile_form():
+    """The opt-in line-buffer form of the 80 x 80 Detect level (`upa_opts.detect_stream = 2`, csrc/detect_stream.hip) inside the whole yolov8n
+    step, against the default tile form on the same model and images (smooth family, bf16, batch 4): same rounding points, another f32 summation
+    order inside the 3x3 convs - head outputs equal up to flipped bf16 ties of the two intermediates, detections the same."""
+    from tests.hip_utils import DEV, detection_agreement
+    from ultralytics_pro_amd.utils.nms import non_max_suppression
+    m = _build("yolov8n", torch.bfloat16, family="smooth:yolov8n")
+    m.model[-1].concurrent = False
+    x = P.synthetic_images(4).to(DEV).to(torch.bfloat16).contiguous()
+    outs = {}
+    for mode in (0, 2):
+        with torch.no_grad(), _dispatch("throughput"):
+            from ultralytics_pro_amd.engine import runtime as R
+            with R.use_opts(detect_stream=mode):
+                y = m(x)[0]
+                outs[mode] = (y.float().cpu().clone(), [o.cpu().numpy() for o in non_max_suppression(y, 0.25, 0.7, max_det=300)])
+    a6400 = 80 * 80
+    d = (outs[2][0] - outs[0][0]).abs()
+    assert d[:, :, a6400:].max().item() == 0.0                 # the other levels run the same launches
+    lvl = d[:, :, :a6400]
+    flips = (lvl[:, 4:] > 1e-6).float().mean().item()
+    print(f"detect level stream vs tile form: level-0 box |d| max {lvl[:, :4].max():.4f} px, score |d| max {lvl[:, 4:].max():.5f}, "
+          f"scores moved {flips:.4f}")
+    assert lvl[:, :4].max().item() <= 0.25 and lvl[:, 4:].max().item() <= 5e-3
+    a = detection_agreement(outs[2][1], outs[0][1], 0.9)
+    assert a["recall"] >= 0.97 and a["precision"] >= 0.97 and a["box_max"] <= 0.25

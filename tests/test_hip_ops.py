@@ -1821,3 +1821,84 @@ def test_msdeform_attn_bf16_values_match_exact_path():
     a, b = y32.cpu(), y16.cpu()
     assert float(a.abs().max()) > 0.05 and float((a == 0).float().mean()) < 0.5
     assert float((a - b).abs().max()) <= 2e-5  # same values, same weights up to v_exp_f32 / v_rcp_f32 (1 ulp) and the order of 48 f32 adds
+
+
+@pytest.mark.parametrize("nc,shape,rows,keys_only", [(80, (2, 13, 21), 0, 0), (80, (3, 40, 40), 0, 0), (80, (2, 40, 40), 12, 0), (20, (1, 9, 16), 0, 0),
+                                                      (80, (2, 23, 47), 8, 1), (80, (4, 80, 80), 0, 0), (80, (4, 80, 80), 40, 1)],
+                         ids=["13x21", "40x40", "40x40_parts12", "nc20_9x16", "23x47_parts8_keys", "80x80", "80x80_parts40_keys"])
+def test_detect_level_stream_vs_oracle(nc, shape, rows, keys_only):
+    """`upa_detect_level_stream` (csrc/detect_stream.hip): one Detect level - conv3x3 -> conv3x3 -> 1x1 -> decode for BOTH branches - as one
+    line-buffer launch (head.py:94-100, 116-126, 151-191), against the oracle's arithmetic on the same bf16-rounded input and weights with the
+    kernel's rounding points (bf16 after each SiLU, f32 logits, f32 decode): boxes / scores of every anchor, the best-class NMS key of every
+    anchor, nothing written outside the level.  Shapes: widths that are not a multiple of the 20-column strips, odd heights, parts of
+    rows (`upa_opts.detect_stream_rows`), fewer classes than the class tail's 80 filters, the keys-only form (class rows not written)."""
+    from tests.hip_utils import DEV, bf16_round, to_dev_nhwc, unit_input
+    from ultralytics_pro_amd import _lib as L
+    from ultralytics_pro_amd.engine import runtime as R
+    from ultralytics_pro_amd.nn.modules.conv import PackedConv
+    import ctypes as C
+    n, h, w = shape
+    a0, extra = 19, 5
+    a_total = a0 + h * w + extra
+    y = torch.full((n, 4 + nc, a_total), -7.0, device=DEV)
+    best_keys = torch.full((n, a_total), -1, dtype=torch.int64, device=DEV)
+    x = bf16_round(unit_input(f"dls_x{nc}{h}", (n, 64, h, w), -1.5, 1.5))
+    # the input as a channel slice of a wider buffer (ld = 96), as the neck hands it over
+    wide = to_dev_nhwc(torch.cat([x, torch.zeros(n, 32, h, w)], 1), torch.bfloat16)
+    xd = wide[:, :64]
+    vx = R.view_of(xd)
+    raws, branches, keep = [], [], []
+    for kind, c, cout in ((1, 64, 64), (2, 80, nc)):
+        w1 = bf16_round(unit_input(f"dls_w1{kind}{nc}", (c, 64, 3, 3), -0.1, 0.1))
+        b1 = unit_input(f"dls_b1{kind}{nc}", (c,), -0.5, 0.5)
+        w2 = bf16_round(unit_input(f"dls_w2{kind}{nc}", (c, c, 3, 3), -0.1, 0.1))
+        b2 = unit_input(f"dls_b2{kind}{nc}", (c,), -0.5, 0.5)
+        wt = bf16_round(unit_input(f"dls_wt{kind}{nc}", (cout, c, 1, 1), -0.4, 0.4))
+        bt = unit_input(f"dls_bt{kind}{nc}", (cout,), -2, 1)
+        t1 = bf16_round(torch.nn.functional.silu(torch.nn.functional.conv2d(x, w1, b1, padding=1)))
+        t2 = bf16_round(torch.nn.functional.silu(torch.nn.functional.conv2d(t1, w2, b2, padding=1)))
+        raws.append(torch.nn.functional.conv2d(t2, wt, bt))
+        ct = 64 if kind == 1 else 80
+        wtp = torch.cat([wt, torch.zeros(ct - cout, c, 1, 1)], 0)
+        btp = torch.cat([bt, torch.zeros(ct - cout)], 0)
+        pk1, pk2, pkt = (PackedConv(w1, b1, 3, DEV, torch.bfloat16, False), PackedConv(w2, b2, 3, DEV, torch.bfloat16, False),
+                         PackedConv(wtp, btp, 1, DEV, torch.bfloat16, False))
+        keep += [pk1, pk2, pkt]
+        branches.append(L.DetectBranch(c, 0, pk1.w.data_ptr(), pk1.bias.data_ptr(), pk2.w.data_ptr(), pk2.bias.data_ptr(), pkt.w.data_ptr(),
+                                       pkt.bias.data_ptr()))
+    with R.use_opts(detect_stream=2, detect_stream_rows=rows, keys_only=keys_only):
+        L.check(L.lib().upa_detect_level_stream(vx.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, C.byref(branches[0]), C.byref(branches[1]), nc, 8.0,
+                                                y.data_ptr(), a_total, a0, best_keys.data_ptr(), L.UPA_BF16, R.opts_ptr(),
+                                                L.current_stream(DEV)), "detect_level_stream")
+    torch.cuda.synchronize()
+    oref = om.Detect(nc, (64,)).eval()
+    oref.stride = torch.tensor([8.0])
+    ref = oref._inference([torch.cat(raws, 1)])
+    yc, keys = y.cpu(), best_keys.cpu()
+    got = yc[:, :, a0:a0 + h * w]
+    assert float(yc[:, :, :a0].min()) == -7.0 and float(yc[:, :, a0 + h * w:].max()) == -7.0  # nothing outside the level
+    assert bool((keys[:, :a0] == -1).all()) and bool((keys[:, a0 + h * w:] == -1).all())
+    db = (got[:, :4] - ref[:, :4]).abs()
+    # f32 summation order differs from torch's: a bf16 rounding of an intermediate that falls the other way moves a logit by <= 2^-8 |h| |w|
+    assert db.max().item() <= 0.5 and db.mean().item() <= 5e-3, (db.max().item(), db.mean().item())
+    sc_ref = ref[:, 4:]
+    kbits = keys[:, a0:a0 + h * w].numpy().view(np.uint64)
+    kscore = torch.from_numpy((~(kbits >> np.uint64(32)) & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.float32))
+    kidx = (kbits & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    anchors = np.arange(a0, a0 + h * w, dtype=np.int64)
+    kcls = torch.from_numpy(kidx - anchors[None, :] * nc)
+    assert bool(((kcls >= 0) & (kcls < nc)).all())
+    if keys_only:
+        assert float(got[:, 4:].min()) == -7.0 and float(got[:, 4:].max()) == -7.0   # class rows untouched
+        best_ref = sc_ref.max(1).values
+        assert (kscore - best_ref).abs().max().item() <= 1e-2
+        # the key's class is the reference's best class wherever the reference's margin is beyond the intermediates' bf16 noise
+        top2 = sc_ref.topk(2, dim=1).values
+        clear = (top2[:, 0] - top2[:, 1]) > 2e-2
+        assert bool((kcls == sc_ref.argmax(1))[clear].all()) and clear.float().mean().item() > 0.2
+    else:
+        ds_ = (got[:, 4:] - sc_ref).abs()
+        assert ds_.max().item() <= 1e-2 and ds_.mean().item() <= 2e-4, (ds_.max().item(), ds_.mean().item())
+        # the keys are exactly the first maxima of the scores the kernel itself wrote (utils/nms key order, nms.py:109)
+        best, arg = got[:, 4:].max(1)
+        assert torch.equal(kscore, best) and torch.equal(kcls, arg)

@@ -886,3 +886,39 @@ def test_eval_after_training_step_sees_the_new_weights():
     # through the eval forward that is a few 1e-3 on 256-px boxes
     assert d1[:, :4].max().item() <= 0.1 * moved[:, :4].max().item() + 5e-3
     assert d1[:, 4:].max().item() <= 0.1 * moved[:, 4:].max().item() + 2e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_gradients_do_not_depend_on_the_stream_layout(dtype):
+    """The backward walk may run the Detect head's 40 x 40 / 20 x 20 levels on a second stream (`DetectT.fork_levels`) and the weight
+    gradients on 0, 1 or 2 side streams (`DetectionTrainer(wgrad_streams=...)`).  None of that changes the arithmetic, so the flat
+    gradient buffer must come out BIT-IDENTICAL for all six layouts.  With `wgrad_streams = 0` the weight gradients of the forked
+    levels are launched on the level stream itself - beside the main stream's - and need their own split-K partial-sum workspace
+    (round-5 advisor finding: they shared one buffer and corrupted each other silently)."""
+    from tests.hip_utils import DEV
+    from ultralytics_pro_amd.engine import trainer as TR
+    from ultralytics_pro_amd.nn.tasks import DetectionModel
+    bs, sz = 4, 256
+    batch = (P.synthetic_images(bs, h=sz, w=sz, seed=3).to(DEV), P.synthetic_labels(bs, seed=3))
+    grads = {}
+    saved = TR.DetectT.fork_levels
+    try:
+        for fork in (True, False):
+            for ns in (0, 1, 2):
+                TR.DetectT.fork_levels = fork
+                m = DetectionModel("yolov8s.yaml")
+                P.apply_procedural_weights(m)
+                tr = TR.DetectionTrainer(m, dtype=dtype, device=DEV, wgrad_streams=ns)
+                for _ in range(2):  # the second pass runs with every workspace already allocated and the streams warm
+                    items = tr.forward_backward(*batch)
+                    tr._join_wgrad()
+                torch.cuda.synchronize()
+                grads[(fork, ns)] = (tr.G.cpu().clone(), items.cpu().clone())
+                del tr, m
+    finally:
+        TR.DetectT.fork_levels = saved
+    g0, i0 = grads[(False, 0)]
+    assert torch.isfinite(g0).all() and float(g0.abs().max()) > 0
+    for key, (g, it) in grads.items():
+        assert torch.equal(it, i0), key
+        assert torch.equal(g, g0), (key, float((g - g0).abs().max()))

@@ -81,6 +81,23 @@ def run(bucketed):
         assert len(table) >= 3
     items = [tr.step(x, lab).clone() for _ in range(3)]
     torch.cuda.synchronize()
+    # the replicate steps of the multi-rank loop (SURVEY 8e) as real RCCL collectives on the one rank there is: rank 0's EMA / BatchNorm
+    # buffers, the stop flag, the rank-averaged validation loss - none may change rank 0's own values
+    import ultralytics_pro_amd.parallel.dp as dp
+    from ultralytics_pro_amd.engine.validator import DetectionValidator
+    saved, dp._multi_rank = dp._multi_rank, (lambda: True)
+    try:
+        rb, erb = tr.RB.clone(), tr.ERB.clone()
+        tr.sync_ema_buffers()
+        assert tr.broadcast_stop(True) is True and tr.broadcast_stop(False) is False
+        v = DetectionValidator()
+        v.add_loss(items[0]); v.add_loss(items[1])
+        got = v.reduce_loss()
+        torch.cuda.synchronize()
+        assert torch.equal(tr.RB, rb) and torch.equal(tr.ERB, erb)
+        assert torch.allclose(got, (items[0] + items[1]) / 2)
+    finally:
+        dp._multi_rank = saved
     exposed = tr.allreduce_exposed_ms()
     n = tr.groups[-1][0] + tr.groups[-1][1]
     return torch.stack(items).cpu(), tr.P[:n].clone().cpu(), exposed, table

@@ -73,7 +73,20 @@ def _ctx_ws(self):
     return self._ws[self._ws_sel]
 
 
+def _ctx_wgrad_ws_here(self):
+    """The weight-gradient partial-sum workspace for a weight gradient launched on the CURRENT stream (`wgrad_streams = 0`): the main
+    stream's, or - while `DetectT._fork_levels` runs the small Detect levels on the level stream - a second buffer of the same size:
+    two streams must never write and reduce split-K partials in one buffer at the same time."""
+    if self._ws_sel == 0:
+        return self.wgrad_ws
+    lv = self.__dict__.get("_wgrad_ws_level")
+    if lv is None or lv.numel() < self.wgrad_ws.numel():
+        lv = self.__dict__["_wgrad_ws_level"] = torch.empty(self.wgrad_ws.numel(), dtype=torch.uint8, device=self.device)
+    return lv
+
+
 _Ctx.ws = property(_ctx_ws)
+_Ctx.wgrad_ws_here = property(_ctx_wgrad_ws_here)
 
 
 def _new(n, c, h, w, dtype, dev, key):
@@ -196,7 +209,7 @@ class ConvT:
             dz = _new(vz.n, vz.c, vz.h, vz.w, c.dtype, c.device, (id(self), "dz"))
             vdz = R.view_of(dz)
             bn = self.bn
-            side_p, ws = None, c.wgrad_ws
+            side_p, ws = None, c.wgrad_ws_here
             if c.wgrad_streams:
                 j = c.wgrad_rr % len(c.wgrad_streams)
                 c.wgrad_rr += 1
@@ -228,7 +241,7 @@ class ConvT:
         if not c.wgrad_streams:
             L.check(lib.upa_conv2d_wgrad(vx.ptr, vx.n, vx.h, vx.w, self.cin, vx.ld, vdz.ptr, self.cout, vdz.ld,
                                          self.conv.weight.grad.data_ptr(), self.k, self.s, self.p, 1, vx.dtype,
-                                         c.wgrad_ws.data_ptr(), c.wgrad_ws.numel(), st), f"wgrad[{self.name}]")
+                                         c.wgrad_ws_here.data_ptr(), c.wgrad_ws_here.numel(), st), f"wgrad[{self.name}]")
         else:
             j = c.wgrad_rr % len(c.wgrad_streams)
             c.wgrad_rr += 1
@@ -971,6 +984,27 @@ class DetectionTrainer:
     def grad_norm(self) -> float:
         """Norm of the (unscaled) gradients in the flat buffer."""
         return float(torch.sqrt(self.grad_sumsq())[0]) / self.scaler.get_scale()
+
+    # ---- the replicate steps of the multi-rank loop (SURVEY 8e) ------------------------------------------------------------------------
+    def sync_ema_buffers(self, src: int = 0):
+        """Rank `src`'s EMA float buffers (BatchNorm running mean / variance) on every rank, to be called before a validate that is
+        sharded over the ranks (engine/trainer.py:695-698).  The parameters need nothing: after the gradient all-reduce every rank
+        applies the same update, so P, M and the EMA parameters E are equal by construction; the BatchNorm running statistics are
+        NOT (every rank normalises with its own shard's batch statistics, there is no SyncBN - trainer.py:253-258 only wraps in DDP,
+        which broadcasts buffers rank 0 -> all at each forward), so without this the ranks would validate different models.  The
+        reference loops over `ema.buffers()`; the EMA buffers live in ONE flat f32 tensor here (`ERB`), so it is one broadcast.
+        The live model's buffers (`RB`) get the same treatment - DDP's `broadcast_buffers` (default True) keeps them rank 0's."""
+        from ..parallel import broadcast_
+        if self.nbuf:
+            if self.ERB is not None:
+                broadcast_(self.ERB[:self.nbuf], src)
+            broadcast_(self.RB[:self.nbuf], src)
+
+    def broadcast_stop(self, stop: bool, src: int = 0) -> bool:
+        """The early-stopping decision of rank `src` on every rank (engine/trainer.py:505-508): all ranks must leave the epoch loop
+        together or the next collective hangs."""
+        from ..parallel import broadcast_flag
+        return broadcast_flag(stop, src, self.device)
 
     def ema_state_dict(self):
         """The EMA weights under the reference's state_dict keys (for validation / checkpoints)."""

@@ -26,6 +26,25 @@ class DetectionValidator:
 
     def reset(self):
         self._det, self._cnt, self._tp, self._gt, self._ngt = [], [], [], [], []
+        self._loss, self._loss_batches = None, 0
+
+    # ---- validation loss (training-time validate only) --------------------------------------------------------------------
+    def add_loss(self, loss_items: torch.Tensor):
+        """Accumulate one batch's (box, cls, dfl) loss items (validator.py:222: `self.loss += model.loss(batch, preds)[1]`)."""
+        li = loss_items.detach().float()
+        self._loss = li.clone() if self._loss is None else self._loss + li
+        self._loss_batches += 1
+
+    def reduce_loss(self, dst: int = 0):
+        """The accumulated validation loss averaged over the ranks on rank `dst` (validator.py:241-249: `dist.reduce(loss, dst=0,
+        op=AVG)`, then divided by the number of batches); every other rank gets None, as the reference returns there."""
+        import torch.distributed as dist
+        if self._loss is None:
+            return None
+        loss = dp.reduce_mean_(self._loss.clone(), dst)
+        if dist.is_available() and dist.is_initialized() and dist.get_rank() != dst:
+            return None
+        return loss / max(self._loss_batches, 1)
 
     # ---- per batch ------------------------------------------------------------------------------------------------------
     def pack_labels(self, labels: dict, batch_size: int, imgsz_hw, device):

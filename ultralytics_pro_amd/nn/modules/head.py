@@ -160,6 +160,51 @@ class Detect(nn.Module, _HipConvMixin):
             plan["hot_levels"].add(i)
         return True
 
+    # ---- one level, both branches, all six convolutions + the decode in ONE line-buffer launch (csrc/detect_stream.hip) ----------------
+    # yolov8n's 80 x 80 level (64 input channels; 64-channel box branch, 80-channel class branch): the stacked first conv + the grouped
+    # branch tails write and re-read a 144-channel intermediate and reload every weight slab per tile; the streaming form keeps t1 / t2 as
+    # a few rows in LDS and the weights in registers.  MEASURED SLOWER than the tile form on MI355X (round 6: 53.9 k vs 57.9 k images/s in flight,
+    # 0.857 vs 0.809 ms one step at a time - the wave roles are vector-issue bound, profiles/r06_detect_stream.txt), so it only runs on request:
+    # `upa_opts.detect_stream = 2` (A/B, tests).
+    level_stream = True
+
+    def _level_stream(self, i: int, x: torch.Tensor, plan) -> bool:
+        """Level i through `upa_detect_level_stream`; False (nothing launched) outside its form."""
+        o_ = R.current_opts()
+        if not self.level_stream or o_ is None or o_.detect_stream != 2 or x.dtype != torch.bfloat16 or self.reg_max != 16:
+            return False
+        b, c = self.cv2[i], self.cv3[i]
+        ok3 = lambda m, ci, co: (isinstance(m, Conv) and not m.training and isinstance(m.act, nn.SiLU) and hasattr(m, "bn")  # noqa: E731
+                                 and m.conv.kernel_size == (3, 3) and m.conv.stride == (1, 1) and m.conv.padding == (1, 1)
+                                 and m.conv.groups == 1 and m.conv.in_channels == ci and m.conv.out_channels == co)
+        ok1 = lambda m, ci, co: (isinstance(m, nn.Conv2d) and m.kernel_size == (1, 1) and m.stride == (1, 1) and m.padding == (0, 0)  # noqa: E731
+                                 and m.groups == 1 and m.in_channels == ci and m.out_channels == co)
+        cin = int(x.shape[1])
+        if not (cin == 64 and self.nc <= 80 and ok3(b[0], 64, 64) and ok3(b[1], 64, 64) and ok1(b[2], 64, 64)
+                and ok3(c[0], 64, 80) and ok3(c[1], 80, 80) and ok1(c[2], 80, self.nc)):
+            return False
+        dev, dt = x.device, x.dtype
+        br = []
+        for seq, cw, ct in ((b, 64, 64), (c, 80, 80)):
+            pk1 = seq[0]._packed(seq[0].conv, seq[0].bn, dev, dt, False)
+            pk2 = seq[1]._packed(seq[1].conv, seq[1].bn, dev, dt, False)
+            pkt = self._packed(seq[2], None, dev, dt, False, pad_cout=ct)
+            br.append(L.DetectBranch(cw, 0, pk1.w.data_ptr(), pk1.bias.data_ptr(), pk2.w.data_ptr(), pk2.bias.data_ptr(), pkt.w.data_ptr(),
+                                     pkt.bias.data_ptr()))
+        import ctypes as C
+        vx = R.view_of(x)
+        hot = plan.get("hot")
+        rc = L.lib().upa_detect_level_stream(vx.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, C.byref(br[0]), C.byref(br[1]), self.nc,
+                                             float(self.stride[i]), plan["y"].data_ptr(), plan["a_total"], plan["a0"][i],
+                                             hot.data_ptr() if hot is not None else None, L.dtype_code(dt), R.opts_ptr(),
+                                             L.current_stream(dev))
+        if rc == L.UPA_EUNSUPPORTED:
+            return False
+        L.check(rc, "detect_level_stream")
+        if hot is not None:
+            plan["hot_levels"].add(i)
+        return True
+
     # ---- several levels per launch (linear graphs: the levels run one after the other on one stream anyway) ---------------------
     # The 40 x 40 and 20 x 20 levels' launches are 400 and 100 workgroups at batch 32 - a fraction of a round each, mostly launch
     # ramp and halo latency.  `upa_conv2d_bias_act_group` / `upa_detect_branch_tail_group` put problems that use the same kernel
@@ -168,7 +213,7 @@ class Detect(nn.Module, _HipConvMixin):
     group_levels = True
     stack_first = True  # the first level's two first convs as one 144-channel convolution (see _levels_grouped)
 
-    def _levels_grouped(self, idx, xs, plan) -> bool:
+    def _levels_grouped(self, idx, xs, plan, allow_stack: bool = True) -> bool:
         """Both branches of the levels `idx` (inputs `xs`, NHWC) through the group entry points; False (nothing launched) when a
         level is outside the fused forms."""
         import ctypes as C
@@ -195,7 +240,7 @@ class Detect(nn.Module, _HipConvMixin):
         o_ = R.current_opts()
         i0 = idx[0]
         b0, c0_ = self.cv2[i0][0], self.cv3[i0][0]
-        stacked = (self.stack_first and (o_ is None or not o_.no_stack_first) and xs[0].dtype == torch.bfloat16
+        stacked = (allow_stack and self.stack_first and (o_ is None or not o_.no_stack_first) and xs[0].dtype == torch.bfloat16
                    and b0.conv.out_channels == 64 and c0_.conv.out_channels == 80 and b0.conv.in_channels == c0_.conv.in_channels
                    and b0.conv.in_channels >= 64)
         order = ([("stack", None, i0)] if stacked else [(kind, seqs, i0) for kind, seqs in todo]) + \
@@ -329,6 +374,11 @@ class Detect(nn.Module, _HipConvMixin):
         linear = not self.concurrent or R.current_tag() != 0
         if defer_ok and linear and fused and self.group_levels and self.fuse_branch and not self.keep_raw:
             return  # `forward` picks it up (grouped with the other small levels)
+        if fused and buf is None and self.fuse_branch and self._level_stream(i, x, plan):
+            # the same line-buffer launch on every walk (grouped, level by level, concurrent): the output does not depend on the walk
+            plan["decoded"].add(i)
+            pend[i] = (None, [])
+            return
         if fused:
             plan["decoded"].add(i)
         if linear:
@@ -373,7 +423,13 @@ class Detect(nn.Module, _HipConvMixin):
         if (len(grp) >= 2 and linear and self.group_levels and self.fuse_branch and not self.keep_raw and plan is not None and plan["fused"]
                 and all(x[i].dtype == torch.bfloat16 and plan["n"] == x[i].shape[0] and plan["hw"][i] == tuple(x[i].shape[2:])
                         and plan["y"].device == x[i].device for i in grp)):
-            if self._levels_grouped(grp, [R.to_nhwc(x[i], x[i].dtype) for i in grp], plan):
+            xs_n = [R.to_nhwc(x[i], x[i].dtype) for i in grp]
+            streamed = self._level_stream(grp[0], xs_n[0], plan)  # the first (largest) level as ONE line-buffer launch where it applies
+            if streamed:
+                plan["decoded"].add(grp[0])
+                pend[grp[0]] = (None, [])
+                grp, xs_n = grp[1:], xs_n[1:]
+            if len(grp) >= 2 and self._levels_grouped(grp, xs_n, plan, allow_stack=not streamed):
                 for i in grp:
                     plan["decoded"].add(i)
                     pend[i] = (None, [])

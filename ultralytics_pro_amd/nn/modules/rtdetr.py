@@ -442,6 +442,40 @@ class RTDETRDecoder(nn.Module):
         finally:
             _LINEAR_BF16[0] = saved_lin
 
+    # Parity instrumentation (tests / bench parity legs only; both None in production).  `query_override`: a (bs, num_queries) integer
+    # tensor of reference token indices (index into the concatenated levels of ONE image, the `topk_ind` of head.py:2175) that replaces
+    # the query selection - the decoder then refines exactly the tokens a reference run selected, so its output can be compared row by
+    # row although the selection itself is chaotic in reduced precision (the top-300 of nearly flat scores).  `taps`: a dict that
+    # receives the encoder-side tensors of the call (`features` = enc_output rows, `enc_scores` = enc_score_head logits, both
+    # level-major, see `level_major_to_image`).
+    query_override = None
+    taps = None
+
+    def token_rows(self, tok, st, bs):
+        """(bs, nq) reference token indices -> (level-major row index, token index) int32 vectors of length bs * nq, the two outputs
+        of upa_topk_tokens (include/upa.h): row = sum_{l' < l} bs * hw[l'] + image * hw[l] + p for token = sum_{l' < l} hw[l'] + p."""
+        tok = torch.as_tensor(tok).to("cpu", torch.int64)
+        if tok.dim() != 2 or tok.shape[0] != bs or tok.shape[1] != self.num_queries:
+            raise L.UpaError(f"query_override must be ({bs}, {self.num_queries}), got {tuple(tok.shape)}")
+        hw = st["hw_host"].to(torch.int64)
+        if int(tok.min()) < 0 or int(tok.max()) >= int(hw.sum()):
+            raise L.UpaError("query_override holds a token index outside the encoder's token range")
+        start = torch.cumsum(hw, 0) - hw                       # first token of every level inside one image
+        lvl = torch.bucketize(tok, start, right=True) - 1
+        p = tok - start[lvl]
+        img = torch.arange(bs, dtype=torch.int64).unsqueeze(1)
+        rows = bs * start[lvl] + img * hw[lvl] + p
+        return rows.reshape(-1).to(torch.int32), tok.reshape(-1).to(torch.int32)
+
+    @staticmethod
+    def level_major_to_image(rows, st, bs):
+        """A level-major token matrix (bs * T, c) as the reference's (bs, T, c) tensor (head.py:2139: levels concatenated per image)."""
+        out, r0 = [], 0
+        for n in st["hw_host"].tolist():
+            out.append(rows[r0: r0 + bs * n].view(bs, n, -1))
+            r0 += bs * n
+        return torch.cat(out, 1)
+
     # perf mode (bf16 backbone): the decoder's nn.Linear products on the bf16 matrix cores (see `_LINEAR_BF16`); False = exact float32
     linear_bf16 = True
     # perf mode: the input projections as bf16 convs straight into the bf16 token matrix; False = widen + exact-f32 convs
@@ -458,8 +492,15 @@ class RTDETRDecoder(nn.Module):
         nq = self.num_queries
         rows = R.alloc_plain((bs * nq,), torch.int32, dev, key=(id(self), "topk_rows"))
         toks = R.alloc_plain((bs * nq,), torch.int32, dev, key=(id(self), "topk_tok"))
-        L.check(lib.upa_topk_tokens(scores.data_ptr(), self.nc, self.nl, st["hw_ptr"], bs, nq, rows.data_ptr(),
-                                    toks.data_ptr(), st_), "topk_tokens")
+        if self.taps is not None:
+            self.taps.update(features=features, enc_scores=scores, static=st, bs=bs)
+        if self.query_override is None:
+            L.check(lib.upa_topk_tokens(scores.data_ptr(), self.nc, self.nl, st["hw_ptr"], bs, nq, rows.data_ptr(),
+                                        toks.data_ptr(), st_), "topk_tokens")
+        else:
+            r_, t_ = self.token_rows(self.query_override, st, bs)
+            rows.copy_(r_.to(dev))
+            toks.copy_(t_.to(dev))
         top_feat = _Rows.new(bs * nq, hd, dev, key=(id(self), "top_feat"))
         L.check(lib.upa_rows_gather(features.data_ptr(), rows.data_ptr(), top_feat.data_ptr(), bs * nq, hd, st_), "gather")
         delta = self.enc_bbox_head(top_feat, key=(id(self), "enc_bbox"))

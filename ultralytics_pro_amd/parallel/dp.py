@@ -145,6 +145,38 @@ def gather_ragged(rows: torch.Tensor, counts: torch.Tensor):
     return g_rows[keep], g_cnt[keep]
 
 
+def _multi_rank() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def broadcast_(t: torch.Tensor, src: int = 0) -> torch.Tensor:
+    """In-place broadcast of `t` from rank `src` (identity on one rank).  Used for the replicate steps of SURVEY 8e: the EMA model's
+    float buffers before a sharded validate (engine/trainer.py:695-698)."""
+    if _multi_rank():
+        dist.broadcast(t, src=src)
+    return t
+
+
+def broadcast_flag(flag: bool, src: int = 0, device=None) -> bool:
+    """Rank `src`'s boolean on every rank: the early-stopping flag of the epoch loop (engine/trainer.py:505-508).  The reference pickles
+    a one-element list through `dist.broadcast_object_list`; one int32 element says the same without pickling."""
+    if not _multi_rank():
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+    dist.broadcast(t, src=src)
+    return bool(int(t.item()))
+
+
+def reduce_mean_(t: torch.Tensor, dst: int = 0) -> torch.Tensor:
+    """`dist.reduce(t, dst, op=AVG)` (engine/validator.py:243-245: the validation loss averaged over the ranks, meaningful on `dst`
+    only).  Written as SUM + one division on `dst` - gloo has no AVG, and on RCCL the two are the same arithmetic."""
+    if _multi_rank():
+        dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM)
+        if dist.get_rank() == dst:
+            t /= dist.get_world_size()
+    return t
+
+
 def allreduce_gradients_(flat_grads: torch.Tensor) -> torch.Tensor:
     """The one exchange step of the batch-DP training step: in-place SUM all-reduce of the flat f32 gradient
     buffer (RCCL on the GPU, gloo in the CPU tests).  The reference multiplies each rank's loss by world_size and lets
