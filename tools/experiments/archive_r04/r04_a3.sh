@@ -1,8 +1,8 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/a3; mkdir -p $O
-python3 $R/tools/experiments/r04_a3.py 2>&1 | grep "wall"
+python3 $R/tools/experiments/archive_r04/r04_a3.py 2>&1 | grep "wall"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/tools/experiments/r04_a3.py 2>&1 | grep "wall"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/tools/experiments/archive_r04/r04_a3.py 2>&1 | grep "wall"
 f=$(find $O/prof -name "*kernel_stats.csv" | head -1); cp $f $O/main_kernel_stats.csv; rm -rf $O/prof
 python3 - $O/main_kernel_stats.csv <<'PY'
 import csv,sys

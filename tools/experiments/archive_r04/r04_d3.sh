@@ -1,8 +1,8 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/d3; mkdir -p $O; rm -rf $O/prof
-python3 $R/tools/experiments/r04_d3.py 2>&1 | grep -v amdgpu.ids | tail -5
+python3 $R/tools/experiments/archive_r04/r04_d3.py 2>&1 | grep -v amdgpu.ids | tail -5
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $O/prof -- python3 $R/tools/experiments/r04_d3.py > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $O/prof -- python3 $R/tools/experiments/archive_r04/r04_d3.py > /dev/null 2>&1
 f=$(find $O/prof -name "*kernel_trace.csv" | head -1)
 python3 - $f <<'PY'
 import csv,sys

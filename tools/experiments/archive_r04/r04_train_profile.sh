@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/train_r04; mkdir -p $O; rm -rf $O/prof_train
 cd $R
 timeout 600 python bench.py --workload train > $O/bench_train.json 2> $O/bench_train.err
-python tools/experiments/r04_o2.py 2>/dev/null > $O/wgrad_layers_yolov8s.txt
+python tools/experiments/wgrad_pmc_table.py 2>/dev/null > $O/wgrad_layers_yolov8s.txt
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_train -- python3 $R/bench.py --workload train --no-cpu-baseline --steps 10 --warmup 3 > /dev/null 2>&1
 cd $R

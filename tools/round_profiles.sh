@@ -17,7 +17,7 @@ timeout 600 python bench.py --model yolov5-BoT3 --batch 32 --no-cpu-baseline --s
 timeout 900 python bench.py --model yolov3-rtdetr --batch 16 > $O/bench_yolov3-rtdetr.json 2>/dev/null   # with the CPU leg: its parity object needs the oracle's output
 timeout 600 python bench.py --workload train > $O/bench_train.json 2> $O/bench_train.err
 timeout 600 python bench.py --model yolov3-rtdetr --batch 16 --serial --no-cpu-baseline --no-kernel-profile > $O/bench_yolov3-rtdetr_serial.json 2>/dev/null
-timeout 300 python tools/experiments/r04_o2.py > $O/wgrad_layers_yolov8s.txt 2>/dev/null   # per-layer weight-gradient table (both floors)
+timeout 300 python tools/experiments/wgrad_pmc_table.py > $O/wgrad_layers_yolov8s.txt 2>/dev/null   # per-layer weight-gradient table (both floors)
 timeout 600 python bench.py --workload val --steps 300 > $O/bench_val.json 2> $O/bench_val.err
 timeout 600 python bench.py --no-cpu-baseline --no-kernel-profile --no-mode-dispatch > $O/bench_default_no_mode_dispatch.json 2>/dev/null   # A/B: the one-step-at-a-time kernels (c2f64, conv_ws3) kept with four steps in flight
 timeout 900 bash tools/pmc_hbm.sh --no-kernel-profile > /dev/null 2>&1

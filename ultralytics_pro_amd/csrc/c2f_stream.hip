@@ -827,6 +827,7 @@ int upa_c2f32_stream_launch(const void* x, int n, int h, int w, int ldx, int sho
   p.N = n; p.H = h; p.W = w; p.ldx = ldx; p.ldy = ldy; p.shortcut = shortcut ? 1 : 0;
   p.strips = cdiv(w, c2fs::WS);
   const int rows = UPA_OPT(opts, c2f_stream_rows);
+  UPA_CHECK_ARG(rows <= 0 || rows >= 4, "c2f_stream_rows = %d: 0 (auto), -1 (whole height) or >= 4", rows);
   p.L = rows >= 4 ? (rows + 1) & ~1 : rows < 0 ? (h + 1) & ~1 : c2fs_pick_rows(n, h, w, cus);
   p.parts = cdiv(h, p.L);
   p.xcd = UPA_OPT(opts, no_xcd) ? 0 : 1;
@@ -869,6 +870,7 @@ int upa_c2f32_stream1_launch(const void* x, int n, int h, int w, int c1, int ldx
   p.up = (const char*)up; p.c1 = c1; p.upC = up ? up_c : 0; p.up_ld = up_ld;
   p.strips = cdiv(w, c2fs::WS);
   const int rows = UPA_OPT(opts, c2f_stream_rows);
+  UPA_CHECK_ARG(rows <= 0 || rows >= 4, "c2f_stream_rows = %d: 0 (auto), -1 (whole height) or >= 4", rows);
   p.L = rows >= 4 ? (rows + 1) & ~1 : rows < 0 ? (h + 1) & ~1 : c2fs_pick_rows(n, h, w, cus);
   p.parts = cdiv(h, p.L);
   p.xcd = UPA_OPT(opts, no_xcd) ? 0 : 1;

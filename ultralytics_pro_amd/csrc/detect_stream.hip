@@ -475,6 +475,7 @@ extern "C" int upa_detect_level_stream(const void* x, int n, int h, int w, int c
   p.strips = cdiv(w, dstream::WS);
   // rows per part: the whole height (fewest pipeline fills: least CU time) unless the caller asks for parts (`detect_stream_rows`: even >= 4)
   int rows = UPA_OPT(opts, detect_stream_rows);
+  UPA_CHECK_ARG(rows == 0 || rows >= 4, "detect_stream_rows = %d: 0 (whole height) or >= 4", rows);
   int L = (h + 1) & ~1;
   if (rows >= 4) L = rows & ~1;
   if (L > ((h + 1) & ~1)) L = (h + 1) & ~1;

@@ -1336,7 +1336,7 @@ __global__ void sgd_nesterov_ema_kernel(float* p, float* g, float* buf, float* e
   }
 }
 
-// GradScaler.update() (torch/amp/grad_scaler.py): state = {scale, growth tracker, found_inf of the last step}.  An overflowing step
+// GradScaler.update() (torch/amp/grad_scaler.py): state = {scale, growth tracker, found_inf of the last step, the scale before this update}.  An overflowing step
 // multiplies the scale by backoff and clears the tracker; `interval` clean steps in a row multiply it by growth.
 __global__ void grad_scaler_update_kernel(float* state, const double* sumsq, float growth, float backoff, int interval) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -1345,6 +1345,7 @@ __global__ void grad_scaler_update_kernel(float* state, const double* sumsq, flo
   int tracker = (int)state[1];
   if (inf) { scale *= backoff; tracker = 0; }
   else if (++tracker == interval) { scale *= growth; tracker = 0; }
+  state[3] = state[0];  // the scale the gradients of the step just taken carried (GradScaler.get_scale() after update() returns the NEW one)
   state[0] = scale; state[1] = (float)tracker; state[2] = inf ? 1.f : 0.f;
 }
 
@@ -1537,7 +1538,15 @@ extern "C" int upa_conv_bn_act_bwd(const void* x, int n, int h, int w, int cin, 
   if (side && side != main_s) {
     // one event per thread is enough: a wait enqueued on the side stream refers to the record that precedes it, re-recording later does
     // not move it
-    static thread_local hipEvent_t ev = nullptr;
+    // (... per DEVICE: an event belongs to the device that was current when it was created; a thread that trains on cuda:1 after cuda:0
+    // must not record cuda:0's event on a cuda:1 stream)
+    static thread_local hipEvent_t evs[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) {
+      upa_set_error("conv_bn_act_bwd: hipGetDevice failed or device index >= 16");
+      return UPA_ELAUNCH;
+    }
+    hipEvent_t& ev = evs[dev];
     if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
       upa_set_error("conv_bn_act_bwd: cannot create an event");
       return UPA_ELAUNCH;

@@ -167,6 +167,13 @@ class ConvT:
                                             None if bias is None else bias.data_ptr(), vy.ptr, cout, vy.ld, rp, rld, k, s, p,
                                             L.ACT_NONE, vx.dtype, R.opts_ptr(), _s(x.device)), f"conv2d[{self.name}]")
 
+    @staticmethod
+    def _momentum(bn) -> float:
+        if bn.momentum is None:
+            raise L.UpaError("BatchNorm2d(momentum=None) (cumulative moving average) is not supported by the training step: the running "
+                             "statistics kernel takes a fixed momentum (nn.BatchNorm2d default 0.1; the reference's YAMLs set 0.03)")
+        return float(bn.momentum)
+
     def forward(self, x, out=None, residual=None):
         c, lib = self.ctx, L.lib()
         n, _, h, w = x.shape
@@ -189,7 +196,7 @@ class ConvT:
             vr = R.view_of(residual)
             rp, rld = vr.ptr, vr.ld
         L.check(lib.upa_conv2d_bn_act_fwd(vx.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, self.wp.data_ptr(), vz.ptr, self.cout, vz.ld,
-                                          self.k, self.s, self.p, float(bn.momentum), self.mean.data_ptr(), self.var.data_ptr(),
+                                          self.k, self.s, self.p, self._momentum(bn), self.mean.data_ptr(), self.var.data_ptr(),
                                           bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.weight.data_ptr(),
                                           bn.bias.data_ptr(), float(bn.eps), self.act, vy.ptr, vy.ld, rp, rld, c.ws.data_ptr(),
                                           vx.dtype, R.opts_ptr(), _s(c.device)), f"conv2d_bn_act_fwd[{self.name}]")
@@ -434,6 +441,13 @@ class GradScaler:
     def get_scale(self) -> float:  # (host synchronisation: logging / tests only)
         return float(self.state[0].item()) if self.enabled else 1.0
 
+    def carried_scale(self, after_update: bool) -> float:
+        """The scale the gradients in the flat buffer were multiplied by: the current one before `update()` ran for them, the one
+        `update()` saved (state[3]) after - on a step where the scale grew or backed off the two differ by that factor."""
+        if not self.enabled:
+            return 1.0
+        return float(self.state[3 if after_update else 0].item())
+
     def found_inf(self) -> bool:
         return bool(self.state[2].item() != 0.0) if self.enabled else False
 
@@ -467,6 +481,7 @@ class DetectionTrainer:
         self.pool = R.BufferPool()
         self.updates = 0
         self.first_step = True
+        self._scaler_updated = False
         self._graphs = None
         self._capturing = False
         self._issue_buckets = False
@@ -605,6 +620,7 @@ class DetectionTrainer:
         ctx, dev = self.ctx, self.device
         L.require_gpu(img, "train")
         self.model.train()
+        self._scaler_updated = False  # the gradients this call produces carry the scaler's CURRENT scale
         if labels is not None:
             # the labels go up BEFORE the forward launches (stream-ordered behind the previous step's loss kernels): packing them on the
             # host overlaps the GPU's work on the previous step instead of standing between this step's forward and its loss
@@ -851,6 +867,7 @@ class DetectionTrainer:
         if self.ERB is not None and self.nbuf:
             L.check(lib.upa_ema_update(self.ERB.data_ptr(), self.RB.data_ptr(), self.nbuf, d, dp, st), "ema_buffers")
         self.scaler.update(self.sumsq, st)  # trainer.py:679
+        self._scaler_updated = True  # (`grad_norm()` now divides by the scale the update saved, not by the new one)
         self.first_step = False
         # parameters and BN buffers were just rewritten through raw pointers: no `_version` moved, so every packed-weight
         # cache of the inference path (Conv / Detect / C2f) is told explicitly
@@ -983,7 +1000,7 @@ class DetectionTrainer:
 
     def grad_norm(self) -> float:
         """Norm of the (unscaled) gradients in the flat buffer."""
-        return float(torch.sqrt(self.grad_sumsq())[0]) / self.scaler.get_scale()
+        return float(torch.sqrt(self.grad_sumsq())[0]) / self.scaler.carried_scale(self._scaler_updated)
 
     # ---- the replicate steps of the multi-rank loop (SURVEY 8e) ------------------------------------------------------------------------
     def sync_ema_buffers(self, src: int = 0):

@@ -233,7 +233,10 @@ class Detect(nn.Module, _HipConvMixin):
         # The two first convs of the first (largest) level read the same input: stacked along the output channels they are ONE 64 + 80 =
         # 144-channel convolution (conv_big's nine-tile variant) - the halo of a tile is fetched once instead of once per branch, the box
         # branch multiplies no padded fifth tile, half the workgroups - and each branch's second half reads its channel slice of the
-        # 144-channel tensor.  Same products in the same order per output channel: bit-identical.  Measured (yolov8n bs 32, round 5, same
+        # 144-channel tensor.  Same products in the same order per output channel as conv_big's two-problem grid: bit-identical to it -
+        # NOT to the level-by-level walks under library-default options, whose 64 -> 64 box conv takes conv_ws3 (another f32 summation order:
+        # last-bit differences, tests/test_hip_e2e.py::test_e2e_grouped_detect_levels_equal_level_by_level runs under conv_ws3 = 1 for that
+        # reason; a default-options tolerance test sits next to it).  Measured (yolov8n bs 32, round 5, same
         # box, upa_opts.no_stack_first = 1 | 0): the stacked launch takes what the two-problem grid took (65.9 vs 66.1 us with four steps
         # in flight, 58.46 k images/s either way; the serial step 0.810 -> 0.808 ms): the first convs are bound by their per-tap matrix /
         # LDS work, not by the second halo fetch.  Kept: one launch and one tensor fewer, never slower.
