@@ -27,12 +27,11 @@ if str(ROOT) not in sys.path:
 
 import torch  # noqa: E402
 
-GFLOP_PER_IMG = 8.744  # yolov8n @640, 2*MAC over all 64 Conv2d
-# the other configs of BASELINE.json (same convention); the headline metric is always yolov8n
-GFLOP_OTHER = {"yolov3-tiny": 19.002, "yolov8s": 28.603, "yolov5-BoT3": 7.882 + 0.041, "yolov3-rtdetr": 256.56 + 11.49}
-PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16 (MI355X_MICROARCH.md)
-PEAK_F32_TFLOPS = 157.3  # MFMA f32
-PEAK_HBM_GBS = 8000.0
+from tools.bench_legs.common import GFLOP_OTHER, GFLOP_PER_IMG, PEAK_BF16_TFLOPS, PEAK_F32_TFLOPS, PEAK_HBM_GBS  # noqa: E402,F401
+from tools.bench_legs.cpu_baseline import (cpu_baseline_child, physical_cores, run_cpu_baseline, run_cpu_baseline_bounded,  # noqa: E402,F401
+                                           run_cpu_train_baseline)
+from tools.bench_legs.parity import gpu_parity  # noqa: E402
+from tools.bench_legs.profile import kernel_profile, step_roofline, wgrad_profile  # noqa: E402
 
 
 def parse():
@@ -765,692 +764,6 @@ def main_train(args):
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def wgrad_profile(tr, L, R, dev, dtype, reps=5, cfg_key=None):
-    """Dominant kernel of the training step = the weight-gradient MFMA kernel: every layer's launch re-issued `reps` times
-    back to back on the current stream between HIP events (its operands are still resident from the last step)."""
-    fam = {}
-    lib = L.lib()
-    st = L.current_stream(dev)
-    scratch = {}
-    for cv in tr.convs:
-        if cv.x is None:
-            continue
-        vx = R.view_of(cv.x)
-        oh, ow = (vx.h + 2 * cv.p - cv.k) // cv.s + 1, (vx.w + 2 * cv.p - cv.k) // cv.s + 1
-        dz = scratch.setdefault((vx.n, cv.cout, oh, ow), torch.zeros(vx.n, oh, ow, cv.cout, dtype=dtype, device=dev))
-        dw = torch.zeros(cv.cout, cv.cin, cv.k, cv.k, device=dev)
-        ws = tr.ctx.wgrad_ws
-
-        def call():
-            L.check(lib.upa_conv2d_wgrad(vx.ptr, vx.n, vx.h, vx.w, cv.cin, vx.ld, dz.data_ptr(), cv.cout, cv.cout, dw.data_ptr(),
-                                         cv.k, cv.s, cv.p, 1, vx.dtype, ws.data_ptr(), ws.numel(), st), "wgrad")
-        call()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            call()
-        e1.record()
-        torch.cuda.synchronize(dev)
-        ms = e0.elapsed_time(e1) / reps
-        bf = dtype == torch.bfloat16
-        # the dispatch of upa_conv2d_wgrad (csrc/train.hip): bf16 MFMA kernels where the channel counts allow
-        if bf and cv.k == 3 and cv.cout >= 16 and (cv.cin % 8 == 0 or cv.cin < 8):
-            # LDS-DMA ring kernels; 9 - 16 input channels keep the register-staged narrow form
-            fam_ = "wgrad_bf16_k3_kernel" if 8 < cv.cin <= 16 else "wgrad_k3_ring_kernel"
-            name, peak = "void (anonymous namespace)::%s<%d, %d>((anonymous namespace)::WgradParams)" % (
-                fam_, cv.s, 16 if cv.cin <= 16 else 64), PEAK_BF16_TFLOPS
-        elif bf and cv.k == 1 and cv.s == 1 and cv.p == 0 and cv.cin >= 32 and cv.cout >= 32 and cv.cin % 8 == 0:
-            name, peak = "(anonymous namespace)::wgrad_k1_ring_kernel((anonymous namespace)::WgradParams)", PEAK_BF16_TFLOPS
-        else:
-            small = cv.cin <= 32 or cv.cout <= 32
-            mt = 4 if (cv.k == 1 and cv.cin >= 128 and cv.cout >= 128) else (1 if small else 2)
-            name = "void (anonymous namespace)::wgrad_kernel<%s, %d, %d, %d>((anonymous namespace)::WgradParams)" % (
-                "unsigned short" if bf else "float", mt, mt, cv.k)
-            peak = PEAK_F32_TFLOPS
-        d = fam.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0, peak=peak))
-        d["launches"] += 1
-        d["ms"] += ms
-        d["flops"] += 2.0 * vx.n * oh * ow * cv.cout * cv.cin * cv.k * cv.k
-        # algorithmic bytes: the layer input and the output gradient read once (activation dtype), the f32 weight gradient written once
-        d["bytes"] += vx.n * (vx.h * vx.w * cv.cin + oh * ow * cv.cout) * (2 if bf else 4) + 4.0 * cv.cout * cv.cin * cv.k * cv.k
-    name, d = max(fam.items(), key=lambda kv: kv[1]["ms"])
-    avg_s = d["ms"] / d["launches"] * 1e-3
-    tf = d["flops"] / d["launches"] / avg_s / 1e12
-    # HBM bytes per launch of the dominant family from the committed PMC passes (tools/pmc_wgrad.sh: FETCH_SIZE x 2 + WRITE_SIZE,
-    # separate passes); only valid for the configuration they were collected on
-    traffic, traffic_src = None, None
-    for pf in sorted((ROOT / "profiles").glob("r*_pmc_wgrad_summary.json"), reverse=True):
-        try:
-            pmc = json.loads(pf.read_text())
-            if pmc.get("config") == cfg_key and name in pmc["kernels"]:
-                traffic = round(pmc["kernels"][name]["hbm_bytes_per_launch"])
-                traffic_src = f"profiles/{pf.name} (rocprofv3 --pmc, separate passes)"
-                break
-        except (OSError, KeyError, ValueError):
-            pass
-    return {"kernel": name, "bound": "mfma", "achieved": round(tf, 2), "peak": d["peak"], "unit": "TFLOP/s",
-            "frac": round(tf / d["peak"], 4), "traffic": traffic, "traffic_source": traffic_src, "launches_per_step": d["launches"],
-            "avg_launch_us": round(avg_s * 1e6, 1),
-            "algorithmic_flops_per_launch": d["flops"] / d["launches"],
-            "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
-            "note": "weight gradient: bf16 MFMA (v_mfma_f32_16x16x32_bf16, operands DMAed into an LDS ring and read with "
-                    "ds_read_b64_tr_b16) where channel counts allow, exact-f32 MFMA otherwise; the time includes the "
-                    "partial-sum reduction kernel",
-            "wgrad_ms_per_step": round(sum(v["ms"] for v in fam.values()), 3),
-            "families": {k: dict(launches=v["launches"], avg_us=round(v["ms"] / v["launches"] * 1e3, 1),
-                                 tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)) for k, v in sorted(fam.items())}}
-
-
-def run_cpu_train_baseline(args):
-    """The oracle training step (torch autograd on this host's cores), bounded sample: bs 4, 320x320."""
-    from oracle import tasks as ot
-    from oracle import train as otr
-    from ultralytics_pro_amd.utils import procedural as P
-
-    host_cores = os.cpu_count() or 1
-    cores = min(host_cores, args.cpu_threads or 32)  # torch CPU convs regress when oversubscribed (see run_cpu_baseline)
-    torch.set_num_threads(cores)
-    m = ot.DetectionModel(args.model + ".yaml")
-    P.apply_procedural_weights(m)
-    st = otr.TrainState(m)
-    bs, sz = 4, 320
-    batch = {"img": P.synthetic_images(bs, h=sz, w=sz), **P.synthetic_labels(bs)}
-    otr.train_step(m, st, batch)
-    best = 1e30
-    for _ in range(2):
-        t0 = time.perf_counter()
-        otr.train_step(m, st, batch)
-        best = min(best, time.perf_counter() - t0)
-    px_ratio = (sz * sz) / float(args.imgsz * args.imgsz)
-    return {"value": round(bs / best * px_ratio, 2), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"oracle train step (torch CPU fp32 autograd) {args.model} bs={bs} {sz}x{sz}, best of 2 = "
-                      f"{bs / best:.2f} images/s at {sz}px, scaled by the pixel ratio to {args.imgsz}px; host has "
-                      f"{host_cores} logical cores"}
-
-
-def step_roofline(img_per_s, ms_per_step, args, kernels):
-    """The whole step against the chip: MFMA (algorithmic FLOPs of every conv / peak), HBM (algorithmic bytes of every conv,
-    each reading its input and writing its output once, / 8 TB/s) and the ratio of the conv HBM floor to the measured step."""
-    peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
-    tf = img_per_s * GFLOP_OTHER.get(args.model, GFLOP_PER_IMG) / 1e3
-    out = {"model_tflops": round(tf, 2), "frac_of_mfma_peak": round(tf / peak, 4)}
-    if kernels:
-        gb = kernels["conv_algorithmic_bytes"] / 1e9
-        out.update({"algorithmic_GB_per_step": round(gb, 4), "algorithmic_GBs": round(gb / (ms_per_step * 1e-3), 1),
-                    "frac_of_hbm_peak": round(gb / (ms_per_step * 1e-3) / PEAK_HBM_GBS, 4),
-                    "conv_hbm_floor_over_step": round(kernels["conv_hbm_floor_ms"] / ms_per_step, 4)})
-    return out
-
-
-def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
-    """Device time of every conv launch of one step, measured live with HIP events on the launch stream.
-
-    One eager forward records the launch list; every launch is then captured `reps` times back to back into its own
-    hipGraph and the replay is bracketed by events on the stream it runs on, so the figure is kernel time (no host
-    launch gaps) and is comparable with rocprofv3's per-kernel AverageNs.  Launches are grouped by the exact kernel
-    instantiation name rocprofv3 reports; the roofline is given for the instantiation with the largest total time."""
-    from ultralytics_pro_amd.engine import runtime as R
-    from ultralytics_pro_amd.nn.modules import block as pblock
-    from ultralytics_pro_amd.nn.modules import head as phead
-
-    code = L.dtype_code(dtype)
-    es = 2 if code == L.UPA_BF16 else 4
-    tname = "unsigned short" if es == 2 else "float"
-    calls = []  # (kernel name, flops, algorithmic bytes, replay callable)
-    orig = pconv.hip_conv2d
-    orig_tail = phead.Detect._tail_call
-
-    def conv_name(n, h, w, cin, pk, stride, pad, act, residual):
-        if pk.stem:
-            return (f"void stem_mfma_kernel<{pk.cout // 16}, {pk.k}, {stride}, {'true' if act == 1 else 'false'}>(StemParams)" if es == 2 else
-                    f"void stem_conv_kernel<{tname}, 16, {'true' if act == 1 else 'false'}>(StemParams)")
-        var = L.lib().upa_conv_variant(n, h, w, cin, pk.cout, pk.k, stride, pad, code, R.opts_ptr())
-        if (var >> 26) & 1:  # 8-wave two-group phased kernel for the MFMA-bound 3x3 stride-1 layers (conv_p8.hip)
-            return "conv_p8_kernel(BigParams)"
-        if (var >> 25) & 1:  # 4-wave 32x32x16-MFMA kernel for the MFMA-bound 3x3 layers (conv_mm.hip): <ACT, RES>
-            return "void conv_mm_kernel<%d, %s>(MmParams)" % (act, "true" if residual is not None else "false")
-        if (var >> 24) & 1:  # persistent weights-stationary 3x3 (conv_ws3.hip): <NT, MT>
-            return "void conv_ws3_kernel<%d, %d>(BigParams)" % ((var >> 4) & 15, var & 15)
-        if (var >> 23) & 1:  # large-tile LDS-shared-operand kernel (conv_big.hip): <KS, STRIDE, WM, WN, MT, NT>
-            ntb, mt = (var >> 4) & 15, 4 if (var & 15) == 2 else 2
-            wm, wn, nt = (8, 1, 4) if (ntb == 4 and mt == 4) else (4, 2, ntb // 2)
-            if ntb == 4:
-                mt = 2
-            if ntb == 5:  # 80 output channels: 8 x 1 waves, 5 tiles each, MT = 2 (256 px) or 1 (128 px)
-                wm, wn, nt, mt = 8, 1, 5, (2 if (var & 15) == 2 else 1)
-            return "void conv_big_kernel<%d, %d, %d, %d, %d, %d, 0>(BigParams)" % (pk.k, stride, wm, wn, mt, nt)
-        if (var >> 22) & 1:  # streaming pointwise kernel (conv1x1.hip): <NTW, MT, WAVES, EPI>
-            return "void conv1x1_stream_kernel<%d, %d, %d, 0>(C1Params)" % (var & 15, (var >> 4) & 15, (var >> 8) & 31)
-        if (var >> 21) & 1 and (var >> 8) & 1:  # 16 -> 16 channel variant of the pipelined kernel: <act, residual>
-            return "void conv3x3_c16_kernel<%d, %s>(PipeParams)" % (act, "true" if residual is not None else "false")
-        if (var >> 21) & 1:  # software-pipelined 3x3 (conv_pipe.hip): <NTW, act, residual>
-            return "void conv3x3_pipe_kernel<%d, %d, %s>(PipeParams)" % (var & 15, act, "true" if residual is not None else "false")
-        return "void %s<%s, %d, %d, %d, %d, %d>(ConvParams)" % (
-            "conv_ws_kernel" if (var >> 20) & 1 else "conv_igemm_kernel", tname, (var >> 12) & 15,
-            (var >> 8) & 15, (var >> 4) & 15, var & 15, (var >> 16) & 15)
-
-    def rec(xx, pk, stride, pad, act, out=None, residual=None, out_dtype=None, key=None, up=None):
-        y = orig(xx, pk, stride, pad, act, out=out, residual=residual, out_dtype=out_dtype, key=key, up=up)
-        n, cin, h, w = xx.shape
-        oh, ow = y.shape[2], y.shape[3]
-        flops = 2.0 * n * oh * ow * pk.cout * cin * pk.k * pk.k
-        nbytes = n * h * w * cin * xx.element_size() + n * oh * ow * pk.cout * es * (2 if residual is not None else 1) \
-            + pk.cout * cin * pk.k * pk.k * es
-        if up is not None:  # virtual Upsample + Concat: the leading channels are read at quarter size
-            nbytes -= n * h * w * up.channels * xx.element_size() * 3 // 4
-        calls.append((conv_name(n, h, w, cin, pk, stride, pad, act, residual), flops, nbytes,
-                      lambda: orig(xx, pk, stride, pad, act, out=y, residual=residual, out_dtype=out_dtype, up=up)))
-        return y
-
-    def rec_tail(self, t, conv, raw, kind, i, plan):
-        orig_tail(self, t, conv, raw, kind, i, plan)
-        n, cin, h, w = t.shape
-        cout = conv.out_channels
-        plan_keep = dict(plan)
-        # the fused 1x1 + decode launch (conv1x1.hip EPI 1 / 2): reads t once, writes 4 or nc f32 rows per anchor
-        var = L.lib().upa_conv_variant(n, h, w, cin, 64 if kind == 1 else max(16, (cout + 7) // 8 * 8), 1, 1, 0, code, R.opts_ptr())
-        name = "void conv1x1_stream_kernel<%d, %d, %d, %d>(C1Params)" % (var & 15, (var >> 4) & 15, (var >> 8) & 31, kind)
-        flops = 2.0 * n * h * w * cout * cin
-        nbytes = n * h * w * cin * 2 + n * h * w * (4 if kind == 1 else self.nc) * 4 + cout * cin * 2 + \
-            (n * h * w * cout * 2 if raw is not None else 0)
-        calls.append((name, flops, nbytes, lambda: orig_tail(self, t, conv, raw, kind, i, plan_keep)))
-
-    orig_pair = L.lib().upa_bottleneck_pair
-    orig_c2f = L.lib().upa_c2f_fused
-    orig_btail = L.lib().upa_detect_branch_tail
-    orig_paircv2 = L.lib().upa_bottleneck_pair_cv2
-    orig_c2f64 = L.lib().upa_c2f64_fused
-    orig_c2f32up = L.lib().upa_c2f32_up_fused
-    c2f32up_calls = []
-    pair_calls, c2f_calls, btail_calls, paircv2_calls, c2f64_calls = [], [], [], [], []
-
-    class _LibProxy:
-        """Forwards every C entry to the real library, recording the fused-block launches (Bottleneck / C2f / Detect call
-        them directly, not through hip_conv2d)."""
-
-        def __getattr__(self, name):
-            return getattr(real_lib, name)
-
-        def upa_bottleneck_pair(self, *a):
-            rc = orig_pair(*a)
-            if rc == 0:
-                pair_calls.append(a)
-            return rc
-
-        def upa_bottleneck_pair_cv2(self, *a):
-            rc = orig_paircv2(*a)
-            if rc == 0:
-                paircv2_calls.append(a)
-            return rc
-
-        def upa_c2f_fused(self, *a):
-            rc = orig_c2f(*a)
-            if rc == 0:
-                c2f_calls.append(a)
-            return rc
-
-        def upa_c2f64_fused(self, *a):
-            rc = orig_c2f64(*a)
-            if rc == 0:
-                c2f64_calls.append(a)
-            return rc
-
-        def upa_c2f32_up_fused(self, *a):
-            rc = orig_c2f32up(*a)
-            if rc == 0:
-                c2f32up_calls.append(a)
-            return rc
-
-        def upa_detect_branch_tail(self, *a):
-            rc = orig_btail(*a)
-            if rc == 0:
-                btail_calls.append(a)
-            return rc
-
-    real_lib = L.lib()
-    proxy = _LibProxy()
-    mods = (pconv, pblock, phead)
-    pool = R.BufferPool()
-    orig_libfn = L.lib
-    try:
-        for m in mods:
-            m.hip_conv2d = rec
-        phead.Detect._tail_call = rec_tail
-        L.lib = lambda: proxy
-        with torch.no_grad(), R.static_buffers(pool):
-            post(model._predict_once(x))
-    finally:
-        for m in mods:
-            m.hip_conv2d = orig
-        phead.Detect._tail_call = orig_tail
-        L.lib = orig_libfn
-    for a in pair_calls:  # (x, n, h, w, c, ldx, w1, b1, w2, b2, y, ldy, residual, act, dtype, opts, stream)
-        n_, h_, w_, c_ = a[1], a[2], a[3], a[4]
-        flops = 2 * 2.0 * n_ * h_ * w_ * c_ * c_ * 9
-        nbytes = 2 * (n_ * h_ * w_ * c_ * 2 * (2 + (0.5 if a[12] else 0)) + c_ * c_ * 9 * 2)  # two convs, each in + out (+ residual)
-        calls.append(("void conv_pair_kernel<%d, %s, false>(PairParams)" % (c_ // 32, "true" if a[12] else "false"), flops, nbytes,
-                      (lambda a=a: orig_pair(*a[:16], L.current_stream(dev)))))
-    for a in paircv2_calls:  # (x, y0, n, h, w, ldx, w1, b1, w2, b2, residual, wc_std, wc_b, bc, out, ldout, act, dtype, opts, stream)
-        npx = a[2] * a[3] * a[4]
-        flops = 2.0 * npx * (2 * 9 * 32 * 32 + 96 * 64)
-        nbytes = npx * (64 + 64) * 2 + (18 * 32 * 32 + 96 * 64) * 2  # y0 | y1 in, 64 channels out, weights
-        calls.append(("void conv_pair_kernel<1, %s, true>(PairParams)" % ("true" if a[10] else "false"), flops, nbytes,
-                      (lambda a=a: orig_paircv2(*a[:19], L.current_stream(dev)))))
-    for a in c2f_calls:  # (x, n, h, w, c1, ldx, c, nb, shortcut, w1, b1, wm, bm, w2, b2, y, c2, ldy, act, dtype, opts, stream)
-        npx, c1_, c_, nb_, c2_ = a[1] * a[2] * a[3], a[4], a[6], a[7], a[16]
-        wts = c1_ * 2 * c_ + nb_ * 18 * c_ * c_ + (2 + nb_) * c_ * c2_
-        flops = 2.0 * npx * wts
-        nbytes = npx * (c1_ + c2_) * 2 + wts * 2  # block input + block output + weights
-        o_ = R.current_opts()
-        th = 10 if (c_ != 16 and nb_ == 2 and o_ is not None and o_.c2f32_th == 10) else 16
-        stream_form = c_ == 32 and th == 16 and (o_ is None or o_.c2f_stream != 1)  # the line-buffer kernels (csrc/c2f_stream.hip)
-        name = ("void c2f16_fused_kernel<%d>(C2fParams)" % (8 if (o_ is not None and o_.c2f16_waves == 8) else 4) if c_ == 16 else
-                ("c2f32_stream2_kernel(C2fsParams)" if nb_ == 2 and (o_ is None or o_.c2f_stream != 2) else
-                 "void c2f32_stream_kernel<2>(C2fsParams)" if nb_ == 2 else "void c2f32_stream1_kernel<1>(C2fsParams)") if stream_form else
-                "void c2f32_fused_kernel<%d, %d>(C2f32Params)" % (nb_, th))
-        calls.append((name, flops, nbytes, (lambda a=a: orig_c2f(*a[:21], L.current_stream(dev)))))
-    for a in c2f32up_calls:  # (x, n, h, w, c1, ldx, up, up_c, up_ld, nb, shortcut, w1, b1, wm, bm, w2, b2, y, c2, ldy, act, dtype, opts, stream)
-        npx, c1_, upc_, nb_, c2_ = a[1] * a[2] * a[3], a[4], a[7], a[9], a[18]
-        wts = c1_ * 64 + nb_ * 18 * 32 * 32 + (2 + nb_) * 32 * c2_
-        o_ = R.current_opts()
-        name = ("void c2f32_stream1_kernel<%d>(C2fsParams)" % (c1_ // 64) if (c1_ <= 192 and (o_ is None or o_.c2f_stream != 1)) else
-                "void c2f32_fused_kernel<1, 16, true>(C2f32Params)")
-        calls.append((name, 2.0 * npx * wts, npx * (c1_ - upc_ * 3 // 4 + c2_) * 2 + wts * 2,  # block input (the upsampled channels at quarter size) + output + weights
-                      (lambda a=a: orig_c2f32up(*a[:23], L.current_stream(dev)))))
-    for a in c2f64_calls:  # (x, n, h, w, c1, ldx, up, up_c, up_ld, nb, shortcut, w1, b1, wm, bm, w2, b2, y, c2, ldy, act, dtype, opts, stream)
-        npx, c1_, upc_, nb_, c2_ = a[1] * a[2] * a[3], a[4], a[7], a[9], a[18]
-        wts = c1_ * 128 + nb_ * 18 * 64 * 64 + (2 + nb_) * 64 * c2_
-        flops = 2.0 * npx * wts
-        nbytes = npx * (c1_ - upc_ * 3 // 4 + c2_) * 2 + wts * 2  # block input (the upsampled channels at quarter size) + output + weights
-        calls.append(("void c2f64_fused_kernel<%d, 10, %d>(C2f64Params)" % (nb_, 10 if nb_ == 2 else 20), flops, nbytes,
-                      (lambda a=a: orig_c2f64(*a[:23], L.current_stream(dev)))))
-    for a in btail_calls:  # (x, n, h, w, c, ldx, w3, b3, wt, bt, kind, nc, stride, y, a_total, a0, best_keys, dtype, opts, stream)
-        npx, c_, kind, nc_ = a[1] * a[2] * a[3], a[4], a[10], a[11]
-        cout = 64 if kind == 1 else nc_
-        flops = 2.0 * npx * (9 * c_ * c_ + c_ * cout)
-        nbytes = npx * c_ * 2 + npx * (4 if kind == 1 else nc_) * 4 + (9 * c_ * c_ + c_ * cout) * 2
-        mt = 1 if (npx + 255) // 256 < torch.cuda.get_device_properties(dev).multi_processor_count else 2
-        calls.append(("void conv_big_kernel<3, 1, 8, 1, %d, %d, %d>(BigParams)" % (mt, 4 if kind == 1 else (5 if c_ == 80 else 6), kind), flops, nbytes,
-                      (lambda a=a: orig_btail(*a[:19], L.current_stream(dev)))))
-    torch.cuda.synchronize(dev)
-    fam = {}
-    with torch.no_grad():
-        for (name, flops, nbytes, replay) in calls:
-            def body():
-                for _ in range(reps):
-                    replay()
-
-            body()
-            g = R.HipGraph()
-            g.capture(body, device=dev)
-            g.replay(dev)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            g.replay(dev)
-            e1.record()
-            torch.cuda.synchronize(dev)
-            ms = e0.elapsed_time(e1) / reps
-            d = fam.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
-            d["launches"] += 1
-            d["ms"] += ms
-            d["flops"] += flops
-            d["bytes"] += nbytes
-    if torch.is_tensor(x) and model._stem_fusable(x, model._concat_placement()):
-        # rows 0-1 run as one kernel that bypasses hip_conv2d (csrc/stem.hip: stem_conv_fused_kernel)
-        n_, _, h_, w_ = x.shape
-        with torch.no_grad(), R.static_buffers(pool):
-            def body_f():
-                for _ in range(reps):
-                    model._fused_stem(x)
-            body_f()
-            g = R.HipGraph()
-            g.capture(body_f, device=dev)
-            g.replay(dev)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            g.replay(dev)
-            e1.record()
-            torch.cuda.synchronize(dev)
-        fl = 2.0 * n_ * ((h_ // 2) * (w_ // 2) * 16 * 27 + (h_ // 4) * (w_ // 4) * 32 * 144)
-        by = n_ * 3 * h_ * w_ * es + n_ * (h_ // 4) * (w_ // 4) * 32 * es
-        o_ = R.current_opts()
-        fam["void stem_conv_fused_kernel<%d>(StemFusedParams)" % (4 if (o_ is not None and o_.stemf_waves == 4) else 8)] = dict(launches=1, ms=e0.elapsed_time(e1) / reps, flops=fl, bytes=float(by))
-    conv_ms = sum(d["ms"] for d in fam.values())
-    conv_flops = sum(d["flops"] for d in fam.values())
-    conv_bytes = sum(d["bytes"] for d in fam.values())
-    dom_name, dom = max(fam.items(), key=lambda kv: kv[1]["ms"])
-    peak = PEAK_BF16_TFLOPS if es == 2 else PEAK_F32_TFLOPS
-    avg_s = dom["ms"] / dom["launches"] * 1e-3
-    achieved_tf = dom["flops"] / dom["launches"] / avg_s / 1e12
-    achieved_gbs = dom["bytes"] / dom["launches"] / avg_s / 1e9
-    ai = dom["flops"] / dom["bytes"]
-    bound = "mfma" if ai > peak * 1e12 / (PEAK_HBM_GBS * 1e9) else "hbm"
-    roofline = {
-        "kernel": dom_name,
-        "bound": bound,
-        "achieved": round(achieved_tf if bound == "mfma" else achieved_gbs, 2),
-        "peak": peak if bound == "mfma" else PEAK_HBM_GBS,
-        "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
-        "frac": round((achieved_tf / peak) if bound == "mfma" else (achieved_gbs / PEAK_HBM_GBS), 4),
-        "traffic": None,
-        "launches_per_step": dom["launches"],
-        "avg_launch_us": round(avg_s * 1e6, 2),
-        "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
-        "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
-        "flop_per_byte": round(ai, 1),
-        "achieved_tflops": round(achieved_tf, 2),
-        "achieved_gbs": round(achieved_gbs, 1),
-        "timing": f"HIP events around a hipGraph replay of {reps} back-to-back launches per layer, on the launch stream "
-                  "(isolated kernel time; agrees with rocprofv3 AverageNs of `bench.py --serial`, while in the default "
-                  "run the Detect branches overlap on side streams and rocprofv3 reports stretched durations)",
-    }
-    # HBM traffic per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see profiles/): only valid for
-    # the configuration they were collected on
-    for pf in sorted((ROOT / "profiles").glob("r*_pmc_hbm_summary.json"), reverse=True):  # the latest round that measured this kernel
-        try:
-            pmc = json.loads(pf.read_text())
-            if pmc.get("config") == f"{args.model} bs={args.batch} {args.dtype}" and dom_name in pmc["kernels"]:
-                roofline["traffic"] = round(pmc["kernels"][dom_name]["hbm_bytes_per_launch"])
-                roofline["traffic_source"] = f"profiles/{pf.name} (rocprofv3 --pmc, separate passes)"
-                break
-        except (OSError, KeyError, ValueError):
-            pass
-    # What bounds the quoted mode: with several steps in flight the small-map launches of other steps hide under the chip-filling
-    # ones, so the step is (nearly) the SUM of the launches that fill the chip by themselves - listed here, each against the tighter
-    # of its two rooflines, with the vector-issue time of its instruction count (PMC INSTS_VALU per launch over 1024 SIMDs at the
-    # measured 2.5 cycles per wave-instruction and 2.1 GHz; transcendental instructions cost 8.2, so this is a lower bound)
-    valu = {}
-    for pf in sorted((ROOT / "profiles").glob("r*_pmc_step_budget.txt"), reverse=True):
-        try:
-            for ln in pf.read_text().splitlines()[1:]:
-                rest = ln[60:].split()  # (kernel name padded to 60 columns) calls INSTS_VALU INSTS_SALU ...
-                if len(rest) > 2 and rest[0].isdigit():
-                    valu.setdefault(ln[:60].strip(), float(rest[1]) / max(int(rest[0]), 1))
-        except (OSError, ValueError, IndexError):
-            pass
-        break
-    crit = []
-    for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"] / kv[1]["launches"]):
-        us = v["ms"] / v["launches"] * 1e3
-        if us < 25.0:
-            continue
-        tf, gb = v["flops"] / (v["ms"] * 1e-3) / 1e12, v["bytes"] / (v["ms"] * 1e-3) / 1e9
-        kn = k.replace("void ", "").split("(")[0]  # the PMC table strips "void " and the parameter list and cuts names at 60 columns
-        vi = next((valu[n_] for n_ in valu if n_ and (kn == n_ or kn[:60].rstrip() == n_)), None)
-        if vi is None:  # same kernel template, one instantiation in the table (its template list may be spelled with defaults)
-            same = [n_ for n_ in valu if n_ and n_.split("<")[0] == kn.split("<")[0]]
-            vi = valu[same[0]] if len(same) == 1 else None
-        crit.append({"kernel": k, "launches": v["launches"], "avg_us": round(us, 1), "frac_mfma": round(tf / peak, 3),
-                     "frac_hbm": round(gb / PEAK_HBM_GBS, 3), "frac_of_tighter_roofline": round(max(tf / peak, gb / PEAK_HBM_GBS), 3),
-                     "valu_issue_us": None if vi is None else round(vi / 1024 * 2.5 / 2.1e3, 1)})
-    kernels = {
-        "critical_path": crit,
-        "conv_ms_per_step": round(conv_ms, 4),
-        "conv_tflops": round(conv_flops / (conv_ms * 1e-3) / 1e12, 1),
-        "conv_algorithmic_gbs": round(conv_bytes / (conv_ms * 1e-3) / 1e9, 1),
-        "conv_hbm_floor_ms": round(conv_bytes / 6.0e12 * 1e3, 4),
-        "conv_algorithmic_bytes": conv_bytes,
-        "conv_launches_per_step": int(sum(d["launches"] for d in fam.values())),
-        "families": {k: dict(launches=v["launches"], avg_us=round(v["ms"] / v["launches"] * 1e3, 2),
-                             tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1),
-                             gbs=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)) for k, v in sorted(fam.items())},
-    }
-    return roofline, kernels
-
-
-def gpu_parity(args, dev, ppath, model, x0, results, pb):
-    """GPU output vs the oracle's on the SAME batch (rank 0's first resident batch = procedural images 0 .. pb - 1), in the same run:
-      f32  - the parity mode (`--dtype f32`: exact-f32 MFMA): one extra forward + NMS of an f32 copy of the model after the timed
-             region; max |box| / |score| over every anchor of the head output, and the detections row by row (north_star: 1e-3);
-      bf16 - the mode the throughput is quoted in: the detections the TIMED region itself produced for that batch (the static result
-             of compiled copy 0) as a set against the oracle's (one-to-one same-class matches at IoU >= 0.9 / 0.5), plus the head
-             output of one eager forward.
-    The oracle's tensors come from the CPU-baseline child (`--parity-out`); nothing of oracle/ is imported here."""
-    import numpy as np
-
-    from ultralytics_pro_amd.nn.tasks import DetectionModel
-    from ultralytics_pro_amd.utils import parity as PA
-    from ultralytics_pro_amd.utils import procedural as P
-    from ultralytics_pro_amd.utils.nms import non_max_suppression
-
-    if not os.path.exists(ppath):
-        return {"error": "the CPU leg produced no oracle output (cut at its wall-clock limit?)"}
-    ref = torch.load(ppath)
-    y_ref = ref["y"]
-    ref_rows = PA.split_rows(ref["rows"].numpy(), ref["n"])
-    out = {"images": int(y_ref.shape[0]), "oracle": f"oracle (CPU f32, fused eval, {ref['threads']} threads) on procedural images 0..{pb - 1}",
-           "reference_detections": int(sum(ref["n"]))}
-    if "rtdetr" in args.model:
-        return _gpu_parity_rtdetr(args, dev, y_ref, model, x0, out, pb)
-    with torch.no_grad():
-        mf = DetectionModel(args.model + ".yaml")
-        P.apply_procedural_weights(mf)
-        mf = mf.to(dev).eval()
-        mf.set_compute_dtype(torch.float32)
-        x32 = P.synthetic_images(pb, first=0).to(dev)
-        yf = mf(x32)[0]
-        det = [d.cpu().numpy() for d in non_max_suppression(yf, 0.25, 0.7, max_det=300)]
-        d = (yf.cpu() - y_ref).abs()
-        eq, _, _ = PA.rows_identical(det, ref_rows, 1e-3)
-        rq = PA.rows_equivalent(det, ref_rows, 1e-3, 0.25, 0.7)
-        out["f32"] = {"max_box_abs_px": float(d[:, :4].max()), "max_score_abs": float(d[:, 4:].max()),
-                      "detections": int(sum(len(r) for r in det)), "rows_equal": eq,
-                      # rows whose presence a threshold decides within the tolerance (score within 1e-3 of conf, IoU within 1e-3 of
-                      # iou_thres, or overlapping such a row) are counted and excused; every other row must have its partner
-                      "rows": rq, "tolerance": 1e-3,
-                      "within_tolerance": bool(d[:, :4].max() <= 1e-3 and d[:, 4:].max() <= 1e-3 and rq["equivalent"])}
-        if args.model == "yolov8s":
-            # the reference's OWN f32 output on this model moves by 2.2e-3 px between 8 and 1 CPU threads and sits 1.8e-3 .. 2.9e-3 px from
-            # its float64 run (tools/ref_noise_floor.py; tests/test_oracle_golden.py): 1e-3 px is below its reproducibility there
-            out["f32"]["box_tolerance_note"] = ("yolov8s: the reference's own f32 noise floor is 2.2e-3 - 2.9e-3 px (8 vs 1 threads, vs float64); "
-                                                "the tests gate its boxes at 3e-3 px, scores at 1e-3")
-            out["f32"]["within_reference_noise_floor"] = bool(d[:, :4].max() <= 3e-3 and d[:, 4:].max() <= 1e-3 and rq["equivalent"])
-        del mf, yf
-        if args.dtype == "bf16":
-            mine = []
-            for (o_, c_, _) in results:
-                oc, cc = o_.cpu().numpy(), c_.cpu().tolist()
-                mine += [oc[i, :int(cc[i])] for i in range(len(cc))]
-            a9, a5 = PA.detection_agreement(mine, ref_rows, 0.9), PA.detection_agreement(mine, ref_rows, 0.5)
-            det_ = model.model[-1]
-            so_ = getattr(det_, "scores_out", True)
-            if hasattr(det_, "scores_out"):
-                det_.scores_out = True  # the head comparison reads the class rows
-            try:
-                yb = model(x0)[0].float().cpu()
-            finally:
-                if hasattr(det_, "scores_out"):
-                    det_.scores_out = so_
-            db = (yb - y_ref).abs()
-            out["bf16"] = {"detections": a9["n_mine"], "recall_iou90": round(a9["recall"], 4), "precision_iou90": round(a9["precision"], 4),
-                           "recall_iou50": round(a5["recall"], 4), "precision_iou50": round(a5["precision"], 4),
-                           "matched_box_p99_px": round(a9["box_p99"], 4), "matched_box_max_px": round(a9["box_max"], 4),
-                           "matched_score_max": round(a9["score_max"], 5),
-                           "head_box_p99_px": float(np.quantile(db[:, :4].numpy().ravel()[::7], 0.99)), "head_box_max_px": float(db[:, :4].max()),
-                           "head_score_max": float(db[:, 4:].max()),
-                           "source": "detections: the timed region's own result for this batch (compiled copy 0); head: one eager forward"}
-    return out
-
-
-def _gpu_parity_rtdetr(args, dev, y_ref, model, x0, out, pb):
-    """Config 5: the (B, 300, 4 + nc) decoder output against the oracle's as SETS of rows per image (the 300 queries are the top-300
-    tokens by encoder score, head.py:2175: two implementations may order near-ties differently, and the bf16 mode may pick other
-    tokens near the cut).  f32: the largest distance of an oracle row to its own partner (1e-3 = north_star's tolerance); bf16: the
-    fraction of oracle rows reproduced within the reference's AMP tolerance (0.5 px of 640, utils/checks.py:780) and 0.01 per score."""
-    from ultralytics_pro_amd.nn.tasks import DetectionModel
-    from ultralytics_pro_amd.utils import procedural as P
-
-    def sets(y):
-        worst, frac = 0.0, []
-        for i in range(y.shape[0]):
-            dist = (y[i][:, None, :] - y_ref[i][None, :, :]).abs().amax(2)
-            worst = max(worst, float(dist.min(0).values.max()))
-            db = (y[i][:, None, :4] - y_ref[i][None, :, :4]).abs().amax(2)
-            j = db.argmin(0)
-            sc = (y[i][j, 4:] - y_ref[i][:, 4:]).abs().amax(1)
-            frac.append(float(((db.min(0).values <= 0.5 / 640) & (sc <= 0.01)).float().mean()))
-        return worst, frac
-    with torch.no_grad():
-        mf = DetectionModel(args.model + ".yaml")
-        P.apply_procedural_weights(mf)
-        mf = mf.to(dev).eval()
-        mf.set_compute_dtype(torch.float32)
-        yf = mf(P.synthetic_images(pb, first=0).to(dev))[0].float().cpu()
-        worst, _ = sets(yf)
-        out["f32"] = {"worst_row_to_partner": worst, "tolerance": 1e-3, "within_tolerance": bool(worst <= 1e-3),
-                      "compared": "decoder output rows as sets per image (normalised boxes, class scores)"}
-        del mf, yf
-        if args.dtype == "bf16":
-            yb = model(x0)[0].float().cpu()
-            _, frac = sets(yb)
-            out["bf16"] = {"oracle_rows_reproduced_mean": round(sum(frac) / len(frac), 4), "oracle_rows_reproduced_min": round(min(frac), 4),
-                           "within": "0.5 px of 640 on the box and 0.01 on every class score",
-                           "note": "random-weight encoder scores are nearly flat: the bf16 mode selects other top-300 tokens near the cut, "
-                                   "so agreement is bounded by the query-set overlap (tests/test_hip_e2e.py pins the backbone and the decoder separately)"}
-    return out
-
-
-def physical_cores() -> int:
-    """Physical cores of this host (unique (physical id, core id) pairs of /proc/cpuinfo; logical count if unavailable)."""
-    try:
-        pairs, phys = set(), None
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("physical id"):
-                phys = line.split(":")[1].strip()
-            elif line.startswith("core id"):
-                pairs.add((phys, line.split(":")[1].strip()))
-        if pairs:
-            return len(pairs)
-    except OSError:
-        pass
-    return os.cpu_count() or 1
-
-
-def cpu_baseline_child(args):
-    """Child-process entry of the CPU baseline leg: never touches the GPU; the result file is rewritten after every line."""
-    out = args.cpu_baseline_child
-    res = run_cpu_train_baseline(args) if args.workload == "train" else run_cpu_baseline(args, progress=out, parity_out=args.parity_out)
-    with open(out, "w") as f:
-        json.dump(res, f)
-    return 0
-
-
-def run_cpu_baseline_bounded(args, limit_s: float = 150.0, parity_out: str | None = None):
-    """Run the CPU baseline leg as a child process (`bench.py --cpu-baseline-child`) with a hard wall-clock limit.
-
-    The leg times torch CPU convolutions at up to all physical cores of a host that bench.py does not own: on a busy or
-    oversubscribed host a single forward can take minutes (it once stalled a whole default run), and an in-process forward
-    cannot be interrupted.  The child keeps its result file current, so whatever was measured before the limit is reported
-    (`"truncated": true`); the GPU numbers never wait for more than `limit_s`."""
-    import subprocess
-    import tempfile
-    fd, out = tempfile.mkstemp(prefix="upa_cpu_baseline_", suffix=".json")
-    os.close(fd)
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", out, "--workload", args.workload, "--model", args.model,
-           "--batch", str(args.batch), "--imgsz", str(args.imgsz), "--cpu-threads", str(args.cpu_threads)]
-    if parity_out:
-        cmd += ["--parity-out", parity_out]
-    env = dict(os.environ, OMP_WAIT_POLICY="passive", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
-    truncated = False
-    try:
-        subprocess.run(cmd, env=env, timeout=limit_s, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
-    except subprocess.TimeoutExpired:  # subprocess.run has killed the child
-        truncated = True
-    try:
-        with open(out) as f:
-            res = json.load(f)
-    except (OSError, ValueError):
-        res = None
-    finally:
-        try:
-            os.unlink(out)
-        except OSError:
-            pass
-    if res is None:
-        return {"value": None, "unit": "images/s", "cores": 0, "kind": "port",
-                "sample": f"CPU baseline leg produced nothing within {limit_s:.0f} s on this host (child process killed)"}
-    if truncated:
-        res["truncated"] = True
-        res["sample"] += f"; the leg was cut at {limit_s:.0f} s wall clock, later (config, threads) lines are missing"
-    return res
-
-
-def _cpu_baseline_result(args, lines, logical, phys):
-    head = [ln for ln in lines if ln["config"] == args.model and "forward_nms_img_s" in ln]
-    if not head:
-        return None
-    top = max(head, key=lambda ln: ln["forward_nms_img_s"])
-    return {"value": top["forward_nms_img_s"], "unit": "images/s", "cores": top["threads"], "kind": "port",
-            "sample": f"oracle (torch CPU fp32, fused eval) {args.model} bs={args.batch} forward+NMS at {top['threads']} threads, best "
-                      f"of {top['best_of']}; host: {logical} logical / {phys} physical cores; every (config, threads) line is in `lines`",
-            "host_logical_cores": logical, "host_physical_cores": phys, "lines": lines}
-
-
-def run_cpu_baseline(args, budget_s: float = 45.0, progress: str | None = None, parity_out: str | None = None):
-    """the oracle (CPU restatement, validated bit for bit against the imported reference) on THIS
-    host's cores - fused eval, fp32 - for C2 (yolov8n, 32 x 3 x 640 x 640) and C1 (yolov3-tiny, 8 x 3 x 640 x 640), with
-    N = 8 threads (the reference's own cap NUM_THREADS = min(8, cpus - 1), utils/__init__.py:43), N = 32 and N = all physical
-    cores; 1 warm-up, best of up to 3 (fewer when one pass is slow: the whole leg is bounded to ~`budget_s` seconds);
-    forward and forward + NMS (conf 0.25, iou 0.7, max_det 300) as images/s and per-image ms in the reference's Profile
-    format (validator.py:253-256).  `value` = the best forward+NMS rate of the headline config."""
-    from oracle import nms as onms
-    from oracle import tasks as ot
-    from ultralytics_pro_amd.utils import procedural as P
-
-    logical, phys = os.cpu_count() or 1, physical_cores()
-    threads = [args.cpu_threads] if args.cpu_threads else sorted({min(8, logical), min(32, logical), phys})
-    configs = [(args.model, args.batch)] + ([("yolov3-tiny", 8)] if args.model == "yolov8n" else [])
-    lines, t_start = [], time.perf_counter()
-    for name, b in configs:
-        m = ot.DetectionModel(name + ".yaml")
-        P.apply_procedural_weights(m)
-        m.fuse()
-        x = P.synthetic_images(b)
-        per_img_best = None
-        for nthr in threads:
-            torch.set_num_threads(nthr)
-            with torch.no_grad():
-                t0 = time.perf_counter()
-                m(x[:2])  # warm-up and oversubscription probe (torch CPU convs collapse when threads >> useful cores)
-                probe = (time.perf_counter() - t0) / 2
-                left = budget_s - (time.perf_counter() - t_start)
-                if (per_img_best is not None and probe > 6 * per_img_best) or probe * b > left:
-                    lines.append({"config": name, "batch": b, "threads": nthr, "skipped": f"probe {probe * 1e3:.0f} ms/image at "
-                                  f"bs 2: slower than fewer threads or over the time budget"})
-                    continue
-                reps = max(1, min(3, int(left / 3 / max(probe * b, 1e-3))))
-                best_f = best_n = 1e30
-                for _ in range(reps):
-                    t0 = time.perf_counter()
-                    y = m(x)[0]
-                    t1 = time.perf_counter()
-                    post = (lambda yy: onms.rtdetr_postprocess(yy, 0.25)) if "rtdetr" in name else (lambda yy: onms.non_max_suppression(yy, 0.25, 0.7, max_det=300))
-                    post(y)
-                    t2 = time.perf_counter()
-                    best_f, best_n = min(best_f, t1 - t0), min(best_n, t2 - t1)
-                    if parity_out and name == args.model and not os.path.exists(parity_out):
-                        # the oracle's answer on the GPU's first resident batch (same procedural images and weights): the parent compares
-                        det = post(y)
-                        torch.save({"y": y, "rows": torch.cat(det, 0), "n": [int(d.shape[0]) for d in det], "threads": nthr,
-                                    "first_image": 0, "batch": b}, parity_out + ".tmp")
-                        os.replace(parity_out + ".tmp", parity_out)
-            per_img_best = min(per_img_best or 1e30, best_f / b)
-            lines.append({"config": name, "batch": b, "threads": nthr, "best_of": reps,
-                          "forward_img_s": round(b / best_f, 2), "forward_nms_img_s": round(b / (best_f + best_n), 2),
-                          "speed": "Speed: %.1fms preprocess, %.1fms inference, %.1fms loss, %.1fms postprocess per image" % (
-                              0.0, best_f / b * 1e3, 0.0, best_n / b * 1e3)})
-            if progress:  # keep the parent's view current: it may have to kill this process at its wall-clock limit
-                part = _cpu_baseline_result(args, lines, logical, phys)
-                if part is not None:
-                    with open(progress + ".tmp", "w") as f:
-                        json.dump(part, f)
-                    os.replace(progress + ".tmp", progress)
-    res = _cpu_baseline_result(args, lines, logical, phys)
-    if res is None:
-        raise RuntimeError("CPU baseline: no line of the headline config was measured")
-    return res
 
 
 if __name__ == "__main__":
