@@ -141,22 +141,27 @@ SEED_BOUNDS = {  # name: (least IoU >= 0.5 recall / precision on ANY seed, least
 
 @pytest.mark.parametrize("name", list(SEED_BOUNDS))
 def test_e2e_bf16_vs_f32_over_image_seeds(name):
-    """The chaotic-family agreement as a DISTRIBUTION instead of one sample: five procedural image seeds, 4 images each, the bf16 mode
-    against the product's own f32 mode (which the f32 tests pin to the reference within 1e-3 and to the oracle at the configs' batch
-    sizes).  (The weight seed stays 0: the family's class bias was placed for that draw - with another weight seed the random head
+    """The chaotic-family agreement as a DISTRIBUTION instead of one sample: six procedural image seeds, 6 images each, the bf16 mode
+    against the f32 ORACLE on the same images (round 6; rounds 4-5 compared with the product's own f32 mode).  (The weight seed stays 0: the family's class bias was placed for that draw - with another weight seed the random head
     fires on 0 or on > 300 anchors per image, measured - so the samples vary the input.)  Gates: the IoU >= 0.5 agreement on EVERY seed
     and the median IoU >= 0.9 agreement over the seeds - bounds set from the measured spread (printed), not from one draw."""
     from tests.hip_utils import DEV, detection_agreement
     from ultralytics_pro_amd.utils.nms import non_max_suppression
-    models = {dt: _build(name, dt) for dt in (torch.float32, torch.bfloat16)}
+    mb = _build(name, torch.bfloat16)
+    # round 6: the f32 side is the ORACLE itself (it was the product's own f32 mode, which the f32 tests pin to the oracle within 1e-3 -
+    # transitively the same statement, but not an oracle test)
+    o = ot.DetectionModel(name + ".yaml")
+    P.apply_procedural_weights(o)
+    o.fuse()
+    conf = SEED_CONF.get(name, 0.1)
     rows = []
     for seed in range(6):
         x = P.synthetic_images(6, seed=seed)
         outs = {}
-        for dt, m in models.items():
-            with torch.no_grad():
-                y = m(x.to(DEV).to(dt).contiguous())[0]
-                outs[dt] = [o.cpu().numpy() for o in non_max_suppression(y, conf_thres=SEED_CONF.get(name, 0.1), iou_thres=0.7, max_det=300)]
+        with torch.no_grad():
+            y = mb(x.to(DEV).to(torch.bfloat16).contiguous())[0]
+            outs[torch.bfloat16] = [r.cpu().numpy() for r in non_max_suppression(y, conf_thres=conf, iou_thres=0.7, max_det=300)]
+            outs[torch.float32] = [r.numpy() for r in onms.non_max_suppression(o(x)[0], conf, 0.7, max_det=300)]
         a9 = detection_agreement(outs[torch.bfloat16], outs[torch.float32], 0.9)
         a5 = detection_agreement(outs[torch.bfloat16], outs[torch.float32], 0.5)
         rows.append((a9["recall"], a9["precision"], a5["recall"], a5["precision"], a9["n_ref"]))
