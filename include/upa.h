@@ -71,7 +71,7 @@ typedef struct upa_opts {
   int32_t no_epi_stats;    /* upa_conv2d_bn_stats: 1 = the batch statistics always by a reduction pass over z (upa_bn_stats), never from the convolution's own workgroups; A/B */
   int32_t nms_stages;      /* upa_nms_batched_opts, multi-label lists longer than 16384 (validation): 0 = prefix keys only (histogram + emit kernels), stages ~nms_first_prefix / ~16384 / exact | 1 = all keys written up front, the sort kernel's pass picks the prefix from the histogram | 2 = no histogram: radix select of the top 16384, then exact (the round-4 form); results identical, A/B */
   int32_t nms_first_prefix; /* target length of the first sorted prefix there: 0 = 4096 | n in [256, 16384) | -1 = none (first prefix ~16384) */
-  int32_t detect_stream;   /* upa_detect_level_stream (csrc/detect_stream.hip: one Detect level, both branches, as one line-buffer launch): 0 / 1 = refuse (callers run the tile form: stacked first conv + upa_detect_head_tails - the default: measured slower, profiles/r06_detect_stream.txt), 2 = run wherever the form applies (A/B, tests) */
+  int32_t detect_stream;   /* upa_detect_level_stream (csrc/detect_stream.hip: one Detect level, both branches, as one line-buffer launch): 0 / 1 = refuse (callers run the tile form: stacked first conv + upa_detect_head_tails - the library default: faster launch for launch), 2 = run wherever the form applies (what the throughput runner asks for with several steps in flight: less CU time and traffic, +2.4 % images/s, profiles/r06_detect_stream.txt) */
   int32_t detect_stream_rows; /* its output rows per workgroup: 0 = the whole image height (one workgroup per strip and branch: least total CU time) | even >= 4 (more, shorter workgroups: a lower latency with one step at a time) */
 } upa_opts;
 

@@ -60,9 +60,15 @@ STEPS = 48
 buf = np.zeros(8 * 8 * STEPS * 2, dtype=np.uint64)
 assert rd(buf.ctypes.data, buf.size) == 0
 allst = buf.reshape(8, 8, STEPS, 2).astype(np.int64)
-for kind, slot, names in (("class", args.wg, ["B01", "B23", "A01", "A23", "TAIL", "DMA", "A4", "B4"]),
-                          ("box", 4 + args.wg, ["A01", "A23", "B01", "B23", "TAIL", "DMA", "idle", "idle"])):
+for kind, slot, names in (("class", args.wg, ["B32a", "B32b", "A32a", "A32b", "A16", "T01", "B16", "T23D"]),
+                          ("box", 4 + args.wg, ["A32a", "A32b", "B32a", "B32b", "T0", "T1", "T2", "T3D"])):
     st = allst[slot]
+    ph = st[:, 44:48, 0]
+    for wv in range(8):
+        if ph[wv, 0] > 0:
+            print(f"  {kind} wave {wv} ({names[wv]}), step 10, first unit: 1x1 MFMAs issued {ph[wv,1]-ph[wv,0]}, keys decoded {ph[wv,2]-ph[wv,1] if ph[wv,2] > 0 else -1}, "
+                  f"decode + store done {ph[wv,3]-(ph[wv,2] if ph[wv,2] > 0 else ph[wv,1])} (cycles)")
+    st = st.copy(); st[:, 44:48, :] = 0
     nsteps = int((st[0, :, 0] > 0).sum())
     if nsteps == 0:
         print(kind, "workgroup: no stamps")

@@ -6,20 +6,27 @@
 // The tile form of this level (conv_big.hip: a stacked 144-channel first conv, then conv_big_mix<..5,2 | ..4,1> = second 3x3 + 1x1 + decode)
 // writes and re-reads the 144-channel intermediate (236 MB per batch of 32), DMAs every 3x3 weight slab into LDS once per 256-pixel tile and
 // pays a halo wait + epilogue per tile: 49 + 70 us at 0.2-0.28 of the MFMA peak.  Here, as in c2f_stream.hip, a workgroup owns a vertical
-// STRIP of one image (WS = 20 output columns, L rows) and walks down it two rows per step with ONE s_barrier per step:
+// STRIP of one image (WS = 30 output columns, L rows) and walks down it two rows per step with ONE s_barrier per step:
 //   * a workgroup runs ONE branch (box workgroups and class workgroups share the grid: 375 KB of weights do not fit one CU's registers,
 //     156 / 220 KB do);  every wave has a fixed ROLE and loads its weights into registers ONCE:
-//       stage A (first 3x3, from the x ring)  and  stage B (second 3x3, from the t1 ring): a wave owns TWO (or the odd one) of the stage's
-//       16-channel n-tiles and all three 16-pixel units of the stage's 2-row band: one ds_read_b128 feeds two MFMAs (half the LDS array time);
-//       tail wave: 1x1 from the t2 ring + the branch's half of the decode (csrc/detect_epi.h) on the three units of the output band;
-//       DMA wave: stages the input band two steps ahead by global_load_lds straight into the PLANAR x ring (one instruction = one 8-channel
-//       plane of a 2 x 32-slot band; out-of-image slots read a zero page: the 3x3's zero padding), counted s_waitcnt vmcnt.
-//   * the intermediates t1 (22 columns) and t2 (20 columns) only exist as LDS rings of 8 / 4 rows, planar [8-channel group][row][column][16 B]:
+//       stage A (first 3x3, from the x ring) and stage B (second 3x3, from the t1 ring) on v_mfma_f32_32x32x16_bf16: a wave owns 32 output
+//       channels of its stage, a unit = one row of the band = 32 pixels (t1 is exactly 32 columns wide), one ds_read_b128 per MFMA, the epilogue of
+//       row 0 dealt out between the MFMAs of row 1 (pinned); the class branch's odd 16 channels (80 = 32 + 32 + 16) as a 16x16x32-form wave;
+//       tail waves: 1x1 from the t2 ring + the branch's half of the decode (csrc/detect_epi.h), the band's four 16-pixel units dealt to waves on
+//       different SIMDs; one of them also stages the input band two steps ahead by global_load_lds straight into the PLANAR x ring (one
+//       instruction = one row of one 8-channel plane; out-of-image slots read a zero page: the 3x3's zero padding).
+//   * the intermediates t1 (32 columns) and t2 (30 columns) only exist as LDS rings of 8 / 4 rows, planar [8-channel group][row][column][16 B]:
 //     a 3x3 tap is an immediate offset of one ds_read_b128.
-//   * class branch, 80 channels = 2 k-tiles of 32 + one of 16: the 16-wide remainder runs on v_mfma_f32_16x16x16_bf16 (ds_read_b64 operands,
+//   * 80 input channels in the 16x16x32 form = 2 k-tiles of 32 + one of 16: the remainder runs on v_mfma_f32_16x16x16_bf16 (ds_read_b64 operands,
 //     the low / high half of the packed third k-tile as A) AFTER the 32-wide chain of a unit (one 8-pass -> 4-pass transition per chain, fenced).
 // Rounding points are those of the separate launches (bf16 t1, t2; f32 accumulation from the bias; f32 decode); the f32 summation order inside a
-// convolution differs (k-tiles of all taps first, then the 16-wide remainders), so results equal the tile form's up to flipped bf16 ties.
+// convolution differs, so results equal the tile form's up to flipped bf16 ties.
+//
+// MEASURED SLOWER than the tile form in both forms built in round 6 (first: 20-column strips on 16x16x32 MFMAs; this one: 30-column strips on
+// 32x32x16) - profiles/r06_detect_stream.txt holds the per-wave stamps: with two waves per SIMD every role is bound by its own in-order issue
+// (a 32-wide 3x3 wave: 72 MFMAs of 32 cycles in 3.9-4.1 k cycles alone on its SIMD; a box tail: 1.8 k per 16-pixel unit alone; the class
+// tails 1.85 k per unit), the class workgroup needs ~27 k issue cycles per step over four SIMDs.  Opt-in only: upa_opts.detect_stream = 2.
+// -DDS_EXP=1 | 2 (timing experiments, wrong results): tails / 32-wide 3x3 stages do nothing.
 #include <stdlib.h>
 
 #include "common.h"
@@ -67,29 +74,32 @@ extern "C" int upa_debug_stamps_dstream(unsigned long long* out, int count) {
 #endif
 
 namespace dstream {
-constexpr int WS = 20;            // output columns of a strip
-constexpr int W1 = WS + 2;        // columns of t1
-constexpr int XSLOTS = 32;        // slots (16 B) per x-ring row: 24 columns + 8 pad, so that a 2-row band of one plane is ONE LDS-DMA instruction
+constexpr int WS = 30;            // output columns of a strip
+constexpr int W1 = WS + 2;        // columns of t1 = 32: one band row IS one 32-pixel unit of v_mfma_f32_32x32x16_bf16
+constexpr int XW = WS + 4;        // input columns of a strip
+constexpr int XSLOTS = 64;        // slots (16 B) per x-ring row: 34 columns + pad, so that a row of one plane is ONE LDS-DMA instruction
 constexpr int XROWB = XSLOTS * 16;
 constexpr int XROWS = 8;          // four bands: two being read, one landed, one landing
 constexpr int XPLANE = XROWS * XROWB;
 constexpr int XB = 0;
 constexpr int XBYTES = 8 * XPLANE;
-constexpr int TROWB = 24 * 16;    // t1 / t2 row pitch
+constexpr int TROWB = 32 * 16;    // t1 / t2 row pitch
 constexpr int T1ROWS = 8, T2ROWS = 4;
 constexpr int T1PLANE = T1ROWS * TROWB, T2PLANE = T2ROWS * TROWB;
 constexpr int T1B = XBYTES;
 template <int C> struct Geo {
   static constexpr int CP = C / 8;                  // 8-channel planes
-  static constexpr int NT = C / 16;                 // n-tiles of the 3x3 stages
+  static constexpr int NT = C / 16;                 // 16-channel n-tiles in the packed 3x3 weights
   static constexpr int KT32 = C / 32;               // whole 32-wide k-tiles of stage B / the tail
   static constexpr int K16 = (C % 32) ? 1 : 0;      // ... and a 16-wide remainder
   static constexpr int KTP = KT32 + K16;            // k-tiles in the packed weights
   static constexpr int T2B = T1B + CP * T1PLANE;
-  static constexpr int DUMMY = T2B + CP * T2PLANE;  // 512 B nobody reads: where lanes outside a band store
-  static constexpr int LDS = DUMMY + 512;
+  static constexpr int DUMMY = T2B + CP * T2PLANE;  // 1 KB nobody reads: where lanes outside a band store
+  static constexpr int LDS = DUMMY + 1024;
 };
 static_assert(XPLANE % 256 == 0 && T1PLANE % 256 == 0 && T2PLANE % 256 == 0, "planes keep the ds_read_b128 lane groups on disjoint banks");
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 __device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 __device__ __forceinline__ f32x4 mfma32(const u32x4& a, const u32x4& b, f32x4 c) {
@@ -97,6 +107,9 @@ __device__ __forceinline__ f32x4 mfma32(const u32x4& a, const u32x4& b, f32x4 c)
 }
 __device__ __forceinline__ f32x4 mfma16(const u32x2& a, const u32x2& b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(*reinterpret_cast<const ds_s16x4*>(&a), *reinterpret_cast<const ds_s16x4*>(&b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma3232(const u32x4& a, const u32x4& b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
 }
 __device__ __forceinline__ void shape_fence() {  // between MFMA shapes on one accumulator chain (see c2f_stream.hip: f_role)
   __builtin_amdgcn_sched_barrier(0);
@@ -106,7 +119,7 @@ __device__ __forceinline__ void shape_fence() {  // between MFMA shapes on one a
 __device__ __forceinline__ u32x4 lds128(const char* sm, int off) { return *reinterpret_cast<const u32x4*>(sm + off); }
 __device__ __forceinline__ u32x2 lds64(const char* sm, int off) { return *reinterpret_cast<const u32x2*>(sm + off); }
 
-// Geometry of one 3x3 stage.  STG 0: x ring -> t1 (22 columns, rows {2s - 1, 2s} at step s);  STG 1: t1 ring -> t2 (20 columns, rows {2s - 4, 2s - 3}).
+// Geometry of one 3x3 stage.  STG 0: x ring -> t1 (32 columns, rows {2s - 1, 2s} at step s);  STG 1: t1 ring -> t2 (30 columns, rows {2s - 4, 2s - 3}).
 template <int C, int STG> struct StageGeo {
   using G = Geo<C>;
   static constexpr int SD = STG ? WS : W1;                       // output columns
@@ -115,332 +128,444 @@ template <int C, int STG> struct StageGeo {
   static constexpr int IN_PLANE = STG ? T1PLANE : XPLANE;
   static constexpr int IN_ROWB = STG ? TROWB : XROWB;
   static constexpr int IN_MASK = (STG ? T1ROWS : XROWS) - 1;
-  static constexpr int KT32 = STG ? G::KT32 : 2;                 // the level's input has 64 channels
-  static constexpr int K16 = STG ? G::K16 : 0;
-  static constexpr int KTP = KT32 + K16;
+  static constexpr int CIN = STG ? C : 64;                       // the level's input has 64 channels
+  static constexpr int KS16 = CIN / 16;                          // 16-wide k-steps (32x32x16 form)
+  static constexpr int KT32 = CIN / 32;                          // 32-wide k-tiles (16x16x32 form) ...
+  static constexpr int K16 = (CIN % 32) ? 1 : 0;                 // ... and a 16-wide remainder
+  static constexpr int KTP = KT32 + K16;                         // k-tiles in the packed weights
   static constexpr int OUT_B = STG ? G::T2B : T1B;
   static constexpr int OUT_PLANE = STG ? T2PLANE : T1PLANE;
   static constexpr int OUT_MASK = (STG ? T2ROWS : T1ROWS) - 1;
   static constexpr int LO = STG ? 2 : 1;                         // valid output rows [LO, LP - LO)
-  static constexpr int NU = (2 * SD + 15) / 16;                  // 16-pixel units of the 2-row band
 };
 
-// ---- a 3x3 stage: this wave owns n-tiles [nt0, nt0 + NTW) of the stage and every unit of its band, weights in registers for the life of the workgroup
-template <int C, int STG, int NTW>
-__device__ __forceinline__ void conv_role(const DsParams& p, const DsBranch& br, char* sm, int nt0, int lane, int S, int py0, int sx0, int LP) {
+struct Ctx {  // what every role of a workgroup shares
+  const DsParams* p;
+  char* sm;
+  int lane, n, py0, sx0, LP, S, slot;
+};
+
+// ---- a 3x3 stage on v_mfma_f32_32x32x16_bf16: this wave owns output channels [32 N, 32 N + 32) of the stage; a unit = one row of the band (32
+// pixels), weights in registers for the life of the workgroup.  Lane (h = lane >> 5, c = lane & 31): B operand = 8 channels (plane 2 s + h) of
+// pixel c, D = channels 32 N + 8 i + 4 h + j (i, j < 4) of pixel c.  The epilogue of row 0 is dealt out between the MFMAs of row 1 (PIPE).
+template <int C, int STG, bool PIPE>
+struct Conv32 {
   using G = Geo<C>;
   using SG = StageGeo<C, STG>;
-  constexpr int NU = SG::NU, KT32 = SG::KT32, NF = 9 * KT32;  // NF = 32-wide fragments per unit
-  constexpr int NBUF = SG::K16 ? 4 : 6;
-  const int g = lane >> 4, r = lane & 15;
-  const char* wp = STG ? br.w2 : br.w1;
-  const float* bp = STG ? br.b2 : br.b1;
-
-  u32x4 w32[9][KT32][NTW];
-  u32x2 w16[SG::K16 ? 9 : 1][NTW];
+  static constexpr int KS = SG::KS16, NF = 9 * KS, NBUF = PIPE ? 6 : 4;
+  u32x4 w[9][KS];
+  f32x4 bias[4];
+  int in0, out_d, h, c;
+  unsigned colm;
+  bool act;
+  __device__ __forceinline__ void init(const Ctx& x, const DsBranch& br, int N) {
+    const int lane = x.lane;
+    h = lane >> 5; c = lane & 31;
+    const char* wp = STG ? br.w2 : br.w1;
+    const float* bp = STG ? br.b2 : br.b1;
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap) {
+    for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-    for (int kt = 0; kt < KT32; ++kt)
+      for (int s = 0; s < KS; ++s)  // lane (h, c): W[co = 32 N + c][ci = 16 s + 8 h .. + 7] = lane ((s & 1) * 2 + h, c & 15) of n-tile 2 N + (c >> 4), k-tile s >> 1
+        w[tap][s] = *reinterpret_cast<const u32x4*>(wp + ((size_t)((tap * SG::KTP + (s >> 1)) * G::NT + 2 * N + (c >> 4)) * 64 + ((s & 1) * 2 + h) * 16 + (c & 15)) * 16);
 #pragma unroll
-      for (int j = 0; j < NTW; ++j)
-        w32[tap][kt][j] = *reinterpret_cast<const u32x4*>(wp + ((size_t)((tap * SG::KTP + kt) * G::NT + nt0 + j) * 64 + lane) * 16);
-    if constexpr (SG::K16 != 0) {
-      // the 16-wide remainder: lane (g, r) needs W[co = 16 nt + r][ci = 32 KT32 + 4g .. + 3] = half (g & 1) of lane (g >> 1, r)'s 16 bytes of k-tile KT32
+    for (int i = 0; i < 4; ++i) bias[i] = *reinterpret_cast<const f32x4*>(bp + 32 * N + 8 * i + 4 * h);
+    act = c < SG::SD;
+    in0 = SG::IN_B + h * SG::IN_PLANE + c * 16;            // tap (dy, dx) reads input column c + dx (both stages)
+    out_d = SG::OUT_B - SG::IN_B + 4 * N * SG::OUT_PLANE - h * SG::IN_PLANE + 8 * h;
+    const int gx = x.sx0 - 1 + c;                          // (only stage A's output lies outside the strip's own columns)
+    colm = (STG || (gx >= 0 && gx < x.p->W)) ? 0xFFFFFFFFu : 0u;
+  }
+  __device__ __forceinline__ void step(const Ctx& x, int s) {
+#if defined(DS_EXP) && DS_EXP == 2  // timing experiment (wrong results): no 32-wide 3x3 work
+    return;
+#endif
+    const int r0 = 2 * s - SG::LAG;
+    if (!(r0 + 2 > SG::LO && r0 < x.LP - SG::LO)) return;  // wave-uniform
+    char* sm = x.sm;
+    int rb[2][3];
 #pragma unroll
-      for (int j = 0; j < NTW; ++j)
-        w16[tap][j] = *reinterpret_cast<const u32x2*>(wp + ((size_t)((tap * SG::KTP + KT32) * G::NT + nt0 + j) * 64 + (g >> 1) * 16 + r) * 16 + (g & 1) * 8);
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) rb[u][dy] = in0 + ((r0 + u + dy - 1) & SG::IN_MASK) * SG::IN_ROWB;
+    auto rd = [&](int t) __attribute__((always_inline)) {
+      const int u = t / NF, f = t % NF, tap = f / KS, ks = f % KS;
+      return lds128(sm, rb[u][tap / 3] + (tap % 3) * 16 + ks * 2 * SG::IN_PLANE);
+    };
+    constexpr int NTOT = 2 * NF;
+    u32x4 buf[NBUF];
+#pragma unroll
+    for (int t = 0; t < NBUF; ++t) buf[t] = rd(t);
+    f32x16 acc[PIPE ? 2 : 1];
+    float sv[4];
+    unsigned e_m = 0u;
+    int e_oa = 0;
+    bool e_ok = false;
+    // the epilogue of one row in 20 slices: slice k < 16 = SiLU of one accumulator value; every fourth one also packs + masks + stores the
+    // four channels 8 i + 4 h .. + 3 (an unconditional store - lanes outside the band write a scratch slot - keeps the step one basic block)
+    auto epi_slice = [&](int u, int k) __attribute__((always_inline)) {
+      const f32x16& a = acc[PIPE ? (u & 1) : 0];
+      if (k == 0) {
+        const int row = r0 + u;
+        const int gy = x.py0 - 2 + row;
+        e_m = (STG || (gy >= 0 && gy < x.p->H)) ? colm : 0u;  // t1 is ZERO outside the image (stage B's padding)
+        e_ok = act && row >= SG::LO && row < x.LP - SG::LO;
+        e_oa = in0 + out_d + (row & SG::OUT_MASK) * TROWB;
+      }
+      if (k < 16) {
+        sv[k & 3] = silu(a[k]);
+        if ((k & 3) == 3) {
+          const u32x2 o = u32x2{pack_bf16x2(sv[0], sv[1]) & e_m, pack_bf16x2(sv[2], sv[3]) & e_m};
+          *reinterpret_cast<u32x2*>(sm + (e_ok ? e_oa + (k >> 2) * SG::OUT_PLANE : G::DUMMY + x.lane * 8)) = o;
+        }
+      }
+    };
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      f32x16& a = acc[PIPE ? (u & 1) : 0];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[4 * i + j] = bias[i][j];
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        const int t = u * NF + f;
+        a = mfma3232(w[f / KS][f % KS], buf[t % NBUF], a);
+        if (t + NBUF < NTOT) buf[t % NBUF] = rd(t + NBUF);
+        if (PIPE && u > 0 && f < 16) epi_slice(u - 1, f);
+        __builtin_amdgcn_sched_barrier(0);  // pinned: a wave issues in order, and left alone the scheduler sinks the ring reads to their MFMAs
+      }
+      if (!PIPE || u == 1) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) epi_slice(u, k);
+      }
     }
   }
-  f32x4 bias[NTW];
-#pragma unroll
-  for (int j = 0; j < NTW; ++j) bias[j] = *reinterpret_cast<const f32x4*>(bp + (nt0 + j) * 16 + 4 * g);
+};
 
-  // lane constants per unit
-  int u_rr[NU], u_in[NU];
-  unsigned u_colm[NU];
-  bool u_act[NU];
+// ---- a 3x3 stage's ODD 16-channel n-tile (class branch: 80 = 32 + 32 + 16) in the 16x16x32 form: units of 16 pixels (two per band row), the 16-wide
+// remainder of an 80-channel input on v_mfma_f32_16x16x16_bf16 after the 32-wide chain (fenced)
+template <int C, int STG>
+struct Conv16 {
+  using G = Geo<C>;
+  using SG = StageGeo<C, STG>;
+  static constexpr int KT32 = SG::KT32, NF = 9 * KT32, NU = 4, NBUF = 4;
+  u32x4 w32[9][KT32];
+  u32x2 w16[SG::K16 ? 9 : 1];
+  f32x4 bias;
+  int u_in[2], in16, out_d, g, r;
+  unsigned u_colm[2];
+  bool u_act[2];
+  __device__ __forceinline__ void init(const Ctx& x, const DsBranch& br, int nt) {
+    const int lane = x.lane;
+    g = lane >> 4; r = lane & 15;
+    const char* wp = STG ? br.w2 : br.w1;
+    const float* bp = STG ? br.b2 : br.b1;
 #pragma unroll
-  for (int u = 0; u < NU; ++u) {
-    const int q = u * 16 + r;
-    u_act[u] = q < 2 * SG::SD;
-    const int qq = u_act[u] ? q : 0;
-    u_rr[u] = qq >= SG::SD ? 1 : 0;
-    const int cc = qq - u_rr[u] * SG::SD;                       // output column; tap (dy, dx) reads input column cc + dx (both stages)
-    u_in[u] = SG::IN_B + g * SG::IN_PLANE + cc * 16;
-    const int gx = sx0 - 1 + cc;                                // (only stage A's output lies outside the strip's own columns)
-    u_colm[u] = (STG || (gx >= 0 && gx < p.W)) ? 0xFFFFFFFFu : 0u;
+    for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+      for (int kt = 0; kt < KT32; ++kt) w32[tap][kt] = *reinterpret_cast<const u32x4*>(wp + ((size_t)((tap * SG::KTP + kt) * G::NT + nt) * 64 + lane) * 16);
+      if constexpr (SG::K16 != 0)
+        w16[tap] = *reinterpret_cast<const u32x2*>(wp + ((size_t)((tap * SG::KTP + KT32) * G::NT + nt) * 64 + (g >> 1) * 16 + r) * 16 + (g & 1) * 8);
+    }
+    bias = *reinterpret_cast<const f32x4*>(bp + nt * 16 + 4 * g);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {  // the two units of a row: columns 16 q + r
+      const int cc = 16 * q + r;
+      u_act[q] = cc < SG::SD;
+      u_in[q] = SG::IN_B + g * SG::IN_PLANE + cc * 16;
+      const int gx = x.sx0 - 1 + cc;
+      u_colm[q] = (STG || (gx >= 0 && gx < x.p->W)) ? 0xFFFFFFFFu : 0u;
+    }
+    in16 = (8 + (g >> 1) - g) * SG::IN_PLANE + (g & 1) * 8;   // 16-wide operand: plane 8 + (g >> 1), half (g & 1), relative to u_in
+    out_d = SG::OUT_B - SG::IN_B + (2 * nt + (g >> 1)) * SG::OUT_PLANE - g * SG::IN_PLANE + (g & 1) * 8;
   }
-  const int in16 = (8 + (g >> 1) - g) * SG::IN_PLANE + (g & 1) * 8;   // 16-wide operand: plane 8 + (g >> 1), half (g & 1), relative to u_in
-  // the lane's 8 output bytes sit at a lane-constant distance from its input address (same column, another ring)
-  const int out_d = SG::OUT_B - SG::IN_B + (2 * nt0 + (g >> 1)) * SG::OUT_PLANE - g * SG::IN_PLANE + (g & 1) * 8;
-
-  for (int s = 0; s < S; ++s) {
-    DS_STAMP(DS_SLOT(p), s, 0);
+  __device__ __forceinline__ void step(const Ctx& x, int s) {
     const int r0 = 2 * s - SG::LAG;
-    if (r0 + 2 > SG::LO && r0 < LP - SG::LO) {  // wave-uniform
-      int rb[NU][3];
+    if (!(r0 + 2 > SG::LO && r0 < x.LP - SG::LO)) return;  // wave-uniform
+    char* sm = x.sm;
 #pragma unroll
-      for (int u = 0; u < NU; ++u)
+    for (int u = 0; u < NU; ++u) {
+      const int row = r0 + (u >> 1), q = u & 1;
+      int rb[3];
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) rb[u][dy] = u_in[u] + ((r0 + u_rr[u] + dy - 1) & SG::IN_MASK) * SG::IN_ROWB;
-      // fragment t of the flattened (unit, tap, k-tile) order
-      auto rd = [&](int t) __attribute__((always_inline)) {
-        const int u = t / NF, f = t % NF, tap = f / KT32, kt = f % KT32;
-        return lds128(sm, rb[u][tap / 3] + (tap % 3) * 16 + kt * 4 * SG::IN_PLANE);
+      for (int dy = 0; dy < 3; ++dy) rb[dy] = u_in[q] + ((row + dy - 1) & SG::IN_MASK) * SG::IN_ROWB;
+      auto rd = [&](int f) __attribute__((always_inline)) {
+        const int tap = f / KT32, kt = f % KT32;
+        return lds128(sm, rb[tap / 3] + (tap % 3) * 16 + kt * 4 * SG::IN_PLANE);
       };
-      constexpr int NTOT = NU * NF;
       u32x4 buf[NBUF];
 #pragma unroll
       for (int t = 0; t < NBUF; ++t) buf[t] = rd(t);
-      // Software pipeline inside the wave: a wave issues in order, so the SiLU / pack / store epilogue of unit u - 1 is written BEFORE the
-      // MFMA chain of unit u and the scheduler is told (sched_group_barrier) to deal it out between that chain's MFMAs - the matrix pipe
-      // works on unit u while the vector unit finishes unit u - 1.  (Measured before: a 3x3 wave alone on its SIMD took 3.9 k cycles per
-      // step for 1.7 k cycles of MFMA work - chain, then epilogue, strictly one after the other.)
-      f32x4 acc[2][NTW];
-      // the epilogue of one unit in 5 NTW slices: slice k < 4 NTW = SiLU of one accumulator value, the last NTW = pack + mask + store of an n-tile
-      // (an unconditional store - lanes outside the band write a scratch slot - keeps the step one basic block)
-      float sv[NTW][4];
-      unsigned e_m = 0u;
-      int e_oa = 0;
-      bool e_ok = false;
-      auto epi_slice = [&](int u, int k) __attribute__((always_inline)) {
-        if (k == 0) {
-          const int row = r0 + u_rr[u];
-          const int gy = py0 - 2 + row;
-          e_m = (STG || (gy >= 0 && gy < p.H)) ? u_colm[u] : 0u;  // t1 is ZERO outside the image (stage B's padding)
-          e_ok = u_act[u] && row >= SG::LO && row < LP - SG::LO;
-          e_oa = u_in[u] + out_d + (row & SG::OUT_MASK) * TROWB;
-        }
-        if (k < 4 * NTW) {
-          sv[k >> 2][k & 3] = silu(acc[u & 1][k >> 2][k & 3]);
-        } else if (k < 5 * NTW) {
-          const int j = k - 4 * NTW;
-          const u32x2 o = u32x2{pack_bf16x2(sv[j][0], sv[j][1]) & e_m, pack_bf16x2(sv[j][2], sv[j][3]) & e_m};
-          *reinterpret_cast<u32x2*>(sm + (e_ok ? e_oa + 2 * j * SG::OUT_PLANE : G::DUMMY + lane * 8)) = o;
-        }
-      };
-      static_assert(5 * NTW <= NF, "the epilogue slices of a unit fit under the next unit's fragments");
+      u32x2 b16[SG::K16 ? 9 : 1];
+      if constexpr (SG::K16 != 0) {
 #pragma unroll
-      for (int u = 0; u < NU; ++u) {
-#pragma unroll
-        for (int j = 0; j < NTW; ++j) acc[u & 1][j] = bias[j];
-        u32x2 b16[3];  // the 16-wide operands, one tap row at a time (the first row's arrive under the 32-wide chain)
-        if constexpr (SG::K16 != 0) {
-#pragma unroll
-          for (int dx = 0; dx < 3; ++dx) b16[dx] = lds64(sm, rb[u][0] + dx * 16 + in16);
-        }
-#pragma unroll
-        for (int f = 0; f < NF; ++f) {
-          const int t = u * NF + f;
-          const u32x4 b = buf[t % NBUF];
-#pragma unroll
-          for (int j = 0; j < NTW; ++j) acc[u & 1][j] = mfma32(w32[f / KT32][f % KT32][j], b, acc[u & 1][j]);
-          if (t + NBUF < NTOT) buf[t % NBUF] = rd(t + NBUF);
-          // a wave issues in order: the previous unit's epilogue is dealt out between this unit's MFMAs, pinned, so that the matrix pipe works
-          // on unit u while the vector unit finishes unit u - 1 (before: chain, then epilogue - 3.9 k cycles per step for 1.7 k of MFMA work)
-          if (u > 0) epi_slice(u - 1, f);
-          __builtin_amdgcn_sched_barrier(0);  // (unit 0 as well: left alone, the scheduler sinks the ring reads down to their MFMAs)
-        }
-        if constexpr (SG::K16 != 0) {
-          shape_fence();
-#pragma unroll
-          for (int dy = 0; dy < 3; ++dy) {
-            u32x2 nx[3];
-            if (dy < 2) {
-#pragma unroll
-              for (int dx = 0; dx < 3; ++dx) nx[dx] = lds64(sm, rb[u][dy + 1] + dx * 16 + in16);
-            }
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-              for (int j = 0; j < NTW; ++j) acc[u & 1][j] = mfma16(w16[dy * 3 + dx][j], b16[dx], acc[u & 1][j]);
-            if (dy < 2) {
-#pragma unroll
-              for (int dx = 0; dx < 3; ++dx) b16[dx] = nx[dx];
-            }
-          }
-        }
+        for (int tap = 0; tap < 9; ++tap) b16[tap] = lds64(sm, rb[tap / 3] + (tap % 3) * 16 + in16);
       }
+      f32x4 acc = bias;
 #pragma unroll
-      for (int k = 0; k < 5 * NTW; ++k) epi_slice(NU - 1, k);
+      for (int f = 0; f < NF; ++f) {
+        acc = mfma32(w32[f / KT32][f % KT32], buf[f % NBUF], acc);
+        if (f + NBUF < NF) buf[f % NBUF] = rd(f + NBUF);
+      }
+      if constexpr (SG::K16 != 0) {
+        shape_fence();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) acc = mfma16(w16[tap], b16[tap], acc);
+      }
+      const int gy = x.py0 - 2 + row;
+      const unsigned m = (STG || (gy >= 0 && gy < x.p->H)) ? u_colm[q] : 0u;
+      const bool ok = u_act[q] && row >= SG::LO && row < x.LP - SG::LO;
+      const int oa = u_in[q] + out_d + (row & SG::OUT_MASK) * TROWB;
+      const u32x2 o = u32x2{pack_bf16x2(silu(acc[0]), silu(acc[1])) & m, pack_bf16x2(silu(acc[2]), silu(acc[3])) & m};
+      *reinterpret_cast<u32x2*>(sm + (ok ? oa : G::DUMMY + x.lane * 8)) = o;
     }
-    DS_STAMP(DS_SLOT(p), s, 1);
-    __syncthreads();
   }
+};
+
+// keys-only class decode of one 16-pixel tile, lean: top-2 of the lane's logits by v_max_f32 + v_med3_f32 (the median of {largest, second, x} is
+// the new second largest), the certainty test of upa_detect_cls_keys_only, then the index of the largest by a descending compare-select scan.
+// Same results as upa_detect_cls_keys_only (csrc/detect_epi.h); here the tail waves are vector-issue bound, so the instruction count matters.
+template <int NTC>
+__device__ __forceinline__ void cls_keys_lean(const DetectEpi& d, const f32x4 (&logit)[NTC], bool ok, int kg, float& best, int& bc) {
+  constexpr float LOG2E = 1.44269504088896340736f;
+  // (classes >= nc - the zero filters the 1x1 weights are padded with - arrive as -inf: the tail's bias holds -inf there, see Tail::init)
+  const f32x4 (&v)[NTC] = logit;
+  float m1 = v[0][0], m2 = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < NTC; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (j == 0 && q == 0) continue;
+      m2 = __builtin_amdgcn_fmed3f(m1, m2, v[j][q]);
+      m1 = fmaxf(m1, v[j][q]);
+    }
+  const float pm = upa_row_max4(m1);
+  const bool mine = m1 == pm;
+  const float ps = upa_row_max4(mine ? m2 : m1);
+  const bool sure = !ok || (pm <= 4.0f && pm - ps >= 1e-4f && upa_row_sum4(mine ? 1.f : 0.f) == 1.f);
+  if (__all(sure)) {
+    int c1 = 0;
+#pragma unroll
+    for (int j = NTC - 1; j >= 0; --j)
+#pragma unroll
+      for (int q = 3; q >= 0; --q) c1 = v[j][q] == m1 ? 16 * j + q : c1;
+    best = ok && mine ? __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(m1 * -LOG2E)) : -1.f;
+    bc = c1 + 4 * kg;
+    return;
+  }
+  upa_detect_cls_keys_only<NTC>(d, logit, ok, kg, best, bc);
 }
 
-// ---- the tail: 1x1 conv from the t2 ring (rows {2s - 6, 2s - 5} at step s) + the branch's half of the decode, all three units of the output band
-// (this wave: units [U0, U0 + NU) of the band's three - the decode is vector work, so a branch deals its units to waves on different SIMDs)
+// ---- the tail: 1x1 conv from the t2 ring (rows {2s - 6, 2s - 5} at step s) + the branch's half of the decode on units [U0, U0 + NU) of the
+// band's four 16-pixel units (unit U = row U >> 1, columns 16 (U & 1) + r); the decode is vector work, so a branch deals its units to waves on
+// different SIMDs
 template <int C, int KIND, int U0, int NU>
-__device__ __forceinline__ void tail_role(const DsParams& p, const DsBranch& br, char* sm, int lane, int S, int n, int py0, int sx0, int LP) {
+struct Tail {
   using G = Geo<C>;
-  constexpr int NTT = KIND == 1 ? 4 : 5;    // output n-tiles: 4 sides x 16 bins | up to 80 classes
-  static_assert(U0 + NU <= (2 * WS + 15) / 16, "unit range");
-  const int g = lane >> 4, r = lane & 15;
+  static constexpr int NTT = KIND == 1 ? 4 : 5;    // output n-tiles: 4 sides x 16 bins | up to 80 classes
   u32x4 w32[G::KT32][NTT];
-  u32x2 w16[NTT];
-#pragma unroll
-  for (int j = 0; j < NTT; ++j) {
-#pragma unroll
-    for (int kt = 0; kt < G::KT32; ++kt) w32[kt][j] = *reinterpret_cast<const u32x4*>(br.wt + ((size_t)(kt * NTT + j) * 64 + lane) * 16);
-    if constexpr (G::K16 != 0)
-      w16[j] = *reinterpret_cast<const u32x2*>(br.wt + ((size_t)(G::KT32 * NTT + j) * 64 + (g >> 1) * 16 + r) * 16 + (g & 1) * 8);
-  }
+  u32x2 w16[G::K16 ? NTT : 1];
   f32x4 bias[NTT];
-#pragma unroll
-  for (int j = 0; j < NTT; ++j) bias[j] = *reinterpret_cast<const f32x4*>(br.bt + j * 16 + 4 * g);
-  int u_rr[NU], u_in[NU], u_gx[NU];
+  int u_in[NU], u_gx[NU], in16, g, r;
   bool u_act[NU];
+  __device__ __forceinline__ void init(const Ctx& x, const DsBranch& br) {
+    const int lane = x.lane;
+    g = lane >> 4; r = lane & 15;
 #pragma unroll
-  for (int u = 0; u < NU; ++u) {
-    const int q = (U0 + u) * 16 + r;
-    u_act[u] = q < 2 * WS;
-    const int qq = u_act[u] ? q : 0;
-    u_rr[u] = qq >= WS ? 1 : 0;
-    const int cc = qq - u_rr[u] * WS;
-    u_in[u] = G::T2B + g * T2PLANE + cc * 16;
-    u_gx[u] = sx0 + cc;
-    u_act[u] = u_act[u] && u_gx[u] < p.W;
-  }
-  const int in16 = (8 + (g >> 1) - g) * T2PLANE + (g & 1) * 8;
-
-  for (int s = 0; s < S; ++s) {
-    DS_STAMP(DS_SLOT(p), s, 0);
-    const int r0 = 2 * s - 6;
-    if (r0 + 2 > 2 && r0 < LP - 2) {  // wave-uniform
-      u32x4 b32[NU][G::KT32];
-      u32x2 b16[NU];
+    for (int j = 0; j < NTT; ++j) {
 #pragma unroll
-      for (int u = 0; u < NU; ++u) {
-        const int a = u_in[u] + ((r0 + u_rr[u]) & (T2ROWS - 1)) * TROWB;
+      for (int kt = 0; kt < G::KT32; ++kt) w32[kt][j] = *reinterpret_cast<const u32x4*>(br.wt + ((size_t)(kt * NTT + j) * 64 + lane) * 16);
+      if constexpr (G::K16 != 0)
+        w16[j] = *reinterpret_cast<const u32x2*>(br.wt + ((size_t)(G::KT32 * NTT + j) * 64 + (g >> 1) * 16 + r) * 16 + (g & 1) * 8);
+      bias[j] = *reinterpret_cast<const f32x4*>(br.bt + j * 16 + 4 * g);
+      if constexpr (KIND == 2) {  // a class beyond nc (zero filters) must never be the best one: its logit is -inf from the start
 #pragma unroll
-        for (int kt = 0; kt < G::KT32; ++kt) b32[u][kt] = lds128(sm, a + kt * 4 * T2PLANE);
-        if constexpr (G::K16 != 0) b16[u] = lds64(sm, a + in16);
-      }
-#pragma unroll
-      for (int u = 0; u < NU; ++u) {
-        f32x4 v[NTT];
-#pragma unroll
-        for (int j = 0; j < NTT; ++j) v[j] = bias[j];
-#pragma unroll
-        for (int kt = 0; kt < G::KT32; ++kt)
-#pragma unroll
-          for (int j = 0; j < NTT; ++j) v[j] = mfma32(w32[kt][j], b32[u][kt], v[j]);
-        if constexpr (G::K16 != 0) {
-          shape_fence();
-#pragma unroll
-          for (int j = 0; j < NTT; ++j) v[j] = mfma16(w16[j], b16[u], v[j]);
-        }
-        const int row = r0 + u_rr[u];
-        const int gy = py0 - 2 + row;
-        const bool ok = u_act[u] && row >= 2 && row < LP - 2 && gy < p.H;
-        const int al = ok ? gy * p.W + u_gx[u] : 0;  // level-local anchor
-        if constexpr (KIND == 1) {
-          upa_detect_box_store(p.de, v, n, al, ok, g);
-        } else {
-          float best = -1.f;
-          int bc = 0;
-          if (p.de.keys_only) {  // uniform
-            upa_detect_cls_keys_only<NTT>(p.de, v, ok, g, best, bc);
-          } else {
-#pragma unroll
-            for (int j = 0; j < NTT; ++j) upa_detect_cls_store(p.de, v[j], j, n, al, ok, g, best, bc);
-          }
-          if (p.de.best_keys) upa_detect_best_key_store(p.de, best, bc, n, al, ok, lane);  // uniform
-        }
+        for (int q = 0; q < 4; ++q)
+          if (16 * j + 4 * g + q >= x.p->de.nc) bias[j][q] = -INFINITY;
       }
     }
-    DS_STAMP(DS_SLOT(p), s, 1);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int cc = 16 * ((U0 + u) & 1) + r;
+      u_in[u] = G::T2B + g * T2PLANE + cc * 16;
+      u_gx[u] = x.sx0 + cc;
+      u_act[u] = cc < WS && u_gx[u] < x.p->W;
+    }
+    in16 = (8 + (g >> 1) - g) * T2PLANE + (g & 1) * 8;
+  }
+  __device__ __forceinline__ void step(const Ctx& x, int s) {
+#if defined(DS_EXP) && DS_EXP == 1  // timing experiment (wrong results): no tail work
+    return;
+#endif
+    const int r0 = 2 * s - 6;
+    if (!(r0 + 2 > 2 && r0 < x.LP - 2)) return;  // wave-uniform
+    const DsParams& p = *x.p;
+    const char* sm = x.sm;
+    u32x4 b32[NU][G::KT32];
+    u32x2 b16[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int a = u_in[u] + ((r0 + ((U0 + u) >> 1)) & (T2ROWS - 1)) * TROWB;
+#pragma unroll
+      for (int kt = 0; kt < G::KT32; ++kt) b32[u][kt] = lds128(sm, a + kt * 4 * T2PLANE);
+      if constexpr (G::K16 != 0) b16[u] = lds64(sm, a + in16);
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      if (s == 10 && u == 0) DS_STAMP(x.slot, 44, 0);
+      f32x4 v[NTT];
+#pragma unroll
+      for (int j = 0; j < NTT; ++j) v[j] = bias[j];
+#pragma unroll
+      for (int kt = 0; kt < G::KT32; ++kt)
+#pragma unroll
+        for (int j = 0; j < NTT; ++j) v[j] = mfma32(w32[kt][j], b32[u][kt], v[j]);
+      if (s == 10 && u == 0) DS_STAMP(x.slot, 45, 0);
+      if constexpr (G::K16 != 0) {
+        shape_fence();
+#pragma unroll
+        for (int j = 0; j < NTT; ++j) v[j] = mfma16(w16[j], b16[u], v[j]);
+      }
+      const int row = r0 + ((U0 + u) >> 1);
+      const int gy = x.py0 - 2 + row;
+      const bool ok = u_act[u] && row >= 2 && row < x.LP - 2 && gy < p.H;
+      const int al = ok ? gy * p.W + u_gx[u] : 0;  // level-local anchor
+      if constexpr (KIND == 1) {
+        upa_detect_box_store(p.de, v, x.n, al, ok, g);
+        if (s == 10 && u == 0) DS_STAMP(x.slot, 47, 0);
+      } else {
+        float best = -1.f;
+        int bc = 0;
+        if (p.de.keys_only) {  // uniform
+          cls_keys_lean<NTT>(p.de, v, ok, g, best, bc);
+          if (s == 10 && u == 0) DS_STAMP(x.slot, 46, 0);
+        } else {
+#pragma unroll
+          for (int j = 0; j < NTT; ++j) upa_detect_cls_store(p.de, v[j], j, x.n, al, ok, g, best, bc);
+        }
+        if (p.de.best_keys) upa_detect_best_key_store(p.de, best, bc, x.n, al, ok, x.lane);  // uniform
+        if (s == 10 && u == 0) DS_STAMP(x.slot, 47, 0);
+      }
+    }
+  }
+};
+
+// ---- the input band two steps ahead: band b = x rows {2b, 2b + 1} (image rows py0 - 2 + ...), 8 planes x 2 rows = 16 LDS-DMA instructions, lane =
+// column slot (34 of 64 used); out-of-image slots read the zero page (the 3x3's zero padding).  The wave that carries this role also runs a tail
+// unit, so it cannot count its loads apart from its stores: it issues the band at the START of a step and waits for everything at the end - the
+// band then has the whole step (>= 3 k cycles) to land, and a further step before anybody reads it.
+struct Dma {
+  const char* ximg;
+  unsigned rowpitch, coloff;
+  bool colok;
+  __device__ __forceinline__ void init(const Ctx& x) {
+    const DsParams& p = *x.p;
+    rowpitch = (unsigned)p.W * (unsigned)p.ldx * 2u;
+    ximg = p.x + (size_t)x.n * p.H * rowpitch;
+    const int gx = x.sx0 - 2 + x.lane;
+    colok = x.lane < XW && gx >= 0 && gx < p.W;
+    coloff = colok ? (unsigned)gx * (unsigned)p.ldx * 2u : 0u;
+  }
+  __device__ __forceinline__ void band(const Ctx& x, int b) {
+    if (2 * b >= x.LP) return;  // wave-uniform
+    const char* zp = reinterpret_cast<const char*>(g_ds_zero_page);
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int gy = x.py0 - 2 + 2 * b + rr;
+      const bool ok = colok && gy >= 0 && gy < x.p->H;
+      const char* src = ok ? ximg + ((unsigned)gy * rowpitch + coloff) : zp;
+      const int dst = XB + ((2 * b + rr) & (XROWS - 1)) * XROWB;  // + lane * 16 by the hardware
+#pragma unroll
+      for (int cg = 0; cg < 8; ++cg)
+        __builtin_amdgcn_global_load_lds((ds_gptr_t)(src + (ok ? cg * 16 : 0)), (ds_lptr_t)(x.sm + dst + cg * XPLANE), 16, 0, 0);
+    }
+  }
+};
+
+template <typename R>
+__device__ __forceinline__ void run_role(const Ctx& x, R& role) {
+  __syncthreads();  // (the DMA wave arrives here with the first two bands landed)
+  for (int s = 0; s < x.S; ++s) {
+    DS_STAMP(x.slot, s, 0);
+    role.step(x, s);
+    DS_STAMP(x.slot, s, 1);
     __syncthreads();
   }
 }
-
-// ---- the input band two steps ahead: band b = x rows {2b, 2b + 1} (image rows py0 - 2 + ...), 8 planes x (2 rows x 32 slots) = 8 LDS-DMA instructions;
-// lane = slot (row lane >> 5, column lane & 31); out-of-image slots (and the 8 pad slots of a row) read the zero page
-__device__ __forceinline__ void dma_role(const DsParams& p, char* sm, int lane, int S, int n, int py0, int sx0, int LP) {
-  const unsigned rowpitch = (unsigned)p.W * (unsigned)p.ldx * 2u;
-  const char* ximg = p.x + (size_t)n * p.H * rowpitch;
-  const int rr = lane >> 5, xc = lane & 31;
-  const int gx = sx0 - 2 + xc;
-  const bool colok = xc < WS + 4 && gx >= 0 && gx < p.W;
-  const unsigned coloff = colok ? (unsigned)gx * (unsigned)p.ldx * 2u : 0u;
-  const char* zp = reinterpret_cast<const char*>(g_ds_zero_page);
-  auto stage_in = [&](int b) __attribute__((always_inline)) {
-    if (2 * b >= LP) return 0;  // wave-uniform
-    const int gy = py0 - 2 + 2 * b + rr;
-    const bool ok = colok && gy >= 0 && gy < p.H;
-    const char* src = ok ? ximg + ((unsigned)gy * rowpitch + coloff) : zp;
-    const int dst = XB + ((2 * b) & (XROWS - 1)) * XROWB;  // + lane * 16 by the hardware
-#pragma unroll
-    for (int cg = 0; cg < 8; ++cg)
-      __builtin_amdgcn_global_load_lds((ds_gptr_t)(src + (ok ? cg * 16 : 0)), (ds_lptr_t)(sm + dst + cg * XPLANE), 16, 0, 0);
-    return 8;
-  };
-  stage_in(0);
-  stage_in(1);
+template <typename RA, typename RB>
+__device__ __forceinline__ void run_roles2(const Ctx& x, RA& ra, RB& rb) {
+  __syncthreads();
+  for (int s = 0; s < x.S; ++s) {
+    DS_STAMP(x.slot, s, 0);
+    ra.step(x, s);
+    rb.step(x, s);
+    DS_STAMP(x.slot, s, 1);
+    __syncthreads();
+  }
+}
+template <typename T>
+__device__ __forceinline__ void run_tail_dma(const Ctx& x, T& tail, Dma& dma) {
+  dma.band(x, 0);
+  dma.band(x, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  for (int s = 0; s < S; ++s) {
-    DS_STAMP(DS_SLOT(p), s, 0);
-    const int inflight = stage_in(s + 2);
-    // band s + 1 has landed once everything but this step's requests is back (a DMA wave issues no other vector-memory operation)
-    if (inflight) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    DS_STAMP(DS_SLOT(p), s, 1);
+  for (int s = 0; s < x.S; ++s) {
+    DS_STAMP(x.slot, s, 0);
+    dma.band(x, s + 2);
+    tail.step(x, s);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DS_STAMP(x.slot, s, 1);
     __syncthreads();
   }
-}
-
-__device__ __forceinline__ void idle_role(int S) {
-  for (int s = 0; s < S; ++s) __syncthreads();
 }
 }  // namespace dstream
 
 __global__ __launch_bounds__(512) void detect_stream_kernel(const DsParams p) {
   using namespace dstream;
   extern __shared__ __attribute__((aligned(16))) char sm[];
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bid = (int)blockIdx.x;
   const bool cls = bid < p.ncls_wg;
   if (!cls) bid -= p.ncls_wg;
-  const int n = bid / (p.parts * p.strips);
-  bid -= n * (p.parts * p.strips);
+  Ctx x;
+  x.p = &p; x.sm = sm; x.lane = tid & 63; x.slot = DS_SLOT(p);
+  x.n = bid / (p.parts * p.strips);
+  bid -= x.n * (p.parts * p.strips);
   const int part = bid / p.strips, strip = bid - part * p.strips;
-  const int py0 = part * p.L, sx0 = strip * WS;
-  int leff = p.H - py0 < p.L ? p.H - py0 : p.L;
+  x.py0 = part * p.L; x.sx0 = strip * WS;
+  int leff = p.H - x.py0 < p.L ? p.H - x.py0 : p.L;
   leff = (leff + 1) & ~1;
-  const int LP = leff + 4;          // x rows of this part
-  const int S = leff / 2 + 4;       // steps until the last output row has left
+  x.LP = leff + 4;          // x rows of this part
+  x.S = leff / 2 + 4;       // steps until the last output row has left
 
-  if (wave != 5) __syncthreads();   // (the DMA wave arrives at this barrier with the first two bands landed)
-  // waves w and w + 4 share a SIMD.  MFMAs (32-wide equivalents) per step:
-  //   class:  SIMD 0  B(0-1) 135 + tail 38    SIMD 1  B(2-3) 135 + DMA    SIMD 2  A(0-1) 108 + A(4) 54    SIMD 3  A(2-3) 108 + B(4) 68
-  //   box:    SIMD 0  A(0-1) 108 + tail unit 0    SIMD 1  A(2-3) 108 + DMA    SIMD 2  B(0-1) 108 + tail unit 1    SIMD 3  B(2-3) 108 + tail unit 2
+  // waves w and w + 4 share a SIMD.  Issue cycles per step (MFMA x 8 + vector x ~5 + LDS), estimated:
+  //   box:    SIMD 0  A32(0) 1.9 k + tail unit 0 1.4 k    SIMD 1  A32(1) + tail unit 1    SIMD 2  B32(0) + tail unit 2    SIMD 3  B32(1) + tail unit 3 + DMA
+  //   class:  SIMD 0  B32(0) 2.2 k + A16 1.4 k            SIMD 1  B32(1) + tail units 0-1 1.8 k    SIMD 2  A32(0) 1.9 k + B16 1.9 k    SIMD 3  A32(1) + tail units 2-3 + DMA
   if (cls) {
     const DsBranch& br = p.br[1];
     switch (wave) {
-      case 0: conv_role<80, 1, 2>(p, br, sm, 0, lane, S, py0, sx0, LP); break;
-      case 1: conv_role<80, 1, 2>(p, br, sm, 2, lane, S, py0, sx0, LP); break;
-      case 2: conv_role<80, 0, 2>(p, br, sm, 0, lane, S, py0, sx0, LP); break;
-      case 3: conv_role<80, 0, 2>(p, br, sm, 2, lane, S, py0, sx0, LP); break;
-      case 4: tail_role<80, 2, 0, 3>(p, br, sm, lane, S, n, py0, sx0, LP); break;
-      case 5: dma_role(p, sm, lane, S, n, py0, sx0, LP); break;
-      case 6: conv_role<80, 0, 1>(p, br, sm, 4, lane, S, py0, sx0, LP); break;
-      default: conv_role<80, 1, 1>(p, br, sm, 4, lane, S, py0, sx0, LP); break;
+      case 0: { Conv32<80, 1, false> r; r.init(x, br, 0); run_role(x, r); break; }  // (80 input channels: 180 weight registers leave no room for a second accumulator set)
+      case 1: { Conv32<80, 1, false> r; r.init(x, br, 1); run_role(x, r); break; }
+      case 2: { Conv32<80, 0, true> r; r.init(x, br, 0); run_role(x, r); break; }
+      case 3: { Conv32<80, 0, true> r; r.init(x, br, 1); run_role(x, r); break; }
+      case 4: { Conv16<80, 0> r; r.init(x, br, 4); run_role(x, r); break; }
+      case 5: { Tail<80, 2, 0, 2> r; r.init(x, br); run_role(x, r); break; }
+      case 6: { Conv16<80, 1> r; r.init(x, br, 4); run_role(x, r); break; }
+      default: { Tail<80, 2, 2, 2> r; Dma d; r.init(x, br); d.init(x); run_tail_dma(x, r, d); break; }
     }
   } else {
     const DsBranch& br = p.br[0];
     switch (wave) {
-      case 0: conv_role<64, 0, 2>(p, br, sm, 0, lane, S, py0, sx0, LP); break;
-      case 1: conv_role<64, 0, 2>(p, br, sm, 2, lane, S, py0, sx0, LP); break;
-      case 2: conv_role<64, 1, 2>(p, br, sm, 0, lane, S, py0, sx0, LP); break;
-      case 3: conv_role<64, 1, 2>(p, br, sm, 2, lane, S, py0, sx0, LP); break;
-      case 4: tail_role<64, 1, 0, 1>(p, br, sm, lane, S, n, py0, sx0, LP); break;
-      case 5: dma_role(p, sm, lane, S, n, py0, sx0, LP); break;
-      case 6: tail_role<64, 1, 1, 1>(p, br, sm, lane, S, n, py0, sx0, LP); break;
-      default: tail_role<64, 1, 2, 1>(p, br, sm, lane, S, n, py0, sx0, LP); break;
+      case 0: { Conv32<64, 0, true> r; r.init(x, br, 0); run_role(x, r); break; }
+      case 1: { Conv32<64, 0, true> r; r.init(x, br, 1); run_role(x, r); break; }
+      case 2: { Conv32<64, 1, true> r; r.init(x, br, 0); run_role(x, r); break; }
+      case 3: { Conv32<64, 1, true> r; r.init(x, br, 1); run_role(x, r); break; }
+      case 4: { Tail<64, 1, 0, 1> r; r.init(x, br); run_role(x, r); break; }
+      case 5: { Tail<64, 1, 1, 1> r; r.init(x, br); run_role(x, r); break; }
+      case 6: { Tail<64, 1, 2, 1> r; r.init(x, br); run_role(x, r); break; }
+      default: { Tail<64, 1, 3, 1> r; Dma d; r.init(x, br); d.init(x); run_tail_dma(x, r, d); break; }
     }
   }
 }

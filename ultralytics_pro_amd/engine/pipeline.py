@@ -46,8 +46,11 @@ class PipelinedRunner:
         #   * the line-buffer C2f kernel (csrc/c2f_stream.hip) pays 11 steps of pipeline fill per workgroup: whole-height strips (128 workgroups
         #     for the 80 x 80 maps at batch 32: half the CUs, the other steps' kernels take the rest) hold 15 % less CU time than the two
         #     parts per strip that fill the chip with one round: 56.0 k vs 55.4 k img/s in flight (same box), 90 vs 53 us one step at a time.
-        # So: in flight > 1 -> upa_opts.c2f = 4, conv_ws3 = 1 and c2f_stream_rows = -1 for the compiled copies, unless the caller's options
-        # already set them.
+        #   * the line-buffer form of the 80 x 80 Detect level (csrc/detect_stream.hip) is SLOWER launch for launch (one step at a time 0.878 vs
+        #     0.799 ms: 192 long-lived workgroups, two waves per SIMD) but holds a quarter less CU time than the tile form's two chip-filling
+        #     launches and moves 130 MB less: 59.4 k vs 58.1 k images/s in flight, same box (round 6).
+        # So: in flight > 1 -> upa_opts.c2f = 4, conv_ws3 = 1, c2f_stream_rows = -1 and detect_stream = 2 for the compiled copies, unless the
+        # caller's options already set them.
         from . import runtime as R
         cur = R.current_opts()
         mode = {}
@@ -58,6 +61,8 @@ class PipelinedRunner:
                 mode["conv_ws3"] = 1
             if cur is None or cur.c2f_stream_rows == 0:
                 mode["c2f_stream_rows"] = -1
+            if cur is None or cur.detect_stream == 0:
+                mode["detect_stream"] = 2
         self.throughput_opts = dict(mode)
         try:
             with torch.no_grad(), (R.use_opts(**mode) if mode else contextlib.nullcontext()):

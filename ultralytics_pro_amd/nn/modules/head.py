@@ -163,9 +163,9 @@ class Detect(nn.Module, _HipConvMixin):
     # ---- one level, both branches, all six convolutions + the decode in ONE line-buffer launch (csrc/detect_stream.hip) ----------------
     # yolov8n's 80 x 80 level (64 input channels; 64-channel box branch, 80-channel class branch): the stacked first conv + the grouped
     # branch tails write and re-read a 144-channel intermediate and reload every weight slab per tile; the streaming form keeps t1 / t2 as
-    # a few rows in LDS and the weights in registers.  MEASURED SLOWER than the tile form on MI355X (round 6: 53.9 k vs 57.9 k images/s in flight,
-    # 0.857 vs 0.809 ms one step at a time - the wave roles are vector-issue bound, profiles/r06_detect_stream.txt), so it only runs on request:
-    # `upa_opts.detect_stream = 2` (A/B, tests).
+    # a few rows in LDS and the weights in registers.  Slower launch for launch (0.878 vs 0.799 ms one step at a time: two waves per SIMD, every
+    # role bound by its own in-order issue, profiles/r06_detect_stream.txt) but 192 workgroups that hold a quarter less CU time: +2.4 % with four
+    # steps in flight.  So it runs on request: `upa_opts.detect_stream = 2`, which `engine/pipeline.py` sets for copies in flight.
     level_stream = True
 
     def _level_stream(self, i: int, x: torch.Tensor, plan) -> bool:
