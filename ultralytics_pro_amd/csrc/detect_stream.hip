@@ -232,7 +232,11 @@ struct Conv32 {
         const int t = u * NF + f;
         a = mfma3232(w[f / KS][f % KS], buf[t % NBUF], a);
         if (t + NBUF < NTOT) buf[t % NBUF] = rd(t + NBUF);
-        if (PIPE && u > 0 && f < 16) epi_slice(u - 1, f);
+        if (PIPE && u > 0) {  // row 0's sixteen epilogue slices, spread evenly over row 1's MFMAs (a slice is ~28 issue cycles, an MFMA 32 of pipe)
+#pragma unroll
+          for (int k = 0; k < 16; ++k)
+            if ((k * NF) / 16 == f) epi_slice(u - 1, k);
+        }
         __builtin_amdgcn_sched_barrier(0);  // pinned: a wave issues in order, and left alone the scheduler sinks the ring reads to their MFMAs
       }
       if (!PIPE || u == 1) {
@@ -249,13 +253,13 @@ template <int C, int STG>
 struct Conv16 {
   using G = Geo<C>;
   using SG = StageGeo<C, STG>;
-  static constexpr int KT32 = SG::KT32, NF = 9 * KT32, NU = 4, NBUF = 4;
+  static constexpr int KT32 = SG::KT32, NF = 9 * KT32, NBUF = 3;
   u32x4 w32[9][KT32];
   u32x2 w16[SG::K16 ? 9 : 1];
   f32x4 bias;
-  int u_in[2], in16, out_d, g, r;
-  unsigned u_colm[2];
-  bool u_act[2];
+  int in0, in16, out_d, g, r;
+  unsigned colm[2];
+  bool act[2];
   __device__ __forceinline__ void init(const Ctx& x, const DsBranch& br, int nt) {
     const int lane = x.lane;
     g = lane >> 4; r = lane & 15;
@@ -269,57 +273,102 @@ struct Conv16 {
         w16[tap] = *reinterpret_cast<const u32x2*>(wp + ((size_t)((tap * SG::KTP + KT32) * G::NT + nt) * 64 + (g >> 1) * 16 + r) * 16 + (g & 1) * 8);
     }
     bias = *reinterpret_cast<const f32x4*>(bp + nt * 16 + 4 * g);
+    in0 = SG::IN_B + g * SG::IN_PLANE + r * 16;   // unit q of a row: columns 16 q + r = + 256 q bytes
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {  // the two units of a row: columns 16 q + r
+    for (int q = 0; q < 2; ++q) {
       const int cc = 16 * q + r;
-      u_act[q] = cc < SG::SD;
-      u_in[q] = SG::IN_B + g * SG::IN_PLANE + cc * 16;
+      act[q] = cc < SG::SD;
       const int gx = x.sx0 - 1 + cc;
-      u_colm[q] = (STG || (gx >= 0 && gx < x.p->W)) ? 0xFFFFFFFFu : 0u;
+      colm[q] = (STG || (gx >= 0 && gx < x.p->W)) ? 0xFFFFFFFFu : 0u;
     }
-    in16 = (8 + (g >> 1) - g) * SG::IN_PLANE + (g & 1) * 8;   // 16-wide operand: plane 8 + (g >> 1), half (g & 1), relative to u_in
+    in16 = (8 + (g >> 1) - g) * SG::IN_PLANE + (g & 1) * 8;   // 16-wide operand: plane 8 + (g >> 1), half (g & 1), relative to in0
     out_d = SG::OUT_B - SG::IN_B + (2 * nt + (g >> 1)) * SG::OUT_PLANE - g * SG::IN_PLANE + (g & 1) * 8;
   }
+  // A band row = two 16-pixel units; both run as ONE pair with two independent accumulator chains (a single chain of dependent 16x16x32
+  // MFMAs issues at half the matrix rate), the ring reads of both prefetched NBUF fragments ahead, and the SiLU / pack / store epilogue of
+  // row 0 dealt out between the MFMAs of row 1 (pinned), as in Conv32.
   __device__ __forceinline__ void step(const Ctx& x, int s) {
     const int r0 = 2 * s - SG::LAG;
     if (!(r0 + 2 > SG::LO && r0 < x.LP - SG::LO)) return;  // wave-uniform
     char* sm = x.sm;
+    int rb[2][3];
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      const int row = r0 + (u >> 1), q = u & 1;
-      int rb[3];
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy) rb[dy] = u_in[q] + ((row + dy - 1) & SG::IN_MASK) * SG::IN_ROWB;
-      auto rd = [&](int f) __attribute__((always_inline)) {
-        const int tap = f / KT32, kt = f % KT32;
-        return lds128(sm, rb[tap / 3] + (tap % 3) * 16 + kt * 4 * SG::IN_PLANE);
-      };
-      u32x4 buf[NBUF];
+      for (int dy = 0; dy < 3; ++dy) rb[u][dy] = in0 + ((r0 + u + dy - 1) & SG::IN_MASK) * SG::IN_ROWB;
+    auto rd = [&](int t, int q) __attribute__((always_inline)) {
+      const int u = t / NF, f = t % NF, tap = f / KT32, kt = f % KT32;
+      return lds128(sm, rb[u][tap / 3] + (tap % 3) * 16 + kt * 4 * SG::IN_PLANE + 256 * q);
+    };
+    constexpr int NTOT = 2 * NF;
+    u32x4 buf[NBUF][2];
 #pragma unroll
-      for (int t = 0; t < NBUF; ++t) buf[t] = rd(t);
-      u32x2 b16[SG::K16 ? 9 : 1];
+    for (int t = 0; t < NBUF; ++t) { buf[t][0] = rd(t, 0); buf[t][1] = rd(t, 1); }
+    f32x4 acc[2][2];  // [row][unit]
+    float sv[4];
+    unsigned e_m = 0u;
+    int e_oa = 0;
+    bool e_row = false;
+    auto epi_slice = [&](int u, int k) __attribute__((always_inline)) {  // k < 8: SiLU of value k & 3 of unit k >> 2; every fourth also packs + stores
+      if (k == 0) {
+        const int row = r0 + u;
+        const int gy = x.py0 - 2 + row;
+        e_m = (STG || (gy >= 0 && gy < x.p->H)) ? 0xFFFFFFFFu : 0u;  // t1 is ZERO outside the image (stage B's padding)
+        e_row = row >= SG::LO && row < x.LP - SG::LO;
+        e_oa = in0 + out_d + (row & SG::OUT_MASK) * TROWB;
+      }
+      const int q = k >> 2;
+      sv[k & 3] = silu(acc[u][q][k & 3]);
+      if ((k & 3) == 3) {
+        const unsigned m = e_m & colm[q];
+        const u32x2 o = u32x2{pack_bf16x2(sv[0], sv[1]) & m, pack_bf16x2(sv[2], sv[3]) & m};
+        *reinterpret_cast<u32x2*>(sm + ((e_row && act[q]) ? e_oa + 256 * q : G::DUMMY + x.lane * 8)) = o;
+      }
+    };
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      acc[u][0] = bias; acc[u][1] = bias;
+      u32x2 b16[2][3];  // the 16-wide operands of both units, one tap row at a time
       if constexpr (SG::K16 != 0) {
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) b16[tap] = lds64(sm, rb[tap / 3] + (tap % 3) * 16 + in16);
+        for (int dx = 0; dx < 3; ++dx) { b16[0][dx] = lds64(sm, rb[u][0] + dx * 16 + in16); b16[1][dx] = lds64(sm, rb[u][0] + dx * 16 + in16 + 256); }
       }
-      f32x4 acc = bias;
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
-        acc = mfma32(w32[f / KT32][f % KT32], buf[f % NBUF], acc);
-        if (f + NBUF < NF) buf[f % NBUF] = rd(f + NBUF);
+        const int t = u * NF + f;
+        acc[u][0] = mfma32(w32[f / KT32][f % KT32], buf[t % NBUF][0], acc[u][0]);
+        acc[u][1] = mfma32(w32[f / KT32][f % KT32], buf[t % NBUF][1], acc[u][1]);
+        if (t + NBUF < NTOT) { buf[t % NBUF][0] = rd(t + NBUF, 0); buf[t % NBUF][1] = rd(t + NBUF, 1); }
+        if (u > 0) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            if ((k * NF) / 8 == f) epi_slice(u - 1, k);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (SG::K16 != 0) {
         shape_fence();
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) acc = mfma16(w16[tap], b16[tap], acc);
+        for (int dy = 0; dy < 3; ++dy) {
+          u32x2 nx[2][3];
+          if (dy < 2) {
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) { nx[0][dx] = lds64(sm, rb[u][dy + 1] + dx * 16 + in16); nx[1][dx] = lds64(sm, rb[u][dy + 1] + dx * 16 + in16 + 256); }
+          }
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            acc[u][0] = mfma16(w16[dy * 3 + dx], b16[0][dx], acc[u][0]);
+            acc[u][1] = mfma16(w16[dy * 3 + dx], b16[1][dx], acc[u][1]);
+          }
+          if (dy < 2) {
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) { b16[0][dx] = nx[0][dx]; b16[1][dx] = nx[1][dx]; }
+          }
+        }
       }
-      const int gy = x.py0 - 2 + row;
-      const unsigned m = (STG || (gy >= 0 && gy < x.p->H)) ? u_colm[q] : 0u;
-      const bool ok = u_act[q] && row >= SG::LO && row < x.LP - SG::LO;
-      const int oa = u_in[q] + out_d + (row & SG::OUT_MASK) * TROWB;
-      const u32x2 o = u32x2{pack_bf16x2(silu(acc[0]), silu(acc[1])) & m, pack_bf16x2(silu(acc[2]), silu(acc[3])) & m};
-      *reinterpret_cast<u32x2*>(sm + (ok ? oa : G::DUMMY + x.lane * 8)) = o;
     }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) epi_slice(1, k);
   }
 };
 
@@ -331,15 +380,20 @@ __device__ __forceinline__ void cls_keys_lean(const DetectEpi& d, const f32x4 (&
   constexpr float LOG2E = 1.44269504088896340736f;
   // (classes >= nc - the zero filters the 1x1 weights are padded with - arrive as -inf: the tail's bias holds -inf there, see Tail::init)
   const f32x4 (&v)[NTC] = logit;
-  float m1 = v[0][0], m2 = -INFINITY;
+  // two independent (largest, second) chains over the even / odd positions - one chain is 2 x 4 NTC dependent instructions deep - merged at the end
+  float a1 = v[0][0], a2 = -INFINITY, b1 = v[0][1], b2 = -INFINITY;
 #pragma unroll
   for (int j = 0; j < NTC; ++j)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 4; q += 2) {
       if (j == 0 && q == 0) continue;
-      m2 = __builtin_amdgcn_fmed3f(m1, m2, v[j][q]);
-      m1 = fmaxf(m1, v[j][q]);
+      a2 = __builtin_amdgcn_fmed3f(a1, a2, v[j][q]);
+      a1 = fmaxf(a1, v[j][q]);
+      b2 = __builtin_amdgcn_fmed3f(b1, b2, v[j][q + 1]);
+      b1 = fmaxf(b1, v[j][q + 1]);
     }
+  const float m1 = fmaxf(a1, b1);
+  const float m2 = fmaxf(fminf(a1, b1), fmaxf(a2, b2));
   const float pm = upa_row_max4(m1);
   const bool mine = m1 == pm;
   const float ps = upa_row_max4(mine ? m2 : m1);
