@@ -494,6 +494,31 @@ struct Tail {
         if (p.de.keys_only) {  // uniform
           cls_keys_lean<NTT>(p.de, v, ok, g, best, bc);
           if (s == 10 && u == 0) DS_STAMP(x.slot, 46, 0);
+        } else if (p.de.nc == 16 * NTT) {  // uniform: every filter is a class (nc = 80) - the score rows in ONE predicated region, no per-class test
+          constexpr float LOG2E = 1.44269504088896340736f;
+          float sg[NTT][4];
+#pragma unroll
+          for (int j = 0; j < NTT; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sg[j][q] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[j][q] * -LOG2E));
+          if (ok) {
+            float* yb = p.de.y + ((size_t)x.n * (4 + p.de.nc) + 4 + 4 * g) * p.de.a_total + p.de.a0 + al;
+#pragma unroll
+            for (int j = 0; j < NTT; ++j)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) yb[(size_t)(16 * j + q) * p.de.a_total] = sg[j][q];
+          }
+          best = ok ? sg[0][0] : -1.f;  // the lane's FIRST maximum (ascending class order: strict >), as upa_detect_cls_store keeps it
+          bc = 4 * g;
+#pragma unroll
+          for (int j = 0; j < NTT; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              if (j == 0 && q == 0) continue;
+              const bool take = ok && sg[j][q] > best;
+              best = take ? sg[j][q] : best;
+              bc = take ? 16 * j + 4 * g + q : bc;
+            }
         } else {
 #pragma unroll
           for (int j = 0; j < NTT; ++j) upa_detect_cls_store(p.de, v[j], j, x.n, al, ok, g, best, bc);
