@@ -292,7 +292,7 @@ int upa_detect_head_tails(const upa_branch_level* box, const upa_branch_level* c
 /* ONE level of a Detect head, both branches and all three convolutions of each, in one launch (bf16; csrc/detect_stream.hip):
  * cv2[i] = Conv(cin, 64, 3) -> Conv(64, 64, 3) -> Conv2d(64, 4 * 16, 1) -> DFL + dist2bbox * stride -> y[b, 0:4, a0 + a],
  * cv3[i] = Conv(cin, 80, 3) -> Conv(80, 80, 3) -> Conv2d(80, nc, 1) -> sigmoid -> y[b, 4:4+nc, a0 + a] (+ best-class NMS keys),
- * the intermediate maps only ever existing as a few rows in LDS (line-buffer form: a workgroup streams down a 20-column strip of one
+ * the intermediate maps only ever existing as a few rows in LDS (line-buffer form: a workgroup streams down a 30-column strip of one
  * image, fixed wave roles, weights in registers).                     head.py:94-100 (cv2 / cv3), :116-126 (forward), :151-191 (_inference)
  * A branch = its channel count c and three upa_pack_conv_weight(UPA_BF16) blobs with BN folded: w1 = 3x3 cin -> c, w2 = 3x3 c -> c,
  * wt = 1x1 c -> 64 (box) | 80 (class, zero filters beyond nc), biases f32 padded to a multiple of 16.

@@ -1824,13 +1824,15 @@ def test_msdeform_attn_bf16_values_match_exact_path():
 
 
 @pytest.mark.parametrize("nc,shape,rows,keys_only", [(80, (2, 13, 21), 0, 0), (80, (3, 40, 40), 0, 0), (80, (2, 40, 40), 12, 0), (20, (1, 9, 16), 0, 0),
-                                                      (80, (2, 23, 47), 8, 1), (80, (4, 80, 80), 0, 0), (80, (4, 80, 80), 40, 1)],
-                         ids=["13x21", "40x40", "40x40_parts12", "nc20_9x16", "23x47_parts8_keys", "80x80", "80x80_parts40_keys"])
+                                                      (80, (2, 23, 47), 8, 1), (80, (4, 80, 80), 0, 0), (80, (4, 80, 80), 40, 1),
+                                                      (80, (1, 6, 61), 0, 1), (80, (2, 5, 30), 4, 0)],
+                         ids=["13x21", "40x40", "40x40_parts12", "nc20_9x16", "23x47_parts8_keys", "80x80", "80x80_parts40_keys",
+                              "6x61_one_column_strip_keys", "5x30_exact_strip_parts4"])
 def test_detect_level_stream_vs_oracle(nc, shape, rows, keys_only):
     """`upa_detect_level_stream` (csrc/detect_stream.hip): one Detect level - conv3x3 -> conv3x3 -> 1x1 -> decode for BOTH branches - as one
     line-buffer launch (head.py:94-100, 116-126, 151-191), against the oracle's arithmetic on the same bf16-rounded input and weights with the
     kernel's rounding points (bf16 after each SiLU, f32 logits, f32 decode): boxes / scores of every anchor, the best-class NMS key of every
-    anchor, nothing written outside the level.  Shapes: widths that are not a multiple of the 20-column strips, odd heights, parts of
+    anchor, nothing written outside the level.  Shapes: widths that are not a multiple of the 30-column strips, odd heights, parts of
     rows (`upa_opts.detect_stream_rows`), fewer classes than the class tail's 80 filters, the keys-only form (class rows not written)."""
     from tests.hip_utils import DEV, bf16_round, to_dev_nhwc, unit_input
     from ultralytics_pro_amd import _lib as L
