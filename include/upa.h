@@ -51,7 +51,7 @@ typedef struct upa_opts {
   int32_t pair_tile64, pair_tile32;  /* its square output tile edge per width (0 = auto) */
   int32_t no_pair_cv2;     /* upa_bottleneck_pair_cv2: 1 = never */
   int32_t c2f;             /* upa_c2f_fused / upa_c2f64_fused / upa_c2f32_up_fused: 0 = every form, 1 = never, 2 = not the 16-wide, 3 = not the 32-wide, 4 = not the 64-wide, 6 = the 64-wide form only for n = 1 blocks (A/B: 52.3 k vs 52.6 k images/s in flight with 4) */
-  int32_t c2f16_waves;     /* 0 = 4 | 8 */
+  int32_t c2f16_waves;     /* C2f(32, 32, n = 1): 0 = the line-buffer form (csrc/c2f16_stream.hip) | 4 | 8 = the 16 x 16 tile form with that many waves per workgroup (A/B) */
   int32_t c2f32_th;        /* output tile rows of the C2f(64, 64, n = 2) form: 0 = 16 | 10 */
   int32_t no_branch_tail;  /* upa_detect_branch_tail: 1 = never */
   int32_t branch_tail_bm;  /* its workgroup pixels: 0 = auto | 128 | 256 */

@@ -592,6 +592,10 @@ int upa_c2f32_stream1_launch(const void* x, int n, int h, int w, int c1, int ldx
                              const void* w1, const float* b1, const void* const* wm, const float* const* bm, const void* w2, const float* b2,
                              void* y, int ldy, const upa_opts* opts, hipStream_t s);
 
+int upa_c2f16_stream_launch(const void* x, int n, int h, int w, int ldx, const void* w1, const float* b1, const void* wa, const float* ba,
+                            const void* wb, const float* bb, const void* w2, const float* b2, void* y, int ldy, const upa_opts* opts,
+                            hipStream_t s);
+
 // x: (n, h, w, c1) NHWC bf16 view; w1 / b1: cv1 (1x1, c1 -> 2c); wm[2i], wm[2i + 1] / bm[..]: Bottleneck i's two 3x3 convs
 // (c -> c); w2 / b2: cv2 (1x1, (2 + nb) c -> c2) - all packed by upa_pack_conv_weight(bf16) with BN folded; y: (n, h, w, c2).
 extern "C" int upa_c2f_fused(const void* x, int n, int h, int w, int c1, int ldx, int c, int nb, int shortcut, const void* w1,
@@ -612,6 +616,13 @@ extern "C" int upa_c2f_fused(const void* x, int n, int h, int w, int c1, int ldx
   long tiles = (long)tx * ty * n;
   UPA_CHECK_ARG(tiles < (1L << 31) / 2, "c2f_fused: too many tiles");
   hipStream_t s = (hipStream_t)stream;
+  if (f16 && UPA_OPT(opts, c2f_stream) != 1 && UPA_OPT(opts, c2f16_waves) == 0) {  // the line-buffer form (csrc/c2f16_stream.hip); c2f_stream = 1 or c2f16_waves = 4 | 8: the 16 x 16 tile form below (A/B)
+    const int rc = upa_c2f16_stream_launch(x, n, h, w, ldx, w1, b1, wm[0], bm[0], wm[1], bm[1], w2, b2, y, ldy, opts, s);
+    if (rc != UPA_EUNSUPPORTED) {
+      if (rc == UPA_OK) UPA_LAUNCH_CHECK();
+      return rc;
+    }
+  }
   if (f16) {
     C2fParams p;
     p.x = (const char*)x; p.y = (char*)y;
