@@ -13,6 +13,7 @@ f2=$(find gpurun_out/c2f16_prof -name "*kernel_trace.csv" | head -1)
 python3 - "$f2" <<'PY'
 import csv,sys,collections
 rows=[r for r in csv.DictReader(open(sys.argv[1])) if 'c2f16_stream' in r['Kernel_Name']]
+for r in rows: r['Grid_Size']=r['Kernel_Name'][:22]+' '+r.get('Grid_Size','')
 # group consecutive runs of 23 launches (one per rows setting) by grid size
 g=collections.OrderedDict()
 for r in rows:

@@ -34,8 +34,9 @@ def t(**o):
 
 
 print(f"tile form (4 waves) {t(c2f16_waves=4):.1f} us | (8 waves) {t(c2f16_waves=8):.1f} us")
-for rows in (0, -1, 80, 54, 40, 32, 20, 16, 8):
+for rows in (0, 80, 54, 40, 32, 20):
     print(f"line-buffer, rows {rows:3d}: {t(c2f_stream_rows=rows):.1f} us")
+
 
 try:
     import ctypes as C
