@@ -73,6 +73,7 @@ typedef struct upa_opts {
   int32_t nms_first_prefix; /* target length of the first sorted prefix there: 0 = 4096 | n in [256, 16384) | -1 = none (first prefix ~16384) */
   int32_t detect_stream;   /* upa_detect_level_stream (csrc/detect_stream.hip: one Detect level, both branches, as one line-buffer launch): 0 / 1 = refuse (callers run the tile form: stacked first conv + upa_detect_head_tails - the library default: faster launch for launch), 2 = run wherever the form applies (what the throughput runner asks for with several steps in flight: less CU time and traffic, +2.4 % images/s, profiles/r06_detect_stream.txt) */
   int32_t detect_stream_rows; /* its output rows per workgroup: 0 = the whole image height (one workgroup per strip and branch: least total CU time) | even >= 4 (more, shorter workgroups: a lower latency with one step at a time) */
+  int32_t no_c2f16_down;   /* 1 = upa_c2f16_down_fused refuses (the C2f(32, 32, n = 1) block and the stride-2 Conv behind it then run as two launches; A/B) */
 } upa_opts;
 
 /* Library / device info. Returns the ABI version (int); fills name with the kernel target ("gfx950"). */
@@ -243,6 +244,14 @@ int upa_bottleneck_pair_cv2(const void* x, const void* y0, int n, int h, int w, 
 int upa_c2f_fused(const void* x, int n, int h, int w, int c1, int ldx, int c, int nb, int shortcut, const void* w1,
                   const float* b1, const void* const* wm, const float* const* bm, const void* w2, const float* b2, void* y,
                   int c2, int ldy, int act, int dtype, const upa_opts* opts, void* stream);
+
+/* C2f(32, 32, n = 1, shortcut) AND the Conv(32, 64, 3, 2) row behind it as ONE line-buffer launch (csrc/c2f16_stream.hip; yolov8n rows 2-3,
+ * cfg/models/v8/yolov8.yaml:18-19): x (n, h, w, 32) -> y (n, ceil(h / 2), ceil(w / 2), 64); the block's own output only ever exists as eight rows
+ * of a strip in LDS.  wd / bd = the stride-2 Conv (upa_pack_conv_weight(bf16), BN folded, SiLU); the other arguments as upa_c2f_fused.
+ * UPA_EUNSUPPORTED outside the form (callers run upa_c2f_fused, then upa_conv2d_bias_act).   block.py:457-488, :644-668, conv.py:188-197 */
+int upa_c2f16_down_fused(const void* x, int n, int h, int w, int ldx, const void* w1, const float* b1, const void* const* wm,
+                         const float* const* bm, const void* w2, const float* b2, const void* wd, const float* bd, void* y, int ldy,
+                         int dtype, const upa_opts* opts, void* stream);
 
 /* The same for the 64-channel-half blocks (csrc/c2f64.hip): C2f(c1 -> 128, c = 64, n = nb in {1, 2}), c1 % 64 == 0 - yolov8n
  * model.6 / model.12 / model.18 at 40 x 40, yolov8s model.4 / model.15 at 80 x 80.  `up` (may be NULL): a (n, h/2, w/2, up_c) tensor

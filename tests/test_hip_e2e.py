@@ -1207,6 +1207,7 @@ def test_e2e_bf16_layer_by_layer_vs_rounding_point_emulation(name):
     m.model[-1].keep_raw = False
     m.fuse_pool = False  # (yolov3-tiny: Conv + MaxPool pairs as separate launches so that every row's output exists; the fused pairs are
     hip = {}             # bit-identical to them, test_e2e_yolov3_tiny_conv_pool_fusion_is_exact)
+    m.fuse_down = False  # (yolov8n rows 2-3 as two launches for the same reason; the one-launch form's row 3 is compared below)
 
     def grab(i):
         return lambda _m, _i, out: hip.__setitem__(i, out.float().cpu()) if torch.is_tensor(out) else None
@@ -1238,6 +1239,21 @@ def test_e2e_bf16_layer_by_layer_vs_rounding_point_emulation(name):
         assert same >= lo_id.get(i, lo_id["rest"]) and within >= lo_ulp.get(i, lo_ulp["rest"]), (name, i, same, within)
     first = min(rows)
     assert rows[first][2] <= (4.0 if name == "yolov8n" else 8.0), "the first rows must reproduce the emulation up to boundary flips"
+    if name == "yolov8n":  # rows 2-3 as ONE launch (upa_c2f16_down_fused): row 3 against the emulation, same bound as the two-launch row 3
+        m.fuse_down = True
+        got = []
+        f = m.model[2].forward_down
+        m.model[2].forward_down = lambda xx, dn, out=None: (got.append(f(xx, dn, out=out)), got[-1])[1]
+        with torch.no_grad():
+            m(x.to(DEV).to(torch.bfloat16).contiguous())
+        torch.cuda.synchronize()
+        assert len(got) == 1 and got[0] is not None, "rows 2-3 did not take the one-launch form"
+        a, b = got[0].float().cpu(), em[3]
+        same = float((a == b).float().mean())
+        u = (a - b).abs() / bf16_ulp(b.abs().clamp_min(float(b.abs().max()) / 64))
+        print(f"  layer  3 (rows 2-3 as one launch) bit-identical {same:.5f}  within 1 ulp {float((u <= 1).float().mean()):.5f}  max {float(u.max()):.1f} ulp")
+        assert same >= lo_id.get(3, lo_id["rest"]) and float((u <= 1).float().mean()) >= lo_ulp.get(3, lo_ulp["rest"]), (same, float(u.max()))
+        assert abs(same - rows[3][0]) <= 0.003, (same, rows[3][0])
 
 
 def test_e2e_yolov3_tiny_conv_pool_fusion_is_exact():

@@ -461,6 +461,53 @@ def test_c2f_fused_kernel(case, th):
     assert float(to_cpu_nchw(buf[:, :c1]).abs().max()) == 0.0  # nothing written outside the output slice
 
 
+C2F16_DOWN_CASES = [
+    # (N, H, W), rows per workgroup (0 / -1 = auto, >= 4: that many input rows)
+    ((2, 160, 160), 0), ((2, 160, 160), 160), ((1, 37, 50), 0), ((2, 37, 51), 8), ((1, 16, 16), 0), ((3, 5, 9), 0),
+    ((1, 41, 23), 4), ((1, 64, 100), 22), ((1, 33, 20), -1), ((1, 2, 2), 0), ((1, 20, 21), 6), ((1, 160, 19), 0),
+]
+
+
+@pytest.mark.parametrize("case", C2F16_DOWN_CASES, ids=[f"{c[0][0]}x{c[0][1]}x{c[0][2]}_r{c[1]}" for c in C2F16_DOWN_CASES])
+def test_c2f16_down_fused_kernel(case):
+    """`upa_c2f16_down_fused` (csrc/c2f16_stream.hip): C2f(32, 32, n = 1, shortcut) AND the Conv(32, 64, 3, 2) row behind it (yolov8.yaml rows
+    2-3; block.py:457-488 / 644-668, conv.py:188-197) as one line-buffer launch.  Against the oracle with bf16 rounding points (the block's
+    output too: it is a bf16 tensor between the two rows) and against the two separate launches, which it must equal up to flipped rounding
+    ties; odd heights and widths (the stride-2 conv's bottom / right padding), ragged strips, parts that end mid-image, maps smaller than a
+    strip, a strided output view with nothing written outside it."""
+    from tests.hip_utils import DEV, assert_bf16_close, bf16_round, bf16_weight_oracle, to_cpu_nchw, to_dev_nhwc
+    from ultralytics_pro_amd.engine import runtime as R
+    pm, _ = _mods()
+    (N, H, W), rows = case
+    o, m = _pair(om.C2f, pm.C2f, (32, 32, 1, True), "c2f16_down_block")
+    od, md = _pair(om.Conv, pm.Conv, (32, 64, 3, 2), "c2f16_down_conv")
+    o, od = bf16_weight_oracle(o), bf16_weight_oracle(od)
+    x = bf16_round(P.uniform(f"c2f16d{case}", (N, 32, H, W), -1.5, 1.5))
+    OH, OW = (H + 1) // 2, (W + 1) // 2
+    with torch.no_grad():
+        y01 = bf16_round(o.cv1(x))
+        ys = list(y01.chunk(2, 1))
+        t = bf16_round(o.m[0].cv1(ys[-1]))
+        ys.append(bf16_round(ys[-1] + o.m[0].cv2(t)))
+        ref = od(bf16_round(o.cv2(torch.cat(ys, 1))))
+        assert tuple(ref.shape) == (N, 64, OH, OW)
+        buf = R.alloc_nhwc(N, 128, OH, OW, torch.bfloat16, DEV)
+        buf.zero_()
+        xd = to_dev_nhwc(x, torch.bfloat16)
+        with R.use_opts(c2f_stream_rows=rows):
+            yv = m.forward_down(xd, md, out=buf[:, 64:])
+            assert yv is not None, "the fused form was not dispatched"
+            y = to_cpu_nchw(yv)
+        with R.use_opts(no_c2f16_down=1):
+            assert m.forward_down(xd, md) is None
+        y2 = to_cpu_nchw(md(m(xd)))
+    scale = max(1.0, ref.abs().max().item())
+    assert_bf16_close(y, ref, f"c2f16_down{case}", abs_=2.0 ** -7)
+    d = (y - y2).abs()
+    assert d.max().item() <= 3e-2 * scale and (d > 1e-6).float().mean().item() <= 0.03, (d.max().item(), (d > 1e-6).float().mean().item())
+    assert float(to_cpu_nchw(buf[:, :64]).abs().max()) == 0.0  # nothing written outside the output slice
+
+
 C2F_STREAM1_CASES = [
     # c1, shortcut, (N, H, W), up_c, rows per workgroup (0 = auto, -1 = whole height)
     (192, False, (2, 80, 80), 128, 0), (192, False, (2, 80, 80), 128, -1), (192, True, (1, 38, 50), 128, 8), (192, False, (2, 18, 24), 0, 0),

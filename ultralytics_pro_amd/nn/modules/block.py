@@ -144,6 +144,38 @@ class C2f(nn.Module):
             L.check(rc, "c2f_fused")
         return None
 
+    def forward_down(self, x, down, out=None):
+        """This block AND the stride-2 `down` = Conv(32, 64, 3, 2) row behind it as one launch (`upa_c2f16_down_fused`: yolov8n rows 2-3,
+        yolov8.yaml:18-19); returns down(self(x)) or None when the pair is outside the form (nothing was launched then)."""
+        import ctypes as C
+        if not (self.fuse_block and torch.is_tensor(x) and x.dtype == torch.bfloat16 and not self.training and len(self.m) == 1
+                and self.m[0].add and (self.cv1.conv.in_channels, self.c, self.cv2.conv.out_channels) == (32, 16, 32)):
+            return None
+        convs = [self.cv1, self.cv2, self.m[0].cv1, self.m[0].cv2, down]
+        dc = down.conv
+        if not (all(isinstance(cv.act, nn.SiLU) and cv.conv.groups == 1 and cv.conv.dilation == (1, 1) and hasattr(cv, "bn") for cv in convs)
+                and all(cv.conv.stride == (1, 1) for cv in convs[:4])
+                and all(cv.conv.kernel_size == (3, 3) and cv.conv.padding == (1, 1) for cv in convs[2:])
+                and all(cv.conv.kernel_size == (1, 1) for cv in convs[:2])
+                and (dc.in_channels, dc.out_channels, dc.stride) == (32, 64, (2, 2)) and not down.training):
+            return None
+        x = R.to_nhwc(x, x.dtype)
+        n, _, h, w = x.shape
+        oh, ow = (h + 1) // 2, (w + 1) // 2
+        y = out if out is not None else R.alloc_nhwc(n, 64, oh, ow, x.dtype, x.device, key=(id(down), "y"))
+        pk = [cv._packed(cv.conv, cv.bn, x.device, x.dtype, False) for cv in convs]
+        wm = (C.c_void_p * 2)(pk[2].w.data_ptr(), pk[3].w.data_ptr())
+        bm = (C.c_void_p * 2)(pk[2].bias.data_ptr(), pk[3].bias.data_ptr())
+        vx, vy = R.view_of(x), R.view_of(y)
+        rc = L.lib().upa_c2f16_down_fused(vx.ptr, vx.n, vx.h, vx.w, vx.ld, pk[0].w.data_ptr(), pk[0].bias.data_ptr(), C.cast(wm, C.c_void_p),
+                                          C.cast(bm, C.c_void_p), pk[1].w.data_ptr(), pk[1].bias.data_ptr(), pk[4].w.data_ptr(),
+                                          pk[4].bias.data_ptr(), vy.ptr, vy.ld, vx.dtype, R.opts_ptr(), L.current_stream(x.device))
+        if rc == 0:
+            return y
+        if rc != L.UPA_EUNSUPPORTED:
+            L.check(rc, "c2f16_down_fused")
+        return None
+
     def forward(self, x, out=None, up=None):
         """`up`: a conv.VirtualUpsample for the leading channels of x (see BaseModel._predict_once) - consumed by cv1."""
         x = R.to_nhwc(x, x.dtype)

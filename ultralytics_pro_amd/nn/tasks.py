@@ -230,6 +230,13 @@ class BaseModel(nn.Module):
                     pooled = (m.i + 1, yp)
                     y.append(None)
                     continue
+            if self._down_fusable(m, place):  # C2f(32, 32, n = 1) -> Conv(32, 64, 3, 2): one launch, the block's output never reaches HBM
+                xin = x if m.f == -1 else y[m.f]
+                yp = m.forward_down(xin, self.model[m.i + 1]) if torch.is_tensor(xin) else None
+                if yp is not None:
+                    pooled = (m.i + 1, yp)
+                    y.append(None)
+                    continue
             if fused_stem and m.i == 0:  # layers 0 and 1 run as ONE kernel: the stem output never reaches HBM
                 x = self._fused_stem(x)
                 y.append(None)
@@ -321,6 +328,20 @@ class BaseModel(nn.Module):
             return False
         nxt = self.model[m.i + 1]
         if type(nxt) is not MaxPool2d or nxt.f != -1 or (nxt.kernel_size, nxt.stride, nxt.padding) != (2, 2, 0):
+            return False
+        return m.i not in self.save and m.i not in place and (m.i + 1) not in place
+
+    fuse_down = True  # C2f(32, 32, n = 1) + the stride-2 Conv(32, 64, 3, 2) row behind it as one launch (A/B switch; upa_opts.no_c2f16_down too)
+
+    def _down_fusable(self, m, place) -> bool:
+        """Row m is a C2f whose ONLY reader is the next row, a stride-2 3x3 Conv (yolov8.yaml rows 2-3): `C2f.forward_down` may run both
+        as one kernel (bf16, the 16-channel-half form only - it returns None otherwise and the rows run separately)."""
+        if not self.fuse_down or type(m) is not C2f or m.i + 1 >= len(self.model) or isinstance(m.f, list):
+            return False
+        if getattr(self, "compute_dtype", None) != torch.bfloat16 or m.training or m.c != 16:
+            return False
+        nxt = self.model[m.i + 1]
+        if type(nxt) is not Conv or nxt.f != -1 or nxt.conv.stride != (2, 2):
             return False
         return m.i not in self.save and m.i not in place and (m.i + 1) not in place
 
