@@ -45,3 +45,25 @@ print(f"two launches: {t(False):.1f} us (tile-form block: {t(False, c2f16_waves=
 for dw in (4,):
     for rows in (0, -1, 160, 80, 54, 40, 32, 20):
         print(f"one launch, {dw} stride-2 waves, input rows per workgroup {rows:3d}: {t(True, c2f_stream_rows=rows):.1f} us")
+
+
+try:  # the -DUPA_STAMP build (make -C ultralytics_pro_amd/csrc stamp; UPA_HIP_LIB=ultralytics_pro_amd/libupa_hip_stamp.so): per-wave step stamps
+    import ctypes as C
+    import numpy as np
+    rd = L.lib().upa_debug_stamps_c2f16s
+except AttributeError:
+    sys.exit(0)
+rd.argtypes = [C.c_void_p, C.c_int]
+t(True, c2f_stream_rows=80)
+STEPS = 64
+buf = np.zeros(4 * 12 * STEPS * 2, dtype=np.uint64)
+assert rd(buf.ctypes.data, buf.size) == 0
+st = buf.reshape(4, 12, STEPS, 2).astype(np.int64)[0]
+names = ["cv1u23+DMA", "t u01", "b u01", "cv2 u01", "cv1 u01", "t u2", "b u2", "cv2 u2", "down 0", "down 1", "down 2", "down 3"]
+n = int((st[0, :, 0] > 0).sum())
+print("workgroup 0: steps", n, "life", int(st[:, n - 1, 1].max() - st[:, 0, 0].min()), "cycles (s_memtime: 100 MHz)")
+print("step   len | busy per wave: " + " ".join(f"{x:>10s}" for x in names))
+for s_ in range(min(n, 24)):
+    start = st[:, s_, 0].min()
+    nxt = st[:, s_ + 1, 0].min() if s_ + 1 < n else st[:, s_, 1].max()
+    print(f"{s_:3d} {int(nxt - start):6d} | " + " ".join(f"{int(b):10d}" for b in (st[:, s_, 1] - st[:, s_, 0])))

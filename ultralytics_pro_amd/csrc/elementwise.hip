@@ -118,6 +118,66 @@ __global__ __launch_bounds__(256) void sppf_pool3_kernel(const char* x, char* y1
   }
 }
 
+// The bf16 form: the plane is held as ORDER KEYS - bf16 bits with the sign bit flipped (positive values) or all bits flipped (negative ones), so
+// that unsigned 16-bit order = float order - and every 5-max is v_pk_max_u16 on pixel vectors of four key pairs: 4 instructions per neighbour
+// instead of 8 unpacks + 8 v_max_f32 (+ 8 packs per result); the keys are made once when the plane is read and undone once per stored vector
+// (the max of bf16 values is one of them: bit-exact, -0 < +0).  One thread per pixel (blockDim = HW rounded up to a wave, <= 1024).
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned bf16x2_key(unsigned v) {   // and its own inverse on `v ^ 0x80008000`-ordered input: see sppf_unkey
+  return v ^ (0x80008000u | (((v >> 15) & 0x00010001u) * 0x7FFFu));
+}
+__device__ __forceinline__ unsigned bf16x2_unkey(unsigned k) {
+  return k ^ (0x80008000u | (((~k >> 15) & 0x00010001u) * 0x7FFFu));
+}
+__device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {
+  const u16x2_t r = __builtin_elementwise_max(*reinterpret_cast<const u16x2_t*>(&a), *reinterpret_cast<const u16x2_t*>(&b));
+  return *reinterpret_cast<const unsigned*>(&r);
+}
+__device__ __forceinline__ u32x4 pk_max4(const u32x4& a, const u32x4& b) {
+  return u32x4{pk_max_u16(a[0], b[0]), pk_max_u16(a[1], b[1]), pk_max_u16(a[2], b[2]), pk_max_u16(a[3], b[3])};
+}
+__global__ __launch_bounds__(1024) void sppf_pool3_bf16_kernel(const char* x, char* y1, char* y2, char* y3, int N, int H, int W, int C, int ldx,
+                                                               int ldy) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  const int CG = C / 8;
+  const int n = blockIdx.x / CG, cg = blockIdx.x % CG;
+  const int HW = H * W, nth = blockDim.x;
+  u32x4* a = reinterpret_cast<u32x4*>(sm);  // current stage input  [HW] (keys)
+  u32x4* t = a + HW;                        // row-max scratch       [HW]
+  for (int p = threadIdx.x; p < HW; p += nth) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(x + (((size_t)n * HW + p) * ldx + cg * 8) * 2);
+    a[p] = u32x4{bf16x2_key(v[0]), bf16x2_key(v[1]), bf16x2_key(v[2]), bf16x2_key(v[3])};
+  }
+  __syncthreads();
+  char* outs[3] = {y1, y2, y3};
+  for (int stage = 0; stage < 3; ++stage) {
+    for (int p = threadIdx.x; p < HW; p += nth) {  // horizontal 5-max
+      const int py = p / W, px = p - py * W;
+      u32x4 m = a[p];
+#pragma unroll
+      for (int dx = -2; dx <= 2; ++dx) {
+        const int qx = px + dx;
+        if (dx != 0 && qx >= 0 && qx < W) m = pk_max4(m, a[p + dx]);
+      }
+      t[p] = m;
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < HW; p += nth) {  // vertical 5-max -> stage output (also next stage's input)
+      const int py = p / W;
+      u32x4 m = t[p];
+#pragma unroll
+      for (int dy = -2; dy <= 2; ++dy) {
+        const int qy = py + dy;
+        if (dy != 0 && qy >= 0 && qy < H) m = pk_max4(m, t[p + dy * W]);
+      }
+      a[p] = m;
+      *reinterpret_cast<u32x4*>(outs[stage] + (((size_t)n * HW + p) * ldy + cg * 8) * 2) =
+          u32x4{bf16x2_unkey(m[0]), bf16x2_unkey(m[1]), bf16x2_unkey(m[2]), bf16x2_unkey(m[3])};
+    }
+    __syncthreads();
+  }
+}
+
 // ---- nearest 2x upsample / copy / add -------------------------------------------------------------------------------
 template <int MODE>  // 0 copy, 1 upsample2x
 __global__ __launch_bounds__(256) void move16_kernel(const char* x, char* y, int N, int OH, int OW, int CG, long ldxB,
@@ -267,10 +327,11 @@ extern "C" int upa_sppf_pool3(const void* x, int n, int h, int w, int c, int ldx
   UPA_CHECK_ARG(lds <= 64 * 1024, "sppf_pool3: plane %dx%d does not fit LDS", h, w);
   const int cg = c / (16 / upa_elem_size(dtype));
   dim3 grid((unsigned)(n * cg));
-  if (dtype == UPA_BF16)
-    hipLaunchKernelGGL(sppf_pool3_kernel<bf16_t>, grid, dim3(256), lds, (hipStream_t)stream, (const char*)x, (char*)y1,
-                       (char*)y2, (char*)y3, n, h, w, c, ldx, ldy);
-  else
+  if (dtype == UPA_BF16) {
+    const int hw = h * w, nth = hw >= 1024 ? 1024 : (hw + 63) / 64 * 64;
+    hipLaunchKernelGGL(sppf_pool3_bf16_kernel, grid, dim3(nth), lds, (hipStream_t)stream, (const char*)x, (char*)y1, (char*)y2, (char*)y3, n, h,
+                       w, c, ldx, ldy);
+  } else
     hipLaunchKernelGGL(sppf_pool3_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, (const char*)x, (char*)y1,
                        (char*)y2, (char*)y3, n, h, w, c, ldx, ldy);
   UPA_LAUNCH_CHECK();

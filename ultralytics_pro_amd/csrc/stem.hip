@@ -485,6 +485,7 @@ static void launch_stem_mfma_nt(const StemParams& p, int n, int nt, hipStream_t 
 //      taps (lane groups 0-1 take tap 2s, groups 2-3 tap 2s+1): 5 k-steps instead of 9; the A fragments are read
 //      straight from the standard packed weights (only the address of a lane's 16 bytes changes);
 //   4. bias, SiLU, bf16, v_permlane16_swap pairs the two 16-channel tiles into 16-byte stores.
+typedef __attribute__((ext_vector_type(4))) short stem_s16x4;
 struct StemFusedParams {
   const void* x; const float* w0; const float* b0; const char* w1; const float* b1; char* y;
   int N, H, W, H0, W0, OH, OW, ldy, x_bf16;
@@ -534,7 +535,7 @@ extern "C" int upa_debug_stem_prof(unsigned long long* out8) {
 // NW waves per workgroup: 4 (two workgroups = two waves per SIMD) or 8 (four per SIMD: the segments of stage 2 and the rows of
 // stage 3 are spread over twice the waves, the same LDS).
 template <int NW, int KS0 = 3>
-__global__ __launch_bounds__(NW * 64) void stem_conv_fused_kernel(const StemFusedParams p) {
+__global__ __launch_bounds__(NW * 64, NW / 2) void stem_conv_fused_kernel(const StemFusedParams p) {
   using namespace sf;
   using G0 = Geo<KS0>;
   constexpr int PR = G0::PR, NCH = G0::NCH, LS = G0::LS, ITEMS = G0::ITEMS, KS0STEPS = G0::KSTEPS;
@@ -601,6 +602,28 @@ __global__ __launch_bounds__(NW * 64) void stem_conv_fused_kernel(const StemFuse
   f32x4 bias0;
 #pragma unroll
   for (int r = 0; r < 4; ++r) bias0[r] = p.b0 ? p.b0[kg * 4 + r] : 0.f;
+  // k = 3 (yolov8): the im2col row as THREE 16-deep k-steps (v_mfma_f32_16x16x16_bf16) whose lane groups each take one patch LINE (ci, kh) and
+  // the four consecutive elements 2c + 4 .. 2c + 7 of it - the three taps kw = 0, 1, 2 behind one element of zero weight: a lane's B fragment is
+  // ONE ds_read2_b32 (4-byte aligned) instead of eight ds_read_u16 + four packs.  Lines are dealt so that the two lane groups that share an LDS
+  // half-wave (kg 0 | 1, kg 2 | 3) read 16-bank windows 16 banks apart (line pitch 40 dwords: window start 8 (5 L mod 4)): (0,0) | (0,2), (0,1) |
+  // (1,0); (1,1) | (2,0), (1,2) | (2,1); the ninth line (2,2) in lane group 0 of the third step, the other groups re-read it (a broadcast) with
+  // zero weights.  Round 5 measured 5.3 M LDS bank-conflict cycles per launch on the eight 2-byte gathers.
+  u32x2 a3[3];
+  int goff3[3];
+  if constexpr (KS0 == 3) {
+    constexpr int LCI[3][4] = {{0, 0, 0, 1}, {1, 2, 1, 2}, {2, 2, 2, 2}}, LKH[3][4] = {{0, 2, 1, 0}, {1, 0, 2, 1}, {2, 2, 2, 2}};
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      const int ci = LCI[m][kg], kh = LKH[m][kg];
+      const bool live = m < 2 || kg == 0;
+      float wv[4];
+      wv[0] = 0.f;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) wv[1 + kw] = live ? p.w0[(((kh * 3 + kw) * 3) + ci) * 16 + l16] : 0.f;
+      a3[m] = u32x2{pack_bf16x2(wv[0], wv[1]), pack_bf16x2(wv[2], wv[3])};
+      goff3[m] = ((ci * PR + kh) * LS + 4) * 2;
+    }
+  }
   // second conv: A fragments [k-step][n-tile] from the standard packed layout [tap][1 k-tile][2 n-tiles][lane][16 B]:
   // lane (kg, r) of k-step s needs W[co = nt*16 + r][ci = (kg&1)*8 ..+7][tap = 2s + (kg>>1)] = the 16 bytes of packed lane
   // ((kg&1)*16 + r) of that tap
@@ -634,6 +657,20 @@ __global__ __launch_bounds__(NW * 64) void stem_conv_fused_kernel(const StemFuse
       }
       goff[ks][j] = (o + shift) * 2;
     }
+  // this wave's segments of the 17 x 33 stem tile (segment = 16 consecutive pixels of the linearised tile; wave + i NW): byte offset of the lane's
+  // pixel inside a patch, of its record in the stem tile (-1: past the tile, never stored), and (row, column) for the padding mask
+  constexpr int NSEG_ = (S0H * S0W + 15) / 16, SEGW = KS0 == 3 ? (NSEG_ + NW - 1) / NW : 1;
+  int sg_in[SEGW], sg_out[SEGW], sg_rc[SEGW];
+#pragma unroll
+  for (int i = 0; i < SEGW; ++i) {
+    const int q = (wave + i * NW) * 16 + l16;
+    const bool qin = q < S0H * S0W;
+    const int qq = qin ? q : S0H * S0W - 1;
+    const int r = qq / S0W, c = qq - r * S0W;
+    sg_in[i] = ((2 * r) * LS + 2 * c) * 2;
+    sg_out[i] = qin ? ((r * 2 + (c & 1)) * S0WH + (c >> 1)) * SPITCH + kg * 8 : -1;
+    sg_rc[i] = r | (c << 8);
+  }
   SP_DECL;
   // (Two restructurings measured with the phase profile, tools/experiments/r05_stem_phases.py, and dropped - profiles/r05_stem_phases.txt:
   // LDS-only barriers + the wait for the next patch moved behind the second conv's matrix work moved the waits, not the 11.2 k cycles a
@@ -657,6 +694,7 @@ __global__ __launch_bounds__(NW * 64) void stem_conv_fused_kernel(const StemFuse
     const char* pb = fsm + cur * PATCH;
     // ---- stage 2: the 17 x 33 stem tile, 16 stem pixels per MFMA; segment = 16 consecutive pixels of the linearised tile.
     // Two copies of the loop: interior tiles (above) carry no padding mask and no tail-segment selects on the gather.
+    // (`stage2`: the k = 6 form, 8 two-byte gathers per k-step; `stage2x` below: the k = 3 form)
     constexpr int NSEG = (S0H * S0W + 15) / 16;  // 36
     auto stage2 = [&](auto masked_tag) __attribute__((always_inline)) {
       constexpr bool MASKED = decltype(masked_tag)::value;
@@ -692,8 +730,51 @@ __global__ __launch_bounds__(NW * 64) void stem_conv_fused_kernel(const StemFuse
               u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
       }
     };
-    if (interior) stage2(std::false_type{});
-    else stage2(std::true_type{});
+    // k = 3: per-lane segment geometry hoisted out of the tile loop (sg_in / sg_out / sg_rc), the gathers of up to three segments issued before
+    // the first is multiplied (126 registers: four would spill at the 128 that two workgroups per CU allow) - 50.6 -> 48.6 us, same-box A/B
+    auto stage2x = [&](auto masked_tag) __attribute__((always_inline)) {
+      constexpr bool MASKED = decltype(masked_tag)::value;
+#pragma unroll
+      for (int i0 = 0; i0 < SEGW; i0 += 3) {
+        u32x2 b[3][3];
+#pragma unroll
+        for (int i = i0; i < i0 + 3 && i < SEGW; ++i)
+          if (wave + i * NW < NSEG) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+              const unsigned* src = reinterpret_cast<const unsigned*>(pb + sg_in[i] + goff3[m]);
+              b[i - i0][m] = u32x2{src[0], src[1]};
+            }
+          }
+#pragma unroll
+        for (int i = i0; i < i0 + 3 && i < SEGW; ++i)
+          if (wave + i * NW < NSEG) {
+            f32x4 acc = bias0;
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+              acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(*reinterpret_cast<stem_s16x4*>(&a3[m]), *reinterpret_cast<stem_s16x4*>(&b[i - i0][m]), acc, 0, 0, 0);
+            bool inmap = true;
+            if constexpr (MASKED) {
+              const int sy = sy0 + (sg_rc[i] & 0xFF), sx = sx0 + (sg_rc[i] >> 8);
+              inmap = sy >= 0 && sy < p.H0 && sx >= 0 && sx < p.W0;
+            }
+            float v[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const float u = acc[t];
+              v[t] = inmap ? u * __builtin_amdgcn_rcpf(1.0f + __expf(-u)) : 0.f;
+            }
+            if (sg_out[i] >= 0) *reinterpret_cast<u32x2*>(stile + sg_out[i]) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          }
+      }
+    };
+    if constexpr (KS0 == 3) {
+      if (interior) stage2x(std::false_type{});
+      else stage2x(std::true_type{});
+    } else {
+      if (interior) stage2(std::false_type{});
+      else stage2(std::true_type{});
+    }
     SP_AT(2);
     __syncthreads();
     SP_AT(3);
