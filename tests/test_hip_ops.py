@@ -493,7 +493,10 @@ def test_c2f16_down_fused_kernel(case):
         assert tuple(ref.shape) == (N, 64, OH, OW)
         buf = R.alloc_nhwc(N, 128, OH, OW, torch.bfloat16, DEV)
         buf.zero_()
-        xd = to_dev_nhwc(x, torch.bfloat16)
+        xbuf = R.alloc_nhwc(N, 64, H, W, torch.bfloat16, DEV)   # x as a channel slice of a wider buffer (pixel pitch 64, as behind a Concat)
+        xbuf.fill_(7.0)
+        xbuf[:, 32:].copy_(to_dev_nhwc(x, torch.bfloat16))
+        xd = xbuf[:, 32:]
         with R.use_opts(c2f_stream_rows=rows):
             yv = m.forward_down(xd, md, out=buf[:, 64:])
             assert yv is not None, "the fused form was not dispatched"

@@ -538,7 +538,7 @@ template <int NW, int KS0 = 3>
 __global__ __launch_bounds__(NW * 64, NW / 2) void stem_conv_fused_kernel(const StemFusedParams p) {
   using namespace sf;
   using G0 = Geo<KS0>;
-  constexpr int PR = G0::PR, NCH = G0::NCH, LS = G0::LS, ITEMS = G0::ITEMS, KS0STEPS = G0::KSTEPS;
+  constexpr int PR = G0::PR, NCH = G0::NCH, LS = G0::LS, ITEMS = G0::ITEMS;
   constexpr int ITEMS_PAD = G0::items_pad(NW);
   constexpr int PATCH = G0::patch_bytes(NW);
   constexpr int NTH = NW * 64;
@@ -587,42 +587,49 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void stem_conv_fused_kernel(const 
   if (slot >= ntiles) return;
   int tile = tile_of(slot);
   stage(tile, fsm);
-  // ---- stem weights -> KS0STEPS A fragments; k = (kh*KS0 + kw)*3 + ci (packed [tap][ci][co16] f32)
-  u32x4 a0[KS0STEPS];
-#pragma unroll
-  for (int ks = 0; ks < KS0STEPS; ++ks) {
-    float wv[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int k = ks * 32 + kg * 8 + j;
-      wv[j] = k < G0::KTOT ? p.w0[k * 16 + l16] : 0.f;
-    }
-    a0[ks] = u32x4{pack_bf16x2(wv[0], wv[1]), pack_bf16x2(wv[2], wv[3]), pack_bf16x2(wv[4], wv[5]), pack_bf16x2(wv[6], wv[7])};
-  }
   f32x4 bias0;
 #pragma unroll
   for (int r = 0; r < 4; ++r) bias0[r] = p.b0 ? p.b0[kg * 4 + r] : 0.f;
-  // k = 3 (yolov8): the im2col row as THREE 16-deep k-steps (v_mfma_f32_16x16x16_bf16) whose lane groups each take one patch LINE (ci, kh) and
-  // the four consecutive elements 2c + 4 .. 2c + 7 of it - the three taps kw = 0, 1, 2 behind one element of zero weight: a lane's B fragment is
-  // ONE ds_read2_b32 (4-byte aligned) instead of eight ds_read_u16 + four packs.  Lines are dealt so that the two lane groups that share an LDS
-  // half-wave (kg 0 | 1, kg 2 | 3) read 16-bank windows 16 banks apart (line pitch 40 dwords: window start 8 (5 L mod 4)): (0,0) | (0,2), (0,1) |
-  // (1,0); (1,1) | (2,0), (1,2) | (2,1); the ninth line (2,2) in lane group 0 of the third step, the other groups re-read it (a broadcast) with
-  // zero weights.  Round 5 measured 5.3 M LDS bank-conflict cycles per launch on the eight 2-byte gathers.
-  u32x2 a3[3];
-  int goff3[3];
-  if constexpr (KS0 == 3) {
-    constexpr int LCI[3][4] = {{0, 0, 0, 1}, {1, 2, 1, 2}, {2, 2, 2, 2}}, LKH[3][4] = {{0, 2, 1, 0}, {1, 0, 2, 1}, {2, 2, 2, 2}};
+  // ---- stem weights.  The im2col row of a stem pixel as NM 16-deep k-steps (v_mfma_f32_16x16x16_bf16): a lane group takes one patch LINE
+  // (ci, kh) and FOUR consecutive bf16 elements of it, so a lane's B fragment is ONE 4-byte-aligned ds_read2_b32 - no 2-byte gathers, no packs
+  // (rounds 1-5: eight ds_read_u16 + four packs per 32-deep k-step, 5.3 M LDS bank-conflict cycles per launch of the yolov8n pair).
+  //   k = 3 (yolov8; a pixel's taps are elements 2c + 5 .. 2c + 7 of the line): elements 2c + 4 .. 2c + 7 = one element of zero weight, then
+  //       kw = 0, 1, 2; nine lines = 3 steps.
+  //   k = 6 (yolov5; taps at 2c + 4 .. 2c + 9): two HALF-lines, elements 2c + 4 .. + 7 (kw 0-3) and 2c + 8 .. + 11 (kw 4, 5 and two elements of
+  //       zero weight, still inside the 80-element line); 18 lines x 2 = 9 steps.
+  // Lines are dealt so that the two lane groups sharing an LDS half-wave (kg 0 | 1 and kg 2 | 3; ds_read2_b32 banks = dword mod 32, line pitch
+  // 40 dwords: window start 8 (L mod 4) + 2 half) read 16-bank windows 16 banks apart - lines whose indices differ by 2 mod 4, same half - or
+  // overlapping windows of ONE line (same dwords: a broadcast).  stem_line(): (ci, kh, half, live) of lane group kg in step m.
+  constexpr int NM = KS0 == 3 ? 3 : 9;
+  u32x2 a3[NM];
+  int goff3[NM];
 #pragma unroll
-    for (int m = 0; m < 3; ++m) {
-      const int ci = LCI[m][kg], kh = LKH[m][kg];
-      const bool live = m < 2 || kg == 0;
-      float wv[4];
-      wv[0] = 0.f;
-#pragma unroll
-      for (int kw = 0; kw < 3; ++kw) wv[1 + kw] = live ? p.w0[(((kh * 3 + kw) * 3) + ci) * 16 + l16] : 0.f;
-      a3[m] = u32x2{pack_bf16x2(wv[0], wv[1]), pack_bf16x2(wv[2], wv[3])};
-      goff3[m] = ((ci * PR + kh) * LS + 4) * 2;
+  for (int m = 0; m < NM; ++m) {
+    int ci, kh, half = 0;
+    bool live = true;
+    if constexpr (KS0 == 3) {
+      constexpr int LCI[3][4] = {{0, 0, 0, 1}, {1, 2, 1, 2}, {2, 2, 2, 2}}, LKH[3][4] = {{0, 2, 1, 0}, {1, 0, 2, 1}, {2, 2, 2, 2}};
+      ci = LCI[m][kg]; kh = LKH[m][kg];
+      live = m < 2 || kg == 0;   // the ninth line (2, 2) in lane group 0 of the third step; the other groups re-read it with zero weights
+    } else {
+      // line index L = 38 ci + kh; L mod 4: class 0 {(0,0) (0,4) (1,2) (2,0) (2,4)}, 2 {(0,2) (1,0) (1,4) (2,2)}, 1 {(0,1) (0,5) (1,3) (2,1) (2,5)},
+      // 3 {(0,3) (1,1) (1,5) (2,3)}: eight pairs (class 0 | 2, class 1 | 3), each once per half, + the two left-over lines as (half 0 | half 1)
+      constexpr int PA[10][2] = {{0, 0}, {0, 4}, {1, 2}, {2, 0}, {0, 1}, {0, 5}, {1, 3}, {2, 1}, {2, 4}, {2, 5}};   // first line of pair slot / 2
+      constexpr int PB[10][2] = {{0, 2}, {1, 0}, {1, 4}, {2, 2}, {0, 3}, {1, 1}, {1, 5}, {2, 3}, {2, 4}, {2, 5}};   // second line
+      const int slot = 2 * m + (kg >> 1);          // 18 pair slots: 0-15 = pair (slot >> 1), half (slot & 1); 16, 17 = the left-over lines
+      const int pr = slot < 16 ? slot >> 1 : 8 + (slot - 16);
+      ci = (kg & 1) ? PB[pr][0] : PA[pr][0];
+      kh = (kg & 1) ? PB[pr][1] : PA[pr][1];
+      half = slot < 16 ? (slot & 1) : (kg & 1);
     }
+    float wv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int kw = KS0 == 3 ? e - 1 : 4 * half + e;
+      wv[e] = (live && kw >= 0 && kw < KS0) ? p.w0[(((kh * KS0 + kw) * 3) + ci) * 16 + l16] : 0.f;
+    }
+    a3[m] = u32x2{pack_bf16x2(wv[0], wv[1]), pack_bf16x2(wv[2], wv[3])};
+    goff3[m] = ((ci * PR + kh) * LS + (KS0 == 3 ? G0::SHIFT - 1 : G0::SHIFT + 4 * half)) * 2;
   }
   // second conv: A fragments [k-step][n-tile] from the standard packed layout [tap][1 k-tile][2 n-tiles][lane][16 B]:
   // lane (kg, r) of k-step s needs W[co = nt*16 + r][ci = (kg&1)*8 ..+7][tap = 2s + (kg>>1)] = the 16 bytes of packed lane
@@ -641,26 +648,10 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void stem_conv_fused_kernel(const 
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) bias1[nt][r] = p.b1 ? p.b1[nt * 16 + kg * 4 + r] : 0.f;
-  // stem gather offsets (elements inside a patch buffer): k -> (tap, ci) -> patch[ci][kh][kw + shift]
-  constexpr int shift = G0::SHIFT;  // 5 (k 3: origin 4 * 16 txi - 3) | 4 (k 6: - 4)
-  int goff[KS0STEPS][8];
-#pragma unroll
-  for (int ks = 0; ks < KS0STEPS; ++ks)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int k = ks * 32 + kg * 8 + j;
-      int o = 0;
-      if (k < G0::KTOT) {
-        const int tap = k / 3, ci = k - tap * 3;
-        const int kh = tap / KS0, kw = tap - kh * KS0;
-        o = (ci * PR + kh) * LS + kw;
-      }
-      goff[ks][j] = (o + shift) * 2;
-    }
   // this wave's segments of the 17 x 33 stem tile (segment = 16 consecutive pixels of the linearised tile; wave + i NW): byte offset of the lane's
-  // pixel inside a patch, of its record in the stem tile (-1: past the tile, never stored), and (row, column) for the padding mask
-  constexpr int NSEG_ = (S0H * S0W + 15) / 16, SEGW = KS0 == 3 ? (NSEG_ + NW - 1) / NW : 1;
-  int sg_in[SEGW], sg_out[SEGW], sg_rc[SEGW];
+  // pixel inside a patch and of its record in the stem tile (-1: past the tile, never stored)
+  constexpr int NSEG_ = (S0H * S0W + 15) / 16, SEGW = (NSEG_ + NW - 1) / NW;
+  int sg_in[SEGW], sg_out[SEGW];
 #pragma unroll
   for (int i = 0; i < SEGW; ++i) {
     const int q = (wave + i * NW) * 16 + l16;
@@ -669,7 +660,6 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void stem_conv_fused_kernel(const 
     const int r = qq / S0W, c = qq - r * S0W;
     sg_in[i] = ((2 * r) * LS + 2 * c) * 2;
     sg_out[i] = qin ? ((r * 2 + (c & 1)) * S0WH + (c >> 1)) * SPITCH + kg * 8 : -1;
-    sg_rc[i] = r | (c << 8);
   }
   SP_DECL;
   // (Two restructurings measured with the phase profile, tools/experiments/r05_stem_phases.py, and dropped - profiles/r05_stem_phases.txt:
@@ -694,68 +684,38 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void stem_conv_fused_kernel(const 
     const char* pb = fsm + cur * PATCH;
     // ---- stage 2: the 17 x 33 stem tile, 16 stem pixels per MFMA; segment = 16 consecutive pixels of the linearised tile.
     // Two copies of the loop: interior tiles (above) carry no padding mask and no tail-segment selects on the gather.
-    // (`stage2`: the k = 6 form, 8 two-byte gathers per k-step; `stage2x` below: the k = 3 form)
     constexpr int NSEG = (S0H * S0W + 15) / 16;  // 36
-    auto stage2 = [&](auto masked_tag) __attribute__((always_inline)) {
-      constexpr bool MASKED = decltype(masked_tag)::value;
-      for (int sg = wave; sg < NSEG; sg += NW) {
-        const int q = sg * 16 + l16;
-        const bool qin = q < S0H * S0W;
-        const int qq = qin ? q : S0H * S0W - 1;     // lanes past the tile (last segment) gather the last pixel, never stored
-        const int r = qq / S0W, c = qq - r * S0W;   // stem tile row / column of this lane's pixel
-        const char* base = pb + ((2 * r) * LS + 2 * c) * 2;
-        f32x4 acc = bias0;
-#pragma unroll
-        for (int ks = 0; ks < KS0STEPS; ++ks) {
-          unsigned e[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) e[j] = *reinterpret_cast<const unsigned short*>(base + goff[ks][j]);
-          u32x4 b = u32x4{e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&a0[ks]), *reinterpret_cast<bf16x8*>(&b), acc, 0, 0, 0);
-        }
-        // lane (kg, l16): channels 4kg..4kg+3 of stem pixel q; zero outside the stem map (padding of the second conv)
-        bool inmap = true;
-        if constexpr (MASKED) {
-          const int sy = sy0 + r, sx = sx0 + c;
-          inmap = sy >= 0 && sy < p.H0 && sx >= 0 && sx < p.W0;
-        }
-        float v[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const float u = acc[t];
-          v[t] = inmap ? u * __builtin_amdgcn_rcpf(1.0f + __expf(-u)) : 0.f;
-        }
-        if (qin)
-          *reinterpret_cast<u32x2*>(stile + ((r * 2 + (c & 1)) * S0WH + (c >> 1)) * SPITCH + kg * 8) =
-              u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-      }
-    };
-    // k = 3: per-lane segment geometry hoisted out of the tile loop (sg_in / sg_out / sg_rc), the gathers of up to three segments issued before
-    // the first is multiplied (126 registers: four would spill at the 128 that two workgroups per CU allow) - 50.6 -> 48.6 us, same-box A/B
+    // Per-lane segment geometry is hoisted out of the tile loop (sg_in / sg_out / sg_rc); the gathers of CH segments are issued before the first
+    // is multiplied (k = 3: three - 126 registers, four would spill at the 128 that two workgroups per CU allow; 50.6 -> 48.6 us, same-box A/B;
+    // k = 6: one segment = nine reads in flight)
+    constexpr int CH = KS0 == 3 ? 3 : 1;
     auto stage2x = [&](auto masked_tag) __attribute__((always_inline)) {
       constexpr bool MASKED = decltype(masked_tag)::value;
 #pragma unroll
-      for (int i0 = 0; i0 < SEGW; i0 += 3) {
-        u32x2 b[3][3];
+      for (int i0 = 0; i0 < SEGW; i0 += CH) {
+        u32x2 b[CH][NM];
 #pragma unroll
-        for (int i = i0; i < i0 + 3 && i < SEGW; ++i)
+        for (int i = i0; i < i0 + CH && i < SEGW; ++i)
           if (wave + i * NW < NSEG) {
 #pragma unroll
-            for (int m = 0; m < 3; ++m) {
+            for (int m = 0; m < NM; ++m) {
               const unsigned* src = reinterpret_cast<const unsigned*>(pb + sg_in[i] + goff3[m]);
               b[i - i0][m] = u32x2{src[0], src[1]};
             }
           }
 #pragma unroll
-        for (int i = i0; i < i0 + 3 && i < SEGW; ++i)
+        for (int i = i0; i < i0 + CH && i < SEGW; ++i)
           if (wave + i * NW < NSEG) {
             f32x4 acc = bias0;
 #pragma unroll
-            for (int m = 0; m < 3; ++m)
+            for (int m = 0; m < NM; ++m)
               acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(*reinterpret_cast<stem_s16x4*>(&a3[m]), *reinterpret_cast<stem_s16x4*>(&b[i - i0][m]), acc, 0, 0, 0);
             bool inmap = true;
             if constexpr (MASKED) {
-              const int sy = sy0 + (sg_rc[i] & 0xFF), sx = sx0 + (sg_rc[i] >> 8);
+              // (row, column) back out of sg_in = 4 (LS r + c): r = floor(x 205 / 2^16) is exact for x = 320 r + 4 c, r <= 16, c <= 32 (LS = 80)
+              static_assert(LS == 80, "the multiply-shift below divides by 4 LS = 320");
+              const int rr_ = (sg_in[i] * 205) >> 16, cc_ = (sg_in[i] - rr_ * (4 * LS)) >> 2;
+              const int sy = sy0 + rr_, sx = sx0 + cc_;
               inmap = sy >= 0 && sy < p.H0 && sx >= 0 && sx < p.W0;
             }
             float v[4];
@@ -768,13 +728,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void stem_conv_fused_kernel(const 
           }
       }
     };
-    if constexpr (KS0 == 3) {
-      if (interior) stage2x(std::false_type{});
-      else stage2x(std::true_type{});
-    } else {
-      if (interior) stage2(std::false_type{});
-      else stage2(std::true_type{});
-    }
+    if (interior) stage2x(std::false_type{});
+    else stage2x(std::true_type{});
     SP_AT(2);
     __syncthreads();
     SP_AT(3);
@@ -1138,7 +1093,7 @@ static int stem_conv_fused_impl(const void* x, int n, int h, int w, int k0, int 
     UPA_LAUNCH_CHECK();
     return UPA_OK;
   }
-  if (k0 == 6) {  // 4 waves: the 4 x 8 gather offsets + 4 A fragments of the 108-deep im2col row do not fit 128 registers
+  if (k0 == 6) {  // 4 waves: the 8-wave form of the 108-deep im2col row needs more than the 128 registers two 8-wave workgroups per CU allow (spills)
     (void)upa_full_lds<stem_conv_fused_kernel<4, 6>>();
     hipLaunchKernelGGL((stem_conv_fused_kernel<4, 6>), grid, dim3(256), (size_t)2 * sf::Geo<6>::patch_bytes(4) + sf::STILE, st, p);
   } else if (nw == 4) {
