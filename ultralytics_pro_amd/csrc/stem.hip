@@ -190,6 +190,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemParams p) {
 // One workgroup = 8 x 64 output pixels x all couts (NT tiles of 16); a wave owns two output rows.
 // All geometry is compile time (no integer divisions in the kernel); the patch origin is rounded down to 8 pixels so a
 // bf16 NCHW input whose width is a multiple of 8 is staged by LDS-DMA in 16-byte chunks (no VGPR round trip).
+typedef __attribute__((ext_vector_type(4))) short stem_s16x4;
 typedef __attribute__((address_space(1))) const void* sgptr_t;
 typedef __attribute__((address_space(3))) void* slptr_t;
 __device__ __attribute__((aligned(16))) unsigned g_stem_zero16[4] = {0u, 0u, 0u, 0u};
@@ -284,8 +285,15 @@ __device__ __forceinline__ unsigned stem_max_bf16x2(unsigned a, unsigned b) {
 // runs on the bf16-rounded activations in the epilogue and only the pooled tensor is written: a wave owns the row PAIR (2 wave,
 // 2 wave + 1) of the tile, the second row is max-ed into the first in the wave's LDS strip, neighbouring pixels when the strip is
 // read back for the 16-byte stores.  Bit-identical to conv -> store -> maxpool (the max of bf16 values is exact).
-template <int NT, int KS, int S, bool SILU, bool POOL = false>
+// G16 (k = 3, stride 1, pad 1: yolov3-tiny / darknet53 first layers; round 6): the im2col row as THREE 16-deep k-steps whose lane groups take one patch
+// LINE (ci, kh) each and read four consecutive elements of it with ONE 4-byte-aligned ds_read2_b32 (as the fused kernels below; the form above
+// costs eight ds_read_u16 + four packs per segment).  At stride 1 the first tap of pixel c sits at element c + 7 of the line - odd for even c - so a
+// segment here is 16 pixels of the SAME parity (c = 32 h + 2 j + par): its lanes read consecutive dwords, and the two parities use two weight
+// sets (taps at elements 1-3 of the four for even pixels, 0-2 for odd ones).  Lines are dealt so that the two lane groups sharing an LDS half-wave
+// read 16-bank windows 16 banks apart: (0,0) | (0,2), (1,2) | (1,0); (2,0) | (2,2), (0,1) | (1,1); (2,1) alone (the other groups re-read it: broadcast).
+template <int NT, int KS, int S, bool SILU, bool POOL = false, bool G16 = false>
 __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemParams p) {
+  static_assert(!G16 || (KS == 3 && S == 1), "the 16-deep gather form is built for k = 3, stride 1 (pad 1: checked by the launcher)");
   using G = StemGeo<KS, S>;
   constexpr int KSTEPS = G::KSTEPS;
   constexpr int PATCH_BYTES = G::ITEMS_PAD * 16;
@@ -302,20 +310,46 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemParams p) {
   // k = (kh*KS + kw)*3 + ci matches the packed [tap][ci][co] order
   const int kg = lane >> 4, l16 = lane & 15;
   const int wstride = (p.Cout + 15) / 16 * 16;
-  u32x4 afrag[NT][KSTEPS];
+  u32x4 afrag[G16 ? 1 : NT][G16 ? 1 : KSTEPS];
+  if constexpr (!G16) {
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-      float wv[8];
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        float wv[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int k = ks * 32 + kg * 8 + j;
-        wv[j] = k < G::KTOT ? p.w[k * wstride + nt * 16 + l16] : 0.f;
+        for (int j = 0; j < 8; ++j) {
+          const int k = ks * 32 + kg * 8 + j;
+          wv[j] = k < G::KTOT ? p.w[k * wstride + nt * 16 + l16] : 0.f;
+        }
+        afrag[nt][ks] = u32x4{pack_bf16x2(wv[0], wv[1]), pack_bf16x2(wv[2], wv[3]), pack_bf16x2(wv[4], wv[5]),
+                              pack_bf16x2(wv[6], wv[7])};
       }
-      afrag[nt][ks] = u32x4{pack_bf16x2(wv[0], wv[1]), pack_bf16x2(wv[2], wv[3]), pack_bf16x2(wv[4], wv[5]),
-                            pack_bf16x2(wv[6], wv[7])};
+  }
+  // G16: weight set q = first tap's element among the four (0: odd pixels, 1: even pixels), step m, and the byte offset of the lane's line
+  u32x2 a16[G16 ? 2 : 1][G16 ? NT : 1][3];
+  int g16[3] = {0, 0, 0};
+  if constexpr (G16) {
+    constexpr int LCI[3][4] = {{0, 0, 1, 1}, {2, 2, 0, 1}, {2, 2, 2, 2}}, LKH[3][4] = {{0, 2, 2, 0}, {0, 2, 1, 1}, {1, 1, 1, 1}};
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      const int ci = LCI[m][kg], kh = LKH[m][kg];
+      const bool live = m < 2 || kg == 0;
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          float wv[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int kw = e - q;
+            wv[e] = (live && kw >= 0 && kw < 3) ? p.w[((kh * 3 + kw) * 3 + ci) * wstride + nt * 16 + l16] : 0.f;
+          }
+          a16[q][nt][m] = u32x2{pack_bf16x2(wv[0], wv[1]), pack_bf16x2(wv[2], wv[3])};
+        }
+      g16[m] = ((ci * G::PR + kh + (POOL ? 2 * wave : wave)) * G::LS) * 2 + l16 * 4;
     }
+  }
   f32x4 bias4[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
@@ -351,31 +385,89 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemParams p) {
     const int tyi = t2 / p.tilesX, txi = t2 - tyi * p.tilesX;
     const int oy0 = tyi * G::TH, ox0 = txi * G::TW;
     const char* pb = stem_sm + cur * PATCH_BYTES;
+    [[maybe_unused]] f32x4 vkeep[(POOL && G16) ? SEGS : 1][(POOL && G16) ? NT : 1];  // POOL + G16: SiLU'd row 2 wave, kept in f32 for the pool
 #pragma unroll
     for (int rr = 0; rr < G::TH / 4; ++rr) {
       if UPA_ABL(p, 2) break;
       f32x4 acc[SEGS][NT];
-      u32x4 b[SEGS][KSTEPS];
+      if constexpr (G16) {
+        // segment sx = (h, par): pixels 32 h + 2 j + par (j = lane & 15); first tap at element c + 7 of the line (origin shift 7 for pad 1):
+        // par 1 -> element 32 h + 2 j + 8 = dword 16 h + j + 4, taps at elements 0-2 (set 0); par 0 -> dword 16 h + j + 3, taps at 1-3 (set 1)
+        u32x2 b[SEGS][3];
 #pragma unroll
-      for (int sx = 0; sx < SEGS; ++sx)
+        for (int sx = 0; sx < SEGS; ++sx)
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-          unsigned e[8];
+          for (int m = 0; m < 3; ++m) {
+            const unsigned* src = reinterpret_cast<const unsigned*>(pb + g16[m] + (rr * (POOL ? 1 : 4) * G::LS) * 2 + (16 * (sx >> 1) + 3 + (sx & 1)) * 4);
+            b[sx][m] = u32x2{src[0], src[1]};
+          }
 #pragma unroll
-          for (int j = 0; j < 8; ++j)
-            e[j] = *reinterpret_cast<const unsigned short*>(pb + gat[ks][j] + (rr * (POOL ? 1 : 4) * S * G::LS + sx * 16 * S) * 2);
-          b[sx][ks] = u32x4{e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
+        for (int sx = 0; sx < SEGS; ++sx)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            acc[sx][nt] = bias4[nt];
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+              acc[sx][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(*reinterpret_cast<stem_s16x4*>(&a16[1 - (sx & 1)][nt][m]),
+                                                                     *reinterpret_cast<stem_s16x4*>(&b[sx][m]), acc[sx][nt], 0, 0, 0);
+          }
+      } else {
+        u32x4 b[SEGS][KSTEPS];
+#pragma unroll
+        for (int sx = 0; sx < SEGS; ++sx)
+#pragma unroll
+          for (int ks = 0; ks < KSTEPS; ++ks) {
+            unsigned e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              e[j] = *reinterpret_cast<const unsigned short*>(pb + gat[ks][j] + (rr * (POOL ? 1 : 4) * S * G::LS + sx * 16 * S) * 2);
+            b[sx][ks] = u32x4{e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
+          }
+#pragma unroll
+        for (int sx = 0; sx < SEGS; ++sx)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            acc[sx][nt] = bias4[nt];
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks)
+              acc[sx][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&afrag[nt][ks]),
+                                                                    *reinterpret_cast<bf16x8*>(&b[sx][ks]), acc[sx][nt], 0, 0, 0);
+          }
+      }
+      if constexpr (POOL && G16) {
+        // the 2 x 2 pool entirely in registers: a lane holds pixels 2 j (segment (h, 0)) and 2 j + 1 (segment (h, 1)) of BOTH rows of the pair, so
+        // the pooled pixel 16 h + j is the max of four of its own f32 values - taken before the bf16 rounding, which is monotone: bit-identical
+        // to rounding first (-0 / +0 aside) - and leaves as one 8-byte store per lane; no LDS strip, no unpack / pack around the max
+#pragma unroll
+        for (int sx = 0; sx < SEGS; ++sx)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float t = acc[sx][nt][r];
+              if (!UPA_ABL(p, 4)) t = t * __builtin_amdgcn_rcpf(1.0f + __expf(-t));
+              vkeep[sx][nt][r] = rr == 0 ? t : fmaxf(vkeep[sx][nt][r], t);
+            }
+        if (rr == 0) continue;
+        const int oyp = (oy0 >> 1) + wave, oxp0 = ox0 >> 1;
+        if (oyp < (p.OH >> 1) && !UPA_ABL(p, 8)) {
+          const unsigned rowpix = ((unsigned)n * (p.OH >> 1) + oyp) * (p.OW >> 1) + oxp0;
+#pragma unroll
+          for (int h = 0; h < SEGS / 2; ++h) {
+            const int px = 16 * h + l16;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              float v[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = fmaxf(vkeep[2 * h][nt][r], vkeep[2 * h + 1][nt][r]);
+              if (oxp0 + px < (p.OW >> 1))
+                *reinterpret_cast<u32x2*>(p.y + ((size_t)(rowpix + px) * p.ldy + nt * 16 + kg * 4) * sizeof(bf16_t)) =
+                    u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            }
+          }
         }
-#pragma unroll
-      for (int sx = 0; sx < SEGS; ++sx)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          acc[sx][nt] = bias4[nt];
-#pragma unroll
-          for (int ks = 0; ks < KSTEPS; ++ks)
-            acc[sx][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&afrag[nt][ks]),
-                                                                  *reinterpret_cast<bf16x8*>(&b[sx][ks]), acc[sx][nt], 0, 0, 0);
-        }
+        continue;
+      }
       // epilogue: bias is in, SiLU, bf16; the row goes through a wave-private LDS strip so that the global stores are
       // whole contiguous 16-byte chunks (1 KiB per wave instruction) instead of 8-byte pieces of four lanes per pixel
 #pragma unroll
@@ -390,7 +482,8 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemParams p) {
             v[r] = t;
           }
           u32x2 pk = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-          u32x2* slot = reinterpret_cast<u32x2*>(ostage + (sx * 16 + l16) * (NT * 32) + nt * 32 + kg * 8);
+          const int pix = G16 ? 32 * (sx >> 1) + 2 * l16 + (sx & 1) : sx * 16 + l16;   // pixel of the tile row this lane holds
+          u32x2* slot = reinterpret_cast<u32x2*>(ostage + pix * (NT * 32) + nt * 32 + kg * 8);
           if constexpr (POOL) {
             if (rr == 1) {  // the pair's second row: max with what this lane stored for the first
               const u32x2 up = *slot;
@@ -449,9 +542,21 @@ static void launch_stem_mfma(const StemParams& p, int n, hipStream_t st) {
   dim3 grid((unsigned)(ntiles < wgs ? ntiles : wgs));
   const size_t lds = (size_t)2 * G::ITEMS_PAD * 16 + 4 * G::TW * NT * 32;
   if constexpr (S == 1 && KS == 3) {
-    if (p.pool) {  // (SiLU only: the launcher's caller checked)
+    if (p.pool && p.pad == 1) {  // (SiLU only: the launcher's caller checked)
+      auto kern = stem_mfma_kernel<NT, KS, S, true, true, true>;
+      (void)upa_full_lds<stem_mfma_kernel<NT, KS, S, true, true, true>>();
+      hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, q);
+      return;
+    }
+    if (p.pool) {
       auto kern = stem_mfma_kernel<NT, KS, S, true, true>;
       (void)upa_full_lds<stem_mfma_kernel<NT, KS, S, true, true>>();
+      hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, q);
+      return;
+    }
+    if (p.pad == 1 && p.act == UPA_ACT_SILU) {
+      auto kern = stem_mfma_kernel<NT, KS, S, true, false, true>;
+      (void)upa_full_lds<stem_mfma_kernel<NT, KS, S, true, false, true>>();
       hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, q);
       return;
     }
@@ -485,7 +590,6 @@ static void launch_stem_mfma_nt(const StemParams& p, int n, int nt, hipStream_t 
 //      taps (lane groups 0-1 take tap 2s, groups 2-3 tap 2s+1): 5 k-steps instead of 9; the A fragments are read
 //      straight from the standard packed weights (only the address of a lane's 16 bytes changes);
 //   4. bias, SiLU, bf16, v_permlane16_swap pairs the two 16-channel tiles into 16-byte stores.
-typedef __attribute__((ext_vector_type(4))) short stem_s16x4;
 struct StemFusedParams {
   const void* x; const float* w0; const float* b0; const char* w1; const float* b1; char* y;
   int N, H, W, H0, W0, OH, OW, ldy, x_bf16;
