@@ -38,9 +38,9 @@ constexpr int HB = NDMA * 1024;            // bytes per halo buffer
 constexpr int WAVES = 4;
 }  // namespace
 
-// POOL: the layer is followed by nn.MaxPool2d(2, 2, 0) (yolov3-tiny.yaml rows 2-5): the epilogue rounds the activations to bf16 as
-// always, takes the maximum over the two rows of a pair in the lane's own registers and over the two pixels of a pair with one
-// lane exchange, and writes only the pooled (H / 2, W / 2) tensor - bit-identical to conv -> store -> maxpool.
+// POOL: the layer is followed by nn.MaxPool2d(2, 2, 0) (yolov3-tiny.yaml rows 2-5): the epilogue takes the maximum of the f32 activations
+// over the two rows of a pair in the lane's own registers and over the two pixels of a pair with one lane exchange, rounds to bf16 and
+// writes only the pooled (H / 2, W / 2) tensor - bit-identical to conv -> store -> maxpool (rounding is monotone: it commutes with max).
 template <int NTW, int ACT, bool RES, bool POOL = false>
 __global__ __launch_bounds__(WAVES * 64, 1) void conv3x3_pipe_kernel(const PipeParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -142,7 +142,6 @@ __global__ __launch_bounds__(WAVES * 64, 1) void conv3x3_pipe_kernel(const PipeP
     if constexpr (ACT == UPA_ACT_SILU) return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
     else return v;
   };
-  auto bf16r = [](float v) __attribute__((always_inline)) { return __uint_as_float(pack_bf16x2(v, 0.f) << 16); };
   auto epilogue_pool = [&](const TileCtx& c) __attribute__((always_inline)) {
     static_assert(!POOL || (!RES && (NTW % 2) == 0), "pooled form: no residual, channel tiles in pairs");
     const int co0 = p.nt0 * 16;
@@ -157,8 +156,10 @@ __global__ __launch_bounds__(WAVES * 64, 1) void conv3x3_pipe_kernel(const PipeP
         float v0[4], v1[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          float a = fmaxf(bf16r(act(acc[i][j][q] + biasv[j][q])), bf16r(act(acc[i + 1][j][q] + biasv[j][q])));
-          float b = fmaxf(bf16r(act(acc[i][j + 1][q] + biasv[j + 1][q])), bf16r(act(acc[i + 1][j + 1][q] + biasv[j + 1][q])));
+          // (the max is taken on the f32 activations: the bf16 rounding of the pack below is monotone, so rounding the four values first - what
+          // conv -> store -> maxpool does - gives the same bits)
+          float a = fmaxf(act(acc[i][j][q] + biasv[j][q]), act(acc[i + 1][j][q] + biasv[j][q]));
+          float b = fmaxf(act(acc[i][j + 1][q] + biasv[j + 1][q]), act(acc[i + 1][j + 1][q] + biasv[j + 1][q]));
           v0[q] = fmaxf(a, __shfl_xor(a, 1));  // the neighbouring pixel of the pair (lanes p16 ^ 1 of the same 16-lane row)
           v1[q] = fmaxf(b, __shfl_xor(b, 1));
         }
@@ -414,7 +415,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_c16_kernel(const PipePa
       // even rows own 8 consecutive channels of tile 0, odd rows 8 of tile 1 (as conv3x3_pipe_kernel)
       const int cb = 16 * (kg & 1) + 8 * (kg >> 1);
       if constexpr (POOL) {
-        auto bf16r = [](float v) __attribute__((always_inline)) { return __uint_as_float(pack_bf16x2(v, 0.f) << 16); };
         const int HP = p.H >> 1, WP = p.W >> 1;
 #pragma unroll
         for (int i = 0; i < TH; i += 2) {
@@ -422,8 +422,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv3x3_c16_kernel(const PipePa
           float v0[4], v1[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const float a = fmaxf(bf16r(act(accn[0][i][q] + biasn[0][q])), bf16r(act(accn[0][i + 1][q] + biasn[0][q])));
-            const float b = fmaxf(bf16r(act(accn[1][i][q] + biasn[1][q])), bf16r(act(accn[1][i + 1][q] + biasn[1][q])));
+            const float a = fmaxf(act(accn[0][i][q] + biasn[0][q]), act(accn[0][i + 1][q] + biasn[0][q]));   // (f32 max, then the monotone rounding)
+            const float b = fmaxf(act(accn[1][i][q] + biasn[1][q]), act(accn[1][i + 1][q] + biasn[1][q]));
             v0[q] = fmaxf(a, __shfl_xor(a, 1));
             v1[q] = fmaxf(b, __shfl_xor(b, 1));
           }
