@@ -178,7 +178,8 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
     orig_paircv2 = L.lib().upa_bottleneck_pair_cv2
     orig_c2f64 = L.lib().upa_c2f64_fused
     orig_c2f32up = L.lib().upa_c2f32_up_fused
-    c2f32up_calls = []
+    orig_c2f16down = L.lib().upa_c2f16_down_fused
+    c2f32up_calls, c2f16down_calls = [], []
     pair_calls, c2f_calls, btail_calls, paircv2_calls, c2f64_calls = [], [], [], [], []
 
     class _LibProxy:
@@ -204,6 +205,12 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
             rc = orig_c2f(*a)
             if rc == 0:
                 c2f_calls.append(a)
+            return rc
+
+        def upa_c2f16_down_fused(self, *a):
+            rc = orig_c2f16down(*a)
+            if rc == 0:
+                c2f16down_calls.append(a)
             return rc
 
         def upa_c2f64_fused(self, *a):
@@ -261,11 +268,18 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
         o_ = R.current_opts()
         th = 10 if (c_ != 16 and nb_ == 2 and o_ is not None and o_.c2f32_th == 10) else 16
         stream_form = c_ == 32 and th == 16 and (o_ is None or o_.c2f_stream != 1)  # the line-buffer kernels (csrc/c2f_stream.hip)
-        name = ("void c2f16_fused_kernel<%d>(C2fParams)" % (8 if (o_ is not None and o_.c2f16_waves == 8) else 4) if c_ == 16 else
+        tile16 = o_ is not None and (o_.c2f16_waves in (4, 8) or o_.c2f_stream == 1)   # else the line-buffer form (csrc/c2f16_stream.hip)
+        name = (("void c2f16_fused_kernel<%d>(C2fParams)" % (8 if o_.c2f16_waves == 8 else 4) if tile16 else "c2f16_stream_kernel(C16Params)") if c_ == 16 else
                 ("c2f32_stream2_kernel(C2fsParams)" if nb_ == 2 and (o_ is None or o_.c2f_stream != 2) else
                  "void c2f32_stream_kernel<2>(C2fsParams)" if nb_ == 2 else "void c2f32_stream1_kernel<1>(C2fsParams)") if stream_form else
                 "void c2f32_fused_kernel<%d, %d>(C2f32Params)" % (nb_, th))
         calls.append((name, flops, nbytes, (lambda a=a: orig_c2f(*a[:21], L.current_stream(dev)))))
+    for a in c2f16down_calls:  # (x, n, h, w, ldx, w1, b1, wm, bm, w2, b2, wd, bd, y, ldy, dtype, opts, stream): yolov8n rows 2-3 as one launch
+        npx = a[1] * a[2] * a[3]
+        wts = 32 * 32 + 18 * 16 * 16 + 48 * 32      # the block's weights per pixel of its map; the stride-2 conv: 9 x 32 x 64 per OUTPUT pixel
+        flops = 2.0 * npx * wts + 2.0 * (npx // 4) * 9 * 32 * 64
+        nbytes = npx * 32 * 2 + (npx // 4) * 64 * 2 + (wts + 9 * 32 * 64) * 2   # block input + stride-2 output + weights (the block's output stays in LDS)
+        calls.append(("c2f16_down_kernel(C16Params)", flops, nbytes, (lambda a=a: orig_c2f16down(*a[:17], L.current_stream(dev)))))
     for a in c2f32up_calls:  # (x, n, h, w, c1, ldx, up, up_c, up_ld, nb, shortcut, w1, b1, wm, bm, w2, b2, y, c2, ldy, act, dtype, opts, stream)
         npx, c1_, upc_, nb_, c2_ = a[1] * a[2] * a[3], a[4], a[7], a[9], a[18]
         wts = c1_ * 64 + nb_ * 18 * 32 * 32 + (2 + nb_) * 32 * c2_
