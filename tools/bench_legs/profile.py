@@ -342,10 +342,15 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
             g.replay(dev)
             e1.record()
             torch.cuda.synchronize(dev)
-        fl = 2.0 * n_ * ((h_ // 2) * (w_ // 2) * 16 * 27 + (h_ // 4) * (w_ // 4) * 32 * 144)
-        by = n_ * 3 * h_ * w_ * es + n_ * (h_ // 4) * (w_ // 4) * 32 * es
+        ca_ = model.model[0].conv
+        k0_, c0_, s0_ = int(ca_.kernel_size[0]), int(ca_.out_channels), int(ca_.stride[0])
+        fl = 2.0 * n_ * ((h_ // s0_) * (w_ // s0_) * c0_ * 3 * k0_ * k0_ + (h_ // (2 * s0_)) * (w_ // (2 * s0_)) * 2 * c0_ * 9 * c0_)
+        by = n_ * 3 * h_ * w_ * es + n_ * (h_ // (2 * s0_)) * (w_ // (2 * s0_)) * 2 * c0_ * es
         o_ = R.current_opts()
-        fam["void stem_conv_fused_kernel<%d>(StemFusedParams)" % (4 if (o_ is not None and o_.stemf_waves == 4) else 8)] = dict(launches=1, ms=e0.elapsed_time(e1) / reps, flops=fl, bytes=float(by))
+        nw_ = 4 if (o_ is not None and o_.stemf_waves == 4) else 8
+        name_ = ("void stem_conv_fused32_kernel<%d>(StemFusedParams)" % s0_ if c0_ == 32 else
+                 "void stem_conv_fused_kernel<%d, %d>(StemFusedParams)" % (4 if k0_ == 6 else nw_, k0_))   # (the names rocprofv3 / the PMC tables print)
+        fam[name_] = dict(launches=1, ms=e0.elapsed_time(e1) / reps, flops=fl, bytes=float(by))
     conv_ms = sum(d["ms"] for d in fam.values())
     conv_flops = sum(d["flops"] for d in fam.values())
     conv_bytes = sum(d["bytes"] for d in fam.values())

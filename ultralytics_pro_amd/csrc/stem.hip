@@ -969,6 +969,28 @@ __global__ __launch_bounds__(512, 4) void stem_conv_fused32_kernel(const StemFus
 #pragma unroll
     for (int r = 0; r < 4; ++r) bias0[nt][r] = p.b0 ? p.b0[nt * 16 + kg * 4 + r] : 0.f;
   }
+  // ST0 = 2 (yolov8s; the patch geometry of sf::Geo<3>): the im2col row as three 16-deep k-steps, one ds_read2_b32 per lane group and patch line
+  // (stem_conv_fused_kernel above: same line table, same bank argument); ST0 = 1 keeps the eight 2-byte gathers (odd / even first taps)
+  u32x2 a3[3][2];
+  int goff3[3] = {0, 0, 0};
+  if constexpr (ST0 == 2) {
+    static_assert(ST0 != 2 || (LS == 80 && PR == 35 && G0::SHIFT == 5), "line table and bank windows assume the 35 x 80 patch");
+    constexpr int LCI[3][4] = {{0, 0, 0, 1}, {1, 2, 1, 2}, {2, 2, 2, 2}}, LKH[3][4] = {{0, 2, 1, 0}, {1, 0, 2, 1}, {2, 2, 2, 2}};
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      const int ci = LCI[m][kg], kh = LKH[m][kg];
+      const bool live = m < 2 || kg == 0;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        float wv[4];
+        wv[0] = 0.f;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) wv[1 + kw] = live ? p.w0[(((kh * 3 + kw) * 3) + ci) * 32 + nt * 16 + l16] : 0.f;
+        a3[m][nt] = u32x2{pack_bf16x2(wv[0], wv[1]), pack_bf16x2(wv[2], wv[3])};
+      }
+      goff3[m] = ((ci * PR + kh) * LS + G0::SHIFT - 1) * 2;
+    }
+  }
   // second conv: this wave's n-tile, one A fragment per tap from the standard packed layout [tap][1 k-tile][4 n-tiles][lane][16 B]
   const int nt1 = wave & 3, rp = wave >> 2;
   u32x4 a1[9];
@@ -1012,10 +1034,20 @@ __global__ __launch_bounds__(512, 4) void stem_conv_fused32_kernel(const StemFus
         const int qq = qin ? q : S0H * S0W - 1;
         const int r = qq / S0W, c = qq - r * S0W;
         const char* base = pb + ((ST0 * r) * LS + ST0 * c) * 2;
-        unsigned e[8];
+        [[maybe_unused]] u32x4 b;
+        [[maybe_unused]] u32x2 b3[3];
+        if constexpr (ST0 == 2) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) e[j] = *reinterpret_cast<const unsigned short*>(base + goff[j]);
-        u32x4 b = u32x4{e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
+          for (int m = 0; m < 3; ++m) {
+            const unsigned* src = reinterpret_cast<const unsigned*>(base + goff3[m]);
+            b3[m] = u32x2{src[0], src[1]};
+          }
+        } else {
+          unsigned e[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) e[j] = *reinterpret_cast<const unsigned short*>(base + goff[j]);
+          b = u32x4{e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
+        }
         bool inmap = true;
         if constexpr (MASKED) {
           const int sy = sy0 + r, sx = sx0 + c;
@@ -1024,7 +1056,14 @@ __global__ __launch_bounds__(512, 4) void stem_conv_fused32_kernel(const StemFus
         char* dst = stile + ((r * 2 + (c & 1)) * S0WH + (c >> 1)) * SP + kg * 8;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-          const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&a0[nt]), *reinterpret_cast<bf16x8*>(&b), bias0[nt], 0, 0, 0);
+          f32x4 acc = bias0[nt];
+          if constexpr (ST0 == 2) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+              acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(*reinterpret_cast<stem_s16x4*>(&a3[m][nt]), *reinterpret_cast<stem_s16x4*>(&b3[m]), acc, 0, 0, 0);
+          } else {
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&a0[nt]), *reinterpret_cast<bf16x8*>(&b), acc, 0, 0, 0);
+          }
           float v[4];
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
