@@ -132,6 +132,8 @@ struct Cv1 {
       u_rr[u] = qq >= G::XW ? 1 : 0;
       const int col = qq - u_rr[u] * G::XW;
       u_in[u] = G::XB + g * G::XPLANE + u_rr[u] * G::XROWB + col * 16;
+      // (two ds_write_b64 per unit at a 16-byte pitch: 2-way bank conflicts; pairing the n-tiles with v_permlane16_swap into ONE conflict-free
+      // ds_write_b128 - here and for the o ring - was measured slower: 60.0 vs 56.6 us, same box)
       u_out[u] = G::YB + (g >> 1) * G::YPLANE + col * 16 + (g & 1) * 8;   // n-tile nt: + 2 nt planes
       const int gxx = x.cx0 + col;
       u_colm[u] = (gxx >= 0 && gxx < p.W) ? 0xFFFFFFFFu : 0u;
@@ -322,8 +324,10 @@ struct Cv2 {
       if constexpr (DOWN) {
         const unsigned m = (gy >= 0 && gy < x.p->H) ? u_colm[u] : 0u;
         const bool ok = u_act[u] && row >= 2 && row < x.LP - 2;
+        // the o ring holds a row DE-INTERLEAVED - even columns in slots 0-10, odd ones in 12-21 - so that the stride-2 conv's ten pixels read
+        // consecutive slots (column 2 r + dx): with the columns in order every ds_read_b128 there was a 2-3-way bank conflict, 36 reads per step
         // lane (g, r): channels 16 nt + 4g .. + 3 -> plane 2 nt + (g >> 1), half (g & 1)
-        const int oa = G::OB + (g >> 1) * G::OPLANE + (row & (G::OROWS - 1)) * G::TROWB + u_col[u] * 16 + (g & 1) * 8;
+        const int oa = G::OB + (g >> 1) * G::OPLANE + (row & (G::OROWS - 1)) * G::TROWB + ((u_col[u] >> 1) + (u_col[u] & 1) * 12) * 16 + (g & 1) * 8;
         *reinterpret_cast<u32x2*>(sm + (ok ? oa : G::DUMMY + x.lane * 8)) = silu_pack(o[u][0], m);
         *reinterpret_cast<u32x2*>(sm + (ok ? oa + 2 * G::OPLANE : G::DUMMY + x.lane * 8)) = silu_pack(o[u][1], m);
       } else {
@@ -361,7 +365,9 @@ struct Down {
     for (int nt = 0; nt < NT; ++nt) bias[nt] = *reinterpret_cast<const f32x4*>(p.bd + (T0 + nt) * 16 + 4 * g);
     const int rr = r < 10 ? r : 9;
     act = r < 10 && x.ox0 + r < p.OW;
-    in0 = G::OB + g * G::OPLANE + 2 * rr * 16;
+    // o column 2 r + dx = slot r (dx 0), 12 + r (dx 1), r + 1 (dx 2) of the de-interleaved row: the sixteen lanes of a lane group read sixteen
+    // consecutive slots (lanes 10-15: slots nobody wrote - or the first bytes behind the ring, inside the allocation - for outputs nobody stores)
+    in0 = G::OB + g * G::OPLANE + r * 16;
     yrow = (size_t)p.OW * p.ldy * 2;
     // NT = 2: after the n-tile pairing lane (g, r) holds channels 16 T0 + 16 (g & 1) + 8 (g >> 1) .. + 7; NT = 1: channels 16 T0 + 4 g .. + 3
     const int ch = NT == 2 ? 16 * T0 + 16 * (g & 1) + 8 * (g >> 1) : 16 * T0 + 4 * g;
@@ -373,7 +379,7 @@ struct Down {
     const char* sm = x.sm;
     u32x4 b[9];
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) b[tap] = lds128(sm, in0 + ((2 * d + 2 + tap / 3) & (G::OROWS - 1)) * G::TROWB + (tap % 3) * 16);
+    for (int tap = 0; tap < 9; ++tap) b[tap] = lds128(sm, in0 + ((2 * d + 2 + tap / 3) & (G::OROWS - 1)) * G::TROWB + (tap % 3 == 1 ? 12 * 16 : (tap % 3) * 8));
     f32x4 o[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) o[nt] = bias[nt];
