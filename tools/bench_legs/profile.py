@@ -179,7 +179,8 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
     orig_c2f64 = L.lib().upa_c2f64_fused
     orig_c2f32up = L.lib().upa_c2f32_up_fused
     orig_c2f16down = L.lib().upa_c2f16_down_fused
-    c2f32up_calls, c2f16down_calls = [], []
+    orig_dstream = L.lib().upa_detect_level_stream
+    c2f32up_calls, c2f16down_calls, dstream_calls = [], [], []
     pair_calls, c2f_calls, btail_calls, paircv2_calls, c2f64_calls = [], [], [], [], []
 
     class _LibProxy:
@@ -205,6 +206,16 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
             rc = orig_c2f(*a)
             if rc == 0:
                 c2f_calls.append(a)
+            return rc
+
+        def upa_detect_level_stream(self, *a):
+            rc = orig_dstream(*a)
+            if rc == 0:  # the two upa_detect_branch structs are passed by reference and die with the caller: keep copies for the replay
+                import ctypes as C_
+                bx, cl = type(a[6]._obj)(), type(a[7]._obj)()
+                C_.memmove(C_.byref(bx), C_.byref(a[6]._obj), C_.sizeof(bx))
+                C_.memmove(C_.byref(cl), C_.byref(a[7]._obj), C_.sizeof(cl))
+                dstream_calls.append((a, bx, cl))
             return rc
 
         def upa_c2f16_down_fused(self, *a):
@@ -280,6 +291,14 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
         flops = 2.0 * npx * wts + 2.0 * (npx // 4) * 9 * 32 * 64
         nbytes = npx * 32 * 2 + (npx // 4) * 64 * 2 + (wts + 9 * 32 * 64) * 2   # block input + stride-2 output + weights (the block's output stays in LDS)
         calls.append(("c2f16_down_kernel(C16Params)", flops, nbytes, (lambda a=a: orig_c2f16down(*a[:17], L.current_stream(dev)))))
+    for (a, bx, cl) in dstream_calls:  # (x, n, h, w, cin, ldx, box, cls, nc, stride, y, a_total, a0, best_keys, dtype, opts, stream): one Detect level, one launch
+        import ctypes as C_
+        npx, cin_, nc_ = a[1] * a[2] * a[3], a[4], a[8]
+        wts = 9 * cin_ * (64 + 80) + 9 * (64 * 64 + 80 * 80) + 64 * 64 + 80 * nc_   # head.py:94-100: cv2 = 3x3, 3x3, 1x1 (64 = 4 reg_max); cv3 = 3x3, 3x3, 1x1 (nc)
+        keys_ = a[13] is not None and R.current_opts() is not None and R.current_opts().keys_only
+        nbytes = npx * cin_ * 2 + npx * (4 if keys_ else 4 + nc_) * 4 + (npx * 8 if a[13] is not None else 0) + wts * 2   # input + decoded rows (+ NMS keys) + weights
+        calls.append(("detect_stream_kernel(DsParams)", 2.0 * npx * wts, nbytes,
+                      (lambda a=a, bx=bx, cl=cl: orig_dstream(*a[:6], C_.byref(bx), C_.byref(cl), *a[8:16], L.current_stream(dev)))))
     for a in c2f32up_calls:  # (x, n, h, w, c1, ldx, up, up_c, up_ld, nb, shortcut, w1, b1, wm, bm, w2, b2, y, c2, ldy, act, dtype, opts, stream)
         npx, c1_, upc_, nb_, c2_ = a[1] * a[2] * a[3], a[4], a[7], a[9], a[18]
         wts = c1_ * 64 + nb_ * 18 * 32 * 32 + (2 + nb_) * 32 * c2_
