@@ -675,12 +675,20 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void stem_conv_fused_kernel(const 
     const int ixa = ix0 & ~7;
     const bf16_t* xb = (const bf16_t*)p.x + (size_t)n * 3 * plane;
     const bf16_t* xt = xb + iy0 * p.W + ixa;  // patch origin (may lie outside the image: only in-image items are read)
+    // the whole staged patch (PR rows x LS columns) inside the image (76 % of the tiles at 640 x 640; workgroup-uniform): no per-item checks
+    const bool inside = iy0 >= 0 && iy0 + PR <= p.H && ixa >= 0 && ixa + LS <= p.W;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
+      const int first = it * NTH + wave * 64;   // this wave's 64 items of the pass (wave-uniform)
+      if (first >= ITEMS) continue;             // all padding: nothing reads those LDS bytes (7 of 8 waves in the last of the k = 3 form's 3 passes)
+      if (inside && first + 64 <= ITEMS) {
+        __builtin_amdgcn_global_load_lds((sgptr_t) reinterpret_cast<const char*>(xt + it_off[it]), (slptr_t)(buf + first * 16), 16, 0, 0);
+        continue;
+      }
       const int iy = iy0 + it_row[it], ix = ixa + it_col[it];
       const bool in = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
       const char* src = in ? reinterpret_cast<const char*>(xt + it_off[it]) : reinterpret_cast<const char*>(g_stem_zero16);
-      __builtin_amdgcn_global_load_lds((sgptr_t)src, (slptr_t)(buf + (it * NTH + wave * 64) * 16), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((sgptr_t)src, (slptr_t)(buf + first * 16), 16, 0, 0);
     }
   };
   // XCD-aware walk (common.h: upa_xcd_tile): slot = blockIdx.x + i * gridDim.x names the XCD by slot & 7 when the grid is a multiple
