@@ -948,12 +948,19 @@ __global__ __launch_bounds__(512, 4) void stem_conv_fused32_kernel(const StemFus
     const int ixa = ix0 & ~7;
     const bf16_t* xb = (const bf16_t*)p.x + (size_t)n * 3 * plane;
     const bf16_t* xt = xb + iy0 * p.W + ixa;
+    const bool inside = iy0 >= 0 && iy0 + PR <= p.H && ixa >= 0 && ixa + LS <= p.W;   // (as stem_conv_fused_kernel: no checks, no all-padding passes)
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
+      const int first = it * NTH + wave * 64;
+      if (first >= ITEMS) continue;
+      if (inside && first + 64 <= ITEMS) {
+        __builtin_amdgcn_global_load_lds((sgptr_t) reinterpret_cast<const char*>(xt + it_off[it]), (slptr_t)(buf + first * 16), 16, 0, 0);
+        continue;
+      }
       const int iy = iy0 + it_row[it], ix = ixa + it_col[it];
       const bool in = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
       const char* src = in ? reinterpret_cast<const char*>(xt + it_off[it]) : reinterpret_cast<const char*>(g_stem_zero16);
-      __builtin_amdgcn_global_load_lds((sgptr_t)src, (slptr_t)(buf + (it * NTH + wave * 64) * 16), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((sgptr_t)src, (slptr_t)(buf + first * 16), 16, 0, 0);
     }
   };
   const bool xcd = !p.no_xcd && ((gridDim.x & 7) == 0 || (int)gridDim.x >= ntiles);
