@@ -808,7 +808,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void stem_conv_fused_kernel(const 
         u32x2 b[CH][NM];
 #pragma unroll
         for (int i = i0; i < i0 + CH && i < SEGW; ++i)
-          if (wave + i * NW < NSEG) {
+          if (wave + i * NW < NSEG) {   // (kept a run-time branch although it is always taken for i < 4: folded, the scheduler hoists more gathers and spills 15 registers - 54.1 vs 46.8 us)
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
               const unsigned* src = reinterpret_cast<const unsigned*>(pb + sg_in[i] + goff3[m]);
@@ -817,7 +817,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void stem_conv_fused_kernel(const 
           }
 #pragma unroll
         for (int i = i0; i < i0 + CH && i < SEGW; ++i)
-          if (wave + i * NW < NSEG) {
+          if (wave + i * NW < NSEG) {   // (kept a run-time branch although it is always taken for i < 4: folded, the scheduler hoists more gathers and spills 15 registers - 54.1 vs 46.8 us)
             f32x4 acc = bias0;
 #pragma unroll
             for (int m = 0; m < NM; ++m)
@@ -836,7 +836,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void stem_conv_fused_kernel(const 
               const float u = acc[t];
               v[t] = inmap ? u * __builtin_amdgcn_rcpf(1.0f + __expf(-u)) : 0.f;
             }
-            if (sg_out[i] >= 0) *reinterpret_cast<u32x2*>(stile + sg_out[i]) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            // (only the tile's last segment has lanes past its end: the store of every other segment needs no exec mask)
+            if ((i + 1) * NW * 16 <= S0H * S0W || sg_out[i] >= 0) *reinterpret_cast<u32x2*>(stile + sg_out[i]) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
           }
       }
     };
