@@ -754,6 +754,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void stem_conv_fused_kernel(const 
       const int tap = 2 * s + (kg >> 1);
       a1[s][nt] = tap < 9 ? *reinterpret_cast<const u32x4*>(p.w1 + ((size_t)(tap * 2 + nt) * 64 + (kg & 1) * 16 + l16) * 16)
                           : u32x4{0u, 0u, 0u, 0u};
+      // ODD stem columns keep the two 4-channel halves of each 8-channel group swapped in the stem tile (below: conflict-free ds_write_b64);
+      // the taps that read odd columns (2 l16 + kw with kw = 1) take their k order from the same swap
+      if (tap < 9 && tap % 3 == 1) a1[s][nt] = u32x4{a1[s][nt][2], a1[s][nt][3], a1[s][nt][0], a1[s][nt][1]};
     }
   f32x4 bias1[2];
 #pragma unroll
@@ -771,7 +774,10 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void stem_conv_fused_kernel(const 
     const int qq = qin ? q : S0H * S0W - 1;
     const int r = qq / S0W, c = qq - r * S0W;
     sg_in[i] = ((2 * r) * LS + 2 * c) * 2;
-    sg_out[i] = qin ? ((r * 2 + (c & 1)) * S0WH + (c >> 1)) * SPITCH + kg * 8 : -1;
+    // a lane group (one kg) writes sixteen pixels' 8-byte pieces: even columns at 12 (c / 2) + 2 kg dwords, odd ones 204 further - the same banks
+    // mod 32 (a 2-way conflict on every ds_write_b64 of stage 2) unless the odd columns store piece kg at (kg ^ 1) * 8: then the two sets differ by
+    // two dwords and interleave
+    sg_out[i] = qin ? ((r * 2 + (c & 1)) * S0WH + (c >> 1)) * SPITCH + (kg ^ (c & 1)) * 8 : -1;
   }
   SP_DECL;
   // (Two restructurings measured with the phase profile, tools/experiments/r05_stem_phases.py, and dropped - profiles/r05_stem_phases.txt:
