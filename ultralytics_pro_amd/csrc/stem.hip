@@ -582,10 +582,10 @@ static void launch_stem_mfma_nt(const StemParams& p, int n, int nt, hipStream_t 
 // The stem output is the largest activation of the network (bs 32: 105 MB written and read back = more HBM time than
 // either conv); here it only ever exists as a 17 x 33 pixel LDS tile.  Per 8 x 16 output tile of the second conv:
 //   1. input patch (35 x 67 pixels x 3) by LDS-DMA, double buffered across tiles (persistent workgroup);
-//   2. stem: im2col gather + one MFMA per 16 stem pixels (as stem_mfma_kernel), SiLU, bf16, written to an LDS tile laid
-//      out [row][column parity][column/2][16 ch] with 48-byte pixel pitch (stride-2 reads of the next stage then step
-//      through consecutive 48-byte slots: conflict-free ds_read_b128); stem pixels outside the stem map are ZERO (the
-//      second conv's padding);
+//   2. stem: im2col gather (16-deep k-steps, one ds_read2_b32 per lane group and patch line: see the kernel) + MFMAs per 16 stem pixels, SiLU,
+//      bf16, written to an LDS tile laid out PLANAR [8-channel plane][row][column parity][column/2][16 B] (sf::SPLANE: the stride-2 reads of the
+//      next stage step through consecutive 16-byte slots of one parity; conflict-free ds_read_b128 and ds_write_b64); stem pixels outside the
+//      stem map are ZERO (the second conv's padding);
 //   3. second conv as implicit GEMM from that tile: 16 input channels = half a 32-wide MFMA k-step, so k-steps pair two
 //      taps (lane groups 0-1 take tap 2s, groups 2-3 tap 2s+1): 5 k-steps instead of 9; the A fragments are read
 //      straight from the standard packed weights (only the address of a lane's 16 bytes changes);
@@ -601,8 +601,12 @@ namespace sf {
 constexpr int T1H = 8, T1W = 16;               // output tile of the second conv
 constexpr int S0H = 2 * T1H + 1, S0W = 2 * T1W + 1;  // stem tile 17 x 33
 constexpr int S0WH = (S0W + 1) / 2;            // 17 columns per parity
-constexpr int SPITCH = 48;                     // bytes per stem pixel in LDS (32 used)
-constexpr int STILE = S0H * 2 * S0WH * SPITCH; // 27744
+// stem tile in LDS, PLANAR: [8-channel plane (2)][row][column parity][column / 2][16 B]; the planes a multiple of 256 B apart, so the two lane groups
+// that share a ds_read_b128 group (the hardware's groups are lanes {0-3, 12-15, 20-27}, ...: kg 0 with kg 1, kg 2 with kg 3) read the same slots of
+// different planes = sixteen distinct 16-byte bank columns.  (Rounds 3-5 kept a pixel's 32 bytes together at a 48-byte pitch: with those lane
+// groups 5 of a group's 16 lanes met an occupied bank row on every read of the second conv.)
+constexpr int SPLANE = (S0H * 2 * S0WH * 16 + 255) / 256 * 256;  // 9472
+constexpr int STILE = 2 * SPLANE;                                // 18944
 // first conv k = KS0 (3: yolov8, pad 1 | 6: yolov5, pad 2), stride 2: input patch (2 (S0H - 1) + KS0) x (2 (S0W - 1) + KS0) = 35 x 67 | 38 x 70
 template <int KS0>
 struct Geo {
@@ -774,10 +778,10 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void stem_conv_fused_kernel(const 
     const int qq = qin ? q : S0H * S0W - 1;
     const int r = qq / S0W, c = qq - r * S0W;
     sg_in[i] = ((2 * r) * LS + 2 * c) * 2;
-    // a lane group (one kg) writes sixteen pixels' 8-byte pieces: even columns at 12 (c / 2) + 2 kg dwords, odd ones 204 further - the same banks
-    // mod 32 (a 2-way conflict on every ds_write_b64 of stage 2) unless the odd columns store piece kg at (kg ^ 1) * 8: then the two sets differ by
-    // two dwords and interleave
-    sg_out[i] = qin ? ((r * 2 + (c & 1)) * S0WH + (c >> 1)) * SPITCH + (kg ^ (c & 1)) * 8 : -1;
+    // a lane group (one kg) writes sixteen pixels' 8-byte pieces at a 16-byte pitch: even columns at dwords 4 (c / 2) + 2 (kg & 1), odd ones 68
+    // further - the same banks mod 32 (a 2-way conflict on every ds_write_b64 of stage 2) unless the odd columns store the two 4-channel halves
+    // of a slot swapped: then the two sets differ by two dwords and interleave
+    sg_out[i] = qin ? (kg >> 1) * SPLANE + ((r * 2 + (c & 1)) * S0WH + (c >> 1)) * 16 + ((kg & 1) ^ (c & 1)) * 8 : -1;
   }
   SP_DECL;
   // (Two restructurings measured with the phase profile, tools/experiments/r05_stem_phases.py, and dropped - profiles/r05_stem_phases.txt:
@@ -863,7 +867,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void stem_conv_fused_kernel(const 
         if (tap > 8) tap = 8;  // zero weights there
         const int kh = tap / 3, kw = tap - kh * 3;
         const int sr = 2 * i + kh, sc = 2 * l16 + kw;
-        const u32x4 b = *reinterpret_cast<const u32x4*>(stile + ((sr * 2 + (sc & 1)) * S0WH + (sc >> 1)) * SPITCH + (kg & 1) * 16);
+        const u32x4 b = *reinterpret_cast<const u32x4*>(stile + (kg & 1) * SPLANE + ((sr * 2 + (sc & 1)) * S0WH + (sc >> 1)) * 16);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
           acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&a1[s][nt]), *reinterpret_cast<const bf16x8*>(&b),
