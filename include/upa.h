@@ -73,6 +73,7 @@ typedef struct upa_opts {
   int32_t nms_first_prefix; /* target length of the first sorted prefix there: 0 = 4096 | n in [256, 16384) | -1 = none (first prefix ~16384) */
   int32_t detect_stream;   /* upa_detect_level_stream (csrc/detect_stream.hip: one Detect level, both branches, as one line-buffer launch): 0 / 1 = refuse (callers run the tile form: stacked first conv + upa_detect_head_tails - the library default: faster launch for launch), 2 = run wherever the form applies (what the throughput runner asks for with several steps in flight: less CU time and traffic, +2.4 % images/s, profiles/r06_detect_stream.txt) */
   int32_t detect_stream_rows; /* its output rows per workgroup: 0 = the whole image height (one workgroup per strip and branch: least total CU time) | even >= 4 (more, shorter workgroups: a lower latency with one step at a time) */
+  int32_t no_sppf_front;   /* 1 = upa_sppf_front refuses (SPPF then runs cv1 and the pools as two launches; A/B) */
   int32_t no_c2f16_down;   /* 1 = upa_c2f16_down_fused refuses (the C2f(32, 32, n = 1) block and the stride-2 Conv behind it then run as two launches; A/B) */
 } upa_opts;
 
@@ -167,6 +168,11 @@ int upa_maxpool2d(const void* x, int n, int h, int w, int c, int ldx, void* y, i
 /* SPPF pooling chain: y1 = mp5(x), y2 = mp5(y1), y3 = mp5(y2) (== 5/9/13 windows)          block.py:402-406 */
 int upa_sppf_pool3(const void* x, int n, int h, int w, int c, int ldx, void* y1, void* y2, void* y3, int ldy,
                    int dtype, void* stream);
+/* SPPF front (block.py:382-406): y[:, 0:c_) = SiLU(cv1(x)) - cv1 = Conv(c1, c_, 1, 1), BN folded, w_packed / bias from upa_pack_conv_weight(bf16) - and
+ * y[:, c_:4c_) = the three chained 5x5 pools of it, as ONE launch; y = the (n, h, w, >= 4 c_) concat buffer cv2 reads.  bf16, c1 = 128 | 256 | 512,
+ * c_ % 16 == 0, h * w <= 1024; UPA_EUNSUPPORTED otherwise (callers run upa_conv2d_bias_act + upa_sppf_pool3). */
+int upa_sppf_front(const void* x, int n, int h, int w, int c1, int ldx, const void* w_packed, const float* bias, void* y, int c_, int ldy, int dtype,
+                   const upa_opts* opts, void* stream);
 /* nn.Upsample(scale 2, nearest) written into a channel slice (fused Upsample+Concat)       conv.py:850-875 */
 int upa_upsample2x(const void* x, int n, int h, int w, int c, int ldx, void* y, int ldy, int dtype, void* stream);
 /* view -> view copy (Concat of tensors that could not be produced in place)                conv.py:874 */

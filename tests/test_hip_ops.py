@@ -853,6 +853,46 @@ def test_blocks_match_golden_and_oracle(name, cls, args, xshape, golden_dir):
     assert np.abs(yb.numpy() - G[name]).max() <= 6e-2 * max(1.0, np.abs(G[name]).max())
 
 
+SPPF_FRONT_CASES = [(256, 256, (2, 20, 20)), (256, 256, (3, 13, 11)), (128, 64, (1, 4, 4)), (512, 512, (2, 20, 20)), (256, 256, (1, 32, 32)), (256, 256, (32, 20, 20))]
+
+
+@pytest.mark.parametrize("case", SPPF_FRONT_CASES, ids=[f"c{c[0]}_{c[2][0]}x{c[2][1]}x{c[2][2]}" for c in SPPF_FRONT_CASES])
+def test_sppf_front_fused_kernel(case):
+    """`upa_sppf_front` (csrc/elementwise.hip): SPPF's cv1 and its three chained 5 x 5 pools (block.py:382-406) as one launch, bf16.  Against the
+    oracle SPPF with the bf16 rounding point after cv1 (where the separate launches round), against the two separate launches (equal up to flipped
+    rounding ties of cv1; the pools themselves are exact: slice i + 1 must be EXACTLY the 5 x 5 max of slice i), odd map sizes, the largest map."""
+    from tests.hip_utils import DEV, assert_bf16_close, bf16_round, bf16_weight_oracle, to_cpu_nchw, to_dev_nhwc
+    from ultralytics_pro_amd.engine import runtime as R
+    pm, _ = _mods()
+    c1, c2, (N, H, W) = case
+    o, m = _pair(om.SPPF, pm.SPPF, (c1, c2, 5), f"sppf_front{c1}")
+    o = bf16_weight_oracle(o)
+    x = bf16_round(P.uniform(f"sppff{case}", (N, c1, H, W), -1.5, 1.5))
+    with torch.no_grad():
+        y0 = bf16_round(o.cv1(x))
+        y1 = o.m(y0); y2 = o.m(y1); y3 = o.m(y2)
+        ref = o.cv2(torch.cat([y0, y1, y2, y3], 1))
+        xd = to_dev_nhwc(x, torch.bfloat16)
+        c_ = c1 // 2
+        cat = R.alloc_nhwc(N, 4 * c_, H, W, torch.bfloat16, DEV)
+        cat.fill_(7.0)
+        assert m._front(xd, cat, c_), "the fused form was not dispatched"
+        torch.cuda.synchronize()
+        catc = to_cpu_nchw(cat)
+        y = to_cpu_nchw(m(xd))
+        with R.use_opts(no_sppf_front=1):
+            assert not m._front(xd, cat, c_)
+            y2l = to_cpu_nchw(m(xd))
+    assert_bf16_close(catc[:, :c_], y0, f"sppf_front y0 {case}", abs_=2.0 ** -7)
+    mp = torch.nn.MaxPool2d(5, 1, 2)
+    for i in range(3):  # the pools are exact on whatever slice i holds
+        assert torch.equal(catc[:, (i + 1) * c_:(i + 2) * c_], mp(catc[:, i * c_:(i + 1) * c_])), f"pool {i}"
+    scale = max(1.0, ref.abs().max().item())
+    assert_bf16_close(y, ref, f"sppf_front {case}", abs_=2.0 ** -6)
+    d = (y - y2l).abs()
+    assert d.max().item() <= 3e-2 * scale and (d > 1e-6).float().mean().item() <= 0.03, (d.max().item(), (d > 1e-6).float().mean().item())
+
+
 @pytest.mark.parametrize("hw,batch", [((20, 20), 2), ((13, 11), 3), ((4, 4), 1), ((20, 20), 32)], ids=["20x20", "13x11", "4x4", "20x20_bs32"])
 def test_mhsa_hot_path_shape_vs_oracle(hw, batch):
     """BoT3's real MHSA problem: 128 channels, 4 heads x 32 dims, 20x20 = 400 keys, plus the fused residual - f32 on the vector

@@ -180,7 +180,8 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
     orig_c2f32up = L.lib().upa_c2f32_up_fused
     orig_c2f16down = L.lib().upa_c2f16_down_fused
     orig_dstream = L.lib().upa_detect_level_stream
-    c2f32up_calls, c2f16down_calls, dstream_calls = [], [], []
+    orig_sppf = L.lib().upa_sppf_front
+    c2f32up_calls, c2f16down_calls, dstream_calls, sppf_calls = [], [], [], []
     pair_calls, c2f_calls, btail_calls, paircv2_calls, c2f64_calls = [], [], [], [], []
 
     class _LibProxy:
@@ -206,6 +207,12 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
             rc = orig_c2f(*a)
             if rc == 0:
                 c2f_calls.append(a)
+            return rc
+
+        def upa_sppf_front(self, *a):
+            rc = orig_sppf(*a)
+            if rc == 0:
+                sppf_calls.append(a)
             return rc
 
         def upa_detect_level_stream(self, *a):
@@ -291,6 +298,10 @@ def kernel_profile(model, x, dtype, dev, args, pconv, L, post, reps=10):
         flops = 2.0 * npx * wts + 2.0 * (npx // 4) * 9 * 32 * 64
         nbytes = npx * 32 * 2 + (npx // 4) * 64 * 2 + (wts + 9 * 32 * 64) * 2   # block input + stride-2 output + weights (the block's output stays in LDS)
         calls.append(("c2f16_down_kernel(C16Params)", flops, nbytes, (lambda a=a: orig_c2f16down(*a[:17], L.current_stream(dev)))))
+    for a in sppf_calls:  # (x, n, h, w, c1, ldx, w_packed, bias, y, c_, ldy, dtype, opts, stream): SPPF's cv1 + its three pools, one launch
+        npx, c1_, cc_ = a[1] * a[2] * a[3], a[4], a[9]
+        calls.append(("sppf_front_kernel<%d>" % (c1_ // 32), 2.0 * npx * c1_ * cc_, npx * c1_ * 2 + npx * 4 * cc_ * 2 + c1_ * cc_ * 2,
+                      (lambda a=a: orig_sppf(*a[:13], L.current_stream(dev)))))
     for (a, bx, cl) in dstream_calls:  # (x, n, h, w, cin, ldx, box, cls, nc, stride, y, a_total, a0, best_keys, dtype, opts, stream): one Detect level, one launch
         import ctypes as C_
         npx, cin_, nc_ = a[1] * a[2] * a[3], a[4], a[8]

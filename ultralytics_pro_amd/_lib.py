@@ -37,7 +37,7 @@ class Opts(C.Structure):
                 ("c2f", _i), ("c2f16_waves", _i), ("c2f32_th", _i),
                 ("no_branch_tail", _i), ("branch_tail_bm", _i),
                 ("stem_wgs", _i), ("stemf_wgs", _i), ("stemf_waves", _i), ("stem_no_mfma", _i),
-                ("ablate_conv", _i), ("ablate_pipe", _i), ("ablate_c1", _i), ("ablate_stem", _i), ("c2f64_max_px", _i), ("conv_ws3", _i), ("no_group", _i), ("no_c2f32_up", _i), ("conv_mm", _i), ("no_xcd", _i), ("keys_only", _i), ("conv_p8", _i), ("c2f_stream", _i), ("c2f_stream_rows", _i), ("no_stack_first", _i), ("no_epi_stats", _i), ("nms_stages", _i), ("nms_first_prefix", _i), ("detect_stream", _i), ("detect_stream_rows", _i), ("no_c2f16_down", _i)]
+                ("ablate_conv", _i), ("ablate_pipe", _i), ("ablate_c1", _i), ("ablate_stem", _i), ("c2f64_max_px", _i), ("conv_ws3", _i), ("no_group", _i), ("no_c2f32_up", _i), ("conv_mm", _i), ("no_xcd", _i), ("keys_only", _i), ("conv_p8", _i), ("c2f_stream", _i), ("c2f_stream_rows", _i), ("no_stack_first", _i), ("no_epi_stats", _i), ("nms_stages", _i), ("nms_first_prefix", _i), ("detect_stream", _i), ("detect_stream_rows", _i), ("no_sppf_front", _i), ("no_c2f16_down", _i)]
 
     def __init__(self, **kw):
         super().__init__()
@@ -148,6 +148,7 @@ PROTOTYPES = {
     "upa_detect_tail": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _f, _vp, _i, _i, _vp, _i, _vp, _i, _op, _vp]),
     "upa_conv1x1_upcat": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _op, _vp]),
     "upa_bottleneck_pair_cv2": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _op, _vp]),
+    "upa_sppf_front": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _op, _vp]),
     "upa_c2f16_down_fused": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _op, _vp]),
     "upa_c2f_fused": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _op, _vp]),
     "upa_c2f64_fused": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _op, _vp]),

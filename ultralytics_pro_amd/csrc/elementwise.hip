@@ -178,6 +178,89 @@ __global__ __launch_bounds__(1024) void sppf_pool3_bf16_kernel(const char* x, ch
   }
 }
 
+// ---- SPPF front: cv1 (1x1, c1 -> c_, BN folded, SiLU) AND the three chained 5x5 pools as ONE launch (block.py:382-406; yolov8n row 9: 256 -> 128 at
+// 20 x 20).  Separately, cv1 (conv1x1_stream) and the pools (above) are two launches of ~11 + ~15 us whose work is a fraction of that: the map is
+// tiny.  Here a workgroup owns (image, 16 output channels of cv1): its waves multiply the whole plane - a wave's weights (c1 / 32 fragments) stay in
+// registers, the pixels' 32-channel groups are read straight from memory as B fragments (the plane is L2-resident: the image's other channel groups
+// read the same bytes) - store y0 = SiLU(cv1) into the concat buffer's first slice AND into LDS as bf16 ORDER KEYS; then the pool stages run on
+// the plane as in sppf_pool3_bf16_kernel and write slices 1-3.  Rounding point: bf16 y0 (as the separate launches); the pools are exact.
+template <int KT>
+__global__ __launch_bounds__(512) void sppf_front_kernel(const char* x, int N, int H, int W, int ldx, const char* wp, const float* bias, char* y, int ldy,
+                                                         int c_) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  const int NT = c_ / 16;
+  const int n = blockIdx.x / NT, j = blockIdx.x % NT;
+  const int HW = H * W;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kg = lane >> 4, l16 = lane & 15;
+  u32x4* a = reinterpret_cast<u32x4*>(sm);   // [2 halves of the 16 channels][HW] keys: current stage input
+  u32x4* t = a + 2 * HW;                     // row-max scratch, same shape
+  u32x4 wf[KT];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) wf[kt] = *reinterpret_cast<const u32x4*>(wp + ((size_t)(kt * NT + j) * 64 + lane) * 16);
+  const f32x4 b4 = bias ? *reinterpret_cast<const f32x4*>(bias + j * 16 + 4 * kg) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const char* xn = x + (size_t)n * HW * ldx * 2;
+  char* yn = y + (size_t)n * HW * ldy * 2;
+  // a wave's m-tiles (wave, wave + 8, ...) two at a time: the 2 KT operand loads of a pair are in flight together (the plane comes from the L2 /
+  // Infinity Cache: ~2 us per dependent round; one tile per round made cv1 four rounds long)
+  for (int mt0 = wave; mt0 * 16 < HW; mt0 += 16) {
+    u32x4 b[2][KT];
+    int pix[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      pix[q] = (mt0 + 8 * q) * 16 + l16;
+      const int pc = pix[q] < HW ? pix[q] : HW - 1;
+      const char* src = xn + (size_t)pc * ldx * 2 + kg * 16;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) b[q][kt] = *reinterpret_cast<const u32x4*>(src + kt * 64);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      f32x4 acc = b4;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&wf[kt]), *reinterpret_cast<const bf16x8*>(&b[q][kt]), acc, 0, 0, 0);
+      // lane (kg, l16): channels 16 j + 4 kg .. + 3 of pixel pix
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-acc[r]));
+      const u32x2 pk = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+      if (pix[q] < HW) {
+        *reinterpret_cast<u32x2*>(yn + ((size_t)pix[q] * ldy + j * 16 + kg * 4) * 2) = pk;
+        *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(&a[(kg >> 1) * HW + pix[q]]) + (kg & 1) * 8) = u32x2{bf16x2_key(pk[0]), bf16x2_key(pk[1])};
+      }
+    }
+  }
+  __syncthreads();
+  // one thread = one pixel, both 8-channel halves (HW <= 512 threads' worth at 20 x 20: a single pass per stage half)
+  for (int stage = 0; stage < 3; ++stage) {
+    for (int p = tid; p < HW; p += 512) {  // horizontal 5-max
+      const int py = p / W, px = p - py * W;
+      u32x4 m0 = a[p], m1 = a[HW + p];
+#pragma unroll
+      for (int dx = -2; dx <= 2; ++dx) {
+        const int qx = px + dx;
+        if (dx != 0 && qx >= 0 && qx < W) { m0 = pk_max4(m0, a[p + dx]); m1 = pk_max4(m1, a[HW + p + dx]); }
+      }
+      t[p] = m0; t[HW + p] = m1;
+    }
+    __syncthreads();
+    for (int p = tid; p < HW; p += 512) {  // vertical 5-max -> slice stage + 1 (and the next stage's input)
+      const int py = p / W;
+      u32x4 m0 = t[p], m1 = t[HW + p];
+#pragma unroll
+      for (int dy = -2; dy <= 2; ++dy) {
+        const int qy = py + dy;
+        if (dy != 0 && qy >= 0 && qy < H) { m0 = pk_max4(m0, t[p + dy * W]); m1 = pk_max4(m1, t[HW + p + dy * W]); }
+      }
+      a[p] = m0; a[HW + p] = m1;
+      char* dst = yn + ((size_t)p * ldy + (stage + 1) * c_ + j * 16) * 2;
+      *reinterpret_cast<u32x4*>(dst) = u32x4{bf16x2_unkey(m0[0]), bf16x2_unkey(m0[1]), bf16x2_unkey(m0[2]), bf16x2_unkey(m0[3])};
+      *reinterpret_cast<u32x4*>(dst + 16) = u32x4{bf16x2_unkey(m1[0]), bf16x2_unkey(m1[1]), bf16x2_unkey(m1[2]), bf16x2_unkey(m1[3])};
+    }
+    __syncthreads();
+  }
+}
+
 // ---- nearest 2x upsample / copy / add -------------------------------------------------------------------------------
 template <int MODE>  // 0 copy, 1 upsample2x
 __global__ __launch_bounds__(256) void move16_kernel(const char* x, char* y, int N, int OH, int OW, int CG, long ldxB,
@@ -334,6 +417,27 @@ extern "C" int upa_sppf_pool3(const void* x, int n, int h, int w, int c, int ldx
   } else
     hipLaunchKernelGGL(sppf_pool3_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, (const char*)x, (char*)y1,
                        (char*)y2, (char*)y3, n, h, w, c, ldx, ldy);
+  UPA_LAUNCH_CHECK();
+  return UPA_OK;
+}
+
+/* SPPF front: y[:, 0:c_) = SiLU(cv1(x)) and y[:, c_:4c_) = its three chained 5x5 pools, ONE launch (bf16, c1 = 128 | 256 | 512, c_ % 16 == 0, maps of up
+ * to 1024 pixels); UPA_EUNSUPPORTED otherwise (callers run upa_conv2d_bias_act + upa_sppf_pool3).  w_packed / bias: upa_pack_conv_weight of cv1. */
+extern "C" int upa_sppf_front(const void* x, int n, int h, int w, int c1, int ldx, const void* w_packed, const float* bias, void* y, int c_, int ldy,
+                              int dtype, const upa_opts* opts, void* stream) {
+  UPA_CHECK_ARG(x && y && w_packed && n > 0 && h > 0 && w > 0, "sppf_front: bad args");
+  const long hw = (long)h * w;
+  if (UPA_OPT(opts, no_sppf_front) || dtype != UPA_BF16 || (c1 != 128 && c1 != 256 && c1 != 512) || c_ % 16 != 0 || c_ <= 0 || ldx % 8 != 0 || ldy % 8 != 0 ||
+      hw > 1024 || ldy < 4 * c_ || ((uintptr_t)x % 16) != 0 || ((uintptr_t)y % 16) != 0 || (long)n * hw * (long)(ldx > ldy ? ldx : ldy) * 2 >= (1L << 31)) {
+    upa_set_error("sppf_front: outside the fused form");
+    return UPA_EUNSUPPORTED;
+  }
+  const size_t lds = (size_t)hw * 64;   // 2 halves x (plane + scratch) x 16 B
+  const dim3 grid((unsigned)(n * (c_ / 16)));
+  hipStream_t st = (hipStream_t)stream;
+  if (c1 == 128) hipLaunchKernelGGL(sppf_front_kernel<4>, grid, dim3(512), lds, st, (const char*)x, n, h, w, ldx, (const char*)w_packed, bias, (char*)y, ldy, c_);
+  else if (c1 == 256) hipLaunchKernelGGL(sppf_front_kernel<8>, grid, dim3(512), lds, st, (const char*)x, n, h, w, ldx, (const char*)w_packed, bias, (char*)y, ldy, c_);
+  else hipLaunchKernelGGL(sppf_front_kernel<16>, grid, dim3(512), lds, st, (const char*)x, n, h, w, ldx, (const char*)w_packed, bias, (char*)y, ldy, c_);
   UPA_LAUNCH_CHECK();
   return UPA_OK;
 }

@@ -310,6 +310,25 @@ class SPPF(nn.Module):
         self.cv2 = Conv(c_ * 4, c2, 1, 1)
         self.m = nn.MaxPool2d(kernel_size=k, stride=1, padding=k // 2)
 
+    fuse_front = True  # cv1 and the three pools as one launch (A/B switch; upa_opts.no_sppf_front too)
+
+    def _front(self, x, cat, c_) -> bool:
+        """`upa_sppf_front`: cat[:, :c_] = cv1(x) and cat[:, c_:] = its three chained pools in ONE launch; False (nothing launched) outside
+        the form (bf16 inference, cv1 = Conv(c1, c_, 1, 1) with SiLU, c1 in (128, 256, 512), maps of up to 1024 pixels)."""
+        cv = self.cv1
+        if not (self.fuse_front and x.dtype == torch.bfloat16 and not self.training and isinstance(cv.act, nn.SiLU) and hasattr(cv, "bn")
+                and cv.conv.kernel_size == (1, 1) and cv.conv.stride == (1, 1) and cv.conv.groups == 1):
+            return False
+        pk = cv._packed(cv.conv, cv.bn, x.device, x.dtype, False)
+        vx, vc = R.view_of(x), R.view_of(cat)
+        rc = L.lib().upa_sppf_front(vx.ptr, vx.n, vx.h, vx.w, vx.c, vx.ld, pk.w.data_ptr(), pk.bias.data_ptr(), vc.ptr, c_, vc.ld, vx.dtype,
+                                    R.opts_ptr(), L.current_stream(x.device))
+        if rc == 0:
+            return True
+        if rc != L.UPA_EUNSUPPORTED:
+            L.check(rc, "sppf_front")
+        return False
+
     def forward(self, x, out=None):
         if self.m.kernel_size != 5:
             raise L.UpaError("HIP SPPF implements k=5 (every reference YAML on the hot path)")
@@ -317,6 +336,8 @@ class SPPF(nn.Module):
         n, _, h, w = x.shape
         c_ = self.cv1.conv.out_channels
         cat = R.alloc_nhwc(n, 4 * c_, h, w, x.dtype, x.device, key=(id(self), "cat"))
+        if self._front(x, cat, c_):  # cv1 and the three pools as ONE launch (bf16; upa_sppf_front)
+            return self.cv2(cat, out=out)
         self.cv1(x, out=cat[:, :c_])
         v = R.view_of(cat[:, :c_])
         ptr = lambda i: R.view_of(cat[:, i * c_: (i + 1) * c_]).ptr  # noqa: E731
