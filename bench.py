@@ -578,7 +578,7 @@ def main_val(args):
         R.set_default_opts(L.Opts.from_env() if args.opts == "env" else
                            L.Opts(**{k: int(v) for k, v in (kv.split("=") for kv in args.opts.split(","))}))
     given = {} if (not args.opts or args.opts == "env") else dict(kv.split("=") for kv in args.opts.split(","))
-    mode = {} if args.no_mode_dispatch else {k: v for k, v in {"c2f": 4, "conv_ws3": 1, "c2f_stream_rows": -1, "detect_stream": 2}.items() if k not in given}
+    mode = {} if args.no_mode_dispatch else {k: v for k, v in {"c2f": 4, "conv_ws3": 1, "c2f_stream_rows": -1, "detect_stream": 2, "conv_big": 2}.items() if k not in given}
     with torch.no_grad(), (R.use_opts(**mode) if mode else contextlib.nullcontext()):
         for j in range(nb):
             first = (rank * nb + j) * pb

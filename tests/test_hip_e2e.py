@@ -205,7 +205,7 @@ def _dispatch(which):
     if which == "serial":
         return R.use_opts(L.Opts())
     assert which == "throughput"
-    return R.use_opts(L.Opts(c2f=4, conv_ws3=1, c2f_stream_rows=-1, detect_stream=2))
+    return R.use_opts(L.Opts(c2f=4, conv_ws3=1, c2f_stream_rows=-1, detect_stream=2, conv_big=2))
 
 
 @pytest.mark.parametrize("dispatch", ["session", "serial", "throughput"])
@@ -558,7 +558,7 @@ def test_e2e_pipelined_runner_copies_equal_single_graph():
     m = _build("yolov8n", torch.bfloat16)
     x = P.synthetic_images(4).to(DEV).to(torch.bfloat16).contiguous()
     with torch.no_grad():
-        with R.use_opts(c2f=4, conv_ws3=1, c2f_stream_rows=-1, detect_stream=2):
+        with R.use_opts(c2f=4, conv_ws3=1, c2f_stream_rows=-1, detect_stream=2, conv_big=2):
             run1 = m.compile(x, post=lambda o: nms_raw(o[0], 0.25, 0.7, key="ref"))
         out1, cnt1, _ = run1()
         torch.cuda.synchronize()
@@ -570,7 +570,7 @@ def test_e2e_pipelined_runner_copies_equal_single_graph():
             lin.step()
         torch.cuda.synchronize()
     assert runner.i == 7 and len(runner.results()) == 3 and len(lin.results()) == 4
-    assert runner.throughput_opts == lin.throughput_opts == {"c2f": 4, "conv_ws3": 1, "c2f_stream_rows": -1, "detect_stream": 2}
+    assert runner.throughput_opts == lin.throughput_opts == {"c2f": 4, "conv_ws3": 1, "c2f_stream_rows": -1, "detect_stream": 2, "conv_big": 2}
     assert m.model[-1].concurrent  # the linear runner restored the head's concurrency flag
     for parts in runner.results():
         out = torch.cat([p_[0] for p_ in parts], 0)
@@ -604,7 +604,7 @@ def test_e2e_full_size_properties():
     x32 = P.synthetic_images(32).to(DEV)
     x = x32.to(torch.bfloat16).contiguous()
     with torch.no_grad():
-        with R.use_opts(c2f=4, conv_ws3=1, c2f_stream_rows=-1, detect_stream=2):  # the runner's throughput dispatch (PipelinedRunner.throughput_opts)
+        with R.use_opts(c2f=4, conv_ws3=1, c2f_stream_rows=-1, detect_stream=2, conv_big=2):  # the runner's throughput dispatch (PipelinedRunner.throughput_opts)
             run1 = m.compile(x, post=lambda o: nms_raw(o[0], 0.25, 0.7, key="ref"))
         out1, cnt1, _ = run1()
         torch.cuda.synchronize()
@@ -1099,7 +1099,7 @@ def test_e2e_throughput_dispatch_matches_default_dispatch():
     with torch.no_grad():
         with R.use_opts(c2f64_max_px=0):  # the library default size rule (the test session's default lifts it)
             y_def = m(x)[0].float().clone()
-        with R.use_opts(c2f=4, conv_ws3=1, c2f_stream_rows=-1, detect_stream=2):
+        with R.use_opts(c2f=4, conv_ws3=1, c2f_stream_rows=-1, detect_stream=2, conv_big=2):
             y_thr = m(x)[0].float().clone()
         d_def = [o.cpu().numpy() for o in non_max_suppression(y_def, 0.25, 0.7, max_det=300)]
         d_thr = [o.cpu().numpy() for o in non_max_suppression(y_thr, 0.25, 0.7, max_det=300)]

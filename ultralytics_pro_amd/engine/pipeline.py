@@ -49,8 +49,12 @@ class PipelinedRunner:
         #   * the line-buffer form of the 80 x 80 Detect level (csrc/detect_stream.hip) is SLOWER launch for launch (one step at a time 0.878 vs
         #     0.799 ms: 192 long-lived workgroups, two waves per SIMD) but holds a quarter less CU time than the tile form's two chip-filling
         #     launches and moves 130 MB less: 59.4 k vs 58.1 k images/s in flight, same box (round 6).
-        # So: in flight > 1 -> upa_opts.c2f = 4, conv_ws3 = 1, c2f_stream_rows = -1 and detect_stream = 2 for the compiled copies, unless the
-        # caller's options already set them.
+        #   * conv_big for every shape it can run (conv_big = 2) instead of the size rule, which sends the smallest stride-2 / pointwise layers to
+        #     conv_igemm (faster alone, but its workgroups re-read their weights through L1 and yolov8n's model.19 moved 2.2x its algorithmic
+        #     bytes): 62.27 k vs 61.74 k images/s in flight (+0.85 %; yolov8s +1.6 %; the validate path, tiny, BoT3, rtdetr within noise), 0.5 % slower
+        #     one step at a time (round 6).
+        # So: in flight > 1 -> upa_opts.c2f = 4, conv_ws3 = 1, c2f_stream_rows = -1, detect_stream = 2 and conv_big = 2 for the compiled copies,
+        # unless the caller's options already set them.
         from . import runtime as R
         cur = R.current_opts()
         mode = {}
@@ -63,6 +67,8 @@ class PipelinedRunner:
                 mode["c2f_stream_rows"] = -1
             if cur is None or cur.detect_stream == 0:
                 mode["detect_stream"] = 2
+            if cur is None or cur.conv_big == 0:
+                mode["conv_big"] = 2
         self.throughput_opts = dict(mode)
         try:
             with torch.no_grad(), (R.use_opts(**mode) if mode else contextlib.nullcontext()):
