@@ -227,6 +227,24 @@ def ranks_seen(dist, dev) -> int:
     return int(round(float(t.item())))
 
 
+def _gc_off() -> bool:
+    """The timed region enqueues its steps from this thread: a cyclic-GC pass of the interpreter in the middle of a 10 ms region (the driver's
+    --steps 20 form) starves the lanes for tens of milliseconds - two of ~70 short runs in round 6 came back at 8.4 k and 15.9 k images/s
+    instead of 59-61 k.  The collector is switched off from the first warm-up step to the end of the timed region; it is NOT run first: a
+    collection (~0.1 s of host time with torch loaded) in front of the warm-up is an idle gap in which the GPU's clocks drop, and the 5 + 20
+    steps of the driver's form are too short to ramp them back up (measured: 51 k against 60 k images/s)."""
+    import gc
+    was = gc.isenabled()
+    gc.disable()
+    return was
+
+
+def _gc_on(was: bool) -> None:
+    import gc
+    if was:
+        gc.enable()
+
+
 _T0 = time.perf_counter()
 
 
@@ -354,6 +372,7 @@ def main():
                                      linear=bool(args.serial or (args.linear_graphs and args.micro_batches == 1)))
         run = runner.runs[0]
         _crumb("graphs compiled" + (" (autotuned)" if tuned else ""))
+        gc_was = _gc_off()
         for _ in range(args.warmup):
             runner.step()
         torch.cuda.synchronize(dev)
@@ -368,6 +387,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t0
+        _gc_on(gc_was)
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -598,6 +618,7 @@ def main_val(args):
     def step(i):
         with torch.cuda.stream(lanes[i % len(lanes)]):
             runs[i % nb]()
+    gc_was = _gc_off()
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize(dev)
@@ -612,6 +633,7 @@ def main_val(args):
         dist.barrier()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
+    _gc_on(gc_was)
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -706,6 +728,7 @@ def main_train(args):
     if mode == "eager launches":
         tr._graphs = None
     tr.allreduce_exposed_ms()  # drop the records of the tuning steps
+    gc_was = _gc_off()
     for _ in range(max(args.warmup, 1)):
         items = tr.step(x, lab)
     torch.cuda.synchronize(dev)
@@ -720,6 +743,7 @@ def main_train(args):
         dist.barrier()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
+    _gc_on(gc_was)
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
